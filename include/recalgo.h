@@ -1,0 +1,188 @@
+/* recalgo.h — C-ABI of librecalgo_hip.so: the MI355X-native (gfx950) CTR hot path of
+ * tangxyw/RecAlgorithm.
+ *
+ * The reference has NO FFI / plugin / C-ABI boundary: its hot path is
+ * TensorFlow-1.14 op sub-graphs built by plain Python functions.  Each entry point below
+ * therefore replaces one such sub-graph; the reference lines it replaces are cited as
+ * `file:line` relative to /root/reference.  INTEGRATION.md shows the ctypes stub a reference
+ * maintainer would add to call these from `algorithm/<MODEL>/...`.
+ *
+ * Conventions (all entry points):
+ *   - return value: hipError_t as int, 0 == success.  Never throws, never aborts.
+ *   - all pointers are DEVICE pointers (HBM) unless the name ends in `_host`.
+ *   - fp32 values, int64 ids (the reference's dtypes); id < 0 == OOV / missing value.
+ *   - stateless, re-entrant, asynchronous on `stream` (a hipStream_t passed as void*).
+ *   - no hidden allocation: outputs and workspaces are caller-owned; required workspace
+ *     sizes are given by the matching *_workspace_bytes() query.
+ *   - nothing is read or written outside the extents documented per argument.
+ *
+ * Embedding storage ("arena"): every table of one model lives in one float arena.  Field f
+ * owns rows [row_base[f], row_base[f] + vocab[f]) of width K (uniform-K entry points) —
+ * row r of the arena starts at arena + r*K.  A row-sharded deployment keeps
+ * rows with r % world == rank on each GPU and passes local row numbers.
+ */
+#ifndef RECALGO_H_
+#define RECALGO_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* recalgo_stream_t; /* hipStream_t */
+
+/* ABI version of this header (bumped on any signature change). */
+#define RECALGO_ABI_VERSION 1
+int recalgo_abi_version(void);
+/* "gfx950" */
+const char* recalgo_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1  embedding gather, single-valued fields, uniform width K (K % 4 == 0).
+ * Replaces fc.embedding_column + fc.input_layer (TF safe_embedding_lookup_sparse) for
+ * single-valued categorical columns: algorithm/DeepFM/deepfm.py:83-93,187-190;
+ * algorithm/DCN/dcn.py:97-107,152-153; algorithm/xDeepFM/xdeepfm.py:102-112,157-158;
+ * algorithm/PNN/pnn.py:75-85,126-130; algorithm/FiBiNET/fibinet.py:106-116,161-163.
+ *   out[b, f, :] = ids[b,f] >= 0 ? arena[row_base[f] + ids[b,f], :] : 0      (bit-exact copy)
+ *   ids       [B, F] int64       row_base [F] int64       arena [rows, K]
+ *   out       [B, out_stride] fp32; field f is written at columns [out_col + f*K, +K)
+ * ------------------------------------------------------------------------------------------ */
+int recalgo_embedding_gather_fwd(const int64_t* ids, const float* arena, const int64_t* row_base,
+                                 int B, int F, int K, float* out, int out_stride, int out_col,
+                                 recalgo_stream_t stream);
+
+/* Backward of K1 (TF autodiff of the lookup; SURVEY.md Appendix D "Gather"):
+ *   grad_arena[row_base[f] + ids[b,f], :] += g[b, out_col + f*K : +K]   for ids[b,f] >= 0
+ * Duplicate ids accumulate (fp32 hardware atomics; order-nondeterministic in the last ulp). */
+int recalgo_embedding_gather_bwd(const int64_t* ids, const float* g, const int64_t* row_base,
+                                 int B, int F, int K, int g_stride, int g_col, float* grad_arena,
+                                 recalgo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K1m  multi-valued field with combiner='mean' (CSR bags).
+ * Replaces fc.embedding_column(col, K, combiner='mean') for list-valued columns:
+ * algorithm/DCN/dcn.py:95,98,103 (`manual_tag_list`, shared `his_read_comment_7d_seq`).
+ *   out[b, out_col:+K] = mean over valid (>=0) values of bag b of table[value, :], 0 if none.
+ *   values [nnz] int64, offsets [B+1] int64, table = arena + row_base*K.
+ * The sum runs sequentially in bag order in fp32 (TF SparseSegmentMean order).
+ * ------------------------------------------------------------------------------------------ */
+int recalgo_embedding_bag_mean_fwd(const int64_t* values, const int64_t* offsets, const float* table,
+                                   int B, int K, float* out, int out_stride, int out_col,
+                                   recalgo_stream_t stream);
+int recalgo_embedding_bag_mean_bwd(const int64_t* values, const int64_t* offsets, const float* g,
+                                   int B, int K, int g_stride, int g_col, float* grad_table,
+                                   recalgo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K1s  sequence gather (zero padded) for DIN.
+ * Replaces tf.contrib.feature_column.sequence_input_layer: algorithm/DIN/din.py:207-214.
+ *   out[b, t, :] = t < len(b) && values[offsets[b]+t] >= 0 ? table[value,:] : 0, t < T
+ *   seq_len[b]   = min(offsets[b+1]-offsets[b], T)           (int32; counts OOV entries)
+ * ------------------------------------------------------------------------------------------ */
+int recalgo_sequence_gather_fwd(const int64_t* values, const int64_t* offsets, const float* table,
+                                int B, int T, int K, float* out, int32_t* seq_len,
+                                recalgo_stream_t stream);
+int recalgo_sequence_gather_bwd(const int64_t* values, const int64_t* offsets, const float* g,
+                                int B, int T, int K, float* grad_table, recalgo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K1+K2+K3  DeepFM sparse path, fused: gather + FM first order + FM second order + deep_input.
+ * Replaces algorithm/DeepFM/deepfm.py:179-181 (indicator -> dense(1)), :184-200 (sum-square
+ * FM) and :204 (concat) in one pass over the gathered rows.
+ *   emb[b, f*K:+K] = row(b,f)                                  (== deep_input, bit-exact)
+ *   fm1[b] = bias[0] + sum_f (ids[b,f]>=0 ? w1[row_base[f]+ids[b,f]] : 0)
+ *   fm2[b] = 0.5 * sum_k ( (sum_f e_fk)^2 - sum_f e_fk^2 )
+ *   w1 [rows] fp32 (the (sum V,1) dense kernel of `fm_first_order_dense`), bias [1].
+ * K % 4 == 0, K <= 64.
+ * ------------------------------------------------------------------------------------------ */
+int recalgo_deepfm_sparse_fwd(const int64_t* ids, const float* arena, const float* w1,
+                              const float* bias, const int64_t* row_base, int B, int F, int K,
+                              float* emb, float* fm1, float* fm2, recalgo_stream_t stream);
+/* Backward:
+ *   row grad (b,f) = g_emb[b,f,:] + g_fm2[b] * (S_b - e_bf)   -> += grad_arena[row]
+ *   grad_w1[row]  += g_fm1[b]
+ * `emb` is the tensor saved by the forward.  d(bias) = sum_b g_fm1[b] is left to the caller. */
+int recalgo_deepfm_sparse_bwd(const int64_t* ids, const float* emb, const float* g_emb,
+                              const float* g_fm1, const float* g_fm2, const int64_t* row_base,
+                              int B, int F, int K, float* grad_arena, float* grad_w1,
+                              recalgo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K4  DCN CrossNet, L layers fused.
+ * Replaces cross_layer(x0, xl, index) algorithm/DCN/cross_layer.py:4-26 stacked by
+ * algorithm/DCN/dcn.py:157-160:   x_{l+1} = x0 * (x_l . w_l) + b_l + x_l
+ *   x0 [B, d] (row stride x_stride), w [L, d], b [L, d], out [B, d] (row stride out_stride).
+ * d % 4 == 0, d <= 2048, 1 <= L <= 8.
+ * ------------------------------------------------------------------------------------------ */
+int recalgo_cross_fwd(const float* x0, int x_stride, const float* w, const float* b, int B, int d,
+                      int L, float* out, int out_stride, recalgo_stream_t stream);
+/* Backward.  Recomputes x_1..x_{L-1} from x0 (nothing but x0 is saved by the forward).
+ *   g    [B, d] (row stride g_stride) upstream gradient of `out`
+ *   g_x0_extra  optional [B, d] (row stride x_stride) added into dx0 (the DNN branch's dx0)
+ *   dx0  [B, d] (row stride x_stride);  dw, db [L, d] (overwritten, deterministic two-pass)
+ *   workspace: recalgo_cross_bwd_workspace_bytes(B, d, L) bytes. */
+int64_t recalgo_cross_bwd_workspace_bytes(int B, int d, int L);
+/* Single layer with the reference's exact signature cross_layer(x0, xl, index)
+ * (algorithm/DCN/cross_layer.py:4): out = x0 * (xl . w) + b + xl, xl distinct from x0.
+ * w, b [d].  Backward also returns dxl; workspace as recalgo_cross_bwd_workspace_bytes(B,d,1). */
+int recalgo_cross_layer_fwd(const float* x0, const float* xl, int x_stride, const float* w,
+                            const float* b, int B, int d, float* out, int out_stride,
+                            recalgo_stream_t stream);
+int recalgo_cross_layer_bwd(const float* x0, const float* xl, int x_stride, const float* w,
+                            const float* b, const float* g, int g_stride, int B, int d, float* dx0,
+                            float* dxl, float* dw, float* db, void* workspace,
+                            recalgo_stream_t stream);
+int recalgo_cross_bwd(const float* x0, int x_stride, const float* w, const float* b, const float* g,
+                      int g_stride, const float* g_x0_extra, int B, int d, int L, float* dx0,
+                      float* dw, float* db, void* workspace, recalgo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a14  loss tail: sigmoid + mean sigmoid cross entropy, forward and d(loss)/d(logit) fused.
+ * Replaces tf.sigmoid + tf.reduce_mean(tf.nn.sigmoid_cross_entropy_with_logits)
+ * algorithm/DeepFM/deepfm.py:217,235 (same in all six model_fns).
+ *   prob[b] = sigmoid(x_b);  loss[0] = mean_b( max(x,0) - x*z + log1p(exp(-|x|)) )
+ *   dlogit[b] = (prob[b] - z_b) * grad_scale / B          (dlogit may be NULL)
+ * ------------------------------------------------------------------------------------------ */
+int recalgo_sigmoid_ce_fwd_bwd(const float* logits, const float* labels, int B, float grad_scale,
+                               float* prob, float* loss, float* dlogit, recalgo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a15  TF1 AdamOptimizer, dense semantics (also what TF1 applies to embedding IndexedSlices:
+ * duplicates summed, then m and v of ALL rows decay).  algorithm/DeepFM/deepfm.py:246-250.
+ *   m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  p -= lr_t * m / (sqrt(v) + eps)
+ *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the caller (host double precision), or read
+ *   from lr_t_dev[0] when lr_t_dev != NULL (see recalgo_adam_tf1_advance).
+ *   zero_grad != 0: g is reset to 0 after use (only non-zero words are rewritten).
+ * n % 4 == 0 not required.
+ * ------------------------------------------------------------------------------------------ */
+int recalgo_adam_tf1_dense(float* p, float* g, float* m, float* v, int64_t n, float lr_t,
+                           const float* lr_t_dev, float beta1, float beta2, float eps, int zero_grad,
+                           recalgo_stream_t stream);
+/* hipGraph-replayable step counter: step_dev[0] += 1; lr_t_dev[0] = lr*sqrt(1-b2^t)/(1-b1^t)
+ * (double precision on device).  Pass lr_t_dev to recalgo_adam_tf1_dense to override lr_t. */
+int recalgo_adam_tf1_advance(int64_t* step_dev, float lr, float beta1, float beta2, float* lr_t_dev,
+                             recalgo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a12 / K10  DIN activations.  Replaces prelu(x, name) / dice(x, name)
+ * algorithm/DIN/activations.py:4-17 / :20-37 (used at algorithm/DIN/din.py:228-232).
+ *   PReLU: y = max(0,x) + alpha*min(0,x)
+ *   Dice : p = sigmoid(x / sqrt(1 + 1e-3));  y = x*p + alpha*x*(1-p)
+ *          (the reference's BN has no training= argument: always inference with the
+ *           never-updated moving stats (0,1), center=False, scale=False — SURVEY.md B-5)
+ *   x, y, gy, dx [rows, C];  alpha, dalpha [C]
+ * ------------------------------------------------------------------------------------------ */
+#define RECALGO_ACT_PRELU 0
+#define RECALGO_ACT_DICE 1
+int recalgo_activation_fwd(const float* x, const float* alpha, int rows, int C, int kind, float* y,
+                           recalgo_stream_t stream);
+int64_t recalgo_activation_bwd_workspace_bytes(int rows, int C);
+int recalgo_activation_bwd(const float* x, const float* alpha, const float* gy, int rows, int C,
+                           int kind, float* dx, float* dalpha, void* workspace,
+                           recalgo_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECALGO_H_ */

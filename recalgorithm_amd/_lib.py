@@ -1,0 +1,76 @@
+"""ctypes binding of librecalgo_hip.so (the C-ABI declared in include/recalgo.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a symbol
+declared in the header is absent, loading raises immediately.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librecalgo_hip.so")
+
+P = c_void_p  # device pointer / stream
+
+# name -> (restype, argtypes); must list every function of include/recalgo.h
+SIGNATURES = {
+    "recalgo_abi_version": (c_int, []),
+    "recalgo_target_arch": (c_char_p, []),
+    "recalgo_embedding_gather_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P, c_int, c_int, P]),
+    "recalgo_embedding_gather_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "recalgo_embedding_bag_mean_fwd": (c_int, [P, P, P, c_int, c_int, P, c_int, c_int, P]),
+    "recalgo_embedding_bag_mean_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "recalgo_sequence_gather_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P]),
+    "recalgo_sequence_gather_bwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
+    "recalgo_deepfm_sparse_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, P, P, P]),
+    "recalgo_deepfm_sparse_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P, P, P]),
+    "recalgo_cross_fwd": (c_int, [P, c_int, P, P, c_int, c_int, c_int, P, c_int, P]),
+    "recalgo_cross_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
+    "recalgo_cross_bwd": (c_int, [P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, P, P, P, P, P]),
+    "recalgo_sigmoid_ce_fwd_bwd": (c_int, [P, P, c_int, c_float, P, P, P, P]),
+    "recalgo_adam_tf1_dense": (c_int, [P, P, P, P, c_int64, c_float, P, c_float, c_float, c_float, c_int, P]),
+    "recalgo_adam_tf1_advance": (c_int, [P, c_float, c_float, c_float, P, P]),
+    "recalgo_cross_layer_fwd": (c_int, [P, P, c_int, P, P, c_int, c_int, P, c_int, P]),
+    "recalgo_cross_layer_bwd": (c_int, [P, P, c_int, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P]),
+    "recalgo_activation_fwd": (c_int, [P, P, c_int, c_int, c_int, P, P]),
+    "recalgo_activation_bwd_workspace_bytes": (c_int64, [c_int, c_int]),
+    "recalgo_activation_bwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, P]),
+}
+
+_lib = None
+
+
+class RecalgoError(RuntimeError):
+    pass
+
+
+def load(path: str = LIB_PATH) -> ctypes.CDLL:
+    """Load the HIP library (once).  Import torch first so that the process-wide HIP
+    runtime (libamdhip64.so.7) is the one torch already mapped."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RecalgoError(
+            f"{path} not found: build it with `python -m recalgorithm_amd.build` "
+            "(there is no CPU fallback for the hot path)")
+    import torch  # noqa: F401  (maps torch's libamdhip64 before ours resolves its NEEDED)
+    lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RecalgoError(f"{path} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.recalgo_abi_version() != 1:
+        raise RecalgoError("librecalgo_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RecalgoError(f"{what} failed with hipError_t={rc}")

@@ -1,0 +1,224 @@
+// Loss tail (a14), TF1 Adam (a15), DIN activations (a12) — small streaming kernels, gfx950.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// sigmoid + mean sigmoid-CE + dlogit.  B is a few thousand: a single 1024-thread workgroup
+// keeps the mean a deterministic tree reduction and needs no zero-initialised accumulator.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void sigmoid_ce_kernel(
+    const float* __restrict__ logits, const float* __restrict__ labels, unsigned B,
+    float grad_scale, float* __restrict__ prob, float* __restrict__ loss,
+    float* __restrict__ dlogit) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    const float invB = 1.0f / (float)B;
+    for (unsigned i = threadIdx.x; i < B; i += 1024) {
+        float x = logits[i], z = labels[i];
+        float ax = fabsf(x);
+        float e = expf(-ax);
+        // tf.nn.sigmoid_cross_entropy_with_logits: max(x,0) - x*z + log1p(exp(-|x|))
+        acc += fmaxf(x, 0.f) - x * z + log1pf(e);
+        float r = e / (1.0f + e);
+        float p = x >= 0.f ? 1.0f / (1.0f + e) : r;
+        prob[i] = p;
+        // d/dx in the form TF's autodiff of the three terms produces:
+        //   [x>=0] - z -/+ e/(1+e)     (keeps 1e-13-size gradients at |x| ~ 30)
+        if (dlogit) {
+            float d = ((x >= 0.f ? 1.0f : 0.f) - z) + (x >= 0.f ? -r : r);
+            dlogit[i] = d * grad_scale * invB;
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float v = threadIdx.x < 16 ? red[threadIdx.x] : 0.f;
+        v = wave_sum(v);
+        if (threadIdx.x == 0) loss[0] = v * invB;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// TF1 Adam, dense.  Pure stream: 4 reads + 3 writes (+ sparse zeroing of g) per element.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void adam1(float& p, float& g, float& m, float& v, float lr_t, float b1,
+                                      float b2, float eps) {
+    m = fmaf(b1, m, (1.f - b1) * g);
+    v = fmaf(b2, v, (1.f - b2) * g * g);
+    p -= lr_t * m / (sqrtf(v) + eps);
+}
+
+__global__ __launch_bounds__(256) void adam_tf1_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v,
+                                                       int64_t n4, int64_t n, float lr_t_val,
+                                                       const float* __restrict__ lr_t_dev, float b1,
+                                                       float b2, float eps, int zero_grad) {
+    const float lr_t = lr_t_dev ? lr_t_dev[0] : lr_t_val;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    float4* g4 = reinterpret_cast<float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+        adam1(pp.x, gg.x, mm.x, vv.x, lr_t, b1, b2, eps);
+        adam1(pp.y, gg.y, mm.y, vv.y, lr_t, b1, b2, eps);
+        adam1(pp.z, gg.z, mm.z, vv.z, lr_t, b1, b2, eps);
+        adam1(pp.w, gg.w, mm.w, vv.w, lr_t, b1, b2, eps);
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        if (zero_grad && (gg.x != 0.f || gg.y != 0.f || gg.z != 0.f || gg.w != 0.f)) g4[i] = f4_zero();
+    }
+    // tail (n % 4)
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - n4 * 4)) {
+        int64_t i = n4 * 4 + threadIdx.x;
+        float pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+        adam1(pp, gg, mm, vv, lr_t, b1, b2, eps);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+        if (zero_grad) g[i] = 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// PReLU / Dice (algorithm/DIN/activations.py:4-37), x: [rows, C], alpha: [C].
+// ---------------------------------------------------------------------------------------
+constexpr float kDiceInvStd = 0.99950037468777310f;  // 1/sqrt(1 + 1e-3): BN inference, stats (0,1)
+
+template <bool DICE>
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x,
+                                                      const float* __restrict__ alpha, int64_t n,
+                                                      unsigned C, float* __restrict__ y) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float xv = x[i], a = alpha[i % C];
+    if (DICE) {
+        float px = 1.0f / (1.0f + expf(-xv * kDiceInvStd));
+        y[i] = xv * px + a * xv * (1.0f - px);
+    } else {
+        y[i] = fmaxf(0.f, xv) + a * fminf(0.f, xv);
+    }
+}
+
+// dx and per-workgroup partial dalpha ([gridDim.x][C], rows of one workgroup are contiguous).
+template <bool DICE>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ x,
+                                                      const float* __restrict__ alpha,
+                                                      const float* __restrict__ gy, unsigned rows,
+                                                      unsigned C, unsigned rows_per_blk,
+                                                      float* __restrict__ dx,
+                                                      float* __restrict__ partial) {
+    const unsigned r0 = blockIdx.x * rows_per_blk;
+    const unsigned r1 = min(rows, r0 + rows_per_blk);
+    for (unsigned c = threadIdx.x; c < C; c += 256) {
+        float a = alpha[c], da = 0.f;
+        for (unsigned r = r0; r < r1; ++r) {
+            size_t i = (size_t)r * C + c;
+            float xv = x[i], g = gy[i];
+            if (DICE) {
+                float px = 1.0f / (1.0f + expf(-xv * kDiceInvStd));
+                float dpx = px * (1.0f - px) * kDiceInvStd;
+                // y = x*px + a*x*(1-px)
+                dx[i] = g * (px + a * (1.0f - px) + xv * dpx * (1.0f - a));
+                da += g * xv * (1.0f - px);
+            } else {
+                dx[i] = g * (xv > 0.f ? 1.0f : (xv < 0.f ? a : 0.f));
+                da += g * fminf(0.f, xv);
+            }
+        }
+        partial[(size_t)blockIdx.x * C + c] = da;
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ partial,
+                                                              unsigned nblk, unsigned C,
+                                                              float* __restrict__ out) {
+    unsigned c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float acc = 0.f;
+    for (unsigned k = 0; k < nblk; ++k) acc += partial[(size_t)k * C + c];
+    out[c] = acc;
+}
+
+constexpr unsigned kActRowsPerBlk = 16;
+
+__global__ void adam_advance_kernel(int64_t* step, float lr, float b1, float b2, float* lr_t) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int64_t t = step[0] + 1;
+        step[0] = t;
+        double td = (double)t;
+        lr_t[0] = (float)((double)lr * sqrt(1.0 - pow((double)b2, td)) / (1.0 - pow((double)b1, td)));
+    }
+}
+}  // namespace
+
+RECALGO_EXPORT int recalgo_abi_version(void) { return RECALGO_ABI_VERSION; }
+RECALGO_EXPORT const char* recalgo_target_arch(void) { return "gfx950"; }
+
+RECALGO_EXPORT int recalgo_sigmoid_ce_fwd_bwd(const float* logits, const float* labels, int B,
+                                              float grad_scale, float* prob, float* loss,
+                                              float* dlogit, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(B > 0);
+    hipLaunchKernelGGL(sigmoid_ce_kernel, dim3(1), dim3(1024), 0, as_stream(stream), logits, labels,
+                       (unsigned)B, grad_scale, prob, loss, dlogit);
+    RECALGO_RETURN_LAST();
+}
+
+RECALGO_EXPORT int recalgo_adam_tf1_advance(int64_t* step_dev, float lr, float beta1, float beta2,
+                                            float* lr_t_dev, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(step_dev != nullptr && lr_t_dev != nullptr);
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, as_stream(stream), step_dev, lr, beta1,
+                       beta2, lr_t_dev);
+    RECALGO_RETURN_LAST();
+}
+
+RECALGO_EXPORT int recalgo_adam_tf1_dense(float* p, float* g, float* m, float* v, int64_t n,
+                                          float lr_t, const float* lr_t_dev, float beta1, float beta2,
+                                          float eps, int zero_grad, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(n >= 0);
+    if (n == 0) return 0;
+    int64_t n4 = n / 4;
+    int64_t want = (n4 + 255) / 256;
+    int blocks = (int)(want < 1 ? 1 : (want > 256 * 16 ? 256 * 16 : want));
+    hipLaunchKernelGGL(adam_tf1_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), p, g, m, v, n4,
+                       n, lr_t, lr_t_dev, beta1, beta2, eps, zero_grad);
+    RECALGO_RETURN_LAST();
+}
+
+RECALGO_EXPORT int recalgo_activation_fwd(const float* x, const float* alpha, int rows, int C,
+                                          int kind, float* y, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(rows >= 0 && C > 0 && (kind == RECALGO_ACT_PRELU || kind == RECALGO_ACT_DICE));
+    int64_t n = (int64_t)rows * C;
+    if (n == 0) return 0;
+    if (kind == RECALGO_ACT_DICE)
+        hipLaunchKernelGGL(act_fwd_kernel<true>, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), x,
+                           alpha, n, (unsigned)C, y);
+    else
+        hipLaunchKernelGGL(act_fwd_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), x,
+                           alpha, n, (unsigned)C, y);
+    RECALGO_RETURN_LAST();
+}
+
+RECALGO_EXPORT int64_t recalgo_activation_bwd_workspace_bytes(int rows, int C) {
+    if (rows <= 0 || C <= 0) return 0;
+    return (int64_t)cdiv(rows, kActRowsPerBlk) * C * (int64_t)sizeof(float);
+}
+
+RECALGO_EXPORT int recalgo_activation_bwd(const float* x, const float* alpha, const float* gy,
+                                          int rows, int C, int kind, float* dx, float* dalpha,
+                                          void* workspace, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(rows > 0 && C > 0 && workspace != nullptr);
+    RECALGO_REQUIRE(kind == RECALGO_ACT_PRELU || kind == RECALGO_ACT_DICE);
+    const unsigned nblk = (unsigned)cdiv(rows, kActRowsPerBlk);
+    float* partial = static_cast<float*>(workspace);
+    hipStream_t st = as_stream(stream);
+    if (kind == RECALGO_ACT_DICE)
+        hipLaunchKernelGGL(act_bwd_kernel<true>, dim3(nblk), dim3(256), 0, st, x, alpha, gy, (unsigned)rows,
+                           (unsigned)C, kActRowsPerBlk, dx, partial);
+    else
+        hipLaunchKernelGGL(act_bwd_kernel<false>, dim3(nblk), dim3(256), 0, st, x, alpha, gy, (unsigned)rows,
+                           (unsigned)C, kActRowsPerBlk, dx, partial);
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, partial, nblk,
+                       (unsigned)C, dalpha);
+    RECALGO_RETURN_LAST();
+}

@@ -1,0 +1,127 @@
+"""tf.layers.{dense, batch_normalization, dropout} look-alikes for the mirrored model_fns.
+
+These are the "context" MLP of the models (plain library GEMMs, not
+feature-interaction hot layers): the GEMMs go to hipBLASLt through torch, fp32.  Parameter
+gradients are written straight into the flat gradient buffer (variables.py).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from .variables import Variable, VariableStore, glorot_uniform, ones, zeros
+
+
+class _DenseFn(Function):
+    @staticmethod
+    def forward(ctx, anchor, x, kernel: Variable, bias: Optional[Variable], relu: bool):
+        x2 = x.reshape(-1, x.shape[-1])
+        if bias is not None:
+            y = torch.addmm(bias.data, x2, kernel.data)
+        else:
+            y = x2 @ kernel.data
+        if relu:
+            y = torch.relu_(y)
+        ctx.vars = (kernel, bias)
+        ctx.relu = relu
+        ctx.xshape = x.shape
+        ctx.save_for_backward(x2, y if relu else None)
+        return y.view(*x.shape[:-1], kernel.data.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        kernel, bias = ctx.vars
+        x2, y = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        if ctx.relu:
+            g2 = g2 * (y > 0)
+        elif not g2.is_contiguous():
+            g2 = g2.contiguous()
+        torch.mm(x2.t(), g2, out=kernel.grad)
+        if bias is not None:
+            torch.sum(g2, dim=0, out=bias.grad)
+        dx = g2 @ kernel.data.t()
+        return None, dx.view(ctx.xshape), None, None, None
+
+
+def dense(store: VariableStore, x: torch.Tensor, units, activation: Optional[str] = None,
+          use_bias: bool = True, name: Optional[str] = None) -> torch.Tensor:
+    """tf.layers.dense(x, units, activation=None|relu, use_bias, name).  `units` may be a
+    str (the reference passes FLAGS.hidden_units.split(','), deepfm.py:286; quirk B-2).
+    Variables: <scope>/<name>/kernel (glorot-uniform), <scope>/<name>/bias (zeros)."""
+    units = int(units)
+    name = name or store.auto_name("dense")
+    with store.variable_scope(name):
+        kernel = store.get_variable("kernel", (x.shape[-1], units), glorot_uniform)
+        bias = store.get_variable("bias", (units,), zeros) if use_bias else None
+    if activation not in (None, "relu"):
+        raise ValueError(f"unsupported activation {activation}")
+    return _DenseFn.apply(store.anchor, x, kernel, bias, activation == "relu")
+
+
+class _BatchNormTrainFn(Function):
+    @staticmethod
+    def forward(ctx, anchor, x, gamma: Variable, beta: Variable, mmean: Variable, mvar: Variable,
+                momentum: float, eps: float):
+        mean = x.mean(dim=0)
+        xc = x - mean
+        var = (xc * xc).mean(dim=0)            # biased, tf.nn.moments
+        rstd = torch.rsqrt(var + eps)
+        xhat = xc * rstd
+        y = xhat * gamma.data + beta.data
+        # moving stats: assign_moving_average, decay = momentum (TF default 0.99)
+        mmean.data.mul_(momentum).add_(mean, alpha=1 - momentum)
+        mvar.data.mul_(momentum).add_(var, alpha=1 - momentum)
+        ctx.vars = (gamma, beta)
+        ctx.save_for_backward(xhat, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        gamma, beta = ctx.vars
+        xhat, rstd = ctx.saved_tensors
+        B = g.shape[0]
+        dbeta = g.sum(dim=0)
+        dgamma = (g * xhat).sum(dim=0)
+        gamma.grad.copy_(dgamma)
+        beta.grad.copy_(dbeta)
+        dx = (gamma.data * rstd / B) * (B * g - dbeta - xhat * dgamma)
+        return None, dx, None, None, None, None, None, None
+
+
+class _BatchNormInferFn(Function):
+    @staticmethod
+    def forward(ctx, x, scale, shift):
+        ctx.save_for_backward(scale)
+        return x * scale + shift
+
+    @staticmethod
+    def backward(ctx, g):
+        (scale,) = ctx.saved_tensors
+        return g * scale, None, None
+
+
+def batch_normalization(store: VariableStore, x: torch.Tensor, training: bool = False,
+                        momentum: float = 0.99, epsilon: float = 1e-3,
+                        name: Optional[str] = None) -> torch.Tensor:
+    """tf.layers.batch_normalization on (B, C)."""
+    name = name or store.auto_name("batch_normalization")
+    C = x.shape[-1]
+    with store.variable_scope(name):
+        gamma = store.get_variable("gamma", (C,), ones)
+        beta = store.get_variable("beta", (C,), zeros)
+        mmean = store.get_variable("moving_mean", (C,), zeros, trainable=False)
+        mvar = store.get_variable("moving_variance", (C,), ones, trainable=False)
+    if training:
+        return _BatchNormTrainFn.apply(store.anchor, x, gamma, beta, mmean, mvar, momentum, epsilon)
+    inv = torch.rsqrt(mvar.data + epsilon) * gamma.data
+    return _BatchNormInferFn.apply(x, inv, beta.data - mmean.data * inv)
+
+
+def dropout(x: torch.Tensor, rate: float, training: bool = False) -> torch.Tensor:
+    """tf.layers.dropout: keep prob 1-rate, scaled by 1/(1-rate); identity when not training."""
+    if not training or rate <= 0.0:
+        return x
+    return torch.nn.functional.dropout(x, p=rate, training=True)

@@ -1,0 +1,360 @@
+"""Torch-tensor level wrappers around the C-ABI (include/recalgo.h).
+
+PyTorch is plumbing here: device memory, the current HIP stream, and autograd to chain the
+activation gradients between the hand-written kernels.  All arithmetic of the hot path runs in
+librecalgo_hip.so; there is no CPU or eager fallback — tensors must live on a HIP device.
+
+Parameter gradients are written by the kernels directly into `Variable.grad` /
+`EmbeddingArena.grad` (see variables.py); the autograd Functions return None for them.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from .variables import EmbeddingArena, Variable, VariableStore
+
+_ACT = {"prelu": 0, "dice": 1}
+
+
+def _lib_():
+    return _lib.load()
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t: torch.Tensor):
+    if not t.is_cuda:
+        raise _lib.RecalgoError(
+            "recalgo ops run only on a HIP device (no CPU fallback); got a CPU tensor")
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """Per-device grow-only scratch (allocated outside graph capture on first use)."""
+    key = (device.type, device.index)
+    w = _ws_cache.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = w
+    return w
+
+
+# =============================================================================================
+# K1: embedding gather
+# =============================================================================================
+class _GatherFn(Function):
+    @staticmethod
+    def forward(ctx, anchor, ids, arena: EmbeddingArena, row_base):
+        B, F = ids.shape
+        K = arena.K
+        out = torch.empty(B, F * K, device=ids.device, dtype=torch.float32)
+        _lib.check(_lib_().recalgo_embedding_gather_fwd(
+            _p(ids), _p(arena.weight), _p(row_base), B, F, K, _p(out), F * K, 0, _stream(ids)),
+            "recalgo_embedding_gather_fwd")
+        ctx.arena, ctx.ids, ctx.row_base = arena, ids, row_base
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, arena = ctx.ids, ctx.arena
+        B, F = ids.shape
+        g = g.contiguous()
+        _lib.check(_lib_().recalgo_embedding_gather_bwd(
+            _p(ids), _p(g), _p(ctx.row_base), B, F, arena.K, F * arena.K, 0, _p(arena.grad),
+            _stream(ids)), "recalgo_embedding_gather_bwd")
+        return None, None, None, None
+
+
+def embedding_gather(store: VariableStore, ids: torch.Tensor, arena: EmbeddingArena,
+                     row_base: torch.Tensor) -> torch.Tensor:
+    """ids [B,F] int64 (id<0 = OOV) -> [B, F*K]; gradient scattered into arena.grad."""
+    _chk(ids, torch.int64, "ids")
+    _chk(row_base, torch.int64, "row_base")
+    return _GatherFn.apply(store.anchor, ids, arena, row_base)
+
+
+class _BagMeanFn(Function):
+    @staticmethod
+    def forward(ctx, anchor, values, offsets, arena: EmbeddingArena, table_name):
+        B = offsets.numel() - 1
+        K = arena.K
+        table = arena.table_view(table_name)
+        out = torch.empty(B, K, device=values.device, dtype=torch.float32)
+        _lib.check(_lib_().recalgo_embedding_bag_mean_fwd(
+            _p(values), _p(offsets), _p(table), B, K, _p(out), K, 0, _stream(offsets)),
+            "recalgo_embedding_bag_mean_fwd")
+        ctx.args = (values, offsets, arena, table_name)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        values, offsets, arena, table_name = ctx.args
+        B = offsets.numel() - 1
+        rb, vocab = arena.tables[table_name]
+        gt = arena.grad[rb:rb + vocab]
+        g = g.contiguous()
+        _lib.check(_lib_().recalgo_embedding_bag_mean_bwd(
+            _p(values), _p(offsets), _p(g), B, arena.K, arena.K, 0, _p(gt), _stream(offsets)),
+            "recalgo_embedding_bag_mean_bwd")
+        return None, None, None, None, None
+
+
+def embedding_bag_mean(store, values, offsets, arena, table_name) -> torch.Tensor:
+    _chk(values, torch.int64, "values")
+    _chk(offsets, torch.int64, "offsets")
+    return _BagMeanFn.apply(store.anchor, values, offsets, arena, table_name)
+
+
+class _SeqGatherFn(Function):
+    @staticmethod
+    def forward(ctx, anchor, values, offsets, arena: EmbeddingArena, table_name, T):
+        B = offsets.numel() - 1
+        K = arena.K
+        table = arena.table_view(table_name)
+        out = torch.empty(B, T, K, device=offsets.device, dtype=torch.float32)
+        seq_len = torch.empty(B, device=offsets.device, dtype=torch.int32)
+        _lib.check(_lib_().recalgo_sequence_gather_fwd(
+            _p(values), _p(offsets), _p(table), B, T, K, _p(out), _p(seq_len), _stream(offsets)),
+            "recalgo_sequence_gather_fwd")
+        ctx.args = (values, offsets, arena, table_name, T)
+        ctx.mark_non_differentiable(seq_len)
+        return out, seq_len
+
+    @staticmethod
+    def backward(ctx, g, _gl):
+        values, offsets, arena, table_name, T = ctx.args
+        B = offsets.numel() - 1
+        rb, vocab = arena.tables[table_name]
+        gt = arena.grad[rb:rb + vocab]
+        g = g.contiguous()
+        _lib.check(_lib_().recalgo_sequence_gather_bwd(
+            _p(values), _p(offsets), _p(g), B, T, arena.K, _p(gt), _stream(offsets)),
+            "recalgo_sequence_gather_bwd")
+        return None, None, None, None, None, None
+
+
+def sequence_gather(store, values, offsets, arena, table_name, T) -> Tuple[torch.Tensor, torch.Tensor]:
+    _chk(values, torch.int64, "values")
+    _chk(offsets, torch.int64, "offsets")
+    return _SeqGatherFn.apply(store.anchor, values, offsets, arena, table_name, int(T))
+
+
+# =============================================================================================
+# K1+K2+K3: DeepFM sparse path
+# =============================================================================================
+class _DeepFMSparseFn(Function):
+    @staticmethod
+    def forward(ctx, anchor, ids, arena: EmbeddingArena, w1: EmbeddingArena, bias: Variable, row_base):
+        B, F = ids.shape
+        K = arena.K
+        emb = torch.empty(B, F * K, device=ids.device, dtype=torch.float32)
+        fm1 = torch.empty(B, 1, device=ids.device, dtype=torch.float32)
+        fm2 = torch.empty(B, 1, device=ids.device, dtype=torch.float32)
+        _lib.check(_lib_().recalgo_deepfm_sparse_fwd(
+            _p(ids), _p(arena.weight), _p(w1.weight), _p(bias.data), _p(row_base), B, F, K,
+            _p(emb), _p(fm1), _p(fm2), _stream(ids)), "recalgo_deepfm_sparse_fwd")
+        ctx.args = (ids, arena, w1, bias, row_base)
+        ctx.save_for_backward(emb)
+        return emb, fm1, fm2
+
+    @staticmethod
+    def backward(ctx, g_emb, g_fm1, g_fm2):
+        ids, arena, w1, bias, row_base = ctx.args
+        (emb,) = ctx.saved_tensors
+        B, F = ids.shape
+        g_emb, g_fm1, g_fm2 = g_emb.contiguous(), g_fm1.contiguous(), g_fm2.contiguous()
+        _lib.check(_lib_().recalgo_deepfm_sparse_bwd(
+            _p(ids), _p(emb), _p(g_emb), _p(g_fm1), _p(g_fm2), _p(row_base), B, F, arena.K,
+            _p(arena.grad), _p(w1.grad), _stream(ids)), "recalgo_deepfm_sparse_bwd")
+        torch.sum(g_fm1, dim=0, out=bias.grad.view(1))
+        return None, None, None, None, None, None
+
+
+def deepfm_sparse(store, ids, arena, w1_arena, bias, row_base):
+    """-> (deep_input [B,F*K], fm_first_order_logit [B,1], fm_second_order_logit [B,1])."""
+    _chk(ids, torch.int64, "ids")
+    return _DeepFMSparseFn.apply(store.anchor, ids, arena, w1_arena, bias, row_base)
+
+
+# =============================================================================================
+# K4: CrossNet
+# =============================================================================================
+class _CrossFn(Function):
+    @staticmethod
+    def forward(ctx, anchor, x0, w: Variable, b: Variable, xl_first):
+        # w.data, b.data: [L, d].  xl_first is None for the fused stack (x_0 = x0).
+        B, d = x0.shape
+        L = w.data.shape[0]
+        out = torch.empty(B, d, device=x0.device, dtype=torch.float32)
+        _lib.check(_lib_().recalgo_cross_fwd(
+            _p(x0), d, _p(w.data), _p(b.data), B, d, L, _p(out), d, _stream(x0)),
+            "recalgo_cross_fwd")
+        ctx.vars = (w, b)
+        ctx.save_for_backward(x0)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w, b = ctx.vars
+        (x0,) = ctx.saved_tensors
+        B, d = x0.shape
+        L = w.data.shape[0]
+        g = g.contiguous()
+        lib = _lib_()
+        ws = _workspace(lib.recalgo_cross_bwd_workspace_bytes(B, d, L), x0.device)
+        dx0 = torch.empty_like(x0)
+        _lib.check(lib.recalgo_cross_bwd(
+            _p(x0), d, _p(w.data), _p(b.data), _p(g), d, None, B, d, L, _p(dx0), _p(w.grad),
+            _p(b.grad), _p(ws), _stream(x0)), "recalgo_cross_bwd")
+        return None, dx0, None, None, None
+
+
+def cross_stack(store, x0: torch.Tensor, w: Variable, b: Variable) -> torch.Tensor:
+    """Fused L-layer CrossNet: w, b are [L, d] block variables."""
+    _chk(x0, torch.float32, "x0")
+    return _CrossFn.apply(store.anchor, x0, w, b, None)
+
+
+class _CrossLayerFn(Function):
+    """The reference's un-fused signature cross_layer(x0, xl, index): xl distinct from x0."""
+
+    @staticmethod
+    def forward(ctx, anchor, x0, xl, w: Variable, b: Variable):
+        B, d = x0.shape
+        out = torch.empty(B, d, device=x0.device, dtype=torch.float32)
+        _lib.check(_lib_().recalgo_cross_layer_fwd(
+            _p(x0), _p(xl), d, _p(w.data), _p(b.data), B, d, _p(out), d, _stream(x0)),
+            "recalgo_cross_layer_fwd")
+        ctx.vars = (w, b)
+        ctx.save_for_backward(x0, xl)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w, b = ctx.vars
+        x0, xl = ctx.saved_tensors
+        B, d = x0.shape
+        g = g.contiguous()
+        lib = _lib_()
+        ws = _workspace(lib.recalgo_cross_bwd_workspace_bytes(B, d, 1), x0.device)
+        dx0, dxl = torch.empty_like(x0), torch.empty_like(x0)
+        _lib.check(lib.recalgo_cross_layer_bwd(
+            _p(x0), _p(xl), d, _p(w.data), _p(b.data), _p(g), d, B, d, _p(dx0), _p(dxl),
+            _p(w.grad), _p(b.grad), _p(ws), _stream(x0)), "recalgo_cross_layer_bwd")
+        return None, dx0, dxl, None, None
+
+
+def cross_layer(store, x0: torch.Tensor, xl: torch.Tensor, w: Variable, b: Variable) -> torch.Tensor:
+    """One layer, w/b of shape (d, 1) or (d,): out = x0 * (xl . w) + b + xl."""
+    _chk(x0, torch.float32, "x0")
+    _chk(xl, torch.float32, "xl")
+    return _CrossLayerFn.apply(store.anchor, x0, xl, w, b)
+
+
+# =============================================================================================
+# a14: loss tail
+# =============================================================================================
+class _SigmoidCEFn(Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        B = logits.numel()
+        lg = logits.contiguous().view(-1)
+        lb = labels.contiguous().view(-1).to(torch.float32)
+        prob = torch.empty_like(lg)
+        loss = torch.empty(1, device=lg.device, dtype=torch.float32)
+        dlogit = torch.empty_like(lg)
+        _lib.check(_lib_().recalgo_sigmoid_ce_fwd_bwd(
+            _p(lg), _p(lb), B, 1.0, _p(prob), _p(loss), _p(dlogit), _stream(lg)),
+            "recalgo_sigmoid_ce_fwd_bwd")
+        ctx.save_for_backward(dlogit)
+        ctx.shape = logits.shape
+        ctx.mark_non_differentiable(prob)
+        return loss.view(()), prob.view(logits.shape)
+
+    @staticmethod
+    def backward(ctx, gloss, _gprob):
+        (dlogit,) = ctx.saved_tensors
+        return (dlogit * gloss).view(ctx.shape), None
+
+
+def sigmoid_cross_entropy(logits: torch.Tensor, labels: torch.Tensor):
+    """-> (mean loss scalar, probabilities)."""
+    return _SigmoidCEFn.apply(logits, labels)
+
+
+# =============================================================================================
+# a12: PReLU / Dice
+# =============================================================================================
+class _ActFn(Function):
+    @staticmethod
+    def forward(ctx, anchor, x, alpha: Variable, kind: int):
+        x = x.contiguous()
+        rows, C = x.shape
+        y = torch.empty_like(x)
+        _lib.check(_lib_().recalgo_activation_fwd(_p(x), _p(alpha.data), rows, C, kind, _p(y), _stream(x)),
+                   "recalgo_activation_fwd")
+        ctx.alpha, ctx.kind = alpha, kind
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        rows, C = x.shape
+        lib = _lib_()
+        gy = gy.contiguous()
+        ws = _workspace(lib.recalgo_activation_bwd_workspace_bytes(rows, C), x.device)
+        dx = torch.empty_like(x)
+        _lib.check(lib.recalgo_activation_bwd(_p(x), _p(ctx.alpha.data), _p(gy), rows, C, ctx.kind, _p(dx),
+                                              _p(ctx.alpha.grad), _p(ws), _stream(x)),
+                   "recalgo_activation_bwd")
+        return None, dx, None, None
+
+
+def activation(store, x: torch.Tensor, alpha: Variable, kind: str) -> torch.Tensor:
+    return _ActFn.apply(store.anchor, x, alpha, _ACT[kind])
+
+
+# =============================================================================================
+# a15: TF1 Adam
+# =============================================================================================
+def adam_tf1_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int,
+              lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+              zero_grad: bool = True, lr_t_dev: Optional[torch.Tensor] = None) -> None:
+    """In-place dense TF1 Adam over flat fp32 buffers (step is 1-based).  With `lr_t_dev`
+    (a 1-element device tensor maintained by adam_tf1_advance_) the launch is hipGraph
+    replayable."""
+    import math
+    import struct
+    # TF keeps lr/beta1/beta2 as float32 scalars: round them first (1 - f32(0.999) != 0.001)
+    f32 = lambda x: struct.unpack("f", struct.pack("f", x))[0]
+    lr_, b1_, b2_ = f32(lr), f32(beta1), f32(beta2)
+    lr_t = 0.0 if lr_t_dev is not None else \
+        lr_ * math.sqrt(1.0 - b2_ ** step) / (1.0 - b1_ ** step)
+    _lib.check(_lib_().recalgo_adam_tf1_dense(
+        _p(p), _p(g), _p(m), _p(v), p.numel(), lr_t, _p(lr_t_dev), beta1, beta2, eps,
+        int(zero_grad), _stream(p)), "recalgo_adam_tf1_dense")
+
+
+def adam_tf1_advance_(step_dev: torch.Tensor, lr_t_dev: torch.Tensor, lr: float,
+                      beta1: float = 0.9, beta2: float = 0.999) -> None:
+    """step_dev (int64[1]) += 1; lr_t_dev (float[1]) = lr*sqrt(1-b2^t)/(1-b1^t), on device."""
+    _lib.check(_lib_().recalgo_adam_tf1_advance(_p(step_dev), lr, beta1, beta2, _p(lr_t_dev),
+                                                 _stream(step_dev)), "recalgo_adam_tf1_advance")

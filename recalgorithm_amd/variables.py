@@ -1,0 +1,245 @@
+"""Parameter store that plays the role of TF1 variable scopes for the mirrored model_fns.
+
+The reference creates parameters implicitly by name (`tf.get_variable`,
+algorithm/DCN/cross_layer.py:18-19; `tf.layers.dense` auto-names `dense`, `dense_1`, ...)
+inside `tf.variable_scope`s.  Here a `VariableStore` keyed by the same names owns them.
+
+Dense parameters are packed into ONE flat fp32 buffer (and one flat gradient buffer, one m,
+one v): the TF1-Adam update is a single kernel launch and the data-parallel all-reduce is a
+single collective over the flat gradient.  Every parameter-owning op writes
+its parameter gradient straight into its slice of the flat gradient buffer (no autograd
+accumulation kernels); only activation gradients flow through torch.autograd.
+
+Embedding tables live in `EmbeddingArena`s (see include/recalgo.h "arena").
+"""
+from __future__ import annotations
+
+import contextlib
+import math
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+
+class Variable:
+    """A named fp32 parameter: `.data` and `.grad` are views into the store's flat buffers
+    once the store is packed."""
+
+    __slots__ = ("name", "data", "grad", "trainable")
+
+    def __init__(self, name: str, data: torch.Tensor, trainable: bool = True):
+        self.name = name
+        self.data = data
+        self.grad = torch.zeros_like(data) if trainable else None
+        self.trainable = trainable
+
+    @property
+    def shape(self):
+        return tuple(self.data.shape)
+
+    def __repr__(self):
+        return f"Variable({self.name}, shape={self.shape})"
+
+
+# ---- initialisers -------------------------------------------------
+def glorot_uniform(shape: Sequence[int], gen: torch.Generator) -> torch.Tensor:
+    """TF default for tf.get_variable / tf.layers.dense kernels."""
+    if len(shape) < 1:
+        fan_in = fan_out = 1
+    elif len(shape) == 1:
+        fan_in = fan_out = shape[0]
+    elif len(shape) == 2:
+        fan_in, fan_out = shape
+    else:
+        rf = 1
+        for s in shape[:-2]:
+            rf *= s
+        fan_in, fan_out = shape[-2] * rf, shape[-1] * rf
+    limit = math.sqrt(6.0 / (fan_in + fan_out))
+    return (torch.rand(*shape, generator=gen) * 2 - 1) * limit
+
+
+def truncated_normal(shape: Sequence[int], stddev: float, gen: torch.Generator) -> torch.Tensor:
+    """TF embedding_column default: truncated_normal(0, 1/sqrt(dim)), resampling |z| > 2."""
+    out = torch.randn(*shape, generator=gen)
+    for _ in range(8):
+        bad = out.abs() > 2
+        if not bad.any():
+            break
+        out = torch.where(bad, torch.randn(*shape, generator=gen), out)
+    return out.clamp(-2, 2) * stddev
+
+
+def zeros(shape, gen=None):
+    return torch.zeros(*shape)
+
+
+def ones(shape, gen=None):
+    return torch.ones(*shape)
+
+
+class VariableStore:
+    def __init__(self, device: torch.device | str = "cpu", seed: int = 42):
+        self.device = torch.device(device)
+        self.vars: Dict[str, Variable] = {}
+        self.order: List[str] = []
+        self._scope: List[str] = []
+        self._auto: Dict[str, int] = {}
+        self._alias: Dict[str, Tuple[str, int]] = {}   # sub-variable -> (block, index)
+        self._gen = torch.Generator().manual_seed(seed)
+        self.packed = False
+        self.flat = self.flat_grad = self.flat_m = self.flat_v = None
+        # autograd anchor: makes parameter-owning ops differentiable even when none of their
+        # tensor inputs requires grad (their parameter grads are written as side effects)
+        self.anchor = torch.zeros(1, device=self.device, requires_grad=True)
+        self.arenas: Dict[str, "EmbeddingArena"] = {}
+
+    # -- scopes -------------------------------------------------------------------------
+    @contextlib.contextmanager
+    def variable_scope(self, name: str):
+        self._scope.append(name)
+        try:
+            yield
+        finally:
+            self._scope.pop()
+
+    def begin_call(self):
+        """A model_fn invocation == a fresh TF graph: auto-naming counters restart."""
+        self._auto.clear()
+        self._scope.clear()
+
+    def scope_name(self) -> str:
+        return "/".join(self._scope)
+
+    def full_name(self, name: str) -> str:
+        return "/".join(self._scope + [name])
+
+    def auto_name(self, base: str) -> str:
+        """tf.layers auto naming inside the current scope: base, base_1, base_2, ..."""
+        key = self.full_name(base)
+        n = self._auto.get(key, 0)
+        self._auto[key] = n + 1
+        return base if n == 0 else f"{base}_{n}"
+
+    # -- variables ------------------------------------------------------------------------
+    def get_variable(self, name: str, shape: Sequence[int],
+                     initializer: Optional[Callable] = None, trainable: bool = True) -> Variable:
+        full = self.full_name(name)
+        v = self.vars.get(full)
+        if v is not None:
+            if tuple(v.shape) != tuple(int(s) for s in shape):
+                raise ValueError(f"variable {full}: shape {v.shape} != requested {tuple(shape)}")
+            return v
+        if self.packed:
+            raise RuntimeError(f"variable {full} requested after the store was packed")
+        shape = [int(s) for s in shape]
+        init = initializer or glorot_uniform
+        data = init(shape, self._gen).to(torch.float32).to(self.device).contiguous()
+        v = Variable(full, data, trainable)
+        self.vars[full] = v
+        self.order.append(full)
+        return v
+
+    def get_variable_block(self, block_name: str, names: Sequence[str], shape: Sequence[int],
+                           initializer: Optional[Callable] = None) -> Tuple[Variable, List[Variable]]:
+        """Allocate len(names) same-shaped variables contiguously ([n, *shape]) so that a fused
+        kernel can treat them as one tensor; the individual names remain addressable."""
+        full = self.full_name(block_name)
+        if full in self.vars:
+            return self.vars[full], [self.vars[self.full_name(n)] for n in names]
+        init = initializer or glorot_uniform
+        shape = [int(s) for s in shape]
+        parts = [init(shape, self._gen).to(torch.float32) for _ in names]
+        data = torch.stack(parts, 0).to(self.device).contiguous()
+        blk = Variable(full, data, True)
+        self.vars[full] = blk
+        self.order.append(full)
+        subs = []
+        for i, n in enumerate(names):
+            sv = Variable.__new__(Variable)
+            sv.name, sv.data, sv.grad, sv.trainable = self.full_name(n), blk.data[i], blk.grad[i], True
+            self.vars[sv.name] = sv          # alias, not in self.order (owned by the block)
+            self._alias[sv.name] = (full, i)
+            subs.append(sv)
+        return blk, subs
+
+    # -- packing --------------------------------------------------------------------------
+    def pack(self):
+        """Move every dense variable into one flat buffer (16-byte aligned slices)."""
+        if self.packed:
+            return
+        owned = [self.vars[n] for n in self.order]
+        offs, total = [], 0
+        for v in owned:
+            offs.append(total)
+            total += (v.data.numel() + 3) // 4 * 4
+        self.flat = torch.zeros(total, device=self.device)
+        self.flat_grad = torch.zeros(total, device=self.device)
+        self.flat_m = torch.zeros(total, device=self.device)
+        self.flat_v = torch.zeros(total, device=self.device)
+        self.trainable_mask = torch.ones(total, device=self.device)
+        for v, o in zip(owned, offs):
+            n = v.data.numel()
+            old = v.data
+            self.flat[o:o + n].copy_(old.reshape(-1))
+            new = self.flat[o:o + n].view(old.shape)
+            newg = self.flat_grad[o:o + n].view(old.shape)
+            if not v.trainable:
+                self.trainable_mask[o:o + n] = 0
+            v.data, v.grad = new, newg
+        for sub, (blk, idx) in self._alias.items():
+            self.vars[sub].data = self.vars[blk].data[idx]
+            self.vars[sub].grad = self.vars[blk].grad[idx]
+        self.packed = True
+
+    def named_arrays(self) -> Dict[str, torch.Tensor]:
+        out = {n: self.vars[n].data for n in self.vars}
+        for ar in self.arenas.values():
+            for tn in ar.tables:
+                out[tn] = ar.table_view(tn)
+        return out
+
+
+class EmbeddingArena:
+    """All embedding tables of width K of one model in one [rows, K] fp32 tensor plus the
+    gradient / Adam-moment arenas of the same shape (include/recalgo.h "arena")."""
+
+    def __init__(self, name: str, K: int, device, seed: int = 43):
+        self.name, self.K, self.device = name, int(K), torch.device(device)
+        self.tables: Dict[str, Tuple[int, int]] = {}   # table name -> (row_base, vocab)
+        self._init: Dict[str, torch.Tensor] = {}
+        self.rows = 0
+        self._gen = torch.Generator().manual_seed(seed)
+        self.weight = self.grad = self.m = self.v = None
+
+    def add_table(self, name: str, vocab: int, init: Optional[torch.Tensor] = None) -> int:
+        if name in self.tables:
+            return self.tables[name][0]
+        if self.weight is not None:
+            raise RuntimeError("arena already materialised")
+        rb = self.rows
+        self.tables[name] = (rb, int(vocab))
+        self.rows += int(vocab)
+        if init is not None:
+            self._init[name] = init
+        return rb
+
+    def materialize(self):
+        if self.weight is not None:
+            return
+        K = self.K
+        w = torch.empty(max(self.rows, 1), K)
+        for name, (rb, vocab) in self.tables.items():
+            if name in self._init:
+                w[rb:rb + vocab] = self._init[name]
+            else:
+                w[rb:rb + vocab] = truncated_normal((vocab, K), 1.0 / math.sqrt(K), self._gen)
+        self.weight = w.to(self.device).contiguous()
+        self.grad = torch.zeros_like(self.weight)
+        self.m = torch.zeros_like(self.weight)
+        self.v = torch.zeros_like(self.weight)
+        self._init.clear()
+
+    def table_view(self, name: str) -> torch.Tensor:
+        rb, vocab = self.tables[name]
+        return self.weight[rb:rb + vocab]

@@ -1,0 +1,296 @@
+"""-m gpu parity tests: HIP kernels (through the C-ABI / ctypes) vs oracle/ref_ops.py on the
+same seeded inputs.  Gradients of the oracle come from torch.autograd in float64."""
+import math
+
+import pytest
+import torch
+
+from oracle import ref_ops as R
+from recalgorithm_amd import ops
+from recalgorithm_amd.variables import EmbeddingArena, Variable, VariableStore
+from tests.util import assert_bit_exact, assert_close, zipf_ids
+
+pytestmark = pytest.mark.gpu
+
+
+def make_arena(vocabs, K, dev, seed=0):
+    ar = EmbeddingArena("t", K, dev, seed=seed)
+    for i, v in enumerate(vocabs):
+        ar.add_table(f"t{i}", v)
+    ar.materialize()
+    rb = torch.tensor([ar.tables[f"t{i}"][0] for i in range(len(vocabs))], dtype=torch.int64, device=dev)
+    return ar, rb
+
+
+def make_ids(gen, B, vocabs, oov=0.02):
+    return torch.stack([zipf_ids(gen, B, v, oov) for v in vocabs], dim=1).contiguous()
+
+
+@pytest.mark.parametrize("B,vocabs,K", [
+    (1, [5], 16), (37, [11, 2, 301], 8), (512, [1000] * 26, 16), (4096, [20000, 106444, 2, 18789] + [997] * 22, 16),
+])
+def test_gather_fwd_bit_exact_and_bwd(dev, B, vocabs, K):
+    gen = torch.Generator().manual_seed(B)
+    ar, rb = make_arena(vocabs, K, dev)
+    ids = make_ids(gen, B, vocabs)
+    store = VariableStore(dev)
+    out = ops.embedding_gather(store, ids.to(dev), ar, rb)
+    w = ar.weight.cpu()
+    ref = torch.cat([R.embedding_lookup_single(ids[:, f], w[rb[f].item():rb[f].item() + vocabs[f]])
+                     for f in range(len(vocabs))], dim=1)
+    assert_bit_exact(out, ref, "gather fwd")
+    # backward: dense-equivalent scatter-add
+    g = torch.randn(B, len(vocabs) * K, generator=gen)
+    out.backward(g.to(dev))
+    w64 = w.double().requires_grad_(True)
+    ref64 = torch.cat([R.embedding_lookup_single(ids[:, f], w64[rb[f].item():rb[f].item() + vocabs[f]])
+                       for f in range(len(vocabs))], dim=1)
+    ref64.backward(g.double())
+    assert_close(ar.grad, w64.grad, what="gather bwd", reduced=True)
+
+
+def test_gather_empty_batch(dev):
+    ar, rb = make_arena([7, 9], 16, dev)
+    store = VariableStore(dev)
+    out = ops.embedding_gather(store, torch.zeros(0, 2, dtype=torch.int64, device=dev), ar, rb)
+    assert out.shape == (0, 32)
+
+
+def _bags(gen, B, vocab, maxlen, oov=0.1):
+    lens = torch.randint(0, maxlen + 1, (B,), generator=gen)
+    lens[0] = 0
+    offsets = torch.zeros(B + 1, dtype=torch.int64)
+    offsets[1:] = lens.cumsum(0)
+    values = zipf_ids(gen, int(offsets[-1]), vocab, oov)
+    return values, offsets
+
+
+@pytest.mark.parametrize("B,vocab,K,maxlen", [(5, 13, 4, 3), (300, 350, 16, 12)])
+def test_bag_mean(dev, B, vocab, K, maxlen):
+    gen = torch.Generator().manual_seed(7)
+    ar, _ = make_arena([3, vocab], K, dev)
+    values, offsets = _bags(gen, B, vocab, maxlen)
+    store = VariableStore(dev)
+    out = ops.embedding_bag_mean(store, values.to(dev), offsets.to(dev), ar, "t1")
+    tab = ar.table_view("t1").cpu()
+    ref = R.embedding_lookup_mean(values, offsets, tab)
+    assert_close(out, R.embedding_lookup_mean(values, offsets, tab.double()), what="bag mean fwd")
+    # bags of exactly one valid id are exact row copies
+    lens = offsets[1:] - offsets[:-1]
+    for b in torch.nonzero(lens == 1).flatten().tolist():
+        assert torch.equal(out[b].cpu(), ref[b])
+    g = torch.randn(B, K, generator=gen)
+    out.backward(g.to(dev))
+    t64 = tab.double().requires_grad_(True)
+    R.embedding_lookup_mean(values, offsets, t64).backward(g.double())
+    rb, v = ar.tables["t1"]
+    assert_close(ar.grad[rb:rb + v], t64.grad, what="bag mean bwd", reduced=True)
+    assert float(ar.grad[:rb].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("B,T", [(4, 3), (129, 50)])
+def test_sequence_gather(dev, B, T):
+    gen = torch.Generator().manual_seed(3)
+    K, vocab = 16, 211
+    ar, _ = make_arena([vocab], K, dev)
+    values, offsets = _bags(gen, B, vocab, T)
+    store = VariableStore(dev)
+    out, sl = ops.sequence_gather(store, values.to(dev), offsets.to(dev), ar, "t0", T)
+    tab = ar.table_view("t0").cpu()
+    ref, lens = R.sequence_lookup(values, offsets, tab, T)
+    assert_bit_exact(out, ref, "sequence gather")
+    assert torch.equal(sl.cpu().long(), lens)
+    g = torch.randn(B, T, K, generator=gen)
+    out.backward(g.to(dev))
+    t64 = tab.double().requires_grad_(True)
+    R.sequence_lookup(values, offsets, t64, T)[0].backward(g.double())
+    assert_close(ar.grad, t64.grad, what="sequence gather bwd", reduced=True)
+
+
+@pytest.mark.parametrize("B,F,K", [(3, 2, 4), (130, 6, 8), (1024, 26, 16), (4096, 26, 16)])
+def test_deepfm_sparse(dev, B, F, K):
+    gen = torch.Generator().manual_seed(B + F)
+    vocabs = [max(2, 1000 // (f + 1)) for f in range(F)]
+    ar, rb = make_arena(vocabs, K, dev)
+    w1 = EmbeddingArena("w1", 1, dev, seed=9)
+    for i, v in enumerate(vocabs):
+        w1.add_table(f"t{i}", v)
+    w1.materialize()
+    ids = make_ids(gen, B, vocabs, oov=0.03)
+    bias = Variable("b", torch.tensor([0.37], device=dev))
+    store = VariableStore(dev)
+    emb, fm1, fm2 = ops.deepfm_sparse(store, ids.to(dev), ar, w1, bias, rb)
+
+    def oracle(dt):
+        W = ar.weight.cpu().to(dt).requires_grad_(True)
+        W1 = w1.weight.cpu().to(dt).reshape(-1).requires_grad_(True)
+        bb = bias.data.cpu().to(dt).requires_grad_(True)
+        fields = [R.embedding_lookup_single(ids[:, f], W[rb[f].item():rb[f].item() + vocabs[f]]) for f in range(F)]
+        o1 = R.indicator_first_order([ids[:, f] for f in range(F)],
+                                     [W1[rb[f].item():rb[f].item() + vocabs[f]] for f in range(F)], bb[0])
+        o2 = R.fm_second_order(fields)
+        return W, W1, bb, torch.cat(fields, 1), o1, o2
+
+    _, _, _, e32, _, _ = oracle(torch.float32)
+    assert_bit_exact(emb, e32.detach(), "deep_input")
+    W, W1, bb, e64, o1, o2 = oracle(torch.float64)
+    assert_close(fm1, o1, what="fm first order")
+    assert_close(fm2, o2, what="fm second order")
+    ge = torch.randn(B, F * K, generator=gen)
+    g1 = torch.randn(B, 1, generator=gen)
+    g2 = torch.randn(B, 1, generator=gen)
+    torch.autograd.backward([emb, fm1, fm2], [ge.to(dev), g1.to(dev), g2.to(dev)])
+    torch.autograd.backward([e64, o1, o2], [ge.double(), g1.double(), g2.double()])
+    assert_close(ar.grad, W.grad, what="deepfm d(table)", reduced=True)
+    assert_close(w1.grad.reshape(-1), W1.grad, what="deepfm d(w1)", reduced=True)
+    assert_close(bias.grad, bb.grad, what="deepfm d(bias)", reduced=True)
+
+
+def test_fm_identity_bruteforce(dev):
+    """0.5*sum_k[(sum e)^2 - sum e^2] == sum_{i<j} <e_i, e_j>  (SURVEY.md §8c (1))."""
+    gen = torch.Generator().manual_seed(1)
+    B, F, K = 64, 7, 16
+    vocabs = [50] * F
+    ar, rb = make_arena(vocabs, K, dev)
+    w1 = EmbeddingArena("w1", 1, dev)
+    for i, v in enumerate(vocabs):
+        w1.add_table(f"t{i}", v)
+    w1.materialize()
+    ids = make_ids(gen, B, vocabs, oov=0.0)
+    store = VariableStore(dev)
+    emb, _, fm2 = ops.deepfm_sparse(store, ids.to(dev), ar, w1, Variable("b", torch.zeros(1, device=dev)), rb)
+    E = emb.detach().cpu().double().view(B, F, K)
+    brute = torch.zeros(B, dtype=torch.float64)
+    for i in range(F):
+        for j in range(i + 1, F):
+            brute += (E[:, i] * E[:, j]).sum(-1)
+    assert_close(fm2.view(-1), brute, what="FM identity")
+
+
+@pytest.mark.parametrize("B,d,L", [(1, 4, 1), (5, 48, 2), (257, 416, 3), (4096, 416, 3), (64, 432, 6), (33, 1024, 4)])
+def test_cross_stack(dev, B, d, L):
+    gen = torch.Generator().manual_seed(d + L)
+    x0 = torch.randn(B, d, generator=gen)
+    w = torch.randn(L, d, generator=gen) / math.sqrt(d)
+    b = torch.randn(L, d, generator=gen) * 0.1
+    store = VariableStore(dev)
+    wv, bv = Variable("w", w.to(dev)), Variable("b", b.to(dev))
+    x0d = x0.to(dev).requires_grad_(True)
+    out = ops.cross_stack(store, x0d, wv, bv)
+    x64 = x0.double().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    b64 = b.double().requires_grad_(True)
+    ref = R.cross_stack(x64, [w64[l].unsqueeze(1) for l in range(L)], [b64[l].unsqueeze(1) for l in range(L)])
+    assert_close(out, ref, what="cross fwd")
+    g = torch.randn(B, d, generator=gen)
+    out.backward(g.to(dev))
+    ref.backward(g.double())
+    assert_close(x0d.grad, x64.grad, what="cross dx0")
+    assert_close(wv.grad, w64.grad, what="cross dw", reduced=True)
+    assert_close(bv.grad, b64.grad, what="cross db", reduced=True)
+
+
+def test_cross_layer_separate_xl_and_identities(dev):
+    gen = torch.Generator().manual_seed(5)
+    B, d = 77, 96
+    x0, xl = torch.randn(B, d, generator=gen), torch.randn(B, d, generator=gen)
+    w, b = torch.randn(d, 1, generator=gen) * 0.1, torch.randn(d, 1, generator=gen)
+    store = VariableStore(dev)
+    wv, bv = Variable("w", w.to(dev)), Variable("b", b.to(dev))
+    x0d, xld = x0.to(dev).requires_grad_(True), xl.to(dev).requires_grad_(True)
+    out = ops.cross_layer(store, x0d, xld, wv, bv)
+    a64 = [t.double().requires_grad_(True) for t in (x0, xl, w, b)]
+    ref = R.cross_layer(*a64)
+    assert_close(out, ref, what="cross_layer fwd")
+    g = torch.randn(B, d, generator=gen)
+    out.backward(g.to(dev))
+    ref.backward(g.double())
+    for got, want, nm in [(x0d.grad, a64[0].grad, "dx0"), (xld.grad, a64[1].grad, "dxl"),
+                          (wv.grad, a64[2].grad, "dw"), (bv.grad, a64[3].grad, "db")]:
+        assert_close(got, want, what=f"cross_layer {nm}", reduced=True)
+    # w = 0  =>  out = xl + b    — exact
+    wz = Variable("wz", torch.zeros(d, 1, device=dev))
+    outz = ops.cross_layer(store, x0.to(dev), xl.to(dev), wz, bv)
+    assert torch.equal(outz.cpu(), (x0 * 0.0 + b.t()) + xl)
+
+
+@pytest.mark.parametrize("B", [1, 100, 4096, 5000])
+def test_sigmoid_ce(dev, B):
+    gen = torch.Generator().manual_seed(B)
+    x = torch.randn(B, 1, generator=gen) * 4
+    x[0] = 30.0
+    if B > 1:
+        x[1] = -30.0
+    z = (torch.rand(B, 1, generator=gen) < 0.3).float()
+    # saturated logits with the label that does NOT cancel (for x=30, z=1 the fp64 autograd
+    # reference itself loses 3 digits forming (1 - r) - 1; the kernel's ((1-z) - r) is exact)
+    z[0] = 0.0
+    if B > 1:
+        z[1] = 1.0
+    xd = x.to(dev).requires_grad_(True)
+    loss, prob = ops.sigmoid_cross_entropy(xd, z.to(dev))
+    x64 = x.double().requires_grad_(True)
+    ref = R.ce_loss(z.double(), x64)
+    assert_close(loss, ref, what="loss")
+    assert_close(prob, torch.sigmoid(x64), what="prob")
+    (loss * 2.5).backward()
+    (ref * 2.5).backward()
+    assert_close(xd.grad, x64.grad, what="dlogit")
+
+
+@pytest.mark.parametrize("n", [1, 7, 4096, 1_000_003])
+def test_adam_tf1(dev, n):
+    gen = torch.Generator().manual_seed(n)
+    p, g = torch.randn(n, generator=gen), torch.randn(n, generator=gen)
+    g[::3] = 0.0
+    m, v = torch.zeros(n), torch.zeros(n)
+    pd, gd, md, vd = (t.clone().to(dev) for t in (p, g, m, v))
+    p64, m64, v64 = p.double(), m.double(), v.double()
+    step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+    lr_dev = torch.zeros(1, device=dev)
+    for step in (1, 2, 3):
+        gs = g * step
+        gd.copy_(gs)
+        if step < 3:
+            ops.adam_tf1_(pd, gd, md, vd, step, 0.005)
+            ops.adam_tf1_advance_(step_dev, lr_dev, 0.005)
+        else:  # device-side step counter path (hipGraph replayable)
+            ops.adam_tf1_advance_(step_dev, lr_dev, 0.005)
+            ops.adam_tf1_(pd, gd, md, vd, -1, 0.005, lr_t_dev=lr_dev)
+        R.adam_tf1_step(p64, gs.double(), m64, v64, step, 0.005)
+        assert float(gd.abs().sum()) == 0.0, "zero_grad"
+    assert int(step_dev) == 3
+    assert_close(pd, p64, what="adam p")
+    assert_close(md, m64, what="adam m")
+    assert_close(vd, v64, what="adam v")
+
+
+@pytest.mark.parametrize("kind", ["prelu", "dice"])
+def test_activation(dev, kind):
+    gen = torch.Generator().manual_seed(11)
+    rows, C = 300, 200
+    x = torch.randn(rows, C, generator=gen) * 2
+    a = torch.rand(C, generator=gen) + 0.5
+    store = VariableStore(dev)
+    av = Variable("alpha", a.to(dev))
+    xd = x.to(dev).requires_grad_(True)
+    y = ops.activation(store, xd, av, kind)
+    x64, a64 = x.double().requires_grad_(True), a.double().requires_grad_(True)
+    ref = (R.prelu if kind == "prelu" else R.dice)(x64, a64)
+    assert_close(y, ref, what=kind)
+    g = torch.randn(rows, C, generator=gen)
+    y.backward(g.to(dev))
+    ref.backward(g.double())
+    assert_close(xd.grad, x64.grad, what=f"{kind} dx")
+    assert_close(av.grad, a64.grad, what=f"{kind} dalpha", reduced=True)
+
+
+def test_cpu_tensor_is_rejected():
+    """The product path has no CPU fallback."""
+    from recalgorithm_amd._lib import RecalgoError
+    store = VariableStore("cpu")
+    ar = EmbeddingArena("t", 16, "cpu")
+    ar.add_table("t0", 4)
+    ar.materialize()
+    with pytest.raises(RecalgoError):
+        ops.embedding_gather(store, torch.zeros(2, 1, dtype=torch.int64), ar, torch.zeros(1, dtype=torch.int64))
