@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""bench.py — CTR examples/sec of one training step (forward + backward + TF1-Adam) of the hot
+path on synthetic WeChat-shaped data: 26 sparse fields x emb 16, batch 4096 per GPU.
+
+    python bench.py --gpus N --steps K --warmup W [--model dcn|deepfm|xdeepfm|din]
+
+N > 1 is launched by the driver as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+one rank per GPU over RCCL; per-GPU batch is fixed (weak scaling), `value` is the whole-job
+examples/sec = N * batch * K / max-over-ranks(time).  Rank 0 prints ONE JSON line.
+
+Workload at N=1 = BASELINE.json configs[1]: DCN, 3-layer CrossNet on the [B, 416] gathered
+embeddings + MLP 512,256,128, B = 4096, fp32, TF1-Adam on every variable (dense Adam over the
+whole embedding arena, the reference's semantics).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+FP32_PEAK_TFLOPS = 157.3       # fp32 vector == fp32 MFMA peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--model", default="dcn", choices=["dcn", "deepfm", "xdeepfm", "din", "fibinet", "pnn"])
+    ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch")
+    ap.add_argument("--fields", type=int, default=26)
+    ap.add_argument("--emb", type=int, default=16)
+    ap.add_argument("--max-vocab", type=int, default=1_000_000)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def build_estimator(args, device, rank=0, world=1):
+    from recalgorithm_amd import feature_column as fc
+    from recalgorithm_amd.estimator import Estimator, RunConfig
+    from recalgorithm_amd.io import synth
+
+    spec = synth.SynthSpec(n_fields=args.fields, max_vocab=args.max_vocab,
+                           with_history=(args.model == "din"), history_len=50 if args.model == "din" else None)
+    cats = [fc.categorical_column_with_identity(n, v) for n, v in zip(spec.names, spec.vocabs)]
+    hidden = ["512", "256", "128"]
+    if args.model == "dcn":
+        from recalgorithm_amd.algorithm.DCN.dcn import dcn_model_fn as model_fn
+        params = {"category_feature_columns": [fc.embedding_column(c, args.emb) for c in cats],
+                  "dense_feature_columns": [], "hidden_units": hidden, "num_cross_layer": 3,
+                  "learning_rate": 0.005}
+        workload = f"DCN 3-layer CrossNet + MLP 512,256,128; {args.fields} fields x emb{args.emb}; batch {args.batch}/GPU"
+    elif args.model == "deepfm":
+        from recalgorithm_amd.algorithm.DeepFM.deepfm import deepfm_model_fn as model_fn
+        params = {"first_order_feature_columns": [fc.indicator_column(c) for c in cats],
+                  "second_order_feature_columns": [fc.embedding_column(c, args.emb) for c in cats],
+                  "hidden_units": hidden, "dropout_rate": 0.0, "batch_norm": True, "learning_rate": 0.005}
+        workload = f"DeepFM FM1+FM2+MLP 512,256,128 (BN); {args.fields} fields x emb{args.emb}; batch {args.batch}/GPU"
+    else:
+        raise SystemExit(f"--model {args.model}: not wired into bench.py yet")
+    est = Estimator(model_fn=model_fn, params=params, config=RunConfig(device=device, seed=42))
+    feats, labels, _ = synth.device_features(spec, args.batch, device, batch_index=rank)
+    est.build(feats, labels)
+    return est, spec, feats, labels, workload
+
+
+def event_time_ms(fn, iters=50, warm=5):
+    """Average duration of `fn()` (enqueues kernels on the current stream) from HIP events
+    recorded on that same stream."""
+    for _ in range(warm):
+        fn()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    start.record()
+    for _ in range(iters):
+        fn()
+    end.record()
+    end.synchronize()
+    return start.elapsed_time(end) / iters
+
+
+def kernel_rooflines(args, est, feats, device):
+    """Per-kernel average launch time (HIP events) and algorithmic-bytes roofline fraction for
+    the hand-written kernels of the step (SURVEY.md §8d byte model)."""
+    import ctypes
+    from recalgorithm_amd import _lib
+    lib = _lib.load()
+    B, F, K = args.batch, args.fields, args.emb
+    d = F * K
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    store = est.store
+    ar = next(iter(store.arenas.values()))
+    names = sorted(feats.keys())
+    ids = torch.stack([feats[n] for n in names if isinstance(feats[n], torch.Tensor) and feats[n].dtype == torch.int64], 1).contiguous()
+    rb = torch.tensor([ar.tables[t][0] for t in list(ar.tables)[:F]], dtype=torch.int64, device=device)
+    x0 = torch.empty(B, d, device=device)
+    out = torch.empty(B, d, device=device)
+    g = torch.randn(B, d, device=device)
+    res = []
+
+    def add(name, fn, alg_bytes, flops=0.0):
+        ms = event_time_ms(fn)
+        t_min = max(alg_bytes / (HBM_PEAK_GBS * 1e9), flops / (FP32_PEAK_TFLOPS * 1e12))
+        res.append({"kernel": name, "avg_us": round(ms * 1e3, 3), "alg_bytes": int(alg_bytes),
+                    "achieved_GBs": round(alg_bytes / (ms * 1e-3) / 1e9, 1),
+                    "frac": round(t_min / (ms * 1e-3), 4)})
+
+    add("gather_fwd", lambda: lib.recalgo_embedding_gather_fwd(p(ids), p(ar.weight), p(rb), B, F, K, p(x0), d, 0, st),
+        B * (F * 8 + 2 * d * 4))
+    add("gather_bwd", lambda: lib.recalgo_embedding_gather_bwd(p(ids), p(g), p(rb), B, F, K, d, 0, p(ar.grad), st),
+        B * (F * 8 + 2 * d * 4))
+    ar.grad.zero_()
+    if args.model == "dcn":
+        L = 3
+        w = torch.randn(L, d, device=device) * 0.05
+        b = torch.randn(L, d, device=device) * 0.05
+        dw, db, dx0 = torch.empty_like(w), torch.empty_like(b), torch.empty_like(x0)
+        ws = torch.empty(lib.recalgo_cross_bwd_workspace_bytes(B, d, L), dtype=torch.uint8, device=device)
+        add("cross_fwd", lambda: lib.recalgo_cross_fwd(p(x0), d, p(w), p(b), B, d, L, p(out), d, st), B * 2 * d * 4)
+        add("cross_bwd", lambda: lib.recalgo_cross_bwd(p(x0), d, p(w), p(b), p(g), d, None, B, d, L, p(dx0), p(dw), p(db), p(ws), st),
+            B * 3 * d * 4)
+    n = ar.weight.numel()
+    add("adam_tf1_dense(arena)", lambda: lib.recalgo_adam_tf1_dense(p(ar.weight), p(ar.grad), p(ar.m), p(ar.v), n, 0.0, None,
+                                                                     0.9, 0.999, 1e-8, 1, st), n * 4 * 7)
+    ar.m.zero_(); ar.v.zero_()
+    return res
+
+
+def cpu_baseline(args, seconds):
+    """The unfused op-for-op oracle (oracle/ref_ops.py, torch-CPU fp32, all host cores) doing the
+    same training step on a bounded sample of the workload."""
+    from oracle import cpu_baseline as cb
+    return cb.run(args.model, batch=args.batch, fields=args.fields, emb=args.emb, max_vocab=args.max_vocab,
+                  seconds=seconds)
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    est, spec, feats, labels, workload = build_estimator(args, device, rank, world)
+    if world > 1:
+        from recalgorithm_amd.parallel import attach_data_parallel
+        attach_data_parallel(est, dist)
+
+    from recalgorithm_amd.estimator import GraphedTrainStep
+    if args.no_graph:
+        step = lambda: est.train_step(feats, labels)
+        for _ in range(max(args.warmup, 1)):
+            loss = step()
+    else:
+        graphed = GraphedTrainStep(est.train_step, feats, labels, warmup=3)
+        step = graphed
+        for _ in range(max(args.warmup - 3, 0)):
+            step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss_v = float(loss)
+
+    # fwd+bwd only (optimizer excluded), reported next to the headline
+    out = {
+        "metric": "CTR examples/sec (train step fwd+bwd+TF1-Adam), batch 4096/GPU, 26 fields x emb16",
+        "value": round(world * args.batch * args.steps / dt, 1),
+        "unit": "examples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": workload, "global_batch": world * args.batch, "fields": args.fields,
+                   "emb_dim": args.emb, "embedding_rows": int(sum(spec.vocabs)),
+                   "optimizer": "TF1 Adam, dense over all tables (reference semantics)",
+                   "launch": "eager" if args.no_graph else "hipGraph replay",
+                   "parallelism": f"dp{world}" if world > 1 else "single"},
+        "final_loss": round(loss_v, 6),
+    }
+    if rank == 0:
+        if not args.no_kernel_timing:
+            ks = kernel_rooflines(args, est, feats, device)
+            hot = [k for k in ks if not k["kernel"].startswith("adam")]
+            dom = max(hot, key=lambda k: k["avg_us"])
+            out["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"],
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": None,
+                               "avg_us": dom["avg_us"], "alg_bytes_per_launch": dom["alg_bytes"]}
+            out["kernels"] = ks
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -93,31 +93,36 @@ int recalgo_sequence_gather_bwd(const int64_t* values, const int64_t* offsets, c
  *   emb[b, f*K:+K] = row(b,f)                                  (== deep_input, bit-exact)
  *   fm1[b] = bias[0] + sum_f (ids[b,f]>=0 ? w1[row_base[f]+ids[b,f]] : 0)
  *   fm2[b] = 0.5 * sum_k ( (sum_f e_fk)^2 - sum_f e_fk^2 )
+ *   field_sum[b, :] = sum_f e_f   ([B, K]; saved for the backward)
  *   w1 [rows] fp32 (the (sum V,1) dense kernel of `fm_first_order_dense`), bias [1].
  * K % 4 == 0, K <= 64.
  * ------------------------------------------------------------------------------------------ */
 int recalgo_deepfm_sparse_fwd(const int64_t* ids, const float* arena, const float* w1,
                               const float* bias, const int64_t* row_base, int B, int F, int K,
-                              float* emb, float* fm1, float* fm2, recalgo_stream_t stream);
+                              float* emb, float* fm1, float* fm2, float* field_sum,
+                              recalgo_stream_t stream);
 /* Backward:
  *   row grad (b,f) = g_emb[b,f,:] + g_fm2[b] * (S_b - e_bf)   -> += grad_arena[row]
  *   grad_w1[row]  += g_fm1[b]
- * `emb` is the tensor saved by the forward.  d(bias) = sum_b g_fm1[b] is left to the caller. */
-int recalgo_deepfm_sparse_bwd(const int64_t* ids, const float* emb, const float* g_emb,
-                              const float* g_fm1, const float* g_fm2, const int64_t* row_base,
-                              int B, int F, int K, float* grad_arena, float* grad_w1,
-                              recalgo_stream_t stream);
+ * `emb`, `field_sum` are the tensors saved by the forward.  d(bias) = sum_b g_fm1[b] is left to
+ * the caller. */
+int recalgo_deepfm_sparse_bwd(const int64_t* ids, const float* emb, const float* field_sum,
+                              const float* g_emb, const float* g_fm1, const float* g_fm2,
+                              const int64_t* row_base, int B, int F, int K, float* grad_arena,
+                              float* grad_w1, recalgo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K4  DCN CrossNet, L layers fused.
  * Replaces cross_layer(x0, xl, index) algorithm/DCN/cross_layer.py:4-26 stacked by
  * algorithm/DCN/dcn.py:157-160:   x_{l+1} = x0 * (x_l . w_l) + b_l + x_l
  *   x0 [B, d] (row stride x_stride), w [L, d], b [L, d], out [B, d] (row stride out_stride).
- * d % 4 == 0, d <= 2048, 1 <= L <= 8.
+ * Evaluated through the stack's closed form  x_l = c_l*x0 + B_l,  c_{l+1} = c_l*(1 + x0.w_l) +
+ * B_l.w_l,  B_l = sum_{j<l} b_j  (identical math, one batched reduction per example).
+ * d % 4 == 0, d <= 1024, 1 <= L <= 6  (beyond: chain recalgo_cross_layer_fwd).
  * ------------------------------------------------------------------------------------------ */
 int recalgo_cross_fwd(const float* x0, int x_stride, const float* w, const float* b, int B, int d,
                       int L, float* out, int out_stride, recalgo_stream_t stream);
-/* Backward.  Recomputes x_1..x_{L-1} from x0 (nothing but x0 is saved by the forward).
+/* Backward.  Recomputes the per-example scalars from x0 (nothing but x0 is saved by the forward).
  *   g    [B, d] (row stride g_stride) upstream gradient of `out`
  *   g_x0_extra  optional [B, d] (row stride x_stride) added into dx0 (the DNN branch's dx0)
  *   dx0  [B, d] (row stride x_stride);  dw, db [L, d] (overwritten, deterministic two-pass)

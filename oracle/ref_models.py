@@ -1,0 +1,117 @@
+"""oracle/ref_models.py — TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Model-level restatement of the six reference model_fns (forward to logits / loss), composed
+from oracle/ref_ops.py, op-for-op in the reference's order.  Parameters come in as a dict
+`P` name -> tensor using the reference's TF variable names (scope/.../kernel etc.); gradients
+are obtained by torch.autograd on the returned loss.  Columns are duck-typed: objects with
+`.name`, `.key`, `.dimension` (embedding), `.shared_name` (shared tables).
+
+Feature batch format: feats[key] is a LongTensor [B] (single-valued, -1 = OOV), a tuple
+(values, offsets) (multi-valued), or a float tensor [B,1] (numeric).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence
+
+import torch
+
+from . import ref_ops as R
+
+
+def _sorted(cols):
+    return sorted(cols, key=lambda c: c.name)     # [TF-ext A-1] input_layer sorts by name
+
+
+def table_name(col, scope_layer: str) -> str:
+    owner = col.shared_name if getattr(col, "shared_name", None) else col.name
+    return f"{scope_layer}/{owner}/embedding_weights"
+
+
+def _lookup(P, feats, col, scope_layer, shared_registry):
+    if getattr(col, "shared_name", None):
+        # [TF-ext A-4] the shared table is created once, by the first layer that uses it
+        tn = shared_registry.setdefault(col.shared_name, table_name(col, scope_layer))
+    else:
+        tn = table_name(col, scope_layer)
+    table = P[tn]
+    ids = feats[col.key]
+    if isinstance(ids, tuple):
+        return R.embedding_lookup_mean(ids[0], ids[1], table)
+    return R.embedding_lookup_single(ids, table)
+
+
+def input_layer(P, feats, cols, scope_layer: str, shared_registry=None) -> torch.Tensor:
+    shared_registry = {} if shared_registry is None else shared_registry
+    parts = []
+    for c in _sorted(cols):
+        if hasattr(c, "dimension"):
+            parts.append(_lookup(P, feats, c, scope_layer, shared_registry))
+        else:                                      # numeric column
+            parts.append(feats[c.key].reshape(feats[c.key].shape[0], -1))
+    return torch.cat(parts, dim=1)
+
+
+def _mlp(P, x, scope, names, relu=True):
+    for n in names:
+        x = R.dense(x, P[f"{scope}/{n}/kernel"], P.get(f"{scope}/{n}/bias"), relu=relu)
+    return x
+
+
+def _tail(logit, labels, extra=None):
+    out = {"logit": logit, "prob": torch.sigmoid(logit)}
+    if labels is not None:
+        loss = R.ce_loss(labels, logit)
+        if extra is not None:
+            loss = loss + extra
+        out["loss"] = loss
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+def dcn(P, feats, labels, params, training=False):
+    """algorithm/DCN/dcn.py:134-191."""
+    dense_cols = params.get("dense_feature_columns") or []
+    reg = {}
+    cat = input_layer(P, feats, params["category_feature_columns"], "category_input/input_layer", reg)
+    if dense_cols:
+        dense_in = input_layer(P, feats, dense_cols, "dense_input/input_layer")
+        concat_all = torch.cat([dense_in, cat], dim=-1)                           # :155
+    else:
+        concat_all = cat
+    L = int(params["num_cross_layer"])
+    cross = R.cross_stack(concat_all, [P[f"cross_part/wl_{i}"] for i in range(L)],
+                          [P[f"cross_part/bl_{i}"] for i in range(L)])            # :157-160
+    dnn = _mlp(P, concat_all, "dnn_part", [f"dnn_dense_{i}" for i in range(len(params["hidden_units"]))])
+    output = torch.cat([cross, dnn], dim=-1)                                      # :168
+    logit = R.dense(output, P["output_part/dense/kernel"], P["output_part/dense/bias"])
+    return _tail(logit, None if labels is None else labels["read_comment"])
+
+
+def deepfm(P, feats, labels, params, training=False, bn_state=None):
+    """algorithm/DeepFM/deepfm.py:165-235.  Dropout is the identity here (rate 0 / eval);
+    batch norm uses batch statistics when `training`."""
+    first_cols = _sorted(params["first_order_feature_columns"])
+    # fm_first_order: (B, sum V) multi-hot @ kernel + bias == sum of per-column weight lookups
+    w1 = [P[f"fm_first_order/fm_first_order_dense/kernel/{c.key}"] for c in first_cols]
+    fm1 = R.indicator_first_order([feats[c.key] for c in first_cols], w1,
+                                  P["fm_first_order/fm_first_order_dense/bias"][0])
+    fields = []
+    for i, c in enumerate(params["second_order_feature_columns"]):                 # :187-190 list order
+        layer = "input_layer" if i == 0 else f"input_layer_{i}"
+        fields.append(_lookup(P, feats, c, layer, {}))
+    fm2 = R.fm_second_order(fields)                                                # :192-200
+    net = torch.cat(fields, dim=1)                                                 # :204
+    for i, _ in enumerate(params["hidden_units"]):
+        dn = "dense" if i == 0 else f"dense_{i}"
+        net = R.dense(net, P[f"fm_deep/{dn}/kernel"], P[f"fm_deep/{dn}/bias"], relu=True)
+        if params.get("batch_norm"):
+            bn = "batch_normalization" if i == 0 else f"batch_normalization_{i}"
+            net = R.batch_norm(net, P[f"fm_deep/{bn}/gamma"], P[f"fm_deep/{bn}/beta"],
+                               P[f"fm_deep/{bn}/moving_mean"], P[f"fm_deep/{bn}/moving_variance"], training)
+    n = len(params["hidden_units"])
+    dn = "dense" if n == 0 else f"dense_{n}"
+    deep = R.dense(net, P[f"fm_deep/{dn}/kernel"], P[f"fm_deep/{dn}/bias"])
+    logit = fm1 + fm2 + deep                                                       # :214
+    out = _tail(logit, None if labels is None else labels["read_comment"])
+    out.update(fm_first_order_logit=fm1, fm_second_order_logit=fm2, deep_logit=deep)
+    return out

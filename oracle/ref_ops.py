@@ -95,6 +95,7 @@ def indicator_first_order(ids_per_col: Sequence[Tensor], w_per_col: Sequence[Ten
     B = ids_per_col[0].shape[0]
     acc = torch.zeros(B, dtype=w_per_col[0].dtype)
     for ids, w in zip(ids_per_col, w_per_col):
+        w = w.reshape(-1)               # the column's slice of the (sum V, 1) kernel
         ok = ids >= 0
         acc = acc + torch.where(ok, w[ids.clamp(min=0)], torch.zeros_like(acc))
     return (acc + bias).unsqueeze(-1)

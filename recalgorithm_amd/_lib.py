@@ -24,8 +24,8 @@ SIGNATURES = {
     "recalgo_embedding_bag_mean_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "recalgo_sequence_gather_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P]),
     "recalgo_sequence_gather_bwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
-    "recalgo_deepfm_sparse_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, P, P, P]),
-    "recalgo_deepfm_sparse_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P, P, P]),
+    "recalgo_deepfm_sparse_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P]),
+    "recalgo_deepfm_sparse_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, P, P, P]),
     "recalgo_cross_fwd": (c_int, [P, c_int, P, P, c_int, c_int, c_int, P, c_int, P]),
     "recalgo_cross_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "recalgo_cross_bwd": (c_int, [P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, P, P, P, P, P]),

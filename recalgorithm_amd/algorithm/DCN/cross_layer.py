@@ -1,0 +1,49 @@
+"""DCN cross layer on MI355X — drop-in for the reference's `cross_layer(x0, xl, index)`
+(/root/reference algorithm/DCN/cross_layer.py:4-26).
+
+Same name, argument meaning and variable names (`wl_{index}`, `bl_{index}`, shape (d, 1),
+default glorot-uniform initialiser for BOTH — SURVEY.md A-7); the arithmetic
+    out = x0 * (xl @ wl) + bl^T + xl
+runs in the hand-written HIP kernel `recalgo_cross_layer_fwd/bwd` (include/recalgo.h).
+`cross_network` is the fused form used by dcn_model_fn: all L layers in one kernel launch,
+with wl_i / bl_i allocated as rows of one [L, d] block (names unchanged).
+"""
+from __future__ import annotations
+
+import torch
+
+from ... import ops
+from ...variables import current_store
+
+
+def cross_layer(x0: torch.Tensor, xl: torch.Tensor, index: int) -> torch.Tensor:
+    """
+    Args:
+        x0: original cross-network input, (batch, d)
+        xl: previous cross layer output, (batch, d)
+        index: layer number (names the variables)
+    Returns:
+        (batch, d)
+    """
+    store = current_store()
+    d = int(x0.shape[-1])
+    wl = store.get_variable(f"wl_{index}", (d, 1))
+    bl = store.get_variable(f"bl_{index}", (d, 1))
+    return ops.cross_layer(store, x0.contiguous(), xl.contiguous(), wl, bl)
+
+
+def cross_network(x0: torch.Tensor, num_cross_layer: int) -> torch.Tensor:
+    """x_{l+1} = cross_layer(x0, x_l, l) for l = 0..L-1 (dcn.py:157-160), fused."""
+    store = current_store()
+    d = int(x0.shape[-1])
+    L = int(num_cross_layer)
+    if L == 0:
+        return x0
+    w, _ = store.get_variable_block("wl", [f"wl_{i}" for i in range(L)], (d, 1))
+    b, _ = store.get_variable_block("bl", [f"bl_{i}" for i in range(L)], (d, 1))
+    if L > 6 or d > 1024:        # outside the fused kernel's envelope: layer by layer
+        xl = x0
+        for i in range(L):
+            xl = cross_layer(x0, xl, i)
+        return xl
+    return ops.cross_stack(store, x0.contiguous(), w, b)

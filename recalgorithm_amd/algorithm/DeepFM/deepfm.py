@@ -1,0 +1,172 @@
+"""DeepFM entry point — MI355X drop-in for /root/reference algorithm/DeepFM/deepfm.py: same
+flags, `create_feature_columns`, `example_parser`, `deepfm_model_fn(features, labels, mode,
+params)`, `main`, same prediction keys (`probabilities`, `fm_first_order_logit`,
+`fm_second_order_logit`, `deep_logit`).
+
+The whole sparse side of the model — the per-field embedding lookup, the FM first-order term
+(indicator -> dense(1), deepfm.py:179-181), the FM second-order sum-square term (:184-200) and
+the concat that feeds the MLP (:204) — is ONE hand-written HIP kernel
+(`recalgo_deepfm_sparse_fwd/bwd`).  The `fm_first_order_dense` kernel of shape (sum V, 1) is
+stored as a width-1 arena whose rows mirror the embedding arena, so a single id gathers both.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Tuple
+
+import torch
+
+from ... import feature_column as fc
+from ... import flags, nn, ops
+from ...estimator import Estimator, EvalSpec, ModeKeys, RunConfig, TrainSpec, train_and_evaluate
+from ...model_tail import finish_model_fn
+from ...variables import EmbeddingArena, current_store, variable_scope, zeros
+from ..utils import eval_input_fn, parse_example, train_input_fn
+
+# flags: /root/reference algorithm/DeepFM/deepfm.py:14-41
+flags.DEFINE_string("model_dir", "./model_dir", "Directory where model parameters, graph, etc are saved")
+flags.DEFINE_string("output_dir", "./output_dir", "Directory where pb file are saved")
+flags.DEFINE_string("train_data", "../../dataset/wechat_algo_data1/tfrecord/train.tfrecord", "Path to the train data")
+flags.DEFINE_string("eval_data", "../../dataset/wechat_algo_data1/tfrecord/test.tfrecord", "Path to the evaluation data")
+flags.DEFINE_string("vocabulary_dir", "../../dataset/wechat_algo_data1/vocabulary/", "Folder where the vocabulary file is stored")
+flags.DEFINE_integer("num_epochs", 1, "Epoch of training phase")
+flags.DEFINE_integer("train_steps", 10000, "Number of (global) training steps to perform")
+flags.DEFINE_integer("shuffle_buffer_size", 10000, "Dataset shuffle buffer size")
+flags.DEFINE_integer("num_parallel_readers", -1, "Number of parallel readers for training data")
+flags.DEFINE_integer("save_checkpoints_steps", 1000, "Save checkpoints every this many steps")
+flags.DEFINE_integer("batch_size", 1024, "Training batch size")
+flags.DEFINE_float("learning_rate", 0.005, "Learning rate")
+flags.DEFINE_integer("embedding_dim", 8, "Embedding dimension")
+flags.DEFINE_string("hidden_units", "512,256,128", "Comma-separated list of number of units in each hidden layer")
+flags.DEFINE_boolean("batch_norm", True, "Perform batch normalization (True or False)")
+flags.DEFINE_float("dropout_rate", 0.1, "Dropout rate")
+FLAGS = flags.FLAGS
+
+CATEGORICAL = ["userid", "feedid", "device", "authorid", "bgm_song_id", "bgm_singer_id"]
+
+
+def create_feature_columns() -> Tuple[list, list, list]:
+    """-> (first_order_feature_columns, second_order_feature_columns, label_feature_columns)."""
+    cats = [fc.categorical_column_with_vocabulary_file(k, os.path.join(FLAGS.vocabulary_dir, k + ".txt"))
+            for k in CATEGORICAL]
+    first = [fc.indicator_column(c) for c in cats]
+    second = [fc.embedding_column(c, FLAGS.embedding_dim) for c in cats]
+    label = [fc.numeric_column("read_comment", default_value=0.0)]
+    return first, second, label
+
+
+total_feature_columns: list = []
+label_feature_columns: list = []
+
+
+def example_parser(serialized_example):
+    spec = fc.make_parse_example_spec(total_feature_columns + label_feature_columns)
+    features = parse_example(serialized_example, spec)
+    read_comment = features.pop("read_comment")
+    return features, {"read_comment": read_comment}
+
+
+def _sparse_part(features, params):
+    """gather + FM1 + FM2 + deep_input through the fused kernel."""
+    store = current_store()
+    first, second = params["first_order_feature_columns"], params["second_order_feature_columns"]
+    keys = [c.key for c in second]
+    K = second[0].dimension
+    if sorted(c.key for c in first) != sorted(keys) or any(c.dimension != K for c in second) or K % 4 or K > 64:
+        raise NotImplementedError(
+            "deepfm_model_fn: the fused sparse kernel needs the first- and second-order columns to "
+            "cover the same categorical keys with one embedding width (multiple of 4, <= 64)")
+    # second-order tables: one fc.input_layer call per column at top level (deepfm.py:187-190)
+    tables = []
+    for i, c in enumerate(second):
+        layer = store.auto_name("input_layer")
+        tables.append(fc._table_for(store, c, store.full_name(layer)))
+    arena = tables[0][0]
+    # first-order (sum V, 1) kernel as a width-1 arena with the same row layout
+    w1 = store.arenas.get("fm_first_order_w1")
+    if w1 is None:
+        w1 = store.arenas["fm_first_order_w1"] = EmbeddingArena("fm_first_order_w1", 1, store.device,
+                                                                 seed=store.seed + 77)
+    if w1.weight is None:
+        total_v = sum(c.categorical_column.num_buckets for c in second)
+        limit = math.sqrt(6.0 / (total_v + 1))              # glorot-uniform of the (sum V, 1) kernel
+        for c in second:
+            v = c.categorical_column.num_buckets
+            init = (torch.rand(v, 1, generator=w1._gen) * 2 - 1) * limit
+            w1.add_table(f"fm_first_order/fm_first_order_dense/kernel/{c.key}", v, init)
+    with variable_scope("fm_first_order"):
+        with variable_scope("fm_first_order_dense"):
+            bias = store.get_variable("bias", (1,), zeros)
+    B = fc._batch_size(features, second[0])
+    if store.building:
+        z = torch.zeros(B, 1, device=store.device)
+        return torch.zeros(B, len(second) * K, device=store.device), z, z
+    if [n for n in w1.tables] != [f"fm_first_order/fm_first_order_dense/kernel/{k}" for k in keys] or \
+            [w1.tables[n][0] for n in w1.tables] != [arena.tables[t][0] for _, t in tables]:
+        raise RuntimeError("first-order arena rows do not mirror the embedding arena")
+    ids = [c.categorical_column.ids(features, store.device) for c in second]
+    if not all(isinstance(i, torch.Tensor) for i in ids):
+        raise NotImplementedError("deepfm_model_fn: multi-valued fields are not part of DeepFM")
+    rb = store.row_base_tensor(arena, [t for _, t in tables])
+    return ops.deepfm_sparse(store, fc._as_matrix(ids), arena, w1, bias, rb)
+
+
+def deepfm_model_fn(features, labels, mode, params):
+    """deepfm.py:165-273."""
+    deep_input, fm_first_order_logit, fm_second_order_logit = _sparse_part(features, params)
+    training = mode == ModeKeys.TRAIN
+    with variable_scope("fm_deep"):
+        net = deep_input
+        for unit in params["hidden_units"]:
+            net = nn.dense(net, unit, activation="relu")
+            if "dropout_rate" in params and 0.0 < params["dropout_rate"] < 1.0:
+                net = nn.dropout(net, params["dropout_rate"], training=training)
+            if params["batch_norm"]:
+                net = nn.batch_normalization(net, training=training)
+        deep_logit = nn.dense(net, 1)
+    total_logit = fm_first_order_logit + fm_second_order_logit + deep_logit
+    return finish_model_fn(
+        mode, total_logit, labels, params,
+        predictions=lambda prob: {"probabilities": prob, "fm_first_order_logit": fm_first_order_logit,
+                                  "fm_second_order_logit": fm_second_order_logit, "deep_logit": deep_logit})
+
+
+def main(unused_argv):
+    global total_feature_columns, label_feature_columns
+    first, second, label_feature_columns = create_feature_columns()
+    total_feature_columns = first + second
+    params = {
+        "first_order_feature_columns": first,
+        "second_order_feature_columns": second,
+        "hidden_units": FLAGS.hidden_units.split(","),
+        "dropout_rate": FLAGS.dropout_rate,
+        "batch_norm": FLAGS.batch_norm,
+        "learning_rate": FLAGS.learning_rate,
+    }
+    print(params)
+    print(FLAGS.embedding_dim, FLAGS.num_epochs)
+    estimator = Estimator(model_fn=deepfm_model_fn, params=params,
+                          config=RunConfig(model_dir=FLAGS.model_dir,
+                                           save_checkpoints_steps=FLAGS.save_checkpoints_steps))
+    train_spec = TrainSpec(
+        input_fn=lambda: train_input_fn(filepath=FLAGS.train_data, example_parser=example_parser,
+                                        batch_size=FLAGS.batch_size, num_epochs=FLAGS.num_epochs,
+                                        shuffle_buffer_size=FLAGS.shuffle_buffer_size),
+        max_steps=FLAGS.train_steps)
+    eval_spec = EvalSpec(
+        input_fn=lambda: eval_input_fn(filepath=FLAGS.eval_data, example_parser=example_parser,
+                                       batch_size=FLAGS.batch_size),
+        throttle_secs=600, steps=None)
+    train_and_evaluate(estimator, train_spec, eval_spec)
+    metrics = estimator.evaluate(input_fn=lambda: eval_input_fn(
+        filepath=FLAGS.eval_data, example_parser=example_parser, batch_size=FLAGS.batch_size))
+    for key in sorted(metrics):
+        print("%s: %s" % (key, metrics[key]))
+    from ..DCN.dcn import write_predictions
+    write_predictions(estimator, example_parser)
+    print("after evaluate")
+
+
+if __name__ == "__main__":
+    flags.run(main)

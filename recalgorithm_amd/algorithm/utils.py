@@ -1,0 +1,100 @@
+"""Shared helpers of the model scripts — drop-in for /root/reference algorithm/utils.py:
+`train_input_fn`, `eval_input_fn` (same signatures, :4-46), `to_sparse_tensor` (:49-64),
+`index_from_upper_triangular` (:67-82), plus `parse_example` (tf.parse_example stand-in).
+
+The input functions return a re-iterable of (features, labels) host batches; the last partial
+batch is kept (no drop_remainder), like the reference's `dataset.batch(batch_size)`.
+"""
+from __future__ import annotations
+
+import random
+from typing import Callable, Dict, Iterator, List
+
+import numpy as np
+import torch
+
+from ..io import tfrecord
+
+
+def parse_example(serialized: List[bytes], spec: Dict[str, tuple]) -> Dict[str, object]:
+    """tf.parse_example(serialized, features=make_parse_example_spec(columns)).
+    FixedLen float features -> float32 tensor (B, *shape) with default_value when absent;
+    VarLen features -> list (len B) of lists of raw values (bytes / int)."""
+    decoded = [tfrecord.decode_example(s) for s in serialized]
+    out: Dict[str, object] = {}
+    for key, sp in spec.items():
+        if sp[0] == "fixed":
+            _, dtype, shape, default = sp
+            n = int(np.prod(shape))
+            arr = np.empty((len(decoded), n), dtype=np.float32)
+            for i, ex in enumerate(decoded):
+                v = ex.get(key)
+                if v is None or len(v) == 0:
+                    if default is None:
+                        raise ValueError(f"feature {key} is required but missing")
+                    arr[i] = default
+                else:
+                    arr[i] = v[:n]
+            out[key] = torch.from_numpy(arr.reshape((len(decoded),) + tuple(shape)))
+        else:
+            out[key] = [ex.get(key, []) for ex in decoded]
+    return out
+
+
+class _Dataset:
+    """TFRecordDataset(filepath)[.shuffle(buf)].repeat(epochs).batch(bs).map(parser)."""
+
+    def __init__(self, filepath, example_parser, batch_size, num_epochs, shuffle_buffer_size, seed=0):
+        self.filepath, self.parser, self.bs = filepath, example_parser, int(batch_size)
+        self.epochs, self.buf, self.seed = num_epochs, int(shuffle_buffer_size or 0), seed
+
+    def _records(self) -> Iterator[bytes]:
+        paths = [self.filepath] if isinstance(self.filepath, str) else list(self.filepath)
+        rng = random.Random(self.seed)
+        ep = 0
+        while self.epochs is None or ep < self.epochs:
+            ep += 1
+            src = (r for p in paths for r in tfrecord.read_records(p))
+            if self.buf > 0:       # tf.data shuffle-buffer semantics
+                buf: List[bytes] = []
+                for r in src:
+                    if len(buf) < self.buf:
+                        buf.append(r)
+                        continue
+                    j = rng.randrange(len(buf))
+                    yield buf[j]
+                    buf[j] = r
+                rng.shuffle(buf)
+                yield from buf
+            else:
+                yield from src
+
+    def __iter__(self):
+        batch: List[bytes] = []
+        for r in self._records():
+            batch.append(r)
+            if len(batch) == self.bs:
+                yield self.parser(batch)
+                batch = []
+        if batch:
+            yield self.parser(batch)
+
+
+def train_input_fn(filepath, example_parser: Callable, batch_size, num_epochs, shuffle_buffer_size):
+    return _Dataset(filepath, example_parser, batch_size, num_epochs, shuffle_buffer_size)
+
+
+def eval_input_fn(filepath, example_parser: Callable, batch_size):
+    return _Dataset(filepath, example_parser, batch_size, 1, 0)
+
+
+def to_sparse_tensor(one_hot_tensor: torch.Tensor):
+    """one-hot / multi-hot (B, V) -> (indices (nnz, 2), values (nnz,), dense_shape); values are
+    the column indices, as the reference builds for safe_embedding_lookup_sparse."""
+    idx = torch.nonzero(one_hot_tensor != 0)
+    return idx, idx[:, 1], tuple(one_hot_tensor.shape)
+
+
+def index_from_upper_triangular(i: int, j: int, n: int) -> int:
+    """Flattened index of entry (i, j), i < j, of an n x n strict upper triangle."""
+    return i * (2 * n - i - 1) // 2 + (j - i - 1)

@@ -1,319 +1,574 @@
-// K4: DCN CrossNet, all L layers fused (algorithm/DCN/cross_layer.py:4-26, dcn.py:157-160).
+// K4: DCN CrossNet (algorithm/DCN/cross_layer.py:4-26 stacked by dcn.py:157-160), gfx950.
 //
-// HBM-bound: per example the forward moves x0 in and x_L out (2*d*4 B), the backward x0 and g
-// in and dx0 out (3*d*4 B); w, b (2*L*d floats) stay in L1/L2.  One wave owns one example:
-// its d floats sit in registers as NV float4 per lane (lane j holds float4 j, j+64, ...), the
-// per-layer scalar x_l.w_l is a 64-lane shuffle reduction.
+//   x_{l+1} = x0 * (x_l . w_l) + b_l + x_l ,   x_0 = x0                      (reference form)
+//
+// Because x_l . w_l is a scalar, the stack has a closed form that the fused kernels use:
+//   x_l = c_l * x0 + B_l ,  B_l = sum_{j<l} b_j ,  c_0 = 1
+//   p_l = x0 . w_l  (per example)      beta_l = B_l . w_l  (batch constant)
+//   s_l = c_l * p_l + beta_l ,  c_{l+1} = c_l + s_l          =>  out = c_L * x0 + B_L
+// All L dot products are independent, so a wave needs ONE batched shuffle reduction per example
+// instead of L dependent ones, and the batch reductions of the backward collapse to
+//   A_l = sum_b dp_l[b] * x0[b,:]   (L vectors),   G = sum_b g[b,:],   T_l = sum_b dbeta_l[b]
+//   dw_l = A_l + T_l * B_l ,   db_j = G + sum_{l>j} T_l * w_l .
+// Same math as the reference, different fp32 evaluation order (parity: 1e-5 rel vs fp64 oracle).
+//
+// HBM-bound: forward x0 in / out out (2*d*4 B per example), backward x0, g in / dx0 out
+// (3*d*4 B); w, b stay in L1/L2.  One wave owns one example: its d floats are NV float4 per lane.
+//
+// The single-layer entry points (reference signature cross_layer(x0, xl, index) with an
+// arbitrary xl) use the direct form.
 #include "common.h"
 
 namespace {
 
-template <int NV>
-__global__ __launch_bounds__(256) void cross_fwd_kernel(
-    const float* __restrict__ x0, const float* __restrict__ xl_in, unsigned x_stride,
-    const float4* __restrict__ w,
-    const float4* __restrict__ b, unsigned B, unsigned d4, unsigned L, float* __restrict__ out,
+constexpr int kFwdThreads = 256;
+constexpr int kBwdThreads = 512;               // 8 waves: <= 256 VGPRs each, no spills
+constexpr int kBwdWaves = kBwdThreads / 64;
+constexpr int kMaxPartialRows = 512;
+
+// batched 64-lane butterfly: reduces N independent values with N shuffles in flight per stage
+template <int N>
+__device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float t[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) t[i] = __shfl_xor(v[i], o, 64);
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] += t[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused stack, forward
+// ---------------------------------------------------------------------------------------------
+template <int NV, int L>
+__global__ __launch_bounds__(kFwdThreads) void cross_stack_fwd_kernel(
+    const float* __restrict__ x0, unsigned x_stride, const float4* __restrict__ w,
+    const float4* __restrict__ b, unsigned B, unsigned d4, float* __restrict__ out,
     unsigned out_stride) {
     const unsigned lane = threadIdx.x & 63;
-    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (unsigned ex = wave; ex < B; ex += nwaves) {
-        const float4* xr = reinterpret_cast<const float4*>(x0 + (size_t)ex * x_stride);
-        float4 x0v[NV], xl[NV];
+    const unsigned wave = (blockIdx.x * kFwdThreads + threadIdx.x) >> 6;
+    const unsigned nwaves = (gridDim.x * kFwdThreads) >> 6;
+
+    // lane-local slices of w_l and of the prefix sums B_l; beta_l partials are batch constants
+    float4 wv[L][NV], Bv[NV];
+    float red[2 * L];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) Bv[v] = f4_zero();
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        float acc = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             unsigned idx = lane + v * 64;
-            x0v[v] = idx < d4 ? xr[idx] : f4_zero();
-            xl[v] = x0v[v];
-            if (xl_in && idx < d4)
-                xl[v] = reinterpret_cast<const float4*>(xl_in + (size_t)ex * x_stride)[idx];
+            wv[l][v] = idx < d4 ? w[l * d4 + idx] : f4_zero();
+            acc += f4_dot(Bv[v], wv[l][v]);
+            if (idx < d4) Bv[v] = f4_add(Bv[v], b[l * d4 + idx]);
         }
-        for (unsigned l = 0; l < L; ++l) {
-            float s = 0.f;
+        red[L + l] = acc;                      // partial of beta_l = B_l . w_l
+    }
+
+    for (unsigned ex = wave; ex < B; ex += nwaves) {
+        const float4* xr = reinterpret_cast<const float4*>(x0 + (size_t)ex * x_stride);
+        float4 xv[NV];
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                unsigned idx = lane + v * 64;
-                if (idx < d4) s += f4_dot(xl[v], w[l * d4 + idx]);
-            }
-            s = wave_sum(s);
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                unsigned idx = lane + v * 64;
-                if (idx < d4) {
-                    float4 bb = b[l * d4 + idx];
-                    // reference order: (x0 * s + b) + xl      cross_layer.py:22-24
-                    xl[v] = f4_add(f4_fma(x0v[v], s, bb), xl[v]);
-                }
-            }
+        for (int v = 0; v < NV; ++v) {
+            unsigned idx = lane + v * 64;
+            xv[v] = idx < d4 ? xr[idx] : f4_zero();
         }
+        float r[2 * L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            float acc = 0.f;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc += f4_dot(xv[v], wv[l][v]);
+            r[l] = acc;
+            r[L + l] = red[L + l];
+        }
+        wave_sum_n<2 * L>(r);
+        float c = 1.f;
+#pragma unroll
+        for (int l = 0; l < L; ++l) c += fmaf(c, r[l], r[L + l]);   // c_{l+1} = c_l + (c_l p_l + beta_l)
         float4* orow = reinterpret_cast<float4*>(out + (size_t)ex * out_stride);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             unsigned idx = lane + v * 64;
-            if (idx < d4) orow[idx] = xl[v];
+            if (idx < d4) orow[idx] = f4_fma(xv[v], c, Bv[v]);
         }
     }
 }
 
-// Backward.  Template on L so that the recomputed x_l and the dw/db accumulators are register
-// arrays with static indices.  A 1024-thread workgroup (16 waves) keeps the number of
-// per-workgroup dw/db partials small; they are reduced across workgroups by a second,
-// deterministic kernel.
-constexpr int kBwdThreads = 1024;
-constexpr int kBwdWaves = kBwdThreads / 64;
-
+// ---------------------------------------------------------------------------------------------
+// fused stack, backward.  Per-wave register accumulators (A_l, G, T_l) -> fixed-order LDS
+// reduction per workgroup -> partial row in global -> cross_stack_finalize_kernel.
+// partial row layout: [A_0 .. A_{L-1} | G | T_0 .. T_{L-1}]   ((L+1)*d + L floats)
+// ---------------------------------------------------------------------------------------------
 template <int NV, int L>
-__global__ __launch_bounds__(kBwdThreads) void cross_bwd_kernel(
-    const float* __restrict__ x0, const float* __restrict__ xl_in, unsigned x_stride,
-    const float4* __restrict__ w,
+__global__ __launch_bounds__(kBwdThreads) void cross_stack_bwd_kernel(
+    const float* __restrict__ x0, unsigned x_stride, const float4* __restrict__ w,
     const float4* __restrict__ b, const float* __restrict__ g, unsigned g_stride,
     const float* __restrict__ g_x0_extra, unsigned B, unsigned d4, float* __restrict__ dx0,
-    float* __restrict__ dxl /* only with xl_in */,
-    float* __restrict__ partials /* [gridDim.x][2][L][d] */) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [kBwdWaves][d]
+    float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [kBwdWaves][d] (+ [kBwdWaves][L])
     const unsigned lane = threadIdx.x & 63;
     const unsigned wib = threadIdx.x >> 6;
     const unsigned wave = blockIdx.x * kBwdWaves + wib;
     const unsigned nwaves = gridDim.x * kBwdWaves;
     const unsigned d = d4 * 4;
 
-    float4 dwacc[L][NV], dbacc[L][NV];
+    float4 wv[L][NV];
+    float beta_part[L];
+    {
+        float4 Bv[NV];
 #pragma unroll
-    for (int l = 0; l < L; ++l)
+        for (int v = 0; v < NV; ++v) Bv[v] = f4_zero();
 #pragma unroll
-        for (int v = 0; v < NV; ++v) dwacc[l][v] = dbacc[l][v] = f4_zero();
+        for (int l = 0; l < L; ++l) {
+            float acc = 0.f;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                unsigned idx = lane + v * 64;
+                wv[l][v] = idx < d4 ? w[l * d4 + idx] : f4_zero();
+                acc += f4_dot(Bv[v], wv[l][v]);
+                if (idx < d4) Bv[v] = f4_add(Bv[v], b[l * d4 + idx]);
+            }
+            beta_part[l] = acc;
+        }
+    }
+    float4 A[L][NV], G[NV];
+    float T[L];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) G[v] = f4_zero();
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        T[l] = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) A[l][v] = f4_zero();
+    }
 
     for (unsigned ex = wave; ex < B; ex += nwaves) {
         const float4* xr = reinterpret_cast<const float4*>(x0 + (size_t)ex * x_stride);
         const float4* gr = reinterpret_cast<const float4*>(g + (size_t)ex * g_stride);
-        float4 x0v[NV], gv[NV], xs[L][NV];
-        float s[L];
+        float4 xv[NV], gv[NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             unsigned idx = lane + v * 64;
-            x0v[v] = idx < d4 ? xr[idx] : f4_zero();
+            xv[v] = idx < d4 ? xr[idx] : f4_zero();
             gv[v] = idx < d4 ? gr[idx] : f4_zero();
-            xs[0][v] = x0v[v];
-            if (xl_in)
-                xs[0][v] = idx < d4 ? reinterpret_cast<const float4*>(xl_in + (size_t)ex * x_stride)[idx]
-                                    : f4_zero();
         }
-        // recompute the forward: xs[l] = x_l, s[l] = x_l . w_l
+        float r[2 * L + 1];
+        {
+            float q = 0.f;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) q += f4_dot(gv[v], xv[v]);
+            r[2 * L] = q;                                   // dc_L = g . x0
+        }
 #pragma unroll
         for (int l = 0; l < L; ++l) {
-            float t = 0.f;
+            float acc = 0.f;
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                unsigned idx = lane + v * 64;
-                if (idx < d4) t += f4_dot(xs[l][v], w[l * d4 + idx]);
-            }
-            s[l] = wave_sum(t);
-            if (l + 1 < L) {
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    unsigned idx = lane + v * 64;
-                    xs[l + 1][v] = idx < d4
-                                       ? f4_add(f4_fma(x0v[v], s[l], b[l * d4 + idx]), xs[l][v])
-                                       : f4_zero();
-                }
-            }
+            for (int v = 0; v < NV; ++v) acc += f4_dot(xv[v], wv[l][v]);
+            r[l] = acc;
+            r[L + l] = beta_part[l];
         }
-        // reverse sweep (Cross)
-        float4 dx0acc[NV];
+        wave_sum_n<2 * L + 1>(r);
+        float c[L + 1];
+        c[0] = 1.f;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) dx0acc[v] = f4_zero();
+        for (int l = 0; l < L; ++l) c[l + 1] = c[l] + fmaf(c[l], r[l], r[L + l]);
+        // reverse scalar sweep
+        float dc = r[2 * L];
+        float dp[L];
 #pragma unroll
         for (int l = L - 1; l >= 0; --l) {
-            float t = 0.f;
-#pragma unroll
-            for (int v = 0; v < NV; ++v) t += f4_dot(gv[v], x0v[v]);
-            t = wave_sum(t);  // g . x0
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                unsigned idx = lane + v * 64;
-                dwacc[l][v] = f4_fma(xs[l][v], t, dwacc[l][v]);
-                dbacc[l][v] = f4_add(dbacc[l][v], gv[v]);
-                dx0acc[v] = f4_fma(gv[v], s[l], dx0acc[v]);
-                if (idx < d4) gv[v] = f4_fma(w[l * d4 + idx], t, gv[v]);
-            }
+            T[l] += dc;                       // dbeta_l = dc_{l+1}
+            dp[l] = dc * c[l];
+            dc = dc * (1.f + r[l]);
         }
         float4* orow = reinterpret_cast<float4*>(dx0 + (size_t)ex * x_stride);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             unsigned idx = lane + v * 64;
+            float4 o = f4_scale(gv[v], c[L]);
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                o = f4_fma(wv[l][v], dp[l], o);
+                A[l][v] = f4_fma(xv[v], dp[l], A[l][v]);
+            }
+            G[v] = f4_add(G[v], gv[v]);
             if (idx < d4) {
-                float4 r = dx0acc[v];
-                if (xl_in)
-                    reinterpret_cast<float4*>(dxl + (size_t)ex * x_stride)[idx] = gv[v];
-                else
-                    r = f4_add(r, gv[v]);
                 if (g_x0_extra)
-                    r = f4_add(r, reinterpret_cast<const float4*>(g_x0_extra + (size_t)ex * x_stride)[idx]);
-                orow[idx] = r;
+                    o = f4_add(o, reinterpret_cast<const float4*>(g_x0_extra + (size_t)ex * x_stride)[idx]);
+                orow[idx] = o;
             }
         }
     }
 
-    // workgroup reduction of dw, then db, through LDS in fixed wave order (deterministic)
-    // one [kBwdWaves][d] LDS tile per (pass, layer): 64 KiB at d = 1024
-    float* pblk = partials + (size_t)blockIdx.x * 2 * L * d;
+    // workgroup reduction in fixed wave order (deterministic)
+    const unsigned row_len = (L + 1) * d + ((L + 3) & ~3);   // padded: rows stay 16-byte aligned
+    float* prow = partials + (size_t)blockIdx.x * row_len;
+#pragma unroll
+    for (int vec = 0; vec <= L; ++vec) {
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            unsigned idx = lane + v * 64;
+            if (idx < d4) {
+                float4 val = G[v];
+#pragma unroll
+                for (int l = 0; l < L; ++l)
+                    if (vec == l) val = A[l][v];
+                *reinterpret_cast<float4*>(smem + (size_t)wib * d + idx * 4) = val;
+            }
+        }
+        __syncthreads();
+        for (unsigned j = threadIdx.x; j < d; j += kBwdThreads) {
+            float acc = 0.f;
+#pragma unroll
+            for (int wv_ = 0; wv_ < kBwdWaves; ++wv_) acc += smem[(size_t)wv_ * d + j];
+            prow[(size_t)vec * d + j] = acc;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) smem[wib * L + l] = T[l];   // T is wave-uniform
+    }
+    __syncthreads();
+    if (threadIdx.x < L) {
+        float acc = 0.f;
+        for (int wv_ = 0; wv_ < kBwdWaves; ++wv_) acc += smem[wv_ * L + threadIdx.x];
+        prow[(size_t)(L + 1) * d + threadIdx.x] = acc;
+    }
+}
+
+// sum the partial rows and apply  dw_l = A_l + T_l*B_l,  db_j = G + sum_{l>j} T_l*w_l.
+// grid (ceil(d/64), L+1): workgroup (cb, vec) sums vector `vec` (A_vec, or G when vec == L) over
+// the partial rows for 64 columns — 16 float4 column lanes x 16 row slices — and writes dw_vec
+// (vec < L) or every db_j (vec == L).  Each workgroup reduces the L scalars T_l itself.
+template <int L>
+__global__ __launch_bounds__(256) void cross_stack_finalize_kernel(
+    const float* __restrict__ partials, unsigned nrows, unsigned d, const float* __restrict__ w,
+    const float* __restrict__ b, float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ float4 sh[16][16];
+    __shared__ float shT[L][4];
+    const unsigned cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const unsigned col4 = blockIdx.x * 16 + cl;          // float4 column
+    const unsigned vec = blockIdx.y;
+    const unsigned row_len = (L + 1) * d + ((L + 3) & ~3);
+    const unsigned d4 = d / 4;
+    float4 acc = f4_zero();
+    if (col4 < d4) {
+#pragma unroll 8
+        for (unsigned r = slice; r < nrows; r += 16)
+            acc = f4_add(acc, *reinterpret_cast<const float4*>(partials + (size_t)r * row_len + (size_t)vec * d + col4 * 4));
+    }
+    sh[slice][cl] = acc;
+    {   // T_l = sum over rows, one wave-level reduction per workgroup
+        float t[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) t[l] = 0.f;
+        for (unsigned r = threadIdx.x; r < nrows; r += 256)
+#pragma unroll
+            for (int l = 0; l < L; ++l) t[l] += partials[(size_t)r * row_len + (size_t)(L + 1) * d + l];
+        wave_sum_n<L>(t);
+        if ((threadIdx.x & 63) == 0)
+#pragma unroll
+            for (int l = 0; l < L; ++l) shT[l][threadIdx.x >> 6] = t[l];
+    }
+    __syncthreads();
+    if (slice == 0 && col4 < d4) {
+        float4 S = f4_zero();
+#pragma unroll
+        for (int s = 0; s < 16; ++s) S = f4_add(S, sh[s][cl]);
+        float T[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) T[l] = (shT[l][0] + shT[l][1]) + (shT[l][2] + shT[l][3]);
+        const float4* b4 = reinterpret_cast<const float4*>(b);
+        const float4* w4 = reinterpret_cast<const float4*>(w);
+        if (vec < (unsigned)L) {
+            float4 Bl = f4_zero();               // B_vec[col] = sum_{j<vec} b_j
+            for (unsigned j = 0; j < vec; ++j) Bl = f4_add(Bl, b4[(size_t)j * d4 + col4]);
+            float Tv = 0.f;
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+                if ((unsigned)l == vec) Tv = T[l];
+            reinterpret_cast<float4*>(dw)[(size_t)vec * d4 + col4] = f4_fma(Bl, Tv, S);
+        } else {
+            float4 tail = f4_zero();             // sum_{l>j} T_l * w_l[col]
+#pragma unroll
+            for (int j = L - 1; j >= 0; --j) {
+                reinterpret_cast<float4*>(db)[(size_t)j * d4 + col4] = f4_add(S, tail);
+                tail = f4_fma(w4[(size_t)j * d4 + col4], T[j], tail);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// single layer, direct form (xl distinct from x0)
+// ---------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(kFwdThreads) void cross_layer_fwd_kernel(
+    const float* __restrict__ x0, const float* __restrict__ xl_in, unsigned x_stride,
+    const float4* __restrict__ w, const float4* __restrict__ b, unsigned B, unsigned d4,
+    float* __restrict__ out, unsigned out_stride) {
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned wave = (blockIdx.x * kFwdThreads + threadIdx.x) >> 6;
+    const unsigned nwaves = (gridDim.x * kFwdThreads) >> 6;
+    for (unsigned ex = wave; ex < B; ex += nwaves) {
+        const float4* xr = reinterpret_cast<const float4*>(x0 + (size_t)ex * x_stride);
+        const float4* lr = reinterpret_cast<const float4*>(xl_in + (size_t)ex * x_stride);
+        float4 x0v[NV], xl[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            unsigned idx = lane + v * 64;
+            x0v[v] = idx < d4 ? xr[idx] : f4_zero();
+            xl[v] = idx < d4 ? lr[idx] : f4_zero();
+            if (idx < d4) s += f4_dot(xl[v], w[idx]);
+        }
+        s = wave_sum(s);
+        float4* orow = reinterpret_cast<float4*>(out + (size_t)ex * out_stride);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            unsigned idx = lane + v * 64;
+            // reference order: (x0 * s + b) + xl      cross_layer.py:22-24
+            if (idx < d4) orow[idx] = f4_add(f4_fma(x0v[v], s, b[idx]), xl[v]);
+        }
+    }
+}
+
+// partial row layout: [dw | db]  (2*d floats)
+template <int NV>
+__global__ __launch_bounds__(kBwdThreads) void cross_layer_bwd_kernel(
+    const float* __restrict__ x0, const float* __restrict__ xl_in, unsigned x_stride,
+    const float4* __restrict__ w, const float* __restrict__ g, unsigned g_stride, unsigned B,
+    unsigned d4, float* __restrict__ dx0, float* __restrict__ dxl, float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned wib = threadIdx.x >> 6;
+    const unsigned wave = blockIdx.x * kBwdWaves + wib;
+    const unsigned nwaves = gridDim.x * kBwdWaves;
+    const unsigned d = d4 * 4;
+    float4 dwacc[NV], dbacc[NV], wv[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        unsigned idx = lane + v * 64;
+        dwacc[v] = dbacc[v] = f4_zero();
+        wv[v] = idx < d4 ? w[idx] : f4_zero();
+    }
+    for (unsigned ex = wave; ex < B; ex += nwaves) {
+        const float4* xr = reinterpret_cast<const float4*>(x0 + (size_t)ex * x_stride);
+        const float4* lr = reinterpret_cast<const float4*>(xl_in + (size_t)ex * x_stride);
+        const float4* gr = reinterpret_cast<const float4*>(g + (size_t)ex * g_stride);
+        float4 x0v[NV], xl[NV], gv[NV];
+        float r[2] = {0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            unsigned idx = lane + v * 64;
+            x0v[v] = idx < d4 ? xr[idx] : f4_zero();
+            xl[v] = idx < d4 ? lr[idx] : f4_zero();
+            gv[v] = idx < d4 ? gr[idx] : f4_zero();
+            r[0] += f4_dot(xl[v], wv[v]);     // s = xl . w
+            r[1] += f4_dot(gv[v], x0v[v]);    // t = g . x0
+        }
+        wave_sum_n<2>(r);
+        float4* o0 = reinterpret_cast<float4*>(dx0 + (size_t)ex * x_stride);
+        float4* ol = reinterpret_cast<float4*>(dxl + (size_t)ex * x_stride);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            unsigned idx = lane + v * 64;
+            dwacc[v] = f4_fma(xl[v], r[1], dwacc[v]);
+            dbacc[v] = f4_add(dbacc[v], gv[v]);
+            if (idx < d4) {
+                o0[idx] = f4_scale(gv[v], r[0]);
+                ol[idx] = f4_fma(wv[v], r[1], gv[v]);
+            }
+        }
+    }
+    float* prow = partials + (size_t)blockIdx.x * 2 * d;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
 #pragma unroll
-        for (int l = 0; l < L; ++l) {
-            __syncthreads();
+        for (int v = 0; v < NV; ++v) {
+            unsigned idx = lane + v * 64;
+            if (idx < d4)
+                *reinterpret_cast<float4*>(smem + (size_t)wib * d + idx * 4) = pass == 0 ? dwacc[v] : dbacc[v];
+        }
+        __syncthreads();
+        for (unsigned j = threadIdx.x; j < d; j += kBwdThreads) {
+            float acc = 0.f;
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                unsigned idx = lane + v * 64;
-                if (idx < d4)
-                    *reinterpret_cast<float4*>(smem + (size_t)wib * d + idx * 4) =
-                        pass == 0 ? dwacc[l][v] : dbacc[l][v];
-            }
-            __syncthreads();
-            for (unsigned j = threadIdx.x; j < d; j += kBwdThreads) {
-                float acc = 0.f;
-#pragma unroll
-                for (int wv = 0; wv < kBwdWaves; ++wv) acc += smem[(size_t)wv * d + j];
-                pblk[((size_t)pass * L + l) * d + j] = acc;
-            }
+            for (int wv_ = 0; wv_ < kBwdWaves; ++wv_) acc += smem[(size_t)wv_ * d + j];
+            prow[(size_t)pass * d + j] = acc;
         }
     }
 }
 
-__global__ __launch_bounds__(256) void cross_reduce_partials_kernel(
-    const float* __restrict__ partials, unsigned nblk, unsigned Ld, float* __restrict__ dw,
-    float* __restrict__ db) {
-    unsigned j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= 2 * Ld) return;
-    float acc = 0.f;
+// plain column sums of [nrows][ncols] partials (ncols % 4 == 0); workgroup = 16 float4 column
+// lanes x 16 row slices
+__global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ partials, unsigned nrows,
+                                                      unsigned ncols, float* __restrict__ out0,
+                                                      float* __restrict__ out1, unsigned split) {
+    __shared__ float4 sh[16][16];
+    const unsigned cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const unsigned col4 = blockIdx.x * 16 + cl;
+    float4 acc = f4_zero();
+    if (col4 * 4 < ncols) {
 #pragma unroll 8
-    for (unsigned k = 0; k < nblk; ++k) acc += partials[(size_t)k * 2 * Ld + j];
-    if (j < Ld) dw[j] = acc; else db[j - Ld] = acc;
+        for (unsigned r = slice; r < nrows; r += 16)
+            acc = f4_add(acc, *reinterpret_cast<const float4*>(partials + (size_t)r * ncols + col4 * 4));
+    }
+    sh[slice][cl] = acc;
+    __syncthreads();
+    if (slice == 0 && col4 * 4 < ncols) {
+        float4 s = f4_zero();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s = f4_add(s, sh[k][cl]);
+        unsigned col = col4 * 4;
+        if (col < split) *reinterpret_cast<float4*>(out0 + col) = s;
+        else *reinterpret_cast<float4*>(out1 + (col - split)) = s;
+    }
 }
 
-inline int cross_bwd_grid(int B) {
+inline int bwd_grid(int B) {
     int need = cdiv(B, kBwdWaves);
-    return need < 256 ? (need < 1 ? 1 : need) : 256;
+    return need < 1 ? 1 : (need > kMaxPartialRows ? kMaxPartialRows : need);
 }
 
 template <int NV, int L>
-int launch_cross_bwd(const float* x0, const float* xl_in, int x_stride, const float* w, const float* b,
-                     const float* g, int g_stride, const float* gx, int B, int d, float* dx0,
-                     float* dxl, float* partials, hipStream_t st) {
-    size_t smem = (size_t)kBwdWaves * d * sizeof(float);
-    if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_bwd_kernel<NV, L>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
+int launch_stack(bool fwd, const float* x0, int x_stride, const float* w, const float* b, const float* g,
+                 int g_stride, const float* gx, int B, int d, float* out, int out_stride, float* dw,
+                 float* db, float* partials, hipStream_t st) {
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+    if (fwd) {
+        hipLaunchKernelGGL((cross_stack_fwd_kernel<NV, L>), dim3(cdiv(B, kFwdThreads / 64)), dim3(kFwdThreads),
+                           0, st, x0, (unsigned)x_stride, w4, b4, (unsigned)B, (unsigned)(d / 4), out,
+                           (unsigned)out_stride);
+        return (int)hipGetLastError();
     }
-    hipLaunchKernelGGL((cross_bwd_kernel<NV, L>), dim3(cross_bwd_grid(B)), dim3(kBwdThreads), smem, st,
-                       x0, xl_in, (unsigned)x_stride, reinterpret_cast<const float4*>(w),
-                       reinterpret_cast<const float4*>(b), g, (unsigned)g_stride, gx, (unsigned)B,
-                       (unsigned)(d / 4), dx0, dxl, partials);
+    const int grid = bwd_grid(B);
+    size_t smem = (size_t)kBwdWaves * d * sizeof(float);
+    if (smem < (size_t)kBwdWaves * L * sizeof(float)) smem = (size_t)kBwdWaves * L * sizeof(float);
+    hipLaunchKernelGGL((cross_stack_bwd_kernel<NV, L>), dim3(grid), dim3(kBwdThreads), smem, st, x0,
+                       (unsigned)x_stride, w4, b4, g, (unsigned)g_stride, gx, (unsigned)B, (unsigned)(d / 4),
+                       out, partials);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((cross_stack_finalize_kernel<L>), dim3(cdiv(d, 64), L + 1), dim3(256), 0, st, partials,
+                       (unsigned)grid, (unsigned)d, w, b, dw, db);
     return (int)hipGetLastError();
 }
 
 template <int NV>
-int dispatch_cross_bwd_L(int L, const float* x0, const float* xl_in, int x_stride, const float* w,
-                         const float* b, const float* g, int g_stride, const float* gx, int B, int d,
-                         float* dx0, float* dxl, float* partials, hipStream_t st) {
+int dispatch_stack_L(int L, bool fwd, const float* x0, int x_stride, const float* w, const float* b,
+                     const float* g, int g_stride, const float* gx, int B, int d, float* out,
+                     int out_stride, float* dw, float* db, float* partials, hipStream_t st) {
     switch (L) {
-#define CASE_L(LL) \
-    case LL: return launch_cross_bwd<NV, LL>(x0, xl_in, x_stride, w, b, g, g_stride, gx, B, d, dx0, dxl, partials, st);
+#define CASE_L(LL)                                                                                      \
+    case LL:                                                                                            \
+        return launch_stack<NV, LL>(fwd, x0, x_stride, w, b, g, g_stride, gx, B, d, out, out_stride, dw, \
+                                    db, partials, st);
         CASE_L(1) CASE_L(2) CASE_L(3) CASE_L(4) CASE_L(5) CASE_L(6)
 #undef CASE_L
         default: return (int)hipErrorInvalidValue;
     }
 }
 
+int dispatch_stack(int L, bool fwd, const float* x0, int x_stride, const float* w, const float* b,
+                   const float* g, int g_stride, const float* gx, int B, int d, float* out, int out_stride,
+                   float* dw, float* db, float* partials, hipStream_t st) {
+    const int nv = cdiv(d / 4, 64);
+    if (nv <= 1) return dispatch_stack_L<1>(L, fwd, x0, x_stride, w, b, g, g_stride, gx, B, d, out, out_stride, dw, db, partials, st);
+    if (nv <= 2) return dispatch_stack_L<2>(L, fwd, x0, x_stride, w, b, g, g_stride, gx, B, d, out, out_stride, dw, db, partials, st);
+    if (nv <= 4) return dispatch_stack_L<4>(L, fwd, x0, x_stride, w, b, g, g_stride, gx, B, d, out, out_stride, dw, db, partials, st);
+    return (int)hipErrorInvalidValue;
+}
+
 }  // namespace
 
-namespace {
-int cross_fwd_impl(const float* x0, const float* xl_in, int x_stride, const float* w, const float* b,
-                   int B, int d, int L, float* out, int out_stride, recalgo_stream_t stream);
-}
+// =============================================================================================
+// C-ABI
+// =============================================================================================
 RECALGO_EXPORT int recalgo_cross_fwd(const float* x0, int x_stride, const float* w, const float* b,
                                      int B, int d, int L, float* out, int out_stride,
                                      recalgo_stream_t stream) {
-    return cross_fwd_impl(x0, nullptr, x_stride, w, b, B, d, L, out, out_stride, stream);
-}
-RECALGO_EXPORT int recalgo_cross_layer_fwd(const float* x0, const float* xl, int x_stride,
-                                           const float* w, const float* b, int B, int d, float* out,
-                                           int out_stride, recalgo_stream_t stream) {
-    RECALGO_REQUIRE(xl != nullptr);
-    return cross_fwd_impl(x0, xl, x_stride, w, b, B, d, 1, out, out_stride, stream);
-}
-namespace {
-int cross_fwd_impl(const float* x0, const float* xl_in, int x_stride, const float* w, const float* b,
-                   int B, int d, int L, float* out, int out_stride, recalgo_stream_t stream) {
-    RECALGO_REQUIRE(B >= 0 && d > 0 && d % 4 == 0 && d <= 2048 && L >= 1 && L <= 8);
+    RECALGO_REQUIRE(B >= 0 && d > 0 && d % 4 == 0 && d <= 1024 && L >= 1 && L <= 6);
     RECALGO_REQUIRE(x_stride % 4 == 0 && out_stride % 4 == 0 && x_stride >= d && out_stride >= d);
     if (B == 0) return 0;
-    const int d4 = d / 4;
-    const int nv = cdiv(d4, 64);
-    const int blocks = cdiv(B, 4);  // 4 waves per 256-thread workgroup, one example per wave
-    hipStream_t st = as_stream(stream);
-#define LAUNCH_FWD(NV)                                                                             \
-    hipLaunchKernelGGL(cross_fwd_kernel<NV>, dim3(blocks), dim3(256), 0, st, x0, xl_in,            \
-                       (unsigned)x_stride, reinterpret_cast<const float4*>(w),                     \
-                       reinterpret_cast<const float4*>(b),                                         \
-                       (unsigned)B, (unsigned)d4, (unsigned)L, out, (unsigned)out_stride)
-    if (nv <= 1) LAUNCH_FWD(1);
-    else if (nv <= 2) LAUNCH_FWD(2);
-    else if (nv <= 4) LAUNCH_FWD(4);
-    else LAUNCH_FWD(8);
-#undef LAUNCH_FWD
-    RECALGO_RETURN_LAST();
+    return dispatch_stack(L, true, x0, x_stride, w, b, nullptr, 0, nullptr, B, d, out, out_stride, nullptr,
+                          nullptr, nullptr, as_stream(stream));
 }
-}  // namespace
 
 RECALGO_EXPORT int64_t recalgo_cross_bwd_workspace_bytes(int B, int d, int L) {
     if (B <= 0 || d <= 0 || L <= 0) return 0;
-    return (int64_t)cross_bwd_grid(B) * 2 * L * d * (int64_t)sizeof(float);
+    int64_t row = (int64_t)(L + 1) * d + ((L + 3) & ~3);
+    if (row < 2 * (int64_t)d) row = 2 * (int64_t)d;
+    return (int64_t)bwd_grid(B) * row * (int64_t)sizeof(float);
 }
 
-namespace {
-int cross_bwd_impl(const float* x0, const float* xl_in, int x_stride, const float* w, const float* b,
-                   const float* g, int g_stride, const float* g_x0_extra, int B, int d, int L,
-                   float* dx0, float* dxl, float* dw, float* db, void* workspace,
-                   recalgo_stream_t stream);
-}
 RECALGO_EXPORT int recalgo_cross_bwd(const float* x0, int x_stride, const float* w, const float* b,
                                      const float* g, int g_stride, const float* g_x0_extra, int B,
                                      int d, int L, float* dx0, float* dw, float* db, void* workspace,
                                      recalgo_stream_t stream) {
-    return cross_bwd_impl(x0, nullptr, x_stride, w, b, g, g_stride, g_x0_extra, B, d, L, dx0, nullptr,
-                          dw, db, workspace, stream);
+    RECALGO_REQUIRE(B > 0 && d > 0 && d % 4 == 0 && d <= 1024 && L >= 1 && L <= 6);
+    RECALGO_REQUIRE(x_stride % 4 == 0 && g_stride % 4 == 0 && x_stride >= d && g_stride >= d);
+    RECALGO_REQUIRE(workspace != nullptr);
+    return dispatch_stack(L, false, x0, x_stride, w, b, g, g_stride, g_x0_extra, B, d, dx0, x_stride, dw, db,
+                          static_cast<float*>(workspace), as_stream(stream));
 }
+
+RECALGO_EXPORT int recalgo_cross_layer_fwd(const float* x0, const float* xl, int x_stride,
+                                           const float* w, const float* b, int B, int d, float* out,
+                                           int out_stride, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(xl != nullptr && B >= 0 && d > 0 && d % 4 == 0 && d <= 2048);
+    RECALGO_REQUIRE(x_stride % 4 == 0 && out_stride % 4 == 0 && x_stride >= d && out_stride >= d);
+    if (B == 0) return 0;
+    const int nv = cdiv(d / 4, 64);
+    hipStream_t st = as_stream(stream);
+#define LAUNCH(NV)                                                                                        \
+    hipLaunchKernelGGL(cross_layer_fwd_kernel<NV>, dim3(cdiv(B, kFwdThreads / 64)), dim3(kFwdThreads), 0, st, \
+                       x0, xl, (unsigned)x_stride, reinterpret_cast<const float4*>(w),                    \
+                       reinterpret_cast<const float4*>(b), (unsigned)B, (unsigned)(d / 4), out,           \
+                       (unsigned)out_stride)
+    if (nv <= 1) LAUNCH(1);
+    else if (nv <= 2) LAUNCH(2);
+    else if (nv <= 4) LAUNCH(4);
+    else LAUNCH(8);
+#undef LAUNCH
+    RECALGO_RETURN_LAST();
+}
+
 RECALGO_EXPORT int recalgo_cross_layer_bwd(const float* x0, const float* xl, int x_stride,
                                            const float* w, const float* b, const float* g,
                                            int g_stride, int B, int d, float* dx0, float* dxl,
                                            float* dw, float* db, void* workspace,
                                            recalgo_stream_t stream) {
-    RECALGO_REQUIRE(xl != nullptr && dxl != nullptr);
-    return cross_bwd_impl(x0, xl, x_stride, w, b, g, g_stride, nullptr, B, d, 1, dx0, dxl, dw, db,
-                          workspace, stream);
-}
-namespace {
-int cross_bwd_impl(const float* x0, const float* xl_in, int x_stride, const float* w, const float* b,
-                   const float* g, int g_stride, const float* g_x0_extra, int B, int d, int L,
-                   float* dx0, float* dxl, float* dw, float* db, void* workspace,
-                   recalgo_stream_t stream) {
-    RECALGO_REQUIRE(B > 0 && d > 0 && d % 4 == 0 && d <= 1024 && L >= 1 && L <= 6);
+    (void)b;
+    RECALGO_REQUIRE(xl != nullptr && dxl != nullptr && workspace != nullptr);
+    RECALGO_REQUIRE(B > 0 && d > 0 && d % 4 == 0 && d <= 2048);
     RECALGO_REQUIRE(x_stride % 4 == 0 && g_stride % 4 == 0 && x_stride >= d && g_stride >= d);
-    RECALGO_REQUIRE(workspace != nullptr);
-    RECALGO_REQUIRE((size_t)kBwdWaves * d * sizeof(float) <= 150 * 1024);
+    const int nv = cdiv(d / 4, 64);
+    const int grid = bwd_grid(B);
     hipStream_t st = as_stream(stream);
     float* partials = static_cast<float*>(workspace);
-    const int nv = cdiv(d / 4, 64);
-    int rc;
-    if (nv <= 1) rc = dispatch_cross_bwd_L<1>(L, x0, xl_in, x_stride, w, b, g, g_stride, g_x0_extra, B, d, dx0, dxl, partials, st);
-    else if (nv <= 2) rc = dispatch_cross_bwd_L<2>(L, x0, xl_in, x_stride, w, b, g, g_stride, g_x0_extra, B, d, dx0, dxl, partials, st);
-    else rc = dispatch_cross_bwd_L<4>(L, x0, xl_in, x_stride, w, b, g, g_stride, g_x0_extra, B, d, dx0, dxl, partials, st);
-    if (rc != 0) return rc;
-    const unsigned Ld = (unsigned)(L * d);
-    hipLaunchKernelGGL(cross_reduce_partials_kernel, dim3(cdiv(2 * (int64_t)Ld, 256)), dim3(256), 0, st,
-                       partials, (unsigned)cross_bwd_grid(B), Ld, dw, db);
+    size_t smem = (size_t)kBwdWaves * d * sizeof(float);
+#define LAUNCH(NV)                                                                                      \
+    hipLaunchKernelGGL(cross_layer_bwd_kernel<NV>, dim3(grid), dim3(kBwdThreads), smem, st, x0, xl,     \
+                       (unsigned)x_stride, reinterpret_cast<const float4*>(w), g, (unsigned)g_stride,   \
+                       (unsigned)B, (unsigned)(d / 4), dx0, dxl, partials)
+    if (nv <= 1) LAUNCH(1);
+    else if (nv <= 2) LAUNCH(2);
+    else if (nv <= 4) LAUNCH(4);
+    else LAUNCH(8);
+#undef LAUNCH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(colsum4_kernel, dim3(cdiv(2 * (int64_t)d, 64)), dim3(256), 0, st, partials, (unsigned)grid,
+                       (unsigned)(2 * d), dw, db, (unsigned)d);
     RECALGO_RETURN_LAST();
 }
-}  // namespace

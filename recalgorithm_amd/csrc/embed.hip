@@ -1,168 +1,304 @@
 // Embedding gathers (K1, K1m, K1s) and the fused DeepFM sparse path (K1+K2+K3), gfx950.
 //
-// All of these are HBM-bound: a 16-float row is 64 B, fetched as 4 x float4 by 4 adjacent
-// lanes, so one wave instruction moves 16 independent rows.  The output side is written
-// fully coalesced (float4 per lane, consecutive lanes -> consecutive addresses).
+// Forward: HBM-bound.  A 16-float row is 64 B, fetched as 4 x float4 by 4 adjacent lanes, so one
+// wave instruction moves 16 independent rows; outputs are written fully coalesced.  Rows whose
+// width is not a multiple of 4 (the reference's dim-2 `device` column) take the scalar (VEC=1)
+// instantiation of the same kernels.
+//
+// Backward (row-gradient scatter): CTR ids are Zipf distributed, so a naive atomicAdd per
+// occurrence serialises thousands of L2 atomics on the cache line of each hot row (measured:
+// 156 us for 106 k rows at B=4096).  Every backward kernel therefore first combines duplicate
+// rows inside the workgroup in an LDS hash table (ds_add_f32), and only then issues ONE global
+// atomic per distinct row per workgroup.  Workgroups are organised per (field, example chunk) so
+// that duplicates meet in the same table.
 #include "common.h"
 
 namespace {
 
 constexpr int kThreads = 256;
 
-// ---------------------------------------------------------------------------------------
-// K1 forward: one float4 of one (b, f) row per thread.
-// ---------------------------------------------------------------------------------------
+template <int VEC> struct VecT;
+template <> struct VecT<4> { using type = float4; };
+template <> struct VecT<1> { using type = float; };
+
+template <int VEC>
+__device__ __forceinline__ typename VecT<VEC>::type vzero();
+template <> __device__ __forceinline__ float4 vzero<4>() { return f4_zero(); }
+template <> __device__ __forceinline__ float vzero<1>() { return 0.f; }
+
+// ---------------------------------------------------------------------------------------------
+// workgroup-local row-gradient aggregator
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned kSlots = 512;                       // power of two
+constexpr unsigned long long kEmpty = ~0ull;
+
+struct Agg {
+    unsigned long long* keys;   // [kSlots]
+    float* acc;                 // [kSlots][W]   (W = row width, + 1 for the fused w1 gradient)
+    unsigned W;
+};
+
+__device__ __forceinline__ void agg_init(const Agg& a) {
+    for (unsigned i = threadIdx.x; i < kSlots; i += blockDim.x) a.keys[i] = kEmpty;
+    for (unsigned i = threadIdx.x; i < kSlots * a.W; i += blockDim.x) a.acc[i] = 0.f;
+}
+
+// returns the slot of `row`, or kSlots if the probe sequence is exhausted
+__device__ __forceinline__ unsigned agg_slot(const Agg& a, unsigned long long row) {
+    unsigned h = (unsigned)((row * 0x9E3779B97F4A7C15ull) >> 40) & (kSlots - 1);
+#pragma unroll 1
+    for (int probe = 0; probe < 16; ++probe) {
+        unsigned long long k = a.keys[h];
+        if (k == row) return h;
+        if (k == kEmpty) {
+            unsigned long long old = atomicCAS(&a.keys[h], kEmpty, row);
+            if (old == kEmpty || old == row) return h;
+        }
+        h = (h + 1) & (kSlots - 1);
+    }
+    return kSlots;
+}
+
+__device__ __forceinline__ void lds_add(float* p, float v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int VEC>
+__device__ __forceinline__ void agg_add(const Agg& a, unsigned long long row, unsigned chunk,
+                                        typename VecT<VEC>::type v, float* __restrict__ gdst_row) {
+    unsigned s = agg_slot(a, row);
+    if constexpr (VEC == 4) {
+        if (s < kSlots) {
+            float* p = a.acc + s * a.W + chunk * 4;
+            lds_add(p + 0, v.x); lds_add(p + 1, v.y); lds_add(p + 2, v.z); lds_add(p + 3, v.w);
+        } else {
+            float* p = gdst_row + chunk * 4;
+            atomic_add_f32(p + 0, v.x); atomic_add_f32(p + 1, v.y);
+            atomic_add_f32(p + 2, v.z); atomic_add_f32(p + 3, v.w);
+        }
+    } else {
+        if (s < kSlots) lds_add(a.acc + s * a.W + chunk, v);
+        else atomic_add_f32(gdst_row + chunk, v);
+    }
+}
+
+// one global atomic per (distinct row, float) of this workgroup; K floats per row go to
+// grad + row*K, the optional (K+1)-th float to grad_w1 + row.
+__device__ __forceinline__ void agg_flush(const Agg& a, unsigned K, float* __restrict__ grad,
+                                          float* __restrict__ grad_w1) {
+    const unsigned lanes = K <= 16 ? 16 : (K <= 32 ? 32 : 64);   // lanes per slot
+    const unsigned per_pass = blockDim.x / lanes;
+    const unsigned l = threadIdx.x % lanes, grp = threadIdx.x / lanes;
+    for (unsigned s = grp; s < kSlots; s += per_pass) {
+        unsigned long long row = a.keys[s];
+        if (row == kEmpty) continue;
+        for (unsigned k = l; k < K; k += lanes) {
+            float v = a.acc[s * a.W + k];
+            if (v != 0.f) atomic_add_f32(grad + row * K + k, v);
+        }
+        if (grad_w1 && l == 0) {
+            float v = a.acc[s * a.W + K];
+            if (v != 0.f) atomic_add_f32(grad_w1 + row, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 forward: one VEC-wide chunk of one (b, f) row per thread.
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
 __global__ __launch_bounds__(kThreads) void gather_fwd_kernel(
-    const int64_t* __restrict__ ids, const float4* __restrict__ arena,
-    const int64_t* __restrict__ row_base, unsigned total4, unsigned F, unsigned K4,
+    const int64_t* __restrict__ ids, const float* __restrict__ arena,
+    const int64_t* __restrict__ row_base, unsigned total, unsigned F, unsigned KV,
     float* __restrict__ out, unsigned out_stride, unsigned out_col) {
+    using V = typename VecT<VEC>::type;
     unsigned i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= total4) return;
-    unsigned row = i / K4;          // flattened (b, f)
-    unsigned q = i - row * K4;
+    if (i >= total) return;
+    unsigned row = i / KV;          // flattened (b, f)
+    unsigned q = i - row * KV;
     unsigned b = row / F;
     unsigned f = row - b * F;
     int64_t id = ids[row];
-    float4 v = f4_zero();
-    if (id >= 0) v = arena[(row_base[f] + id) * K4 + q];
-    *reinterpret_cast<float4*>(out + (size_t)b * out_stride + out_col + (f * K4 + q) * 4) = v;
+    V v = vzero<VEC>();
+    if (id >= 0) v = reinterpret_cast<const V*>(arena)[(row_base[f] + id) * KV + q];
+    *reinterpret_cast<V*>(out + (size_t)b * out_stride + out_col + (f * KV + q) * VEC) = v;
 }
 
+// K1 backward: grid (F, chunks); workgroup = one field x kExPerBlk examples.
+constexpr unsigned kExPerBlk = 256;
+
+template <int VEC>
 __global__ __launch_bounds__(kThreads) void gather_bwd_kernel(
     const int64_t* __restrict__ ids, const float* __restrict__ g,
-    const int64_t* __restrict__ row_base, unsigned total4, unsigned F, unsigned K4,
-    unsigned g_stride, unsigned g_col, float* __restrict__ grad_arena) {
-    unsigned i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= total4) return;
-    unsigned row = i / K4;
-    unsigned q = i - row * K4;
-    unsigned b = row / F;
-    unsigned f = row - b * F;
-    int64_t id = ids[row];
-    if (id < 0) return;
-    float4 v = *reinterpret_cast<const float4*>(g + (size_t)b * g_stride + g_col + (f * K4 + q) * 4);
-    float* dst = grad_arena + ((row_base[f] + id) * K4 + q) * 4;
-    atomic_add_f32(dst + 0, v.x);
-    atomic_add_f32(dst + 1, v.y);
-    atomic_add_f32(dst + 2, v.z);
-    atomic_add_f32(dst + 3, v.w);
+    const int64_t* __restrict__ row_base, unsigned B, unsigned F, unsigned KV, unsigned g_stride,
+    unsigned g_col, float* __restrict__ grad_arena) {
+    using V = typename VecT<VEC>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const unsigned K = KV * VEC;
+    Agg a{reinterpret_cast<unsigned long long*>(smem_raw),
+          reinterpret_cast<float*>(smem_raw + kSlots * sizeof(unsigned long long)), K};
+    agg_init(a);
+    __syncthreads();
+    const unsigned f = blockIdx.x;
+    const unsigned b0 = blockIdx.y * kExPerBlk;
+    const unsigned nex = min(kExPerBlk, B - b0);
+    const int64_t rb = row_base[f];
+    for (unsigned i = threadIdx.x; i < nex * KV; i += kThreads) {
+        unsigned e = i / KV, q = i - e * KV;
+        unsigned b = b0 + e;
+        int64_t id = ids[(size_t)b * F + f];
+        if (id < 0) continue;
+        unsigned long long row = (unsigned long long)(rb + id);
+        V v = *reinterpret_cast<const V*>(g + (size_t)b * g_stride + g_col + (f * KV + q) * VEC);
+        agg_add<VEC>(a, row, q, v, grad_arena + row * K);
+    }
+    __syncthreads();
+    agg_flush(a, K, grad_arena, nullptr);
 }
 
-// ---------------------------------------------------------------------------------------
-// K1m: mean-combined bags.  One thread per (bag, float4 column chunk); the bag is walked
-// sequentially so the fp32 sum order is the bag order (TF SparseSegmentMean).
-// ---------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// K1m: mean-combined bags.  Forward: one thread per (bag, chunk), the bag is walked sequentially
+// so the fp32 sum order is the bag order (TF SparseSegmentMean).
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
 __global__ __launch_bounds__(kThreads) void bag_mean_fwd_kernel(
     const int64_t* __restrict__ values, const int64_t* __restrict__ offsets,
-    const float4* __restrict__ table, unsigned total4, unsigned K4, float* __restrict__ out,
+    const float* __restrict__ table, unsigned total, unsigned KV, float* __restrict__ out,
     unsigned out_stride, unsigned out_col) {
+    using V = typename VecT<VEC>::type;
     unsigned i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= total4) return;
-    unsigned b = i / K4;
-    unsigned q = i - b * K4;
+    if (i >= total) return;
+    unsigned b = i / KV;
+    unsigned q = i - b * KV;
     int64_t beg = offsets[b], end = offsets[b + 1];
-    float4 acc = f4_zero();
+    float acc[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc[c] = 0.f;
     int cnt = 0;
     for (int64_t j = beg; j < end; ++j) {
         int64_t id = values[j];
         if (id >= 0) {
-            acc = f4_add(acc, table[id * K4 + q]);
+            V r = reinterpret_cast<const V*>(table)[id * KV + q];
+            const float* rp = reinterpret_cast<const float*>(&r);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) acc[c] += rp[c];
             ++cnt;
         }
     }
-    if (cnt > 0) {
-        float c = (float)cnt;
-        acc = make_float4(acc.x / c, acc.y / c, acc.z / c, acc.w / c);
-    }
-    *reinterpret_cast<float4*>(out + (size_t)b * out_stride + out_col + q * 4) = acc;
+    float* o = out + (size_t)b * out_stride + out_col + q * VEC;
+    float cf = (float)(cnt > 0 ? cnt : 1);
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) o[c] = acc[c] / cf;
 }
 
+template <int VEC>
 __global__ __launch_bounds__(kThreads) void bag_mean_bwd_kernel(
     const int64_t* __restrict__ values, const int64_t* __restrict__ offsets,
-    const float* __restrict__ g, unsigned total4, unsigned K4, unsigned g_stride, unsigned g_col,
+    const float* __restrict__ g, unsigned B, unsigned KV, unsigned g_stride, unsigned g_col,
     float* __restrict__ grad_table) {
-    unsigned i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= total4) return;
-    unsigned b = i / K4;
-    unsigned q = i - b * K4;
-    int64_t beg = offsets[b], end = offsets[b + 1];
-    int cnt = 0;
-    for (int64_t j = beg; j < end; ++j) cnt += values[j] >= 0;
-    if (cnt == 0) return;
-    float4 v = *reinterpret_cast<const float4*>(g + (size_t)b * g_stride + g_col + q * 4);
-    float c = (float)cnt;
-    v = make_float4(v.x / c, v.y / c, v.z / c, v.w / c);
-    for (int64_t j = beg; j < end; ++j) {
-        int64_t id = values[j];
-        if (id < 0) continue;
-        float* dst = grad_table + (id * K4 + q) * 4;
-        atomic_add_f32(dst + 0, v.x);
-        atomic_add_f32(dst + 1, v.y);
-        atomic_add_f32(dst + 2, v.z);
-        atomic_add_f32(dst + 3, v.w);
+    using V = typename VecT<VEC>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const unsigned K = KV * VEC;
+    Agg a{reinterpret_cast<unsigned long long*>(smem_raw),
+          reinterpret_cast<float*>(smem_raw + kSlots * sizeof(unsigned long long)), K};
+    agg_init(a);
+    __syncthreads();
+    const unsigned b0 = blockIdx.x * kExPerBlk;
+    const unsigned nex = min(kExPerBlk, B - b0);
+    for (unsigned i = threadIdx.x; i < nex * KV; i += kThreads) {
+        unsigned e = i / KV, q = i - e * KV;
+        unsigned b = b0 + e;
+        int64_t beg = offsets[b], end = offsets[b + 1];
+        int cnt = 0;
+        for (int64_t j = beg; j < end; ++j) cnt += values[j] >= 0;
+        if (cnt == 0) continue;
+        V v = *reinterpret_cast<const V*>(g + (size_t)b * g_stride + g_col + q * VEC);
+        float c = (float)cnt;
+        float* vp = reinterpret_cast<float*>(&v);
+#pragma unroll
+        for (int cc = 0; cc < VEC; ++cc) vp[cc] = vp[cc] / c;
+        for (int64_t j = beg; j < end; ++j) {
+            int64_t id = values[j];
+            if (id < 0) continue;
+            agg_add<VEC>(a, (unsigned long long)id, q, v, grad_table + id * K);
+        }
     }
+    __syncthreads();
+    agg_flush(a, K, grad_table, nullptr);
 }
 
-// ---------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
 // K1s: zero padded sequence gather (B, T, K).
-// ---------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
 __global__ __launch_bounds__(kThreads) void seq_gather_fwd_kernel(
     const int64_t* __restrict__ values, const int64_t* __restrict__ offsets,
-    const float4* __restrict__ table, unsigned total4, unsigned T, unsigned K4,
-    float4* __restrict__ out, int32_t* __restrict__ seq_len) {
+    const float* __restrict__ table, unsigned total, unsigned T, unsigned KV,
+    float* __restrict__ out, int32_t* __restrict__ seq_len) {
+    using V = typename VecT<VEC>::type;
     unsigned i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= total4) return;
-    unsigned row = i / K4;  // (b, t)
-    unsigned q = i - row * K4;
+    if (i >= total) return;
+    unsigned row = i / KV;  // (b, t)
+    unsigned q = i - row * KV;
     unsigned b = row / T;
     unsigned t = row - b * T;
     int64_t beg = offsets[b];
     int64_t len = offsets[b + 1] - beg;
     if (t == 0 && q == 0) seq_len[b] = (int32_t)(len < (int64_t)T ? len : (int64_t)T);
-    float4 v = f4_zero();
+    V v = vzero<VEC>();
     if ((int64_t)t < len) {
         int64_t id = values[beg + t];
-        if (id >= 0) v = table[id * K4 + q];
+        if (id >= 0) v = reinterpret_cast<const V*>(table)[id * KV + q];
     }
-    out[i] = v;
+    reinterpret_cast<V*>(out)[i] = v;
 }
 
+// workgroup = kExPerBlk consecutive (b, t) positions
+template <int VEC>
 __global__ __launch_bounds__(kThreads) void seq_gather_bwd_kernel(
     const int64_t* __restrict__ values, const int64_t* __restrict__ offsets,
-    const float4* __restrict__ g, unsigned total4, unsigned T, unsigned K4,
+    const float* __restrict__ g, unsigned BT, unsigned T, unsigned KV,
     float* __restrict__ grad_table) {
-    unsigned i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= total4) return;
-    unsigned row = i / K4;
-    unsigned q = i - row * K4;
-    unsigned b = row / T;
-    unsigned t = row - b * T;
-    int64_t beg = offsets[b];
-    int64_t len = offsets[b + 1] - beg;
-    if ((int64_t)t >= len) return;
-    int64_t id = values[beg + t];
-    if (id < 0) return;
-    float4 v = g[i];
-    float* dst = grad_table + (id * K4 + q) * 4;
-    atomic_add_f32(dst + 0, v.x);
-    atomic_add_f32(dst + 1, v.y);
-    atomic_add_f32(dst + 2, v.z);
-    atomic_add_f32(dst + 3, v.w);
+    using V = typename VecT<VEC>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const unsigned K = KV * VEC;
+    Agg a{reinterpret_cast<unsigned long long*>(smem_raw),
+          reinterpret_cast<float*>(smem_raw + kSlots * sizeof(unsigned long long)), K};
+    agg_init(a);
+    __syncthreads();
+    const unsigned r0 = blockIdx.x * kExPerBlk;
+    const unsigned nr = min(kExPerBlk, BT - r0);
+    for (unsigned i = threadIdx.x; i < nr * KV; i += kThreads) {
+        unsigned e = i / KV, q = i - e * KV;
+        unsigned row = r0 + e;
+        unsigned b = row / T, t = row - b * T;
+        int64_t beg = offsets[b];
+        int64_t len = offsets[b + 1] - beg;
+        if ((int64_t)t >= len) continue;
+        int64_t id = values[beg + t];
+        if (id < 0) continue;
+        V v = reinterpret_cast<const V*>(g)[(size_t)row * KV + q];
+        agg_add<VEC>(a, (unsigned long long)id, q, v, grad_table + id * K);
+    }
+    __syncthreads();
+    agg_flush(a, K, grad_table, nullptr);
 }
 
-// ---------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
 // DeepFM sparse path, fused.  One workgroup owns EB examples.  Phase 1 gathers the EB*F rows
 // (float4 per lane), streams them to `emb` and parks them in an LDS tile; phase 2 gives every
 // example a 16-lane group that walks the F fields in LDS (sum and sum of squares per k), then
 // shuffle-reduces over k.  Example stride in LDS is padded by 16 floats so that the two
-// examples sharing a 32-lane ds_read_b32 group land on disjoint banks.
-// ---------------------------------------------------------------------------------------
+// examples sharing a 32-lane ds_read_b32 group land on disjoint banks.  The per-example field
+// sum S[b, :] is also written out: the backward needs it (d fm2 / d e_f = g2 * (S - e_f)).
+// ---------------------------------------------------------------------------------------------
 template <int EB>
 __global__ __launch_bounds__(kThreads) void deepfm_sparse_fwd_kernel(
     const int64_t* __restrict__ ids, const float4* __restrict__ arena,
     const float* __restrict__ w1, const float* __restrict__ bias,
     const int64_t* __restrict__ row_base, unsigned B, unsigned F, unsigned K4,
-    float4* __restrict__ emb, float* __restrict__ fm1, float* __restrict__ fm2) {
+    float4* __restrict__ emb, float* __restrict__ fm1, float* __restrict__ fm2,
+    float* __restrict__ fsum) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const unsigned K = K4 * 4;
     const unsigned FK = F * K;
@@ -208,6 +344,7 @@ __global__ __launch_bounds__(kThreads) void deepfm_sparse_fwd_kernel(
                     sq = fmaf(x, x, sq);
                 }
                 acc2 += 0.5f * (s * s - sq);
+                fsum[(size_t)(b0 + e) * K + k] = s;
             }
             for (unsigned f = l16; f < F; f += 16) acc1 += w1s[e * F + f];
         }
@@ -220,82 +357,86 @@ __global__ __launch_bounds__(kThreads) void deepfm_sparse_fwd_kernel(
     }
 }
 
-template <int EB>
+// backward: grid (F, chunks) like gather_bwd; the LDS rows carry K + 1 floats (w1 gradient).
 __global__ __launch_bounds__(kThreads) void deepfm_sparse_bwd_kernel(
     const int64_t* __restrict__ ids, const float4* __restrict__ emb,
-    const float4* __restrict__ g_emb, const float* __restrict__ g_fm1,
-    const float* __restrict__ g_fm2, const int64_t* __restrict__ row_base, unsigned B,
-    unsigned F, unsigned K4, float* __restrict__ grad_arena, float* __restrict__ grad_w1) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const float4* __restrict__ fsum, const float4* __restrict__ g_emb,
+    const float* __restrict__ g_fm1, const float* __restrict__ g_fm2,
+    const int64_t* __restrict__ row_base, unsigned B, unsigned F, unsigned K4,
+    float* __restrict__ grad_arena, float* __restrict__ grad_w1) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const unsigned K = K4 * 4;
-    const unsigned FK = F * K;
-    const unsigned ex_stride = FK + 16;
-    float* tile = smem;                   // [EB][ex_stride]
-    float* S = smem + EB * ex_stride;     // [EB][K]
-    const unsigned b0 = blockIdx.x * EB;
-    const unsigned nex = min((unsigned)EB, B - b0);
-    const unsigned per_ex4 = F * K4;
-    const unsigned total4 = nex * per_ex4;
-
-    for (unsigned i = threadIdx.x; i < total4; i += kThreads) {
-        unsigned e = i / per_ex4;
-        unsigned r = i - e * per_ex4;
-        float4 v = emb[(size_t)(b0 + e) * per_ex4 + r];
-        *reinterpret_cast<float4*>(tile + e * ex_stride + r * 4) = v;
-    }
+    Agg a{reinterpret_cast<unsigned long long*>(smem_raw),
+          reinterpret_cast<float*>(smem_raw + kSlots * sizeof(unsigned long long)), K + 1};
+    agg_init(a);
     __syncthreads();
-    {
-        const unsigned e = threadIdx.x >> 4;
-        const unsigned l16 = threadIdx.x & 15;
-        if (e < nex) {
-            const float* te = tile + e * ex_stride;
-            for (unsigned k = l16; k < K; k += 16) {
-                float s = 0.f;
-                for (unsigned f = 0; f < F; ++f) s += te[f * K + k];
-                S[e * K + k] = s;
-            }
+    const unsigned f = blockIdx.x;
+    const unsigned b0 = blockIdx.y * kExPerBlk;
+    const unsigned nex = min(kExPerBlk, B - b0);
+    const int64_t rb = row_base[f];
+    for (unsigned i = threadIdx.x; i < nex * K4; i += kThreads) {
+        unsigned e = i / K4, q = i - e * K4;
+        unsigned b = b0 + e;
+        int64_t id = ids[(size_t)b * F + f];
+        if (id < 0) continue;
+        unsigned long long row = (unsigned long long)(rb + id);
+        size_t gi = ((size_t)b * F + f) * K4 + q;
+        float4 ge = g_emb[gi], ev = emb[gi], sv = fsum[(size_t)b * K4 + q];
+        float g2 = g_fm2[b];
+        float4 v = make_float4(fmaf(g2, sv.x - ev.x, ge.x), fmaf(g2, sv.y - ev.y, ge.y),
+                               fmaf(g2, sv.z - ev.z, ge.z), fmaf(g2, sv.w - ev.w, ge.w));
+        unsigned s = agg_slot(a, row);
+        if (s < kSlots) {
+            float* p = a.acc + s * a.W + q * 4;
+            lds_add(p + 0, v.x); lds_add(p + 1, v.y); lds_add(p + 2, v.z); lds_add(p + 3, v.w);
+            if (q == 0) lds_add(a.acc + s * a.W + K, g_fm1[b]);
+        } else {
+            float* p = grad_arena + row * K + q * 4;
+            atomic_add_f32(p + 0, v.x); atomic_add_f32(p + 1, v.y);
+            atomic_add_f32(p + 2, v.z); atomic_add_f32(p + 3, v.w);
+            if (q == 0) atomic_add_f32(grad_w1 + row, g_fm1[b]);
         }
     }
     __syncthreads();
-    for (unsigned i = threadIdx.x; i < total4; i += kThreads) {
-        unsigned e = i / per_ex4;
-        unsigned r = i - e * per_ex4;
-        unsigned f = r / K4;
-        unsigned q = r - f * K4;
-        size_t grow = (size_t)(b0 + e) * F + f;
-        int64_t id = ids[grow];
-        if (id < 0) continue;
-        int64_t arow = row_base[f] + id;
-        float4 ge = g_emb[grow * K4 + q];
-        float g2 = g_fm2[b0 + e];
-        float4 ev = *reinterpret_cast<const float4*>(tile + e * ex_stride + r * 4);
-        float4 sv = *reinterpret_cast<const float4*>(S + e * K + q * 4);
-        float* dst = grad_arena + (arow * K4 + q) * 4;
-        atomic_add_f32(dst + 0, fmaf(g2, sv.x - ev.x, ge.x));
-        atomic_add_f32(dst + 1, fmaf(g2, sv.y - ev.y, ge.y));
-        atomic_add_f32(dst + 2, fmaf(g2, sv.z - ev.z, ge.z));
-        atomic_add_f32(dst + 3, fmaf(g2, sv.w - ev.w, ge.w));
-        if (q == 0) atomic_add_f32(grad_w1 + arow, g_fm1[b0 + e]);
-    }
+    agg_flush(a, K, grad_arena, grad_w1);
 }
+
+inline size_t agg_smem(int W) { return kSlots * sizeof(unsigned long long) + (size_t)kSlots * W * sizeof(float); }
+
+// dynamic LDS above 64 KiB must be opted into per kernel
+#define ENSURE_SMEM(kern, bytes)                                                                       \
+    do {                                                                                               \
+        if ((bytes) > 64 * 1024) {                                                                     \
+            hipError_t e__ = hipFuncSetAttribute(reinterpret_cast<const void*>(&kern),                 \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+            if (e__ != hipSuccess) return (int)e__;                                                    \
+        }                                                                                              \
+    } while (0)
+
+inline int vec_of(int K, int stride, int col) { return (K % 4 == 0 && stride % 4 == 0 && col % 4 == 0) ? 4 : 1; }
 
 }  // namespace
 
-// =========================================================================================
+// =============================================================================================
 // C-ABI
-// =========================================================================================
+// =============================================================================================
 RECALGO_EXPORT int recalgo_embedding_gather_fwd(const int64_t* ids, const float* arena,
                                                 const int64_t* row_base, int B, int F, int K,
                                                 float* out, int out_stride, int out_col,
                                                 recalgo_stream_t stream) {
-    RECALGO_REQUIRE(B >= 0 && F > 0 && K > 0 && K % 4 == 0 && out_stride % 4 == 0 && out_col % 4 == 0);
-    int64_t total4 = (int64_t)B * F * (K / 4);
-    RECALGO_REQUIRE(total4 < (1ll << 31));
-    if (total4 == 0) return 0;
-    hipLaunchKernelGGL(gather_fwd_kernel, dim3(cdiv(total4, kThreads)), dim3(kThreads), 0,
-                       as_stream(stream), ids, reinterpret_cast<const float4*>(arena), row_base,
-                       (unsigned)total4, (unsigned)F, (unsigned)(K / 4), out, (unsigned)out_stride,
-                       (unsigned)out_col);
+    RECALGO_REQUIRE(B >= 0 && F > 0 && K > 0 && out_stride >= out_col + F * K);
+    const int vec = vec_of(K, out_stride, out_col);
+    int64_t total = (int64_t)B * F * (K / vec);
+    RECALGO_REQUIRE(total < (1ll << 31));
+    if (total == 0) return 0;
+    if (vec == 4)
+        hipLaunchKernelGGL(gather_fwd_kernel<4>, dim3(cdiv(total, kThreads)), dim3(kThreads), 0, as_stream(stream),
+                           ids, arena, row_base, (unsigned)total, (unsigned)F, (unsigned)(K / 4), out,
+                           (unsigned)out_stride, (unsigned)out_col);
+    else
+        hipLaunchKernelGGL(gather_fwd_kernel<1>, dim3(cdiv(total, kThreads)), dim3(kThreads), 0, as_stream(stream),
+                           ids, arena, row_base, (unsigned)total, (unsigned)F, (unsigned)K, out,
+                           (unsigned)out_stride, (unsigned)out_col);
     RECALGO_RETURN_LAST();
 }
 
@@ -303,13 +444,21 @@ RECALGO_EXPORT int recalgo_embedding_gather_bwd(const int64_t* ids, const float*
                                                 const int64_t* row_base, int B, int F, int K,
                                                 int g_stride, int g_col, float* grad_arena,
                                                 recalgo_stream_t stream) {
-    RECALGO_REQUIRE(B >= 0 && F > 0 && K > 0 && K % 4 == 0 && g_stride % 4 == 0 && g_col % 4 == 0);
-    int64_t total4 = (int64_t)B * F * (K / 4);
-    RECALGO_REQUIRE(total4 < (1ll << 31));
-    if (total4 == 0) return 0;
-    hipLaunchKernelGGL(gather_bwd_kernel, dim3(cdiv(total4, kThreads)), dim3(kThreads), 0,
-                       as_stream(stream), ids, g, row_base, (unsigned)total4, (unsigned)F,
-                       (unsigned)(K / 4), (unsigned)g_stride, (unsigned)g_col, grad_arena);
+    RECALGO_REQUIRE(B >= 0 && F > 0 && K > 0 && K <= 64 && g_stride >= g_col + F * K);
+    if (B == 0) return 0;
+    const int vec = vec_of(K, g_stride, g_col);
+    dim3 grid(F, cdiv(B, kExPerBlk));
+    if (vec == 4) {
+        ENSURE_SMEM(gather_bwd_kernel<4>, agg_smem(K));
+        hipLaunchKernelGGL(gather_bwd_kernel<4>, grid, dim3(kThreads), agg_smem(K), as_stream(stream), ids, g,
+                           row_base, (unsigned)B, (unsigned)F, (unsigned)(K / 4), (unsigned)g_stride,
+                           (unsigned)g_col, grad_arena);
+    } else {
+        ENSURE_SMEM(gather_bwd_kernel<1>, agg_smem(K));
+        hipLaunchKernelGGL(gather_bwd_kernel<1>, grid, dim3(kThreads), agg_smem(K), as_stream(stream), ids, g,
+                           row_base, (unsigned)B, (unsigned)F, (unsigned)K, (unsigned)g_stride,
+                           (unsigned)g_col, grad_arena);
+    }
     RECALGO_RETURN_LAST();
 }
 
@@ -317,14 +466,19 @@ RECALGO_EXPORT int recalgo_embedding_bag_mean_fwd(const int64_t* values, const i
                                                   const float* table, int B, int K, float* out,
                                                   int out_stride, int out_col,
                                                   recalgo_stream_t stream) {
-    RECALGO_REQUIRE(B >= 0 && K > 0 && K % 4 == 0 && out_stride % 4 == 0 && out_col % 4 == 0);
-    int64_t total4 = (int64_t)B * (K / 4);
-    RECALGO_REQUIRE(total4 < (1ll << 31));
-    if (total4 == 0) return 0;
-    hipLaunchKernelGGL(bag_mean_fwd_kernel, dim3(cdiv(total4, kThreads)), dim3(kThreads), 0,
-                       as_stream(stream), values, offsets, reinterpret_cast<const float4*>(table),
-                       (unsigned)total4, (unsigned)(K / 4), out, (unsigned)out_stride,
-                       (unsigned)out_col);
+    RECALGO_REQUIRE(B >= 0 && K > 0 && out_stride >= out_col + K);
+    const int vec = vec_of(K, out_stride, out_col);
+    int64_t total = (int64_t)B * (K / vec);
+    RECALGO_REQUIRE(total < (1ll << 31));
+    if (total == 0) return 0;
+    if (vec == 4)
+        hipLaunchKernelGGL(bag_mean_fwd_kernel<4>, dim3(cdiv(total, kThreads)), dim3(kThreads), 0, as_stream(stream),
+                           values, offsets, table, (unsigned)total, (unsigned)(K / 4), out, (unsigned)out_stride,
+                           (unsigned)out_col);
+    else
+        hipLaunchKernelGGL(bag_mean_fwd_kernel<1>, dim3(cdiv(total, kThreads)), dim3(kThreads), 0, as_stream(stream),
+                           values, offsets, table, (unsigned)total, (unsigned)K, out, (unsigned)out_stride,
+                           (unsigned)out_col);
     RECALGO_RETURN_LAST();
 }
 
@@ -332,79 +486,95 @@ RECALGO_EXPORT int recalgo_embedding_bag_mean_bwd(const int64_t* values, const i
                                                   const float* g, int B, int K, int g_stride,
                                                   int g_col, float* grad_table,
                                                   recalgo_stream_t stream) {
-    RECALGO_REQUIRE(B >= 0 && K > 0 && K % 4 == 0 && g_stride % 4 == 0 && g_col % 4 == 0);
-    int64_t total4 = (int64_t)B * (K / 4);
-    RECALGO_REQUIRE(total4 < (1ll << 31));
-    if (total4 == 0) return 0;
-    hipLaunchKernelGGL(bag_mean_bwd_kernel, dim3(cdiv(total4, kThreads)), dim3(kThreads), 0,
-                       as_stream(stream), values, offsets, g, (unsigned)total4, (unsigned)(K / 4),
-                       (unsigned)g_stride, (unsigned)g_col, grad_table);
+    RECALGO_REQUIRE(B >= 0 && K > 0 && K <= 64 && g_stride >= g_col + K);
+    if (B == 0) return 0;
+    const int vec = vec_of(K, g_stride, g_col);
+    if (vec == 4) {
+        ENSURE_SMEM(bag_mean_bwd_kernel<4>, agg_smem(K));
+        hipLaunchKernelGGL(bag_mean_bwd_kernel<4>, dim3(cdiv(B, kExPerBlk)), dim3(kThreads), agg_smem(K),
+                           as_stream(stream), values, offsets, g, (unsigned)B, (unsigned)(K / 4),
+                           (unsigned)g_stride, (unsigned)g_col, grad_table);
+    } else {
+        ENSURE_SMEM(bag_mean_bwd_kernel<1>, agg_smem(K));
+        hipLaunchKernelGGL(bag_mean_bwd_kernel<1>, dim3(cdiv(B, kExPerBlk)), dim3(kThreads), agg_smem(K),
+                           as_stream(stream), values, offsets, g, (unsigned)B, (unsigned)K,
+                           (unsigned)g_stride, (unsigned)g_col, grad_table);
+    }
     RECALGO_RETURN_LAST();
 }
 
 RECALGO_EXPORT int recalgo_sequence_gather_fwd(const int64_t* values, const int64_t* offsets,
                                                const float* table, int B, int T, int K, float* out,
                                                int32_t* seq_len, recalgo_stream_t stream) {
-    RECALGO_REQUIRE(B >= 0 && T > 0 && K > 0 && K % 4 == 0);
-    int64_t total4 = (int64_t)B * T * (K / 4);
-    RECALGO_REQUIRE(total4 < (1ll << 31));
-    if (total4 == 0) return 0;
-    hipLaunchKernelGGL(seq_gather_fwd_kernel, dim3(cdiv(total4, kThreads)), dim3(kThreads), 0,
-                       as_stream(stream), values, offsets, reinterpret_cast<const float4*>(table),
-                       (unsigned)total4, (unsigned)T, (unsigned)(K / 4),
-                       reinterpret_cast<float4*>(out), seq_len);
+    RECALGO_REQUIRE(B >= 0 && T > 0 && K > 0);
+    const int vec = K % 4 == 0 ? 4 : 1;
+    int64_t total = (int64_t)B * T * (K / vec);
+    RECALGO_REQUIRE(total < (1ll << 31));
+    if (total == 0) return 0;
+    if (vec == 4)
+        hipLaunchKernelGGL(seq_gather_fwd_kernel<4>, dim3(cdiv(total, kThreads)), dim3(kThreads), 0,
+                           as_stream(stream), values, offsets, table, (unsigned)total, (unsigned)T,
+                           (unsigned)(K / 4), out, seq_len);
+    else
+        hipLaunchKernelGGL(seq_gather_fwd_kernel<1>, dim3(cdiv(total, kThreads)), dim3(kThreads), 0,
+                           as_stream(stream), values, offsets, table, (unsigned)total, (unsigned)T, (unsigned)K,
+                           out, seq_len);
     RECALGO_RETURN_LAST();
 }
 
 RECALGO_EXPORT int recalgo_sequence_gather_bwd(const int64_t* values, const int64_t* offsets,
                                                const float* g, int B, int T, int K,
                                                float* grad_table, recalgo_stream_t stream) {
-    RECALGO_REQUIRE(B >= 0 && T > 0 && K > 0 && K % 4 == 0);
-    int64_t total4 = (int64_t)B * T * (K / 4);
-    RECALGO_REQUIRE(total4 < (1ll << 31));
-    if (total4 == 0) return 0;
-    hipLaunchKernelGGL(seq_gather_bwd_kernel, dim3(cdiv(total4, kThreads)), dim3(kThreads), 0,
-                       as_stream(stream), values, offsets, reinterpret_cast<const float4*>(g),
-                       (unsigned)total4, (unsigned)T, (unsigned)(K / 4), grad_table);
+    RECALGO_REQUIRE(B >= 0 && T > 0 && K > 0 && K <= 64);
+    int64_t BT = (int64_t)B * T;
+    RECALGO_REQUIRE(BT < (1ll << 31));
+    if (BT == 0) return 0;
+    if (K % 4 == 0) {
+        ENSURE_SMEM(seq_gather_bwd_kernel<4>, agg_smem(K));
+        hipLaunchKernelGGL(seq_gather_bwd_kernel<4>, dim3(cdiv(BT, kExPerBlk)), dim3(kThreads), agg_smem(K),
+                           as_stream(stream), values, offsets, g, (unsigned)BT, (unsigned)T, (unsigned)(K / 4),
+                           grad_table);
+    } else {
+        ENSURE_SMEM(seq_gather_bwd_kernel<1>, agg_smem(K));
+        hipLaunchKernelGGL(seq_gather_bwd_kernel<1>, dim3(cdiv(BT, kExPerBlk)), dim3(kThreads), agg_smem(K),
+                           as_stream(stream), values, offsets, g, (unsigned)BT, (unsigned)T, (unsigned)K,
+                           grad_table);
+    }
     RECALGO_RETURN_LAST();
 }
 
 namespace {
 constexpr int kDeepfmEB = 4;
-inline size_t deepfm_smem(int F, int K, int extra_per_ex) {
-    return (size_t)kDeepfmEB * (F * K + 16 + extra_per_ex) * sizeof(float);
-}
 }  // namespace
 
 RECALGO_EXPORT int recalgo_deepfm_sparse_fwd(const int64_t* ids, const float* arena,
                                              const float* w1, const float* bias,
                                              const int64_t* row_base, int B, int F, int K,
-                                             float* emb, float* fm1, float* fm2,
+                                             float* emb, float* fm1, float* fm2, float* field_sum,
                                              recalgo_stream_t stream) {
-    RECALGO_REQUIRE(B >= 0 && F > 0 && K > 0 && K % 4 == 0 && K <= 64);
+    RECALGO_REQUIRE(B >= 0 && F > 0 && K > 0 && K % 4 == 0 && K <= 64 && field_sum != nullptr);
     if (B == 0) return 0;
-    size_t smem = deepfm_smem(F, K, F);
+    size_t smem = (size_t)kDeepfmEB * (F * K + 16 + F) * sizeof(float);
     RECALGO_REQUIRE(smem <= 64 * 1024);
     hipLaunchKernelGGL(deepfm_sparse_fwd_kernel<kDeepfmEB>, dim3(cdiv(B, kDeepfmEB)),
                        dim3(kThreads), smem, as_stream(stream), ids,
                        reinterpret_cast<const float4*>(arena), w1, bias, row_base, (unsigned)B,
-                       (unsigned)F, (unsigned)(K / 4), reinterpret_cast<float4*>(emb), fm1, fm2);
+                       (unsigned)F, (unsigned)(K / 4), reinterpret_cast<float4*>(emb), fm1, fm2, field_sum);
     RECALGO_RETURN_LAST();
 }
 
 RECALGO_EXPORT int recalgo_deepfm_sparse_bwd(const int64_t* ids, const float* emb,
-                                             const float* g_emb, const float* g_fm1,
-                                             const float* g_fm2, const int64_t* row_base, int B,
-                                             int F, int K, float* grad_arena, float* grad_w1,
+                                             const float* field_sum, const float* g_emb,
+                                             const float* g_fm1, const float* g_fm2,
+                                             const int64_t* row_base, int B, int F, int K,
+                                             float* grad_arena, float* grad_w1,
                                              recalgo_stream_t stream) {
     RECALGO_REQUIRE(B >= 0 && F > 0 && K > 0 && K % 4 == 0 && K <= 64);
     if (B == 0) return 0;
-    size_t smem = deepfm_smem(F, K, K);
-    RECALGO_REQUIRE(smem <= 64 * 1024);
-    hipLaunchKernelGGL(deepfm_sparse_bwd_kernel<kDeepfmEB>, dim3(cdiv(B, kDeepfmEB)),
-                       dim3(kThreads), smem, as_stream(stream), ids,
-                       reinterpret_cast<const float4*>(emb),
-                       reinterpret_cast<const float4*>(g_emb), g_fm1, g_fm2, row_base, (unsigned)B,
-                       (unsigned)F, (unsigned)(K / 4), grad_arena, grad_w1);
+    ENSURE_SMEM(deepfm_sparse_bwd_kernel, agg_smem(K + 1));
+    hipLaunchKernelGGL(deepfm_sparse_bwd_kernel, dim3(F, cdiv(B, kExPerBlk)), dim3(kThreads), agg_smem(K + 1),
+                       as_stream(stream), ids, reinterpret_cast<const float4*>(emb),
+                       reinterpret_cast<const float4*>(field_sum), reinterpret_cast<const float4*>(g_emb),
+                       g_fm1, g_fm2, row_base, (unsigned)B, (unsigned)F, (unsigned)(K / 4), grad_arena, grad_w1);
     RECALGO_RETURN_LAST();
 }

@@ -1,0 +1,419 @@
+"""tf.estimator / tf.train look-alikes: the call surface the reference's model scripts drive
+(algorithm/DeepFM/deepfm.py:231-343 and the same skeleton in every model).
+
+  model_fn(features, labels, mode, params) -> EstimatorSpec     (unchanged contract)
+  Estimator(model_fn, params, config).train / evaluate / predict, train_and_evaluate
+
+Execution model (MI355X-first, not TF's): model_fn is run eagerly once per step on the
+Estimator's VariableStore; its kernels are enqueued on one HIP stream.  For fixed-shape batches
+the whole step (forward, backward, TF1-Adam) is captured once into a hipGraph and replayed
+(`GraphedTrainStep`), so a step costs one graph launch instead of ~40 kernel launches.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Callable, Dict, Iterable, Optional
+
+import torch
+
+from . import ops
+from .variables import VariableStore, use_store
+
+
+class ModeKeys:
+    TRAIN = "train"
+    EVAL = "eval"
+    PREDICT = "infer"
+
+
+class EstimatorSpec:
+    def __init__(self, mode, predictions=None, loss=None, train_op=None, eval_metric_ops=None,
+                 export_outputs=None, training_hooks=None, **_ignored):
+        self.mode, self.predictions, self.loss, self.train_op = mode, predictions, loss, train_op
+        self.eval_metric_ops = eval_metric_ops
+        self.export_outputs, self.training_hooks = export_outputs, training_hooks
+
+
+class RunConfig:
+    def __init__(self, model_dir=None, save_checkpoints_steps=None, device=None, seed=42,
+                 use_hip_graph=True, **_ignored):
+        self.model_dir, self.save_checkpoints_steps = model_dir, save_checkpoints_steps
+        self.device, self.seed, self.use_hip_graph = device, seed, use_hip_graph
+
+
+class TrainSpec:
+    def __init__(self, input_fn, max_steps=None, hooks=None):
+        self.input_fn, self.max_steps, self.hooks = input_fn, max_steps, hooks
+
+
+class EvalSpec:
+    def __init__(self, input_fn, steps=None, throttle_secs=600, exporters=None, **_ignored):
+        self.input_fn, self.steps, self.throttle_secs, self.exporters = input_fn, steps, throttle_secs, exporters
+
+
+# --------------------------------------------------------------------------------------------
+# tf.train.AdamOptimizer (a15)
+# --------------------------------------------------------------------------------------------
+class TrainOp:
+    def __init__(self, optimizer: "AdamOptimizer", loss: torch.Tensor, store: VariableStore):
+        self.optimizer, self.loss, self.store = optimizer, loss, store
+
+    def run(self):
+        self.loss.backward()
+        self.optimizer.apply_gradients(self.store)
+
+
+class AdamOptimizer:
+    """tf.train.AdamOptimizer(learning_rate, beta1, beta2, epsilon).minimize(loss):
+    dense TF1 semantics for every variable, embedding tables included."""
+
+    def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        self.lr, self.beta1, self.beta2, self.eps = float(learning_rate), beta1, beta2, epsilon
+
+    def minimize(self, loss, global_step=None) -> TrainOp:
+        from .variables import current_store
+        return TrainOp(self, loss, current_store())
+
+    def apply_gradients(self, store: VariableStore, grad_hook: Optional[Callable] = None):
+        st = store.opt_state
+        if st is None:
+            st = store.opt_state = {
+                "step": torch.zeros(1, dtype=torch.int64, device=store.device),
+                "lr_t": torch.zeros(1, dtype=torch.float32, device=store.device),
+            }
+        if grad_hook is not None:           # data-parallel all-reduce of the flat dense grads
+            grad_hook(store)
+        ops.adam_tf1_advance_(st["step"], st["lr_t"], self.lr, self.beta1, self.beta2)
+        kw = dict(step=-1, lr=self.lr, beta1=self.beta1, beta2=self.beta2, eps=self.eps,
+                  zero_grad=True, lr_t_dev=st["lr_t"])
+        if store.flat is not None and store.flat.numel():
+            ops.adam_tf1_(store.flat, store.flat_grad, store.flat_m, store.flat_v, **kw)
+        for ar in store.arenas.values():
+            if ar.weight is not None and ar.trainable:
+                ops.adam_tf1_(ar.weight.view(-1), ar.grad.view(-1), ar.m.view(-1), ar.v.view(-1), **kw)
+
+
+def get_global_step():
+    return None
+
+
+# --------------------------------------------------------------------------------------------
+# tf.metrics.{accuracy, auc} (a14) — streaming accumulators
+# --------------------------------------------------------------------------------------------
+class Metric:
+    def update(self):
+        raise NotImplementedError
+
+    def result(self) -> float:
+        raise NotImplementedError
+
+
+class AccuracyMetric(Metric):
+    def __init__(self, labels, predictions):
+        self.labels, self.predictions = labels, predictions
+        self.correct, self.total = 0.0, 0.0
+
+    def merge(self, other):
+        self.labels, self.predictions = other.labels, other.predictions
+
+    def update(self):
+        self.correct += float((self.labels.reshape(-1) == self.predictions.reshape(-1)).sum())
+        self.total += self.labels.numel()
+
+    def result(self):
+        return self.correct / max(self.total, 1.0)
+
+
+class AUCMetric(Metric):
+    """tf.metrics.auc defaults: 200 thresholds, trapezoidal ROC."""
+
+    def __init__(self, labels, predictions, num_thresholds=200):
+        self.labels, self.predictions, self.n = labels, predictions, num_thresholds
+        eps = 1e-7
+        th = [(i + 1) * 1.0 / (num_thresholds - 1) for i in range(num_thresholds - 2)]
+        self.th = torch.tensor([0.0 - eps] + th + [1.0 + eps], dtype=torch.float32)
+        self.tp = torch.zeros(num_thresholds, dtype=torch.float64)
+        self.fp = torch.zeros_like(self.tp)
+        self.fn = torch.zeros_like(self.tp)
+        self.tn = torch.zeros_like(self.tp)
+
+    def merge(self, other):
+        self.labels, self.predictions = other.labels, other.predictions
+
+    def update(self):
+        p = self.predictions.detach().reshape(1, -1).float().cpu()
+        y = self.labels.detach().reshape(1, -1).cpu() > 0.5
+        pred_pos = p > self.th.unsqueeze(1)
+        self.tp += (pred_pos & y).sum(1)
+        self.fp += (pred_pos & ~y).sum(1)
+        self.fn += (~pred_pos & y).sum(1)
+        self.tn += (~pred_pos & ~y).sum(1)
+
+    def result(self):
+        eps = 1e-7
+        tpr = (self.tp + eps) / (self.tp + self.fn + eps)
+        fpr = self.fp / (self.fp + self.tn + eps)
+        return float(((fpr[:-1] - fpr[1:]) * (tpr[:-1] + tpr[1:]) / 2).sum())
+
+
+class metrics:  # namespace mirror of tf.metrics
+    @staticmethod
+    def accuracy(labels, predictions):
+        m = AccuracyMetric(labels, predictions)
+        return (m, m)
+
+    @staticmethod
+    def auc(labels, predictions, num_thresholds=200):
+        m = AUCMetric(labels, predictions, num_thresholds)
+        return (m, m)
+
+
+# --------------------------------------------------------------------------------------------
+# hipGraph-captured training step
+# --------------------------------------------------------------------------------------------
+def _tree_tensors(obj, prefix=""):
+    from .feature_column import Ragged
+    if isinstance(obj, torch.Tensor):
+        yield prefix, obj
+    elif isinstance(obj, Ragged):
+        yield prefix + ".values", obj.values
+        yield prefix + ".offsets", obj.offsets
+    elif isinstance(obj, dict):
+        for k in sorted(obj):
+            yield from _tree_tensors(obj[k], f"{prefix}/{k}")
+
+
+class GraphedTrainStep:
+    """Capture `step_fn(features, labels)` (forward + backward + optimizer, everything enqueued
+    on the current stream) into a hipGraph over static input buffers; `__call__` copies the new
+    batch into the static buffers and replays.  Shapes must not change between calls."""
+
+    def __init__(self, step_fn: Callable, features, labels, warmup: int = 3):
+        self.step_fn = step_fn
+        self.static_f, self.static_l = features, labels
+        self._static = list(_tree_tensors(features, "f")) + list(_tree_tensors(labels, "l"))
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self.out = step_fn(features, labels)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = step_fn(features, labels)
+        self.warmup_steps = warmup
+
+    def load(self, features, labels):
+        new = list(_tree_tensors(features, "f")) + list(_tree_tensors(labels, "l"))
+        for (k0, dst), (k1, src) in zip(self._static, new):
+            if k0 != k1 or dst.shape != src.shape:
+                raise ValueError(f"graphed step: input {k1} changed shape/structure")
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+
+    def __call__(self, features=None, labels=None):
+        if features is not None:
+            self.load(features, labels)
+        self.graph.replay()
+        return self.out
+
+
+# --------------------------------------------------------------------------------------------
+# Estimator
+# --------------------------------------------------------------------------------------------
+class Estimator:
+    def __init__(self, model_fn, params=None, config: Optional[RunConfig] = None, model_dir=None):
+        self.model_fn, self.params = model_fn, params or {}
+        self.config = config or RunConfig(model_dir=model_dir)
+        dev = self.config.device
+        if dev is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("recalgorithm_amd needs a HIP device (no CPU fallback)")
+            dev = "cuda"
+        self.device = torch.device(dev)
+        self.store = VariableStore(self.device, seed=self.config.seed)
+        self.global_step = 0
+        self._built = False
+        self.grad_hook = None     # set by parallel wrappers (dense-grad all-reduce)
+
+    # -- plumbing -------------------------------------------------------------------------
+    def _to_device(self, features, labels):
+        from .feature_column import Ragged
+
+        def mv(x):
+            if isinstance(x, torch.Tensor):
+                return x.to(self.device, non_blocking=True)
+            if isinstance(x, Ragged):
+                return Ragged(mv(x.values), mv(x.offsets))
+            if isinstance(x, dict):
+                return {k: mv(v) for k, v in x.items()}
+            return x
+        return mv(features), mv(labels)
+
+    def _call_model_fn(self, features, labels, mode) -> EstimatorSpec:
+        with use_store(self.store):
+            self.store.begin_call()
+            return self.model_fn(features, labels, mode, self.params)
+
+    def _build(self, features, labels, mode):
+        if self._built:
+            return
+        self.store.building = True
+        with torch.no_grad():
+            self._call_model_fn(features, labels, mode)
+        self.store.finalize()
+        self._built = True
+        self._maybe_restore()
+
+    def build(self, features, labels=None, mode=ModeKeys.TRAIN):
+        features, labels = self._to_device(features, labels)
+        self._build(features, labels, mode)
+        return self
+
+    def train_step(self, features, labels):
+        """One eager training step on device-resident inputs; returns the loss tensor."""
+        spec = self._call_model_fn(features, labels, ModeKeys.TRAIN)
+        op = spec.train_op
+        op.loss.backward()
+        op.optimizer.apply_gradients(self.store, self.grad_hook)
+        return spec.loss.detach()
+
+    # -- public API -----------------------------------------------------------------------
+    def train(self, input_fn, steps=None, max_steps=None, hooks=None, log_every=100):
+        it = iter(input_fn())
+        graphed = None
+        t0 = time.time()
+        n = 0
+        while True:
+            if max_steps is not None and self.global_step >= max_steps:
+                break
+            if steps is not None and n >= steps:
+                break
+            try:
+                features, labels = next(it)
+            except StopIteration:
+                break
+            features, labels = self._to_device(features, labels)
+            self._build(features, labels, ModeKeys.TRAIN)
+            loss = None
+            # the first two steps run eagerly (they also warm the allocator and hipBLASLt);
+            # from the third fixed-shape batch on, the step is one hipGraph replay
+            if self.config.use_hip_graph and _static_batch(features) and n >= 2:
+                try:
+                    if graphed is None:
+                        graphed = GraphedTrainStep(self.train_step, features, labels, warmup=0)
+                        loss = graphed()
+                    else:
+                        loss = graphed(features, labels)
+                except ValueError:       # last partial batch: eager step
+                    loss = self.train_step(features, labels)
+            else:
+                loss = self.train_step(features, labels)
+            self.global_step += 1
+            n += 1
+            if log_every and self.global_step % log_every < 1:
+                print(f"[recalgo] step {self.global_step} loss {float(loss):.6f} "
+                      f"({n / max(time.time() - t0, 1e-9):.1f} steps/s)", flush=True)
+            sc = self.config.save_checkpoints_steps
+            if sc and self.config.model_dir and self.global_step % sc == 0:
+                self.save_checkpoint()
+        if self.config.model_dir:
+            self.save_checkpoint()
+        return self
+
+    @torch.no_grad()
+    def evaluate(self, input_fn, steps=None) -> Dict[str, float]:
+        agg: Dict[str, Metric] = {}
+        loss_sum, nb = 0.0, 0
+        for i, (features, labels) in enumerate(input_fn()):
+            if steps is not None and i >= steps:
+                break
+            features, labels = self._to_device(features, labels)
+            self._build(features, labels, ModeKeys.EVAL)
+            spec = self._call_model_fn(features, labels, ModeKeys.EVAL)
+            for k, (m, _) in (spec.eval_metric_ops or {}).items():
+                if k in agg:
+                    agg[k].merge(m)
+                else:
+                    agg[k] = m
+                agg[k].update()
+            loss_sum += float(spec.loss)
+            nb += 1
+        out = {k: m.result() for k, m in agg.items()}
+        out["loss"] = loss_sum / max(nb, 1)
+        out["global_step"] = self.global_step
+        return out
+
+    @torch.no_grad()
+    def predict(self, input_fn) -> Iterable[Dict[str, object]]:
+        for features, labels in _with_labels(input_fn()):
+            features, labels = self._to_device(features, labels)
+            self._build(features, labels, ModeKeys.PREDICT)
+            spec = self._call_model_fn(features, None, ModeKeys.PREDICT)
+            preds = {k: v.detach().cpu().numpy() for k, v in spec.predictions.items()}
+            B = len(next(iter(preds.values())))
+            for b in range(B):
+                yield {k: v[b] for k, v in preds.items()}
+
+    # -- checkpoints (RunConfig(model_dir, save_checkpoints_steps)) -------------------------
+    def _ckpt_path(self):
+        return os.path.join(self.config.model_dir, "model.ckpt.pt")
+
+    def save_checkpoint(self):
+        os.makedirs(self.config.model_dir, exist_ok=True)
+        state = {
+            "global_step": self.global_step,
+            "variables": {k: v.detach().cpu() for k, v in self.store.named_arrays().items()},
+            "flat_m": None if self.store.flat_m is None else self.store.flat_m.cpu(),
+            "flat_v": None if self.store.flat_v is None else self.store.flat_v.cpu(),
+            "arena_m": {n: a.m.cpu() for n, a in self.store.arenas.items()},
+            "arena_v": {n: a.v.cpu() for n, a in self.store.arenas.items()},
+            "opt_step": None if self.store.opt_state is None else int(self.store.opt_state["step"]),
+        }
+        tmp = self._ckpt_path() + ".tmp"
+        torch.save(state, tmp)
+        os.replace(tmp, self._ckpt_path())
+
+    def _maybe_restore(self):
+        md = self.config.model_dir
+        if not md or not os.path.exists(self._ckpt_path()):
+            return
+        state = torch.load(self._ckpt_path(), map_location="cpu")
+        arrays = self.store.named_arrays()
+        for k, v in state["variables"].items():
+            if k in arrays and arrays[k].shape == v.shape:
+                arrays[k].copy_(v)
+        if state.get("flat_m") is not None and self.store.flat_m.shape == state["flat_m"].shape:
+            self.store.flat_m.copy_(state["flat_m"])
+            self.store.flat_v.copy_(state["flat_v"])
+        for n, a in self.store.arenas.items():
+            if n in state.get("arena_m", {}) and a.m.shape == state["arena_m"][n].shape:
+                a.m.copy_(state["arena_m"][n])
+                a.v.copy_(state["arena_v"][n])
+        if state.get("opt_step") is not None:
+            self.store.opt_state = {
+                "step": torch.tensor([state["opt_step"]], dtype=torch.int64, device=self.device),
+                "lr_t": torch.zeros(1, device=self.device)}
+        self.global_step = state["global_step"]
+
+
+def _static_batch(features) -> bool:
+    from .feature_column import Ragged
+    return all(isinstance(v, torch.Tensor) for v in features.values()) and \
+        not any(isinstance(v, Ragged) for v in features.values())
+
+
+def _with_labels(it):
+    for item in it:
+        if isinstance(item, tuple) and len(item) == 2:
+            yield item
+        else:
+            yield item, None
+
+
+def train_and_evaluate(estimator: Estimator, train_spec: TrainSpec, eval_spec: EvalSpec):
+    """tf.estimator.train_and_evaluate (deepfm.py:323): train to max_steps, then evaluate."""
+    estimator.train(train_spec.input_fn, max_steps=train_spec.max_steps)
+    return estimator.evaluate(eval_spec.input_fn, steps=eval_spec.steps)

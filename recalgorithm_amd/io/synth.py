@@ -1,0 +1,187 @@
+"""Seeded synthetic "WeChat-shaped" CTR data.
+
+26 single-valued categorical fields (the six reference names + c06..c25), keys
+"<name>_<int>" like /root/reference dataset/wechat_algo_data1/DataGenerator.py:147-159, Zipf
+ids, 1 % OOV (''), 16 dense floats log1p(Poisson(3)) (DataGenerator.py:374-380), an optional
+<=50-long `his_read_comment_7d_seq` history over the feedid vocabulary and a `manual_tag_list`
+bag, label `read_comment` ~ Bernoulli(0.0356) (EDA.ipynb cell 30).
+
+Two forms: (a) vocabulary files + TFRecord of tf.train.Example (the plumbing config), and
+(b) device-resident already-encoded id tensors (the throughput configs).
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import tfrecord
+
+REAL_FIELDS = ["userid", "feedid", "device", "authorid", "bgm_song_id", "bgm_singer_id"]
+REAL_VOCABS = [20000, 106444, 2, 18789, 25159, 17500]
+DENSE_FEATURES = [
+    "videoplayseconds", "u_read_comment_7d_sum", "u_like_7d_sum", "u_click_avatar_7d_sum",
+    "u_forward_7d_sum", "u_comment_7d_sum", "u_follow_7d_sum", "u_favorite_7d_sum",
+    "i_read_comment_7d_sum", "i_like_7d_sum", "i_click_avatar_7d_sum", "i_forward_7d_sum",
+    "i_comment_7d_sum", "i_follow_7d_sum", "i_favorite_7d_sum", "c_user_author_read_comment_7d_sum",
+]
+LABELS = ["read_comment", "comment", "like", "click_avatar", "forward", "follow", "favorite"]
+
+
+def field_names(n_fields: int = 26) -> List[str]:
+    return REAL_FIELDS[:n_fields] + [f"c{i:02d}" for i in range(len(REAL_FIELDS), n_fields)]
+
+
+def vocab_sizes(n_fields: int = 26, max_vocab: int = 1_000_000) -> List[int]:
+    """Six real-field sizes + log-spaced sizes in [1e2, max_vocab] (seed independent)."""
+    extra = n_fields - len(REAL_VOCABS)
+    if extra <= 0:
+        return REAL_VOCABS[:n_fields]
+    logs = np.linspace(2.0, np.log10(max_vocab), extra)
+    return REAL_VOCABS + [int(round(10 ** x)) for x in logs]
+
+
+def zipf_ids(rng: np.random.Generator, n: int, vocab: int, s: float = 1.05) -> np.ndarray:
+    """Truncated Zipf(s) over [0, vocab) by inverse-CDF on the exact pmf."""
+    ranks = np.arange(1, vocab + 1, dtype=np.float64)
+    cdf = np.cumsum(ranks ** (-s))
+    cdf /= cdf[-1]
+    return np.searchsorted(cdf, rng.random(n), side="left").astype(np.int64)
+
+
+@dataclass
+class SynthSpec:
+    n_fields: int = 26
+    max_vocab: int = 1_000_000
+    oov_frac: float = 0.01
+    with_dense: bool = False
+    with_history: bool = False
+    with_tags: bool = False
+    history_len: Optional[int] = None        # fixed length (throughput) or None = U{0..50}
+    max_history: int = 50
+    tag_vocab: int = 350
+    seed: int = 1234
+    names: List[str] = field(default_factory=list)
+    vocabs: List[int] = field(default_factory=list)
+
+    def __post_init__(self):
+        if not self.names:
+            self.names = field_names(self.n_fields)
+        if not self.vocabs:
+            self.vocabs = vocab_sizes(self.n_fields, self.max_vocab)
+
+
+def make_id_batch(spec: SynthSpec, B: int, batch_index: int = 0, names: Optional[List[str]] = None):
+    """-> (ids int64 [B, F] in the order of `names` (default spec.names), labels float32 [B,1],
+    dense float32 [B,16] or None, history (values, offsets) or None, tags (values, offsets) or None).
+    ids == -1 marks OOV."""
+    rng = np.random.default_rng([spec.seed, batch_index])
+    names = names or spec.names
+    vmap = dict(zip(spec.names, spec.vocabs))
+    ids = np.empty((B, len(names)), dtype=np.int64)
+    for j, nm in enumerate(names):
+        col = zipf_ids(rng, B, vmap[nm])
+        if spec.oov_frac > 0:
+            col[rng.random(B) < spec.oov_frac] = -1
+        ids[:, j] = col
+    labels = (rng.random((B, 1)) < 0.0356).astype(np.float32)
+    dense = np.log1p(rng.poisson(3.0, size=(B, 16))).astype(np.float32) if spec.with_dense else None
+    hist = tags = None
+    if spec.with_history:
+        lens = (np.full(B, spec.history_len) if spec.history_len is not None
+                else rng.integers(0, spec.max_history + 1, size=B))
+        off = np.zeros(B + 1, dtype=np.int64)
+        off[1:] = np.cumsum(lens)
+        vals = zipf_ids(rng, int(off[-1]), vmap["feedid"])
+        hist = (vals, off)
+    if spec.with_tags:
+        lens = rng.integers(0, 6, size=B)
+        off = np.zeros(B + 1, dtype=np.int64)
+        off[1:] = np.cumsum(lens)
+        tags = (zipf_ids(rng, int(off[-1]), spec.tag_vocab), off)
+    return ids, labels, dense, hist, tags
+
+
+def device_features(spec: SynthSpec, B: int, device, batch_index: int = 0, sorted_layout: bool = True):
+    """Already-encoded, device-resident (features, labels) for the throughput configs.  The id
+    matrix is laid out in sorted(column-name) order so that fc.input_layer can hand it to the
+    gather kernel without a copy; features[name] are column views of it."""
+    from ..feature_column import Ragged
+    names = sorted(spec.names) if sorted_layout else list(spec.names)
+    ids, labels, dense, hist, tags = make_id_batch(spec, B, batch_index, names)
+    mat = torch.from_numpy(ids).to(device)
+    feats: Dict[str, object] = {nm: mat[:, j] for j, nm in enumerate(names)}
+    feats_meta = {"__ids_matrix__": mat, "__ids_names__": names}
+    if dense is not None:
+        d = torch.from_numpy(dense).to(device)
+        for j, nm in enumerate(DENSE_FEATURES):
+            feats[nm] = d[:, j:j + 1]
+    if hist is not None:
+        feats["his_read_comment_7d_seq"] = Ragged(torch.from_numpy(hist[0]).to(device),
+                                                  torch.from_numpy(hist[1]).to(device))
+    if tags is not None:
+        feats["manual_tag_list"] = Ragged(torch.from_numpy(tags[0]).to(device),
+                                          torch.from_numpy(tags[1]).to(device))
+    lab = {"read_comment": torch.from_numpy(labels).to(device)}
+    return feats, lab, feats_meta
+
+
+# ---- on-disk form: vocabulary files + TFRecord ------------------------------------------------
+def key_of(name: str, i: int) -> bytes:
+    return f"{name}_{i}".encode()
+
+
+def write_vocabularies(spec: SynthSpec, vocab_dir: str) -> None:
+    os.makedirs(vocab_dir, exist_ok=True)
+    for nm, v in zip(spec.names, spec.vocabs):
+        with open(os.path.join(vocab_dir, nm + ".txt"), "wb") as f:
+            f.write(b"\n".join(key_of(nm, i) for i in range(v)) + b"\n")
+    with open(os.path.join(vocab_dir, "manual_tag_id.txt"), "wb") as f:
+        f.write(b"\n".join(key_of("manual_tag_id", i) for i in range(spec.tag_vocab)) + b"\n")
+
+
+def write_tfrecord(spec: SynthSpec, path: str, n_examples: int, chunk: int = 4096,
+                   as_sequence_example: bool = False) -> int:
+    """tf.train.Example per row: 16 float dense, bytes categorical ('' for OOV), 7 float labels
+    (DataGenerator.py:409-425).  List features go into multi-valued bytes_list (the layout the
+    models' parse spec expects) or, with as_sequence_example, into feature_lists exactly like the
+    checked-in writer (quirk B-9: they then parse as empty)."""
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+
+    def gen():
+        done = 0
+        bi = 0
+        while done < n_examples:
+            B = min(chunk, n_examples - done)
+            ids, labels, dense, hist, tags = make_id_batch(spec, B, bi)
+            rng = np.random.default_rng([spec.seed, bi, 7])
+            for r in range(B):
+                ctx = {}
+                if dense is not None:
+                    for j, nm in enumerate(DENSE_FEATURES):
+                        ctx[nm] = ("float", [float(dense[r, j])])
+                for j, nm in enumerate(spec.names):
+                    i = int(ids[r, j])
+                    ctx[nm] = ("bytes", [key_of(nm, i) if i >= 0 else b""])
+                ctx["read_comment"] = ("float", [float(labels[r, 0])])
+                for lb in LABELS[1:]:
+                    ctx[lb] = ("float", [float(rng.random() < 0.02)])
+                lists = {}
+                if hist is not None:
+                    hv = hist[0][hist[1][r]:hist[1][r + 1]]
+                    lists["his_read_comment_7d_seq"] = ("bytes", [key_of("feedid", int(i)) for i in hv])
+                if tags is not None:
+                    tv = tags[0][tags[1][r]:tags[1][r + 1]]
+                    lists["manual_tag_list"] = ("bytes", [key_of("manual_tag_id", int(i)) for i in tv])
+                if as_sequence_example:
+                    yield tfrecord.encode_sequence_example(ctx, lists)
+                else:
+                    ctx.update(lists)
+                    yield tfrecord.encode_example(ctx)
+            done += B
+            bi += 1
+
+    return tfrecord.write_records(path, gen())

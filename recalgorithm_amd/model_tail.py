@@ -1,0 +1,41 @@
+"""The prediction / loss / metric / train_op tail every reference model_fn repeats
+(e.g. /root/reference algorithm/DeepFM/deepfm.py:214-273): sigmoid, mean sigmoid-CE
+(fused HIP kernel, a14), tf.metrics accuracy@0.5 + 200-bucket AUC, Adam(lr, .9, .999, 1e-8)."""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import torch
+
+from . import ops
+from .estimator import AdamOptimizer, EstimatorSpec, ModeKeys, metrics
+
+
+def sigmoid(logit: torch.Tensor) -> torch.Tensor:
+    return torch.sigmoid(logit)
+
+
+def finish_model_fn(mode, logit: torch.Tensor, labels, params,
+                    predictions: Optional[Callable[[torch.Tensor], Dict[str, torch.Tensor]]] = None,
+                    extra_loss: Optional[Callable[[], torch.Tensor]] = None,
+                    label_key: str = "read_comment") -> EstimatorSpec:
+    if mode == ModeKeys.PREDICT:
+        prob = torch.sigmoid(logit)
+        preds = predictions(prob) if predictions else {"probabilities": prob}
+        return EstimatorSpec(mode, predictions=preds, export_outputs={"prediction": preds})
+
+    y = labels[label_key]
+    loss, prob = ops.sigmoid_cross_entropy(logit, y)
+    if extra_loss is not None:
+        extra = extra_loss()
+        if extra is not None:
+            loss = loss + extra
+    acc = metrics.accuracy(labels=y, predictions=(prob >= 0.5).to(torch.float32))
+    auc = metrics.auc(labels=y, predictions=prob)
+    if mode == ModeKeys.EVAL:
+        return EstimatorSpec(mode, loss=loss, eval_metric_ops={"eval_accuracy": acc, "eval_auc": auc})
+
+    assert mode == ModeKeys.TRAIN
+    optimizer = AdamOptimizer(learning_rate=params["learning_rate"], beta1=0.9, beta2=0.999, epsilon=1e-8)
+    train_op = optimizer.minimize(loss=loss)
+    return EstimatorSpec(mode, loss=loss, train_op=train_op, predictions={"probabilities": prob})

@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 from torch.autograd import Function
 
-from .variables import Variable, VariableStore, glorot_uniform, ones, zeros
+from .variables import Variable, current_store, glorot_uniform, ones, zeros
 
 
 class _DenseFn(Function):
@@ -46,11 +46,12 @@ class _DenseFn(Function):
         return None, dx.view(ctx.xshape), None, None, None
 
 
-def dense(store: VariableStore, x: torch.Tensor, units, activation: Optional[str] = None,
+def dense(x: torch.Tensor, units, activation: Optional[str] = None,
           use_bias: bool = True, name: Optional[str] = None) -> torch.Tensor:
     """tf.layers.dense(x, units, activation=None|relu, use_bias, name).  `units` may be a
     str (the reference passes FLAGS.hidden_units.split(','), deepfm.py:286; quirk B-2).
     Variables: <scope>/<name>/kernel (glorot-uniform), <scope>/<name>/bias (zeros)."""
+    store = current_store()
     units = int(units)
     name = name or store.auto_name("dense")
     with store.variable_scope(name):
@@ -103,10 +104,11 @@ class _BatchNormInferFn(Function):
         return g * scale, None, None
 
 
-def batch_normalization(store: VariableStore, x: torch.Tensor, training: bool = False,
+def batch_normalization(x: torch.Tensor, training: bool = False,
                         momentum: float = 0.99, epsilon: float = 1e-3,
                         name: Optional[str] = None) -> torch.Tensor:
     """tf.layers.batch_normalization on (B, C)."""
+    store = current_store()
     name = name or store.auto_name("batch_normalization")
     C = x.shape[-1]
     with store.variable_scope(name):

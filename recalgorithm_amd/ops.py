@@ -167,21 +167,22 @@ class _DeepFMSparseFn(Function):
         emb = torch.empty(B, F * K, device=ids.device, dtype=torch.float32)
         fm1 = torch.empty(B, 1, device=ids.device, dtype=torch.float32)
         fm2 = torch.empty(B, 1, device=ids.device, dtype=torch.float32)
+        fsum = torch.empty(B, K, device=ids.device, dtype=torch.float32)
         _lib.check(_lib_().recalgo_deepfm_sparse_fwd(
             _p(ids), _p(arena.weight), _p(w1.weight), _p(bias.data), _p(row_base), B, F, K,
-            _p(emb), _p(fm1), _p(fm2), _stream(ids)), "recalgo_deepfm_sparse_fwd")
+            _p(emb), _p(fm1), _p(fm2), _p(fsum), _stream(ids)), "recalgo_deepfm_sparse_fwd")
         ctx.args = (ids, arena, w1, bias, row_base)
-        ctx.save_for_backward(emb)
+        ctx.save_for_backward(emb, fsum)
         return emb, fm1, fm2
 
     @staticmethod
     def backward(ctx, g_emb, g_fm1, g_fm2):
         ids, arena, w1, bias, row_base = ctx.args
-        (emb,) = ctx.saved_tensors
+        emb, fsum = ctx.saved_tensors
         B, F = ids.shape
         g_emb, g_fm1, g_fm2 = g_emb.contiguous(), g_fm1.contiguous(), g_fm2.contiguous()
         _lib.check(_lib_().recalgo_deepfm_sparse_bwd(
-            _p(ids), _p(emb), _p(g_emb), _p(g_fm1), _p(g_fm2), _p(row_base), B, F, arena.K,
+            _p(ids), _p(emb), _p(fsum), _p(g_emb), _p(g_fm1), _p(g_fm2), _p(row_base), B, F, arena.K,
             _p(arena.grad), _p(w1.grad), _stream(ids)), "recalgo_deepfm_sparse_bwd")
         torch.sum(g_fm1, dim=0, out=bias.grad.view(1))
         return None, None, None, None, None, None

@@ -93,6 +93,30 @@ class VariableStore:
         # tensor inputs requires grad (their parameter grads are written as side effects)
         self.anchor = torch.zeros(1, device=self.device, requires_grad=True)
         self.arenas: Dict[str, "EmbeddingArena"] = {}
+        self.seed = seed
+        # building == True: a dry model_fn pass that only registers variables / tables
+        # (input layers return zeros and launch nothing); see Estimator._build
+        self.building = False
+        self.shared_tables: Dict[tuple, str] = {}
+        self.opt_state = None            # device-side Adam step counter / lr_t (estimator.py)
+        self._rb_cache: Dict[tuple, torch.Tensor] = {}
+
+    def row_base_tensor(self, arena: "EmbeddingArena", table_names: Sequence[str]) -> torch.Tensor:
+        """int64 device tensor of the first arena row of each named table (cached)."""
+        key = (arena.name, tuple(table_names))
+        t = self._rb_cache.get(key)
+        if t is None:
+            t = torch.tensor([arena.tables[n][0] for n in table_names], dtype=torch.int64,
+                             device=self.device)
+            self._rb_cache[key] = t
+        return t
+
+    def finalize(self):
+        """End of the building pass: allocate the arenas and pack the dense variables."""
+        for ar in self.arenas.values():
+            ar.materialize()
+        self.pack()
+        self.building = False
 
     # -- scopes -------------------------------------------------------------------------
     @contextlib.contextmanager
@@ -200,6 +224,45 @@ class VariableStore:
         return out
 
 
+def named_grads(store: VariableStore) -> Dict[str, torch.Tensor]:
+    """name -> gradient tensor, same keys as VariableStore.named_arrays()."""
+    out = {n: v.grad for n, v in store.vars.items() if v.grad is not None}
+    for ar in store.arenas.values():
+        for tn, (rb, vocab) in ar.tables.items():
+            out[tn] = ar.grad[rb:rb + vocab]
+    return out
+
+
+_STORE_STACK: List[VariableStore] = []
+
+
+def current_store() -> VariableStore:
+    """The store model-building functions create their variables in (TF's default graph +
+    variable scope stack).  Set by `use_store` (the Estimator does this around model_fn)."""
+    if not _STORE_STACK:
+        raise RuntimeError("no active VariableStore: wrap the call in `with use_store(store):`")
+    return _STORE_STACK[-1]
+
+
+@contextlib.contextmanager
+def use_store(store: VariableStore):
+    _STORE_STACK.append(store)
+    try:
+        yield store
+    finally:
+        _STORE_STACK.pop()
+
+
+def variable_scope(name: str):
+    """tf.variable_scope(name) on the current store."""
+    return current_store().variable_scope(name)
+
+
+def get_variable(name: str, shape, initializer=None, trainable: bool = True) -> Variable:
+    """tf.get_variable(name, shape) on the current store (default init glorot-uniform, A-7)."""
+    return current_store().get_variable(name, shape, initializer, trainable)
+
+
 class EmbeddingArena:
     """All embedding tables of width K of one model in one [rows, K] fp32 tensor plus the
     gradient / Adam-moment arenas of the same shape (include/recalgo.h "arena")."""
@@ -211,6 +274,7 @@ class EmbeddingArena:
         self.rows = 0
         self._gen = torch.Generator().manual_seed(seed)
         self.weight = self.grad = self.m = self.v = None
+        self.trainable = True
 
     def add_table(self, name: str, vocab: int, init: Optional[torch.Tensor] = None) -> int:
         if name in self.tables:

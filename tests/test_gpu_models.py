@@ -1,0 +1,140 @@
+"""-m gpu model-level parity: the mirrored model_fns (HIP kernels + hipBLASLt MLP) vs
+oracle/ref_models.py on the same weights and batch: logits, loss, every gradient, and the
+weights after one TF1-Adam step.  Also: hipGraph replay == eager."""
+import pytest
+import torch
+
+from oracle import ref_models as M
+from oracle import ref_ops as R
+from recalgorithm_amd import feature_column as fc
+from recalgorithm_amd.estimator import Estimator, GraphedTrainStep, ModeKeys, RunConfig
+from recalgorithm_amd.io import synth
+from recalgorithm_amd.variables import named_grads
+from tests.util import assert_bit_exact, assert_close
+
+pytestmark = pytest.mark.gpu
+
+ORACLE = {"dcn": M.dcn, "deepfm": M.deepfm}
+
+
+def make(model, dev, n_fields=8, K=16, B=300, hidden=("64", "32"), max_vocab=400, **extra):
+    spec = synth.SynthSpec(n_fields=n_fields, max_vocab=max_vocab, seed=11, oov_frac=0.05)
+    cats = [fc.categorical_column_with_identity(n, v) for n, v in zip(spec.names, spec.vocabs)]
+    if model == "dcn":
+        from recalgorithm_amd.algorithm.DCN.dcn import dcn_model_fn as fn
+        params = {"category_feature_columns": [fc.embedding_column(c, K) for c in cats],
+                  "dense_feature_columns": [], "hidden_units": list(hidden), "num_cross_layer": 3,
+                  "learning_rate": 0.005}
+    elif model == "deepfm":
+        from recalgorithm_amd.algorithm.DeepFM.deepfm import deepfm_model_fn as fn
+        params = {"first_order_feature_columns": [fc.indicator_column(c) for c in cats],
+                  "second_order_feature_columns": [fc.embedding_column(c, K) for c in cats],
+                  "hidden_units": list(hidden), "dropout_rate": 0.0, "batch_norm": True,
+                  "learning_rate": 0.005}
+    params.update(extra)
+    est = Estimator(fn, params, RunConfig(device=dev, seed=5))
+    feats, labels, _ = synth.device_features(spec, B, dev)
+    est.build(feats, labels)
+    return est, params, feats, labels
+
+
+def oracle_inputs(est, feats, labels, dtype=torch.float64):
+    P = {k: v.detach().cpu().to(dtype).requires_grad_(True) for k, v in est.store.named_arrays().items()}
+    cf = {k: (v.cpu() if isinstance(v, torch.Tensor) else (v.values.cpu(), v.offsets.cpu())) for k, v in feats.items()}
+    cf = {k: (v.to(dtype) if isinstance(v, torch.Tensor) and v.is_floating_point() else v) for k, v in cf.items()}
+    cl = {k: v.cpu().to(dtype) for k, v in labels.items()}
+    return P, cf, cl
+
+
+@pytest.mark.parametrize("model", ["dcn", "deepfm"])
+def test_model_forward_backward_adam(dev, model):
+    est, params, feats, labels = make(model, dev)
+    P, cf, cl = oracle_inputs(est, feats, labels)
+    ref = ORACLE[model](P, cf, cl, params, training=True)
+    ref["loss"].backward()
+
+    spec = est._call_model_fn(feats, labels, ModeKeys.TRAIN)
+    assert_close(spec.loss, ref["loss"], what=f"{model} loss")
+    assert_close(spec.predictions["probabilities"], ref["prob"], what=f"{model} prob")
+    spec.loss.backward()
+    grads = named_grads(est.store)
+    skipped = []
+    for name, p in P.items():
+        if p.grad is None:
+            skipped.append(name)
+            continue
+        assert_close(grads[name], p.grad, what=f"{model} d({name})", reduced=True)
+    assert all("moving_" in s or s.endswith("/wl") or s.endswith("/bl") for s in skipped), skipped
+
+    # one TF1-Adam step on both sides
+    before = {k: v.detach().cpu().double().clone() for k, v in est.store.named_arrays().items()}
+    spec.train_op.optimizer.apply_gradients(est.store)
+    after = est.store.named_arrays()
+    for name, p in P.items():
+        if p.grad is None:
+            continue
+        pp, m, v = before[name].clone(), torch.zeros_like(before[name]), torch.zeros_like(before[name])
+        R.adam_tf1_step(pp, p.grad, m, v, 1, params["learning_rate"])
+        # compare the UPDATE (p_after - p_before), not p: at step 1 it is lr*g/(|g| + eps'), i.e.
+        # ~lr*sign(g) — and ill-conditioned in g where |g| ~ eps' = 3e-7, so the bound is
+        # absolute, 2e-4 of the step size lr
+        # absolute: 2e-4 of the step size lr, plus the already-accepted gradient tolerance
+        # propagated through d(update)/dg = lr*eps'/(|g|+eps')^2
+        lr = params["learning_rate"]
+        gref = p.grad.abs()
+        tol_g = 1e-5 * (gref + gref.pow(2).mean().sqrt()) + 1e-6 * gref.max()
+        eps1 = 1e-8 / (1.0 - 0.999) ** 0.5
+        tol = lr * (2e-4 + tol_g * eps1 / (gref + eps1) ** 2)
+        upd = after[name].detach().cpu().double() - before[name]
+        err = (upd - (pp - before[name])).abs()
+        assert bool((err <= tol).all()), \
+            f"{model} adam update {name}: worst err/tol {float((err / tol).max()):.3g}"
+    # gradients were consumed and zeroed by the fused optimizer
+    assert float(est.store.flat_grad.abs().sum()) == 0.0
+    for ar in est.store.arenas.values():
+        assert float(ar.grad.abs().sum()) == 0.0
+
+
+def test_dcn_eval_and_predict_modes(dev):
+    est, params, feats, labels = make("dcn", dev)
+    P, cf, cl = oracle_inputs(est, feats, labels)
+    ref = M.dcn(P, cf, cl, params)
+    ev = est._call_model_fn(feats, labels, ModeKeys.EVAL)
+    assert set(ev.eval_metric_ops) == {"eval_accuracy", "eval_auc"}
+    assert_close(ev.loss, ref["loss"], what="eval loss")
+    pr = est._call_model_fn(feats, None, ModeKeys.PREDICT)
+    assert set(pr.predictions) == {"logit", "probabilities"}
+    assert_close(pr.predictions["logit"], ref["logit"], what="predict logit")
+    for k, (m, _) in ev.eval_metric_ops.items():
+        m.update()
+    auc = ev.eval_metric_ops["eval_auc"][0].result()
+    assert abs(auc - R.tf_metrics_auc(cl["read_comment"], ref["prob"])) < 1e-6
+
+
+def test_deepfm_prediction_keys(dev):
+    est, params, feats, labels = make("deepfm", dev)
+    pr = est._call_model_fn(feats, None, ModeKeys.PREDICT)
+    assert set(pr.predictions) == {"probabilities", "fm_first_order_logit", "fm_second_order_logit", "deep_logit"}
+
+
+def test_string_hyperparameters_accepted(dev):
+    """hidden_units arrive as strings from FLAGS.hidden_units.split(',') (quirk B-2)."""
+    est, params, feats, labels = make("dcn", dev, hidden=("32", "16"))
+    assert est.store.vars["dnn_part/dnn_dense_0/kernel"].shape == (8 * 16, 32)
+
+
+@pytest.mark.parametrize("model", ["dcn", "deepfm"])
+def test_hipgraph_replay_matches_eager(dev, model):
+    estA, params, feats, labels = make(model, dev, B=512)
+    estB, _, _, _ = make(model, dev, B=512)
+    for _ in range(5):
+        la = estA.train_step(feats, labels)
+    g = GraphedTrainStep(estB.train_step, feats, labels, warmup=3)   # 3 eager + capture
+    g()                                                               # replay #1 -> 4 steps
+    lb = g()                                                          # replay #2 -> 5 steps
+    torch.cuda.synchronize()
+    a, b = estA.store.named_arrays(), estB.store.named_arrays()
+    for k in a:
+        assert_close(b[k], a[k], rtol=1e-4, what=f"graph vs eager {k}", reduced=True)
+    assert_close(lb, la, rtol=1e-5, what="graph vs eager loss")
+    assert int(estB.store.opt_state["step"]) == 5
