@@ -143,6 +143,31 @@ int recalgo_cross_bwd(const float* x0, int x_stride, const float* w, const float
                       float* dw, float* db, void* workspace, recalgo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K5  xDeepFM CIN layer on the fp32 matrix cores (implicit GEMM, outer product never stored).
+ * Replaces cin_layer(x0, xk, hk_1, index) algorithm/xDeepFM/cin_layer.py:4-30 (einsum + reshape
+ * + width-1 conv1d + transpose) and the sum-pooling of algorithm/xDeepFM/xdeepfm.py:173.
+ *   out[b, n, d]  = sum_{i<Hk} sum_{j<m} filters[i*m + j, n] * xk[b, i, d] * x0[b, j, d]
+ *   pool[b, pool_col + n] = sum_d out[b, n, d]          (row stride pool_stride; pool may be NULL)
+ *   x0 [B, m, D], xk [B, Hk, D], filters [Hk*m, N] (the reference's (1, Hk*m, N) variable),
+ *   out [B, N, D].   D in {4, 8, 16, 32}; N <= 128.  No bias, no activation (quirk B-8).
+ * ------------------------------------------------------------------------------------------ */
+int recalgo_cin_layer_fwd(const float* x0, const float* xk, const float* filters, int B, int m,
+                          int Hk, int N, int D, float* out, float* pool, int pool_stride,
+                          int pool_col, recalgo_stream_t stream);
+/* Backward (CIN).  Upstream gradient G = g_out (or 0 if NULL) +
+ * broadcast_d(g_pool[b, pool_col + n]) (or 0 if NULL).
+ *   dxk[b,i,d] (=|+=) sum_{j,n} W[(i,j),n] x0[b,j,d] G[b,n,d]      (dxk may be NULL)
+ *   dx0[b,j,d] (=|+=) sum_{i,n} W[(i,j),n] xk[b,i,d] G[b,n,d]
+ *   dfilters[(i,j),n] = sum_{b,d} xk[b,i,d] x0[b,j,d] G[b,n,d]     (overwritten, deterministic)
+ * m, Hk, N <= 128, m >= 4.  workspace: recalgo_cin_layer_bwd_workspace_bytes(). */
+int64_t recalgo_cin_layer_bwd_workspace_bytes(int B, int m, int Hk, int N, int D);
+int recalgo_cin_layer_bwd(const float* x0, const float* xk, const float* filters, const float* g_out,
+                          const float* g_pool, int pool_stride, int pool_col, int B, int m, int Hk,
+                          int N, int D, float* dx0, int dx0_accumulate, float* dxk,
+                          int dxk_accumulate, float* dfilters, void* workspace,
+                          recalgo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * a14  loss tail: sigmoid + mean sigmoid cross entropy, forward and d(loss)/d(logit) fused.
  * Replaces tf.sigmoid + tf.reduce_mean(tf.nn.sigmoid_cross_entropy_with_logits)
  * algorithm/DeepFM/deepfm.py:217,235 (same in all six model_fns).

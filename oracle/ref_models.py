@@ -115,3 +115,23 @@ def deepfm(P, feats, labels, params, training=False, bn_state=None):
     out = _tail(logit, None if labels is None else labels["read_comment"])
     out.update(fm_first_order_logit=fm1, fm_second_order_logit=fm2, deep_logit=deep)
     return out
+
+
+def xdeepfm(P, feats, labels, params, training=False):
+    """algorithm/xDeepFM/xdeepfm.py:139-207."""
+    dense_cols = params.get("dense_feature_columns") or []
+    cat = input_layer(P, feats, params["category_feature_columns"], "category_input/input_layer", {})
+    if dense_cols:
+        linear_vec = torch.cat([input_layer(P, feats, dense_cols, "dense_input/input_layer"), cat], dim=-1)  # :162
+    else:
+        linear_vec = cat
+    linear_logit = R.dense(linear_vec, P["linear_part/dense/kernel"], P["linear_part/dense/bias"])            # :163
+    m, D = len(params["category_feature_columns"]), int(params["embedding_dim"])
+    x0 = cat.reshape(-1, m, D)                                                                               # :167
+    filters = [P[f"cin_part/cin_layer_{i + 1}_filter"] for i in range(len(params["cin_layer_feature_maps"]))]
+    _, p_plus = R.cin_stack(x0, filters)                                                                     # :170-174
+    cin_logit = R.dense(p_plus, P["cin_part/dense/kernel"])                                                  # :175 no bias
+    dnn = _mlp(P, linear_vec, "dnn_part", [f"dense_{i}" for i in range(len(params["hidden_units"]))])
+    n = len(params["hidden_units"])
+    dnn_logit = R.dense(dnn, P["dnn_part/dense/kernel"])                                                     # :182 no bias
+    return _tail(linear_logit + cin_logit + dnn_logit, None if labels is None else labels["read_comment"])

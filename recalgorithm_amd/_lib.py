@@ -29,6 +29,10 @@ SIGNATURES = {
     "recalgo_cross_fwd": (c_int, [P, c_int, P, P, c_int, c_int, c_int, P, c_int, P]),
     "recalgo_cross_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "recalgo_cross_bwd": (c_int, [P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, P, P, P, P, P]),
+    "recalgo_cin_layer_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P]),
+    "recalgo_cin_layer_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "recalgo_cin_layer_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      P, c_int, P, c_int, P, P, P]),
     "recalgo_sigmoid_ce_fwd_bwd": (c_int, [P, P, c_int, c_float, P, P, P, P]),
     "recalgo_adam_tf1_dense": (c_int, [P, P, P, P, c_int64, c_float, P, c_float, c_float, c_float, c_int, P]),
     "recalgo_adam_tf1_advance": (c_int, [P, c_float, c_float, c_float, P, P]),

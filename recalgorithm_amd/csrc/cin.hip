@@ -1,0 +1,488 @@
+// K5: xDeepFM CIN layer (algorithm/xDeepFM/cin_layer.py:4-30, xdeepfm.py:166-175) on the gfx950
+// fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD).
+//
+//   X^{k+1}[b,n,d] = sum_{i,j} W[i*m+j, n] * X^k[b,i,d] * X^0[b,j,d]
+//
+// is an implicit GEMM  C[(b,d), n] = A[(b,d),(i,j)] * W[(i,j), n]  whose A operand
+// A = X^k (x) X^0 (a Khatri-Rao product) is never materialised (the reference writes it to
+// memory: 872 MB at B=4096, Hk=128 — cin_layer.py:21-22): every MFMA A-fragment element is
+// produced in registers by one v_mul from a value of X^k and a value of X^0.
+//
+// One kernel, `cin_contract_kernel`, computes the generalised contraction
+//   out[b,c,d] = sum_{p<HP} sum_{q<HQ} F[p*HQ+q, c] * P[b,p,d] * Q[b,q,d]
+// and serves
+//   forward : P = X^k, Q = X^0, F = W            -> X^{k+1}   (C = H_{k+1})
+//   dX^k    : P = G,   Q = X^0, F = W' [n*m+j, i] -> dX^k      (C = H_k)
+//   dX^0    : P = X^k, Q = G,   F = W''[i*N+n, j] -> dX^0      (C = m)
+// (W', W'' are index permutations of W, made by cin_permute_kernel), and
+// `cin_filter_grad_kernel` computes dW[(i,j),n] = sum_{(b,d)} A[(b,d),(i,j)] * G[(b,d),n]
+// (split over the batch, deterministic second-pass sum).
+//
+// Fragment maps of v_mfma_f32_32x32x2_f32 (guides: cdna_hip_programming.md §3): lane l supplies
+// A[row = l&31][k = l>>5] and B[k = l>>5][col = l&31]; acc reg r holds C[row = (r&3) + 8*(r>>2) +
+// 4*(l>>5)][col = l&31].
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kThreads = 256;     // 4 waves; one 32-row MFMA tile per wave
+constexpr int kTM = 128;          // (b,d) rows per workgroup
+constexpr int kQC = 32;           // q rows of F staged per slab
+
+// ---------------------------------------------------------------------------------------------
+// generalised contraction
+// ---------------------------------------------------------------------------------------------
+template <int D, int NT>
+__global__ __launch_bounds__(kThreads) void cin_contract_kernel(
+    const float* __restrict__ P, const float* __restrict__ Q, const float* __restrict__ F,
+    unsigned B, unsigned HP, unsigned HQ, unsigned C, float* __restrict__ out, int accumulate,
+    float* __restrict__ pool, unsigned pool_stride, unsigned pool_col) {
+    constexpr unsigned EX = kTM / D;           // examples per workgroup
+    constexpr unsigned CS = NT * 32;           // LDS row stride of an F slab (cols zero padded)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const unsigned HQp = (HQ + 1) & ~1u;
+    const unsigned QS = HQp * D + 16;          // +16: the two examples of a 32-lane group hit disjoint banks
+    float* Qs = smem;                          // [EX][QS]
+    float* Fs = smem + EX * QS;                // [2][kQC][CS]
+
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned hi = lane >> 5, l32 = lane & 31;
+    const unsigned row = wave * 32 + l32;      // row of the workgroup tile this lane feeds as A
+    const unsigned exl = row / D, dd = row % D;
+    const unsigned b0 = blockIdx.x * EX;
+    const unsigned b = b0 + exl;
+    const bool valid = b < B;
+
+    // ---- stage the Q tile (contiguous [EX][HQ][D] block of Q) and zero the F slabs ----------
+    for (unsigned e = tid; e < EX * QS; e += kThreads) Qs[e] = 0.f;
+    for (unsigned e = tid; e < 2 * kQC * CS; e += kThreads) Fs[e] = 0.f;
+    __syncthreads();
+    {
+        const unsigned per_ex = HQ * D;
+        for (unsigned e = tid; e < EX * per_ex; e += kThreads) {
+            unsigned ex = e / per_ex, rem = e - ex * per_ex;
+            if (b0 + ex < B) Qs[ex * QS + rem] = Q[(size_t)(b0 + ex) * per_ex + rem];
+        }
+    }
+    const unsigned nqc = (HQ + kQC - 1) / kQC;             // slabs per p
+    const unsigned nslab = HP * nqc;
+    constexpr unsigned kStg = (kQC * CS + kThreads - 1) / kThreads;   // staged floats per thread
+    float stg[kStg];
+    auto slab_rows = [&](unsigned s) { unsigned qc = s % nqc; return min((unsigned)kQC, HQ - qc * kQC); };
+    auto slab_src = [&](unsigned s) { unsigned p = s / nqc, qc = s % nqc; return F + ((size_t)p * HQ + (size_t)qc * kQC) * C; };
+    auto stage_load = [&](unsigned s) {
+        const float* src = slab_src(s);
+        const unsigned n = slab_rows(s) * C;
+#pragma unroll
+        for (unsigned k = 0; k < kStg; ++k) {
+            unsigned e = tid + k * kThreads;
+            stg[k] = e < n ? src[e] : 0.f;
+        }
+    };
+    auto stage_store = [&](unsigned s, unsigned buf) {
+        const unsigned n = slab_rows(s) * C;
+        float* dst = Fs + buf * kQC * CS;
+#pragma unroll
+        for (unsigned k = 0; k < kStg; ++k) {
+            unsigned e = tid + k * kThreads;
+            if (e < n) {
+                unsigned q = e / C, c = e - q * C;
+                dst[q * CS + c] = stg[k];
+            }
+        }
+    };
+    stage_load(0);
+    stage_store(0, 0);
+    __syncthreads();
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+    const float* Pp = P + ((size_t)b * HP) * D + dd;       // P[b, p, dd] at stride D
+    float a_p = valid ? Pp[0] : 0.f;
+    const float* Qlane = Qs + exl * QS + dd;
+
+    for (unsigned s = 0; s < nslab; ++s) {
+        const unsigned buf = s & 1;
+        const unsigned p = s / nqc, qc = s - p * nqc;
+        const bool more = s + 1 < nslab;
+        if (more) stage_load(s + 1);
+        float a_next = a_p;
+        if (more && qc + 1 == nqc && valid) a_next = Pp[(size_t)(p + 1) * D];   // next p's value
+        const float* Fb = Fs + buf * kQC * CS + hi * CS + l32;
+        const float* Qb = Qlane + (qc * kQC + hi) * D;
+        const unsigned steps = (slab_rows(s) + 1) >> 1;
+        for (unsigned qq = 0; qq < steps; ++qq) {
+            float a = a_p * Qb[(2 * qq) * D];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float bf = Fb[(2 * qq) * CS + nt * 32];
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf, acc[nt], 0, 0, 0);
+            }
+        }
+        if (more) {
+            // the other buffer was last read in iteration s-1, i.e. before the previous barrier
+            stage_store(s + 1, buf ^ 1);
+        }
+        a_p = a_next;
+        __syncthreads();
+    }
+
+    // ---- epilogue: out[b, c, d] (float4 of 4 consecutive d) and the sum-pooling over d --------
+    const unsigned R0 = blockIdx.x * kTM + wave * 32;      // first (b,d) row of this wave's tile
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const unsigned c = nt * 32 + l32;
+        const bool cok = c < C;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const unsigned R = R0 + 8 * g4 + 4 * hi;
+            const unsigned bb = R / D, d0 = R % D;
+            if (cok && bb < B) {
+                float4* o = reinterpret_cast<float4*>(out + ((size_t)bb * C + c) * D + d0);
+                float4 v = make_float4(acc[nt][4 * g4 + 0], acc[nt][4 * g4 + 1], acc[nt][4 * g4 + 2], acc[nt][4 * g4 + 3]);
+                if (accumulate) v = f4_add(v, *o);
+                *o = v;
+            }
+        }
+        if (pool) {
+            if constexpr (D >= 8) {
+                constexpr int EXW = 32 / D;                 // examples per wave tile
+                constexpr int GPE = 4 / EXW;                // reg groups (of 4 rows x 2 halves) per example
+#pragma unroll
+                for (int e = 0; e < EXW; ++e) {
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int g = 0; g < GPE; ++g)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sacc += acc[nt][4 * (e * GPE + g) + r];
+                    sacc += __shfl_xor(sacc, 32, 64);
+                    const unsigned bb = R0 / D + e;
+                    if (hi == 0 && cok && bb < B) pool[(size_t)bb * pool_stride + pool_col + c] = sacc;
+                }
+            } else {                                        // D == 4: every (g4, hi) group is one example
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float sacc = acc[nt][4 * g4] + acc[nt][4 * g4 + 1] + acc[nt][4 * g4 + 2] + acc[nt][4 * g4 + 3];
+                    const unsigned bb = (R0 + 8 * g4 + 4 * hi) / D;
+                    if (cok && bb < B) pool[(size_t)bb * pool_stride + pool_col + c] = sacc;
+                }
+            }
+        }
+    }
+}
+
+// F'[(a1*n2 + a2) * n0 + a0] = W[(a0*n1... see callers]  — generic 3-index permutation of the
+// filter: dst[(x*NY + y)*NZ + z] = src[x*sx + y*sy + z*sz]
+__global__ __launch_bounds__(256) void cin_permute_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                          unsigned NX, unsigned NY, unsigned NZ, unsigned sx,
+                                                          unsigned sy, unsigned sz) {
+    unsigned i = blockIdx.x * 256 + threadIdx.x;
+    unsigned total = NX * NY * NZ;
+    if (i >= total) return;
+    unsigned z = i % NZ, t = i / NZ;
+    unsigned y = t % NY, x = t / NY;
+    dst[i] = src[(size_t)x * sx + (size_t)y * sy + (size_t)z * sz];
+}
+
+// G[b,n,d] = g_out[b,n,d] (or 0) + g_pool[b, n] (or 0)
+template <int D>
+__global__ __launch_bounds__(256) void cin_combine_grad_kernel(const float* __restrict__ g_out,
+                                                               const float* __restrict__ g_pool,
+                                                               unsigned pool_stride, unsigned pool_col,
+                                                               unsigned total /* B*N */, unsigned N,
+                                                               float* __restrict__ G) {
+    constexpr int D4 = D / 4;
+    unsigned i = blockIdx.x * 256 + threadIdx.x;     // over B*N*D4
+    if (i >= total * D4) return;
+    unsigned bn = i / D4;
+    float4 v = g_out ? reinterpret_cast<const float4*>(g_out)[i] : f4_zero();
+    if (g_pool) {
+        unsigned bb = bn / N, n = bn - bb * N;
+        float gp = g_pool[(size_t)bb * pool_stride + pool_col + n];
+        v.x += gp; v.y += gp; v.z += gp; v.w += gp;
+    }
+    reinterpret_cast<float4*>(G)[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// filter gradient: dW[kk, c] = sum_r (P[r, kk / HQ] * Q[r, kk % HQ]) * G[r, c],  r = (b, d)
+// workgroup = 128 rows kk (one 32-row MFMA tile per wave) x all C columns, over a slab of the
+// batch (split-K over blockIdx.y); partial sums go to `partials[blockIdx.y][Kdim][C]`.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRC = 64;        // reduction rows (b,d) staged per chunk
+constexpr int kPW = 34;        // >= distinct p values touched by the 128 kk rows of a workgroup (m >= 4)
+
+template <int D, int NT>
+__global__ __launch_bounds__(kThreads) void cin_filter_grad_kernel(
+    const float* __restrict__ P, const float* __restrict__ Q, const float* __restrict__ G, unsigned B,
+    unsigned HP, unsigned HQ, unsigned C, unsigned ex_per_split, float* __restrict__ partials) {
+    constexpr unsigned EXC = kRC / D;            // examples per chunk
+    constexpr unsigned GS = NT * 32 + 4;         // LDS row strides
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Gs = smem;                            // [kRC][GS]
+    float* Ps = Gs + kRC * GS;                   // [kRC][kPW]
+    float* Qs = Ps + kRC * kPW;                  // [kRC][HQ]
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned hi = lane >> 5, l32 = lane & 31;
+    const unsigned Kdim = HP * HQ;
+    const unsigned kk0 = blockIdx.x * 128;                  // first kk row of the workgroup
+    const unsigned kk = kk0 + wave * 32 + l32;              // this lane's A' row
+    const bool kok = kk < Kdim;
+    const unsigned p_first = kk0 / HQ;
+    const unsigned p_lane = kok ? kk / HQ : p_first, q_lane = kok ? kk % HQ : 0;
+    const unsigned pp_lane = p_lane - p_first;              // column in Ps
+    unsigned p_cnt = min(HP, (min(kk0 + 128, Kdim) - 1) / HQ + 1) - p_first;   // p values staged
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+    const unsigned ex_begin = blockIdx.y * ex_per_split;
+    const unsigned ex_end = min(B, ex_begin + ex_per_split);
+    for (unsigned e0 = ex_begin; e0 < ex_end; e0 += EXC) {
+        __syncthreads();                                    // previous chunk fully consumed
+        // ---- stage chunk: rows r = (ex, d), ex in [e0, e0+EXC) ----
+        for (unsigned e = tid; e < EXC * C * D; e += kThreads) {        // G[b][c][d] -> Gs[(ex,d)][c]
+            unsigned d = e % D, t = e / D;
+            unsigned c = t % C, ex = t / C;
+            unsigned bb = e0 + ex;
+            Gs[(ex * D + d) * GS + c] = bb < ex_end ? G[((size_t)bb * C + c) * D + d] : 0.f;
+        }
+        for (unsigned e = tid; e < EXC * p_cnt * D; e += kThreads) {    // P[b][p][d] -> Ps[(ex,d)][pp]
+            unsigned d = e % D, t = e / D;
+            unsigned pp = t % p_cnt, ex = t / p_cnt;
+            unsigned bb = e0 + ex;
+            Ps[(ex * D + d) * kPW + pp] = bb < ex_end ? P[((size_t)bb * HP + p_first + pp) * D + d] : 0.f;
+        }
+        for (unsigned e = tid; e < EXC * HQ * D; e += kThreads) {       // Q[b][q][d] -> Qs[(ex,d)][q]
+            unsigned d = e % D, t = e / D;
+            unsigned q = t % HQ, ex = t / HQ;
+            unsigned bb = e0 + ex;
+            Qs[(ex * D + d) * HQ + q] = bb < ex_end ? Q[((size_t)bb * HQ + q) * D + d] : 0.f;
+        }
+        __syncthreads();
+        const float* Pl = Ps + hi * kPW + pp_lane;
+        const float* Ql = Qs + hi * HQ + q_lane;
+        const float* Gl = Gs + hi * GS + l32;
+#pragma unroll 4
+        for (unsigned st = 0; st < kRC / 2; ++st) {
+            float a = kok ? Pl[(2 * st) * kPW] * Ql[(2 * st) * HQ] : 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float bf = Gl[(2 * st) * GS + nt * 32];
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf, acc[nt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- write the partial tile: rows kk0 + wave*32 + (r&3) + 8*(r>>2) + 4*hi, col nt*32 + l32 ----
+    float* pout = partials + (size_t)blockIdx.y * Kdim * C;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const unsigned c = nt * 32 + l32;
+        if (c >= C) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            unsigned rr = kk0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (rr < Kdim) pout[(size_t)rr * C + c] = acc[nt][r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cin_sum_partials_kernel(const float* __restrict__ partials, unsigned S,
+                                                               size_t n, float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.f;
+    for (unsigned s = 0; s < S; ++s) acc += partials[(size_t)s * n + i];
+    out[i] = acc;
+}
+
+// ---- host helpers ---------------------------------------------------------------------------
+inline bool d_ok(int D) { return D == 4 || D == 8 || D == 16 || D == 32; }
+
+inline size_t contract_smem(int D, int NT, int HQ) {
+    unsigned HQp = (HQ + 1) & ~1u;
+    return ((size_t)(kTM / D) * (HQp * D + 16) + 2 * (size_t)kQC * NT * 32) * sizeof(float);
+}
+
+template <int D, int NT>
+int launch_contract_DN(const float* P, const float* Q, const float* F, int B, int HP, int HQ, int C, float* out,
+                       int accumulate, float* pool, int pool_stride, int pool_col, hipStream_t st) {
+    size_t smem = contract_smem(D, NT, HQ);
+    if (smem > 160 * 1024) return (int)hipErrorInvalidValue;
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_contract_kernel<D, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    int grid = cdiv((int64_t)B * D, kTM);
+    hipLaunchKernelGGL((cin_contract_kernel<D, NT>), dim3(grid), dim3(kThreads), smem, st, P, Q, F, (unsigned)B,
+                       (unsigned)HP, (unsigned)HQ, (unsigned)C, out, accumulate, pool, (unsigned)pool_stride,
+                       (unsigned)pool_col);
+    return (int)hipGetLastError();
+}
+
+template <int D>
+int launch_contract_D(int NT, const float* P, const float* Q, const float* F, int B, int HP, int HQ, int C,
+                      float* out, int accumulate, float* pool, int pool_stride, int pool_col, hipStream_t st) {
+    switch (NT) {
+        case 1: return launch_contract_DN<D, 1>(P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);
+        case 2: return launch_contract_DN<D, 2>(P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);
+        case 3: return launch_contract_DN<D, 3>(P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);
+        case 4: return launch_contract_DN<D, 4>(P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);
+        default: return (int)hipErrorInvalidValue;
+    }
+}
+
+// out[b, c0:c0+C', d] for C' <= 128 per launch (column chunks of the filter are strided views, so
+// chunking over C needs a compact filter: handled by the callers with C <= 128)
+int launch_contract(const float* P, const float* Q, const float* F, int B, int HP, int HQ, int C, int D, float* out,
+                    int accumulate, float* pool, int pool_stride, int pool_col, hipStream_t st) {
+    if (C <= 0 || C > 128) return (int)hipErrorInvalidValue;
+    const int NT = cdiv(C, 32);
+    switch (D) {
+        case 4: return launch_contract_D<4>(NT, P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);
+        case 8: return launch_contract_D<8>(NT, P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);
+        case 16: return launch_contract_D<16>(NT, P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);
+        case 32: return launch_contract_D<32>(NT, P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);
+        default: return (int)hipErrorInvalidValue;
+    }
+}
+
+inline int filter_grad_splits(int B, int D, int Kdim) {
+    int row_blocks = cdiv(Kdim, 128);
+    int want = cdiv(768, row_blocks);                       // ~3 workgroups per CU in total
+    int exc = kRC / D;
+    int max_s = cdiv(B, exc);
+    int S = want < 1 ? 1 : (want > max_s ? max_s : want);
+    return S > 64 ? 64 : S;
+}
+
+template <int D, int NT>
+int launch_filter_grad_DN(const float* P, const float* Q, const float* G, int B, int HP, int HQ, int C, int S,
+                          float* partials, hipStream_t st) {
+    size_t smem = ((size_t)kRC * (NT * 32 + 4) + (size_t)kRC * kPW + (size_t)kRC * HQ) * sizeof(float);
+    if (smem > 160 * 1024) return (int)hipErrorInvalidValue;
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_filter_grad_kernel<D, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int exc = kRC / D;
+    int ex_per_split = cdiv(cdiv(B, S), exc) * exc;
+    dim3 grid(cdiv(HP * HQ, 128), S);
+    hipLaunchKernelGGL((cin_filter_grad_kernel<D, NT>), grid, dim3(kThreads), smem, st, P, Q, G, (unsigned)B,
+                       (unsigned)HP, (unsigned)HQ, (unsigned)C, (unsigned)ex_per_split, partials);
+    return (int)hipGetLastError();
+}
+
+template <int D>
+int launch_filter_grad_D(int NT, const float* P, const float* Q, const float* G, int B, int HP, int HQ, int C, int S,
+                         float* partials, hipStream_t st) {
+    switch (NT) {
+        case 1: return launch_filter_grad_DN<D, 1>(P, Q, G, B, HP, HQ, C, S, partials, st);
+        case 2: return launch_filter_grad_DN<D, 2>(P, Q, G, B, HP, HQ, C, S, partials, st);
+        case 3: return launch_filter_grad_DN<D, 3>(P, Q, G, B, HP, HQ, C, S, partials, st);
+        case 4: return launch_filter_grad_DN<D, 4>(P, Q, G, B, HP, HQ, C, S, partials, st);
+        default: return (int)hipErrorInvalidValue;
+    }
+}
+
+struct BwdWs {
+    size_t g, wp, wpp, partials, total;
+};
+inline BwdWs bwd_ws(int B, int m, int Hk, int N, int D) {
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    BwdWs w;
+    size_t kdim = (size_t)Hk * m;
+    w.g = 0;
+    size_t off = al((size_t)B * N * D * sizeof(float));
+    w.wp = off;   off += al(kdim * N * sizeof(float));
+    w.wpp = off;  off += al(kdim * N * sizeof(float));
+    w.partials = off;
+    off += al((size_t)filter_grad_splits(B, D, (int)kdim) * kdim * N * sizeof(float));
+    w.total = off;
+    return w;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C-ABI
+// =============================================================================================
+RECALGO_EXPORT int recalgo_cin_layer_fwd(const float* x0, const float* xk, const float* filters, int B, int m,
+                                         int Hk, int N, int D, float* out, float* pool, int pool_stride,
+                                         int pool_col, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(B >= 0 && m > 0 && Hk > 0 && N > 0 && N <= 128 && d_ok(D));
+    if (B == 0) return 0;
+    return launch_contract(xk, x0, filters, B, Hk, m, N, D, out, 0, pool, pool_stride, pool_col, as_stream(stream));
+}
+
+RECALGO_EXPORT int64_t recalgo_cin_layer_bwd_workspace_bytes(int B, int m, int Hk, int N, int D) {
+    if (B <= 0 || m <= 0 || Hk <= 0 || N <= 0 || !d_ok(D)) return 0;
+    return (int64_t)bwd_ws(B, m, Hk, N, D).total;
+}
+
+RECALGO_EXPORT int recalgo_cin_layer_bwd(const float* x0, const float* xk, const float* filters,
+                                         const float* g_out, const float* g_pool, int pool_stride, int pool_col,
+                                         int B, int m, int Hk, int N, int D, float* dx0, int dx0_accumulate,
+                                         float* dxk, int dxk_accumulate, float* dfilters, void* workspace,
+                                         recalgo_stream_t stream) {
+    RECALGO_REQUIRE(B > 0 && m > 0 && m <= 128 && Hk > 0 && Hk <= 128 && N > 0 && N <= 128 && d_ok(D));
+    RECALGO_REQUIRE(workspace != nullptr && (g_out != nullptr || g_pool != nullptr));
+    RECALGO_REQUIRE(127 / m + 2 <= kPW);
+    hipStream_t st = as_stream(stream);
+    const BwdWs ws = bwd_ws(B, m, Hk, N, D);
+    char* base = static_cast<char*>(workspace);
+    float* G = reinterpret_cast<float*>(base + ws.g);
+    float* Wp = reinterpret_cast<float*>(base + ws.wp);      // W' [n*m + j, i]
+    float* Wpp = reinterpret_cast<float*>(base + ws.wpp);    // W''[i*N + n, j]
+    float* partials = reinterpret_cast<float*>(base + ws.partials);
+    const unsigned BN = (unsigned)B * N;
+    // G = g_out + broadcast(g_pool)
+    {
+        const unsigned total4 = BN * (D / 4);
+#define COMBINE(DD)                                                                                          \
+    hipLaunchKernelGGL(cin_combine_grad_kernel<DD>, dim3(cdiv(total4, 256)), dim3(256), 0, st, g_out, g_pool, \
+                       (unsigned)pool_stride, (unsigned)pool_col, BN, (unsigned)N, G)
+        if (D == 4) COMBINE(4); else if (D == 8) COMBINE(8); else if (D == 16) COMBINE(16); else COMBINE(32);
+#undef COMBINE
+    }
+    const unsigned wn = (unsigned)Hk * m * N;
+    // W[(i*m + j)*N + n] -> W'[(n*m + j)*Hk + i] : x=n, y=j, z=i
+    hipLaunchKernelGGL(cin_permute_kernel, dim3(cdiv(wn, 256)), dim3(256), 0, st, filters, Wp, (unsigned)N, (unsigned)m,
+                       (unsigned)Hk, 1u, (unsigned)N, (unsigned)(m * N));
+    // W -> W''[(i*N + n)*m + j] : x=i, y=n, z=j
+    hipLaunchKernelGGL(cin_permute_kernel, dim3(cdiv(wn, 256)), dim3(256), 0, st, filters, Wpp, (unsigned)Hk, (unsigned)N,
+                       (unsigned)m, (unsigned)(m * N), 1u, (unsigned)N);
+    int rc;
+    // dX^k[b,i,d] = sum_{n,j} W'[(n,j), i] G[b,n,d] X0[b,j,d]
+    if (dxk) {
+        rc = launch_contract(G, x0, Wp, B, N, m, Hk, D, dxk, dxk_accumulate, nullptr, 0, 0, st);
+        if (rc) return rc;
+    }
+    // dX^0[b,j,d] = sum_{i,n} W''[(i,n), j] X^k[b,i,d] G[b,n,d]
+    rc = launch_contract(xk, G, Wpp, B, Hk, N, m, D, dx0, dx0_accumulate, nullptr, 0, 0, st);
+    if (rc) return rc;
+    // dW
+    const int S = filter_grad_splits(B, D, Hk * m);
+    const int NT = cdiv(N, 32);
+    switch (D) {
+        case 4: rc = launch_filter_grad_D<4>(NT, xk, x0, G, B, Hk, m, N, S, partials, st); break;
+        case 8: rc = launch_filter_grad_D<8>(NT, xk, x0, G, B, Hk, m, N, S, partials, st); break;
+        case 16: rc = launch_filter_grad_D<16>(NT, xk, x0, G, B, Hk, m, N, S, partials, st); break;
+        default: rc = launch_filter_grad_D<32>(NT, xk, x0, G, B, Hk, m, N, S, partials, st); break;
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(cin_sum_partials_kernel, dim3(cdiv(wn, 256)), dim3(256), 0, st, partials, (unsigned)S, (size_t)wn,
+                       dfilters);
+    RECALGO_RETURN_LAST();
+}

@@ -270,6 +270,54 @@ def cross_layer(store, x0: torch.Tensor, xl: torch.Tensor, w: Variable, b: Varia
 
 
 # =============================================================================================
+# K5: CIN layer (fp32 MFMA implicit GEMM)
+# =============================================================================================
+class _CinFn(Function):
+    @staticmethod
+    def forward(ctx, anchor, x0, xk, filt: Variable):
+        B, m, D = x0.shape
+        Hk = xk.shape[1]
+        N = filt.data.shape[-1]
+        out = torch.empty(B, N, D, device=x0.device, dtype=torch.float32)
+        pool = torch.empty(B, N, device=x0.device, dtype=torch.float32)
+        _lib.check(_lib_().recalgo_cin_layer_fwd(
+            _p(x0), _p(xk), _p(filt.data), B, m, Hk, N, D, _p(out), _p(pool), N, 0, _stream(x0)),
+            "recalgo_cin_layer_fwd")
+        ctx.filt = filt
+        ctx.save_for_backward(x0, xk)
+        ctx.set_materialize_grads(False)
+        return out, pool
+
+    @staticmethod
+    def backward(ctx, g_out, g_pool):
+        x0, xk = ctx.saved_tensors
+        filt = ctx.filt
+        B, m, D = x0.shape
+        Hk = xk.shape[1]
+        N = filt.data.shape[-1]
+        dx0 = torch.empty_like(x0)
+        dxk = torch.empty_like(xk)
+        if g_out is None and g_pool is None:
+            filt.grad.zero_()
+            return None, dx0.zero_(), dxk.zero_(), None
+        g_out = None if g_out is None else g_out.contiguous()
+        g_pool = None if g_pool is None else g_pool.contiguous()
+        lib = _lib_()
+        ws = _workspace(lib.recalgo_cin_layer_bwd_workspace_bytes(B, m, Hk, N, D), x0.device)
+        _lib.check(lib.recalgo_cin_layer_bwd(
+            _p(x0), _p(xk), _p(filt.data), _p(g_out), _p(g_pool), N, 0, B, m, Hk, N, D,
+            _p(dx0), 0, _p(dxk), 0, _p(filt.grad), _p(ws), _stream(x0)), "recalgo_cin_layer_bwd")
+        return None, dx0, dxk, None
+
+
+def cin_layer(store, x0: torch.Tensor, xk: torch.Tensor, filt: Variable):
+    """x0 [B,m,D], xk [B,Hk,D], filt (1, Hk*m, N) -> (xk_1 [B,N,D], sum-pooled [B,N])."""
+    _chk(x0, torch.float32, "x0")
+    _chk(xk, torch.float32, "xk")
+    return _CinFn.apply(store.anchor, x0, xk, filt)
+
+
+# =============================================================================================
 # a14: loss tail
 # =============================================================================================
 class _SigmoidCEFn(Function):

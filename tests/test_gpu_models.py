@@ -138,3 +138,31 @@ def test_hipgraph_replay_matches_eager(dev, model):
         assert_close(b[k], a[k], rtol=1e-4, what=f"graph vs eager {k}", reduced=True)
     assert_close(lb, la, rtol=1e-5, what="graph vs eager loss")
     assert int(estB.store.opt_state["step"]) == 5
+
+
+def _make_xdeepfm(dev, n_fields=8, K=8, B=160, maps=("12", "10")):
+    from recalgorithm_amd.algorithm.xDeepFM.xdeepfm import xdeepfm_model_fn
+    spec = synth.SynthSpec(n_fields=n_fields, max_vocab=300, seed=13, oov_frac=0.05)
+    cats = [fc.categorical_column_with_identity(n, v) for n, v in zip(spec.names, spec.vocabs)]
+    params = {"category_feature_columns": [fc.embedding_column(c, K) for c in cats],
+              "dense_feature_columns": [], "hidden_units": ["32", "16"], "learning_rate": 0.005,
+              "embedding_dim": K, "cin_layer_feature_maps": list(maps)}
+    est = Estimator(xdeepfm_model_fn, params, RunConfig(device=dev, seed=5))
+    feats, labels, _ = synth.device_features(spec, B, dev)
+    est.build(feats, labels)
+    return est, params, feats, labels
+
+
+def test_xdeepfm_forward_backward(dev):
+    est, params, feats, labels = _make_xdeepfm(dev)
+    P, cf, cl = oracle_inputs(est, feats, labels)
+    ref = M.xdeepfm(P, cf, cl, params, training=True)
+    ref["loss"].backward()
+    spec = est._call_model_fn(feats, labels, ModeKeys.TRAIN)
+    assert_close(spec.loss, ref["loss"], what="xdeepfm loss")
+    assert_close(spec.predictions["probabilities"], ref["prob"], what="xdeepfm prob")
+    spec.loss.backward()
+    grads = named_grads(est.store)
+    for name, p in P.items():
+        if p.grad is not None:
+            assert_close(grads[name], p.grad, what=f"xdeepfm d({name})", reduced=True)
