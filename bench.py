@@ -68,6 +68,12 @@ def build_estimator(args, device, rank=0, world=1):
                   "second_order_feature_columns": [fc.embedding_column(c, args.emb) for c in cats],
                   "hidden_units": hidden, "dropout_rate": 0.0, "batch_norm": True, "learning_rate": 0.005}
         workload = f"DeepFM FM1+FM2+MLP 512,256,128 (BN); {args.fields} fields x emb{args.emb}; batch {args.batch}/GPU"
+    elif args.model == "xdeepfm":
+        from recalgorithm_amd.algorithm.xDeepFM.xdeepfm import xdeepfm_model_fn as model_fn
+        params = {"category_feature_columns": [fc.embedding_column(c, args.emb) for c in cats],
+                  "dense_feature_columns": [], "hidden_units": hidden, "learning_rate": 0.005,
+                  "embedding_dim": args.emb, "cin_layer_feature_maps": ["128", "128"]}
+        workload = f"xDeepFM CIN [128,128] + MLP 512,256,128; {args.fields} fields x emb{args.emb}; batch {args.batch}/GPU"
     else:
         raise SystemExit(f"--model {args.model}: not wired into bench.py yet")
     est = Estimator(model_fn=model_fn, params=params, config=RunConfig(device=device, seed=42))
@@ -112,11 +118,16 @@ def kernel_rooflines(args, est, feats, device):
     res = []
 
     def add(name, fn, alg_bytes, flops=0.0):
-        ms = event_time_ms(fn)
-        t_min = max(alg_bytes / (HBM_PEAK_GBS * 1e9), flops / (FP32_PEAK_TFLOPS * 1e12))
-        res.append({"kernel": name, "avg_us": round(ms * 1e3, 3), "alg_bytes": int(alg_bytes),
-                    "achieved_GBs": round(alg_bytes / (ms * 1e-3) / 1e9, 1),
-                    "frac": round(t_min / (ms * 1e-3), 4)})
+        ms = event_time_ms(fn, iters=50 if flops < 1e9 else 10, warm=5 if flops < 1e9 else 2)
+        t_hbm, t_fl = alg_bytes / (HBM_PEAK_GBS * 1e9), flops / (FP32_PEAK_TFLOPS * 1e12)
+        r = {"kernel": name, "avg_us": round(ms * 1e3, 3), "alg_bytes": int(alg_bytes),
+             "achieved_GBs": round(alg_bytes / (ms * 1e-3) / 1e9, 1),
+             "bound": "mfma" if t_fl > t_hbm else "hbm",
+             "frac": round(max(t_hbm, t_fl) / (ms * 1e-3), 4)}
+        if flops:
+            r["alg_flops"] = float(flops)
+            r["achieved_TFLOPs"] = round(flops / (ms * 1e-3) / 1e12, 2)
+        res.append(r)
 
     add("gather_fwd", lambda: lib.recalgo_embedding_gather_fwd(p(ids), p(ar.weight), p(rb), B, F, K, p(x0), d, 0, st),
         B * (F * 8 + 2 * d * 4))
@@ -132,6 +143,25 @@ def kernel_rooflines(args, est, feats, device):
         add("cross_fwd", lambda: lib.recalgo_cross_fwd(p(x0), d, p(w), p(b), B, d, L, p(out), d, st), B * 2 * d * 4)
         add("cross_bwd", lambda: lib.recalgo_cross_bwd(p(x0), d, p(w), p(b), p(g), d, None, B, d, L, p(dx0), p(dw), p(db), p(ws), st),
             B * 3 * d * 4)
+    if args.model == "xdeepfm":
+        m, D = F, K
+        x3 = torch.randn(B, m, D, device=device)
+        ws = torch.empty(lib.recalgo_cin_layer_bwd_workspace_bytes(B, m, 128, 128, D), dtype=torch.uint8, device=device)
+        for li, Hk in enumerate((m, 128)):
+            N = 128
+            xk = torch.randn(B, Hk, D, device=device)
+            w = torch.randn(Hk * m, N, device=device) * 0.02
+            o = torch.empty(B, N, D, device=device)
+            pool = torch.empty(B, N, device=device)
+            go = torch.randn(B, N, D, device=device)
+            dx0, dxk, dw = torch.empty_like(x3), torch.empty_like(xk), torch.empty_like(w)
+            fl = 2.0 * B * D * Hk * m * N
+            byt = B * (m * D + Hk * D + N * D + N) * 4 + w.numel() * 4
+            add(f"cin_fwd(L{li + 1},Hk={Hk})", lambda: lib.recalgo_cin_layer_fwd(p(x3), p(xk), p(w), B, m, Hk, N, D, p(o), p(pool), N, 0, st),
+                byt, fl)
+            add(f"cin_bwd(L{li + 1},Hk={Hk})", lambda: lib.recalgo_cin_layer_bwd(p(x3), p(xk), p(w), p(go), p(pool), N, 0, B, m, Hk, N, D,
+                                                                                 p(dx0), 0, p(dxk), 0, p(dw), p(ws), st),
+                2 * byt, 3.0 * fl)
     n = ar.weight.numel()
     add("adam_tf1_dense(arena)", lambda: lib.recalgo_adam_tf1_dense(p(ar.weight), p(ar.grad), p(ar.m), p(ar.v), n, 0.0, None,
                                                                      0.9, 0.999, 1e-8, 1, st), n * 4 * 7)
@@ -223,9 +253,15 @@ def main():
             ks = kernel_rooflines(args, est, feats, device)
             hot = [k for k in ks if not k["kernel"].startswith("adam")]
             dom = max(hot, key=lambda k: k["avg_us"])
-            out["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"],
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": None,
-                               "avg_us": dom["avg_us"], "alg_bytes_per_launch": dom["alg_bytes"]}
+            if dom["bound"] == "mfma":
+                out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_TFLOPs"],
+                                   "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
+                                   "traffic": None, "avg_us": dom["avg_us"],
+                                   "alg_flops_per_launch": dom["alg_flops"]}
+            else:
+                out["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"],
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": None,
+                                   "avg_us": dom["avg_us"], "alg_bytes_per_launch": dom["alg_bytes"]}
             out["kernels"] = ks
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)

@@ -168,6 +168,32 @@ int recalgo_cin_layer_bwd(const float* x0, const float* xk, const float* filters
                           recalgo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K9  DIN attention pooling of the behaviour history.
+ * Replaces din_attention(query, keys, keys_length, is_softmax) algorithm/DIN/din_attention.py:4-43
+ * (tile/concat, three tf.layers.dense f1_att/f2_att/f3_att, mask, softmax | mask-multiply, matmul).
+ *   x_t = [q, k_t, q-k_t, q*k_t];  s_t = f3(relu(f2(relu(f1 x_t))))          (4H -> 64 -> 32 -> 1)
+ *   is_softmax: w = softmax_t((t < len ? s_t : -2^32+1) / sqrt(H));  else: w_t = s_t * [t < len]
+ *   out[b, :] = sum_t w_t * keys[b, t, :]
+ *   query [B,H], keys [B,T,H] (zero padded), keys_length [B] int32, f1_w [4H,64], f1_b [64],
+ *   f2_w [64,32], f2_b [32], f3_w [32,1], f3_b [1], out [B,H].   T <= 64, H in {4, 8, 16}.
+ * ------------------------------------------------------------------------------------------ */
+int recalgo_din_attention_fwd(const float* query, const float* keys, const int32_t* keys_length,
+                              const float* f1_w, const float* f1_b, const float* f2_w,
+                              const float* f2_b, const float* f3_w, const float* f3_b, int B, int T,
+                              int H, int is_softmax, float* out, recalgo_stream_t stream);
+/* Backward (DIN attention): recomputes the forward, returns dquery [B,H],
+ * dkeys [B,T,H] and the six parameter gradients (overwritten; deterministic two-pass sum).
+ * workspace: recalgo_din_attention_bwd_workspace_bytes(B, T, H). */
+int64_t recalgo_din_attention_bwd_workspace_bytes(int B, int T, int H);
+int recalgo_din_attention_bwd(const float* query, const float* keys, const int32_t* keys_length,
+                              const float* f1_w, const float* f1_b, const float* f2_w,
+                              const float* f2_b, const float* f3_w, const float* f3_b,
+                              const float* g_out, int B, int T, int H, int is_softmax, float* dquery,
+                              float* dkeys, float* d_f1_w, float* d_f1_b, float* d_f2_w,
+                              float* d_f2_b, float* d_f3_w, float* d_f3_b, void* workspace,
+                              recalgo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * a14  loss tail: sigmoid + mean sigmoid cross entropy, forward and d(loss)/d(logit) fused.
  * Replaces tf.sigmoid + tf.reduce_mean(tf.nn.sigmoid_cross_entropy_with_logits)
  * algorithm/DeepFM/deepfm.py:217,235 (same in all six model_fns).

@@ -135,3 +135,44 @@ def xdeepfm(P, feats, labels, params, training=False):
     n = len(params["hidden_units"])
     dnn_logit = R.dense(dnn, P["dnn_part/dense/kernel"])                                                     # :182 no bias
     return _tail(linear_logit + cin_logit + dnn_logit, None if labels is None else labels["read_comment"])
+
+
+def din(P, feats, labels, params, training=False):
+    """algorithm/DIN/din.py:186-257 (dropout is the identity here: rate 0 / eval)."""
+    reg = {}
+    parts = []
+    dense_cols = params.get("dense_feature_columns") or []
+    if dense_cols:
+        parts.append(input_layer(P, feats, dense_cols, "dense_input/input_layer"))                 # :200-201
+    category = input_layer(P, feats, params["category_feature_columns"], "category_input/input_layer", reg)
+    tcol = params["target_feedid_feature_columns"][0]
+    scol = params["sequence_feature_columns"][0]
+    tname = reg.setdefault(tcol.shared_name, table_name(tcol, "target_input/sequence_input_layer"))
+    table = P[tname]
+    target = R.embedding_lookup_single(feats[tcol.key], table)                                     # :208-210
+    vals, offs = feats[scol.key]
+    seq, seq_len = R.sequence_lookup(vals, offs, table, params.get("sequence_max_length"))         # :213-214
+    a = "attention_part"
+    att = R.din_attention(target, seq, seq_len,
+                          P[f"{a}/f1_att/kernel"], P[f"{a}/f1_att/bias"], P[f"{a}/f2_att/kernel"],
+                          P[f"{a}/f2_att/bias"], P[f"{a}/f3_att/kernel"], P[f"{a}/f3_att/bias"],
+                          is_softmax=params["use_softmax"])                                        # :217-218
+    net = torch.cat(parts + [category, target, att], dim=-1)                                       # :221
+    for i, _ in enumerate(params["hidden_units"]):
+        dn = "dense" if i == 0 else f"dense_{i}"
+        net = R.dense(net, P[f"fcn/{dn}/kernel"], P[f"fcn/{dn}/bias"])                              # :227
+        if params["activation"] == "dice":
+            net = R.dice(net, P[f"fcn/dice_alpha_{i + 1}"])
+        else:
+            net = R.prelu(net, P[f"fcn/prelu_alpha_{i + 1}"])
+        if params["batch_norm"]:
+            bn = "batch_normalization" if i == 0 else f"batch_normalization_{i}"
+            net = R.batch_norm(net, P[f"fcn/{bn}/gamma"], P[f"fcn/{bn}/beta"], P[f"fcn/{bn}/moving_mean"],
+                               P[f"fcn/{bn}/moving_variance"], training)
+    n = len(params["hidden_units"])
+    dn = "dense" if n == 0 else f"dense_{n}"
+    logit = R.dense(net, P[f"fcn/{dn}/kernel"], P[f"fcn/{dn}/bias"])
+    extra = None
+    if labels is not None and params["mini_batch_aware_regularization"] and params["l2_lambda"] > 0:
+        extra = R.din_mba_reg(category, target, att, params["l2_lambda"])                          # :254-257
+    return _tail(logit, None if labels is None else labels["read_comment"], extra)

@@ -33,6 +33,10 @@ SIGNATURES = {
     "recalgo_cin_layer_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "recalgo_cin_layer_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       P, c_int, P, c_int, P, P, P]),
+    "recalgo_din_attention_fwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "recalgo_din_attention_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
+    "recalgo_din_attention_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int,
+                                          P, P, P, P, P, P, P, P, P, P]),
     "recalgo_sigmoid_ce_fwd_bwd": (c_int, [P, P, c_int, c_float, P, P, P, P]),
     "recalgo_adam_tf1_dense": (c_int, [P, P, P, P, c_int64, c_float, P, c_float, c_float, c_float, c_int, P]),
     "recalgo_adam_tf1_advance": (c_int, [P, c_float, c_float, c_float, P, P]),

@@ -1,0 +1,114 @@
+"""DIN (Deep Interest Network) entry point — MI355X drop-in for /root/reference
+algorithm/DIN/din.py: same flags, `create_feature_columns` (5 lists), `example_parser`,
+`din_model_fn(features, labels, mode, params)`, `main`, scopes (`target_input`, `his_seq_input`,
+`attention_part`, `fcn`), prediction key `probabilities`, Dice / PReLU MLP and the
+mini-batch-aware regulariser of din.py:254-257 (an L2 on the *activations* — quirk B-11).
+
+    python -m recalgorithm_amd.algorithm.DIN.din --use_softmax=True --activation=dice
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+
+from ... import feature_column as fc
+from ... import flags, nn
+from ...estimator import ModeKeys
+from ...model_tail import finish_model_fn
+from ...variables import variable_scope
+from .. import _common as common
+from .activations import dice, prelu
+from .din_attention import din_attention
+
+common.define_common_flags()
+flags.DEFINE_string("hidden_units", "512,256,128", "Comma-separated list of number of units in each hidden layer of the deep part")
+flags.DEFINE_boolean("batch_norm", True, "Perform batch normalization (True or False)")
+flags.DEFINE_float("dropout_rate", 0.1, "Dropout rate")
+flags.DEFINE_string("activation", "dice", "Dense layer activation, supported strings are in {'prelu', dice'}")
+flags.DEFINE_boolean("mini_batch_aware_regularization", True, "Whether to use mini_batch_aware_regularization")
+flags.DEFINE_float("l2_lambda", 0.2, "Coefficient when using mini_batch_aware_regularization")
+flags.DEFINE_boolean("use_softmax", False, "Whether to use softmax on attention score")
+FLAGS = flags.FLAGS
+
+
+def create_feature_columns() -> Tuple[list, list, list, list, list]:
+    """-> (dense, category, target_feedid, sequence, label) feature columns; din.py:50-120.
+    feedid / his_read_comment_7d_seq are *sequence* categorical columns sharing one 16-wide table;
+    [0] is the target feed, [1] the history (shared_embedding_columns keeps input order)."""
+    dims = {"userid": 16, "device": 2, "authorid": 4, "bgm_song_id": 4, "bgm_singer_id": 4,
+            "manual_tag_list": 4, "feedid": 16}
+    cols, feedid_emb = common.wechat_category_columns(dims, sequence_feed=True)
+    return common.dense_columns(), cols, [feedid_emb[0]], [feedid_emb[1]], common.label_columns()
+
+
+total_feature_columns: list = []
+label_feature_columns: list = []
+example_parser = common.make_example_parser(lambda: (total_feature_columns, label_feature_columns))
+
+
+def din_model_fn(features, labels, mode, params):
+    """din.py:186-290."""
+    training = mode == ModeKeys.TRAIN
+    parts = []
+    with variable_scope("dense_input"):
+        dense_cols = params.get("dense_feature_columns") or []
+        if dense_cols:
+            parts.append(fc.input_layer(features, dense_cols))
+    with variable_scope("category_input"):
+        category_input = fc.input_layer(features, params["category_feature_columns"])
+    with variable_scope("target_input"):
+        target_input, _ = fc.sequence_input_layer(features, params["target_feedid_feature_columns"], max_length=1)
+        target_input = target_input.squeeze(1)                                   # (B, H)
+    with variable_scope("his_seq_input"):
+        seq_input, seq_length = fc.sequence_input_layer(features, params["sequence_feature_columns"],
+                                                        max_length=params.get("sequence_max_length"))
+    with variable_scope("attention_part"):
+        attention_output = din_attention(target_input, seq_input, seq_length,
+                                         is_softmax=params["use_softmax"])       # (B, H)
+    concat_all = torch.cat(parts + [category_input, target_input, attention_output], dim=-1)
+
+    with variable_scope("fcn"):
+        net = concat_all
+        for i, unit in enumerate(params["hidden_units"]):
+            layer_index = i + 1
+            net = nn.dense(net, unit, activation=None)
+            net = dice(net, name=layer_index) if params["activation"] == "dice" else prelu(net, name=layer_index)
+            if params["batch_norm"]:
+                net = nn.batch_normalization(net, training=training)
+            if "dropout_rate" in params and 0.0 < params["dropout_rate"] < 1.0:
+                net = nn.dropout(net, params["dropout_rate"], training=training)
+        logit = nn.dense(net, 1)
+
+    def mba_reg():
+        if params["mini_batch_aware_regularization"] and params["l2_lambda"] > 0:
+            ev = torch.cat([category_input, target_input, attention_output], dim=-1)
+            return params["l2_lambda"] * (ev * ev).sum() / 2 / ev.shape[0]
+        return None
+
+    return finish_model_fn(mode, logit, labels, params, extra_loss=mba_reg)
+
+
+def main(unused_argv):
+    global total_feature_columns, label_feature_columns
+    dense_cols, category_cols, target_cols, seq_cols, label_feature_columns = create_feature_columns()
+    total_feature_columns = dense_cols + category_cols + target_cols + seq_cols
+    params = {
+        "dense_feature_columns": dense_cols,
+        "category_feature_columns": category_cols,
+        "sequence_feature_columns": seq_cols,
+        "target_feedid_feature_columns": target_cols,
+        "hidden_units": FLAGS.hidden_units.split(","),
+        "dropout_rate": FLAGS.dropout_rate,
+        "batch_norm": FLAGS.batch_norm,
+        "learning_rate": FLAGS.learning_rate,
+        "activation": FLAGS.activation,
+        "mini_batch_aware_regularization": FLAGS.mini_batch_aware_regularization,
+        "l2_lambda": FLAGS.l2_lambda,
+        "use_softmax": FLAGS.use_softmax,
+    }
+    common.run_estimator(din_model_fn, params, example_parser)
+
+
+if __name__ == "__main__":
+    flags.run(main)

@@ -318,6 +318,47 @@ def cin_layer(store, x0: torch.Tensor, xk: torch.Tensor, filt: Variable):
 
 
 # =============================================================================================
+# K9: DIN attention
+# =============================================================================================
+class _DinAttentionFn(Function):
+    @staticmethod
+    def forward(ctx, anchor, query, keys, keys_length, vs, is_softmax: bool):
+        # vs = (f1_w, f1_b, f2_w, f2_b, f3_w, f3_b) Variables
+        B, T, H = keys.shape
+        out = torch.empty(B, H, device=query.device, dtype=torch.float32)
+        _lib.check(_lib_().recalgo_din_attention_fwd(
+            _p(query), _p(keys), _p(keys_length), *[_p(v.data) for v in vs], B, T, H, int(is_softmax),
+            _p(out), _stream(query)), "recalgo_din_attention_fwd")
+        ctx.vs, ctx.is_softmax, ctx.kl = vs, is_softmax, keys_length
+        ctx.save_for_backward(query, keys)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        query, keys = ctx.saved_tensors
+        B, T, H = keys.shape
+        vs = ctx.vs
+        lib = _lib_()
+        g = g.contiguous()
+        ws = _workspace(lib.recalgo_din_attention_bwd_workspace_bytes(B, T, H), query.device)
+        dq, dk = torch.empty_like(query), torch.empty_like(keys)
+        _lib.check(lib.recalgo_din_attention_bwd(
+            _p(query), _p(keys), _p(ctx.kl), *[_p(v.data) for v in vs], _p(g), B, T, H,
+            int(ctx.is_softmax), _p(dq), _p(dk), *[_p(v.grad) for v in vs], _p(ws), _stream(query)),
+            "recalgo_din_attention_bwd")
+        return None, dq, dk, None, None, None
+
+
+def din_attention(store, query, keys, keys_length, vs, is_softmax=False) -> torch.Tensor:
+    """query [B,H], keys [B,T,H], keys_length [B] int32 -> [B,H]."""
+    _chk(query, torch.float32, "query")
+    _chk(keys, torch.float32, "keys")
+    if keys_length.dtype != torch.int32:
+        keys_length = keys_length.to(torch.int32)
+    return _DinAttentionFn.apply(store.anchor, query, keys, keys_length.contiguous(), tuple(vs), bool(is_softmax))
+
+
+# =============================================================================================
 # a14: loss tail
 # =============================================================================================
 class _SigmoidCEFn(Function):
