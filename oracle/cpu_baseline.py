@@ -59,7 +59,11 @@ def run(model: str, batch=4096, fields=26, emb=16, max_vocab=1_000_000, seconds=
     if model != "dcn":
         return {"value": None, "unit": "examples/s", "cores": 0, "kind": "port",
                 "sample": f"{model}: cpu baseline not wired yet"}
-    threads = threads or os.cpu_count() or 1
+    # threads actually used: the cores this process may run on, capped at 32 (the per-op work of
+    # a 4096-example batch does not scale past that; TF1's default intra-op pool has the same
+    # problem on many-core hosts)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = threads or max(1, min(avail, 32))
     torch.set_num_threads(threads)
     real = [20000, 106444, 2, 18789, 25159, 17500]
     extra = fields - len(real)
@@ -82,7 +86,7 @@ def run(model: str, batch=4096, fields=26, emb=16, max_vocab=1_000_000, seconds=
             for k, p in P.items():
                 g = p.grad if p.grad is not None else torch.zeros_like(p)
                 R.adam_tf1_step(p, g, m[k], v2[k], t, 0.005)       # dense: all rows decay (TF1)
-        return float(out["loss"])
+        return float(out["loss"].detach())
 
     step(1)                                            # warm-up (allocations, MKL init)
     times, t, t_start = [], 2, time.perf_counter()
@@ -91,7 +95,7 @@ def run(model: str, batch=4096, fields=26, emb=16, max_vocab=1_000_000, seconds=
         step(t)
         times.append(time.perf_counter() - t0)
         t += 1
-        if len(times) >= 3 and time.perf_counter() - t_start > seconds:
+        if time.perf_counter() - t_start > seconds:
             break
         if len(times) >= 50:
             break
@@ -100,3 +104,18 @@ def run(model: str, batch=4096, fields=26, emb=16, max_vocab=1_000_000, seconds=
             "sample": f"{len(times)} full train steps (fwd+bwd+dense TF1-Adam over {sum(vocabs)} rows) "
                       f"of the DCN workload at batch {batch}, median {med * 1e3:.1f} ms/step, "
                       f"torch-CPU fp32 op-for-op restatement (TF 1.14 not installable)"}
+
+
+if __name__ == "__main__":
+    import argparse
+    import json
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="dcn")
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--fields", type=int, default=26)
+    ap.add_argument("--emb", type=int, default=16)
+    ap.add_argument("--max-vocab", type=int, default=1_000_000)
+    ap.add_argument("--seconds", type=float, default=15.0)
+    ap.add_argument("--threads", type=int, default=None)
+    a = ap.parse_args()
+    print(json.dumps(run(a.model, a.batch, a.fields, a.emb, a.max_vocab, a.seconds, a.threads)), flush=True)

@@ -206,12 +206,27 @@ class GraphedTrainStep:
         self.warmup_steps = warmup
 
     def load(self, features, labels):
+        """Copy a new batch into the static input buffers.  Inputs that are views of one
+        allocation with the same layout on both sides (the 26 id columns of one [B, F] matrix)
+        are moved by a single whole-allocation copy."""
         new = list(_tree_tensors(features, "f")) + list(_tree_tensors(labels, "l"))
+        whole = {}
         for (k0, dst), (k1, src) in zip(self._static, new):
             if k0 != k1 or dst.shape != src.shape:
                 raise ValueError(f"graphed step: input {k1} changed shape/structure")
-            if dst.data_ptr() != src.data_ptr():
+            if dst.data_ptr() == src.data_ptr():
+                continue
+            ds, ss = dst.untyped_storage(), src.untyped_storage()
+            if (dst.dtype == src.dtype and dst.stride() == src.stride() and ds.nbytes() == ss.nbytes()
+                    and dst.storage_offset() == src.storage_offset() and src.device == dst.device):
+                whole.setdefault((ds.data_ptr(), ss.data_ptr()), (dst, src))
+            else:
                 dst.copy_(src, non_blocking=True)
+        for dst, src in whole.values():
+            n = dst.untyped_storage().nbytes() // dst.element_size()
+            d = torch.empty(0, dtype=dst.dtype, device=dst.device).set_(dst.untyped_storage(), 0, (n,), (1,))
+            s_ = torch.empty(0, dtype=src.dtype, device=src.device).set_(src.untyped_storage(), 0, (n,), (1,))
+            d.copy_(s_, non_blocking=True)
 
     def __call__(self, features=None, labels=None):
         if features is not None:
