@@ -194,6 +194,83 @@ int recalgo_din_attention_bwd(const float* query, const float* keys, const int32
                               recalgo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K7  FiBiNET SENET re-weighting.
+ * Replaces senet(input, embedding_dim, reduction_ratio) algorithm/FiBiNET/senet.py:4-36:
+ *   z = mean_k(emb);  a = relu(relu(z @ w1) @ w2);  v_out = emb * a[..., None]     (no biases)
+ *   emb, v_out [B, F, K];  w1 [F, reduction_dim];  w2 [reduction_dim, F];  a_out [B, F] or NULL.
+ * reduction_dim = embedding_dim // reduction_ratio, derived from K (not F) and required to be
+ * < K exactly like the reference's assert (senet.py:18-19).
+ * ------------------------------------------------------------------------------------------ */
+int recalgo_senet_fwd(const float* emb, const float* w1, const float* w2, int B, int F, int K,
+                      int reduction_dim, float* v_out, float* a_out, recalgo_stream_t stream);
+/* Backward (SENET): recomputes z, h, a.
+ *   d_emb (=|+=) g_v * a + broadcast_k(dz) / K;   dw1 [F, Rd], dw2 [Rd, F] overwritten
+ *   (deterministic two-pass sum).  workspace: recalgo_senet_bwd_workspace_bytes(). */
+int64_t recalgo_senet_bwd_workspace_bytes(int B, int F, int K, int reduction_dim);
+int recalgo_senet_bwd(const float* emb, const float* w1, const float* w2, const float* g_v, int B,
+                      int F, int K, int reduction_dim, float* d_emb, int accumulate, float* dw1,
+                      float* dw2, void* workspace, recalgo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K8  FiBiNET bilinear interaction of up to two (input, weight) sets, concatenated on the last
+ * axis.  Replaces bilinear_interaction_layer(input, embedding_dim, type, name)
+ * algorithm/FiBiNET/bilinear_interaction_layer.py:5-42 and, with two sets, the
+ * tf.concat([original, senet], axis=-1) of algorithm/FiBiNET/fibinet.py:177-186.
+ *   pairs (i, j) = itertools.combinations(range(F-1), 2), P = (F-1)(F-2)/2 of them: the LAST
+ *   field never participates.  Pair index = i(2n-i-1)/2 + (j-i-1), n = F-1.
+ *   out[b, pair, out_col + s*K : +K] = (x_s[b,i,:] @ W_s[sel]) * x_s[b,j,:]
+ *   type RECALGO_BILINEAR_ALL: W_s [K,K], sel = 0;   _EACH: W_s [F-1,K,K], sel = i;
+ *   _INTERACTION: W_s [>= P, K, K], sel = pair (the reference allocates F(F-1)/2 slices and
+ *   zip-truncates to the first P: only those are read, and only those receive gradient).
+ *   x_s [B, F, K]; x1 == w1 == NULL for a single set.  out row stride `out_stride` floats per
+ *   pair (>= out_col + n_sets*K), out_stride % 4 == 0, out_col % 4 == 0.
+ * K in {4, 8, 16, 32, 64};  3 <= F <= 128.
+ * ------------------------------------------------------------------------------------------ */
+#define RECALGO_BILINEAR_ALL 0
+#define RECALGO_BILINEAR_EACH 1
+#define RECALGO_BILINEAR_INTERACTION 2
+int recalgo_bilinear_fwd(const float* x0, const float* w0, const float* x1, const float* w1, int B,
+                         int F, int K, int type, float* out, int out_stride, int out_col,
+                         recalgo_stream_t stream);
+/* Backward (Bilinear).  g has the layout of `out`.
+ *   dx_s [B, F, K] overwritten (row F-1 is zero);  dw_s overwritten: [K,K] | [F-1,K,K] | the
+ *   first P slices of the interaction weight (deterministic two-pass sum over the batch).
+ * workspace: recalgo_bilinear_bwd_workspace_bytes(B, F, K, n_sets, type). */
+int64_t recalgo_bilinear_bwd_workspace_bytes(int B, int F, int K, int n_sets, int type);
+int recalgo_bilinear_bwd(const float* x0, const float* w0, const float* x1, const float* w1,
+                         const float* g, int g_stride, int g_col, int B, int F, int K, int type,
+                         float* dx0, float* dw0, float* dx1, float* dw1, void* workspace,
+                         recalgo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K6  PNN product layer, algorithm/PNN/pnn.py:133-181.  The reference's D-iteration loops
+ *   IPNN (:146-158)  lp_i = || sum_f theta[i,f] e_f ||^2
+ *   OPNN (:160-173)  lp_i = sum_{a,c} (s s^T)[a,c] sym(W_i)[a,c],  s = sum_f e_f,
+ *                    sym(W) = triu(W) + triu(W)^T - diag(W)        (quirk B-10)
+ * are quadratic forms in per-example second-order statistics: lp = phi @ omega with
+ *   phi[b, t]   t = (r <= r') over the upper triangle of a Gram matrix, T = R(R+1)/2 columns,
+ *               t(r, r') = r*R - r(r-1)/2 + (r' - r)
+ *               IPNN: R = F, phi = <e_r, e_r'>;     OPNN: R = K, phi = s_r * s_r'
+ *   omega[t, i] = c_t * theta[i,r] * theta[i,r']  |  c_t * W_i[r, r']   (c_t = 1 if r == r' else 2)
+ * These entry points build phi / omega and their gradients; the caller runs the plain GEMM
+ * relu(emb_flat @ linear_w + phi @ omega + bias) on hipBLASLt (pnn.py:139,175-181).
+ *   emb [B, F, K];  product_w: IPNN [D, F], OPNN [D, K, K];  phi [B, T];  omega [T, D].
+ * ------------------------------------------------------------------------------------------ */
+#define RECALGO_PNN_IPNN 0
+#define RECALGO_PNN_OPNN 1
+int recalgo_pnn_feature_count(int F, int K, int method); /* T */
+int recalgo_pnn_features_fwd(const float* emb, int B, int F, int K, int method, float* phi,
+                             recalgo_stream_t stream);
+/* d_emb (=|+=) d(phi)/d(emb)^T dphi  (IPNN / OPNN de_f). */
+int recalgo_pnn_features_bwd(const float* emb, const float* dphi, int B, int F, int K, int method,
+                             float* d_emb, int accumulate, recalgo_stream_t stream);
+int recalgo_pnn_weights_fwd(const float* product_w, int D, int F, int K, int method, float* omega,
+                            recalgo_stream_t stream);
+/* d_product_w overwritten; OPNN: entries below the diagonal get exactly 0. */
+int recalgo_pnn_weights_bwd(const float* product_w, const float* domega, int D, int F, int K,
+                            int method, float* d_product_w, recalgo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * a14  loss tail: sigmoid + mean sigmoid cross entropy, forward and d(loss)/d(logit) fused.
  * Replaces tf.sigmoid + tf.reduce_mean(tf.nn.sigmoid_cross_entropy_with_logits)
  * algorithm/DeepFM/deepfm.py:217,235 (same in all six model_fns).

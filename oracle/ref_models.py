@@ -176,3 +176,53 @@ def din(P, feats, labels, params, training=False):
     if labels is not None and params["mini_batch_aware_regularization"] and params["l2_lambda"] > 0:
         extra = R.din_mba_reg(category, target, att, params["l2_lambda"])                          # :254-257
     return _tail(logit, None if labels is None else labels["read_comment"], extra)
+
+
+def _dnn_bn(P, net, scope, hidden_units, batch_norm, training):
+    """dense(relu) -> [dropout: identity here] -> BN, the DeepFM/PNN/FiBiNET MLP order (quirk B-7)."""
+    for i, _ in enumerate(hidden_units):
+        dn = "dense" if i == 0 else f"dense_{i}"
+        net = R.dense(net, P[f"{scope}/{dn}/kernel"], P[f"{scope}/{dn}/bias"], relu=True)
+        if batch_norm:
+            bn = "batch_normalization" if i == 0 else f"batch_normalization_{i}"
+            net = R.batch_norm(net, P[f"{scope}/{bn}/gamma"], P[f"{scope}/{bn}/beta"],
+                               P[f"{scope}/{bn}/moving_mean"], P[f"{scope}/{bn}/moving_variance"], training)
+    n = len(hidden_units)
+    dn = "dense" if n == 0 else f"dense_{n}"
+    return R.dense(net, P[f"{scope}/{dn}/kernel"], P[f"{scope}/{dn}/bias"])
+
+
+def fibinet(P, feats, labels, params, training=False):
+    """algorithm/FiBiNET/fibinet.py:143-221."""
+    dense_cols = params.get("dense_feature_columns") or []
+    cat = input_layer(P, feats, params["category_feature_columns"], "category_input/input_layer", {})
+    F, K = len(params["category_feature_columns"]), int(params["embedding_dim"])
+    cat = cat.reshape(-1, F, K)                                                                    # :163
+    t = params["bilinear_interaction_type"]
+    bi = R.fibinet_interaction(cat, P["senet_part/senet_w1"], P["senet_part/senet_w2"],
+                               P[f"bilinear_interaction_part/orginal_w_{t}"],
+                               P[f"bilinear_interaction_part/senet_w_{t}"], t)                     # :171-187
+    logit = _dnn_bn(P, bi, "dnn_part", params["hidden_units"], params.get("batch_norm"), training)  # :189-197
+    if dense_cols:
+        dense_in = input_layer(P, feats, dense_cols, "dense_input/input_layer")
+        logit = R.dense(dense_in, P["linear_part/dense/kernel"], P["linear_part/dense/bias"]) + logit   # :168,199
+    return _tail(logit, None if labels is None else labels["read_comment"])
+
+
+def pnn(P, feats, labels, params, training=False):
+    """algorithm/PNN/pnn.py:112-214."""
+    fields = []
+    for i, c in enumerate(params["category_feature_columns"]):                                     # :126-129 list order
+        layer = "input_layer" if i == 0 else f"input_layer_{i}"
+        fields.append(_lookup(P, feats, c, layer, {}))
+    emb = torch.cat(fields, dim=-1)                                                                # :130
+    F, K = len(fields), int(params["embedding_dim"])
+    method = params["product_method"]
+    pw = P["product_part/inner_product_w"] if method == "IPNN" else P["product_part/outer_product_w"]
+    _, _, product_final = R.pnn_product_fast(emb, P["linear_part/linear_w"], pw, P["bias"], F, K, method)   # :133-181
+    logit = _dnn_bn(P, product_final, "fcn", params["hidden_units"], params.get("batch_norm"), training)    # :184-193
+    extra = None
+    wr = float(params.get("weight_regularizer") or 0.0)
+    if labels is not None and wr > 0:            # tf.contrib.layers.l2_regularizer(scale): scale * sum(w^2) / 2
+        extra = wr * 0.5 * ((P["linear_part/linear_w"] ** 2).sum() + (pw ** 2).sum())               # :138,151,164,209-211
+    return _tail(logit, None if labels is None else labels["read_comment"], extra)

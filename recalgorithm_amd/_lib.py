@@ -37,6 +37,17 @@ SIGNATURES = {
     "recalgo_din_attention_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "recalgo_din_attention_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int,
                                           P, P, P, P, P, P, P, P, P, P]),
+    "recalgo_senet_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
+    "recalgo_senet_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
+    "recalgo_senet_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P]),
+    "recalgo_bilinear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_int, c_int, P]),
+    "recalgo_bilinear_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "recalgo_bilinear_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P]),
+    "recalgo_pnn_feature_count": (c_int, [c_int, c_int, c_int]),
+    "recalgo_pnn_features_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
+    "recalgo_pnn_features_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, P]),
+    "recalgo_pnn_weights_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
+    "recalgo_pnn_weights_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
     "recalgo_sigmoid_ce_fwd_bwd": (c_int, [P, P, c_int, c_float, P, P, P, P]),
     "recalgo_adam_tf1_dense": (c_int, [P, P, P, P, c_int64, c_float, P, c_float, c_float, c_float, c_int, P]),
     "recalgo_adam_tf1_advance": (c_int, [P, c_float, c_float, c_float, P, P]),

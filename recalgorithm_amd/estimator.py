@@ -82,6 +82,8 @@ class AdamOptimizer:
                 "step": torch.zeros(1, dtype=torch.int64, device=store.device),
                 "lr_t": torch.zeros(1, dtype=torch.float32, device=store.device),
             }
+        from . import nn
+        nn.apply_parked_grads()             # l2-regulariser contributions (PNN weight_regularizer)
         if grad_hook is not None:           # data-parallel all-reduce of the flat dense grads
             grad_hook(store)
         ops.adam_tf1_advance_(st["step"], st["lr_t"], self.lr, self.beta1, self.beta2)

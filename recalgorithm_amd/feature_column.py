@@ -296,6 +296,39 @@ def input_layer(features, feature_columns, _layer_name: Optional[str] = None) ->
     return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
 
 
+def input_layers_concat(features, feature_columns) -> torch.Tensor:
+    """tf.concat([fc.input_layer(features, [c]) for c in feature_columns], axis=-1): one
+    input_layer call PER COLUMN in LIST order (pnn.py:126-130, deepfm.py:187-190,204), so the
+    TF layer names are input_layer, input_layer_1, ... and the field order is the list order,
+    not the alphabetical one.  Single-valued columns of one width go through ONE fused gather."""
+    store = current_store()
+    dev = store.device
+    cols = list(feature_columns)
+    tables = []
+    for c in cols:
+        layer = store.auto_name("input_layer")
+        if not isinstance(c, EmbeddingColumn):
+            raise TypeError("input_layers_concat: embedding columns only")
+        tables.append(_table_for(store, c, store.full_name(layer)))
+    B = _batch_size(features, cols[0])
+    if store.building:
+        return torch.zeros(B, sum(c.dimension for c in cols), device=dev)
+    idl = [c.categorical_column.ids(features, dev) for c in cols]
+    if len({c.dimension for c in cols}) == 1 and all(isinstance(i, torch.Tensor) for i in idl) \
+            and len({id(t[0]) for t in tables}) == 1:
+        ar = tables[0][0]
+        rb = store.row_base_tensor(ar, [t for _, t in tables])
+        return ops.embedding_gather(store, _as_matrix(idl), ar, rb)
+    parts = []
+    for c, ids, (ar, tname) in zip(cols, idl, tables):
+        if isinstance(ids, Ragged):
+            parts.append(ops.embedding_bag_mean(store, ids.values, ids.offsets, ar, tname))
+        else:
+            rb = store.row_base_tensor(ar, [tname])
+            parts.append(ops.embedding_gather(store, ids.reshape(-1, 1).contiguous(), ar, rb))
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+
+
 def sequence_input_layer(features, feature_columns, max_length: Optional[int] = None):
     """tf.contrib.feature_column.sequence_input_layer (A-6): (B, T, H) zero padded with T the
     longest sequence of the batch (or `max_length` when given, for static shapes), and

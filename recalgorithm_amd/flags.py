@@ -73,6 +73,14 @@ def DEFINE_boolean(name, default, help=""):
 DEFINE_bool = DEFINE_boolean
 
 
+def DEFINE_enum(name, default, enum_values, help=""):
+    """tf.app.flags.DEFINE_enum (fibinet.py:45): a string flag restricted to `enum_values`."""
+    try:
+        FLAGS._parser.add_argument(f"--{name}", default=default, type=str, choices=list(enum_values), help=help)
+    except argparse.ArgumentError:
+        pass
+
+
 def run(main, argv=None):
     """tf.app.run(main)."""
     rest = FLAGS._parse(argv)

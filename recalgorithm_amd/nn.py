@@ -127,3 +127,35 @@ def dropout(x: torch.Tensor, rate: float, training: bool = False) -> torch.Tenso
     if not training or rate <= 0.0:
         return x
     return torch.nn.functional.dropout(x, p=rate, training=True)
+
+
+class _L2RegFn(Function):
+    @staticmethod
+    def forward(ctx, anchor, scale: float, variables):
+        ctx.scale, ctx.vars = scale, variables
+        return sum((v.data * v.data).sum() for v in variables) * (0.5 * scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        # runs before the kernels that OVERWRITE these variables' grads?  No: the parameter-owning
+        # ops overwrite .grad during their own backward, in autograd order.  To be order independent
+        # the regulariser's contribution is parked and added by `apply_parked_grads` (called by the
+        # optimizer before the update).
+        for v in ctx.vars:
+            _PARKED.append((v, ctx.scale, g))
+        return None, None, None
+
+
+_PARKED = []
+
+
+def apply_parked_grads():
+    """grad += scale * g * w for every parked l2 term (called once per step, after backward)."""
+    while _PARKED:
+        v, scale, g = _PARKED.pop()
+        v.grad.add_(v.data * (scale * g))
+
+
+def l2_regularization(scale: float, variables) -> torch.Tensor:
+    """sum_v tf.contrib.layers.l2_regularizer(scale)(v) = scale * sum(v^2) / 2."""
+    return _L2RegFn.apply(current_store().anchor, float(scale), tuple(variables))

@@ -359,6 +359,149 @@ def din_attention(store, query, keys, keys_length, vs, is_softmax=False) -> torc
 
 
 # =============================================================================================
+# K7/K8: FiBiNET SENET + bilinear interaction
+# =============================================================================================
+BILINEAR_TYPES = {"all": 0, "each": 1, "interaction": 2}
+
+
+class _SenetFn(Function):
+    @staticmethod
+    def forward(ctx, anchor, emb, w1: Variable, w2: Variable):
+        B, F, K = emb.shape
+        Rd = w1.data.shape[1]
+        v = torch.empty_like(emb)
+        _lib.check(_lib_().recalgo_senet_fwd(_p(emb), _p(w1.data), _p(w2.data), B, F, K, Rd, _p(v), None,
+                                             _stream(emb)), "recalgo_senet_fwd")
+        ctx.vars = (w1, w2)
+        ctx.save_for_backward(emb)
+        return v
+
+    @staticmethod
+    def backward(ctx, g):
+        w1, w2 = ctx.vars
+        (emb,) = ctx.saved_tensors
+        B, F, K = emb.shape
+        Rd = w1.data.shape[1]
+        lib = _lib_()
+        g = g.contiguous()
+        ws = _workspace(lib.recalgo_senet_bwd_workspace_bytes(B, F, K, Rd), emb.device)
+        d = torch.empty_like(emb)
+        _lib.check(lib.recalgo_senet_bwd(_p(emb), _p(w1.data), _p(w2.data), _p(g), B, F, K, Rd, _p(d), 0,
+                                         _p(w1.grad), _p(w2.grad), _p(ws), _stream(emb)), "recalgo_senet_bwd")
+        return None, d, None, None
+
+
+def senet(store, emb: torch.Tensor, w1: Variable, w2: Variable) -> torch.Tensor:
+    """emb [B,F,K], w1 (F, Rd), w2 (Rd, F) -> re-weighted embeddings [B,F,K]."""
+    _chk(emb, torch.float32, "input")
+    return _SenetFn.apply(store.anchor, emb, w1, w2)
+
+
+class _BilinearFn(Function):
+    @staticmethod
+    def forward(ctx, anchor, btype: int, x0, w0: Variable, x1, w1: Optional[Variable]):
+        B, F, K = x0.shape
+        nv = 1 if x1 is None else 2
+        P = (F - 1) * (F - 2) // 2
+        out = torch.empty(B, P, nv * K, device=x0.device, dtype=torch.float32)
+        _lib.check(_lib_().recalgo_bilinear_fwd(
+            _p(x0), _p(w0.data), _p(x1), None if w1 is None else _p(w1.data), B, F, K, btype, _p(out), nv * K, 0,
+            _stream(x0)), "recalgo_bilinear_fwd")
+        ctx.vars, ctx.btype, ctx.nv = (w0, w1), btype, nv
+        ctx.save_for_backward(x0, x1)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w0, w1 = ctx.vars
+        x0, x1 = ctx.saved_tensors
+        B, F, K = x0.shape
+        nv = ctx.nv
+        lib = _lib_()
+        g = g.contiguous()
+        ws = _workspace(lib.recalgo_bilinear_bwd_workspace_bytes(B, F, K, nv, ctx.btype), x0.device)
+        dx0 = torch.empty_like(x0)
+        dx1 = None if x1 is None else torch.empty_like(x1)
+        _lib.check(lib.recalgo_bilinear_bwd(
+            _p(x0), _p(w0.data), _p(x1), None if w1 is None else _p(w1.data), _p(g), nv * K, 0, B, F, K, ctx.btype,
+            _p(dx0), _p(w0.grad), _p(dx1), None if w1 is None else _p(w1.grad), _p(ws), _stream(x0)),
+            "recalgo_bilinear_bwd")
+        return None, None, dx0, None, dx1, None
+
+
+def bilinear_interaction(store, btype: str, x0: torch.Tensor, w0: Variable,
+                         x1: Optional[torch.Tensor] = None, w1: Optional[Variable] = None) -> torch.Tensor:
+    """(x_s [B,F,K], W_s) for one or two sets -> [B, (F-1)(F-2)/2, n_sets*K] (sets concatenated on
+    the last axis).  For type "interaction" only the first (F-1)(F-2)/2 slices of W_s are read and
+    receive gradient (the reference's zip truncation); the rest keep a zero gradient."""
+    if btype not in BILINEAR_TYPES:
+        raise ValueError(f"Bilinear Interaction type must be in ['all','each','interaction'], got '{btype}'")
+    _chk(x0, torch.float32, "input")
+    if x1 is not None:
+        _chk(x1, torch.float32, "input")
+    return _BilinearFn.apply(store.anchor, BILINEAR_TYPES[btype], x0, w0, x1, w1)
+
+
+# =============================================================================================
+# K6: PNN product layer
+# =============================================================================================
+PNN_METHODS = {"IPNN": 0, "OPNN": 1}
+
+
+class _PnnProductFn(Function):
+    """relu(emb @ linear_w + phi(emb) @ omega(product_w) + bias): the feature / weight builders
+    and their gradients are HIP kernels, the two contractions are plain hipBLASLt GEMMs."""
+
+    @staticmethod
+    def forward(ctx, anchor, emb_flat, linear_w: Variable, product_w: Variable, bias: Variable, F, K, method):
+        B = emb_flat.shape[0]
+        D = linear_w.data.shape[1]
+        lib = _lib_()
+        T = lib.recalgo_pnn_feature_count(F, K, method)
+        st = _stream(emb_flat)
+        phi = torch.empty(B, T, device=emb_flat.device, dtype=torch.float32)
+        omega = torch.empty(T, D, device=emb_flat.device, dtype=torch.float32)
+        _lib.check(lib.recalgo_pnn_features_fwd(_p(emb_flat), B, F, K, method, _p(phi), st), "recalgo_pnn_features_fwd")
+        _lib.check(lib.recalgo_pnn_weights_fwd(_p(product_w.data), D, F, K, method, _p(omega), st),
+                   "recalgo_pnn_weights_fwd")
+        y = torch.addmm(bias.data, emb_flat, linear_w.data)       # lz + bias        (pnn.py:139,178)
+        y.addmm_(phi, omega)                                       # + lp             (pnn.py:175)
+        torch.relu_(y)                                             # pnn.py:181
+        ctx.vars = (linear_w, product_w, bias)
+        ctx.dims = (F, K, method)
+        ctx.save_for_backward(emb_flat, phi, omega, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        linear_w, product_w, bias = ctx.vars
+        F, K, method = ctx.dims
+        emb_flat, phi, omega, y = ctx.saved_tensors
+        B, D = y.shape
+        lib = _lib_()
+        st = _stream(emb_flat)
+        gz = g * (y > 0)
+        torch.sum(gz, dim=0, out=bias.grad)
+        torch.mm(emb_flat.t(), gz, out=linear_w.grad)
+        d_emb = gz @ linear_w.data.t()
+        dphi = gz @ omega.t()
+        domega = phi.t() @ gz
+        _lib.check(lib.recalgo_pnn_features_bwd(_p(emb_flat), _p(dphi), B, F, K, method, _p(d_emb), 1, st),
+                   "recalgo_pnn_features_bwd")
+        _lib.check(lib.recalgo_pnn_weights_bwd(_p(product_w.data), _p(domega), D, F, K, method, _p(product_w.grad), st),
+                   "recalgo_pnn_weights_bwd")
+        return None, d_emb, None, None, None, None, None, None
+
+
+def pnn_product_layer(store, emb_flat: torch.Tensor, linear_w: Variable, product_w: Variable, bias: Variable,
+                      F: int, K: int, method: str) -> torch.Tensor:
+    """emb_flat [B, F*K] -> relu(lz + lp + bias) [B, D] (pnn.py:133-181)."""
+    _chk(emb_flat, torch.float32, "fields_embeddings")
+    return _PnnProductFn.apply(store.anchor, emb_flat, linear_w, product_w, bias, int(F), int(K),
+                               PNN_METHODS["IPNN" if method == "IPNN" else "OPNN"])
+
+
+# =============================================================================================
 # a14: loss tail
 # =============================================================================================
 class _SigmoidCEFn(Function):

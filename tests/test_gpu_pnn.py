@@ -1,0 +1,78 @@
+"""-m gpu parity of the PNN product-layer kernels (K6) against the oracle's op-for-op restatement
+of /root/reference algorithm/PNN/pnn.py:133-181 (the D-iteration loop, `pnn_product`)."""
+import ctypes
+
+import pytest
+import torch
+
+from oracle import ref_ops as R
+from recalgorithm_amd import _lib
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("method", ["IPNN", "OPNN"])
+@pytest.mark.parametrize("B,F,K,D", [(129, 26, 16, 64), (40, 8, 8, 33), (7, 3, 4, 5), (66, 70, 12, 16)])
+def test_pnn_product_layer_pieces(dev, method, B, F, K, D):
+    """lp = phi @ omega reproduces the reference loop; the feature / weight backward kernels
+    reproduce autograd through the loop."""
+    lib = _lib.load()
+    m = {"IPNN": 0, "OPNN": 1}[method]
+    gen = torch.Generator().manual_seed(B + D)
+    emb = torch.randn(B, F * K, generator=gen) * 0.5
+    lw = torch.randn(F * K, D, generator=gen) * 0.1
+    pw = torch.randn(*((D, F) if method == "IPNN" else (D, K, K)), generator=gen) * 0.3
+    bias = torch.randn(D, generator=gen) * 0.1
+    g = torch.randn(B, D, generator=gen)
+    ed, lwd, pwd, bd = (t.double().requires_grad_(True) for t in (emb, lw, pw, bias))
+    _, lp_ref, out_ref = R.pnn_product(ed, lwd, pwd, bd, F, K, method)        # the literal D-iteration loop
+    lp_ref.backward(g.double())
+
+    T = lib.recalgo_pnn_feature_count(F, K, m)
+    assert T == (F * (F + 1) // 2 if method == "IPNN" else K * (K + 1) // 2)
+    eg, pg, gg = emb.to(dev), pw.to(dev), g.to(dev)
+    phi = torch.empty(B, T, device=dev)
+    omega = torch.empty(T, D, device=dev)
+    _lib.check(lib.recalgo_pnn_features_fwd(_p(eg), B, F, K, m, _p(phi), _st()), "features fwd")
+    _lib.check(lib.recalgo_pnn_weights_fwd(_p(pg), D, F, K, m, _p(omega), _st()), "weights fwd")
+    lp = phi.double() @ omega.double()
+    assert_close(lp, lp_ref, what=f"{method} lp = phi @ omega")
+    # backward pieces, chained in fp64 around the kernels
+    dphi = (gg.double() @ omega.double().t()).float()
+    domega = (phi.double().t() @ gg.double()).float()
+    d_emb = torch.full((B, F * K), 0.25, device=dev)
+    _lib.check(lib.recalgo_pnn_features_bwd(_p(eg), _p(dphi), B, F, K, m, _p(d_emb), 1, _st()), "features bwd")
+    assert_close(d_emb - 0.25, ed.grad, what=f"{method} d_emb (accumulate)", reduced=True)
+    d_emb2 = torch.empty_like(d_emb)
+    _lib.check(lib.recalgo_pnn_features_bwd(_p(eg), _p(dphi), B, F, K, m, _p(d_emb2), 0, _st()), "features bwd")
+    assert_close(d_emb2, ed.grad, what=f"{method} d_emb", reduced=True)
+    dpw = torch.empty_like(pg)
+    _lib.check(lib.recalgo_pnn_weights_bwd(_p(pg), _p(domega), D, F, K, m, _p(dpw), _st()), "weights bwd")
+    assert_close(dpw, pwd.grad, what=f"{method} d_product_w", reduced=True)
+    if method == "OPNN":
+        assert float(torch.tril(dpw, diagonal=-1).abs().max()) == 0.0        # quirk B-10
+
+
+def test_ipnn_identity(dev):
+    """lp_i == sum_{f,g} theta_if theta_ig <e_f, e_g>  (SURVEY.md §8c property 6)."""
+    lib = _lib.load()
+    B, F, K, D = 5, 6, 4, 3
+    gen = torch.Generator().manual_seed(0)
+    E = torch.randn(B, F, K, generator=gen)
+    th = torch.randn(D, F, generator=gen)
+    phi = torch.empty(B, F * (F + 1) // 2, device=dev)
+    omega = torch.empty(F * (F + 1) // 2, D, device=dev)
+    _lib.check(lib.recalgo_pnn_features_fwd(_p(E.to(dev)), B, F, K, 0, _p(phi), _st()), "f")
+    _lib.check(lib.recalgo_pnn_weights_fwd(_p(th.to(dev)), D, F, K, 0, _p(omega), _st()), "w")
+    gram = torch.einsum("bfk,bgk->bfg", E.double(), E.double())
+    brute = torch.einsum("if,ig,bfg->bi", th.double(), th.double(), gram)
+    assert_close(phi.double() @ omega.double(), brute, what="ipnn identity")
