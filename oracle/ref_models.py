@@ -211,10 +211,10 @@ def fibinet(P, feats, labels, params, training=False):
 
 def pnn(P, feats, labels, params, training=False):
     """algorithm/PNN/pnn.py:112-214."""
-    fields = []
+    fields, reg = [], {}
     for i, c in enumerate(params["category_feature_columns"]):                                     # :126-129 list order
         layer = "input_layer" if i == 0 else f"input_layer_{i}"
-        fields.append(_lookup(P, feats, c, layer, {}))
+        fields.append(_lookup(P, feats, c, layer, reg))      # shared table: made by the first layer using it
     emb = torch.cat(fields, dim=-1)                                                                # :130
     F, K = len(fields), int(params["embedding_dim"])
     method = params["product_method"]

@@ -9,6 +9,7 @@ import torch
 
 from . import ops
 from .estimator import AdamOptimizer, EstimatorSpec, ModeKeys, metrics
+from .variables import current_store
 
 
 def sigmoid(logit: torch.Tensor) -> torch.Tensor:
@@ -25,7 +26,10 @@ def finish_model_fn(mode, logit: torch.Tensor, labels, params,
         return EstimatorSpec(mode, predictions=preds, export_outputs={"prediction": preds})
 
     y = labels[label_key]
-    loss, prob = ops.sigmoid_cross_entropy(logit, y)
+    if current_store().building:          # variable-registration pass: nothing is launched
+        loss, prob = logit.new_zeros(()), torch.zeros_like(logit)
+    else:
+        loss, prob = ops.sigmoid_cross_entropy(logit, y)
     if extra_loss is not None:
         extra = extra_loss()
         if extra is not None:

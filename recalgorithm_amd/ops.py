@@ -229,6 +229,8 @@ class _CrossFn(Function):
 
 def cross_stack(store, x0: torch.Tensor, w: Variable, b: Variable) -> torch.Tensor:
     """Fused L-layer CrossNet: w, b are [L, d] block variables."""
+    if store.building:
+        return torch.zeros_like(x0)
     _chk(x0, torch.float32, "x0")
     return _CrossFn.apply(store.anchor, x0, w, b, None)
 
@@ -264,6 +266,8 @@ class _CrossLayerFn(Function):
 
 def cross_layer(store, x0: torch.Tensor, xl: torch.Tensor, w: Variable, b: Variable) -> torch.Tensor:
     """One layer, w/b of shape (d, 1) or (d,): out = x0 * (xl . w) + b + xl."""
+    if store.building:
+        return torch.zeros_like(x0)
     _chk(x0, torch.float32, "x0")
     _chk(xl, torch.float32, "xl")
     return _CrossLayerFn.apply(store.anchor, x0, xl, w, b)
@@ -312,6 +316,9 @@ class _CinFn(Function):
 
 def cin_layer(store, x0: torch.Tensor, xk: torch.Tensor, filt: Variable):
     """x0 [B,m,D], xk [B,Hk,D], filt (1, Hk*m, N) -> (xk_1 [B,N,D], sum-pooled [B,N])."""
+    if store.building:
+        N = filt.data.shape[-1]
+        return x0.new_zeros(x0.shape[0], N, x0.shape[2]), x0.new_zeros(x0.shape[0], N)
     _chk(x0, torch.float32, "x0")
     _chk(xk, torch.float32, "xk")
     return _CinFn.apply(store.anchor, x0, xk, filt)
@@ -351,6 +358,8 @@ class _DinAttentionFn(Function):
 
 def din_attention(store, query, keys, keys_length, vs, is_softmax=False) -> torch.Tensor:
     """query [B,H], keys [B,T,H], keys_length [B] int32 -> [B,H]."""
+    if store.building:
+        return torch.zeros_like(query)
     _chk(query, torch.float32, "query")
     _chk(keys, torch.float32, "keys")
     if keys_length.dtype != torch.int32:
@@ -393,6 +402,8 @@ class _SenetFn(Function):
 
 def senet(store, emb: torch.Tensor, w1: Variable, w2: Variable) -> torch.Tensor:
     """emb [B,F,K], w1 (F, Rd), w2 (Rd, F) -> re-weighted embeddings [B,F,K]."""
+    if store.building:
+        return torch.zeros_like(emb)
     _chk(emb, torch.float32, "input")
     return _SenetFn.apply(store.anchor, emb, w1, w2)
 
@@ -436,6 +447,9 @@ def bilinear_interaction(store, btype: str, x0: torch.Tensor, w0: Variable,
     receive gradient (the reference's zip truncation); the rest keep a zero gradient."""
     if btype not in BILINEAR_TYPES:
         raise ValueError(f"Bilinear Interaction type must be in ['all','each','interaction'], got '{btype}'")
+    if store.building:
+        B, F, K = x0.shape
+        return x0.new_zeros(B, (F - 1) * (F - 2) // 2, (1 if x1 is None else 2) * K)
     _chk(x0, torch.float32, "input")
     if x1 is not None:
         _chk(x1, torch.float32, "input")
@@ -496,6 +510,8 @@ class _PnnProductFn(Function):
 def pnn_product_layer(store, emb_flat: torch.Tensor, linear_w: Variable, product_w: Variable, bias: Variable,
                       F: int, K: int, method: str) -> torch.Tensor:
     """emb_flat [B, F*K] -> relu(lz + lp + bias) [B, D] (pnn.py:133-181)."""
+    if store.building:
+        return emb_flat.new_zeros(emb_flat.shape[0], linear_w.data.shape[1])
     _chk(emb_flat, torch.float32, "fields_embeddings")
     return _PnnProductFn.apply(store.anchor, emb_flat, linear_w, product_w, bias, int(F), int(K),
                                PNN_METHODS["IPNN" if method == "IPNN" else "OPNN"])
@@ -562,6 +578,8 @@ class _ActFn(Function):
 
 
 def activation(store, x: torch.Tensor, alpha: Variable, kind: str) -> torch.Tensor:
+    if store.building:
+        return torch.zeros_like(x)
     return _ActFn.apply(store.anchor, x, alpha, _ACT[kind])
 
 

@@ -1,0 +1,128 @@
+"""Helpers shared by the golden-vector tests (tests/golden/*.npz, written by oracle/gen_golden.py
+from the reference's own sources run on oracle/tf1_shim)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+MODELS = ["model_deepfm", "model_dcn", "model_xdeepfm", "model_din_dice", "model_din_prelu_softmax",
+          "model_fibinet_all", "model_fibinet_each", "model_fibinet_interaction", "model_pnn_ipnn",
+          "model_pnn_opnn_reg"]
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def section(d, prefix):
+    return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
+
+
+def write_vocab_dir(path):
+    """The synthetic vocabulary directory the goldens were generated with (`<stem>_<i>` keys)."""
+    b = load("batch")
+    os.makedirs(path, exist_ok=True)
+    for k, n in section(b, "vocab/").items():
+        with open(os.path.join(path, k + ".txt"), "w") as f:
+            for i in range(int(n)):
+                f.write(f"{k}_{i}\n")
+    return path.rstrip("/") + "/"
+
+
+def string_batch():
+    """-> (features: key -> list of lists of str | float32 [B,1] tensors, labels [B,1] float64)."""
+    b = load("batch")
+    feats = {}
+    for key in {k.split("/")[1] for k in b if k.startswith("str/")}:
+        vals, offs = b[f"str/{key}/values"], b[f"str/{key}/offsets"]
+        feats[key] = [[str(w) for w in vals[offs[i]:offs[i + 1]]] for i in range(len(offs) - 1)]
+    dense = b["dense"]
+    for j, nm in enumerate(b["dense_names"]):
+        feats[str(nm)] = torch.from_numpy(dense[:, j:j + 1].copy())
+    return feats, torch.from_numpy(b["labels"].copy())
+
+
+def mirror_setup(name, vocab_dir):
+    """Build (model_fn, params, oracle_fn_name) for golden `name` from the MIRROR's own
+    create_feature_columns() — the column definitions are part of what the goldens pin."""
+    from recalgorithm_amd import flags
+    d = load(name)
+    fl = {k: (v.item() if v.shape == () else v) for k, v in section(d, "flag/").items()}
+    FL = flags.FLAGS
+    FL.vocabulary_dir = vocab_dir
+    for k, v in fl.items():
+        setattr(FL, k, v)
+    hidden = str(fl["hidden_units"]).split(",")
+    lr = float(fl["learning_rate"])
+    if name == "model_deepfm":
+        from recalgorithm_amd.algorithm.DeepFM import deepfm as m
+        first, second, _ = m.create_feature_columns()
+        return m.deepfm_model_fn, {"first_order_feature_columns": first, "second_order_feature_columns": second,
+                                   "hidden_units": hidden, "learning_rate": lr, "dropout_rate": 0.0,
+                                   "batch_norm": True}, "deepfm"
+    if name == "model_dcn":
+        from recalgorithm_amd.algorithm.DCN import dcn as m
+        dense, cat, _ = m.create_feature_columns()
+        return m.dcn_model_fn, {"category_feature_columns": cat, "dense_feature_columns": dense,
+                                "hidden_units": hidden, "num_cross_layer": int(fl["num_cross_layer"]),
+                                "learning_rate": lr}, "dcn"
+    if name == "model_xdeepfm":
+        from recalgorithm_amd.algorithm.xDeepFM import xdeepfm as m
+        dense, cat, _ = m.create_feature_columns()
+        return m.xdeepfm_model_fn, {"category_feature_columns": cat, "dense_feature_columns": dense,
+                                    "hidden_units": hidden, "learning_rate": lr,
+                                    "embedding_dim": int(fl["embedding_dim"]),
+                                    "cin_layer_feature_maps": str(fl["cin_layer_feature_maps"]).split(",")}, "xdeepfm"
+    if name.startswith("model_din"):
+        from recalgorithm_amd.algorithm.DIN import din as m
+        dense, cat, tgt, seq, _ = m.create_feature_columns()
+        return m.din_model_fn, {"dense_feature_columns": dense, "category_feature_columns": cat,
+                                "sequence_feature_columns": seq, "target_feedid_feature_columns": tgt,
+                                "hidden_units": hidden, "dropout_rate": 0.0, "batch_norm": True, "learning_rate": lr,
+                                "activation": str(fl["activation"]),
+                                "mini_batch_aware_regularization": bool(fl["mini_batch_aware_regularization"]),
+                                "l2_lambda": float(fl["l2_lambda"]), "use_softmax": bool(fl["use_softmax"])}, "din"
+    if name.startswith("model_fibinet"):
+        from recalgorithm_amd.algorithm.FiBiNET import fibinet as m
+        dense, cat, _ = m.create_feature_columns()
+        return m.fibinet_model_fn, {"category_feature_columns": cat, "dense_feature_columns": dense,
+                                    "hidden_units": hidden, "dropout_rate": 0.0, "batch_norm": True,
+                                    "learning_rate": lr, "embedding_dim": int(fl["embedding_dim"]),
+                                    "reduction_ratio": int(fl["reduction_ratio"]),
+                                    "bilinear_interaction_type": str(fl["bilinear_interaction_type"])}, "fibinet"
+    if name.startswith("model_pnn"):
+        from recalgorithm_amd.algorithm.PNN import pnn as m
+        cat, _ = m.create_feature_columns()
+        return m.pnn_model_fn, {"category_feature_columns": cat, "hidden_units": hidden, "dropout_rate": 0.0,
+                                "batch_norm": True, "learning_rate": lr,
+                                "output_dimension": int(fl["output_dimension"]),
+                                "product_method": str(fl["product_method"]),
+                                "weight_regularizer": float(fl["weight_regularizer"]),
+                                "embedding_dim": int(fl["embedding_dim"])}, "pnn"
+    raise KeyError(name)
+
+
+def all_columns(params):
+    cols = []
+    for k, v in params.items():
+        if k.endswith("_feature_columns"):
+            cols += list(v)
+    return cols
+
+
+def golden_to_oracle_vars(name, gvars, params):
+    """Golden variables are keyed by the reference's TF names.  The oracle / mirror use the same
+    names except that DeepFM's (sum V, 1) first-order kernel is kept as one slice per indicator
+    column (rows in sorted(column.name) order)."""
+    out = dict(gvars)
+    if name == "model_deepfm":
+        kern = out.pop("fm_first_order/fm_first_order_dense/kernel")
+        row = 0
+        for c in sorted(params["first_order_feature_columns"], key=lambda c: c.name):
+            v = c.categorical_column.num_buckets
+            out[f"fm_first_order/fm_first_order_dense/kernel/{c.key}"] = kern[row:row + v]
+            row += v
+        assert row == kern.shape[0]
+    return out

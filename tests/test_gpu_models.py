@@ -191,9 +191,21 @@ def test_din_forward_backward(dev, use_softmax, activation):
     est = Estimator(din_model_fn, params, RunConfig(device=dev, seed=5))
     feats, labels, _ = synth.device_features(spec, 200, dev)
     est.build(feats, labels)
+    # alpha starts at 1.0, which makes PReLU and Dice the identity (activations.py:13-17,31) and the
+    # whole fcn stack affine: move it away so that the activations are exercised for real
+    g = torch.Generator().manual_seed(99)
+    for name, v in est.store.vars.items():
+        if "alpha" in name:
+            v.data.copy_((0.25 + 0.5 * torch.rand(v.data.shape, generator=g)).to(dev))
     P, cf, cl = oracle_inputs(est, feats, labels)
     ref = M.din(P, cf, cl, params, training=True)
     ref["loss"].backward()
+    # fp32 evaluation noise of the reference arithmetic itself (the same op-for-op restatement run
+    # in float32, i.e. what the TF1-CPU graph would do): batch-summed gradients behind a
+    # BatchNorm cancel heavily (sum_b g_b = 0), so their error scales with sum|terms|, which only
+    # the fp32 run of the same sum can tell
+    P32, cf32, cl32 = oracle_inputs(est, feats, labels, dtype=torch.float32)
+    M.din(P32, cf32, cl32, params, training=True)["loss"].backward()
     spec_ = est._call_model_fn(feats, labels, ModeKeys.TRAIN)
     assert_close(spec_.loss, ref["loss"], what="din loss")
     assert_close(spec_.predictions["probabilities"], ref["prob"], what="din prob")
@@ -202,17 +214,16 @@ def test_din_forward_backward(dev, use_softmax, activation):
     for name, p in P.items():
         if p.grad is None:
             continue
-        if name.endswith("f3_att/bias") or re.search(r"fcn/dense(_\d+)?/bias$", name):
-            # gradients that cancel to ~0 analytically, judged at the scale of the sibling kernel
-            # gradient (same upstream terms, no cancellation):
-            #  * f3_att/bias = sum_t ds_t: exactly 0 under softmax (shift invariance);
-            #  * fcn/dense*/bias: DIN is dense -> dice|prelu -> BN (din.py:228-236); with alpha = 1
-            #    (the initial value) both activations are the identity, and a bias that feeds a
-            #    training-mode BatchNorm is removed by the mean subtraction -> gradient exactly 0.
+        noise = float((P32[name].grad.double() - p.grad).abs().max())
+        if name.endswith("/bias") and name.replace("bias", "kernel") in P:
+            # biases whose gradient cancels analytically (f3_att/bias = sum_t ds_t is exactly 0 under
+            # softmax; a dense bias feeding a training-mode BatchNorm): judged at the scale of the
+            # sibling kernel gradient (same upstream terms, no cancellation)
             scale = float(P[name.replace("bias", "kernel")].grad.abs().max())
-            assert float((grads[name].cpu().double() - p.grad).abs().max()) <= 1e-5 * scale, name
+            err = float((grads[name].cpu().double() - p.grad).abs().max())
+            assert err <= 1e-5 * scale + 4 * noise, f"{name}: err {err} scale {scale} noise {noise}"
             continue
-        assert_close(grads[name], p.grad, what=f"din d({name})", reduced=True)
+        assert_close(grads[name], p.grad, what=f"din d({name})", reduced=True, floor=4 * noise)
 
 
 def _grad_parity(model, est, P, grads):
@@ -248,6 +259,13 @@ def test_fibinet_forward_backward(dev, btype):
     names = set(est.store.named_arrays())
     assert f"bilinear_interaction_part/orginal_w_{btype}" in names and "senet_part/senet_w1" in names
     P, cf, cl = oracle_inputs(est, feats, labels)
+    # eval / predict modes share the forward (before TRAIN, whose forward updates the BN moving stats)
+    ev = est._call_model_fn(feats, labels, ModeKeys.EVAL)
+    ref_e = M.fibinet(P, cf, cl, params, training=False)
+    assert_close(ev.loss, ref_e["loss"], what="fibinet eval loss")
+    pr = est._call_model_fn(feats, None, ModeKeys.PREDICT)
+    assert set(pr.predictions) == {"logit", "probabilities"}
+    assert_close(pr.predictions["logit"], ref_e["logit"], what="fibinet logit")
     ref = M.fibinet(P, cf, cl, params, training=True)
     ref["loss"].backward()
     spec_ = est._call_model_fn(feats, labels, ModeKeys.TRAIN)
@@ -255,13 +273,6 @@ def test_fibinet_forward_backward(dev, btype):
     assert_close(spec_.predictions["probabilities"], ref["prob"], what="fibinet prob")
     spec_.loss.backward()
     _grad_parity("fibinet", est, P, named_grads(est.store))
-    # eval / predict modes share the forward
-    ev = est._call_model_fn(feats, labels, ModeKeys.EVAL)
-    ref_e = M.fibinet(P, cf, cl, params, training=False)
-    assert_close(ev.loss, ref_e["loss"], what="fibinet eval loss")
-    pr = est._call_model_fn(feats, None, ModeKeys.PREDICT)
-    assert set(pr.predictions) == {"logit", "probabilities"}
-    assert_close(pr.predictions["logit"], ref_e["logit"], what="fibinet logit")
 
 
 @pytest.mark.parametrize("method,wr", [("IPNN", 0.0), ("OPNN", 0.0), ("IPNN", 0.01), ("OPNN", 0.02)])

@@ -1,0 +1,98 @@
+"""CPU (no kernels launched): host logic of the mirrored reference interface.
+  * every mirrored model_fn, built from the mirror's own create_feature_columns(), creates exactly
+    the variables (TF names and shapes) that the reference's model_fn created when it was executed
+    for the golden vectors (oracle/gen_golden.py) — the variable-registration pass is launch-free;
+  * a1: vocabulary-file string -> id encoding is exact (line number, '' / unknown -> -1), for
+    single-valued, multi-valued and sequence columns;
+  * flags / string hyper-parameters / utils known answers."""
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from recalgorithm_amd import feature_column as fc
+from recalgorithm_amd.estimator import Estimator, RunConfig
+from tests import golden_util as GU
+
+
+@pytest.mark.parametrize("name", GU.MODELS)
+def test_mirror_creates_the_reference_variables(name, tmp_path):
+    vocab_dir = GU.write_vocab_dir(str(tmp_path / "vocabulary"))
+    model_fn, params, _ = GU.mirror_setup(name, vocab_dir)
+    d = GU.load(name)
+    sfeats, labels = GU.string_batch()
+    feats = {k: (v.float() if isinstance(v, torch.Tensor) else v) for k, v in sfeats.items()}
+    est = Estimator(model_fn, params, RunConfig(device="cpu", seed=3, use_hip_graph=False))
+    est.build(feats, {"read_comment": labels.float()})          # registration pass only: no HIP call
+    arrays = est.store.named_arrays()
+    gv = GU.golden_to_oracle_vars(name, GU.section(d, "var/"), params)
+    # Dice's BN statistics are never trained (quirk B-5): constants of the kernel, not variables here
+    missing = [k for k in gv if k not in arrays and "dice_bn" not in k]
+    # cross_part/wl, cross_part/bl: the contiguous blocks behind wl_i / bl_i (fused kernel operands)
+    extra = [k for k in arrays if k not in gv and not re.search(r"/(wl|bl)$", k)]
+    assert not missing, f"reference variables absent from the mirror: {missing}"
+    assert not extra, f"mirror variables the reference does not have: {extra}"
+    for k, v in gv.items():
+        if k in arrays:
+            assert tuple(arrays[k].shape) == tuple(v.shape), (k, arrays[k].shape, v.shape)
+
+
+def test_vocabulary_encoding_is_exact(tmp_path):
+    vocab_dir = GU.write_vocab_dir(str(tmp_path / "vocabulary"))
+    sfeats, _ = GU.string_batch()
+    b = GU.load("batch")
+
+    def expect(word, stem):
+        m = re.fullmatch(rf"{stem}_(\d+)", word)
+        return int(m.group(1)) if m and int(m.group(1)) < int(b[f"vocab/{stem}"]) else -1
+    for key, stem, seq in [("userid", "userid", False), ("device", "device", False),
+                           ("manual_tag_list", "manual_tag_id", False), ("his_read_comment_7d_seq", "feedid", True)]:
+        mk = fc.sequence_categorical_column_with_vocabulary_file if seq else fc.categorical_column_with_vocabulary_file
+        col = mk(key, vocab_dir + stem + ".txt")
+        assert col.num_buckets == int(b[f"vocab/{stem}"])
+        enc = col.encode(sfeats[key])
+        flat = [expect(w, stem) for row in sfeats[key] for w in row]
+        assert enc.values.tolist() == flat
+        assert enc.offsets.tolist() == np.cumsum([0] + [len(r) for r in sfeats[key]]).tolist()
+        assert -1 in flat          # the batch exercises the OOV path
+    # single-valued VarLen feature -> dense [B] ids, -1 where missing
+    col = fc.categorical_column_with_vocabulary_file("userid", vocab_dir + "userid.txt")
+    ids = col.ids({"userid": sfeats["userid"]}, torch.device("cpu"))
+    assert ids.shape == (len(sfeats["userid"]),) and ids.dtype == torch.int64
+    assert ids.tolist() == [expect(r[0], "userid") if r else -1 for r in sfeats["userid"]]
+
+
+def test_input_layer_sorts_columns_by_name():
+    """fc.input_layer concatenates in sorted(column.name) order; shared columns are
+    named <key>_shared_embedding and returned in input order (A-4)."""
+    cats = {k: fc.categorical_column_with_identity(k, 10) for k in ("userid", "device", "authorid", "feedid", "his")}
+    shared = fc.shared_embedding_columns([cats["feedid"], cats["his"]], 8)
+    assert [c.key for c in shared] == ["feedid", "his"]
+    assert shared[0].shared_name == shared[1].shared_name == "feedid_his_shared_embedding"
+    cols = [fc.embedding_column(cats["userid"], 8), fc.embedding_column(cats["device"], 8),
+            fc.embedding_column(cats["authorid"], 8)] + shared
+    assert [c.name for c in sorted(cols, key=lambda c: c.name)] == [
+        "authorid_embedding", "device_embedding", "feedid_shared_embedding", "his_shared_embedding", "userid_embedding"]
+
+
+def test_utils_known_answers():
+    from recalgorithm_amd.algorithm.utils import index_from_upper_triangular
+    n = 7
+    k = 0
+    for i in range(n):
+        for j in range(i + 1, n):
+            assert index_from_upper_triangular(i, j, n) == k      # utils.py:67-82
+            k += 1
+
+
+def test_string_hyperparameters_and_enum_flag():
+    from recalgorithm_amd import flags
+    from recalgorithm_amd.algorithm.FiBiNET import fibinet  # noqa: F401  (defines the flags)
+    flags.FLAGS._overrides.clear()       # programmatic overrides (other tests) shadow parsed values
+    rest = flags.FLAGS._parse(["--bilinear_interaction_type=each", "--hidden_units=64,32", "--batch_norm=False"])
+    assert rest == [] and flags.FLAGS.bilinear_interaction_type == "each"
+    assert flags.FLAGS.hidden_units.split(",") == ["64", "32"] and flags.FLAGS.batch_norm is False
+    with pytest.raises(SystemExit):
+        flags.FLAGS._parse(["--bilinear_interaction_type=bogus"])
+    flags.FLAGS._parse([])

@@ -1,0 +1,148 @@
+"""CPU: the oracle restatement (oracle/ref_ops.py, oracle/ref_models.py) must reproduce the golden
+vectors that oracle/gen_golden.py obtained by executing the reference's own sources
+(/root/reference/algorithm/...) on oracle/tf1_shim.  float64 on both sides -> tight tolerance.
+This is the pin of the oracle (composition level; see oracle/__init__.py "Pinning status")."""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_models as M
+from oracle import ref_ops as R
+from tests import golden_util as GU
+
+TOL = 1e-10
+
+
+def close(a, b, what, tol=TOL):
+    a = torch.as_tensor(np.asarray(a.detach() if isinstance(a, torch.Tensor) else a), dtype=torch.float64).reshape(-1)
+    b = torch.as_tensor(np.asarray(b), dtype=torch.float64).reshape(-1)
+    assert a.shape == b.shape, f"{what}: {a.shape} vs {b.shape}"
+    scale = max(float(b.abs().max()), 1e-30) if b.numel() else 1.0
+    err = float((a - b).abs().max()) if b.numel() else 0.0
+    # + 1e-15 absolute: gradients that vanish analytically (a bias ahead of a training-mode BatchNorm)
+    # are pure fp64 rounding noise (~1e-17) on both sides
+    assert err <= tol * scale + 1e-15, f"{what}: max err {err:.3e} at scale {scale:.3e}"
+
+
+def _layer(name, fn):
+    """Run `fn(inputs: dict of grad-enabled fp64 tensors, vars: dict)` -> out and compare out and
+    all gradients of sum(out * G) with the golden."""
+    d = GU.load(name)
+    ins = {k: torch.from_numpy(v.copy()) for k, v in GU.section(d, "in/").items()}
+    for v in ins.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    vs = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in GU.section(d, "var/").items()}
+    out = fn(ins, vs, d)
+    close(out, d["out"], f"{name} out")
+    (out * torch.from_numpy(d["G"])).sum().backward()
+    for k, g in GU.section(d, "grad_in/").items():
+        close(ins[k].grad, g, f"{name} d(in {k})")
+    for k, g in GU.section(d, "grad_var/").items():
+        got = vs[k].grad if vs[k].grad is not None else torch.zeros_like(vs[k])
+        close(got, g, f"{name} d(var {k})")
+
+
+def test_cross_layer_golden():
+    _layer("layer_cross_stack", lambda i, v, d: R.cross_stack(
+        i["x0"], [v[f"cross_part/wl_{l}"] for l in range(3)], [v[f"cross_part/bl_{l}"] for l in range(3)]))
+    _layer("layer_cross_single", lambda i, v, d: R.cross_layer(i["x0"], i["xl"], v["wl_7"], v["bl_7"]))
+
+
+def test_cin_layer_golden():
+    def stack(i, v, d):
+        _, p_plus = R.cin_stack(i["x0"], [v["cin_part/cin_layer_1_filter"], v["cin_part/cin_layer_2_filter"]])
+        return p_plus
+    _layer("layer_cin_stack", stack)
+    _layer("layer_cin_single", lambda i, v, d: R.cin_layer(i["x0"], i["xk"], v["cin_layer_3_filter"]))
+
+
+@pytest.mark.parametrize("branch", ["default", "softmax"])
+def test_din_attention_golden(branch):
+    a = "attention_part"
+    _layer(f"layer_din_attention_{branch}", lambda i, v, d: R.din_attention(
+        i["query"], i["keys"], i["keys_length"], v[f"{a}/f1_att/kernel"], v[f"{a}/f1_att/bias"],
+        v[f"{a}/f2_att/kernel"], v[f"{a}/f2_att/bias"], v[f"{a}/f3_att/kernel"], v[f"{a}/f3_att/bias"],
+        is_softmax=bool(d["meta/is_softmax"])))
+
+
+def test_activations_golden():
+    _layer("layer_prelu", lambda i, v, d: R.prelu(i["x"], v["prelu_alpha_1"]))
+    _layer("layer_dice", lambda i, v, d: R.dice(i["x"], v["dice_alpha_1"]))
+    d = GU.load("layer_dice")        # quirk B-5: the Dice BN never trains — its stats stay (0, 1)
+    assert np.all(d["var/dice_bn_1/moving_mean"] == 0) and np.all(d["var/dice_bn_1/moving_variance"] == 1)
+
+
+def test_fibinet_layers_golden():
+    _layer("layer_senet", lambda i, v, d: R.senet(i["input"], v["senet_part/senet_w1"], v["senet_part/senet_w2"]))
+    for ty in ("all", "each", "interaction"):
+        _layer(f"layer_bilinear_{ty}", lambda i, v, d, ty=ty: R.bilinear_interaction(
+            i["input"], v[f"bilinear_interaction_part/orginal_w_{ty}"], ty))
+    d = GU.load("layer_bilinear_interaction")     # quirk B-3: F=7 -> 15 pairs, 21 weight slices, 6 unused
+    assert d["out"].shape[1] == 15 and d["var/bilinear_interaction_part/orginal_w_interaction"].shape[0] == 21
+    assert np.all(d["grad_var/bilinear_interaction_part/orginal_w_interaction"][15:] == 0)
+    assert np.all(d["grad_in/input"][:, 6] == 0)
+
+
+def _encode(params, sfeats):
+    """string features -> oracle feature batch (ids; (values, offsets) for multi-valued keys)."""
+    from recalgorithm_amd.feature_column import NumericColumn, Ragged
+    feats = {}
+    for c in GU.all_columns(params):
+        if isinstance(c, NumericColumn):
+            feats[c.key] = sfeats[c.key].double()
+            continue
+        cat = c.categorical_column
+        x = cat.ids({cat.key: sfeats[cat.key]}, torch.device("cpu"))
+        if isinstance(x, Ragged) and cat.key == "feedid":
+            # DIN declares the target `feedid` as a *sequence* column of length <= 1 (din.py:93):
+            # the oracle takes it as a single id per example (-1 = missing)
+            lens = x.offsets[1:] - x.offsets[:-1]
+            dense = torch.full((lens.numel(),), -1, dtype=torch.int64)
+            dense[lens == 1] = x.values
+            x = dense
+        feats[cat.key] = (x.values, x.offsets) if isinstance(x, Ragged) else x
+    return feats
+
+
+@pytest.mark.parametrize("name", GU.MODELS)
+def test_model_golden(name, tmp_path):
+    vocab_dir = GU.write_vocab_dir(str(tmp_path / "vocabulary"))
+    _, params, oracle_name = GU.mirror_setup(name, vocab_dir)
+    d = GU.load(name)
+    sfeats, labels = GU.string_batch()
+    feats = _encode(params, sfeats)
+    gv = GU.golden_to_oracle_vars(name, GU.section(d, "var/"), params)
+    P = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in gv.items()}
+    fn = getattr(M, oracle_name)
+    # PREDICT
+    out = fn(P, feats, None, params, training=False)
+    close(out["prob"], d["predict/probabilities"], f"{name} probabilities")
+    if "predict/logit" in d:
+        close(out["logit"], d["predict/logit"], f"{name} logit")
+    for k in ("fm_first_order_logit", "fm_second_order_logit", "deep_logit"):
+        if f"predict/{k}" in d:
+            close(out[k], d[f"predict/{k}"], f"{name} {k}")
+    # TRAIN: loss and every gradient
+    out = fn(P, feats, {"read_comment": labels}, params, training=True)
+    close(out["loss"], d["train/loss"], f"{name} loss")
+    out["loss"].backward()
+    gg = GU.golden_to_oracle_vars(name, GU.section(d, "grad/"), params)
+    ga = GU.golden_to_oracle_vars(name, GU.section(d, "var_after/"), params)
+    checked = 0
+    for k, g in gg.items():
+        if k not in P:
+            assert "dice_bn" in k, f"golden variable {k} unknown to the oracle"
+            continue
+        got = P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])
+        close(got, g, f"{name} d({k})", tol=1e-9)
+        # one TF1-Adam step (A-10)
+        p = P[k].detach().clone()
+        R.adam_tf1_step(p, torch.from_numpy(g.copy()), torch.zeros_like(p), torch.zeros_like(p), 1,
+                        float(d["meta/learning_rate"]))
+        # step 1 moves by ~lr*g/(|g| + eps'): ill-conditioned where |g| ~ eps' = 3e-7, hence 1e-7
+        close(p, ga[k], f"{name} adam({k})", tol=1e-7)
+        checked += 1
+    assert checked >= 10
