@@ -223,8 +223,11 @@ def main():
 
     est, spec, feats, labels, workload = build_estimator(args, device, rank, world)
     if world > 1:
+        # row-shard the embedding arenas over the ranks, all-reduce the dense gradients; the id /
+        # row all_to_all has data-dependent split sizes, so N > 1 steps are launched eagerly
         from recalgorithm_amd.parallel import attach_data_parallel
         attach_data_parallel(est, dist)
+        args.no_graph = True
 
     from recalgorithm_amd.estimator import GraphedTrainStep
     from recalgorithm_amd.io import synth
@@ -279,7 +282,8 @@ def main():
                    "emb_dim": args.emb, "embedding_rows": int(sum(spec.vocabs)),
                    "optimizer": "TF1 Adam, dense over all tables (reference semantics)",
                    "launch": "eager" if args.no_graph else "hipGraph replay",
-                   "parallelism": f"dp{world}" if world > 1 else "single"},
+                   "parallelism": (f"dp{world} + embedding rows sharded r % {world} (RCCL all_to_all), dense grads all-reduced"
+                                   if world > 1 else "single")},
         "final_loss": round(loss_v, 6),
     }
     if rank == 0:

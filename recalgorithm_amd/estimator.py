@@ -254,6 +254,7 @@ class Estimator:
         self.global_step = 0
         self._built = False
         self.grad_hook = None     # set by parallel wrappers (dense-grad all-reduce)
+        self.loss_grad_scale = None   # 1/world under data parallelism (parallel.attach_data_parallel)
 
     # -- plumbing -------------------------------------------------------------------------
     def _to_device(self, features, labels):
@@ -293,7 +294,10 @@ class Estimator:
         """One eager training step on device-resident inputs; returns the loss tensor."""
         spec = self._call_model_fn(features, labels, ModeKeys.TRAIN)
         op = spec.train_op
-        op.loss.backward()
+        if self.loss_grad_scale is None:
+            op.loss.backward()
+        else:
+            op.loss.backward(torch.full_like(op.loss, self.loss_grad_scale))
         op.optimizer.apply_gradients(self.store, self.grad_hook)
         return spec.loss.detach()
 

@@ -46,6 +46,24 @@ def _chk(t: torch.Tensor, dtype, name: str):
 _ws_cache = {}
 
 
+def _flush(arena) -> None:
+    """Row-sharded deployment (parallel.py): the kernel scattered into a staged gradient; send it
+    to the rows' owners now."""
+    f = getattr(arena, "flush_grad", None)
+    if f is not None:
+        f()
+
+
+def _staged(arena, rows: torch.Tensor):
+    """(staged arena, identity ids [M]) for a row-sharded arena, or None when the arena is local."""
+    sd = getattr(arena, "sharding", None)
+    if sd is None:
+        return None
+    from . import parallel
+    plan = sd.plan(rows)
+    return plan, parallel.StagedArena(plan, arena), parallel.identity_ids(rows, rows.shape)
+
+
 def _workspace(nbytes: int, device) -> torch.Tensor:
     """Per-device grow-only scratch (allocated outside graph capture on first use)."""
     key = (device.type, device.index)
@@ -79,6 +97,7 @@ class _GatherFn(Function):
         _lib.check(_lib_().recalgo_embedding_gather_bwd(
             _p(ids), _p(g), _p(ctx.row_base), B, F, arena.K, F * arena.K, 0, _p(arena.grad),
             _stream(ids)), "recalgo_embedding_gather_bwd")
+        _flush(arena)
         return None, None, None, None
 
 
@@ -87,6 +106,10 @@ def embedding_gather(store: VariableStore, ids: torch.Tensor, arena: EmbeddingAr
     """ids [B,F] int64 (id<0 = OOV) -> [B, F*K]; gradient scattered into arena.grad."""
     _chk(ids, torch.int64, "ids")
     _chk(row_base, torch.int64, "row_base")
+    if getattr(arena, "sharding", None) is not None:
+        from . import parallel
+        _, staged, ident = _staged(arena, parallel.global_rows(ids, row_base))
+        return _GatherFn.apply(store.anchor, ident.reshape(ids.shape), staged, torch.zeros_like(row_base))
     return _GatherFn.apply(store.anchor, ids, arena, row_base)
 
 
@@ -113,12 +136,17 @@ class _BagMeanFn(Function):
         _lib.check(_lib_().recalgo_embedding_bag_mean_bwd(
             _p(values), _p(offsets), _p(g), B, arena.K, arena.K, 0, _p(gt), _stream(offsets)),
             "recalgo_embedding_bag_mean_bwd")
+        _flush(arena)
         return None, None, None, None, None
 
 
 def embedding_bag_mean(store, values, offsets, arena, table_name) -> torch.Tensor:
     _chk(values, torch.int64, "values")
     _chk(offsets, torch.int64, "offsets")
+    if getattr(arena, "sharding", None) is not None:
+        rows = torch.where(values >= 0, values + arena.tables[table_name][0], torch.full_like(values, -1))
+        _, staged, ident = _staged(arena, rows)
+        return _BagMeanFn.apply(store.anchor, ident, offsets, staged, "__staged__")
     return _BagMeanFn.apply(store.anchor, values, offsets, arena, table_name)
 
 
@@ -147,12 +175,17 @@ class _SeqGatherFn(Function):
         _lib.check(_lib_().recalgo_sequence_gather_bwd(
             _p(values), _p(offsets), _p(g), B, T, arena.K, _p(gt), _stream(offsets)),
             "recalgo_sequence_gather_bwd")
+        _flush(arena)
         return None, None, None, None, None, None
 
 
 def sequence_gather(store, values, offsets, arena, table_name, T) -> Tuple[torch.Tensor, torch.Tensor]:
     _chk(values, torch.int64, "values")
     _chk(offsets, torch.int64, "offsets")
+    if getattr(arena, "sharding", None) is not None:
+        rows = torch.where(values >= 0, values + arena.tables[table_name][0], torch.full_like(values, -1))
+        _, staged, ident = _staged(arena, rows)
+        return _SeqGatherFn.apply(store.anchor, ident, offsets, staged, "__staged__", int(T))
     return _SeqGatherFn.apply(store.anchor, values, offsets, arena, table_name, int(T))
 
 
@@ -184,6 +217,8 @@ class _DeepFMSparseFn(Function):
         _lib.check(_lib_().recalgo_deepfm_sparse_bwd(
             _p(ids), _p(emb), _p(fsum), _p(g_emb), _p(g_fm1), _p(g_fm2), _p(row_base), B, F, arena.K,
             _p(arena.grad), _p(w1.grad), _stream(ids)), "recalgo_deepfm_sparse_bwd")
+        _flush(arena)
+        _flush(w1)
         torch.sum(g_fm1, dim=0, out=bias.grad.view(1))
         return None, None, None, None, None, None
 
@@ -191,39 +226,67 @@ class _DeepFMSparseFn(Function):
 def deepfm_sparse(store, ids, arena, w1_arena, bias, row_base):
     """-> (deep_input [B,F*K], fm_first_order_logit [B,1], fm_second_order_logit [B,1])."""
     _chk(ids, torch.int64, "ids")
+    if getattr(arena, "sharding", None) is not None:
+        # the first-order arena mirrors the embedding arena's row layout: one exchange plan, two fetches
+        from . import parallel
+        plan, staged, ident = _staged(arena, parallel.global_rows(ids, row_base))
+        staged_w1 = parallel.StagedArena(plan, w1_arena)
+        return _DeepFMSparseFn.apply(store.anchor, ident.reshape(ids.shape), staged, staged_w1, bias,
+                                     torch.zeros_like(row_base))
     return _DeepFMSparseFn.apply(store.anchor, ids, arena, w1_arena, bias, row_base)
 
 
 # =============================================================================================
 # K4: CrossNet
 # =============================================================================================
+def _pad4(t: torch.Tensor) -> torch.Tensor:
+    """Zero-pad the last dimension to a multiple of 4 (the CrossNet kernels move float4s; the
+    reference's default DCN input is d = 82).  Zero columns of x0 / w / b are inert: they add
+    nothing to x_l . w_l and produce zero output columns."""
+    pad = (-t.shape[-1]) % 4
+    return t if pad == 0 else torch.nn.functional.pad(t, (0, pad))
+
+
 class _CrossFn(Function):
     @staticmethod
     def forward(ctx, anchor, x0, w: Variable, b: Variable, xl_first):
         # w.data, b.data: [L, d].  xl_first is None for the fused stack (x_0 = x0).
         B, d = x0.shape
         L = w.data.shape[0]
-        out = torch.empty(B, d, device=x0.device, dtype=torch.float32)
+        x0p, wp, bp = _pad4(x0), _pad4(w.data.reshape(L, d)), _pad4(b.data.reshape(L, d))
+        dp = x0p.shape[1]
+        out = torch.empty(B, dp, device=x0.device, dtype=torch.float32)
         _lib.check(_lib_().recalgo_cross_fwd(
-            _p(x0), d, _p(w.data), _p(b.data), B, d, L, _p(out), d, _stream(x0)),
+            _p(x0p), dp, _p(wp), _p(bp), B, dp, L, _p(out), dp, _stream(x0)),
             "recalgo_cross_fwd")
         ctx.vars = (w, b)
-        ctx.save_for_backward(x0)
-        return out
+        ctx.d = d
+        ctx.save_for_backward(x0p)
+        return out if dp == d else out[:, :d]
 
     @staticmethod
     def backward(ctx, g):
         w, b = ctx.vars
-        (x0,) = ctx.saved_tensors
-        B, d = x0.shape
+        (x0p,) = ctx.saved_tensors
+        B, dp = x0p.shape
+        d = ctx.d
         L = w.data.shape[0]
-        g = g.contiguous()
+        g = _pad4(g).contiguous()
         lib = _lib_()
-        ws = _workspace(lib.recalgo_cross_bwd_workspace_bytes(B, d, L), x0.device)
-        dx0 = torch.empty_like(x0)
+        ws = _workspace(lib.recalgo_cross_bwd_workspace_bytes(B, dp, L), x0p.device)
+        dx0 = torch.empty_like(x0p)
+        if dp == d:
+            wp, bp, dw, db = w.data, b.data, w.grad, b.grad
+        else:
+            wp, bp = _pad4(w.data.reshape(L, d)), _pad4(b.data.reshape(L, d))
+            dw, db = torch.empty_like(wp), torch.empty_like(bp)
         _lib.check(lib.recalgo_cross_bwd(
-            _p(x0), d, _p(w.data), _p(b.data), _p(g), d, None, B, d, L, _p(dx0), _p(w.grad),
-            _p(b.grad), _p(ws), _stream(x0)), "recalgo_cross_bwd")
+            _p(x0p), dp, _p(wp), _p(bp), _p(g), dp, None, B, dp, L, _p(dx0), _p(dw),
+            _p(db), _p(ws), _stream(x0p)), "recalgo_cross_bwd")
+        if dp != d:
+            w.grad.copy_(dw[:, :d].reshape(w.grad.shape))
+            b.grad.copy_(db[:, :d].reshape(b.grad.shape))
+            dx0 = dx0[:, :d]
         return None, dx0, None, None, None
 
 
@@ -241,26 +304,40 @@ class _CrossLayerFn(Function):
     @staticmethod
     def forward(ctx, anchor, x0, xl, w: Variable, b: Variable):
         B, d = x0.shape
-        out = torch.empty(B, d, device=x0.device, dtype=torch.float32)
+        x0p, xlp = _pad4(x0), _pad4(xl)
+        wp, bp = _pad4(w.data.reshape(1, d)), _pad4(b.data.reshape(1, d))
+        dp = x0p.shape[1]
+        out = torch.empty(B, dp, device=x0.device, dtype=torch.float32)
         _lib.check(_lib_().recalgo_cross_layer_fwd(
-            _p(x0), _p(xl), d, _p(w.data), _p(b.data), B, d, _p(out), d, _stream(x0)),
+            _p(x0p), _p(xlp), dp, _p(wp), _p(bp), B, dp, _p(out), dp, _stream(x0)),
             "recalgo_cross_layer_fwd")
         ctx.vars = (w, b)
-        ctx.save_for_backward(x0, xl)
-        return out
+        ctx.d = d
+        ctx.save_for_backward(x0p, xlp)
+        return out if dp == d else out[:, :d]
 
     @staticmethod
     def backward(ctx, g):
         w, b = ctx.vars
-        x0, xl = ctx.saved_tensors
-        B, d = x0.shape
-        g = g.contiguous()
+        x0p, xlp = ctx.saved_tensors
+        B, dp = x0p.shape
+        d = ctx.d
+        g = _pad4(g).contiguous()
         lib = _lib_()
-        ws = _workspace(lib.recalgo_cross_bwd_workspace_bytes(B, d, 1), x0.device)
-        dx0, dxl = torch.empty_like(x0), torch.empty_like(x0)
+        ws = _workspace(lib.recalgo_cross_bwd_workspace_bytes(B, dp, 1), x0p.device)
+        dx0, dxl = torch.empty_like(x0p), torch.empty_like(x0p)
+        if dp == d:
+            wp, bp, dw, db = w.data, b.data, w.grad, b.grad
+        else:
+            wp, bp = _pad4(w.data.reshape(1, d)), _pad4(b.data.reshape(1, d))
+            dw, db = torch.empty_like(wp), torch.empty_like(bp)
         _lib.check(lib.recalgo_cross_layer_bwd(
-            _p(x0), _p(xl), d, _p(w.data), _p(b.data), _p(g), d, B, d, _p(dx0), _p(dxl),
-            _p(w.grad), _p(b.grad), _p(ws), _stream(x0)), "recalgo_cross_layer_bwd")
+            _p(x0p), _p(xlp), dp, _p(wp), _p(bp), _p(g), dp, B, dp, _p(dx0), _p(dxl),
+            _p(dw), _p(db), _p(ws), _stream(x0p)), "recalgo_cross_layer_bwd")
+        if dp != d:
+            w.grad.copy_(dw[:, :d].reshape(w.grad.shape))
+            b.grad.copy_(db[:, :d].reshape(b.grad.shape))
+            dx0, dxl = dx0[:, :d], dxl[:, :d]
         return None, dx0, dxl, None, None
 
 

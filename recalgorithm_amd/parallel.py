@@ -1,0 +1,225 @@
+"""Multi-GPU: one process per GPU, torch.distributed over RCCL/xGMI (backend "nccl" on ROCm).
+
+The reference is single-process: everything here is new functionality
+whose oracle is "N ranks == 1 rank on the same global batch" (tests/test_dist_gloo.py).
+
+Partitioning
+  * examples: data parallel, B_local per rank;
+  * embedding arenas: ROW-sharded — global arena row r lives on rank r % N at local row r // N
+    (modulo, not ranges: Zipf-hot rows are the low ids of every table and would pile onto rank 0);
+    the Adam moments are sharded with the rows, so TF1's dense Adam is a local pass over the shard;
+  * dense variables: replicated; their flat gradient buffer is all-reduced (one collective).
+
+Per step and arena lookup (`ExchangePlan`)
+  1. bucket the (valid) global rows by owner;  all_to_all of the bucket sizes, then of the local
+     row numbers (int64; B_local*F*8 B per rank, 7/8 of it leaves the GPU);
+  2. every owner gathers its rows from its shard (HIP gather kernel) and all_to_all's them back
+     (B_local*F*K*4 B per rank);  the rows land in a *staged arena* [M, K] in request order;
+  3. the unchanged single-GPU kernels (gather, fused DeepFM sparse path, bag mean, sequence
+     gather) run on the staged arena with identity ids;
+  4. backward: the kernels scatter into the staged gradient, which is all_to_all'ed back to the
+     owners and scatter-added into the shard's gradient (HIP kernel).
+On the 8-GPU xGMI full mesh every peer pair has its own link, so the all_to_all is link-parallel
+(≈0.85 MB per link per direction at B_local=4096, F=26, K=16); the dense all-reduce (≈1.5 MB) is
+latency-bound.  Each rank back-propagates loss_rank / N, so SUM collectives yield the gradient
+of the global-batch mean loss.  BatchNorm uses per-replica statistics (the reference's BN is
+single-device; documented deviation for N > 1).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from .variables import EmbeddingArena
+
+
+class ShardSpec:
+    def __init__(self, rank: int, world: int, group=None, dist=None):
+        self.rank, self.world, self.group = int(rank), int(world), group
+        if dist is None:
+            import torch.distributed as dist
+        self.dist = dist
+
+    def all_to_all(self, out: torch.Tensor, inp: torch.Tensor, out_splits: List[int], in_splits: List[int]):
+        self.dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+
+
+class ExchangePlan:
+    """Who asks whom for which rows: built once per (batch, arena row set), used for the forward
+    fetch of any arena with that row layout and for the gradient push of the backward."""
+
+    def __init__(self, rows: torch.Tensor, sh: ShardSpec):
+        # rows: int64 [M] global arena rows, -1 = OOV / padding (nothing is exchanged for those)
+        self.sh, self.M = sh, rows.numel()
+        W = sh.world
+        pos = torch.nonzero(rows >= 0).squeeze(1)
+        r = rows[pos]
+        owner = r % W
+        order = torch.argsort(owner, stable=True)
+        self.send_pos = pos[order]                       # request slot of every sent row, bucket order
+        send_local = (r // W)[order].contiguous()
+        send_counts = torch.bincount(owner, minlength=W)
+        recv_counts = torch.empty_like(send_counts)
+        sh.dist.all_to_all_single(recv_counts, send_counts, group=sh.group)
+        self.sc = send_counts.tolist()                   # the one host sync of the exchange
+        self.rc = recv_counts.tolist()
+        self.recv_local = torch.empty(sum(self.rc), dtype=torch.int64, device=rows.device)
+        sh.all_to_all(self.recv_local, send_local, self.rc, self.sc)
+
+    def fetch(self, shard_weight: torch.Tensor, local_gather) -> torch.Tensor:
+        """-> [M, K] rows in request order (zero rows where the request was -1)."""
+        K = shard_weight.shape[1]
+        rows_out = local_gather(shard_weight, self.recv_local)             # [sum(rc), K]
+        back = torch.empty(sum(self.sc), K, dtype=shard_weight.dtype, device=shard_weight.device)
+        self.sh.all_to_all(back, rows_out, [c for c in self.sc], [c for c in self.rc])
+        out = torch.zeros(self.M, K, dtype=shard_weight.dtype, device=shard_weight.device)
+        out.index_copy_(0, self.send_pos, back)
+        return out
+
+    def push_grad(self, staged_grad: torch.Tensor, shard_grad: torch.Tensor, local_scatter_add) -> None:
+        """shard_grad[owner rows] += staged_grad rows (duplicates accumulate on the owner)."""
+        K = staged_grad.shape[1]
+        gsend = staged_grad.index_select(0, self.send_pos)
+        grecv = torch.empty(sum(self.rc), K, dtype=staged_grad.dtype, device=staged_grad.device)
+        self.sh.all_to_all(grecv, gsend, [c for c in self.rc], [c for c in self.sc])
+        local_scatter_add(shard_grad, self.recv_local, grecv)
+
+
+# ---- the two local kernels of the exchange (HIP; tests substitute CPU doubles) ------------------
+def hip_local_gather(shard_weight: torch.Tensor, local_rows: torch.Tensor) -> torch.Tensor:
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    n, K = local_rows.numel(), shard_weight.shape[1]
+    out = torch.empty(n, K, dtype=torch.float32, device=shard_weight.device)
+    if n:
+        zero = torch.zeros(1, dtype=torch.int64, device=shard_weight.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream(shard_weight.device).cuda_stream)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        _lib.check(lib.recalgo_embedding_gather_fwd(p(local_rows), p(shard_weight), p(zero), n, 1, K, p(out), K, 0, st),
+                   "recalgo_embedding_gather_fwd")
+    return out
+
+
+def hip_local_scatter_add(shard_grad: torch.Tensor, local_rows: torch.Tensor, g: torch.Tensor) -> None:
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    n, K = local_rows.numel(), shard_grad.shape[1]
+    if n:
+        zero = torch.zeros(1, dtype=torch.int64, device=shard_grad.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream(shard_grad.device).cuda_stream)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        g = g.contiguous()
+        _lib.check(lib.recalgo_embedding_gather_bwd(p(local_rows), p(g), p(zero), n, 1, K, K, 0, p(shard_grad), st),
+                   "recalgo_embedding_gather_bwd")
+
+
+class Sharding:
+    """Attached to an EmbeddingArena (`arena.sharding`): the arena then holds only the rows
+    r % world == rank (at local index r // world)."""
+
+    def __init__(self, sh: ShardSpec, global_rows: int, local_gather=hip_local_gather,
+                 local_scatter_add=hip_local_scatter_add):
+        self.sh, self.global_rows = sh, int(global_rows)
+        self.local_gather, self.local_scatter_add = local_gather, local_scatter_add
+
+    def plan(self, rows: torch.Tensor) -> ExchangePlan:
+        return ExchangePlan(rows, self.sh)
+
+
+class StagedArena:
+    """The rows one batch needs, fetched from their owners into a local [M, K] table in request
+    order.  Quacks like an EmbeddingArena for the single-GPU kernels (identity ids); the gradient
+    they scatter into `.grad` is pushed back to the owners by `flush_grad()` (called by the op's
+    backward right after its kernel)."""
+
+    def __init__(self, plan: ExchangePlan, arena: EmbeddingArena):
+        self.plan, self.arena, self.K = plan, arena, arena.K
+        self.name = arena.name + "/staged"
+        sd: Sharding = arena.sharding
+        self.weight = plan.fetch(arena.weight, sd.local_gather)
+        self.tables = {"__staged__": (0, plan.M)}
+        self._grad: Optional[torch.Tensor] = None
+
+    @property
+    def grad(self) -> torch.Tensor:
+        if self._grad is None:
+            self._grad = torch.zeros_like(self.weight)
+        return self._grad
+
+    def table_view(self, _name):
+        return self.weight
+
+    def flush_grad(self):
+        if self._grad is not None:
+            sd: Sharding = self.arena.sharding
+            self.plan.push_grad(self._grad, self.arena.grad, sd.local_scatter_add)
+            self._grad = None
+
+
+def global_rows(ids: torch.Tensor, row_base: torch.Tensor) -> torch.Tensor:
+    """ids [B, F] (id < 0 = OOV) + row_base [F] -> global arena rows [B*F], -1 where OOV."""
+    rows = ids + row_base.unsqueeze(0)
+    return torch.where(ids >= 0, rows, torch.full_like(rows, -1)).reshape(-1)
+
+
+def identity_ids(rows: torch.Tensor, shape) -> torch.Tensor:
+    """ids into the staged arena: slot number where a row was requested, -1 where it was not."""
+    ar = torch.arange(rows.numel(), dtype=torch.int64, device=rows.device)
+    return torch.where(rows >= 0, ar, torch.full_like(ar, -1)).reshape(shape)
+
+
+def shard_arena_(arena: EmbeddingArena, sh: ShardSpec, local_gather=hip_local_gather,
+                 local_scatter_add=hip_local_scatter_add) -> None:
+    """Re-shard a fully materialised (replicated-at-init) arena in place: keep rows r % N == rank.
+    Every rank must have built the same arena (same seed) — that is what makes N ranks == 1 rank."""
+    if getattr(arena, "sharding", None) is not None:
+        return
+    rows = arena.weight.shape[0]
+    take = lambda t: t[sh.rank::sh.world].contiguous().clone()
+    arena.weight, arena.grad, arena.m, arena.v = take(arena.weight), take(arena.grad), take(arena.m), take(arena.v)
+    arena.sharding = Sharding(sh, rows, local_gather, local_scatter_add)
+
+
+def unshard_arena(arena: EmbeddingArena, what: str = "weight") -> torch.Tensor:
+    """all_gather the shards back into the [global_rows, K] tensor (tests, checkpoints)."""
+    sd: Sharding = arena.sharding
+    sh = sd.sh
+    local = getattr(arena, what)
+    n_max = (sd.global_rows + sh.world - 1) // sh.world
+    pad = torch.zeros(n_max, local.shape[1], dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(sh.world)]
+    sh.dist.all_gather(parts, pad, group=sh.group)
+    full = torch.empty(sd.global_rows, local.shape[1], dtype=local.dtype, device=local.device)
+    for r, part in enumerate(parts):
+        n = (sd.global_rows - r + sh.world - 1) // sh.world
+        full[r::sh.world] = part[:n]
+    return full
+
+
+def attach_data_parallel(est, dist=None, group=None, local_gather=hip_local_gather,
+                         local_scatter_add=hip_local_scatter_add):
+    """Make a built Estimator one rank of an N-rank job: shard every embedding arena row-wise,
+    all-reduce the flat dense gradient before the optimizer, scale the loss gradient by 1/N."""
+    if dist is None:
+        import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sh = ShardSpec(rank, world, group, dist)
+    if not est._built:
+        raise RuntimeError("attach_data_parallel: call est.build(features, labels) first")
+    # replicated dense variables must start identical
+    if est.store.flat is not None and est.store.flat.numel():
+        dist.broadcast(est.store.flat, src=0, group=group)
+    for ar in est.store.arenas.values():
+        shard_arena_(ar, sh, local_gather, local_scatter_add)
+
+    def grad_hook(store):
+        if store.flat_grad is not None and store.flat_grad.numel():
+            dist.all_reduce(store.flat_grad, op=dist.ReduceOp.SUM, group=group)
+    est.grad_hook = grad_hook
+    est.loss_grad_scale = 1.0 / world
+    est.shard_spec = sh
+    return est

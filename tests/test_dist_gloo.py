@@ -1,0 +1,149 @@
+"""CPU, world_size 2, gloo: the multi-GPU exchange logic of recalgorithm_amd/parallel.py (SURVEY.md
+§8e).  Oracle = the single-process result on the same global batch.  The two local kernels of the
+exchange (owner-side gather / scatter-add, HIP in production) are replaced by CPU test doubles;
+everything else — row sharding, bucketing, the three all_to_alls, staging, gradient push, dense
+all-reduce with the 1/N loss scale, un-sharding — is the production code."""
+import os
+import socket
+import types
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+WORLD = 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def cpu_gather(shard_weight, local_rows):                     # test double of hip_local_gather
+    return shard_weight.index_select(0, local_rows)
+
+
+def cpu_scatter_add(shard_grad, local_rows, g):               # test double of hip_local_scatter_add
+    shard_grad.index_add_(0, local_rows, g)
+
+
+def _make_arena(K=8, vocabs=(13, 7, 29, 5)):
+    from recalgorithm_amd.variables import EmbeddingArena
+    ar = EmbeddingArena("emb", K, "cpu", seed=123)
+    for i, v in enumerate(vocabs):
+        ar.add_table(f"t{i}", v)
+    ar.materialize()
+    return ar, list(vocabs)
+
+
+def _global_batch(vocabs, B=24, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.stack([torch.randint(0, v, (B,), generator=g) for v in vocabs], 1)
+    oov = torch.rand(B, len(vocabs), generator=g) < 0.15
+    ids = torch.where(oov, torch.full_like(ids, -1), ids)
+    ids[:, 0] = torch.where(torch.rand(B, generator=g) < 0.5, torch.zeros(B, dtype=torch.int64), ids[:, 0])  # hot row
+    return ids
+
+
+def _worker(rank, port, errq):
+    try:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+        from recalgorithm_amd import parallel as P
+        from recalgorithm_amd.variables import VariableStore
+
+        ar, vocabs = _make_arena()
+        W_full = ar.weight.clone()
+        K = ar.K
+        rb = torch.tensor([ar.tables[f"t{i}"][0] for i in range(len(vocabs))], dtype=torch.int64)
+        ids_all = _global_batch(vocabs)
+        Bl = ids_all.shape[0] // WORLD
+        ids = ids_all[rank * Bl:(rank + 1) * Bl]
+
+        # a stub estimator around a real store: attach_data_parallel shards the arenas, installs
+        # the dense all-reduce hook and the 1/N loss scale
+        store = VariableStore("cpu", seed=7 + rank)               # deliberately different dense init per rank
+        with P.torch.no_grad():
+            v = store.get_variable("w", (6, 3))
+        store.arenas[ar.name] = ar
+        store.pack()
+        est = types.SimpleNamespace(_built=True, store=store, grad_hook=None, loss_grad_scale=None)
+        P.attach_data_parallel(est, dist, local_gather=cpu_gather, local_scatter_add=cpu_scatter_add)
+        w0 = [torch.empty_like(store.flat) for _ in range(WORLD)]
+        dist.all_gather(w0, store.flat)
+        assert torch.equal(w0[0], w0[1]), "dense variables were not broadcast from rank 0"
+        assert est.loss_grad_scale == 1.0 / WORLD
+
+        # ---- sharding: local rows are the global rows r % N == rank ----
+        assert torch.equal(ar.weight, W_full[rank::WORLD])
+        assert torch.equal(P.unshard_arena(ar, "weight"), W_full)
+
+        # ---- forward: staged rows == table rows (bit exact), zeros for OOV ----
+        rows = P.global_rows(ids, rb)
+        plan = ar.sharding.plan(rows)
+        staged = P.StagedArena(plan, ar)
+        expect = torch.where((rows >= 0).unsqueeze(1), W_full[rows.clamp(min=0)], torch.zeros(1, K))
+        assert torch.equal(staged.weight, expect), "staged rows differ from the table rows"
+        ident = P.identity_ids(rows, ids.shape)
+        assert torch.equal(ident.reshape(-1)[rows >= 0], torch.nonzero(rows >= 0).squeeze(1))
+        assert bool((ident.reshape(-1)[rows < 0] == -1).all())
+
+        # ---- backward: push staged gradients to the owners == single-process scatter-add ----
+        g_all = torch.randn(ids_all.numel(), K, generator=torch.Generator().manual_seed(11))
+        g_loc = g_all[rank * Bl * len(vocabs):(rank + 1) * Bl * len(vocabs)]
+        staged.grad.add_(torch.where((rows >= 0).unsqueeze(1), g_loc, torch.zeros(1, K)))
+        staged.flush_grad()
+        got = P.unshard_arena(ar, "grad")
+        rows_all = P.global_rows(ids_all, rb)
+        ok = rows_all >= 0
+        ref = torch.zeros_like(W_full).index_add_(0, rows_all[ok], g_all[ok])
+        assert torch.allclose(got, ref, rtol=1e-6, atol=1e-6), "sharded gradient != single-process gradient"
+        assert float(ref.abs().sum()) > 0
+
+        # ---- dense gradient: SUM all-reduce of grads of loss_rank / N == grad of the global mean loss ----
+        x_all = torch.randn(ids_all.shape[0], 6, generator=torch.Generator().manual_seed(3))
+        wt = store.vars["w"].data.clone().requires_grad_(True)
+        loss_rank = (x_all[rank * Bl:(rank + 1) * Bl] @ wt).pow(2).mean()
+        loss_rank.backward(torch.full_like(loss_rank, est.loss_grad_scale))
+        store.vars["w"].grad.copy_(wt.grad)
+        est.grad_hook(store)
+        wg = store.vars["w"].data.clone().requires_grad_(True)
+        (x_all @ wg).pow(2).mean().backward()
+        assert torch.allclose(store.vars["w"].grad, wg.grad, rtol=1e-6, atol=1e-7)
+
+        # ---- ragged buckets: a rank that requests nothing still takes part in the collectives ----
+        rows2 = rows if rank == 0 else torch.full_like(rows, -1)
+        st2 = P.StagedArena(ar.sharding.plan(rows2), ar)
+        if rank == 1:
+            assert float(st2.weight.abs().sum()) == 0.0
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        import traceback
+        errq.put(f"rank {rank}:\n{traceback.format_exc()}")
+        raise
+
+
+@pytest.mark.timeout(180)
+def test_row_sharded_exchange_world2_matches_single_process():
+    ctx = mp.get_context("spawn")
+    errq = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, errq)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(150)
+    errs = []
+    while not errq.empty():
+        errs.append(errq.get())
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+            errs.append("worker timed out")
+    assert not errs, "\n".join(errs)
+    assert all(p.exitcode == 0 for p in procs)

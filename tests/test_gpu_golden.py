@@ -49,7 +49,11 @@ def _layer(dev, name, fn, scope=None, var_names=None):
     for vn, g in GU.section(d, "grad_var/").items():
         if "dice_bn" in vn:
             continue
-        assert_close(store.vars[vn].grad, torch.from_numpy(g), what=f"{name} d(var {vn})", reduced=True)
+        sib = vn.replace("/bias", "/kernel")
+        gsec = GU.section(d, "grad_var/")
+        # f3_att/bias = sum_t ds_t is exactly 0 under softmax: judged at its sibling kernel's scale
+        floor = 1e-5 * float(np.abs(gsec[sib]).max()) if vn.endswith("/bias") and sib in gsec else 0.0
+        assert_close(store.vars[vn].grad, torch.from_numpy(g), what=f"{name} d(var {vn})", reduced=True, floor=floor)
 
 
 def test_cross_layer_golden(dev):
@@ -126,6 +130,7 @@ def test_model_golden(dev, name, tmp_path):
     for k, v in gv.items():
         if k in arrays:
             arrays[k].copy_(torch.from_numpy(v).float().reshape(arrays[k].shape))
+    before = {k: v.detach().cpu().double().clone() for k, v in est.store.named_arrays().items()}
     # PREDICT
     pr = est._call_model_fn(feats, None, ModeKeys.PREDICT)
     for k, v in GU.section(d, "predict/").items():
@@ -137,13 +142,15 @@ def test_model_golden(dev, name, tmp_path):
     grads = named_grads(est.store)
     gg = GU.golden_to_oracle_vars(name, GU.section(d, "grad/"), params)
     gmax = {k: float(np.abs(v).max()) for k, v in gg.items()}
+    # batch-summed gradients downstream of a BatchNorm cancel (sum_b g_b = 0): their fp32 error is
+    # set by the size of the terms, i.e. by the largest gradients of the dense stack
+    dense_floor = 1e-6 * max(v for k, v in gmax.items() if "embedding_weights" not in k)
     for k, g in gg.items():
         if k not in grads:
             continue
         sib = k.replace("/bias", "/kernel")
-        floor = 1e-5 * gmax[sib] if k.endswith("/bias") and sib in gmax else 0.0   # cancelling bias grads
+        floor = dense_floor + (1e-5 * gmax[sib] if k.endswith("/bias") and sib in gmax else 0.0)
         assert_close(grads[k], torch.from_numpy(g), what=f"{name} d({k})", reduced=True, floor=floor)
-    before = {k: v.detach().cpu().double().clone() for k, v in est.store.named_arrays().items()}
     spec.train_op.optimizer.apply_gradients(est.store)
     after = est.store.named_arrays()
     ga = GU.golden_to_oracle_vars(name, GU.section(d, "var_after/"), params)
@@ -159,7 +166,7 @@ def test_model_golden(dev, name, tmp_path):
             continue
         # step 1 moves by lr*g/(|g|+eps'): ill-conditioned where |g| ~ eps' — bound as in test_gpu_models
         gref = torch.from_numpy(gg[k]).reshape(before[k].shape).abs()
-        tol_g = 1e-5 * (gref + gref.pow(2).mean().sqrt()) + 1e-6 * gref.max() + \
+        tol_g = 1e-5 * (gref + gref.pow(2).mean().sqrt()) + 1e-6 * gref.max() + dense_floor + \
             (1e-5 * gmax.get(k.replace("/bias", "/kernel"), 0.0) if k.endswith("/bias") else 0.0)
         tol = lr * (2e-4 + tol_g * eps1 / (gref + eps1) ** 2)
         err = (upd - ref_upd).abs()
