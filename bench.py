@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guides/MI355X_MICROARCH
 FP32_PEAK_TFLOPS = 157.3       # fp32 vector == fp32 MFMA peak
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def build_estimator(args, device, rank=0, world=1):
@@ -75,8 +75,38 @@ def build_estimator(args, device, rank=0, world=1):
                   "dense_feature_columns": [], "hidden_units": hidden, "learning_rate": 0.005,
                   "embedding_dim": args.emb, "cin_layer_feature_maps": ["128", "128"]}
         workload = f"xDeepFM CIN [128,128] + MLP 512,256,128; {args.fields} fields x emb{args.emb}; batch {args.batch}/GPU"
+    elif args.model == "din":
+        # DIN: 25 profile fields x emb + the target feedid and its 50-long history sharing one table
+        from recalgorithm_amd.algorithm.DIN.din import din_model_fn as model_fn
+        cmap = dict(zip(spec.names, cats))
+        his = fc.categorical_column_with_identity("his_read_comment_7d_seq", cmap["feedid"].num_buckets)
+        his.is_sequence = True
+        feed = cmap.pop("feedid")
+        feed.is_sequence = True
+        shared = fc.shared_embedding_columns([feed, his], args.emb, combiner="mean")
+        params = {"dense_feature_columns": [], "category_feature_columns": [fc.embedding_column(c, args.emb) for c in cmap.values()],
+                  "target_feedid_feature_columns": [shared[0]], "sequence_feature_columns": [shared[1]],
+                  "hidden_units": hidden, "dropout_rate": 0.0, "batch_norm": True, "learning_rate": 0.005,
+                  "activation": "dice", "mini_batch_aware_regularization": True, "l2_lambda": 0.2,
+                  "use_softmax": False, "sequence_max_length": 50}
+        workload = (f"DIN attention over a 50-long history (default non-softmax branch, dice) + MLP 512,256,128; "
+                    f"{args.fields - 1} profile fields + target feed x emb{args.emb}; batch {args.batch}/GPU")
+    elif args.model == "fibinet":
+        from recalgorithm_amd.algorithm.FiBiNET.fibinet import fibinet_model_fn as model_fn
+        params = {"category_feature_columns": [fc.embedding_column(c, args.emb) for c in cats],
+                  "dense_feature_columns": [], "hidden_units": hidden, "dropout_rate": 0.0, "batch_norm": True,
+                  "learning_rate": 0.005, "embedding_dim": args.emb, "reduction_ratio": 2,
+                  "bilinear_interaction_type": "all"}
+        workload = f"FiBiNET SENET(r=2) + bilinear 'all' + MLP 512,256,128; {args.fields} fields x emb{args.emb}; batch {args.batch}/GPU"
+    elif args.model == "pnn":
+        from recalgorithm_amd.algorithm.PNN.pnn import pnn_model_fn as model_fn
+        params = {"category_feature_columns": [fc.embedding_column(c, args.emb) for c in cats],
+                  "hidden_units": hidden, "dropout_rate": 0.0, "batch_norm": True, "learning_rate": 0.005,
+                  "output_dimension": 1024, "product_method": "IPNN", "weight_regularizer": 0.0,
+                  "embedding_dim": args.emb}
+        workload = f"PNN IPNN D=1024 + MLP 512,256,128; {args.fields} fields x emb{args.emb}; batch {args.batch}/GPU"
     else:
-        raise SystemExit(f"--model {args.model}: not wired into bench.py yet")
+        raise SystemExit(f"--model {args.model}: unknown")
     est = Estimator(model_fn=model_fn, params=params, config=RunConfig(device=device, seed=42))
     feats, labels, _ = synth.device_features(spec, args.batch, device, batch_index=rank)
     est.build(feats, labels)
@@ -178,6 +208,82 @@ def kernel_rooflines(args, est, feats, device):
             add(f"cin_bwd(L{li + 1},Hk={Hk})", lambda: lib.recalgo_cin_layer_bwd(p(x3), p(xk), p(w), p(go), p(pool), N, 0, B, m, Hk, N, D,
                                                                                  p(dx0), 0, p(dxk), 0, p(dw), p(ws), st),
                 2 * byt, 3.0 * fl)
+    if args.model == "deepfm":
+        w1 = store.arenas["fm_first_order_w1"]
+        bias = torch.zeros(1, device=device)
+        emb = torch.empty(B, d, device=device)
+        fm1, fm2, fs = torch.empty(B, device=device), torch.empty(B, device=device), torch.empty(B, K, device=device)
+        g1, g2 = torch.randn(B, device=device), torch.randn(B, device=device)
+        add("deepfm_sparse_fwd", lambda: lib.recalgo_deepfm_sparse_fwd(p(ids), p(ar.weight), p(w1.weight), p(bias), p(rb), B, F, K,
+                                                                      p(emb), p(fm1), p(fm2), p(fs), st),
+            B * (F * 8 + F * K * 4 + F * 4 + F * K * 4 + 8))                       # 3648 B/example
+        add("deepfm_sparse_bwd", lambda: lib.recalgo_deepfm_sparse_bwd(p(ids), p(emb), p(fs), p(g), p(g1), p(g2), p(rb), B, F, K,
+                                                                      p(ar.grad), p(w1.grad), st),
+            B * (F * K * 4 + 8 + F * K * 4 + F * 8 + F * K * 4 + F * 4))           # 5312 B/example
+        ar.grad.zero_(); w1.grad.zero_()
+    if args.model == "din":
+        T, H = 50, K
+        q = torch.randn(B, H, device=device)
+        keys = torch.randn(B, T, H, device=device)
+        kl = torch.full((B,), T, dtype=torch.int32, device=device)
+        f1w, f1b = torch.randn(4 * H, 64, device=device) * 0.1, torch.zeros(64, device=device)
+        f2w, f2b = torch.randn(64, 32, device=device) * 0.1, torch.zeros(32, device=device)
+        f3w, f3b = torch.randn(32, 1, device=device) * 0.1, torch.zeros(1, device=device)
+        o = torch.empty(B, H, device=device)
+        go = torch.randn(B, H, device=device)
+        dq, dk = torch.empty_like(q), torch.empty_like(keys)
+        dws = [torch.empty_like(t) for t in (f1w, f1b, f2w, f2b, f3w, f3b)]
+        ws = torch.empty(lib.recalgo_din_attention_bwd_workspace_bytes(B, T, H), dtype=torch.uint8, device=device)
+        fl = 2.0 * B * T * (4 * H * 64 + 64 * 32 + 32) + 2.0 * B * T * H            # MLP + weighted sum, as the reference computes it
+        byt = B * ((T + 1) * H * 4 + 4 + H * 4)
+        add("din_attention_fwd", lambda: lib.recalgo_din_attention_fwd(p(q), p(keys), p(kl), p(f1w), p(f1b), p(f2w), p(f2b), p(f3w),
+                                                                      p(f3b), B, T, H, 0, p(o), st), byt, fl)
+        add("din_attention_bwd", lambda: lib.recalgo_din_attention_bwd(p(q), p(keys), p(kl), p(f1w), p(f1b), p(f2w), p(f2b), p(f3w),
+                                                                      p(f3b), p(go), B, T, H, 0, p(dq), p(dk), *[p(t) for t in dws],
+                                                                      p(ws), st), 2 * byt + B * T * H * 4, 3.0 * fl)
+        vals = torch.randint(0, 1000, (B * T,), device=device)
+        offs = torch.arange(0, B * T + 1, T, device=device, dtype=torch.int64)
+        so, sl = torch.empty(B, T, H, device=device), torch.empty(B, dtype=torch.int32, device=device)
+        add("sequence_gather_fwd", lambda: lib.recalgo_sequence_gather_fwd(p(vals), p(offs), p(ar.weight), B, T, H, p(so), p(sl), st),
+            B * T * (8 + 2 * H * 4))
+        add("sequence_gather_bwd", lambda: lib.recalgo_sequence_gather_bwd(p(vals), p(offs), p(so), B, T, H, p(ar.grad), st),
+            B * T * (8 + 2 * H * 4))
+        ar.grad.zero_()
+    if args.model == "fibinet":
+        E = torch.randn(B, F, K, device=device)
+        V = torch.empty_like(E)
+        Rd = K // 2
+        w1s, w2s = torch.randn(F, Rd, device=device) * 0.3, torch.randn(Rd, F, device=device) * 0.3
+        Wo, Wsn = torch.randn(K, K, device=device) * 0.2, torch.randn(K, K, device=device) * 0.2
+        P_ = (F - 1) * (F - 2) // 2
+        out2 = torch.empty(B, P_, 2 * K, device=device)
+        g2 = torch.randn(B, P_, 2 * K, device=device)
+        dE, dV = torch.empty_like(E), torch.empty_like(E)
+        dWo, dWs, dw1, dw2 = torch.empty_like(Wo), torch.empty_like(Wsn), torch.empty_like(w1s), torch.empty_like(w2s)
+        wsb = torch.empty(lib.recalgo_bilinear_bwd_workspace_bytes(B, F, K, 2, 0), dtype=torch.uint8, device=device)
+        wss = torch.empty(lib.recalgo_senet_bwd_workspace_bytes(B, F, K, Rd), dtype=torch.uint8, device=device)
+        add("senet_fwd", lambda: lib.recalgo_senet_fwd(p(E), p(w1s), p(w2s), B, F, K, Rd, p(V), None, st), B * 2 * F * K * 4)
+        add("senet_bwd", lambda: lib.recalgo_senet_bwd(p(E), p(w1s), p(w2s), p(E), B, F, K, Rd, p(dE), 0, p(dw1), p(dw2), p(wss), st),
+            B * 3 * F * K * 4)
+        add("bilinear_fwd(all, 2 sets)", lambda: lib.recalgo_bilinear_fwd(p(E), p(Wo), p(V), p(Wsn), B, F, K, 0, p(out2), 2 * K, 0, st),
+            B * (2 * F * K * 4 + P_ * 2 * K * 4))
+        add("bilinear_bwd(all, 2 sets)", lambda: lib.recalgo_bilinear_bwd(p(E), p(Wo), p(V), p(Wsn), p(g2), 2 * K, 0, B, F, K, 0, p(dE),
+                                                                         p(dWo), p(dV), p(dWs), p(wsb), st),
+            B * (4 * F * K * 4 + P_ * 2 * K * 4))
+    if args.model == "pnn":
+        E = torch.randn(B, F * K, device=device)
+        T_ = F * (F + 1) // 2
+        D_ = 1024
+        phi, dphi = torch.empty(B, T_, device=device), torch.randn(B, T_, device=device)
+        th = torch.randn(D_, F, device=device) * 0.1
+        om, dom = torch.empty(T_, D_, device=device), torch.randn(T_, D_, device=device)
+        dE, dth = torch.empty_like(E), torch.empty_like(th)
+        add("pnn_features_fwd(IPNN)", lambda: lib.recalgo_pnn_features_fwd(p(E), B, F, K, 0, p(phi), st), B * (F * K + T_) * 4)
+        add("pnn_features_bwd(IPNN)", lambda: lib.recalgo_pnn_features_bwd(p(E), p(dphi), B, F, K, 0, p(dE), 0, st),
+            B * (2 * F * K + T_) * 4)
+        add("pnn_weights_fwd(IPNN)", lambda: lib.recalgo_pnn_weights_fwd(p(th), D_, F, K, 0, p(om), st), (D_ * F + T_ * D_) * 4)
+        add("pnn_weights_bwd(IPNN)", lambda: lib.recalgo_pnn_weights_bwd(p(th), p(dom), D_, F, K, 0, p(dth), st),
+            (2 * D_ * F + T_ * D_) * 4)
     n = ar.weight.numel()
     add("adam_tf1_dense(arena)", lambda: lib.recalgo_adam_tf1_dense(p(ar.weight), p(ar.grad), p(ar.m), p(ar.v), n, 0.0, None,
                                                                      0.9, 0.999, 1e-8, 1, st), n * 4 * 7)

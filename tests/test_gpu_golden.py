@@ -162,7 +162,9 @@ def test_model_golden(dev, name, tmp_path):
         ref_upd = torch.from_numpy(va).reshape(before[k].shape) - torch.from_numpy(gv[k]).reshape(before[k].shape)
         upd = after[k].detach().cpu().double() - before[k]
         if "moving_" in k:        # BatchNorm moving statistics (momentum 0.99), updated by the forward
-            assert_close(upd, ref_upd, what=f"{name} {k} update", reduced=True)
+            # 1e-7 absolute: (1 - 0.99) * batch mean, where the mean of a centred activation is an
+            # analytic zero (DIN with alpha = 1)
+            assert_close(upd, ref_upd, what=f"{name} {k} update", reduced=True, floor=1e-7)
             continue
         # step 1 moves by lr*g/(|g|+eps'): ill-conditioned where |g| ~ eps' — bound as in test_gpu_models
         gref = torch.from_numpy(gg[k]).reshape(before[k].shape).abs()
