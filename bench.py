@@ -41,6 +41,8 @@ def parse_args(argv=None):
     ap.add_argument("--emb", type=int, default=16)
     ap.add_argument("--max-vocab", type=int, default=1_000_000)
     ap.add_argument("--data-batches", type=int, default=8, help="distinct synthetic batches rotated through")
+    ap.add_argument("--tunable", action="store_true",
+                    help="let PyTorch TunableOp pick the fp32 GEMM kernels of the context MLP during warm-up")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -327,6 +329,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
 
+    if args.tunable:
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.tuning_enable(True)
+        tunable.set_max_tuning_duration(50)        # ms per candidate
+        tunable.set_max_tuning_iterations(20)
+        tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"recalgo_tunableop_{rank}.csv"))
     est, spec, feats, labels, workload = build_estimator(args, device, rank, world)
     if world > 1:
         # row-shard the embedding arenas over the ranks, all-reduce the dense gradients; the id /
@@ -358,6 +367,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.tunable:
+        tunable.tuning_enable(False)               # selections are frozen before the timed region
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -388,6 +399,7 @@ def main():
                    "emb_dim": args.emb, "embedding_rows": int(sum(spec.vocabs)),
                    "optimizer": "TF1 Adam, dense over all tables (reference semantics)",
                    "launch": "eager" if args.no_graph else "hipGraph replay",
+                   "gemm_selection": "TunableOp" if args.tunable else "hipBLASLt default",
                    "parallelism": (f"dp{world} + embedding rows sharded r % {world} (RCCL all_to_all), dense grads all-reduced"
                                    if world > 1 else "single")},
         "final_loss": round(loss_v, 6),

@@ -59,3 +59,34 @@ __device__ __forceinline__ float f4_dot(float4 a, float4 b) {
 
 // Hardware fp32 atomic add (global_atomic_add_f32); build uses -munsafe-fp-atomics.
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+// ---- deterministic column sum of partial rows ---------------------------------------------------
+// out[c] = sum_{r < S} partials[r * n + c].  256 threads = 16 columns x 16 row groups: a thread adds
+// rows rg, rg+16, ... in order, then the 16 groups are added in order (fixed summation order, and
+// S/16 instead of S dependent loads per thread — the one-thread-per-column form of this loop cost
+// 60-240 us for S = 256..1024 partial rows).  Columns [0, n0) go to out0, the rest to out1.
+namespace {
+__global__ __launch_bounds__(256) void colsum16_kernel(const float* __restrict__ partials, unsigned S, unsigned n,
+                                                       float* __restrict__ out0, unsigned n0,
+                                                       float* __restrict__ out1) {
+    __shared__ float sh[16][17];
+    const unsigned cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const unsigned c = blockIdx.x * 16 + cl;
+    float acc = 0.f;
+    if (c < n)
+        for (unsigned r = rg; r < S; r += 16) acc += partials[(size_t)r * n + c];
+    sh[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0 && c < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += sh[g][cl];
+        if (c < n0) out0[c] = t;
+        else out1[c - n0] = t;
+    }
+}
+inline void launch_colsum16(const float* partials, unsigned S, unsigned n, float* out0, unsigned n0, float* out1,
+                            hipStream_t st) {
+    hipLaunchKernelGGL(colsum16_kernel, dim3((n + 15) / 16), dim3(256), 0, st, partials, S, n, out0, n0, out1);
+}
+}  // namespace

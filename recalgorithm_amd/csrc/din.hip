@@ -6,15 +6,26 @@
 //   default branch : w_t = s_t * [t < len]
 //   out = sum_t w_t k_t
 //
-// FLOP-bound (fp32 vector).  Mapping: one wave per example, lane t owns history position t
-// (T <= 64) and runs the tiny MLP on its own row entirely in registers; the weights are staged
-// once per (persistent) workgroup in LDS and read as wave-uniform broadcasts.  f1 is factored so
-// that its q-only part is computed once per example:
-//   f1 x = q (W1a + W1c) + k (W1b - W1c) + (q*k) W1d
-// (half the layer-1 FLOPs of the reference's concat + dense; same math, different fp32 order).
-// The backward recomputes the forward per row, back-propagates per row on the VALU, and forms the
-// weight gradients — sums over all (b, t) rows of outer products — on the fp32 MFMA pipe, which
-// runs concurrently with the VALU work of the other waves.
+// FLOP-bound (fp32): per history row 2*(2H*64 + 64*32) MACs forward, ~3.5x that backward.  The
+// MLP over the T rows of one example is a chain of small GEMMs with M = 64 rows (T <= 64, zero
+// padded), so it runs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32; same peak as the VALU on
+// gfx950, but an MFMA needs 2 LDS dwords per lane per 64 cycles where the register-resident VALU
+// formulation needed one broadcast ds_read_b128 per 4 FMAs and was LDS-bound, and its backward
+// spilled 1000+ VGPRs).  One wave owns one example:
+//   f1 is factored so that its q-only part is computed once per example:
+//       f1 x = q (W1a + W1c) + k (W1b - W1c) + (q*k) W1d  =  cq + X Wx,   X = [k | q*k]  (64 x 2H)
+//   H1 = relu(X Wx + cq)      64 MFMAs      (A = X from LDS, B = Wx from LDS, C initialised with cq)
+//   H2 = relu(H1 W2 + b2)     64 MFMAs      (H1 goes through LDS: accumulator layout -> A layout)
+//   s  = H2 W3 + b3           VALU, lane = row
+// backward (recomputes the forward; nothing but q, k is read):
+//   dW2 += H1^T dH2  (64)   dH1 = (dH2 W2^T) * [H1>0]  (64)   dWx += X^T dH1  (64)   dX = dH1 Wx^T  (64)
+// Weights are staged once per persistent workgroup in LDS with odd row strides (33 / 65 floats) so
+// that both the row-major (B operand) and the transposed (B operand of the backward) fragment
+// reads are bank-conflict free.  Weight-gradient accumulators stay in registers across the
+// examples of a wave, then: fixed-order reduction over the 4 waves -> partial row -> column sums.
+//
+// Fragment maps of v_mfma_f32_32x32x2_f32: lane l supplies A[row = l&31][k = l>>5] and
+// B[k = l>>5][col = l&31]; acc reg r holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
 #include "common.h"
 
 namespace {
@@ -24,35 +35,43 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
 constexpr int N1 = 64, N2 = 32;
-constexpr int kXS = 33, kS64 = 68, kS32 = 36;            // padded LDS row strides (floats)
-constexpr int kScratch = 64 * kS64 + 64 * kS32;          // per-wave backward scratch (floats)
+constexpr int XS = 33;                           // row stride of X / H2 / W2 tiles (floats)
+constexpr int HS = 65;                           // row stride of H1 / Wx tiles
 constexpr float kPadScore = -4294967296.0f;      // float32(-2**32 + 1), din_attention.py:31
 
 template <int H>
-struct Smem {
-    float Wq[H][N1];       // W1a + W1c
-    float Wk[H][N1];       // W1b - W1c
-    float Wd[H][N1];       // W1d
+struct Weights {            // workgroup-shared, staged once
+    float Wx[32][HS];       // rows 0..H-1: W1b - W1c (k part), rows H..2H-1: W1d (q*k part), rest 0
+    float Wq[H][N1];        // W1a + W1c
     float b1[N1];
-    float W2[N1][N2];
+    float W2[N1][XS];
     float b2[N2];
     float W3[N2];
     float b3[4];
-    float cq[kWaves][N1];  // per-example q-only part of layer 1
+};
+
+struct WaveScratch {        // one per wave
+    float Xs[64][XS];       // [k | q*k | 0]; later dX
+    float H1s[64][HS];      // relu(H1); later dH1
+    float H2s[64][XS];      // relu(H2); later dH2
+    float v64[2][64];       // cq ; ds | dcq
 };
 
 template <int H>
-__device__ __forceinline__ void stage_weights(Smem<H>& S, const float* __restrict__ f1w,
+__device__ __forceinline__ void stage_weights(Weights<H>& S, const float* __restrict__ f1w,
                                               const float* __restrict__ f1b, const float* __restrict__ f2w,
                                               const float* __restrict__ f2b, const float* __restrict__ f3w,
                                               const float* __restrict__ f3b) {
+    for (unsigned e = threadIdx.x; e < 32 * N1; e += kThreads) {
+        unsigned i = e / N1, j = e - i * N1;
+        float v = 0.f;
+        if (i < (unsigned)H) v = f1w[(1 * H + i) * N1 + j] - f1w[(2 * H + i) * N1 + j];
+        else if (i < 2u * H) v = f1w[(3 * H + (i - H)) * N1 + j];
+        S.Wx[i][j] = v;
+    }
     for (unsigned e = threadIdx.x; e < H * N1; e += kThreads) {
         unsigned i = e / N1, j = e - i * N1;
-        float a = f1w[(0 * H + i) * N1 + j], b = f1w[(1 * H + i) * N1 + j];
-        float c = f1w[(2 * H + i) * N1 + j], d = f1w[(3 * H + i) * N1 + j];
-        S.Wq[i][j] = a + c;
-        S.Wk[i][j] = b - c;
-        S.Wd[i][j] = d;
+        S.Wq[i][j] = f1w[(0 * H + i) * N1 + j] + f1w[(2 * H + i) * N1 + j];
     }
     for (unsigned e = threadIdx.x; e < N1 * N2; e += kThreads) S.W2[e / N2][e % N2] = f2w[e];
     if (threadIdx.x < N1) S.b1[threadIdx.x] = f1b[threadIdx.x];
@@ -63,59 +82,15 @@ __device__ __forceinline__ void stage_weights(Smem<H>& S, const float* __restric
     if (threadIdx.x == 0) S.b3[0] = f3b[0];
 }
 
-// per-row forward: fills h1, h2 (post-relu) and returns the raw score
-template <int H>
-__device__ __forceinline__ float row_forward(const Smem<H>& S, unsigned wave, const float (&k)[H],
-                                             const float (&qk)[H], float (&h1)[N1], float (&h2)[N2]) {
-#pragma unroll
-    for (int j = 0; j < N1; j += 4) {
-        float4 c = *reinterpret_cast<const float4*>(&S.cq[wave][j]);
-        h1[j] = c.x; h1[j + 1] = c.y; h1[j + 2] = c.z; h1[j + 3] = c.w;
-    }
-#pragma unroll
-    for (int i = 0; i < H; ++i) {
-#pragma unroll
-        for (int j = 0; j < N1; j += 4) {
-            float4 wk = *reinterpret_cast<const float4*>(&S.Wk[i][j]);
-            float4 wd = *reinterpret_cast<const float4*>(&S.Wd[i][j]);
-            h1[j + 0] = fmaf(k[i], wk.x, fmaf(qk[i], wd.x, h1[j + 0]));
-            h1[j + 1] = fmaf(k[i], wk.y, fmaf(qk[i], wd.y, h1[j + 1]));
-            h1[j + 2] = fmaf(k[i], wk.z, fmaf(qk[i], wd.z, h1[j + 2]));
-            h1[j + 3] = fmaf(k[i], wk.w, fmaf(qk[i], wd.w, h1[j + 3]));
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < N1; ++j) h1[j] = fmaxf(h1[j], 0.f);
-#pragma unroll
-    for (int j = 0; j < N2; j += 4) {
-        float4 c = *reinterpret_cast<const float4*>(&S.b2[j]);
-        h2[j] = c.x; h2[j + 1] = c.y; h2[j + 2] = c.z; h2[j + 3] = c.w;
-    }
-#pragma unroll
-    for (int i = 0; i < N1; ++i) {
-#pragma unroll
-        for (int j = 0; j < N2; j += 4) {
-            float4 w = *reinterpret_cast<const float4*>(&S.W2[i][j]);
-            h2[j + 0] = fmaf(h1[i], w.x, h2[j + 0]);
-            h2[j + 1] = fmaf(h1[i], w.y, h2[j + 1]);
-            h2[j + 2] = fmaf(h1[i], w.z, h2[j + 2]);
-            h2[j + 3] = fmaf(h1[i], w.w, h2[j + 3]);
-        }
-    }
-    float s = S.b3[0];
-#pragma unroll
-    for (int j = 0; j < N2; ++j) {
-        h2[j] = fmaxf(h2[j], 0.f);
-        s = fmaf(h2[j], S.W3[j], s);
-    }
-    return s;
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ unsigned acc_row(int r, unsigned hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-// loads q (wave-uniform) and this lane's key row, computes the per-example q-only layer-1 part
+// loads q (wave-uniform) and this lane's key row (zero beyond T)
 template <int H>
-__device__ __forceinline__ void load_example(Smem<H>& S, unsigned wave, unsigned lane, unsigned ex, unsigned T,
-                                             const float* __restrict__ query, const float* __restrict__ keys,
-                                             float (&q)[H], float (&k)[H], float (&qk)[H]) {
+__device__ __forceinline__ void load_example(unsigned lane, unsigned ex, unsigned T, const float* __restrict__ query,
+                                             const float* __restrict__ keys, float (&q)[H], float (&k)[H]) {
     const float4* qr = reinterpret_cast<const float4*>(query + (size_t)ex * H);
 #pragma unroll
     for (int i = 0; i < H; i += 4) {
@@ -133,14 +108,81 @@ __device__ __forceinline__ void load_example(Smem<H>& S, unsigned wave, unsigned
 #pragma unroll
         for (int i = 0; i < H; ++i) k[i] = 0.f;
     }
+}
+
+// the MLP of one example on the matrix cores: leaves relu(H1) in sc.H1s, relu(H2) in sc.H2s, X in
+// sc.Xs and returns the raw score of row `lane`
+template <int H>
+__device__ __forceinline__ float mlp_forward(const Weights<H>& W, WaveScratch& sc, unsigned lane,
+                                             const float (&q)[H], const float (&k)[H]) {
+    const unsigned hi = lane >> 5, l32 = lane & 31;
 #pragma unroll
-    for (int i = 0; i < H; ++i) qk[i] = q[i] * k[i];
-    // cq[j] = b1[j] + sum_i q_i (W1a + W1c)[i][j]   — lane j computes output j
-    float c = S.b1[lane];
+    for (int i = 0; i < H; ++i) {
+        sc.Xs[lane][i] = k[i];
+        sc.Xs[lane][H + i] = q[i] * k[i];
+    }
 #pragma unroll
-    for (int i = 0; i < H; ++i) c = fmaf(q[i], S.Wq[i][lane], c);
-    S.cq[wave][lane] = c;
+    for (int i = 2 * H; i < 32; ++i) sc.Xs[lane][i] = 0.f;
+    {   // cq[j] = b1[j] + sum_i q_i (W1a + W1c)[i][j]   — lane j computes output j
+        float c = W.b1[lane];
+#pragma unroll
+        for (int i = 0; i < H; ++i) c = fmaf(q[i], W.Wq[i][lane], c);
+        sc.v64[0][lane] = c;
+    }
     __builtin_amdgcn_wave_barrier();
+    // ---- layer 1: H1[64 x 64] = X[64 x 2H] Wx[2H x 64] + cq ----
+    f32x16 a1[2][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const float c = sc.v64[0][nt * 32 + l32];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a1[mt][nt][r] = c;
+    }
+#pragma unroll 4
+    for (int k0 = 0; k0 < 2 * H; k0 += 2) {
+        const float x0 = sc.Xs[l32][k0 + hi], x1 = sc.Xs[32 + l32][k0 + hi];
+        const float w0 = W.Wx[k0 + hi][l32], w1 = W.Wx[k0 + hi][32 + l32];
+        a1[0][0] = mfma(x0, w0, a1[0][0]);
+        a1[0][1] = mfma(x0, w1, a1[0][1]);
+        a1[1][0] = mfma(x1, w0, a1[1][0]);
+        a1[1][1] = mfma(x1, w1, a1[1][1]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sc.H1s[mt * 32 + acc_row(r, hi)][nt * 32 + l32] = fmaxf(a1[mt][nt][r], 0.f);
+    __builtin_amdgcn_wave_barrier();
+    // ---- layer 2: H2[64 x 32] = H1[64 x 64] W2[64 x 32] + b2 ----
+    f32x16 a2[2];
+    {
+        const float c = W.b2[l32];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a2[mt][r] = c;
+    }
+#pragma unroll 8
+    for (int k0 = 0; k0 < N1; k0 += 2) {
+        const float h0 = sc.H1s[l32][k0 + hi], h1 = sc.H1s[32 + l32][k0 + hi];
+        const float w = W.W2[k0 + hi][l32];
+        a2[0] = mfma(h0, w, a2[0]);
+        a2[1] = mfma(h1, w, a2[1]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc.H2s[mt * 32 + acc_row(r, hi)][l32] = fmaxf(a2[mt][r], 0.f);
+    __builtin_amdgcn_wave_barrier();
+    // ---- layer 3 (lane = row) ----
+    float s = W.b3[0];
+#pragma unroll
+    for (int n = 0; n < N2; ++n) s = fmaf(sc.H2s[lane][n], W.W3[n], s);
+    return s;
 }
 
 template <int H>
@@ -162,17 +204,20 @@ __global__ __launch_bounds__(kThreads) void din_attention_fwd_kernel(
     const float* __restrict__ f1w, const float* __restrict__ f1b, const float* __restrict__ f2w,
     const float* __restrict__ f2b, const float* __restrict__ f3w, const float* __restrict__ f3b, unsigned B,
     unsigned T, int is_softmax, float* __restrict__ out) {
-    __shared__ Smem<H> S;
-    stage_weights<H>(S, f1w, f1b, f2w, f2b, f3w, f3b);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Weights<H>& W = *reinterpret_cast<Weights<H>*>(smem_raw);
+    WaveScratch* scs = reinterpret_cast<WaveScratch*>(smem_raw + ((sizeof(Weights<H>) + 15) & ~(size_t)15));
+    stage_weights<H>(W, f1w, f1b, f2w, f2b, f3w, f3b);
     __syncthreads();
     const unsigned lane = threadIdx.x & 63;
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    WaveScratch& sc = scs[wave];
     for (unsigned ex = blockIdx.x * kWaves + wave; ex < B; ex += gridDim.x * kWaves) {
-        float q[H], k[H], qk[H], h1[N1], h2[N2];
-        load_example<H>(S, wave, lane, ex, T, query, keys, q, k, qk);
-        float s = row_forward<H>(S, wave, k, qk, h1, h2);
+        float q[H], k[H];
+        load_example<H>(lane, ex, T, query, keys, q, k);
+        const float s = mlp_forward<H>(W, sc, lane, q, k);
         const int len = keys_length[ex];
-        float w = attention_weight<H>(s, lane < T && (int)lane < len, lane < T, is_softmax);
+        const float w = attention_weight<H>(s, lane < T && (int)lane < len, lane < T, is_softmax);
         float o[H];
 #pragma unroll
         for (int i = 0; i < H; ++i) o[i] = w * k[i];
@@ -207,18 +252,16 @@ __global__ __launch_bounds__(kThreads) void din_attention_bwd_kernel(
     float* __restrict__ dkeys, float* __restrict__ partials) {
     static_assert(2 * H <= 32, "k and q*k must fit one 32-wide MFMA tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Smem<H>& S = *reinterpret_cast<Smem<H>*>(smem_raw);
-    // per-wave scratch (kScratch floats): X|dH1, then H1|dH2, then H2|ds.  Row strides are padded
-    // (33 / 68 / 36 floats) so that the row-per-lane ds_write_b32 / b128 stores are conflict free
-    float* scratch_all = reinterpret_cast<float*>(smem_raw + ((sizeof(Smem<H>) + 15) & ~(size_t)15));
-    stage_weights<H>(S, f1w, f1b, f2w, f2b, f3w, f3b);
+    Weights<H>& W = *reinterpret_cast<Weights<H>*>(smem_raw);
+    WaveScratch* scs = reinterpret_cast<WaveScratch*>(smem_raw + ((sizeof(Weights<H>) + 15) & ~(size_t)15));
+    stage_weights<H>(W, f1w, f1b, f2w, f2b, f3w, f3b);
     __syncthreads();
     const unsigned lane = threadIdx.x & 63;
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned hi = lane >> 5, l32 = lane & 31;
-    float* sc = scratch_all + wave * kScratch;
+    WaveScratch& sc = scs[wave];
 
-    // MFMA accumulators: dWx [32 (k|qk, zero padded) x 64] = 2 tiles, dW2 [64 x 32] = 2 tiles
+    // persistent accumulators: dWx [32 (k|qk) x 64] = 2 tiles, dW2 [64 x 32] = 2 tiles
     f32x16 accX[2], acc2[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -230,13 +273,13 @@ __global__ __launch_bounds__(kThreads) void din_attention_bwd_kernel(
     float db1 = 0.f, db2 = 0.f, dW3 = 0.f, db3 = 0.f;
 
     for (unsigned ex = blockIdx.x * kWaves + wave; ex < B; ex += gridDim.x * kWaves) {
-        float q[H], k[H], qk[H], h1[N1], h2[N2];
-        load_example<H>(S, wave, lane, ex, T, query, keys, q, k, qk);
-        const float s = row_forward<H>(S, wave, k, qk, h1, h2);
+        float q[H], k[H];
+        load_example<H>(lane, ex, T, query, keys, q, k);
+        const float s = mlp_forward<H>(W, sc, lane, q, k);
         const int len = keys_length[ex];
         const bool in_T = lane < T, in_len = in_T && (int)lane < len;
         const float w = attention_weight<H>(s, in_len, in_T, is_softmax);
-        // ---- attention output backward ----
+        // ---- attention output backward (lane = row) ----
         float g[H];
         {
             const float4* gr = reinterpret_cast<const float4*>(g_out + (size_t)ex * H);
@@ -256,39 +299,107 @@ __global__ __launch_bounds__(kThreads) void din_attention_bwd_kernel(
         } else {
             ds = in_len ? dwt : 0.f;
         }
-        float dk[H];
-#pragma unroll
-        for (int i = 0; i < H; ++i) dk[i] = w * g[i];
-        // ---- MLP backward (per row) ----
-        float dh2[N2];
-#pragma unroll
-        for (int j = 0; j < N2; ++j) dh2[j] = h2[j] > 0.f ? ds * S.W3[j] : 0.f;
-        float dh1[N1];
-#pragma unroll
-        for (int i = 0; i < N1; ++i) {
+        sc.v64[1][lane] = ds;
+        db3 += wave_sum(ds);
+        __builtin_amdgcn_wave_barrier();
+        // dW3[n] = sum_t ds_t h2[t][n]   (lane n), then dH2 in place over H2s (lane = row)
+        if (lane < N2) {
             float a = 0.f;
-#pragma unroll
-            for (int j = 0; j < N2; j += 4) {
-                float4 wv = *reinterpret_cast<const float4*>(&S.W2[i][j]);
-                a = fmaf(dh2[j], wv.x, fmaf(dh2[j + 1], wv.y, fmaf(dh2[j + 2], wv.z, fmaf(dh2[j + 3], wv.w, a))));
-            }
-            dh1[i] = h1[i] > 0.f ? a : 0.f;
+#pragma unroll 8
+            for (int t = 0; t < 64; ++t) a = fmaf(sc.v64[1][t], sc.H2s[t][lane], a);
+            dW3 += a;
         }
-        float dq[H];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int n = 0; n < N2; ++n) {
+            const float h = sc.H2s[lane][n];
+            sc.H2s[lane][n] = h > 0.f ? ds * W.W3[n] : 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < N2) {
+            float cs = 0.f;
+#pragma unroll 8
+            for (int t = 0; t < 64; ++t) cs += sc.H2s[t][lane];
+            db2 += cs;
+        }
+        // ---- dW2 += H1^T dH2   (A[i][t] = H1[t][i], B[t][n] = dH2[t][n]) ----
+#pragma unroll 8
+        for (int k0 = 0; k0 < 64; k0 += 2) {
+            const float b = sc.H2s[k0 + hi][l32];
+            acc2[0] = mfma(sc.H1s[k0 + hi][l32], b, acc2[0]);
+            acc2[1] = mfma(sc.H1s[k0 + hi][32 + l32], b, acc2[1]);
+        }
+        // ---- dH1 = (dH2 W2^T) * [H1 > 0]   (A[t][n] = dH2[t][n], B[n][i] = W2[i][n]) ----
+        {
+            f32x16 d1[2][2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) d1[mt][nt][r] = 0.f;
+#pragma unroll 4
+            for (int k0 = 0; k0 < N2; k0 += 2) {
+                const float x0 = sc.H2s[l32][k0 + hi], x1 = sc.H2s[32 + l32][k0 + hi];
+                const float w0 = W.W2[l32][k0 + hi], w1 = W.W2[32 + l32][k0 + hi];
+                d1[0][0] = mfma(x0, w0, d1[0][0]);
+                d1[0][1] = mfma(x0, w1, d1[0][1]);
+                d1[1][0] = mfma(x1, w0, d1[1][0]);
+                d1[1][1] = mfma(x1, w1, d1[1][1]);
+            }
+            __builtin_amdgcn_wave_barrier();          // dW2 has consumed H1s
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float* p = &sc.H1s[mt * 32 + acc_row(r, hi)][nt * 32 + l32];
+                        *p = *p > 0.f ? d1[mt][nt][r] : 0.f;
+                    }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // column sums of dH1 (lane = column j): db1, the q-only part of dW1, and d(cq)
+        float dcq = 0.f;
+#pragma unroll 8
+        for (int t = 0; t < 64; ++t) dcq += sc.H1s[t][lane];
+        db1 += dcq;
+#pragma unroll
+        for (int i = 0; i < H; ++i) dWq[i] = fmaf(q[i], dcq, dWq[i]);
+        // ---- dWx += X^T dH1   (A[c][t] = X[t][c], B[t][j] = dH1[t][j]) ----
+#pragma unroll 8
+        for (int k0 = 0; k0 < 64; k0 += 2) {
+            const float a = sc.Xs[k0 + hi][l32];
+            accX[0] = mfma(a, sc.H1s[k0 + hi][l32], accX[0]);
+            accX[1] = mfma(a, sc.H1s[k0 + hi][32 + l32], accX[1]);
+        }
+        // ---- dX = dH1 Wx^T   (A[t][j] = dH1[t][j], B[j][c] = Wx[c][j]) ----
+        {
+            f32x16 dx[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dx[mt][r] = 0.f;
+#pragma unroll 8
+            for (int k0 = 0; k0 < N1; k0 += 2) {
+                const float b = W.Wx[l32][k0 + hi];
+                dx[0] = mfma(sc.H1s[l32][k0 + hi], b, dx[0]);
+                dx[1] = mfma(sc.H1s[32 + l32][k0 + hi], b, dx[1]);
+            }
+            __builtin_amdgcn_wave_barrier();          // dWx has consumed Xs
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc.Xs[mt * 32 + acc_row(r, hi)][l32] = dx[mt][r];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- back to lane = row: dk, dq ----
+        float dq[H], dk[H];
 #pragma unroll
         for (int i = 0; i < H; ++i) {
-            float aq = 0.f, ak = 0.f, ad = 0.f;
-#pragma unroll
-            for (int j = 0; j < N1; j += 4) {
-                float4 wq = *reinterpret_cast<const float4*>(&S.Wq[i][j]);
-                float4 wk = *reinterpret_cast<const float4*>(&S.Wk[i][j]);
-                float4 wd = *reinterpret_cast<const float4*>(&S.Wd[i][j]);
-                aq = fmaf(dh1[j], wq.x, fmaf(dh1[j + 1], wq.y, fmaf(dh1[j + 2], wq.z, fmaf(dh1[j + 3], wq.w, aq))));
-                ak = fmaf(dh1[j], wk.x, fmaf(dh1[j + 1], wk.y, fmaf(dh1[j + 2], wk.z, fmaf(dh1[j + 3], wk.w, ak))));
-                ad = fmaf(dh1[j], wd.x, fmaf(dh1[j + 1], wd.y, fmaf(dh1[j + 2], wd.z, fmaf(dh1[j + 3], wd.w, ad))));
-            }
-            dq[i] = fmaf(ad, k[i], aq);
-            dk[i] += fmaf(ad, q[i], ak);
+            const float dxk = sc.Xs[lane][i], dxd = sc.Xs[lane][H + i];
+            dk[i] = fmaf(w, g[i], fmaf(dxd, q[i], dxk));
+            dq[i] = fmaf(dxd, k[i], dcq * W.Wq[i][lane]);        // + this lane's (column j = lane) share of dcq Wq^T
         }
         if (in_T) {
             float4* dkr = reinterpret_cast<float4*>(dkeys + ((size_t)ex * T + lane) * H);
@@ -305,102 +416,24 @@ __global__ __launch_bounds__(kThreads) void din_attention_bwd_kernel(
             for (int i = 1; i < H; ++i) v = lane == (unsigned)i ? dq[i] : v;
             dquery[(size_t)ex * H + lane] = v;
         }
-
-        // ---- weight gradients: outer products summed over the 64 rows, on the MFMA pipe ----
-        // phase A: X = [k | q*k | 0] (32 cols) and dH1 (64 cols)
-        {
-            float* X = sc;               // [64][kXS]
-            float* Dh = sc + 64 * kXS;   // [64][kS64]  (64*33 is a multiple of 4: float4 aligned)
-#pragma unroll
-            for (int i = 0; i < H; ++i) {
-                X[lane * kXS + i] = k[i];
-                X[lane * kXS + H + i] = qk[i];
-            }
-#pragma unroll
-            for (int i = 2 * H; i < 32; ++i) X[lane * kXS + i] = 0.f;
-#pragma unroll
-            for (int j = 0; j < N1; j += 4)
-                *reinterpret_cast<float4*>(&Dh[lane * kS64 + j]) = make_float4(dh1[j], dh1[j + 1], dh1[j + 2], dh1[j + 3]);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-            for (int st = 0; st < 32; ++st) {
-                float a = X[(2 * st + hi) * kXS + l32];
-#pragma unroll
-                for (int jt = 0; jt < 2; ++jt) {
-                    float bfr = Dh[(2 * st + hi) * kS64 + jt * 32 + l32];
-                    accX[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bfr, accX[jt], 0, 0, 0);
-                }
-            }
-            float cs = 0.f;            // column sum of dH1 for column `lane`
-#pragma unroll 8
-            for (int r = 0; r < 64; ++r) cs += Dh[r * kS64 + lane];
-            db1 += cs;
-#pragma unroll
-            for (int i = 0; i < H; ++i) dWq[i] = fmaf(q[i], cs, dWq[i]);
-            __builtin_amdgcn_wave_barrier();
-        }
-        // phase B: H1 (64 cols) and dH2 (32 cols)
-        {
-            float* Hs = sc;              // [64][kS64]
-            float* Dh = sc + 64 * kS64;  // [64][kS32]
-#pragma unroll
-            for (int j = 0; j < N1; j += 4)
-                *reinterpret_cast<float4*>(&Hs[lane * kS64 + j]) = make_float4(h1[j], h1[j + 1], h1[j + 2], h1[j + 3]);
-#pragma unroll
-            for (int j = 0; j < N2; j += 4)
-                *reinterpret_cast<float4*>(&Dh[lane * kS32 + j]) = make_float4(dh2[j], dh2[j + 1], dh2[j + 2], dh2[j + 3]);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-            for (int st = 0; st < 32; ++st) {
-                float bfr = Dh[(2 * st + hi) * kS32 + l32];
-#pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    float a = Hs[(2 * st + hi) * kS64 + it * 32 + l32];
-                    acc2[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bfr, acc2[it], 0, 0, 0);
-                }
-            }
-            if (lane < N2) {
-                float cs = 0.f;
-#pragma unroll 8
-                for (int r = 0; r < 64; ++r) cs += Dh[r * kS32 + lane];
-                db2 += cs;
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        // phase C: dW3[j] = sum_rows ds * h2[j], db3 = sum_rows ds
-        {
-            float* Hs = sc;              // [64][kS32] h2
-            float* Ds = sc + 64 * kS32;  // [64]
-#pragma unroll
-            for (int j = 0; j < N2; j += 4)
-                *reinterpret_cast<float4*>(&Hs[lane * kS32 + j]) = make_float4(h2[j], h2[j + 1], h2[j + 2], h2[j + 3]);
-            Ds[lane] = ds;
-            __builtin_amdgcn_wave_barrier();
-            if (lane < N2) {
-                float a = 0.f;
-#pragma unroll 8
-                for (int r = 0; r < 64; ++r) a = fmaf(Ds[r], Hs[r * kS32 + lane], a);
-                dW3 += a;
-            }
-            db3 += wave_sum(ds);
-            __builtin_amdgcn_wave_barrier();
-        }
+        __builtin_amdgcn_wave_barrier();
     }
 
     // ---- workgroup reduction of the weight-gradient partials (fixed wave order) ----
     constexpr int PF = din_partial_floats<H>();
+    static_assert(PF * sizeof(float) <= kWaves * sizeof(WaveScratch), "partial row must fit the wave scratch");
     __syncthreads();
-    float* red = scratch_all;                       // [PF], reuses the wave scratch area
+    float* red = reinterpret_cast<float*>(scs);     // [PF], reuses the wave scratch area
     for (unsigned wv = 0; wv < kWaves; ++wv) {
         if (wave == wv) {
             auto put = [&](unsigned idx, float v) { red[idx] = (wv == 0 ? 0.f : red[idx]) + v; };
-            // dWx tile jt: rows i = (r&3)+8*(r>>2)+4*hi (0..31: k rows 0..H-1, qk rows H..2H-1), col jt*32+l32
+            // dWx tile jt: rows i = acc_row (0..31: k rows 0..H-1, qk rows H..2H-1), col jt*32+l32
             // final dW1 = [dWq ; dWk ; dWq - dWk ; dWqk]   (blocks a, b, c, d of f1's kernel)
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    int i = acc_row(r, hi);
                     unsigned j = jt * 32 + l32;
                     if (i < H) {                       // k part: block b (+), block c (-)
                         put((1 * H + i) * N1 + j, accX[jt][r]);
@@ -423,7 +456,7 @@ __global__ __launch_bounds__(kThreads) void din_attention_bwd_kernel(
             for (int it = 0; it < 2; ++it)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    int i = it * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    int i = it * 32 + acc_row(r, hi);
                     put(o_w2 + i * N2 + l32, acc2[it][r]);
                 }
             if (lane < N2) {
@@ -461,7 +494,7 @@ inline int din_grid(int B) {
 }
 
 template <int H>
-size_t din_bwd_smem() { return ((sizeof(Smem<H>) + 15) & ~(size_t)15) + (size_t)kWaves * kScratch * sizeof(float); }
+size_t din_smem() { return ((sizeof(Weights<H>) + 15) & ~(size_t)15) + (size_t)kWaves * sizeof(WaveScratch); }
 
 }  // namespace
 
@@ -473,9 +506,15 @@ RECALGO_EXPORT int recalgo_din_attention_fwd(const float* query, const float* ke
     if (B == 0) return 0;
     hipStream_t st = as_stream(stream);
 #define LAUNCH(HH)                                                                                          \
-    hipLaunchKernelGGL(din_attention_fwd_kernel<HH>, dim3(din_grid(B) * 2 > cdiv(B, kWaves) ? cdiv(B, kWaves) : din_grid(B) * 2), \
-                       dim3(kThreads), 0, st, query, keys, keys_length, f1_w, f1_b, f2_w, f2_b, f3_w, f3_b,  \
-                       (unsigned)B, (unsigned)T, is_softmax, out)
+    do {                                                                                                    \
+        size_t smem = din_smem<HH>();                                                                       \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&din_attention_fwd_kernel<HH>),    \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);          \
+        if (e != hipSuccess) return (int)e;                                                                 \
+        hipLaunchKernelGGL(din_attention_fwd_kernel<HH>, dim3(din_grid(B)), dim3(kThreads), smem, st, query, keys, \
+                           keys_length, f1_w, f1_b, f2_w, f2_b, f3_w, f3_b, (unsigned)B, (unsigned)T, is_softmax,  \
+                           out);                                                                            \
+    } while (0)
     if (H == 4) LAUNCH(4); else if (H == 8) LAUNCH(8); else LAUNCH(16);
 #undef LAUNCH
     RECALGO_RETURN_LAST();
@@ -503,7 +542,7 @@ RECALGO_EXPORT int recalgo_din_attention_bwd(const float* query, const float* ke
 #define LAUNCH(HH)                                                                                            \
     do {                                                                                                      \
         pf = din_partial_floats<HH>();                                                                        \
-        size_t smem = din_bwd_smem<HH>();                                                                     \
+        size_t smem = din_smem<HH>();                                                                     \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&din_attention_bwd_kernel<HH>),      \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);            \
         if (e != hipSuccess) return (int)e;                                                                   \

@@ -162,18 +162,6 @@ __global__ __launch_bounds__(kThreads) void senet_bwd_kernel(
     }
 }
 
-// out[i] = sum_s partials[s][i]   (fixed order)
-__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ partials, unsigned S, unsigned n,
-                                                       float* __restrict__ out0, unsigned n0,
-                                                       float* __restrict__ out1) {
-    unsigned i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float acc = 0.f;
-    for (unsigned s = 0; s < S; ++s) acc += partials[(size_t)s * n + i];
-    if (i < n0) out0[i] = acc;
-    else out1[i - n0] = acc;
-}
-
 // =============================================================================================
 // bilinear interaction
 // =============================================================================================
@@ -590,13 +578,12 @@ RECALGO_EXPORT int recalgo_senet_bwd(const float* emb, const float* w1, const fl
     const size_t smem = ((size_t)kWaves * (((size_t)F * K + 3 * F + 2 * reduction_dim + 3) & ~(size_t)3) +
                          (size_t)kWaves * 2 * WR) * sizeof(float);
     ENSURE_SMEM(senet_bwd_kernel, smem);
-    const int grid = grid_for(B);
+    const int grid = grid_for(B) > 256 ? 256 : grid_for(B);        // persistent: one partial row per workgroup
     float* partials = static_cast<float*>(workspace);
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(senet_bwd_kernel, dim3(grid), dim3(kThreads), smem, st, emb, w1, w2, g_v, (unsigned)B,
                        (unsigned)F, (unsigned)K, (unsigned)reduction_dim, d_emb, accumulate, partials);
-    hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv(2 * WR, 256)), dim3(256), 0, st, partials, (unsigned)grid, 2 * WR,
-                       dw1, WR, dw2);
+    launch_colsum16(partials, (unsigned)grid, 2 * WR, dw1, WR, dw2, st);
     RECALGO_RETURN_LAST();
 }
 
@@ -651,8 +638,7 @@ RECALGO_EXPORT int recalgo_bilinear_bwd(const float* x0, const float* w0, const 
         DISPATCH_K(K, rc = (launch_bi_wgrad<KK>(xv, dvw + (size_t)v * B * nK, g, g_stride, g_col + v * K, B, F, type,
                                                 S, M, partials, st)));
         if (rc) return rc;
-        hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv(wn, 256)), dim3(256), 0, st, partials, (unsigned)S, wn, dwv, wn,
-                           static_cast<float*>(nullptr));
+        launch_colsum16(partials, (unsigned)S, wn, dwv, wn, static_cast<float*>(nullptr), st);
     }
     RECALGO_RETURN_LAST();
 }

@@ -130,16 +130,6 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ partial,
-                                                              unsigned nblk, unsigned C,
-                                                              float* __restrict__ out) {
-    unsigned c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float acc = 0.f;
-    for (unsigned k = 0; k < nblk; ++k) acc += partial[(size_t)k * C + c];
-    out[c] = acc;
-}
-
 constexpr unsigned kActRowsPerBlk = 16;
 
 __global__ void adam_advance_kernel(int64_t* step, float lr, float b1, float b2, float* lr_t) {
@@ -218,7 +208,6 @@ RECALGO_EXPORT int recalgo_activation_bwd(const float* x, const float* alpha, co
     else
         hipLaunchKernelGGL(act_bwd_kernel<false>, dim3(nblk), dim3(256), 0, st, x, alpha, gy, (unsigned)rows,
                            (unsigned)C, kActRowsPerBlk, dx, partial);
-    hipLaunchKernelGGL(colsum_partials_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, partial, nblk,
-                       (unsigned)C, dalpha);
+    launch_colsum16(partial, nblk, (unsigned)C, dalpha, (unsigned)C, static_cast<float*>(nullptr), st);
     RECALGO_RETURN_LAST();
 }
