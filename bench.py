@@ -41,8 +41,9 @@ def parse_args(argv=None):
     ap.add_argument("--emb", type=int, default=16)
     ap.add_argument("--max-vocab", type=int, default=1_000_000)
     ap.add_argument("--data-batches", type=int, default=8, help="distinct synthetic batches rotated through")
-    ap.add_argument("--tunable", action="store_true",
-                    help="let PyTorch TunableOp pick the fp32 GEMM kernels of the context MLP during warm-up")
+    ap.add_argument("--no-tunable", dest="tunable", action="store_false",
+                    help="keep hipBLASLt's default fp32 GEMM selection for the context MLP (default: PyTorch "
+                         "TunableOp picks the GEMM kernels during warm-up; selections are frozen before timing)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")

@@ -67,7 +67,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(compile_one, jobs))
-    if jobs or not os.path.exists(LIB) or force:
+    stale_lib = not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)
+    if jobs or stale_lib or force:
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB]
         if verbose:
             print("[recalgo build]", " ".join(cmd), flush=True)

@@ -177,6 +177,124 @@ __global__ __launch_bounds__(kThreads) void cin_contract_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// input gradients, fused: ONE implicit GEMM  dA^T[(i,j), (b,d)] = sum_n W[(i,j), n] * G[(b,d), n]
+// (the gradient of the never-materialised outer product) whose tiles are consumed on the fly:
+//   dX^k[b,i,d] = sum_j dA[(b,d),(i,j)] * X^0[b,j,d]     dX^0[b,j,d] = sum_i dA[(b,d),(i,j)] * X^k[b,i,d]
+// i.e. half the matrix-core work of contracting dX^k and dX^0 separately.  Orientation: MFMA rows =
+// j (one i per 32-row tile, j zero-padded to 32), MFMA columns = 32 (b,d) columns per wave, so that
+//   * the B operand G[(b,d), n] of a wave never changes: it is loaded once into registers (N/2 VGPRs),
+//   * sum_j is a lane-local sum over the 16 accumulator registers plus one cross-half shuffle,
+//   * sum_i is a lane-local accumulation across tiles,
+// and the only LDS traffic is one ds_read_b32 of the W tile per MFMA (row stride N+1: conflict free).
+// Workgroup = 128 (b,d) columns (4 waves) sharing double-buffered W tiles; m <= 32, N <= 128.
+// ---------------------------------------------------------------------------------------------
+template <int D, int KS>
+__global__ __launch_bounds__(kThreads) void cin_input_grad_kernel(
+    const float* __restrict__ x0, const float* __restrict__ xk, const float* __restrict__ W,
+    const float* __restrict__ G, unsigned B, unsigned m, unsigned Hk, unsigned N, float* __restrict__ dx0,
+    int dx0_accumulate, float* __restrict__ dxk, int dxk_accumulate) {
+    constexpr unsigned EX = kTM / D;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const unsigned NS = 2 * KS + 1;                  // LDS row stride of a W tile (k zero padded to 2*KS)
+    float* Ws = smem;                                // [2][32][NS]
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned hi = lane >> 5, l32 = lane & 31;
+    const unsigned col = wave * 32 + l32;
+    const unsigned exl = col / D, dd = col % D;
+    const unsigned b = blockIdx.x * EX + exl;
+    const bool valid = b < B;
+
+    for (unsigned e = tid; e < 2 * 32 * NS; e += kThreads) Ws[e] = 0.f;
+
+    // B operand: G[b, n = 2s + hi, dd], register resident for the whole kernel
+    float Breg[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const unsigned n = 2 * s + hi;
+        Breg[s] = (valid && n < N) ? G[((size_t)b * N + n) * D + dd] : 0.f;
+    }
+    // X^0[b, j = acc_row(r, hi), dd] for this lane's column
+    float x0v[16], dx0acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned j = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        x0v[r] = (valid && j < m) ? x0[((size_t)b * m + j) * D + dd] : 0.f;
+        dx0acc[r] = 0.f;
+    }
+    const unsigned tileN = m * N;                    // floats of one W tile (rows j < m, contiguous in W)
+    constexpr unsigned kStg = (32 * 128 + kThreads - 1) / kThreads;
+    float stg[kStg];
+    auto stage_load = [&](unsigned i) {
+        const float* src = W + (size_t)i * tileN;
+#pragma unroll
+        for (unsigned k = 0; k < kStg; ++k) {
+            unsigned e = tid + k * kThreads;
+            stg[k] = e < tileN ? src[e] : 0.f;
+        }
+    };
+    auto stage_store = [&](unsigned buf) {
+        float* dst = Ws + buf * 32 * NS;
+#pragma unroll
+        for (unsigned k = 0; k < kStg; ++k) {
+            unsigned e = tid + k * kThreads;
+            if (e < tileN) {
+                unsigned j = e / N, n = e - j * N;
+                dst[j * NS + n] = stg[k];
+            }
+        }
+    };
+    __syncthreads();                                 // zero fill done
+    stage_load(0);
+    stage_store(0);
+    float xkv = valid ? xk[((size_t)b * Hk) * D + dd] : 0.f;
+    __syncthreads();
+
+    for (unsigned i = 0; i < Hk; ++i) {
+        const unsigned buf = i & 1;
+        const bool more = i + 1 < Hk;
+        float xkv_next = 0.f;
+        if (more) {
+            stage_load(i + 1);
+            if (valid) xkv_next = xk[((size_t)b * Hk + i + 1) * D + dd];
+        }
+        f32x16 accE, accO;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accE[r] = accO[r] = 0.f;
+        const float* Wb = Ws + buf * 32 * NS + l32 * NS + hi;
+#pragma unroll
+        for (int s = 0; s < KS; s += 2) {
+            accE = __builtin_amdgcn_mfma_f32_32x32x2f32(Wb[2 * s], Breg[s], accE, 0, 0, 0);
+            accO = __builtin_amdgcn_mfma_f32_32x32x2f32(Wb[2 * s + 2], Breg[s + 1], accO, 0, 0, 0);
+        }
+        float dk = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float a = accE[r] + accO[r];       // dA[(b,d), (i, j = acc_row(r, hi))]
+            dk = fmaf(a, x0v[r], dk);
+            dx0acc[r] = fmaf(a, xkv, dx0acc[r]);
+        }
+        dk += __shfl_xor(dk, 32, 64);
+        if (hi == 0 && valid) {
+            float* p = dxk + ((size_t)b * Hk + i) * D + dd;
+            *p = dxk_accumulate ? *p + dk : dk;
+        }
+        if (more) stage_store(buf ^ 1);              // last read before the previous barrier
+        xkv = xkv_next;
+        __syncthreads();
+    }
+    if (valid) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned j = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (j < m) {
+                float* p = dx0 + ((size_t)b * m + j) * D + dd;
+                *p = dx0_accumulate ? *p + dx0acc[r] : dx0acc[r];
+            }
+        }
+    }
+}
+
 // F'[(a1*n2 + a2) * n0 + a0] = W[(a0*n1... see callers]  — generic 3-index permutation of the
 // filter: dst[(x*NY + y)*NZ + z] = src[x*sx + y*sy + z*sz]
 __global__ __launch_bounds__(256) void cin_permute_kernel(const float* __restrict__ src, float* __restrict__ dst,
@@ -357,6 +475,42 @@ int launch_contract(const float* P, const float* Q, const float* F, int B, int H
     }
 }
 
+template <int D, int KS>
+int launch_input_grad_DK(const float* x0, const float* xk, const float* W, const float* G, int B, int m, int Hk, int N,
+                         float* dx0, int dx0_acc, float* dxk, int dxk_acc, hipStream_t st) {
+    const size_t smem = (size_t)2 * 32 * (2 * KS + 1) * sizeof(float);
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_input_grad_kernel<D, KS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((cin_input_grad_kernel<D, KS>), dim3(cdiv((int64_t)B * D, kTM)), dim3(kThreads), smem, st, x0, xk,
+                       W, G, (unsigned)B, (unsigned)m, (unsigned)Hk, (unsigned)N, dx0, dx0_acc, dxk, dxk_acc);
+    return (int)hipGetLastError();
+}
+template <int D>
+int launch_input_grad_D(const float* x0, const float* xk, const float* W, const float* G, int B, int m, int Hk, int N,
+                        float* dx0, int dx0_acc, float* dxk, int dxk_acc, hipStream_t st) {
+    const int ks = cdiv(cdiv(N, 2), 16) * 16;
+    switch (ks) {
+        case 16: return launch_input_grad_DK<D, 16>(x0, xk, W, G, B, m, Hk, N, dx0, dx0_acc, dxk, dxk_acc, st);
+        case 32: return launch_input_grad_DK<D, 32>(x0, xk, W, G, B, m, Hk, N, dx0, dx0_acc, dxk, dxk_acc, st);
+        case 48: return launch_input_grad_DK<D, 48>(x0, xk, W, G, B, m, Hk, N, dx0, dx0_acc, dxk, dxk_acc, st);
+        case 64: return launch_input_grad_DK<D, 64>(x0, xk, W, G, B, m, Hk, N, dx0, dx0_acc, dxk, dxk_acc, st);
+        default: return (int)hipErrorInvalidValue;
+    }
+}
+int launch_input_grad(const float* x0, const float* xk, const float* W, const float* G, int B, int m, int Hk, int N,
+                      int D, float* dx0, int dx0_acc, float* dxk, int dxk_acc, hipStream_t st) {
+    switch (D) {
+        case 4: return launch_input_grad_D<4>(x0, xk, W, G, B, m, Hk, N, dx0, dx0_acc, dxk, dxk_acc, st);
+        case 8: return launch_input_grad_D<8>(x0, xk, W, G, B, m, Hk, N, dx0, dx0_acc, dxk, dxk_acc, st);
+        case 16: return launch_input_grad_D<16>(x0, xk, W, G, B, m, Hk, N, dx0, dx0_acc, dxk, dxk_acc, st);
+        case 32: return launch_input_grad_D<32>(x0, xk, W, G, B, m, Hk, N, dx0, dx0_acc, dxk, dxk_acc, st);
+        default: return (int)hipErrorInvalidValue;
+    }
+}
+
 inline int filter_grad_splits(int B, int D, int Kdim) {
     int row_blocks = cdiv(Kdim, 128);
     int want = cdiv(768, row_blocks);                       // ~3 workgroups per CU in total
@@ -457,21 +611,27 @@ RECALGO_EXPORT int recalgo_cin_layer_bwd(const float* x0, const float* xk, const
 #undef COMBINE
     }
     const unsigned wn = (unsigned)Hk * m * N;
-    // W[(i*m + j)*N + n] -> W'[(n*m + j)*Hk + i] : x=n, y=j, z=i
-    hipLaunchKernelGGL(cin_permute_kernel, dim3(cdiv(wn, 256)), dim3(256), 0, st, filters, Wp, (unsigned)N, (unsigned)m,
-                       (unsigned)Hk, 1u, (unsigned)N, (unsigned)(m * N));
-    // W -> W''[(i*N + n)*m + j] : x=i, y=n, z=j
-    hipLaunchKernelGGL(cin_permute_kernel, dim3(cdiv(wn, 256)), dim3(256), 0, st, filters, Wpp, (unsigned)Hk, (unsigned)N,
-                       (unsigned)m, (unsigned)(m * N), 1u, (unsigned)N);
     int rc;
-    // dX^k[b,i,d] = sum_{n,j} W'[(n,j), i] G[b,n,d] X0[b,j,d]
-    if (dxk) {
-        rc = launch_contract(G, x0, Wp, B, N, m, Hk, D, dxk, dxk_accumulate, nullptr, 0, 0, st);
+    if (m <= 32 && dxk != nullptr) {
+        // fused: one implicit GEMM G W^T feeds both dX^k and dX^0 (cin_input_grad_kernel)
+        rc = launch_input_grad(x0, xk, filters, G, B, m, Hk, N, D, dx0, dx0_accumulate, dxk, dxk_accumulate, st);
+        if (rc) return rc;
+    } else {
+        // W[(i*m + j)*N + n] -> W'[(n*m + j)*Hk + i] : x=n, y=j, z=i
+        hipLaunchKernelGGL(cin_permute_kernel, dim3(cdiv(wn, 256)), dim3(256), 0, st, filters, Wp, (unsigned)N,
+                           (unsigned)m, (unsigned)Hk, 1u, (unsigned)N, (unsigned)(m * N));
+        // W -> W''[(i*N + n)*m + j] : x=i, y=n, z=j
+        hipLaunchKernelGGL(cin_permute_kernel, dim3(cdiv(wn, 256)), dim3(256), 0, st, filters, Wpp, (unsigned)Hk,
+                           (unsigned)N, (unsigned)m, (unsigned)(m * N), 1u, (unsigned)N);
+        // dX^k[b,i,d] = sum_{n,j} W'[(n,j), i] G[b,n,d] X0[b,j,d]
+        if (dxk) {
+            rc = launch_contract(G, x0, Wp, B, N, m, Hk, D, dxk, dxk_accumulate, nullptr, 0, 0, st);
+            if (rc) return rc;
+        }
+        // dX^0[b,j,d] = sum_{i,n} W''[(i,n), j] X^k[b,i,d] G[b,n,d]
+        rc = launch_contract(xk, G, Wpp, B, Hk, N, m, D, dx0, dx0_accumulate, nullptr, 0, 0, st);
         if (rc) return rc;
     }
-    // dX^0[b,j,d] = sum_{i,n} W''[(i,n), j] X^k[b,i,d] G[b,n,d]
-    rc = launch_contract(xk, G, Wpp, B, Hk, N, m, D, dx0, dx0_accumulate, nullptr, 0, 0, st);
-    if (rc) return rc;
     // dW
     const int S = filter_grad_splits(B, D, Hk * m);
     const int NT = cdiv(N, 32);
