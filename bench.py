@@ -210,7 +210,7 @@ def kernel_rooflines(args, est, feats, device):
                 byt, fl)
             add(f"cin_bwd(L{li + 1},Hk={Hk})", lambda: lib.recalgo_cin_layer_bwd(p(x3), p(xk), p(w), p(go), p(pool), N, 0, B, m, Hk, N, D,
                                                                                  p(dx0), 0, p(dxk), 0, p(dw), p(ws), st),
-                2 * byt, 3.0 * fl)
+                2 * byt, 2.0 * fl)      # bwd = 2x fwd (one GEMM G.W^T feeding dX^k and dX^0, one for dW)
     if args.model == "deepfm":
         w1 = store.arenas["fm_first_order_w1"]
         bias = torch.zeros(1, device=device)

@@ -336,12 +336,14 @@ __global__ __launch_bounds__(256) void cin_combine_grad_kernel(const float* __re
 constexpr int kRC = 64;        // reduction rows (b,d) staged per chunk
 constexpr int kPW = 34;        // >= distinct p values touched by the 128 kk rows of a workgroup (m >= 4)
 
-template <int D, int NT>
+template <int D, int NT, int QI>
 __global__ __launch_bounds__(kThreads) void cin_filter_grad_kernel(
     const float* __restrict__ P, const float* __restrict__ Q, const float* __restrict__ G, unsigned B,
     unsigned HP, unsigned HQ, unsigned C, unsigned ex_per_split, float* __restrict__ partials) {
     constexpr unsigned EXC = kRC / D;            // examples per chunk
     constexpr unsigned GS = NT * 32 + 4;         // LDS row strides
+    constexpr unsigned GI = kRC * NT * 32 / kThreads;          // staged G floats per thread
+    constexpr unsigned PI = (kRC * kPW + kThreads - 1) / kThreads;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Gs = smem;                            // [kRC][GS]
     float* Ps = Gs + kRC * GS;                   // [kRC][kPW]
@@ -365,28 +367,69 @@ __global__ __launch_bounds__(kThreads) void cin_filter_grad_kernel(
 
     const unsigned ex_begin = blockIdx.y * ex_per_split;
     const unsigned ex_end = min(B, ex_begin + ex_per_split);
+    // Chunks are prefetched global -> registers one chunk ahead, so that the HBM/L2 latency of chunk
+    // c+1 is hidden under the MFMA loop of chunk c; only the register -> LDS transposing stores sit
+    // between the two barriers.  The G and Q chunks are contiguous in memory ([b][c][d] over
+    // consecutive b): float4 (4 consecutive d) per load.
+    constexpr unsigned GI4 = GI / 4;
+    float4 gst[GI4], qst[QI];
+    float pst[PI];
+    const unsigned nG4 = EXC * C * D / 4, nQ4 = EXC * HQ * D / 4, nP = EXC * p_cnt * D;
+    auto prefetch = [&](unsigned e0) {
+        const unsigned nex = min(EXC, ex_end - e0);
+        const float4* gsrc = reinterpret_cast<const float4*>(G + (size_t)e0 * C * D);
+        const float4* qsrc = reinterpret_cast<const float4*>(Q + (size_t)e0 * HQ * D);
+#pragma unroll
+        for (unsigned k = 0; k < GI4; ++k) {
+            const unsigned e = tid + k * kThreads;
+            gst[k] = e < nex * C * D / 4 ? gsrc[e] : f4_zero();
+        }
+#pragma unroll
+        for (unsigned k = 0; k < QI; ++k) {
+            const unsigned e = tid + k * kThreads;
+            qst[k] = e < nex * HQ * D / 4 ? qsrc[e] : f4_zero();
+        }
+#pragma unroll
+        for (unsigned k = 0; k < PI; ++k) {                 // P[b][p_first + pp][d]
+            const unsigned e = tid + k * kThreads;
+            const unsigned ex = e / (p_cnt * D), rem = e - ex * p_cnt * D;
+            pst[k] = (e < nP && ex < nex) ? P[((size_t)(e0 + ex) * HP + p_first) * D + rem] : 0.f;
+        }
+    };
+    auto commit = [&]() {                                   // registers -> LDS, transposed to [(ex,d)][col]
+#pragma unroll
+        for (unsigned k = 0; k < GI4; ++k) {
+            const unsigned e4 = tid + k * kThreads;
+            if (e4 < nG4) {
+                const unsigned e = e4 * 4, d = e % D, t = e / D, c = t % C, ex = t / C;
+                float* dst = Gs + (ex * D + d) * GS + c;
+                dst[0] = gst[k].x; dst[GS] = gst[k].y; dst[2 * GS] = gst[k].z; dst[3 * GS] = gst[k].w;
+            }
+        }
+#pragma unroll
+        for (unsigned k = 0; k < QI; ++k) {
+            const unsigned e4 = tid + k * kThreads;
+            if (e4 < nQ4) {
+                const unsigned e = e4 * 4, d = e % D, t = e / D, q = t % HQ, ex = t / HQ;
+                float* dst = Qs + (ex * D + d) * HQ + q;
+                dst[0] = qst[k].x; dst[HQ] = qst[k].y; dst[2 * HQ] = qst[k].z; dst[3 * HQ] = qst[k].w;
+            }
+        }
+#pragma unroll
+        for (unsigned k = 0; k < PI; ++k) {
+            const unsigned e = tid + k * kThreads;
+            if (e < nP) {
+                const unsigned d = e % D, t = e / D, pp = t % p_cnt, ex = t / p_cnt;
+                Ps[(ex * D + d) * kPW + pp] = pst[k];
+            }
+        }
+    };
+    if (ex_begin < ex_end) prefetch(ex_begin);
     for (unsigned e0 = ex_begin; e0 < ex_end; e0 += EXC) {
         __syncthreads();                                    // previous chunk fully consumed
-        // ---- stage chunk: rows r = (ex, d), ex in [e0, e0+EXC) ----
-        for (unsigned e = tid; e < EXC * C * D; e += kThreads) {        // G[b][c][d] -> Gs[(ex,d)][c]
-            unsigned d = e % D, t = e / D;
-            unsigned c = t % C, ex = t / C;
-            unsigned bb = e0 + ex;
-            Gs[(ex * D + d) * GS + c] = bb < ex_end ? G[((size_t)bb * C + c) * D + d] : 0.f;
-        }
-        for (unsigned e = tid; e < EXC * p_cnt * D; e += kThreads) {    // P[b][p][d] -> Ps[(ex,d)][pp]
-            unsigned d = e % D, t = e / D;
-            unsigned pp = t % p_cnt, ex = t / p_cnt;
-            unsigned bb = e0 + ex;
-            Ps[(ex * D + d) * kPW + pp] = bb < ex_end ? P[((size_t)bb * HP + p_first + pp) * D + d] : 0.f;
-        }
-        for (unsigned e = tid; e < EXC * HQ * D; e += kThreads) {       // Q[b][q][d] -> Qs[(ex,d)][q]
-            unsigned d = e % D, t = e / D;
-            unsigned q = t % HQ, ex = t / HQ;
-            unsigned bb = e0 + ex;
-            Qs[(ex * D + d) * HQ + q] = bb < ex_end ? Q[((size_t)bb * HQ + q) * D + d] : 0.f;
-        }
+        commit();
         __syncthreads();
+        if (e0 + EXC < ex_end) prefetch(e0 + EXC);
         const float* Pl = Ps + hi * kPW + pp_lane;
         const float* Ql = Qs + hi * HQ + q_lane;
         const float* Gl = Gs + hi * GS + l32;
@@ -513,29 +556,37 @@ int launch_input_grad(const float* x0, const float* xk, const float* W, const fl
 
 inline int filter_grad_splits(int B, int D, int Kdim) {
     int row_blocks = cdiv(Kdim, 128);
-    int want = cdiv(768, row_blocks);                       // ~3 workgroups per CU in total
+    int want = 512 / row_blocks;                            // <= 2 workgroups per CU (VGPR-bound occupancy): no tail round
     int exc = kRC / D;
     int max_s = cdiv(B, exc);
     int S = want < 1 ? 1 : (want > max_s ? max_s : want);
     return S > 64 ? 64 : S;
 }
 
-template <int D, int NT>
-int launch_filter_grad_DN(const float* P, const float* Q, const float* G, int B, int HP, int HQ, int C, int S,
-                          float* partials, hipStream_t st) {
+template <int D, int NT, int QI>
+int launch_filter_grad_DNQ(const float* P, const float* Q, const float* G, int B, int HP, int HQ, int C, int S,
+                           float* partials, hipStream_t st) {
     size_t smem = ((size_t)kRC * (NT * 32 + 4) + (size_t)kRC * kPW + (size_t)kRC * HQ) * sizeof(float);
     if (smem > 160 * 1024) return (int)hipErrorInvalidValue;
     if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_filter_grad_kernel<D, NT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_filter_grad_kernel<D, NT, QI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
     const int exc = kRC / D;
     int ex_per_split = cdiv(cdiv(B, S), exc) * exc;
     dim3 grid(cdiv(HP * HQ, 128), S);
-    hipLaunchKernelGGL((cin_filter_grad_kernel<D, NT>), grid, dim3(kThreads), smem, st, P, Q, G, (unsigned)B,
+    hipLaunchKernelGGL((cin_filter_grad_kernel<D, NT, QI>), grid, dim3(kThreads), smem, st, P, Q, G, (unsigned)B,
                        (unsigned)HP, (unsigned)HQ, (unsigned)C, (unsigned)ex_per_split, partials);
     return (int)hipGetLastError();
+}
+template <int D, int NT>
+int launch_filter_grad_DN(const float* P, const float* Q, const float* G, int B, int HP, int HQ, int C, int S,
+                          float* partials, hipStream_t st) {
+    const int qi = cdiv(kRC * HQ, 4 * kThreads);          // staged Q float4s per thread: HQ <= 32 | 64 | 128
+    if (qi <= 2) return launch_filter_grad_DNQ<D, NT, 2>(P, Q, G, B, HP, HQ, C, S, partials, st);
+    if (qi <= 4) return launch_filter_grad_DNQ<D, NT, 4>(P, Q, G, B, HP, HQ, C, S, partials, st);
+    return launch_filter_grad_DNQ<D, NT, 8>(P, Q, G, B, HP, HQ, C, S, partials, st);
 }
 
 template <int D>
