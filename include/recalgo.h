@@ -271,6 +271,35 @@ int recalgo_pnn_weights_bwd(const float* product_w, const float* domega, int D, 
                             int method, float* d_product_w, recalgo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Context-MLP glue around the library GEMMs (not interaction layers; fused because the step is
+ * otherwise dominated by their launch count).  Widths must satisfy recalgo_mlp_width_supported(C)
+ * (C % 4 == 0 and 256 % (C/4) == 0); callers keep their own path for other widths.
+ *
+ * Backward epilogue of tf.layers.dense(..., activation=tf.nn.relu) (algorithm/DeepFM/deepfm.py:207
+ * and the same line in every model_fn):   g_out = g * [y > 0],  dbias = colsum(g_out).
+ * y == g_out == NULL: no activation, dbias = colsum(g).  g, y, g_out [rows, C].
+ * ------------------------------------------------------------------------------------------ */
+int recalgo_mlp_width_supported(int C);
+int64_t recalgo_relu_bwd_bias_workspace_bytes(int rows, int C);
+int recalgo_relu_bwd_bias(const float* g, const float* y, int rows, int C, float* g_out, float* dbias,
+                          void* workspace, recalgo_stream_t stream);
+/* tf.layers.batch_normalization(net, training=True) (algorithm/DeepFM/deepfm.py:210-211; PNN
+ * pnn.py:190-191; FiBiNET fibinet.py:195-196; DIN din.py:233-234), [TF-ext A-8]:
+ *   mean/var = batch moments (biased variance);  y = (x - mean) * rsqrt(var + eps) * gamma + beta
+ *   moving_mean/var <- moving * momentum + batch * (1 - momentum)   (updated in place; may be NULL)
+ *   save_mean, save_rstd [C] are kept for the backward, which returns
+ *   dbeta = colsum(g), dgamma = colsum(g * xhat), dx = gamma * rstd / rows * (rows*g - dbeta - xhat*dgamma).
+ * workspace: recalgo_batchnorm_workspace_bytes(rows, C) for both directions. */
+int64_t recalgo_batchnorm_workspace_bytes(int rows, int C);
+int recalgo_batchnorm_train_fwd(const float* x, const float* gamma, const float* beta, int rows, int C,
+                                float eps, float momentum, float* moving_mean, float* moving_var,
+                                float* y, float* save_mean, float* save_rstd, void* workspace,
+                                recalgo_stream_t stream);
+int recalgo_batchnorm_train_bwd(const float* x, const float* gamma, const float* save_mean,
+                                const float* save_rstd, const float* g, int rows, int C, float* dx,
+                                float* dgamma, float* dbeta, void* workspace, recalgo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * a14  loss tail: sigmoid + mean sigmoid cross entropy, forward and d(loss)/d(logit) fused.
  * Replaces tf.sigmoid + tf.reduce_mean(tf.nn.sigmoid_cross_entropy_with_logits)
  * algorithm/DeepFM/deepfm.py:217,235 (same in all six model_fns).

@@ -48,6 +48,12 @@ SIGNATURES = {
     "recalgo_pnn_features_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, P]),
     "recalgo_pnn_weights_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
     "recalgo_pnn_weights_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
+    "recalgo_mlp_width_supported": (c_int, [c_int]),
+    "recalgo_relu_bwd_bias_workspace_bytes": (c_int64, [c_int, c_int]),
+    "recalgo_relu_bwd_bias": (c_int, [P, P, c_int, c_int, P, P, P, P]),
+    "recalgo_batchnorm_workspace_bytes": (c_int64, [c_int, c_int]),
+    "recalgo_batchnorm_train_fwd": (c_int, [P, P, P, c_int, c_int, c_float, c_float, P, P, P, P, P, P, P]),
+    "recalgo_batchnorm_train_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, P, P, P]),
     "recalgo_sigmoid_ce_fwd_bwd": (c_int, [P, P, c_int, c_float, P, P, P, P]),
     "recalgo_adam_tf1_dense": (c_int, [P, P, P, P, c_int64, c_float, P, c_float, c_float, c_float, c_int, P]),
     "recalgo_adam_tf1_advance": (c_int, [P, c_float, c_float, c_float, P, P]),

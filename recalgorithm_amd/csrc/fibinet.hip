@@ -316,27 +316,33 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
                     vW[v * nK + idx] = acc;
                 }
             __builtin_amdgcn_wave_barrier();
-            // dvW[i][k'] = sum_{j>i} g[(i,j)][k'] x_j[k'] ;  dX[j][k'] = sum_{i<j} g[(i,j)][k'] vW[i][k']
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const float* gv = gb + v * K;
-                const float* Xv = X + v * FK;
-                const float* vWv = vW + v * nK;
-                for (unsigned idx = lane; idx < FK; idx += 64) {
-                    const unsigned r = idx / K, kk = idx % K;
-                    float s1 = 0.f, s2 = 0.f;
-                    if (r < n) {
-                        const float* gp = gv + (size_t)tri_index(r, r + 1, n) * g_stride + kk;   // pairs (r, r+1..)
-                        for (unsigned j = r + 1; j < n; ++j, gp += g_stride) s1 = fmaf(gp[0], Xv[j * K + kk], s1);
-                        for (unsigned i = 0; i < r; ++i)
-                            s2 = fmaf(gv[(size_t)tri_index(i, r, n) * g_stride + kk], vWv[i * K + kk], s2);
-                        dvW[v * nK + idx] = s1;
-                        dvw_ws[((size_t)v * B + b) * nK + idx] = s1;
-                    }
-                    dX[v * FK + idx] = s2;
+            // dvW[i][k'] = sum_{j>i} g[(i,j)][k'] x_j[k'] ;  dX[j][k'] = sum_{i<j} g[(i,j)][k'] vW[i][k'].
+            // One pass over g in pair order (the forward's write pattern: PPP pairs x whole 128-byte rows
+            // per wave instruction, float4 per lane); both sums are scattered with LDS atomics
+            // (ds_add_f32) — consecutive pairs share i, so the dvW adds of a pass collide on up to PPP
+            // lanes per address, the dX adds (distinct j) do not.
+            for (unsigned i = lane; i < NV * FK; i += 64) dX[i] = 0.f;
+            for (unsigned i = lane; i < NV * nK; i += 64) dvW[i] = 0.f;
+            __builtin_amdgcn_wave_barrier();
+            for (unsigned p0 = 0; p0 < P; p0 += PPP) {
+                const unsigned pair = p0 + pl;
+                if (pair < P) {
+                    const unsigned ij = ptab[pair], i = ij & 255u, j = ij >> 8;
+                    const float4 g4 = *reinterpret_cast<const float4*>(gb + (size_t)pair * g_stride + c4 * 4);
+                    const float4 xj = *reinterpret_cast<const float4*>(X + v_l * FK + j * K + k0);
+                    const float4 vw = *reinterpret_cast<const float4*>(vW + v_l * nK + i * K + k0);
+                    float* di = dvW + v_l * nK + i * K + k0;
+                    float* dj = dX + v_l * FK + j * K + k0;
+                    lds_add(di + 0, g4.x * xj.x); lds_add(di + 1, g4.y * xj.y);
+                    lds_add(di + 2, g4.z * xj.z); lds_add(di + 3, g4.w * xj.w);
+                    lds_add(dj + 0, g4.x * vw.x); lds_add(dj + 1, g4.y * vw.y);
+                    lds_add(dj + 2, g4.z * vw.z); lds_add(dj + 3, g4.w * vw.w);
                 }
             }
             __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                for (unsigned idx = lane; idx < nK; idx += 64) dvw_ws[((size_t)v * B + b) * nK + idx] = dvW[v * nK + idx];
             // dX[i][k] += sum_k' dvW[i][k'] W[k][k']
 #pragma unroll
             for (int v = 0; v < NV; ++v)

@@ -1,0 +1,273 @@
+// Glue of the context MLP around the library GEMMs (tf.layers.dense / batch_normalization of
+// every model_fn, e.g. algorithm/DeepFM/deepfm.py:206-212), gfx950.  The GEMMs themselves stay on
+// hipBLASLt; what is fused here is the memory-bound work between them, which torch would run as
+// 3 (ReLU backward + bias gradient) to 8 (BatchNorm training forward / backward) separate launches:
+//   relu_bwd_bias        g2 = g * [y > 0],  dbias = colsum(g2)                      (dense backward)
+//   batchnorm_train_fwd  batch mean / biased variance (Chan-merged per-block moments, as accurate
+//                        as tf.nn.moments' two-pass form), moving-stat update (momentum 0.99),
+//                        y = (x - mean) * rsqrt(var + eps) * gamma + beta
+//   batchnorm_train_bwd  dbeta = colsum(g), dgamma = colsum(g * xhat),
+//                        dx = gamma * rstd / B * (B*g - dbeta - xhat * dgamma)
+// All three are HBM-bound streams over [rows, C] fp32 with column reductions: a thread owns one
+// float4 column group, a workgroup a block of rows; per-workgroup partials are summed in a fixed
+// order (deterministic).  Requires C % 4 == 0 and 256 % (C/4) == 0 (C in {4,...,1024} a power of
+// two times 4) — the caller keeps torch ops for other widths.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kRowsPerBlk = 32;
+
+__device__ __forceinline__ float4 f4_sub(float4 a, float4 b) {
+    return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+}
+__device__ __forceinline__ float4 f4_mul(float4 a, float4 b) {
+    return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+}
+
+// reduce `v` (one float4 per thread, column group c4 = tid % C4, row lane rs = tid / C4) over the
+// row lanes in fixed order; result valid for rs == 0
+__device__ __forceinline__ float4 reduce_row_lanes(float4 v, float4* sh, unsigned C4) {
+    const unsigned RP = kThreads / C4;
+    if (RP == 1) return v;
+    __syncthreads();
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    float4 acc = sh[threadIdx.x % C4];
+    for (unsigned r = 1; r < RP; ++r) acc = f4_add(acc, sh[r * C4 + threadIdx.x % C4]);
+    return acc;
+}
+
+__global__ __launch_bounds__(kThreads) void relu_bwd_bias_kernel(const float4* __restrict__ g,
+                                                                 const float4* __restrict__ y, unsigned rows,
+                                                                 unsigned C4, float4* __restrict__ g_out,
+                                                                 float4* __restrict__ partials) {
+    __shared__ float4 sh[kThreads];
+    const unsigned c4 = threadIdx.x % C4, rs = threadIdx.x / C4, RP = kThreads / C4;
+    const unsigned r0 = blockIdx.x * kRowsPerBlk;
+    float4 acc = f4_zero();
+    for (unsigned r = r0 + rs; r < min(rows, r0 + kRowsPerBlk); r += RP) {
+        float4 v = g[(size_t)r * C4 + c4];
+        if (y) {
+            const float4 yy = y[(size_t)r * C4 + c4];
+            v = make_float4(yy.x > 0.f ? v.x : 0.f, yy.y > 0.f ? v.y : 0.f, yy.z > 0.f ? v.z : 0.f,
+                            yy.w > 0.f ? v.w : 0.f);
+            g_out[(size_t)r * C4 + c4] = v;
+        }
+        acc = f4_add(acc, v);
+    }
+    acc = reduce_row_lanes(acc, sh, C4);
+    if (rs == 0) partials[(size_t)blockIdx.x * C4 + c4] = acc;
+}
+
+// ---- BatchNorm ------------------------------------------------------------------------------
+// per-block moments: partials[blk][0:C] = block mean, [C:2C] = block M2 (sum of squared deviations
+// from the block mean); block row counts are implied by (rows, kRowsPerBlk)
+__global__ __launch_bounds__(kThreads) void bn_moments_kernel(const float4* __restrict__ x, unsigned rows,
+                                                              unsigned C4, float4* __restrict__ partials) {
+    __shared__ float4 sh[kThreads];
+    const unsigned c4 = threadIdx.x % C4, rs = threadIdx.x / C4, RP = kThreads / C4;
+    const unsigned r0 = blockIdx.x * kRowsPerBlk, r1 = min(rows, r0 + kRowsPerBlk);
+    const float n = (float)(r1 - r0);
+    float4 s = f4_zero();
+    for (unsigned r = r0 + rs; r < r1; r += RP) s = f4_add(s, x[(size_t)r * C4 + c4]);
+    s = reduce_row_lanes(s, sh, C4);
+    if (RP > 1) {                                    // broadcast the block sum to every row lane
+        __syncthreads();
+        if (rs == 0) sh[c4] = s;
+        __syncthreads();
+        s = sh[c4];
+    }
+    const float4 mean = f4_scale(s, 1.0f / n);
+    float4 m2 = f4_zero();
+    for (unsigned r = r0 + rs; r < r1; r += RP) {
+        const float4 d = f4_sub(x[(size_t)r * C4 + c4], mean);
+        m2 = f4_add(m2, f4_mul(d, d));
+    }
+    m2 = reduce_row_lanes(m2, sh, C4);
+    if (rs == 0) {
+        partials[(size_t)blockIdx.x * 2 * C4 + c4] = mean;
+        partials[(size_t)blockIdx.x * 2 * C4 + C4 + c4] = m2;
+    }
+}
+
+// Chan merge of the block moments (fixed order: 16 interleaved block groups, then the groups) ->
+// mean, rstd; moving-stat update.  256 threads = 16 columns x 16 block groups.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, unsigned nblk,
+                                                          unsigned rows, unsigned C, float eps, float momentum,
+                                                          float* __restrict__ moving_mean,
+                                                          float* __restrict__ moving_var,
+                                                          float* __restrict__ save_mean,
+                                                          float* __restrict__ save_rstd) {
+    __shared__ float sh[16][17];
+    const unsigned cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const unsigned c = blockIdx.x * 16 + cl;
+    const bool ok = c < C;
+    float acc = 0.f;
+    if (ok)
+        for (unsigned b = rg; b < nblk; b += 16) {
+            const float nb = (float)(min(rows, (b + 1) * kRowsPerBlk) - b * kRowsPerBlk);
+            acc += nb * partials[(size_t)b * 2 * C + c];
+        }
+    sh[rg][cl] = acc;
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) mean += sh[g][cl];
+    mean /= (float)rows;
+    __syncthreads();
+    acc = 0.f;
+    if (ok)
+        for (unsigned b = rg; b < nblk; b += 16) {
+            const float nb = (float)(min(rows, (b + 1) * kRowsPerBlk) - b * kRowsPerBlk);
+            const float d = partials[(size_t)b * 2 * C + c] - mean;
+            acc += partials[(size_t)b * 2 * C + C + c] + nb * d * d;
+        }
+    sh[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0 && ok) {
+        float m2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) m2 += sh[g][cl];
+        const float var = m2 / (float)rows;                    // biased (tf.nn.moments)
+        save_mean[c] = mean;
+        save_rstd[c] = rsqrtf(var + eps);
+        if (moving_mean) {                                      // assign_moving_average, decay = momentum
+            moving_mean[c] = moving_mean[c] * momentum + mean * (1.f - momentum);
+            moving_var[c] = moving_var[c] * momentum + var * (1.f - momentum);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float4* __restrict__ x,
+                                                            const float4* __restrict__ gamma,
+                                                            const float4* __restrict__ beta,
+                                                            const float4* __restrict__ mean,
+                                                            const float4* __restrict__ rstd, size_t total4,
+                                                            unsigned C4, float4* __restrict__ y) {
+    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= total4) return;
+    const unsigned c4 = (unsigned)(i % C4);
+    const float4 sc = f4_mul(rstd[c4], gamma[c4]);
+    const float4 xh = f4_sub(x[i], mean[c4]);
+    const float4 b = beta[c4];
+    y[i] = make_float4(fmaf(xh.x, sc.x, b.x), fmaf(xh.y, sc.y, b.y), fmaf(xh.z, sc.z, b.z), fmaf(xh.w, sc.w, b.w));
+}
+
+// partial[blk][0:C] = colsum(g), [C:2C] = colsum(g * xhat)
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float4* __restrict__ x,
+                                                                 const float4* __restrict__ g,
+                                                                 const float4* __restrict__ mean,
+                                                                 const float4* __restrict__ rstd, unsigned rows,
+                                                                 unsigned C4, float4* __restrict__ partials) {
+    __shared__ float4 sh[kThreads];
+    const unsigned c4 = threadIdx.x % C4, rs = threadIdx.x / C4, RP = kThreads / C4;
+    const unsigned r0 = blockIdx.x * kRowsPerBlk;
+    const float4 mu = mean[c4], rs4 = rstd[c4];
+    float4 sg = f4_zero(), sgx = f4_zero();
+    for (unsigned r = r0 + rs; r < min(rows, r0 + kRowsPerBlk); r += RP) {
+        const float4 gv = g[(size_t)r * C4 + c4];
+        const float4 xh = f4_mul(f4_sub(x[(size_t)r * C4 + c4], mu), rs4);
+        sg = f4_add(sg, gv);
+        sgx = f4_add(sgx, f4_mul(gv, xh));
+    }
+    sg = reduce_row_lanes(sg, sh, C4);
+    sgx = reduce_row_lanes(sgx, sh, C4);
+    if (rs == 0) {
+        partials[(size_t)blockIdx.x * 2 * C4 + c4] = sg;
+        partials[(size_t)blockIdx.x * 2 * C4 + C4 + c4] = sgx;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
+    const float4* __restrict__ x, const float4* __restrict__ g, const float4* __restrict__ gamma,
+    const float4* __restrict__ mean, const float4* __restrict__ rstd, const float4* __restrict__ dbeta,
+    const float4* __restrict__ dgamma, size_t total4, unsigned C4, float inv_rows, float4* __restrict__ dx) {
+    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= total4) return;
+    const unsigned c4 = (unsigned)(i % C4);
+    const float4 rs4 = rstd[c4];
+    const float4 xh = f4_mul(f4_sub(x[i], mean[c4]), rs4);
+    const float4 k = f4_mul(gamma[c4], rs4);
+    const float4 db = dbeta[c4], dg = dgamma[c4], gv = g[i];
+    dx[i] = make_float4(k.x * (gv.x - inv_rows * (db.x + xh.x * dg.x)), k.y * (gv.y - inv_rows * (db.y + xh.y * dg.y)),
+                        k.z * (gv.z - inv_rows * (db.z + xh.z * dg.z)), k.w * (gv.w - inv_rows * (db.w + xh.w * dg.w)));
+}
+
+inline bool width_ok(int C) { return C >= 4 && C % 4 == 0 && C / 4 <= kThreads && kThreads % (C / 4) == 0; }
+inline int nblk_of(int rows) { return cdiv(rows, kRowsPerBlk); }
+
+}  // namespace
+
+RECALGO_EXPORT int recalgo_mlp_width_supported(int C) { return width_ok(C) ? 1 : 0; }
+
+RECALGO_EXPORT int64_t recalgo_relu_bwd_bias_workspace_bytes(int rows, int C) {
+    if (rows <= 0 || !width_ok(C)) return 0;
+    return (int64_t)nblk_of(rows) * C * (int64_t)sizeof(float);
+}
+
+RECALGO_EXPORT int recalgo_relu_bwd_bias(const float* g, const float* y, int rows, int C, float* g_out, float* dbias,
+                                         void* workspace, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(rows > 0 && width_ok(C) && g && dbias && workspace && ((y == nullptr) == (g_out == nullptr)));
+    hipStream_t st = as_stream(stream);
+    const int nb = nblk_of(rows);
+    float* partials = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(relu_bwd_bias_kernel, dim3(nb), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(g),
+                       reinterpret_cast<const float4*>(y), (unsigned)rows, (unsigned)(C / 4),
+                       reinterpret_cast<float4*>(g_out), reinterpret_cast<float4*>(partials));
+    launch_colsum16(partials, (unsigned)nb, (unsigned)C, dbias, (unsigned)C, static_cast<float*>(nullptr), st);
+    RECALGO_RETURN_LAST();
+}
+
+RECALGO_EXPORT int64_t recalgo_batchnorm_workspace_bytes(int rows, int C) {
+    if (rows <= 0 || !width_ok(C)) return 0;
+    return (int64_t)nblk_of(rows) * 2 * C * (int64_t)sizeof(float);
+}
+
+RECALGO_EXPORT int recalgo_batchnorm_train_fwd(const float* x, const float* gamma, const float* beta, int rows, int C,
+                                               float eps, float momentum, float* moving_mean, float* moving_var,
+                                               float* y, float* save_mean, float* save_rstd, void* workspace,
+                                               recalgo_stream_t stream) {
+    RECALGO_REQUIRE(rows > 0 && width_ok(C) && x && gamma && beta && y && save_mean && save_rstd && workspace);
+    RECALGO_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr));
+    hipStream_t st = as_stream(stream);
+    const int nb = nblk_of(rows);
+    const unsigned C4 = C / 4;
+    float* partials = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(bn_moments_kernel, dim3(nb), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
+                       (unsigned)rows, C4, reinterpret_cast<float4*>(partials));
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, partials, (unsigned)nb, (unsigned)rows,
+                       (unsigned)C, eps, momentum, moving_mean, moving_var, save_mean, save_rstd);
+    const size_t total4 = (size_t)rows * C4;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv((int64_t)total4, kThreads)), dim3(kThreads), 0, st,
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(gamma),
+                       reinterpret_cast<const float4*>(beta), reinterpret_cast<const float4*>(save_mean),
+                       reinterpret_cast<const float4*>(save_rstd), total4, C4, reinterpret_cast<float4*>(y));
+    RECALGO_RETURN_LAST();
+}
+
+RECALGO_EXPORT int recalgo_batchnorm_train_bwd(const float* x, const float* gamma, const float* save_mean,
+                                               const float* save_rstd, const float* g, int rows, int C, float* dx,
+                                               float* dgamma, float* dbeta, void* workspace,
+                                               recalgo_stream_t stream) {
+    RECALGO_REQUIRE(rows > 0 && width_ok(C) && x && gamma && save_mean && save_rstd && g && dx && dgamma && dbeta &&
+                    workspace);
+    hipStream_t st = as_stream(stream);
+    const int nb = nblk_of(rows);
+    const unsigned C4 = C / 4;
+    float* partials = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
+                       reinterpret_cast<const float4*>(g), reinterpret_cast<const float4*>(save_mean),
+                       reinterpret_cast<const float4*>(save_rstd), (unsigned)rows, C4,
+                       reinterpret_cast<float4*>(partials));
+    launch_colsum16(partials, (unsigned)nb, (unsigned)(2 * C), dbeta, (unsigned)C, dgamma, st);
+    const size_t total4 = (size_t)rows * C4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv((int64_t)total4, kThreads)), dim3(kThreads), 0, st,
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(g),
+                       reinterpret_cast<const float4*>(gamma), reinterpret_cast<const float4*>(save_mean),
+                       reinterpret_cast<const float4*>(save_rstd), reinterpret_cast<const float4*>(dbeta),
+                       reinterpret_cast<const float4*>(dgamma), total4, C4, 1.0f / (float)rows,
+                       reinterpret_cast<float4*>(dx));
+    RECALGO_RETURN_LAST();
+}

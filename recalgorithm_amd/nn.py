@@ -14,16 +14,22 @@ from torch.autograd import Function
 from .variables import Variable, current_store, glorot_uniform, ones, zeros
 
 
+def _hip(x: torch.Tensor, C: int) -> bool:
+    """The fused HIP glue kernels serve contiguous fp32 device tensors of a supported width."""
+    from . import ops
+    return x.is_cuda and x.dtype == torch.float32 and ops.mlp_width_supported(C)
+
+
 class _DenseFn(Function):
     @staticmethod
     def forward(ctx, anchor, x, kernel: Variable, bias: Optional[Variable], relu: bool):
         x2 = x.reshape(-1, x.shape[-1])
-        if bias is not None:
-            y = torch.addmm(bias.data, x2, kernel.data)
+        if bias is not None and relu and x2.is_cuda:
+            y = torch._addmm_activation(bias.data, x2, kernel.data)     # GEMM + bias + ReLU epilogue (hipBLASLt)
         else:
-            y = x2 @ kernel.data
-        if relu:
-            y = torch.relu_(y)
+            y = torch.addmm(bias.data, x2, kernel.data) if bias is not None else x2 @ kernel.data
+            if relu:
+                y = torch.relu_(y)
         ctx.vars = (kernel, bias)
         ctx.relu = relu
         ctx.xshape = x.shape
@@ -32,16 +38,21 @@ class _DenseFn(Function):
 
     @staticmethod
     def backward(ctx, g):
+        from . import ops
         kernel, bias = ctx.vars
         x2, y = ctx.saved_tensors
         g2 = g.reshape(-1, g.shape[-1])
-        if ctx.relu:
-            g2 = g2 * (y > 0)
-        elif not g2.is_contiguous():
+        if not g2.is_contiguous():
             g2 = g2.contiguous()
+        if bias is not None and _hip(g2, g2.shape[1]):
+            # one fused pass: ReLU mask + bias gradient (csrc/mlp.hip)
+            g2 = ops.relu_bwd_bias_(g2, y if ctx.relu else None, bias.grad)
+        else:
+            if ctx.relu:
+                g2 = g2 * (y > 0)
+            if bias is not None:
+                torch.sum(g2, dim=0, out=bias.grad)
         torch.mm(x2.t(), g2, out=kernel.grad)
-        if bias is not None:
-            torch.sum(g2, dim=0, out=bias.grad)
         dx = g2 @ kernel.data.t()
         return None, dx.view(ctx.xshape), None, None, None
 
@@ -66,6 +77,13 @@ class _BatchNormTrainFn(Function):
     @staticmethod
     def forward(ctx, anchor, x, gamma: Variable, beta: Variable, mmean: Variable, mvar: Variable,
                 momentum: float, eps: float):
+        ctx.vars = (gamma, beta)
+        ctx.hip = x.dim() == 2 and x.is_contiguous() and _hip(x, x.shape[1])
+        if ctx.hip:
+            from . import ops
+            y, mean, rstd = ops.batchnorm_train_fwd(x, gamma.data, beta.data, mmean.data, mvar.data, momentum, eps)
+            ctx.save_for_backward(x, mean, rstd)
+            return y
         mean = x.mean(dim=0)
         xc = x - mean
         var = (xc * xc).mean(dim=0)            # biased, tf.nn.moments
@@ -75,13 +93,17 @@ class _BatchNormTrainFn(Function):
         # moving stats: assign_moving_average, decay = momentum (TF default 0.99)
         mmean.data.mul_(momentum).add_(mean, alpha=1 - momentum)
         mvar.data.mul_(momentum).add_(var, alpha=1 - momentum)
-        ctx.vars = (gamma, beta)
         ctx.save_for_backward(xhat, rstd)
         return y
 
     @staticmethod
     def backward(ctx, g):
         gamma, beta = ctx.vars
+        if ctx.hip:
+            from . import ops
+            x, mean, rstd = ctx.saved_tensors
+            dx = ops.batchnorm_train_bwd(x, gamma.data, mean, rstd, g.contiguous(), gamma.grad, beta.grad)
+            return None, dx, None, None, None, None, None, None
         xhat, rstd = ctx.saved_tensors
         B = g.shape[0]
         dbeta = g.sum(dim=0)

@@ -595,6 +595,47 @@ def pnn_product_layer(store, emb_flat: torch.Tensor, linear_w: Variable, product
 
 
 # =============================================================================================
+# context-MLP glue (csrc/mlp.hip): dense backward epilogue, BatchNorm training
+# =============================================================================================
+def mlp_width_supported(C: int) -> bool:
+    return bool(_lib_().recalgo_mlp_width_supported(int(C)))
+
+
+def relu_bwd_bias_(g: torch.Tensor, y: Optional[torch.Tensor], dbias: torch.Tensor) -> torch.Tensor:
+    """g2 = g * [y > 0] (g itself when y is None), dbias[:] = colsum(g2); -> g2.  g, y [rows, C]."""
+    rows, C = g.shape
+    lib = _lib_()
+    ws = _workspace(lib.recalgo_relu_bwd_bias_workspace_bytes(rows, C), g.device)
+    g2 = None if y is None else torch.empty_like(g)
+    _lib.check(lib.recalgo_relu_bwd_bias(_p(g), _p(y), rows, C, _p(g2), _p(dbias), _p(ws), _stream(g)),
+               "recalgo_relu_bwd_bias")
+    return g if y is None else g2
+
+
+def batchnorm_train_fwd(x, gamma, beta, moving_mean, moving_var, momentum: float, eps: float):
+    rows, C = x.shape
+    lib = _lib_()
+    ws = _workspace(lib.recalgo_batchnorm_workspace_bytes(rows, C), x.device)
+    y = torch.empty_like(x)
+    mean = torch.empty(C, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(C, device=x.device, dtype=torch.float32)
+    _lib.check(lib.recalgo_batchnorm_train_fwd(_p(x), _p(gamma), _p(beta), rows, C, eps, momentum, _p(moving_mean),
+                                               _p(moving_var), _p(y), _p(mean), _p(rstd), _p(ws), _stream(x)),
+               "recalgo_batchnorm_train_fwd")
+    return y, mean, rstd
+
+
+def batchnorm_train_bwd(x, gamma, mean, rstd, g, dgamma, dbeta) -> torch.Tensor:
+    rows, C = x.shape
+    lib = _lib_()
+    ws = _workspace(lib.recalgo_batchnorm_workspace_bytes(rows, C), x.device)
+    dx = torch.empty_like(x)
+    _lib.check(lib.recalgo_batchnorm_train_bwd(_p(x), _p(gamma), _p(mean), _p(rstd), _p(g), rows, C, _p(dx), _p(dgamma),
+                                               _p(dbeta), _p(ws), _stream(x)), "recalgo_batchnorm_train_bwd")
+    return dx
+
+
+# =============================================================================================
 # a14: loss tail
 # =============================================================================================
 class _SigmoidCEFn(Function):

@@ -294,3 +294,44 @@ def test_cpu_tensor_is_rejected():
     ar.materialize()
     with pytest.raises(RecalgoError):
         ops.embedding_gather(store, torch.zeros(2, 1, dtype=torch.int64), ar, torch.zeros(1, dtype=torch.int64))
+
+
+@pytest.mark.parametrize("rows,C", [(4096, 512), (300, 128), (33, 16), (1000, 1024), (7, 4)])
+def test_mlp_glue_relu_bwd_bias_and_batchnorm(dev, rows, C):
+    """csrc/mlp.hip vs a float64 torch restatement of tf.layers.dense's ReLU/bias backward and of
+    tf.layers.batch_normalization(training=True) [TF-ext A-8]."""
+    from recalgorithm_amd import ops
+    assert ops.mlp_width_supported(C) and not ops.mlp_width_supported(82)
+    gen = torch.Generator().manual_seed(rows + C)
+    g = torch.randn(rows, C, generator=gen)
+    y = torch.relu(torch.randn(rows, C, generator=gen))
+    dbias = torch.empty(C, device=dev)
+    g2 = ops.relu_bwd_bias_(g.to(dev), y.to(dev), dbias)
+    ref = g.double() * (y.double() > 0)
+    assert_bit_exact(g2, ref.float(), "relu mask")
+    assert_close(dbias, ref.sum(0), what="dbias", reduced=True)
+    g3 = ops.relu_bwd_bias_(g.to(dev), None, dbias)
+    assert_close(dbias, g.double().sum(0), what="dbias (no relu)", reduced=True)
+    assert g3.data_ptr() != 0
+    # batch norm, with a column offset much larger than the spread (stresses the variance formula)
+    x = torch.randn(rows, C, generator=gen) * 0.5 + torch.linspace(-20, 20, C)
+    gamma, beta = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen)
+    mm, mv = torch.randn(C, generator=gen), torch.rand(C, generator=gen) + 0.5
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    mean = xd.mean(0)
+    var = ((xd - mean) ** 2).mean(0)
+    yref = (xd - mean) * torch.rsqrt(var + 1e-3) * gd + bd
+    yref.backward(g.double())
+    mmg, mvg = mm.to(dev), mv.to(dev)
+    yh, smean, srstd = ops.batchnorm_train_fwd(x.to(dev), gamma.to(dev), beta.to(dev), mmg, mvg, 0.99, 1e-3)
+    assert_close(yh, yref, what="bn y")
+    assert_close(smean, mean, what="bn mean")
+    assert_close(srstd, torch.rsqrt(var + 1e-3), what="bn rstd")
+    assert_close(mmg, mm.double() * 0.99 + mean.detach() * 0.01, what="moving_mean")
+    assert_close(mvg, mv.double() * 0.99 + var.detach() * 0.01, what="moving_variance")
+    dgamma, dbeta = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    dx = ops.batchnorm_train_bwd(x.to(dev), gamma.to(dev), smean, srstd, g.to(dev), dgamma, dbeta)
+    assert_close(dbeta, bd.grad, what="bn dbeta", reduced=True)
+    assert_close(dgamma, gd.grad, what="bn dgamma", reduced=True, floor=1e-6 * float(g.abs().sum(0).max()))
+    assert_close(dx, xd.grad, what="bn dx", reduced=True, floor=2e-6 * float(xd.grad.abs().max()))
