@@ -266,7 +266,8 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const unsigned n = F - 1, P = n * (n - 1) / 2, FK = F * K, nK = n * K;
     unsigned short* ptab = reinterpret_cast<unsigned short*>(smem);
-    float* Wl = smem + ptab_floats(P);
+    unsigned short* dtab = reinterpret_cast<unsigned short*>(smem + ptab_floats(P));   // pairs in diagonal order
+    float* Wl = smem + 2 * ptab_floats(P);
     float* wave0 = Wl + (type == kAll ? NV * K * kWS(K) : 0);
     const unsigned lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     float* X = wave0 + wib * NV * 2 * (FK + nK);     // [NV][FK]
@@ -275,6 +276,10 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
     float* dvW = dX + NV * FK;                       // [NV][nK]
 
     build_pair_table<K>(ptab, n);
+    for (unsigned dl = threadIdx.x + 1; dl < n; dl += kThreads) {
+        const unsigned off = (dl - 1) * n - (dl - 1) * dl / 2;      // pairs on the diagonals 1..dl-1
+        for (unsigned i = 0; i + dl < n; ++i) dtab[off + i] = (unsigned short)tri_index(i, i + dl, n);
+    }
     if (type == kAll)
         for (unsigned e = threadIdx.x; e < NV * K * K; e += kThreads) {
             unsigned v = e / (K * K), r = e % (K * K);
@@ -324,19 +329,32 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
             for (unsigned i = lane; i < NV * FK; i += 64) dX[i] = 0.f;
             for (unsigned i = lane; i < NV * nK; i += 64) dvW[i] = 0.f;
             __builtin_amdgcn_wave_barrier();
-            for (unsigned p0 = 0; p0 < P; p0 += PPP) {
-                const unsigned pair = p0 + pl;
-                if (pair < P) {
-                    const unsigned ij = ptab[pair], i = ij & 255u, j = ij >> 8;
-                    const float4 g4 = *reinterpret_cast<const float4*>(gb + (size_t)pair * g_stride + c4 * 4);
+            // pairs are visited diagonal by diagonal ((i, i+delta) for fixed delta: dtab) so that the
+            // PPP pairs of a pass have distinct i AND distinct j -> conflict-free LDS atomics; every pair
+            // row is still one whole 128-byte line.  kU rows are in flight per lane.
+            constexpr unsigned kU = 4;
+            for (unsigned p0 = 0; p0 < P; p0 += PPP * kU) {
+                float4 g4[kU];
+                unsigned pr[kU];
+#pragma unroll
+                for (unsigned u = 0; u < kU; ++u) {
+                    const unsigned q = p0 + u * PPP + pl;
+                    pr[u] = q < P ? dtab[q] : 0xffffu;
+                    g4[u] = pr[u] != 0xffffu ? *reinterpret_cast<const float4*>(gb + (size_t)pr[u] * g_stride + c4 * 4)
+                                             : f4_zero();
+                }
+#pragma unroll
+                for (unsigned u = 0; u < kU; ++u) {
+                    if (pr[u] == 0xffffu) continue;
+                    const unsigned ij = ptab[pr[u]], i = ij & 255u, j = ij >> 8;
                     const float4 xj = *reinterpret_cast<const float4*>(X + v_l * FK + j * K + k0);
                     const float4 vw = *reinterpret_cast<const float4*>(vW + v_l * nK + i * K + k0);
                     float* di = dvW + v_l * nK + i * K + k0;
                     float* dj = dX + v_l * FK + j * K + k0;
-                    lds_add(di + 0, g4.x * xj.x); lds_add(di + 1, g4.y * xj.y);
-                    lds_add(di + 2, g4.z * xj.z); lds_add(di + 3, g4.w * xj.w);
-                    lds_add(dj + 0, g4.x * vw.x); lds_add(dj + 1, g4.y * vw.y);
-                    lds_add(dj + 2, g4.z * vw.z); lds_add(dj + 3, g4.w * vw.w);
+                    lds_add(di + 0, g4[u].x * xj.x); lds_add(di + 1, g4[u].y * xj.y);
+                    lds_add(di + 2, g4[u].z * xj.z); lds_add(di + 3, g4[u].w * xj.w);
+                    lds_add(dj + 0, g4[u].x * vw.x); lds_add(dj + 1, g4[u].y * vw.y);
+                    lds_add(dj + 2, g4[u].z * vw.z); lds_add(dj + 3, g4[u].w * vw.w);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -490,7 +508,7 @@ inline int grid_for(int B) {
 }
 inline size_t bi_smem(int F, int K, int nv, int type, bool bwd) {
     const unsigned n = F - 1, P = n * (n - 1) / 2;
-    size_t fl = ptab_floats(P) + (type == kAll ? (size_t)nv * K * (K + 1) : 0);
+    size_t fl = (bwd ? 2 : 1) * (size_t)ptab_floats(P) + (type == kAll ? (size_t)nv * K * (K + 1) : 0);
     fl += (size_t)kWaves * nv * (bwd ? 2 : 1) * ((size_t)F * K + (size_t)n * K);
     return fl * sizeof(float);
 }

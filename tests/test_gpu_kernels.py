@@ -307,7 +307,7 @@ def test_mlp_glue_relu_bwd_bias_and_batchnorm(dev, rows, C):
     y = torch.relu(torch.randn(rows, C, generator=gen))
     dbias = torch.empty(C, device=dev)
     g2 = ops.relu_bwd_bias_(g.to(dev), y.to(dev), dbias)
-    ref = g.double() * (y.double() > 0)
+    ref = torch.where(y > 0, g, torch.zeros_like(g)).double()
     assert_bit_exact(g2, ref.float(), "relu mask")
     assert_close(dbias, ref.sum(0), what="dbias", reduced=True)
     g3 = ops.relu_bwd_bias_(g.to(dev), None, dbias)
