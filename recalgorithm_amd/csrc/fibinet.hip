@@ -173,7 +173,7 @@ struct BiSets {
 
 template <int K>
 __device__ __forceinline__ void build_pair_table(unsigned short* ptab, unsigned n) {
-    for (unsigned i = threadIdx.x; i + 1 < n; i += kThreads)
+    for (unsigned i = threadIdx.x; i + 1 < n; i += blockDim.x)
         for (unsigned j = i + 1; j < n; ++j) ptab[tri_index(i, j, n)] = (unsigned short)(i | (j << 8));
 }
 
@@ -262,26 +262,25 @@ __global__ __launch_bounds__(kThreads) void bilinear_fwd_kernel(BiSets a, unsign
 template <int K, int NV>
 __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsigned B, unsigned F, int type,
                                                                 const float* __restrict__ g, unsigned g_stride,
-                                                                unsigned g_col, float* __restrict__ dvw_ws) {
+                                                                unsigned g_col, float* __restrict__ dvw_ws,
+                                                                int stage_g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const unsigned n = F - 1, P = n * (n - 1) / 2, FK = F * K, nK = n * K;
     unsigned short* ptab = reinterpret_cast<unsigned short*>(smem);
-    unsigned short* dtab = reinterpret_cast<unsigned short*>(smem + ptab_floats(P));   // pairs in diagonal order
-    float* Wl = smem + 2 * ptab_floats(P);
+    float* Wl = smem + ptab_floats(P);
     float* wave0 = Wl + (type == kAll ? NV * K * kWS(K) : 0);
     const unsigned lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    float* X = wave0 + wib * NV * 2 * (FK + nK);     // [NV][FK]
+    const unsigned nwaves = blockDim.x >> 6;         // waves per workgroup (LDS budget decides, <= kWaves)
+    const unsigned per_wave = NV * 2 * (FK + nK) + (stage_g ? P * NV * K : 0);
+    float* X = wave0 + wib * per_wave;               // [NV][FK]
     float* vW = X + NV * FK;                         // [NV][nK]
     float* dX = vW + NV * nK;                        // [NV][FK]
     float* dvW = dX + NV * FK;                       // [NV][nK]
+    float* gL = stage_g ? dvW + NV * nK : nullptr;   // [P][NV*K] gradient tile of the current example
 
     build_pair_table<K>(ptab, n);
-    for (unsigned dl = threadIdx.x + 1; dl < n; dl += kThreads) {
-        const unsigned off = (dl - 1) * n - (dl - 1) * dl / 2;      // pairs on the diagonals 1..dl-1
-        for (unsigned i = 0; i + dl < n; ++i) dtab[off + i] = (unsigned short)tri_index(i, i + dl, n);
-    }
     if (type == kAll)
-        for (unsigned e = threadIdx.x; e < NV * K * K; e += kThreads) {
+        for (unsigned e = threadIdx.x; e < NV * K * K; e += blockDim.x) {
             unsigned v = e / (K * K), r = e % (K * K);
             Wl[v * K * kWS(K) + (r / K) * kWS(K) + (r % K)] = a.w[v][r];
         }
@@ -293,7 +292,7 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
     const unsigned pl = lane / C4, c4 = lane % C4;
     const unsigned v_l = (c4 * 4) / K, k0 = (c4 * 4) % K;
 
-    for (unsigned b = blockIdx.x * kWaves + wib; b < B; b += gridDim.x * kWaves) {
+    for (unsigned b = blockIdx.x * nwaves + wib; b < B; b += gridDim.x * nwaves) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const float4* xr = reinterpret_cast<const float4*>(a.x[v] + (size_t)b * FK);
@@ -322,45 +321,56 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
                 }
             __builtin_amdgcn_wave_barrier();
             // dvW[i][k'] = sum_{j>i} g[(i,j)][k'] x_j[k'] ;  dX[j][k'] = sum_{i<j} g[(i,j)][k'] vW[i][k'].
-            // One pass over g in pair order (the forward's write pattern: PPP pairs x whole 128-byte rows
-            // per wave instruction, float4 per lane); both sums are scattered with LDS atomics
-            // (ds_add_f32) — consecutive pairs share i, so the dvW adds of a pass collide on up to PPP
-            // lanes per address, the dX adds (distinct j) do not.
-            for (unsigned i = lane; i < NV * FK; i += 64) dX[i] = 0.f;
-            for (unsigned i = lane; i < NV * nK; i += 64) dvW[i] = 0.f;
-            __builtin_amdgcn_wave_barrier();
-            // pairs are visited diagonal by diagonal ((i, i+delta) for fixed delta: dtab) so that the
-            // PPP pairs of a pass have distinct i AND distinct j -> conflict-free LDS atomics; every pair
-            // row is still one whole 128-byte line.  kU rows are in flight per lane.
-            constexpr unsigned kU = 4;
-            for (unsigned p0 = 0; p0 < P; p0 += PPP * kU) {
-                float4 g4[kU];
-                unsigned pr[kU];
-#pragma unroll
-                for (unsigned u = 0; u < kU; ++u) {
-                    const unsigned q = p0 + u * PPP + pl;
-                    pr[u] = q < P ? dtab[q] : 0xffffu;
-                    g4[u] = pr[u] != 0xffffu ? *reinterpret_cast<const float4*>(gb + (size_t)pr[u] * g_stride + c4 * 4)
-                                             : f4_zero();
+            // Every g element is needed twice (once per sum) along two different walks of the pair
+            // triangle.  Fast path: the example's whole gradient tile [P][NV*K] (38.4 KB at F=26, K=16)
+            // is staged in LDS with whole-row float4 loads (the forward's write pattern), and both sums
+            // are then lane-owned loops over conflict-free ds_read_b32 (lane = column c of one row;
+            // LDS float atomics were measured 2x slower than even the direct-from-global walk below).
+            constexpr unsigned NVK = NV * K;
+            if (gL) {
+                float4* gL4 = reinterpret_cast<float4*>(gL);
+                for (unsigned p0 = 0; p0 < P; p0 += PPP) {
+                    const unsigned pair = p0 + pl;
+                    if (pair < P)
+                        gL4[pair * C4 + c4] = *reinterpret_cast<const float4*>(gb + (size_t)pair * g_stride + c4 * 4);
                 }
+                __builtin_amdgcn_wave_barrier();
+                for (unsigned idx = lane; idx < F * NVK; idx += 64) {
+                    const unsigned r = idx / NVK, c = idx % NVK, v = c / K, kk = c % K;
+                    const float* Xv = X + v * FK + kk;
+                    const float* vWv = vW + v * nK + kk;
+                    float s1 = 0.f, s2 = 0.f;
+                    if (r < n) {
+                        const float* gp = gL + tri_index(r, r + 1, n) * NVK + c;            // pairs (r, r+1..)
+                        for (unsigned j = r + 1; j < n; ++j, gp += NVK) s1 = fmaf(gp[0], Xv[j * K], s1);
+                        for (unsigned i = 0; i < r; ++i) s2 = fmaf(gL[tri_index(i, r, n) * NVK + c], vWv[i * K], s2);
+                        dvW[v * nK + r * K + kk] = s1;
+                        dvw_ws[((size_t)v * B + b) * nK + r * K + kk] = s1;
+                    }
+                    dX[v * FK + r * K + kk] = s2;
+                }
+            } else {
 #pragma unroll
-                for (unsigned u = 0; u < kU; ++u) {
-                    if (pr[u] == 0xffffu) continue;
-                    const unsigned ij = ptab[pr[u]], i = ij & 255u, j = ij >> 8;
-                    const float4 xj = *reinterpret_cast<const float4*>(X + v_l * FK + j * K + k0);
-                    const float4 vw = *reinterpret_cast<const float4*>(vW + v_l * nK + i * K + k0);
-                    float* di = dvW + v_l * nK + i * K + k0;
-                    float* dj = dX + v_l * FK + j * K + k0;
-                    lds_add(di + 0, g4[u].x * xj.x); lds_add(di + 1, g4[u].y * xj.y);
-                    lds_add(di + 2, g4[u].z * xj.z); lds_add(di + 3, g4[u].w * xj.w);
-                    lds_add(dj + 0, g4[u].x * vw.x); lds_add(dj + 1, g4[u].y * vw.y);
-                    lds_add(dj + 2, g4[u].z * vw.z); lds_add(dj + 3, g4[u].w * vw.w);
+                for (int v = 0; v < NV; ++v) {
+                    const float* gv = gb + v * K;
+                    const float* Xv = X + v * FK;
+                    const float* vWv = vW + v * nK;
+                    for (unsigned idx = lane; idx < FK; idx += 64) {
+                        const unsigned r = idx / K, kk = idx % K;
+                        float s1 = 0.f, s2 = 0.f;
+                        if (r < n) {
+                            const float* gp = gv + (size_t)tri_index(r, r + 1, n) * g_stride + kk;
+                            for (unsigned j = r + 1; j < n; ++j, gp += g_stride) s1 = fmaf(gp[0], Xv[j * K + kk], s1);
+                            for (unsigned i = 0; i < r; ++i)
+                                s2 = fmaf(gv[(size_t)tri_index(i, r, n) * g_stride + kk], vWv[i * K + kk], s2);
+                            dvW[v * nK + idx] = s1;
+                            dvw_ws[((size_t)v * B + b) * nK + idx] = s1;
+                        }
+                        dX[v * FK + idx] = s2;
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int v = 0; v < NV; ++v)
-                for (unsigned idx = lane; idx < nK; idx += 64) dvw_ws[((size_t)v * B + b) * nK + idx] = dvW[v * nK + idx];
             // dX[i][k] += sum_k' dvW[i][k'] W[k][k']
 #pragma unroll
             for (int v = 0; v < NV; ++v)
@@ -508,7 +518,7 @@ inline int grid_for(int B) {
 }
 inline size_t bi_smem(int F, int K, int nv, int type, bool bwd) {
     const unsigned n = F - 1, P = n * (n - 1) / 2;
-    size_t fl = (bwd ? 2 : 1) * (size_t)ptab_floats(P) + (type == kAll ? (size_t)nv * K * (K + 1) : 0);
+    size_t fl = (size_t)ptab_floats(P) + (type == kAll ? (size_t)nv * K * (K + 1) : 0);
     fl += (size_t)kWaves * nv * (bwd ? 2 : 1) * ((size_t)F * K + (size_t)n * K);
     return fl * sizeof(float);
 }
@@ -549,10 +559,27 @@ int launch_bi_fwd(const BiSets& a, int B, int F, int type, float* out, int out_s
 template <int K, int NV>
 int launch_bi_bwd(const BiSets& a, int B, int F, int type, const float* g, int g_stride, int g_col, float* dvw,
                   hipStream_t st) {
-    const size_t smem = bi_smem(F, K, NV, type, true);
+    // LDS budget decides the waves per workgroup and whether the per-example gradient tile is staged
+    const unsigned n = F - 1, P = n * (n - 1) / 2;
+    const size_t shared = ((size_t)ptab_floats(P) + (type == kAll ? (size_t)NV * K * (K + 1) : 0)) * sizeof(float);
+    const size_t base = (size_t)NV * 2 * ((size_t)F * K + (size_t)n * K) * sizeof(float);
+    const size_t tile = (size_t)P * NV * K * sizeof(float);
+    const size_t budget = 160 * 1024;
+    int stage = 0, wpb = 0;
+    if (type != kInteraction && shared + base + tile <= budget) {
+        stage = 1;
+        wpb = (int)((budget - shared) / (base + tile));
+    } else if (shared + base <= budget) {
+        wpb = (int)((budget - shared) / base);
+    }
+    if (wpb < 1) return (int)hipErrorInvalidValue;
+    if (wpb > kWaves) wpb = kWaves;
+    const size_t smem = shared + (size_t)wpb * (base + (stage ? tile : 0));
     ENSURE_SMEM((bilinear_bwd_kernel<K, NV>), smem);
-    hipLaunchKernelGGL((bilinear_bwd_kernel<K, NV>), dim3(grid_for(B)), dim3(kThreads), smem, st, a, (unsigned)B,
-                       (unsigned)F, type, g, (unsigned)g_stride, (unsigned)g_col, dvw);
+    int grid = cdiv(B, wpb);
+    if (grid > kMaxBlocks) grid = kMaxBlocks;
+    hipLaunchKernelGGL((bilinear_bwd_kernel<K, NV>), dim3(grid), dim3(64 * wpb), smem, st, a, (unsigned)B,
+                       (unsigned)F, type, g, (unsigned)g_stride, (unsigned)g_col, dvw, stage);
     return (int)hipGetLastError();
 }
 template <int K>

@@ -62,7 +62,16 @@ __global__ __launch_bounds__(256) void adam_tf1_kernel(float* __restrict__ p, fl
     float4* m4 = reinterpret_cast<float4*>(m);
     float4* v4 = reinterpret_cast<float4*>(v);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-        float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+        float4 gg = g4[i];
+        float4 mm = m4[i], vv = v4[i];
+        // Exact shortcut of the dense update: where g, m and v are all zero (embedding rows no batch
+        // has touched yet), m' = v' = 0 and p' = p - lr_t*0/(0+eps) = p — nothing to read or write.
+        // TF1's dense semantics are kept bit for bit; only the traffic of inert words is skipped
+        // (12 instead of 28 bytes per parameter).
+        const bool inert = gg.x == 0.f && gg.y == 0.f && gg.z == 0.f && gg.w == 0.f && mm.x == 0.f && mm.y == 0.f &&
+                           mm.z == 0.f && mm.w == 0.f && vv.x == 0.f && vv.y == 0.f && vv.z == 0.f && vv.w == 0.f;
+        if (inert) continue;
+        float4 pp = p4[i];
         adam1(pp.x, gg.x, mm.x, vv.x, lr_t, b1, b2, eps);
         adam1(pp.y, gg.y, mm.y, vv.y, lr_t, b1, b2, eps);
         adam1(pp.z, gg.z, mm.z, vv.z, lr_t, b1, b2, eps);

@@ -5,6 +5,7 @@ the all_to_alls, owner-side HIP gather / scatter-add, staged arena, identity ids
 kernel on staged rows, gradient push, dense all-reduce hook — runs, and its result must equal the
 plain single-GPU step.  (N = 2 is covered on CPU/gloo by tests/test_dist_gloo.py.)"""
 import os
+import re
 import socket
 
 import pytest
@@ -78,6 +79,8 @@ def test_sharded_single_rank_equals_plain(dev, pg, model):
     for k in a0:
         if "embedding_weights" in k or "kernel/" in k:
             continue
+        if re.search(r"/dense(_\d+)?/bias$", k) and any(n.startswith(k.rsplit("/", 2)[0] + "/batch_normalization") for n in a0):
+            continue    # a bias ahead of a training-mode BatchNorm: zero gradient analytically, its Adam step is rounding noise
         assert_close(a1[k], a0[k], rtol=1e-4, what=f"{model} {k} after 3 steps", reduced=True)
     for name, ar in ref.store.arenas.items():
         full = unshard_arena(shd.store.arenas[name], "weight")
