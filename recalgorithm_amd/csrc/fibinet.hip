@@ -43,9 +43,28 @@ __device__ __forceinline__ float4 f4_mul(float4 a, float4 b) {
 // =============================================================================================
 // SENET
 // =============================================================================================
-// per-wave LDS: X[F*K] | z[F] | h[Rd] | a[F] | (bwd) dap[F] | dhp[Rd]
+// per-wave LDS: X[F*K] | z[F] | h[Rd] | a[F] | (bwd) dap[F] | dhp[Rd] | Gv[F*K]
 __device__ __forceinline__ unsigned senet_wave_floats(unsigned F, unsigned K, unsigned Rd) {
-    return ((F * K + 3 * F + 2 * Rd) + 3) & ~3u;
+    return ((2 * F * K + 3 * F + 2 * Rd) + 3) & ~3u;
+}
+
+// global -> LDS row copy with the loads of 4 iterations in flight (a plain load/store loop waits
+// for the HBM latency once per iteration)
+__device__ __forceinline__ void copy_row(float* __restrict__ dst, const float* __restrict__ src, unsigned n,
+                                         unsigned lane) {
+    for (unsigned i0 = 0; i0 < n; i0 += 256) {
+        float t[4];
+#pragma unroll
+        for (unsigned u = 0; u < 4; ++u) {
+            const unsigned i = i0 + u * 64 + lane;
+            t[u] = i < n ? src[i] : 0.f;
+        }
+#pragma unroll
+        for (unsigned u = 0; u < 4; ++u) {
+            const unsigned i = i0 + u * 64 + lane;
+            if (i < n) dst[i] = t[u];
+        }
+    }
 }
 
 // z, h, a of one example from X (already in LDS); all lanes must call
@@ -75,7 +94,7 @@ __device__ __forceinline__ void senet_squeeze_excite(const float* X, float* z, f
 }
 
 __global__ __launch_bounds__(kThreads) void senet_fwd_kernel(
-    const float* __restrict__ emb, const float* __restrict__ w1, const float* __restrict__ w2, unsigned B,
+    const float* __restrict__ emb, const float* w1, const float* w2, unsigned B,
     unsigned F, unsigned K, unsigned Rd, float* __restrict__ v_out, float* __restrict__ a_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const unsigned lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -84,9 +103,17 @@ __global__ __launch_bounds__(kThreads) void senet_fwd_kernel(
     float* z = X + FK;
     float* h = z + F;
     float* a = h + Rd;
+    float* w1s = smem + kWaves * senet_wave_floats(F, K, Rd);      // [F][Rd] | [Rd][F], staged once
+    float* w2s = w1s + F * Rd;
+    for (unsigned i = threadIdx.x; i < F * Rd; i += kThreads) {
+        w1s[i] = w1[i];
+        w2s[i] = w2[i];
+    }
+    __syncthreads();
+    w1 = w1s;
+    w2 = w2s;
     for (unsigned b = blockIdx.x * kWaves + wib; b < B; b += gridDim.x * kWaves) {
-        const float* er = emb + (size_t)b * FK;
-        for (unsigned i = lane; i < FK; i += 64) X[i] = er[i];
+        copy_row(X, emb + (size_t)b * FK, FK, lane);
         __builtin_amdgcn_wave_barrier();
         senet_squeeze_excite(X, z, h, a, w1, w2, F, K, Rd, lane);
         float* vr = v_out + (size_t)b * FK;
@@ -99,7 +126,7 @@ __global__ __launch_bounds__(kThreads) void senet_fwd_kernel(
 
 // backward; per-wave gradient accumulators for (w1, w2) live in LDS across the wave's examples
 __global__ __launch_bounds__(kThreads) void senet_bwd_kernel(
-    const float* __restrict__ emb, const float* __restrict__ w1, const float* __restrict__ w2,
+    const float* __restrict__ emb, const float* w1, const float* w2,
     const float* __restrict__ g_v, unsigned B, unsigned F, unsigned K, unsigned Rd,
     float* __restrict__ d_emb, int accumulate, float* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -112,13 +139,23 @@ __global__ __launch_bounds__(kThreads) void senet_bwd_kernel(
     float* a = h + Rd;
     float* dap = a + F;
     float* dhp = dap + F;
+    float* Gv = dhp + Rd;                                    // upstream gradient row [F*K]
     float* acc = smem + kWaves * wf + wib * 2 * WR;          // [dw1 (F,Rd) | dw2 (Rd,F)]
+    float* w1s = smem + kWaves * wf + kWaves * 2 * WR;       // [F][Rd] | [Rd][F], staged once
+    float* w2s = w1s + WR;
+    for (unsigned i = threadIdx.x; i < WR; i += kThreads) {
+        w1s[i] = w1[i];
+        w2s[i] = w2[i];
+    }
     for (unsigned i = lane; i < 2 * WR; i += 64) acc[i] = 0.f;
+    __syncthreads();
+    w1 = w1s;
+    w2 = w2s;
     const float invK = 1.0f / (float)K;
     for (unsigned b = blockIdx.x * kWaves + wib; b < B; b += gridDim.x * kWaves) {
-        const float* er = emb + (size_t)b * FK;
-        const float* gr = g_v + (size_t)b * FK;
-        for (unsigned i = lane; i < FK; i += 64) X[i] = er[i];
+        copy_row(X, emb + (size_t)b * FK, FK, lane);
+        copy_row(Gv, g_v + (size_t)b * FK, FK, lane);
+        const float* gr = Gv;
         __builtin_amdgcn_wave_barrier();
         senet_squeeze_excite(X, z, h, a, w1, w2, F, K, Rd, lane);
         // da_f = sum_k gV[f,k] E[f,k], through relu
@@ -329,10 +366,22 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
             constexpr unsigned NVK = NV * K;
             if (gL) {
                 float4* gL4 = reinterpret_cast<float4*>(gL);
-                for (unsigned p0 = 0; p0 < P; p0 += PPP) {
-                    const unsigned pair = p0 + pl;
-                    if (pair < P)
-                        gL4[pair * C4 + c4] = *reinterpret_cast<const float4*>(gb + (size_t)pair * g_stride + c4 * 4);
+                // kU whole rows per lane are requested before the first is parked in LDS: a
+                // load -> wait -> ds_write loop would pay the full HBM latency once per row
+                constexpr unsigned kU = 16;
+                for (unsigned p0 = 0; p0 < P; p0 += PPP * kU) {
+                    float4 t[kU];
+#pragma unroll
+                    for (unsigned u = 0; u < kU; ++u) {
+                        const unsigned pair = p0 + u * PPP + pl;
+                        t[u] = pair < P ? *reinterpret_cast<const float4*>(gb + (size_t)pair * g_stride + c4 * 4)
+                                        : f4_zero();
+                    }
+#pragma unroll
+                    for (unsigned u = 0; u < kU; ++u) {
+                        const unsigned pair = p0 + u * PPP + pl;
+                        if (pair < P) gL4[pair * C4 + c4] = t[u];
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
                 for (unsigned idx = lane; idx < F * NVK; idx += 64) {
@@ -609,7 +658,8 @@ RECALGO_EXPORT int recalgo_senet_fwd(const float* emb, const float* w1, const fl
                                      int reduction_dim, float* v_out, float* a_out, recalgo_stream_t stream) {
     RECALGO_REQUIRE(B >= 0 && F > 0 && K > 0 && reduction_dim > 0 && reduction_dim < K);
     if (B == 0) return 0;
-    const size_t smem = (size_t)kWaves * (((size_t)F * K + 3 * F + 2 * reduction_dim + 3) & ~(size_t)3) * sizeof(float);
+    const size_t smem = ((size_t)kWaves * ((2 * (size_t)F * K + 3 * F + 2 * reduction_dim + 3) & ~(size_t)3) +
+                         2 * (size_t)F * reduction_dim) * sizeof(float);
     ENSURE_SMEM(senet_fwd_kernel, smem);
     hipLaunchKernelGGL(senet_fwd_kernel, dim3(grid_for(B)), dim3(kThreads), smem, as_stream(stream), emb, w1, w2,
                        (unsigned)B, (unsigned)F, (unsigned)K, (unsigned)reduction_dim, v_out, a_out);
@@ -626,8 +676,8 @@ RECALGO_EXPORT int recalgo_senet_bwd(const float* emb, const float* w1, const fl
                                      float* dw2, void* workspace, recalgo_stream_t stream) {
     RECALGO_REQUIRE(B > 0 && F > 0 && K > 0 && reduction_dim > 0 && reduction_dim < K && workspace != nullptr);
     const unsigned WR = (unsigned)F * reduction_dim;
-    const size_t smem = ((size_t)kWaves * (((size_t)F * K + 3 * F + 2 * reduction_dim + 3) & ~(size_t)3) +
-                         (size_t)kWaves * 2 * WR) * sizeof(float);
+    const size_t smem = ((size_t)kWaves * ((2 * (size_t)F * K + 3 * F + 2 * reduction_dim + 3) & ~(size_t)3) +
+                         (size_t)kWaves * 2 * WR + 2 * (size_t)WR) * sizeof(float);
     ENSURE_SMEM(senet_bwd_kernel, smem);
     const int grid = grid_for(B) > 256 ? 256 : grid_for(B);        // persistent: one partial row per workgroup
     float* partials = static_cast<float*>(workspace);

@@ -48,7 +48,19 @@ __global__ __launch_bounds__(kThreads) void ipnn_features_fwd_kernel(const float
     __syncthreads();
     for (unsigned b = blockIdx.x * kWaves + wib; b < B; b += gridDim.x * kWaves) {
         const float* er = emb + (size_t)b * FK;
-        for (unsigned i = lane; i < FK; i += 64) X[(i / K) * KS + (i % K)] = er[i];
+        for (unsigned i0 = 0; i0 < FK; i0 += 256) {           // 4 loads in flight per lane, then the LDS stores
+            float t[4];
+#pragma unroll
+            for (unsigned u = 0; u < 4; ++u) {
+                const unsigned i = i0 + u * 64 + lane;
+                t[u] = i < FK ? er[i] : 0.f;
+            }
+#pragma unroll
+            for (unsigned u = 0; u < 4; ++u) {
+                const unsigned i = i0 + u * 64 + lane;
+                if (i < FK) X[(i / K) * KS + (i % K)] = t[u];
+            }
+        }
         __builtin_amdgcn_wave_barrier();
         float* pr = phi + (size_t)b * T;
         for (unsigned t = lane; t < T; t += 64) {
@@ -76,8 +88,19 @@ __global__ __launch_bounds__(kThreads) void ipnn_features_bwd_kernel(const float
     for (unsigned b = blockIdx.x * kWaves + wib; b < B; b += gridDim.x * kWaves) {
         const float* er = emb + (size_t)b * FK;
         const float* pr = dphi + (size_t)b * T;
-        for (unsigned i = lane; i < FK; i += 64) X[i] = er[i];
-        for (unsigned t = lane; t < T; t += 64) dP[t] = pr[t];
+        for (unsigned i0 = 0; i0 < FK + T; i0 += 256) {       // X and dP are adjacent in LDS: one batched copy
+            float t[4];
+#pragma unroll
+            for (unsigned u = 0; u < 4; ++u) {
+                const unsigned i = i0 + u * 64 + lane;
+                t[u] = i < FK ? er[i] : (i < FK + T ? pr[i - FK] : 0.f);
+            }
+#pragma unroll
+            for (unsigned u = 0; u < 4; ++u) {
+                const unsigned i = i0 + u * 64 + lane;
+                if (i < FK + T) X[i] = t[u];
+            }
+        }
         __builtin_amdgcn_wave_barrier();
         float* dr = d_emb + (size_t)b * FK;
         for (unsigned i = lane; i < FK; i += 64) {
