@@ -61,6 +61,13 @@ def _make(model, dev):
     est = Estimator(fn, params, RunConfig(device=dev, seed=9, use_hip_graph=False))
     feats, labels, _ = synth.device_features(spec, 192, dev)
     est.build(feats, labels)
+    # DIN's alpha = 1 makes dice/prelu the identity and the fcn stack affine: whole families of
+    # gradients (biases and BN offsets ahead of the next BatchNorm) then vanish analytically and their
+    # Adam steps are rounding noise — move alpha away so that every parameter has a real gradient
+    g = torch.Generator().manual_seed(99)
+    for name, v in est.store.vars.items():
+        if "alpha" in name:
+            v.data.copy_((0.25 + 0.5 * torch.rand(v.data.shape, generator=g)).to(dev))
     return est, feats, labels
 
 
