@@ -44,6 +44,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-tunable", dest="tunable", action="store_false",
                     help="keep hipBLASLt's default fp32 GEMM selection for the context MLP (default: PyTorch "
                          "TunableOp picks the GEMM kernels during warm-up; selections are frozen before timing)")
+    ap.add_argument("--capacity-factor", type=float, default=2.0,
+                    help="N > 1: bucket capacity of the static id/row exchange, in units of the mean bucket size")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -344,12 +346,11 @@ def main():
         tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"recalgo_tunableop_{rank}.csv"))
     est, spec, feats, labels, workload = build_estimator(args, device, rank, world)
     if world > 1:
-        # row-shard the embedding arenas over the ranks, all-reduce the dense gradients; the id /
-        # row all_to_all has data-dependent split sizes, so N > 1 steps are launched eagerly
+        # row-shard the embedding arenas over the ranks (fixed-capacity id / row all_to_all over
+        # RCCL: static shapes, no host sync -> the N-GPU step is still one hipGraph), all-reduce the
+        # flat dense gradient, back-propagate loss / N
         from recalgorithm_amd.parallel import attach_data_parallel
-        attach_data_parallel(est, dist)
-        args.no_graph = True
-
+        attach_data_parallel(est, dist, capacity_factor=args.capacity_factor)
     from recalgorithm_amd.estimator import GraphedTrainStep
     from recalgorithm_amd.io import synth
     # distinct synthetic batches, all resident in HBM before the timed region; step i consumes
@@ -358,12 +359,22 @@ def main():
     batches = [(feats, labels)] + [
         synth.device_features(spec, args.batch, device, batch_index=rank + world * (1 + i))[:2]
         for i in range(args.data_batches - 1)]
-    if args.no_graph:
+    launch = "eager"
+    graphed = None
+    if not args.no_graph:
+        try:
+            graphed = GraphedTrainStep(est.train_step, feats, labels, warmup=3)
+            launch = "hipGraph replay"
+        except Exception as e:      # e.g. a collective that cannot be captured: run the same step eagerly
+            if rank == 0:
+                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches",
+                      file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+    if graphed is None:
         step = lambda i: est.train_step(*batches[i % len(batches)])
         for i in range(max(args.warmup, 1)):
             loss = step(i)
     else:
-        graphed = GraphedTrainStep(est.train_step, feats, labels, warmup=3)
         step = lambda i: graphed(*batches[i % len(batches)])
         for i in range(max(args.warmup - 3, 0)):
             step(i)
@@ -386,6 +397,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     loss_v = float(loss)
+    if world > 1:
+        from recalgorithm_amd.parallel import exchange_overflowed
+        ovf = torch.tensor([1.0 if exchange_overflowed(est) else 0.0], device=device)
+        dist.all_reduce(ovf)
+        if float(ovf) > 0:
+            raise SystemExit("bench.py: an id/row exchange bucket overflowed its capacity: the run is invalid; "
+                             "rerun with a larger --capacity-factor")
 
     # fwd+bwd only (optimizer excluded), reported next to the headline
     out = {
@@ -404,7 +422,7 @@ def main():
         "config": {"workload": workload, "data_batches": args.data_batches, "global_batch": world * args.batch, "fields": args.fields,
                    "emb_dim": args.emb, "embedding_rows": int(sum(spec.vocabs)),
                    "optimizer": "TF1 Adam, dense over all tables (reference semantics)",
-                   "launch": "eager" if args.no_graph else "hipGraph replay",
+                   "launch": launch,
                    "gemm_selection": "TunableOp" if args.tunable else "hipBLASLt default",
                    "parallelism": (f"dp{world} + embedding rows sharded r % {world} (RCCL all_to_all), dense grads all-reduced"
                                    if world > 1 else "single")},

@@ -391,8 +391,15 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
                     float s1 = 0.f, s2 = 0.f;
                     if (r < n) {
                         const float* gp = gL + tri_index(r, r + 1, n) * NVK + c;            // pairs (r, r+1..)
+#pragma unroll 8
                         for (unsigned j = r + 1; j < n; ++j, gp += NVK) s1 = fmaf(gp[0], Xv[j * K], s1);
-                        for (unsigned i = 0; i < r; ++i) s2 = fmaf(gL[tri_index(i, r, n) * NVK + c], vWv[i * K], s2);
+                        // pair (i, r) sits at tri(i, r) = tri(i-1, r) + (n - i - 1): walk it incrementally
+                        unsigned t = r - 1;                                                  // tri_index(0, r, n)
+#pragma unroll 8
+                        for (unsigned i = 0; i < r; ++i) {
+                            s2 = fmaf(gL[t * NVK + c], vWv[i * K], s2);
+                            t += n - i - 2;
+                        }
                         dvW[v * nK + r * K + kk] = s1;
                         dvw_ws[((size_t)v * B + b) * nK + r * K + kk] = s1;
                     }

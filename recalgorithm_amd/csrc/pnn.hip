@@ -68,6 +68,7 @@ __global__ __launch_bounds__(kThreads) void ipnn_features_fwd_kernel(const float
             const float* xr = X + r * KS;
             const float* xc = X + c * KS;
             float acc = 0.f;
+#pragma unroll 8
             for (unsigned k = 0; k < K; ++k) acc = fmaf(xr[k], xc[k], acc);
             pr[t] = acc;
         }
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(kThreads) void ipnn_features_bwd_kernel(const float
         for (unsigned i = lane; i < FK; i += 64) {
             const unsigned f = i / K, k = i % K;
             float acc = 0.f;
+#pragma unroll 8
             for (unsigned c = 0; c < F; ++c) {
                 const unsigned t = c >= f ? tri_t(f, c, F) : tri_t(c, f, F);
                 const float w = c == f ? 2.f * dP[t] : dP[t];

@@ -19,6 +19,15 @@ Per step and arena lookup (`ExchangePlan`)
      gather) run on the staged arena with identity ids;
   4. backward: the kernels scatter into the staged gradient, which is all_to_all'ed back to the
      owners and scatter-added into the shard's gradient (HIP kernel).
+Two exchange plans implement steps 1-4:
+  * `ExchangePlan`: exact bucket sizes (data-dependent all_to_all splits -> one small host sync per
+    lookup; steps must be launched eagerly);
+  * `StaticExchangePlan` (default under `attach_data_parallel`): every (source, owner) bucket has a
+    fixed capacity of `capacity_factor` x the mean bucket size, unused slots carry id -1 / zero
+    rows.  All shapes are static and nothing is read back to the host, so the whole N-GPU step is
+    hipGraph-capturable; a device-side flag records a bucket overflow (the step's result is then
+    invalid and the caller re-plans with a larger factor).  With Zipf ids the largest bucket stays
+    below 1.5x the mean (each field's hottest row holds ~7 % of its ids); the default factor is 2.
 On the 8-GPU xGMI full mesh every peer pair has its own link, so the all_to_all is link-parallel
 (≈0.85 MB per link per direction at B_local=4096, F=26, K=16); the dense all-reduce (≈1.5 MB) is
 latency-bound.  Each rank back-propagates loss_rank / N, so SUM collectives yield the gradient
@@ -86,6 +95,52 @@ class ExchangePlan:
         local_scatter_add(shard_grad, self.recv_local, grecv)
 
 
+class StaticExchangePlan:
+    """Fixed-capacity variant of ExchangePlan: same interface, static shapes, no host sync."""
+
+    def __init__(self, rows: torch.Tensor, sh: ShardSpec, capacity: int, overflow: torch.Tensor):
+        self.sh, self.M = sh, rows.numel()
+        W, M, cap, dev = sh.world, rows.numel(), int(capacity), rows.device
+        self.cap = cap
+        valid = rows >= 0
+        owner = torch.where(valid, rows % W, torch.full_like(rows, W))           # invalid -> sentinel bucket W
+        order = torch.argsort(owner, stable=True)
+        so = owner[order]
+        counts = torch.zeros(W + 1, dtype=torch.int64, device=dev).scatter_add_(0, owner, torch.ones_like(owner))
+        start = torch.cumsum(counts, 0) - counts
+        slot = torch.arange(M, device=dev, dtype=torch.int64) - start[so]
+        keep = (so < W) & (slot < cap)
+        overflow.logical_or_(((so < W) & (slot >= cap)).any().reshape(1))
+        dummy = W * cap
+        dest = torch.where(keep, so * cap + slot, torch.full_like(so, dummy))
+        send_local = torch.full((W * cap + 1,), -1, dtype=torch.int64, device=dev)
+        send_local.scatter_(0, dest, torch.div(rows[order], W, rounding_mode="floor"))
+        send_local[dummy] = -1
+        pos = torch.full((W * cap + 1,), M, dtype=torch.int64, device=dev)       # request slot of every buffer entry
+        pos.scatter_(0, dest, order)
+        pos[dummy] = M
+        self.send_pos = pos[:W * cap].contiguous()                               # M = "nobody": a dummy row
+        self.recv_local = torch.empty(W * cap, dtype=torch.int64, device=dev)
+        sh.dist.all_to_all_single(self.recv_local, send_local[:W * cap].contiguous(), group=sh.group)
+
+    def fetch(self, shard_weight: torch.Tensor, local_gather) -> torch.Tensor:
+        K = shard_weight.shape[1]
+        rows_out = local_gather(shard_weight, self.recv_local)                   # id -1 -> zero row
+        back = torch.empty_like(rows_out)
+        self.sh.dist.all_to_all_single(back, rows_out, group=self.sh.group)
+        out = torch.zeros(self.M + 1, K, dtype=shard_weight.dtype, device=shard_weight.device)
+        out.index_copy_(0, self.send_pos, back)
+        return out[:self.M]
+
+    def push_grad(self, staged_grad: torch.Tensor, shard_grad: torch.Tensor, local_scatter_add) -> None:
+        K = staged_grad.shape[1]
+        ext = torch.cat([staged_grad, staged_grad.new_zeros(1, K)], 0)
+        gsend = ext.index_select(0, self.send_pos)
+        grecv = torch.empty_like(gsend)
+        self.sh.dist.all_to_all_single(grecv, gsend, group=self.sh.group)
+        local_scatter_add(shard_grad, self.recv_local, grecv)                    # id -1 is skipped
+
+
 # ---- the two local kernels of the exchange (HIP; tests substitute CPU doubles) ------------------
 def hip_local_gather(shard_weight: torch.Tensor, local_rows: torch.Tensor) -> torch.Tensor:
     import ctypes
@@ -121,12 +176,25 @@ class Sharding:
     r % world == rank (at local index r // world)."""
 
     def __init__(self, sh: ShardSpec, global_rows: int, local_gather=hip_local_gather,
-                 local_scatter_add=hip_local_scatter_add):
+                 local_scatter_add=hip_local_scatter_add, capacity_factor: Optional[float] = None):
         self.sh, self.global_rows = sh, int(global_rows)
         self.local_gather, self.local_scatter_add = local_gather, local_scatter_add
+        self.capacity_factor = capacity_factor          # None: exact (dynamic) buckets
+        self.overflow: Optional[torch.Tensor] = None    # device flag, sticky
 
-    def plan(self, rows: torch.Tensor) -> ExchangePlan:
-        return ExchangePlan(rows, self.sh)
+    def capacity(self, M: int) -> int:
+        W = self.sh.world
+        if W == 1:
+            return max(M, 1)
+        c = int(-(-M * self.capacity_factor // W))
+        return min(max((c + 7) // 8 * 8, 8), max(M, 1))
+
+    def plan(self, rows: torch.Tensor):
+        if self.capacity_factor is None:
+            return ExchangePlan(rows, self.sh)
+        if self.overflow is None:
+            self.overflow = torch.zeros(1, dtype=torch.bool, device=rows.device)
+        return StaticExchangePlan(rows, self.sh, self.capacity(rows.numel()), self.overflow)
 
 
 class StagedArena:
@@ -172,7 +240,7 @@ def identity_ids(rows: torch.Tensor, shape) -> torch.Tensor:
 
 
 def shard_arena_(arena: EmbeddingArena, sh: ShardSpec, local_gather=hip_local_gather,
-                 local_scatter_add=hip_local_scatter_add) -> None:
+                 local_scatter_add=hip_local_scatter_add, capacity_factor: Optional[float] = None) -> None:
     """Re-shard a fully materialised (replicated-at-init) arena in place: keep rows r % N == rank.
     Every rank must have built the same arena (same seed) — that is what makes N ranks == 1 rank."""
     if getattr(arena, "sharding", None) is not None:
@@ -180,7 +248,7 @@ def shard_arena_(arena: EmbeddingArena, sh: ShardSpec, local_gather=hip_local_ga
     rows = arena.weight.shape[0]
     take = lambda t: t[sh.rank::sh.world].contiguous().clone()
     arena.weight, arena.grad, arena.m, arena.v = take(arena.weight), take(arena.grad), take(arena.m), take(arena.v)
-    arena.sharding = Sharding(sh, rows, local_gather, local_scatter_add)
+    arena.sharding = Sharding(sh, rows, local_gather, local_scatter_add, capacity_factor)
 
 
 def unshard_arena(arena: EmbeddingArena, what: str = "weight") -> torch.Tensor:
@@ -201,9 +269,10 @@ def unshard_arena(arena: EmbeddingArena, what: str = "weight") -> torch.Tensor:
 
 
 def attach_data_parallel(est, dist=None, group=None, local_gather=hip_local_gather,
-                         local_scatter_add=hip_local_scatter_add):
+                         local_scatter_add=hip_local_scatter_add, capacity_factor: Optional[float] = 2.0):
     """Make a built Estimator one rank of an N-rank job: shard every embedding arena row-wise,
-    all-reduce the flat dense gradient before the optimizer, scale the loss gradient by 1/N."""
+    all-reduce the flat dense gradient before the optimizer, scale the loss gradient by 1/N.
+    `capacity_factor` selects the static (graph-capturable) exchange; None = exact dynamic buckets."""
     if dist is None:
         import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -214,7 +283,7 @@ def attach_data_parallel(est, dist=None, group=None, local_gather=hip_local_gath
     if est.store.flat is not None and est.store.flat.numel():
         dist.broadcast(est.store.flat, src=0, group=group)
     for ar in est.store.arenas.values():
-        shard_arena_(ar, sh, local_gather, local_scatter_add)
+        shard_arena_(ar, sh, local_gather, local_scatter_add, capacity_factor)
 
     def grad_hook(store):
         if store.flat_grad is not None and store.flat_grad.numel():
@@ -223,3 +292,9 @@ def attach_data_parallel(est, dist=None, group=None, local_gather=hip_local_gath
     est.loss_grad_scale = 1.0 / world
     est.shard_spec = sh
     return est
+
+
+def exchange_overflowed(est) -> bool:
+    """True if any static exchange bucket overflowed since attach (reads the device flags)."""
+    return any(bool(a.sharding.overflow.item()) for a in est.store.arenas.values()
+               if getattr(a, "sharding", None) is not None and a.sharding.overflow is not None)

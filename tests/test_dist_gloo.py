@@ -23,12 +23,14 @@ def _free_port():
     return p
 
 
-def cpu_gather(shard_weight, local_rows):                     # test double of hip_local_gather
-    return shard_weight.index_select(0, local_rows)
+def cpu_gather(shard_weight, local_rows):                     # test double of hip_local_gather (id < 0 -> zero row)
+    rows = shard_weight.index_select(0, local_rows.clamp(min=0))
+    return torch.where((local_rows >= 0).unsqueeze(1), rows, torch.zeros_like(rows))
 
 
-def cpu_scatter_add(shard_grad, local_rows, g):               # test double of hip_local_scatter_add
-    shard_grad.index_add_(0, local_rows, g)
+def cpu_scatter_add(shard_grad, local_rows, g):               # test double of hip_local_scatter_add (id < 0 skipped)
+    ok = local_rows >= 0
+    shard_grad.index_add_(0, local_rows[ok], g[ok])
 
 
 def _make_arena(K=8, vocabs=(13, 7, 29, 5)):
@@ -72,7 +74,8 @@ def _worker(rank, port, errq):
         store.arenas[ar.name] = ar
         store.pack()
         est = types.SimpleNamespace(_built=True, store=store, grad_hook=None, loss_grad_scale=None)
-        P.attach_data_parallel(est, dist, local_gather=cpu_gather, local_scatter_add=cpu_scatter_add)
+        P.attach_data_parallel(est, dist, local_gather=cpu_gather, local_scatter_add=cpu_scatter_add,
+                               capacity_factor=None)
         w0 = [torch.empty_like(store.flat) for _ in range(WORLD)]
         dist.all_gather(w0, store.flat)
         assert torch.equal(w0[0], w0[1]), "dense variables were not broadcast from rank 0"
@@ -84,10 +87,35 @@ def _worker(rank, port, errq):
 
         # ---- forward: staged rows == table rows (bit exact), zeros for OOV ----
         rows = P.global_rows(ids, rb)
+        expect = torch.where((rows >= 0).unsqueeze(1), W_full[rows.clamp(min=0)], torch.zeros(1, K))
+        # the static (fixed-capacity, graph-capturable) plan must agree with the exact one ...
+        ar.sharding.capacity_factor = 2.0
+        splan = ar.sharding.plan(rows)
+        assert isinstance(splan, P.StaticExchangePlan)
+        sstaged = P.StagedArena(splan, ar)
+        assert torch.equal(sstaged.weight, expect), "static plan: staged rows differ from the table rows"
+        assert not bool(ar.sharding.overflow.item())
+        g_probe = torch.randn(rows.numel(), K, generator=torch.Generator().manual_seed(21 + rank))
+        sstaged.grad.add_(torch.where((rows >= 0).unsqueeze(1), g_probe, torch.zeros(1, K)))
+        sstaged.flush_grad()
+        static_grad = ar.grad.clone()
+        ar.grad.zero_()
+        # ... and a capacity that is too small must raise the overflow flag instead of silently dropping rows
+        ar.sharding.capacity_factor = 0.25
+        ar.sharding.overflow = None
+        P.StagedArena(ar.sharding.plan(rows), ar)
+        flag = ar.sharding.overflow.float()
+        dist.all_reduce(flag)
+        assert float(flag) > 0, "undersized buckets did not raise the overflow flag"
+        ar.sharding.capacity_factor, ar.sharding.overflow = None, None
         plan = ar.sharding.plan(rows)
         staged = P.StagedArena(plan, ar)
-        expect = torch.where((rows >= 0).unsqueeze(1), W_full[rows.clamp(min=0)], torch.zeros(1, K))
         assert torch.equal(staged.weight, expect), "staged rows differ from the table rows"
+        staged.grad.add_(torch.where((rows >= 0).unsqueeze(1), g_probe, torch.zeros(1, K)))
+        staged.flush_grad()
+        assert torch.allclose(ar.grad, static_grad, rtol=1e-6, atol=1e-6), "static and exact plans push different gradients"
+        ar.grad.zero_()
+        staged = P.StagedArena(plan, ar)
         ident = P.identity_ids(rows, ids.shape)
         assert torch.equal(ident.reshape(-1)[rows >= 0], torch.nonzero(rows >= 0).squeeze(1))
         assert bool((ident.reshape(-1)[rows < 0] == -1).all())
