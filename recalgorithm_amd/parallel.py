@@ -114,11 +114,9 @@ class StaticExchangePlan:
         dummy = W * cap
         dest = torch.where(keep, so * cap + slot, torch.full_like(so, dummy))
         send_local = torch.full((W * cap + 1,), -1, dtype=torch.int64, device=dev)
-        send_local.scatter_(0, dest, torch.div(rows[order], W, rounding_mode="floor"))
-        send_local[dummy] = -1
+        send_local.scatter_(0, dest, torch.div(rows[order], W, rounding_mode="floor"))   # slot `dummy` is never read
         pos = torch.full((W * cap + 1,), M, dtype=torch.int64, device=dev)       # request slot of every buffer entry
         pos.scatter_(0, dest, order)
-        pos[dummy] = M
         self.send_pos = pos[:W * cap].contiguous()                               # M = "nobody": a dummy row
         self.recv_local = torch.empty(W * cap, dtype=torch.int64, device=dev)
         sh.dist.all_to_all_single(self.recv_local, send_local[:W * cap].contiguous(), group=sh.group)

@@ -88,10 +88,10 @@ def test_sharded_single_rank_equals_plain(dev, pg, model):
             continue
         if re.search(r"/dense(_\d+)?/bias$", k) and any(n.startswith(k.rsplit("/", 2)[0] + "/batch_normalization") for n in a0):
             continue    # a bias ahead of a training-mode BatchNorm: zero gradient analytically, its Adam step is rounding noise
-        assert_close(a1[k], a0[k], rtol=1e-4, what=f"{model} {k} after 3 steps", reduced=True)
+        assert_close(a1[k], a0[k], rtol=3e-4, what=f"{model} {k} after 3 steps", reduced=True)
     for name, ar in ref.store.arenas.items():
         full = unshard_arena(shd.store.arenas[name], "weight")
-        assert_close(full, ar.weight, rtol=1e-4, what=f"{model} arena {name} after 3 steps", reduced=True)
+        assert_close(full, ar.weight, rtol=3e-4, what=f"{model} arena {name} after 3 steps", reduced=True)
 
 
 def test_static_exchange_step_is_graph_capturable(dev, pg):
