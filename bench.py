@@ -290,13 +290,16 @@ def kernel_rooflines(args, est, feats, device):
         add("pnn_weights_bwd(IPNN)", lambda: lib.recalgo_pnn_weights_bwd(p(th), p(dom), D_, F, K, 0, p(dth), st),
             (2 * D_ * F + T_ * D_) * 4)
     # TF1 dense Adam over the whole arena (state as left by the timed steps; lr = 0 so that the
-    # repeated launches do not move the weights).  Algorithmic bytes: g, m, v are read for every
-    # parameter (12 B); p is read and p, m, v are written (16 B) only where g, m or v is non-zero —
-    # the update is the identity elsewhere (exact shortcut, csrc/tail.hip).
+    # repeated launches do not move the weights).  Algorithmic bytes: g (4 B) of every parameter and
+    # one liveness byte per row are read; m, v, p are read and written (24 B) only for rows some
+    # batch has touched — the dense update is the identity for the others (csrc/tail.hip).
     n = ar.weight.numel()
-    n_live = int(((ar.grad != 0) | (ar.m != 0) | (ar.v != 0)).sum())
-    add("adam_tf1_dense(arena)", lambda: lib.recalgo_adam_tf1_dense(p(ar.weight), p(ar.grad), p(ar.m), p(ar.v), n, 0.0, None,
-                                                                     0.9, 0.999, 1e-8, 1, st), n * 12 + n_live * 16)
+    live = ar.live_rows()
+    n_live = int(live.sum()) * K
+    zero_lr = torch.zeros(1, device=device)
+    add("adam_tf1_rows(arena)", lambda: lib.recalgo_adam_tf1_rows(p(ar.weight), p(ar.grad), p(ar.m), p(ar.v), p(live),
+                                                                  ar.weight.shape[0], K, 0.0, p(zero_lr), 0.9, 0.999, 1e-8, 1, st),
+        n * 4 + ar.weight.shape[0] + n_live * 24)
     res[-1]["live_fraction"] = round(n_live / max(n, 1), 4)
     return res
 

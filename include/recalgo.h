@@ -321,6 +321,15 @@ int recalgo_sigmoid_ce_fwd_bwd(const float* logits, const float* labels, int B, 
 int recalgo_adam_tf1_dense(float* p, float* g, float* m, float* v, int64_t n, float lr_t,
                            const float* lr_t_dev, float beta1, float beta2, float eps, int zero_grad,
                            recalgo_stream_t stream);
+/* The same dense update over an embedding arena [rows, K] (K in {4,8,16,32,64}) with one liveness
+ * byte per row.  A row no batch has touched yet has g = m = v = 0, for which the dense update is
+ * the identity; such rows cost one read of g (to detect the first touch) and of the byte instead
+ * of 28 bytes per parameter.  Bit-identical to recalgo_adam_tf1_dense on the same buffers.
+ * row_live [rows] uint8, in/out; invariant row_live[r] == 0 => m[r,:] == v[r,:] == 0 (start from
+ * zeros with zero moments; after restoring moments set row_live[r] = any(m[r,:] | v[r,:] != 0)). */
+int recalgo_adam_tf1_rows(float* p, float* g, float* m, float* v, unsigned char* row_live, int64_t rows,
+                          int K, float lr_t, const float* lr_t_dev, float beta1, float beta2, float eps,
+                          int zero_grad, recalgo_stream_t stream);
 /* hipGraph-replayable step counter: step_dev[0] += 1; lr_t_dev[0] = lr*sqrt(1-b2^t)/(1-b1^t)
  * (double precision on device).  Pass lr_t_dev to recalgo_adam_tf1_dense to override lr_t. */
 int recalgo_adam_tf1_advance(int64_t* step_dev, float lr, float beta1, float beta2, float* lr_t_dev,

@@ -89,6 +89,43 @@ __global__ __launch_bounds__(256) void adam_tf1_kernel(float* __restrict__ p, fl
     }
 }
 
+// TF1 dense Adam over an embedding arena [rows, K] with a per-row liveness byte.  A row is inert
+// until some batch first touches it (g != 0): until then g = m = v = 0 and the dense update is the
+// identity, so nothing but g (to detect the first touch) and the byte is read.  Bit-identical to
+// adam_tf1_kernel over the same buffers; invariant: live[r] == 0  =>  m[r,:] == v[r,:] == 0.
+// K4 = K/4 lanes own one row (K4 divides 64, so a row never straddles a wave).
+template <int K4>
+__global__ __launch_bounds__(256) void adam_tf1_rows_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                            float* __restrict__ m, float* __restrict__ v,
+                                                            unsigned char* __restrict__ live, int64_t total4,
+                                                            float lr_t_val, const float* __restrict__ lr_t_dev,
+                                                            float b1, float b2, float eps, int zero_grad) {
+    const float lr_t = lr_t_dev ? lr_t_dev[0] : lr_t_val;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    float4* g4 = reinterpret_cast<float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+        const int64_t row = i / K4;
+        float4 gg = g4[i];
+        int nz = (gg.x != 0.f) | (gg.y != 0.f) | (gg.z != 0.f) | (gg.w != 0.f);
+        int any = nz;
+#pragma unroll
+        for (int o = 1; o < K4; o <<= 1) any |= __shfl_xor(any, o, 64);
+        const unsigned char was = live[row];
+        if (!was && !any) continue;                       // inert row: identity update
+        if (!was && (i % K4) == 0) live[row] = 1;
+        float4 mm = m4[i], vv = v4[i], pp = p4[i];
+        adam1(pp.x, gg.x, mm.x, vv.x, lr_t, b1, b2, eps);
+        adam1(pp.y, gg.y, mm.y, vv.y, lr_t, b1, b2, eps);
+        adam1(pp.z, gg.z, mm.z, vv.z, lr_t, b1, b2, eps);
+        adam1(pp.w, gg.w, mm.w, vv.w, lr_t, b1, b2, eps);
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        if (zero_grad && nz) g4[i] = f4_zero();
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // PReLU / Dice (algorithm/DIN/activations.py:4-37), x: [rows, C], alpha: [C].
 // ---------------------------------------------------------------------------------------
@@ -181,6 +218,30 @@ RECALGO_EXPORT int recalgo_adam_tf1_dense(float* p, float* g, float* m, float* v
     int blocks = (int)(want < 1 ? 1 : (want > 256 * 16 ? 256 * 16 : want));
     hipLaunchKernelGGL(adam_tf1_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), p, g, m, v, n4,
                        n, lr_t, lr_t_dev, beta1, beta2, eps, zero_grad);
+    RECALGO_RETURN_LAST();
+}
+
+RECALGO_EXPORT int recalgo_adam_tf1_rows(float* p, float* g, float* m, float* v, unsigned char* row_live,
+                                         int64_t rows, int K, float lr_t, const float* lr_t_dev, float beta1,
+                                         float beta2, float eps, int zero_grad, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(rows >= 0 && row_live != nullptr);
+    RECALGO_REQUIRE(K == 4 || K == 8 || K == 16 || K == 32 || K == 64);
+    if (rows == 0) return 0;
+    const int64_t total4 = rows * (K / 4);
+    int64_t want = (total4 + 255) / 256;
+    int blocks = (int)(want < 1 ? 1 : (want > 256 * 16 ? 256 * 16 : want));
+    hipStream_t st = as_stream(stream);
+#define LAUNCH(KK4)                                                                                       \
+    hipLaunchKernelGGL(adam_tf1_rows_kernel<KK4>, dim3(blocks), dim3(256), 0, st, p, g, m, v, row_live, total4, \
+                       lr_t, lr_t_dev, beta1, beta2, eps, zero_grad)
+    switch (K / 4) {
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        case 4: LAUNCH(4); break;
+        case 8: LAUNCH(8); break;
+        default: LAUNCH(16); break;
+    }
+#undef LAUNCH
     RECALGO_RETURN_LAST();
 }
 

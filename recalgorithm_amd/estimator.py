@@ -93,7 +93,12 @@ class AdamOptimizer:
             ops.adam_tf1_(store.flat, store.flat_grad, store.flat_m, store.flat_v, **kw)
         for ar in store.arenas.values():
             if ar.weight is not None and ar.trainable:
-                ops.adam_tf1_(ar.weight.view(-1), ar.grad.view(-1), ar.m.view(-1), ar.v.view(-1), **kw)
+                if ar.K in (4, 8, 16, 32, 64):
+                    # dense TF1 semantics, rows no batch has touched yet are skipped (identity update)
+                    ops.adam_tf1_rows_(ar.weight, ar.grad, ar.m, ar.v, ar.live_rows(), st["lr_t"],
+                                       self.beta1, self.beta2, self.eps)
+                else:
+                    ops.adam_tf1_(ar.weight.view(-1), ar.grad.view(-1), ar.m.view(-1), ar.v.view(-1), **kw)
 
 
 def get_global_step():
@@ -413,6 +418,7 @@ class Estimator:
             if n in state.get("arena_m", {}) and a.m.shape == state["arena_m"][n].shape:
                 a.m.copy_(state["arena_m"][n])
                 a.v.copy_(state["arena_v"][n])
+                a.live = None            # rebuilt from the restored moments on next use
         if state.get("opt_step") is not None:
             self.store.opt_state = {
                 "step": torch.tensor([state["opt_step"]], dtype=torch.int64, device=self.device),

@@ -722,6 +722,17 @@ def adam_tf1_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor
         int(zero_grad), _stream(p)), "recalgo_adam_tf1_dense")
 
 
+def adam_tf1_rows_(weight: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torch.Tensor,
+                   row_live: torch.Tensor, lr_t_dev: torch.Tensor, beta1: float = 0.9, beta2: float = 0.999,
+                   eps: float = 1e-8, zero_grad: bool = True) -> None:
+    """TF1 dense Adam over an embedding arena [rows, K] that skips rows no batch has touched yet
+    (exactly the identity for them); row_live [rows] uint8 is maintained by the kernel."""
+    rows, K = weight.shape
+    _lib.check(_lib_().recalgo_adam_tf1_rows(
+        _p(weight), _p(grad), _p(m), _p(v), _p(row_live), rows, K, 0.0, _p(lr_t_dev), beta1, beta2, eps,
+        int(zero_grad), _stream(weight)), "recalgo_adam_tf1_rows")
+
+
 def adam_tf1_advance_(step_dev: torch.Tensor, lr_t_dev: torch.Tensor, lr: float,
                       beta1: float = 0.9, beta2: float = 0.999) -> None:
     """step_dev (int64[1]) += 1; lr_t_dev (float[1]) = lr*sqrt(1-b2^t)/(1-b1^t), on device."""

@@ -246,6 +246,7 @@ def shard_arena_(arena: EmbeddingArena, sh: ShardSpec, local_gather=hip_local_ga
     rows = arena.weight.shape[0]
     take = lambda t: t[sh.rank::sh.world].contiguous().clone()
     arena.weight, arena.grad, arena.m, arena.v = take(arena.weight), take(arena.grad), take(arena.m), take(arena.v)
+    arena.live = None
     arena.sharding = Sharding(sh, rows, local_gather, local_scatter_add, capacity_factor)
 
 

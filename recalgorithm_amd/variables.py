@@ -276,6 +276,7 @@ class EmbeddingArena:
         self.rows = 0
         self._gen = torch.Generator().manual_seed(seed)
         self.weight = self.grad = self.m = self.v = None
+        self.live = None          # uint8 [rows]: row has been touched by a gradient (optimizer bookkeeping)
         self.trainable = True
 
     def add_table(self, name: str, vocab: int, init: Optional[torch.Tensor] = None) -> int:
@@ -309,3 +310,10 @@ class EmbeddingArena:
     def table_view(self, name: str) -> torch.Tensor:
         rb, vocab = self.tables[name]
         return self.weight[rb:rb + vocab]
+
+    def live_rows(self) -> torch.Tensor:
+        """uint8 [rows], 1 where the row's Adam moments may be non-zero (maintained by
+        recalgo_adam_tf1_rows; rebuilt from the moments after a restore)."""
+        if self.live is None or self.live.shape[0] != self.weight.shape[0]:
+            self.live = ((self.m != 0) | (self.v != 0)).any(dim=1).to(torch.uint8)
+        return self.live
