@@ -560,10 +560,16 @@ RECALGO_EXPORT int recalgo_din_attention_bwd(const float* query, const float* ke
     const int o_b1 = 4 * H * N1, o_w2 = o_b1 + N1, o_b2 = o_w2 + N1 * N2, o_w3 = o_b2 + N2, o_b3 = o_w3 + N2;
     const Seg segs[6] = {{d_f1_w, 0, o_b1}, {d_f1_b, o_b1, N1}, {d_f2_w, o_w2, N1 * N2},
                          {d_f2_b, o_b2, N2}, {d_f3_w, o_w3, N2}, {d_f3_b, o_b3, 1}};
-    for (int sgi = 0; sgi < 6; ++sgi) {
-        const Seg& sg = segs[sgi];
-        hipLaunchKernelGGL(din_sum_partials_kernel, dim3(cdiv(sg.n, 64)), dim3(256), 0, st, partials + sg.off,
-                           (unsigned)grid, (unsigned)pf, (unsigned)sg.n, sg.dst);
+    bool contiguous = true;                       // the six outputs laid out like the partial row (flat gradient buffer)?
+    for (int sgi = 1; sgi < 6; ++sgi) contiguous = contiguous && segs[sgi].dst == d_f1_w + segs[sgi].off;
+    if (contiguous) {
+        launch_colsum16(partials, (unsigned)grid, (unsigned)pf, d_f1_w, (unsigned)pf, static_cast<float*>(nullptr), st);
+    } else {
+        for (int sgi = 0; sgi < 6; ++sgi) {
+            const Seg& sg = segs[sgi];
+            hipLaunchKernelGGL(din_sum_partials_kernel, dim3(cdiv(sg.n, 64)), dim3(256), 0, st, partials + sg.off,
+                               (unsigned)grid, (unsigned)pf, (unsigned)sg.n, sg.dst);
+        }
     }
     RECALGO_RETURN_LAST();
 }
