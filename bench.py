@@ -444,6 +444,17 @@ def main():
                 out["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"],
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": None,
                                    "avg_us": dom["avg_us"], "alg_bytes_per_launch": dom["alg_bytes"]}
+            # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this
+            # round (FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled per
+            # guides/MI355X_MICROARCH.md: gfx950 counts a wide coalesced read at half its bytes)
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                    t = json.load(f).get(args.model, {}).get(dom["kernel"])
+                if t:
+                    out["roofline"]["traffic"] = int(2 * t["fetch_size_kb"] * 1024 + t["write_size_kb"] * 1024)
+                    out["roofline"]["traffic_source"] = t["source"]
+            except (OSError, ValueError, KeyError):
+                pass
             out["kernels"] = ks
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)

@@ -34,12 +34,12 @@ def main(args):
                 if k and c and v not in (None, ""):
                     acc[k][c].append(float(v))
     counters = sorted({c for k in acc for c in acc[k]})
-    print("| kernel | dispatches | " + " | ".join(f"avg {c}" for c in counters) + " |")
-    print("|---|---:|" + "---:|" * len(counters))
+    print("| kernel | dispatches | " + " | ".join(f"avg {c} | max {c}" for c in counters) + " |")
+    print("|---|---:|" + "---:|---:|" * len(counters))
     for k in sorted(acc, key=lambda k: -sum(sum(v) for v in acc[k].values())):
         n = max(len(v) for v in acc[k].values())
         name = k if len(k) < 100 else k[:97] + "..."
-        cells = [f"{sum(acc[k][c]) / len(acc[k][c]):.1f}" if acc[k].get(c) else "" for c in counters]
+        cells = [f"{sum(acc[k][c]) / len(acc[k][c]):.1f} | {max(acc[k][c]):.1f}" if acc[k].get(c) else " | " for c in counters]
         print(f"| `{name}` | {n} | " + " | ".join(cells) + " |")
 
 
