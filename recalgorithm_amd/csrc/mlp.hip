@@ -17,7 +17,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kRowsPerBlk = 32;
+constexpr int kRowsPerBlk = 8;        // 512 workgroups at B = 4096: every CU streams
 
 __device__ __forceinline__ float4 f4_sub(float4 a, float4 b) {
     return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);

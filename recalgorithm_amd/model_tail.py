@@ -34,11 +34,13 @@ def finish_model_fn(mode, logit: torch.Tensor, labels, params,
         extra = extra_loss()
         if extra is not None:
             loss = loss + extra
-    acc = metrics.accuracy(labels=y, predictions=(prob >= 0.5).to(torch.float32))
-    auc = metrics.auc(labels=y, predictions=prob)
     if mode == ModeKeys.EVAL:
+        acc = metrics.accuracy(labels=y, predictions=(prob >= 0.5).to(torch.float32))
+        auc = metrics.auc(labels=y, predictions=prob)
         return EstimatorSpec(mode, loss=loss, eval_metric_ops={"eval_accuracy": acc, "eval_auc": auc})
 
+    # TRAIN: the reference also builds the two metric ops here, but only to feed tf.summary /
+    # LoggingTensorHook (deepfm.py:237-238,256-271); they are not part of the training step
     assert mode == ModeKeys.TRAIN
     optimizer = AdamOptimizer(learning_rate=params["learning_rate"], beta1=0.9, beta2=0.999, epsilon=1e-8)
     train_op = optimizer.minimize(loss=loss)
