@@ -130,7 +130,7 @@ def event_time_ms(fn, reps=20, replays=10):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
         for _ in range(reps):
             fn()
     g.replay()

@@ -208,7 +208,9 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: HIP calls of OTHER threads (the RCCL watchdog of torch.distributed polls events)
+        # must not be treated as capture violations while this thread captures
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out = step_fn(features, labels)
         self.warmup_steps = warmup
 
