@@ -58,7 +58,7 @@ def test_deepfm_from_tfrecord_batch512(dev, tmp_path):
     # the Estimator drivers over the file: train (eager + hipGraph + eager for the partial batch), evaluate, predict
     est2 = Estimator(deepfm_model_fn, params, RunConfig(device=dev, seed=11))
     est2.train(lambda: train_input_fn(path, example_parser, B, num_epochs=2, shuffle_buffer_size=0), log_every=0)
-    assert est2.global_step == 6
+    assert est2.global_step == 5        # repeat(2) THEN batch(512): 2400 records -> 4 full batches + one of 352 (utils.py:20-21)
     metrics = est2.evaluate(lambda: eval_input_fn(path, example_parser, B))
     assert set(metrics) >= {"eval_accuracy", "eval_auc", "loss", "global_step"} and 0.0 <= metrics["eval_auc"] <= 1.0
     preds = list(est2.predict(lambda: eval_input_fn(path, example_parser, B)))
