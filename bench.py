@@ -289,18 +289,18 @@ def kernel_rooflines(args, est, feats, device):
         add("pnn_weights_fwd(IPNN)", lambda: lib.recalgo_pnn_weights_fwd(p(th), D_, F, K, 0, p(om), st), (D_ * F + T_ * D_) * 4)
         add("pnn_weights_bwd(IPNN)", lambda: lib.recalgo_pnn_weights_bwd(p(th), p(dom), D_, F, K, 0, p(dth), st),
             (2 * D_ * F + T_ * D_) * 4)
-    # TF1 dense Adam over the whole arena (state as left by the timed steps; lr = 0 so that the
-    # repeated launches do not move the weights).  Algorithmic bytes: g (4 B) of every parameter and
-    # one liveness byte per row are read; m, v, p are read and written (24 B) only for rows some
-    # batch has touched — the dense update is the identity for the others (csrc/tail.hip).
+    # TF1 dense Adam over the arena (state as left by the timed steps; lr = 0 so that the repeated
+    # launches do not move the weights): the update visits the live-row list only — rows no
+    # gradient has ever reached have g = m = v = 0, for which the dense update is the identity.
+    # Algorithmic bytes: 28 B per parameter of a live row (g, m, v, p in; p, m, v out) + 4 B per list entry.
     n = ar.weight.numel()
-    live = ar.live_rows()
-    n_live = int(live.sum()) * K
+    _, lst, cnt = ar.live_state()
+    n_rows_live = int(cnt.item())
     zero_lr = torch.zeros(1, device=device)
-    add("adam_tf1_rows(arena)", lambda: lib.recalgo_adam_tf1_rows(p(ar.weight), p(ar.grad), p(ar.m), p(ar.v), p(live),
+    add("adam_tf1_list(arena)", lambda: lib.recalgo_adam_tf1_list(p(ar.weight), p(ar.grad), p(ar.m), p(ar.v), p(lst), p(cnt),
                                                                   ar.weight.shape[0], K, 0.0, p(zero_lr), 0.9, 0.999, 1e-8, 1, st),
-        n * 4 + ar.weight.shape[0] + n_live * 24)
-    res[-1]["live_fraction"] = round(n_live / max(n, 1), 4)
+        n_rows_live * (K * 28 + 4))
+    res[-1]["live_fraction"] = round(n_rows_live * K / max(n, 1), 4)
     return res
 
 
@@ -424,7 +424,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": workload, "data_batches": args.data_batches, "global_batch": world * args.batch, "fields": args.fields,
                    "emb_dim": args.emb, "embedding_rows": int(sum(spec.vocabs)),
-                   "optimizer": "TF1 Adam, dense semantics over all tables (rows never touched are skipped: identity update)",
+                   "optimizer": "TF1 Adam, dense semantics over all tables (only rows a gradient has ever reached are visited: identity update elsewhere)",
                    "launch": launch,
                    "gemm_selection": "TunableOp" if args.tunable else "hipBLASLt default",
                    "parallelism": (f"dp{world} + embedding rows sharded r % {world} (RCCL all_to_all), dense grads all-reduced"

@@ -330,6 +330,19 @@ int recalgo_adam_tf1_dense(float* p, float* g, float* m, float* v, int64_t n, fl
 int recalgo_adam_tf1_rows(float* p, float* g, float* m, float* v, unsigned char* row_live, int64_t rows,
                           int K, float lr_t, const float* lr_t_dev, float beta1, float beta2, float eps,
                           int zero_grad, recalgo_stream_t stream);
+/* Live-row list (optimizer cost proportional to the rows a model has touched, dense
+ * TF1 semantics kept exactly).  recalgo_mark_live_rows visits the ids of one lookup
+ * (row = ids[i] + row_base[i % F], id < 0 skipped; row_base may be NULL with F = 1) and appends every
+ * row whose liveness byte was 0 to live_list, bumping live_count[0] (device int).  Call it for each
+ * lookup whose gradient is scattered into the arena.  row_live must be 4-byte aligned and padded to
+ * a multiple of 4 bytes.  recalgo_adam_tf1_list applies the dense update to the listed rows only: for
+ * all other rows g = m = v = 0 and the update is the identity.  The launch is sized by max_rows, the
+ * count is read on the device (hipGraph replayable). */
+int recalgo_mark_live_rows(const int64_t* ids, const int64_t* row_base, int64_t n, int F,
+                           unsigned char* row_live, int* live_list, int* live_count, recalgo_stream_t stream);
+int recalgo_adam_tf1_list(float* p, float* g, float* m, float* v, const int* live_list,
+                          const int* live_count, int64_t max_rows, int K, float lr_t, const float* lr_t_dev,
+                          float beta1, float beta2, float eps, int zero_grad, recalgo_stream_t stream);
 /* hipGraph-replayable step counter: step_dev[0] += 1; lr_t_dev[0] = lr*sqrt(1-b2^t)/(1-b1^t)
  * (double precision on device).  Pass lr_t_dev to recalgo_adam_tf1_dense to override lr_t. */
 int recalgo_adam_tf1_advance(int64_t* step_dev, float lr, float beta1, float beta2, float* lr_t_dev,

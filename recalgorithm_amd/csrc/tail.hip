@@ -127,6 +127,57 @@ __global__ __launch_bounds__(256) void adam_tf1_rows_kernel(float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------
+// Live-row bookkeeping for embedding arenas (optimizer cost proportional to the
+// rows a model has touched, with TF1's dense semantics kept exactly).
+//   live[r] (one byte per row) == 1 and r is in list[0 .. count)  <=>  some gradient has reached row r.
+// mark: every valid (b, f) id of a batch is checked; the first toucher of a row (atomicOr on the
+// aligned 32-bit word holding the byte) appends it to the list.  adam_list: the dense TF1 update
+// applied to the listed rows only — all other rows have g = m = v = 0, for which it is the identity.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mark_live_rows_kernel(const int64_t* __restrict__ ids,
+                                                             const int64_t* __restrict__ row_base, int64_t n,
+                                                             unsigned F, unsigned* __restrict__ live_words,
+                                                             int* __restrict__ list, int* __restrict__ count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t id = ids[i];
+    if (id < 0) return;
+    const int64_t row = id + (row_base ? row_base[i % F] : 0);
+    const unsigned bit = 1u << (8 * (unsigned)(row & 3));
+    unsigned* w = live_words + (row >> 2);
+    if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) return;      // common case: already live
+    const unsigned old = atomicOr(w, bit);
+    if (!(old & bit)) list[atomicAdd(count, 1)] = (int)row;
+}
+
+template <int K4>
+__global__ __launch_bounds__(256) void adam_tf1_list_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                            float* __restrict__ m, float* __restrict__ v,
+                                                            const int* __restrict__ list,
+                                                            const int* __restrict__ count, float lr_t_val,
+                                                            const float* __restrict__ lr_t_dev, float b1,
+                                                            float b2, float eps, int zero_grad) {
+    const float lr_t = lr_t_dev ? lr_t_dev[0] : lr_t_val;
+    const int64_t total4 = (int64_t)count[0] * K4;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    float4* g4 = reinterpret_cast<float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total4; t += stride) {
+        const int64_t i = (int64_t)list[t / K4] * K4 + (t % K4);
+        float4 gg = g4[i], mm = m4[i], vv = v4[i], pp = p4[i];
+        const bool nz = gg.x != 0.f || gg.y != 0.f || gg.z != 0.f || gg.w != 0.f;
+        adam1(pp.x, gg.x, mm.x, vv.x, lr_t, b1, b2, eps);
+        adam1(pp.y, gg.y, mm.y, vv.y, lr_t, b1, b2, eps);
+        adam1(pp.z, gg.z, mm.z, vv.z, lr_t, b1, b2, eps);
+        adam1(pp.w, gg.w, mm.w, vv.w, lr_t, b1, b2, eps);
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        if (zero_grad && nz) g4[i] = f4_zero();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // PReLU / Dice (algorithm/DIN/activations.py:4-37), x: [rows, C], alpha: [C].
 // ---------------------------------------------------------------------------------------
 constexpr float kDiceInvStd = 0.99950037468777310f;  // 1/sqrt(1 + 1e-3): BN inference, stats (0,1)
@@ -233,6 +284,42 @@ RECALGO_EXPORT int recalgo_adam_tf1_rows(float* p, float* g, float* m, float* v,
     hipStream_t st = as_stream(stream);
 #define LAUNCH(KK4)                                                                                       \
     hipLaunchKernelGGL(adam_tf1_rows_kernel<KK4>, dim3(blocks), dim3(256), 0, st, p, g, m, v, row_live, total4, \
+                       lr_t, lr_t_dev, beta1, beta2, eps, zero_grad)
+    switch (K / 4) {
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        case 4: LAUNCH(4); break;
+        case 8: LAUNCH(8); break;
+        default: LAUNCH(16); break;
+    }
+#undef LAUNCH
+    RECALGO_RETURN_LAST();
+}
+
+RECALGO_EXPORT int recalgo_mark_live_rows(const int64_t* ids, const int64_t* row_base, int64_t n, int F,
+                                          unsigned char* row_live, int* live_list, int* live_count,
+                                          recalgo_stream_t stream) {
+    RECALGO_REQUIRE(n >= 0 && F >= 1 && row_live != nullptr && live_list != nullptr && live_count != nullptr);
+    RECALGO_REQUIRE((reinterpret_cast<uintptr_t>(row_live) & 3) == 0);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(mark_live_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), ids, row_base, n,
+                       (unsigned)F, reinterpret_cast<unsigned*>(row_live), live_list, live_count);
+    RECALGO_RETURN_LAST();
+}
+
+RECALGO_EXPORT int recalgo_adam_tf1_list(float* p, float* g, float* m, float* v, const int* live_list,
+                                         const int* live_count, int64_t max_rows, int K, float lr_t,
+                                         const float* lr_t_dev, float beta1, float beta2, float eps,
+                                         int zero_grad, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(max_rows >= 0 && live_list != nullptr && live_count != nullptr);
+    RECALGO_REQUIRE(K == 4 || K == 8 || K == 16 || K == 32 || K == 64);
+    if (max_rows == 0) return 0;
+    // the launch is sized for the largest possible list (graph replayable); surplus workgroups exit at once
+    int64_t want = (max_rows * (K / 4) + 255) / 256;
+    int blocks = (int)(want < 1 ? 1 : (want > 256 * 8 ? 256 * 8 : want));
+    hipStream_t st = as_stream(stream);
+#define LAUNCH(KK4)                                                                                         \
+    hipLaunchKernelGGL(adam_tf1_list_kernel<KK4>, dim3(blocks), dim3(256), 0, st, p, g, m, v, live_list, live_count, \
                        lr_t, lr_t_dev, beta1, beta2, eps, zero_grad)
     switch (K / 4) {
         case 1: LAUNCH(1); break;

@@ -93,10 +93,10 @@ class AdamOptimizer:
             ops.adam_tf1_(store.flat, store.flat_grad, store.flat_m, store.flat_v, **kw)
         for ar in store.arenas.values():
             if ar.weight is not None and ar.trainable:
-                if ar.K in (4, 8, 16, 32, 64):
-                    # dense TF1 semantics, rows no batch has touched yet are skipped (identity update)
-                    ops.adam_tf1_rows_(ar.weight, ar.grad, ar.m, ar.v, ar.live_rows(), st["lr_t"],
-                                       self.beta1, self.beta2, self.eps)
+                if ar.tracks_live_rows:
+                    # dense TF1 semantics; only rows a gradient has ever reached are visited (the
+                    # update is the identity for the others)
+                    ops.adam_tf1_list_(ar, st["lr_t"], self.beta1, self.beta2, self.eps)
                 else:
                     ops.adam_tf1_(ar.weight.view(-1), ar.grad.view(-1), ar.m.view(-1), ar.v.view(-1), **kw)
 

@@ -46,12 +46,34 @@ def _chk(t: torch.Tensor, dtype, name: str):
 _ws_cache = {}
 
 
+_rb1_cache = {}
+
+
+def arena_row_base(arena, table_name: str, device) -> torch.Tensor:
+    """int64 [1] device tensor holding the first arena row of `table_name` (cached)."""
+    key = (id(arena), table_name)
+    t = _rb1_cache.get(key)
+    if t is None:
+        t = torch.tensor([arena.tables[table_name][0]], dtype=torch.int64, device=device)
+        _rb1_cache[key] = t
+    return t
+
+
 def _flush(arena) -> None:
     """Row-sharded deployment (parallel.py): the kernel scattered into a staged gradient; send it
     to the rows' owners now."""
     f = getattr(arena, "flush_grad", None)
     if f is not None:
         f()
+
+
+def mark_live_rows(arena, ids: torch.Tensor, row_base: Optional[torch.Tensor], F: int) -> None:
+    """Record the rows a scatter has just touched in the arena's live-row list (first touch only)."""
+    if not getattr(arena, "tracks_live_rows", False):
+        return
+    live, lst, cnt = arena.live_state()
+    _lib.check(_lib_().recalgo_mark_live_rows(_p(ids), _p(row_base), ids.numel(), int(F), _p(live), _p(lst), _p(cnt),
+                                              _stream(ids)), "recalgo_mark_live_rows")
 
 
 def _staged(arena, rows: torch.Tensor):
@@ -97,6 +119,7 @@ class _GatherFn(Function):
         _lib.check(_lib_().recalgo_embedding_gather_bwd(
             _p(ids), _p(g), _p(ctx.row_base), B, F, arena.K, F * arena.K, 0, _p(arena.grad),
             _stream(ids)), "recalgo_embedding_gather_bwd")
+        mark_live_rows(arena, ids, ctx.row_base, F)
         _flush(arena)
         return None, None, None, None
 
@@ -136,6 +159,7 @@ class _BagMeanFn(Function):
         _lib.check(_lib_().recalgo_embedding_bag_mean_bwd(
             _p(values), _p(offsets), _p(g), B, arena.K, arena.K, 0, _p(gt), _stream(offsets)),
             "recalgo_embedding_bag_mean_bwd")
+        mark_live_rows(arena, values, arena_row_base(arena, table_name, values.device), 1)
         _flush(arena)
         return None, None, None, None, None
 
@@ -175,6 +199,7 @@ class _SeqGatherFn(Function):
         _lib.check(_lib_().recalgo_sequence_gather_bwd(
             _p(values), _p(offsets), _p(g), B, T, arena.K, _p(gt), _stream(offsets)),
             "recalgo_sequence_gather_bwd")
+        mark_live_rows(arena, values, arena_row_base(arena, table_name, values.device), 1)
         _flush(arena)
         return None, None, None, None, None, None
 
@@ -217,6 +242,7 @@ class _DeepFMSparseFn(Function):
         _lib.check(_lib_().recalgo_deepfm_sparse_bwd(
             _p(ids), _p(emb), _p(fsum), _p(g_emb), _p(g_fm1), _p(g_fm2), _p(row_base), B, F, arena.K,
             _p(arena.grad), _p(w1.grad), _stream(ids)), "recalgo_deepfm_sparse_bwd")
+        mark_live_rows(arena, ids, row_base, F)
         _flush(arena)
         _flush(w1)
         torch.sum(g_fm1, dim=0, out=bias.grad.view(1))
@@ -731,6 +757,17 @@ def adam_tf1_rows_(weight: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v:
     _lib.check(_lib_().recalgo_adam_tf1_rows(
         _p(weight), _p(grad), _p(m), _p(v), _p(row_live), rows, K, 0.0, _p(lr_t_dev), beta1, beta2, eps,
         int(zero_grad), _stream(weight)), "recalgo_adam_tf1_rows")
+
+
+def adam_tf1_list_(arena, lr_t_dev: torch.Tensor, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                   zero_grad: bool = True) -> None:
+    """TF1 dense Adam applied to the arena's live rows only (identity elsewhere: bit-identical to
+    the dense pass)."""
+    _, lst, cnt = arena.live_state()
+    rows, K = arena.weight.shape
+    _lib.check(_lib_().recalgo_adam_tf1_list(
+        _p(arena.weight), _p(arena.grad), _p(arena.m), _p(arena.v), _p(lst), _p(cnt), rows, K, 0.0, _p(lr_t_dev),
+        beta1, beta2, eps, int(zero_grad), _stream(arena.weight)), "recalgo_adam_tf1_list")
 
 
 def adam_tf1_advance_(step_dev: torch.Tensor, lr_t_dev: torch.Tensor, lr: float,

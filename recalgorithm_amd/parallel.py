@@ -86,13 +86,13 @@ class ExchangePlan:
         out.index_copy_(0, self.send_pos, back)
         return out
 
-    def push_grad(self, staged_grad: torch.Tensor, shard_grad: torch.Tensor, local_scatter_add) -> None:
-        """shard_grad[owner rows] += staged_grad rows (duplicates accumulate on the owner)."""
+    def push_grad(self, staged_grad: torch.Tensor, arena, local_scatter_add) -> None:
+        """arena.grad[owner rows] += staged_grad rows (duplicates accumulate on the owner)."""
         K = staged_grad.shape[1]
         gsend = staged_grad.index_select(0, self.send_pos)
         grecv = torch.empty(sum(self.rc), K, dtype=staged_grad.dtype, device=staged_grad.device)
         self.sh.all_to_all(grecv, gsend, [c for c in self.rc], [c for c in self.sc])
-        local_scatter_add(shard_grad, self.recv_local, grecv)
+        local_scatter_add(arena, self.recv_local, grecv)
 
 
 class StaticExchangePlan:
@@ -130,13 +130,13 @@ class StaticExchangePlan:
         out.index_copy_(0, self.send_pos, back)
         return out[:self.M]
 
-    def push_grad(self, staged_grad: torch.Tensor, shard_grad: torch.Tensor, local_scatter_add) -> None:
+    def push_grad(self, staged_grad: torch.Tensor, arena, local_scatter_add) -> None:
         K = staged_grad.shape[1]
         ext = torch.cat([staged_grad, staged_grad.new_zeros(1, K)], 0)
         gsend = ext.index_select(0, self.send_pos)
         grecv = torch.empty_like(gsend)
         self.sh.dist.all_to_all_single(grecv, gsend, group=self.sh.group)
-        local_scatter_add(shard_grad, self.recv_local, grecv)                    # id -1 is skipped
+        local_scatter_add(arena, self.recv_local, grecv)                         # id -1 is skipped
 
 
 # ---- the two local kernels of the exchange (HIP; tests substitute CPU doubles) ------------------
@@ -155,10 +155,12 @@ def hip_local_gather(shard_weight: torch.Tensor, local_rows: torch.Tensor) -> to
     return out
 
 
-def hip_local_scatter_add(shard_grad: torch.Tensor, local_rows: torch.Tensor, g: torch.Tensor) -> None:
+def hip_local_scatter_add(arena: EmbeddingArena, local_rows: torch.Tensor, g: torch.Tensor) -> None:
+    """arena.grad[local_rows] += g on the owner (id -1 skipped), and the rows join the live-row list."""
     import ctypes
-    from . import _lib
+    from . import _lib, ops
     lib = _lib.load()
+    shard_grad = arena.grad
     n, K = local_rows.numel(), shard_grad.shape[1]
     if n:
         zero = torch.zeros(1, dtype=torch.int64, device=shard_grad.device)
@@ -167,6 +169,7 @@ def hip_local_scatter_add(shard_grad: torch.Tensor, local_rows: torch.Tensor, g:
         g = g.contiguous()
         _lib.check(lib.recalgo_embedding_gather_bwd(p(local_rows), p(g), p(zero), n, 1, K, K, 0, p(shard_grad), st),
                    "recalgo_embedding_gather_bwd")
+        ops.mark_live_rows(arena, local_rows, None, 1)
 
 
 class Sharding:
@@ -221,7 +224,7 @@ class StagedArena:
     def flush_grad(self):
         if self._grad is not None:
             sd: Sharding = self.arena.sharding
-            self.plan.push_grad(self._grad, self.arena.grad, sd.local_scatter_add)
+            self.plan.push_grad(self._grad, self.arena, sd.local_scatter_add)
             self._grad = None
 
 
@@ -246,7 +249,7 @@ def shard_arena_(arena: EmbeddingArena, sh: ShardSpec, local_gather=hip_local_ga
     rows = arena.weight.shape[0]
     take = lambda t: t[sh.rank::sh.world].contiguous().clone()
     arena.weight, arena.grad, arena.m, arena.v = take(arena.weight), take(arena.grad), take(arena.m), take(arena.v)
-    arena.live = None
+    arena.live = None           # live-row bookkeeping is rebuilt for the shard on next use
     arena.sharding = Sharding(sh, rows, local_gather, local_scatter_add, capacity_factor)
 
 

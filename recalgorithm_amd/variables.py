@@ -276,7 +276,8 @@ class EmbeddingArena:
         self.rows = 0
         self._gen = torch.Generator().manual_seed(seed)
         self.weight = self.grad = self.m = self.v = None
-        self.live = None          # uint8 [rows]: row has been touched by a gradient (optimizer bookkeeping)
+        self.live = self.live_list = self.live_count = None   # live-row bookkeeping (see live_state)
+        self._live_rows = -1
         self.trainable = True
 
     def add_table(self, name: str, vocab: int, init: Optional[torch.Tensor] = None) -> int:
@@ -311,9 +312,28 @@ class EmbeddingArena:
         rb, vocab = self.tables[name]
         return self.weight[rb:rb + vocab]
 
+    # -- live-row bookkeeping (optimizer cost proportional to the rows ever touched; see
+    #    include/recalgo.h recalgo_mark_live_rows / recalgo_adam_tf1_list) ---------------------------
+    @property
+    def tracks_live_rows(self) -> bool:
+        return self.K in (4, 8, 16, 32, 64) and self.weight is not None and self.weight.is_cuda
+
+    def live_state(self):
+        """-> (live uint8 [rows padded to 4], live_list int32 [rows], live_count int32 [1]); built
+        lazily, and rebuilt from the Adam moments when the arena was re-sharded or restored."""
+        rows = self.weight.shape[0]
+        if self.live is None or self._live_rows != rows:
+            dev = self.weight.device
+            alive = ((self.m != 0) | (self.v != 0)).any(dim=1)
+            self.live = torch.zeros((rows + 3) // 4 * 4, dtype=torch.uint8, device=dev)
+            self.live[:rows] = alive.to(torch.uint8)
+            idx = torch.nonzero(alive).squeeze(1).to(torch.int32)
+            self.live_list = torch.zeros(max(rows, 1), dtype=torch.int32, device=dev)
+            self.live_list[:idx.numel()] = idx
+            self.live_count = torch.tensor([idx.numel()], dtype=torch.int32, device=dev)
+            self._live_rows = rows
+        return self.live, self.live_list, self.live_count
+
     def live_rows(self) -> torch.Tensor:
-        """uint8 [rows], 1 where the row's Adam moments may be non-zero (maintained by
-        recalgo_adam_tf1_rows; rebuilt from the moments after a restore)."""
-        if self.live is None or self.live.shape[0] != self.weight.shape[0]:
-            self.live = ((self.m != 0) | (self.v != 0)).any(dim=1).to(torch.uint8)
-        return self.live
+        """uint8 [rows]: 1 where a gradient has reached the row."""
+        return self.live_state()[0][:self.weight.shape[0]]

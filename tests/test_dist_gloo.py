@@ -28,9 +28,9 @@ def cpu_gather(shard_weight, local_rows):                     # test double of h
     return torch.where((local_rows >= 0).unsqueeze(1), rows, torch.zeros_like(rows))
 
 
-def cpu_scatter_add(shard_grad, local_rows, g):               # test double of hip_local_scatter_add (id < 0 skipped)
+def cpu_scatter_add(arena, local_rows, g):                    # test double of hip_local_scatter_add (id < 0 skipped)
     ok = local_rows >= 0
-    shard_grad.index_add_(0, local_rows[ok], g[ok])
+    arena.grad.index_add_(0, local_rows[ok], g[ok])
 
 
 def _make_arena(K=8, vocabs=(13, 7, 29, 5)):
