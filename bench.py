@@ -46,6 +46,9 @@ def parse_args(argv=None):
                          "TunableOp picks the GEMM kernels during warm-up; selections are frozen before timing)")
     ap.add_argument("--capacity-factor", type=float, default=2.0,
                     help="N > 1: bucket capacity of the static id/row exchange, in units of the mean bucket size")
+    ap.add_argument("--big-table-rows", type=int, default=0,
+                    help="replace the vocabulary of the last field by a table of this many rows "
+                         "(BASELINE configs[4]: one 100M x 16 table)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -60,6 +63,8 @@ def build_estimator(args, device, rank=0, world=1):
 
     spec = synth.SynthSpec(n_fields=args.fields, max_vocab=args.max_vocab,
                            with_history=(args.model == "din"), history_len=50 if args.model == "din" else None)
+    if args.big_table_rows:
+        spec.vocabs[-1] = int(args.big_table_rows)
     cats = [fc.categorical_column_with_identity(n, v) for n, v in zip(spec.names, spec.vocabs)]
     hidden = ["512", "256", "128"]
     if args.model == "dcn":

@@ -337,7 +337,7 @@ int recalgo_adam_tf1_rows(float* p, float* g, float* m, float* v, unsigned char*
  * lookup whose gradient is scattered into the arena.  row_live must be 4-byte aligned and padded to
  * a multiple of 4 bytes.  recalgo_adam_tf1_list applies the dense update to the listed rows only: for
  * all other rows g = m = v = 0 and the update is the identity.  The launch is sized by max_rows, the
- * count is read on the device (hipGraph replayable). */
+ * count is read on the device (hipGraph replayable).  Any K >= 1 (float4 path for K in {4..64}). */
 int recalgo_mark_live_rows(const int64_t* ids, const int64_t* row_base, int64_t n, int F,
                            unsigned char* row_live, int* live_list, int* live_count, recalgo_stream_t stream);
 int recalgo_adam_tf1_list(float* p, float* g, float* m, float* v, const int* live_list,

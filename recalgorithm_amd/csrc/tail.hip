@@ -296,6 +296,26 @@ RECALGO_EXPORT int recalgo_adam_tf1_rows(float* p, float* g, float* m, float* v,
     RECALGO_RETURN_LAST();
 }
 
+// any row width (e.g. the K = 1 first-order weights of DeepFM): one float per thread
+__global__ __launch_bounds__(256) void adam_tf1_list_scalar_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                                   float* __restrict__ m, float* __restrict__ v,
+                                                                   const int* __restrict__ list,
+                                                                   const int* __restrict__ count, unsigned K,
+                                                                   float lr_t_val, const float* __restrict__ lr_t_dev,
+                                                                   float b1, float b2, float eps, int zero_grad) {
+    const float lr_t = lr_t_dev ? lr_t_dev[0] : lr_t_val;
+    const int64_t total = (int64_t)count[0] * K;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+        const int64_t i = (int64_t)list[t / K] * K + (t % K);
+        float gg = g[i], mm = m[i], vv = v[i], pp = p[i];
+        const bool nz = gg != 0.f;
+        adam1(pp, gg, mm, vv, lr_t, b1, b2, eps);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+        if (zero_grad && nz) g[i] = 0.f;
+    }
+}
+
 RECALGO_EXPORT int recalgo_mark_live_rows(const int64_t* ids, const int64_t* row_base, int64_t n, int F,
                                           unsigned char* row_live, int* live_list, int* live_count,
                                           recalgo_stream_t stream) {
@@ -311,13 +331,19 @@ RECALGO_EXPORT int recalgo_adam_tf1_list(float* p, float* g, float* m, float* v,
                                          const int* live_count, int64_t max_rows, int K, float lr_t,
                                          const float* lr_t_dev, float beta1, float beta2, float eps,
                                          int zero_grad, recalgo_stream_t stream) {
-    RECALGO_REQUIRE(max_rows >= 0 && live_list != nullptr && live_count != nullptr);
-    RECALGO_REQUIRE(K == 4 || K == 8 || K == 16 || K == 32 || K == 64);
+    RECALGO_REQUIRE(max_rows >= 0 && K >= 1 && live_list != nullptr && live_count != nullptr);
     if (max_rows == 0) return 0;
+    hipStream_t st = as_stream(stream);
+    if (!(K == 4 || K == 8 || K == 16 || K == 32 || K == 64)) {
+        int64_t want1 = (max_rows * K + 255) / 256;
+        int blocks1 = (int)(want1 < 1 ? 1 : (want1 > 256 * 8 ? 256 * 8 : want1));
+        hipLaunchKernelGGL(adam_tf1_list_scalar_kernel, dim3(blocks1), dim3(256), 0, st, p, g, m, v, live_list,
+                           live_count, (unsigned)K, lr_t, lr_t_dev, beta1, beta2, eps, zero_grad);
+        RECALGO_RETURN_LAST();
+    }
     // the launch is sized for the largest possible list (graph replayable); surplus workgroups exit at once
     int64_t want = (max_rows * (K / 4) + 255) / 256;
     int blocks = (int)(want < 1 ? 1 : (want > 256 * 8 ? 256 * 8 : want));
-    hipStream_t st = as_stream(stream);
 #define LAUNCH(KK4)                                                                                         \
     hipLaunchKernelGGL(adam_tf1_list_kernel<KK4>, dim3(blocks), dim3(256), 0, st, p, g, m, v, live_list, live_count, \
                        lr_t, lr_t_dev, beta1, beta2, eps, zero_grad)

@@ -45,7 +45,17 @@ def vocab_sizes(n_fields: int = 26, max_vocab: int = 1_000_000) -> List[int]:
 
 
 def zipf_ids(rng: np.random.Generator, n: int, vocab: int, s: float = 1.05) -> np.ndarray:
-    """Truncated Zipf(s) over [0, vocab) by inverse-CDF on the exact pmf."""
+    """Truncated Zipf(s) over [0, vocab) by inverse-CDF on the exact pmf (vocabularies above 2^24:
+    rejection from numpy's unbounded Zipf sampler — the same distribution without a vocab-sized table)."""
+    if vocab > (1 << 24):
+        out = np.empty(n, dtype=np.int64)
+        filled = 0
+        while filled < n:
+            x = rng.zipf(s, size=2 * (n - filled) + 16)
+            x = x[x <= vocab][:n - filled]
+            out[filled:filled + x.size] = x - 1
+            filled += x.size
+        return out
     ranks = np.arange(1, vocab + 1, dtype=np.float64)
     cdf = np.cumsum(ranks ** (-s))
     cdf /= cdf[-1]

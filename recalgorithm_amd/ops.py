@@ -243,6 +243,7 @@ class _DeepFMSparseFn(Function):
             _p(ids), _p(emb), _p(fsum), _p(g_emb), _p(g_fm1), _p(g_fm2), _p(row_base), B, F, arena.K,
             _p(arena.grad), _p(w1.grad), _stream(ids)), "recalgo_deepfm_sparse_bwd")
         mark_live_rows(arena, ids, row_base, F)
+        mark_live_rows(w1, ids, row_base, F)          # the first-order weights share the row layout
         _flush(arena)
         _flush(w1)
         torch.sum(g_fm1, dim=0, out=bias.grad.view(1))

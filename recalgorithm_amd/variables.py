@@ -292,14 +292,29 @@ class EmbeddingArena:
             self._init[name] = init
         return rb
 
+    # tables at least this large are initialised directly in HBM (a 100 M x 16 table is 6.4 GB:
+    # generating it on the host and copying it over would take minutes)
+    DEVICE_INIT_ROWS = 4_000_000
+
     def materialize(self):
         if self.weight is not None:
             return
         K = self.K
-        w = torch.empty(max(self.rows, 1), K)
+        rows = max(self.rows, 1)
+        big = self.rows >= self.DEVICE_INIT_ROWS and self.device.type == "cuda"
+        w = torch.empty(rows, K, device=self.device if big else "cpu")
+        dgen = torch.Generator(device=self.device).manual_seed(self._gen.initial_seed() + 1) if big else None
         for name, (rb, vocab) in self.tables.items():
             if name in self._init:
-                w[rb:rb + vocab] = self._init[name]
+                w[rb:rb + vocab] = self._init[name].to(w.device)
+            elif big:
+                # truncated_normal(0, 1/sqrt(K)) on the device: resample |z| > 2 a few times, then clamp
+                t = torch.randn(vocab, K, device=self.device, generator=dgen)
+                for _ in range(4):
+                    bad = t.abs() > 2
+                    t = torch.where(bad, torch.randn(vocab, K, device=self.device, generator=dgen), t)
+                w[rb:rb + vocab] = t.clamp_(-2, 2).mul_(1.0 / math.sqrt(K))
+                del t
             else:
                 w[rb:rb + vocab] = truncated_normal((vocab, K), 1.0 / math.sqrt(K), self._gen)
         self.weight = w.to(self.device).contiguous()
@@ -316,7 +331,7 @@ class EmbeddingArena:
     #    include/recalgo.h recalgo_mark_live_rows / recalgo_adam_tf1_list) ---------------------------
     @property
     def tracks_live_rows(self) -> bool:
-        return self.K in (4, 8, 16, 32, 64) and self.weight is not None and self.weight.is_cuda
+        return self.weight is not None and self.weight.is_cuda
 
     def live_state(self):
         """-> (live uint8 [rows padded to 4], live_list int32 [rows], live_count int32 [1]); built

@@ -364,7 +364,7 @@ def test_adam_rows_is_bit_identical_to_dense(dev, rows, K):
     assert float(st_b[1].abs().sum()) == 0.0       # gradients consumed
 
 
-@pytest.mark.parametrize("rows,K,F", [(5003, 16, 3), (700, 8, 1), (260, 64, 2)])
+@pytest.mark.parametrize("rows,K,F", [(5003, 16, 3), (700, 8, 1), (260, 64, 2), (1500, 1, 2), (900, 6, 1)])
 def test_live_row_list_adam_is_bit_identical_to_dense(dev, rows, K, F):
     """recalgo_mark_live_rows + recalgo_adam_tf1_list == recalgo_adam_tf1_dense, bit for bit, over
     several steps of sparse row gradients; every touched row enters the list exactly once."""
