@@ -1,0 +1,53 @@
+/* recalgo_host.h — C-ABI of librecalgo_host.so: native host-side data plumbing in front of the
+ * MI355X hot path.  Replaces what the reference obtains from TensorFlow's C++
+ * runtime: tf.data.TFRecordDataset + tf.parse_example (/root/reference algorithm/utils.py:18-24,
+ * algorithm/DeepFM/deepfm.py:102-117) and the vocabulary-file HashTable behind
+ * fc.categorical_column_with_vocabulary_file (deepfm.py:56-64).  Record / Example layout as written
+ * by dataset/wechat_algo_data1/DataGenerator.py:390-447.  Host pointers only; no GPU involved.
+ */
+#ifndef RECALGO_HOST_H_
+#define RECALGO_HOST_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RECALGO_HOST_ABI_VERSION 1
+int recalgo_host_abi_version(void);
+
+/* CRC-32C (Castagnoli) of a buffer, unmasked. */
+uint32_t recalgo_crc32c(const void* data, uint64_t n);
+
+/* Vocabulary file: one key per line, id = 0-based line number (first occurrence wins), absent
+ * key -> -1 (tf: num_oov_buckets=0, default_value=-1).  NULL if the file cannot be read. */
+void* recalgo_vocab_open(const char* path);
+int64_t recalgo_vocab_size(const void* vocab);
+int64_t recalgo_vocab_lookup(const void* vocab, const char* key, uint64_t len);
+void recalgo_vocab_close(void* vocab);
+
+/* TFRecord reader with a batch buffer.  verify_crc != 0 checks both masked crc32c words. */
+void* recalgo_reader_open(const char* path, int verify_crc);
+void recalgo_reader_close(void* reader);
+int recalgo_reader_rewind(void* reader);
+/* dataset.repeat(num_epochs) (< 0: forever) and dataset.shuffle(buffer_size) (0: off; tf.data's
+ * buffer semantics, own seeded generator); call before the first recalgo_reader_next_batch. */
+void recalgo_reader_configure(void* reader, int64_t num_epochs, int64_t shuffle_buffer_size, uint64_t seed);
+const char* recalgo_reader_error(const void* reader);
+/* Read up to max_records records; returns the count (0 = end of file, -1 = error). */
+int64_t recalgo_reader_next_batch(void* reader, int64_t max_records);
+/* Decode one feature of the current batch (tf.parse_example semantics; SequenceExample
+ * feature_lists are not read):
+ *   float:  FixedLenFeature((n,), float32, default) -> out [B, n];  -1 if required and missing
+ *   id:     VarLenFeature(string) looked up in `vocab` -> offsets [B+1], values [nnz]; returns nnz
+ *           (only offsets are written when values_cap < nnz) */
+int recalgo_reader_float_feature(void* reader, const char* key, int n, float default_value, int has_default,
+                                 float* out);
+int64_t recalgo_reader_id_feature(void* reader, const char* key, const void* vocab, int64_t* offsets,
+                                  int64_t* values, int64_t values_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECALGO_HOST_H_ */

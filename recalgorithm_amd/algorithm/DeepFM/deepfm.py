@@ -67,6 +67,9 @@ def example_parser(serialized_example):
     return features, {"read_comment": read_comment}
 
 
+example_parser.columns_getter = lambda: (total_feature_columns, label_feature_columns)   # native decoder hook
+
+
 def _sparse_part(features, params):
     """gather + FM1 + FM2 + deep_input through the fused kernel."""
     store = current_store()

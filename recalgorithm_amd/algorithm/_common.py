@@ -80,6 +80,7 @@ def make_example_parser(columns_getter: Callable[[], Tuple[list, list]]):
         features = parse_example(serialized_example, spec)
         read_comment = features.pop("read_comment")
         return features, {"read_comment": read_comment}
+    example_parser.columns_getter = columns_getter        # lets the input fns use the native decoder
     return example_parser
 
 

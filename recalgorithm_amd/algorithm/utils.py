@@ -80,12 +80,31 @@ class _Dataset:
             yield self.parser(batch)
 
 
-def train_input_fn(filepath, example_parser: Callable, batch_size, num_epochs, shuffle_buffer_size):
+def _dataset(filepath, example_parser, batch_size, num_epochs, shuffle_buffer_size):
+    """The native (C++) reader/decoder serves parsers that declare their feature columns
+    (`example_parser.columns_getter`, set by the model scripts) over a single file; anything else —
+    an arbitrary parser callable, a list of files — takes the pure-Python path.  Both yield the same
+    batches (tests/test_native_reader.py); only the shuffle order differs (different seeded generators)."""
+    import os
+    from ..io import native
+    getter = getattr(example_parser, "columns_getter", None)
+    if getter is not None and isinstance(filepath, str) and native.available() \
+            and os.environ.get("RECALGO_PYTHON_READER", "0") != "1":
+        total, label = getter()
+        try:
+            return native.NativeDataset(filepath, list(total) + list(label), [c.key for c in label], batch_size,
+                                        num_epochs, shuffle_buffer_size)
+        except (ValueError, TypeError):
+            pass                     # e.g. identity columns without a vocabulary file
     return _Dataset(filepath, example_parser, batch_size, num_epochs, shuffle_buffer_size)
 
 
+def train_input_fn(filepath, example_parser: Callable, batch_size, num_epochs, shuffle_buffer_size):
+    return _dataset(filepath, example_parser, batch_size, num_epochs, shuffle_buffer_size)
+
+
 def eval_input_fn(filepath, example_parser: Callable, batch_size):
-    return _Dataset(filepath, example_parser, batch_size, 1, 0)
+    return _dataset(filepath, example_parser, batch_size, 1, 0)
 
 
 def to_sparse_tensor(one_hot_tensor: torch.Tensor):

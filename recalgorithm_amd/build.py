@@ -76,5 +76,25 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+HOST_SRC = os.path.join(HERE, "csrc_host", "tfrecord_reader.cpp")
+HOST_LIB = os.path.join(HERE, "librecalgo_host.so")
+
+
+def build_host(force: bool = False, verbose: bool = True) -> str:
+    """librecalgo_host.so: the native TFRecord / Example / vocabulary plumbing (g++, no GPU code)."""
+    hdr = os.path.join(INCLUDE, "recalgo_host.h")
+    stale = force or not os.path.exists(HOST_LIB) or \
+        os.path.getmtime(HOST_LIB) < max(os.path.getmtime(HOST_SRC), os.path.getmtime(hdr))
+    if stale:
+        cxx = shutil.which("g++") or "g++"
+        cmd = [cxx, "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", f"-I{INCLUDE}",
+               HOST_SRC, "-o", HOST_LIB]
+        if verbose:
+            print("[recalgo build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return HOST_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    print(build_host(force="--force" in sys.argv))

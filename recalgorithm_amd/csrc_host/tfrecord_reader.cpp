@@ -1,0 +1,388 @@
+// Host-side native data plumbing in front of the hot path: TFRecord framing,
+// tf.train.Example decoding and vocabulary-file string -> id lookup, i.e. what the reference gets
+// from TensorFlow's C++ tf.data / parse_example / HashTable kernels
+// (/root/reference algorithm/utils.py:18-24, algorithm/DeepFM/deepfm.py:102-117,56-64;
+//  record format written by dataset/wechat_algo_data1/DataGenerator.py:390-447).
+// Plain C ABI (include/recalgo_host.h), no dependencies, built with g++ into librecalgo_host.so.
+//
+//   record  = uint64 len | uint32 masked_crc32c(len) | bytes | uint32 masked_crc32c(bytes)
+//   Example = {1: Features{1: map<string, Feature{1: BytesList | 2: FloatList | 3: Int64List}>}}
+//   SequenceExample: field 1 (context) is read like Example.features, field 2 (feature_lists) is
+//   skipped — exactly what tf.parse_example does.
+//   vocabulary id = 0-based line number of the key, -1 when absent (A-2).
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/recalgo_host.h"
+
+namespace {
+
+// ---- crc32c (Castagnoli), slicing-by-8 -----------------------------------------------------------
+struct CrcTables {
+    uint32_t t[8][256];
+    CrcTables() {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1) ? 0x82F63B78u : 0u);
+            t[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int s = 1; s < 8; ++s) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xFF];
+    }
+};
+const CrcTables kCrc;
+
+uint32_t crc32c(const uint8_t* p, size_t n) {
+    uint32_t c = 0xFFFFFFFFu;
+    while (n >= 8) {
+        uint32_t lo, hi;
+        memcpy(&lo, p, 4);
+        memcpy(&hi, p + 4, 4);
+        lo ^= c;
+        c = kCrc.t[7][lo & 0xFF] ^ kCrc.t[6][(lo >> 8) & 0xFF] ^ kCrc.t[5][(lo >> 16) & 0xFF] ^ kCrc.t[4][lo >> 24] ^
+            kCrc.t[3][hi & 0xFF] ^ kCrc.t[2][(hi >> 8) & 0xFF] ^ kCrc.t[1][(hi >> 16) & 0xFF] ^ kCrc.t[0][hi >> 24];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) c = kCrc.t[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+uint32_t masked(uint32_t c) { return ((c >> 15) | (c << 17)) + 0xA282EAD8u; }
+
+// ---- protobuf wire helpers -------------------------------------------------------------------------
+struct Span {
+    const uint8_t* p = nullptr;
+    size_t n = 0;
+};
+bool read_varint(const uint8_t*& p, const uint8_t* end, uint64_t& v) {
+    v = 0;
+    for (int shift = 0; p < end && shift < 70; shift += 7) {
+        uint8_t b = *p++;
+        v |= (uint64_t)(b & 0x7F) << shift;
+        if (!(b & 0x80)) return true;
+    }
+    return false;
+}
+// iterate the fields of a message; calls f(field, wire_type, payload_span_or_value)
+template <class Fn>
+bool for_fields(Span s, Fn&& f) {
+    const uint8_t* p = s.p;
+    const uint8_t* end = s.p + s.n;
+    while (p < end) {
+        uint64_t key;
+        if (!read_varint(p, end, key)) return false;
+        const uint32_t field = (uint32_t)(key >> 3), wt = (uint32_t)(key & 7);
+        if (wt == 2) {
+            uint64_t n;
+            if (!read_varint(p, end, n) || n > (uint64_t)(end - p)) return false;
+            f(field, wt, Span{p, (size_t)n}, (uint64_t)0);
+            p += n;
+        } else if (wt == 0) {
+            uint64_t v;
+            if (!read_varint(p, end, v)) return false;
+            f(field, wt, Span{}, v);
+        } else if (wt == 5) {
+            if (end - p < 4) return false;
+            f(field, wt, Span{p, 4}, (uint64_t)0);
+            p += 4;
+        } else if (wt == 1) {
+            if (end - p < 8) return false;
+            f(field, wt, Span{p, 8}, (uint64_t)0);
+            p += 8;
+        } else {
+            return false;
+        }
+    }
+    return true;
+}
+
+struct Vocab {
+    std::string blob;                                      // the file, keys are views into it
+    std::unordered_map<std::string_view, int64_t> map;
+};
+
+struct Reader {
+    FILE* f = nullptr;
+    bool verify = false;
+    int64_t epochs = 1, epoch = 0;                         // dataset.repeat(epochs); epochs < 0: forever
+    size_t shuffle = 0;                                    // dataset.shuffle(buffer_size), 0 = off
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    std::vector<std::string> pool;                         // shuffle buffer
+    bool source_done = false;
+    std::vector<uint8_t> buf;                              // concatenated payloads of the current batch
+    std::vector<size_t> off;                               // record i = buf[off[i] .. off[i+1])
+    // per record: feature name -> Feature message span (built lazily per batch)
+    std::vector<std::unordered_map<std::string_view, Span>> index;
+    bool indexed = false;
+    std::string error;
+};
+
+bool index_batch(Reader& r) {
+    const size_t B = r.off.size() - 1;
+    r.index.assign(B, {});
+    for (size_t i = 0; i < B; ++i) {
+        Span rec{r.buf.data() + r.off[i], r.off[i + 1] - r.off[i]};
+        auto& idx = r.index[i];
+        bool ok = for_fields(rec, [&](uint32_t field, uint32_t wt, Span features, uint64_t) {
+            if (field != 1 || wt != 2) return;             // SequenceExample.feature_lists (2) is skipped
+            for_fields(features, [&](uint32_t f2, uint32_t w2, Span entry, uint64_t) {
+                if (f2 != 1 || w2 != 2) return;
+                std::string_view name;
+                Span feat;
+                for_fields(entry, [&](uint32_t f3, uint32_t w3, Span pl, uint64_t) {
+                    if (w3 != 2) return;
+                    if (f3 == 1) name = std::string_view((const char*)pl.p, pl.n);
+                    else if (f3 == 2) feat = pl;
+                });
+                idx[name] = feat;
+            });
+        });
+        if (!ok) {
+            r.error = "malformed Example in record " + std::to_string(i);
+            return false;
+        }
+    }
+    r.indexed = true;
+    return true;
+}
+
+uint64_t next_rand(Reader& r) {                            // xorshift64*
+    r.rng ^= r.rng >> 12;
+    r.rng ^= r.rng << 25;
+    r.rng ^= r.rng >> 27;
+    return r.rng * 0x2545F4914F6CDD1Dull;
+}
+
+// next record of the (repeated) file: 1 = ok, 0 = end of data, -1 = error
+int read_one(Reader& r, std::string& out) {
+    for (;;) {
+        uint8_t hdr[12];
+        size_t got = fread(hdr, 1, 12, r.f);
+        if (got == 0) {
+            ++r.epoch;
+            if (r.epochs >= 0 && r.epoch >= r.epochs) return 0;
+            if (fseek(r.f, 0, SEEK_SET) != 0) { r.error = "rewind failed"; return -1; }
+            if (fread(hdr, 1, 12, r.f) != 12) return 0;    // empty file
+        } else if (got < 12) {
+            r.error = "truncated record header";
+            return -1;
+        }
+        uint64_t len;
+        uint32_t hcrc;
+        memcpy(&len, hdr, 8);
+        memcpy(&hcrc, hdr + 8, 4);
+        if (r.verify && masked(crc32c(hdr, 8)) != hcrc) { r.error = "length crc mismatch"; return -1; }
+        out.resize((size_t)len);
+        uint8_t tail[4];
+        if ((len && fread(out.data(), 1, (size_t)len, r.f) != (size_t)len) || fread(tail, 1, 4, r.f) != 4) {
+            r.error = "truncated record";
+            return -1;
+        }
+        if (r.verify) {
+            uint32_t dcrc;
+            memcpy(&dcrc, tail, 4);
+            if (masked(crc32c((const uint8_t*)out.data(), (size_t)len)) != dcrc) { r.error = "data crc mismatch"; return -1; }
+        }
+        return 1;
+    }
+}
+
+// next record after the shuffle buffer (tf.data semantics: fill the buffer, emit a random slot and
+// refill it from the source; drain in random order at the end)
+int next_record(Reader& r, std::string& out) {
+    if (r.shuffle == 0) return r.source_done ? 0 : read_one(r, out);
+    while (!r.source_done && r.pool.size() < r.shuffle) {
+        std::string rec;
+        int rc = read_one(r, rec);
+        if (rc < 0) return -1;
+        if (rc == 0) { r.source_done = true; break; }
+        r.pool.push_back(std::move(rec));
+    }
+    if (r.pool.empty()) return 0;
+    const size_t j = (size_t)(next_rand(r) % r.pool.size());
+    out.swap(r.pool[j]);
+    if (!r.source_done) {
+        int rc = read_one(r, r.pool[j]);
+        if (rc < 0) return -1;
+        if (rc == 0) r.source_done = true;
+    }
+    if (r.source_done) {                                   // slot j is stale: close the gap
+        r.pool[j].swap(r.pool.back());
+        r.pool.pop_back();
+    }
+    return 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+#define EXPORT __attribute__((visibility("default")))
+
+EXPORT int recalgo_host_abi_version(void) { return RECALGO_HOST_ABI_VERSION; }
+
+EXPORT uint32_t recalgo_crc32c(const void* data, uint64_t n) { return crc32c((const uint8_t*)data, (size_t)n); }
+
+// ---- vocabulary ------------------------------------------------------------------------------------
+EXPORT void* recalgo_vocab_open(const char* path) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return nullptr;
+    auto* v = new Vocab();
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    v->blob.resize((size_t)n);
+    if (n && fread(v->blob.data(), 1, (size_t)n, f) != (size_t)n) {
+        fclose(f);
+        delete v;
+        return nullptr;
+    }
+    fclose(f);
+    size_t start = 0;
+    int64_t line = 0;
+    const std::string& b = v->blob;
+    v->map.reserve(b.size() / 8 + 16);
+    while (start < b.size()) {
+        size_t e = b.find('\n', start);
+        if (e == std::string::npos) e = b.size();
+        v->map.emplace(std::string_view(b.data() + start, e - start), line++);   // first occurrence wins
+        start = e + 1;
+    }
+    return v;
+}
+EXPORT int64_t recalgo_vocab_size(const void* vocab) { return vocab ? (int64_t)((const Vocab*)vocab)->map.size() : -1; }
+EXPORT int64_t recalgo_vocab_lookup(const void* vocab, const char* key, uint64_t len) {
+    const auto& m = ((const Vocab*)vocab)->map;
+    auto it = m.find(std::string_view(key, (size_t)len));
+    return it == m.end() ? -1 : it->second;
+}
+EXPORT void recalgo_vocab_close(void* vocab) { delete (Vocab*)vocab; }
+
+// ---- TFRecord reader -------------------------------------------------------------------------------
+EXPORT void* recalgo_reader_open(const char* path, int verify_crc) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return nullptr;
+    auto* r = new Reader();
+    r->f = f;
+    r->verify = verify_crc != 0;
+    r->off.push_back(0);
+    setvbuf(f, nullptr, _IOFBF, 1 << 20);
+    return r;
+}
+EXPORT void recalgo_reader_close(void* reader) {
+    auto* r = (Reader*)reader;
+    if (!r) return;
+    if (r->f) fclose(r->f);
+    delete r;
+}
+EXPORT const char* recalgo_reader_error(const void* reader) { return ((const Reader*)reader)->error.c_str(); }
+EXPORT int recalgo_reader_rewind(void* reader) {
+    auto* r = (Reader*)reader;
+    r->epoch = 0;
+    r->source_done = false;
+    r->pool.clear();
+    return fseek(r->f, 0, SEEK_SET);
+}
+
+// Reads up to max_records records into the reader's batch buffer.  Returns the number read
+// (0 at end of file), -1 on a framing / crc error (see recalgo_reader_error).
+EXPORT int64_t recalgo_reader_next_batch(void* reader, int64_t max_records) {
+    auto* r = (Reader*)reader;
+    r->buf.clear();
+    r->off.assign(1, 0);
+    r->indexed = false;
+    r->error.clear();
+    std::string rec;
+    for (int64_t i = 0; i < max_records; ++i) {
+        int rc = next_record(*r, rec);
+        if (rc < 0) return -1;
+        if (rc == 0) break;
+        r->buf.insert(r->buf.end(), rec.begin(), rec.end());
+        r->off.push_back(r->buf.size());
+    }
+    return (int64_t)r->off.size() - 1;
+}
+
+// dataset.repeat(num_epochs) (num_epochs < 0: forever) and dataset.shuffle(buffer_size) with a seed;
+// call before the first recalgo_reader_next_batch.
+EXPORT void recalgo_reader_configure(void* reader, int64_t num_epochs, int64_t shuffle_buffer_size, uint64_t seed) {
+    auto* r = (Reader*)reader;
+    r->epochs = num_epochs;
+    r->shuffle = shuffle_buffer_size > 0 ? (size_t)shuffle_buffer_size : 0;
+    r->rng = seed * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+    if (r->rng == 0) r->rng = 1;
+}
+
+// FixedLenFeature((n,), float32, default): out[B, n].  Returns 0, or -1 when a record lacks the
+// feature (or holds fewer than n values) and has_default == 0.
+EXPORT int recalgo_reader_float_feature(void* reader, const char* key, int n, float default_value, int has_default,
+                                        float* out) {
+    auto* r = (Reader*)reader;
+    if (!r->indexed && !index_batch(*r)) return -1;
+    const std::string_view k(key);
+    const size_t B = r->off.size() - 1;
+    for (size_t i = 0; i < B; ++i) {
+        float* o = out + i * (size_t)n;
+        int filled = 0;
+        auto it = r->index[i].find(k);
+        if (it != r->index[i].end()) {
+            for_fields(it->second, [&](uint32_t field, uint32_t wt, Span list, uint64_t) {
+                if (field != 2 || wt != 2) return;                           // FloatList
+                for_fields(list, [&](uint32_t f2, uint32_t w2, Span pl, uint64_t) {
+                    if (f2 != 1) return;
+                    if (w2 == 2) {                                           // packed
+                        for (size_t b = 0; b + 4 <= pl.n && filled < n; b += 4) memcpy(&o[filled++], pl.p + b, 4);
+                    } else if (w2 == 5 && filled < n) {
+                        memcpy(&o[filled++], pl.p, 4);
+                    }
+                });
+            });
+        }
+        if (filled < n) {
+            if (!(filled == 0 && has_default)) {
+                r->error = std::string("feature ") + key + " is required but missing in record " + std::to_string(i);
+                return -1;
+            }
+            for (int j = 0; j < n; ++j) o[j] = default_value;
+        }
+    }
+    return 0;
+}
+
+// VarLenFeature(string) -> vocabulary ids: offsets[B+1], values[nnz] (-1 = key not in vocabulary).
+// Returns nnz; when values_cap < nnz only the offsets are written (call again with a larger buffer).
+EXPORT int64_t recalgo_reader_id_feature(void* reader, const char* key, const void* vocab, int64_t* offsets,
+                                         int64_t* values, int64_t values_cap) {
+    auto* r = (Reader*)reader;
+    if (!r->indexed && !index_batch(*r)) return -1;
+    const auto& vm = ((const Vocab*)vocab)->map;
+    const std::string_view k(key);
+    const size_t B = r->off.size() - 1;
+    int64_t nnz = 0;
+    offsets[0] = 0;
+    for (size_t i = 0; i < B; ++i) {
+        auto it = r->index[i].find(k);
+        if (it != r->index[i].end()) {
+            for_fields(it->second, [&](uint32_t field, uint32_t wt, Span list, uint64_t) {
+                if (field != 1 || wt != 2) return;                           // BytesList
+                for_fields(list, [&](uint32_t f2, uint32_t w2, Span pl, uint64_t) {
+                    if (f2 != 1 || w2 != 2) return;
+                    if (nnz < values_cap) {
+                        auto v = vm.find(std::string_view((const char*)pl.p, pl.n));
+                        values[nnz] = v == vm.end() ? -1 : v->second;
+                    }
+                    ++nnz;
+                });
+            });
+        }
+        offsets[i + 1] = nnz;
+    }
+    return nnz;
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+"""ctypes binding of librecalgo_host.so (include/recalgo_host.h): native TFRecord reading,
+tf.train.Example decoding and vocabulary lookup — the host-side step right before the hot path
+(SURVEY.md §8f-2).  `NativeDataset` is the drop-in producer behind `train_input_fn` /
+`eval_input_fn` (algorithm/utils.py) when the parser was built from feature columns: it yields the
+same (features, labels) batches as the pure-Python path, with categorical features already
+encoded as ids (int64 [B], or Ragged for multi-valued / sequence columns)."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_uint32, c_uint64, c_void_p
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_HERE, "librecalgo_host.so")
+
+SIGNATURES = {
+    "recalgo_host_abi_version": (c_int, []),
+    "recalgo_crc32c": (c_uint32, [c_void_p, c_uint64]),
+    "recalgo_vocab_open": (c_void_p, [c_char_p]),
+    "recalgo_vocab_size": (c_int64, [c_void_p]),
+    "recalgo_vocab_lookup": (c_int64, [c_void_p, c_char_p, c_uint64]),
+    "recalgo_vocab_close": (None, [c_void_p]),
+    "recalgo_reader_open": (c_void_p, [c_char_p, c_int]),
+    "recalgo_reader_close": (None, [c_void_p]),
+    "recalgo_reader_rewind": (c_int, [c_void_p]),
+    "recalgo_reader_configure": (None, [c_void_p, c_int64, c_int64, c_uint64]),
+    "recalgo_reader_error": (c_char_p, [c_void_p]),
+    "recalgo_reader_next_batch": (c_int64, [c_void_p, c_int64]),
+    "recalgo_reader_float_feature": (c_int, [c_void_p, c_char_p, c_int, c_float, c_int, c_void_p]),
+    "recalgo_reader_id_feature": (c_int64, [c_void_p, c_char_p, c_void_p, c_void_p, c_void_p, c_int64]),
+}
+
+_lib = None
+
+
+def load(path: str = LIB_PATH) -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not found: build it with `python -m recalgorithm_amd.build`")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    if lib.recalgo_host_abi_version() != 1:
+        raise RuntimeError("librecalgo_host.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def crc32c(data: bytes) -> int:
+    return int(load().recalgo_crc32c(data, len(data)))
+
+
+class Vocabulary:
+    _cache: Dict[str, "Vocabulary"] = {}
+
+    def __init__(self, path: str):
+        self.path = path
+        self.h = load().recalgo_vocab_open(path.encode())
+        if not self.h:
+            raise IOError(f"cannot read vocabulary file {path}")
+
+    @classmethod
+    def get(cls, path: str) -> "Vocabulary":
+        v = cls._cache.get(path)
+        if v is None:
+            v = cls._cache[path] = Vocabulary(path)
+        return v
+
+    def __len__(self):
+        return int(load().recalgo_vocab_size(self.h))
+
+    def lookup(self, key) -> int:
+        if isinstance(key, str):
+            key = key.encode()
+        return int(load().recalgo_vocab_lookup(self.h, key, len(key)))
+
+
+class NativeDataset:
+    """TFRecordDataset(filepath)[.shuffle(buf)].repeat(epochs).batch(bs).map(parse) with the record
+    framing, Example decoding and vocabulary lookup done in C++."""
+
+    def __init__(self, filepath: str, feature_columns, label_keys, batch_size: int, num_epochs: Optional[int] = 1,
+                 shuffle_buffer_size: int = 0, seed: int = 0, verify_crc: bool = False):
+        from ..feature_column import CategoricalColumn, NumericColumn
+        self.filepath, self.bs = filepath, int(batch_size)
+        self.epochs = -1 if num_epochs is None else int(num_epochs)
+        self.shuffle, self.seed, self.verify = int(shuffle_buffer_size or 0), int(seed), verify_crc
+        self.label_keys = list(label_keys)
+        self.numeric: List[NumericColumn] = []
+        self.categorical: List[CategoricalColumn] = []
+        seen = set()
+        for c in feature_columns:
+            base = getattr(c, "categorical_column", c)
+            if base.key in seen:
+                continue
+            seen.add(base.key)
+            if isinstance(base, NumericColumn):
+                self.numeric.append(base)
+            elif isinstance(base, CategoricalColumn):
+                if not base.vocabulary_file:
+                    raise ValueError(f"native decoding needs a vocabulary file for {base.key}")
+                self.categorical.append(base)
+            else:
+                raise TypeError(base)
+
+    def __iter__(self):
+        from ..feature_column import Ragged
+        lib = load()
+        h = lib.recalgo_reader_open(self.filepath.encode(), int(self.verify))
+        if not h:
+            raise IOError(f"cannot open {self.filepath}")
+        try:
+            lib.recalgo_reader_configure(h, self.epochs, self.shuffle, self.seed)
+            vocabs = {c.key: Vocabulary.get(c.vocabulary_file) for c in self.categorical}
+            while True:
+                B = int(lib.recalgo_reader_next_batch(h, self.bs))
+                if B < 0:
+                    raise IOError(f"{self.filepath}: {lib.recalgo_reader_error(h).decode()}")
+                if B == 0:
+                    return
+                feats: Dict[str, object] = {}
+                for c in self.numeric:
+                    n = int(np.prod(c.shape))
+                    out = np.empty((B, n), dtype=np.float32)
+                    has_def = c.default_value is not None
+                    rc = lib.recalgo_reader_float_feature(h, c.key.encode(), n, float(c.default_value or 0.0), int(has_def),
+                                                          out.ctypes.data_as(c_void_p))
+                    if rc != 0:
+                        raise ValueError(lib.recalgo_reader_error(h).decode())
+                    feats[c.key] = torch.from_numpy(out.reshape((B,) + tuple(c.shape)))
+                for c in self.categorical:
+                    offs = np.empty(B + 1, dtype=np.int64)
+                    vals = np.empty(max(B, 1) * 4, dtype=np.int64)
+                    nnz = int(lib.recalgo_reader_id_feature(h, c.key.encode(), vocabs[c.key].h, offs.ctypes.data_as(c_void_p),
+                                                            vals.ctypes.data_as(c_void_p), vals.size))
+                    if nnz > vals.size:
+                        vals = np.empty(nnz, dtype=np.int64)
+                        lib.recalgo_reader_id_feature(h, c.key.encode(), vocabs[c.key].h, offs.ctypes.data_as(c_void_p),
+                                                      vals.ctypes.data_as(c_void_p), vals.size)
+                    vals = vals[:nnz]
+                    lens = np.diff(offs)
+                    if not c.is_sequence and (lens <= 1).all():
+                        dense = np.full(B, -1, dtype=np.int64)       # single-valued in this batch: [B] ids, -1 = missing
+                        dense[lens == 1] = vals
+                        feats[c.key] = torch.from_numpy(dense)
+                    else:
+                        feats[c.key] = Ragged(torch.from_numpy(vals.copy()), torch.from_numpy(offs))
+                labels = {k: feats.pop(k) for k in self.label_keys}
+                yield feats, labels
+        finally:
+            lib.recalgo_reader_close(h)

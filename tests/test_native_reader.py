@@ -1,0 +1,165 @@
+"""CPU: librecalgo_host.so (include/recalgo_host.h) — the native TFRecord / tf.train.Example /
+vocabulary plumbing — against the pure-Python codec (recalgorithm_amd/io/tfrecord.py) and the
+known answers it is itself tested with; plus a decode-throughput figure."""
+import ctypes
+import os
+import re
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from recalgorithm_amd import build as B
+from recalgorithm_amd import feature_column as fc
+from recalgorithm_amd.algorithm.utils import _Dataset, eval_input_fn, parse_example, train_input_fn
+from recalgorithm_amd.io import native, synth, tfrecord as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def host_lib():
+    B.build_host(verbose=False)
+    return native.load()
+
+
+def test_header_and_binding_agree():
+    hdr = open(os.path.join(ROOT, "include", "recalgo_host.h")).read()
+    declared = set(re.findall(r"\b(recalgo_\w+)\s*\(", hdr))
+    assert declared == set(native.SIGNATURES), declared ^ set(native.SIGNATURES)
+    lib = ctypes.CDLL(native.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_crc32c_known_answers_native():
+    assert native.crc32c(b"") == 0 and native.crc32c(b"123456789") == 0xE3069283
+    assert native.crc32c(bytes(32)) == 0x8A9136AA and native.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43
+    rng = np.random.default_rng(0)
+    for n in (1, 7, 8, 9, 63, 1000, 4097):
+        b = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert native.crc32c(b) == T.crc32c(b)
+
+
+def test_vocabulary_lookup(tmp_path):
+    p = tmp_path / "v.txt"
+    p.write_bytes(b"userid_0\nuserid_1\n\nuserid_1\nlast_without_newline")
+    v = native.Vocabulary(str(p))
+    assert v.lookup(b"userid_0") == 0 and v.lookup("userid_1") == 1          # first occurrence wins
+    assert v.lookup(b"") == 2 and v.lookup(b"last_without_newline") == 4 and v.lookup(b"nope") == -1
+    with pytest.raises(IOError):
+        native.Vocabulary(str(tmp_path / "missing.txt"))
+
+
+def _dataset(tmp_path, n=300, seq_example=False):
+    spec = synth.SynthSpec(n_fields=6, max_vocab=300, seed=5, oov_frac=0.1, with_dense=True, with_history=True,
+                           with_tags=True)
+    vocab_dir = str(tmp_path / "vocabulary") + "/"
+    synth.write_vocabularies(spec, vocab_dir)
+    path = str(tmp_path / ("seq.tfrecord" if seq_example else "ex.tfrecord"))
+    synth.write_tfrecord(spec, path, n, chunk=64, as_sequence_example=seq_example)
+    from recalgorithm_amd.algorithm._common import DENSE_FEATURES
+    cols = [fc.numeric_column(k, default_value=0.0) for k in DENSE_FEATURES]
+    cols += [fc.embedding_column(fc.categorical_column_with_vocabulary_file(nm, vocab_dir + nm + ".txt"), 8) for nm in spec.names
+             if nm != "feedid"]
+    feed = fc.sequence_categorical_column_with_vocabulary_file("feedid", vocab_dir + "feedid.txt")
+    his = fc.sequence_categorical_column_with_vocabulary_file("his_read_comment_7d_seq", vocab_dir + "feedid.txt")
+    cols += fc.shared_embedding_columns([feed, his], 8)
+    cols += [fc.embedding_column(fc.categorical_column_with_vocabulary_file("manual_tag_list", vocab_dir + "manual_tag_id.txt"), 8)]
+    labels = [fc.numeric_column("read_comment", default_value=0.0)]
+
+    def parser(serialized):
+        f = parse_example(serialized, fc.make_parse_example_spec(cols + labels))
+        y = f.pop("read_comment")
+        return f, {"read_comment": y}
+    parser.columns_getter = lambda: (cols, labels)
+    return spec, path, cols, labels, parser
+
+
+def _encoded(cols, feats):
+    """Python-path features (raw keys) -> ids, the way the model's input layers would encode them."""
+    out = {}
+    for c in cols:
+        base = getattr(c, "categorical_column", c)
+        x = feats[base.key]
+        out[base.key] = x if isinstance(x, torch.Tensor) else base.ids({base.key: x}, torch.device("cpu"))
+    return out
+
+
+@pytest.mark.parametrize("seq_example", [False, True])
+def test_native_batches_equal_python_batches(tmp_path, seq_example):
+    spec, path, cols, labels, parser = _dataset(tmp_path, seq_example=seq_example)
+    nat = eval_input_fn(path, parser, 64)
+    assert isinstance(nat, native.NativeDataset)
+    py = _Dataset(path, parser, 64, 1, 0)
+    nb, pb = list(nat), list(py)
+    assert [b[1]["read_comment"].shape[0] for b in nb] == [64, 64, 64, 64, 44] == [b[1]["read_comment"].shape[0] for b in pb]
+    for (nf, nl), (pf, pl) in zip(nb, pb):
+        assert torch.equal(nl["read_comment"], pl["read_comment"])
+        enc = _encoded(cols, pf)
+        assert set(nf) == set(enc)
+        for k, v in enc.items():
+            if isinstance(v, torch.Tensor):
+                assert isinstance(nf[k], torch.Tensor) and torch.equal(nf[k], v), k
+            else:
+                assert torch.equal(nf[k].values, v.values) and torch.equal(nf[k].offsets, v.offsets), k
+    if seq_example:      # quirk B-9: list features written under feature_lists parse as empty
+        assert all(int(f["his_read_comment_7d_seq"].values.numel()) == 0 for f, _ in nb)
+    else:
+        assert any(int(f["his_read_comment_7d_seq"].values.numel()) > 0 for f, _ in nb)
+
+
+def test_native_repeat_shuffle_and_crc(tmp_path):
+    spec, path, cols, labels, parser = _dataset(tmp_path, n=100)
+    n3 = sum(l["read_comment"].shape[0] for _, l in train_input_fn(path, parser, 32, 3, 0))
+    assert n3 == 300                                                          # repeat(3) then batch
+    sizes = [l["read_comment"].shape[0] for _, l in train_input_fn(path, parser, 32, 3, 0)]
+    assert sizes == [32] * 9 + [12]
+    a = torch.cat([f["userid"] for f, _ in train_input_fn(path, parser, 100, 1, 16)])
+    b = torch.cat([f["userid"] for f, _ in train_input_fn(path, parser, 100, 1, 16)])
+    c = torch.cat([f["userid"] for f, _ in eval_input_fn(path, parser, 100)])
+    assert torch.equal(a, b) and not torch.equal(a, c) and torch.equal(a.sort().values, c.sort().values)
+    raw = bytearray(open(path, "rb").read())
+    raw[40] ^= 0x10
+    bad = str(tmp_path / "bad.tfrecord")
+    open(bad, "wb").write(bytes(raw))
+    ds = native.NativeDataset(bad, cols + labels, ["read_comment"], 32, verify_crc=True)
+    with pytest.raises(IOError):
+        list(ds)
+    # a required feature without default
+    req = [fc.numeric_column("not_there")]
+    with pytest.raises(ValueError):
+        list(native.NativeDataset(path, req, [], 32))
+
+
+def test_native_decode_throughput(tmp_path, capsys):
+    spec = synth.SynthSpec(n_fields=26, max_vocab=100000, seed=9)
+    vocab_dir = str(tmp_path / "vocabulary") + "/"
+    synth.write_vocabularies(spec, vocab_dir)
+    path = str(tmp_path / "big.tfrecord")
+    n = 20000
+    synth.write_tfrecord(spec, path, n)
+    cols = [fc.embedding_column(fc.categorical_column_with_vocabulary_file(nm, vocab_dir + nm + ".txt"), 16) for nm in spec.names]
+    labels = [fc.numeric_column("read_comment", default_value=0.0)]
+
+    def parser(serialized):
+        f = parse_example(serialized, fc.make_parse_example_spec(cols + labels))
+        y = f.pop("read_comment")
+        return f, {"read_comment": y}
+    parser.columns_getter = lambda: (cols, labels)
+    list(eval_input_fn(path, parser, 4096))                                   # warm: vocabularies loaded
+    t0 = time.perf_counter()
+    got = sum(l["read_comment"].shape[0] for _, l in eval_input_fn(path, parser, 4096))
+    t_nat = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    m = 4096
+    f, _ = next(iter(_Dataset(path, parser, m, 1, 0)))
+    for c in cols:
+        c.categorical_column.ids({c.key: f[c.key]}, torch.device("cpu"))
+    t_py = (time.perf_counter() - t0) * n / m
+    assert got == n
+    with capsys.disabled():
+        print(f"\n[native reader] 26 string fields/example: native {n / t_nat:,.0f} ex/s, python {n / t_py:,.0f} ex/s "
+              f"({t_py / t_nat:.0f}x)")
+    assert t_nat < t_py
