@@ -306,6 +306,12 @@ def kernel_rooflines(args, est, feats, device):
                                                                   ar.weight.shape[0], K, 0.0, p(zero_lr), 0.9, 0.999, 1e-8, 1, st),
         n_rows_live * (K * 28 + 4))
     res[-1]["live_fraction"] = round(n_rows_live * K / max(n, 1), 4)
+    if os.environ.get("RECALGO_BENCH_SORTED_LIST") == "1":      # diagnostic: the same launch over an address-ordered list
+        slst = lst.clone()
+        slst[:n_rows_live] = torch.sort(lst[:n_rows_live]).values
+        add("adam_tf1_list(arena, sorted list)", lambda: lib.recalgo_adam_tf1_list(
+            p(ar.weight), p(ar.grad), p(ar.m), p(ar.v), p(slst), p(cnt), ar.weight.shape[0], K, 0.0, p(zero_lr), 0.9, 0.999, 1e-8, 1, st),
+            n_rows_live * (K * 28 + 4))
     return res
 
 
@@ -328,37 +334,19 @@ def cpu_baseline(args, seconds):
     return {"value": None, "unit": "examples/s", "cores": 0, "kind": "port", "sample": note}
 
 
-def main():
-    args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
-
+def timed_run(args, device, rank, world, dist, capacity_factor):
+    """Build the model on this rank, (N > 1) shard it, capture the step, warm up, time `steps` steps
+    between barriers; returns the max-over-ranks wall time."""
     if args.tunable:
         import torch.cuda.tunable as tunable
-        tunable.enable(True)
         tunable.tuning_enable(True)
-        tunable.set_max_tuning_duration(50)        # ms per candidate
-        tunable.set_max_tuning_iterations(20)
-        tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"recalgo_tunableop_{rank}.csv"))
     est, spec, feats, labels, workload = build_estimator(args, device, rank, world)
     if world > 1:
         # row-shard the embedding arenas over the ranks (fixed-capacity id / row all_to_all over
         # RCCL: static shapes, no host sync -> the N-GPU step is still one hipGraph), all-reduce the
         # flat dense gradient, back-propagate loss / N
         from recalgorithm_amd.parallel import attach_data_parallel
-        attach_data_parallel(est, dist, capacity_factor=args.capacity_factor)
+        attach_data_parallel(est, dist, capacity_factor=capacity_factor)
     from recalgorithm_amd.estimator import GraphedTrainStep
     from recalgorithm_amd.io import synth
     # distinct synthetic batches, all resident in HBM before the timed region; step i consumes
@@ -374,12 +362,23 @@ def main():
             graphed = GraphedTrainStep(est.train_step, feats, labels, warmup=3)
             launch = "hipGraph replay"
         except Exception as e:      # e.g. a collective that cannot be captured: run the same step eagerly
-            if rank == 0:
-                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches",
-                      file=sys.stderr, flush=True)
+            print(f"[bench] rank {rank}: hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches",
+                  file=sys.stderr, flush=True)
+            graphed = None
             torch.cuda.synchronize()
+        if dist is not None:        # all ranks launch the same way: eager everywhere if any capture failed
+            ok = torch.tensor([1.0 if graphed is not None else 0.0], device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok) == 0.0:
+                graphed, launch = None, "eager"
     if graphed is None:
-        step = lambda i: est.train_step(*batches[i % len(batches)])
+        from recalgorithm_amd.estimator import HOUSEKEEPING_EVERY
+
+        def step(i):
+            out = est.train_step(*batches[i % len(batches)])
+            if i % HOUSEKEEPING_EVERY == HOUSEKEEPING_EVERY - 1:
+                est.store.housekeeping()
+            return out
         for i in range(max(args.warmup, 1)):
             loss = step(i)
     else:
@@ -404,14 +403,69 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
-    loss_v = float(loss)
+    overflow = False
     if world > 1:
         from recalgorithm_amd.parallel import exchange_overflowed
         ovf = torch.tensor([1.0 if exchange_overflowed(est) else 0.0], device=device)
         dist.all_reduce(ovf)
-        if float(ovf) > 0:
-            raise SystemExit("bench.py: an id/row exchange bucket overflowed its capacity: the run is invalid; "
-                             "rerun with a larger --capacity-factor")
+        overflow = float(ovf) > 0
+    return {"est": est, "spec": spec, "feats": feats, "workload": workload, "dt": dt, "loss": float(loss),
+            "launch": launch, "overflow": overflow}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device")
+    # RECALGO_DIST_BACKEND=gloo_staged: bring-up aid for boxes with fewer GPUs than ranks (ranks share
+    # devices, collectives bounce through host memory; see parallel.HostStagedCollectives) — the
+    # numbers it prints are not benchmark results.  Default: one rank per GPU over RCCL.
+    staged = os.environ.get("RECALGO_DIST_BACKEND", "nccl") == "gloo_staged"
+    if staged:
+        local_rank %= torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if staged:
+            from recalgorithm_amd.parallel import HostStagedCollectives
+            dist.init_process_group("gloo")
+            dist = HostStagedCollectives(dist)
+        else:
+            dist.init_process_group("nccl", device_id=device)
+
+    if args.tunable:
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.tuning_enable(True)
+        tunable.set_max_tuning_duration(50)        # ms per candidate
+        tunable.set_max_tuning_iterations(20)
+        tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"recalgo_tunableop_{rank}.csv"))
+    # N > 1: the id/row exchange uses fixed-capacity buckets (capacity_factor x the mean bucket, so
+    # that the step has static shapes and is one hipGraph).  A bucket that overflows invalidates
+    # the run: it is repeated with the capacity doubled, up to `world` x the mean, at which every
+    # bucket holds a whole batch and cannot overflow.
+    cf = args.capacity_factor
+    while True:
+        r = timed_run(args, device, rank, world, dist, cf)
+        if not r["overflow"] or world == 1:
+            break
+        if cf >= world:
+            raise SystemExit("bench.py: exchange bucket overflow at full capacity (cannot happen)")
+        if rank == 0:
+            print(f"[bench] exchange bucket overflow at capacity factor {cf}: repeating with {min(2 * cf, world)}",
+                  file=sys.stderr, flush=True)
+        cf = min(2 * cf, float(world))
+        del r
+        torch.cuda.empty_cache()
+    est, spec, feats, workload, dt, loss_v, launch = (r[k] for k in ("est", "spec", "feats", "workload", "dt", "loss", "launch"))
 
     # fwd+bwd only (optimizer excluded), reported next to the headline
     out = {
@@ -433,12 +487,18 @@ def main():
                    "launch": launch,
                    "gemm_selection": "TunableOp" if args.tunable else "hipBLASLt default",
                    "parallelism": (f"dp{world} + embedding rows sharded r % {world} (RCCL all_to_all), dense grads all-reduced"
+                                   + (" [gloo_staged bring-up mode: NOT a benchmark]" if staged else "")
                                    if world > 1 else "single")},
         "final_loss": round(loss_v, 6),
     }
     if rank == 0:
+        ks = None
         if not args.no_kernel_timing:
-            ks = kernel_rooflines(args, est, feats, device)
+            try:
+                ks = kernel_rooflines(args, est, feats, device)
+            except Exception as e:          # the per-kernel table must never take the headline line down with it
+                print(f"[bench] per-kernel timing failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+        if ks:
             dom = max(ks, key=lambda k: k["avg_us"])
             if dom["bound"] == "mfma":
                 out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_TFLOPs"],
@@ -465,7 +525,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.destroy_process_group()
+        dist.barrier()
+        (dist._d if staged else dist).destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -191,6 +191,9 @@ def _tree_tensors(obj, prefix=""):
             yield from _tree_tensors(obj[k], f"{prefix}/{k}")
 
 
+HOUSEKEEPING_EVERY = 32      # steps between VariableStore.housekeeping() calls (live-row list ordering)
+
+
 class GraphedTrainStep:
     """Capture `step_fn(features, labels)` (forward + backward + optimizer, everything enqueued
     on the current stream) into a hipGraph over static input buffers; `__call__` copies the new
@@ -213,6 +216,9 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out = step_fn(features, labels)
         self.warmup_steps = warmup
+        owner = getattr(step_fn, "__self__", None)                # Estimator.train_step -> its VariableStore
+        self._housekeeping = getattr(getattr(owner, "store", None), "housekeeping", None)
+        self._calls = 0
 
     def load(self, features, labels):
         """Copy a new batch into the static input buffers.  Inputs that are views of one
@@ -241,6 +247,9 @@ class GraphedTrainStep:
         if features is not None:
             self.load(features, labels)
         self.graph.replay()
+        self._calls += 1
+        if self._housekeeping is not None and self._calls % HOUSEKEEPING_EVERY == 0:
+            self._housekeeping()       # enqueued between replays on the same stream; never waits for the GPU
         return self.out
 
 
@@ -339,6 +348,8 @@ class Estimator:
                     loss = self.train_step(features, labels)
             else:
                 loss = self.train_step(features, labels)
+                if n % HOUSEKEEPING_EVERY == HOUSEKEEPING_EVERY - 1:
+                    self.store.housekeeping()
             self.global_step += 1
             n += 1
             if log_every and self.global_step % log_every < 1:

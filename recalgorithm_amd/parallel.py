@@ -300,3 +300,46 @@ def exchange_overflowed(est) -> bool:
     """True if any static exchange bucket overflowed since attach (reads the device flags)."""
     return any(bool(a.sharding.overflow.item()) for a in est.store.arenas.values()
                if getattr(a, "sharding", None) is not None and a.sharding.overflow is not None)
+
+
+class HostStagedCollectives:
+    """`torch.distributed` look-alike whose collectives bounce device tensors through host memory
+    (gloo underneath).  Test and bring-up aid only: it lets N ranks share ONE GPU — RCCL refuses
+    two ranks on a device — so that the N > 1 data path runs on the real HIP kernels on a 1-GPU box
+    (tests/test_gpu_dist.py).  Not graph-capturable (every call synchronises), never the product path."""
+
+    def __init__(self, dist):
+        self._d = dist
+        self.ReduceOp = dist.ReduceOp
+
+    def get_world_size(self, group=None):
+        return self._d.get_world_size(group)
+
+    def get_rank(self, group=None):
+        return self._d.get_rank(group)
+
+    def barrier(self, group=None):
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        self._d.barrier(group=group)
+
+    def broadcast(self, t, src, group=None):
+        h = t.detach().cpu()
+        self._d.broadcast(h, src=src, group=group)
+        t.copy_(h)
+
+    def all_reduce(self, t, op=None, group=None):
+        h = t.detach().cpu()
+        self._d.all_reduce(h, op=op if op is not None else self.ReduceOp.SUM, group=group)
+        t.copy_(h)
+
+    def all_to_all_single(self, out, inp, out_splits=None, in_splits=None, group=None):
+        hin, hout = inp.detach().cpu().contiguous(), torch.empty(out.shape, dtype=out.dtype)
+        self._d.all_to_all_single(hout, hin, out_splits, in_splits, group=group)
+        out.copy_(hout)
+
+    def all_gather(self, parts, t, group=None):
+        hs = [p.detach().cpu() for p in parts]
+        self._d.all_gather(hs, t.detach().cpu(), group=group)
+        for p, h in zip(parts, hs):
+            p.copy_(h)

@@ -188,6 +188,12 @@ class VariableStore:
         return blk, subs
 
     # -- packing --------------------------------------------------------------------------
+    def housekeeping(self) -> None:
+        """Cheap, sync-free maintenance the training loops call every few dozen steps."""
+        for ar in self.arenas.values():
+            if getattr(ar, "tracks_live_rows", False):
+                ar.order_live_list()
+
     def pack(self):
         """Move every dense variable into one flat buffer (16-byte aligned slices)."""
         if self.packed:
@@ -278,6 +284,8 @@ class EmbeddingArena:
         self.weight = self.grad = self.m = self.v = None
         self.live = self.live_list = self.live_count = None   # live-row bookkeeping (see live_state)
         self._live_rows = -1
+        self._cnt_host = self._cnt_event = None                # order_live_list's asynchronous count read-back
+        self._ordered_n = 0
         self.trainable = True
 
     def add_table(self, name: str, vocab: int, init: Optional[torch.Tensor] = None) -> int:
@@ -347,7 +355,31 @@ class EmbeddingArena:
             self.live_list[:idx.numel()] = idx
             self.live_count = torch.tensor([idx.numel()], dtype=torch.int32, device=dev)
             self._live_rows = rows
+            self._ordered_n, self._cnt_event = idx.numel(), None   # nonzero() lists ascending rows
         return self.live, self.live_list, self.live_count
+
+    def order_live_list(self, min_growth: float = 0.02) -> None:
+        """Housekeeping between steps, no host synchronisation: put the live-row list in address order.
+        recalgo_mark_live_rows appends rows in first-touch order, i.e. at random; the list Adam then
+        walks HBM at random (measured: 40 us vs 32 us address-ordered, 345 k rows x 64 B x 7 streams).
+        Any permutation of the valid prefix is an equivalent list, so the prefix is sorted in place
+        whenever it has grown by `min_growth` since the last sort.  The prefix length comes from an
+        asynchronous copy of the device counter issued by the PREVIOUS call: a stale count is a lower
+        bound (the list is append-only), and nothing here waits for the GPU."""
+        if self.live is None or not self.weight.is_cuda:
+            return
+        if self._cnt_host is None:
+            self._cnt_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        if self._cnt_event is not None and self._cnt_event.query():
+            n = min(int(self._cnt_host[0]), self.live_list.numel())
+            if n > 1 and n > self._ordered_n * (1.0 + min_growth):
+                self.live_list[:n] = torch.sort(self.live_list[:n]).values
+                self._ordered_n = n
+            self._cnt_event = None
+        if self._cnt_event is None:
+            self._cnt_host.copy_(self.live_count, non_blocking=True)
+            self._cnt_event = torch.cuda.Event()
+            self._cnt_event.record()
 
     def live_rows(self) -> torch.Tensor:
         """uint8 [rows]: 1 where a gradient has reached the row."""

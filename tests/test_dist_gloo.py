@@ -51,12 +51,15 @@ def _global_batch(vocabs, B=24, seed=5):
     return ids
 
 
-def _worker(rank, port, errq):
+def _worker(rank, port, errq, staged=False):
     try:
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
         dist.init_process_group("gloo", rank=rank, world_size=WORLD)
         from recalgorithm_amd import parallel as P
         from recalgorithm_amd.variables import VariableStore
+        pg = dist
+        if staged:                   # the host-staging adapter the 1-GPU two-rank GPU test relies on
+            globals()["dist"] = P.HostStagedCollectives(pg)
 
         ar, vocabs = _make_arena()
         W_full = ar.weight.clone()
@@ -149,7 +152,7 @@ def _worker(rank, port, errq):
         if rank == 1:
             assert float(st2.weight.abs().sum()) == 0.0
         dist.barrier()
-        dist.destroy_process_group()
+        pg.destroy_process_group()
     except Exception:  # noqa: BLE001
         import traceback
         errq.put(f"rank {rank}:\n{traceback.format_exc()}")
@@ -157,11 +160,12 @@ def _worker(rank, port, errq):
 
 
 @pytest.mark.timeout(180)
-def test_row_sharded_exchange_world2_matches_single_process():
+@pytest.mark.parametrize("staged", [False, True])
+def test_row_sharded_exchange_world2_matches_single_process(staged):
     ctx = mp.get_context("spawn")
     errq = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, port, errq)) for r in range(WORLD)]
+    procs = [ctx.Process(target=_worker, args=(r, port, errq, staged)) for r in range(WORLD)]
     for p in procs:
         p.start()
     for p in procs:

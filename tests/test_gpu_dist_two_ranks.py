@@ -1,0 +1,120 @@
+"""-m gpu: TWO ranks of the row-sharded data-parallel step on the real HIP kernels, on the one GPU a
+test box has.  RCCL refuses two ranks on one device, so the collectives go through
+parallel.HostStagedCollectives (gloo via host memory); everything else is the production N > 1
+path: arenas sharded r % 2, fixed-capacity id/row exchange with -1 padding, owner-side HIP gather and
+scatter-add, live-row marking on the shard, list Adam on the shard, dense all-reduce, loss / N.
+Oracle: the single-process step on the concatenated global batch (same seeds) — N ranks == 1 rank.
+Also runs bench.py's N = 2 code path in the same mode (launch agreement, eager fallback, overflow
+retry, JSON line)."""
+import json
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORLD = 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _slice(x, lo, hi):
+    return x[lo:hi].contiguous() if isinstance(x, torch.Tensor) else x
+
+
+def _worker(rank, port, model, capacity_factor, errq):
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+        from recalgorithm_amd import parallel as P
+        from tests.test_gpu_dist import _make
+        from tests.util import assert_close
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        d = P.HostStagedCollectives(dist)
+
+        # (no BatchNorm: its batch statistics are per rank by design, as in any data-parallel job)
+        ref, feats, labels = _make(model, dev, batch_norm=False)   # the 1-rank oracle, global batch
+        shd, _, _ = _make(model, dev, batch_norm=False)
+        B = next(iter(labels.values())).shape[0]
+        lo, hi = rank * B // WORLD, (rank + 1) * B // WORLD
+        f_loc = {k: _slice(v, lo, hi) for k, v in feats.items()}
+        l_loc = {k: _slice(v, lo, hi) for k, v in labels.items()}
+        P.attach_data_parallel(shd, d, capacity_factor=capacity_factor)
+        for step in range(3):
+            l0 = ref.train_step(feats, labels)
+            l1 = shd.train_step(f_loc, l_loc).detach().clone()
+            d.all_reduce(l1)
+            assert_close(l1 / WORLD, l0, what=f"{model} mean-of-rank losses vs global loss, step {step}", rtol=2e-5)
+        assert not P.exchange_overflowed(shd)
+        a0, a1 = ref.store.named_arrays(), shd.store.named_arrays()
+        for k in a0:
+            if "embedding_weights" in k or "kernel/" in k:     # arena tables: compared un-sharded below
+                continue
+            assert_close(a1[k], a0[k], rtol=3e-4, what=f"{model} {k} after 3 steps", reduced=True)
+        for name, ar in ref.store.arenas.items():
+            sar = shd.store.arenas[name]
+            assert sar.weight.shape[0] == (ar.weight.shape[0] - rank + WORLD - 1) // WORLD
+            for what in ("weight", "m", "v"):
+                full = P.unshard_arena(sar, what)
+                assert_close(full, getattr(ar, what), rtol=3e-4, what=f"{model} arena {name}.{what} after 3 steps", reduced=True)
+        d.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        import traceback
+        errq.put(f"rank {rank}:\n{traceback.format_exc()}")
+        raise
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("model,capacity_factor", [("dcn", 2.0), ("deepfm", None), ("deepfm", 2.0)])
+def test_two_ranks_equal_one_rank(model, capacity_factor):
+    ctx = mp.get_context("spawn")
+    errq = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, model, capacity_factor, errq)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(500)
+    errs = []
+    while not errq.empty():
+        errs.append(errq.get())
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+            errs.append("worker timed out")
+    assert not errs, "\n".join(errs)
+    assert all(p.exitcode == 0 for p in procs)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("capacity_factor", ["2.0", "0.6"])          # 0.6 x mean must overflow -> bench repeats at 1.2, 2.0
+def test_bench_two_rank_code_path(capacity_factor):
+    env = dict(os.environ, RECALGO_DIST_BACKEND="gloo_staged", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "4", "--batch", "512",
+           "--max-vocab", "20000", "--data-batches", "3", "--no-tunable", "--no-cpu-baseline", "--capacity-factor", capacity_factor]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 1024 and out["value"] > 0
+    assert out["config"]["launch"] == "eager"                       # host-staged collectives cannot be captured
+    assert "roofline" in out
+    if capacity_factor == "0.6":
+        assert re.search(r"overflow at capacity factor 0.6", r.stderr), r.stderr[-2000:]

@@ -406,6 +406,17 @@ def test_live_row_list_adam_is_bit_identical_to_dense(dev, rows, K, F):
         assert n == int(touched.sum())
         assert sorted(lst[:n].tolist()) == torch.nonzero(touched).squeeze(1).tolist()     # each row exactly once
         assert torch.equal(live[:rows].cpu().bool(), touched)
+        # housekeeping between steps: the valid prefix gets address-ordered (a permutation; the count
+        # it uses is the one read back asynchronously by the previous call)
+        ar.order_live_list(min_growth=0.0)
+        torch.cuda.synchronize()
+        if step >= 2:
+            k = ar._ordered_n
+            assert 1 < k <= n
+            pre = lst[:k].tolist()
+            assert pre == sorted(pre)
+            assert sorted(lst[:n].tolist()) == torch.nonzero(touched).squeeze(1).tolist()
+    assert ar._ordered_n > 0
     # rebuilt from the moments (restore / re-shard path) it is the same set
     ar.live = None
     _, lst2, cnt2 = ar.live_state()
