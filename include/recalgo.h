@@ -343,6 +343,18 @@ int recalgo_mark_live_rows(const int64_t* ids, const int64_t* row_base, int64_t 
 int recalgo_adam_tf1_list(float* p, float* g, float* m, float* v, const int* live_list,
                           const int* live_count, int64_t max_rows, int K, float lr_t, const float* lr_t_dev,
                           float beta1, float beta2, float eps, int zero_grad, recalgo_stream_t stream);
+/* Owner bucketing of one batch's row requests for row-sharded arenas (the reference is
+ * single-process and has no counterpart): global row r is owned by rank r % world at local row
+ * r / world.  rows [M] int64 (< 0 = no request).  Outputs, all int64: send_local [world*cap] — bucket
+ * w occupies [w*cap, (w+1)*cap), holds the owner-local rows requested from rank w, -1 padded;
+ * send_pos [world*cap] (may be NULL) — the request index i each bucket entry came from, -1 for padding;
+ * req_slot [M] — the bucket entry of request i, -1 for no request or a dropped one.  A bucket that
+ * would exceed cap sets overflow[0] = 1 (sticky, never cleared here) and drops the surplus requests.
+ * counters [world] int32 is scratch.  Order inside a bucket is unspecified.  Two launches, no host
+ * synchronisation (hipGraph replayable). */
+int recalgo_exchange_plan(const int64_t* rows, int64_t M, int world, int64_t cap, int64_t* send_local,
+                          int64_t* send_pos, int64_t* req_slot, int* counters, unsigned char* overflow,
+                          recalgo_stream_t stream);
 /* hipGraph-replayable step counter: step_dev[0] += 1; lr_t_dev[0] = lr*sqrt(1-b2^t)/(1-b1^t)
  * (double precision on device).  Pass lr_t_dev to recalgo_adam_tf1_dense to override lr_t. */
 int recalgo_adam_tf1_advance(int64_t* step_dev, float lr, float beta1, float beta2, float* lr_t_dev,

@@ -83,7 +83,7 @@ def _staged(arena, rows: torch.Tensor):
         return None
     from . import parallel
     plan = sd.plan(rows)
-    return plan, parallel.StagedArena(plan, arena), parallel.identity_ids(rows, rows.shape)
+    return plan, parallel.StagedArena(plan, arena), plan.staged_ids(rows, rows.shape)
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:

@@ -86,6 +86,9 @@ class ExchangePlan:
         out.index_copy_(0, self.send_pos, back)
         return out
 
+    def staged_ids(self, rows: torch.Tensor, shape) -> torch.Tensor:
+        return identity_ids(rows, shape)           # the staged table is in request order
+
     def push_grad(self, staged_grad: torch.Tensor, arena, local_scatter_add) -> None:
         """arena.grad[owner rows] += staged_grad rows (duplicates accumulate on the owner)."""
         K = staged_grad.shape[1]
@@ -96,50 +99,60 @@ class ExchangePlan:
 
 
 class StaticExchangePlan:
-    """Fixed-capacity variant of ExchangePlan: same interface, static shapes, no host sync."""
+    """Fixed-capacity variant of ExchangePlan: same interface, static shapes, no host sync.  The
+    bucketing is one HIP pass (`recalgo_exchange_plan`); the staged table IS the all_to_all receive
+    buffer [world*cap, K] and the kernels address it through `req_slot`, so neither direction needs
+    an unpack copy: forward = owner gather -> all_to_all; backward = all_to_all -> owner scatter-add."""
 
-    def __init__(self, rows: torch.Tensor, sh: ShardSpec, capacity: int, overflow: torch.Tensor):
-        self.sh, self.M = sh, rows.numel()
-        W, M, cap, dev = sh.world, rows.numel(), int(capacity), rows.device
-        self.cap = cap
-        valid = rows >= 0
-        owner = torch.where(valid, rows % W, torch.full_like(rows, W))           # invalid -> sentinel bucket W
-        order = torch.argsort(owner, stable=True)
-        so = owner[order]
-        counts = torch.zeros(W + 1, dtype=torch.int64, device=dev).scatter_add_(0, owner, torch.ones_like(owner))
-        start = torch.cumsum(counts, 0) - counts
-        slot = torch.arange(M, device=dev, dtype=torch.int64) - start[so]
-        keep = (so < W) & (slot < cap)
-        overflow.logical_or_(((so < W) & (slot >= cap)).any().reshape(1))
-        dummy = W * cap
-        dest = torch.where(keep, so * cap + slot, torch.full_like(so, dummy))
-        send_local = torch.full((W * cap + 1,), -1, dtype=torch.int64, device=dev)
-        send_local.scatter_(0, dest, torch.div(rows[order], W, rounding_mode="floor"))   # slot `dummy` is never read
-        pos = torch.full((W * cap + 1,), M, dtype=torch.int64, device=dev)       # request slot of every buffer entry
-        pos.scatter_(0, dest, order)
-        self.send_pos = pos[:W * cap].contiguous()                               # M = "nobody": a dummy row
-        self.recv_local = torch.empty(W * cap, dtype=torch.int64, device=dev)
-        sh.dist.all_to_all_single(self.recv_local, send_local[:W * cap].contiguous(), group=sh.group)
+    def __init__(self, rows: torch.Tensor, sh: ShardSpec, capacity: int, overflow: torch.Tensor, planner):
+        self.sh, self.M, self.cap = sh, rows.numel(), int(capacity)
+        self.send_local, self.req_slot = planner(rows.reshape(-1), sh.world, self.cap, overflow)
+        self.recv_local = torch.empty_like(self.send_local)
+        sh.dist.all_to_all_single(self.recv_local, self.send_local, group=sh.group)
+
+    def staged_ids(self, rows: torch.Tensor, shape) -> torch.Tensor:
+        return self.req_slot.reshape(shape)
 
     def fetch(self, shard_weight: torch.Tensor, local_gather) -> torch.Tensor:
-        K = shard_weight.shape[1]
         rows_out = local_gather(shard_weight, self.recv_local)                   # id -1 -> zero row
         back = torch.empty_like(rows_out)
         self.sh.dist.all_to_all_single(back, rows_out, group=self.sh.group)
-        out = torch.zeros(self.M + 1, K, dtype=shard_weight.dtype, device=shard_weight.device)
-        out.index_copy_(0, self.send_pos, back)
-        return out[:self.M]
+        return back
 
     def push_grad(self, staged_grad: torch.Tensor, arena, local_scatter_add) -> None:
-        K = staged_grad.shape[1]
-        ext = torch.cat([staged_grad, staged_grad.new_zeros(1, K)], 0)
-        gsend = ext.index_select(0, self.send_pos)
-        grecv = torch.empty_like(gsend)
-        self.sh.dist.all_to_all_single(grecv, gsend, group=self.sh.group)
+        grecv = torch.empty_like(staged_grad)
+        self.sh.dist.all_to_all_single(grecv, staged_grad, group=self.sh.group)
         local_scatter_add(arena, self.recv_local, grecv)                         # id -1 is skipped
 
 
 # ---- the two local kernels of the exchange (HIP; tests substitute CPU doubles) ------------------
+_zero_base = {}
+
+
+def _zero(device) -> torch.Tensor:
+    """int64 [1] = 0 (the row_base of a one-table lookup), one per device, made outside graph capture."""
+    z = _zero_base.get(device)
+    if z is None:
+        z = _zero_base[device] = torch.zeros(1, dtype=torch.int64, device=device)
+    return z
+
+
+def hip_exchange_plan(rows: torch.Tensor, world: int, cap: int, overflow: torch.Tensor):
+    """-> (send_local int64 [world*cap], req_slot int64 [M]) by include/recalgo.h recalgo_exchange_plan."""
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    dev, M = rows.device, rows.numel()
+    send_local = torch.empty(world * cap, dtype=torch.int64, device=dev)
+    req_slot = torch.empty(M, dtype=torch.int64, device=dev)
+    counters = torch.empty(world, dtype=torch.int32, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.check(lib.recalgo_exchange_plan(p(rows.contiguous()), M, world, cap, p(send_local), None, p(req_slot), p(counters),
+                                         p(overflow), st), "recalgo_exchange_plan")
+    return send_local, req_slot
+
+
 def hip_local_gather(shard_weight: torch.Tensor, local_rows: torch.Tensor) -> torch.Tensor:
     import ctypes
     from . import _lib
@@ -147,7 +160,7 @@ def hip_local_gather(shard_weight: torch.Tensor, local_rows: torch.Tensor) -> to
     n, K = local_rows.numel(), shard_weight.shape[1]
     out = torch.empty(n, K, dtype=torch.float32, device=shard_weight.device)
     if n:
-        zero = torch.zeros(1, dtype=torch.int64, device=shard_weight.device)
+        zero = _zero(shard_weight.device)
         st = ctypes.c_void_p(torch.cuda.current_stream(shard_weight.device).cuda_stream)
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         _lib.check(lib.recalgo_embedding_gather_fwd(p(local_rows), p(shard_weight), p(zero), n, 1, K, p(out), K, 0, st),
@@ -163,7 +176,7 @@ def hip_local_scatter_add(arena: EmbeddingArena, local_rows: torch.Tensor, g: to
     shard_grad = arena.grad
     n, K = local_rows.numel(), shard_grad.shape[1]
     if n:
-        zero = torch.zeros(1, dtype=torch.int64, device=shard_grad.device)
+        zero = _zero(shard_grad.device)
         st = ctypes.c_void_p(torch.cuda.current_stream(shard_grad.device).cuda_stream)
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         g = g.contiguous()
@@ -177,9 +190,10 @@ class Sharding:
     r % world == rank (at local index r // world)."""
 
     def __init__(self, sh: ShardSpec, global_rows: int, local_gather=hip_local_gather,
-                 local_scatter_add=hip_local_scatter_add, capacity_factor: Optional[float] = None):
+                 local_scatter_add=hip_local_scatter_add, capacity_factor: Optional[float] = None,
+                 planner=hip_exchange_plan):
         self.sh, self.global_rows = sh, int(global_rows)
-        self.local_gather, self.local_scatter_add = local_gather, local_scatter_add
+        self.local_gather, self.local_scatter_add, self.planner = local_gather, local_scatter_add, planner
         self.capacity_factor = capacity_factor          # None: exact (dynamic) buckets
         self.overflow: Optional[torch.Tensor] = None    # device flag, sticky
 
@@ -195,12 +209,13 @@ class Sharding:
             return ExchangePlan(rows, self.sh)
         if self.overflow is None:
             self.overflow = torch.zeros(1, dtype=torch.bool, device=rows.device)
-        return StaticExchangePlan(rows, self.sh, self.capacity(rows.numel()), self.overflow)
+        return StaticExchangePlan(rows, self.sh, self.capacity(rows.numel()), self.overflow, self.planner)
 
 
 class StagedArena:
-    """The rows one batch needs, fetched from their owners into a local [M, K] table in request
-    order.  Quacks like an EmbeddingArena for the single-GPU kernels (identity ids); the gradient
+    """The rows one batch needs, fetched from their owners into a local table (request order for the
+    exact plan, bucket order for the static plan: `plan.staged_ids` maps each request to its staged
+    row).  Quacks like an EmbeddingArena for the single-GPU kernels; the gradient
     they scatter into `.grad` is pushed back to the owners by `flush_grad()` (called by the op's
     backward right after its kernel)."""
 
@@ -209,7 +224,7 @@ class StagedArena:
         self.name = arena.name + "/staged"
         sd: Sharding = arena.sharding
         self.weight = plan.fetch(arena.weight, sd.local_gather)
-        self.tables = {"__staged__": (0, plan.M)}
+        self.tables = {"__staged__": (0, self.weight.shape[0])}
         self._grad: Optional[torch.Tensor] = None
 
     @property
@@ -241,7 +256,8 @@ def identity_ids(rows: torch.Tensor, shape) -> torch.Tensor:
 
 
 def shard_arena_(arena: EmbeddingArena, sh: ShardSpec, local_gather=hip_local_gather,
-                 local_scatter_add=hip_local_scatter_add, capacity_factor: Optional[float] = None) -> None:
+                 local_scatter_add=hip_local_scatter_add, capacity_factor: Optional[float] = None,
+                 planner=hip_exchange_plan) -> None:
     """Re-shard a fully materialised (replicated-at-init) arena in place: keep rows r % N == rank.
     Every rank must have built the same arena (same seed) — that is what makes N ranks == 1 rank."""
     if getattr(arena, "sharding", None) is not None:
@@ -250,7 +266,7 @@ def shard_arena_(arena: EmbeddingArena, sh: ShardSpec, local_gather=hip_local_ga
     take = lambda t: t[sh.rank::sh.world].contiguous().clone()
     arena.weight, arena.grad, arena.m, arena.v = take(arena.weight), take(arena.grad), take(arena.m), take(arena.v)
     arena.live = None           # live-row bookkeeping is rebuilt for the shard on next use
-    arena.sharding = Sharding(sh, rows, local_gather, local_scatter_add, capacity_factor)
+    arena.sharding = Sharding(sh, rows, local_gather, local_scatter_add, capacity_factor, planner)
 
 
 def unshard_arena(arena: EmbeddingArena, what: str = "weight") -> torch.Tensor:
@@ -271,7 +287,8 @@ def unshard_arena(arena: EmbeddingArena, what: str = "weight") -> torch.Tensor:
 
 
 def attach_data_parallel(est, dist=None, group=None, local_gather=hip_local_gather,
-                         local_scatter_add=hip_local_scatter_add, capacity_factor: Optional[float] = 2.0):
+                         local_scatter_add=hip_local_scatter_add, capacity_factor: Optional[float] = 2.0,
+                         planner=hip_exchange_plan):
     """Make a built Estimator one rank of an N-rank job: shard every embedding arena row-wise,
     all-reduce the flat dense gradient before the optimizer, scale the loss gradient by 1/N.
     `capacity_factor` selects the static (graph-capturable) exchange; None = exact dynamic buckets."""
@@ -285,7 +302,7 @@ def attach_data_parallel(est, dist=None, group=None, local_gather=hip_local_gath
     if est.store.flat is not None and est.store.flat.numel():
         dist.broadcast(est.store.flat, src=0, group=group)
     for ar in est.store.arenas.values():
-        shard_arena_(ar, sh, local_gather, local_scatter_add, capacity_factor)
+        shard_arena_(ar, sh, local_gather, local_scatter_add, capacity_factor, planner)
 
     def grad_hook(store):
         if store.flat_grad is not None and store.flat_grad.numel():

@@ -23,14 +23,7 @@ def _free_port():
     return p
 
 
-def cpu_gather(shard_weight, local_rows):                     # test double of hip_local_gather (id < 0 -> zero row)
-    rows = shard_weight.index_select(0, local_rows.clamp(min=0))
-    return torch.where((local_rows >= 0).unsqueeze(1), rows, torch.zeros_like(rows))
-
-
-def cpu_scatter_add(arena, local_rows, g):                    # test double of hip_local_scatter_add (id < 0 skipped)
-    ok = local_rows >= 0
-    arena.grad.index_add_(0, local_rows[ok], g[ok])
+from tests.dist_doubles import cpu_gather, cpu_scatter_add, torch_exchange_plan  # noqa: E402
 
 
 def _make_arena(K=8, vocabs=(13, 7, 29, 5)):
@@ -78,7 +71,16 @@ def _worker(rank, port, errq, staged=False):
         store.pack()
         est = types.SimpleNamespace(_built=True, store=store, grad_hook=None, loss_grad_scale=None)
         P.attach_data_parallel(est, dist, local_gather=cpu_gather, local_scatter_add=cpu_scatter_add,
-                               capacity_factor=None)
+                               capacity_factor=None, planner=torch_exchange_plan)
+
+        def requested(staged, plan):          # staged rows in request order (zeros where nothing was requested)
+            sid = plan.staged_ids(rows, rows.shape)
+            got = staged.weight[sid.clamp(min=0)]
+            return torch.where((sid >= 0).unsqueeze(1), got, torch.zeros_like(got))
+
+        def add_grad(staged, plan, g):        # what a kernel's backward does: scatter into the staged gradient
+            sid = plan.staged_ids(rows, rows.shape)
+            staged.grad.index_add_(0, sid[sid >= 0], g[sid >= 0])
         w0 = [torch.empty_like(store.flat) for _ in range(WORLD)]
         dist.all_gather(w0, store.flat)
         assert torch.equal(w0[0], w0[1]), "dense variables were not broadcast from rank 0"
@@ -96,10 +98,11 @@ def _worker(rank, port, errq, staged=False):
         splan = ar.sharding.plan(rows)
         assert isinstance(splan, P.StaticExchangePlan)
         sstaged = P.StagedArena(splan, ar)
-        assert torch.equal(sstaged.weight, expect), "static plan: staged rows differ from the table rows"
+        assert torch.equal(requested(sstaged, splan), expect), "static plan: staged rows differ from the table rows"
+        assert sstaged.weight.shape[0] == WORLD * splan.cap
         assert not bool(ar.sharding.overflow.item())
         g_probe = torch.randn(rows.numel(), K, generator=torch.Generator().manual_seed(21 + rank))
-        sstaged.grad.add_(torch.where((rows >= 0).unsqueeze(1), g_probe, torch.zeros(1, K)))
+        add_grad(sstaged, splan, g_probe)
         sstaged.flush_grad()
         static_grad = ar.grad.clone()
         ar.grad.zero_()
@@ -113,8 +116,8 @@ def _worker(rank, port, errq, staged=False):
         ar.sharding.capacity_factor, ar.sharding.overflow = None, None
         plan = ar.sharding.plan(rows)
         staged = P.StagedArena(plan, ar)
-        assert torch.equal(staged.weight, expect), "staged rows differ from the table rows"
-        staged.grad.add_(torch.where((rows >= 0).unsqueeze(1), g_probe, torch.zeros(1, K)))
+        assert torch.equal(requested(staged, plan), expect), "staged rows differ from the table rows"
+        add_grad(staged, plan, g_probe)
         staged.flush_grad()
         assert torch.allclose(ar.grad, static_grad, rtol=1e-6, atol=1e-6), "static and exact plans push different gradients"
         ar.grad.zero_()
@@ -126,7 +129,7 @@ def _worker(rank, port, errq, staged=False):
         # ---- backward: push staged gradients to the owners == single-process scatter-add ----
         g_all = torch.randn(ids_all.numel(), K, generator=torch.Generator().manual_seed(11))
         g_loc = g_all[rank * Bl * len(vocabs):(rank + 1) * Bl * len(vocabs)]
-        staged.grad.add_(torch.where((rows >= 0).unsqueeze(1), g_loc, torch.zeros(1, K)))
+        add_grad(staged, plan, g_loc)
         staged.flush_grad()
         got = P.unshard_arena(ar, "grad")
         rows_all = P.global_rows(ids_all, rb)

@@ -111,3 +111,56 @@ def test_static_exchange_step_is_graph_capturable(dev, pg):
         l1 = g()
         assert_close(l1, l0, what="graph replay loss vs eager", rtol=1e-5)
     assert not exchange_overflowed(graphd)
+
+
+@pytest.mark.parametrize("world,M,capf", [(1, 1000, 1.0), (2, 4097, 2.0), (3, 999, 1.5), (8, 106496, 2.0), (8, 106496, 0.9),
+                                          (64, 20000, 2.0), (100, 5000, 3.0), (4, 63, 4.0), (8, 0, 2.0)])
+def test_exchange_plan_kernel_against_torch_bucketing(dev, world, M, capf):
+    """recalgo_exchange_plan vs the stable torch bucketing (tests/dist_doubles.py): same overflow flag,
+    same bucket contents as multisets (slot order inside a bucket is unspecified), and send_local /
+    send_pos / req_slot mutually consistent."""
+    import ctypes
+    from recalgorithm_amd import _lib
+    from tests.dist_doubles import torch_exchange_plan
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(world * 7919 + M)
+    rows = torch.randint(0, 50000, (M,), generator=g)
+    rows = torch.where(torch.rand(M, generator=g) < 0.3, (rows % 7) * world, rows)        # hot rows on owner 0
+    rows = torch.where(torch.rand(M, generator=g) < 0.1, torch.full_like(rows, -1), rows).to(dev)
+    cap = max(8, int(M * capf / world + 7) // 8 * 8)
+    ovf_ref = torch.zeros(1, dtype=torch.bool, device=dev)
+    sl_ref, rs_ref = torch_exchange_plan(rows, world, cap, ovf_ref)
+    send_local = torch.empty(world * cap, dtype=torch.int64, device=dev)
+    send_pos = torch.empty(world * cap, dtype=torch.int64, device=dev)
+    req_slot = torch.empty(M, dtype=torch.int64, device=dev)
+    counters = torch.empty(world, dtype=torch.int32, device=dev)
+    ovf = torch.zeros(1, dtype=torch.bool, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.recalgo_exchange_plan(p(rows), M, world, cap, p(send_local), p(send_pos), p(req_slot), p(counters), p(ovf), st),
+               "recalgo_exchange_plan")
+    torch.cuda.synchronize()
+    assert bool(ovf.item()) == bool(ovf_ref.item())
+    valid = rows >= 0
+    want = torch.bincount((rows[valid] % world), minlength=world)
+    assert torch.equal(counters.long(), want)                                   # requests per owner
+    filled = (send_local.reshape(world, cap) >= 0).sum(1)
+    assert torch.equal(filled, want.clamp(max=cap))
+    if M:
+        ok = req_slot >= 0
+        assert not bool((ok & ~valid).any())
+        assert int(ok.sum()) == int(filled.sum())
+        assert torch.equal(send_local[req_slot[ok]], rows[ok] // world)
+        assert torch.equal(req_slot[ok] // cap, rows[ok] % world)
+        assert torch.equal(send_pos[req_slot[ok]], torch.nonzero(ok).squeeze(1))
+        assert int((send_pos >= 0).sum()) == int(ok.sum())
+    if not bool(ovf.item()):
+        assert bool((req_slot[valid] >= 0).all()) if M else True
+        a = send_local.reshape(world, cap).sort(1).values
+        b = sl_ref.reshape(world, cap).sort(1).values
+        assert torch.equal(a, b)
+    # send_pos is optional
+    sl2 = torch.empty_like(send_local)
+    _lib.check(lib.recalgo_exchange_plan(p(rows), M, world, cap, p(sl2), None, p(req_slot), p(counters), p(ovf), st), "plan")
+    torch.cuda.synchronize()
+    assert torch.equal(sl2.reshape(world, cap).sort(1).values, send_local.reshape(world, cap).sort(1).values)
