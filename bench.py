@@ -394,11 +394,21 @@ def timed_run(args, device, rank, world, dist, capacity_factor):
     if args.tunable:
         tunable.tuning_enable(False)               # selections are frozen before the timed region
     barrier()
+    marks = []                                      # a HIP event every 25 steps (no sync): per-chunk step times
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if i % 25 == 0:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((i, ev))
         loss = step(i)
     barrier()
     dt = time.perf_counter() - t0
+    end = torch.cuda.Event(enable_timing=True)
+    end.record()
+    end.synchronize()
+    marks.append((args.steps, end))
+    chunk_ms = [round(a[1].elapsed_time(b[1]) / max(b[0] - a[0], 1), 4) for a, b in zip(marks, marks[1:])]
     if dist is not None:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -410,7 +420,7 @@ def timed_run(args, device, rank, world, dist, capacity_factor):
         dist.all_reduce(ovf)
         overflow = float(ovf) > 0
     return {"est": est, "spec": spec, "feats": feats, "workload": workload, "dt": dt, "loss": float(loss),
-            "launch": launch, "overflow": overflow}
+            "launch": launch, "overflow": overflow, "chunk_ms": chunk_ms}
 
 
 def main():
@@ -428,6 +438,7 @@ def main():
     staged = os.environ.get("RECALGO_DIST_BACKEND", "nccl") == "gloo_staged"
     if staged:
         local_rank %= torch.cuda.device_count()
+        args.no_graph = True          # host-staged collectives synchronise: nothing to capture
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -490,6 +501,7 @@ def main():
                                    + (" [gloo_staged bring-up mode: NOT a benchmark]" if staged else "")
                                    if world > 1 else "single")},
         "final_loss": round(loss_v, 6),
+        "ms_per_step_by_chunk_of_25": r["chunk_ms"],
     }
     if rank == 0:
         ks = None

@@ -343,6 +343,15 @@ int recalgo_mark_live_rows(const int64_t* ids, const int64_t* row_base, int64_t 
 int recalgo_adam_tf1_list(float* p, float* g, float* m, float* v, const int* live_list,
                           const int* live_count, int64_t max_rows, int K, float lr_t, const float* lr_t_dev,
                           float beta1, float beta2, float eps, int zero_grad, recalgo_stream_t stream);
+/* Housekeeping for the live-row list: rebuild live_list in ascending row order from the liveness
+ * bytes (same set, live_count rewritten with the same total).  recalgo_mark_live_rows appends rows in
+ * first-touch order; an address-ordered list lets recalgo_adam_tf1_list walk HBM monotonically.  Run
+ * it between steps on the stream the steps run on (every few dozen steps).  row_live as for
+ * recalgo_mark_live_rows (4-byte aligned, padded to a multiple of 4 with zeros); workspace of
+ * recalgo_order_live_list_workspace_bytes(rows).  Three launches, no host synchronisation. */
+int64_t recalgo_order_live_list_workspace_bytes(int64_t rows);
+int recalgo_order_live_list(const unsigned char* row_live, int64_t rows, int* live_list, int* live_count,
+                            void* workspace, recalgo_stream_t stream);
 /* Owner bucketing of one batch's row requests for row-sharded arenas (the reference is
  * single-process and has no counterpart): global row r is owned by rank r % world at local row
  * r / world.  rows [M] int64 (< 0 = no request).  Outputs, all int64: send_local [world*cap] — bucket

@@ -150,6 +150,96 @@ __global__ __launch_bounds__(256) void mark_live_rows_kernel(const int64_t* __re
     if (!(old & bit)) list[atomicAdd(count, 1)] = (int)row;
 }
 
+// Address-ordered rebuild of the live-row list from the liveness bytes (housekeeping between steps:
+// mark_live_rows appends in first-touch order, i.e. at random, and the list Adam then walks HBM at
+// random — measured 40 us vs 32 us in address order for 345 k rows x 64 B x 7 streams).  Ordered
+// compaction in three small launches: per-chunk popcounts, one-block exclusive scan of the chunk
+// counts, ordered write.  A chunk = 1024 liveness words = 4096 rows, one word per thread and round.
+constexpr unsigned kChunkWords = 1024;
+
+__device__ __forceinline__ unsigned live_bytes_in(unsigned w) {       // number of non-zero bytes in a word
+    return ((w & 0xffu) != 0) + ((w & 0xff00u) != 0) + ((w & 0xff0000u) != 0) + ((w & 0xff000000u) != 0);
+}
+
+__global__ __launch_bounds__(256) void live_chunk_count_kernel(const unsigned* __restrict__ live_words,
+                                                               int64_t n_words, int* __restrict__ chunk_count) {
+    __shared__ int part[4];
+    const int64_t base = (int64_t)blockIdx.x * kChunkWords;
+    int c = 0;
+#pragma unroll
+    for (unsigned r = 0; r < kChunkWords / 256; ++r) {
+        const int64_t w = base + r * 256 + threadIdx.x;
+        if (w < n_words) c += (int)live_bytes_in(live_words[w]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_count[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+// exclusive scan of chunk_count in place, total -> live_count[0]; one block, any number of chunks
+__global__ __launch_bounds__(1024) void live_chunk_scan_kernel(int* __restrict__ chunk_count, int n_chunks,
+                                                               int* __restrict__ live_count) {
+    __shared__ int wave_tot[16];
+    __shared__ int carry_s;
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n_chunks; base += 1024) {
+        const int i = base + (int)threadIdx.x;
+        const int x = i < n_chunks ? chunk_count[i] : 0;
+        int incl = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(incl, o, 64);
+            if ((int)lane >= o) incl += y;
+        }
+        if (lane == 63) wave_tot[wv] = incl;
+        __syncthreads();
+        int before = carry_s;
+        for (unsigned k = 0; k < wv; ++k) before += wave_tot[k];
+        if (i < n_chunks) chunk_count[i] = before + incl - x;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) live_count[0] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void live_chunk_write_kernel(const unsigned* __restrict__ live_words,
+                                                               int64_t n_words, int64_t rows,
+                                                               const int* __restrict__ chunk_base,
+                                                               int* __restrict__ list) {
+    __shared__ int wave_tot[4];
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * kChunkWords;
+    int out = chunk_base[blockIdx.x];
+    for (unsigned r = 0; r < kChunkWords / 256; ++r) {
+        const int64_t w = base + r * 256 + threadIdx.x;
+        const unsigned word = w < n_words ? live_words[w] : 0u;
+        const int x = (int)live_bytes_in(word);
+        int incl = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(incl, o, 64);
+            if ((int)lane >= o) incl += y;
+        }
+        if (lane == 63) wave_tot[wv] = incl;
+        __syncthreads();
+        int pos = out + incl - x;
+        for (unsigned k = 0; k < wv; ++k) pos += wave_tot[k];
+#pragma unroll
+        for (unsigned b = 0; b < 4; ++b)
+            if ((word >> (8 * b)) & 0xffu) {
+                const int64_t row = w * 4 + b;
+                if (row < rows) list[pos++] = (int)row;
+            }
+        out += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __syncthreads();
+    }
+}
+
 template <int K4>
 __global__ __launch_bounds__(256) void adam_tf1_list_kernel(float* __restrict__ p, float* __restrict__ g,
                                                             float* __restrict__ m, float* __restrict__ v,
@@ -324,6 +414,28 @@ RECALGO_EXPORT int recalgo_mark_live_rows(const int64_t* ids, const int64_t* row
     if (n == 0) return 0;
     hipLaunchKernelGGL(mark_live_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), ids, row_base, n,
                        (unsigned)F, reinterpret_cast<unsigned*>(row_live), live_list, live_count);
+    RECALGO_RETURN_LAST();
+}
+
+RECALGO_EXPORT int64_t recalgo_order_live_list_workspace_bytes(int64_t rows) {
+    const int64_t n_words = (rows + 3) / 4;
+    return ((n_words + kChunkWords - 1) / kChunkWords) * (int64_t)sizeof(int);
+}
+
+RECALGO_EXPORT int recalgo_order_live_list(const unsigned char* row_live, int64_t rows, int* live_list,
+                                           int* live_count, void* workspace, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(rows >= 0 && row_live != nullptr && live_list != nullptr && live_count != nullptr);
+    RECALGO_REQUIRE((reinterpret_cast<uintptr_t>(row_live) & 3) == 0);
+    if (rows == 0) return 0;
+    RECALGO_REQUIRE(workspace != nullptr);
+    hipStream_t st = as_stream(stream);
+    const int64_t n_words = (rows + 3) / 4;
+    const int n_chunks = cdiv(n_words, kChunkWords);
+    const unsigned* words = reinterpret_cast<const unsigned*>(row_live);
+    int* chunk = static_cast<int*>(workspace);
+    hipLaunchKernelGGL(live_chunk_count_kernel, dim3(n_chunks), dim3(256), 0, st, words, n_words, chunk);
+    hipLaunchKernelGGL(live_chunk_scan_kernel, dim3(1), dim3(1024), 0, st, chunk, n_chunks, live_count);
+    hipLaunchKernelGGL(live_chunk_write_kernel, dim3(n_chunks), dim3(256), 0, st, words, n_words, rows, chunk, live_list);
     RECALGO_RETURN_LAST();
 }
 

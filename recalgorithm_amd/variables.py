@@ -14,6 +14,8 @@ Embedding tables live in `EmbeddingArena`s (see include/recalgo.h "arena").
 """
 from __future__ import annotations
 
+import os
+
 import contextlib
 import math
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
@@ -190,6 +192,8 @@ class VariableStore:
     # -- packing --------------------------------------------------------------------------
     def housekeeping(self) -> None:
         """Cheap, sync-free maintenance the training loops call every few dozen steps."""
+        if os.environ.get("RECALGO_NO_HOUSEKEEPING") == "1":
+            return
         for ar in self.arenas.values():
             if getattr(ar, "tracks_live_rows", False):
                 ar.order_live_list()
@@ -284,8 +288,7 @@ class EmbeddingArena:
         self.weight = self.grad = self.m = self.v = None
         self.live = self.live_list = self.live_count = None   # live-row bookkeeping (see live_state)
         self._live_rows = -1
-        self._cnt_host = self._cnt_event = None                # order_live_list's asynchronous count read-back
-        self._ordered_n = 0
+        self._order_ws = None                                  # order_live_list's scratch
         self.trainable = True
 
     def add_table(self, name: str, vocab: int, init: Optional[torch.Tensor] = None) -> int:
@@ -355,31 +358,27 @@ class EmbeddingArena:
             self.live_list[:idx.numel()] = idx
             self.live_count = torch.tensor([idx.numel()], dtype=torch.int32, device=dev)
             self._live_rows = rows
-            self._ordered_n, self._cnt_event = idx.numel(), None   # nonzero() lists ascending rows
+            self._order_ws = None
         return self.live, self.live_list, self.live_count
 
-    def order_live_list(self, min_growth: float = 0.02) -> None:
-        """Housekeeping between steps, no host synchronisation: put the live-row list in address order.
-        recalgo_mark_live_rows appends rows in first-touch order, i.e. at random; the list Adam then
-        walks HBM at random (measured: 40 us vs 32 us address-ordered, 345 k rows x 64 B x 7 streams).
-        Any permutation of the valid prefix is an equivalent list, so the prefix is sorted in place
-        whenever it has grown by `min_growth` since the last sort.  The prefix length comes from an
-        asynchronous copy of the device counter issued by the PREVIOUS call: a stale count is a lower
-        bound (the list is append-only), and nothing here waits for the GPU."""
+    def order_live_list(self) -> None:
+        """Housekeeping between steps, no host synchronisation: rebuild the live-row list in address
+        order (include/recalgo.h recalgo_order_live_list).  recalgo_mark_live_rows appends rows in
+        first-touch order, i.e. at random; the list Adam then walks HBM at random (measured: 40 us vs
+        32 us address-ordered, 345 k rows x 64 B x 7 streams)."""
         if self.live is None or not self.weight.is_cuda:
             return
-        if self._cnt_host is None:
-            self._cnt_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        if self._cnt_event is not None and self._cnt_event.query():
-            n = min(int(self._cnt_host[0]), self.live_list.numel())
-            if n > 1 and n > self._ordered_n * (1.0 + min_growth):
-                self.live_list[:n] = torch.sort(self.live_list[:n]).values
-                self._ordered_n = n
-            self._cnt_event = None
-        if self._cnt_event is None:
-            self._cnt_host.copy_(self.live_count, non_blocking=True)
-            self._cnt_event = torch.cuda.Event()
-            self._cnt_event.record()
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        rows = self.weight.shape[0]
+        if self._order_ws is None:
+            self._order_ws = torch.empty(max(int(lib.recalgo_order_live_list_workspace_bytes(rows)), 4), dtype=torch.uint8,
+                                         device=self.weight.device)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        st = ctypes.c_void_p(torch.cuda.current_stream(self.weight.device).cuda_stream)
+        _lib.check(lib.recalgo_order_live_list(p(self.live), rows, p(self.live_list), p(self.live_count), p(self._order_ws), st),
+                   "recalgo_order_live_list")
 
     def live_rows(self) -> torch.Tensor:
         """uint8 [rows]: 1 where a gradient has reached the row."""

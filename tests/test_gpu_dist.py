@@ -163,4 +163,6 @@ def test_exchange_plan_kernel_against_torch_bucketing(dev, world, M, capf):
     sl2 = torch.empty_like(send_local)
     _lib.check(lib.recalgo_exchange_plan(p(rows), M, world, cap, p(sl2), None, p(req_slot), p(counters), p(ovf), st), "plan")
     torch.cuda.synchronize()
-    assert torch.equal(sl2.reshape(world, cap).sort(1).values, send_local.reshape(world, cap).sort(1).values)
+    if not bool(ovf.item()):          # which requests an overflowing bucket drops is unspecified
+        assert torch.equal(sl2.reshape(world, cap).sort(1).values, send_local.reshape(world, cap).sort(1).values)
+    assert torch.equal((sl2.reshape(world, cap) >= 0).sum(1), filled)

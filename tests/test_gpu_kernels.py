@@ -406,18 +406,36 @@ def test_live_row_list_adam_is_bit_identical_to_dense(dev, rows, K, F):
         assert n == int(touched.sum())
         assert sorted(lst[:n].tolist()) == torch.nonzero(touched).squeeze(1).tolist()     # each row exactly once
         assert torch.equal(live[:rows].cpu().bool(), touched)
-        # housekeeping between steps: the valid prefix gets address-ordered (a permutation; the count
-        # it uses is the one read back asynchronously by the previous call)
-        ar.order_live_list(min_growth=0.0)
-        torch.cuda.synchronize()
-        if step >= 2:
-            k = ar._ordered_n
-            assert 1 < k <= n
-            pre = lst[:k].tolist()
-            assert pre == sorted(pre)
-            assert sorted(lst[:n].tolist()) == torch.nonzero(touched).squeeze(1).tolist()
-    assert ar._ordered_n > 0
+        # housekeeping between steps: the list is rebuilt in address order from the liveness bytes
+        if step % 2 == 0:
+            ar.order_live_list()
+            assert int(cnt.item()) == n
+            assert lst[:n].tolist() == torch.nonzero(touched).squeeze(1).tolist()
     # rebuilt from the moments (restore / re-shard path) it is the same set
     ar.live = None
     _, lst2, cnt2 = ar.live_state()
     assert sorted(lst2[:int(cnt2.item())].tolist()) == torch.nonzero(touched).squeeze(1).tolist()
+
+
+@pytest.mark.parametrize("rows,density", [(1, 1.0), (4095, 0.5), (4097, 0.01), (300001, 0.12), (5_000_003, 0.1), (5_000_003, 0.0)])
+def test_order_live_list_matches_nonzero(dev, rows, density):
+    """recalgo_order_live_list == torch.nonzero(row_live) (ascending), count included; covers partial
+    words, chunk boundaries and more than one round of the chunk scan (> 1024 chunks of 4096 rows)."""
+    import ctypes
+    from recalgorithm_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(rows)
+    live = torch.zeros((rows + 3) // 4 * 4, dtype=torch.uint8)
+    live[:rows] = (torch.rand(rows, generator=g) < density).to(torch.uint8) * torch.randint(1, 255, (rows,), generator=g).to(torch.uint8)
+    live = live.to(dev)
+    lst = torch.full((rows,), -7, dtype=torch.int32, device=dev)
+    cnt = torch.full((1,), -1, dtype=torch.int32, device=dev)
+    ws = torch.empty(max(int(lib.recalgo_order_live_list_workspace_bytes(rows)), 4), dtype=torch.uint8, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.recalgo_order_live_list(p(live), rows, p(lst), p(cnt), p(ws), st), "recalgo_order_live_list")
+    want = torch.nonzero(live[:rows]).squeeze(1).to(torch.int32)
+    n = int(cnt.item())
+    assert n == want.numel()
+    assert torch.equal(lst[:n], want)
+    assert bool((lst[n:] == -7).all())
