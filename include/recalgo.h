@@ -270,6 +270,20 @@ int recalgo_pnn_weights_fwd(const float* product_w, int D, int F, int K, int met
 int recalgo_pnn_weights_bwd(const float* product_w, const float* domega, int D, int F, int K,
                             int method, float* d_product_w, recalgo_stream_t stream);
 
+/* One-unit dense head over a virtual concatenation of n_parts (1..4) row-major inputs x_p [B, widths[p]]:
+ *   out[b] = bias[0] + sum_p <x_p[b,:], w[off_p : off_p + widths[p]]>,   off_p = sum of earlier widths
+ * = `tf.layers.dense(tf.concat([...], -1), 1)`, the logit tail of every model (dcn.py:160-162,
+ * deepfm.py:300, xdeepfm.py, din.py, fibinet.py, pnn.py: last dense of the dnn part), without
+ * materialising the concat.  x_parts / dx_parts / widths are HOST arrays (read at launch).
+ * Backward: dx_p[b,:] = g[b] * w[off_p:...] (entries of dx_parts, or dx_parts itself, may be NULL),
+ * dw[C] = sum_b g[b] x[b,:], dbias[0] = sum_b g[b] (NULL to skip); gradients are assigned, fixed
+ * summation order.  C = sum of widths.  workspace of recalgo_dense1_bwd_workspace_bytes(B, C). */
+int recalgo_dense1_fwd(const float* const* x_parts, const int* widths, int n_parts, int B, const float* w,
+                       const float* bias, float* out, recalgo_stream_t stream);
+int64_t recalgo_dense1_bwd_workspace_bytes(int B, int C);
+int recalgo_dense1_bwd(const float* const* x_parts, const int* widths, int n_parts, int B, const float* w,
+                       const float* g, float* const* dx_parts, float* dw, float* dbias, void* workspace,
+                       recalgo_stream_t stream);
 /* ------------------------------------------------------------------------------------------
  * Context-MLP glue around the library GEMMs (not interaction layers; fused because the step is
  * otherwise dominated by their launch count).  Widths must satisfy recalgo_mlp_width_supported(C)

@@ -58,6 +58,9 @@ SIGNATURES = {
     "recalgo_adam_tf1_dense": (c_int, [P, P, P, P, c_int64, c_float, P, c_float, c_float, c_float, c_int, P]),
     "recalgo_adam_tf1_rows": (c_int, [P, P, P, P, P, c_int64, c_int, c_float, P, c_float, c_float, c_float, c_int, P]),
     "recalgo_mark_live_rows": (c_int, [P, P, c_int64, c_int, P, P, P, P]),
+    "recalgo_dense1_fwd": (c_int, [P, P, c_int, c_int, P, P, P, P]),
+    "recalgo_dense1_bwd_workspace_bytes": (c_int64, [c_int, c_int]),
+    "recalgo_dense1_bwd": (c_int, [P, P, c_int, c_int, P, P, P, P, P, P, P]),
     "recalgo_order_live_list_workspace_bytes": (c_int64, [c_int64]),
     "recalgo_order_live_list": (c_int, [P, c_int64, P, P, P, P]),
     "recalgo_exchange_plan": (c_int, [P, c_int64, c_int, c_int64, P, P, P, P, P, P]),

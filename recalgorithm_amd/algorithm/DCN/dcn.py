@@ -99,7 +99,7 @@ def dcn_model_fn(features, labels, mode, params):
             dnn_vec = nn.dense(dnn_vec, unit, activation="relu", name=f"dnn_dense_{i}")
 
     with variable_scope("output_part"):
-        output = torch.cat([cross_vec, dnn_vec], dim=-1)
+        output = nn.concat([cross_vec, dnn_vec], axis=-1)       # read in place by the one-unit head (nn.LazyConcat)
         logit = nn.dense(output, 1, activation=None)
 
     return finish_model_fn(mode, logit, labels, params,

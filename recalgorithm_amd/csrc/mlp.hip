@@ -198,7 +198,129 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
 inline bool width_ok(int C) { return C >= 4 && C % 4 == 0 && C / 4 <= kThreads && kThreads % (C / 4) == 0; }
 inline int nblk_of(int rows) { return cdiv(rows, kRowsPerBlk); }
 
+// ---------------------------------------------------------------------------------------
+// One-unit dense head over a (virtual) concatenation of up to 4 row-major inputs:
+//   logit[b] = bias + sum_p <x_p[b, :], w[off_p : off_p + width_p]>
+// the `tf.concat([...]) -> tf.layers.dense(., 1)` tail every model ends with.  As library calls it
+// is a concat copy + split-K GEMV (2 launches) forward and a reduce, a GEMV, a rank-1 GEMM and two
+// slice copies backward — ~10 launches of ~5 us for 9 MB of traffic.  Here: one pass each way.
+// ---------------------------------------------------------------------------------------
+constexpr int kHeadMaxParts = 4;
+struct HeadParts {
+    const float* x[kHeadMaxParts];
+    float* dx[kHeadMaxParts];
+    int width[kHeadMaxParts];
+    int n;
+};
+
+// one wave per example; lanes stride the columns (each wave load = 256 contiguous bytes)
+__global__ __launch_bounds__(256) void dense1_fwd_kernel(HeadParts P, int B, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ out) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const unsigned lane = threadIdx.x & 63;
+    if (b >= B) return;
+    float acc = 0.f;
+    int off = 0;
+    for (int p = 0; p < P.n; ++p) {
+        const float* __restrict__ xr = P.x[p] + (size_t)b * P.width[p];
+        for (int j = lane; j < P.width[p]; j += 64) acc = fmaf(xr[j], w[off + j], acc);
+        off += P.width[p];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[b] = acc + (bias ? bias[0] : 0.f);
+}
+
+// block = kHeadRows examples; thread t owns columns t, t+256, ...: dx[b, c] = g[b] w[c] is written and
+// dw[c] += g[b] x[b, c] accumulated in the same pass over x.  Per-block partial rows of dw (and of
+// db in column C) are summed in fixed order by colsum16.
+constexpr int kHeadRows = 16;
+__global__ __launch_bounds__(256) void dense1_bwd_kernel(HeadParts P, int B, int C, const float* __restrict__ w,
+                                                         const float* __restrict__ g, float* __restrict__ partials) {
+    __shared__ float gs[kHeadRows];
+    const int b0 = blockIdx.x * kHeadRows;
+    const int nb = min(kHeadRows, B - b0);
+    if ((int)threadIdx.x < kHeadRows) gs[threadIdx.x] = (int)threadIdx.x < nb ? g[b0 + threadIdx.x] : 0.f;
+    __syncthreads();
+    float* __restrict__ prow = partials + (size_t)blockIdx.x * (C + 1);
+    int off = 0;
+    for (int p = 0; p < P.n; ++p) {
+        const int W = P.width[p];
+        for (int j = threadIdx.x; j < W; j += 256) {
+            const float wj = w[off + j];
+            float acc = 0.f;
+#pragma unroll 4
+            for (int r = 0; r < nb; ++r) {
+                const size_t at = (size_t)(b0 + r) * W + j;
+                acc = fmaf(gs[r], P.x[p][at], acc);
+                if (P.dx[p]) P.dx[p][at] = gs[r] * wj;
+            }
+            prow[off + j] = acc;
+        }
+        off += W;
+    }
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int r = 0; r < nb; ++r) s += gs[r];
+        prow[C] = s;
+    }
+}
+
 }  // namespace
+
+static int head_parts(const float* const* x_parts, float* const* dx_parts, const int* widths, int n_parts,
+                      HeadParts* P) {
+    if (n_parts < 1 || n_parts > kHeadMaxParts || x_parts == nullptr || widths == nullptr) return -1;
+    int C = 0;
+    P->n = n_parts;
+    for (int p = 0; p < kHeadMaxParts; ++p) {
+        const bool on = p < n_parts;
+        if (on && (x_parts[p] == nullptr || widths[p] < 1)) return -1;
+        P->x[p] = on ? x_parts[p] : nullptr;
+        P->dx[p] = on && dx_parts ? dx_parts[p] : nullptr;
+        P->width[p] = on ? widths[p] : 0;
+        C += P->width[p];
+    }
+    return C;
+}
+
+RECALGO_EXPORT int recalgo_dense1_fwd(const float* const* x_parts, const int* widths, int n_parts, int B,
+                                      const float* w, const float* bias, float* out, recalgo_stream_t stream) {
+    HeadParts P;
+    const int C = head_parts(x_parts, nullptr, widths, n_parts, &P);
+    RECALGO_REQUIRE(C > 0 && B >= 0 && w != nullptr && out != nullptr);
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(dense1_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, as_stream(stream), P, B, w, bias, out);
+    RECALGO_RETURN_LAST();
+}
+
+RECALGO_EXPORT int64_t recalgo_dense1_bwd_workspace_bytes(int B, int C) {
+    return (int64_t)cdiv(B > 0 ? B : 1, kHeadRows) * (C + 1) * (int64_t)sizeof(float);
+}
+
+RECALGO_EXPORT int recalgo_dense1_bwd(const float* const* x_parts, const int* widths, int n_parts, int B,
+                                      const float* w, const float* g, float* const* dx_parts, float* dw, float* dbias,
+                                      void* workspace, recalgo_stream_t stream) {
+    HeadParts P;
+    const int C = head_parts(x_parts, dx_parts, widths, n_parts, &P);
+    RECALGO_REQUIRE(C > 0 && B >= 0 && w != nullptr && dw != nullptr);
+    hipStream_t st = as_stream(stream);
+    if (B == 0) {
+        (void)hipMemsetAsync(dw, 0, (size_t)C * sizeof(float), st);
+        if (dbias) (void)hipMemsetAsync(dbias, 0, sizeof(float), st);
+        RECALGO_RETURN_LAST();
+    }
+    RECALGO_REQUIRE(g != nullptr && workspace != nullptr);
+    const int blocks = cdiv(B, kHeadRows);
+    float* partials = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(dense1_bwd_kernel, dim3(blocks), dim3(256), 0, st, P, B, C, w, g, partials);
+    // columns [0, C) -> dw, column C -> dbias (a scratch float of the workspace row 0 is not needed: colsum16 splits)
+    if (dbias) {
+        launch_colsum16(partials, (unsigned)blocks, (unsigned)(C + 1), dw, (unsigned)C, dbias, st);
+    } else {
+        launch_colsum16(partials, (unsigned)blocks, (unsigned)C, dw, (unsigned)C, dw, st);
+    }
+    RECALGO_RETURN_LAST();
+}
 
 RECALGO_EXPORT int recalgo_mlp_width_supported(int C) { return width_ok(C) ? 1 : 0; }
 

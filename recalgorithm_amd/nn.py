@@ -57,7 +57,51 @@ class _DenseFn(Function):
         return None, dx.view(ctx.xshape), None, None, None
 
 
-def dense(x: torch.Tensor, units, activation: Optional[str] = None,
+class _Dense1Fn(Function):
+    """tf.layers.dense(tf.concat(parts, -1), 1): one fused pass each way (csrc/mlp.hip dense1_*)."""
+
+    @staticmethod
+    def forward(ctx, anchor, kernel: Variable, bias: Optional[Variable], *parts):
+        from . import ops
+        ctx.vars = (kernel, bias)
+        ctx.save_for_backward(*parts)
+        return ops.dense1_fwd(parts, kernel.data, None if bias is None else bias.data)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        kernel, bias = ctx.vars
+        parts = ctx.saved_tensors
+        dxs = [torch.empty_like(t) if need else None for t, need in zip(parts, ctx.needs_input_grad[3:])]
+        ops.dense1_bwd(parts, kernel.data, g.contiguous(), dxs, kernel.grad, None if bias is None else bias.grad)
+        return (None, None, None, *dxs)
+
+
+class LazyConcat:
+    """`tf.concat(values, axis=-1)` whose consumer is a one-unit `dense`: the head kernel reads the
+    parts in place, so the [B, sum(widths)] copy (and the two slice copies of its gradient) never
+    happen.  Any other use goes through `materialize()`."""
+
+    def __init__(self, values):
+        self.parts = list(values)
+
+    @property
+    def shape(self):
+        return (*self.parts[0].shape[:-1], sum(int(t.shape[-1]) for t in self.parts))
+
+    def materialize(self) -> torch.Tensor:
+        return torch.cat(self.parts, dim=-1)
+
+
+def concat(values, axis: int = -1):
+    """tf.concat along the last axis; lazy (see LazyConcat) when every value is a 2-D device tensor."""
+    values = list(values)
+    if axis in (-1, values[0].dim() - 1) and len(values) <= 4 and all(t.dim() == 2 and t.is_cuda for t in values):
+        return LazyConcat(values)
+    return torch.cat(values, dim=axis)
+
+
+def dense(x, units, activation: Optional[str] = None,
           use_bias: bool = True, name: Optional[str] = None) -> torch.Tensor:
     """tf.layers.dense(x, units, activation=None|relu, use_bias, name).  `units` may be a
     str (the reference passes FLAGS.hidden_units.split(','), deepfm.py:286; quirk B-2).
@@ -70,6 +114,14 @@ def dense(x: torch.Tensor, units, activation: Optional[str] = None,
         bias = store.get_variable("bias", (units,), zeros) if use_bias else None
     if activation not in (None, "relu"):
         raise ValueError(f"unsupported activation {activation}")
+    parts = x.parts if isinstance(x, LazyConcat) else [x]
+    if units == 1 and activation is None:
+        from . import ops
+        parts = [t if t.is_contiguous() else t.contiguous() for t in parts]
+        if ops.dense1_supported(parts):
+            return _Dense1Fn.apply(store.anchor, kernel, bias, *parts)
+    if isinstance(x, LazyConcat):
+        x = x.materialize()
     return _DenseFn.apply(store.anchor, x, kernel, bias, activation == "relu")
 
 

@@ -639,6 +639,38 @@ def relu_bwd_bias_(g: torch.Tensor, y: Optional[torch.Tensor], dbias: torch.Tens
     return g if y is None else g2
 
 
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def dense1_supported(parts) -> bool:
+    """The one-unit head kernel takes 1..4 contiguous fp32 [B, w] device tensors with one B."""
+    return (1 <= len(parts) <= 4 and all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous()
+                                         and t.shape[0] == parts[0].shape[0] and t.shape[1] >= 1 for t in parts))
+
+
+def dense1_fwd(parts, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """[B, 1] = concat(parts, -1) @ w + bias without the concat (include/recalgo.h recalgo_dense1_fwd)."""
+    import ctypes
+    B = parts[0].shape[0]
+    widths = (ctypes.c_int * len(parts))(*[int(t.shape[1]) for t in parts])
+    out = torch.empty(B, 1, dtype=torch.float32, device=parts[0].device)
+    _lib.check(_lib_().recalgo_dense1_fwd(_ptr_array(parts), widths, len(parts), B, _p(w), _p(bias), _p(out), _stream(out)),
+               "recalgo_dense1_fwd")
+    return out
+
+
+def dense1_bwd(parts, w: torch.Tensor, g: torch.Tensor, dxs, dw: torch.Tensor, dbias: Optional[torch.Tensor]) -> None:
+    import ctypes
+    B, C = parts[0].shape[0], sum(int(t.shape[1]) for t in parts)
+    lib = _lib_()
+    widths = (ctypes.c_int * len(parts))(*[int(t.shape[1]) for t in parts])
+    ws = _workspace(lib.recalgo_dense1_bwd_workspace_bytes(B, C), g.device)
+    _lib.check(lib.recalgo_dense1_bwd(_ptr_array(parts), widths, len(parts), B, _p(w), _p(g), _ptr_array(dxs), _p(dw), _p(dbias),
+                                      _p(ws), _stream(g)), "recalgo_dense1_bwd")
+
+
 def batchnorm_train_fwd(x, gamma, beta, moving_mean, moving_var, momentum: float, eps: float):
     rows, C = x.shape
     lib = _lib_()

@@ -439,3 +439,34 @@ def test_order_live_list_matches_nonzero(dev, rows, density):
     assert n == want.numel()
     assert torch.equal(lst[:n], want)
     assert bool((lst[n:] == -7).all())
+
+
+@pytest.mark.parametrize("B,widths,bias,skip_dx", [(4096, (416, 128), True, None), (1000, (82,), True, None), (15, (1,), False, None),
+                                                   (257, (7, 130, 3, 64), True, 1), (1, (300, 20), False, 0), (0, (16, 8), True, None),
+                                                   (513, (2048,), True, None)])
+def test_dense1_head_against_torch(dev, B, widths, bias, skip_dx):
+    """recalgo_dense1_{fwd,bwd} == concat + matmul (fp64 reference), incl. unaligned widths, missing
+    bias, a part that needs no input gradient, an empty batch."""
+    g = torch.Generator().manual_seed(B + sum(widths))
+    parts = [torch.randn(B, w, generator=g).to(dev) for w in widths]
+    C = sum(widths)
+    w = torch.randn(C, 1, generator=g).to(dev)
+    b = torch.randn(1, generator=g).to(dev) if bias else None
+    out = ops.dense1_fwd(parts, w, b)
+    x64 = torch.cat([p.double() for p in parts], 1) if B else torch.zeros(0, C, dtype=torch.float64, device=dev)
+    ref = x64 @ w.double() + (b.double() if bias else 0.0)
+    assert out.shape == (B, 1)
+    assert_close(out, ref, what="dense1 fwd")
+    gl = torch.randn(B, 1, generator=g).to(dev)
+    dxs = [None if i == skip_dx else torch.full_like(p, float("nan")) for i, p in enumerate(parts)]
+    dw = torch.full((C, 1), float("nan"), device=dev)
+    db = torch.full((1,), float("nan"), device=dev) if bias else None
+    ops.dense1_bwd(parts, w, gl, dxs, dw, db)
+    assert_close(dw, x64.t() @ gl.double(), what="dense1 dw", reduced=True)
+    if bias:
+        assert_close(db, gl.double().sum().reshape(1), what="dense1 dbias", reduced=True)
+    off = 0
+    for i, (p, dx) in enumerate(zip(parts, dxs)):
+        if dx is not None:
+            assert_close(dx, gl.double() * w.double()[off:off + p.shape[1]].t(), what=f"dense1 dx[{i}]")
+        off += p.shape[1]
