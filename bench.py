@@ -168,6 +168,13 @@ def kernel_rooflines(args, est, feats, device):
     names = sorted(feats.keys())
     ids = torch.stack([feats[n] for n in names if isinstance(feats[n], torch.Tensor) and feats[n].dtype == torch.int64], 1).contiguous()
     rb = torch.tensor([ar.tables[t][0] for t in list(ar.tables)[:F]], dtype=torch.int64, device=device)
+    sd = getattr(ar, "sharding", None)
+    if sd is not None:
+        # N > 1: this rank's arena holds the rows r % N == rank at r // N.  The per-kernel table times
+        # the local kernels on the shard, so the batch's rows are folded into it (same distribution)
+        rows = ids + rb.unsqueeze(0)
+        ids = torch.where(ids >= 0, torch.div(rows, sd.sh.world, rounding_mode="floor"), ids).contiguous()
+        rb = torch.zeros_like(rb)
     x0 = torch.empty(B, d, device=device)
     out = torch.empty(B, d, device=device)
     g = torch.randn(B, d, device=device)

@@ -87,7 +87,7 @@ def build_host(force: bool = False, verbose: bool = True) -> str:
         os.path.getmtime(HOST_LIB) < max(os.path.getmtime(HOST_SRC), os.path.getmtime(hdr))
     if stale:
         cxx = shutil.which("g++") or "g++"
-        cmd = [cxx, "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", f"-I{INCLUDE}",
+        cmd = [cxx, "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fvisibility=hidden", "-Wall", f"-I{INCLUDE}",
                HOST_SRC, "-o", HOST_LIB]
         if verbose:
             print("[recalgo build]", " ".join(cmd), flush=True)

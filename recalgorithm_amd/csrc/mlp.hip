@@ -294,7 +294,7 @@ RECALGO_EXPORT int recalgo_dense1_fwd(const float* const* x_parts, const int* wi
 }
 
 RECALGO_EXPORT int64_t recalgo_dense1_bwd_workspace_bytes(int B, int C) {
-    return (int64_t)cdiv(B > 0 ? B : 1, kHeadRows) * (C + 1) * (int64_t)sizeof(float);
+    return ((int64_t)cdiv(B > 0 ? B : 1, kHeadRows) * (C + 1) + 1) * (int64_t)sizeof(float);   // + 1 scratch float
 }
 
 RECALGO_EXPORT int recalgo_dense1_bwd(const float* const* x_parts, const int* widths, int n_parts, int B,
@@ -313,12 +313,9 @@ RECALGO_EXPORT int recalgo_dense1_bwd(const float* const* x_parts, const int* wi
     const int blocks = cdiv(B, kHeadRows);
     float* partials = static_cast<float*>(workspace);
     hipLaunchKernelGGL(dense1_bwd_kernel, dim3(blocks), dim3(256), 0, st, P, B, C, w, g, partials);
-    // columns [0, C) -> dw, column C -> dbias (a scratch float of the workspace row 0 is not needed: colsum16 splits)
-    if (dbias) {
-        launch_colsum16(partials, (unsigned)blocks, (unsigned)(C + 1), dw, (unsigned)C, dbias, st);
-    } else {
-        launch_colsum16(partials, (unsigned)blocks, (unsigned)C, dw, (unsigned)C, dw, st);
-    }
+    // columns [0, C) -> dw, column C -> dbias (or the scratch float behind the partial rows)
+    launch_colsum16(partials, (unsigned)blocks, (unsigned)(C + 1), dw, (unsigned)C,
+                    dbias ? dbias : partials + (size_t)blocks * (C + 1), st);
     RECALGO_RETURN_LAST();
 }
 

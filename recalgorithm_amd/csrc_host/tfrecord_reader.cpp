@@ -10,13 +10,20 @@
 //   SequenceExample: field 1 (context) is read like Example.features, field 2 (feature_lists) is
 //   skipped — exactly what tf.parse_example does.
 //   vocabulary id = 0-based line number of the key, -1 when absent (A-2).
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <unordered_map>
 #include <vector>
+#include <algorithm>
 
 #include "../../include/recalgo_host.h"
 
@@ -106,6 +113,92 @@ struct Vocab {
     std::unordered_map<std::string_view, int64_t> map;
 };
 
+// ---- a small persistent worker pool: decode is per-record independent ------------------------------
+// parallel_for(n, f) runs f(chunk) for chunk in [0, n) on the workers and the calling thread; chunks
+// are handed out by an atomic counter.  RECALGO_READER_THREADS (default: hardware threads, at most
+// 16; 1 = everything inline) sizes it.  One job at a time (callers are serialised by the mutex).
+class Pool {
+  public:
+    static Pool& get() {
+        static Pool p;
+        return p;
+    }
+    size_t threads() const { return workers_.size() + 1; }
+    void parallel_for(size_t n, const std::function<void(size_t)>& f) {
+        if (n == 0) return;
+        if (workers_.empty() || n == 1) {
+            for (size_t i = 0; i < n; ++i) f(i);
+            return;
+        }
+        std::lock_guard<std::mutex> serial(call_);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &f;
+            n_ = n;
+            next_.store(0);
+            busy_ = workers_.size();
+            ++gen_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return busy_ == 0; });
+        job_ = nullptr;
+    }
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+
+  private:
+    Pool() {
+        size_t n = std::thread::hardware_concurrency();
+        if (n == 0) n = 1;
+        if (n > 16) n = 16;
+        if (const char* e = std::getenv("RECALGO_READER_THREADS")) {
+            long v = std::atol(e);
+            if (v >= 1 && v <= 256) n = (size_t)v;
+        }
+        for (size_t i = 1; i < n; ++i) workers_.emplace_back([this] { loop(); });
+    }
+    void work() {
+        for (size_t i = next_.fetch_add(1); i < n_; i = next_.fetch_add(1)) (*job_)(i);
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+            }
+            work();
+            std::lock_guard<std::mutex> lk(m_);
+            if (--busy_ == 0) done_.notify_one();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_, call_;
+    std::condition_variable cv_, done_;
+    const std::function<void(size_t)>* job_ = nullptr;
+    size_t n_ = 0, busy_ = 0;
+    std::atomic<size_t> next_{0};
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+constexpr size_t kChunk = 128;                             // records per parallel_for chunk
+
+struct Entry {                                             // one (feature name -> Feature message) pair
+    std::string_view name;
+    Span feat;
+};
+
 struct Reader {
     FILE* f = nullptr;
     bool verify = false;
@@ -116,36 +209,61 @@ struct Reader {
     bool source_done = false;
     std::vector<uint8_t> buf;                              // concatenated payloads of the current batch
     std::vector<size_t> off;                               // record i = buf[off[i] .. off[i+1])
-    // per record: feature name -> Feature message span (built lazily per batch)
-    std::vector<std::unordered_map<std::string_view, Span>> index;
+    // per record: its (name, Feature span) pairs in wire order (built lazily per batch).  Records of
+    // one writer list their features in one order, so a lookup starts at the position the key had
+    // in the previous record and is O(1) in practice; a repeated map key keeps its LAST entry
+    // (protobuf map semantics; resolved while the index is built).
+    std::vector<std::vector<Entry>> index;
     bool indexed = false;
     std::string error;
 };
 
+const Span* find_feature(const std::vector<Entry>& idx, std::string_view k, size_t& hint) {
+    const size_t n = idx.size();
+    if (hint < n && idx[hint].name == k) return &idx[hint].feat;
+    for (size_t j = 0; j < n; ++j)
+        if (idx[j].name == k) {
+            hint = j;
+            return &idx[j].feat;
+        }
+    return nullptr;
+}
+
 bool index_batch(Reader& r) {
     const size_t B = r.off.size() - 1;
-    r.index.assign(B, {});
-    for (size_t i = 0; i < B; ++i) {
-        Span rec{r.buf.data() + r.off[i], r.off[i + 1] - r.off[i]};
-        auto& idx = r.index[i];
-        bool ok = for_fields(rec, [&](uint32_t field, uint32_t wt, Span features, uint64_t) {
-            if (field != 1 || wt != 2) return;             // SequenceExample.feature_lists (2) is skipped
-            for_fields(features, [&](uint32_t f2, uint32_t w2, Span entry, uint64_t) {
-                if (f2 != 1 || w2 != 2) return;
-                std::string_view name;
-                Span feat;
-                for_fields(entry, [&](uint32_t f3, uint32_t w3, Span pl, uint64_t) {
-                    if (w3 != 2) return;
-                    if (f3 == 1) name = std::string_view((const char*)pl.p, pl.n);
-                    else if (f3 == 2) feat = pl;
+    r.index.resize(B);
+    std::atomic<long> bad{-1};
+    Pool::get().parallel_for((B + kChunk - 1) / kChunk, [&](size_t c) {
+        for (size_t i = c * kChunk; i < std::min(B, (c + 1) * kChunk); ++i) {
+            Span rec{r.buf.data() + r.off[i], r.off[i + 1] - r.off[i]};
+            auto& idx = r.index[i];
+            idx.clear();
+            bool ok = for_fields(rec, [&](uint32_t field, uint32_t wt, Span features, uint64_t) {
+                if (field != 1 || wt != 2) return;             // SequenceExample.feature_lists (2) is skipped
+                for_fields(features, [&](uint32_t f2, uint32_t w2, Span entry, uint64_t) {
+                    if (f2 != 1 || w2 != 2) return;
+                    Entry e;
+                    for_fields(entry, [&](uint32_t f3, uint32_t w3, Span pl, uint64_t) {
+                        if (w3 != 2) return;
+                        if (f3 == 1) e.name = std::string_view((const char*)pl.p, pl.n);
+                        else if (f3 == 2) e.feat = pl;
+                    });
+                    bool dup = false;                          // a repeated map key: the last entry wins
+                    for (auto& old : idx)
+                        if (old.name == e.name) {
+                            old.feat = e.feat;
+                            dup = true;
+                            break;
+                        }
+                    if (!dup) idx.push_back(e);
                 });
-                idx[name] = feat;
             });
-        });
-        if (!ok) {
-            r.error = "malformed Example in record " + std::to_string(i);
-            return false;
+            if (!ok) bad.store((long)i);
         }
+    });
+    if (bad.load() >= 0) {
+        r.error = "malformed Example in record " + std::to_string(bad.load());
+        return false;
     }
     r.indexed = true;
     return true;
@@ -326,30 +444,38 @@ EXPORT int recalgo_reader_float_feature(void* reader, const char* key, int n, fl
     if (!r->indexed && !index_batch(*r)) return -1;
     const std::string_view k(key);
     const size_t B = r->off.size() - 1;
-    for (size_t i = 0; i < B; ++i) {
-        float* o = out + i * (size_t)n;
-        int filled = 0;
-        auto it = r->index[i].find(k);
-        if (it != r->index[i].end()) {
-            for_fields(it->second, [&](uint32_t field, uint32_t wt, Span list, uint64_t) {
-                if (field != 2 || wt != 2) return;                           // FloatList
-                for_fields(list, [&](uint32_t f2, uint32_t w2, Span pl, uint64_t) {
-                    if (f2 != 1) return;
-                    if (w2 == 2) {                                           // packed
-                        for (size_t b = 0; b + 4 <= pl.n && filled < n; b += 4) memcpy(&o[filled++], pl.p + b, 4);
-                    } else if (w2 == 5 && filled < n) {
-                        memcpy(&o[filled++], pl.p, 4);
-                    }
+    std::atomic<long> missing{-1};
+    Pool::get().parallel_for((B + kChunk - 1) / kChunk, [&](size_t c) {
+        size_t hint = 0;
+        for (size_t i = c * kChunk; i < std::min(B, (c + 1) * kChunk); ++i) {
+            float* o = out + i * (size_t)n;
+            int filled = 0;
+            if (const Span* feat = find_feature(r->index[i], k, hint)) {
+                for_fields(*feat, [&](uint32_t field, uint32_t wt, Span list, uint64_t) {
+                    if (field != 2 || wt != 2) return;                       // FloatList
+                    for_fields(list, [&](uint32_t f2, uint32_t w2, Span pl, uint64_t) {
+                        if (f2 != 1) return;
+                        if (w2 == 2) {                                       // packed
+                            for (size_t b = 0; b + 4 <= pl.n && filled < n; b += 4) memcpy(&o[filled++], pl.p + b, 4);
+                        } else if (w2 == 5 && filled < n) {
+                            memcpy(&o[filled++], pl.p, 4);
+                        }
+                    });
                 });
-            });
-        }
-        if (filled < n) {
-            if (!(filled == 0 && has_default)) {
-                r->error = std::string("feature ") + key + " is required but missing in record " + std::to_string(i);
-                return -1;
             }
-            for (int j = 0; j < n; ++j) o[j] = default_value;
+            if (filled < n) {
+                if (!(filled == 0 && has_default)) {
+                    long want = -1;
+                    missing.compare_exchange_strong(want, (long)i);
+                    continue;
+                }
+                for (int j = 0; j < n; ++j) o[j] = default_value;
+            }
         }
+    });
+    if (missing.load() >= 0) {
+        r->error = std::string("feature ") + key + " is required but missing in record " + std::to_string(missing.load());
+        return -1;
     }
     return 0;
 }
@@ -363,25 +489,41 @@ EXPORT int64_t recalgo_reader_id_feature(void* reader, const char* key, const vo
     const auto& vm = ((const Vocab*)vocab)->map;
     const std::string_view k(key);
     const size_t B = r->off.size() - 1;
-    int64_t nnz = 0;
-    offsets[0] = 0;
-    for (size_t i = 0; i < B; ++i) {
-        auto it = r->index[i].find(k);
-        if (it != r->index[i].end()) {
-            for_fields(it->second, [&](uint32_t field, uint32_t wt, Span list, uint64_t) {
+    const size_t chunks = (B + kChunk - 1) / kChunk;
+    // visit the byte strings of record i's feature
+    auto each_value = [&](size_t i, size_t& hint, auto&& fn) {
+        if (const Span* feat = find_feature(r->index[i], k, hint)) {
+            for_fields(*feat, [&](uint32_t field, uint32_t wt, Span list, uint64_t) {
                 if (field != 1 || wt != 2) return;                           // BytesList
                 for_fields(list, [&](uint32_t f2, uint32_t w2, Span pl, uint64_t) {
-                    if (f2 != 1 || w2 != 2) return;
-                    if (nnz < values_cap) {
-                        auto v = vm.find(std::string_view((const char*)pl.p, pl.n));
-                        values[nnz] = v == vm.end() ? -1 : v->second;
-                    }
-                    ++nnz;
+                    if (f2 == 1 && w2 == 2) fn(pl);
                 });
             });
         }
-        offsets[i + 1] = nnz;
-    }
+    };
+    // pass 1: value counts per record -> offsets (serial prefix sum); pass 2: lookups, in place
+    offsets[0] = 0;
+    Pool::get().parallel_for(chunks, [&](size_t c) {
+        size_t hint = 0;
+        for (size_t i = c * kChunk; i < std::min(B, (c + 1) * kChunk); ++i) {
+            int64_t cnt = 0;
+            each_value(i, hint, [&](Span) { ++cnt; });
+            offsets[i + 1] = cnt;
+        }
+    });
+    for (size_t i = 0; i < B; ++i) offsets[i + 1] += offsets[i];
+    const int64_t nnz = offsets[B];
+    if (nnz > values_cap) return nnz;
+    Pool::get().parallel_for(chunks, [&](size_t c) {
+        size_t hint = 0;
+        for (size_t i = c * kChunk; i < std::min(B, (c + 1) * kChunk); ++i) {
+            int64_t at = offsets[i];
+            each_value(i, hint, [&](Span pl) {
+                auto v = vm.find(std::string_view((const char*)pl.p, pl.n));
+                values[at++] = v == vm.end() ? -1 : v->second;
+            });
+        }
+    });
     return nnz;
 }
 
