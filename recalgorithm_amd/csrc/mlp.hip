@@ -39,26 +39,43 @@ __device__ __forceinline__ float4 reduce_row_lanes(float4 v, float4* sh, unsigne
     return acc;
 }
 
+// Tile = 64 rows x 64 columns (16 float4 column groups x 16 row lanes, 4 rows per thread): a
+// [4096, 512] layer is 512 workgroups and only rows/64 partial rows are left for the fixed-order
+// column sum (the first version reduced rows/8 partial rows: its colsum pass cost 9-11 us per layer).
+constexpr int kTileRows = 64;
 __global__ __launch_bounds__(kThreads) void relu_bwd_bias_kernel(const float4* __restrict__ g,
                                                                  const float4* __restrict__ y, unsigned rows,
                                                                  unsigned C4, float4* __restrict__ g_out,
                                                                  float4* __restrict__ partials) {
     __shared__ float4 sh[kThreads];
-    const unsigned c4 = threadIdx.x % C4, rs = threadIdx.x / C4, RP = kThreads / C4;
-    const unsigned r0 = blockIdx.x * kRowsPerBlk;
+    const unsigned cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const unsigned c4 = blockIdx.x * 16 + cl;
+    const unsigned r0 = blockIdx.y * kTileRows;
     float4 acc = f4_zero();
-    for (unsigned r = r0 + rs; r < min(rows, r0 + kRowsPerBlk); r += RP) {
-        float4 v = g[(size_t)r * C4 + c4];
-        if (y) {
-            const float4 yy = y[(size_t)r * C4 + c4];
-            v = make_float4(yy.x > 0.f ? v.x : 0.f, yy.y > 0.f ? v.y : 0.f, yy.z > 0.f ? v.z : 0.f,
-                            yy.w > 0.f ? v.w : 0.f);
-            g_out[(size_t)r * C4 + c4] = v;
+    if (c4 < C4) {
+#pragma unroll
+        for (unsigned k = 0; k < kTileRows / 16; ++k) {
+            const unsigned r = r0 + rl + 16 * k;
+            if (r < rows) {
+                float4 v = g[(size_t)r * C4 + c4];
+                if (y) {
+                    const float4 yy = y[(size_t)r * C4 + c4];
+                    v = make_float4(yy.x > 0.f ? v.x : 0.f, yy.y > 0.f ? v.y : 0.f, yy.z > 0.f ? v.z : 0.f,
+                                    yy.w > 0.f ? v.w : 0.f);
+                    g_out[(size_t)r * C4 + c4] = v;
+                }
+                acc = f4_add(acc, v);
+            }
         }
-        acc = f4_add(acc, v);
     }
-    acc = reduce_row_lanes(acc, sh, C4);
-    if (rs == 0) partials[(size_t)blockIdx.x * C4 + c4] = acc;
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0 && c4 < C4) {
+        float4 t = sh[cl];
+#pragma unroll
+        for (unsigned k = 1; k < 16; ++k) t = f4_add(t, sh[k * 16 + cl]);
+        partials[(size_t)blockIdx.y * C4 + c4] = t;
+    }
 }
 
 // ---- BatchNorm ------------------------------------------------------------------------------
@@ -230,38 +247,49 @@ __global__ __launch_bounds__(256) void dense1_fwd_kernel(HeadParts P, int B, con
     if (lane == 0) out[b] = acc + (bias ? bias[0] : 0.f);
 }
 
-// block = kHeadRows examples; thread t owns columns t, t+256, ...: dx[b, c] = g[b] w[c] is written and
-// dw[c] += g[b] x[b, c] accumulated in the same pass over x.  Per-block partial rows of dw (and of
-// db in column C) are summed in fixed order by colsum16.
-constexpr int kHeadRows = 16;
+// workgroup = kHeadRows examples x 256 columns of the virtual concat (grid.x = column chunk, grid.y =
+// row tile); thread = one column: dx[b, c] = g[b] w[c] is written and dw[c] += g[b] x[b, c]
+// accumulated in the same pass over x (8 independent loads in flight per thread).  Per-tile partial
+// rows of dw (and of db in column C) are summed in fixed order by colsum16.
+constexpr int kHeadRows = 32;
 __global__ __launch_bounds__(256) void dense1_bwd_kernel(HeadParts P, int B, int C, const float* __restrict__ w,
                                                          const float* __restrict__ g, float* __restrict__ partials) {
     __shared__ float gs[kHeadRows];
-    const int b0 = blockIdx.x * kHeadRows;
+    const int b0 = blockIdx.y * kHeadRows;
     const int nb = min(kHeadRows, B - b0);
     if ((int)threadIdx.x < kHeadRows) gs[threadIdx.x] = (int)threadIdx.x < nb ? g[b0 + threadIdx.x] : 0.f;
     __syncthreads();
-    float* __restrict__ prow = partials + (size_t)blockIdx.x * (C + 1);
-    int off = 0;
-    for (int p = 0; p < P.n; ++p) {
-        const int W = P.width[p];
-        for (int j = threadIdx.x; j < W; j += 256) {
-            const float wj = w[off + j];
-            float acc = 0.f;
-#pragma unroll 4
-            for (int r = 0; r < nb; ++r) {
-                const size_t at = (size_t)(b0 + r) * W + j;
-                acc = fmaf(gs[r], P.x[p][at], acc);
-                if (P.dx[p]) P.dx[p][at] = gs[r] * wj;
+    float* __restrict__ prow = partials + (size_t)blockIdx.y * (C + 1);
+    const int c = blockIdx.x * 256 + threadIdx.x;          // column of the concat
+    if (c < C) {
+        int p = 0, off = 0;
+        while (c >= off + P.width[p]) off += P.width[p++];
+        const int W = P.width[p], j = c - off;
+        const float* __restrict__ xp = P.x[p] + (size_t)b0 * W + j;
+        float* __restrict__ dxp = P.dx[p] ? P.dx[p] + (size_t)b0 * W + j : nullptr;
+        const float wj = w[c];
+        float acc = 0.f;
+        int r = 0;
+        for (; r + 8 <= nb; r += 8) {
+            float xv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xv[k] = xp[(size_t)(r + k) * W];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                acc = fmaf(gs[r + k], xv[k], acc);
+                if (dxp) dxp[(size_t)(r + k) * W] = gs[r + k] * wj;
             }
-            prow[off + j] = acc;
         }
-        off += W;
+        for (; r < nb; ++r) {
+            acc = fmaf(gs[r], xp[(size_t)r * W], acc);
+            if (dxp) dxp[(size_t)r * W] = gs[r] * wj;
+        }
+        prow[c] = acc;
     }
-    if (threadIdx.x == 0) {
-        float s = 0.f;
-        for (int r = 0; r < nb; ++r) s += gs[r];
-        prow[C] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float sgs = 0.f;
+        for (int r = 0; r < nb; ++r) sgs += gs[r];
+        prow[C] = sgs;
     }
 }
 
@@ -312,7 +340,7 @@ RECALGO_EXPORT int recalgo_dense1_bwd(const float* const* x_parts, const int* wi
     RECALGO_REQUIRE(g != nullptr && workspace != nullptr);
     const int blocks = cdiv(B, kHeadRows);
     float* partials = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(dense1_bwd_kernel, dim3(blocks), dim3(256), 0, st, P, B, C, w, g, partials);
+    hipLaunchKernelGGL(dense1_bwd_kernel, dim3(cdiv(C, 256), blocks), dim3(256), 0, st, P, B, C, w, g, partials);
     // columns [0, C) -> dw, column C -> dbias (or the scratch float behind the partial rows)
     launch_colsum16(partials, (unsigned)blocks, (unsigned)(C + 1), dw, (unsigned)C,
                     dbias ? dbias : partials + (size_t)blocks * (C + 1), st);
@@ -323,16 +351,16 @@ RECALGO_EXPORT int recalgo_mlp_width_supported(int C) { return width_ok(C) ? 1 :
 
 RECALGO_EXPORT int64_t recalgo_relu_bwd_bias_workspace_bytes(int rows, int C) {
     if (rows <= 0 || !width_ok(C)) return 0;
-    return (int64_t)nblk_of(rows) * C * (int64_t)sizeof(float);
+    return (int64_t)cdiv(rows, kTileRows) * C * (int64_t)sizeof(float);
 }
 
 RECALGO_EXPORT int recalgo_relu_bwd_bias(const float* g, const float* y, int rows, int C, float* g_out, float* dbias,
                                          void* workspace, recalgo_stream_t stream) {
     RECALGO_REQUIRE(rows > 0 && width_ok(C) && g && dbias && workspace && ((y == nullptr) == (g_out == nullptr)));
     hipStream_t st = as_stream(stream);
-    const int nb = nblk_of(rows);
+    const int nb = cdiv(rows, kTileRows);
     float* partials = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(relu_bwd_bias_kernel, dim3(nb), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(g),
+    hipLaunchKernelGGL(relu_bwd_bias_kernel, dim3(cdiv(C / 4, 16), nb), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(g),
                        reinterpret_cast<const float4*>(y), (unsigned)rows, (unsigned)(C / 4),
                        reinterpret_cast<float4*>(g_out), reinterpret_cast<float4*>(partials));
     launch_colsum16(partials, (unsigned)nb, (unsigned)C, dbias, (unsigned)C, static_cast<float*>(nullptr), st);
