@@ -271,6 +271,7 @@ class Estimator:
         self._built = False
         self.grad_hook = None     # set by parallel wrappers (dense-grad all-reduce)
         self.loss_grad_scale = None   # 1/world under data parallelism (parallel.attach_data_parallel)
+        self._seed_grad, self._seed_value = None, None
 
     # -- plumbing -------------------------------------------------------------------------
     def _to_device(self, features, labels):
@@ -308,12 +309,14 @@ class Estimator:
 
     def train_step(self, features, labels):
         """One eager training step on device-resident inputs; returns the loss tensor."""
-        spec = self._call_model_fn(features, labels, ModeKeys.TRAIN)
+        from . import ops
+        seed = 1.0 if self.loss_grad_scale is None else float(self.loss_grad_scale)
+        with ops.loss_seed(seed):
+            spec = self._call_model_fn(features, labels, ModeKeys.TRAIN)
         op = spec.train_op
-        if self.loss_grad_scale is None:
-            op.loss.backward()
-        else:
-            op.loss.backward(torch.full_like(op.loss, self.loss_grad_scale))
+        if self._seed_grad is None or float(self._seed_value) != seed or self._seed_grad.device != op.loss.device:
+            self._seed_grad, self._seed_value = torch.full_like(op.loss.detach(), seed), seed   # made once, reused
+        op.loss.backward(self._seed_grad)
         op.optimizer.apply_gradients(self.store, self.grad_hook)
         return spec.loss.detach()
 

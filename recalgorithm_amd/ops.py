@@ -697,9 +697,33 @@ def batchnorm_train_bwd(x, gamma, mean, rstd, g, dgamma, dbeta) -> torch.Tensor:
 # =============================================================================================
 # a14: loss tail
 # =============================================================================================
+# The gradient the training loop seeds the loss with (1, or 1/world under data parallelism) is known
+# before the forward runs: inside `loss_seed(c)` the loss kernel bakes c into dlogit and the backward
+# hands dlogit on unchanged — no ones_like fill, no scaling launch.  The caller promises to seed
+# loss.backward() with exactly c (Estimator.train_step does).
+_loss_seed: Optional[float] = None
+
+
+class loss_seed:
+    def __init__(self, c: float):
+        self.c = float(c)
+
+    def __enter__(self):
+        global _loss_seed
+        self.prev, _loss_seed = _loss_seed, self.c
+        return self
+
+    def __exit__(self, *exc):
+        global _loss_seed
+        _loss_seed = self.prev
+        return False
+
+
 class _SigmoidCEFn(Function):
     @staticmethod
     def forward(ctx, logits, labels):
+        ctx.set_materialize_grads(False)      # no zero tensor for the (non-differentiable) probabilities
+        ctx.seed = _loss_seed
         B = logits.numel()
         lg = logits.contiguous().view(-1)
         lb = labels.contiguous().view(-1).to(torch.float32)
@@ -707,7 +731,7 @@ class _SigmoidCEFn(Function):
         loss = torch.empty(1, device=lg.device, dtype=torch.float32)
         dlogit = torch.empty_like(lg)
         _lib.check(_lib_().recalgo_sigmoid_ce_fwd_bwd(
-            _p(lg), _p(lb), B, 1.0, _p(prob), _p(loss), _p(dlogit), _stream(lg)),
+            _p(lg), _p(lb), B, 1.0 if ctx.seed is None else ctx.seed, _p(prob), _p(loss), _p(dlogit), _stream(lg)),
             "recalgo_sigmoid_ce_fwd_bwd")
         ctx.save_for_backward(dlogit)
         ctx.shape = logits.shape
@@ -717,6 +741,10 @@ class _SigmoidCEFn(Function):
     @staticmethod
     def backward(ctx, gloss, _gprob):
         (dlogit,) = ctx.saved_tensors
+        if gloss is None:
+            return None, None
+        if ctx.seed is not None:
+            return dlogit.view(ctx.shape), None
         return (dlogit * gloss).view(ctx.shape), None
 
 
