@@ -287,7 +287,7 @@ int recalgo_dense1_bwd(const float* const* x_parts, const int* widths, int n_par
 /* ------------------------------------------------------------------------------------------
  * Context-MLP glue around the library GEMMs (not interaction layers; fused because the step is
  * otherwise dominated by their launch count).  Widths must satisfy recalgo_mlp_width_supported(C)
- * (C % 4 == 0 and 256 % (C/4) == 0); callers keep their own path for other widths.
+ * (C % 4 == 0); callers keep their own path for other widths.
  *
  * Backward epilogue of tf.layers.dense(..., activation=tf.nn.relu) (algorithm/DeepFM/deepfm.py:207
  * and the same line in every model_fn):   g_out = g * [y > 0],  dbias = colsum(g_out).

@@ -8,16 +8,17 @@
 //                        y = (x - mean) * rsqrt(var + eps) * gamma + beta
 //   batchnorm_train_bwd  dbeta = colsum(g), dgamma = colsum(g * xhat),
 //                        dx = gamma * rstd / B * (B*g - dbeta - xhat * dgamma)
-// All three are HBM-bound streams over [rows, C] fp32 with column reductions: a thread owns one
-// float4 column group, a workgroup a block of rows; per-workgroup partials are summed in a fixed
-// order (deterministic).  Requires C % 4 == 0 and 256 % (C/4) == 0 (C in {4,...,1024} a power of
-// two times 4) — the caller keeps torch ops for other widths.
+// All three are HBM-bound streams over [rows, C] fp32 with column reductions.  Tile = 64 rows x 64
+// columns per workgroup (16 float4 column groups x 16 row lanes, 4 rows per thread, held in
+// registers): a [4096, 512] layer is 512 workgroups, and only rows/64 partial rows per column are
+// left for the fixed-order (deterministic) second stage.  (The first version used 8-row blocks:
+// its second stages walked rows/8 partial rows and cost 10-22 us per layer.)  Requires C % 4 == 0.
 #include "common.h"
 
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kRowsPerBlk = 8;        // 512 workgroups at B = 4096: every CU streams
+constexpr int kTileRows = 64;
 
 __device__ __forceinline__ float4 f4_sub(float4 a, float4 b) {
     return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
@@ -26,23 +27,20 @@ __device__ __forceinline__ float4 f4_mul(float4 a, float4 b) {
     return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
 }
 
-// reduce `v` (one float4 per thread, column group c4 = tid % C4, row lane rs = tid / C4) over the
-// row lanes in fixed order; result valid for rs == 0
-__device__ __forceinline__ float4 reduce_row_lanes(float4 v, float4* sh, unsigned C4) {
-    const unsigned RP = kThreads / C4;
-    if (RP == 1) return v;
+// sum of the 16 row lanes of column group cl in fixed order (every thread gets the total)
+__device__ __forceinline__ float4 tile_colsum(float4 v, float4* sh, unsigned cl) {
     __syncthreads();
     sh[threadIdx.x] = v;
     __syncthreads();
-    float4 acc = sh[threadIdx.x % C4];
-    for (unsigned r = 1; r < RP; ++r) acc = f4_add(acc, sh[r * C4 + threadIdx.x % C4]);
-    return acc;
+    float4 t = sh[cl];
+#pragma unroll
+    for (unsigned k = 1; k < 16; ++k) t = f4_add(t, sh[k * 16 + cl]);
+    return t;
 }
 
 // Tile = 64 rows x 64 columns (16 float4 column groups x 16 row lanes, 4 rows per thread): a
 // [4096, 512] layer is 512 workgroups and only rows/64 partial rows are left for the fixed-order
 // column sum (the first version reduced rows/8 partial rows: its colsum pass cost 9-11 us per layer).
-constexpr int kTileRows = 64;
 __global__ __launch_bounds__(kThreads) void relu_bwd_bias_kernel(const float4* __restrict__ g,
                                                                  const float4* __restrict__ y, unsigned rows,
                                                                  unsigned C4, float4* __restrict__ g_out,
@@ -68,44 +66,42 @@ __global__ __launch_bounds__(kThreads) void relu_bwd_bias_kernel(const float4* _
             }
         }
     }
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    if (rl == 0 && c4 < C4) {
-        float4 t = sh[cl];
-#pragma unroll
-        for (unsigned k = 1; k < 16; ++k) t = f4_add(t, sh[k * 16 + cl]);
-        partials[(size_t)blockIdx.y * C4 + c4] = t;
-    }
+    acc = tile_colsum(acc, sh, cl);
+    if (rl == 0 && c4 < C4) partials[(size_t)blockIdx.y * C4 + c4] = acc;
 }
 
 // ---- BatchNorm ------------------------------------------------------------------------------
 // per-block moments: partials[blk][0:C] = block mean, [C:2C] = block M2 (sum of squared deviations
-// from the block mean); block row counts are implied by (rows, kRowsPerBlk)
+// from the tile mean); tile row counts are implied by (rows, kTileRows)
 __global__ __launch_bounds__(kThreads) void bn_moments_kernel(const float4* __restrict__ x, unsigned rows,
                                                               unsigned C4, float4* __restrict__ partials) {
     __shared__ float4 sh[kThreads];
-    const unsigned c4 = threadIdx.x % C4, rs = threadIdx.x / C4, RP = kThreads / C4;
-    const unsigned r0 = blockIdx.x * kRowsPerBlk, r1 = min(rows, r0 + kRowsPerBlk);
+    const unsigned cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const unsigned c4 = blockIdx.x * 16 + cl;
+    const unsigned r0 = blockIdx.y * kTileRows, r1 = min(rows, r0 + kTileRows);
     const float n = (float)(r1 - r0);
+    float4 v[kTileRows / 16];
+    bool has[kTileRows / 16];
     float4 s = f4_zero();
-    for (unsigned r = r0 + rs; r < r1; r += RP) s = f4_add(s, x[(size_t)r * C4 + c4]);
-    s = reduce_row_lanes(s, sh, C4);
-    if (RP > 1) {                                    // broadcast the block sum to every row lane
-        __syncthreads();
-        if (rs == 0) sh[c4] = s;
-        __syncthreads();
-        s = sh[c4];
+#pragma unroll
+    for (unsigned k = 0; k < kTileRows / 16; ++k) {
+        const unsigned r = r0 + rl + 16 * k;
+        has[k] = c4 < C4 && r < r1;
+        v[k] = has[k] ? x[(size_t)r * C4 + c4] : f4_zero();
+        s = f4_add(s, v[k]);
     }
-    const float4 mean = f4_scale(s, 1.0f / n);
+    const float4 mean = f4_scale(tile_colsum(s, sh, cl), 1.0f / n);
     float4 m2 = f4_zero();
-    for (unsigned r = r0 + rs; r < r1; r += RP) {
-        const float4 d = f4_sub(x[(size_t)r * C4 + c4], mean);
-        m2 = f4_add(m2, f4_mul(d, d));
-    }
-    m2 = reduce_row_lanes(m2, sh, C4);
-    if (rs == 0) {
-        partials[(size_t)blockIdx.x * 2 * C4 + c4] = mean;
-        partials[(size_t)blockIdx.x * 2 * C4 + C4 + c4] = m2;
+#pragma unroll
+    for (unsigned k = 0; k < kTileRows / 16; ++k)
+        if (has[k]) {
+            const float4 d = f4_sub(v[k], mean);
+            m2 = f4_add(m2, f4_mul(d, d));
+        }
+    m2 = tile_colsum(m2, sh, cl);
+    if (rl == 0 && c4 < C4) {
+        partials[(size_t)blockIdx.y * 2 * C4 + c4] = mean;
+        partials[(size_t)blockIdx.y * 2 * C4 + C4 + c4] = m2;
     }
 }
 
@@ -124,7 +120,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     float acc = 0.f;
     if (ok)
         for (unsigned b = rg; b < nblk; b += 16) {
-            const float nb = (float)(min(rows, (b + 1) * kRowsPerBlk) - b * kRowsPerBlk);
+            const float nb = (float)(min(rows, (b + 1) * kTileRows) - b * kTileRows);
             acc += nb * partials[(size_t)b * 2 * C + c];
         }
     sh[rg][cl] = acc;
@@ -137,7 +133,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     acc = 0.f;
     if (ok)
         for (unsigned b = rg; b < nblk; b += 16) {
-            const float nb = (float)(min(rows, (b + 1) * kRowsPerBlk) - b * kRowsPerBlk);
+            const float nb = (float)(min(rows, (b + 1) * kTileRows) - b * kTileRows);
             const float d = partials[(size_t)b * 2 * C + c] - mean;
             acc += partials[(size_t)b * 2 * C + C + c] + nb * d * d;
         }
@@ -179,21 +175,28 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float4* _
                                                                  const float4* __restrict__ rstd, unsigned rows,
                                                                  unsigned C4, float4* __restrict__ partials) {
     __shared__ float4 sh[kThreads];
-    const unsigned c4 = threadIdx.x % C4, rs = threadIdx.x / C4, RP = kThreads / C4;
-    const unsigned r0 = blockIdx.x * kRowsPerBlk;
-    const float4 mu = mean[c4], rs4 = rstd[c4];
+    const unsigned cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const unsigned c4 = blockIdx.x * 16 + cl;
+    const unsigned r0 = blockIdx.y * kTileRows;
     float4 sg = f4_zero(), sgx = f4_zero();
-    for (unsigned r = r0 + rs; r < min(rows, r0 + kRowsPerBlk); r += RP) {
-        const float4 gv = g[(size_t)r * C4 + c4];
-        const float4 xh = f4_mul(f4_sub(x[(size_t)r * C4 + c4], mu), rs4);
-        sg = f4_add(sg, gv);
-        sgx = f4_add(sgx, f4_mul(gv, xh));
+    if (c4 < C4) {
+        const float4 mu = mean[c4], rs4 = rstd[c4];
+#pragma unroll
+        for (unsigned k = 0; k < kTileRows / 16; ++k) {
+            const unsigned r = r0 + rl + 16 * k;
+            if (r < rows) {
+                const float4 gv = g[(size_t)r * C4 + c4];
+                const float4 xh = f4_mul(f4_sub(x[(size_t)r * C4 + c4], mu), rs4);
+                sg = f4_add(sg, gv);
+                sgx = f4_add(sgx, f4_mul(gv, xh));
+            }
+        }
     }
-    sg = reduce_row_lanes(sg, sh, C4);
-    sgx = reduce_row_lanes(sgx, sh, C4);
-    if (rs == 0) {
-        partials[(size_t)blockIdx.x * 2 * C4 + c4] = sg;
-        partials[(size_t)blockIdx.x * 2 * C4 + C4 + c4] = sgx;
+    sg = tile_colsum(sg, sh, cl);
+    sgx = tile_colsum(sgx, sh, cl);
+    if (rl == 0 && c4 < C4) {
+        partials[(size_t)blockIdx.y * 2 * C4 + c4] = sg;
+        partials[(size_t)blockIdx.y * 2 * C4 + C4 + c4] = sgx;
     }
 }
 
@@ -212,8 +215,8 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
                         k.z * (gv.z - inv_rows * (db.z + xh.z * dg.z)), k.w * (gv.w - inv_rows * (db.w + xh.w * dg.w)));
 }
 
-inline bool width_ok(int C) { return C >= 4 && C % 4 == 0 && C / 4 <= kThreads && kThreads % (C / 4) == 0; }
-inline int nblk_of(int rows) { return cdiv(rows, kRowsPerBlk); }
+inline bool width_ok(int C) { return C >= 4 && C % 4 == 0; }
+inline int nblk_of(int rows) { return cdiv(rows, kTileRows); }
 
 // ---------------------------------------------------------------------------------------
 // One-unit dense head over a (virtual) concatenation of up to 4 row-major inputs:
@@ -295,14 +298,14 @@ __global__ __launch_bounds__(256) void dense1_bwd_kernel(HeadParts P, int B, int
 
 }  // namespace
 
-static int head_parts(const float* const* x_parts, float* const* dx_parts, const int* widths, int n_parts,
+static int head_parts(const float* const* x_parts, float* const* dx_parts, const int* widths, int n_parts, int B,
                       HeadParts* P) {
     if (n_parts < 1 || n_parts > kHeadMaxParts || x_parts == nullptr || widths == nullptr) return -1;
     int C = 0;
     P->n = n_parts;
     for (int p = 0; p < kHeadMaxParts; ++p) {
         const bool on = p < n_parts;
-        if (on && (x_parts[p] == nullptr || widths[p] < 1)) return -1;
+        if (on && ((B > 0 && x_parts[p] == nullptr) || widths[p] < 1)) return -1;
         P->x[p] = on ? x_parts[p] : nullptr;
         P->dx[p] = on && dx_parts ? dx_parts[p] : nullptr;
         P->width[p] = on ? widths[p] : 0;
@@ -314,7 +317,7 @@ static int head_parts(const float* const* x_parts, float* const* dx_parts, const
 RECALGO_EXPORT int recalgo_dense1_fwd(const float* const* x_parts, const int* widths, int n_parts, int B,
                                       const float* w, const float* bias, float* out, recalgo_stream_t stream) {
     HeadParts P;
-    const int C = head_parts(x_parts, nullptr, widths, n_parts, &P);
+    const int C = head_parts(x_parts, nullptr, widths, n_parts, B, &P);
     RECALGO_REQUIRE(C > 0 && B >= 0 && w != nullptr && out != nullptr);
     if (B == 0) return 0;
     hipLaunchKernelGGL(dense1_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, as_stream(stream), P, B, w, bias, out);
@@ -329,7 +332,7 @@ RECALGO_EXPORT int recalgo_dense1_bwd(const float* const* x_parts, const int* wi
                                       const float* w, const float* g, float* const* dx_parts, float* dw, float* dbias,
                                       void* workspace, recalgo_stream_t stream) {
     HeadParts P;
-    const int C = head_parts(x_parts, dx_parts, widths, n_parts, &P);
+    const int C = head_parts(x_parts, dx_parts, widths, n_parts, B, &P);
     RECALGO_REQUIRE(C > 0 && B >= 0 && w != nullptr && dw != nullptr);
     hipStream_t st = as_stream(stream);
     if (B == 0) {
@@ -351,14 +354,14 @@ RECALGO_EXPORT int recalgo_mlp_width_supported(int C) { return width_ok(C) ? 1 :
 
 RECALGO_EXPORT int64_t recalgo_relu_bwd_bias_workspace_bytes(int rows, int C) {
     if (rows <= 0 || !width_ok(C)) return 0;
-    return (int64_t)cdiv(rows, kTileRows) * C * (int64_t)sizeof(float);
+    return (int64_t)nblk_of(rows) * C * (int64_t)sizeof(float);
 }
 
 RECALGO_EXPORT int recalgo_relu_bwd_bias(const float* g, const float* y, int rows, int C, float* g_out, float* dbias,
                                          void* workspace, recalgo_stream_t stream) {
     RECALGO_REQUIRE(rows > 0 && width_ok(C) && g && dbias && workspace && ((y == nullptr) == (g_out == nullptr)));
     hipStream_t st = as_stream(stream);
-    const int nb = cdiv(rows, kTileRows);
+    const int nb = nblk_of(rows);
     float* partials = static_cast<float*>(workspace);
     hipLaunchKernelGGL(relu_bwd_bias_kernel, dim3(cdiv(C / 4, 16), nb), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(g),
                        reinterpret_cast<const float4*>(y), (unsigned)rows, (unsigned)(C / 4),
@@ -382,7 +385,7 @@ RECALGO_EXPORT int recalgo_batchnorm_train_fwd(const float* x, const float* gamm
     const int nb = nblk_of(rows);
     const unsigned C4 = C / 4;
     float* partials = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(bn_moments_kernel, dim3(nb), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
+    hipLaunchKernelGGL(bn_moments_kernel, dim3(cdiv(C4, 16), nb), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
                        (unsigned)rows, C4, reinterpret_cast<float4*>(partials));
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, partials, (unsigned)nb, (unsigned)rows,
                        (unsigned)C, eps, momentum, moving_mean, moving_var, save_mean, save_rstd);
@@ -404,7 +407,7 @@ RECALGO_EXPORT int recalgo_batchnorm_train_bwd(const float* x, const float* gamm
     const int nb = nblk_of(rows);
     const unsigned C4 = C / 4;
     float* partials = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C4, 16), nb), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
                        reinterpret_cast<const float4*>(g), reinterpret_cast<const float4*>(save_mean),
                        reinterpret_cast<const float4*>(save_rstd), (unsigned)rows, C4,
                        reinterpret_cast<float4*>(partials));

@@ -296,12 +296,12 @@ def test_cpu_tensor_is_rejected():
         ops.embedding_gather(store, torch.zeros(2, 1, dtype=torch.int64), ar, torch.zeros(1, dtype=torch.int64))
 
 
-@pytest.mark.parametrize("rows,C", [(4096, 512), (300, 128), (33, 16), (1000, 1024), (7, 4)])
+@pytest.mark.parametrize("rows,C", [(4096, 512), (300, 128), (33, 16), (1000, 1024), (7, 4), (65, 200), (129, 2052), (64, 68)])
 def test_mlp_glue_relu_bwd_bias_and_batchnorm(dev, rows, C):
     """csrc/mlp.hip vs a float64 torch restatement of tf.layers.dense's ReLU/bias backward and of
     tf.layers.batch_normalization(training=True) [TF-ext A-8]."""
     from recalgorithm_amd import ops
-    assert ops.mlp_width_supported(C) and not ops.mlp_width_supported(82)
+    assert ops.mlp_width_supported(C) and not ops.mlp_width_supported(82) and not ops.mlp_width_supported(0)
     gen = torch.Generator().manual_seed(rows + C)
     g = torch.randn(rows, C, generator=gen)
     y = torch.relu(torch.randn(rows, C, generator=gen))
