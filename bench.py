@@ -75,6 +75,10 @@ def build_estimator(args, device, rank=0, world=1):
         workload = f"DCN 3-layer CrossNet + MLP 512,256,128; {args.fields} fields x emb{args.emb}; batch {args.batch}/GPU"
     elif args.model == "deepfm":
         from recalgorithm_amd.algorithm.DeepFM.deepfm import deepfm_model_fn as model_fn
+        # DeepFM consumes its columns in the order given (one input_layer call per column, deepfm.py:187-190);
+        # listing them in the order of the resident id matrix (sorted names, as fc.input_layer sorts for
+        # the other models) lets the fused kernel read the matrix in place
+        cats = sorted(cats, key=lambda c: c.key)
         params = {"first_order_feature_columns": [fc.indicator_column(c) for c in cats],
                   "second_order_feature_columns": [fc.embedding_column(c, args.emb) for c in cats],
                   "hidden_units": hidden, "dropout_rate": 0.0, "batch_norm": True, "learning_rate": 0.005}
