@@ -318,7 +318,7 @@ RECALGO_EXPORT int recalgo_dense1_fwd(const float* const* x_parts, const int* wi
                                       const float* w, const float* bias, float* out, recalgo_stream_t stream) {
     HeadParts P;
     const int C = head_parts(x_parts, nullptr, widths, n_parts, B, &P);
-    RECALGO_REQUIRE(C > 0 && B >= 0 && w != nullptr && out != nullptr);
+    RECALGO_REQUIRE(C > 0 && B >= 0 && w != nullptr && (B == 0 || out != nullptr));
     if (B == 0) return 0;
     hipLaunchKernelGGL(dense1_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, as_stream(stream), P, B, w, bias, out);
     RECALGO_RETURN_LAST();
