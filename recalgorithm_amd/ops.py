@@ -598,8 +598,11 @@ class _PnnProductFn(Function):
         B, D = y.shape
         lib = _lib_()
         st = _stream(emb_flat)
-        gz = g * (y > 0)
-        torch.sum(gz, dim=0, out=bias.grad)
+        if mlp_width_supported(D):
+            gz = relu_bwd_bias_(g.contiguous(), y, bias.grad)         # ReLU mask + bias gradient, one pass
+        else:
+            gz = g * (y > 0)
+            torch.sum(gz, dim=0, out=bias.grad)
         torch.mm(emb_flat.t(), gz, out=linear_w.grad)
         d_emb = gz @ linear_w.data.t()
         dphi = gz @ omega.t()

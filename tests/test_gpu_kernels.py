@@ -265,10 +265,10 @@ def test_adam_tf1(dev, n):
     assert_close(vd, v64, what="adam v")
 
 
+@pytest.mark.parametrize("rows,C", [(300, 200), (4096, 128), (65, 68), (130, 203), (1, 4)])
 @pytest.mark.parametrize("kind", ["prelu", "dice"])
-def test_activation(dev, kind):
-    gen = torch.Generator().manual_seed(11)
-    rows, C = 300, 200
+def test_activation(dev, kind, rows, C):
+    gen = torch.Generator().manual_seed(11 + rows + C)
     x = torch.randn(rows, C, generator=gen) * 2
     a = torch.rand(C, generator=gen) + 0.5
     store = VariableStore(dev)
