@@ -10,7 +10,7 @@ O=$R/gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
 for m in $MODELS; do
-  timeout 300 python bench.py --model $m --steps 200 --warmup 20 > $O/bench_${TAG}_$m.json 2> $O/bench_${TAG}_$m.err
+  timeout 300 python bench.py --model $m --steps 400 --warmup 20 --no-cpu-baseline > $O/bench_${TAG}_$m.json 2> $O/bench_${TAG}_$m.err
   echo "== $m: $(head -c 300 $O/bench_${TAG}_$m.json)"
   tail -2 $O/bench_${TAG}_$m.err
   D=/tmp/prof_${TAG}_$m
