@@ -544,6 +544,13 @@ def main():
             except (OSError, ValueError, KeyError):
                 pass
             out["kernels"] = ks
+            # whole-step view (BASELINE.json: "absolute and as fraction of HBM roofline"): the algorithmic
+            # bytes of the step's HBM-bound hand-written kernels over the WHOLE step time, library GEMMs
+            # and launch gaps included in the denominator
+            hb = sum(k["alg_bytes"] for k in ks if k["bound"] == "hbm")
+            out["step_hbm"] = {"alg_bytes_hot_path_kernels": int(hb), "ms_per_step": out["ms_per_step"],
+                               "achieved_GBs": round(hb / (out["ms_per_step"] * 1e-3) / 1e9, 1),
+                               "frac_of_peak": round(hb / (out["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(out), flush=True)
