@@ -11,8 +11,6 @@
 // rows inside the workgroup in an LDS hash table (ds_add_f32), and only then issues ONE global
 // atomic per distinct row per workgroup.  Workgroups are organised per (field, example chunk) so
 // that duplicates meet in the same table.
-#include <cstdlib>
-
 #include "common.h"
 
 namespace {
@@ -403,227 +401,6 @@ __global__ __launch_bounds__(kThreads) void deepfm_sparse_bwd_kernel(
     agg_flush(a, K, grad_arena, grad_w1);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Sorted workgroup aggregator (float4 rows): the same job as Agg — combine the duplicate rows of up
-// to kExPerBlk items inside the workgroup, then ONE global atomic per distinct row and float — without
-// LDS float atomics (ds_add_f32 retires ~1 lane per clock: the 4096 adds of a [256 x 16] tile were
-// half of gather_bwd's time).  The items' gradient rows are staged in an LDS tile; items are grouped
-// by row with integer LDS work only (hash slot per item, per-slot count, exclusive scan, order[]);
-// then each distinct row is summed by KV lanes reading its items' tile rows with ds_read_b128.
-//   item t <-> thread t (t < n <= kExPerBlk = blockDim.x).
-// ---------------------------------------------------------------------------------------------
-struct SAgg {
-    float4* tile;               // [kExPerBlk][KV]
-    float* w1g;                 // [kExPerBlk]   (fused first-order weight gradient; DeepFM only)
-    unsigned long long* keys;   // [kSlots]
-    int* cnt;                   // [kSlots]
-    int* start;                 // [kSlots]
-    int* cursor;                // [kSlots]
-    unsigned short* slot_of;    // [kExPerBlk]
-    unsigned short* order;      // [kExPerBlk]
-};
-inline size_t sagg_smem(int KV) {
-    return (size_t)kExPerBlk * KV * 16 + kExPerBlk * 4 + kSlots * 8 + 3 * kSlots * 4 + 2 * kExPerBlk * 2;
-}
-__device__ __forceinline__ SAgg sagg_carve(unsigned char* smem, unsigned KV) {
-    SAgg a;
-    a.tile = reinterpret_cast<float4*>(smem);
-    smem += (size_t)kExPerBlk * KV * 16;
-    a.keys = reinterpret_cast<unsigned long long*>(smem);
-    smem += kSlots * 8;
-    a.w1g = reinterpret_cast<float*>(smem);
-    smem += kExPerBlk * 4;
-    a.cnt = reinterpret_cast<int*>(smem);
-    a.start = a.cnt + kSlots;
-    a.cursor = a.start + kSlots;
-    smem += 3 * kSlots * 4;
-    a.slot_of = reinterpret_cast<unsigned short*>(smem);
-    a.order = a.slot_of + kExPerBlk;
-    return a;
-}
-__device__ __forceinline__ void sagg_init(const SAgg& a) {
-    for (unsigned i = threadIdx.x; i < kSlots; i += kThreads) {
-        a.keys[i] = kEmpty;
-        a.cnt[i] = 0;
-    }
-}
-__device__ __forceinline__ unsigned sagg_slot(const SAgg& a, unsigned long long row) {
-    unsigned h = (unsigned)((row * 0x9E3779B97F4A7C15ull) >> 40) & (kSlots - 1);
-#pragma unroll 1
-    for (int probe = 0; probe < 32; ++probe) {
-        unsigned long long k = a.keys[h];
-        if (k == row) return h;
-        if (k == kEmpty) {
-            unsigned long long old = atomicCAS(&a.keys[h], kEmpty, row);
-            if (old == kEmpty || old == row) return h;
-        }
-        h = (h + 1) & (kSlots - 1);
-    }
-    return kSlots;
-}
-
-// Call with the tile (and w1g) written by the caller and sagg_init done (no sync needed in between:
-// this function starts with the hash phase, which only touches keys/cnt, and syncs before it reads
-// the tile).  `row` = this thread's item row, kEmpty for none.  K = 4 * KV floats per row.
-template <bool W1>
-__device__ __forceinline__ void sagg_scatter(const SAgg& a, unsigned long long row, unsigned KV,
-                                             float* __restrict__ grad, float* __restrict__ grad_w1) {
-    __shared__ int wave_tot[kThreads / 64];
-    const unsigned t = threadIdx.x;
-    constexpr unsigned kNone = 0xFFFFu, kDirect = 0xFFFEu;
-    __syncthreads();                                   // keys / cnt initialised, tile staged
-    unsigned s = kNone;
-    if (row != kEmpty) {
-        const unsigned ss = sagg_slot(a, row);
-        if (ss < kSlots) {
-            s = ss;
-            atomicAdd(&a.cnt[ss], 1);
-        } else {
-            s = kDirect;                               // probe sequence exhausted: no aggregation for this item
-        }
-    }
-    __syncthreads();
-    {   // exclusive scan of cnt[kSlots] (two slots per thread) -> start, cursor
-        const int c0 = a.cnt[2 * t], c1 = a.cnt[2 * t + 1];
-        const int sum = c0 + c1;
-        int incl = sum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int y = __shfl_up(incl, o, 64);
-            if ((int)(t & 63) >= o) incl += y;
-        }
-        if ((t & 63) == 63) wave_tot[t >> 6] = incl;
-        __syncthreads();
-        int before = 0;
-        for (unsigned w = 0; w < (t >> 6); ++w) before += wave_tot[w];
-        const int excl = before + incl - sum;
-        a.start[2 * t] = excl;
-        a.cursor[2 * t] = excl;
-        a.start[2 * t + 1] = excl + c0;
-        a.cursor[2 * t + 1] = excl + c0;
-    }
-    __syncthreads();
-    if (s < kSlots) a.order[atomicAdd(&a.cursor[s], 1)] = (unsigned short)t;
-    __syncthreads();
-    const unsigned K = KV * 4;
-    const unsigned q = t % KV, grp = t / KV, groups = kThreads / KV;
-    for (unsigned sl = grp; sl < kSlots; sl += groups) {
-        const int c = a.cnt[sl];
-        if (c == 0) continue;
-        const int st = a.start[sl];
-        unsigned e = a.order[st];
-        float4 acc = a.tile[e * KV + q];
-        float w = (W1 && q == 0) ? a.w1g[e] : 0.f;
-        for (int j = 1; j < c; ++j) {
-            e = a.order[st + j];
-            acc = f4_add(acc, a.tile[e * KV + q]);
-            if (W1 && q == 0) w += a.w1g[e];
-        }
-        const unsigned long long r = a.keys[sl];
-        float* p = grad + r * K + q * 4;
-        if (acc.x != 0.f) atomic_add_f32(p + 0, acc.x);
-        if (acc.y != 0.f) atomic_add_f32(p + 1, acc.y);
-        if (acc.z != 0.f) atomic_add_f32(p + 2, acc.z);
-        if (acc.w != 0.f) atomic_add_f32(p + 3, acc.w);
-        if (W1 && q == 0 && w != 0.f) atomic_add_f32(grad_w1 + r, w);
-    }
-    if (s == kDirect) {
-        for (unsigned qq = 0; qq < KV; ++qq) {
-            const float4 v = a.tile[t * KV + qq];
-            float* p = grad + row * K + qq * 4;
-            atomic_add_f32(p + 0, v.x); atomic_add_f32(p + 1, v.y);
-            atomic_add_f32(p + 2, v.z); atomic_add_f32(p + 3, v.w);
-        }
-        if (W1) atomic_add_f32(grad_w1 + row, a.w1g[t]);
-    }
-}
-
-// K1 backward, float4 rows: grid (F, chunks) as gather_bwd_kernel
-__global__ __launch_bounds__(kThreads) void gather_bwd_sorted_kernel(
-    const int64_t* __restrict__ ids, const float* __restrict__ g, const int64_t* __restrict__ row_base,
-    unsigned B, unsigned F, unsigned KV, unsigned g_stride, unsigned g_col, float* __restrict__ grad_arena) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const SAgg a = sagg_carve(smem_raw, KV);
-    sagg_init(a);
-    const unsigned f = blockIdx.x;
-    const unsigned b0 = blockIdx.y * kExPerBlk;
-    const unsigned nex = min(kExPerBlk, B - b0);
-    for (unsigned i = threadIdx.x; i < nex * KV; i += kThreads) {
-        const unsigned e = i / KV, q = i - e * KV;
-        a.tile[i] = *reinterpret_cast<const float4*>(g + (size_t)(b0 + e) * g_stride + g_col + (f * KV + q) * 4);
-    }
-    unsigned long long row = kEmpty;
-    if (threadIdx.x < nex) {
-        const int64_t id = ids[(size_t)(b0 + threadIdx.x) * F + f];
-        if (id >= 0) row = (unsigned long long)(row_base[f] + id);
-    }
-    sagg_scatter<false>(a, row, KV, grad_arena, nullptr);
-}
-
-// K1s backward, float4 rows: workgroup = kExPerBlk consecutive (b, t) positions
-__global__ __launch_bounds__(kThreads) void seq_gather_bwd_sorted_kernel(
-    const int64_t* __restrict__ values, const int64_t* __restrict__ offsets, const float* __restrict__ g,
-    unsigned BT, unsigned T, unsigned KV, float* __restrict__ grad_table) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const SAgg a = sagg_carve(smem_raw, KV);
-    sagg_init(a);
-    const unsigned r0 = blockIdx.x * kExPerBlk;
-    const unsigned nr = min(kExPerBlk, BT - r0);
-    for (unsigned i = threadIdx.x; i < nr * KV; i += kThreads)
-        a.tile[i] = reinterpret_cast<const float4*>(g)[(size_t)r0 * KV + i];
-    unsigned long long row = kEmpty;
-    if (threadIdx.x < nr) {
-        const unsigned pos = r0 + threadIdx.x;
-        const unsigned b = pos / T, t = pos - b * T;
-        const int64_t beg = offsets[b];
-        if ((int64_t)t < offsets[b + 1] - beg) {
-            const int64_t id = values[beg + t];
-            if (id >= 0) row = (unsigned long long)id;
-        }
-    }
-    sagg_scatter<false>(a, row, KV, grad_table, nullptr);
-}
-
-// DeepFM sparse backward, float4 rows: grid (F, chunks); row grad = g_emb + g_fm2 * (S - e), the
-// first-order weight gradient g_fm1 rides along in w1g
-__global__ __launch_bounds__(kThreads) void deepfm_sparse_bwd_sorted_kernel(
-    const int64_t* __restrict__ ids, const float4* __restrict__ emb, const float4* __restrict__ fsum,
-    const float4* __restrict__ g_emb, const float* __restrict__ g_fm1, const float* __restrict__ g_fm2,
-    const int64_t* __restrict__ row_base, unsigned B, unsigned F, unsigned K4, float* __restrict__ grad_arena,
-    float* __restrict__ grad_w1) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const SAgg a = sagg_carve(smem_raw, K4);
-    sagg_init(a);
-    const unsigned f = blockIdx.x;
-    const unsigned b0 = blockIdx.y * kExPerBlk;
-    const unsigned nex = min(kExPerBlk, B - b0);
-    for (unsigned i = threadIdx.x; i < nex * K4; i += kThreads) {
-        const unsigned e = i / K4, q = i - e * K4;
-        const unsigned b = b0 + e;
-        const size_t gi = ((size_t)b * F + f) * K4 + q;
-        const float4 ge = g_emb[gi], ev = emb[gi], sv = fsum[(size_t)b * K4 + q];
-        const float g2 = g_fm2[b];
-        a.tile[i] = make_float4(fmaf(g2, sv.x - ev.x, ge.x), fmaf(g2, sv.y - ev.y, ge.y),
-                                fmaf(g2, sv.z - ev.z, ge.z), fmaf(g2, sv.w - ev.w, ge.w));
-    }
-    unsigned long long row = kEmpty;
-    if (threadIdx.x < nex) {
-        a.w1g[threadIdx.x] = g_fm1[b0 + threadIdx.x];
-        const int64_t id = ids[(size_t)(b0 + threadIdx.x) * F + f];
-        if (id >= 0) row = (unsigned long long)(row_base[f] + id);
-    }
-    sagg_scatter<true>(a, row, K4, grad_arena, grad_w1);
-}
-
-// RECALGO_SCATTER=atomic selects the LDS-float-atomic aggregator for the float4 paths too (A/B switch)
-inline bool use_sorted_scatter() {
-    static const bool on = [] {
-        const char* e = getenv("RECALGO_SCATTER");
-        return !(e && e[0] == 'a');
-    }();
-    return on;
-}
-
 inline size_t agg_smem(int W) { return kSlots * sizeof(unsigned long long) + (size_t)kSlots * W * sizeof(float); }
 
 // dynamic LDS above 64 KiB must be opted into per kernel
@@ -671,12 +448,7 @@ RECALGO_EXPORT int recalgo_embedding_gather_bwd(const int64_t* ids, const float*
     if (B == 0) return 0;
     const int vec = vec_of(K, g_stride, g_col);
     dim3 grid(F, cdiv(B, kExPerBlk));
-    if (vec == 4 && use_sorted_scatter()) {
-        ENSURE_SMEM(gather_bwd_sorted_kernel, sagg_smem(K / 4));
-        hipLaunchKernelGGL(gather_bwd_sorted_kernel, grid, dim3(kThreads), sagg_smem(K / 4), as_stream(stream), ids, g,
-                           row_base, (unsigned)B, (unsigned)F, (unsigned)(K / 4), (unsigned)g_stride,
-                           (unsigned)g_col, grad_arena);
-    } else if (vec == 4) {
+    if (vec == 4) {
         ENSURE_SMEM(gather_bwd_kernel<4>, agg_smem(K));
         hipLaunchKernelGGL(gather_bwd_kernel<4>, grid, dim3(kThreads), agg_smem(K), as_stream(stream), ids, g,
                            row_base, (unsigned)B, (unsigned)F, (unsigned)(K / 4), (unsigned)g_stride,
@@ -757,11 +529,7 @@ RECALGO_EXPORT int recalgo_sequence_gather_bwd(const int64_t* values, const int6
     int64_t BT = (int64_t)B * T;
     RECALGO_REQUIRE(BT < (1ll << 31));
     if (BT == 0) return 0;
-    if (K % 4 == 0 && use_sorted_scatter()) {
-        ENSURE_SMEM(seq_gather_bwd_sorted_kernel, sagg_smem(K / 4));
-        hipLaunchKernelGGL(seq_gather_bwd_sorted_kernel, dim3(cdiv(BT, kExPerBlk)), dim3(kThreads), sagg_smem(K / 4),
-                           as_stream(stream), values, offsets, g, (unsigned)BT, (unsigned)T, (unsigned)(K / 4), grad_table);
-    } else if (K % 4 == 0) {
+    if (K % 4 == 0) {
         ENSURE_SMEM(seq_gather_bwd_kernel<4>, agg_smem(K));
         hipLaunchKernelGGL(seq_gather_bwd_kernel<4>, dim3(cdiv(BT, kExPerBlk)), dim3(kThreads), agg_smem(K),
                            as_stream(stream), values, offsets, g, (unsigned)BT, (unsigned)T, (unsigned)(K / 4),
@@ -803,14 +571,6 @@ RECALGO_EXPORT int recalgo_deepfm_sparse_bwd(const int64_t* ids, const float* em
                                              recalgo_stream_t stream) {
     RECALGO_REQUIRE(B >= 0 && F > 0 && K > 0 && K % 4 == 0 && K <= 64);
     if (B == 0) return 0;
-    if (use_sorted_scatter()) {
-        ENSURE_SMEM(deepfm_sparse_bwd_sorted_kernel, sagg_smem(K / 4));
-        hipLaunchKernelGGL(deepfm_sparse_bwd_sorted_kernel, dim3(F, cdiv(B, kExPerBlk)), dim3(kThreads),
-                           sagg_smem(K / 4), as_stream(stream), ids, reinterpret_cast<const float4*>(emb),
-                           reinterpret_cast<const float4*>(field_sum), reinterpret_cast<const float4*>(g_emb), g_fm1,
-                           g_fm2, row_base, (unsigned)B, (unsigned)F, (unsigned)(K / 4), grad_arena, grad_w1);
-        RECALGO_RETURN_LAST();
-    }
     ENSURE_SMEM(deepfm_sparse_bwd_kernel, agg_smem(K + 1));
     hipLaunchKernelGGL(deepfm_sparse_bwd_kernel, dim3(F, cdiv(B, kExPerBlk)), dim3(kThreads), agg_smem(K + 1),
                        as_stream(stream), ids, reinterpret_cast<const float4*>(emb),
