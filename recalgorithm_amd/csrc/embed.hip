@@ -126,7 +126,6 @@ __global__ __launch_bounds__(kThreads) void gather_fwd_kernel(
 
 // K1 backward: grid (F, chunks); workgroup = one field x kExPerBlk examples.
 constexpr unsigned kExPerBlk = 256;
-constexpr unsigned kBatch = 4;      // items whose loads a thread keeps in flight
 
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void gather_bwd_kernel(
@@ -144,30 +143,14 @@ __global__ __launch_bounds__(kThreads) void gather_bwd_kernel(
     const unsigned b0 = blockIdx.y * kExPerBlk;
     const unsigned nex = min(kExPerBlk, B - b0);
     const int64_t rb = row_base[f];
-    // kBatch items per thread and round: all their id and gradient loads are issued before the first
-    // LDS update (a load -> wait -> update loop pays the full HBM latency once per item)
-    const unsigned total = nex * KV;
-    for (unsigned base = threadIdx.x; base < total; base += kThreads * kBatch) {
-        int64_t id[kBatch];
-        V v[kBatch];
-#pragma unroll
-        for (unsigned u = 0; u < kBatch; ++u) {
-            const unsigned i = base + u * kThreads;
-            id[u] = -1;
-            if (i < total) {
-                const unsigned e = i / KV, q = i - e * KV;
-                id[u] = ids[(size_t)(b0 + e) * F + f];
-                v[u] = *reinterpret_cast<const V*>(g + (size_t)(b0 + e) * g_stride + g_col + (f * KV + q) * VEC);
-            }
-        }
-#pragma unroll
-        for (unsigned u = 0; u < kBatch; ++u) {
-            if (id[u] < 0) continue;
-            const unsigned i = base + u * kThreads;
-            const unsigned q = i % KV;
-            const unsigned long long row = (unsigned long long)(rb + id[u]);
-            agg_add<VEC>(a, row, q, v[u], grad_arena + row * K);
-        }
+    for (unsigned i = threadIdx.x; i < nex * KV; i += kThreads) {
+        unsigned e = i / KV, q = i - e * KV;
+        unsigned b = b0 + e;
+        int64_t id = ids[(size_t)b * F + f];
+        if (id < 0) continue;
+        unsigned long long row = (unsigned long long)(rb + id);
+        V v = *reinterpret_cast<const V*>(g + (size_t)b * g_stride + g_col + (f * KV + q) * VEC);
+        agg_add<VEC>(a, row, q, v, grad_arena + row * K);
     }
     __syncthreads();
     agg_flush(a, K, grad_arena, nullptr);
@@ -285,29 +268,17 @@ __global__ __launch_bounds__(kThreads) void seq_gather_bwd_kernel(
     __syncthreads();
     const unsigned r0 = blockIdx.x * kExPerBlk;
     const unsigned nr = min(kExPerBlk, BT - r0);
-    const unsigned total = nr * KV;
-    for (unsigned base = threadIdx.x; base < total; base += kThreads * kBatch) {
-        int64_t id[kBatch];
-        V v[kBatch];
-#pragma unroll
-        for (unsigned u = 0; u < kBatch; ++u) {                  // loads of kBatch items in flight together
-            const unsigned i = base + u * kThreads;
-            id[u] = -1;
-            if (i < total) {
-                const unsigned e = i / KV;
-                const unsigned row = r0 + e;
-                const unsigned b = row / T, t = row - b * T;
-                const int64_t beg = offsets[b];
-                if ((int64_t)t < offsets[b + 1] - beg) id[u] = values[beg + t];
-                v[u] = reinterpret_cast<const V*>(g)[(size_t)r0 * KV + i];
-            }
-        }
-#pragma unroll
-        for (unsigned u = 0; u < kBatch; ++u) {
-            if (id[u] < 0) continue;
-            const unsigned q = (base + u * kThreads) % KV;
-            agg_add<VEC>(a, (unsigned long long)id[u], q, v[u], grad_table + id[u] * K);
-        }
+    for (unsigned i = threadIdx.x; i < nr * KV; i += kThreads) {
+        unsigned e = i / KV, q = i - e * KV;
+        unsigned row = r0 + e;
+        unsigned b = row / T, t = row - b * T;
+        int64_t beg = offsets[b];
+        int64_t len = offsets[b + 1] - beg;
+        if ((int64_t)t >= len) continue;
+        int64_t id = values[beg + t];
+        if (id < 0) continue;
+        V v = reinterpret_cast<const V*>(g)[(size_t)row * KV + q];
+        agg_add<VEC>(a, (unsigned long long)id, q, v, grad_table + id * K);
     }
     __syncthreads();
     agg_flush(a, K, grad_table, nullptr);
@@ -403,45 +374,27 @@ __global__ __launch_bounds__(kThreads) void deepfm_sparse_bwd_kernel(
     const unsigned b0 = blockIdx.y * kExPerBlk;
     const unsigned nex = min(kExPerBlk, B - b0);
     const int64_t rb = row_base[f];
-    const unsigned total = nex * K4;
-    for (unsigned base = threadIdx.x; base < total; base += kThreads * kBatch) {
-        int64_t id[kBatch];
-        float4 ge[kBatch], ev[kBatch], sv[kBatch];
-        float g1[kBatch], g2[kBatch];
-#pragma unroll
-        for (unsigned u = 0; u < kBatch; ++u) {                  // loads of kBatch items in flight together
-            const unsigned i = base + u * kThreads;
-            id[u] = -1;
-            if (i < total) {
-                const unsigned e = i / K4, q = i - e * K4;
-                const unsigned b = b0 + e;
-                const size_t gi = ((size_t)b * F + f) * K4 + q;
-                id[u] = ids[(size_t)b * F + f];
-                ge[u] = g_emb[gi];
-                ev[u] = emb[gi];
-                sv[u] = fsum[(size_t)b * K4 + q];
-                g2[u] = g_fm2[b];
-                g1[u] = g_fm1[b];
-            }
-        }
-#pragma unroll
-        for (unsigned u = 0; u < kBatch; ++u) {
-            if (id[u] < 0) continue;
-            const unsigned q = (base + u * kThreads) % K4;
-            const unsigned long long row = (unsigned long long)(rb + id[u]);
-            const float4 v = make_float4(fmaf(g2[u], sv[u].x - ev[u].x, ge[u].x), fmaf(g2[u], sv[u].y - ev[u].y, ge[u].y),
-                                         fmaf(g2[u], sv[u].z - ev[u].z, ge[u].z), fmaf(g2[u], sv[u].w - ev[u].w, ge[u].w));
-            const unsigned s = agg_slot(a, row);
-            if (s < kSlots) {
-                float* p = a.acc + s * a.W + q * 4;
-                lds_add(p + 0, v.x); lds_add(p + 1, v.y); lds_add(p + 2, v.z); lds_add(p + 3, v.w);
-                if (q == 0) lds_add(a.acc + s * a.W + K, g1[u]);
-            } else {
-                float* p = grad_arena + row * K + q * 4;
-                atomic_add_f32(p + 0, v.x); atomic_add_f32(p + 1, v.y);
-                atomic_add_f32(p + 2, v.z); atomic_add_f32(p + 3, v.w);
-                if (q == 0) atomic_add_f32(grad_w1 + row, g1[u]);
-            }
+    for (unsigned i = threadIdx.x; i < nex * K4; i += kThreads) {
+        unsigned e = i / K4, q = i - e * K4;
+        unsigned b = b0 + e;
+        int64_t id = ids[(size_t)b * F + f];
+        if (id < 0) continue;
+        unsigned long long row = (unsigned long long)(rb + id);
+        size_t gi = ((size_t)b * F + f) * K4 + q;
+        float4 ge = g_emb[gi], ev = emb[gi], sv = fsum[(size_t)b * K4 + q];
+        float g2 = g_fm2[b];
+        float4 v = make_float4(fmaf(g2, sv.x - ev.x, ge.x), fmaf(g2, sv.y - ev.y, ge.y),
+                               fmaf(g2, sv.z - ev.z, ge.z), fmaf(g2, sv.w - ev.w, ge.w));
+        unsigned s = agg_slot(a, row);
+        if (s < kSlots) {
+            float* p = a.acc + s * a.W + q * 4;
+            lds_add(p + 0, v.x); lds_add(p + 1, v.y); lds_add(p + 2, v.z); lds_add(p + 3, v.w);
+            if (q == 0) lds_add(a.acc + s * a.W + K, g_fm1[b]);
+        } else {
+            float* p = grad_arena + row * K + q * 4;
+            atomic_add_f32(p + 0, v.x); atomic_add_f32(p + 1, v.y);
+            atomic_add_f32(p + 2, v.z); atomic_add_f32(p + 3, v.w);
+            if (q == 0) atomic_add_f32(grad_w1 + row, g_fm1[b]);
         }
     }
     __syncthreads();
