@@ -30,23 +30,17 @@ template <> __device__ __forceinline__ float vzero<1>() { return 0.f; }
 // workgroup-local row-gradient aggregator
 // ---------------------------------------------------------------------------------------------
 constexpr unsigned kSlots = 512;                       // power of two
-constexpr unsigned kExPerBlk = 256;                    // items (rows to scatter) per workgroup = threads
 constexpr unsigned long long kEmpty = ~0ull;
 
 struct Agg {
     unsigned long long* keys;   // [kSlots]
     float* acc;                 // [kSlots][W]   (W = row width, + 1 for the fused w1 gradient)
     unsigned W;
-    int* cnt;                   // [kSlots]  items per slot            (two-phase kernels only)
-    unsigned short* slot_of;    // [kExPerBlk] slot of item e          (two-phase kernels only)
 };
-constexpr unsigned kNoItem = 0xFFFFu;      // slot_of: the item requests nothing (id < 0, padding)
 
 __device__ __forceinline__ void agg_init(const Agg& a) {
     for (unsigned i = threadIdx.x; i < kSlots; i += blockDim.x) a.keys[i] = kEmpty;
     for (unsigned i = threadIdx.x; i < kSlots * a.W; i += blockDim.x) a.acc[i] = 0.f;
-    if (a.cnt)
-        for (unsigned i = threadIdx.x; i < kSlots; i += blockDim.x) a.cnt[i] = 0;
 }
 
 // returns the slot of `row`, or kSlots if the probe sequence is exhausted
@@ -109,76 +103,6 @@ __device__ __forceinline__ void agg_flush(const Agg& a, unsigned K, float* __res
     }
 }
 
-__device__ __forceinline__ Agg agg_carve2(unsigned char* smem, unsigned W) {
-    Agg a;
-    a.keys = reinterpret_cast<unsigned long long*>(smem);
-    a.acc = reinterpret_cast<float*>(smem + kSlots * sizeof(unsigned long long));
-    a.W = W;
-    a.cnt = reinterpret_cast<int*>(a.acc + (size_t)kSlots * W);
-    a.slot_of = reinterpret_cast<unsigned short*>(a.cnt + kSlots);
-    return a;
-}
-
-// ---- two-phase use (one item per thread; gather / sequence / DeepFM backward) -------------------
-// LDS float atomics are the scarce resource of these kernels (ds_add_f32 keeps the LDS pipe busy
-// ~29 cycles per wave instruction: SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS, profiles/r01q_dcn_pmc_sq.md),
-// and a row that occurs ONCE in the workgroup gains nothing from being accumulated in LDS: its K
-// floats need K global atomics either way.  Phase A hashes every item's row and counts the items
-// per slot (one integer LDS atomic per item instead of K float ones); phase B sends the rows with a
-// count of 1 straight to the global atomics and only the duplicated rows through the LDS accumulator;
-// the flush then visits the duplicated slots only.
-__device__ __forceinline__ void agg_register(const Agg& a, unsigned item, bool valid, unsigned long long row) {
-    unsigned s = kNoItem;
-    if (valid) {
-        s = agg_slot(a, row);
-        if (s < kSlots) atomicAdd(&a.cnt[s], 1);
-    }
-    a.slot_of[item] = (unsigned short)s;               // kSlots (< 0xFFFF) = probe sequence exhausted
-}
-
-template <int VEC>
-__device__ __forceinline__ void agg_add2(const Agg& a, unsigned s, unsigned chunk, typename VecT<VEC>::type v,
-                                         float* __restrict__ gdst_row) {
-    if (s < kSlots && a.cnt[s] > 1) {
-        if constexpr (VEC == 4) {
-            float* p = a.acc + s * a.W + chunk * 4;
-            lds_add(p + 0, v.x); lds_add(p + 1, v.y); lds_add(p + 2, v.z); lds_add(p + 3, v.w);
-        } else {
-            lds_add(a.acc + s * a.W + chunk, v);
-        }
-    } else {
-        if constexpr (VEC == 4) {
-            float* p = gdst_row + chunk * 4;
-            if (v.x != 0.f) atomic_add_f32(p + 0, v.x);
-            if (v.y != 0.f) atomic_add_f32(p + 1, v.y);
-            if (v.z != 0.f) atomic_add_f32(p + 2, v.z);
-            if (v.w != 0.f) atomic_add_f32(p + 3, v.w);
-        } else {
-            if (v != 0.f) atomic_add_f32(gdst_row + chunk, v);
-        }
-    }
-}
-
-// flush of the duplicated slots only (cnt > 1)
-__device__ __forceinline__ void agg_flush2(const Agg& a, unsigned K, float* __restrict__ grad,
-                                           float* __restrict__ grad_w1) {
-    const unsigned lanes = K <= 16 ? 16 : (K <= 32 ? 32 : 64);
-    const unsigned per_pass = blockDim.x / lanes;
-    const unsigned l = threadIdx.x % lanes, grp = threadIdx.x / lanes;
-    for (unsigned s = grp; s < kSlots; s += per_pass) {
-        if (a.cnt[s] <= 1) continue;
-        const unsigned long long row = a.keys[s];
-        for (unsigned k = l; k < K; k += lanes) {
-            float v = a.acc[s * a.W + k];
-            if (v != 0.f) atomic_add_f32(grad + row * K + k, v);
-        }
-        if (grad_w1 && l == 0) {
-            float v = a.acc[s * a.W + K];
-            if (v != 0.f) atomic_add_f32(grad_w1 + row, v);
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // K1 forward: one VEC-wide chunk of one (b, f) row per thread.
 // ---------------------------------------------------------------------------------------------
@@ -201,6 +125,7 @@ __global__ __launch_bounds__(kThreads) void gather_fwd_kernel(
 }
 
 // K1 backward: grid (F, chunks); workgroup = one field x kExPerBlk examples.
+constexpr unsigned kExPerBlk = 256;
 
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void gather_bwd_kernel(
@@ -210,30 +135,25 @@ __global__ __launch_bounds__(kThreads) void gather_bwd_kernel(
     using V = typename VecT<VEC>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const unsigned K = KV * VEC;
-    const Agg a = agg_carve2(smem_raw, K);
+    Agg a{reinterpret_cast<unsigned long long*>(smem_raw),
+          reinterpret_cast<float*>(smem_raw + kSlots * sizeof(unsigned long long)), K};
     agg_init(a);
     __syncthreads();
     const unsigned f = blockIdx.x;
     const unsigned b0 = blockIdx.y * kExPerBlk;
     const unsigned nex = min(kExPerBlk, B - b0);
     const int64_t rb = row_base[f];
-    {   // phase A: item = example threadIdx.x
-        int64_t id = -1;
-        if (threadIdx.x < nex) id = ids[(size_t)(b0 + threadIdx.x) * F + f];
-        agg_register(a, threadIdx.x, id >= 0, (unsigned long long)(rb + id));
-    }
-    __syncthreads();
     for (unsigned i = threadIdx.x; i < nex * KV; i += kThreads) {
         unsigned e = i / KV, q = i - e * KV;
-        const unsigned s = a.slot_of[e];
-        if (s == kNoItem) continue;
         unsigned b = b0 + e;
-        const unsigned long long row = s < kSlots ? a.keys[s] : (unsigned long long)(rb + ids[(size_t)b * F + f]);
+        int64_t id = ids[(size_t)b * F + f];
+        if (id < 0) continue;
+        unsigned long long row = (unsigned long long)(rb + id);
         V v = *reinterpret_cast<const V*>(g + (size_t)b * g_stride + g_col + (f * KV + q) * VEC);
-        agg_add2<VEC>(a, s, q, v, grad_arena + row * K);
+        agg_add<VEC>(a, row, q, v, grad_arena + row * K);
     }
     __syncthreads();
-    agg_flush2(a, K, grad_arena, nullptr);
+    agg_flush(a, K, grad_arena, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -280,7 +200,7 @@ __global__ __launch_bounds__(kThreads) void bag_mean_bwd_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const unsigned K = KV * VEC;
     Agg a{reinterpret_cast<unsigned long long*>(smem_raw),
-          reinterpret_cast<float*>(smem_raw + kSlots * sizeof(unsigned long long)), K, nullptr, nullptr};
+          reinterpret_cast<float*>(smem_raw + kSlots * sizeof(unsigned long long)), K};
     agg_init(a);
     __syncthreads();
     const unsigned b0 = blockIdx.x * kExPerBlk;
@@ -342,39 +262,26 @@ __global__ __launch_bounds__(kThreads) void seq_gather_bwd_kernel(
     using V = typename VecT<VEC>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const unsigned K = KV * VEC;
-    const Agg a = agg_carve2(smem_raw, K);
+    Agg a{reinterpret_cast<unsigned long long*>(smem_raw),
+          reinterpret_cast<float*>(smem_raw + kSlots * sizeof(unsigned long long)), K};
     agg_init(a);
     __syncthreads();
     const unsigned r0 = blockIdx.x * kExPerBlk;
     const unsigned nr = min(kExPerBlk, BT - r0);
-    {   // phase A: item = position r0 + threadIdx.x
-        int64_t id = -1;
-        if (threadIdx.x < nr) {
-            const unsigned pos = r0 + threadIdx.x;
-            const unsigned b = pos / T, t = pos - b * T;
-            const int64_t beg = offsets[b];
-            if ((int64_t)t < offsets[b + 1] - beg) id = values[beg + t];
-        }
-        agg_register(a, threadIdx.x, id >= 0, (unsigned long long)id);
-    }
-    __syncthreads();
     for (unsigned i = threadIdx.x; i < nr * KV; i += kThreads) {
         unsigned e = i / KV, q = i - e * KV;
-        const unsigned s = a.slot_of[e];
-        if (s == kNoItem) continue;
-        unsigned long long id;
-        if (s < kSlots) {
-            id = a.keys[s];
-        } else {
-            const unsigned pos = r0 + e;
-            const unsigned b = pos / T, t = pos - b * T;
-            id = (unsigned long long)values[offsets[b] + t];
-        }
-        V v = reinterpret_cast<const V*>(g)[(size_t)(r0 + e) * KV + q];
-        agg_add2<VEC>(a, s, q, v, grad_table + id * K);
+        unsigned row = r0 + e;
+        unsigned b = row / T, t = row - b * T;
+        int64_t beg = offsets[b];
+        int64_t len = offsets[b + 1] - beg;
+        if ((int64_t)t >= len) continue;
+        int64_t id = values[beg + t];
+        if (id < 0) continue;
+        V v = reinterpret_cast<const V*>(g)[(size_t)row * KV + q];
+        agg_add<VEC>(a, (unsigned long long)id, q, v, grad_table + id * K);
     }
     __syncthreads();
-    agg_flush2(a, K, grad_table, nullptr);
+    agg_flush(a, K, grad_table, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -459,31 +366,27 @@ __global__ __launch_bounds__(kThreads) void deepfm_sparse_bwd_kernel(
     float* __restrict__ grad_arena, float* __restrict__ grad_w1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const unsigned K = K4 * 4;
-    const Agg a = agg_carve2(smem_raw, K + 1);
+    Agg a{reinterpret_cast<unsigned long long*>(smem_raw),
+          reinterpret_cast<float*>(smem_raw + kSlots * sizeof(unsigned long long)), K + 1};
     agg_init(a);
     __syncthreads();
     const unsigned f = blockIdx.x;
     const unsigned b0 = blockIdx.y * kExPerBlk;
     const unsigned nex = min(kExPerBlk, B - b0);
     const int64_t rb = row_base[f];
-    {   // phase A: item = example threadIdx.x
-        int64_t id = -1;
-        if (threadIdx.x < nex) id = ids[(size_t)(b0 + threadIdx.x) * F + f];
-        agg_register(a, threadIdx.x, id >= 0, (unsigned long long)(rb + id));
-    }
-    __syncthreads();
     for (unsigned i = threadIdx.x; i < nex * K4; i += kThreads) {
         unsigned e = i / K4, q = i - e * K4;
-        const unsigned s = a.slot_of[e];
-        if (s == kNoItem) continue;
         unsigned b = b0 + e;
-        const unsigned long long row = s < kSlots ? a.keys[s] : (unsigned long long)(rb + ids[(size_t)b * F + f]);
+        int64_t id = ids[(size_t)b * F + f];
+        if (id < 0) continue;
+        unsigned long long row = (unsigned long long)(rb + id);
         size_t gi = ((size_t)b * F + f) * K4 + q;
         float4 ge = g_emb[gi], ev = emb[gi], sv = fsum[(size_t)b * K4 + q];
         float g2 = g_fm2[b];
         float4 v = make_float4(fmaf(g2, sv.x - ev.x, ge.x), fmaf(g2, sv.y - ev.y, ge.y),
                                fmaf(g2, sv.z - ev.z, ge.z), fmaf(g2, sv.w - ev.w, ge.w));
-        if (s < kSlots && a.cnt[s] > 1) {
+        unsigned s = agg_slot(a, row);
+        if (s < kSlots) {
             float* p = a.acc + s * a.W + q * 4;
             lds_add(p + 0, v.x); lds_add(p + 1, v.y); lds_add(p + 2, v.z); lds_add(p + 3, v.w);
             if (q == 0) lds_add(a.acc + s * a.W + K, g_fm1[b]);
@@ -495,11 +398,10 @@ __global__ __launch_bounds__(kThreads) void deepfm_sparse_bwd_kernel(
         }
     }
     __syncthreads();
-    agg_flush2(a, K, grad_arena, grad_w1);
+    agg_flush(a, K, grad_arena, grad_w1);
 }
 
 inline size_t agg_smem(int W) { return kSlots * sizeof(unsigned long long) + (size_t)kSlots * W * sizeof(float); }
-inline size_t agg_smem2(int W) { return agg_smem(W) + kSlots * sizeof(int) + kExPerBlk * sizeof(unsigned short); }
 
 // dynamic LDS above 64 KiB must be opted into per kernel
 #define ENSURE_SMEM(kern, bytes)                                                                       \
@@ -547,13 +449,13 @@ RECALGO_EXPORT int recalgo_embedding_gather_bwd(const int64_t* ids, const float*
     const int vec = vec_of(K, g_stride, g_col);
     dim3 grid(F, cdiv(B, kExPerBlk));
     if (vec == 4) {
-        ENSURE_SMEM(gather_bwd_kernel<4>, agg_smem2(K));
-        hipLaunchKernelGGL(gather_bwd_kernel<4>, grid, dim3(kThreads), agg_smem2(K), as_stream(stream), ids, g,
+        ENSURE_SMEM(gather_bwd_kernel<4>, agg_smem(K));
+        hipLaunchKernelGGL(gather_bwd_kernel<4>, grid, dim3(kThreads), agg_smem(K), as_stream(stream), ids, g,
                            row_base, (unsigned)B, (unsigned)F, (unsigned)(K / 4), (unsigned)g_stride,
                            (unsigned)g_col, grad_arena);
     } else {
-        ENSURE_SMEM(gather_bwd_kernel<1>, agg_smem2(K));
-        hipLaunchKernelGGL(gather_bwd_kernel<1>, grid, dim3(kThreads), agg_smem2(K), as_stream(stream), ids, g,
+        ENSURE_SMEM(gather_bwd_kernel<1>, agg_smem(K));
+        hipLaunchKernelGGL(gather_bwd_kernel<1>, grid, dim3(kThreads), agg_smem(K), as_stream(stream), ids, g,
                            row_base, (unsigned)B, (unsigned)F, (unsigned)K, (unsigned)g_stride,
                            (unsigned)g_col, grad_arena);
     }
@@ -628,13 +530,13 @@ RECALGO_EXPORT int recalgo_sequence_gather_bwd(const int64_t* values, const int6
     RECALGO_REQUIRE(BT < (1ll << 31));
     if (BT == 0) return 0;
     if (K % 4 == 0) {
-        ENSURE_SMEM(seq_gather_bwd_kernel<4>, agg_smem2(K));
-        hipLaunchKernelGGL(seq_gather_bwd_kernel<4>, dim3(cdiv(BT, kExPerBlk)), dim3(kThreads), agg_smem2(K),
+        ENSURE_SMEM(seq_gather_bwd_kernel<4>, agg_smem(K));
+        hipLaunchKernelGGL(seq_gather_bwd_kernel<4>, dim3(cdiv(BT, kExPerBlk)), dim3(kThreads), agg_smem(K),
                            as_stream(stream), values, offsets, g, (unsigned)BT, (unsigned)T, (unsigned)(K / 4),
                            grad_table);
     } else {
-        ENSURE_SMEM(seq_gather_bwd_kernel<1>, agg_smem2(K));
-        hipLaunchKernelGGL(seq_gather_bwd_kernel<1>, dim3(cdiv(BT, kExPerBlk)), dim3(kThreads), agg_smem2(K),
+        ENSURE_SMEM(seq_gather_bwd_kernel<1>, agg_smem(K));
+        hipLaunchKernelGGL(seq_gather_bwd_kernel<1>, dim3(cdiv(BT, kExPerBlk)), dim3(kThreads), agg_smem(K),
                            as_stream(stream), values, offsets, g, (unsigned)BT, (unsigned)T, (unsigned)K,
                            grad_table);
     }
@@ -669,8 +571,8 @@ RECALGO_EXPORT int recalgo_deepfm_sparse_bwd(const int64_t* ids, const float* em
                                              recalgo_stream_t stream) {
     RECALGO_REQUIRE(B >= 0 && F > 0 && K > 0 && K % 4 == 0 && K <= 64);
     if (B == 0) return 0;
-    ENSURE_SMEM(deepfm_sparse_bwd_kernel, agg_smem2(K + 1));
-    hipLaunchKernelGGL(deepfm_sparse_bwd_kernel, dim3(F, cdiv(B, kExPerBlk)), dim3(kThreads), agg_smem2(K + 1),
+    ENSURE_SMEM(deepfm_sparse_bwd_kernel, agg_smem(K + 1));
+    hipLaunchKernelGGL(deepfm_sparse_bwd_kernel, dim3(F, cdiv(B, kExPerBlk)), dim3(kThreads), agg_smem(K + 1),
                        as_stream(stream), ids, reinterpret_cast<const float4*>(emb),
                        reinterpret_cast<const float4*>(field_sum), reinterpret_cast<const float4*>(g_emb),
                        g_fm1, g_fm2, row_base, (unsigned)B, (unsigned)F, (unsigned)(K / 4), grad_arena, grad_w1);
