@@ -29,7 +29,7 @@ template <> __device__ __forceinline__ float vzero<1>() { return 0.f; }
 // ---------------------------------------------------------------------------------------------
 // workgroup-local row-gradient aggregator
 // ---------------------------------------------------------------------------------------------
-constexpr unsigned kSlots = 512;                       // power of two
+constexpr unsigned kSlots = 128;                       // power of two, 2x the examples of a workgroup
 constexpr unsigned long long kEmpty = ~0ull;
 
 struct Agg {
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kThreads) void gather_fwd_kernel(
 }
 
 // K1 backward: grid (F, chunks); workgroup = one field x kExPerBlk examples.
-constexpr unsigned kExPerBlk = 256;
+constexpr unsigned kExPerBlk = 64;       // small workgroup tiles: 6.5 waves per SIMD at B = 4096, F = 26 (256-example tiles left 1.6 and the waves 70 % parked: profiles/r01q_dcn_pmc_sq.md)
 
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void gather_bwd_kernel(
