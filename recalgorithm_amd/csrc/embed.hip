@@ -11,6 +11,8 @@
 // rows inside the workgroup in an LDS hash table (ds_add_f32), and only then issues ONE global
 // atomic per distinct row per workgroup.  Workgroups are organised per (field, example chunk) so
 // that duplicates meet in the same table.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -29,23 +31,29 @@ template <> __device__ __forceinline__ float vzero<1>() { return 0.f; }
 // ---------------------------------------------------------------------------------------------
 // workgroup-local row-gradient aggregator
 // ---------------------------------------------------------------------------------------------
-constexpr unsigned kSlots = 128;                       // power of two, 2x the examples of a workgroup
+// The table has 2x as many slots as the workgroup has examples (a power of two, runtime: the tile
+// size is chosen per kernel, see scatter_tile()).
 constexpr unsigned long long kEmpty = ~0ull;
 
 struct Agg {
-    unsigned long long* keys;   // [kSlots]
-    float* acc;                 // [kSlots][W]   (W = row width, + 1 for the fused w1 gradient)
+    unsigned long long* keys;   // [slots]
+    float* acc;                 // [slots][W]   (W = row width, + 1 for the fused w1 gradient)
     unsigned W;
+    unsigned slots;
 };
-
-__device__ __forceinline__ void agg_init(const Agg& a) {
-    for (unsigned i = threadIdx.x; i < kSlots; i += blockDim.x) a.keys[i] = kEmpty;
-    for (unsigned i = threadIdx.x; i < kSlots * a.W; i += blockDim.x) a.acc[i] = 0.f;
+__device__ __forceinline__ Agg agg_carve(unsigned char* smem, unsigned W, unsigned slots) {
+    return Agg{reinterpret_cast<unsigned long long*>(smem),
+               reinterpret_cast<float*>(smem + slots * sizeof(unsigned long long)), W, slots};
 }
 
-// returns the slot of `row`, or kSlots if the probe sequence is exhausted
+__device__ __forceinline__ void agg_init(const Agg& a) {
+    for (unsigned i = threadIdx.x; i < a.slots; i += blockDim.x) a.keys[i] = kEmpty;
+    for (unsigned i = threadIdx.x; i < a.slots * a.W; i += blockDim.x) a.acc[i] = 0.f;
+}
+
+// returns the slot of `row`, or a.slots if the probe sequence is exhausted
 __device__ __forceinline__ unsigned agg_slot(const Agg& a, unsigned long long row) {
-    unsigned h = (unsigned)((row * 0x9E3779B97F4A7C15ull) >> 40) & (kSlots - 1);
+    unsigned h = (unsigned)((row * 0x9E3779B97F4A7C15ull) >> 40) & (a.slots - 1);
 #pragma unroll 1
     for (int probe = 0; probe < 16; ++probe) {
         unsigned long long k = a.keys[h];
@@ -54,9 +62,9 @@ __device__ __forceinline__ unsigned agg_slot(const Agg& a, unsigned long long ro
             unsigned long long old = atomicCAS(&a.keys[h], kEmpty, row);
             if (old == kEmpty || old == row) return h;
         }
-        h = (h + 1) & (kSlots - 1);
+        h = (h + 1) & (a.slots - 1);
     }
-    return kSlots;
+    return a.slots;
 }
 
 __device__ __forceinline__ void lds_add(float* p, float v) {
@@ -68,7 +76,7 @@ __device__ __forceinline__ void agg_add(const Agg& a, unsigned long long row, un
                                         typename VecT<VEC>::type v, float* __restrict__ gdst_row) {
     unsigned s = agg_slot(a, row);
     if constexpr (VEC == 4) {
-        if (s < kSlots) {
+        if (s < a.slots) {
             float* p = a.acc + s * a.W + chunk * 4;
             lds_add(p + 0, v.x); lds_add(p + 1, v.y); lds_add(p + 2, v.z); lds_add(p + 3, v.w);
         } else {
@@ -77,7 +85,7 @@ __device__ __forceinline__ void agg_add(const Agg& a, unsigned long long row, un
             atomic_add_f32(p + 2, v.z); atomic_add_f32(p + 3, v.w);
         }
     } else {
-        if (s < kSlots) lds_add(a.acc + s * a.W + chunk, v);
+        if (s < a.slots) lds_add(a.acc + s * a.W + chunk, v);
         else atomic_add_f32(gdst_row + chunk, v);
     }
 }
@@ -89,7 +97,7 @@ __device__ __forceinline__ void agg_flush(const Agg& a, unsigned K, float* __res
     const unsigned lanes = K <= 16 ? 16 : (K <= 32 ? 32 : 64);   // lanes per slot
     const unsigned per_pass = blockDim.x / lanes;
     const unsigned l = threadIdx.x % lanes, grp = threadIdx.x / lanes;
-    for (unsigned s = grp; s < kSlots; s += per_pass) {
+    for (unsigned s = grp; s < a.slots; s += per_pass) {
         unsigned long long row = a.keys[s];
         if (row == kEmpty) continue;
         for (unsigned k = l; k < K; k += lanes) {
@@ -124,24 +132,25 @@ __global__ __launch_bounds__(kThreads) void gather_fwd_kernel(
     *reinterpret_cast<V*>(out + (size_t)b * out_stride + out_col + (f * KV + q) * VEC) = v;
 }
 
-// K1 backward: grid (F, chunks); workgroup = one field x kExPerBlk examples.
-constexpr unsigned kExPerBlk = 64;       // small workgroup tiles: 6.5 waves per SIMD at B = 4096, F = 26 (256-example tiles left 1.6 and the waves 70 % parked: profiles/r01q_dcn_pmc_sq.md)
+// K1 backward: grid (F, chunks); workgroup = one field x ex examples.
+// `ex` (examples per workgroup, a kernel argument) trades duplicate combining against parallelism: with
+// 256-example tiles a B = 4096, F = 26 launch is 1.6 waves per SIMD and the waves sit parked 70 % of the
+// time (profiles/r01q_dcn_pmc_sq.md); 64-example tiles give 6.5 waves per SIMD (gather_bwd 21 -> 16.5 us).
 
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void gather_bwd_kernel(
     const int64_t* __restrict__ ids, const float* __restrict__ g,
     const int64_t* __restrict__ row_base, unsigned B, unsigned F, unsigned KV, unsigned g_stride,
-    unsigned g_col, float* __restrict__ grad_arena) {
+    unsigned g_col, float* __restrict__ grad_arena, unsigned ex) {
     using V = typename VecT<VEC>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const unsigned K = KV * VEC;
-    Agg a{reinterpret_cast<unsigned long long*>(smem_raw),
-          reinterpret_cast<float*>(smem_raw + kSlots * sizeof(unsigned long long)), K};
+    const Agg a = agg_carve(smem_raw, K, 2 * ex);
     agg_init(a);
     __syncthreads();
     const unsigned f = blockIdx.x;
-    const unsigned b0 = blockIdx.y * kExPerBlk;
-    const unsigned nex = min(kExPerBlk, B - b0);
+    const unsigned b0 = blockIdx.y * ex;
+    const unsigned nex = min(ex, B - b0);
     const int64_t rb = row_base[f];
     for (unsigned i = threadIdx.x; i < nex * KV; i += kThreads) {
         unsigned e = i / KV, q = i - e * KV;
@@ -195,16 +204,15 @@ template <int VEC>
 __global__ __launch_bounds__(kThreads) void bag_mean_bwd_kernel(
     const int64_t* __restrict__ values, const int64_t* __restrict__ offsets,
     const float* __restrict__ g, unsigned B, unsigned KV, unsigned g_stride, unsigned g_col,
-    float* __restrict__ grad_table) {
+    float* __restrict__ grad_table, unsigned ex) {
     using V = typename VecT<VEC>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const unsigned K = KV * VEC;
-    Agg a{reinterpret_cast<unsigned long long*>(smem_raw),
-          reinterpret_cast<float*>(smem_raw + kSlots * sizeof(unsigned long long)), K};
+    const Agg a = agg_carve(smem_raw, K, 2 * ex);
     agg_init(a);
     __syncthreads();
-    const unsigned b0 = blockIdx.x * kExPerBlk;
-    const unsigned nex = min(kExPerBlk, B - b0);
+    const unsigned b0 = blockIdx.x * ex;
+    const unsigned nex = min(ex, B - b0);
     for (unsigned i = threadIdx.x; i < nex * KV; i += kThreads) {
         unsigned e = i / KV, q = i - e * KV;
         unsigned b = b0 + e;
@@ -253,21 +261,20 @@ __global__ __launch_bounds__(kThreads) void seq_gather_fwd_kernel(
     reinterpret_cast<V*>(out)[i] = v;
 }
 
-// workgroup = kExPerBlk consecutive (b, t) positions
+// workgroup = ex consecutive (b, t) positions
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void seq_gather_bwd_kernel(
     const int64_t* __restrict__ values, const int64_t* __restrict__ offsets,
     const float* __restrict__ g, unsigned BT, unsigned T, unsigned KV,
-    float* __restrict__ grad_table) {
+    float* __restrict__ grad_table, unsigned ex) {
     using V = typename VecT<VEC>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const unsigned K = KV * VEC;
-    Agg a{reinterpret_cast<unsigned long long*>(smem_raw),
-          reinterpret_cast<float*>(smem_raw + kSlots * sizeof(unsigned long long)), K};
+    const Agg a = agg_carve(smem_raw, K, 2 * ex);
     agg_init(a);
     __syncthreads();
-    const unsigned r0 = blockIdx.x * kExPerBlk;
-    const unsigned nr = min(kExPerBlk, BT - r0);
+    const unsigned r0 = blockIdx.x * ex;
+    const unsigned nr = min(ex, BT - r0);
     for (unsigned i = threadIdx.x; i < nr * KV; i += kThreads) {
         unsigned e = i / KV, q = i - e * KV;
         unsigned row = r0 + e;
@@ -363,16 +370,15 @@ __global__ __launch_bounds__(kThreads) void deepfm_sparse_bwd_kernel(
     const float4* __restrict__ fsum, const float4* __restrict__ g_emb,
     const float* __restrict__ g_fm1, const float* __restrict__ g_fm2,
     const int64_t* __restrict__ row_base, unsigned B, unsigned F, unsigned K4,
-    float* __restrict__ grad_arena, float* __restrict__ grad_w1) {
+    float* __restrict__ grad_arena, float* __restrict__ grad_w1, unsigned ex) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const unsigned K = K4 * 4;
-    Agg a{reinterpret_cast<unsigned long long*>(smem_raw),
-          reinterpret_cast<float*>(smem_raw + kSlots * sizeof(unsigned long long)), K + 1};
+    const Agg a = agg_carve(smem_raw, K + 1, 2 * ex);
     agg_init(a);
     __syncthreads();
     const unsigned f = blockIdx.x;
-    const unsigned b0 = blockIdx.y * kExPerBlk;
-    const unsigned nex = min(kExPerBlk, B - b0);
+    const unsigned b0 = blockIdx.y * ex;
+    const unsigned nex = min(ex, B - b0);
     const int64_t rb = row_base[f];
     for (unsigned i = threadIdx.x; i < nex * K4; i += kThreads) {
         unsigned e = i / K4, q = i - e * K4;
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(kThreads) void deepfm_sparse_bwd_kernel(
         float4 v = make_float4(fmaf(g2, sv.x - ev.x, ge.x), fmaf(g2, sv.y - ev.y, ge.y),
                                fmaf(g2, sv.z - ev.z, ge.z), fmaf(g2, sv.w - ev.w, ge.w));
         unsigned s = agg_slot(a, row);
-        if (s < kSlots) {
+        if (s < a.slots) {
             float* p = a.acc + s * a.W + q * 4;
             lds_add(p + 0, v.x); lds_add(p + 1, v.y); lds_add(p + 2, v.z); lds_add(p + 3, v.w);
             if (q == 0) lds_add(a.acc + s * a.W + K, g_fm1[b]);
@@ -401,7 +407,17 @@ __global__ __launch_bounds__(kThreads) void deepfm_sparse_bwd_kernel(
     agg_flush(a, K, grad_arena, grad_w1);
 }
 
-inline size_t agg_smem(int W) { return kSlots * sizeof(unsigned long long) + (size_t)kSlots * W * sizeof(float); }
+inline size_t agg_smem(int W, unsigned ex) { return 2 * ex * (sizeof(unsigned long long) + (size_t)W * sizeof(float)); }
+
+// examples per workgroup of a scatter kernel; RECALGO_SCATTER_TILE=32|64|128|256 overrides (tuning knob)
+inline unsigned scatter_tile(unsigned dflt) {
+    static const unsigned forced = [] {
+        const char* e = getenv("RECALGO_SCATTER_TILE");
+        const long v = e ? atol(e) : 0;
+        return (v == 32 || v == 64 || v == 128 || v == 256) ? (unsigned)v : 0u;
+    }();
+    return forced ? forced : dflt;
+}
 
 // dynamic LDS above 64 KiB must be opted into per kernel
 #define ENSURE_SMEM(kern, bytes)                                                                       \
@@ -447,17 +463,18 @@ RECALGO_EXPORT int recalgo_embedding_gather_bwd(const int64_t* ids, const float*
     RECALGO_REQUIRE(B >= 0 && F > 0 && K > 0 && K <= 64 && g_stride >= g_col + F * K);
     if (B == 0) return 0;
     const int vec = vec_of(K, g_stride, g_col);
-    dim3 grid(F, cdiv(B, kExPerBlk));
+    const unsigned ex = scatter_tile(64);
+    dim3 grid(F, cdiv(B, ex));
     if (vec == 4) {
-        ENSURE_SMEM(gather_bwd_kernel<4>, agg_smem(K));
-        hipLaunchKernelGGL(gather_bwd_kernel<4>, grid, dim3(kThreads), agg_smem(K), as_stream(stream), ids, g,
+        ENSURE_SMEM(gather_bwd_kernel<4>, agg_smem(K, ex));
+        hipLaunchKernelGGL(gather_bwd_kernel<4>, grid, dim3(kThreads), agg_smem(K, ex), as_stream(stream), ids, g,
                            row_base, (unsigned)B, (unsigned)F, (unsigned)(K / 4), (unsigned)g_stride,
-                           (unsigned)g_col, grad_arena);
+                           (unsigned)g_col, grad_arena, ex);
     } else {
-        ENSURE_SMEM(gather_bwd_kernel<1>, agg_smem(K));
-        hipLaunchKernelGGL(gather_bwd_kernel<1>, grid, dim3(kThreads), agg_smem(K), as_stream(stream), ids, g,
+        ENSURE_SMEM(gather_bwd_kernel<1>, agg_smem(K, ex));
+        hipLaunchKernelGGL(gather_bwd_kernel<1>, grid, dim3(kThreads), agg_smem(K, ex), as_stream(stream), ids, g,
                            row_base, (unsigned)B, (unsigned)F, (unsigned)K, (unsigned)g_stride,
-                           (unsigned)g_col, grad_arena);
+                           (unsigned)g_col, grad_arena, ex);
     }
     RECALGO_RETURN_LAST();
 }
@@ -489,16 +506,17 @@ RECALGO_EXPORT int recalgo_embedding_bag_mean_bwd(const int64_t* values, const i
     RECALGO_REQUIRE(B >= 0 && K > 0 && K <= 64 && g_stride >= g_col + K);
     if (B == 0) return 0;
     const int vec = vec_of(K, g_stride, g_col);
+    const unsigned ex = scatter_tile(256);
     if (vec == 4) {
-        ENSURE_SMEM(bag_mean_bwd_kernel<4>, agg_smem(K));
-        hipLaunchKernelGGL(bag_mean_bwd_kernel<4>, dim3(cdiv(B, kExPerBlk)), dim3(kThreads), agg_smem(K),
+        ENSURE_SMEM(bag_mean_bwd_kernel<4>, agg_smem(K, ex));
+        hipLaunchKernelGGL(bag_mean_bwd_kernel<4>, dim3(cdiv(B, ex)), dim3(kThreads), agg_smem(K, ex),
                            as_stream(stream), values, offsets, g, (unsigned)B, (unsigned)(K / 4),
-                           (unsigned)g_stride, (unsigned)g_col, grad_table);
+                           (unsigned)g_stride, (unsigned)g_col, grad_table, ex);
     } else {
-        ENSURE_SMEM(bag_mean_bwd_kernel<1>, agg_smem(K));
-        hipLaunchKernelGGL(bag_mean_bwd_kernel<1>, dim3(cdiv(B, kExPerBlk)), dim3(kThreads), agg_smem(K),
+        ENSURE_SMEM(bag_mean_bwd_kernel<1>, agg_smem(K, ex));
+        hipLaunchKernelGGL(bag_mean_bwd_kernel<1>, dim3(cdiv(B, ex)), dim3(kThreads), agg_smem(K, ex),
                            as_stream(stream), values, offsets, g, (unsigned)B, (unsigned)K,
-                           (unsigned)g_stride, (unsigned)g_col, grad_table);
+                           (unsigned)g_stride, (unsigned)g_col, grad_table, ex);
     }
     RECALGO_RETURN_LAST();
 }
@@ -529,16 +547,17 @@ RECALGO_EXPORT int recalgo_sequence_gather_bwd(const int64_t* values, const int6
     int64_t BT = (int64_t)B * T;
     RECALGO_REQUIRE(BT < (1ll << 31));
     if (BT == 0) return 0;
+    const unsigned ex = scatter_tile(64);
     if (K % 4 == 0) {
-        ENSURE_SMEM(seq_gather_bwd_kernel<4>, agg_smem(K));
-        hipLaunchKernelGGL(seq_gather_bwd_kernel<4>, dim3(cdiv(BT, kExPerBlk)), dim3(kThreads), agg_smem(K),
+        ENSURE_SMEM(seq_gather_bwd_kernel<4>, agg_smem(K, ex));
+        hipLaunchKernelGGL(seq_gather_bwd_kernel<4>, dim3(cdiv(BT, ex)), dim3(kThreads), agg_smem(K, ex),
                            as_stream(stream), values, offsets, g, (unsigned)BT, (unsigned)T, (unsigned)(K / 4),
-                           grad_table);
+                           grad_table, ex);
     } else {
-        ENSURE_SMEM(seq_gather_bwd_kernel<1>, agg_smem(K));
-        hipLaunchKernelGGL(seq_gather_bwd_kernel<1>, dim3(cdiv(BT, kExPerBlk)), dim3(kThreads), agg_smem(K),
+        ENSURE_SMEM(seq_gather_bwd_kernel<1>, agg_smem(K, ex));
+        hipLaunchKernelGGL(seq_gather_bwd_kernel<1>, dim3(cdiv(BT, ex)), dim3(kThreads), agg_smem(K, ex),
                            as_stream(stream), values, offsets, g, (unsigned)BT, (unsigned)T, (unsigned)K,
-                           grad_table);
+                           grad_table, ex);
     }
     RECALGO_RETURN_LAST();
 }
@@ -571,10 +590,11 @@ RECALGO_EXPORT int recalgo_deepfm_sparse_bwd(const int64_t* ids, const float* em
                                              recalgo_stream_t stream) {
     RECALGO_REQUIRE(B >= 0 && F > 0 && K > 0 && K % 4 == 0 && K <= 64);
     if (B == 0) return 0;
-    ENSURE_SMEM(deepfm_sparse_bwd_kernel, agg_smem(K + 1));
-    hipLaunchKernelGGL(deepfm_sparse_bwd_kernel, dim3(F, cdiv(B, kExPerBlk)), dim3(kThreads), agg_smem(K + 1),
+    const unsigned ex = scatter_tile(256);
+    ENSURE_SMEM(deepfm_sparse_bwd_kernel, agg_smem(K + 1, ex));
+    hipLaunchKernelGGL(deepfm_sparse_bwd_kernel, dim3(F, cdiv(B, ex)), dim3(kThreads), agg_smem(K + 1, ex),
                        as_stream(stream), ids, reinterpret_cast<const float4*>(emb),
                        reinterpret_cast<const float4*>(field_sum), reinterpret_cast<const float4*>(g_emb),
-                       g_fm1, g_fm2, row_base, (unsigned)B, (unsigned)F, (unsigned)(K / 4), grad_arena, grad_w1);
+                       g_fm1, g_fm2, row_base, (unsigned)B, (unsigned)F, (unsigned)(K / 4), grad_arena, grad_w1, ex);
     RECALGO_RETURN_LAST();
 }
