@@ -135,7 +135,10 @@ __global__ __launch_bounds__(kThreads) void gather_fwd_kernel(
 // K1 backward: grid (F, chunks); workgroup = one field x ex examples.
 // `ex` (examples per workgroup, a kernel argument) trades duplicate combining against parallelism: with
 // 256-example tiles a B = 4096, F = 26 launch is 1.6 waves per SIMD and the waves sit parked 70 % of the
-// time (profiles/r01q_dcn_pmc_sq.md); 64-example tiles give 6.5 waves per SIMD (gather_bwd 21 -> 16.5 us).
+// time (profiles/r01q_dcn_pmc_sq.md); 64-example tiles give 6.5 waves per SIMD.  Measured in the step
+// (600 steps, two repeats, +-0.1 %): gather_bwd 64 vs 256 -> DCN step 0.317 vs 0.324 ms; the sequence and
+// DeepFM variants are faster with 256 (more duplicates per tile; with 64 the DIN step is 3 % slower even
+// though the isolated, L2-warm launch is faster: the extra global atomics land on cold lines in the step).
 
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void gather_bwd_kernel(
@@ -547,7 +550,7 @@ RECALGO_EXPORT int recalgo_sequence_gather_bwd(const int64_t* values, const int6
     int64_t BT = (int64_t)B * T;
     RECALGO_REQUIRE(BT < (1ll << 31));
     if (BT == 0) return 0;
-    const unsigned ex = scatter_tile(64);
+    const unsigned ex = scatter_tile(256);     // history ids repeat across the batch: big tiles combine more
     if (K % 4 == 0) {
         ENSURE_SMEM(seq_gather_bwd_kernel<4>, agg_smem(K, ex));
         hipLaunchKernelGGL(seq_gather_bwd_kernel<4>, dim3(cdiv(BT, ex)), dim3(kThreads), agg_smem(K, ex),
