@@ -22,7 +22,8 @@ def _hip(x: torch.Tensor, C: int) -> bool:
 
 class _DenseFn(Function):
     @staticmethod
-    def forward(ctx, anchor, x, kernel: Variable, bias: Optional[Variable], relu: bool):
+    def forward(ctx, anchor, x, kernel: Variable, bias: Optional[Variable], relu: bool, input_l2: float = 0.0):
+        ctx.input_l2 = float(input_l2)
         x2 = x.reshape(-1, x.shape[-1])
         if bias is not None and relu and x2.is_cuda:
             y = torch._addmm_activation(bias.data, x2, kernel.data)     # GEMM + bias + ReLU epilogue (hipBLASLt)
@@ -53,8 +54,12 @@ class _DenseFn(Function):
             if bias is not None:
                 torch.sum(g2, dim=0, out=bias.grad)
         torch.mm(x2.t(), g2, out=kernel.grad)
-        dx = g2 @ kernel.data.t()
-        return None, dx.view(ctx.xshape), None, None, None
+        if ctx.input_l2:
+            # d/dx of the activity regulariser (input_l2 / 2) * sum(x^2) rides on the GEMM as its beta * C term
+            dx = torch.addmm(x2, g2, kernel.data.t(), beta=ctx.input_l2)
+        else:
+            dx = g2 @ kernel.data.t()
+        return None, dx.view(ctx.xshape), None, None, None, None
 
 
 class _Dense1Fn(Function):
@@ -102,10 +107,13 @@ def concat(values, axis: int = -1):
 
 
 def dense(x, units, activation: Optional[str] = None,
-          use_bias: bool = True, name: Optional[str] = None) -> torch.Tensor:
+          use_bias: bool = True, name: Optional[str] = None, input_l2: float = 0.0) -> torch.Tensor:
     """tf.layers.dense(x, units, activation=None|relu, use_bias, name).  `units` may be a
     str (the reference passes FLAGS.hidden_units.split(','), deepfm.py:286; quirk B-2).
-    Variables: <scope>/<name>/kernel (glorot-uniform), <scope>/<name>/bias (zeros)."""
+    Variables: <scope>/<name>/kernel (glorot-uniform), <scope>/<name>/bias (zeros).
+    `input_l2` = c (not a TF argument): the caller adds the loss term (c / 2) * sum(x^2) as a VALUE only
+    (`l2_value`) and this layer adds its gradient c * x to the input gradient inside the dgrad GEMM
+    (beta * C epilogue) — c must already contain the loss-gradient seed (ops.loss_seed)."""
     store = current_store()
     units = int(units)
     name = name or store.auto_name("dense")
@@ -122,7 +130,14 @@ def dense(x, units, activation: Optional[str] = None,
             return _Dense1Fn.apply(store.anchor, kernel, bias, *parts)
     if isinstance(x, LazyConcat):
         x = x.materialize()
-    return _DenseFn.apply(store.anchor, x, kernel, bias, activation == "relu")
+    return _DenseFn.apply(store.anchor, x, kernel, bias, activation == "relu", input_l2)
+
+
+def l2_value(x: torch.Tensor, half_coeff: float) -> torch.Tensor:
+    """half_coeff * sum(x^2) as a detached scalar (its gradient is taken care of by `dense(input_l2=)`)."""
+    with torch.no_grad():
+        v = x.reshape(-1)
+        return torch.dot(v, v) * half_coeff
 
 
 class _BatchNormTrainFn(Function):
