@@ -317,12 +317,6 @@ def kernel_rooflines(args, est, feats, device):
                                                                   ar.weight.shape[0], K, 0.0, p(zero_lr), 0.9, 0.999, 1e-8, 1, st),
         n_rows_live * (K * 28 + 4))
     res[-1]["live_fraction"] = round(n_rows_live * K / max(n, 1), 4)
-    if os.environ.get("RECALGO_BENCH_SORTED_LIST") == "1":      # diagnostic: the same launch over an address-ordered list
-        slst = lst.clone()
-        slst[:n_rows_live] = torch.sort(lst[:n_rows_live]).values
-        add("adam_tf1_list(arena, sorted list)", lambda: lib.recalgo_adam_tf1_list(
-            p(ar.weight), p(ar.grad), p(ar.m), p(ar.v), p(slst), p(cnt), ar.weight.shape[0], K, 0.0, p(zero_lr), 0.9, 0.999, 1e-8, 1, st),
-            n_rows_live * (K * 28 + 4))
     return res
 
 
