@@ -35,7 +35,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--model", default="dcn", choices=["dcn", "deepfm", "xdeepfm", "din", "fibinet", "pnn"])
+    ap.add_argument("--model", default="dcn", choices=["dcn", "deepfm", "xdeepfm", "din", "fibinet", "pnn", "fwfm"])
     ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch")
     ap.add_argument("--fields", type=int, default=26)
     ap.add_argument("--emb", type=int, default=16)
@@ -119,6 +119,13 @@ def build_estimator(args, device, rank=0, world=1):
                   "output_dimension": 1024, "product_method": "IPNN", "weight_regularizer": 0.0,
                   "embedding_dim": args.emb}
         workload = f"PNN IPNN D=1024 + MLP 512,256,128; {args.fields} fields x emb{args.emb}; batch {args.batch}/GPU"
+    elif args.model == "fwfm":              # SURVEY.md §8f-3 sibling: no MLP, the step is the sparse path + Adam
+        from recalgorithm_amd.algorithm.FwFM.fwfm import fwfm_model_fn as model_fn
+        cats = sorted(cats, key=lambda c: c.key)
+        params = {"first_order_feature_columns": [fc.indicator_column(c) for c in cats],
+                  "second_order_feature_columns": [fc.embedding_column(c, args.emb) for c in cats],
+                  "embedding_dim": args.emb, "learning_rate": 0.005}
+        workload = f"FwFM first order + field-pair-weighted second order; {args.fields} fields x emb{args.emb}; batch {args.batch}/GPU"
     else:
         raise SystemExit(f"--model {args.model}: unknown")
     est = Estimator(model_fn=model_fn, params=params, config=RunConfig(device=device, seed=42))
@@ -229,8 +236,8 @@ def kernel_rooflines(args, est, feats, device):
             add(f"cin_bwd(L{li + 1},Hk={Hk})", lambda: lib.recalgo_cin_layer_bwd(p(x3), p(xk), p(w), p(go), p(pool), N, 0, B, m, Hk, N, D,
                                                                                  p(dx0), 0, p(dxk), 0, p(dw), p(ws), st),
                 2 * byt, 2.0 * fl)      # bwd = 2x fwd (one GEMM G.W^T feeding dX^k and dX^0, one for dW)
-    if args.model == "deepfm":
-        w1 = store.arenas["fm_first_order_w1"]
+    if args.model in ("deepfm", "fwfm"):
+        w1 = next(a for n, a in store.arenas.items() if n.endswith("_w1"))
         bias = torch.zeros(1, device=device)
         emb = torch.empty(B, d, device=device)
         fm1, fm2, fs = torch.empty(B, device=device), torch.empty(B, device=device), torch.empty(B, K, device=device)
@@ -291,7 +298,7 @@ def kernel_rooflines(args, est, feats, device):
         add("bilinear_bwd(all, 2 sets)", lambda: lib.recalgo_bilinear_bwd(p(E), p(Wo), p(V), p(Wsn), p(g2), 2 * K, 0, B, F, K, 0, p(dE),
                                                                          p(dWo), p(dV), p(dWs), p(wsb), st),
             B * (4 * F * K * 4 + P_ * 2 * K * 4))
-    if args.model == "pnn":
+    if args.model in ("pnn", "fwfm"):
         E = torch.randn(B, F * K, device=device)
         T_ = F * (F + 1) // 2
         D_ = 1024
@@ -302,9 +309,10 @@ def kernel_rooflines(args, est, feats, device):
         add("pnn_features_fwd(IPNN)", lambda: lib.recalgo_pnn_features_fwd(p(E), B, F, K, 0, p(phi), st), B * (F * K + T_) * 4)
         add("pnn_features_bwd(IPNN)", lambda: lib.recalgo_pnn_features_bwd(p(E), p(dphi), B, F, K, 0, p(dE), 0, st),
             B * (2 * F * K + T_) * 4)
-        add("pnn_weights_fwd(IPNN)", lambda: lib.recalgo_pnn_weights_fwd(p(th), D_, F, K, 0, p(om), st), (D_ * F + T_ * D_) * 4)
-        add("pnn_weights_bwd(IPNN)", lambda: lib.recalgo_pnn_weights_bwd(p(th), p(dom), D_, F, K, 0, p(dth), st),
-            (2 * D_ * F + T_ * D_) * 4)
+        if args.model == "pnn":
+            add("pnn_weights_fwd(IPNN)", lambda: lib.recalgo_pnn_weights_fwd(p(th), D_, F, K, 0, p(om), st), (D_ * F + T_ * D_) * 4)
+            add("pnn_weights_bwd(IPNN)", lambda: lib.recalgo_pnn_weights_bwd(p(th), p(dom), D_, F, K, 0, p(dth), st),
+                (2 * D_ * F + T_ * D_) * 4)
     # TF1 dense Adam over the arena (state as left by the timed steps; lr = 0 so that the repeated
     # launches do not move the weights): the update visits the live-row list only — rows no
     # gradient has ever reached have g = m = v = 0, for which the dense update is the identity.

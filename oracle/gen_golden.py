@@ -340,6 +340,14 @@ def model_goldens(tf, vocab_dir):
         dict(common, embedding_dim=8, dropout_rate=0.0, batch_norm=True, output_dimension=20,
              product_method="OPNN", weight_regularizer=0.01))
 
+    # §8f-3 sibling: FwFM (first-order dense over indicators + field-pair-weighted inner products, no MLP)
+    def fwfm_params(m):
+        first, second, label = m.create_feature_columns()
+        return ({"first_order_feature_columns": first, "second_order_feature_columns": second,
+                 "embedding_dim": m.FLAGS.embedding_dim, "learning_rate": m.FLAGS.learning_rate}, first + second)
+    run("model_fwfm", _import_ref("FwFM", "fwfm"), "fwfm_model_fn", fwfm_params,
+        dict(learning_rate=0.005, embedding_dim=8))
+
     # the shared batch
     batch = {"dense": dense, "labels": labels, "dense_names": np.array(DENSE)}
     for k, rows in sfeats.items():
@@ -362,7 +370,10 @@ def main():
         allg = {}
         allg.update(layer_goldens(tf))
         allg.update(model_goldens(tf, vocab_dir))
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]       # e.g. `gen_golden.py model_fwfm`: write these only
     for name, d in allg.items():
+        if only and name not in only:
+            continue
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
         print(f"[golden] {name}.npz  ({len(d)} arrays)")
 

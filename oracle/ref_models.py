@@ -1,6 +1,6 @@
 """oracle/ref_models.py — TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 
-Model-level restatement of the six reference model_fns (forward to logits / loss), composed
+Model-level restatement of the six north_star model_fns (+ the FwFM sibling) (forward to logits / loss), composed
 from oracle/ref_ops.py, op-for-op in the reference's order.  Parameters come in as a dict
 `P` name -> tensor using the reference's TF variable names (scope/.../kernel etc.); gradients
 are obtained by torch.autograd on the returned loss.  Columns are duck-typed: objects with
@@ -114,6 +114,32 @@ def deepfm(P, feats, labels, params, training=False, bn_state=None):
     logit = fm1 + fm2 + deep                                                       # :214
     out = _tail(logit, None if labels is None else labels["read_comment"])
     out.update(fm_first_order_logit=fm1, fm_second_order_logit=fm2, deep_logit=deep)
+    return out
+
+
+def fwfm(P, feats, labels, params, training=False):
+    """algorithm/FwFM/fwfm.py:123-161 (SURVEY.md §8f-3 sibling).  First order as in DeepFM; second order
+    the reference's double loop: sum over i < j of r[index_from_upper_triangular(i, j, F)] * <e_i, e_j>
+    (utils.py:67-82: row-major strict upper triangle), accumulated in loop order."""
+    first_cols = _sorted(params["first_order_feature_columns"])
+    w1 = [P[f"fwfm_first_order/fwfm_first_order_dense/kernel/{c.key}"] for c in first_cols]
+    first = R.indicator_first_order([feats[c.key] for c in first_cols], w1,
+                                    P["fwfm_first_order/fwfm_first_order_dense/bias"][0])         # :135-137
+    fields = []
+    for i, c in enumerate(params["second_order_feature_columns"]):                               # :140-143 list order
+        layer = "input_layer" if i == 0 else f"input_layer_{i}"
+        fields.append(_lookup(P, feats, c, layer, {}))
+    F = len(fields)
+    r = P["fields_pair_strength/fields_pair_strength_weight"]                                     # :146-149
+    second = torch.zeros(fields[0].shape[0], 1, dtype=fields[0].dtype)
+    index = 0
+    for i in range(F - 1):                                                                        # :152-158
+        for j in range(i + 1, F):
+            second = second + r[index] * (fields[i] * fields[j]).sum(dim=1, keepdim=True)
+            index += 1
+    logit = first + second                                                                        # :160
+    out = _tail(logit, None if labels is None else labels["read_comment"])
+    out.update(fwfm_first_order_logit=first, fwfm_second_order_logit=second)
     return out
 
 

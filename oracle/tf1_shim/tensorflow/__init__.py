@@ -310,6 +310,20 @@ def multiply(a, b, name=None):
     return _t(a) * b
 
 
+def scalar_mul(scalar, x, name=None):
+    """tf.scalar_mul: scalar * x (fwfm.py:156)."""
+    return T(_raw(scalar) * _raw(x))
+
+
+def _batch_dot(x, y, axes=None):
+    """[TF-ext] tf.keras.backend.batch_dot on two (B, K) tensors with axes=1: the per-example inner
+    product, kept 2-D -> (B, 1) (Keras expands a rank-1 result; fwfm.py:157)."""
+    a, b = _raw(x), _raw(y)
+    if a.dim() != 2 or b.dim() != 2 or axes not in (1, (1, 1), [1, 1]):
+        raise NotImplementedError("tf1_shim: batch_dot is restated for (B, K) x (B, K), axes=1 only")
+    return T((a * b).sum(dim=1, keepdim=True))
+
+
 def add(a, b, name=None):
     return _t(a) + b
 
@@ -696,6 +710,7 @@ class _Flags:
 
 
 app = types.SimpleNamespace(flags=_Flags, run=lambda *a, **k: None)
+keras = types.SimpleNamespace(backend=types.SimpleNamespace(batch_dot=_batch_dot))
 
 from . import feature_column  # noqa: E402
 from .feature_column import sequence_input_layer as _sequence_input_layer  # noqa: E402

@@ -22,6 +22,7 @@ from ... import flags, nn, ops
 from ...estimator import Estimator, EvalSpec, ModeKeys, RunConfig, TrainSpec, train_and_evaluate
 from ...model_tail import finish_model_fn
 from ...variables import EmbeddingArena, current_store, variable_scope, zeros
+from .. import _common as common
 from ..utils import eval_input_fn, parse_example, train_input_fn
 
 # flags: /root/reference algorithm/DeepFM/deepfm.py:14-41
@@ -70,54 +71,10 @@ def example_parser(serialized_example):
 example_parser.columns_getter = lambda: (total_feature_columns, label_feature_columns)   # native decoder hook
 
 
-def _sparse_part(features, params):
-    """gather + FM1 + FM2 + deep_input through the fused kernel."""
-    store = current_store()
-    first, second = params["first_order_feature_columns"], params["second_order_feature_columns"]
-    keys = [c.key for c in second]
-    K = second[0].dimension
-    if sorted(c.key for c in first) != sorted(keys) or any(c.dimension != K for c in second) or K % 4 or K > 64:
-        raise NotImplementedError(
-            "deepfm_model_fn: the fused sparse kernel needs the first- and second-order columns to "
-            "cover the same categorical keys with one embedding width (multiple of 4, <= 64)")
-    # second-order tables: one fc.input_layer call per column at top level (deepfm.py:187-190)
-    tables = []
-    for i, c in enumerate(second):
-        layer = store.auto_name("input_layer")
-        tables.append(fc._table_for(store, c, store.full_name(layer)))
-    arena = tables[0][0]
-    # first-order (sum V, 1) kernel as a width-1 arena with the same row layout
-    w1 = store.arenas.get("fm_first_order_w1")
-    if w1 is None:
-        w1 = store.arenas["fm_first_order_w1"] = EmbeddingArena("fm_first_order_w1", 1, store.device,
-                                                                 seed=store.seed + 77)
-    if w1.weight is None:
-        total_v = sum(c.categorical_column.num_buckets for c in second)
-        limit = math.sqrt(6.0 / (total_v + 1))              # glorot-uniform of the (sum V, 1) kernel
-        for c in second:
-            v = c.categorical_column.num_buckets
-            init = (torch.rand(v, 1, generator=w1._gen) * 2 - 1) * limit
-            w1.add_table(f"fm_first_order/fm_first_order_dense/kernel/{c.key}", v, init)
-    with variable_scope("fm_first_order"):
-        with variable_scope("fm_first_order_dense"):
-            bias = store.get_variable("bias", (1,), zeros)
-    B = fc._batch_size(features, second[0])
-    if store.building:
-        z = torch.zeros(B, 1, device=store.device)
-        return torch.zeros(B, len(second) * K, device=store.device), z, z
-    if [n for n in w1.tables] != [f"fm_first_order/fm_first_order_dense/kernel/{k}" for k in keys] or \
-            [w1.tables[n][0] for n in w1.tables] != [arena.tables[t][0] for _, t in tables]:
-        raise RuntimeError("first-order arena rows do not mirror the embedding arena")
-    ids = [c.categorical_column.ids(features, store.device) for c in second]
-    if not all(isinstance(i, torch.Tensor) for i in ids):
-        raise NotImplementedError("deepfm_model_fn: multi-valued fields are not part of DeepFM")
-    rb = store.row_base_tensor(arena, [t for _, t in tables])
-    return ops.deepfm_sparse(store, fc._as_matrix(ids), arena, w1, bias, rb)
-
-
 def deepfm_model_fn(features, labels, mode, params):
     """deepfm.py:165-273."""
-    deep_input, fm_first_order_logit, fm_second_order_logit = _sparse_part(features, params)
+    deep_input, fm_first_order_logit, fm_second_order_logit = common.fused_fm_sparse_part(
+        features, params, "fm_first_order", "fm_first_order_dense", "deepfm_model_fn")
     training = mode == ModeKeys.TRAIN
     with variable_scope("fm_deep"):
         net = deep_input

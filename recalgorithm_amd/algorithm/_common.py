@@ -5,11 +5,14 @@ specific to its model.  Reference: the skeleton of /root/reference algorithm/Dee
 from __future__ import annotations
 
 import csv
+import math
 import os
+import torch
 from typing import Callable, Dict, List, Optional, Tuple
 
 from .. import feature_column as fc
-from .. import flags
+from .. import flags, ops
+from ..variables import EmbeddingArena, current_store, variable_scope, zeros
 from ..estimator import Estimator, EvalSpec, RunConfig, TrainSpec, train_and_evaluate
 from .utils import eval_input_fn, parse_example, train_input_fn
 
@@ -126,3 +129,52 @@ def run_estimator(model_fn, params, example_parser):
         print("%s: %s" % (key, metrics[key]))
     write_predictions(estimator, example_parser)
     return estimator
+
+
+def fused_fm_sparse_part(features, params, first_scope: str, dense_name: str, who: str):
+    """gather + first-order (indicator -> dense(1)) + FM second-order + concatenated embeddings through the
+    fused kernel (`recalgo_deepfm_sparse_*`); shared by DeepFM (deepfm.py:179-204) and FwFM (fwfm.py:135-143).
+    The (sum V, 1) kernel `<first_scope>/<dense_name>/kernel` is a width-1 arena mirroring the embedding arena's
+    rows.  -> (embeddings [B, F*K], first_order_logit [B, 1], fm_second_order_logit [B, 1])."""
+    store = current_store()
+    first, second = params["first_order_feature_columns"], params["second_order_feature_columns"]
+    keys = [c.key for c in second]
+    K = second[0].dimension
+    if sorted(c.key for c in first) != sorted(keys) or any(c.dimension != K for c in second) or K % 4 or K > 64:
+        raise NotImplementedError(
+            f"{who}: the fused sparse kernel needs the first- and second-order columns to "
+            "cover the same categorical keys with one embedding width (multiple of 4, <= 64)")
+    # second-order tables: one fc.input_layer call per column at top level (deepfm.py:187-190)
+    tables = []
+    for i, c in enumerate(second):
+        layer = store.auto_name("input_layer")
+        tables.append(fc._table_for(store, c, store.full_name(layer)))
+    arena = tables[0][0]
+    # first-order (sum V, 1) kernel as a width-1 arena with the same row layout
+    w1_name = f"{first_scope}_w1"
+    kprefix = f"{first_scope}/{dense_name}/kernel/"
+    w1 = store.arenas.get(w1_name)
+    if w1 is None:
+        w1 = store.arenas[w1_name] = EmbeddingArena(w1_name, 1, store.device, seed=store.seed + 77)
+    if w1.weight is None:
+        total_v = sum(c.categorical_column.num_buckets for c in second)
+        limit = math.sqrt(6.0 / (total_v + 1))              # glorot-uniform of the (sum V, 1) kernel
+        for c in second:
+            v = c.categorical_column.num_buckets
+            init = (torch.rand(v, 1, generator=w1._gen) * 2 - 1) * limit
+            w1.add_table(kprefix + c.key, v, init)
+    with variable_scope(first_scope):
+        with variable_scope(dense_name):
+            bias = store.get_variable("bias", (1,), zeros)
+    B = fc._batch_size(features, second[0])
+    if store.building:
+        z = torch.zeros(B, 1, device=store.device)
+        return torch.zeros(B, len(second) * K, device=store.device), z, z
+    if [n for n in w1.tables] != [kprefix + k for k in keys] or \
+            [w1.tables[n][0] for n in w1.tables] != [arena.tables[t][0] for _, t in tables]:
+        raise RuntimeError("first-order arena rows do not mirror the embedding arena")
+    ids = [c.categorical_column.ids(features, store.device) for c in second]
+    if not all(isinstance(i, torch.Tensor) for i in ids):
+        raise NotImplementedError(f"{who}: multi-valued fields are not supported by the fused sparse kernel")
+    rb = store.row_base_tensor(arena, [t for _, t in tables])
+    return ops.deepfm_sparse(store, fc._as_matrix(ids), arena, w1, bias, rb)

@@ -624,6 +624,65 @@ def pnn_product_layer(store, emb_flat: torch.Tensor, linear_w: Variable, product
                                PNN_METHODS["IPNN" if method == "IPNN" else "OPNN"])
 
 
+class _FieldPairLogitFn(Function):
+    """logit[b] = sum_{i<j} r[index(i,j)] * <e_i[b], e_j[b]>  (FwFM second order, fwfm.py:146-158): the Gram
+    upper triangle of the fields is `recalgo_pnn_features_*` (IPNN features, diagonal included), the
+    weighted sum over it the one-unit head (`recalgo_dense1_*`) with the pair strengths scattered into a
+    [T] weight vector whose diagonal entries are 0."""
+
+    @staticmethod
+    def forward(ctx, anchor, emb_flat, r: Variable, F, K):
+        B = emb_flat.shape[0]
+        lib = _lib_()
+        T = lib.recalgo_pnn_feature_count(F, K, 0)
+        dev = emb_flat.device
+        phi = torch.empty(B, T, device=dev, dtype=torch.float32)
+        _lib.check(lib.recalgo_pnn_features_fwd(_p(emb_flat), B, F, K, 0, _p(phi), _stream(emb_flat)),
+                   "recalgo_pnn_features_fwd")
+        idx = _pair_index(F, dev)
+        w = torch.zeros(T, 1, device=dev, dtype=torch.float32)
+        w.index_copy_(0, idx, r.data.reshape(-1, 1))
+        ctx.r, ctx.dims = r, (F, K)
+        ctx.save_for_backward(emb_flat, phi, w, idx)
+        return dense1_fwd([phi], w, None)
+
+    @staticmethod
+    def backward(ctx, g):
+        emb_flat, phi, w, idx = ctx.saved_tensors
+        F, K = ctx.dims
+        B = emb_flat.shape[0]
+        dphi = torch.empty_like(phi)
+        dw = torch.empty_like(w)
+        dense1_bwd([phi], w, g.contiguous(), [dphi], dw, None)
+        ctx.r.grad.copy_(dw.reshape(-1).index_select(0, idx).reshape(ctx.r.grad.shape))
+        d_emb = torch.empty_like(emb_flat)
+        _lib.check(_lib_().recalgo_pnn_features_bwd(_p(emb_flat), _p(dphi), B, F, K, 0, _p(d_emb), 0, _stream(emb_flat)),
+                   "recalgo_pnn_features_bwd")
+        return None, d_emb, None, None, None
+
+
+_pair_index_cache = {}
+
+
+def _pair_index(F: int, device) -> torch.Tensor:
+    """index_from_upper_triangular(i, j, F) (reference utils.py:67-82, row-major strict upper triangle) ->
+    column t(i, j) = i*F - i(i-1)/2 + (j - i) of the Gram upper triangle with diagonal (include/recalgo.h)."""
+    key = (F, device)
+    t = _pair_index_cache.get(key)
+    if t is None:
+        cols = [i * F - i * (i - 1) // 2 + (j - i) for i in range(F - 1) for j in range(i + 1, F)]
+        t = _pair_index_cache[key] = torch.tensor(cols, dtype=torch.int64, device=device)
+    return t
+
+
+def field_pair_logit(store, emb_flat: torch.Tensor, r: Variable, F: int, K: int) -> torch.Tensor:
+    """emb_flat [B, F*K], r [F(F-1)/2] -> [B, 1]."""
+    if store.building:
+        return emb_flat.new_zeros(emb_flat.shape[0], 1)
+    _chk(emb_flat, torch.float32, "fields_embeddings")
+    return _FieldPairLogitFn.apply(store.anchor, emb_flat.contiguous(), r, int(F), int(K))
+
+
 # =============================================================================================
 # context-MLP glue (csrc/mlp.hip): dense backward epilogue, BatchNorm training
 # =============================================================================================

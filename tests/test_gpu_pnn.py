@@ -76,3 +76,34 @@ def test_ipnn_identity(dev):
     gram = torch.einsum("bfk,bgk->bfg", E.double(), E.double())
     brute = torch.einsum("if,ig,bfg->bi", th.double(), th.double(), gram)
     assert_close(phi.double() @ omega.double(), brute, what="ipnn identity")
+
+
+@pytest.mark.parametrize("B,F,K", [(4096, 26, 16), (37, 6, 8), (5, 2, 4), (64, 3, 12)])
+def test_field_pair_logit_against_reference_double_loop(dev, B, F, K):
+    """FwFM second order (reference algorithm/FwFM/fwfm.py:146-158): ops.field_pair_logit (IPNN Gram features +
+    one-unit head over the scattered pair strengths) == the reference's double loop over i < j with
+    index_from_upper_triangular ordering, values and gradients (fp64 loop as the reference)."""
+    from recalgorithm_amd import ops
+    from recalgorithm_amd.variables import Variable, VariableStore
+    gen = torch.Generator().manual_seed(B * 31 + F)
+    emb = torch.randn(B, F * K, generator=gen) * 0.5
+    n = F * (F - 1) // 2
+    r = torch.randn(n, generator=gen) * 0.3
+    g = torch.randn(B, 1, generator=gen)
+    ed, rd = emb.double().requires_grad_(True), r.double().requires_grad_(True)
+    fields = [ed[:, f * K:(f + 1) * K] for f in range(F)]
+    ref = torch.zeros(B, 1, dtype=torch.float64)
+    index = 0
+    for i in range(F - 1):
+        for j in range(i + 1, F):
+            ref = ref + rd[index] * (fields[i] * fields[j]).sum(1, keepdim=True)
+            index += 1
+    ref.backward(g.double())
+    store = VariableStore(dev)
+    rv = Variable("fields_pair_strength/fields_pair_strength_weight", r.to(dev))
+    x = emb.to(dev).requires_grad_(True)
+    out = ops.field_pair_logit(store, x, rv, F, K)
+    assert_close(out, ref.detach(), what="fwfm second-order logit")
+    out.backward(g.to(dev))
+    assert_close(x.grad, ed.grad, what="fwfm d(embeddings)")
+    assert_close(rv.grad, rd.grad, what="fwfm d(pair strengths)", reduced=True)
