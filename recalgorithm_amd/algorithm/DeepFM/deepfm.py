@@ -11,17 +11,14 @@ stored as a width-1 arena whose rows mirror the embedding arena, so a single id 
 """
 from __future__ import annotations
 
-import math
 import os
 from typing import Tuple
 
-import torch
-
 from ... import feature_column as fc
-from ... import flags, nn, ops
+from ... import flags, nn
 from ...estimator import Estimator, EvalSpec, ModeKeys, RunConfig, TrainSpec, train_and_evaluate
 from ...model_tail import finish_model_fn
-from ...variables import EmbeddingArena, current_store, variable_scope, zeros
+from ...variables import variable_scope
 from .. import _common as common
 from ..utils import eval_input_fn, parse_example, train_input_fn
 

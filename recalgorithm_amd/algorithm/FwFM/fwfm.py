@@ -20,7 +20,6 @@ from ... import flags, ops
 from ...model_tail import finish_model_fn
 from ...variables import current_store, glorot_uniform, variable_scope
 from .. import _common as common
-from ..utils import parse_example
 
 # flags: /root/reference algorithm/FwFM/fwfm.py:16-40
 common.define_common_flags(batch_size=1024, learning_rate=0.005)

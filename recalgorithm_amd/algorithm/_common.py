@@ -8,7 +8,7 @@ import csv
 import math
 import os
 import torch
-from typing import Callable, Dict, List, Optional, Tuple
+from typing import Callable, Dict, Optional, Tuple
 
 from .. import feature_column as fc
 from .. import flags, ops
