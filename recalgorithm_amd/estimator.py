@@ -418,6 +418,79 @@ class Estimator:
         torch.save(state, tmp)
         os.replace(tmp, self._ckpt_path())
 
+    # -- variables by their reference (TF) names --------------------------------
+    # The mirror keeps every variable under the reference's TF name with the reference's shape, with one
+    # exception: the (sum V, 1) first-order kernel of DeepFM / FwFM (`.../fm_first_order_dense/kernel`) is
+    # stored as one slice per indicator column (`<kernel name>/<column key>`).  TF's input_layer lays the
+    # indicator columns out sorted by column name (`<key>_indicator`), which fixes the row order.
+    def _kernel_slices(self, arrays, name):
+        subs = [k for k in arrays if k.startswith(name + "/")]
+        return sorted(subs, key=lambda k: k[len(name) + 1:] + "_indicator")
+
+    def export_variables(self) -> dict:
+        """{reference TF variable name: numpy array} of the built model (per-column first-order slices are
+        concatenated back into the reference's (sum V, 1) kernel)."""
+        import numpy as np
+        if not self._built:
+            raise RuntimeError("export_variables: call build(features, labels) first")
+        arrays = self.store.named_arrays()
+        out, merged = {}, {}
+        for k, v in arrays.items():
+            base = k.rsplit("/", 1)[0]
+            if base.endswith("/kernel") and base not in arrays:
+                merged.setdefault(base, None)
+            else:
+                out[k] = v.detach().cpu().numpy().copy()
+        for base in merged:
+            out[base] = np.concatenate([arrays[k].detach().cpu().numpy() for k in self._kernel_slices(arrays, base)], 0)
+        return out
+
+    def load_variables(self, values, strict: bool = True):
+        """Assign variables from {reference TF variable name: array} — e.g. the tensors of a TF-1.14
+        checkpoint of the reference script dumped with `tf.train.load_checkpoint(dir).get_tensor(name)`
+        (scripts/tf_ckpt_to_npz.py) — so that reference-trained weights run on these kernels.  Optimizer
+        slots (`.../Adam`, `.../Adam_1`), `global_step` and `beta*_power` entries are ignored.  Returns the
+        names assigned; with `strict`, a shape mismatch or a model variable without a value raises."""
+        if not self._built:
+            raise RuntimeError("load_variables: call build(features, labels) first")
+        arrays = self.store.named_arrays()
+        done = set()
+        with torch.no_grad():
+            for name, val in values.items():
+                if name.endswith("/Adam") or name.endswith("/Adam_1") or name in ("global_step", "beta1_power", "beta2_power"):
+                    continue
+                t = torch.as_tensor(val).to(torch.float32)
+                if name in arrays:
+                    if tuple(arrays[name].shape) != tuple(t.shape):
+                        if strict:
+                            raise ValueError(f"load_variables: {name} has shape {tuple(t.shape)}, the model wants {tuple(arrays[name].shape)}")
+                        continue
+                    arrays[name].copy_(t)
+                    done.add(name)
+                    continue
+                subs = self._kernel_slices(arrays, name)
+                if subs and sum(arrays[k].shape[0] for k in subs) != t.shape[0]:
+                    if strict:
+                        raise ValueError(f"load_variables: {name} has {t.shape[0]} rows, the model's columns add up to "
+                                         f"{sum(arrays[k].shape[0] for k in subs)}")
+                    continue
+                if subs:
+                    row = 0
+                    for k in subs:
+                        n = arrays[k].shape[0]
+                        arrays[k].copy_(t[row:row + n].reshape(arrays[k].shape))
+                        row += n
+                        done.add(k)
+                elif strict and not name.endswith(("moving_mean", "moving_variance")):
+                    raise KeyError(f"load_variables: the model has no variable {name}")
+            blocks = {b for b, _ in self.store._alias.values()}     # fused blocks are covered by their named parts
+            missing = [k for k in arrays if k not in done and k not in blocks]
+            if strict and missing:
+                raise KeyError(f"load_variables: no value for {missing[:5]}{' ...' if len(missing) > 5 else ''}")
+        for a in self.store.arenas.values():
+            a.live = None                    # liveness is rebuilt from the (unchanged) moments on next use
+        return sorted(done)
+
     def _maybe_restore(self):
         md = self.config.model_dir
         if not md or not os.path.exists(self._ckpt_path()):
