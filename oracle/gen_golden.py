@@ -348,6 +348,15 @@ def model_goldens(tf, vocab_dir):
     run("model_fwfm", _import_ref("FwFM", "fwfm"), "fwfm_model_fn", fwfm_params,
         dict(learning_rate=0.005, embedding_dim=8))
 
+    # §8f-3 sibling, oracle pinned ahead of its kernels: AFM (pair Hadamard products + attention net, afm.py:143-190)
+    def afm_params(m):
+        dense_c, cat, label = m.create_feature_columns()
+        return ({"category_feature_columns": cat, "dense_feature_columns": dense_c,
+                 "embedding_dim": m.FLAGS.embedding_dim, "attention_factor": m.FLAGS.attention_factor,
+                 "learning_rate": m.FLAGS.learning_rate}, dense_c + cat)
+    run("model_afm", _import_ref("AFM", "afm"), "afm_model_fn", afm_params,
+        dict(learning_rate=0.005, embedding_dim=8, attention_factor=12))
+
     # the shared batch
     batch = {"dense": dense, "labels": labels, "dense_names": np.array(DENSE)}
     for k, rows in sfeats.items():

@@ -143,6 +143,28 @@ def fwfm(P, feats, labels, params, training=False):
     return out
 
 
+def afm(P, feats, labels, params, training=False):
+    """algorithm/AFM/afm.py:143-192 (SURVEY.md §8f-3 sibling; pinned ahead of its kernels).  Quirk: the model
+    also builds `category_input = fc.input_layer(...)` (:150-151) — its tables exist as variables and get zero
+    gradients — but the pair interactions use a second set of tables, one `input_layer` call per column under
+    `pair_interaction_part` (:156-159)."""
+    dense_in = input_layer(P, feats, params["dense_feature_columns"], "dense_input/input_layer")
+    dense_logit = R.dense(dense_in, P["dense_input/dense_logit/kernel"], P["dense_input/dense_logit/bias"])  # :145-147
+    fields = []
+    for i, c in enumerate(params["category_feature_columns"]):                                         # :156-159
+        layer = "pair_interaction_part/input_layer" + ("" if i == 0 else f"_{i}")
+        fields.append(_lookup(P, feats, c, layer, {}))
+    F = len(fields)
+    pairs = torch.stack([fields[i] * fields[j] for i in range(F) for j in range(i + 1, F)], dim=1)      # :163-167 (B, P, K)
+    w, b, h = P["attention_part/attention_w"], P["attention_part/attention_b"], P["attention_part/attention_h"]
+    att = torch.relu(pairs @ w + b) @ h                                                                 # :181-183 (B, P, 1)
+    score = torch.softmax(att, dim=1)                                                                   # :184
+    weighted = (pairs * score).sum(dim=1)                                                               # :187-188 (B, K)
+    afm_logit = weighted @ P["prediction_score_part/p"]                                                 # :189-190
+    logit = dense_logit + afm_logit                                                                     # :192
+    return _tail(logit, None if labels is None else labels["read_comment"])
+
+
 def xdeepfm(P, feats, labels, params, training=False):
     """algorithm/xDeepFM/xdeepfm.py:139-207."""
     dense_cols = params.get("dense_feature_columns") or []

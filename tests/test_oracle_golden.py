@@ -146,3 +146,39 @@ def test_model_golden(name, tmp_path):
         close(p, ga[k], f"{name} adam({k})", tol=1e-7)
         checked += 1
     assert checked >= 10
+
+
+def test_afm_golden_pins_the_oracle_ahead_of_its_kernels(tmp_path):
+    """AFM has no mirror / kernels yet; its oracle restatement is already pinned to the
+    golden obtained from the reference's afm.py, so that the kernels can be built against it next."""
+    import os
+    from recalgorithm_amd import feature_column as fc
+    from recalgorithm_amd.algorithm._common import DENSE_FEATURES
+    name = "model_afm"
+    d = GU.load(name)
+    vocab_dir = GU.write_vocab_dir(str(tmp_path / "vocabulary"))
+    K = int(d["flag/embedding_dim"])
+    cat = [fc.embedding_column(fc.categorical_column_with_vocabulary_file(k, os.path.join(vocab_dir, k + ".txt")), K)
+           for k in ("userid", "feedid", "device", "authorid", "bgm_song_id", "bgm_singer_id")]
+    cat.append(fc.embedding_column(fc.categorical_column_with_vocabulary_file(
+        "manual_tag_list", os.path.join(vocab_dir, "manual_tag_id.txt")), K, combiner="mean"))          # afm.py:100
+    params = {"dense_feature_columns": [fc.numeric_column(k, default_value=0.0) for k in DENSE_FEATURES],
+              "category_feature_columns": cat, "embedding_dim": K,
+              "attention_factor": int(d["flag/attention_factor"]), "learning_rate": float(d["meta/learning_rate"])}
+    sfeats, labels = GU.string_batch()
+    feats = _encode(params, sfeats)
+    P = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in GU.section(d, "var/").items()}
+    out = M.afm(P, feats, None, params)
+    close(out["prob"], d["predict/probabilities"], "afm probabilities")
+    close(out["logit"], d["predict/logit"], "afm logit")
+    out = M.afm(P, feats, {"read_comment": labels}, params, training=True)
+    close(out["loss"], d["train/loss"], "afm loss")
+    out["loss"].backward()
+    checked = 0
+    for k, g in GU.section(d, "grad/").items():
+        got = P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])
+        close(got, g, f"afm d({k})", tol=1e-9)
+        if k.startswith("category_input/"):
+            assert not np.any(g), "the unused category_input tables must have zero gradients"
+        checked += 1
+    assert checked == len(P)
