@@ -357,6 +357,14 @@ def model_goldens(tf, vocab_dir):
     run("model_afm", _import_ref("AFM", "afm"), "afm_model_fn", afm_params,
         dict(learning_rate=0.005, embedding_dim=8, attention_factor=12))
 
+    # §8f-3 sibling, oracle pinned ahead of its kernels: FFM (field-aware pair inner products, ffm.py:118-163)
+    def ffm_params(m):
+        cols, label = m.create_feature_columns()
+        return ({"one_hot_category_feature_columns": cols, "learning_rate": m.FLAGS.learning_rate,
+                 "embedding_dim": m.FLAGS.embedding_dim,
+                 "fields_vocabulary_size_tuple": [(c.categorical_column.name, int(c.variable_shape[-1])) for c in cols]}, cols)
+    run("model_ffm", _import_ref("FFM", "ffm"), "ffm_model_fn", ffm_params, dict(learning_rate=0.005, embedding_dim=4))
+
     # the shared batch
     batch = {"dense": dense, "labels": labels, "dense_names": np.array(DENSE)}
     for k, rows in sfeats.items():

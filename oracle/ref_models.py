@@ -165,6 +165,60 @@ def afm(P, feats, labels, params, training=False):
     return _tail(logit, None if labels is None else labels["read_comment"])
 
 
+def _bags(ids):
+    """feature batch entry -> list (len B) of lists of valid ids, in input order."""
+    if isinstance(ids, tuple):
+        vals, offs = ids
+        return [[int(v) for v in vals[int(offs[b]):int(offs[b + 1])] if int(v) >= 0] for b in range(len(offs) - 1)]
+    return [[int(v)] if int(v) >= 0 else [] for v in ids]
+
+
+def ffm(P, feats, labels, params, training=False):
+    """algorithm/FFM/ffm.py:118-163 (SURVEY.md §8f-3 sibling; pinned ahead of its kernels).
+    First order: multi-hot indicator rows @ (sum V, 1) kernel + bias — an id that occurs twice in a bag counts
+    twice (A-5).  Second order: field i owns F-1 tables `<name>_embedding[(F-1), V_i, K]`; for a pair i < j the
+    reference looks field i up in its sub-table j-1 and field j in its sub-table i (:150-157) through
+    `to_sparse_tensor` (utils.py:49-64: the coordinates of the non-zero multi-hot entries, i.e. the DISTINCT
+    ids in ascending order) + safe_embedding_lookup_sparse (mean), and sums <v_i, v_j> over the pairs."""
+    cols = params["one_hot_category_feature_columns"]
+    bags = {c.key: _bags(feats[c.key]) for c in cols}
+    B = len(next(iter(bags.values())))
+    kern = P["ffm_first_order/fm_first_order_dense/kernel"].reshape(-1)
+    first = torch.zeros(B, dtype=kern.dtype)
+    row0 = 0
+    for c in _sorted(cols):                                            # :118-119 input_layer: sorted by column name
+        V = c.categorical_column.num_buckets
+        for b in range(B):
+            for v in bags[c.key][b]:
+                first[b] = first[b] + kern[row0 + v]
+        row0 += V
+    first = (first + P["ffm_first_order/fm_first_order_dense/bias"][0]).unsqueeze(-1)              # :120
+    F = len(cols)
+    tables = [P[f"embedding_variables/{name}_embedding"] for name, _ in params["fields_vocabulary_size_tuple"]]  # :125-130
+
+    def lookup(table2d, key):
+        rows = []
+        for b in range(B):
+            ids = sorted(set(bags[key][b]))
+            if ids:
+                acc = table2d[ids[0]]
+                for v in ids[1:]:
+                    acc = acc + table2d[v]
+                rows.append(acc / len(ids))
+            else:
+                rows.append(torch.zeros(table2d.shape[1], dtype=table2d.dtype))
+        return torch.stack(rows, 0)
+
+    second = torch.zeros(B, 1, dtype=kern.dtype)
+    for i in range(F - 1):                                             # :146-160
+        for j in range(i + 1, F):
+            vi = lookup(tables[i][j - 1], cols[i].key)
+            vj = lookup(tables[j][i], cols[j].key)
+            second = second + (vi * vj).sum(dim=-1, keepdim=True)
+    logit = first + second                                            # :163
+    return _tail(logit, None if labels is None else labels["read_comment"])
+
+
 def xdeepfm(P, feats, labels, params, training=False):
     """algorithm/xDeepFM/xdeepfm.py:139-207."""
     dense_cols = params.get("dense_feature_columns") or []

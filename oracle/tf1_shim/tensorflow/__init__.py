@@ -414,7 +414,31 @@ class _ShapeVec(list):
     """tf.shape(x): indexable, elements usable as ints."""
 
 
-def shape(x, name=None):
+def _safe_embedding_lookup_sparse(embedding_weights, sparse_ids, sparse_weights=None, combiner="mean", **_kw):
+    """[TF-ext A-3] tf.nn.safe_embedding_lookup_sparse on a rank-2 SparseTensor of ids: per row, the
+    `combiner` (default mean: sequential sum in id order / count) of the looked-up rows; rows without ids
+    give zeros; ids < 0 are dropped (ffm.py:156-157)."""
+    if sparse_weights is not None or combiner != "mean":
+        raise NotImplementedError("tf1_shim: safe_embedding_lookup_sparse is restated for combiner='mean', no weights")
+    w = _raw(embedding_weights)
+    idx, vals = _raw(sparse_ids.indices), _raw(sparse_ids.values)
+    B = int(_raw(sparse_ids.dense_shape)[0]) if not isinstance(sparse_ids.dense_shape, (list, tuple)) else int(sparse_ids.dense_shape[0])
+    out = torch.zeros(B, w.shape[1], dtype=w.dtype)
+    cnt = torch.zeros(B, dtype=w.dtype)
+    rows = []
+    for n in range(vals.shape[0]):          # in SparseTensor order (row-major): the sum order of SparseSegmentMean
+        if int(vals[n]) < 0:
+            continue
+        rows.append((int(idx[n, 0]), int(vals[n])))
+    acc = [None] * B
+    for b, v in rows:
+        acc[b] = w[v] if acc[b] is None else acc[b] + w[v]
+        cnt[b] += 1
+    parts = [torch.zeros(w.shape[1], dtype=w.dtype) if a is None else a / cnt[b] for b, a in enumerate(acc)]
+    return T(torch.stack(parts, 0))
+
+
+def shape(x, name=None, out_type=None):
     return _ShapeVec(int(s) for s in _raw(x).shape)
 
 
@@ -442,6 +466,8 @@ def not_equal(a, b):
 
 
 def where(condition, x=None, y=None):
+    if x is None and y is None:          # coordinates of the true elements, row-major, int64 (utils.py:58)
+        return T(torch.nonzero(_raw(condition)))
     return T(torch.where(_raw(condition), _raw(x), _raw(y)))
 
 
@@ -492,7 +518,8 @@ def _conv1d(value, filters, stride, padding, name=None):
 
 
 nn = types.SimpleNamespace(relu=_relu, softmax=_softmax, sigmoid=sigmoid,
-                           sigmoid_cross_entropy_with_logits=_sigmoid_ce, l2_loss=_l2_loss, conv1d=_conv1d)
+                           sigmoid_cross_entropy_with_logits=_sigmoid_ce, l2_loss=_l2_loss, conv1d=_conv1d,
+                           safe_embedding_lookup_sparse=_safe_embedding_lookup_sparse)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -57,6 +57,10 @@ class _Indicator:
     def __init__(self, cat):
         self.categorical_column, self.key, self.name = cat, cat.key, f"{cat.key}_indicator"
 
+    @property
+    def variable_shape(self):                 # TensorShape([num_buckets]) (ffm.py:234)
+        return (self.categorical_column.num_buckets,)
+
 
 def numeric_column(key, shape=(1,), default_value=None, dtype=None, normalizer_fn=None):
     return _Numeric(key, shape, default_value, dtype)

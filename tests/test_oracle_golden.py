@@ -182,3 +182,33 @@ def test_afm_golden_pins_the_oracle_ahead_of_its_kernels(tmp_path):
             assert not np.any(g), "the unused category_input tables must have zero gradients"
         checked += 1
     assert checked == len(P)
+
+
+def test_ffm_golden_pins_the_oracle_ahead_of_its_kernels(tmp_path):
+    """FFM: oracle restatement pinned to the golden obtained from the reference's ffm.py
+    (incl. its multi-hot `manual_tag_list` field: counts in the first-order term, distinct ids + mean in
+    the field-aware lookups)."""
+    import os
+    from recalgorithm_amd import feature_column as fc
+    d = GU.load("model_ffm")
+    vocab_dir = GU.write_vocab_dir(str(tmp_path / "vocabulary"))
+    cats = [fc.categorical_column_with_vocabulary_file(k, os.path.join(vocab_dir, k + ".txt"))
+            for k in ("userid", "feedid", "device", "authorid", "bgm_song_id", "bgm_singer_id")]
+    cats.append(fc.categorical_column_with_vocabulary_file("manual_tag_list", os.path.join(vocab_dir, "manual_tag_id.txt")))
+    cols = [fc.indicator_column(c) for c in cats]
+    params = {"one_hot_category_feature_columns": cols, "embedding_dim": int(d["flag/embedding_dim"]),
+              "learning_rate": float(d["meta/learning_rate"]),
+              "fields_vocabulary_size_tuple": [(c.categorical_column.key, c.categorical_column.num_buckets) for c in cols]}
+    sfeats, labels = GU.string_batch()
+    feats = _encode(params, sfeats)
+    assert any(isinstance(v, tuple) for v in feats.values())          # the multi-valued field is in play
+    P = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in GU.section(d, "var/").items()}
+    out = M.ffm(P, feats, None, params)
+    close(out["prob"], d["predict/probabilities"], "ffm probabilities")
+    close(out["logit"], d["predict/logit"], "ffm logit")
+    out = M.ffm(P, feats, {"read_comment": labels}, params, training=True)
+    close(out["loss"], d["train/loss"], "ffm loss")
+    out["loss"].backward()
+    for k, g in GU.section(d, "grad/").items():
+        got = P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])
+        close(got, g, f"ffm d({k})", tol=1e-9)
