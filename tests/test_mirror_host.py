@@ -126,3 +126,31 @@ def test_load_and_export_variables_by_reference_names(name, tmp_path):
         est.load_variables({k: (v[:-1] if v.ndim and v.shape[0] > 1 else v) for k, v in ref.items()})
     with pytest.raises(KeyError):
         est.load_variables(dict(ref, **{"no/such/variable": np.zeros(2)}))
+
+
+def test_host_columns_are_packed_into_one_matrix_per_kind():
+    """Estimator._pack_host_columns: [B] int64 id vectors -> column views of one [B, F] matrix in sorted key
+    order (the layout feature_column._as_matrix reads in place), [B, 1] float columns -> views of one [B, n]
+    matrix; values unchanged, other entries untouched."""
+    from recalgorithm_amd import feature_column as fc
+    from recalgorithm_amd.estimator import Estimator, RunConfig
+    g = torch.Generator().manual_seed(1)
+    B = 33
+    feats = {f"f{j:02d}": torch.randint(-1, 50, (B,), generator=g) for j in (3, 0, 7, 1)}
+    feats.update({f"d{j}": torch.randn(B, 1, generator=g) for j in range(3)})
+    feats["odd_len"] = torch.zeros(B + 1, dtype=torch.int64)
+    feats["strings"] = [["a"]] * B
+    feats["ragged"] = fc.Ragged(torch.arange(5), torch.tensor([0, 5] + [5] * (B - 1)))
+    est = Estimator(lambda *a: None, {}, RunConfig(device="cpu"))
+    assert est._pack_host_columns(feats) is feats                      # nothing to do for a CPU estimator
+    out = est._pack_host_columns(feats, force=True)
+    ids = [out[k] for k in ("f00", "f01", "f03", "f07")]
+    for k in feats:
+        if isinstance(feats[k], torch.Tensor):
+            assert torch.equal(out[k], feats[k]), k
+    assert out["strings"] is feats["strings"] and out["ragged"] is feats["ragged"] and out["odd_len"] is feats["odd_len"]
+    m = fc._as_matrix(ids)
+    assert m.data_ptr() == ids[0].data_ptr() and m.shape == (B, 4) and m.is_contiguous()      # zero-copy
+    assert torch.equal(m, torch.stack([feats[k] for k in ("f00", "f01", "f03", "f07")], 1))
+    d = [out[f"d{j}"] for j in range(3)]
+    assert d[1].data_ptr() == d[0].data_ptr() + 4 and d[0].stride() == (3, 1)
