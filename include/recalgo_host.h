@@ -47,6 +47,13 @@ int recalgo_reader_float_feature(void* reader, const char* key, int n, float def
 int64_t recalgo_reader_id_feature(void* reader, const char* key, const void* vocab, int64_t* offsets,
                                   int64_t* values, int64_t values_cap);
 
+/* All single-valued id features of the current batch in one parallel pass: out [B, n_keys] int64 row-major,
+ * column f = keys[f] looked up in vocabs[f]; -1 where a record has no value (or the value is not in the
+ * vocabulary).  multi[f] is set to 1 if some record holds more than one value for keys[f] (the column then
+ * holds the first one: decode that key with recalgo_reader_id_feature instead).  Returns 0, -1 on error. */
+int recalgo_reader_id_matrix(void* reader, int n_keys, const char* const* keys, const void* const* vocabs,
+                             int64_t* out, int32_t* multi);
+
 #ifdef __cplusplus
 }
 #endif

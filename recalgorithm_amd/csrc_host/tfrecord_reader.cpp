@@ -527,4 +527,49 @@ EXPORT int64_t recalgo_reader_id_feature(void* reader, const char* key, const vo
     return nnz;
 }
 
+// All single-valued id features of the current batch in ONE parallel pass over the records:
+// out [B, n_keys] int64 row-major (column f = keys[f] looked up in vocabs[f]); a record without a value for
+// a key gives -1.  A feature that holds MORE than one value in some record sets multi[f] = 1 (its column
+// then holds the first value; use recalgo_reader_id_feature for that key).  Returns 0, -1 on a malformed batch.
+EXPORT int recalgo_reader_id_matrix(void* reader, int n_keys, const char* const* keys, const void* const* vocabs,
+                                    int64_t* out, int32_t* multi) {
+    auto* r = (Reader*)reader;
+    if (n_keys < 0 || (n_keys > 0 && (!keys || !vocabs || !out || !multi))) return -1;
+    if (!r->indexed && !index_batch(*r)) return -1;
+    const size_t B = r->off.size() - 1, F = (size_t)n_keys;
+    std::vector<std::string_view> ks(F);
+    for (size_t f = 0; f < F; ++f) {
+        ks[f] = std::string_view(keys[f]);
+        multi[f] = 0;
+    }
+    std::vector<std::atomic<int>> mflag(F);
+    for (auto& m : mflag) m.store(0);
+    Pool::get().parallel_for((B + kChunk - 1) / kChunk, [&](size_t c) {
+        std::vector<size_t> hint(F, 0);
+        for (size_t i = c * kChunk; i < std::min(B, (c + 1) * kChunk); ++i) {
+            for (size_t f = 0; f < F; ++f) {
+                int64_t id = -1;
+                int n = 0;
+                if (const Span* feat = find_feature(r->index[i], ks[f], hint[f])) {
+                    const auto& vm = ((const Vocab*)vocabs[f])->map;
+                    for_fields(*feat, [&](uint32_t field, uint32_t wt, Span list, uint64_t) {
+                        if (field != 1 || wt != 2) return;                       // BytesList
+                        for_fields(list, [&](uint32_t f2, uint32_t w2, Span pl, uint64_t) {
+                            if (f2 != 1 || w2 != 2) return;
+                            if (n++ == 0) {
+                                auto v = vm.find(std::string_view((const char*)pl.p, pl.n));
+                                id = v == vm.end() ? -1 : v->second;
+                            }
+                        });
+                    });
+                }
+                if (n > 1) mflag[f].store(1, std::memory_order_relaxed);
+                out[i * F + f] = id;
+            }
+        }
+    });
+    for (size_t f = 0; f < F; ++f) multi[f] = mflag[f].load();
+    return 0;
+}
+
 }  // extern "C"

@@ -32,6 +32,7 @@ SIGNATURES = {
     "recalgo_reader_next_batch": (c_int64, [c_void_p, c_int64]),
     "recalgo_reader_float_feature": (c_int, [c_void_p, c_char_p, c_int, c_float, c_int, c_void_p]),
     "recalgo_reader_id_feature": (c_int64, [c_void_p, c_char_p, c_void_p, c_void_p, c_void_p, c_int64]),
+    "recalgo_reader_id_matrix": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None
@@ -96,6 +97,7 @@ class NativeDataset:
         self.filepath, self.bs = filepath, int(batch_size)
         self.epochs = -1 if num_epochs is None else int(num_epochs)
         self.shuffle, self.seed, self.verify = int(shuffle_buffer_size or 0), int(seed), verify_crc
+        self._multi = set()          # keys seen holding several values per record: decoded as ragged features
         self.label_keys = list(label_keys)
         self.numeric: List[NumericColumn] = []
         self.categorical: List[CategoricalColumn] = []
@@ -139,7 +141,26 @@ class NativeDataset:
                     if rc != 0:
                         raise ValueError(lib.recalgo_reader_error(h).decode())
                     feats[c.key] = torch.from_numpy(out.reshape((B,) + tuple(c.shape)))
+                # single-valued id features: one [B, F] matrix from one parallel pass; a key that turns out to
+                # hold several values per record (or is declared a sequence) goes through the ragged call
+                flat = [c for c in self.categorical if not c.is_sequence and c.key not in self._multi]
+                if flat:
+                    keys = (ctypes.c_char_p * len(flat))(*[c.key.encode() for c in flat])
+                    vh = (c_void_p * len(flat))(*[vocabs[c.key].h for c in flat])
+                    mat = np.empty((B, len(flat)), dtype=np.int64)
+                    multi = np.zeros(len(flat), dtype=np.int32)
+                    if lib.recalgo_reader_id_matrix(h, len(flat), keys, vh, mat.ctypes.data_as(c_void_p),
+                                                    multi.ctypes.data_as(c_void_p)) != 0:
+                        raise IOError(f"{self.filepath}: {lib.recalgo_reader_error(h).decode()}")
+                    tmat = torch.from_numpy(mat)
+                    for j, c in enumerate(flat):
+                        if multi[j]:
+                            self._multi.add(c.key)
+                        else:
+                            feats[c.key] = tmat[:, j]
                 for c in self.categorical:
+                    if c.key in feats:
+                        continue
                     offs = np.empty(B + 1, dtype=np.int64)
                     vals = np.empty(max(B, 1) * 4, dtype=np.int64)
                     nnz = int(lib.recalgo_reader_id_feature(h, c.key.encode(), vocabs[c.key].h, offs.ctypes.data_as(c_void_p),
