@@ -44,7 +44,7 @@ def _global_batch(vocabs, B=24, seed=5):
     return ids
 
 
-def _worker(rank, port, errq, staged=False):
+def _worker(rank, port, errq, staged=False, WORLD=2):
     try:
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
         dist.init_process_group("gloo", rank=rank, world_size=WORLD)
@@ -83,7 +83,7 @@ def _worker(rank, port, errq, staged=False):
             staged.grad.index_add_(0, sid[sid >= 0], g[sid >= 0])
         w0 = [torch.empty_like(store.flat) for _ in range(WORLD)]
         dist.all_gather(w0, store.flat)
-        assert torch.equal(w0[0], w0[1]), "dense variables were not broadcast from rank 0"
+        assert all(torch.equal(w0[0], w) for w in w0[1:]), "dense variables were not broadcast from rank 0"
         assert est.loss_grad_scale == 1.0 / WORLD
 
         # ---- sharding: local rows are the global rows r % N == rank ----
@@ -163,12 +163,13 @@ def _worker(rank, port, errq, staged=False):
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("staged", [False, True])
-def test_row_sharded_exchange_world2_matches_single_process(staged):
+@pytest.mark.parametrize("staged,world", [(False, 2), (True, 2), (False, 3)])
+def test_row_sharded_exchange_world2_matches_single_process(staged, world):
+    """world 3: uneven shards (rows % 3 != 0) and a batch of 24 = 3 x 8 examples."""
     ctx = mp.get_context("spawn")
     errq = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, port, errq, staged)) for r in range(WORLD)]
+    procs = [ctx.Process(target=_worker, args=(r, port, errq, staged, world)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
