@@ -302,3 +302,35 @@ def test_pnn_forward_backward(dev, method, wr):
     if method == "OPNN" and wr == 0.0:      # quirk B-10: only the upper triangle of each (K,K) weight is used
         gw = grads["product_part/outer_product_w"]
         assert float(torch.tril(gw, diagonal=-1).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("model", ["dcn", "deepfm"])
+def test_checkpoint_resume_equals_uninterrupted_training(dev, model, tmp_path):
+    """4 training steps in one process == 2 steps, save_checkpoint, a NEW estimator restoring from model_dir,
+    2 more steps: variables, Adam moments and losses bit for bit (the live-row list is rebuilt from the restored
+    moments in a different order, which must not matter)."""
+    from recalgorithm_amd.algorithm.DCN.dcn import dcn_model_fn
+    from recalgorithm_amd.algorithm.DeepFM.deepfm import deepfm_model_fn
+    fn = {"dcn": dcn_model_fn, "deepfm": deepfm_model_fn}[model]
+    ref, params, feats, labels = make(model, dev)
+    spec = synth.SynthSpec(n_fields=8, max_vocab=400, seed=11, oov_frac=0.05)
+    batches = [(feats, labels)] + [synth.device_features(spec, 300, dev, batch_index=i)[:2] for i in (1, 2, 3)]
+    losses_ref = [float(ref.train_step(*b)) for b in batches]
+    md = str(tmp_path / "model_dir")
+    a = Estimator(fn, params, RunConfig(device=dev, seed=5, model_dir=md, use_hip_graph=False))
+    a.build(feats, labels)
+    la = [float(a.train_step(*b)) for b in batches[:2]]
+    a.global_step = 2
+    a.save_checkpoint()
+    b = Estimator(fn, params, RunConfig(device=dev, seed=77, model_dir=md, use_hip_graph=False))   # other seed: state comes from the file
+    b.build(feats, labels)
+    assert b.global_step == 2
+    lb = [float(b.train_step(*bt)) for bt in batches[2:]]
+    assert la + lb == losses_ref
+    for k, v in ref.store.named_arrays().items():
+        assert_bit_exact(b.store.named_arrays()[k], v, f"{model} {k} after resume")
+    for n, ar in ref.store.arenas.items():
+        assert_bit_exact(b.store.arenas[n].m, ar.m, f"{model} arena {n}.m")
+        assert_bit_exact(b.store.arenas[n].v, ar.v, f"{model} arena {n}.v")
+    assert_bit_exact(b.store.flat_m, ref.store.flat_m, "dense m")
+    assert_bit_exact(b.store.flat_v, ref.store.flat_v, "dense v")

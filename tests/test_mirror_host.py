@@ -154,3 +154,38 @@ def test_host_columns_are_packed_into_one_matrix_per_kind():
     assert torch.equal(m, torch.stack([feats[k] for k in ("f00", "f01", "f03", "f07")], 1))
     d = [out[f"d{j}"] for j in range(3)]
     assert d[1].data_ptr() == d[0].data_ptr() + 4 and d[0].stride() == (3, 1)
+
+
+def test_checkpoint_round_trip_restores_variables_moments_and_step(tmp_path):
+    """Estimator.save_checkpoint / restore-on-build (the reference gets this from tf.estimator's model_dir,
+    deepfm.py:290-293): variables, both Adam moments (dense and per arena), the optimizer step and the global
+    step survive; the arena's live-row bookkeeping is rebuilt from the restored moments."""
+    from recalgorithm_amd.estimator import Estimator, RunConfig
+    vocab_dir = GU.write_vocab_dir(str(tmp_path / "vocabulary"))
+    model_fn, params, _ = GU.mirror_setup("model_dcn", vocab_dir)
+    sfeats, labels = GU.string_batch()
+    feats = {k: (v.float() if isinstance(v, torch.Tensor) else v) for k, v in sfeats.items()}
+    lab = {"read_comment": labels.float()}
+    md = str(tmp_path / "model_dir")
+    a = Estimator(model_fn, params, RunConfig(device="cpu", seed=5, use_hip_graph=False, model_dir=md))
+    a.build(feats, lab)
+    g = torch.Generator().manual_seed(0)
+    for v in a.store.named_arrays().values():
+        v.copy_(torch.randn(v.shape, generator=g))
+    a.store.flat_m.copy_(torch.randn(a.store.flat_m.shape, generator=g))
+    a.store.flat_v.copy_(torch.rand(a.store.flat_v.shape, generator=g))
+    for ar in a.store.arenas.values():
+        ar.m[::3] = torch.randn(ar.m[::3].shape, generator=g)
+        ar.v[::3] = torch.rand(ar.v[::3].shape, generator=g)
+    a.store.opt_state = {"step": torch.tensor([17]), "lr_t": torch.zeros(1)}
+    a.global_step = 17
+    a.save_checkpoint()
+    b = Estimator(model_fn, params, RunConfig(device="cpu", seed=99, use_hip_graph=False, model_dir=md))
+    b.build(feats, lab)                                     # different seed: everything must come from the file
+    assert b.global_step == 17 and int(b.store.opt_state["step"]) == 17
+    for k, v in a.store.named_arrays().items():
+        assert torch.equal(b.store.named_arrays()[k], v), k
+    assert torch.equal(b.store.flat_m, a.store.flat_m) and torch.equal(b.store.flat_v, a.store.flat_v)
+    for n, ar in a.store.arenas.items():
+        assert torch.equal(b.store.arenas[n].m, ar.m) and torch.equal(b.store.arenas[n].v, ar.v)
+        assert b.store.arenas[n].live is None               # rebuilt lazily from the moments (variables.live_state)
