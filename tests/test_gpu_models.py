@@ -307,8 +307,9 @@ def test_pnn_forward_backward(dev, method, wr):
 @pytest.mark.parametrize("model", ["dcn", "deepfm"])
 def test_checkpoint_resume_equals_uninterrupted_training(dev, model, tmp_path):
     """4 training steps in one process == 2 steps, save_checkpoint, a NEW estimator restoring from model_dir,
-    2 more steps: variables, Adam moments and losses bit for bit (the live-row list is rebuilt from the restored
-    moments in a different order, which must not matter)."""
+    2 more steps: variables, Adam moments and losses (the live-row list is rebuilt from the restored moments in
+    a different order, which must not matter).  Not bit for bit: two runs of the same steps already differ in
+    the last bits because the row-gradient scatter adds with float atomics."""
     from recalgorithm_amd.algorithm.DCN.dcn import dcn_model_fn
     from recalgorithm_amd.algorithm.DeepFM.deepfm import deepfm_model_fn
     fn = {"dcn": dcn_model_fn, "deepfm": deepfm_model_fn}[model]
@@ -326,11 +327,12 @@ def test_checkpoint_resume_equals_uninterrupted_training(dev, model, tmp_path):
     b.build(feats, labels)
     assert b.global_step == 2
     lb = [float(b.train_step(*bt)) for bt in batches[2:]]
-    assert la + lb == losses_ref
+    for got, want in zip(la + lb, losses_ref):
+        assert abs(got - want) <= 1e-6 * abs(want), (la + lb, losses_ref)
     for k, v in ref.store.named_arrays().items():
-        assert_bit_exact(b.store.named_arrays()[k], v, f"{model} {k} after resume")
+        assert_close(b.store.named_arrays()[k], v.double(), rtol=1e-4, what=f"{model} {k} after resume", reduced=True)
     for n, ar in ref.store.arenas.items():
-        assert_bit_exact(b.store.arenas[n].m, ar.m, f"{model} arena {n}.m")
-        assert_bit_exact(b.store.arenas[n].v, ar.v, f"{model} arena {n}.v")
-    assert_bit_exact(b.store.flat_m, ref.store.flat_m, "dense m")
-    assert_bit_exact(b.store.flat_v, ref.store.flat_v, "dense v")
+        assert_close(b.store.arenas[n].m, ar.m.double(), rtol=1e-4, what=f"{model} arena {n}.m", reduced=True)
+        assert_close(b.store.arenas[n].v, ar.v.double(), rtol=1e-4, what=f"{model} arena {n}.v", reduced=True)
+    assert_close(b.store.flat_m, ref.store.flat_m.double(), rtol=1e-4, what="dense m", reduced=True)
+    assert_close(b.store.flat_v, ref.store.flat_v.double(), rtol=1e-4, what="dense v", reduced=True)
