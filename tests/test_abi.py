@@ -69,3 +69,26 @@ def test_missing_library_fails_loudly(tmp_path):
             _lib.load(str(tmp_path / "nope.so"))
     finally:
         _lib._lib = saved
+
+
+def test_product_path_never_imports_the_oracle():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+    (a child process running `-m oracle.cpu_baseline`) may touch it.  Static scan of the product sources."""
+    import ast
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    offenders = []
+    for path in glob.glob(os.path.join(root, "recalgorithm_amd", "**", "*.py"), recursive=True) + [os.path.join(root, "bench.py")]:
+        tree = ast.parse(open(path).read())
+        for node in ast.walk(tree):
+            mods = []
+            if isinstance(node, ast.Import):
+                mods = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom) and node.level == 0 and node.module:
+                mods = [node.module]
+            if any(m == "oracle" or m.startswith("oracle.") for m in mods):
+                offenders.append(f"{os.path.relpath(path, root)}:{node.lineno}")
+    assert not offenders, offenders
+    # bench.py reaches the oracle only through the cpu_baseline child process
+    src = open(os.path.join(root, "bench.py")).read()
+    assert '"-m", "oracle.cpu_baseline"' in src
