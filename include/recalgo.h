@@ -9,12 +9,15 @@
  *
  * Conventions (all entry points):
  *   - return value: hipError_t as int, 0 == success.  Never throws, never aborts.
- *   - all pointers are DEVICE pointers (HBM) unless the name ends in `_host`.
+ *   - all pointers are DEVICE pointers (HBM); the one exception, documented in place, are the short
+ *     HOST arrays that list the parts of recalgo_dense1_* (read at launch time).
  *   - fp32 values, int64 ids (the reference's dtypes); id < 0 == OOV / missing value.
  *   - stateless, re-entrant, asynchronous on `stream` (a hipStream_t passed as void*).
  *   - no hidden allocation: outputs and workspaces are caller-owned; required workspace
  *     sizes are given by the matching *_workspace_bytes() query.
  *   - nothing is read or written outside the extents documented per argument.
+ *   - one environment knob, read once per process: RECALGO_SCATTER_TILE=32|64|128|256 overrides the
+ *     examples-per-workgroup tile of the row-gradient scatter kernels (a tuning aid; results are the same).
  *
  * Embedding storage ("arena"): every table of one model lives in one float arena.  Field f
  * owns rows [row_base[f], row_base[f] + vocab[f]) of width K (uniform-K entry points) —
