@@ -127,6 +127,14 @@ def test_native_repeat_shuffle_and_crc(tmp_path):
     ds = native.NativeDataset(bad, cols + labels, ["read_comment"], 32, verify_crc=True)
     with pytest.raises(IOError):
         list(ds)
+    # a file cut in the middle of its last record, and an empty file
+    cut = str(tmp_path / "cut.tfrecord")
+    open(cut, "wb").write(open(path, "rb").read()[:-3])
+    with pytest.raises(IOError):
+        list(native.NativeDataset(cut, cols + labels, ["read_comment"], 32))
+    empty = str(tmp_path / "empty.tfrecord")
+    open(empty, "wb").close()
+    assert list(native.NativeDataset(empty, cols + labels, ["read_comment"], 32, num_epochs=3)) == []
     # a required feature without default
     req = [fc.numeric_column("not_there")]
     with pytest.raises(ValueError):
