@@ -253,6 +253,8 @@ def model_goldens(tf, vocab_dir):
         lab = {"read_comment": tf.T(torch.from_numpy(labels.copy()))}
         spec = model_fn(feats, lab, M.TRAIN, params)
         d["train/loss"] = _np(spec.loss)
+        for i, mk in enumerate(g.collections.get("__dropout_masks__", [])):       # training-mode dropout keep masks, call order
+            d[f"aux/dropout_mask_{i}"] = mk.numpy().copy()
         grads = spec.train_op.run()
         for vn, gv in grads.items():
             d[f"grad/{vn}"] = _np(gv)
@@ -364,6 +366,16 @@ def model_goldens(tf, vocab_dir):
                  "embedding_dim": m.FLAGS.embedding_dim,
                  "fields_vocabulary_size_tuple": [(c.categorical_column.name, int(c.variable_shape[-1])) for c in cols]}, cols)
     run("model_ffm", _import_ref("FFM", "ffm"), "ffm_model_fn", ffm_params, dict(learning_rate=0.005, embedding_dim=4))
+
+    # §8f-3 sibling, oracle pinned ahead of its kernels: NFM (bi-interaction pooling + MLP, nfm.py:143-182); its
+    # dropout after the pooling is hard-coded (0.1, :170): the TRAIN golden carries the keep mask
+    def nfm_params(m):
+        dense_c, cat, label = m.create_feature_columns()
+        return ({"category_feature_columns": cat, "dense_feature_columns": dense_c,
+                 "hidden_units": m.FLAGS.hidden_units.split(","), "learning_rate": m.FLAGS.learning_rate,
+                 "dropout_rate": m.FLAGS.dropout_rate, "batch_norm": m.FLAGS.batch_norm}, dense_c + cat)
+    run("model_nfm", _import_ref("NFM", "nfm"), "nfm_model_fn", nfm_params,
+        dict(common, embedding_dim=8, dropout_rate=0.0, batch_norm=True))
 
     # the shared batch
     batch = {"dense": dense, "labels": labels, "dense_names": np.array(DENSE)}

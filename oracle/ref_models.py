@@ -219,6 +219,46 @@ def ffm(P, feats, labels, params, training=False):
     return _tail(logit, None if labels is None else labels["read_comment"])
 
 
+def nfm(P, feats, labels, params, training=False, dropout_masks=None):
+    """algorithm/NFM/nfm.py:143-184 (SURVEY.md §8f-3 sibling; pinned ahead of its kernels).  Bi-interaction pooling
+    0.5 * ((sum_f e_f)^2 - sum_f e_f^2) -> BatchNorm `bi_interaction_bn` -> dropout with the HARD-CODED rate 0.1
+    (:170, independent of the dropout_rate flag) -> MLP (dense(relu) -> BN -> dropout(rate flag)) -> dense(1).
+    In training mode `dropout_masks[0]` is the keep mask of that dropout (TF's random stream cannot be
+    reproduced; the golden records the mask it used).  Like AFM, the model also creates an unused
+    `category_input` set of tables (:150-151)."""
+    dense_in = input_layer(P, feats, params["dense_feature_columns"], "dense_input/input_layer")
+    dense_logit = R.dense(dense_in, P["dense_input/dense_logit/kernel"], P["dense_input/dense_logit/bias"])      # :145-147
+    fields = []
+    for i, c in enumerate(params["category_feature_columns"]):                                                  # :158-161
+        layer = "bi_interaction_part/input_layer" + ("" if i == 0 else f"_{i}")
+        fields.append(_lookup(P, feats, c, layer, {}))
+    s_, q_ = fields[0], fields[0] ** 2
+    for e in fields[1:]:                                                                                        # add_n: in list order
+        s_, q_ = s_ + e, q_ + e ** 2
+    x = 0.5 * (s_ ** 2 - q_)                                                                                    # :163-167
+    b = "bi_interaction_part/bi_interaction_bn"
+    x = R.batch_norm(x, P[f"{b}/gamma"], P[f"{b}/beta"], P[f"{b}/moving_mean"], P[f"{b}/moving_variance"], training)  # :168
+    if training:                                                                                                # :170
+        if not dropout_masks:
+            raise ValueError("nfm(training=True) needs the keep mask of the hard-coded dropout (rate 0.1)")
+        x = x * dropout_masks[0] / 0.9
+    if 0.0 < float(params.get("dropout_rate", 0.0)) < 1.0 and training:
+        raise NotImplementedError("the MLP dropouts are only restated at rate 0")
+    net = x
+    for i, _ in enumerate(params["hidden_units"]):                                                              # :174-180
+        dn = "dense" if i == 0 else f"dense_{i}"
+        net = R.dense(net, P[f"dnn_part/{dn}/kernel"], P[f"dnn_part/{dn}/bias"], relu=True)
+        if params.get("batch_norm"):
+            bn = "batch_normalization" if i == 0 else f"batch_normalization_{i}"
+            net = R.batch_norm(net, P[f"dnn_part/{bn}/gamma"], P[f"dnn_part/{bn}/beta"],
+                               P[f"dnn_part/{bn}/moving_mean"], P[f"dnn_part/{bn}/moving_variance"], training)
+    n = len(params["hidden_units"])
+    dn = "dense" if n == 0 else f"dense_{n}"
+    nfm_logit = R.dense(net, P[f"dnn_part/{dn}/kernel"], P[f"dnn_part/{dn}/bias"])                               # :181
+    logit = dense_logit + nfm_logit                                                                             # :183
+    return _tail(logit, None if labels is None else labels["read_comment"])
+
+
 def xdeepfm(P, feats, labels, params, training=False):
     """algorithm/xDeepFM/xdeepfm.py:139-207."""
     dense_cols = params.get("dense_feature_columns") or []

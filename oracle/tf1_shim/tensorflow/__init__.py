@@ -575,9 +575,18 @@ def _batch_normalization(inputs, training=False, center=True, scale=True, moment
 
 
 def _dropout(inputs, rate=0.5, training=False, **_kw):
-    if training and 0.0 < rate < 1.0:
-        raise NotImplementedError("tf1_shim: stochastic dropout is not restated; generate goldens with rate 0")
-    return inputs
+    """[TF-ext A-8] tf.layers.dropout: identity unless training; in training each element is kept with
+    probability 1 - rate and scaled by 1 / (1 - rate).  TF's random stream cannot be reproduced, so the keep mask
+    is drawn from a generator seeded per call and RECORDED (graph collection "__dropout_masks__", call order):
+    gen_golden.py stores the masks next to the outputs and the oracle / mirror are checked with the same masks."""
+    if not (training and 0.0 < rate < 1.0):
+        return inputs
+    x = _raw(inputs)
+    masks = _G.collections["__dropout_masks__"]
+    g = torch.Generator().manual_seed(977 * 1000003 + len(masks))
+    keep = (torch.rand(x.shape, generator=g, dtype=torch.float64) >= rate).to(x.dtype)
+    masks.append(keep)
+    return T(x * keep / (1.0 - rate))
 
 
 def _flatten(inputs, name=None):
