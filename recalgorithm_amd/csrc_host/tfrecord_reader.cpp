@@ -13,6 +13,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <pthread.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -184,9 +185,17 @@ struct Vocab {
 // 16; 1 = everything inline) sizes it.  One job at a time (callers are serialised by the mutex).
 class Pool {
   public:
+    // Heap singleton, never destroyed.  After fork() the child has none of the worker threads: the
+    // pthread_atfork child handler swaps in a pool without workers (everything inline), so a forked
+    // data-loader worker keeps decoding instead of waiting for threads that do not exist.
     static Pool& get() {
-        static Pool p;
-        return p;
+        static Pool* p = [] {
+            inst() = new Pool(false);
+            pthread_atfork(nullptr, nullptr, [] { inst() = new Pool(true); });
+            return inst();
+        }();
+        (void)p;
+        return *inst();
     }
     size_t threads() const { return workers_.size() + 1; }
     void parallel_for(size_t n, const std::function<void(size_t)>& f) {
@@ -220,7 +229,12 @@ class Pool {
     }
 
   private:
-    Pool() {
+    static Pool*& inst() {
+        static Pool* p = nullptr;
+        return p;
+    }
+    explicit Pool(bool inline_only) {
+        if (inline_only) return;
         size_t n = std::thread::hardware_concurrency();
         if (n == 0) n = 1;
         if (n > 16) n = 16;

@@ -171,3 +171,23 @@ def test_native_decode_throughput(tmp_path, capsys):
         print(f"\n[native reader] 26 string fields/example: native {n / t_nat:,.0f} ex/s, python {n / t_py:,.0f} ex/s "
               f"({t_py / t_nat:.0f}x)")
     assert t_nat < t_py
+
+
+def test_native_reader_survives_fork(tmp_path):
+    """The decode worker pool does not exist in a forked child (e.g. a fork-based data-loader worker): the
+    child must fall back to inline decoding instead of waiting for the parent's threads."""
+    import multiprocessing as mp
+    spec, path, cols, labels, parser = _dataset(tmp_path, n=200)
+    parent = [l["read_comment"].shape[0] for _, l in eval_input_fn(path, parser, 64)]      # pool is up in the parent
+    q = mp.get_context("fork").Queue()
+
+    def child():
+        q.put([l["read_comment"].shape[0] for _, l in eval_input_fn(path, parser, 64)])
+    p = mp.get_context("fork").Process(target=child)
+    p.start()
+    p.join(60)
+    alive = p.is_alive()
+    if alive:
+        p.terminate()
+    assert not alive, "forked child hung in the native reader"
+    assert p.exitcode == 0 and q.get(timeout=5) == parent == [64, 64, 64, 8]
