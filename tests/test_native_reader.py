@@ -191,3 +191,36 @@ def test_native_reader_survives_fork(tmp_path):
         p.terminate()
     assert not alive, "forked child hung in the native reader"
     assert p.exitcode == 0 and q.get(timeout=5) == parent == [64, 64, 64, 8]
+
+
+def test_native_decoder_rejects_or_survives_corrupt_examples(tmp_path):
+    """Bit-flipped and random record payloads (valid TFRecord framing, crc check off): the decoder must either
+    report a malformed batch or decode something — never read out of bounds or crash."""
+    spec, path, cols, labels, parser = _dataset(tmp_path, n=40)
+    recs = list(T.read_records(path)) if hasattr(T, "read_records") else None
+    if recs is None:
+        pytest.skip("python codec has no record iterator")
+    rng = np.random.default_rng(3)
+    outcomes = {"ok": 0, "error": 0}
+    for case in range(60):
+        muts = []
+        for r in recs[:20]:
+            b = bytearray(r)
+            kind = case % 3
+            if kind == 0 and b:                                   # flip a few bytes
+                for _ in range(3):
+                    b[int(rng.integers(0, len(b)))] ^= int(rng.integers(1, 256))
+            elif kind == 1:                                       # truncate
+                b = b[:int(rng.integers(0, len(b) + 1))]
+            else:                                                 # random bytes
+                b = bytearray(rng.integers(0, 256, int(rng.integers(0, 200)), dtype=np.uint8).tobytes())
+            muts.append(bytes(b))
+        p = str(tmp_path / f"fuzz_{case}.tfrecord")
+        T.write_records(p, muts)
+        try:
+            for _ in native.NativeDataset(p, cols + labels, ["read_comment"], 8):
+                pass
+            outcomes["ok"] += 1
+        except (IOError, ValueError):
+            outcomes["error"] += 1
+    assert outcomes["ok"] + outcomes["error"] == 60 and outcomes["error"] > 0
