@@ -55,6 +55,31 @@ def test_header_arg_counts_match_binding():
         assert len(params) == len(args), f"{name}: header has {len(params)} params, binding {len(args)}"
 
 
+def test_header_arg_types_match_binding():
+    """Every parameter and return type of recalgo.h against the ctypes signature (int vs int64_t vs float vs
+    pointer): a wrong width here silently corrupts arguments at call time."""
+    from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+    from recalgorithm_amd import _lib
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+
+    def ctype_of(decl):
+        decl = decl.strip()
+        if "*" in decl or decl.startswith("recalgo_stream_t"):
+            return c_void_p
+        base = decl.rsplit(" ", 1)[0].replace("const ", "").strip()
+        return {"int": c_int, "int64_t": c_int64, "float": c_float, "unsigned": c_int, "unsigned int": c_int}[base]
+
+    for name, (res, args) in _lib.SIGNATURES.items():
+        m = re.search(r"([A-Za-z_0-9 \*]+?)\b" + name + r"\s*\(([^)]*)\)", src)
+        assert m, name
+        ret = m.group(1).strip()
+        want_res = c_char_p if "char" in ret else {"int": c_int, "int64_t": c_int64}[ret.replace("const ", "")]
+        assert res is want_res, f"{name}: returns {ret}, binding {res}"
+        params = [p for p in m.group(2).split(",") if p.strip() and p.strip() != "void"]
+        for i, (decl, bound) in enumerate(zip(params, args)):
+            assert ctype_of(decl) is bound, f"{name} arg {i} `{decl.strip()}`: binding {bound.__name__}"
+
+
 def test_object_code_is_gfx950(lib_path):
     data = open(lib_path, "rb").read()
     assert b"gfx950" in data

@@ -224,3 +224,32 @@ def test_native_decoder_rejects_or_survives_corrupt_examples(tmp_path):
         except (IOError, ValueError):
             outcomes["error"] += 1
     assert outcomes["ok"] + outcomes["error"] == 60 and outcomes["error"] > 0
+
+
+def test_host_header_arg_types_match_binding():
+    """include/recalgo_host.h parameter / return types against io/native.py's ctypes signatures."""
+    from ctypes import c_char_p, c_float, c_int, c_int64, c_uint32, c_uint64, c_void_p
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "recalgo_host.h")).read(), flags=re.S)
+
+    def ctype_of(decl):
+        decl = decl.strip()
+        if "char" in decl and decl.count("*") == 1:
+            return c_char_p
+        if "*" in decl:
+            return c_void_p
+        base = decl.rsplit(" ", 1)[0].replace("const ", "").strip()
+        return {"int": c_int, "int64_t": c_int64, "uint64_t": c_uint64, "uint32_t": c_uint32, "float": c_float}[base]
+
+    for name, (res, args) in native.SIGNATURES.items():
+        m = re.search(r"([A-Za-z_0-9 \*]+?)\b" + name + r"\s*\(([^)]*)\)", src)
+        assert m, name
+        ret = m.group(1).strip()
+        want = None if ret == "void" else (c_char_p if "char" in ret else (c_void_p if "*" in ret else
+               {"int": c_int, "int64_t": c_int64, "uint32_t": c_uint32}[ret]))
+        assert res is want, f"{name}: returns `{ret}`, binding {res}"
+        params = [p for p in m.group(2).split(",") if p.strip() and p.strip() != "void"]
+        assert len(params) == len(args), name
+        for i, (decl, bound) in enumerate(zip(params, args)):
+            got = ctype_of(decl)
+            # byte buffers are passed as c_void_p / c_char_p interchangeably
+            assert got is bound or {got, bound} == {c_char_p, c_void_p}, f"{name} arg {i} `{decl.strip()}`: binding {bound.__name__}"
