@@ -516,6 +516,10 @@ def main():
         "final_loss": round(loss_v, 6),
         "ms_per_step_by_chunk_of_25": r["chunk_ms"],
     }
+    cs = sorted(r["chunk_ms"])
+    if cs:          # spread of the per-chunk step times (median and p10 / p90)
+        pick = lambda q: cs[min(len(cs) - 1, int(q * len(cs)))]
+        out["ms_per_step_p10_p50_p90"] = [pick(0.1), pick(0.5), pick(0.9)]
     if rank == 0:
         ks = None
         if not args.no_kernel_timing:
