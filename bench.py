@@ -491,7 +491,6 @@ def main():
         torch.cuda.empty_cache()
     est, spec, feats, workload, dt, loss_v, launch = (r[k] for k in ("est", "spec", "feats", "workload", "dt", "loss", "launch"))
 
-    # fwd+bwd only (optimizer excluded), reported next to the headline
     out = {
         "metric": "CTR examples/sec (train step fwd+bwd+TF1-Adam), batch 4096/GPU, 26 fields x emb16",
         "value": round(world * args.batch * args.steps / dt, 1),
