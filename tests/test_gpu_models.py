@@ -12,7 +12,7 @@ from recalgorithm_amd import feature_column as fc
 from recalgorithm_amd.estimator import Estimator, GraphedTrainStep, ModeKeys, RunConfig
 from recalgorithm_amd.io import synth
 from recalgorithm_amd.variables import named_grads
-from tests.util import assert_bit_exact, assert_close
+from tests.util import assert_adam_update, assert_bit_exact, assert_close
 
 pytestmark = pytest.mark.gpu
 
@@ -77,20 +77,13 @@ def test_model_forward_backward_adam(dev, model):
             continue
         pp, m, v = before[name].clone(), torch.zeros_like(before[name]), torch.zeros_like(before[name])
         R.adam_tf1_step(pp, p.grad, m, v, 1, params["learning_rate"])
-        # compare the UPDATE (p_after - p_before), not p: at step 1 it is lr*g/(|g| + eps'), i.e.
-        # ~lr*sign(g) — and ill-conditioned in g where |g| ~ eps' = 3e-7, so the bound is
-        # absolute, 2e-4 of the step size lr
-        # absolute: 2e-4 of the step size lr, plus the already-accepted gradient tolerance
-        # propagated through d(update)/dg = lr*eps'/(|g|+eps')^2
+        # compare the UPDATE (p_after - p_before), not p: at step 1 it is lr*g/(|g| + eps'), ~lr*sign(g), and
+        # ill-conditioned in g only where |g| ~ eps' = 3e-7 (tests/util.py assert_adam_update)
         lr = params["learning_rate"]
         gref = p.grad.abs()
         tol_g = 1e-5 * (gref + gref.pow(2).mean().sqrt()) + 1e-6 * gref.max()
-        eps1 = 1e-8 / (1.0 - 0.999) ** 0.5
-        tol = lr * (2e-4 + tol_g * eps1 / (gref + eps1) ** 2)
         upd = after[name].detach().cpu().double() - before[name]
-        err = (upd - (pp - before[name])).abs()
-        assert bool((err <= tol).all()), \
-            f"{model} adam update {name}: worst err/tol {float((err / tol).max()):.3g}"
+        assert_adam_update(upd, pp - before[name], before[name], gref, tol_g, lr, what=f"{model} adam update {name}")
     # gradients were consumed and zeroed by the fused optimizer
     assert float(est.store.flat_grad.abs().sum()) == 0.0
     for ar in est.store.arenas.values():
