@@ -300,6 +300,31 @@ int recalgo_mlp_width_supported(int C);
 int64_t recalgo_relu_bwd_bias_workspace_bytes(int rows, int C);
 int recalgo_relu_bwd_bias(const float* g, const float* y, int rows, int C, float* g_out, float* dbias,
                           void* workspace, recalgo_stream_t stream);
+/* ------------------------------------------------------------------------------------------
+ * tf.layers.dense on the fp32 matrix cores (csrc/dense.hip; v_mfma_f32_32x32x2_f32: exact fp32, a
+ * k-ordered fmaf chain).  Replaces `tf.layers.dense(x, units, activation=relu)` of every model_fn
+ * (algorithm/DCN/dcn.py:163-166, DeepFM/deepfm.py:206-208, xDeepFM/xdeepfm.py:178-181, DIN/din.py:226-227,
+ * FiBiNET/fibinet.py:191-193, PNN/pnn.py:186-188) and, with the second operand pair, the D-way contraction
+ * of the PNN product layer `relu(lz + lp + bias)` (algorithm/PNN/pnn.py:139,146-181).  All matrices fp32
+ * row-major, leading dimensions in floats; any M, K, N (operands whose base is 16-byte aligned and whose
+ * leading dimension is a multiple of 4 are read as float4, others element-wise; w / w2 have ld = N).
+ *   fwd          y[M,N] = act( x[M,K] w[K,N] (+ x2[M,K2] w2[K2,N]) + bias[N] )     act = ReLU when relu != 0;
+ *                x2/w2 and bias may be NULL
+ *   bwd_input    dx[M,K] (+)= (g (.) [y_mask > 0])[M,N] w[K,N]^T + beta * c_in[M,K]
+ *                y_mask (the forward output, same layout as g) and c_in may be NULL; accumulate != 0 adds to dx
+ *   bwd_weights  dw[K,N] = x[M,K]^T (g (.) [y_mask > 0]),  dbias[N] = column sums of the masked g (dbias may be NULL)
+ *                split over M with a fixed-order second pass (deterministic);
+ *                workspace: recalgo_dense_bwd_weights_workspace_bytes(M, K, N) (0 => may be NULL)
+ * The masked gradient g (.) [y > 0] is applied while tiles are staged and never materialised.
+ * ------------------------------------------------------------------------------------------ */
+int recalgo_dense_fwd(const float* x, int ldx, const float* w, int K, const float* x2, int ldx2, const float* w2, int K2,
+                      const float* bias, int M, int N, int relu, float* y, int ldy, recalgo_stream_t stream);
+int recalgo_dense_bwd_input(const float* g, int ldg, const float* y_mask, const float* w, int M, int N, int K,
+                            const float* c_in, int ldc, float beta, float* dx, int lddx, int accumulate,
+                            recalgo_stream_t stream);
+int64_t recalgo_dense_bwd_weights_workspace_bytes(int M, int K, int N);
+int recalgo_dense_bwd_weights(const float* x, int ldx, const float* g, int ldg, const float* y_mask, int M, int K, int N,
+                              float* dw, float* dbias, void* workspace, recalgo_stream_t stream);
 /* tf.layers.batch_normalization(net, training=True) (algorithm/DeepFM/deepfm.py:210-211; PNN
  * pnn.py:190-191; FiBiNET fibinet.py:195-196; DIN din.py:233-234), [TF-ext A-8]:
  *   mean/var = batch moments (biased variance);  y = (x - mean) * rsqrt(var + eps) * gamma + beta

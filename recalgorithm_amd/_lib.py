@@ -68,6 +68,10 @@ SIGNATURES = {
     "recalgo_adam_tf1_advance": (c_int, [P, c_float, c_float, c_float, P, P]),
     "recalgo_cross_layer_fwd": (c_int, [P, P, c_int, P, P, c_int, c_int, P, c_int, P]),
     "recalgo_cross_layer_bwd": (c_int, [P, P, c_int, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P]),
+    "recalgo_dense_fwd": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, P, c_int, P]),
+    "recalgo_dense_bwd_input": (c_int, [P, c_int, P, P, c_int, c_int, c_int, P, c_int, c_float, P, c_int, c_int, P]),
+    "recalgo_dense_bwd_weights_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
+    "recalgo_dense_bwd_weights": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, P, P, P, P]),
     "recalgo_activation_fwd": (c_int, [P, P, c_int, c_int, c_int, P, P]),
     "recalgo_activation_bwd_workspace_bytes": (c_int64, [c_int, c_int]),
     "recalgo_activation_bwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, P]),

@@ -1,0 +1,549 @@
+// tf.layers.dense (the context MLP of every model_fn, e.g. algorithm/DCN/dcn.py:163-166, and the D-way
+// contraction of the PNN product layer, algorithm/PNN/pnn.py:139,146-181) on the gfx950 fp32 matrix
+// cores: v_mfma_f32_32x32x2_f32, exact fp32 (a k-ordered fmaf chain), 64 FLOP/clk/SIMD = the chip's fp32
+// peak (157 TFLOP/s).  Three GEMM forms, one tile engine:
+//
+//   forward   Y[M,N]  = act( X[M,K] W[K,N] (+ X2[M,K2] W2[K2,N]) + bias[N] )            A: rows x red-contiguous, B: red-major
+//   dgrad     dX[M,K] = (G (.) [Ymask > 0])[M,N] W[K,N]^T  (+ beta * C[M,K])           A: red-contiguous,      B: red-contiguous
+//   wgrad     dW[K,N] = X[M,K]^T (G (.) [Ymask > 0])[M,N],  dbias[N] = colsum(G (.) mask)   A: red-major, B: red-major; split over M
+//
+// Fused epilogues / prologues (what the library GEMMs needed extra launches for): bias + ReLU in the
+// forward store; the ReLU mask of the backward applied while the gradient tile is staged (G2 = G * [Y > 0]
+// is never materialised); the bias gradient accumulated from the staged gradient tiles of the wgrad; the
+// `beta * C` term of the first DIN layer's mini-batch-aware regulariser in the dgrad store.
+//
+// Tile engine: workgroup = 4 waves = 64 x 64 output tile (one 32 x 32 MFMA accumulator per wave: the
+// dependent-accumulator latency of v_mfma_f32_32x32x2_f32 equals its issue interval, 64 cycles, so one chain
+// per wave already issues back to back), reduction chunks of 32 double-buffered through LDS (global ->
+// registers for chunk c+1 is in flight under the 16 MFMAs of chunk c; one barrier per chunk).  LDS layouts
+// are chosen per operand form so that every MFMA operand read is a conflict-free ds_read_b32:
+//   red-contiguous operand ([idx][red] in memory): LDS [64 idx][32 red], row stride 33 (odd): lane l reads
+//       [idx0 + (l & 31)][kk + (l >> 5)] -> 32 distinct banks per half wave; staged by 4 scalar stores;
+//   red-major operand ([red][idx] in memory): LDS [32 red][64 idx], row stride 64: lanes read 32 consecutive
+//       floats; staged by one ds_write_b128.
+// A [4096 x 512 x 416] layer is 512 workgroups (2 per CU, 2 waves per SIMD: one wave's staging and barrier
+// hide under the other's MFMAs).  blockIdx -> tile is XCD-aware: the 8 XCDs (block b runs on XCD b % 8) each
+// own a contiguous range of row tiles, so an XCD's L2 holds its own 1/8 of X plus the (small) W.
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kThreads = 256;
+constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int kLdRC = BK + 1;                     // red-contiguous operand: [64][33]
+constexpr int kLdRM = 64;                         // red-major operand:      [32][64]
+constexpr int kBufFloats = 64 * kLdRC;            // 2112 >= 32 * 64
+
+struct Operand {
+    const float* p;        // RC: [n_idx][ld] (red contiguous)   RM: [n_red][ld] (idx contiguous)
+    const float* mask;     // optional, same layout: element := 0 where mask <= 0   (ReLU backward)
+    int ld;
+    int vec;               // base 16-byte aligned and ld % 4 == 0: float4 loads (else four scalar loads, e.g. the
+                           // reference's default DCN input d = 82, or the 351 Gram features of IPNN at F = 26)
+    int bytes;             // extent of the operand in bytes (buffer descriptor num_records); 0: not buffer-addressable
+};
+
+__device__ __forceinline__ float4 load4_guard(const float* p, int remaining, int vec) {
+    if (remaining >= 4) {
+        if (vec) return *reinterpret_cast<const float4*>(p);
+        return make_float4(p[0], p[1], p[2], p[3]);
+    }
+    float4 v = f4_zero();
+    if (remaining > 0) v.x = p[0];
+    if (remaining > 1) v.y = p[1];
+    if (remaining > 2) v.z = p[2];
+    return v;
+}
+__device__ __forceinline__ float4 relu_mask(float4 v, float4 m) {
+    return make_float4(m.x > 0.f ? v.x : 0.f, m.y > 0.f ? v.y : 0.f, m.z > 0.f ? v.z : 0.f, m.w > 0.f ? v.w : 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Operand staging: global -> registers -> LDS.
+// FAST (operand float4-addressable: base 16-byte aligned, ld % 4 == 0, extent of the contiguous dimension
+// % 4 == 0, < 2 GiB): raw buffer loads through a buffer descriptor whose num_records is the operand's extent —
+// an out-of-range coordinate gets the offset 0x80000000 and the hardware returns zeros, so a chunk's loads are
+// branch-free, issue back to back, and may run past the end of the reduction (the software pipeline below never
+// tests "is there a next chunk").
+// !FAST: element-wise guarded loads (any alignment / extent; e.g. the reference's default DCN width 82).
+// ---------------------------------------------------------------------------------------------
+using u32x4 = __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int;
+constexpr int kOOB = (int)0x80000000u;
+
+template <bool MASK>
+struct StageRegs {
+    float4 v[2];
+    float4 m[2];           // raw mask values (MASK only); applied when the tile is written to LDS
+};
+
+template <bool RC, bool FAST, bool MASK>
+struct Stager {
+    __amdgpu_buffer_rsrc_t rs, rm;     // FAST
+    int off[2];                        // FAST: byte offsets of this thread's two float4 at chunk 0 (kOOB: never valid)
+    int step_b;                        // FAST: bytes per chunk
+    const float* p[2];                 // !FAST
+    const float* m[2];
+    size_t step;
+    int red[2], idx[2];
+    bool idx_ok[2];
+    int n_idx, red_end, vec;
+
+    __device__ __forceinline__ void init(const Operand& op, int idx0, int red0, int n_idx_, int red_end_) {
+        const int t = threadIdx.x;
+        n_idx = n_idx_; red_end = red_end_; vec = op.vec;
+        step = RC ? (size_t)BK : (size_t)BK * op.ld;
+        step_b = (int)(step * sizeof(float));
+        if constexpr (FAST) {
+            rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(op.p), (short)0, op.bytes, 0x00020000);
+            rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(MASK ? op.mask : op.p), (short)0, op.bytes, 0x00020000);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (RC) { idx[j] = idx0 + (t >> 3) + 32 * j; red[j] = red0 + (t & 7) * 4; }
+            else { red[j] = red0 + (t >> 4) + 16 * j; idx[j] = idx0 + (t & 15) * 4; }
+            idx_ok[j] = idx[j] < n_idx;
+            const size_t o = RC ? (size_t)idx[j] * op.ld + red[j] : (size_t)red[j] * op.ld + idx[j];
+            if constexpr (FAST) {
+                off[j] = idx_ok[j] ? (int)(o * sizeof(float)) : kOOB;
+            } else {
+                p[j] = op.p + o;
+                m[j] = MASK ? op.mask + o : nullptr;
+            }
+        }
+    }
+    // issue the load of this thread's float4 `j` of chunk `c` (relative to init's red0)
+    __device__ __forceinline__ void issue(int c, int j, StageRegs<MASK>& st) const {
+        const int r = red[j] + c * BK;
+        if constexpr (FAST) {
+            // beyond red_end (the split's end, or the matrix's): zeros.  idx beyond n_idx: off[j] is already kOOB
+            // (kOOB + c * step_b stays >= 2^31 as an unsigned offset for every c the loop can reach)
+            const int o = r < red_end ? off[j] + c * step_b : kOOB;
+            st.v[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0));
+            if constexpr (MASK) st.m[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rm, o, 0, 0));
+        } else {
+            float4 v = f4_zero(), mk = make_float4(1.f, 1.f, 1.f, 1.f);
+            const size_t o = (size_t)c * step;
+            if (RC ? (idx_ok[j] && r < red_end) : r < red_end) {
+                const int remaining = RC ? red_end - r : n_idx - idx[j];
+                v = load4_guard(p[j] + o, remaining, vec);
+                if (MASK) mk = load4_guard(m[j] + o, remaining, vec);
+            }
+            st.v[j] = v;
+            if constexpr (MASK) st.m[j] = mk;
+        }
+    }
+};
+
+template <bool MASK>
+__device__ __forceinline__ float4 staged(const StageRegs<MASK>& st, int j) {
+    if constexpr (MASK) return relu_mask(st.v[j], st.m[j]);
+    else return st.v[j];
+}
+
+// registers -> LDS, in pieces so that the stores can be spread between the MFMAs of a chain:
+// RC: piece q in 0..3 = (row j = q >> 1, half = q & 1) -> one ds_write2_b32;   RM: piece q in 0..1 -> one ds_write_b128
+template <bool RC, bool MASK>
+__device__ __forceinline__ void stage_store_piece(float* __restrict__ S, const StageRegs<MASK>& st, int q) {
+    const int t = threadIdx.x;
+    if constexpr (RC) {
+        const int j = q >> 1, h = q & 1;
+        const float4 v = staged<MASK>(st, j);
+        float* d = S + ((t >> 3) + 32 * j) * kLdRC + (t & 7) * 4 + 2 * h;
+        d[0] = h ? v.z : v.x;
+        d[1] = h ? v.w : v.y;
+    } else {
+        *reinterpret_cast<float4*>(S + ((t >> 4) + 16 * q) * kLdRM + (t & 15) * 4) = staged<MASK>(st, q);
+    }
+}
+template <bool RC, bool MASK>
+__device__ __forceinline__ void stage_store(float* __restrict__ S, const StageRegs<MASK>& st) {
+#pragma unroll
+    for (int q = 0; q < (RC ? 4 : 2); ++q) stage_store_piece<RC, MASK>(S, st, q);
+}
+
+// MFMA operand values k, k+1 (k even) of this lane for one staged chunk
+template <bool RC>
+__device__ __forceinline__ void read_frag_pair(const float* __restrict__ S, int idx_local, int hi, int k, float (&f)[BK / 2]) {
+    if constexpr (RC) {
+        f[k] = S[idx_local * kLdRC + 2 * k + hi];
+        f[k + 1] = S[idx_local * kLdRC + 2 * k + 2 + hi];
+    } else {
+        f[k] = S[(2 * k + hi) * kLdRM + idx_local];
+        f[k + 1] = S[(2 * k + 2 + hi) * kLdRM + idx_local];
+    }
+}
+
+struct Segment {           // one (A, B) pair contracted over n_red; a launch accumulates up to 2 of them
+    Operand a, b;
+    int n_red;
+};
+
+constexpr int kStages = 3;                        // LDS ring
+
+// acc(32x32 of this wave) += sum over the segment's reduction range [red_begin, red_end) of A B.
+// COLSUM: also accumulate, per thread, the column sums of the B tiles this thread stages (wgrad: dbias).
+//
+// Software pipeline.  One wave per SIMD must keep the matrix pipe busy by itself (co-resident workgroups run in
+// lockstep, so their non-MFMA phases coincide instead of complementing each other), hence ALL other work of an
+// iteration is issued in the shadow of its own 16 MFMAs (an MFMA occupies the pipe for 64 cycles but only one issue
+// slot), in this fixed order (`sched_barrier` pins it):
+//   iteration c:  MFMA k of chunk c            k = 0..15, alternating between two accumulator chains
+//                 + global loads of chunk c+3  (k = 0..3; consumed at the END of iteration c+1: ~2 iterations of latency)
+//                 + LDS -> operand registers of chunk c+1, one read pair per MFMA
+//                 + registers (loaded in iteration c-1) -> LDS slot of chunk c+2   (k = 8..13)
+//                 one barrier
+// LDS ring of 3: while chunk c+1 is read out of slot (c+1) % 3, chunk c+2 lands in slot (c+2) % 3 = (c-1) % 3, whose
+// last readers passed two barriers ago.  Loads and slots past the end of the reduction are zeros / unused.
+template <bool A_RC, bool B_RC, bool FAST, bool MASK_A, bool MASK_B, bool COLSUM>
+__device__ __forceinline__ void tile_mainloop(const Segment& sg, int m0, int n0, int M, int N, int red_begin, int red_end,
+                                              float* __restrict__ As, float* __restrict__ Bs, f32x16& acc, f32x16& acc1, float4& colsum) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hi = lane >> 5, l32 = lane & 31;
+    const int am = (wave >> 1) * 32 + l32, bn = (wave & 1) * 32 + l32;
+    const int nchunks = (red_end - red_begin + BK - 1) / BK;
+    if (nchunks <= 0) return;
+    Stager<A_RC, FAST, MASK_A> ga;
+    Stager<B_RC, FAST, MASK_B> gb;
+    ga.init(sg.a, m0, red_begin, M, red_end);
+    gb.init(sg.b, n0, red_begin, N, red_end);
+    StageRegs<MASK_A> sa0, sa1;
+    StageRegs<MASK_B> sb0, sb1;
+    // prologue: chunks 0, 1 -> slots 0, 1; chunk 2 in flight in set 0
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { ga.issue(0, j, sa0); gb.issue(0, j, sb0); ga.issue(1, j, sa1); gb.issue(1, j, sb1); }
+    __syncthreads();                                      // previous users of the LDS ring are done
+    stage_store<A_RC, MASK_A>(As, sa0);
+    stage_store<B_RC, MASK_B>(Bs, sb0);
+    stage_store<A_RC, MASK_A>(As + kBufFloats, sa1);
+    stage_store<B_RC, MASK_B>(Bs + kBufFloats, sb1);
+    if constexpr (COLSUM) {
+        colsum = f4_add(colsum, f4_add(staged<MASK_B>(sb0, 0), staged<MASK_B>(sb0, 1)));
+        colsum = f4_add(colsum, f4_add(staged<MASK_B>(sb1, 0), staged<MASK_B>(sb1, 1)));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { ga.issue(2, j, sa0); gb.issue(2, j, sb0); }
+    __syncthreads();
+    float fa0[BK / 2], fb0[BK / 2], fa1[BK / 2], fb1[BK / 2];
+#pragma unroll
+    for (int k = 0; k < BK / 2; k += 2) {
+        read_frag_pair<A_RC>(As, am, hi, k, fa0);
+        read_frag_pair<B_RC>(Bs, bn, hi, k, fb0);
+    }
+    int s1 = 1, s2 = 2;                                   // ring slots of chunks c+1, c+2
+    // cur: staged registers of chunk c+2 (loaded in the previous iteration); nxt: receives chunk c+3
+    auto step = [&](int c, float (&fa)[BK / 2], float (&fb)[BK / 2], float (&na)[BK / 2], float (&nb)[BK / 2],
+                    StageRegs<MASK_A>& curA, StageRegs<MASK_B>& curB, StageRegs<MASK_A>& nxtA, StageRegs<MASK_B>& nxtB) {
+        const float* rA = As + s1 * kBufFloats;
+        const float* rB = Bs + s1 * kBufFloats;
+        float* wA = As + s2 * kBufFloats;
+        float* wB = Bs + s2 * kBufFloats;
+#pragma unroll
+        for (int k = 0; k < BK / 2; ++k) {
+            if (k & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k], fb[k], acc1, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k], fb[k], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k < 2) ga.issue(c + 3, k, nxtA);
+            else if (k < 4) gb.issue(c + 3, k - 2, nxtB);
+            if (k & 1) read_frag_pair<B_RC>(rB, bn, hi, k - 1, nb);
+            else read_frag_pair<A_RC>(rA, am, hi, k, na);
+            if (k >= 8 && k < 8 + (A_RC ? 4 : 2)) stage_store_piece<A_RC, MASK_A>(wA, curA, k - 8);
+            if (k >= 12 && k < 12 + (B_RC ? 4 : 2)) stage_store_piece<B_RC, MASK_B>(wB, curB, k - 12);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (COLSUM) colsum = f4_add(colsum, f4_add(staged<MASK_B>(curB, 0), staged<MASK_B>(curB, 1)));
+        s1 = s2;
+        s2 = s2 + 1 == kStages ? 0 : s2 + 1;
+        __syncthreads();
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+        step(c, fa0, fb0, fa1, fb1, sa0, sb0, sa1, sb1);
+        if (c + 1 < nchunks) step(c + 1, fa1, fb1, fa0, fb0, sa1, sb1, sa0, sb0);
+    }
+}
+
+// XCD-aware linear block -> (tile_m, tile_n): block b runs on XCD b % 8; give every XCD a contiguous
+// range of the m-major tile order (all n-tiles of an m-tile land on one XCD).
+__device__ __forceinline__ int xcd_swizzle(int b, int total) {
+    if (total % 8) return b;
+    return (b % 8) * (total / 8) + b / 8;
+}
+
+struct FwdArgs {
+    Segment seg[2];
+    int nseg;
+    const float* bias;     // [N] or null
+    int relu;
+    float* y;
+    int ldy;
+    int M, N;
+};
+
+template <bool FAST>
+__global__ __launch_bounds__(kThreads) void dense_fwd_kernel(FwdArgs P) {
+    __shared__ __attribute__((aligned(16))) float As[kStages * kBufFloats];
+    __shared__ __attribute__((aligned(16))) float Bs[kStages * kBufFloats];
+    const int tn_count = (P.N + BN - 1) / BN;
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tn_count) * BM, n0 = (tile % tn_count) * BN;
+    f32x16 acc, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
+    float4 unused = f4_zero();
+    for (int s = 0; s < P.nseg; ++s)
+        tile_mainloop<true, false, FAST, false, false, false>(P.seg[s], m0, n0, P.M, P.N, 0, P.seg[s].n_red, As, Bs, acc, acc1, unused);
+    acc += acc1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hi = lane >> 5, l32 = lane & 31;
+    const int col = n0 + (wave & 1) * 32 + l32;
+    if (col >= P.N) return;
+    const float bv = P.bias ? P.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (row < P.M) {
+            float v = acc[r] + bv;
+            if (P.relu) v = fmaxf(v, 0.f);
+            P.y[(size_t)row * P.ldy + col] = v;
+        }
+    }
+}
+
+struct DgradArgs {
+    Segment seg;           // a = G (+mask) [M][N] red-contiguous, b = W [K][N] red-contiguous, n_red = N
+    const float* c_in;     // [M][ldc] or null: dx += beta * c_in
+    float beta;
+    int ldc;
+    float* dx;
+    int lddx;
+    int M, K;              // output is [M][K]
+    int accumulate;        // dx += result (the second operand pair of the PNN layer)
+};
+
+template <bool FAST, bool MASK>
+__global__ __launch_bounds__(kThreads) void dense_dgrad_kernel(DgradArgs P) {
+    __shared__ __attribute__((aligned(16))) float As[kStages * kBufFloats];
+    __shared__ __attribute__((aligned(16))) float Bs[kStages * kBufFloats];
+    const int tn_count = (P.K + BN - 1) / BN;
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tn_count) * BM, n0 = (tile % tn_count) * BN;
+    f32x16 acc, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
+    float4 unused = f4_zero();
+    tile_mainloop<true, true, FAST, MASK, false, false>(P.seg, m0, n0, P.M, P.K, 0, P.seg.n_red, As, Bs, acc, acc1, unused);
+    acc += acc1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hi = lane >> 5, l32 = lane & 31;
+    const int col = n0 + (wave & 1) * 32 + l32;
+    if (col >= P.K) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (row < P.M) {
+            float v = acc[r];
+            if (P.c_in) v = fmaf(P.beta, P.c_in[(size_t)row * P.ldc + col], v);
+            float* o = P.dx + (size_t)row * P.lddx + col;
+            *o = P.accumulate ? *o + v : v;
+        }
+    }
+}
+
+struct WgradArgs {
+    Segment seg;           // a = X [M][K] red-major (red = m), b = G (+mask) [M][N] red-major, n_red = M
+    int K, N;              // output [K][N]
+    int splits, rows_per_split;
+    float* out;            // splits == 1: dW itself (ld N); else partials [splits][K*N + Npad]
+    float* dbias_out;      // splits == 1: dbias or null
+    int want_dbias;
+    size_t slab;           // floats per split slab (K*N + N rounded)
+};
+
+template <bool FAST, bool MASK>
+__global__ __launch_bounds__(kThreads) void dense_wgrad_kernel(WgradArgs P) {
+    __shared__ __attribute__((aligned(16))) float As[kStages * kBufFloats];
+    __shared__ __attribute__((aligned(16))) float Bs[kStages * kBufFloats];
+    const int tn_count = (P.N + BN - 1) / BN, tm_count = (P.K + BM - 1) / BM;
+    const int ntiles = tn_count * tm_count;
+    // XCD placement: all tiles of one split read the same rows of X and G -> keep a split on one XCD
+    int split, tile;
+    if (P.splits % 8 == 0) {
+        const int b = blockIdx.x, x = b % 8, j = b / 8;
+        split = x + 8 * (j / ntiles);
+        tile = j % ntiles;
+    } else {
+        split = blockIdx.x / ntiles;
+        tile = blockIdx.x % ntiles;
+    }
+    const int m0 = (tile / tn_count) * BM, n0 = (tile % tn_count) * BN;
+    const int r_begin = split * P.rows_per_split;
+    const int r_end = min(P.seg.n_red, r_begin + P.rows_per_split);
+    f32x16 acc, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
+    float4 colsum = f4_zero();
+    const bool do_bias = P.want_dbias && m0 == 0;
+    if (do_bias) tile_mainloop<false, false, FAST, false, MASK, true>(P.seg, m0, n0, P.K, P.N, r_begin, r_end, As, Bs, acc, acc1, colsum);
+    else tile_mainloop<false, false, FAST, false, MASK, false>(P.seg, m0, n0, P.K, P.N, r_begin, r_end, As, Bs, acc, acc1, colsum);
+    acc += acc1;
+    float* base = P.out + (size_t)split * P.slab;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hi = lane >> 5, l32 = lane & 31;
+    const int col = n0 + (wave & 1) * 32 + l32;
+    if (col < P.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (row < P.K) base[(size_t)row * P.N + col] = acc[r];
+        }
+    }
+    if (do_bias) {
+        // thread t staged rows (t >> 4) + 16 j, columns (t & 15) * 4 .. + 3: reduce the 16 row lanes in fixed order
+        float4* sh = reinterpret_cast<float4*>(As);
+        __syncthreads();
+        sh[threadIdx.x] = colsum;
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            float4 t = sh[threadIdx.x];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) t = f4_add(t, sh[k * 16 + threadIdx.x]);
+            float* db = (P.splits == 1 ? P.dbias_out : base + (size_t)P.K * P.N);
+            const int c = n0 + threadIdx.x * 4;
+            if (c + 0 < P.N) db[c + 0] = t.x;
+            if (c + 1 < P.N) db[c + 1] = t.y;
+            if (c + 2 < P.N) db[c + 2] = t.z;
+            if (c + 3 < P.N) db[c + 3] = t.w;
+        }
+    }
+}
+
+// fixed-order sum of the split slabs: out[i] = sum_s partials[s][i]; elements [0, n0) -> out0, the rest -> out1
+template <bool VEC>
+__global__ __launch_bounds__(256) void dense_sum_slabs_kernel(const float* __restrict__ partials, int S, size_t slab,
+                                                              size_t n0, size_t n, float* __restrict__ out0,
+                                                              float* __restrict__ out1) {
+    if constexpr (VEC) {
+        const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+        if (i >= n) return;
+        float4 acc = f4_zero();
+        for (int s = 0; s < S; ++s) acc = f4_add(acc, *reinterpret_cast<const float4*>(partials + (size_t)s * slab + i));
+        *reinterpret_cast<float4*>(i < n0 ? out0 + i : out1 + (i - n0)) = acc;
+    } else {
+        const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+        if (i >= n) return;
+        float acc = 0.f;
+        for (int s = 0; s < S; ++s) acc += partials[(size_t)s * slab + i];
+        *(i < n0 ? out0 + i : out1 + (i - n0)) = acc;
+    }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int vec_ok(const float* p, int ld) { return (aligned16(p) && ld % 4 == 0) ? 1 : 0; }
+// rows x cols: the extent of the matrix in memory (row-major, leading dimension ld)
+inline Operand operand(const float* p, const float* mask, int ld, int64_t rows, int64_t cols) {
+    const int64_t bytes = rows > 0 ? ((rows - 1) * ld + cols) * (int64_t)sizeof(float) : 0;
+    return Operand{p, mask, ld, (vec_ok(p, ld) && (mask == nullptr || aligned16(mask))) ? 1 : 0,
+                   bytes < (1ll << 31) - (1ll << 24) ? (int)bytes : 0};
+}
+
+// FAST-path predicates: the contiguous extent of the operand must be float4-addressable
+inline bool fast_rc(const Operand& o, int n_red) { return o.p == nullptr || (o.vec && o.bytes > 0 && n_red % 4 == 0); }
+inline bool fast_rm(const Operand& o, int n_idx) { return o.p == nullptr || (o.vec && o.bytes > 0 && n_idx % 4 == 0); }
+
+inline int wgrad_splits(int M, int K, int N) {
+    const int ntiles = cdiv(K, BM) * cdiv(N, BN);
+    int want = cdiv(512, ntiles);                       // >= 2 workgroups per CU
+    const int max_s = cdiv(M, 4 * BK);                  // at least four chunks per split
+    if (want > max_s) want = max_s;
+    if (want >= 8) want = want / 8 * 8;                 // whole XCD groups
+    return want < 1 ? 1 : want;
+}
+inline size_t wgrad_slab(int K, int N) { return ((size_t)K * N + N + 3) / 4 * 4; }
+
+}  // namespace
+
+// =============================================================================================
+// C-ABI
+// =============================================================================================
+RECALGO_EXPORT int recalgo_dense_fwd(const float* x, int ldx, const float* w, int K, const float* x2, int ldx2,
+                                     const float* w2, int K2, const float* bias, int M, int N, int relu, float* y,
+                                     int ldy, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(M >= 0 && N > 0 && K > 0 && y != nullptr && ldy >= N);
+    RECALGO_REQUIRE(x != nullptr && ldx >= K && w != nullptr);
+    RECALGO_REQUIRE(x2 == nullptr || (ldx2 >= K2 && K2 > 0 && w2 != nullptr));
+    if (M == 0) return 0;
+    FwdArgs P;
+    P.seg[0] = Segment{operand(x, nullptr, ldx, M, K), operand(w, nullptr, N, K, N), K};
+    P.seg[1] = Segment{operand(x2, nullptr, ldx2, M, K2), operand(w2, nullptr, N, K2, N), K2};
+    P.nseg = x2 ? 2 : 1;
+    P.bias = bias; P.relu = relu; P.y = y; P.ldy = ldy; P.M = M; P.N = N;
+    const int grid = cdiv(M, BM) * cdiv(N, BN);
+    const bool fast = fast_rc(P.seg[0].a, K) && fast_rm(P.seg[0].b, N) && fast_rc(P.seg[1].a, K2) && fast_rm(P.seg[1].b, N);
+    if (fast) hipLaunchKernelGGL(dense_fwd_kernel<true>, dim3(grid), dim3(kThreads), 0, as_stream(stream), P);
+    else hipLaunchKernelGGL(dense_fwd_kernel<false>, dim3(grid), dim3(kThreads), 0, as_stream(stream), P);
+    RECALGO_RETURN_LAST();
+}
+
+RECALGO_EXPORT int recalgo_dense_bwd_input(const float* g, int ldg, const float* y_mask, const float* w, int M, int N,
+                                           int K, const float* c_in, int ldc, float beta, float* dx, int lddx,
+                                           int accumulate, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(M >= 0 && N > 0 && K > 0 && dx != nullptr && lddx >= K);
+    RECALGO_REQUIRE(g != nullptr && ldg >= N && w != nullptr);
+    RECALGO_REQUIRE(c_in == nullptr || ldc >= K);
+    if (M == 0) return 0;
+    DgradArgs P;
+    P.seg = Segment{operand(g, y_mask, ldg, M, N), operand(w, nullptr, N, K, N), N};
+    P.c_in = c_in; P.beta = beta; P.ldc = ldc; P.dx = dx; P.lddx = lddx; P.M = M; P.K = K; P.accumulate = accumulate;
+    const int grid = cdiv(M, BM) * cdiv(K, BN);
+    const bool fast = fast_rc(P.seg.a, N) && fast_rc(P.seg.b, N);
+    hipStream_t st = as_stream(stream);
+    if (fast && y_mask) hipLaunchKernelGGL((dense_dgrad_kernel<true, true>), dim3(grid), dim3(kThreads), 0, st, P);
+    else if (fast) hipLaunchKernelGGL((dense_dgrad_kernel<true, false>), dim3(grid), dim3(kThreads), 0, st, P);
+    else if (y_mask) hipLaunchKernelGGL((dense_dgrad_kernel<false, true>), dim3(grid), dim3(kThreads), 0, st, P);
+    else hipLaunchKernelGGL((dense_dgrad_kernel<false, false>), dim3(grid), dim3(kThreads), 0, st, P);
+    RECALGO_RETURN_LAST();
+}
+
+RECALGO_EXPORT int64_t recalgo_dense_bwd_weights_workspace_bytes(int M, int K, int N) {
+    if (M <= 0 || K <= 0 || N <= 0) return 0;
+    const int S = wgrad_splits(M, K, N);
+    return S <= 1 ? 0 : (int64_t)S * (int64_t)wgrad_slab(K, N) * (int64_t)sizeof(float);
+}
+
+RECALGO_EXPORT int recalgo_dense_bwd_weights(const float* x, int ldx, const float* g, int ldg, const float* y_mask,
+                                             int M, int K, int N, float* dw, float* dbias, void* workspace,
+                                             recalgo_stream_t stream) {
+    RECALGO_REQUIRE(M > 0 && N > 0 && K > 0 && dw != nullptr);
+    RECALGO_REQUIRE(x != nullptr && ldx >= K && g != nullptr && ldg >= N);
+    const int S = wgrad_splits(M, K, N);
+    RECALGO_REQUIRE(S == 1 || (workspace != nullptr && aligned16(workspace)));
+    hipStream_t st = as_stream(stream);
+    WgradArgs P;
+    P.seg = Segment{operand(x, nullptr, ldx, M, K), operand(g, y_mask, ldg, M, N), M};
+    P.K = K; P.N = N; P.splits = S;
+    P.rows_per_split = cdiv(cdiv(M, S), BK) * BK;
+    P.want_dbias = dbias != nullptr;
+    P.slab = S == 1 ? 0 : wgrad_slab(K, N);
+    P.out = S == 1 ? dw : static_cast<float*>(workspace);
+    P.dbias_out = dbias;
+    const int grid = cdiv(K, BM) * cdiv(N, BN) * S;
+    const bool fast = fast_rm(P.seg.a, K) && fast_rm(P.seg.b, N);
+    if (fast && y_mask) hipLaunchKernelGGL((dense_wgrad_kernel<true, true>), dim3(grid), dim3(kThreads), 0, st, P);
+    else if (fast) hipLaunchKernelGGL((dense_wgrad_kernel<true, false>), dim3(grid), dim3(kThreads), 0, st, P);
+    else if (y_mask) hipLaunchKernelGGL((dense_wgrad_kernel<false, true>), dim3(grid), dim3(kThreads), 0, st, P);
+    else hipLaunchKernelGGL((dense_wgrad_kernel<false, false>), dim3(grid), dim3(kThreads), 0, st, P);
+    if (S > 1) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        const size_t n0 = (size_t)K * N, n = n0 + (dbias ? (size_t)N : 0);
+        const bool vec = n0 % 4 == 0 && N % 4 == 0 && aligned16(dw) && (dbias == nullptr || aligned16(dbias));
+        if (vec)
+            hipLaunchKernelGGL(dense_sum_slabs_kernel<true>, dim3(cdiv((int64_t)cdiv((int64_t)n, 4), 256)), dim3(256), 0, st,
+                               static_cast<const float*>(workspace), S, P.slab, n0, n, dw, dbias);
+        else
+            hipLaunchKernelGGL(dense_sum_slabs_kernel<false>, dim3(cdiv((int64_t)n, 256)), dim3(256), 0, st,
+                               static_cast<const float*>(workspace), S, P.slab, n0, n, dw, dbias);
+    }
+    RECALGO_RETURN_LAST();
+}

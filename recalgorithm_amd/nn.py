@@ -1,7 +1,8 @@
 """tf.layers.{dense, batch_normalization, dropout} look-alikes for the mirrored model_fns.
 
-These are the "context" MLP of the models (plain library GEMMs, not
-feature-interaction hot layers): the GEMMs go to hipBLASLt through torch, fp32.  Parameter
+These are the "context" MLP of the models.  `dense` runs on the hand-written fp32-MFMA
+kernels of csrc/dense.hip (bias + ReLU fused in the forward, the ReLU mask and the bias gradient fused in the
+backward); RECALGO_DENSE=blas switches back to hipBLASLt through torch for A/B measurements.  Parameter
 gradients are written straight into the flat gradient buffer (variables.py).
 """
 from __future__ import annotations
@@ -20,12 +21,26 @@ def _hip(x: torch.Tensor, C: int) -> bool:
     return x.is_cuda and x.dtype == torch.float32 and ops.mlp_width_supported(C)
 
 
+def _mfma_dense() -> bool:
+    """RECALGO_DENSE=blas keeps the library GEMMs (hipBLASLt through torch) for A/B measurements; the default is the
+    hand-written fp32-MFMA kernels with fused epilogues (csrc/dense.hip)."""
+    import os
+    return os.environ.get("RECALGO_DENSE", "mfma") != "blas"
+
+
 class _DenseFn(Function):
     @staticmethod
     def forward(ctx, anchor, x, kernel: Variable, bias: Optional[Variable], relu: bool, input_l2: float = 0.0):
         ctx.input_l2 = float(input_l2)
         x2 = x.reshape(-1, x.shape[-1])
-        if bias is not None and relu and x2.is_cuda:
+        ctx.hip = x2.is_cuda and x2.dtype == torch.float32 and _mfma_dense()
+        if ctx.hip:
+            from . import ops
+            if x2.stride(1) != 1:
+                x2 = x2.contiguous()
+            # GEMM + bias + ReLU in one launch
+            y = ops.dense_fwd(x2, kernel.data, None if bias is None else bias.data, relu)
+        elif bias is not None and relu and x2.is_cuda:
             y = torch._addmm_activation(bias.data, x2, kernel.data)     # GEMM + bias + ReLU epilogue (hipBLASLt)
         else:
             y = torch.addmm(bias.data, x2, kernel.data) if bias is not None else x2 @ kernel.data
@@ -43,6 +58,16 @@ class _DenseFn(Function):
         kernel, bias = ctx.vars
         x2, y = ctx.saved_tensors
         g2 = g.reshape(-1, g.shape[-1])
+        if ctx.hip:
+            if g2.stride(1) != 1 or (y is not None and g2.stride() != y.stride()):
+                g2 = g2.contiguous()
+            # the ReLU mask rides on the staging of g in both kernels; the bias gradient on the weight-gradient one
+            ops.dense_bwd_weights(x2, g2, y if ctx.relu else None, kernel.grad, None if bias is None else bias.grad)
+            dx = None
+            if ctx.needs_input_grad[1]:
+                dx = ops.dense_bwd_input(g2, y if ctx.relu else None, kernel.data,
+                                         c_in=x2 if ctx.input_l2 else None, beta=ctx.input_l2).view(ctx.xshape)
+            return None, dx, None, None, None, None
         if not g2.is_contiguous():
             g2 = g2.contiguous()
         if bias is not None and _hip(g2, g2.shape[1]):

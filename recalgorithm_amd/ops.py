@@ -567,8 +567,9 @@ PNN_METHODS = {"IPNN": 0, "OPNN": 1}
 
 
 class _PnnProductFn(Function):
-    """relu(emb @ linear_w + phi(emb) @ omega(product_w) + bias): the feature / weight builders
-    and their gradients are HIP kernels, the two contractions are plain hipBLASLt GEMMs."""
+    """relu(emb @ linear_w + phi(emb) @ omega(product_w) + bias): feature / weight builders (csrc/pnn.hip) and
+    the D-way contraction (csrc/dense.hip, fp32 MFMA: both operand pairs, the bias and the ReLU in ONE
+    launch; pnn.py:139,146-181) are hand-written kernels, forward and backward."""
 
     @staticmethod
     def forward(ctx, anchor, emb_flat, linear_w: Variable, product_w: Variable, bias: Variable, F, K, method):
@@ -582,9 +583,8 @@ class _PnnProductFn(Function):
         _lib.check(lib.recalgo_pnn_features_fwd(_p(emb_flat), B, F, K, method, _p(phi), st), "recalgo_pnn_features_fwd")
         _lib.check(lib.recalgo_pnn_weights_fwd(_p(product_w.data), D, F, K, method, _p(omega), st),
                    "recalgo_pnn_weights_fwd")
-        y = torch.addmm(bias.data, emb_flat, linear_w.data)       # lz + bias        (pnn.py:139,178)
-        y.addmm_(phi, omega)                                       # + lp             (pnn.py:175)
-        torch.relu_(y)                                             # pnn.py:181
+        # lz + lp + bias, ReLU  (pnn.py:139,175,178,181)
+        y = dense_fwd(emb_flat, linear_w.data.reshape(-1, D), bias.data.reshape(-1), True, x2=phi, w2=omega)
         ctx.vars = (linear_w, product_w, bias)
         ctx.dims = (F, K, method)
         ctx.save_for_backward(emb_flat, phi, omega, y)
@@ -598,15 +598,13 @@ class _PnnProductFn(Function):
         B, D = y.shape
         lib = _lib_()
         st = _stream(emb_flat)
-        if mlp_width_supported(D):
-            gz = relu_bwd_bias_(g.contiguous(), y, bias.grad)         # ReLU mask + bias gradient, one pass
-        else:
-            gz = g * (y > 0)
-            torch.sum(gz, dim=0, out=bias.grad)
-        torch.mm(emb_flat.t(), gz, out=linear_w.grad)
-        d_emb = gz @ linear_w.data.t()
-        dphi = gz @ omega.t()
-        domega = phi.t() @ gz
+        g = g.contiguous()
+        # gz = g * [y > 0] is applied inside the kernels (never materialised)
+        dense_bwd_weights(emb_flat, g, y, linear_w.grad.view(-1, D), bias.grad.view(-1))
+        domega = torch.empty_like(omega)
+        dense_bwd_weights(phi, g, y, domega, None)
+        d_emb = dense_bwd_input(g, y, linear_w.data.reshape(-1, D))
+        dphi = dense_bwd_input(g, y, omega)
         _lib.check(lib.recalgo_pnn_features_bwd(_p(emb_flat), _p(dphi), B, F, K, method, _p(d_emb), 1, st),
                    "recalgo_pnn_features_bwd")
         _lib.check(lib.recalgo_pnn_weights_bwd(_p(product_w.data), _p(domega), D, F, K, method, _p(product_w.grad), st),
@@ -686,6 +684,77 @@ def field_pair_logit(store, emb_flat: torch.Tensor, r: Variable, F: int, K: int)
 # =============================================================================================
 # context-MLP glue (csrc/mlp.hip): dense backward epilogue, BatchNorm training
 # =============================================================================================
+def _mat(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda:
+        raise ValueError(f"{name}: expected a row-major fp32 device matrix, got {t.dtype} {tuple(t.shape)} strides {t.stride()}")
+    return t
+
+
+def dense_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu: bool,
+              x2: Optional[torch.Tensor] = None, w2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(x @ w (+ x2 @ w2) + bias) on the fp32 matrix cores (include/recalgo.h recalgo_dense_fwd)."""
+    x, w = _mat(x, "x"), _mat(w, "w")
+    M, K = x.shape
+    N = w.shape[1]
+    if w.shape[0] != K or w.stride(0) != N:
+        raise ValueError("dense_fwd: w must be a contiguous [K, N] matrix")
+    if x2 is not None:
+        x2, w2 = _mat(x2, "x2"), _mat(w2, "w2")
+        if w2.shape != (x2.shape[1], N) or w2.stride(0) != N or x2.shape[0] != M:
+            raise ValueError("dense_fwd: second operand pair does not match")
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    _lib.check(_lib_().recalgo_dense_fwd(
+        _p(x), x.stride(0), _p(w), K, _p(x2), 0 if x2 is None else x2.stride(0), _p(w2), 0 if x2 is None else x2.shape[1],
+        _p(bias), M, N, int(relu), _p(y), N, _stream(x)), "recalgo_dense_fwd")
+    return y
+
+
+def dense_bwd_input(g: torch.Tensor, y_mask: Optional[torch.Tensor], w: torch.Tensor, c_in: Optional[torch.Tensor] = None,
+                    beta: float = 0.0, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """dx = (g * [y_mask > 0]) @ w^T (+ beta * c_in); y_mask contiguous with g's layout (recalgo_dense_bwd_input)."""
+    g, w = _mat(g, "g"), _mat(w, "w")
+    M, N = g.shape
+    K = w.shape[0]
+    if w.shape[1] != N or w.stride(0) != N:
+        raise ValueError("dense_bwd_input: w must be a contiguous [K, N] matrix")
+    if y_mask is not None and (y_mask.shape != g.shape or y_mask.stride() != g.stride()):
+        raise ValueError("dense_bwd_input: y_mask must have g's layout")
+    dx = out if out is not None else torch.empty(M, K, device=g.device, dtype=torch.float32)
+    _lib.check(_lib_().recalgo_dense_bwd_input(
+        _p(g), g.stride(0), _p(y_mask), _p(w), M, N, K, _p(c_in), 0 if c_in is None else c_in.stride(0), float(beta),
+        _p(dx), dx.stride(0), int(accumulate), _stream(g)), "recalgo_dense_bwd_input")
+    return dx
+
+
+_dense_ws = {}
+
+
+def dense_bwd_weights(x: torch.Tensor, g: torch.Tensor, y_mask: Optional[torch.Tensor], dw: torch.Tensor,
+                      dbias: Optional[torch.Tensor]) -> None:
+    """dw = x^T (g * [y_mask > 0]), dbias = colsum(g * [y_mask > 0]) (recalgo_dense_bwd_weights; deterministic)."""
+    x, g = _mat(x, "x"), _mat(g, "g")
+    M, K = x.shape
+    N = g.shape[1]
+    if g.shape[0] != M or tuple(dw.shape) != (K, N) or not dw.is_contiguous():
+        raise ValueError("dense_bwd_weights: shape mismatch")
+    if y_mask is not None and (y_mask.shape != g.shape or y_mask.stride() != g.stride()):
+        raise ValueError("dense_bwd_weights: y_mask must have g's layout")
+    lib = _lib_()
+    if M == 0:
+        dw.zero_()
+        if dbias is not None:
+            dbias.zero_()
+        return
+    # own grow-only scratch (the shared one may be in use by a concurrent op of the same backward)
+    nbytes = int(lib.recalgo_dense_bwd_weights_workspace_bytes(M, K, N))
+    key = (x.device.type, x.device.index)
+    ws = _dense_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _dense_ws[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.recalgo_dense_bwd_weights(_p(x), x.stride(0), _p(g), g.stride(0), _p(y_mask), M, K, N, _p(dw), _p(dbias),
+                                             _p(ws), _stream(x)), "recalgo_dense_bwd_weights")
+
+
 def mlp_width_supported(C: int) -> bool:
     return bool(_lib_().recalgo_mlp_width_supported(int(C)))
 

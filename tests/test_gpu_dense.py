@@ -1,0 +1,95 @@
+"""-m gpu parity of the fp32-MFMA dense kernels (csrc/dense.hip: forward with fused bias + ReLU and an optional
+second operand pair; input gradient with the fused ReLU mask and beta * C term; weight gradient with the fused
+mask, bias gradient and deterministic split over the batch) against an fp64 restatement of
+tf.layers.dense / its autodiff, at the BASELINE MLP shapes (4096 x 416 -> 512 -> 256 -> 128) and at ragged /
+unaligned shapes (the reference's default DCN width 82; IPNN's 351 Gram features)."""
+import pytest
+import torch
+
+from recalgorithm_amd import ops
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(4096, 416, 512), (4096, 512, 256), (4096, 256, 128), (37, 82, 50), (130, 351, 1024), (1, 4, 4),
+          (300, 48, 8), (65, 33, 65), (512, 9600, 64)]
+
+
+def _ref_fwd(x, w, b, relu, x2=None, w2=None):
+    y = x.double() @ w.double()
+    if x2 is not None:
+        y = y + x2.double() @ w2.double()
+    if b is not None:
+        y = y + b.double()
+    return torch.relu(y) if relu else y
+
+
+@pytest.mark.parametrize("M,K,N", SHAPES)
+@pytest.mark.parametrize("relu,use_bias", [(True, True), (False, False)])
+def test_dense_fwd_bwd(dev, M, K, N, relu, use_bias):
+    gen = torch.Generator().manual_seed(M * 31 + K * 7 + N)
+    x = torch.randn(M, K, generator=gen)
+    w = torch.randn(K, N, generator=gen) / K ** 0.5
+    b = torch.randn(N, generator=gen) * 0.1 if use_bias else None
+    g = torch.randn(M, N, generator=gen)
+    xd, wd, gd = x.to(dev), w.to(dev), g.to(dev)
+    bd = None if b is None else b.to(dev)
+    y = ops.dense_fwd(xd, wd, bd, relu)
+    ref = _ref_fwd(x, w, b, relu)
+    assert_close(y, ref, what=f"dense fwd {M}x{K}x{N}", reduced=True)
+    # backward with the mask taken from the kernel's own forward output (what nn._DenseFn does)
+    mask = (y.cpu() > 0).double() if relu else torch.ones_like(ref)
+    g2 = g.double() * mask
+    dx = ops.dense_bwd_input(gd, y if relu else None, wd)
+    assert_close(dx, g2 @ w.double().t(), what="dense dgrad", reduced=True)
+    dw = torch.empty(K, N, device=dev)
+    db = torch.empty(N, device=dev) if use_bias else None
+    ops.dense_bwd_weights(xd, gd, y if relu else None, dw, db)
+    assert_close(dw, x.double().t() @ g2, what="dense wgrad", reduced=True)
+    if use_bias:
+        assert_close(db, g2.sum(0), what="dense dbias", reduced=True)
+    # deterministic: a second run is bit-identical (fixed-order split sum, no atomics)
+    dw2 = torch.empty_like(dw)
+    ops.dense_bwd_weights(xd, gd, y if relu else None, dw2, None)
+    assert torch.equal(dw, dw2)
+
+
+def test_dense_two_operand_pairs_and_beta_c(dev):
+    """The PNN form relu(x w + x2 w2 + b) (pnn.py:139-181) and the dgrad's fused beta * C term (DIN's
+    mini-batch-aware regulariser, din.py:254-257), accumulate mode."""
+    gen = torch.Generator().manual_seed(5)
+    M, K, K2, N = 700, 416, 351, 1024
+    x, x2 = torch.randn(M, K, generator=gen), torch.randn(M, K2, generator=gen)
+    w, w2 = torch.randn(K, N, generator=gen) / K ** 0.5, torch.randn(K2, N, generator=gen) / K2 ** 0.5
+    b = torch.randn(N, generator=gen)
+    y = ops.dense_fwd(x.to(dev), w.to(dev), b.to(dev), True, x2=x2.to(dev), w2=w2.to(dev))
+    assert_close(y, _ref_fwd(x, w, b, True, x2, w2), what="two-pair fwd", reduced=True)
+    g = torch.randn(M, N, generator=gen)
+    c = torch.randn(M, K, generator=gen)
+    dx = ops.dense_bwd_input(g.to(dev), None, w.to(dev), c_in=c.to(dev), beta=0.25)
+    assert_close(dx, g.double() @ w.double().t() + 0.25 * c.double(), what="dgrad + beta*C", reduced=True)
+    base = torch.randn(M, K, generator=gen)
+    out = base.to(dev).clone()
+    ops.dense_bwd_input(g.to(dev), None, w.to(dev), out=out, accumulate=True)
+    assert_close(out, base.double() + g.double() @ w.double().t(), what="dgrad accumulate", reduced=True)
+
+
+def test_dense_strided_views(dev):
+    """Row-strided operands (a column block of a wider activation matrix) are read in place."""
+    gen = torch.Generator().manual_seed(9)
+    big = torch.randn(260, 200, generator=gen).to(dev)
+    x = big[:, 40:168]                         # ld 200, base offset 160 B: aligned, vector path
+    xu = big[:, 41:169]                        # base offset 164 B: unaligned -> element loads
+    w = (torch.randn(128, 64, generator=gen) / 11).to(dev)
+    for v in (x, xu):
+        y = ops.dense_fwd(v, w, None, False)
+        assert_close(y, v.cpu().double() @ w.cpu().double(), what="strided fwd", reduced=True)
+
+
+def test_dense_matches_exact_fmaf_order(dev):
+    """v_mfma_f32_32x32x2_f32 is an exact k-ordered fmaf chain: integer-valued operands give exact results."""
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randint(-4, 5, (200, 96), generator=gen).float()
+    w = torch.randint(-4, 5, (96, 72), generator=gen).float()
+    y = ops.dense_fwd(x.to(dev), w.to(dev), None, False)
+    assert torch.equal(y.cpu(), x @ w)
