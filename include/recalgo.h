@@ -313,8 +313,12 @@ int recalgo_relu_bwd_bias(const float* g, const float* y, int rows, int C, float
  *   bwd_input    dx[M,K] (+)= (g (.) [y_mask > 0])[M,N] w[K,N]^T + beta * c_in[M,K]
  *                y_mask (the forward output, same layout as g) and c_in may be NULL; accumulate != 0 adds to dx
  *   bwd_weights  dw[K,N] = x[M,K]^T (g (.) [y_mask > 0]),  dbias[N] = column sums of the masked g (dbias may be NULL)
- *                split over M with a fixed-order second pass (deterministic);
- *                workspace: recalgo_dense_bwd_weights_workspace_bytes(M, K, N) (0 => may be NULL)
+ *                split over M, the split partials summed in split order by a second pass (deterministic);
+ *                workspace: recalgo_dense_bwd_weights_workspace_bytes(M, K, N) (0 => may be NULL), 16-byte aligned.
+ *                defer_reduce != 0 leaves the partials in the workspace: dw / dbias are valid only after
+ *                recalgo_dense_bwd_weights_reduce() has been called with this call's (M, K, N, workspace, dw, dbias)
+ *                — ONE launch then finishes all the layers of a backward pass (each deferred call needs its own
+ *                workspace until then).
  * The masked gradient g (.) [y > 0] is applied while tiles are staged and never materialised.
  * ------------------------------------------------------------------------------------------ */
 int recalgo_dense_fwd(const float* x, int ldx, const float* w, int K, const float* x2, int ldx2, const float* w2, int K2,
@@ -324,7 +328,15 @@ int recalgo_dense_bwd_input(const float* g, int ldg, const float* y_mask, const 
                             recalgo_stream_t stream);
 int64_t recalgo_dense_bwd_weights_workspace_bytes(int M, int K, int N);
 int recalgo_dense_bwd_weights(const float* x, int ldx, const float* g, int ldg, const float* y_mask, int M, int K, int N,
-                              float* dw, float* dbias, void* workspace, recalgo_stream_t stream);
+                              float* dw, float* dbias, void* workspace, int defer_reduce, recalgo_stream_t stream);
+typedef struct {
+    int M, K, N;
+    const void* workspace;
+    float* dw;
+    float* dbias;          /* may be NULL */
+} recalgo_dense_split_t;
+/* jobs: HOST array, read at launch time */
+int recalgo_dense_bwd_weights_reduce(const recalgo_dense_split_t* jobs, int n_jobs, recalgo_stream_t stream);
 /* tf.layers.batch_normalization(net, training=True) (algorithm/DeepFM/deepfm.py:210-211; PNN
  * pnn.py:190-191; FiBiNET fibinet.py:195-196; DIN din.py:233-234), [TF-ext A-8]:
  *   mean/var = batch moments (biased variance);  y = (x - mean) * rsqrt(var + eps) * gamma + beta

@@ -62,7 +62,8 @@ class _DenseFn(Function):
             if g2.stride(1) != 1 or (y is not None and g2.stride() != y.stride()):
                 g2 = g2.contiguous()
             # the ReLU mask rides on the staging of g in both kernels; the bias gradient on the weight-gradient one
-            ops.dense_bwd_weights(x2, g2, y if ctx.relu else None, kernel.grad, None if bias is None else bias.grad)
+            ops.dense_bwd_weights(x2, g2, y if ctx.relu else None, kernel.grad, None if bias is None else bias.grad,
+                                  defer=True)           # split partials are summed by ONE launch per backward pass
             dx = None
             if ctx.needs_input_grad[1]:
                 dx = ops.dense_bwd_input(g2, y if ctx.relu else None, kernel.data,
@@ -264,7 +265,11 @@ _PARKED = []
 
 
 def apply_parked_grads():
-    """grad += scale * g * w for every parked l2 term (called once per step, after backward)."""
+    """Finish the gradients that backward left parked (called once per step, after backward, by the optimizer and by
+    `variables.named_grads`): the deferred weight-gradient split sums of `dense` (ops.flush_dense_splits), then
+    grad += scale * g * w for every parked l2 term."""
+    from . import ops
+    ops.flush_dense_splits()
     while _PARKED:
         v, scale, g = _PARKED.pop()
         v.grad.add_(v.data * (scale * g))

@@ -46,16 +46,13 @@ def _chk(t: torch.Tensor, dtype, name: str):
 _ws_cache = {}
 
 
-_rb1_cache = {}
-
-
 def arena_row_base(arena, table_name: str, device) -> torch.Tensor:
-    """int64 [1] device tensor holding the first arena row of `table_name` (cached)."""
-    key = (id(arena), table_name)
-    t = _rb1_cache.get(key)
-    if t is None:
-        t = torch.tensor([arena.tables[table_name][0]], dtype=torch.int64, device=device)
-        _rb1_cache[key] = t
+    """int64 [1] device tensor holding the first arena row of `table_name`.  Cached ON the arena object: a
+    module-level cache keyed by id(arena) hands a dead arena's row bases to a new arena that re-uses its address."""
+    cache = arena.__dict__.setdefault("_row_base_1", {})
+    t = cache.get(table_name)
+    if t is None or t.device != torch.device(device):
+        t = cache[table_name] = torch.tensor([arena.tables[table_name][0]], dtype=torch.int64, device=device)
     return t
 
 
@@ -600,7 +597,7 @@ class _PnnProductFn(Function):
         st = _stream(emb_flat)
         g = g.contiguous()
         # gz = g * [y > 0] is applied inside the kernels (never materialised)
-        dense_bwd_weights(emb_flat, g, y, linear_w.grad.view(-1, D), bias.grad.view(-1))
+        dense_bwd_weights(emb_flat, g, y, linear_w.grad.view(-1, D), bias.grad.view(-1), defer=True)
         domega = torch.empty_like(omega)
         dense_bwd_weights(phi, g, y, domega, None)
         d_emb = dense_bwd_input(g, y, linear_w.data.reshape(-1, D))
@@ -727,11 +724,19 @@ def dense_bwd_input(g: torch.Tensor, y_mask: Optional[torch.Tensor], w: torch.Te
 
 
 _dense_ws = {}
+_dense_pending = []          # deferred split reductions of this backward pass: (M, K, N, ws, dw, dbias)
+
+
+class _DenseSplit(ctypes.Structure):          # include/recalgo.h recalgo_dense_split_t
+    _fields_ = [("M", ctypes.c_int), ("K", ctypes.c_int), ("N", ctypes.c_int), ("workspace", ctypes.c_void_p),
+                ("dw", ctypes.c_void_p), ("dbias", ctypes.c_void_p)]
 
 
 def dense_bwd_weights(x: torch.Tensor, g: torch.Tensor, y_mask: Optional[torch.Tensor], dw: torch.Tensor,
-                      dbias: Optional[torch.Tensor]) -> None:
-    """dw = x^T (g * [y_mask > 0]), dbias = colsum(g * [y_mask > 0]) (recalgo_dense_bwd_weights; deterministic)."""
+                      dbias: Optional[torch.Tensor], defer: bool = False) -> None:
+    """dw = x^T (g * [y_mask > 0]), dbias = colsum(g * [y_mask > 0]) (recalgo_dense_bwd_weights; deterministic).
+    `defer`: the fixed-order sum of the batch-split partials is left to `flush_dense_splits()` (one launch for all
+    the layers of a backward pass; the optimizer and `named_grads` call it) — dw / dbias are valid only after it."""
     x, g = _mat(x, "x"), _mat(g, "g")
     M, K = x.shape
     N = g.shape[1]
@@ -745,14 +750,29 @@ def dense_bwd_weights(x: torch.Tensor, g: torch.Tensor, y_mask: Optional[torch.T
         if dbias is not None:
             dbias.zero_()
         return
-    # own grow-only scratch (the shared one may be in use by a concurrent op of the same backward)
+    # own scratch per weight tensor: a deferred reduction reads it after later layers have run
     nbytes = int(lib.recalgo_dense_bwd_weights_workspace_bytes(M, K, N))
-    key = (x.device.type, x.device.index)
+    key = (x.device.type, x.device.index, M, K, N, dw.data_ptr() if defer else 0)
     ws = _dense_ws.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = _dense_ws[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=x.device)
+    if ws is None:
+        ws = _dense_ws[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    defer = bool(defer and nbytes > 0)
     _lib.check(lib.recalgo_dense_bwd_weights(_p(x), x.stride(0), _p(g), g.stride(0), _p(y_mask), M, K, N, _p(dw), _p(dbias),
-                                             _p(ws), _stream(x)), "recalgo_dense_bwd_weights")
+                                             _p(ws), int(defer), _stream(x)), "recalgo_dense_bwd_weights")
+    if defer:
+        _dense_pending.append((M, K, N, ws, dw, dbias))
+
+
+def flush_dense_splits() -> None:
+    """Finish every deferred weight-gradient split reduction (one launch per 8 layers)."""
+    if not _dense_pending:
+        return
+    jobs = (_DenseSplit * len(_dense_pending))()
+    for i, (M, K, N, ws, dw, dbias) in enumerate(_dense_pending):
+        jobs[i] = _DenseSplit(M, K, N, ws.data_ptr(), dw.data_ptr(), 0 if dbias is None else dbias.data_ptr())
+    dev_t = _dense_pending[0][4]
+    _dense_pending.clear()
+    _lib.check(_lib_().recalgo_dense_bwd_weights_reduce(jobs, len(jobs), _stream(dev_t)), "recalgo_dense_bwd_weights_reduce")
 
 
 def mlp_width_supported(C: int) -> bool:

@@ -93,3 +93,25 @@ def test_dense_matches_exact_fmaf_order(dev):
     w = torch.randint(-4, 5, (96, 72), generator=gen).float()
     y = ops.dense_fwd(x.to(dev), w.to(dev), None, False)
     assert torch.equal(y.cpu(), x @ w)
+
+
+@pytest.mark.parametrize("M,K,N", [(4096, 416, 512), (4096, 256, 128), (2048, 100, 36)])
+def test_dense_wgrad_split_handoff_stress(dev, M, K, N):
+    """The split partials of the weight gradient are summed by the last-arriving workgroup of each tile (agent-scope
+    release / ticket / acquire).  Re-using ONE workspace over many launches with fresh data makes every consumer
+    read lines it has cached from earlier launches: a missing release or acquire shows up as a stale partial, i.e.
+    an O(1) relative error.  Also: bit-identical to itself (fixed summation order, whoever arrives last)."""
+    gen = torch.Generator(device=dev).manual_seed(123)
+    dw, db = torch.empty(K, N, device=dev), torch.empty(N, device=dev)
+    dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
+    for it in range(25):
+        x = torch.randn(M, K, device=dev, generator=gen)
+        g = torch.randn(M, N, device=dev, generator=gen)
+        y = torch.randn(M, N, device=dev, generator=gen)
+        ops.dense_bwd_weights(x, g, y, dw, db)
+        ops.dense_bwd_weights(x, g, y, dw2, db2)
+        g2 = (g * (y > 0)).double()
+        ref = x.double().t() @ g2
+        assert_close(dw, ref, what=f"wgrad launch {it}", reduced=True)
+        assert_close(db, g2.sum(0), what=f"dbias launch {it}", reduced=True)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)
