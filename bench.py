@@ -205,7 +205,7 @@ def kernel_rooflines(args, est, feats, device):
 
     add("gather_fwd", lambda: lib.recalgo_embedding_gather_fwd(p(ids), p(ar.weight), p(rb), B, F, K, p(x0), d, 0, st),
         B * (F * 8 + 2 * d * 4))
-    add("gather_bwd", lambda: lib.recalgo_embedding_gather_bwd(p(ids), p(g), p(rb), B, F, K, d, 0, p(ar.grad), st),
+    add("gather_bwd", lambda: lib.recalgo_embedding_gather_bwd(p(ids), p(g), p(rb), B, F, K, d, 0, p(ar.grad), None, st),
         B * (F * 8 + 2 * d * 4))
     ar.grad.zero_()
     if args.model == "dcn":
@@ -246,7 +246,7 @@ def kernel_rooflines(args, est, feats, device):
                                                                       p(emb), p(fm1), p(fm2), p(fs), st),
             B * (F * 8 + F * K * 4 + F * 4 + F * K * 4 + 8))                       # 3648 B/example
         add("deepfm_sparse_bwd", lambda: lib.recalgo_deepfm_sparse_bwd(p(ids), p(emb), p(fs), p(g), p(g1), p(g2), p(rb), B, F, K,
-                                                                      p(ar.grad), p(w1.grad), st),
+                                                                      p(ar.grad), p(w1.grad), None, None, st),
             B * (F * K * 4 + 8 + F * K * 4 + F * 8 + F * K * 4 + F * 4))           # 5312 B/example
         ar.grad.zero_(); w1.grad.zero_()
     if args.model == "din":
@@ -274,7 +274,7 @@ def kernel_rooflines(args, est, feats, device):
         so, sl = torch.empty(B, T, H, device=device), torch.empty(B, dtype=torch.int32, device=device)
         add("sequence_gather_fwd", lambda: lib.recalgo_sequence_gather_fwd(p(vals), p(offs), p(ar.weight), B, T, H, p(so), p(sl), st),
             B * T * (8 + 2 * H * 4))
-        add("sequence_gather_bwd", lambda: lib.recalgo_sequence_gather_bwd(p(vals), p(offs), p(so), B, T, H, p(ar.grad), st),
+        add("sequence_gather_bwd", lambda: lib.recalgo_sequence_gather_bwd(p(vals), p(offs), p(so), B, T, H, p(ar.grad), None, st),
             B * T * (8 + 2 * H * 4))
         ar.grad.zero_()
     if args.model == "fibinet":

@@ -55,12 +55,24 @@ int recalgo_embedding_gather_fwd(const int64_t* ids, const float* arena, const i
                                  int B, int F, int K, float* out, int out_stride, int out_col,
                                  recalgo_stream_t stream);
 
+/* Live-row bookkeeping of the arena a backward kernel scatters into (optional last argument of the four
+ * scatter kernels; NULL or row_live == NULL: none).  Every distinct row a workgroup flushes is test-and-set in
+ * row_live (one byte per ARENA row, 4-byte aligned, padded to a multiple of 4) and, on first touch, appended to
+ * live_list[live_count[0]++] — exactly what a separate recalgo_mark_live_rows pass over the lookup's ids would
+ * do, without that pass.  row_offset = arena row of row 0 of the table the kernel's ids index. */
+typedef struct {
+    unsigned char* row_live;
+    int* live_list;
+    int* live_count;
+    int64_t row_offset;
+} recalgo_live_t;
+
 /* Backward of K1 (TF autodiff of the lookup; SURVEY.md Appendix D "Gather"):
  *   grad_arena[row_base[f] + ids[b,f], :] += g[b, out_col + f*K : +K]   for ids[b,f] >= 0
  * Duplicate ids accumulate (fp32 hardware atomics; order-nondeterministic in the last ulp). */
 int recalgo_embedding_gather_bwd(const int64_t* ids, const float* g, const int64_t* row_base,
                                  int B, int F, int K, int g_stride, int g_col, float* grad_arena,
-                                 recalgo_stream_t stream);
+                                 const recalgo_live_t* live, recalgo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K1m  multi-valued field with combiner='mean' (CSR bags).
@@ -75,7 +87,7 @@ int recalgo_embedding_bag_mean_fwd(const int64_t* values, const int64_t* offsets
                                    recalgo_stream_t stream);
 int recalgo_embedding_bag_mean_bwd(const int64_t* values, const int64_t* offsets, const float* g,
                                    int B, int K, int g_stride, int g_col, float* grad_table,
-                                   recalgo_stream_t stream);
+                                   const recalgo_live_t* live, recalgo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K1s  sequence gather (zero padded) for DIN.
@@ -87,7 +99,8 @@ int recalgo_sequence_gather_fwd(const int64_t* values, const int64_t* offsets, c
                                 int B, int T, int K, float* out, int32_t* seq_len,
                                 recalgo_stream_t stream);
 int recalgo_sequence_gather_bwd(const int64_t* values, const int64_t* offsets, const float* g,
-                                int B, int T, int K, float* grad_table, recalgo_stream_t stream);
+                                int B, int T, int K, float* grad_table, const recalgo_live_t* live,
+                                recalgo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K1+K2+K3  DeepFM sparse path, fused: gather + FM first order + FM second order + deep_input.
@@ -112,7 +125,8 @@ int recalgo_deepfm_sparse_fwd(const int64_t* ids, const float* arena, const floa
 int recalgo_deepfm_sparse_bwd(const int64_t* ids, const float* emb, const float* field_sum,
                               const float* g_emb, const float* g_fm1, const float* g_fm2,
                               const int64_t* row_base, int B, int F, int K, float* grad_arena,
-                              float* grad_w1, recalgo_stream_t stream);
+                              float* grad_w1, const recalgo_live_t* live, const recalgo_live_t* live_w1,
+                              recalgo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K4  DCN CrossNet, L layers fused.
@@ -335,8 +349,21 @@ typedef struct {
     float* dw;
     float* dbias;          /* may be NULL */
 } recalgo_dense_split_t;
-/* jobs: HOST array, read at launch time */
-int recalgo_dense_bwd_weights_reduce(const recalgo_dense_split_t* jobs, int n_jobs, recalgo_stream_t stream);
+/* Plain fixed-order column sums of partial rows that a kernel of the step left behind (the loss tail's
+ * recalgo_logit_loss_fwd_bwd): out[i] = sum_{r < rows} partials[r * row_stride + i], i < n. */
+typedef struct {
+    const float* partials;
+    float* out;
+    int rows;
+    int64_t row_stride;
+    int64_t n;
+} recalgo_colsum_t;
+/* jobs, sums: HOST arrays, read at launch time.  step_dev (may be NULL): the optimizer's int64 step counter; the launch
+ * advances it by one (this launch runs once per training step, right before recalgo_adam_tf1_step with
+ * advance = 0, which then only reads it — no separate counter launch, no in-kernel race).  With n_jobs == 0 and
+ * step_dev != NULL a one-workgroup launch still advances the counter. */
+int recalgo_dense_bwd_weights_reduce(const recalgo_dense_split_t* jobs, int n_jobs, const recalgo_colsum_t* sums,
+                                     int n_sums, int64_t* step_dev, recalgo_stream_t stream);
 /* tf.layers.batch_normalization(net, training=True) (algorithm/DeepFM/deepfm.py:210-211; PNN
  * pnn.py:190-191; FiBiNET fibinet.py:195-196; DIN din.py:233-234), [TF-ext A-8]:
  *   mean/var = batch moments (biased variance);  y = (x - mean) * rsqrt(var + eps) * gamma + beta
@@ -362,6 +389,24 @@ int recalgo_batchnorm_train_bwd(const float* x, const float* gamma, const float*
  * ------------------------------------------------------------------------------------------ */
 int recalgo_sigmoid_ce_fwd_bwd(const float* logits, const float* labels, int B, float grad_scale,
                                float* prob, float* loss, float* dlogit, recalgo_stream_t stream);
+
+/* The whole logit / loss tail of a TRAIN step in ONE launch (replaces recalgo_dense1_fwd + recalgo_sigmoid_ce_fwd_bwd +
+ * recalgo_dense1_bwd when the loss-gradient seed `grad_scale` is known before the forward):
+ *   logit[b] = sum_p <x_p[b, :], w_p> + bias + addend0[b] + addend1[b]      (1..4 parts, each with ITS OWN weight
+ *              vector: tf.layers.dense(concat, 1) or a sum of one-unit heads, xdeepfm.py:163,175,182,184;
+ *              addends: DeepFM's FM first / second order logits, deepfm.py:214)
+ *   prob, mean sigmoid-CE as recalgo_sigmoid_ce_fwd_bwd;  dlogit[b] = d loss / d logit * grad_scale
+ *   dx_p[b, :] = dlogit[b] * w_p          (dx_parts[p] may be NULL)
+ *   partials [recalgo_logit_loss_partial_rows(B)][C + 2], C = sum of widths: per-workgroup partial sums of
+ *   [dw over the C concatenated columns | d bias | loss]; their fixed-order column sums (recalgo_colsum_t jobs of
+ *   recalgo_dense_bwd_weights_reduce) are dw_p, d bias and the loss value.  bias, addend0/1 may be NULL.
+ *   loss_addend (device scalar, may be NULL) is added to the loss VALUE (a regulariser term whose gradient is
+ *   handled elsewhere: DIN's mini-batch-aware regularisation, din.py:254-257). */
+int64_t recalgo_logit_loss_partial_rows(int B);
+int recalgo_logit_loss_fwd_bwd(const float* const* x_parts, const float* const* w_parts, const int* widths, int n_parts,
+                               const float* bias, const float* addend0, const float* addend1, const float* labels,
+                               const float* loss_addend, int B, float grad_scale, float* logit, float* prob, float* dlogit,
+                               float* const* dx_parts, float* partials, recalgo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * a15  TF1 AdamOptimizer, dense semantics (also what TF1 applies to embedding IndexedSlices:
@@ -397,6 +442,26 @@ int recalgo_mark_live_rows(const int64_t* ids, const int64_t* row_base, int64_t 
 int recalgo_adam_tf1_list(float* p, float* g, float* m, float* v, const int* live_list,
                           const int* live_count, int64_t max_rows, int K, float lr_t, const float* lr_t_dev,
                           float beta1, float beta2, float eps, int zero_grad, recalgo_stream_t stream);
+/* One launch per optimizer step (replaces recalgo_adam_tf1_advance + recalgo_adam_tf1_dense + one
+ * recalgo_adam_tf1_list per arena): lr_t = lr*sqrt(1-b2^t)/(1-b1^t) (double precision, on the device, per
+ * workgroup), the dense TF1 update of the flat buffer p/g/m/v [n] (n may be 0) and of the live rows of up to 4
+ * arenas.  Same arithmetic as the separate entry points (bit-identical results).
+ *   advance == 0: t = step_dev[0] (already advanced for this step, e.g. by recalgo_dense_bwd_weights_reduce);
+ *                 ticket_dev unused (may be NULL)
+ *   advance != 0: t = step_dev[0] + 1 and the last workgroup to finish stores step_dev[0] = t (arrival ticket
+ *                 ticket_dev: one int, zero before the first call, left zero by every call; one atomic per
+ *                 workgroup on one address — ~12 ns each, use advance == 0 inside a training step)
+ * arenas: HOST array, read at launch time.  hipGraph replayable. */
+typedef struct {
+    float* p; float* g; float* m; float* v;      /* [rows, K] */
+    const int* live_list;
+    const int* live_count;
+    int64_t max_rows;
+    int K;
+} recalgo_adam_arena_t;
+int recalgo_adam_tf1_step(float* p, float* g, float* m, float* v, int64_t n, const recalgo_adam_arena_t* arenas,
+                          int n_arenas, int64_t* step_dev, int* ticket_dev, int advance, float lr, float beta1,
+                          float beta2, float eps, int zero_grad, recalgo_stream_t stream);
 /* Housekeeping for the live-row list: rebuild live_list in ascending row order from the liveness
  * bytes (same set, live_count rewritten with the same total).  recalgo_mark_live_rows appends rows in
  * first-touch order; an address-ordered list lets recalgo_adam_tf1_list walk HBM monotonically.  Run

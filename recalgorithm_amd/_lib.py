@@ -19,13 +19,13 @@ SIGNATURES = {
     "recalgo_abi_version": (c_int, []),
     "recalgo_target_arch": (c_char_p, []),
     "recalgo_embedding_gather_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P, c_int, c_int, P]),
-    "recalgo_embedding_gather_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "recalgo_embedding_gather_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "recalgo_embedding_bag_mean_fwd": (c_int, [P, P, P, c_int, c_int, P, c_int, c_int, P]),
-    "recalgo_embedding_bag_mean_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "recalgo_embedding_bag_mean_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "recalgo_sequence_gather_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P]),
-    "recalgo_sequence_gather_bwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
+    "recalgo_sequence_gather_bwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P]),
     "recalgo_deepfm_sparse_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P]),
-    "recalgo_deepfm_sparse_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, P, P, P]),
+    "recalgo_deepfm_sparse_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P]),
     "recalgo_cross_fwd": (c_int, [P, c_int, P, P, c_int, c_int, c_int, P, c_int, P]),
     "recalgo_cross_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "recalgo_cross_bwd": (c_int, [P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, P, P, P, P, P]),
@@ -65,6 +65,7 @@ SIGNATURES = {
     "recalgo_order_live_list": (c_int, [P, c_int64, P, P, P, P]),
     "recalgo_exchange_plan": (c_int, [P, c_int64, c_int, c_int64, P, P, P, P, P, P]),
     "recalgo_adam_tf1_list": (c_int, [P, P, P, P, P, P, c_int64, c_int, c_float, P, c_float, c_float, c_float, c_int, P]),
+    "recalgo_adam_tf1_step": (c_int, [P, P, P, P, c_int64, P, c_int, P, P, c_int, c_float, c_float, c_float, c_float, c_int, P]),
     "recalgo_adam_tf1_advance": (c_int, [P, c_float, c_float, c_float, P, P]),
     "recalgo_cross_layer_fwd": (c_int, [P, P, c_int, P, P, c_int, c_int, P, c_int, P]),
     "recalgo_cross_layer_bwd": (c_int, [P, P, c_int, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P]),
@@ -72,7 +73,9 @@ SIGNATURES = {
     "recalgo_dense_bwd_input": (c_int, [P, c_int, P, P, c_int, c_int, c_int, P, c_int, c_float, P, c_int, c_int, P]),
     "recalgo_dense_bwd_weights_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "recalgo_dense_bwd_weights": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, P, P, P, c_int, P]),
-    "recalgo_dense_bwd_weights_reduce": (c_int, [P, c_int, P]),
+    "recalgo_dense_bwd_weights_reduce": (c_int, [P, c_int, P, c_int, P, P]),
+    "recalgo_logit_loss_partial_rows": (c_int64, [c_int]),
+    "recalgo_logit_loss_fwd_bwd": (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, P, P, P, P, P]),
     "recalgo_activation_fwd": (c_int, [P, P, c_int, c_int, c_int, P, P]),
     "recalgo_activation_bwd_workspace_bytes": (c_int64, [c_int, c_int]),
     "recalgo_activation_bwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, P]),

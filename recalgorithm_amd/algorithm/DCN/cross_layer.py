@@ -32,8 +32,9 @@ def cross_layer(x0: torch.Tensor, xl: torch.Tensor, index: int) -> torch.Tensor:
     return ops.cross_layer(store, x0.contiguous(), xl.contiguous(), wl, bl)
 
 
-def cross_network(x0: torch.Tensor, num_cross_layer: int) -> torch.Tensor:
-    """x_{l+1} = cross_layer(x0, x_l, l) for l = 0..L-1 (dcn.py:157-160), fused."""
+def cross_network(x0: torch.Tensor, num_cross_layer: int, grad_join=None) -> torch.Tensor:
+    """x_{l+1} = cross_layer(x0, x_l, l) for l = 0..L-1 (dcn.py:157-160), fused.  `grad_join` (nn.GradJoin): shared with
+    the other consumer of x0 so that the two input gradients are summed inside the backward kernel."""
     store = current_store()
     d = int(x0.shape[-1])
     L = int(num_cross_layer)
@@ -42,8 +43,10 @@ def cross_network(x0: torch.Tensor, num_cross_layer: int) -> torch.Tensor:
     w, _ = store.get_variable_block("wl", [f"wl_{i}" for i in range(L)], (d, 1))
     b, _ = store.get_variable_block("bl", [f"bl_{i}" for i in range(L)], (d, 1))
     if L > 6 or d > 1024:        # outside the fused kernel's envelope: layer by layer
+        if grad_join is not None:
+            grad_join.consumer_done = True        # no fused consumer: the other branch returns its gradient normally
         xl = x0
         for i in range(L):
             xl = cross_layer(x0, xl, i)
         return xl
-    return ops.cross_stack(store, x0.contiguous(), w, b)
+    return ops.cross_stack(store, x0.contiguous(), w, b, grad_join)

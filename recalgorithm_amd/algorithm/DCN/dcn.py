@@ -90,13 +90,15 @@ def dcn_model_fn(features, labels, mode, params):
         category_input = fc.input_layer(features, params["category_feature_columns"])
     concat_all = category_input if dense_input is None else torch.cat([dense_input, category_input], dim=-1)
 
+    # concat_all feeds both branches: their two input gradients are summed inside cross_bwd (nn.GradJoin)
+    join = nn.GradJoin() if int(params["num_cross_layer"]) > 0 and len(params["hidden_units"]) > 0 else None
     with variable_scope("cross_part"):
-        cross_vec = cross_network(concat_all, params["num_cross_layer"])
+        cross_vec = cross_network(concat_all, params["num_cross_layer"], grad_join=join)
 
     with variable_scope("dnn_part"):
         dnn_vec = concat_all
         for i, unit in enumerate(params["hidden_units"]):
-            dnn_vec = nn.dense(dnn_vec, unit, activation="relu", name=f"dnn_dense_{i}")
+            dnn_vec = nn.dense(dnn_vec, unit, activation="relu", name=f"dnn_dense_{i}", grad_join=join if i == 0 else None)
 
     with variable_scope("output_part"):
         output = nn.concat([cross_vec, dnn_vec], axis=-1)       # read in place by the one-unit head (nn.LazyConcat)

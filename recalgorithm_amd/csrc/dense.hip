@@ -425,27 +425,49 @@ __global__ __launch_bounds__(kThreads) void dense_wgrad_kernel(WgradArgs P) {
 // (Tried instead: letting the last-arriving workgroup of each tile do the sum inside the wgrad kernel, with the
 // agent-scope release / ticket / acquire hand-off — correct, but the per-workgroup L2 write-back made the
 // [4096 x 256 x 128] wgrad 56 us instead of 18 + 7; the partials of one launch stay cheap only across a kernel boundary.)
-constexpr int kMaxSplitJobs = 8;
+constexpr int kMaxSplitJobs = 16;
 struct SplitJob {
     const float* partials;
     float* out0;
     float* out1;
     unsigned long long slab, n0, n;
-    int S, vec;
+    int S, vec;                // vec: 1 float4 per thread, 0 one float per thread, 2 "tall" (S >> n): 16 columns x 16 row
+                               //      groups per workgroup (a thread walking hundreds of partial rows alone is latency bound)
     unsigned first_block;      // blocks [first_block, next job's first_block) belong to this job
 };
 struct SplitJobs {
     SplitJob job[kMaxSplitJobs];
     int n_jobs;
+    long long* step;           // optional: the optimizer's step counter, advanced by this launch (it runs once per
+                               // step, right before recalgo_adam_tf1_step, which then only READS the counter)
 };
 
 __global__ __launch_bounds__(256) void dense_sum_slabs_kernel(SplitJobs J) {
+    if (J.step != nullptr && blockIdx.x == 0 && threadIdx.x == 0) J.step[0] += 1;
+    if (J.n_jobs == 0) return;
     int j = 0;
 #pragma unroll
     for (int k = 1; k < kMaxSplitJobs; ++k)
         if (k < J.n_jobs && blockIdx.x >= J.job[k].first_block) j = k;
     const SplitJob& jb = J.job[j];
     const size_t t = (size_t)(blockIdx.x - jb.first_block) * 256 + threadIdx.x;
+    if (jb.vec == 2) {
+        __shared__ float sh[16][17];
+        const unsigned cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+        const size_t c = (size_t)(blockIdx.x - jb.first_block) * 16 + cl;
+        float acc = 0.f;
+        if (c < jb.n)
+            for (int r = rg; r < jb.S; r += 16) acc += jb.partials[(size_t)r * jb.slab + c];
+        sh[rg][cl] = acc;
+        __syncthreads();
+        if (rg == 0 && c < jb.n) {
+            float tt = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) tt += sh[g][cl];
+            jb.out0[c] = tt;
+        }
+        return;
+    }
     if (jb.vec) {
         const size_t i = t * 4;
         if (i >= jb.n) return;
@@ -534,8 +556,8 @@ RECALGO_EXPORT int64_t recalgo_dense_bwd_weights_workspace_bytes(int M, int K, i
 }
 
 static int launch_split_jobs(const SplitJobs& J, unsigned blocks, hipStream_t st) {
-    if (J.n_jobs == 0) return 0;
-    hipLaunchKernelGGL(dense_sum_slabs_kernel, dim3(blocks), dim3(256), 0, st, J);
+    if (J.n_jobs == 0 && J.step == nullptr) return 0;
+    hipLaunchKernelGGL(dense_sum_slabs_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, st, J);
     return (int)hipGetLastError();
 }
 
@@ -581,17 +603,39 @@ RECALGO_EXPORT int recalgo_dense_bwd_weights(const float* x, int ldx, const floa
         unsigned blocks = 0;
         J.job[0] = make_split_job(static_cast<const float*>(workspace), S, K, N, dw, dbias, 0, &blocks);
         J.n_jobs = 1;
+        J.step = nullptr;
         return launch_split_jobs(J, blocks, st);
     }
     RECALGO_RETURN_LAST();
 }
 
-RECALGO_EXPORT int recalgo_dense_bwd_weights_reduce(const recalgo_dense_split_t* jobs, int n_jobs, recalgo_stream_t stream) {
-    RECALGO_REQUIRE(n_jobs >= 0 && (n_jobs == 0 || jobs != nullptr));
+RECALGO_EXPORT int recalgo_dense_bwd_weights_reduce(const recalgo_dense_split_t* jobs, int n_jobs,
+                                                    const recalgo_colsum_t* sums, int n_sums, int64_t* step_dev,
+                                                    recalgo_stream_t stream) {
+    RECALGO_REQUIRE(n_jobs >= 0 && (n_jobs == 0 || jobs != nullptr) && n_sums >= 0 && (n_sums == 0 || sums != nullptr));
     hipStream_t st = as_stream(stream);
     SplitJobs J;
     J.n_jobs = 0;
+    J.step = reinterpret_cast<long long*>(step_dev);
     unsigned blocks = 0;
+    for (int i = 0; i < n_sums; ++i) {                       // plain column sums of partial rows (the loss tail's)
+        const recalgo_colsum_t& c = sums[i];
+        RECALGO_REQUIRE(c.partials != nullptr && c.out != nullptr && c.rows >= 1 && c.n >= 1 && c.row_stride >= c.n);
+        SplitJob jb;
+        jb.partials = c.partials; jb.out0 = c.out; jb.out1 = nullptr; jb.S = c.rows;
+        jb.slab = (unsigned long long)c.row_stride; jb.n0 = jb.n = (unsigned long long)c.n;
+        jb.vec = 2;
+        jb.first_block = blocks;
+        blocks += (unsigned)cdiv((int64_t)jb.n, 16);
+        J.job[J.n_jobs++] = jb;
+        if (J.n_jobs == kMaxSplitJobs) {
+            int rc = launch_split_jobs(J, blocks, st);
+            if (rc) return rc;
+            J.n_jobs = 0;
+            J.step = nullptr;
+            blocks = 0;
+        }
+    }
     for (int i = 0; i < n_jobs; ++i) {
         const recalgo_dense_split_t& d = jobs[i];
         RECALGO_REQUIRE(d.M > 0 && d.K > 0 && d.N > 0 && d.dw != nullptr);
@@ -605,6 +649,7 @@ RECALGO_EXPORT int recalgo_dense_bwd_weights_reduce(const recalgo_dense_split_t*
             int rc = launch_split_jobs(J, blocks, st);
             if (rc) return rc;
             J.n_jobs = 0;
+            J.step = nullptr;
             blocks = 0;
         }
     }

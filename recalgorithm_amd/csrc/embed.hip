@@ -40,15 +40,20 @@ struct Agg {
     float* acc;                 // [slots][W]   (W = row width, + 1 for the fused w1 gradient)
     unsigned W;
     unsigned slots;
+    int* new_rows;              // [slots] rows this workgroup touched first (live-row bookkeeping)
+    unsigned* new_cnt;          // [2]: number of entries in new_rows, base index reserved in the arena's list
 };
 __device__ __forceinline__ Agg agg_carve(unsigned char* smem, unsigned W, unsigned slots) {
+    unsigned char* after = smem + slots * (sizeof(unsigned long long) + (size_t)W * sizeof(float));
     return Agg{reinterpret_cast<unsigned long long*>(smem),
-               reinterpret_cast<float*>(smem + slots * sizeof(unsigned long long)), W, slots};
+               reinterpret_cast<float*>(smem + slots * sizeof(unsigned long long)), W, slots,
+               reinterpret_cast<int*>(after), reinterpret_cast<unsigned*>(after + slots * sizeof(int))};
 }
 
 __device__ __forceinline__ void agg_init(const Agg& a) {
     for (unsigned i = threadIdx.x; i < a.slots; i += blockDim.x) a.keys[i] = kEmpty;
     for (unsigned i = threadIdx.x; i < a.slots * a.W; i += blockDim.x) a.acc[i] = 0.f;
+    if (threadIdx.x < 2) a.new_cnt[threadIdx.x] = 0;
 }
 
 // returns the slot of `row`, or a.slots if the probe sequence is exhausted
@@ -71,10 +76,31 @@ __device__ __forceinline__ void lds_add(float* p, float v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// Live-row bookkeeping of the arena the gradient is scattered into (include/recalgo.h recalgo_live_t): the
+// first workgroup to flush a row sets its liveness byte (test-and-set on the aligned word) and appends the row to
+// the arena's live list — the flush has the distinct row in hand, so the separate recalgo_mark_live_rows pass
+// over all B*F ids (14 us in the DCN step, as much as the scatter itself) is not needed.
+struct Live {
+    unsigned* words;          // liveness bytes as aligned 32-bit words; nullptr: no bookkeeping
+    int* list;
+    int* count;
+    long long row_offset;     // arena row of row 0 of the table the kernel scatters into
+};
+__device__ __forceinline__ void live_mark(const Live& L, unsigned long long row) {
+    if (L.words == nullptr) return;
+    row += (unsigned long long)L.row_offset;
+    const unsigned bit = 1u << (8 * (unsigned)(row & 3));
+    unsigned* w = L.words + (row >> 2);
+    if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) return;      // common case: already live
+    const unsigned old = atomicOr(w, bit);
+    if (!(old & bit)) L.list[atomicAdd(L.count, 1)] = (int)row;
+}
+
 template <int VEC>
 __device__ __forceinline__ void agg_add(const Agg& a, unsigned long long row, unsigned chunk,
-                                        typename VecT<VEC>::type v, float* __restrict__ gdst_row) {
+                                        typename VecT<VEC>::type v, float* __restrict__ gdst_row, const Live& live) {
     unsigned s = agg_slot(a, row);
+    if (s >= a.slots && chunk == 0) live_mark(live, row);     // probe sequence exhausted: this row bypasses the flush
     if constexpr (VEC == 4) {
         if (s < a.slots) {
             float* p = a.acc + s * a.W + chunk * 4;
@@ -90,10 +116,38 @@ __device__ __forceinline__ void agg_add(const Agg& a, unsigned long long row, un
     }
 }
 
+// Live-row bookkeeping for the distinct rows of this workgroup: test-and-set the liveness byte of every row; rows
+// touched for the first time are collected in LDS and appended to the arena's list with ONE global atomic per
+// workgroup (a global atomic per new row serialises ~1e5 adds on one counter while the model is still meeting new
+// rows: gather_bwd 18 -> 60-260 us in the first steps).
+__device__ __forceinline__ void agg_mark_live(const Agg& a, const Live& L) {
+    if (L.words == nullptr) return;                       // kernel argument: uniform
+    __syncthreads();
+    if (threadIdx.x < 2) a.new_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (unsigned s = threadIdx.x; s < a.slots; s += blockDim.x) {
+        const unsigned long long key = a.keys[s];
+        if (key == kEmpty) continue;
+        const unsigned long long row = key + (unsigned long long)L.row_offset;
+        const unsigned bit = 1u << (8 * (unsigned)(row & 3));
+        unsigned* w = L.words + (row >> 2);
+        if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) continue;   // common case: already live
+        const unsigned old = atomicOr(w, bit);
+        if (!(old & bit)) a.new_rows[atomicAdd(&a.new_cnt[0], 1u)] = (int)row;
+    }
+    __syncthreads();
+    const unsigned n = a.new_cnt[0];
+    if (n == 0) return;
+    if (threadIdx.x == 0) a.new_cnt[1] = (unsigned)atomicAdd(L.count, (int)n);
+    __syncthreads();
+    const unsigned base = a.new_cnt[1];
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) L.list[base + i] = a.new_rows[i];
+}
+
 // one global atomic per (distinct row, float) of this workgroup; K floats per row go to
 // grad + row*K, the optional (K+1)-th float to grad_w1 + row.
 __device__ __forceinline__ void agg_flush(const Agg& a, unsigned K, float* __restrict__ grad,
-                                          float* __restrict__ grad_w1) {
+                                          float* __restrict__ grad_w1, const Live& live, const Live& live_w1) {
     const unsigned lanes = K <= 16 ? 16 : (K <= 32 ? 32 : 64);   // lanes per slot
     const unsigned per_pass = blockDim.x / lanes;
     const unsigned l = threadIdx.x % lanes, grp = threadIdx.x / lanes;
@@ -109,6 +163,8 @@ __device__ __forceinline__ void agg_flush(const Agg& a, unsigned K, float* __res
             if (v != 0.f) atomic_add_f32(grad_w1 + row, v);
         }
     }
+    agg_mark_live(a, live);
+    if (grad_w1) agg_mark_live(a, live_w1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -144,7 +200,7 @@ template <int VEC>
 __global__ __launch_bounds__(kThreads) void gather_bwd_kernel(
     const int64_t* __restrict__ ids, const float* __restrict__ g,
     const int64_t* __restrict__ row_base, unsigned B, unsigned F, unsigned KV, unsigned g_stride,
-    unsigned g_col, float* __restrict__ grad_arena, unsigned ex) {
+    unsigned g_col, float* __restrict__ grad_arena, unsigned ex, Live live) {
     using V = typename VecT<VEC>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const unsigned K = KV * VEC;
@@ -162,10 +218,10 @@ __global__ __launch_bounds__(kThreads) void gather_bwd_kernel(
         if (id < 0) continue;
         unsigned long long row = (unsigned long long)(rb + id);
         V v = *reinterpret_cast<const V*>(g + (size_t)b * g_stride + g_col + (f * KV + q) * VEC);
-        agg_add<VEC>(a, row, q, v, grad_arena + row * K);
+        agg_add<VEC>(a, row, q, v, grad_arena + row * K, live);
     }
     __syncthreads();
-    agg_flush(a, K, grad_arena, nullptr);
+    agg_flush(a, K, grad_arena, nullptr, live, live);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -207,7 +263,7 @@ template <int VEC>
 __global__ __launch_bounds__(kThreads) void bag_mean_bwd_kernel(
     const int64_t* __restrict__ values, const int64_t* __restrict__ offsets,
     const float* __restrict__ g, unsigned B, unsigned KV, unsigned g_stride, unsigned g_col,
-    float* __restrict__ grad_table, unsigned ex) {
+    float* __restrict__ grad_table, unsigned ex, Live live) {
     using V = typename VecT<VEC>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const unsigned K = KV * VEC;
@@ -231,11 +287,11 @@ __global__ __launch_bounds__(kThreads) void bag_mean_bwd_kernel(
         for (int64_t j = beg; j < end; ++j) {
             int64_t id = values[j];
             if (id < 0) continue;
-            agg_add<VEC>(a, (unsigned long long)id, q, v, grad_table + id * K);
+            agg_add<VEC>(a, (unsigned long long)id, q, v, grad_table + id * K, live);
         }
     }
     __syncthreads();
-    agg_flush(a, K, grad_table, nullptr);
+    agg_flush(a, K, grad_table, nullptr, live, live);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -269,7 +325,7 @@ template <int VEC>
 __global__ __launch_bounds__(kThreads) void seq_gather_bwd_kernel(
     const int64_t* __restrict__ values, const int64_t* __restrict__ offsets,
     const float* __restrict__ g, unsigned BT, unsigned T, unsigned KV,
-    float* __restrict__ grad_table, unsigned ex) {
+    float* __restrict__ grad_table, unsigned ex, Live live) {
     using V = typename VecT<VEC>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const unsigned K = KV * VEC;
@@ -288,10 +344,10 @@ __global__ __launch_bounds__(kThreads) void seq_gather_bwd_kernel(
         int64_t id = values[beg + t];
         if (id < 0) continue;
         V v = reinterpret_cast<const V*>(g)[(size_t)row * KV + q];
-        agg_add<VEC>(a, (unsigned long long)id, q, v, grad_table + id * K);
+        agg_add<VEC>(a, (unsigned long long)id, q, v, grad_table + id * K, live);
     }
     __syncthreads();
-    agg_flush(a, K, grad_table, nullptr);
+    agg_flush(a, K, grad_table, nullptr, live, live);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -373,7 +429,7 @@ __global__ __launch_bounds__(kThreads) void deepfm_sparse_bwd_kernel(
     const float4* __restrict__ fsum, const float4* __restrict__ g_emb,
     const float* __restrict__ g_fm1, const float* __restrict__ g_fm2,
     const int64_t* __restrict__ row_base, unsigned B, unsigned F, unsigned K4,
-    float* __restrict__ grad_arena, float* __restrict__ grad_w1, unsigned ex) {
+    float* __restrict__ grad_arena, float* __restrict__ grad_w1, unsigned ex, Live live, Live live_w1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const unsigned K = K4 * 4;
     const Agg a = agg_carve(smem_raw, K + 1, 2 * ex);
@@ -403,14 +459,20 @@ __global__ __launch_bounds__(kThreads) void deepfm_sparse_bwd_kernel(
             float* p = grad_arena + row * K + q * 4;
             atomic_add_f32(p + 0, v.x); atomic_add_f32(p + 1, v.y);
             atomic_add_f32(p + 2, v.z); atomic_add_f32(p + 3, v.w);
-            if (q == 0) atomic_add_f32(grad_w1 + row, g_fm1[b]);
+            if (q == 0) {
+                atomic_add_f32(grad_w1 + row, g_fm1[b]);
+                live_mark(live, row);
+                live_mark(live_w1, row);
+            }
         }
     }
     __syncthreads();
-    agg_flush(a, K, grad_arena, grad_w1);
+    agg_flush(a, K, grad_arena, grad_w1, live, live_w1);
 }
 
-inline size_t agg_smem(int W, unsigned ex) { return 2 * ex * (sizeof(unsigned long long) + (size_t)W * sizeof(float)); }
+inline size_t agg_smem(int W, unsigned ex) {
+    return 2 * ex * (sizeof(unsigned long long) + (size_t)W * sizeof(float) + sizeof(int)) + 16;
+}
 
 // examples per workgroup of a scatter kernel; RECALGO_SCATTER_TILE=32|64|128|256 overrides (tuning knob)
 inline unsigned scatter_tile(unsigned dflt) {
@@ -431,6 +493,15 @@ inline unsigned scatter_tile(unsigned dflt) {
             if (e__ != hipSuccess) return (int)e__;                                                    \
         }                                                                                              \
     } while (0)
+
+inline Live to_live(const recalgo_live_t* l) {
+    if (l == nullptr || l->row_live == nullptr) return Live{nullptr, nullptr, nullptr, 0};
+    return Live{reinterpret_cast<unsigned*>(l->row_live), l->live_list, l->live_count, (long long)l->row_offset};
+}
+inline bool live_ok(const recalgo_live_t* l) {
+    return l == nullptr || l->row_live == nullptr ||
+           (l->live_list != nullptr && l->live_count != nullptr && (reinterpret_cast<uintptr_t>(l->row_live) & 3) == 0);
+}
 
 inline int vec_of(int K, int stride, int col) { return (K % 4 == 0 && stride % 4 == 0 && col % 4 == 0) ? 4 : 1; }
 
@@ -462,8 +533,8 @@ RECALGO_EXPORT int recalgo_embedding_gather_fwd(const int64_t* ids, const float*
 RECALGO_EXPORT int recalgo_embedding_gather_bwd(const int64_t* ids, const float* g,
                                                 const int64_t* row_base, int B, int F, int K,
                                                 int g_stride, int g_col, float* grad_arena,
-                                                recalgo_stream_t stream) {
-    RECALGO_REQUIRE(B >= 0 && F > 0 && K > 0 && K <= 64 && g_stride >= g_col + F * K);
+                                                const recalgo_live_t* live, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(B >= 0 && F > 0 && K > 0 && K <= 64 && g_stride >= g_col + F * K && live_ok(live));
     if (B == 0) return 0;
     const int vec = vec_of(K, g_stride, g_col);
     const unsigned ex = scatter_tile(64);
@@ -472,12 +543,12 @@ RECALGO_EXPORT int recalgo_embedding_gather_bwd(const int64_t* ids, const float*
         ENSURE_SMEM(gather_bwd_kernel<4>, agg_smem(K, ex));
         hipLaunchKernelGGL(gather_bwd_kernel<4>, grid, dim3(kThreads), agg_smem(K, ex), as_stream(stream), ids, g,
                            row_base, (unsigned)B, (unsigned)F, (unsigned)(K / 4), (unsigned)g_stride,
-                           (unsigned)g_col, grad_arena, ex);
+                           (unsigned)g_col, grad_arena, ex, to_live(live));
     } else {
         ENSURE_SMEM(gather_bwd_kernel<1>, agg_smem(K, ex));
         hipLaunchKernelGGL(gather_bwd_kernel<1>, grid, dim3(kThreads), agg_smem(K, ex), as_stream(stream), ids, g,
                            row_base, (unsigned)B, (unsigned)F, (unsigned)K, (unsigned)g_stride,
-                           (unsigned)g_col, grad_arena, ex);
+                           (unsigned)g_col, grad_arena, ex, to_live(live));
     }
     RECALGO_RETURN_LAST();
 }
@@ -504,9 +575,9 @@ RECALGO_EXPORT int recalgo_embedding_bag_mean_fwd(const int64_t* values, const i
 
 RECALGO_EXPORT int recalgo_embedding_bag_mean_bwd(const int64_t* values, const int64_t* offsets,
                                                   const float* g, int B, int K, int g_stride,
-                                                  int g_col, float* grad_table,
+                                                  int g_col, float* grad_table, const recalgo_live_t* live,
                                                   recalgo_stream_t stream) {
-    RECALGO_REQUIRE(B >= 0 && K > 0 && K <= 64 && g_stride >= g_col + K);
+    RECALGO_REQUIRE(B >= 0 && K > 0 && K <= 64 && g_stride >= g_col + K && live_ok(live));
     if (B == 0) return 0;
     const int vec = vec_of(K, g_stride, g_col);
     const unsigned ex = scatter_tile(256);
@@ -514,12 +585,12 @@ RECALGO_EXPORT int recalgo_embedding_bag_mean_bwd(const int64_t* values, const i
         ENSURE_SMEM(bag_mean_bwd_kernel<4>, agg_smem(K, ex));
         hipLaunchKernelGGL(bag_mean_bwd_kernel<4>, dim3(cdiv(B, ex)), dim3(kThreads), agg_smem(K, ex),
                            as_stream(stream), values, offsets, g, (unsigned)B, (unsigned)(K / 4),
-                           (unsigned)g_stride, (unsigned)g_col, grad_table, ex);
+                           (unsigned)g_stride, (unsigned)g_col, grad_table, ex, to_live(live));
     } else {
         ENSURE_SMEM(bag_mean_bwd_kernel<1>, agg_smem(K, ex));
         hipLaunchKernelGGL(bag_mean_bwd_kernel<1>, dim3(cdiv(B, ex)), dim3(kThreads), agg_smem(K, ex),
                            as_stream(stream), values, offsets, g, (unsigned)B, (unsigned)K,
-                           (unsigned)g_stride, (unsigned)g_col, grad_table, ex);
+                           (unsigned)g_stride, (unsigned)g_col, grad_table, ex, to_live(live));
     }
     RECALGO_RETURN_LAST();
 }
@@ -545,8 +616,8 @@ RECALGO_EXPORT int recalgo_sequence_gather_fwd(const int64_t* values, const int6
 
 RECALGO_EXPORT int recalgo_sequence_gather_bwd(const int64_t* values, const int64_t* offsets,
                                                const float* g, int B, int T, int K,
-                                               float* grad_table, recalgo_stream_t stream) {
-    RECALGO_REQUIRE(B >= 0 && T > 0 && K > 0 && K <= 64);
+                                               float* grad_table, const recalgo_live_t* live, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(B >= 0 && T > 0 && K > 0 && K <= 64 && live_ok(live));
     int64_t BT = (int64_t)B * T;
     RECALGO_REQUIRE(BT < (1ll << 31));
     if (BT == 0) return 0;
@@ -555,12 +626,12 @@ RECALGO_EXPORT int recalgo_sequence_gather_bwd(const int64_t* values, const int6
         ENSURE_SMEM(seq_gather_bwd_kernel<4>, agg_smem(K, ex));
         hipLaunchKernelGGL(seq_gather_bwd_kernel<4>, dim3(cdiv(BT, ex)), dim3(kThreads), agg_smem(K, ex),
                            as_stream(stream), values, offsets, g, (unsigned)BT, (unsigned)T, (unsigned)(K / 4),
-                           grad_table, ex);
+                           grad_table, ex, to_live(live));
     } else {
         ENSURE_SMEM(seq_gather_bwd_kernel<1>, agg_smem(K, ex));
         hipLaunchKernelGGL(seq_gather_bwd_kernel<1>, dim3(cdiv(BT, ex)), dim3(kThreads), agg_smem(K, ex),
                            as_stream(stream), values, offsets, g, (unsigned)BT, (unsigned)T, (unsigned)K,
-                           grad_table, ex);
+                           grad_table, ex, to_live(live));
     }
     RECALGO_RETURN_LAST();
 }
@@ -589,15 +660,16 @@ RECALGO_EXPORT int recalgo_deepfm_sparse_bwd(const int64_t* ids, const float* em
                                              const float* field_sum, const float* g_emb,
                                              const float* g_fm1, const float* g_fm2,
                                              const int64_t* row_base, int B, int F, int K,
-                                             float* grad_arena, float* grad_w1,
-                                             recalgo_stream_t stream) {
-    RECALGO_REQUIRE(B >= 0 && F > 0 && K > 0 && K % 4 == 0 && K <= 64);
+                                             float* grad_arena, float* grad_w1, const recalgo_live_t* live,
+                                             const recalgo_live_t* live_w1, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(B >= 0 && F > 0 && K > 0 && K % 4 == 0 && K <= 64 && live_ok(live) && live_ok(live_w1));
     if (B == 0) return 0;
     const unsigned ex = scatter_tile(256);
     ENSURE_SMEM(deepfm_sparse_bwd_kernel, agg_smem(K + 1, ex));
     hipLaunchKernelGGL(deepfm_sparse_bwd_kernel, dim3(F, cdiv(B, ex)), dim3(kThreads), agg_smem(K + 1, ex),
                        as_stream(stream), ids, reinterpret_cast<const float4*>(emb),
                        reinterpret_cast<const float4*>(field_sum), reinterpret_cast<const float4*>(g_emb),
-                       g_fm1, g_fm2, row_base, (unsigned)B, (unsigned)F, (unsigned)(K / 4), grad_arena, grad_w1, ex);
+                       g_fm1, g_fm2, row_base, (unsigned)B, (unsigned)F, (unsigned)(K / 4), grad_arena, grad_w1, ex, to_live(live),
+                       to_live(live_w1));
     RECALGO_RETURN_LAST();
 }

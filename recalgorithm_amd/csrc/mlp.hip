@@ -296,6 +296,109 @@ __global__ __launch_bounds__(256) void dense1_bwd_kernel(HeadParts P, int B, int
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// The whole logit / loss tail of a TRAIN step in one pass (algorithm/DeepFM/deepfm.py:206-217,234-235 and the same
+// tail in every model_fn): logit = sum_p <x_p, w_p> + bias + addends, prob = sigmoid, mean sigmoid-CE, and — the
+// loss-gradient seed being known — d loss / d logit, dx_p = dlogit * w_p, and per-workgroup partial sums of
+// dw_p = sum_b dlogit_b x_p[b, :], d bias and the loss.  Was: dense1_fwd + sigmoid_ce + dense1_bwd + colsum16
+// (4 launches of 5-7 us on 9 MB of traffic).  Workgroup = kTailRows examples: phase 1 one wave per example (dot
+// products, lanes stride the columns), phase 2 one thread per column (the tile is re-read from L1/L2).
+// partial row layout: [dw over the C concatenated columns | d bias | loss / B]  (C + 2 floats); the rows are summed
+// in fixed order by the deferred-sum launch (recalgo_dense_bwd_weights_reduce).
+// ---------------------------------------------------------------------------------------
+constexpr int kTailRows = 8;
+struct TailArgs {
+    const float* x[kHeadMaxParts];
+    const float* w[kHeadMaxParts];      // one weight vector per part (xDeepFM sums three one-unit heads)
+    float* dx[kHeadMaxParts];           // may be null per part
+    int width[kHeadMaxParts];
+    int n;
+    const float* bias;                  // [1] or null
+    const float* addend[2];             // [B] extra logit terms or null (DeepFM: FM first / second order)
+    const float* labels;                // [B]
+    const float* loss_addend;           // device scalar added to the loss value (a regulariser's VALUE), or null
+    float grad_scale;
+    float* logit; float* prob; float* dlogit;       // [B]
+    float* partials;                    // [gridDim.x][C + 2]
+    int B, C;
+};
+
+__global__ __launch_bounds__(256) void logit_loss_kernel(TailArgs P) {
+    __shared__ float s_dl[kTailRows], s_loss[kTailRows];
+    const int b0 = blockIdx.x * kTailRows;
+    const int nb = min(kTailRows, P.B - b0);
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float invB = 1.0f / (float)P.B;
+    // phase 1: wave w owns rows w, w + 4, ...; the loads of all its rows are in flight together
+    constexpr int RW = kTailRows / 4;
+    float acc[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) acc[i] = 0.f;
+    for (int p = 0; p < P.n; ++p) {
+        const int W = P.width[p];
+        const float* __restrict__ wp = P.w[p];
+        for (int j = lane; j < W; j += 64) {
+            const float wj = wp[j];
+#pragma unroll
+            for (int i = 0; i < RW; ++i) {
+                const int r = wave + 4 * i;
+                if (r < nb) acc[i] = fmaf(P.x[p][(size_t)(b0 + r) * W + j], wj, acc[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int r = wave + 4 * i;
+        float d = 0.f, ls = 0.f;
+        const float dot = wave_sum(acc[i]);
+        if (r < nb) {
+            const int b = b0 + r;
+            float x = dot + (P.bias ? P.bias[0] : 0.f);
+            if (P.addend[0]) x += P.addend[0][b];
+            if (P.addend[1]) x += P.addend[1][b];
+            const float z = P.labels[b];
+            const float e = expf(-fabsf(x));
+            ls = fmaxf(x, 0.f) - x * z + log1pf(e);               // tf.nn.sigmoid_cross_entropy_with_logits
+            const float rr = e / (1.0f + e);
+            const float pr = x >= 0.f ? 1.0f / (1.0f + e) : rr;
+            d = (((x >= 0.f ? 1.0f : 0.f) - z) + (x >= 0.f ? -rr : rr)) * P.grad_scale * invB;
+            if (lane == 0) {
+                P.logit[b] = x;
+                P.prob[b] = pr;
+                P.dlogit[b] = d;
+            }
+        }
+        if (lane == 0) { s_dl[r] = d; s_loss[r] = ls; }
+    }
+    __syncthreads();
+    float* __restrict__ prow = P.partials + (size_t)blockIdx.x * (P.C + 2);
+    for (int c = threadIdx.x; c < P.C; c += 256) {
+        int p = 0, off = 0;
+        while (c >= off + P.width[p]) off += P.width[p++];
+        const int W = P.width[p], j = c - off;
+        const float* __restrict__ xp = P.x[p] + (size_t)b0 * W + j;
+        float* __restrict__ dxp = P.dx[p] ? P.dx[p] + (size_t)b0 * W + j : nullptr;
+        const float wj = P.w[p][j];
+        float acc = 0.f;
+        float xv[kTailRows];
+#pragma unroll
+        for (int r = 0; r < kTailRows; ++r) xv[r] = r < nb ? xp[(size_t)r * W] : 0.f;
+#pragma unroll
+        for (int r = 0; r < kTailRows; ++r) {
+            acc = fmaf(s_dl[r], xv[r], acc);
+            if (dxp && r < nb) dxp[(size_t)r * W] = s_dl[r] * wj;
+        }
+        prow[c] = acc;
+    }
+    if (threadIdx.x == 0) {
+        float sd = 0.f, sl = 0.f;
+        for (int r = 0; r < kTailRows; ++r) { sd += s_dl[r]; sl += s_loss[r]; }
+        prow[P.C] = sd;
+        prow[P.C + 1] = sl * invB + ((blockIdx.x == 0 && P.loss_addend) ? P.loss_addend[0] : 0.f);
+    }
+}
+
 }  // namespace
 
 static int head_parts(const float* const* x_parts, float* const* dx_parts, const int* widths, int n_parts, int B,
@@ -419,5 +522,32 @@ RECALGO_EXPORT int recalgo_batchnorm_train_bwd(const float* x, const float* gamm
                        reinterpret_cast<const float4*>(save_rstd), reinterpret_cast<const float4*>(dbeta),
                        reinterpret_cast<const float4*>(dgamma), total4, C4, 1.0f / (float)rows,
                        reinterpret_cast<float4*>(dx));
+    RECALGO_RETURN_LAST();
+}
+
+RECALGO_EXPORT int64_t recalgo_logit_loss_partial_rows(int B) { return (int64_t)cdiv(B > 0 ? B : 1, kTailRows); }
+
+RECALGO_EXPORT int recalgo_logit_loss_fwd_bwd(const float* const* x_parts, const float* const* w_parts, const int* widths,
+                                              int n_parts, const float* bias, const float* addend0, const float* addend1,
+                                              const float* labels, const float* loss_addend, int B, float grad_scale,
+                                              float* logit, float* prob,
+                                              float* dlogit, float* const* dx_parts, float* partials,
+                                              recalgo_stream_t stream) {
+    RECALGO_REQUIRE(n_parts >= 1 && n_parts <= kHeadMaxParts && x_parts && w_parts && widths && B > 0);
+    RECALGO_REQUIRE(labels && logit && prob && dlogit && partials);
+    TailArgs P;
+    P.n = n_parts; P.C = 0;
+    for (int p = 0; p < kHeadMaxParts; ++p) {
+        const bool on = p < n_parts;
+        if (on) RECALGO_REQUIRE(x_parts[p] != nullptr && w_parts[p] != nullptr && widths[p] >= 1);
+        P.x[p] = on ? x_parts[p] : nullptr;
+        P.w[p] = on ? w_parts[p] : nullptr;
+        P.dx[p] = on && dx_parts ? dx_parts[p] : nullptr;
+        P.width[p] = on ? widths[p] : 0;
+        P.C += P.width[p];
+    }
+    P.bias = bias; P.addend[0] = addend0; P.addend[1] = addend1; P.labels = labels; P.loss_addend = loss_addend; P.grad_scale = grad_scale;
+    P.logit = logit; P.prob = prob; P.dlogit = dlogit; P.partials = partials; P.B = B;
+    hipLaunchKernelGGL(logit_loss_kernel, dim3(cdiv(B, kTailRows)), dim3(256), 0, as_stream(stream), P);
     RECALGO_RETURN_LAST();
 }

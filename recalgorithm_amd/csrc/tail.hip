@@ -372,6 +372,130 @@ __global__ __launch_bounds__(256) void act_bwd_tile_kernel(const float4* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// One launch per optimizer step: the step counter, TF1 Adam over the flat dense-variable buffer and
+// over the live rows of up to kAdamMaxArenas embedding arenas (previously adam_advance + adam_tf1 +
+// one adam_tf1_list per arena: 3-4 launches of 5-30 us, the first two at the launch floor).
+// Every workgroup reads step[0] when it starts and derives lr_t itself (two pow and a sqrt in double);
+// the LAST workgroup to finish (arrival ticket) publishes step[0] = t and re-arms the ticket — by then
+// every workgroup has read the old value, so there is no race, and the next launch (a kernel boundary
+// later) sees the new one.  hipGraph replayable: nothing depends on host-side state.
+// ---------------------------------------------------------------------------------------
+constexpr int kAdamMaxArenas = 4;
+struct AdamArena {
+    float* p; float* g; float* m; float* v;
+    const int* list;
+    const int* count;
+    int K;
+    int k4_shift;             // log2(K / 4) when K / 4 is a power of two, else -1
+    unsigned first_block, n_blocks;
+};
+struct AdamStepArgs {
+    float* p; float* g; float* m; float* v;        // flat dense buffer (n may be 0)
+    long long n;
+    unsigned dense_blocks;
+    AdamArena ar[kAdamMaxArenas];
+    int n_arenas;
+    long long* step;
+    int* ticket;
+    int advance;
+    float lr, b1, b2, eps;
+    int zero_grad;
+};
+
+__global__ __launch_bounds__(256) void adam_tf1_step_kernel(AdamStepArgs A) {
+    __shared__ float s_lr_t;
+    const long long t = A.step[0] + (A.advance ? 1 : 0);
+    if (threadIdx.x == 0) {
+        const double td = (double)t;
+        s_lr_t = (float)((double)A.lr * sqrt(1.0 - pow((double)A.b2, td)) / (1.0 - pow((double)A.b1, td)));
+    }
+    __syncthreads();
+    const float lr_t = s_lr_t, b1 = A.b1, b2 = A.b2, eps = A.eps;
+    if (blockIdx.x < A.dense_blocks) {
+        const long long n4 = A.n / 4;
+        const long long stride = (long long)A.dense_blocks * 256;
+        float4* p4 = reinterpret_cast<float4*>(A.p);
+        float4* g4 = reinterpret_cast<float4*>(A.g);
+        float4* m4 = reinterpret_cast<float4*>(A.m);
+        float4* v4 = reinterpret_cast<float4*>(A.v);
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+            float4 gg = g4[i], mm = m4[i], vv = v4[i];
+            const bool inert = gg.x == 0.f && gg.y == 0.f && gg.z == 0.f && gg.w == 0.f && mm.x == 0.f && mm.y == 0.f &&
+                               mm.z == 0.f && mm.w == 0.f && vv.x == 0.f && vv.y == 0.f && vv.z == 0.f && vv.w == 0.f;
+            if (inert) continue;                       // exact: the update of an all-zero word is the identity
+            float4 pp = p4[i];
+            adam1(pp.x, gg.x, mm.x, vv.x, lr_t, b1, b2, eps);
+            adam1(pp.y, gg.y, mm.y, vv.y, lr_t, b1, b2, eps);
+            adam1(pp.z, gg.z, mm.z, vv.z, lr_t, b1, b2, eps);
+            adam1(pp.w, gg.w, mm.w, vv.w, lr_t, b1, b2, eps);
+            p4[i] = pp; m4[i] = mm; v4[i] = vv;
+            if (A.zero_grad && (gg.x != 0.f || gg.y != 0.f || gg.z != 0.f || gg.w != 0.f)) g4[i] = f4_zero();
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (unsigned)(A.n - n4 * 4)) {
+            const long long i = n4 * 4 + threadIdx.x;
+            float pp = A.p[i], gg = A.g[i], mm = A.m[i], vv = A.v[i];
+            adam1(pp, gg, mm, vv, lr_t, b1, b2, eps);
+            A.p[i] = pp; A.m[i] = mm; A.v[i] = vv;
+            if (A.zero_grad) A.g[i] = 0.f;
+        }
+    } else {
+        int a = 0;
+#pragma unroll
+        for (int k = 1; k < kAdamMaxArenas; ++k)
+            if (k < A.n_arenas && blockIdx.x >= A.ar[k].first_block) a = k;
+        AdamArena R = A.ar[0];                       // select by value (a dynamic index into the kernel arguments
+#pragma unroll                                       // would go through scratch)
+        for (int k = 1; k < kAdamMaxArenas; ++k)
+            if (a == k) R = A.ar[k];
+        const unsigned blk = blockIdx.x - R.first_block;
+        const long long stride = (long long)R.n_blocks * 256;
+        const int K = R.K;
+        if ((K & 3) == 0) {
+            const int K4 = K >> 2;
+            const long long total4 = (long long)R.count[0] * K4;
+            float4* p4 = reinterpret_cast<float4*>(R.p);
+            float4* g4 = reinterpret_cast<float4*>(R.g);
+            float4* m4 = reinterpret_cast<float4*>(R.m);
+            float4* v4 = reinterpret_cast<float4*>(R.v);
+            const int sh = R.k4_shift;
+            for (long long tt = (long long)blk * 256 + threadIdx.x; tt < total4; tt += stride) {
+                const long long r = sh >= 0 ? tt >> sh : tt / K4;
+                const long long i = (long long)R.list[r] * K4 + (tt - r * K4);
+                float4 gg = g4[i], mm = m4[i], vv = v4[i], pp = p4[i];
+                const bool nz = gg.x != 0.f || gg.y != 0.f || gg.z != 0.f || gg.w != 0.f;
+                adam1(pp.x, gg.x, mm.x, vv.x, lr_t, b1, b2, eps);
+                adam1(pp.y, gg.y, mm.y, vv.y, lr_t, b1, b2, eps);
+                adam1(pp.z, gg.z, mm.z, vv.z, lr_t, b1, b2, eps);
+                adam1(pp.w, gg.w, mm.w, vv.w, lr_t, b1, b2, eps);
+                p4[i] = pp; m4[i] = mm; v4[i] = vv;
+                if (A.zero_grad && nz) g4[i] = f4_zero();
+            }
+        } else {
+            const long long total = (long long)R.count[0] * K;
+            for (long long tt = (long long)blk * 256 + threadIdx.x; tt < total; tt += stride) {
+                const long long r = tt / K;
+                const long long i = (long long)R.list[r] * K + (tt - r * K);
+                float gg = R.g[i], mm = R.m[i], vv = R.v[i], pp = R.p[i];
+                const bool nz = gg != 0.f;
+                adam1(pp, gg, mm, vv, lr_t, b1, b2, eps);
+                R.p[i] = pp; R.m[i] = mm; R.v[i] = vv;
+                if (A.zero_grad && nz) R.g[i] = 0.f;
+            }
+        }
+    }
+    if (!A.advance) return;
+    // the last workgroup to arrive publishes the new step count
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int arrived = __hip_atomic_fetch_add(A.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == (int)gridDim.x - 1) {
+            __hip_atomic_store(A.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            A.step[0] = t;
+        }
+    }
+}
+
 __global__ void adam_advance_kernel(int64_t* step, float lr, float b1, float b2, float* lr_t) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         int64_t t = step[0] + 1;
@@ -571,5 +695,44 @@ RECALGO_EXPORT int recalgo_activation_bwd(const float* x, const float* alpha, co
         hipLaunchKernelGGL(act_bwd_kernel<false>, dim3(nblk), dim3(256), 0, st, x, alpha, gy, (unsigned)rows,
                            (unsigned)C, kActRowsPerBlk, dx, partial);
     launch_colsum16(partial, nblk, (unsigned)C, dalpha, (unsigned)C, static_cast<float*>(nullptr), st);
+    RECALGO_RETURN_LAST();
+}
+
+RECALGO_EXPORT int recalgo_adam_tf1_step(float* p, float* g, float* m, float* v, int64_t n,
+                                         const recalgo_adam_arena_t* arenas, int n_arenas, int64_t* step_dev,
+                                         int* ticket_dev, int advance, float lr, float beta1, float beta2, float eps,
+                                         int zero_grad, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(n >= 0 && n_arenas >= 0 && n_arenas <= kAdamMaxArenas && step_dev != nullptr);
+    RECALGO_REQUIRE(!advance || ticket_dev != nullptr);
+    RECALGO_REQUIRE(n == 0 || (p && g && m && v));
+    RECALGO_REQUIRE(n_arenas == 0 || arenas != nullptr);
+    AdamStepArgs A;
+    A.p = p; A.g = g; A.m = m; A.v = v; A.n = n;
+    const int64_t want = (n / 4 + 255) / 256;
+    A.dense_blocks = n == 0 ? 0u : (unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+    unsigned blocks = A.dense_blocks;
+    A.n_arenas = 0;
+    for (int i = 0; i < n_arenas; ++i) {
+        const recalgo_adam_arena_t& a = arenas[i];
+        if (a.max_rows <= 0) continue;
+        RECALGO_REQUIRE(a.p && a.g && a.m && a.v && a.live_list && a.live_count && a.K >= 1);
+        AdamArena& R = A.ar[A.n_arenas++];
+        R.p = a.p; R.g = a.g; R.m = a.m; R.v = a.v; R.list = a.live_list; R.count = a.live_count; R.K = a.K;
+        R.k4_shift = -1;
+        if ((a.K & 3) == 0)
+            for (int sft = 0; sft < 16; ++sft)
+                if ((a.K >> 2) == (1 << sft)) R.k4_shift = sft;
+        // sized for the largest possible list (graph replayable); surplus workgroups find nothing to do
+        const int64_t per = (a.K & 3) == 0 ? a.max_rows * (a.K / 4) : a.max_rows * a.K;
+        const int64_t w = (per + 255) / 256;
+        R.n_blocks = (unsigned)(w < 1 ? 1 : (w > 2048 ? 2048 : w));
+        R.first_block = blocks;
+        blocks += R.n_blocks;
+    }
+    for (int i = A.n_arenas; i < kAdamMaxArenas; ++i) A.ar[i] = AdamArena{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 4, 0, 0xffffffffu, 0};
+    A.step = reinterpret_cast<long long*>(step_dev); A.ticket = ticket_dev; A.advance = advance;
+    A.lr = lr; A.b1 = beta1; A.b2 = beta2; A.eps = eps; A.zero_grad = zero_grad;
+    if (blocks == 0) blocks = 1;                      // still advances the step counter
+    hipLaunchKernelGGL(adam_tf1_step_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), A);
     RECALGO_RETURN_LAST();
 }

@@ -83,22 +83,29 @@ class AdamOptimizer:
                 "lr_t": torch.zeros(1, dtype=torch.float32, device=store.device),
             }
         from . import nn
-        nn.apply_parked_grads()             # l2-regulariser contributions (PNN weight_regularizer)
+        arenas = [ar for ar in store.arenas.values() if ar.weight is not None and ar.trainable]
+        fused = all(ar.tracks_live_rows for ar in arenas) and len(arenas) <= 4 and store.device.type == "cuda"
+        # parked gradients: deferred weight-gradient split sums (+ the step counter, advanced by the same launch),
+        # l2-regulariser contributions (PNN weight_regularizer)
+        nn.apply_parked_grads(step_dev=st["step"] if fused else None)
         if grad_hook is not None:           # data-parallel all-reduce of the flat dense grads
             grad_hook(store)
+        if fused:
+            # one launch: dense TF1 Adam over the flat buffer + dense-semantics TF1 Adam over the rows a gradient has ever
+            # reached (the update is the identity for all others); lr_t derived on the device from the step counter
+            ops.adam_tf1_step_(store.flat, store.flat_grad, store.flat_m, store.flat_v, arenas, st["step"], None,
+                               self.lr, self.beta1, self.beta2, self.eps)
+            return
         ops.adam_tf1_advance_(st["step"], st["lr_t"], self.lr, self.beta1, self.beta2)
         kw = dict(step=-1, lr=self.lr, beta1=self.beta1, beta2=self.beta2, eps=self.eps,
                   zero_grad=True, lr_t_dev=st["lr_t"])
         if store.flat is not None and store.flat.numel():
             ops.adam_tf1_(store.flat, store.flat_grad, store.flat_m, store.flat_v, **kw)
-        for ar in store.arenas.values():
-            if ar.weight is not None and ar.trainable:
-                if ar.tracks_live_rows:
-                    # dense TF1 semantics; only rows a gradient has ever reached are visited (the
-                    # update is the identity for the others)
-                    ops.adam_tf1_list_(ar, st["lr_t"], self.beta1, self.beta2, self.eps)
-                else:
-                    ops.adam_tf1_(ar.weight.view(-1), ar.grad.view(-1), ar.m.view(-1), ar.v.view(-1), **kw)
+        for ar in arenas:
+            if ar.tracks_live_rows:
+                ops.adam_tf1_list_(ar, st["lr_t"], self.beta1, self.beta2, self.eps)
+            else:
+                ops.adam_tf1_(ar.weight.view(-1), ar.grad.view(-1), ar.m.view(-1), ar.v.view(-1), **kw)
 
 
 def get_global_step():

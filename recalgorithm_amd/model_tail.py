@@ -20,18 +20,37 @@ def finish_model_fn(mode, logit: torch.Tensor, labels, params,
                     predictions: Optional[Callable[[torch.Tensor], Dict[str, torch.Tensor]]] = None,
                     extra_loss: Optional[Callable[[], torch.Tensor]] = None,
                     label_key: str = "read_comment") -> EstimatorSpec:
+    from .nn import LazyLogit
+    lazy = logit if isinstance(logit, LazyLogit) else None
+    extra = None
+    if lazy is not None:
+        ok = mode == ModeKeys.TRAIN and lazy.fusable() and not current_store().building
+        if ok and extra_loss is not None:
+            # the fused tail delivers the loss VALUE through the step's deferred sums: an extra term can only join it as
+            # a detached addend (DIN's regulariser value; its gradient rides on the first fcn layer)
+            extra = extra_loss()
+            ok = extra is None or not extra.requires_grad
+        if not ok:
+            logit, lazy = lazy.materialize(), None
     if mode == ModeKeys.PREDICT:
         prob = torch.sigmoid(logit)
         preds = predictions(prob) if predictions else {"probabilities": prob}
         return EstimatorSpec(mode, predictions=preds, export_outputs={"prediction": preds})
 
     y = labels[label_key]
-    if current_store().building:          # variable-registration pass: nothing is launched
+    if lazy is not None:
+        # one launch: one-unit head(s) + sigmoid-CE + the backward of both (the loss-gradient seed is known)
+        heads = [(k, len(ps)) for k, _, ps in lazy.heads]
+        bias = next((b for _, b, _ in lazy.heads if b is not None), None)
+        parts = [t for _, _, ps in lazy.heads for t in ps]
+        loss, prob, logit = ops.logit_loss(current_store(), y, heads, bias, parts, lazy.tensors, loss_addend=extra)
+    elif current_store().building:          # variable-registration pass: nothing is launched
         loss, prob = logit.new_zeros(()), torch.zeros_like(logit)
     else:
         loss, prob = ops.sigmoid_cross_entropy(logit, y)
-    if extra_loss is not None:
-        extra = extra_loss()
+    if extra_loss is not None and lazy is None:
+        if extra is None:
+            extra = extra_loss()
         if extra is not None:
             loss = loss + extra
     if mode == ModeKeys.EVAL:

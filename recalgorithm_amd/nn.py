@@ -28,10 +28,35 @@ def _mfma_dense() -> bool:
     return os.environ.get("RECALGO_DENSE", "mfma") != "blas"
 
 
+class GradJoin:
+    """A tensor consumed by two branches (DCN's x0 feeds the cross network and the MLP, dcn.py:157-166) receives the
+    SUM of the two input gradients — in autograd an extra elementwise launch.  With a GradJoin shared by the two ops,
+    the branch whose backward runs first (`dense`: it is created later in the forward) parks its input gradient here
+    instead of returning it, and the other branch's backward kernel adds it in its own epilogue
+    (`recalgo_cross_bwd`'s g_x0_extra) and returns the total.  If the order is ever the other way round, or the
+    consumer cannot take it, both gradients are returned normally and autograd adds them."""
+
+    def __init__(self):
+        self.pending: Optional[torch.Tensor] = None
+        self.consumer_done = False
+
+    def park(self, dx: torch.Tensor) -> bool:
+        if self.consumer_done or self.pending is not None:
+            return False
+        self.pending = dx
+        return True
+
+    def take(self) -> Optional[torch.Tensor]:
+        t, self.pending, self.consumer_done = self.pending, None, True
+        return t
+
+
 class _DenseFn(Function):
     @staticmethod
-    def forward(ctx, anchor, x, kernel: Variable, bias: Optional[Variable], relu: bool, input_l2: float = 0.0):
+    def forward(ctx, anchor, x, kernel: Variable, bias: Optional[Variable], relu: bool, input_l2: float = 0.0,
+                grad_join: Optional[GradJoin] = None):
         ctx.input_l2 = float(input_l2)
+        ctx.grad_join = grad_join
         x2 = x.reshape(-1, x.shape[-1])
         ctx.hip = x2.is_cuda and x2.dtype == torch.float32 and _mfma_dense()
         if ctx.hip:
@@ -68,7 +93,9 @@ class _DenseFn(Function):
             if ctx.needs_input_grad[1]:
                 dx = ops.dense_bwd_input(g2, y if ctx.relu else None, kernel.data,
                                          c_in=x2 if ctx.input_l2 else None, beta=ctx.input_l2).view(ctx.xshape)
-            return None, dx, None, None, None, None
+                if ctx.grad_join is not None and ctx.grad_join.park(dx):
+                    dx = None                      # added by the other consumer of x in its backward kernel
+            return None, dx, None, None, None, None, None
         if not g2.is_contiguous():
             g2 = g2.contiguous()
         if bias is not None and _hip(g2, g2.shape[1]):
@@ -85,7 +112,7 @@ class _DenseFn(Function):
             dx = torch.addmm(x2, g2, kernel.data.t(), beta=ctx.input_l2)
         else:
             dx = g2 @ kernel.data.t()
-        return None, dx.view(ctx.xshape), None, None, None, None
+        return None, dx.view(ctx.xshape), None, None, None, None, None
 
 
 class _Dense1Fn(Function):
@@ -124,6 +151,47 @@ class LazyConcat:
         return torch.cat(self.parts, dim=-1)
 
 
+class LazyLogit:
+    """`tf.layers.dense(x, 1)` (and sums of such heads and of [B, 1] tensors) whose consumer is the loss of a TRAIN
+    step: model_tail.finish_model_fn hands the un-evaluated sum to ONE kernel that computes the logit, the
+    probabilities, the loss and the whole backward of this tail (ops.logit_loss).  Any other use goes through
+    `materialize()`, i.e. the separate head kernel."""
+
+    def __init__(self, heads=(), tensors=()):
+        self.heads = list(heads)          # [(kernel Variable, bias Variable | None, [parts])]
+        self.tensors = list(tensors)      # [B, 1] addends
+
+    @property
+    def shape(self):
+        B = (self.heads[0][2][0] if self.heads else self.tensors[0]).shape[0]
+        return (B, 1)
+
+    def __add__(self, other):
+        if isinstance(other, LazyLogit):
+            return LazyLogit(self.heads + other.heads, self.tensors + other.tensors)
+        if isinstance(other, torch.Tensor):
+            return LazyLogit(self.heads, self.tensors + [other])
+        return NotImplemented
+
+    __radd__ = __add__
+
+    def fusable(self) -> bool:
+        from . import ops
+        parts = [t for _, _, ps in self.heads for t in ps]
+        return (len(self.heads) >= 1 and sum(b is not None for _, b, _ in self.heads) <= 1
+                and ops.logit_loss_supported(parts, self.tensors))
+
+    def materialize(self) -> torch.Tensor:
+        store = current_store()
+        out = None
+        for kernel, bias, parts in self.heads:
+            t = _Dense1Fn.apply(store.anchor, kernel, bias, *parts)
+            out = t if out is None else out + t
+        for t in self.tensors:
+            out = t if out is None else out + t
+        return out
+
+
 def concat(values, axis: int = -1):
     """tf.concat along the last axis; lazy (see LazyConcat) when every value is a 2-D device tensor."""
     values = list(values)
@@ -133,7 +201,8 @@ def concat(values, axis: int = -1):
 
 
 def dense(x, units, activation: Optional[str] = None,
-          use_bias: bool = True, name: Optional[str] = None, input_l2: float = 0.0) -> torch.Tensor:
+          use_bias: bool = True, name: Optional[str] = None, input_l2: float = 0.0,
+          grad_join: Optional[GradJoin] = None) -> torch.Tensor:
     """tf.layers.dense(x, units, activation=None|relu, use_bias, name).  `units` may be a
     str (the reference passes FLAGS.hidden_units.split(','), deepfm.py:286; quirk B-2).
     Variables: <scope>/<name>/kernel (glorot-uniform), <scope>/<name>/bias (zeros).
@@ -153,10 +222,12 @@ def dense(x, units, activation: Optional[str] = None,
         from . import ops
         parts = [t if t.is_contiguous() else t.contiguous() for t in parts]
         if ops.dense1_supported(parts):
+            if ops.logit_loss_supported(parts, []) and not store.building:
+                return LazyLogit([(kernel, bias, parts)])     # TRAIN step: evaluated together with the loss
             return _Dense1Fn.apply(store.anchor, kernel, bias, *parts)
     if isinstance(x, LazyConcat):
         x = x.materialize()
-    return _DenseFn.apply(store.anchor, x, kernel, bias, activation == "relu", input_l2)
+    return _DenseFn.apply(store.anchor, x, kernel, bias, activation == "relu", input_l2, grad_join)
 
 
 def l2_value(x: torch.Tensor, half_coeff: float) -> torch.Tensor:
@@ -264,12 +335,12 @@ class _L2RegFn(Function):
 _PARKED = []
 
 
-def apply_parked_grads():
+def apply_parked_grads(step_dev=None):
     """Finish the gradients that backward left parked (called once per step, after backward, by the optimizer and by
     `variables.named_grads`): the deferred weight-gradient split sums of `dense` (ops.flush_dense_splits), then
     grad += scale * g * w for every parked l2 term."""
     from . import ops
-    ops.flush_dense_splits()
+    ops.flush_dense_splits(step_dev)
     while _PARKED:
         v, scale, g = _PARKED.pop()
         v.grad.add_(v.data * (scale * g))

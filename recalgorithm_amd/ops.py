@@ -73,6 +73,20 @@ def mark_live_rows(arena, ids: torch.Tensor, row_base: Optional[torch.Tensor], F
                                               _stream(ids)), "recalgo_mark_live_rows")
 
 
+class _Live(ctypes.Structure):          # include/recalgo.h recalgo_live_t
+    _fields_ = [("row_live", ctypes.c_void_p), ("live_list", ctypes.c_void_p), ("live_count", ctypes.c_void_p),
+                ("row_offset", ctypes.c_int64)]
+
+
+def _live(arena, row_offset: int = 0):
+    """recalgo_live_t* of the arena's live-row bookkeeping (the scatter kernels mark the rows they flush), or None
+    for arenas without it (row-sharded staging buffers: their owners mark on receipt)."""
+    if not getattr(arena, "tracks_live_rows", False):
+        return None
+    live, lst, cnt = arena.live_state()
+    return ctypes.byref(_Live(live.data_ptr(), lst.data_ptr(), cnt.data_ptr(), int(row_offset)))
+
+
 def _staged(arena, rows: torch.Tensor):
     """(staged arena, identity ids [M]) for a row-sharded arena, or None when the arena is local."""
     sd = getattr(arena, "sharding", None)
@@ -114,9 +128,8 @@ class _GatherFn(Function):
         B, F = ids.shape
         g = g.contiguous()
         _lib.check(_lib_().recalgo_embedding_gather_bwd(
-            _p(ids), _p(g), _p(ctx.row_base), B, F, arena.K, F * arena.K, 0, _p(arena.grad),
+            _p(ids), _p(g), _p(ctx.row_base), B, F, arena.K, F * arena.K, 0, _p(arena.grad), _live(arena),
             _stream(ids)), "recalgo_embedding_gather_bwd")
-        mark_live_rows(arena, ids, ctx.row_base, F)
         _flush(arena)
         return None, None, None, None
 
@@ -154,9 +167,8 @@ class _BagMeanFn(Function):
         gt = arena.grad[rb:rb + vocab]
         g = g.contiguous()
         _lib.check(_lib_().recalgo_embedding_bag_mean_bwd(
-            _p(values), _p(offsets), _p(g), B, arena.K, arena.K, 0, _p(gt), _stream(offsets)),
+            _p(values), _p(offsets), _p(g), B, arena.K, arena.K, 0, _p(gt), _live(arena, rb), _stream(offsets)),
             "recalgo_embedding_bag_mean_bwd")
-        mark_live_rows(arena, values, arena_row_base(arena, table_name, values.device), 1)
         _flush(arena)
         return None, None, None, None, None
 
@@ -194,9 +206,8 @@ class _SeqGatherFn(Function):
         gt = arena.grad[rb:rb + vocab]
         g = g.contiguous()
         _lib.check(_lib_().recalgo_sequence_gather_bwd(
-            _p(values), _p(offsets), _p(g), B, T, arena.K, _p(gt), _stream(offsets)),
+            _p(values), _p(offsets), _p(g), B, T, arena.K, _p(gt), _live(arena, rb), _stream(offsets)),
             "recalgo_sequence_gather_bwd")
-        mark_live_rows(arena, values, arena_row_base(arena, table_name, values.device), 1)
         _flush(arena)
         return None, None, None, None, None, None
 
@@ -238,9 +249,7 @@ class _DeepFMSparseFn(Function):
         g_emb, g_fm1, g_fm2 = g_emb.contiguous(), g_fm1.contiguous(), g_fm2.contiguous()
         _lib.check(_lib_().recalgo_deepfm_sparse_bwd(
             _p(ids), _p(emb), _p(fsum), _p(g_emb), _p(g_fm1), _p(g_fm2), _p(row_base), B, F, arena.K,
-            _p(arena.grad), _p(w1.grad), _stream(ids)), "recalgo_deepfm_sparse_bwd")
-        mark_live_rows(arena, ids, row_base, F)
-        mark_live_rows(w1, ids, row_base, F)          # the first-order weights share the row layout
+            _p(arena.grad), _p(w1.grad), _live(arena), _live(w1), _stream(ids)), "recalgo_deepfm_sparse_bwd")
         _flush(arena)
         _flush(w1)
         torch.sum(g_fm1, dim=0, out=bias.grad.view(1))
@@ -273,8 +282,9 @@ def _pad4(t: torch.Tensor) -> torch.Tensor:
 
 class _CrossFn(Function):
     @staticmethod
-    def forward(ctx, anchor, x0, w: Variable, b: Variable, xl_first):
-        # w.data, b.data: [L, d].  xl_first is None for the fused stack (x_0 = x0).
+    def forward(ctx, anchor, x0, w: Variable, b: Variable, grad_join):
+        # w.data, b.data: [L, d].  grad_join: nn.GradJoin shared with the other consumer of x0 (or None).
+        ctx.grad_join = grad_join
         B, d = x0.shape
         L = w.data.shape[0]
         x0p, wp, bp = _pad4(x0), _pad4(w.data.reshape(L, d)), _pad4(b.data.reshape(L, d))
@@ -304,22 +314,27 @@ class _CrossFn(Function):
         else:
             wp, bp = _pad4(w.data.reshape(L, d)), _pad4(b.data.reshape(L, d))
             dw, db = torch.empty_like(wp), torch.empty_like(bp)
+        # the gradient the MLP branch parked for x0 is added in this kernel's epilogue (no separate add launch)
+        extra = ctx.grad_join.take() if ctx.grad_join is not None else None
+        fused_extra = extra is not None and dp == d and extra.is_contiguous() and tuple(extra.shape) == (B, d)
         _lib.check(lib.recalgo_cross_bwd(
-            _p(x0p), dp, _p(wp), _p(bp), _p(g), dp, None, B, dp, L, _p(dx0), _p(dw),
+            _p(x0p), dp, _p(wp), _p(bp), _p(g), dp, _p(extra) if fused_extra else None, B, dp, L, _p(dx0), _p(dw),
             _p(db), _p(ws), _stream(x0p)), "recalgo_cross_bwd")
         if dp != d:
             w.grad.copy_(dw[:, :d].reshape(w.grad.shape))
             b.grad.copy_(db[:, :d].reshape(b.grad.shape))
             dx0 = dx0[:, :d]
+        if extra is not None and not fused_extra:
+            dx0 = dx0 + extra.reshape(dx0.shape)
         return None, dx0, None, None, None
 
 
-def cross_stack(store, x0: torch.Tensor, w: Variable, b: Variable) -> torch.Tensor:
+def cross_stack(store, x0: torch.Tensor, w: Variable, b: Variable, grad_join=None) -> torch.Tensor:
     """Fused L-layer CrossNet: w, b are [L, d] block variables."""
     if store.building:
         return torch.zeros_like(x0)
     _chk(x0, torch.float32, "x0")
-    return _CrossFn.apply(store.anchor, x0, w, b, None)
+    return _CrossFn.apply(store.anchor, x0, w, b, grad_join)
 
 
 class _CrossLayerFn(Function):
@@ -725,6 +740,12 @@ def dense_bwd_input(g: torch.Tensor, y_mask: Optional[torch.Tensor], w: torch.Te
 
 _dense_ws = {}
 _dense_pending = []          # deferred split reductions of this backward pass: (M, K, N, ws, dw, dbias)
+_colsum_pending = []         # deferred plain column sums: (partials, element offset, rows, row_stride, n, out)
+
+
+class _ColSum(ctypes.Structure):              # include/recalgo.h recalgo_colsum_t
+    _fields_ = [("partials", ctypes.c_void_p), ("out", ctypes.c_void_p), ("rows", ctypes.c_int),
+                ("row_stride", ctypes.c_int64), ("n", ctypes.c_int64)]
 
 
 class _DenseSplit(ctypes.Structure):          # include/recalgo.h recalgo_dense_split_t
@@ -763,16 +784,24 @@ def dense_bwd_weights(x: torch.Tensor, g: torch.Tensor, y_mask: Optional[torch.T
         _dense_pending.append((M, K, N, ws, dw, dbias))
 
 
-def flush_dense_splits() -> None:
-    """Finish every deferred weight-gradient split reduction (one launch per 8 layers)."""
-    if not _dense_pending:
+def flush_dense_splits(step_dev: Optional[torch.Tensor] = None) -> None:
+    """Finish every deferred sum of the step in ONE launch: the weight-gradient split reductions of `dense`, the column
+    sums the loss tail left behind, and (`step_dev`, the optimizer's int64 step counter) the step increment — the
+    optimizer kernel that follows then only reads the counter."""
+    if not _dense_pending and not _colsum_pending and step_dev is None:
         return
-    jobs = (_DenseSplit * len(_dense_pending))()
+    jobs = (_DenseSplit * max(len(_dense_pending), 1))()
     for i, (M, K, N, ws, dw, dbias) in enumerate(_dense_pending):
         jobs[i] = _DenseSplit(M, K, N, ws.data_ptr(), dw.data_ptr(), 0 if dbias is None else dbias.data_ptr())
-    dev_t = _dense_pending[0][4]
+    sums = (_ColSum * max(len(_colsum_pending), 1))()
+    for i, (part, off, rows, stride, n, out) in enumerate(_colsum_pending):
+        sums[i] = _ColSum(part.data_ptr() + 4 * off, out.data_ptr(), rows, stride, n)
+    dev_t = _dense_pending[0][4] if _dense_pending else (_colsum_pending[0][0] if _colsum_pending else step_dev)
+    nj, ns = len(_dense_pending), len(_colsum_pending)
     _dense_pending.clear()
-    _lib.check(_lib_().recalgo_dense_bwd_weights_reduce(jobs, len(jobs), _stream(dev_t)), "recalgo_dense_bwd_weights_reduce")
+    _colsum_pending.clear()
+    _lib.check(_lib_().recalgo_dense_bwd_weights_reduce(jobs, nj, sums, ns, _p(step_dev), _stream(dev_t)),
+               "recalgo_dense_bwd_weights_reduce")
 
 
 def mlp_width_supported(C: int) -> bool:
@@ -904,6 +933,80 @@ def sigmoid_cross_entropy(logits: torch.Tensor, labels: torch.Tensor):
     return _SigmoidCEFn.apply(logits, labels)
 
 
+class _LogitLossFn(Function):
+    """TRAIN-step tail in one launch (include/recalgo.h recalgo_logit_loss_fwd_bwd): one-unit head(s) + sigmoid-CE +
+    their backward.  Requires the loss-gradient seed to be known (ops.loss_seed): the gradients are produced by the
+    forward launch, the backward only hands them out.  The loss VALUE and the head's weight / bias gradients are
+    column sums of per-workgroup partials, finished by the step's deferred-sum launch (flush_dense_splits)."""
+
+    @staticmethod
+    def forward(ctx, anchor, labels, heads, bias, n_addends, loss_addend, *tensors):
+        # heads: [(kernel Variable, n_parts)]; tensors = parts of all heads (in order) + the addend tensors [B, 1]
+        ctx.set_materialize_grads(False)
+        lib = _lib_()
+        n_parts = sum(n for _, n in heads)
+        parts, addends = list(tensors[:n_parts]), list(tensors[n_parts:])
+        B = parts[0].shape[0]
+        dev = parts[0].device
+        widths = [int(t.shape[1]) for t in parts]
+        C = sum(widths)
+        ws_w, i = [], 0
+        for kernel, n in heads:                      # weight slice of every part inside its head's (sum w, 1) kernel
+            off = 0
+            for t in parts[i:i + n]:
+                ws_w.append(kernel.data.reshape(-1)[off:off + t.shape[1]])
+                off += t.shape[1]
+            i += n
+        rows = int(lib.recalgo_logit_loss_partial_rows(B))
+        partials = torch.empty(rows, C + 2, device=dev, dtype=torch.float32)
+        logit = torch.empty(B, 1, device=dev, dtype=torch.float32)
+        prob, dlogit = torch.empty_like(logit), torch.empty_like(logit)
+        loss = torch.empty(1, device=dev, dtype=torch.float32)
+        need = ctx.needs_input_grad[6:6 + n_parts]
+        dxs = [torch.empty_like(t) if nd else None for t, nd in zip(parts, need)]
+        lb = labels.contiguous().view(-1).to(torch.float32)
+        wi = (ctypes.c_int * n_parts)(*widths)
+        _lib.check(lib.recalgo_logit_loss_fwd_bwd(
+            _ptr_array(parts), _ptr_array(ws_w), wi, n_parts, None if bias is None else _p(bias.data),
+            _p(addends[0].contiguous().view(-1)) if n_addends > 0 else None,
+            _p(addends[1].contiguous().view(-1)) if n_addends > 1 else None,
+            _p(lb), _p(loss_addend), B, float(_loss_seed), _p(logit), _p(prob), _p(dlogit), _ptr_array(dxs), _p(partials), _stream(logit)),
+            "recalgo_logit_loss_fwd_bwd")
+        # deferred column sums: dw of every head (contiguous columns of the partial rows), d bias, the loss value
+        col, i = 0, 0
+        for kernel, n in heads:
+            wsum = sum(widths[i:i + n])
+            _colsum_pending.append((partials, col, rows, C + 2, wsum, kernel.grad))
+            col += wsum
+            i += n
+        if bias is not None:
+            _colsum_pending.append((partials, C, rows, C + 2, 1, bias.grad))
+        _colsum_pending.append((partials, C + 1, rows, C + 2, 1, loss))
+        ctx.dxs, ctx.dlogit, ctx.n_addends = dxs, dlogit, n_addends
+        ctx.mark_non_differentiable(prob, logit)
+        return loss.view(()), prob, logit
+
+    @staticmethod
+    def backward(ctx, gloss, _gprob, _glogit):
+        if gloss is None:
+            return (None,) * (6 + len(ctx.dxs) + ctx.n_addends)
+        # the seed was baked into dlogit / dx by the forward launch (the caller promises to seed backward with it)
+        return (None, None, None, None, None, None, *ctx.dxs, *([ctx.dlogit] * ctx.n_addends))
+
+
+def logit_loss_supported(parts, addends) -> bool:
+    return (_loss_seed is not None and torch.is_grad_enabled() and dense1_supported(parts) and len(addends) <= 2
+            and all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == 1 for t in addends))
+
+
+def logit_loss(store, labels: torch.Tensor, heads, bias, parts, addends, loss_addend: Optional[torch.Tensor] = None):
+    """-> (mean sigmoid-CE loss (+ loss_addend, a detached device scalar), probabilities [B,1], logit [B,1]) of
+    logit = sum_heads dense1(parts) + bias + addends."""
+    if loss_addend is not None:
+        loss_addend = loss_addend.detach().reshape(1).to(torch.float32)
+    return _LogitLossFn.apply(store.anchor, labels, heads, bias, len(addends), loss_addend, *parts, *addends)
+
+
 # =============================================================================================
 # a12: PReLU / Dice
 # =============================================================================================
@@ -987,3 +1090,32 @@ def adam_tf1_advance_(step_dev: torch.Tensor, lr_t_dev: torch.Tensor, lr: float,
     """step_dev (int64[1]) += 1; lr_t_dev (float[1]) = lr*sqrt(1-b2^t)/(1-b1^t), on device."""
     _lib.check(_lib_().recalgo_adam_tf1_advance(_p(step_dev), lr, beta1, beta2, _p(lr_t_dev),
                                                  _stream(step_dev)), "recalgo_adam_tf1_advance")
+
+
+class _AdamArena(ctypes.Structure):          # include/recalgo.h recalgo_adam_arena_t
+    _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
+                ("live_list", ctypes.c_void_p), ("live_count", ctypes.c_void_p), ("max_rows", ctypes.c_int64),
+                ("K", ctypes.c_int)]
+
+
+def adam_tf1_step_(flat, flat_grad, flat_m, flat_v, arenas, step_dev: torch.Tensor, ticket_dev: Optional[torch.Tensor],
+                   lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, zero_grad: bool = True,
+                   advance: bool = False) -> None:
+    """ONE launch: TF1 Adam over the flat dense buffer and over the live rows of every arena, lr_t derived on the device
+    from step_dev (already advanced unless `advance`; include/recalgo.h recalgo_adam_tf1_step)."""
+    lib = _lib_()
+    n = 0 if flat is None else flat.numel()
+    for i in range(0, max(len(arenas), 1), 4):
+        chunk = arenas[i:i + 4]
+        arr = (_AdamArena * max(len(chunk), 1))()
+        for j, a in enumerate(chunk):
+            _, lst, cnt = a.live_state()
+            rows, K = a.weight.shape
+            arr[j] = _AdamArena(a.weight.data_ptr(), a.grad.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), lst.data_ptr(),
+                                cnt.data_ptr(), rows, K)
+        first = i == 0
+        if not first:
+            raise NotImplementedError("more than 4 embedding arenas in one model")
+        _lib.check(lib.recalgo_adam_tf1_step(_p(flat) if n else None, _p(flat_grad) if n else None, _p(flat_m) if n else None,
+                                             _p(flat_v) if n else None, n, arr, len(chunk), _p(step_dev), _p(ticket_dev),
+                                             int(advance), lr, beta1, beta2, eps, int(zero_grad), _stream(step_dev)), "recalgo_adam_tf1_step")

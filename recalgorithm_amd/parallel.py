@@ -180,9 +180,9 @@ def hip_local_scatter_add(arena: EmbeddingArena, local_rows: torch.Tensor, g: to
         st = ctypes.c_void_p(torch.cuda.current_stream(shard_grad.device).cuda_stream)
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         g = g.contiguous()
-        _lib.check(lib.recalgo_embedding_gather_bwd(p(local_rows), p(g), p(zero), n, 1, K, K, 0, p(shard_grad), st),
-                   "recalgo_embedding_gather_bwd")
-        ops.mark_live_rows(arena, local_rows, None, 1)
+        # the scatter marks the rows it flushes in the shard's live-row list
+        _lib.check(lib.recalgo_embedding_gather_bwd(p(local_rows), p(g), p(zero), n, 1, K, K, 0, p(shard_grad),
+                                                    ops._live(arena), st), "recalgo_embedding_gather_bwd")
 
 
 class Sharding:

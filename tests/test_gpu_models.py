@@ -329,3 +329,50 @@ def test_checkpoint_resume_equals_uninterrupted_training(dev, model, tmp_path):
         assert_close(b.store.arenas[n].v, ar.v.double(), rtol=1e-4, what=f"{model} arena {n}.v", reduced=True)
     assert_close(b.store.flat_m, ref.store.flat_m.double(), rtol=1e-4, what="dense m", reduced=True)
     assert_close(b.store.flat_v, ref.store.flat_v.double(), rtol=1e-4, what="dense v", reduced=True)
+
+
+@pytest.mark.parametrize("model", ["dcn", "deepfm", "xdeepfm", "din"])
+def test_fused_train_step_matches_unfused_graph(dev, model):
+    """Estimator.train_step knows the loss-gradient seed before the forward, so the one-unit head(s), the sigmoid-CE and
+    their backward run as ONE kernel, the step counter / weight-gradient split sums / loss value are finished by one
+    deferred launch and the two gradients of a shared input are joined inside a kernel.  The same step driven op by op
+    (model_fn, loss.backward(), apply_gradients: separate head, loss and optimizer launches) must give the same
+    losses and variables."""
+    if model in ("dcn", "deepfm"):
+        mk = lambda: make(model, dev)
+    elif model == "xdeepfm":
+        mk = lambda: _make_xdeepfm(dev)
+    else:
+        def mk():
+            import bench
+            args = bench.parse_args(["--model", "din", "--batch", "256", "--fields", "8", "--max-vocab", "500"])
+            est, spec, feats, labels, _ = bench.build_estimator(args, dev)
+            return est, est.params, feats, labels
+    a, params, feats, labels = mk()
+    b, _, _, _ = mk()
+    if model == "din":
+        # alpha = 1 makes Dice the identity: every dense -> BN pair is then affine and the gradients of the biases / BN
+        # shifts in between cancel analytically (noise that Adam turns into O(lr) moves) — move alpha away from 1
+        for est in (a, b):
+            g = torch.Generator().manual_seed(99)
+            for name, v in est.store.vars.items():
+                if "alpha" in name:
+                    v.data.copy_((0.25 + 0.5 * torch.rand(v.data.shape, generator=g)).to(dev))
+    la, lb = [], []
+    for _ in range(3):
+        la.append(float(a.train_step(feats, labels)))                       # fused tail
+        spec = b._call_model_fn(feats, labels, ModeKeys.TRAIN)               # op by op
+        spec.loss.backward()
+        spec.train_op.optimizer.apply_gradients(b.store)
+        lb.append(float(spec.loss))
+    torch.cuda.synchronize()
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 2e-6 * abs(y), (la, lb)
+    A, B_ = a.store.named_arrays(), b.store.named_arrays()
+    for k in A:
+        if k.endswith("/bias") and model in ("deepfm", "din"):
+            # a dense bias in front of a training-mode BatchNorm: its gradient cancels analytically, what is left is
+            # rounding noise, and Adam's g / (|g| + eps') turns noise into O(lr) moves — not comparable run to run
+            continue
+        assert_close(A[k], B_[k].double(), rtol=2e-5, what=f"{model} {k}: fused vs op-by-op after 3 steps", reduced=True)
+    assert int(a.store.opt_state["step"]) == int(b.store.opt_state["step"]) == 3
