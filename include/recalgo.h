@@ -343,6 +343,10 @@ int recalgo_dense_bwd_input(const float* g, int ldg, const float* y_mask, const 
 int64_t recalgo_dense_bwd_weights_workspace_bytes(int M, int K, int N);
 int recalgo_dense_bwd_weights(const float* x, int ldx, const float* g, int ldg, const float* y_mask, int M, int K, int N,
                               float* dw, float* dbias, void* workspace, int defer_reduce, recalgo_stream_t stream);
+/* bwd: both of the above in ONE launch (dx = ... + beta * c_in, no accumulate mode); same arguments, same results. */
+int recalgo_dense_bwd(const float* x, int ldx, const float* g, int ldg, const float* y_mask, const float* w, int M, int K,
+                      int N, const float* c_in, int ldc, float beta, float* dx, int lddx, float* dw, float* dbias,
+                      void* workspace, int defer_reduce, recalgo_stream_t stream);
 typedef struct {
     int M, K, N;
     const void* workspace;

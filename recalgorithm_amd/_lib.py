@@ -73,6 +73,7 @@ SIGNATURES = {
     "recalgo_dense_bwd_input": (c_int, [P, c_int, P, P, c_int, c_int, c_int, P, c_int, c_float, P, c_int, c_int, P]),
     "recalgo_dense_bwd_weights_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "recalgo_dense_bwd_weights": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, P, P, P, c_int, P]),
+    "recalgo_dense_bwd": (c_int, [P, c_int, P, c_int, P, P, c_int, c_int, c_int, P, c_int, c_float, P, c_int, P, P, P, c_int, P]),
     "recalgo_dense_bwd_weights_reduce": (c_int, [P, c_int, P, c_int, P, P]),
     "recalgo_logit_loss_partial_rows": (c_int64, [c_int]),
     "recalgo_logit_loss_fwd_bwd": (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, P, P, P, P, P]),

@@ -324,11 +324,9 @@ struct DgradArgs {
 };
 
 template <bool FAST, bool MASK>
-__global__ __launch_bounds__(kThreads) void dense_dgrad_kernel(DgradArgs P) {
-    __shared__ __attribute__((aligned(16))) float As[kStages * kBufFloats];
-    __shared__ __attribute__((aligned(16))) float Bs[kStages * kBufFloats];
+__device__ __forceinline__ void dgrad_tile(const DgradArgs& P, int block, int nblocks, float* As, float* Bs) {
     const int tn_count = (P.K + BN - 1) / BN;
-    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile = xcd_swizzle(block, nblocks);
     const int m0 = (tile / tn_count) * BM, n0 = (tile % tn_count) * BN;
     f32x16 acc, acc1;
 #pragma unroll
@@ -352,6 +350,13 @@ __global__ __launch_bounds__(kThreads) void dense_dgrad_kernel(DgradArgs P) {
     }
 }
 
+template <bool FAST, bool MASK>
+__global__ __launch_bounds__(kThreads) void dense_dgrad_kernel(DgradArgs P) {
+    __shared__ __attribute__((aligned(16))) float As[kStages * kBufFloats];
+    __shared__ __attribute__((aligned(16))) float Bs[kStages * kBufFloats];
+    dgrad_tile<FAST, MASK>(P, blockIdx.x, gridDim.x, As, Bs);
+}
+
 struct WgradArgs {
     Segment seg;           // a = X [M][K] red-major (red = m), b = G (+mask) [M][N] red-major, n_red = M
     int K, N;              // output [K][N]
@@ -363,20 +368,18 @@ struct WgradArgs {
 };
 
 template <bool FAST, bool MASK>
-__global__ __launch_bounds__(kThreads) void dense_wgrad_kernel(WgradArgs P) {
-    __shared__ __attribute__((aligned(16))) float As[kStages * kBufFloats];
-    __shared__ __attribute__((aligned(16))) float Bs[kStages * kBufFloats];
+__device__ __forceinline__ void wgrad_tile(const WgradArgs& P, int block, float* As, float* Bs) {
     const int tn_count = (P.N + BN - 1) / BN, tm_count = (P.K + BM - 1) / BM;
     const int ntiles = tn_count * tm_count;
     // XCD placement: all tiles of one split read the same rows of X and G -> keep a split on one XCD
     int split, tile;
     if (P.splits % 8 == 0) {
-        const int b = blockIdx.x, x = b % 8, j = b / 8;
+        const int b = block, x = b % 8, j = b / 8;
         split = x + 8 * (j / ntiles);
         tile = j % ntiles;
     } else {
-        split = blockIdx.x / ntiles;
-        tile = blockIdx.x % ntiles;
+        split = block / ntiles;
+        tile = block % ntiles;
     }
     const int m0 = (tile / tn_count) * BM, n0 = (tile % tn_count) * BN;
     const int r_begin = split * P.rows_per_split;
@@ -418,6 +421,25 @@ __global__ __launch_bounds__(kThreads) void dense_wgrad_kernel(WgradArgs P) {
             if (c + 3 < P.N) db[c + 3] = t.w;
         }
     }
+}
+
+template <bool FAST, bool MASK>
+__global__ __launch_bounds__(kThreads) void dense_wgrad_kernel(WgradArgs P) {
+    __shared__ __attribute__((aligned(16))) float As[kStages * kBufFloats];
+    __shared__ __attribute__((aligned(16))) float Bs[kStages * kBufFloats];
+    wgrad_tile<FAST, MASK>(P, blockIdx.x, As, Bs);
+}
+
+// Both gradients of a layer in ONE launch: workgroups [0, dgrad_blocks) compute input-gradient tiles (the next
+// layer's backward waits for them), the rest weight-gradient tiles.  The two GEMMs share nothing but their inputs;
+// what the merge buys is one launch ramp / drain / boundary instead of two (each ~6 us per layer at these sizes,
+// scripts/bench_dense_k.py) and a fuller chip for the small layers (256 + 256 workgroups for [4096 x 256 x 128]).
+template <bool FAST, bool MASK>
+__global__ __launch_bounds__(kThreads) void dense_bwd_kernel(DgradArgs D, WgradArgs W, int dgrad_blocks) {
+    __shared__ __attribute__((aligned(16))) float As[kStages * kBufFloats];
+    __shared__ __attribute__((aligned(16))) float Bs[kStages * kBufFloats];
+    if ((int)blockIdx.x < dgrad_blocks) dgrad_tile<FAST, MASK>(D, blockIdx.x, dgrad_blocks, As, Bs);
+    else wgrad_tile<FAST, MASK>(W, blockIdx.x - dgrad_blocks, As, Bs);
 }
 
 // fixed-order sum of split slabs, batched over up to kMaxSplitJobs weight gradients (one launch for all the layers
@@ -529,18 +551,25 @@ RECALGO_EXPORT int recalgo_dense_fwd(const float* x, int ldx, const float* w, in
     RECALGO_RETURN_LAST();
 }
 
+static bool build_dgrad(DgradArgs& P, const float* g, int ldg, const float* y_mask, const float* w, int M, int N, int K,
+                        const float* c_in, int ldc, float beta, float* dx, int lddx, int accumulate) {
+    if (!(M >= 0 && N > 0 && K > 0 && dx != nullptr && lddx >= K)) return false;
+    if (!(g != nullptr && ldg >= N && w != nullptr)) return false;
+    if (!(c_in == nullptr || ldc >= K)) return false;
+    P.seg = Segment{operand(g, y_mask, ldg, M, N), operand(w, nullptr, N, K, N), N};
+    P.c_in = c_in; P.beta = beta; P.ldc = ldc; P.dx = dx; P.lddx = lddx; P.M = M; P.K = K; P.accumulate = accumulate;
+    return true;
+}
+static bool dgrad_fast(const DgradArgs& P) { return fast_rc(P.seg.a, P.seg.n_red) && fast_rc(P.seg.b, P.seg.n_red); }
+
 RECALGO_EXPORT int recalgo_dense_bwd_input(const float* g, int ldg, const float* y_mask, const float* w, int M, int N,
                                            int K, const float* c_in, int ldc, float beta, float* dx, int lddx,
                                            int accumulate, recalgo_stream_t stream) {
-    RECALGO_REQUIRE(M >= 0 && N > 0 && K > 0 && dx != nullptr && lddx >= K);
-    RECALGO_REQUIRE(g != nullptr && ldg >= N && w != nullptr);
-    RECALGO_REQUIRE(c_in == nullptr || ldc >= K);
-    if (M == 0) return 0;
     DgradArgs P;
-    P.seg = Segment{operand(g, y_mask, ldg, M, N), operand(w, nullptr, N, K, N), N};
-    P.c_in = c_in; P.beta = beta; P.ldc = ldc; P.dx = dx; P.lddx = lddx; P.M = M; P.K = K; P.accumulate = accumulate;
+    RECALGO_REQUIRE(build_dgrad(P, g, ldg, y_mask, w, M, N, K, c_in, ldc, beta, dx, lddx, accumulate));
+    if (M == 0) return 0;
     const int grid = cdiv(M, BM) * cdiv(K, BN);
-    const bool fast = fast_rc(P.seg.a, N) && fast_rc(P.seg.b, N);
+    const bool fast = dgrad_fast(P);
     hipStream_t st = as_stream(stream);
     if (fast && y_mask) hipLaunchKernelGGL((dense_dgrad_kernel<true, true>), dim3(grid), dim3(kThreads), 0, st, P);
     else if (fast) hipLaunchKernelGGL((dense_dgrad_kernel<true, false>), dim3(grid), dim3(kThreads), 0, st, P);
@@ -574,15 +603,13 @@ static SplitJob make_split_job(const float* ws, int S, int K, int N, float* dw, 
     return jb;
 }
 
-RECALGO_EXPORT int recalgo_dense_bwd_weights(const float* x, int ldx, const float* g, int ldg, const float* y_mask,
-                                             int M, int K, int N, float* dw, float* dbias, void* workspace,
-                                             int defer_reduce, recalgo_stream_t stream) {
-    RECALGO_REQUIRE(M > 0 && N > 0 && K > 0 && dw != nullptr);
-    RECALGO_REQUIRE(x != nullptr && ldx >= K && g != nullptr && ldg >= N);
+// -> number of splits (>= 1), or 0 on bad arguments
+static int build_wgrad(WgradArgs& P, const float* x, int ldx, const float* g, int ldg, const float* y_mask, int M, int K,
+                       int N, float* dw, float* dbias, void* workspace) {
+    if (!(M > 0 && N > 0 && K > 0 && dw != nullptr)) return 0;
+    if (!(x != nullptr && ldx >= K && g != nullptr && ldg >= N)) return 0;
     const int S = wgrad_splits(M, K, N);
-    RECALGO_REQUIRE(S == 1 || (workspace != nullptr && aligned16(workspace)));
-    hipStream_t st = as_stream(stream);
-    WgradArgs P;
+    if (!(S == 1 || (workspace != nullptr && aligned16(workspace)))) return 0;
     P.seg = Segment{operand(x, nullptr, ldx, M, K), operand(g, y_mask, ldg, M, N), M};
     P.K = K; P.N = N; P.splits = S;
     P.rows_per_split = cdiv(cdiv(M, S), BK) * BK;
@@ -590,15 +617,14 @@ RECALGO_EXPORT int recalgo_dense_bwd_weights(const float* x, int ldx, const floa
     P.slab = S == 1 ? 0 : wgrad_slab(K, N);
     P.out = S == 1 ? dw : static_cast<float*>(workspace);
     P.dbias_out = dbias;
-    const int grid = cdiv(K, BM) * cdiv(N, BN) * S;
-    const bool fast = fast_rm(P.seg.a, K) && fast_rm(P.seg.b, N);
-    if (fast && y_mask) hipLaunchKernelGGL((dense_wgrad_kernel<true, true>), dim3(grid), dim3(kThreads), 0, st, P);
-    else if (fast) hipLaunchKernelGGL((dense_wgrad_kernel<true, false>), dim3(grid), dim3(kThreads), 0, st, P);
-    else if (y_mask) hipLaunchKernelGGL((dense_wgrad_kernel<false, true>), dim3(grid), dim3(kThreads), 0, st, P);
-    else hipLaunchKernelGGL((dense_wgrad_kernel<false, false>), dim3(grid), dim3(kThreads), 0, st, P);
+    return S;
+}
+static bool wgrad_fast(const WgradArgs& P) { return fast_rm(P.seg.a, P.K) && fast_rm(P.seg.b, P.N); }
+
+static int finish_wgrad(int S, int defer_reduce, int K, int N, float* dw, float* dbias, void* workspace, hipStream_t st) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
     if (S > 1 && !defer_reduce) {
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return (int)e;
         SplitJobs J;
         unsigned blocks = 0;
         J.job[0] = make_split_job(static_cast<const float*>(workspace), S, K, N, dw, dbias, 0, &blocks);
@@ -606,7 +632,41 @@ RECALGO_EXPORT int recalgo_dense_bwd_weights(const float* x, int ldx, const floa
         J.step = nullptr;
         return launch_split_jobs(J, blocks, st);
     }
-    RECALGO_RETURN_LAST();
+    return 0;
+}
+
+RECALGO_EXPORT int recalgo_dense_bwd_weights(const float* x, int ldx, const float* g, int ldg, const float* y_mask,
+                                             int M, int K, int N, float* dw, float* dbias, void* workspace,
+                                             int defer_reduce, recalgo_stream_t stream) {
+    WgradArgs P;
+    const int S = build_wgrad(P, x, ldx, g, ldg, y_mask, M, K, N, dw, dbias, workspace);
+    RECALGO_REQUIRE(S >= 1);
+    hipStream_t st = as_stream(stream);
+    const int grid = cdiv(K, BM) * cdiv(N, BN) * S;
+    const bool fast = wgrad_fast(P);
+    if (fast && y_mask) hipLaunchKernelGGL((dense_wgrad_kernel<true, true>), dim3(grid), dim3(kThreads), 0, st, P);
+    else if (fast) hipLaunchKernelGGL((dense_wgrad_kernel<true, false>), dim3(grid), dim3(kThreads), 0, st, P);
+    else if (y_mask) hipLaunchKernelGGL((dense_wgrad_kernel<false, true>), dim3(grid), dim3(kThreads), 0, st, P);
+    else hipLaunchKernelGGL((dense_wgrad_kernel<false, false>), dim3(grid), dim3(kThreads), 0, st, P);
+    return finish_wgrad(S, defer_reduce, K, N, dw, dbias, workspace, st);
+}
+
+RECALGO_EXPORT int recalgo_dense_bwd(const float* x, int ldx, const float* g, int ldg, const float* y_mask, const float* w,
+                                     int M, int K, int N, const float* c_in, int ldc, float beta, float* dx, int lddx,
+                                     float* dw, float* dbias, void* workspace, int defer_reduce, recalgo_stream_t stream) {
+    DgradArgs D;
+    WgradArgs W;
+    RECALGO_REQUIRE(M > 0 && build_dgrad(D, g, ldg, y_mask, w, M, N, K, c_in, ldc, beta, dx, lddx, 0));
+    const int S = build_wgrad(W, x, ldx, g, ldg, y_mask, M, K, N, dw, dbias, workspace);
+    RECALGO_REQUIRE(S >= 1);
+    hipStream_t st = as_stream(stream);
+    const int gd = cdiv(M, BM) * cdiv(K, BN), gw = cdiv(K, BM) * cdiv(N, BN) * S;
+    const bool fast = dgrad_fast(D) && wgrad_fast(W);
+    if (fast && y_mask) hipLaunchKernelGGL((dense_bwd_kernel<true, true>), dim3(gd + gw), dim3(kThreads), 0, st, D, W, gd);
+    else if (fast) hipLaunchKernelGGL((dense_bwd_kernel<true, false>), dim3(gd + gw), dim3(kThreads), 0, st, D, W, gd);
+    else if (y_mask) hipLaunchKernelGGL((dense_bwd_kernel<false, true>), dim3(gd + gw), dim3(kThreads), 0, st, D, W, gd);
+    else hipLaunchKernelGGL((dense_bwd_kernel<false, false>), dim3(gd + gw), dim3(kThreads), 0, st, D, W, gd);
+    return finish_wgrad(S, defer_reduce, K, N, dw, dbias, workspace, st);
 }
 
 RECALGO_EXPORT int recalgo_dense_bwd_weights_reduce(const recalgo_dense_split_t* jobs, int n_jobs,

@@ -51,6 +51,16 @@ class GradJoin:
         return t
 
 
+def _wgrad_side_stream() -> bool:
+    import os
+    return os.environ.get("RECALGO_WGRAD_STREAM", "0") == "1"
+
+
+def _merged_bwd() -> bool:
+    import os
+    return os.environ.get("RECALGO_DENSE_MERGED_BWD", "1") != "0"
+
+
 class _DenseFn(Function):
     @staticmethod
     def forward(ctx, anchor, x, kernel: Variable, bias: Optional[Variable], relu: bool, input_l2: float = 0.0,
@@ -86,9 +96,28 @@ class _DenseFn(Function):
         if ctx.hip:
             if g2.stride(1) != 1 or (y is not None and g2.stride() != y.stride()):
                 g2 = g2.contiguous()
-            # the ReLU mask rides on the staging of g in both kernels; the bias gradient on the weight-gradient one
-            ops.dense_bwd_weights(x2, g2, y if ctx.relu else None, kernel.grad, None if bias is None else bias.grad,
-                                  defer=True)           # split partials are summed by ONE launch per backward pass
+            # the ReLU mask rides on the staging of g in both GEMMs, the bias gradient on the weight-gradient one; the
+            # split partials of the weight gradient are summed by ONE launch per backward pass (ops.flush_dense_splits)
+            mask = y if ctx.relu else None
+            db = None if bias is None else bias.grad
+            if ctx.needs_input_grad[1] and _merged_bwd():
+                # input and weight gradient in ONE launch
+                dx = ops.dense_bwd(x2, g2, mask, kernel.data, kernel.grad, db, c_in=x2 if ctx.input_l2 else None,
+                                   beta=ctx.input_l2, defer=True).view(ctx.xshape)
+                if ctx.grad_join is not None and ctx.grad_join.park(dx):
+                    dx = None                      # added by the other consumer of x in its backward kernel
+                return None, dx, None, None, None, None, None
+            if _wgrad_side_stream():
+                # (measured: slower — DCN step 0.319 vs 0.268 ms: the cross-stream dependencies cost more than the overlap
+                # buys.  Kept as an experiment switch.)
+                cur, side = torch.cuda.current_stream(g2.device), ops.side_stream(g2.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    ops.dense_bwd_weights(x2, g2, mask, kernel.grad, db, defer=True)
+                ops._side_keepalive.append((x2, g2, y))
+                ops._side_dirty.add(g2.device)
+            else:
+                ops.dense_bwd_weights(x2, g2, mask, kernel.grad, db, defer=True)
             dx = None
             if ctx.needs_input_grad[1]:
                 dx = ops.dense_bwd_input(g2, y if ctx.relu else None, kernel.data,

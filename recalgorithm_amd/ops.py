@@ -738,6 +738,29 @@ def dense_bwd_input(g: torch.Tensor, y_mask: Optional[torch.Tensor], w: torch.Te
     return dx
 
 
+_side_streams = {}
+_side_keepalive = []         # tensors a side-stream kernel still reads (kept alive until the streams are joined)
+_side_dirty = set()          # devices whose side stream has un-joined work
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    """The second HIP stream of the step (one per device): the weight-gradient GEMMs run on it, concurrently with the
+    input-gradient chain on the main stream (they only meet again in the step's deferred-sum launch)."""
+    key = (device.type, device.index)
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def join_side_streams() -> None:
+    """Make the current stream wait for the side-stream work of this step."""
+    for dev in list(_side_dirty):
+        torch.cuda.current_stream(dev).wait_stream(side_stream(dev))
+    _side_dirty.clear()
+    _side_keepalive.clear()
+
+
 _dense_ws = {}
 _dense_pending = []          # deferred split reductions of this backward pass: (M, K, N, ws, dw, dbias)
 _colsum_pending = []         # deferred plain column sums: (partials, element offset, rows, row_stride, n, out)
@@ -784,10 +807,42 @@ def dense_bwd_weights(x: torch.Tensor, g: torch.Tensor, y_mask: Optional[torch.T
         _dense_pending.append((M, K, N, ws, dw, dbias))
 
 
+def dense_bwd(x: torch.Tensor, g: torch.Tensor, y_mask: Optional[torch.Tensor], w: torch.Tensor, dw: torch.Tensor,
+              dbias: Optional[torch.Tensor], c_in: Optional[torch.Tensor] = None, beta: float = 0.0,
+              defer: bool = False) -> torch.Tensor:
+    """Both gradients of a dense layer in one launch (recalgo_dense_bwd): returns dx = (g * [y_mask > 0]) @ w^T
+    (+ beta * c_in); dw / dbias as dense_bwd_weights (valid after flush_dense_splits() when `defer`)."""
+    x, g, w = _mat(x, "x"), _mat(g, "g"), _mat(w, "w")
+    M, K = x.shape
+    N = g.shape[1]
+    if M == 0:
+        dense_bwd_weights(x, g, y_mask, dw, dbias)
+        return torch.zeros(0, K, device=g.device, dtype=torch.float32)
+    if g.shape[0] != M or tuple(dw.shape) != (K, N) or not dw.is_contiguous() or tuple(w.shape) != (K, N) or w.stride(0) != N:
+        raise ValueError("dense_bwd: shape mismatch")
+    if y_mask is not None and (y_mask.shape != g.shape or y_mask.stride() != g.stride()):
+        raise ValueError("dense_bwd: y_mask must have g's layout")
+    lib = _lib_()
+    nbytes = int(lib.recalgo_dense_bwd_weights_workspace_bytes(M, K, N))
+    key = (x.device.type, x.device.index, M, K, N, dw.data_ptr() if defer else 0)
+    ws = _dense_ws.get(key)
+    if ws is None:
+        ws = _dense_ws[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    defer = bool(defer and nbytes > 0)
+    dx = torch.empty(M, K, device=g.device, dtype=torch.float32)
+    _lib.check(lib.recalgo_dense_bwd(_p(x), x.stride(0), _p(g), g.stride(0), _p(y_mask), _p(w), M, K, N, _p(c_in),
+                                     0 if c_in is None else c_in.stride(0), float(beta), _p(dx), K, _p(dw), _p(dbias), _p(ws),
+                                     int(defer), _stream(x)), "recalgo_dense_bwd")
+    if defer:
+        _dense_pending.append((M, K, N, ws, dw, dbias))
+    return dx
+
+
 def flush_dense_splits(step_dev: Optional[torch.Tensor] = None) -> None:
     """Finish every deferred sum of the step in ONE launch: the weight-gradient split reductions of `dense`, the column
     sums the loss tail left behind, and (`step_dev`, the optimizer's int64 step counter) the step increment — the
     optimizer kernel that follows then only reads the counter."""
+    join_side_streams()
     if not _dense_pending and not _colsum_pending and step_dev is None:
         return
     jobs = (_DenseSplit * max(len(_dense_pending), 1))()

@@ -115,3 +115,17 @@ def test_dense_wgrad_split_handoff_stress(dev, M, K, N):
         assert_close(dw, ref, what=f"wgrad launch {it}", reduced=True)
         assert_close(db, g2.sum(0), what=f"dbias launch {it}", reduced=True)
         assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("M,K,N", [(4096, 416, 512), (4096, 256, 128), (300, 82, 50)])
+def test_dense_merged_bwd_is_bit_identical_to_the_two_launches(dev, M, K, N):
+    """recalgo_dense_bwd (input + weight gradient tiles in one grid) runs the same tiles as the two separate launches."""
+    gen = torch.Generator(device=dev).manual_seed(M + N)
+    x, g, y = (torch.randn(M, c, device=dev, generator=gen) for c in (K, N, N))
+    w = torch.randn(K, N, device=dev, generator=gen) / K ** 0.5
+    c_in = torch.randn(M, K, device=dev, generator=gen)
+    dw, db, dw2, db2 = torch.empty(K, N, device=dev), torch.empty(N, device=dev), torch.empty(K, N, device=dev), torch.empty(N, device=dev)
+    dx = ops.dense_bwd(x, g, y, w, dw, db, c_in=c_in, beta=0.5)
+    dx2 = ops.dense_bwd_input(g, y, w, c_in=c_in, beta=0.5)
+    ops.dense_bwd_weights(x, g, y, dw2, db2)
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)

@@ -374,5 +374,5 @@ def test_fused_train_step_matches_unfused_graph(dev, model):
             # a dense bias in front of a training-mode BatchNorm: its gradient cancels analytically, what is left is
             # rounding noise, and Adam's g / (|g| + eps') turns noise into O(lr) moves — not comparable run to run
             continue
-        assert_close(A[k], B_[k].double(), rtol=2e-5, what=f"{model} {k}: fused vs op-by-op after 3 steps", reduced=True)
+        assert_close(A[k], B_[k].double(), rtol=1e-4, what=f"{model} {k}: fused vs op-by-op after 3 steps", reduced=True)
     assert int(a.store.opt_state["step"]) == int(b.store.opt_state["step"]) == 3
