@@ -80,7 +80,10 @@ struct StageRegs {
     float4 m[2];           // raw mask values (MASK only); applied when the tile is written to LDS
 };
 
-template <bool RC, bool FAST, bool MASK>
+// EXACT (FAST only): the reduction extent is a whole number of chunks — the chunk advance is then a scalar offset of the
+// buffer load and no per-load bounds arithmetic is left (loads past the end fetch in-bounds garbage or OOB zeros into
+// ring slots that are never consumed).
+template <bool RC, bool FAST, bool MASK, bool EXACT>
 struct Stager {
     __amdgpu_buffer_rsrc_t rs, rm;     // FAST
     int off[2];                        // FAST: byte offsets of this thread's two float4 at chunk 0 (kOOB: never valid)
@@ -121,9 +124,15 @@ struct Stager {
         if constexpr (FAST) {
             // beyond red_end (the split's end, or the matrix's): zeros.  idx beyond n_idx: off[j] is already kOOB
             // (kOOB + c * step_b stays >= 2^31 as an unsigned offset for every c the loop can reach)
-            const int o = r < red_end ? off[j] + c * step_b : kOOB;
-            st.v[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0));
-            if constexpr (MASK) st.m[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rm, o, 0, 0));
+            if constexpr (EXACT) {
+                const int so = c * step_b;                 // wave-uniform: an SGPR offset
+                st.v[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off[j], so, 0));
+                if constexpr (MASK) st.m[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rm, off[j], so, 0));
+            } else {
+                const int o = r < red_end ? off[j] + c * step_b : kOOB;
+                st.v[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0));
+                if constexpr (MASK) st.m[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rm, o, 0, 0));
+            }
         } else {
             float4 v = f4_zero(), mk = make_float4(1.f, 1.f, 1.f, 1.f);
             const size_t o = (size_t)c * step;
@@ -198,16 +207,16 @@ constexpr int kStages = 3;                        // LDS ring
 //                 one barrier
 // LDS ring of 3: while chunk c+1 is read out of slot (c+1) % 3, chunk c+2 lands in slot (c+2) % 3 = (c-1) % 3, whose
 // last readers passed two barriers ago.  Loads and slots past the end of the reduction are zeros / unused.
-template <bool A_RC, bool B_RC, bool FAST, bool MASK_A, bool MASK_B, bool COLSUM>
-__device__ __forceinline__ void tile_mainloop(const Segment& sg, int m0, int n0, int M, int N, int red_begin, int red_end,
+template <bool A_RC, bool B_RC, bool FAST, bool MASK_A, bool MASK_B, bool COLSUM, bool EXACT>
+__device__ __forceinline__ void tile_mainloop_impl(const Segment& sg, int m0, int n0, int M, int N, int red_begin, int red_end,
                                               float* __restrict__ As, float* __restrict__ Bs, f32x16& acc, f32x16& acc1, float4& colsum) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hi = lane >> 5, l32 = lane & 31;
     const int am = (wave >> 1) * 32 + l32, bn = (wave & 1) * 32 + l32;
     const int nchunks = (red_end - red_begin + BK - 1) / BK;
     if (nchunks <= 0) return;
-    Stager<A_RC, FAST, MASK_A> ga;
-    Stager<B_RC, FAST, MASK_B> gb;
+    Stager<A_RC, FAST, MASK_A, EXACT> ga;
+    Stager<B_RC, FAST, MASK_B, EXACT> gb;
     ga.init(sg.a, m0, red_begin, M, red_end);
     gb.init(sg.b, n0, red_begin, N, red_end);
     StageRegs<MASK_A> sa0, sa1;
@@ -222,7 +231,7 @@ __device__ __forceinline__ void tile_mainloop(const Segment& sg, int m0, int n0,
     stage_store<B_RC, MASK_B>(Bs + kBufFloats, sb1);
     if constexpr (COLSUM) {
         colsum = f4_add(colsum, f4_add(staged<MASK_B>(sb0, 0), staged<MASK_B>(sb0, 1)));
-        colsum = f4_add(colsum, f4_add(staged<MASK_B>(sb1, 0), staged<MASK_B>(sb1, 1)));
+        if (nchunks > 1) colsum = f4_add(colsum, f4_add(staged<MASK_B>(sb1, 0), staged<MASK_B>(sb1, 1)));
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) { ga.issue(2, j, sa0); gb.issue(2, j, sb0); }
@@ -246,15 +255,23 @@ __device__ __forceinline__ void tile_mainloop(const Segment& sg, int m0, int n0,
             if (k & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k], fb[k], acc1, 0, 0, 0);
             else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k], fb[k], acc, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            // side work of the iteration, spread so that no MFMA shadow is overfull and the last two are free (the
+            // LDS traffic has drained by the time the barrier is reached)
             if (k < 2) ga.issue(c + 3, k, nxtA);
             else if (k < 4) gb.issue(c + 3, k - 2, nxtB);
-            if (k & 1) read_frag_pair<B_RC>(rB, bn, hi, k - 1, nb);
-            else read_frag_pair<A_RC>(rA, am, hi, k, na);
-            if (k >= 8 && k < 8 + (A_RC ? 4 : 2)) stage_store_piece<A_RC, MASK_A>(wA, curA, k - 8);
-            if (k >= 12 && k < 12 + (B_RC ? 4 : 2)) stage_store_piece<B_RC, MASK_B>(wB, curB, k - 12);
+            if (k < 8) {
+                read_frag_pair<A_RC>(rA, am, hi, 2 * k, na);
+                read_frag_pair<B_RC>(rB, bn, hi, 2 * k, nb);
+            }
+            constexpr int nA = A_RC ? 4 : 2, nB = B_RC ? 4 : 2, w0 = 14 - nA - nB;       // stores end at k = 13
+            if (k >= w0 && k < w0 + nA) stage_store_piece<A_RC, MASK_A>(wA, curA, k - w0);
+            if (k >= w0 + nA && k < w0 + nA + nB) stage_store_piece<B_RC, MASK_B>(wB, curB, k - w0 - nA);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (COLSUM) colsum = f4_add(colsum, f4_add(staged<MASK_B>(curB, 0), staged<MASK_B>(curB, 1)));
+        if constexpr (COLSUM) {
+            // chunk c+2; staged tiles past the end of the reduction hold garbage (EXACT) and must not be counted
+            if (c + 2 < nchunks) colsum = f4_add(colsum, f4_add(staged<MASK_B>(curB, 0), staged<MASK_B>(curB, 1)));
+        }
         s1 = s2;
         s2 = s2 + 1 == kStages ? 0 : s2 + 1;
         __syncthreads();
@@ -263,6 +280,15 @@ __device__ __forceinline__ void tile_mainloop(const Segment& sg, int m0, int n0,
         step(c, fa0, fb0, fa1, fb1, sa0, sb0, sa1, sb1);
         if (c + 1 < nchunks) step(c + 1, fa1, fb1, fa0, fb0, sa1, sb1, sa0, sb0);
     }
+}
+
+template <bool A_RC, bool B_RC, bool FAST, bool MASK_A, bool MASK_B, bool COLSUM>
+__device__ __forceinline__ void tile_mainloop(const Segment& sg, int m0, int n0, int M, int N, int red_begin, int red_end,
+                                              float* __restrict__ As, float* __restrict__ Bs, f32x16& acc, f32x16& acc1, float4& colsum) {
+    // whole chunks only (and, for a batch split, split boundaries on chunk boundaries): wave-uniform
+    const bool exact = FAST && ((red_end - red_begin) % BK == 0) && (red_begin % BK == 0);
+    if (exact) tile_mainloop_impl<A_RC, B_RC, FAST, MASK_A, MASK_B, COLSUM, FAST>(sg, m0, n0, M, N, red_begin, red_end, As, Bs, acc, acc1, colsum);
+    else tile_mainloop_impl<A_RC, B_RC, FAST, MASK_A, MASK_B, COLSUM, false>(sg, m0, n0, M, N, red_begin, red_end, As, Bs, acc, acc1, colsum);
 }
 
 // XCD-aware linear block -> (tile_m, tile_n): block b runs on XCD b % 8; give every XCD a contiguous
