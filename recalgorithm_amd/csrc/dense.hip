@@ -543,9 +543,13 @@ inline Operand operand(const float* p, const float* mask, int ld, int64_t rows, 
 inline bool fast_rc(const Operand& o, int n_red) { return o.p == nullptr || (o.vec && o.bytes > 0 && n_red % 4 == 0); }
 inline bool fast_rm(const Operand& o, int n_idx) { return o.p == nullptr || (o.vec && o.bytes > 0 && n_idx % 4 == 0); }
 
+// workgroups a weight-gradient grid aims for (it shares its launch with the 64-256 input-gradient workgroups of the
+// same layer); RECALGO_DENSE_WGRAD_BLOCKS overrides (tuning knob)
+static const int kWgradTargetBlocks = [] { const char* e = getenv("RECALGO_DENSE_WGRAD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+
 inline int wgrad_splits(int M, int K, int N) {
     const int ntiles = cdiv(K, BM) * cdiv(N, BN);
-    int want = cdiv(512, ntiles);                       // >= 2 workgroups per CU
+    int want = cdiv(kWgradTargetBlocks, ntiles);
     const int max_s = cdiv(M, 4 * BK);                  // at least four chunks per split
     if (want > max_s) want = max_s;
     if (want >= 8) want = want / 8 * 8;                 // whole XCD groups

@@ -325,33 +325,44 @@ struct TailArgs {
 };
 
 __global__ __launch_bounds__(256) void logit_loss_kernel(TailArgs P) {
+    // dynamic LDS: the workgroup's [kTailRows][C] tile of the (virtually concatenated) inputs + the C weights: the
+    // inputs are read from HBM once and serve both the dot products and the weight-gradient column pass
+    extern __shared__ __attribute__((aligned(16))) float tail_smem[];
     __shared__ float s_dl[kTailRows], s_loss[kTailRows];
+    const int C = P.C;
+    float* tile = tail_smem;                      // [kTailRows][C]
+    float* wcat = tail_smem + kTailRows * C;      // [C]
     const int b0 = blockIdx.x * kTailRows;
     const int nb = min(kTailRows, P.B - b0);
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float invB = 1.0f / (float)P.B;
-    // phase 1: wave w owns rows w, w + 4, ...; the loads of all its rows are in flight together
     constexpr int RW = kTailRows / 4;
-    float acc[RW];
-#pragma unroll
-    for (int i = 0; i < RW; ++i) acc[i] = 0.f;
-    for (int p = 0; p < P.n; ++p) {
-        const int W = P.width[p];
-        const float* __restrict__ wp = P.w[p];
-        for (int j = lane; j < W; j += 64) {
-            const float wj = wp[j];
+    {
+        int off = 0;
+        for (int p = 0; p < P.n; ++p) {
+            const int W = P.width[p];
+            for (int j = threadIdx.x; j < W; j += 256) wcat[off + j] = P.w[p][j];
 #pragma unroll
             for (int i = 0; i < RW; ++i) {
                 const int r = wave + 4 * i;
-                if (r < nb) acc[i] = fmaf(P.x[p][(size_t)(b0 + r) * W + j], wj, acc[i]);
+                if (r < nb) {
+                    const float* __restrict__ xr = P.x[p] + (size_t)(b0 + r) * W;
+                    for (int j = lane; j < W; j += 64) tile[r * C + off + j] = xr[j];
+                }
             }
+            off += W;
         }
     }
+    __syncthreads();
+    // phase 1: wave w owns rows w, w + 4, ...
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
         const int r = wave + 4 * i;
         float d = 0.f, ls = 0.f;
-        const float dot = wave_sum(acc[i]);
+        float acc = 0.f;
+        if (r < nb)
+            for (int c = lane; c < C; c += 64) acc = fmaf(tile[r * C + c], wcat[c], acc);
+        const float dot = wave_sum(acc);
         if (r < nb) {
             const int b = b0 + r;
             float x = dot + (P.bias ? P.bias[0] : 0.f);
@@ -372,30 +383,29 @@ __global__ __launch_bounds__(256) void logit_loss_kernel(TailArgs P) {
         if (lane == 0) { s_dl[r] = d; s_loss[r] = ls; }
     }
     __syncthreads();
-    float* __restrict__ prow = P.partials + (size_t)blockIdx.x * (P.C + 2);
-    for (int c = threadIdx.x; c < P.C; c += 256) {
+    // phase 2: one thread per column of the concatenation
+    float* __restrict__ prow = P.partials + (size_t)blockIdx.x * (C + 2);
+    for (int c = threadIdx.x; c < C; c += 256) {
         int p = 0, off = 0;
         while (c >= off + P.width[p]) off += P.width[p++];
         const int W = P.width[p], j = c - off;
-        const float* __restrict__ xp = P.x[p] + (size_t)b0 * W + j;
         float* __restrict__ dxp = P.dx[p] ? P.dx[p] + (size_t)b0 * W + j : nullptr;
-        const float wj = P.w[p][j];
+        const float wj = wcat[c];
         float acc = 0.f;
-        float xv[kTailRows];
-#pragma unroll
-        for (int r = 0; r < kTailRows; ++r) xv[r] = r < nb ? xp[(size_t)r * W] : 0.f;
 #pragma unroll
         for (int r = 0; r < kTailRows; ++r) {
-            acc = fmaf(s_dl[r], xv[r], acc);
-            if (dxp && r < nb) dxp[(size_t)r * W] = s_dl[r] * wj;
+            if (r < nb) {
+                acc = fmaf(s_dl[r], tile[r * C + c], acc);
+                if (dxp) dxp[(size_t)r * W] = s_dl[r] * wj;
+            }
         }
         prow[c] = acc;
     }
     if (threadIdx.x == 0) {
         float sd = 0.f, sl = 0.f;
         for (int r = 0; r < kTailRows; ++r) { sd += s_dl[r]; sl += s_loss[r]; }
-        prow[P.C] = sd;
-        prow[P.C + 1] = sl * invB + ((blockIdx.x == 0 && P.loss_addend) ? P.loss_addend[0] : 0.f);
+        prow[C] = sd;
+        prow[C + 1] = sl * invB + ((blockIdx.x == 0 && P.loss_addend) ? P.loss_addend[0] : 0.f);
     }
 }
 
@@ -548,6 +558,13 @@ RECALGO_EXPORT int recalgo_logit_loss_fwd_bwd(const float* const* x_parts, const
     }
     P.bias = bias; P.addend[0] = addend0; P.addend[1] = addend1; P.labels = labels; P.loss_addend = loss_addend; P.grad_scale = grad_scale;
     P.logit = logit; P.prob = prob; P.dlogit = dlogit; P.partials = partials; P.B = B;
-    hipLaunchKernelGGL(logit_loss_kernel, dim3(cdiv(B, kTailRows)), dim3(256), 0, as_stream(stream), P);
+    const size_t smem = (size_t)(kTailRows + 1) * P.C * sizeof(float);
+    RECALGO_REQUIRE(smem <= 150 * 1024);
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&logit_loss_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(logit_loss_kernel, dim3(cdiv(B, kTailRows)), dim3(256), smem, as_stream(stream), P);
     RECALGO_RETURN_LAST();
 }

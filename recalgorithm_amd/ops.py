@@ -1051,6 +1051,7 @@ class _LogitLossFn(Function):
 
 def logit_loss_supported(parts, addends) -> bool:
     return (_loss_seed is not None and torch.is_grad_enabled() and dense1_supported(parts) and len(addends) <= 2
+            and sum(int(t.shape[1]) for t in parts) <= 4096          # the kernel keeps an [8, C] tile + the weights in LDS
             and all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == 1 for t in addends))
 
 
