@@ -42,7 +42,9 @@ def cross_network(x0: torch.Tensor, num_cross_layer: int, grad_join=None) -> tor
         return x0
     w, _ = store.get_variable_block("wl", [f"wl_{i}" for i in range(L)], (d, 1))
     b, _ = store.get_variable_block("bl", [f"bl_{i}" for i in range(L)], (d, 1))
-    if L > 6 or d > 1024:        # outside the fused kernel's envelope: layer by layer
+    # outside the fused kernel's envelope — more than 6 layers, d > 1024, or d > 512 with >= 4 fused layers (its backward
+    # would spill registers, profiles/r01_kernel_resource_usage.md): layer by layer with the single-layer kernels
+    if L > 6 or d > 1024 or (d > 512 and L >= 4):
         if grad_join is not None:
             grad_join.consumer_done = True        # no fused consumer: the other branch returns its gradient normally
         xl = x0

@@ -87,16 +87,24 @@ def _dataset(filepath, example_parser, batch_size, num_epochs, shuffle_buffer_si
     batches (tests/test_native_reader.py); only the shuffle order differs (different seeded generators)."""
     import os
     from ..io import native
+    seed = _shuffle_seed()
     getter = getattr(example_parser, "columns_getter", None)
     if getter is not None and isinstance(filepath, str) and native.available() \
             and os.environ.get("RECALGO_PYTHON_READER", "0") != "1":
         total, label = getter()
         try:
             return native.NativeDataset(filepath, list(total) + list(label), [c.key for c in label], batch_size,
-                                        num_epochs, shuffle_buffer_size)
+                                        num_epochs, shuffle_buffer_size, seed=seed)
         except (ValueError, TypeError):
             pass                     # e.g. identity columns without a vocabulary file
-    return _Dataset(filepath, example_parser, batch_size, num_epochs, shuffle_buffer_size)
+    return _Dataset(filepath, example_parser, batch_size, num_epochs, shuffle_buffer_size, seed=seed)
+
+
+def _shuffle_seed() -> int:
+    """dataset.shuffle(buffer) without a seed (utils.py:19) draws a fresh order every run; RECALGO_SHUFFLE_SEED pins it."""
+    import os
+    e = os.environ.get("RECALGO_SHUFFLE_SEED")
+    return int(e) if e is not None else int.from_bytes(os.urandom(8), "little") >> 1
 
 
 def train_input_fn(filepath, example_parser: Callable, batch_size, num_epochs, shuffle_buffer_size):

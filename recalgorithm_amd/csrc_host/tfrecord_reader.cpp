@@ -287,7 +287,8 @@ struct Reader {
     size_t shuffle = 0;                                    // dataset.shuffle(buffer_size), 0 = off
     uint64_t rng = 0x9E3779B97F4A7C15ull;
     std::vector<Span> pool;                                // shuffle buffer
-    bool source_done = false;
+    bool source_done = false;                              // every pass of dataset.repeat() consumed
+    bool pass_done = false;                                // current pass read to its end (shuffle buffer draining)
     std::vector<Span> recs;                                // payloads of the current batch
     // per record: its (name, Feature span) pairs in wire order (built lazily per batch).  Records of
     // one writer list their features in one order, so a lookup starts at the position the key had
@@ -356,14 +357,9 @@ uint64_t next_rand(Reader& r) {                            // xorshift64*
     return r.rng * 0x2545F4914F6CDD1Dull;
 }
 
-// next record of the (repeated) file: 1 = ok, 0 = end of data, -1 = error
+// next record of the CURRENT pass over the file: 1 = ok, 0 = end of the pass, -1 = error
 int read_one(Reader& r, Span& out) {
-    if (r.pos >= r.size) {
-        ++r.epoch;
-        if (r.epochs >= 0 && r.epoch >= r.epochs) return 0;
-        r.pos = 0;
-        if (r.size == 0) return 0;                         // empty file
-    }
+    if (r.pos >= r.size) return 0;
     if (r.size - r.pos < 12) {
         r.error = "truncated record header";
         return -1;
@@ -389,30 +385,52 @@ int read_one(Reader& r, Span& out) {
     return 1;
 }
 
-// next record after the shuffle buffer (tf.data semantics: fill the buffer, emit a random slot and
-// refill it from the source; drain in random order at the end)
+// start the next pass if dataset.repeat() has one left: true = rewound
+bool next_epoch(Reader& r) {
+    ++r.epoch;
+    if ((r.epochs >= 0 && r.epoch >= r.epochs) || r.size == 0) return false;
+    r.pos = 0;
+    return true;
+}
+
+// next record of dataset.shuffle(buffer).repeat(epochs) — the reference's order (algorithm/utils.py:19-21: shuffle
+// BEFORE repeat): within a pass tf.data fills the buffer, emits a random slot and refills it from the source; at
+// the end of the pass the buffer is drained in random order, and only then does the next pass start, so records of
+// different epochs never mix.
 int next_record(Reader& r, Span& out) {
-    if (r.shuffle == 0) return r.source_done ? 0 : read_one(r, out);
-    while (!r.source_done && r.pool.size() < r.shuffle) {
-        Span rec;
-        int rc = read_one(r, rec);
-        if (rc < 0) return -1;
-        if (rc == 0) { r.source_done = true; break; }
-        r.pool.push_back(rec);
+    for (;;) {
+        if (r.source_done) return 0;
+        if (r.shuffle == 0) {
+            int rc = read_one(r, out);
+            if (rc != 0) return rc;
+            if (!next_epoch(r)) { r.source_done = true; return 0; }
+            continue;
+        }
+        while (!r.pass_done && r.pool.size() < r.shuffle) {
+            Span rec;
+            int rc = read_one(r, rec);
+            if (rc < 0) return -1;
+            if (rc == 0) { r.pass_done = true; break; }
+            r.pool.push_back(rec);
+        }
+        if (r.pool.empty()) {                              // pass drained: on to the next one
+            if (!next_epoch(r)) { r.source_done = true; return 0; }
+            r.pass_done = false;
+            continue;
+        }
+        const size_t j = (size_t)(next_rand(r) % r.pool.size());
+        out = r.pool[j];
+        if (!r.pass_done) {
+            int rc = read_one(r, r.pool[j]);
+            if (rc < 0) return -1;
+            if (rc == 0) r.pass_done = true;
+        }
+        if (r.pass_done) {                                 // slot j is stale: close the gap
+            r.pool[j] = r.pool.back();
+            r.pool.pop_back();
+        }
+        return 1;
     }
-    if (r.pool.empty()) return 0;
-    const size_t j = (size_t)(next_rand(r) % r.pool.size());
-    out = r.pool[j];
-    if (!r.source_done) {
-        int rc = read_one(r, r.pool[j]);
-        if (rc < 0) return -1;
-        if (rc == 0) r.source_done = true;
-    }
-    if (r.source_done) {                                   // slot j is stale: close the gap
-        r.pool[j] = r.pool.back();
-        r.pool.pop_back();
-    }
-    return 1;
 }
 
 }  // namespace
@@ -501,6 +519,7 @@ EXPORT int recalgo_reader_rewind(void* reader) {
     auto* r = (Reader*)reader;
     r->epoch = 0;
     r->source_done = false;
+    r->pass_done = false;
     r->pool.clear();
     r->pos = 0;
     return 0;

@@ -198,7 +198,35 @@ def _tree_tensors(obj, prefix=""):
             yield from _tree_tensors(obj[k], f"{prefix}/{k}")
 
 
+def _clone_tree(obj):
+    """Deep copy of a (features, labels) tree of tensors / Ragged / dicts that preserves storage sharing: tensors that
+    are views of one allocation become views (same offset / strides) of ONE cloned allocation."""
+    from .feature_column import Ragged
+    storages = {}
+
+    def cl(t):
+        st = t.untyped_storage()
+        key = st.data_ptr()
+        if key not in storages:
+            whole = torch.empty(0, dtype=torch.uint8, device=t.device).set_(st, 0, (st.nbytes(),), (1,))
+            storages[key] = whole.clone().untyped_storage()
+        return torch.empty(0, dtype=t.dtype, device=t.device).set_(storages[key], t.storage_offset(), t.shape, t.stride())
+
+    def walk(o):
+        if isinstance(o, torch.Tensor):
+            return cl(o)
+        if isinstance(o, Ragged):
+            return Ragged(cl(o.values), cl(o.offsets))
+        if isinstance(o, dict):
+            return {k: walk(v) for k, v in o.items()}
+        if isinstance(o, (tuple, list)):
+            return type(o)(walk(v) for v in o)
+        return o
+    return walk(obj)
+
+
 HOUSEKEEPING_EVERY = 32      # steps between VariableStore.housekeeping() calls (live-row list ordering)
+OVERFLOW_POLL_EVERY = 64     # steps between reads of the static row-exchange overflow flag (N > 1; one host sync)
 
 
 class GraphedTrainStep:
@@ -208,6 +236,10 @@ class GraphedTrainStep:
 
     def __init__(self, step_fn: Callable, features, labels, warmup: int = 3):
         self.step_fn = step_fn
+        # PRIVATE static input buffers: clones of the first batch (storage-preserving: the 26 id columns of one [B, F]
+        # matrix stay views of one allocation).  Capturing on the caller's tensors would overwrite the user's batch on
+        # every load() and replay stale data when that tensor comes round again.
+        features, labels = _clone_tree((features, labels))
         self.static_f, self.static_l = features, labels
         self._static = list(_tree_tensors(features, "f")) + list(_tree_tensors(labels, "l"))
         s = torch.cuda.Stream()
@@ -236,8 +268,6 @@ class GraphedTrainStep:
         for (k0, dst), (k1, src) in zip(self._static, new):
             if k0 != k1 or dst.shape != src.shape:
                 raise ValueError(f"graphed step: input {k1} changed shape/structure")
-            if dst.data_ptr() == src.data_ptr():
-                continue
             ds, ss = dst.untyped_storage(), src.untyped_storage()
             if (dst.dtype == src.dtype and dst.stride() == src.stride() and ds.nbytes() == ss.nbytes()
                     and dst.storage_offset() == src.storage_offset() and src.device == dst.device):
@@ -401,9 +431,12 @@ class Estimator:
             if log_every and self.global_step % log_every < 1:
                 print(f"[recalgo] step {self.global_step} loss {float(loss):.6f} "
                       f"({n / max(time.time() - t0, 1e-9):.1f} steps/s)", flush=True)
+            if self.global_step % OVERFLOW_POLL_EVERY == 0:
+                self._check_exchange_overflow()
             sc = self.config.save_checkpoints_steps
             if sc and self.config.model_dir and self.global_step % sc == 0:
                 self.save_checkpoint()
+        self._check_exchange_overflow()
         if self.config.model_dir:
             self.save_checkpoint()
         return self
@@ -447,19 +480,17 @@ class Estimator:
         return os.path.join(self.config.model_dir, "model.ckpt.pt")
 
     def save_checkpoint(self):
-        os.makedirs(self.config.model_dir, exist_ok=True)
-        state = {
-            "global_step": self.global_step,
-            "variables": {k: v.detach().cpu() for k, v in self.store.named_arrays().items()},
-            "flat_m": None if self.store.flat_m is None else self.store.flat_m.cpu(),
-            "flat_v": None if self.store.flat_v is None else self.store.flat_v.cpu(),
-            "arena_m": {n: a.m.cpu() for n, a in self.store.arenas.items()},
-            "arena_v": {n: a.v.cpu() for n, a in self.store.arenas.items()},
-            "opt_step": None if self.store.opt_state is None else int(self.store.opt_state["step"]),
-        }
-        tmp = self._ckpt_path() + ".tmp"
-        torch.save(state, tmp)
-        os.replace(tmp, self._ckpt_path())
+        """Every rank must call (collective when the arenas are row-sharded): the shards are gathered, rank 0 writes."""
+        self._check_exchange_overflow()
+        state, writer = collect_checkpoint_state(self.store, self.global_step)
+        if writer:
+            os.makedirs(self.config.model_dir, exist_ok=True)
+            tmp = self._ckpt_path() + ".tmp"
+            torch.save(state, tmp)
+            os.replace(tmp, self._ckpt_path())
+        sh = getattr(self, "shard_spec", None)
+        if sh is not None and sh.world > 1:
+            sh.dist.barrier(group=sh.group)            # nobody resumes from a half-written file
 
     # -- variables by their reference (TF) names (SURVEY.md §8f-4) --------------------------------
     # The mirror keeps every variable under the reference's TF name with the reference's shape, with one
@@ -538,24 +569,95 @@ class Estimator:
         md = self.config.model_dir
         if not md or not os.path.exists(self._ckpt_path()):
             return
-        state = torch.load(self._ckpt_path(), map_location="cpu")
-        arrays = self.store.named_arrays()
-        for k, v in state["variables"].items():
-            if k in arrays and arrays[k].shape == v.shape:
-                arrays[k].copy_(v)
-        if state.get("flat_m") is not None and self.store.flat_m.shape == state["flat_m"].shape:
-            self.store.flat_m.copy_(state["flat_m"])
-            self.store.flat_v.copy_(state["flat_v"])
-        for n, a in self.store.arenas.items():
-            if n in state.get("arena_m", {}) and a.m.shape == state["arena_m"][n].shape:
-                a.m.copy_(state["arena_m"][n])
-                a.v.copy_(state["arena_v"][n])
-                a.live = None            # rebuilt from the restored moments on next use
-        if state.get("opt_step") is not None:
-            self.store.opt_state = {
-                "step": torch.tensor([state["opt_step"]], dtype=torch.int64, device=self.device),
-                "lr_t": torch.zeros(1, device=self.device)}
-        self.global_step = state["global_step"]
+        state = torch.load(self._ckpt_path(), map_location="cpu", weights_only=True)
+        self.global_step = restore_checkpoint_state(self.store, state, self.device, where=self._ckpt_path())
+
+    def _check_exchange_overflow(self):
+        """Row-sharded arenas with the static (graph-capturable) exchange drop the requests that do not fit a bucket
+        (the staged row reads as zeros, its gradient is discarded) and only raise a device flag: poll it."""
+        if getattr(self, "shard_spec", None) is None:
+            return
+        from .parallel import exchange_overflowed
+        if exchange_overflowed(self):
+            raise RuntimeError(
+                "row exchange bucket overflow: a (source, owner) bucket received more requests than its fixed capacity, "
+                "so some embedding rows were read as zeros and their gradients dropped since the last check.  Re-attach "
+                "with a larger capacity_factor (attach_data_parallel(..., capacity_factor=world) can never overflow) or "
+                "with capacity_factor=None (exact, eager exchange).")
+
+
+def collect_checkpoint_state(store: VariableStore, global_step: int):
+    """-> (state dict, this rank writes it).  COLLECTIVE when arenas are row-sharded (parallel.attach_data_parallel): the
+    weight / m / v shards are all_gather'ed back into whole tables, so the file is independent of the number of ranks
+    (restore happens before re-sharding); only rank 0 writes."""
+    from . import parallel
+    variables = {k: v.detach().cpu() for k, v in store.named_arrays(gather=True).items()}
+    arena_m, arena_v, writer = {}, {}, True
+    for n, a in store.arenas.items():
+        sd = getattr(a, "sharding", None)
+        if sd is not None:
+            arena_m[n] = parallel.unshard_arena(a, "m").cpu()
+            arena_v[n] = parallel.unshard_arena(a, "v").cpu()
+            writer = writer and sd.sh.rank == 0
+        else:
+            arena_m[n], arena_v[n] = a.m.cpu(), a.v.cpu()
+    state = {
+        "global_step": int(global_step),
+        "variables": variables,
+        "flat_m": None if store.flat_m is None else store.flat_m.cpu(),
+        "flat_v": None if store.flat_v is None else store.flat_v.cpu(),
+        "arena_m": arena_m, "arena_v": arena_v,
+        "opt_step": None if store.opt_state is None else int(store.opt_state["step"]),
+    }
+    return state, writer
+
+
+def restore_checkpoint_state(store: VariableStore, state: dict, device, where: str = "checkpoint") -> int:
+    """Load `state` into a built, NOT yet sharded store; returns the global step.  A variable that is missing from the
+    file or whose shape changed (another vocabulary, other hidden_units) makes the restore fail: resuming the step
+    counter and Adam's bias correction on a partly re-initialised model is never what the caller wants."""
+    if any(getattr(a, "sharding", None) is not None for a in store.arenas.values()):
+        raise RuntimeError("restore_checkpoint_state: restore before attach_data_parallel shards the arenas")
+    arrays = store.named_arrays()
+    saved = state["variables"]
+    blocks = {b for b, _ in store._alias.values()}
+    problems = []
+    for k, t in arrays.items():
+        if k in blocks:
+            continue                                           # fused blocks are covered by their named parts
+        if k not in saved:
+            problems.append(f"{k}: not in the file")
+        elif tuple(saved[k].shape) != tuple(t.shape):
+            problems.append(f"{k}: file has {tuple(saved[k].shape)}, model wants {tuple(t.shape)}")
+    for n, a in store.arenas.items():
+        for slot in ("arena_m", "arena_v"):
+            if n not in state.get(slot, {}) or tuple(state[slot][n].shape) != tuple(a.m.shape):
+                problems.append(f"{slot}[{n}]: missing or shape differs")
+    if state.get("flat_m") is not None and store.flat_m is not None and state["flat_m"].shape != store.flat_m.shape:
+        problems.append(f"dense Adam moments: file has {tuple(state['flat_m'].shape)}, model wants {tuple(store.flat_m.shape)}")
+    if problems:
+        raise RuntimeError(f"{where} does not match the model ({len(problems)} problem(s)): " + "; ".join(problems[:8])
+                           + (" ..." if len(problems) > 8 else ""))
+    unused = [k for k in saved if k not in arrays]
+    if unused:
+        import warnings
+        warnings.warn(f"{where}: {len(unused)} saved variable(s) the model does not have were ignored: {unused[:5]}")
+    with torch.no_grad():
+        for k, t in arrays.items():
+            if k not in blocks:
+                t.copy_(saved[k])
+        if state.get("flat_m") is not None and store.flat_m is not None:
+            store.flat_m.copy_(state["flat_m"])
+            store.flat_v.copy_(state["flat_v"])
+        for n, a in store.arenas.items():
+            a.m.copy_(state["arena_m"][n])
+            a.v.copy_(state["arena_v"][n])
+            a.live = None            # rebuilt from the restored moments on next use
+    if state.get("opt_step") is not None:
+        store.opt_state = {
+            "step": torch.tensor([state["opt_step"]], dtype=torch.int64, device=device),
+            "lr_t": torch.zeros(1, device=device)}
+    return int(state["global_step"])
 
 
 def _static_batch(features) -> bool:

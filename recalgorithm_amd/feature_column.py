@@ -104,11 +104,30 @@ class CategoricalColumn:
                     dense = torch.full((lens.numel(),), -1, dtype=torch.int64)
                     dense[lens == 1] = x.values
                     x = dense
+        x = self._in_range(x)
         if isinstance(x, Ragged):
             return Ragged(x.values.to(device), x.offsets.to(device))
         if x.dim() == 2 and x.shape[1] == 1:
             x = x[:, 0]
         return x.to(device)
+
+    def _in_range(self, x):
+        """Pre-encoded ids are not checked by the kernels (include/recalgo.h: an id >= vocab would read and
+        atomic-add outside its table).  Host-resident ids are clamped to OOV (default_value) here; device-resident
+        ids are trusted, and verified only under RECALGO_CHECK_IDS=1 (one host sync per lookup)."""
+        import os
+        vals = x.values if isinstance(x, Ragged) else x
+        if not isinstance(vals, torch.Tensor) or vals.dtype != torch.int64:
+            return x
+        nb = self.num_buckets
+        if vals.device.type == "cpu":
+            bad = vals >= nb
+            if bool(bad.any()):
+                vals = torch.where(bad, torch.full_like(vals, self.default_value), vals)
+                return Ragged(vals, x.offsets) if isinstance(x, Ragged) else vals
+        elif os.environ.get("RECALGO_CHECK_IDS") == "1" and vals.numel() and int(vals.max()) >= nb:
+            raise ValueError(f"feature {self.key}: id {int(vals.max())} >= vocabulary size {nb}")
+        return x
 
 
 class EmbeddingColumn:

@@ -393,51 +393,88 @@ def cross_layer(store, x0: torch.Tensor, xl: torch.Tensor, w: Variable, b: Varia
 # K5: CIN layer (fp32 MFMA implicit GEMM)
 # =============================================================================================
 class _CinFn(Function):
+    """One launch-sized piece of a CIN layer: the feature maps [n0, n1) of the contribution of the previous layer's maps
+    [h0, h1) (the whole layer when that is everything).  The kernels take <= 128 maps on either side per launch."""
+
     @staticmethod
-    def forward(ctx, anchor, x0, xk, filt: Variable):
+    def forward(ctx, anchor, x0, xk, filt: Variable, h0, h1, n0, n1):
         B, m, D = x0.shape
-        Hk = xk.shape[1]
-        N = filt.data.shape[-1]
+        Hk_full = filt.data.shape[-2] // m
+        N_full = filt.data.shape[-1]
+        whole = (h0, h1, n0, n1) == (0, Hk_full, 0, N_full)
+        if whole:
+            w, xk_c = filt.data, xk
+        else:
+            w = filt.data.reshape(Hk_full, m, N_full)[h0:h1, :, n0:n1].reshape((h1 - h0) * m, n1 - n0).contiguous()
+            xk_c = xk[:, h0:h1, :].contiguous()
+        Hk, N = h1 - h0, n1 - n0
         out = torch.empty(B, N, D, device=x0.device, dtype=torch.float32)
         pool = torch.empty(B, N, device=x0.device, dtype=torch.float32)
         _lib.check(_lib_().recalgo_cin_layer_fwd(
-            _p(x0), _p(xk), _p(filt.data), B, m, Hk, N, D, _p(out), _p(pool), N, 0, _stream(x0)),
+            _p(x0), _p(xk_c), _p(w), B, m, Hk, N, D, _p(out), _p(pool), N, 0, _stream(x0)),
             "recalgo_cin_layer_fwd")
-        ctx.filt = filt
-        ctx.save_for_backward(x0, xk)
+        ctx.filt, ctx.box, ctx.whole = filt, (h0, h1, n0, n1), whole
+        ctx.xk_shape = xk.shape
+        ctx.save_for_backward(x0, xk_c, w)
         ctx.set_materialize_grads(False)
         return out, pool
 
     @staticmethod
     def backward(ctx, g_out, g_pool):
-        x0, xk = ctx.saved_tensors
+        x0, xk, w = ctx.saved_tensors
         filt = ctx.filt
+        h0, h1, n0, n1 = ctx.box
         B, m, D = x0.shape
-        Hk = xk.shape[1]
-        N = filt.data.shape[-1]
+        Hk, N = h1 - h0, n1 - n0
         dx0 = torch.empty_like(x0)
         dxk = torch.empty_like(xk)
+        dw = filt.grad if ctx.whole else torch.empty_like(w)
         if g_out is None and g_pool is None:
-            filt.grad.zero_()
-            return None, dx0.zero_(), dxk.zero_(), None
-        g_out = None if g_out is None else g_out.contiguous()
-        g_pool = None if g_pool is None else g_pool.contiguous()
-        lib = _lib_()
-        ws = _workspace(lib.recalgo_cin_layer_bwd_workspace_bytes(B, m, Hk, N, D), x0.device)
-        _lib.check(lib.recalgo_cin_layer_bwd(
-            _p(x0), _p(xk), _p(filt.data), _p(g_out), _p(g_pool), N, 0, B, m, Hk, N, D,
-            _p(dx0), 0, _p(dxk), 0, _p(filt.grad), _p(ws), _stream(x0)), "recalgo_cin_layer_bwd")
-        return None, dx0, dxk, None
+            dw.zero_()
+            dx0.zero_(), dxk.zero_()
+        else:
+            g_out = None if g_out is None else g_out.contiguous()
+            g_pool = None if g_pool is None else g_pool.contiguous()
+            lib = _lib_()
+            ws = _workspace(lib.recalgo_cin_layer_bwd_workspace_bytes(B, m, Hk, N, D), x0.device)
+            _lib.check(lib.recalgo_cin_layer_bwd(
+                _p(x0), _p(xk), _p(w), _p(g_out), _p(g_pool), N, 0, B, m, Hk, N, D,
+                _p(dx0), 0, _p(dxk), 0, _p(dw), _p(ws), _stream(x0)), "recalgo_cin_layer_bwd")
+        if not ctx.whole:
+            Hk_full = filt.data.shape[-2] // m
+            filt.grad.reshape(Hk_full, m, filt.data.shape[-1])[h0:h1, :, n0:n1].copy_(dw.reshape(Hk, m, N))
+            full = torch.zeros(ctx.xk_shape, device=x0.device, dtype=torch.float32)
+            full[:, h0:h1, :] = dxk
+            dxk = full
+        return None, dx0, dxk, None, None, None, None, None
+
+
+CIN_MAX_MAPS = 128          # feature maps per launch on either side (csrc/cin.hip)
 
 
 def cin_layer(store, x0: torch.Tensor, xk: torch.Tensor, filt: Variable):
-    """x0 [B,m,D], xk [B,Hk,D], filt (1, Hk*m, N) -> (xk_1 [B,N,D], sum-pooled [B,N])."""
+    """x0 [B,m,D], xk [B,Hk,D], filt (1, Hk*m, N) -> (xk_1 [B,N,D], sum-pooled [B,N]).  Layers wider than the kernels'
+    128 x 128 maps per launch (e.g. --cin_layer_feature_maps=200,200) are tiled: output maps in column chunks
+    (concatenated), previous-layer maps in row chunks (the layer is linear in X^k: the chunks' contributions add)."""
     if store.building:
         N = filt.data.shape[-1]
         return x0.new_zeros(x0.shape[0], N, x0.shape[2]), x0.new_zeros(x0.shape[0], N)
     _chk(x0, torch.float32, "x0")
     _chk(xk, torch.float32, "xk")
-    return _CinFn.apply(store.anchor, x0, xk, filt)
+    Hk, N = xk.shape[1], filt.data.shape[-1]
+    if Hk <= CIN_MAX_MAPS and N <= CIN_MAX_MAPS:
+        return _CinFn.apply(store.anchor, x0, xk, filt, 0, Hk, 0, N)
+    hs = [(h, min(h + CIN_MAX_MAPS, Hk)) for h in range(0, Hk, CIN_MAX_MAPS)]
+    ns = [(n, min(n + CIN_MAX_MAPS, N)) for n in range(0, N, CIN_MAX_MAPS)]
+    outs, pools = [], []
+    for n0, n1 in ns:
+        o = p = None
+        for h0, h1 in hs:
+            oc, pc = _CinFn.apply(store.anchor, x0, xk, filt, h0, h1, n0, n1)
+            o, p = (oc, pc) if o is None else (o + oc, p + pc)
+        outs.append(o)
+        pools.append(p)
+    return torch.cat(outs, dim=1), torch.cat(pools, dim=1)
 
 
 # =============================================================================================

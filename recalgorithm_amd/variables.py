@@ -226,9 +226,17 @@ class VariableStore:
             self.vars[sub].grad = self.vars[blk].grad[idx]
         self.packed = True
 
-    def named_arrays(self) -> Dict[str, torch.Tensor]:
+    def named_arrays(self, gather: bool = False) -> Dict[str, torch.Tensor]:
+        """name -> tensor of every variable and embedding table.  Tables of a row-sharded arena are not local views:
+        with `gather` they are all_gather'ed (a COLLECTIVE: every rank must call), without it they raise."""
         out = {n: self.vars[n].data for n in self.vars}
         for ar in self.arenas.values():
+            if gather and getattr(ar, "sharding", None) is not None:
+                from . import parallel
+                full = parallel.unshard_arena(ar, "weight")
+                for tn, (rb, vocab) in ar.tables.items():
+                    out[tn] = full[rb:rb + vocab]
+                continue
             for tn in ar.tables:
                 out[tn] = ar.table_view(tn)
         return out
@@ -335,6 +343,9 @@ class EmbeddingArena:
         self._init.clear()
 
     def table_view(self, name: str) -> torch.Tensor:
+        if getattr(self, "sharding", None) is not None:
+            raise RuntimeError(f"arena {self.name} is row-sharded over {self.sharding.sh.world} ranks: its tables are not "
+                               "local views (gather them with parallel.unshard_arena / VariableStore.named_arrays(gather=True))")
         rb, vocab = self.tables[name]
         return self.weight[rb:rb + vocab]
 

@@ -183,3 +183,79 @@ def test_row_sharded_exchange_world2_matches_single_process(staged, world):
             errs.append("worker timed out")
     assert not errs, "\n".join(errs)
     assert all(p.exitcode == 0 for p in procs)
+
+
+def _worker_ckpt(rank, port, errq, tmpdir, WORLD=2):
+    """Two ranks, row-sharded arena: save_checkpoint gathers the shards (weight, m, v) into whole tables, rank 0 alone
+    writes; a single-process restore of that file reproduces the global state (the sharded save used to
+    slice the LOCAL shard with GLOBAL row ranges and let every rank race on one tmp file)."""
+    try:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+        from recalgorithm_amd import parallel as P
+        from recalgorithm_amd.estimator import Estimator, collect_checkpoint_state, restore_checkpoint_state
+        from recalgorithm_amd.variables import VariableStore
+
+        def build():
+            ar, vocabs = _make_arena()
+            store = VariableStore("cpu", seed=7)
+            store.get_variable("w", (6, 3))
+            store.arenas[ar.name] = ar
+            store.pack()
+            return store, ar
+        store, ar = build()
+        rows, K = ar.weight.shape
+        # a recognisable global state: every element a function of its global (row, column)
+        g = torch.arange(rows * K, dtype=torch.float32).reshape(rows, K)
+        ar.weight.copy_(g); ar.m.copy_(g + 0.25); ar.v.copy_(g + 0.5)
+        store.flat_m.fill_(1.5); store.flat_v.fill_(2.5)
+        store.opt_state = {"step": torch.tensor([9]), "lr_t": torch.zeros(1)}
+        est = types.SimpleNamespace(_built=True, store=store, grad_hook=None, loss_grad_scale=None)
+        P.attach_data_parallel(est, dist, local_gather=cpu_gather, local_scatter_add=cpu_scatter_add,
+                               capacity_factor=None, planner=torch_exchange_plan)
+        assert ar.weight.shape[0] == (rows - rank + WORLD - 1) // WORLD          # really sharded
+        try:
+            ar.table_view("t0")
+            raise AssertionError("table_view of a sharded arena must raise")
+        except RuntimeError:
+            pass
+        # the Estimator method itself (bound to a stub): collective gather, rank 0 writes, barrier
+        stub = types.SimpleNamespace(store=store, global_step=9, shard_spec=est.shard_spec,
+                                     config=types.SimpleNamespace(model_dir=tmpdir),
+                                     _check_exchange_overflow=lambda: None,
+                                     _ckpt_path=lambda: os.path.join(tmpdir, "model.ckpt.pt"))
+        Estimator.save_checkpoint(stub)
+        files = sorted(os.listdir(tmpdir))
+        assert files == ["model.ckpt.pt"], files                                   # no stray tmp file, one writer
+        state = torch.load(os.path.join(tmpdir, "model.ckpt.pt"), weights_only=True)
+        fresh, far = build()                                                       # unsharded, single process
+        assert restore_checkpoint_state(fresh, state, torch.device("cpu")) == 9
+        assert torch.equal(far.weight, g) and torch.equal(far.m, g + 0.25) and torch.equal(far.v, g + 0.5)
+        assert torch.equal(fresh.vars["w"].data, store.vars["w"].data) and float(fresh.flat_v[0]) == 2.5
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        import traceback
+        errq.put(f"rank {rank}:\n{traceback.format_exc()}")
+        raise
+
+
+@pytest.mark.timeout(180)
+def test_checkpoint_of_row_sharded_arenas_two_ranks(tmp_path):
+    ctx = mp.get_context("spawn")
+    errq = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ckpt, args=(r, port, errq, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(150)
+    errs = []
+    while not errq.empty():
+        errs.append(errq.get())
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+            errs.append("worker timed out")
+    assert not errs, "\n".join(errs)
+    assert all(p.exitcode == 0 for p in procs)

@@ -70,3 +70,26 @@ def test_cin_only_pool_gradient(dev):
     a0 = x0.double().requires_grad_(True)
     R.cin_layer(a0, a0, w.double()).sum().backward()
     assert_close(x0d.grad, a0.grad, what="cin dx0 (xk is x0, pool grad only)")
+
+
+@pytest.mark.parametrize("B,m,Hk,N,D", [(24, 8, 8, 200, 8), (24, 8, 200, 200, 8), (10, 26, 150, 130, 16)])
+def test_cin_layers_wider_than_one_launch(dev, B, m, Hk, N, D):
+    """--cin_layer_feature_maps=200,200: more than 128 maps on either side is tiled over several launches."""
+    gen = torch.Generator().manual_seed(B + Hk + N)
+    x0 = torch.randn(B, m, D, generator=gen)
+    xk = torch.randn(B, Hk, D, generator=gen)
+    w = torch.randn(1, Hk * m, N, generator=gen) / (Hk * m) ** 0.5
+    store = VariableStore(dev)
+    wv = Variable("f", w.to(dev))
+    x0d, xkd = x0.to(dev).requires_grad_(True), xk.to(dev).requires_grad_(True)
+    out, pooled = ops.cin_layer(store, x0d, xkd, wv)
+    a = [t.double().requires_grad_(True) for t in (x0, xk, w)]
+    ref = R.cin_layer(a[0], a[1], a[2])
+    assert_close(out, ref, what="wide cin fwd", reduced=True)
+    assert_close(pooled, ref.sum(-1), what="wide cin pooled", reduced=True)
+    go, gp = torch.randn(B, N, D, generator=gen), torch.randn(B, N, generator=gen)
+    torch.autograd.backward([out, pooled], [go.to(dev), gp.to(dev)])
+    torch.autograd.backward([ref, ref.sum(-1)], [go.double(), gp.double()])
+    assert_close(x0d.grad, a[0].grad, what="wide cin dx0", reduced=True)
+    assert_close(xkd.grad, a[1].grad, what="wide cin dxk", reduced=True)
+    assert_close(wv.grad, a[2].grad, what="wide cin dW", reduced=True)

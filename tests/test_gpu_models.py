@@ -376,3 +376,23 @@ def test_fused_train_step_matches_unfused_graph(dev, model):
             continue
         assert_close(A[k], B_[k].double(), rtol=1e-4, what=f"{model} {k}: fused vs op-by-op after 3 steps", reduced=True)
     assert int(a.store.opt_state["step"]) == int(b.store.opt_state["step"]) == 3
+
+
+def test_graphed_step_copies_into_private_buffers(dev):
+    """GraphedTrainStep captures on PRIVATE static input buffers (storage-preserving clones of the first batch): the
+    caller's tensors are never written, and a batch tensor that comes round again is copied again, not skipped."""
+    est, params, feats, labels = make("dcn", dev, B=256)
+    ref, _, _, _ = make("dcn", dev, B=256)
+    spec = synth.SynthSpec(n_fields=8, max_vocab=400, seed=11, oov_frac=0.05)
+    b1 = synth.device_features(spec, 256, dev, batch_index=1)[:2]
+    keep0 = {k: v.clone() for k, v in feats.items()}
+    keep1 = {k: v.clone() for k, v in b1[0].items()}
+    g = GraphedTrainStep(est.train_step, feats, labels, warmup=0)
+    seq = [(feats, labels), b1, (feats, labels), b1, (feats, labels)]
+    la = [float(g(*b)) for b in seq]
+    lr_ = [float(ref.train_step(*b)) for b in seq]
+    torch.cuda.synchronize()
+    assert all(torch.equal(feats[k], keep0[k]) for k in keep0) and all(torch.equal(b1[0][k], keep1[k]) for k in keep1)
+    for x, y in zip(la, lr_):
+        assert abs(x - y) <= 5e-6 * abs(y), (la, lr_)
+    assert any(v.data_ptr() != g.static_f[k].data_ptr() for k, v in feats.items())

@@ -189,3 +189,70 @@ def test_checkpoint_round_trip_restores_variables_moments_and_step(tmp_path):
     for n, ar in a.store.arenas.items():
         assert torch.equal(b.store.arenas[n].m, ar.m) and torch.equal(b.store.arenas[n].v, ar.v)
         assert b.store.arenas[n].live is None               # rebuilt lazily from the moments (variables.live_state)
+
+
+def test_checkpoint_restore_refuses_a_different_model(tmp_path):
+    """A checkpoint whose variables do not match the model (another vocabulary, other hidden_units) must not be
+    half-applied: restoring the step counter and Adam's bias correction on a partly re-initialised model is silent
+    corruption.  Also: a matching state round-trips, moments included."""
+    import torch
+    from recalgorithm_amd.estimator import collect_checkpoint_state, restore_checkpoint_state
+    from recalgorithm_amd.variables import EmbeddingArena, VariableStore
+
+    def store(vocab=11, hidden=4):
+        st = VariableStore("cpu", seed=3)
+        st.get_variable("dense/kernel", (6, hidden))
+        ar = st.arenas["emb"] = EmbeddingArena("emb", 4, "cpu", seed=5)
+        ar.add_table("t0", vocab)
+        st.finalize()
+        return st
+    a = store()
+    a.flat_m.uniform_(0, 1); a.flat_v.uniform_(0, 1)
+    a.arenas["emb"].m.uniform_(0, 1); a.arenas["emb"].v.uniform_(0, 1)
+    a.opt_state = {"step": torch.tensor([17]), "lr_t": torch.zeros(1)}
+    state, writer = collect_checkpoint_state(a, global_step=17)
+    assert writer
+    path = tmp_path / "ck.pt"
+    torch.save(state, path)
+    state = torch.load(path, weights_only=True)              # the file is plain tensors / ints
+    b = store()
+    b.vars["dense/kernel"].data.zero_()
+    assert restore_checkpoint_state(b, state, torch.device("cpu")) == 17
+    assert torch.equal(b.vars["dense/kernel"].data, a.vars["dense/kernel"].data)
+    assert torch.equal(b.arenas["emb"].m, a.arenas["emb"].m) and torch.equal(b.flat_v, a.flat_v)
+    assert int(b.opt_state["step"]) == 17
+    for other in (store(vocab=12), store(hidden=5)):
+        before = {k: v.clone() for k, v in other.named_arrays().items()}
+        with pytest.raises(RuntimeError, match="does not match the model"):
+            restore_checkpoint_state(other, state, torch.device("cpu"))
+        assert all(torch.equal(v, before[k]) for k, v in other.named_arrays().items())     # nothing was applied
+        assert other.opt_state is None
+
+
+def test_preencoded_ids_out_of_range_become_oov():
+    """The gather / scatter kernels do not bounds-check ids against the vocabulary: host-resident pre-encoded ids
+    that are out of range are mapped to OOV before they reach the device."""
+    import torch
+    from recalgorithm_amd import feature_column as fc
+    from recalgorithm_amd.feature_column import Ragged
+    c = fc.categorical_column_with_identity("x", 10)
+    ids = c.ids({"x": torch.tensor([0, 9, 10, -1, 12345])}, torch.device("cpu"))
+    assert ids.tolist() == [0, 9, -1, -1, -1]
+    r = c.ids({"x": Ragged(torch.tensor([3, 10, 2]), torch.tensor([0, 2, 3]))}, torch.device("cpu"))
+    assert r.values.tolist() == [3, -1, 2]
+
+
+def test_train_loop_raises_on_row_exchange_overflow():
+    """The static row exchange drops requests that do not fit a bucket and only raises a device flag; Estimator.train
+    polls it (every OVERFLOW_POLL_EVERY steps, at every checkpoint and at the end) and refuses to go on."""
+    import types
+    import torch
+    from recalgorithm_amd.estimator import Estimator
+    sharding = types.SimpleNamespace(overflow=torch.zeros(1, dtype=torch.bool))
+    arena = types.SimpleNamespace(sharding=sharding)
+    stub = types.SimpleNamespace(shard_spec=object(), store=types.SimpleNamespace(arenas={"a": arena}))
+    Estimator._check_exchange_overflow(stub)                      # flag clear: fine
+    sharding.overflow[0] = True
+    with pytest.raises(RuntimeError, match="bucket overflow"):
+        Estimator._check_exchange_overflow(stub)
+    Estimator._check_exchange_overflow(types.SimpleNamespace())   # not data parallel: nothing to poll

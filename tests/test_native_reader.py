@@ -110,7 +110,8 @@ def test_native_batches_equal_python_batches(tmp_path, seq_example):
         assert any(int(f["his_read_comment_7d_seq"].values.numel()) > 0 for f, _ in nb)
 
 
-def test_native_repeat_shuffle_and_crc(tmp_path):
+def test_native_repeat_shuffle_and_crc(tmp_path, monkeypatch):
+    monkeypatch.setenv("RECALGO_SHUFFLE_SEED", "7")            # pinned: two runs give the same order
     spec, path, cols, labels, parser = _dataset(tmp_path, n=100)
     n3 = sum(l["read_comment"].shape[0] for _, l in train_input_fn(path, parser, 32, 3, 0))
     assert n3 == 300                                                          # repeat(3) then batch
@@ -120,6 +121,23 @@ def test_native_repeat_shuffle_and_crc(tmp_path):
     b = torch.cat([f["userid"] for f, _ in train_input_fn(path, parser, 100, 1, 16)])
     c = torch.cat([f["userid"] for f, _ in eval_input_fn(path, parser, 100)])
     assert torch.equal(a, b) and not torch.equal(a, c) and torch.equal(a.sort().values, c.sort().values)
+    # shuffle(buffer).repeat(epochs), the reference's order (utils.py:19-21): every pass is a permutation of the file —
+    # records of different epochs never mix (native reader and Python reader alike)
+    monkeypatch.setenv("RECALGO_PYTHON_READER", "0")
+    for reader in ("native", "python"):
+        if reader == "python":
+            monkeypatch.setenv("RECALGO_PYTHON_READER", "1")
+        two = torch.cat([f["userid"] for f, _ in train_input_fn(path, parser, 50, 2, 16)]) if reader == "native" else \
+            torch.cat([torch.as_tensor(_encoded(cols, f)["userid"]) for f, _ in train_input_fn(path, parser, 50, 2, 16)])
+        assert two.numel() == 200
+        assert torch.equal(two[:100].sort().values, c.sort().values) and torch.equal(two[100:].sort().values, c.sort().values)
+        assert not torch.equal(two[:100], c)
+    monkeypatch.delenv("RECALGO_PYTHON_READER")
+    # without a pinned seed every run draws its own order (dataset.shuffle without a seed)
+    monkeypatch.delenv("RECALGO_SHUFFLE_SEED")
+    d = torch.cat([f["userid"] for f, _ in train_input_fn(path, parser, 100, 1, 16)])
+    e = torch.cat([f["userid"] for f, _ in train_input_fn(path, parser, 100, 1, 16)])
+    assert not torch.equal(d, e) and torch.equal(d.sort().values, e.sort().values)
     raw = bytearray(open(path, "rb").read())
     raw[40] ^= 0x10
     bad = str(tmp_path / "bad.tfrecord")
