@@ -49,6 +49,12 @@ def parse_args(argv=None):
     ap.add_argument("--big-table-rows", type=int, default=0,
                     help="replace the vocabulary of the last field by a table of this many rows "
                          "(BASELINE configs[4]: one 100M x 16 table)")
+    ap.add_argument("--lazy-adam", action="store_true",
+                    help="LazyAdamOptimizer on the embedding tables (rows without a gradient keep weights and moments): a "
+                         "labelled DEVIATION from the reference's tf.train.AdamOptimizer (SURVEY.md §8f-1)")
+    ap.add_argument("--sweep-batches", type=int, default=192,
+                    help="optimizer-state sweep after the timed run: this many FRESH batches (one per step, never repeated) "
+                         "and a forced all-rows-live run; 0 = off")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -128,6 +134,8 @@ def build_estimator(args, device, rank=0, world=1):
         workload = f"FwFM first order + field-pair-weighted second order; {args.fields} fields x emb{args.emb}; batch {args.batch}/GPU"
     else:
         raise SystemExit(f"--model {args.model}: unknown")
+    if args.lazy_adam:
+        params["lazy_adam"] = True
     est = Estimator(model_fn=model_fn, params=params, config=RunConfig(device=device, seed=42))
     feats, labels, _ = synth.device_features(spec, args.batch, device, batch_index=rank)
     est.build(feats, labels)
@@ -313,19 +321,90 @@ def kernel_rooflines(args, est, feats, device):
             add("pnn_weights_fwd(IPNN)", lambda: lib.recalgo_pnn_weights_fwd(p(th), D_, F, K, 0, p(om), st), (D_ * F + T_ * D_) * 4)
             add("pnn_weights_bwd(IPNN)", lambda: lib.recalgo_pnn_weights_bwd(p(th), p(dom), D_, F, K, 0, p(dth), st),
                 (2 * D_ * F + T_ * D_) * 4)
-    # TF1 dense Adam over the arena (state as left by the timed steps; lr = 0 so that the repeated
-    # launches do not move the weights): the update visits the live-row list only — rows no
+    # context MLP on the fp32 matrix cores (csrc/dense.hip): forward (bias + ReLU fused) and the merged backward launch
+    # (input + weight gradient tiles, ReLU mask and bias gradient fused) of the three layers 416 -> 512 -> 256 -> 128
+    from recalgorithm_amd import ops
+    widths = [d, 512, 256, 128]
+    for li in range(3):
+        Kd, Nd = widths[li], widths[li + 1]
+        xd = torch.randn(B, Kd, device=device)
+        wd = torch.randn(Kd, Nd, device=device) / Kd ** 0.5
+        bd = torch.zeros(Nd, device=device)
+        gd = torch.randn(B, Nd, device=device)
+        yd = ops.dense_fwd(xd, wd, bd, True)
+        dwd, dbd = torch.empty_like(wd), torch.empty_like(bd)
+        fl = 2.0 * B * Kd * Nd
+        add(f"dense_fwd({Kd}->{Nd})", lambda: ops.dense_fwd(xd, wd, bd, True), (B * (Kd + Nd) + Kd * Nd) * 4, fl)
+        add(f"dense_bwd({Kd}->{Nd})", lambda: ops.dense_bwd(xd, gd, yd, wd, dwd, dbd),
+            (B * (2 * Kd + 2 * Nd) + 2 * Kd * Nd) * 4, 2.0 * fl)
+    # The optimizer launch (recalgo_adam_tf1_step: TF1 dense Adam over the flat dense buffer + over the arena's live-row
+    # list; state as left by the timed steps; lr = 0 so that the repeated launches do not move the weights).  Rows no
     # gradient has ever reached have g = m = v = 0, for which the dense update is the identity.
-    # Algorithmic bytes: 28 B per parameter of a live row (g, m, v, p in; p, m, v out) + 4 B per list entry.
+    # Algorithmic bytes: 28 B per parameter of a live row (g, m, v, p in; p, m, v out) + 4 B per list entry + 28 B per
+    # dense parameter.
     n = ar.weight.numel()
     _, lst, cnt = ar.live_state()
     n_rows_live = int(cnt.item())
-    zero_lr = torch.zeros(1, device=device)
-    add("adam_tf1_list(arena)", lambda: lib.recalgo_adam_tf1_list(p(ar.weight), p(ar.grad), p(ar.m), p(ar.v), p(lst), p(cnt),
-                                                                  ar.weight.shape[0], K, 0.0, p(zero_lr), 0.9, 0.999, 1e-8, 1, st),
-        n_rows_live * (K * 28 + 4))
+    arenas = [a for a in store.arenas.values() if a.weight is not None]
+    n_dense = 0 if store.flat is None else store.flat.numel()
+    live_bytes = sum(int(a.live_state()[2].item()) * (a.K * 28 + 4) for a in arenas)
+    add("adam_tf1_step(dense + arenas)", lambda: ops.adam_tf1_step_(store.flat, store.flat_grad, store.flat_m, store.flat_v, arenas,
+                                                                     store.opt_state["step"], None, 0.0, lazy=args.lazy_adam),
+        live_bytes + n_dense * 28)
     res[-1]["live_fraction"] = round(n_rows_live * K / max(n, 1), 4)
     return res
+
+
+def live_fraction(est) -> float:
+    """Fraction of the embedding parameters whose row a gradient has reached (= what the optimizer walks every step)."""
+    tot = live = 0
+    for a in est.store.arenas.values():
+        if a.weight is None:
+            continue
+        tot += a.weight.numel()
+        live += int(a.live_state()[2].item()) * a.K
+    return live / max(tot, 1)
+
+
+def optimizer_state_sweep(args, r, device, rank, world):
+    """The headline rotates `--data-batches` fixed batches, so its live-row set saturates.  Real training draws fresh
+    batches: the rows TF1's dense Adam has to walk only grow.  This sweep continues the SAME run with fresh batches (one
+    per step, never repeated; generated and moved to HBM outside the timed chunks) and reports the step time against the
+    live fraction, then forces every row live (the dense pass a long run converges to)."""
+    from recalgorithm_amd.io import synth
+    est, spec, graphed = r["est"], r["spec"], r["graphed"]
+    pts = [{"phase": f"headline ({args.data_batches} rotating batches)", "live_fraction": round(live_fraction(est), 4),
+            "ms_per_step": round(r["dt"] / args.steps * 1e3, 4)}]
+    run = (lambda b: graphed(*b)) if graphed is not None else (lambda b: est.train_step(*b))
+
+    def timed(batches):
+        """Median of the per-step device times of the chunk (a HIP event after every step): a host-side hiccup while the
+        chunk is fed — an allocator or GC pause leaves the device idle — then does not pass for step time."""
+        torch.cuda.synchronize()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(batches) + 1)]
+        evs[0].record()
+        for i, bt in enumerate(batches):
+            run(bt)
+            evs[i + 1].record()
+        evs[-1].synchronize()
+        per = sorted(x.elapsed_time(y) for x, y in zip(evs, evs[1:]))
+        return per[len(per) // 2]
+    chunk, base = 32, 100_000 + rank
+    for c0 in range(0, args.sweep_batches, chunk):
+        n = min(chunk, args.sweep_batches - c0)
+        fresh = [synth.device_features(spec, args.batch, device, batch_index=base + world * (c0 + i))[:2] for i in range(n)]
+        ms = timed(fresh)
+        pts.append({"phase": f"fresh batches {c0}..{c0 + n - 1} (never repeated)", "live_fraction": round(live_fraction(est), 4),
+                    "ms_per_step": round(ms, 4)})
+        del fresh
+    for a in est.store.arenas.values():
+        if a.weight is not None and a.tracks_live_rows:
+            a.force_all_live()
+    fresh = [synth.device_features(spec, args.batch, device, batch_index=base + world * (args.sweep_batches + i))[:2] for i in range(24)]
+    timed(fresh[:4])
+    pts.append({"phase": "every row forced live (TF1 dense Adam at full cost)", "live_fraction": round(live_fraction(est), 4),
+                "ms_per_step": round(timed(fresh[4:]), 4)})
+    return pts
 
 
 def cpu_baseline(args, seconds):
@@ -432,7 +511,7 @@ def timed_run(args, device, rank, world, dist, capacity_factor):
         ovf = torch.tensor([1.0 if exchange_overflowed(est) else 0.0], device=device)
         dist.all_reduce(ovf)
         overflow = float(ovf) > 0
-    return {"est": est, "spec": spec, "feats": feats, "workload": workload, "dt": dt, "loss": float(loss),
+    return {"est": est, "spec": spec, "feats": feats, "workload": workload, "dt": dt, "loss": float(loss), "graphed": graphed,
             "launch": launch, "overflow": overflow, "chunk_ms": chunk_ms}
 
 
@@ -506,7 +585,10 @@ def main():
         "data": "synthetic",
         "config": {"workload": workload, "data_batches": args.data_batches, "global_batch": world * args.batch, "fields": args.fields,
                    "emb_dim": args.emb, "embedding_rows": int(sum(spec.vocabs)),
-                   "optimizer": "TF1 Adam, dense semantics over all tables (only rows a gradient has ever reached are visited: identity update elsewhere)",
+                   "optimizer": ("LazyAdam on the embedding tables (DEVIATION from the reference's tf.train.AdamOptimizer: rows without a "
+                                 "gradient in a step keep weights and moments), Adam on the dense variables" if args.lazy_adam else
+                                 "TF1 Adam, dense semantics over all tables (only rows a gradient has ever reached are visited: "
+                                 "identity update elsewhere)"),
                    "launch": launch,
                    "gemm_selection": "TunableOp" if args.tunable else "hipBLASLt default",
                    "parallelism": (f"dp{world} + embedding rows sharded r % {world} (RCCL all_to_all), dense grads all-reduced"
@@ -519,13 +601,30 @@ def main():
     if cs:          # spread of the per-chunk step times (median and p10 / p90)
         pick = lambda q: cs[min(len(cs) - 1, int(q * len(cs)))]
         out["ms_per_step_p10_p50_p90"] = [pick(0.1), pick(0.5), pick(0.9)]
+    ks = None
+    if rank == 0 and not args.no_kernel_timing:
+        # per-kernel table in the HEADLINE's state (before the optimizer-state sweep grows the live set); the repeated
+        # lr = 0 optimizer launches decay the Adam moments, so those are put back afterwards
+        snap = [(a, a.m.clone(), a.v.clone()) for a in est.store.arenas.values() if a.weight is not None]
+        fm, fv = (None, None) if est.store.flat_m is None else (est.store.flat_m.clone(), est.store.flat_v.clone())
+        try:
+            ks = kernel_rooflines(args, est, feats, device)
+        except Exception as e:          # the per-kernel table must never take the headline line down with it
+            print(f"[bench] per-kernel timing failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+        for a, m_, v_ in snap:
+            a.m.copy_(m_); a.v.copy_(v_)
+        if fm is not None:
+            est.store.flat_m.copy_(fm); est.store.flat_v.copy_(fv)
+        del snap, fm, fv
+    sweep = None
+    if args.sweep_batches > 0 and world == 1:
+        try:
+            sweep = optimizer_state_sweep(args, r, device, rank, world)
+        except Exception as e:          # never take the headline line down
+            print(f"[bench] optimizer-state sweep failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+    if sweep:
+        out["optimizer_state_sweep"] = sweep
     if rank == 0:
-        ks = None
-        if not args.no_kernel_timing:
-            try:
-                ks = kernel_rooflines(args, est, feats, device)
-            except Exception as e:          # the per-kernel table must never take the headline line down with it
-                print(f"[bench] per-kernel timing failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
         if ks:
             dom = max(ks, key=lambda k: k["avg_us"])
             if dom["bound"] == "mfma":
@@ -543,7 +642,8 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                     t = json.load(f).get(args.model, {}).get(dom["kernel"])
-                if t:
+                # only a measurement taken in (nearly) this run's state is comparable with this run's algorithmic bytes
+                if t and abs(t.get("alg_bytes", 0) - dom["alg_bytes"]) <= 0.1 * dom["alg_bytes"]:
                     out["roofline"]["traffic"] = int(2 * t["fetch_size_kb"] * 1024 + t["write_size_kb"] * 1024)
                     out["roofline"]["traffic_source"] = t["source"]
             except (OSError, ValueError, KeyError):

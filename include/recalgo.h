@@ -462,6 +462,9 @@ typedef struct {
     const int* live_count;
     int64_t max_rows;
     int K;
+    int lazy;      /* != 0: tf.contrib.opt.LazyAdamOptimizer semantics for this arena (the reference's DIEN, dien.py:328): a row
+                      whose gradient is all zero in this step keeps p, m and v — a DEVIATION from tf.train.AdamOptimizer,
+                      whose m and v decay (and p moves) for every row every step */
 } recalgo_adam_arena_t;
 int recalgo_adam_tf1_step(float* p, float* g, float* m, float* v, int64_t n, const recalgo_adam_arena_t* arenas,
                           int n_arenas, int64_t* step_dev, int* ticket_dev, int advance, float lr, float beta1,

@@ -388,6 +388,7 @@ struct AdamArena {
     const int* count;
     int K;
     int k4_shift;             // log2(K / 4) when K / 4 is a power of two, else -1
+    int lazy;                 // LazyAdam: rows whose gradient is all zero this step are left untouched
     unsigned first_block, n_blocks;
 };
 struct AdamStepArgs {
@@ -462,8 +463,17 @@ __global__ __launch_bounds__(256) void adam_tf1_step_kernel(AdamStepArgs A) {
             for (long long tt = (long long)blk * 256 + threadIdx.x; tt < total4; tt += stride) {
                 const long long r = sh >= 0 ? tt >> sh : tt / K4;
                 const long long i = (long long)R.list[r] * K4 + (tt - r * K4);
-                float4 gg = g4[i], mm = m4[i], vv = v4[i], pp = p4[i];
+                float4 gg = g4[i];
                 const bool nz = gg.x != 0.f || gg.y != 0.f || gg.z != 0.f || gg.w != 0.f;
+                if (R.lazy) {
+                    // tf.contrib.opt.LazyAdamOptimizer (the reference's DIEN, dien.py:328): only the rows of this step's
+                    // IndexedSlices move — here: rows with a non-zero gradient (the K4 lanes of a row vote)
+                    int any = nz;
+                    if (sh > 0)
+                        for (int o = 1; o < K4; o <<= 1) any |= __shfl_xor(any, o, 64);
+                    if (!any) continue;
+                }
+                float4 mm = m4[i], vv = v4[i], pp = p4[i];
                 adam1(pp.x, gg.x, mm.x, vv.x, lr_t, b1, b2, eps);
                 adam1(pp.y, gg.y, mm.y, vv.y, lr_t, b1, b2, eps);
                 adam1(pp.z, gg.z, mm.z, vv.z, lr_t, b1, b2, eps);
@@ -476,8 +486,10 @@ __global__ __launch_bounds__(256) void adam_tf1_step_kernel(AdamStepArgs A) {
             for (long long tt = (long long)blk * 256 + threadIdx.x; tt < total; tt += stride) {
                 const long long r = tt / K;
                 const long long i = (long long)R.list[r] * K + (tt - r * K);
-                float gg = R.g[i], mm = R.m[i], vv = R.v[i], pp = R.p[i];
+                float gg = R.g[i];
                 const bool nz = gg != 0.f;
+                if (R.lazy && !nz) continue;                 // (element-wise vote for widths that are not 4 * 2^n)
+                float mm = R.m[i], vv = R.v[i], pp = R.p[i];
                 adam1(pp, gg, mm, vv, lr_t, b1, b2, eps);
                 R.p[i] = pp; R.m[i] = mm; R.v[i] = vv;
                 if (A.zero_grad && nz) R.g[i] = 0.f;
@@ -719,6 +731,7 @@ RECALGO_EXPORT int recalgo_adam_tf1_step(float* p, float* g, float* m, float* v,
         AdamArena& R = A.ar[A.n_arenas++];
         R.p = a.p; R.g = a.g; R.m = a.m; R.v = a.v; R.list = a.live_list; R.count = a.live_count; R.K = a.K;
         R.k4_shift = -1;
+        R.lazy = a.lazy;
         if ((a.K & 3) == 0)
             for (int sft = 0; sft < 16; ++sft)
                 if ((a.K >> 2) == (1 << sft)) R.k4_shift = sft;
@@ -729,7 +742,7 @@ RECALGO_EXPORT int recalgo_adam_tf1_step(float* p, float* g, float* m, float* v,
         R.first_block = blocks;
         blocks += R.n_blocks;
     }
-    for (int i = A.n_arenas; i < kAdamMaxArenas; ++i) A.ar[i] = AdamArena{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 4, 0, 0xffffffffu, 0};
+    for (int i = A.n_arenas; i < kAdamMaxArenas; ++i) A.ar[i] = AdamArena{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 4, 0, 0, 0xffffffffu, 0};
     A.step = reinterpret_cast<long long*>(step_dev); A.ticket = ticket_dev; A.advance = advance;
     A.lr = lr; A.b1 = beta1; A.b2 = beta2; A.eps = eps; A.zero_grad = zero_grad;
     if (blocks == 0) blocks = 1;                      // still advances the step counter

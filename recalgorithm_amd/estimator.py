@@ -68,6 +68,8 @@ class AdamOptimizer:
     """tf.train.AdamOptimizer(learning_rate, beta1, beta2, epsilon).minimize(loss):
     dense TF1 semantics for every variable, embedding tables included."""
 
+    lazy_embeddings = False
+
     def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8):
         self.lr, self.beta1, self.beta2, self.eps = float(learning_rate), beta1, beta2, epsilon
 
@@ -94,8 +96,10 @@ class AdamOptimizer:
             # one launch: dense TF1 Adam over the flat buffer + dense-semantics TF1 Adam over the rows a gradient has ever
             # reached (the update is the identity for all others); lr_t derived on the device from the step counter
             ops.adam_tf1_step_(store.flat, store.flat_grad, store.flat_m, store.flat_v, arenas, st["step"], None,
-                               self.lr, self.beta1, self.beta2, self.eps)
+                               self.lr, self.beta1, self.beta2, self.eps, lazy=self.lazy_embeddings)
             return
+        if self.lazy_embeddings:
+            raise NotImplementedError("LazyAdamOptimizer needs the fused optimizer launch (HIP device, <= 4 arenas)")
         ops.adam_tf1_advance_(st["step"], st["lr_t"], self.lr, self.beta1, self.beta2)
         kw = dict(step=-1, lr=self.lr, beta1=self.beta1, beta2=self.beta2, eps=self.eps,
                   zero_grad=True, lr_t_dev=st["lr_t"])
@@ -106,6 +110,15 @@ class AdamOptimizer:
                 ops.adam_tf1_list_(ar, st["lr_t"], self.beta1, self.beta2, self.eps)
             else:
                 ops.adam_tf1_(ar.weight.view(-1), ar.grad.view(-1), ar.m.view(-1), ar.v.view(-1), **kw)
+
+
+class LazyAdamOptimizer(AdamOptimizer):
+    """tf.contrib.opt.LazyAdamOptimizer (the reference's DIEN, /root/reference algorithm/DIEN/dien.py:328): embedding rows
+    without a gradient in a step keep their weights AND moments; dense variables update as in Adam.  The six hot-path
+    models use tf.train.AdamOptimizer (dense semantics on the tables): selecting this class for them
+    (params["lazy_adam"] = True / bench.py --lazy-adam) is a labelled DEVIATION that makes the optimizer cost
+    proportional to the rows of the batch instead of the rows ever touched."""
+    lazy_embeddings = True
 
 
 def get_global_step():

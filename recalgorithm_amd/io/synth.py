@@ -56,10 +56,17 @@ def zipf_ids(rng: np.random.Generator, n: int, vocab: int, s: float = 1.05) -> n
             out[filled:filled + x.size] = x - 1
             filled += x.size
         return out
-    ranks = np.arange(1, vocab + 1, dtype=np.float64)
-    cdf = np.cumsum(ranks ** (-s))
-    cdf /= cdf[-1]
+    cdf = _ZIPF_CDF.get((vocab, s))
+    if cdf is None:                       # the table depends on (vocab, s) only: built once, not per batch
+        ranks = np.arange(1, vocab + 1, dtype=np.float64)
+        cdf = np.cumsum(ranks ** (-s))
+        cdf /= cdf[-1]
+        if len(_ZIPF_CDF) < 256:
+            _ZIPF_CDF[(vocab, s)] = cdf
     return np.searchsorted(cdf, rng.random(n), side="left").astype(np.int64)
+
+
+_ZIPF_CDF: Dict[tuple, np.ndarray] = {}
 
 
 @dataclass
@@ -122,7 +129,14 @@ def device_features(spec: SynthSpec, B: int, device, batch_index: int = 0, sorte
     from ..feature_column import Ragged
     names = sorted(spec.names) if sorted_layout else list(spec.names)
     ids, labels, dense, hist, tags = make_id_batch(spec, B, batch_index, names)
-    mat = torch.from_numpy(ids).to(device)
+    # ONE allocation for the id matrix and the labels (int64 [B, F] followed by float32 [B, 1]): a training loop that
+    # copies a batch into the static input buffers of a captured step then moves it with a single copy
+    nid = ids.size * 8
+    host = torch.empty(nid + B * 4, dtype=torch.uint8)
+    host[:nid] = torch.from_numpy(np.ascontiguousarray(ids)).view(-1).view(torch.uint8)
+    host[nid:] = torch.from_numpy(np.ascontiguousarray(labels)).view(-1).view(torch.uint8)
+    buf = host.to(device)
+    mat = buf[:nid].view(torch.int64).view(B, len(names))
     feats: Dict[str, object] = {nm: mat[:, j] for j, nm in enumerate(names)}
     feats_meta = {"__ids_matrix__": mat, "__ids_names__": names}
     if dense is not None:
@@ -135,7 +149,7 @@ def device_features(spec: SynthSpec, B: int, device, batch_index: int = 0, sorte
     if tags is not None:
         feats["manual_tag_list"] = Ragged(torch.from_numpy(tags[0]).to(device),
                                           torch.from_numpy(tags[1]).to(device))
-    lab = {"read_comment": torch.from_numpy(labels).to(device)}
+    lab = {"read_comment": buf[nid:].view(torch.float32).view(B, 1)}
     return feats, lab, feats_meta
 
 

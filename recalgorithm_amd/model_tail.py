@@ -8,7 +8,7 @@ from typing import Callable, Dict, Optional
 import torch
 
 from . import ops
-from .estimator import AdamOptimizer, EstimatorSpec, ModeKeys, metrics
+from .estimator import AdamOptimizer, EstimatorSpec, LazyAdamOptimizer, ModeKeys, metrics
 from .variables import current_store
 
 
@@ -61,6 +61,7 @@ def finish_model_fn(mode, logit: torch.Tensor, labels, params,
     # TRAIN: the reference also builds the two metric ops here, but only to feed tf.summary /
     # LoggingTensorHook (deepfm.py:237-238,256-271); they are not part of the training step
     assert mode == ModeKeys.TRAIN
-    optimizer = AdamOptimizer(learning_rate=params["learning_rate"], beta1=0.9, beta2=0.999, epsilon=1e-8)
+    opt_cls = LazyAdamOptimizer if params.get("lazy_adam") else AdamOptimizer      # lazy_adam: labelled deviation (§8f-1)
+    optimizer = opt_cls(learning_rate=params["learning_rate"], beta1=0.9, beta2=0.999, epsilon=1e-8)
     train_op = optimizer.minimize(loss=loss)
     return EstimatorSpec(mode, loss=loss, train_op=train_op, predictions={"probabilities": prob})

@@ -1188,12 +1188,12 @@ def adam_tf1_advance_(step_dev: torch.Tensor, lr_t_dev: torch.Tensor, lr: float,
 class _AdamArena(ctypes.Structure):          # include/recalgo.h recalgo_adam_arena_t
     _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
                 ("live_list", ctypes.c_void_p), ("live_count", ctypes.c_void_p), ("max_rows", ctypes.c_int64),
-                ("K", ctypes.c_int)]
+                ("K", ctypes.c_int), ("lazy", ctypes.c_int)]
 
 
 def adam_tf1_step_(flat, flat_grad, flat_m, flat_v, arenas, step_dev: torch.Tensor, ticket_dev: Optional[torch.Tensor],
                    lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, zero_grad: bool = True,
-                   advance: bool = False) -> None:
+                   advance: bool = False, lazy: bool = False) -> None:
     """ONE launch: TF1 Adam over the flat dense buffer and over the live rows of every arena, lr_t derived on the device
     from step_dev (already advanced unless `advance`; include/recalgo.h recalgo_adam_tf1_step)."""
     lib = _lib_()
@@ -1205,7 +1205,7 @@ def adam_tf1_step_(flat, flat_grad, flat_m, flat_v, arenas, step_dev: torch.Tens
             _, lst, cnt = a.live_state()
             rows, K = a.weight.shape
             arr[j] = _AdamArena(a.weight.data_ptr(), a.grad.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), lst.data_ptr(),
-                                cnt.data_ptr(), rows, K)
+                                cnt.data_ptr(), rows, K, int(lazy))
         first = i == 0
         if not first:
             raise NotImplementedError("more than 4 embedding arenas in one model")

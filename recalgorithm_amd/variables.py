@@ -391,6 +391,15 @@ class EmbeddingArena:
         _lib.check(lib.recalgo_order_live_list(p(self.live), rows, p(self.live_list), p(self.live_count), p(self._order_ws), st),
                    "recalgo_order_live_list")
 
+    def force_all_live(self) -> None:
+        """Mark every row live: the optimizer then walks the whole arena, i.e. TF1's dense Adam at its full cost (what a
+        long training run converges to; bench.py's forced-dense point)."""
+        live, lst, cnt = self.live_state()
+        rows = self.weight.shape[0]
+        live[:rows] = 1
+        lst[:rows] = torch.arange(rows, dtype=torch.int32, device=lst.device)
+        cnt.fill_(rows)
+
     def live_rows(self) -> torch.Tensor:
         """uint8 [rows]: 1 where a gradient has reached the row."""
         return self.live_state()[0][:self.weight.shape[0]]

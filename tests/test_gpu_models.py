@@ -387,7 +387,9 @@ def test_graphed_step_copies_into_private_buffers(dev):
     b1 = synth.device_features(spec, 256, dev, batch_index=1)[:2]
     keep0 = {k: v.clone() for k, v in feats.items()}
     keep1 = {k: v.clone() for k, v in b1[0].items()}
-    g = GraphedTrainStep(est.train_step, feats, labels, warmup=0)
+    g = GraphedTrainStep(est.train_step, feats, labels, warmup=2)      # two eager steps (lazy state is built), then capture
+    for _ in range(2):
+        ref.train_step(feats, labels)                                  # the two warm-up steps (the capture pass executes nothing)
     seq = [(feats, labels), b1, (feats, labels), b1, (feats, labels)]
     la = [float(g(*b)) for b in seq]
     lr_ = [float(ref.train_step(*b)) for b in seq]
