@@ -74,6 +74,15 @@ int recalgo_embedding_gather_bwd(const int64_t* ids, const float* g, const int64
                                  int B, int F, int K, int g_stride, int g_col, float* grad_arena,
                                  const recalgo_live_t* live, recalgo_stream_t stream);
 
+/* Deterministic alternative to the float-atomic scatter of the four backward kernels (RECALGO_SCATTER=sorted on the
+ * host side; parity / checkpoint-resume runs that must be bit-reproducible):
+ *   grad[sorted_rows[i], :] += vals[perm[i], :]   for sorted_rows[i] >= 0
+ * sorted_rows [M] ascending (a STABLE sort of the lookup's arena rows, -1 = OOV first), perm [M] the sort's
+ * permutation, vals [M, K] the per-item row gradients.  Each row is summed in item order by one thread group and
+ * written by a plain read-modify-write: no atomics, bit-identical from run to run. */
+int recalgo_scatter_rows_sorted(const int64_t* sorted_rows, const int64_t* perm, const float* vals, int64_t M, int K,
+                                float* grad, recalgo_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * K1m  multi-valued field with combiner='mean' (CSR bags).
  * Replaces fc.embedding_column(col, K, combiner='mean') for list-valued columns:

@@ -20,6 +20,7 @@ SIGNATURES = {
     "recalgo_target_arch": (c_char_p, []),
     "recalgo_embedding_gather_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P, c_int, c_int, P]),
     "recalgo_embedding_gather_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "recalgo_scatter_rows_sorted": (c_int, [P, P, P, c_int64, c_int, P, P]),
     "recalgo_embedding_bag_mean_fwd": (c_int, [P, P, P, c_int, c_int, P, c_int, c_int, P]),
     "recalgo_embedding_bag_mean_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "recalgo_sequence_gather_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P]),

@@ -196,6 +196,12 @@ __global__ __launch_bounds__(kThreads) void gather_fwd_kernel(
 // DeepFM variants are faster with 256 (more duplicates per tile; with 64 the DIN step is 3 % slower even
 // though the isolated, L2-warm launch is faster: the extra global atomics land on cold lines in the step).
 
+// kFieldsPerWG adjacent fields per workgroup: the gradient pieces of two K = 16 fields of one example are ONE 128-byte
+// line.  With one field per workgroup every line of g was fetched by two workgroups (20 MB for 7.7 MB algorithmic,
+// profiles/r01r_dcn_pmc_fullrun.md); the rows of the two fields live in different tables, so they share the LDS
+// aggregator without meeting.
+constexpr unsigned kFieldsPerWG = 2;
+
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void gather_bwd_kernel(
     const int64_t* __restrict__ ids, const float* __restrict__ g,
@@ -204,19 +210,24 @@ __global__ __launch_bounds__(kThreads) void gather_bwd_kernel(
     using V = typename VecT<VEC>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const unsigned K = KV * VEC;
-    const Agg a = agg_carve(smem_raw, K, 2 * ex);
+    const Agg a = agg_carve(smem_raw, K, 2 * ex * kFieldsPerWG);
     agg_init(a);
     __syncthreads();
-    const unsigned f = blockIdx.x;
+    const unsigned f0 = blockIdx.x * kFieldsPerWG;
+    const unsigned nf = min(kFieldsPerWG, F - f0);
     const unsigned b0 = blockIdx.y * ex;
     const unsigned nex = min(ex, B - b0);
-    const int64_t rb = row_base[f];
-    for (unsigned i = threadIdx.x; i < nex * KV; i += kThreads) {
-        unsigned e = i / KV, q = i - e * KV;
-        unsigned b = b0 + e;
+    const unsigned per_ex = nf * KV;                       // contiguous VEC-chunks of one example in this tile
+    int64_t rb[kFieldsPerWG];
+#pragma unroll
+    for (unsigned j = 0; j < kFieldsPerWG; ++j) rb[j] = row_base[min(f0 + j, F - 1)];
+    for (unsigned i = threadIdx.x; i < nex * per_ex; i += kThreads) {
+        const unsigned e = i / per_ex, r = i - e * per_ex;
+        const unsigned ff = r / KV, q = r - ff * KV;
+        const unsigned b = b0 + e, f = f0 + ff;
         int64_t id = ids[(size_t)b * F + f];
         if (id < 0) continue;
-        unsigned long long row = (unsigned long long)(rb + id);
+        unsigned long long row = (unsigned long long)((ff ? rb[1] : rb[0]) + id);
         V v = *reinterpret_cast<const V*>(g + (size_t)b * g_stride + g_col + (f * KV + q) * VEC);
         agg_add<VEC>(a, row, q, v, grad_arena + row * K, live);
     }
@@ -470,6 +481,27 @@ __global__ __launch_bounds__(kThreads) void deepfm_sparse_bwd_kernel(
     agg_flush(a, K, grad_arena, grad_w1, live, live_w1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Deterministic scatter (RECALGO_SCATTER=sorted): the (row, item) pairs arrive sorted by row (stable: items of one
+// row keep their original order); the thread that holds the first item of a row sums the row's items in that order
+// and adds the total to the gradient row with a plain read-modify-write (one writer per row per launch) — no float
+// atomics, so two runs are bit-identical.  A parity / resume mode: a hot row is summed by one lane group sequentially.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void scatter_sorted_kernel(const int64_t* __restrict__ sorted_rows,
+                                                                  const int64_t* __restrict__ perm,
+                                                                  const float* __restrict__ vals, int64_t M, unsigned K,
+                                                                  float* __restrict__ grad) {
+    const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int64_t i = t / K;
+    const unsigned k = (unsigned)(t - i * K);
+    if (i >= M) return;
+    const int64_t row = sorted_rows[i];
+    if (row < 0 || (i > 0 && sorted_rows[i - 1] == row)) return;
+    float acc = 0.f;
+    for (int64_t j = i; j < M && sorted_rows[j] == row; ++j) acc += vals[(size_t)perm[j] * K + k];
+    grad[(size_t)row * K + k] += acc;
+}
+
 inline size_t agg_smem(int W, unsigned ex) {
     return 2 * ex * (sizeof(unsigned long long) + (size_t)W * sizeof(float) + sizeof(int)) + 16;
 }
@@ -537,16 +569,17 @@ RECALGO_EXPORT int recalgo_embedding_gather_bwd(const int64_t* ids, const float*
     RECALGO_REQUIRE(B >= 0 && F > 0 && K > 0 && K <= 64 && g_stride >= g_col + F * K && live_ok(live));
     if (B == 0) return 0;
     const int vec = vec_of(K, g_stride, g_col);
-    const unsigned ex = scatter_tile(64);
-    dim3 grid(F, cdiv(B, ex));
+    const unsigned ex = scatter_tile(32);          // x kFieldsPerWG fields = 64 (example, field) items per workgroup
+    dim3 grid(cdiv(F, kFieldsPerWG), cdiv(B, ex));
+    const size_t smem = agg_smem(K, ex * kFieldsPerWG);
     if (vec == 4) {
-        ENSURE_SMEM(gather_bwd_kernel<4>, agg_smem(K, ex));
-        hipLaunchKernelGGL(gather_bwd_kernel<4>, grid, dim3(kThreads), agg_smem(K, ex), as_stream(stream), ids, g,
+        ENSURE_SMEM(gather_bwd_kernel<4>, smem);
+        hipLaunchKernelGGL(gather_bwd_kernel<4>, grid, dim3(kThreads), smem, as_stream(stream), ids, g,
                            row_base, (unsigned)B, (unsigned)F, (unsigned)(K / 4), (unsigned)g_stride,
                            (unsigned)g_col, grad_arena, ex, to_live(live));
     } else {
-        ENSURE_SMEM(gather_bwd_kernel<1>, agg_smem(K, ex));
-        hipLaunchKernelGGL(gather_bwd_kernel<1>, grid, dim3(kThreads), agg_smem(K, ex), as_stream(stream), ids, g,
+        ENSURE_SMEM(gather_bwd_kernel<1>, smem);
+        hipLaunchKernelGGL(gather_bwd_kernel<1>, grid, dim3(kThreads), smem, as_stream(stream), ids, g,
                            row_base, (unsigned)B, (unsigned)F, (unsigned)K, (unsigned)g_stride,
                            (unsigned)g_col, grad_arena, ex, to_live(live));
     }
@@ -671,5 +704,16 @@ RECALGO_EXPORT int recalgo_deepfm_sparse_bwd(const int64_t* ids, const float* em
                        reinterpret_cast<const float4*>(field_sum), reinterpret_cast<const float4*>(g_emb),
                        g_fm1, g_fm2, row_base, (unsigned)B, (unsigned)F, (unsigned)(K / 4), grad_arena, grad_w1, ex, to_live(live),
                        to_live(live_w1));
+    RECALGO_RETURN_LAST();
+}
+
+RECALGO_EXPORT int recalgo_scatter_rows_sorted(const int64_t* sorted_rows, const int64_t* perm, const float* vals,
+                                               int64_t M, int K, float* grad, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(M >= 0 && K >= 1 && (M == 0 || (sorted_rows && perm && vals && grad)));
+    if (M == 0) return 0;
+    const int64_t total = M * K;
+    RECALGO_REQUIRE(cdiv(total, kThreads) > 0);
+    hipLaunchKernelGGL(scatter_sorted_kernel, dim3(cdiv(total, kThreads)), dim3(kThreads), 0, as_stream(stream), sorted_rows,
+                       perm, vals, M, (unsigned)K, grad);
     RECALGO_RETURN_LAST();
 }

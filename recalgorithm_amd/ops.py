@@ -87,6 +87,23 @@ def _live(arena, row_offset: int = 0):
     return ctypes.byref(_Live(live.data_ptr(), lst.data_ptr(), cnt.data_ptr(), int(row_offset)))
 
 
+def _sorted_scatter() -> bool:
+    """RECALGO_SCATTER=sorted: the row-gradient scatters run as stable sort + ordered segment sums (no float atomics):
+    bit-reproducible steps for parity and checkpoint-resume runs; slower than the LDS-aggregated atomic kernels."""
+    import os
+    return os.environ.get("RECALGO_SCATTER", "atomic") == "sorted"
+
+
+def scatter_rows_sorted(arena, rows: torch.Tensor, vals: torch.Tensor) -> None:
+    """arena.grad[rows[i], :] += vals[i, :] (rows < 0 skipped), deterministically; the rows join the live list."""
+    rows = rows.reshape(-1).contiguous()
+    vals = vals.reshape(rows.numel(), -1).contiguous()
+    srt, perm = torch.sort(rows, stable=True)
+    _lib.check(_lib_().recalgo_scatter_rows_sorted(_p(srt), _p(perm), _p(vals), rows.numel(), vals.shape[1], _p(arena.grad),
+                                                   _stream(vals)), "recalgo_scatter_rows_sorted")
+    mark_live_rows(arena, rows, None, 1)
+
+
 def _staged(arena, rows: torch.Tensor):
     """(staged arena, identity ids [M]) for a row-sharded arena, or None when the arena is local."""
     sd = getattr(arena, "sharding", None)
@@ -127,6 +144,11 @@ class _GatherFn(Function):
         ids, arena = ctx.ids, ctx.arena
         B, F = ids.shape
         g = g.contiguous()
+        if _sorted_scatter():
+            rows = torch.where(ids >= 0, ids + ctx.row_base.unsqueeze(0), torch.full_like(ids, -1))
+            scatter_rows_sorted(arena, rows, g.reshape(B * F, arena.K))
+            _flush(arena)
+            return None, None, None, None
         _lib.check(_lib_().recalgo_embedding_gather_bwd(
             _p(ids), _p(g), _p(ctx.row_base), B, F, arena.K, F * arena.K, 0, _p(arena.grad), _live(arena),
             _stream(ids)), "recalgo_embedding_gather_bwd")
@@ -166,6 +188,14 @@ class _BagMeanFn(Function):
         rb, vocab = arena.tables[table_name]
         gt = arena.grad[rb:rb + vocab]
         g = g.contiguous()
+        if _sorted_scatter():
+            lens = offsets[1:] - offsets[:-1]
+            bag = torch.repeat_interleave(torch.arange(B, device=values.device), lens)
+            cnt = torch.zeros(B, device=values.device).index_add_(0, bag, (values >= 0).float()).clamp_(min=1.0)
+            vals = g[bag] / cnt[bag].unsqueeze(1)
+            scatter_rows_sorted(arena, torch.where(values >= 0, values + rb, torch.full_like(values, -1)), vals)
+            _flush(arena)
+            return None, None, None, None, None
         _lib.check(_lib_().recalgo_embedding_bag_mean_bwd(
             _p(values), _p(offsets), _p(g), B, arena.K, arena.K, 0, _p(gt), _live(arena, rb), _stream(offsets)),
             "recalgo_embedding_bag_mean_bwd")
@@ -205,6 +235,15 @@ class _SeqGatherFn(Function):
         rb, vocab = arena.tables[table_name]
         gt = arena.grad[rb:rb + vocab]
         g = g.contiguous()
+        if _sorted_scatter():
+            lens = (offsets[1:] - offsets[:-1]).clamp(max=T)
+            tpos = torch.arange(T, device=values.device).unsqueeze(0)
+            valid = tpos < lens.unsqueeze(1)                                   # [B, T]
+            src = (offsets[:-1].unsqueeze(1) + tpos).clamp(max=max(values.numel() - 1, 0))
+            ids_bt = torch.where(valid, values[src] if values.numel() else torch.full_like(src, -1), torch.full_like(src, -1))
+            scatter_rows_sorted(arena, torch.where(ids_bt >= 0, ids_bt + rb, torch.full_like(ids_bt, -1)), g.reshape(B * T, arena.K))
+            _flush(arena)
+            return None, None, None, None, None, None
         _lib.check(_lib_().recalgo_sequence_gather_bwd(
             _p(values), _p(offsets), _p(g), B, T, arena.K, _p(gt), _live(arena, rb), _stream(offsets)),
             "recalgo_sequence_gather_bwd")
@@ -247,6 +286,17 @@ class _DeepFMSparseFn(Function):
         emb, fsum = ctx.saved_tensors
         B, F = ids.shape
         g_emb, g_fm1, g_fm2 = g_emb.contiguous(), g_fm1.contiguous(), g_fm2.contiguous()
+        if _sorted_scatter():
+            K = arena.K
+            rows = torch.where(ids >= 0, ids + row_base.unsqueeze(0), torch.full_like(ids, -1))
+            e3, s3 = emb.reshape(B, F, K), fsum.reshape(B, 1, K)
+            vals = torch.addcmul(g_emb.reshape(B, F, K), g_fm2.reshape(B, 1, 1), s3 - e3)     # g_emb + g_fm2 * (S - e)
+            scatter_rows_sorted(arena, rows, vals)
+            scatter_rows_sorted(w1, rows, g_fm1.reshape(B, 1, 1).expand(B, F, 1))
+            _flush(arena)
+            _flush(w1)
+            torch.sum(g_fm1, dim=0, out=bias.grad.view(1))
+            return None, None, None, None, None, None
         _lib.check(_lib_().recalgo_deepfm_sparse_bwd(
             _p(ids), _p(emb), _p(fsum), _p(g_emb), _p(g_fm1), _p(g_fm2), _p(row_base), B, F, arena.K,
             _p(arena.grad), _p(w1.grad), _live(arena), _live(w1), _stream(ids)), "recalgo_deepfm_sparse_bwd")

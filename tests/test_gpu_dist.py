@@ -82,7 +82,7 @@ def test_sharded_single_rank_equals_plain(dev, pg, model):
         l0 = ref.train_step(feats, labels)
         l1 = shd.train_step(feats, labels)
         assert_close(l1, l0, what=f"{model} loss step {step}")
-    a0, a1 = ref.store.named_arrays(), shd.store.named_arrays()
+    a0, a1 = ref.store.named_arrays(), shd.store.named_arrays(gather=True)       # (tables of a sharded arena: collective gather)
     for k in a0:
         if "embedding_weights" in k or "kernel/" in k:
             continue

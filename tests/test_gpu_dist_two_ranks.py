@@ -60,7 +60,7 @@ def _worker(rank, port, model, capacity_factor, errq):
             d.all_reduce(l1)
             assert_close(l1 / WORLD, l0, what=f"{model} mean-of-rank losses vs global loss, step {step}", rtol=2e-5)
         assert not P.exchange_overflowed(shd)
-        a0, a1 = ref.store.named_arrays(), shd.store.named_arrays()
+        a0, a1 = ref.store.named_arrays(), shd.store.named_arrays(gather=True)   # (tables of a sharded arena: collective gather)
         for k in a0:
             if "embedding_weights" in k or "kernel/" in k:     # arena tables: compared un-sharded below
                 continue
