@@ -394,6 +394,28 @@ int recalgo_batchnorm_train_bwd(const float* x, const float* gamma, const float*
                                 float* dgamma, float* dbeta, void* workspace, recalgo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Sibling models on the same kernels: their remaining interaction steps.
+ *   NFM bi-interaction pooling (algorithm/NFM/nfm.py:155-167): emb [B, F, K] ->
+ *       out[b, k] = 0.5 * ((sum_f e_fk)^2 - sum_f e_fk^2)          (the FM second order without the sum over k)
+ *       bwd: d_emb[b, f, k] = g[b, k] * (S[b, k] - e[b, f, k])
+ *   AFM attention pooling (algorithm/AFM/afm.py:184-188): pairs [B, P, K] (the pair Hadamard products: the bilinear
+ *       kernel with W = I), att [B, P] (the attention MLP's scores: the dense kernels) ->
+ *       score = softmax over P, out[b, :] = sum_p score[b, p] * pairs[b, p, :];  score [B, P] is saved for
+ *       bwd: d_pairs[b, p, :] = score * g[b, :], d_att = score * (<g, pairs_p> - sum_q score_q <g, pairs_q>)
+ *   FFM field-aware pair dots (algorithm/FFM/ffm.py:146-160): x [B, F, F-1, K], row (i, s) = field i looked up in
+ *       its s-th sub-table -> out[b] = sum_{i<j} <x[b, i, j-1, :], x[b, j, i, :]>
+ *       bwd: dx[b, a, s, :] = g[b] * x[b, partner(a, s), :]
+ * ------------------------------------------------------------------------------------------ */
+int recalgo_bi_interaction_fwd(const float* emb, int B, int F, int K, float* out, recalgo_stream_t stream);
+int recalgo_bi_interaction_bwd(const float* emb, const float* g, int B, int F, int K, float* d_emb, recalgo_stream_t stream);
+int recalgo_attention_pool_fwd(const float* pairs, const float* att, int B, int P, int K, float* out, float* score,
+                               recalgo_stream_t stream);
+int recalgo_attention_pool_bwd(const float* pairs, const float* score, const float* g, int B, int P, int K, float* d_pairs,
+                               float* d_att, recalgo_stream_t stream);
+int recalgo_ffm_pairs_fwd(const float* x, int B, int F, int K, float* out, recalgo_stream_t stream);
+int recalgo_ffm_pairs_bwd(const float* x, const float* g, int B, int F, int K, float* dx, recalgo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * a14  loss tail: sigmoid + mean sigmoid cross entropy, forward and d(loss)/d(logit) fused.
  * Replaces tf.sigmoid + tf.reduce_mean(tf.nn.sigmoid_cross_entropy_with_logits)
  * algorithm/DeepFM/deepfm.py:217,235 (same in all six model_fns).

@@ -259,6 +259,18 @@ def dense(x, units, activation: Optional[str] = None,
     return _DenseFn.apply(store.anchor, x, kernel, bias, activation == "relu", input_l2, grad_join)
 
 
+def dense_with(x: torch.Tensor, kernel: Variable, bias: Optional[Variable] = None, relu: bool = False) -> torch.Tensor:
+    """tf.matmul(x, kernel) (+ bias) (+ relu) on variables the model created itself with tf.get_variable (AFM's attention
+    network, afm.py:168-190): the same kernels as `dense` (one-unit outputs go through the head kernel)."""
+    store = current_store()
+    if kernel.data.shape[1] == 1 and not relu:
+        from . import ops
+        xc = x if x.is_contiguous() else x.contiguous()
+        if ops.dense1_supported([xc]):
+            return _Dense1Fn.apply(store.anchor, kernel, bias, xc)
+    return _DenseFn.apply(store.anchor, x, kernel, bias, relu, 0.0, None)
+
+
 def l2_value(x: torch.Tensor, half_coeff: float) -> torch.Tensor:
     """half_coeff * sum(x^2) as a detached scalar (its gradient is taken care of by `dense(input_l2=)`)."""
     with torch.no_grad():
@@ -337,10 +349,17 @@ def batch_normalization(x: torch.Tensor, training: bool = False,
     return _BatchNormInferFn.apply(x, inv, beta.data - mmean.data * inv)
 
 
+DROPOUT_KEEP_MASKS: list = []      # test hook: keep masks consumed (FIFO) by the next training-mode dropout calls
+
+
 def dropout(x: torch.Tensor, rate: float, training: bool = False) -> torch.Tensor:
-    """tf.layers.dropout: keep prob 1-rate, scaled by 1/(1-rate); identity when not training."""
+    """tf.layers.dropout: keep prob 1-rate, scaled by 1/(1-rate); identity when not training.  TF's random stream
+    cannot be reproduced: parity tests inject the keep mask the golden recorded through DROPOUT_KEEP_MASKS."""
     if not training or rate <= 0.0:
         return x
+    if DROPOUT_KEEP_MASKS:
+        keep = DROPOUT_KEEP_MASKS.pop(0).to(device=x.device, dtype=x.dtype)
+        return x * keep / (1.0 - rate)
     return torch.nn.functional.dropout(x, p=rate, training=True)
 
 

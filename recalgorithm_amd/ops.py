@@ -781,6 +781,90 @@ def field_pair_logit(store, emb_flat: torch.Tensor, r: Variable, F: int, K: int)
 
 
 # =============================================================================================
+# sibling models (SURVEY.md §8f-3): NFM bi-interaction, AFM attention pooling, FFM pair dots (csrc/siblings.hip)
+# =============================================================================================
+class _BiInteractionFn(Function):
+    @staticmethod
+    def forward(ctx, emb, F, K):
+        emb = emb.contiguous()
+        B = emb.shape[0]
+        out = torch.empty(B, K, device=emb.device, dtype=torch.float32)
+        _lib.check(_lib_().recalgo_bi_interaction_fwd(_p(emb), B, F, K, _p(out), _stream(emb)), "recalgo_bi_interaction_fwd")
+        ctx.dims = (F, K)
+        ctx.save_for_backward(emb)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (emb,) = ctx.saved_tensors
+        F, K = ctx.dims
+        d = torch.empty_like(emb)
+        _lib.check(_lib_().recalgo_bi_interaction_bwd(_p(emb), _p(g.contiguous()), emb.shape[0], F, K, _p(d), _stream(emb)),
+                   "recalgo_bi_interaction_bwd")
+        return d, None, None
+
+
+def bi_interaction(emb_flat: torch.Tensor, F: int, K: int) -> torch.Tensor:
+    """[B, F*K] -> [B, K]: 0.5 * ((sum_f e_f)^2 - sum_f e_f^2) (nfm.py:155-167)."""
+    _chk(emb_flat, torch.float32, "fields_embeddings")
+    return _BiInteractionFn.apply(emb_flat, int(F), int(K))
+
+
+class _AttentionPoolFn(Function):
+    @staticmethod
+    def forward(ctx, pairs, att):
+        pairs, att = pairs.contiguous(), att.contiguous()
+        B, P, K = pairs.shape
+        out = torch.empty(B, K, device=pairs.device, dtype=torch.float32)
+        score = torch.empty(B, P, device=pairs.device, dtype=torch.float32)
+        _lib.check(_lib_().recalgo_attention_pool_fwd(_p(pairs), _p(att), B, P, K, _p(out), _p(score), _stream(pairs)),
+                   "recalgo_attention_pool_fwd")
+        ctx.save_for_backward(pairs, score)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pairs, score = ctx.saved_tensors
+        B, P, K = pairs.shape
+        dp, da = torch.empty_like(pairs), torch.empty_like(score)
+        _lib.check(_lib_().recalgo_attention_pool_bwd(_p(pairs), _p(score), _p(g.contiguous()), B, P, K, _p(dp), _p(da),
+                                                      _stream(pairs)), "recalgo_attention_pool_bwd")
+        return dp, da
+
+
+def attention_pool(pairs: torch.Tensor, att: torch.Tensor) -> torch.Tensor:
+    """pairs [B, P, K], att [B, P] -> sum_p softmax(att)[p] * pairs[:, p, :]  (afm.py:184-188)."""
+    return _AttentionPoolFn.apply(pairs, att.reshape(pairs.shape[0], pairs.shape[1]))
+
+
+class _FfmPairsFn(Function):
+    @staticmethod
+    def forward(ctx, x, F, K):
+        x = x.contiguous()
+        B = x.shape[0]
+        out = torch.empty(B, 1, device=x.device, dtype=torch.float32)
+        _lib.check(_lib_().recalgo_ffm_pairs_fwd(_p(x), B, F, K, _p(out), _stream(x)), "recalgo_ffm_pairs_fwd")
+        ctx.dims = (F, K)
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        F, K = ctx.dims
+        dx = torch.empty_like(x)
+        _lib.check(_lib_().recalgo_ffm_pairs_bwd(_p(x), _p(g.contiguous()), x.shape[0], F, K, _p(dx), _stream(x)),
+                   "recalgo_ffm_pairs_bwd")
+        return dx, None, None
+
+
+def ffm_pairs(x: torch.Tensor, F: int, K: int) -> torch.Tensor:
+    """x [B, F*(F-1)*K] (field i in its sub-table s at [i, s]) -> [B, 1] = sum_{i<j} <x[i][j-1], x[j][i]> (ffm.py:146-160)."""
+    _chk(x, torch.float32, "field-aware embeddings")
+    return _FfmPairsFn.apply(x, int(F), int(K))
+
+
+# =============================================================================================
 # context-MLP glue (csrc/mlp.hip): dense backward epilogue, BatchNorm training
 # =============================================================================================
 def _mat(t: torch.Tensor, name: str) -> torch.Tensor:

@@ -235,7 +235,7 @@ class VariableStore:
                 from . import parallel
                 full = parallel.unshard_arena(ar, "weight")
                 for tn, (rb, vocab) in ar.tables.items():
-                    out[tn] = full[rb:rb + vocab]
+                    out[tn] = ar.shaped(tn, full[rb:rb + vocab])
                 continue
             for tn in ar.tables:
                 out[tn] = ar.table_view(tn)
@@ -249,7 +249,7 @@ def named_grads(store: VariableStore) -> Dict[str, torch.Tensor]:
     out = {n: v.grad for n, v in store.vars.items() if v.grad is not None}
     for ar in store.arenas.values():
         for tn, (rb, vocab) in ar.tables.items():
-            out[tn] = ar.grad[rb:rb + vocab]
+            out[tn] = ar.shaped(tn, ar.grad[rb:rb + vocab])
     return out
 
 
@@ -299,9 +299,14 @@ class EmbeddingArena:
         self._order_ws = None                                  # order_live_list's scratch
         self.trainable = True
 
-    def add_table(self, name: str, vocab: int, init: Optional[torch.Tensor] = None) -> int:
+    def add_table(self, name: str, vocab: int, init: Optional[torch.Tensor] = None,
+                  view_shape: Optional[Sequence[int]] = None) -> int:
+        """`view_shape`: the shape the reference's variable of this name has when it is not [vocab, K] (FFM's
+        (F-1, V, K) per-field tables occupy (F-1) * V arena rows): named_arrays / named_grads present it that way."""
         if name in self.tables:
             return self.tables[name][0]
+        if view_shape is not None:
+            self.__dict__.setdefault("view_shapes", {})[name] = tuple(int(x) for x in view_shape)
         if self.weight is not None:
             raise RuntimeError("arena already materialised")
         rb = self.rows
@@ -347,7 +352,11 @@ class EmbeddingArena:
             raise RuntimeError(f"arena {self.name} is row-sharded over {self.sharding.sh.world} ranks: its tables are not "
                                "local views (gather them with parallel.unshard_arena / VariableStore.named_arrays(gather=True))")
         rb, vocab = self.tables[name]
-        return self.weight[rb:rb + vocab]
+        return self.shaped(name, self.weight[rb:rb + vocab])
+
+    def shaped(self, name: str, rows: torch.Tensor) -> torch.Tensor:
+        vs = self.__dict__.get("view_shapes", {}).get(name)
+        return rows if vs is None else rows.view(vs)
 
     # -- live-row bookkeeping (optimizer cost proportional to the rows ever touched; see
     #    include/recalgo.h recalgo_mark_live_rows / recalgo_adam_tf1_list) ---------------------------

@@ -136,6 +136,9 @@ def test_model_golden(dev, name, tmp_path):
     for k, v in GU.section(d, "predict/").items():
         assert_close(pr.predictions[k], torch.from_numpy(v), what=f"{name} predict/{k}")
     # TRAIN: loss, gradients, one TF1-Adam step
+    if "aux/dropout_mask_0" in d:       # NFM's hard-coded dropout: the keep mask the reference run drew is part of the golden
+        from recalgorithm_amd import nn
+        nn.DROPOUT_KEEP_MASKS[:] = [torch.from_numpy(d["aux/dropout_mask_0"])]
     spec = est._call_model_fn(feats, labels, ModeKeys.TRAIN)
     assert_close(spec.loss, torch.from_numpy(d["train/loss"]), what=f"{name} loss")
     spec.loss.backward()
