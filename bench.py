@@ -44,8 +44,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-tunable", dest="tunable", action="store_false",
                     help="keep hipBLASLt's default fp32 GEMM selection for the context MLP (default: PyTorch "
                          "TunableOp picks the GEMM kernels during warm-up; selections are frozen before timing)")
-    ap.add_argument("--capacity-factor", type=float, default=2.0,
-                    help="N > 1: bucket capacity of the static id/row exchange, in units of the mean bucket size")
+    ap.add_argument("--capacity-factor", type=float, default=1.5,
+                    help="N > 1: bucket capacity of the static id/row exchange, in units of requests / world "
+                         "(the buckets hold DISTINCT rows, so the mean fill is well below 1)")
     ap.add_argument("--big-table-rows", type=int, default=0,
                     help="replace the vocabulary of the last field by a table of this many rows "
                          "(BASELINE configs[4]: one 100M x 16 table)")
@@ -62,7 +63,7 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def build_estimator(args, device, rank=0, world=1):
+def build_estimator(args, device, rank=0, world=1, before_build=None):
     from recalgorithm_amd import feature_column as fc
     from recalgorithm_amd.estimator import Estimator, RunConfig
     from recalgorithm_amd.io import synth
@@ -138,6 +139,8 @@ def build_estimator(args, device, rank=0, world=1):
         params["lazy_adam"] = True
     est = Estimator(model_fn=model_fn, params=params, config=RunConfig(device=device, seed=42))
     feats, labels, _ = synth.device_features(spec, args.batch, device, batch_index=rank)
+    if before_build is not None:
+        before_build(est)
     est.build(feats, labels)
     return est, spec, feats, labels, workload
 
@@ -432,13 +435,14 @@ def timed_run(args, device, rank, world, dist, capacity_factor):
     if args.tunable:
         import torch.cuda.tunable as tunable
         tunable.tuning_enable(True)
-    est, spec, feats, labels, workload = build_estimator(args, device, rank, world)
+    shard = None
     if world > 1:
-        # row-shard the embedding arenas over the ranks (fixed-capacity id / row all_to_all over
-        # RCCL: static shapes, no host sync -> the N-GPU step is still one hipGraph), all-reduce the
-        # flat dense gradient, back-propagate loss / N
+        # row-shard the embedding arenas over the ranks, BEFORE the build so that every rank only ever holds its own
+        # rows (de-duplicated, fixed-capacity id / row all_to_all over RCCL: static shapes, no host sync -> the
+        # N-GPU step is still one hipGraph), all-reduce the flat dense gradient, back-propagate loss / N
         from recalgorithm_amd.parallel import attach_data_parallel
-        attach_data_parallel(est, dist, capacity_factor=capacity_factor)
+        shard = lambda e: attach_data_parallel(e, dist, capacity_factor=capacity_factor)
+    est, spec, feats, labels, workload = build_estimator(args, device, rank, world, before_build=shard)
     from recalgorithm_amd.estimator import GraphedTrainStep
     from recalgorithm_amd.io import synth
     # distinct synthetic batches, all resident in HBM before the timed region; step i consumes

@@ -521,6 +521,16 @@ int recalgo_order_live_list(const unsigned char* row_live, int64_t rows, int* li
 int recalgo_exchange_plan(const int64_t* rows, int64_t M, int world, int64_t cap, int64_t* send_local,
                           int64_t* send_pos, int64_t* req_slot, int* counters, unsigned char* overflow,
                           recalgo_stream_t stream);
+/* De-duplication of one batch's row requests before the owner bucketing (a Zipf batch asks for its hot rows many
+ * times; only one request per distinct row needs to cross xGMI).  rows [M] int64 (< 0 = no request), M < 2^30.
+ * rep [M] int64: the SMALLEST request index that asks for the same row as request i (rep[i] = i for the first
+ * request of a row and for rows < 0); unique_rows [M] = rows[i] where rep[i] == i, -1 elsewhere.  Plan the exchange
+ * on unique_rows; request i then reads / accumulates into the staged row of request rep[i].  Deterministic (does
+ * not depend on the arrival order of the atomics), three launches, no host synchronisation.  workspace of
+ * recalgo_dedup_rows_workspace_bytes(M) bytes (-1 for an M out of range), contents irrelevant on entry. */
+int64_t recalgo_dedup_rows_workspace_bytes(int64_t M);
+int recalgo_dedup_rows(const int64_t* rows, int64_t M, int64_t* unique_rows, int64_t* rep, void* workspace,
+                       recalgo_stream_t stream);
 /* hipGraph-replayable step counter: step_dev[0] += 1; lr_t_dev[0] = lr*sqrt(1-b2^t)/(1-b1^t)
  * (double precision on device).  Pass lr_t_dev to recalgo_adam_tf1_dense to override lr_t. */
 int recalgo_adam_tf1_advance(int64_t* step_dev, float lr, float beta1, float beta2, float* lr_t_dev,

@@ -350,7 +350,7 @@ def model_goldens(tf, vocab_dir):
     run("model_fwfm", _import_ref("FwFM", "fwfm"), "fwfm_model_fn", fwfm_params,
         dict(learning_rate=0.005, embedding_dim=8))
 
-    # §8f-3 sibling, oracle pinned ahead of its kernels: AFM (pair Hadamard products + attention net, afm.py:143-190)
+    # §8f-3 sibling: AFM (pair Hadamard products + attention net, afm.py:143-190)
     def afm_params(m):
         dense_c, cat, label = m.create_feature_columns()
         return ({"category_feature_columns": cat, "dense_feature_columns": dense_c,
@@ -359,7 +359,7 @@ def model_goldens(tf, vocab_dir):
     run("model_afm", _import_ref("AFM", "afm"), "afm_model_fn", afm_params,
         dict(learning_rate=0.005, embedding_dim=8, attention_factor=12))
 
-    # §8f-3 sibling, oracle pinned ahead of its kernels: FFM (field-aware pair inner products, ffm.py:118-163)
+    # §8f-3 sibling: FFM (field-aware pair inner products, ffm.py:118-163)
     def ffm_params(m):
         cols, label = m.create_feature_columns()
         return ({"one_hot_category_feature_columns": cols, "learning_rate": m.FLAGS.learning_rate,
@@ -367,7 +367,7 @@ def model_goldens(tf, vocab_dir):
                  "fields_vocabulary_size_tuple": [(c.categorical_column.name, int(c.variable_shape[-1])) for c in cols]}, cols)
     run("model_ffm", _import_ref("FFM", "ffm"), "ffm_model_fn", ffm_params, dict(learning_rate=0.005, embedding_dim=4))
 
-    # §8f-3 sibling, oracle pinned ahead of its kernels: NFM (bi-interaction pooling + MLP, nfm.py:143-182); its
+    # §8f-3 sibling: NFM (bi-interaction pooling + MLP, nfm.py:143-182); its
     # dropout after the pooling is hard-coded (0.1, :170): the TRAIN golden carries the keep mask
     def nfm_params(m):
         dense_c, cat, label = m.create_feature_columns()

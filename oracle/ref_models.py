@@ -144,7 +144,7 @@ def fwfm(P, feats, labels, params, training=False):
 
 
 def afm(P, feats, labels, params, training=False):
-    """algorithm/AFM/afm.py:143-192 (SURVEY.md §8f-3 sibling; pinned ahead of its kernels).  Quirk: the model
+    """algorithm/AFM/afm.py:143-192 (SURVEY.md §8f-3 sibling).  Quirk: the model
     also builds `category_input = fc.input_layer(...)` (:150-151) — its tables exist as variables and get zero
     gradients — but the pair interactions use a second set of tables, one `input_layer` call per column under
     `pair_interaction_part` (:156-159)."""
@@ -174,7 +174,7 @@ def _bags(ids):
 
 
 def ffm(P, feats, labels, params, training=False):
-    """algorithm/FFM/ffm.py:118-163 (SURVEY.md §8f-3 sibling; pinned ahead of its kernels).
+    """algorithm/FFM/ffm.py:118-163 (SURVEY.md §8f-3 sibling).
     First order: multi-hot indicator rows @ (sum V, 1) kernel + bias — an id that occurs twice in a bag counts
     twice (A-5).  Second order: field i owns F-1 tables `<name>_embedding[(F-1), V_i, K]`; for a pair i < j the
     reference looks field i up in its sub-table j-1 and field j in its sub-table i (:150-157) through
@@ -183,7 +183,8 @@ def ffm(P, feats, labels, params, training=False):
     cols = params["one_hot_category_feature_columns"]
     bags = {c.key: _bags(feats[c.key]) for c in cols}
     B = len(next(iter(bags.values())))
-    kern = P["ffm_first_order/fm_first_order_dense/kernel"].reshape(-1)
+    kk = "ffm_first_order/fm_first_order_dense/kernel"      # whole (sum V, 1) kernel, or one slice per column (A-1)
+    kern = (P[kk] if kk in P else torch.cat([P[f"{kk}/{c.key}"] for c in _sorted(cols)])).reshape(-1)
     first = torch.zeros(B, dtype=kern.dtype)
     row0 = 0
     for c in _sorted(cols):                                            # :118-119 input_layer: sorted by column name
@@ -220,7 +221,7 @@ def ffm(P, feats, labels, params, training=False):
 
 
 def nfm(P, feats, labels, params, training=False, dropout_masks=None):
-    """algorithm/NFM/nfm.py:143-184 (SURVEY.md §8f-3 sibling; pinned ahead of its kernels).  Bi-interaction pooling
+    """algorithm/NFM/nfm.py:143-184 (SURVEY.md §8f-3 sibling).  Bi-interaction pooling
     0.5 * ((sum_f e_f)^2 - sum_f e_f^2) -> BatchNorm `bi_interaction_bn` -> dropout with the HARD-CODED rate 0.1
     (:170, independent of the dropout_rate flag) -> MLP (dense(relu) -> BN -> dropout(rate flag)) -> dense(1).
     In training mode `dropout_masks[0]` is the keep mask of that dropout (TF's random stream cannot be

@@ -64,6 +64,8 @@ SIGNATURES = {
     "recalgo_dense1_bwd": (c_int, [P, P, c_int, c_int, P, P, P, P, P, P, P]),
     "recalgo_order_live_list_workspace_bytes": (c_int64, [c_int64]),
     "recalgo_order_live_list": (c_int, [P, c_int64, P, P, P, P]),
+    "recalgo_dedup_rows_workspace_bytes": (c_int64, [c_int64]),
+    "recalgo_dedup_rows": (c_int, [P, c_int64, P, P, P, P]),
     "recalgo_exchange_plan": (c_int, [P, c_int64, c_int, c_int64, P, P, P, P, P, P]),
     "recalgo_adam_tf1_list": (c_int, [P, P, P, P, P, P, c_int64, c_int, c_float, P, c_float, c_float, c_float, c_int, P]),
     "recalgo_adam_tf1_step": (c_int, [P, P, P, P, c_int64, P, c_int, P, P, c_int, c_float, c_float, c_float, c_float, c_int, P]),

@@ -62,7 +62,79 @@ __global__ __launch_bounds__(256) void exchange_plan_assign_kernel(const int64_t
     req_slot[i] = dest;
 }
 
+// ---- request de-duplication ---------------------------------------------------------------------------------
+// A Zipf batch asks for its hot rows many times; only the FIRST request of each row needs to travel.  An
+// open-addressing table (keys = rows, value = the smallest request index that asked for the row) is filled with one
+// atomicCAS + one atomicMin per request, then every request reads its row's entry back: deterministic (the
+// representative is the smallest index whatever the arrival order), static shapes, no sort.
+__global__ __launch_bounds__(256) void dedup_init_kernel(int64_t* __restrict__ keys, int* __restrict__ first, int64_t slots) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < slots) {
+        keys[i] = -1;
+        first[i] = 0x7fffffff;
+    }
+}
+
+__global__ __launch_bounds__(256) void dedup_insert_kernel(const int64_t* __restrict__ rows, int64_t M,
+                                                           int64_t* __restrict__ keys, int* __restrict__ first,
+                                                           unsigned shift, unsigned mask, int* __restrict__ slot_of) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const int64_t row = rows[i];
+    if (row < 0) return;
+    unsigned h = (unsigned)(((unsigned long long)row * 0x9E3779B97F4A7C15ull) >> shift) & mask;
+    for (;;) {
+        const unsigned long long seen = atomicCAS((unsigned long long*)&keys[h], ~0ull, (unsigned long long)row);
+        if (seen == ~0ull || seen == (unsigned long long)row) break;
+        h = (h + 1) & mask;                       // load factor <= 1/2: short probes
+    }
+    atomicMin(&first[h], (int)i);
+    slot_of[i] = (int)h;
+}
+
+__global__ __launch_bounds__(256) void dedup_resolve_kernel(const int64_t* __restrict__ rows, int64_t M,
+                                                            const int* __restrict__ first, const int* __restrict__ slot_of,
+                                                            int64_t* __restrict__ unique_rows, int64_t* __restrict__ rep) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const int64_t row = rows[i];
+    const int64_t r = row < 0 ? i : (int64_t)first[slot_of[i]];
+    rep[i] = r;
+    unique_rows[i] = r == i ? row : -1;
+}
+
+struct DedupLayout {
+    int64_t slots;
+    unsigned shift, mask;
+};
+DedupLayout dedup_layout(int64_t M) {
+    unsigned lg = 6;
+    while ((1ll << lg) < 2 * M) ++lg;
+    return {1ll << lg, 64u - lg, (unsigned)((1ll << lg) - 1)};
+}
+
 }  // namespace
+
+RECALGO_EXPORT int64_t recalgo_dedup_rows_workspace_bytes(int64_t M) {
+    if (M < 0 || M >= (1ll << 30)) return -1;
+    return dedup_layout(M).slots * 12 + M * 4;
+}
+
+RECALGO_EXPORT int recalgo_dedup_rows(const int64_t* rows, int64_t M, int64_t* unique_rows, int64_t* rep, void* workspace,
+                                      recalgo_stream_t stream) {
+    RECALGO_REQUIRE(M >= 0 && M < (1ll << 30));
+    if (M == 0) return 0;
+    RECALGO_REQUIRE(rows != nullptr && unique_rows != nullptr && rep != nullptr && workspace != nullptr);
+    const DedupLayout L = dedup_layout(M);
+    int64_t* keys = (int64_t*)workspace;
+    int* first = (int*)(keys + L.slots);
+    int* slot_of = first + L.slots;
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(dedup_init_kernel, dim3(cdiv(L.slots, 256)), dim3(256), 0, st, keys, first, L.slots);
+    hipLaunchKernelGGL(dedup_insert_kernel, dim3(cdiv(M, 256)), dim3(256), 0, st, rows, M, keys, first, L.shift, L.mask, slot_of);
+    hipLaunchKernelGGL(dedup_resolve_kernel, dim3(cdiv(M, 256)), dim3(256), 0, st, rows, M, first, slot_of, unique_rows, rep);
+    RECALGO_RETURN_LAST();
+}
 
 RECALGO_EXPORT int recalgo_exchange_plan(const int64_t* rows, int64_t M, int world, int64_t cap,
                                          int64_t* send_local, int64_t* send_pos, int64_t* req_slot,

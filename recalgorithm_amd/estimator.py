@@ -319,6 +319,7 @@ class Estimator:
         self.store = VariableStore(self.device, seed=self.config.seed)
         self.global_step = 0
         self._built = False
+        self._after_build = []           # callables run once at the end of the build (parallel.attach_data_parallel)
         self.grad_hook = None     # set by parallel wrappers (dense-grad all-reduce)
         self.loss_grad_scale = None   # 1/world under data parallelism (parallel.attach_data_parallel)
         self._seed_grad, self._seed_value = None, None
@@ -387,6 +388,8 @@ class Estimator:
         self.store.finalize()
         self._built = True
         self._maybe_restore()
+        for fn in self._after_build:
+            fn()
 
     def build(self, features, labels=None, mode=ModeKeys.TRAIN):
         features, labels = self._to_device(features, labels)
@@ -626,32 +629,38 @@ def collect_checkpoint_state(store: VariableStore, global_step: int):
 
 
 def restore_checkpoint_state(store: VariableStore, state: dict, device, where: str = "checkpoint") -> int:
-    """Load `state` into a built, NOT yet sharded store; returns the global step.  A variable that is missing from the
-    file or whose shape changed (another vocabulary, other hidden_units) makes the restore fail: resuming the step
-    counter and Adam's bias correction on a partly re-initialised model is never what the caller wants."""
-    if any(getattr(a, "sharding", None) is not None for a in store.arenas.values()):
-        raise RuntimeError("restore_checkpoint_state: restore before attach_data_parallel shards the arenas")
-    arrays = store.named_arrays()
+    """Load `state` into a built store; returns the global step.  The file holds whole tables (it is independent of
+    the number of ranks): a row-sharded arena takes its own rows r % world == rank from them.  A variable that is
+    missing from the file or whose shape changed (another vocabulary, other hidden_units) makes the restore fail:
+    resuming the step counter and Adam's bias correction on a partly re-initialised model is never what the caller
+    wants."""
     saved = state["variables"]
+    arrays = {n: v.data for n, v in store.vars.items()}
+    table_shape = {}
+    for a in store.arenas.values():
+        for tn, (rb, vocab) in a.tables.items():
+            table_shape[tn] = a.__dict__.get("view_shapes", {}).get(tn, (vocab, a.K))
     blocks = {b for b, _ in store._alias.values()}
     problems = []
-    for k, t in arrays.items():
+    for k, shape in list((k, tuple(t.shape)) for k, t in arrays.items()) + list(table_shape.items()):
         if k in blocks:
             continue                                           # fused blocks are covered by their named parts
         if k not in saved:
             problems.append(f"{k}: not in the file")
-        elif tuple(saved[k].shape) != tuple(t.shape):
-            problems.append(f"{k}: file has {tuple(saved[k].shape)}, model wants {tuple(t.shape)}")
+        elif tuple(saved[k].shape) != tuple(shape):
+            problems.append(f"{k}: file has {tuple(saved[k].shape)}, model wants {tuple(shape)}")
     for n, a in store.arenas.items():
+        sd = getattr(a, "sharding", None)
+        full = (sd.global_rows if sd is not None else a.m.shape[0], a.K)
         for slot in ("arena_m", "arena_v"):
-            if n not in state.get(slot, {}) or tuple(state[slot][n].shape) != tuple(a.m.shape):
+            if n not in state.get(slot, {}) or tuple(state[slot][n].shape) != full:
                 problems.append(f"{slot}[{n}]: missing or shape differs")
     if state.get("flat_m") is not None and store.flat_m is not None and state["flat_m"].shape != store.flat_m.shape:
         problems.append(f"dense Adam moments: file has {tuple(state['flat_m'].shape)}, model wants {tuple(store.flat_m.shape)}")
     if problems:
         raise RuntimeError(f"{where} does not match the model ({len(problems)} problem(s)): " + "; ".join(problems[:8])
                            + (" ..." if len(problems) > 8 else ""))
-    unused = [k for k in saved if k not in arrays]
+    unused = [k for k in saved if k not in arrays and k not in table_shape]
     if unused:
         import warnings
         warnings.warn(f"{where}: {len(unused)} saved variable(s) the model does not have were ignored: {unused[:5]}")
@@ -663,8 +672,16 @@ def restore_checkpoint_state(store: VariableStore, state: dict, device, where: s
             store.flat_m.copy_(state["flat_m"])
             store.flat_v.copy_(state["flat_v"])
         for n, a in store.arenas.items():
-            a.m.copy_(state["arena_m"][n])
-            a.v.copy_(state["arena_v"][n])
+            sd = getattr(a, "sharding", None)
+            rank, world = (0, 1) if sd is None else (sd.sh.rank, sd.sh.world)
+            for tn, (rb, vocab) in a.tables.items():
+                first = (rank - rb) % world                    # first row of the table this rank owns
+                mine = saved[tn].reshape(vocab, a.K)[first::world]
+                l0 = (rb + first) // world
+                a.weight[l0:l0 + mine.shape[0]].copy_(mine)
+            n_local = len(range(rank, state["arena_m"][n].shape[0], world))
+            a.m[:n_local].copy_(state["arena_m"][n][rank::world])
+            a.v[:n_local].copy_(state["arena_v"][n][rank::world])
             a.live = None            # rebuilt from the restored moments on next use
     if state.get("opt_step") is not None:
         store.opt_state = {

@@ -26,8 +26,13 @@ Two exchange plans implement steps 1-4:
     fixed capacity of `capacity_factor` x the mean bucket size, unused slots carry id -1 / zero
     rows.  All shapes are static and nothing is read back to the host, so the whole N-GPU step is
     hipGraph-capturable; a device-side flag records a bucket overflow (the step's result is then
-    invalid and the caller re-plans with a larger factor).  With Zipf ids the largest bucket stays
-    below 1.5x the mean (each field's hottest row holds ~7 % of its ids); the default factor is 2.
+    invalid and the caller re-plans with a larger factor).
+Both plans first DE-DUPLICATE the requests (`recalgo_dedup_rows`): a Zipf batch asks for each field's hottest row
+~7 % of the time, and only the first request of a distinct row is bucketed — later requests read (forward) and
+accumulate into (backward, summed locally by the scatter kernel) the same staged row, so a row crosses xGMI once
+per rank and step in each direction and the owner sees one gradient row per requesting rank.  That also removes
+the hot-row skew from the bucket sizes (distinct rows spread uniformly over r % N), so the static capacity is
+1.5 x the mean instead of the 2 x a per-request bucketing needs.
 On the 8-GPU xGMI full mesh every peer pair has its own link, so the all_to_all is link-parallel
 (≈0.85 MB per link per direction at B_local=4096, F=26, K=16); the dense all-reduce (≈1.5 MB) is
 latency-bound.  Each rank back-propagates loss_rank / N, so SUM collectives yield the gradient
@@ -58,10 +63,14 @@ class ExchangePlan:
     """Who asks whom for which rows: built once per (batch, arena row set), used for the forward
     fetch of any arena with that row layout and for the gradient push of the backward."""
 
-    def __init__(self, rows: torch.Tensor, sh: ShardSpec):
+    def __init__(self, rows: torch.Tensor, sh: ShardSpec, dedup=None):
         # rows: int64 [M] global arena rows, -1 = OOV / padding (nothing is exchanged for those)
         self.sh, self.M = sh, rows.numel()
         W = sh.world
+        self.rep = None
+        if dedup is not None:
+            # only the first request of every distinct row travels; the others read its staged row
+            rows, self.rep = dedup(rows.reshape(-1))
         pos = torch.nonzero(rows >= 0).squeeze(1)
         r = rows[pos]
         owner = r % W
@@ -87,10 +96,14 @@ class ExchangePlan:
         return out
 
     def staged_ids(self, rows: torch.Tensor, shape) -> torch.Tensor:
-        return identity_ids(rows, shape)           # the staged table is in request order
+        if self.rep is None:
+            return identity_ids(rows, shape)       # the staged table is in request order
+        flat = rows.reshape(-1)
+        return torch.where(flat >= 0, self.rep, torch.full_like(self.rep, -1)).reshape(shape)
 
     def push_grad(self, staged_grad: torch.Tensor, arena, local_scatter_add) -> None:
-        """arena.grad[owner rows] += staged_grad rows (duplicates accumulate on the owner)."""
+        """arena.grad[owner rows] += staged_grad rows (duplicate requests were already summed into their
+        representative's staged row by the local scatter; without dedup they accumulate on the owner)."""
         K = staged_grad.shape[1]
         gsend = staged_grad.index_select(0, self.send_pos)
         grecv = torch.empty(sum(self.rc), K, dtype=staged_grad.dtype, device=staged_grad.device)
@@ -104,9 +117,16 @@ class StaticExchangePlan:
     buffer [world*cap, K] and the kernels address it through `req_slot`, so neither direction needs
     an unpack copy: forward = owner gather -> all_to_all; backward = all_to_all -> owner scatter-add."""
 
-    def __init__(self, rows: torch.Tensor, sh: ShardSpec, capacity: int, overflow: torch.Tensor, planner):
+    def __init__(self, rows: torch.Tensor, sh: ShardSpec, capacity: int, overflow: torch.Tensor, planner, dedup=None):
         self.sh, self.M, self.cap = sh, rows.numel(), int(capacity)
-        self.send_local, self.req_slot = planner(rows.reshape(-1), sh.world, self.cap, overflow)
+        rows = rows.reshape(-1)
+        if dedup is None:
+            self.send_local, self.req_slot = planner(rows, sh.world, self.cap, overflow)
+        else:
+            # bucket the distinct rows only: a duplicate request shares the bucket entry of the row's first request
+            unique_rows, rep = dedup(rows)
+            self.send_local, slot = planner(unique_rows, sh.world, self.cap, overflow)
+            self.req_slot = slot.index_select(0, rep)
         self.recv_local = torch.empty_like(self.send_local)
         sh.dist.all_to_all_single(self.recv_local, self.send_local, group=sh.group)
 
@@ -153,6 +173,22 @@ def hip_exchange_plan(rows: torch.Tensor, world: int, cap: int, overflow: torch.
     return send_local, req_slot
 
 
+def hip_dedup_rows(rows: torch.Tensor):
+    """-> (unique_rows int64 [M], rep int64 [M]) by include/recalgo.h recalgo_dedup_rows."""
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    rows = rows.contiguous()
+    dev, M = rows.device, rows.numel()
+    unique_rows, rep = torch.empty_like(rows), torch.empty_like(rows)
+    if M:
+        ws = torch.empty(int(lib.recalgo_dedup_rows_workspace_bytes(M)), dtype=torch.uint8, device=dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        _lib.check(lib.recalgo_dedup_rows(p(rows), M, p(unique_rows), p(rep), p(ws), st), "recalgo_dedup_rows")
+    return unique_rows, rep
+
+
 def hip_local_gather(shard_weight: torch.Tensor, local_rows: torch.Tensor) -> torch.Tensor:
     import ctypes
     from . import _lib
@@ -191,9 +227,10 @@ class Sharding:
 
     def __init__(self, sh: ShardSpec, global_rows: int, local_gather=hip_local_gather,
                  local_scatter_add=hip_local_scatter_add, capacity_factor: Optional[float] = None,
-                 planner=hip_exchange_plan):
+                 planner=hip_exchange_plan, dedup=hip_dedup_rows):
         self.sh, self.global_rows = sh, int(global_rows)
         self.local_gather, self.local_scatter_add, self.planner = local_gather, local_scatter_add, planner
+        self.dedup = dedup                              # None: every request travels
         self.capacity_factor = capacity_factor          # None: exact (dynamic) buckets
         self.overflow: Optional[torch.Tensor] = None    # device flag, sticky
 
@@ -206,10 +243,10 @@ class Sharding:
 
     def plan(self, rows: torch.Tensor):
         if self.capacity_factor is None:
-            return ExchangePlan(rows, self.sh)
+            return ExchangePlan(rows, self.sh, self.dedup)
         if self.overflow is None:
             self.overflow = torch.zeros(1, dtype=torch.bool, device=rows.device)
-        return StaticExchangePlan(rows, self.sh, self.capacity(rows.numel()), self.overflow, self.planner)
+        return StaticExchangePlan(rows, self.sh, self.capacity(rows.numel()), self.overflow, self.planner, self.dedup)
 
 
 class StagedArena:
@@ -257,16 +294,17 @@ def identity_ids(rows: torch.Tensor, shape) -> torch.Tensor:
 
 def shard_arena_(arena: EmbeddingArena, sh: ShardSpec, local_gather=hip_local_gather,
                  local_scatter_add=hip_local_scatter_add, capacity_factor: Optional[float] = None,
-                 planner=hip_exchange_plan) -> None:
+                 planner=hip_exchange_plan, dedup=hip_dedup_rows) -> None:
     """Re-shard a fully materialised (replicated-at-init) arena in place: keep rows r % N == rank.
-    Every rank must have built the same arena (same seed) — that is what makes N ranks == 1 rank."""
+    Every rank must have built the same arena (same seed) — that is what makes N ranks == 1 rank.
+    (The production order is attach_data_parallel BEFORE the build, which never materialises the whole arena.)"""
     if getattr(arena, "sharding", None) is not None:
         return
     rows = arena.weight.shape[0]
     take = lambda t: t[sh.rank::sh.world].contiguous().clone()
     arena.weight, arena.grad, arena.m, arena.v = take(arena.weight), take(arena.grad), take(arena.m), take(arena.v)
     arena.live = None           # live-row bookkeeping is rebuilt for the shard on next use
-    arena.sharding = Sharding(sh, rows, local_gather, local_scatter_add, capacity_factor, planner)
+    arena.sharding = Sharding(sh, rows, local_gather, local_scatter_add, capacity_factor, planner, dedup)
 
 
 def unshard_arena(arena: EmbeddingArena, what: str = "weight") -> torch.Tensor:
@@ -286,23 +324,46 @@ def unshard_arena(arena: EmbeddingArena, what: str = "weight") -> torch.Tensor:
     return full
 
 
+class _ShardAtBuild:
+    """Carried by the VariableStore from attach_data_parallel to the end of the build: every arena is materialised
+    as this rank's rows only (EmbeddingArena.materialize(shard=...)) and gets its Sharding."""
+
+    def __init__(self, sh: ShardSpec, **sharding_kw):
+        self.sh, self.kw = sh, sharding_kw
+
+    def attach(self, arena: EmbeddingArena) -> None:
+        arena.live = None
+        arena.sharding = Sharding(self.sh, arena.rows, **self.kw)
+
+
 def attach_data_parallel(est, dist=None, group=None, local_gather=hip_local_gather,
-                         local_scatter_add=hip_local_scatter_add, capacity_factor: Optional[float] = 2.0,
-                         planner=hip_exchange_plan):
-    """Make a built Estimator one rank of an N-rank job: shard every embedding arena row-wise,
-    all-reduce the flat dense gradient before the optimizer, scale the loss gradient by 1/N.
-    `capacity_factor` selects the static (graph-capturable) exchange; None = exact dynamic buckets."""
+                         local_scatter_add=hip_local_scatter_add, capacity_factor: Optional[float] = 1.5,
+                         planner=hip_exchange_plan, dedup=hip_dedup_rows):
+    """Make an Estimator one rank of an N-rank job: shard every embedding arena row-wise, all-reduce the flat dense
+    gradient before the optimizer, scale the loss gradient by 1/N.  Call it BEFORE the first build / train call:
+    the arenas are then created sharded (no rank ever holds a whole table).  Called on an already built Estimator
+    it re-shards the replicated arenas in place (every rank must have built them from the same seed).
+    `capacity_factor` selects the static (graph-capturable) exchange — buckets of capacity_factor x the mean number
+    of DISTINCT-row requests per owner; None = exact dynamic buckets.  `dedup` = None sends every request."""
     if dist is None:
         import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     sh = ShardSpec(rank, world, group, dist)
-    if not est._built:
-        raise RuntimeError("attach_data_parallel: call est.build(features, labels) first")
-    # replicated dense variables must start identical
-    if est.store.flat is not None and est.store.flat.numel():
-        dist.broadcast(est.store.flat, src=0, group=group)
-    for ar in est.store.arenas.values():
-        shard_arena_(ar, sh, local_gather, local_scatter_add, capacity_factor, planner)
+    kw = dict(local_gather=local_gather, local_scatter_add=local_scatter_add, capacity_factor=capacity_factor,
+              planner=planner, dedup=dedup)
+
+    def sync_dense():
+        # replicated dense variables must start identical
+        if est.store.flat is not None and est.store.flat.numel():
+            dist.broadcast(est.store.flat, src=0, group=group)
+
+    if est._built:
+        sync_dense()
+        for ar in est.store.arenas.values():
+            shard_arena_(ar, sh, **kw)
+    else:
+        est.store.shard_at_build = _ShardAtBuild(sh, **kw)
+        est._after_build.append(sync_dense)
 
     def grad_hook(store):
         if store.flat_grad is not None and store.flat_grad.numel():

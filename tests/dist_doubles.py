@@ -40,3 +40,20 @@ def torch_exchange_plan(rows, world, cap, overflow, with_send_pos=False):
         pos[dummy] = -1
         return send_local[:world * cap].contiguous(), pos[:world * cap].contiguous(), req_slot
     return send_local[:world * cap].contiguous(), req_slot
+
+
+def torch_dedup_rows(rows):
+    """-> (unique_rows, rep): rep[i] = the smallest request index asking for rows[i] (i itself for rows < 0);
+    unique_rows[i] = rows[i] where rep[i] == i, else -1.  Static shapes (stable sort + running maximum)."""
+    M, dev = rows.numel(), rows.device
+    ar = torch.arange(M, dtype=torch.int64, device=dev)
+    if M == 0:
+        return rows.clone(), ar
+    srt, perm = torch.sort(rows, stable=True)
+    first = torch.ones(M, dtype=torch.bool, device=dev)
+    first[1:] = srt[1:] != srt[:-1]
+    start = torch.cummax(torch.where(first, ar, torch.zeros_like(ar)), 0).values
+    rep = torch.empty_like(ar)
+    rep[perm] = perm[start]
+    rep = torch.where(rows >= 0, rep, ar)
+    return torch.where(rep == ar, rows, torch.full_like(rows, -1)), rep

@@ -23,15 +23,16 @@ def _free_port():
     return p
 
 
-from tests.dist_doubles import cpu_gather, cpu_scatter_add, torch_exchange_plan  # noqa: E402
+from tests.dist_doubles import cpu_gather, cpu_scatter_add, torch_dedup_rows, torch_exchange_plan  # noqa: E402
 
 
-def _make_arena(K=8, vocabs=(13, 7, 29, 5)):
+def _make_arena(K=8, vocabs=(13, 7, 29, 5), materialize=True):
     from recalgorithm_amd.variables import EmbeddingArena
     ar = EmbeddingArena("emb", K, "cpu", seed=123)
     for i, v in enumerate(vocabs):
         ar.add_table(f"t{i}", v)
-    ar.materialize()
+    if materialize:
+        ar.materialize()
     return ar, list(vocabs)
 
 
@@ -44,7 +45,7 @@ def _global_batch(vocabs, B=24, seed=5):
     return ids
 
 
-def _worker(rank, port, errq, staged=False, WORLD=2):
+def _worker(rank, port, errq, staged=False, WORLD=2, dedup=True):
     try:
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
         dist.init_process_group("gloo", rank=rank, world_size=WORLD)
@@ -71,7 +72,8 @@ def _worker(rank, port, errq, staged=False, WORLD=2):
         store.pack()
         est = types.SimpleNamespace(_built=True, store=store, grad_hook=None, loss_grad_scale=None)
         P.attach_data_parallel(est, dist, local_gather=cpu_gather, local_scatter_add=cpu_scatter_add,
-                               capacity_factor=None, planner=torch_exchange_plan)
+                               capacity_factor=None, planner=torch_exchange_plan,
+                               dedup=torch_dedup_rows if dedup else None)
 
         def requested(staged, plan):          # staged rows in request order (zeros where nothing was requested)
             sid = plan.staged_ids(rows, rows.shape)
@@ -109,7 +111,9 @@ def _worker(rank, port, errq, staged=False, WORLD=2):
         # ... and a capacity that is too small must raise the overflow flag instead of silently dropping rows
         ar.sharding.capacity_factor = 0.25
         ar.sharding.overflow = None
+        ar.sharding.capacity = lambda M: 2        # below the 8-slot floor: the distinct rows of a 3-rank batch fit 8
         P.StagedArena(ar.sharding.plan(rows), ar)
+        del ar.sharding.capacity
         flag = ar.sharding.overflow.float()
         dist.all_reduce(flag)
         assert float(flag) > 0, "undersized buckets did not raise the overflow flag"
@@ -117,6 +121,9 @@ def _worker(rank, port, errq, staged=False, WORLD=2):
         plan = ar.sharding.plan(rows)
         staged = P.StagedArena(plan, ar)
         assert torch.equal(requested(staged, plan), expect), "staged rows differ from the table rows"
+        # with de-duplication every distinct row travels once (the batch repeats row 0 of table 0 in half its examples)
+        n_valid, n_distinct = int((rows >= 0).sum()), int(torch.unique(rows[rows >= 0]).numel())
+        assert sum(plan.sc) == (n_distinct if dedup else n_valid) and n_distinct < n_valid
         add_grad(staged, plan, g_probe)
         staged.flush_grad()
         assert torch.allclose(ar.grad, static_grad, rtol=1e-6, atol=1e-6), "static and exact plans push different gradients"
@@ -163,13 +170,14 @@ def _worker(rank, port, errq, staged=False, WORLD=2):
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("staged,world", [(False, 2), (True, 2), (False, 3)])
-def test_row_sharded_exchange_world2_matches_single_process(staged, world):
-    """world 3: uneven shards (rows % 3 != 0) and a batch of 24 = 3 x 8 examples."""
+@pytest.mark.parametrize("staged,world,dedup", [(False, 2, True), (True, 2, True), (False, 3, True), (False, 2, False)])
+def test_row_sharded_exchange_world2_matches_single_process(staged, world, dedup):
+    """world 3: uneven shards (rows % 3 != 0) and a batch of 24 = 3 x 8 examples.  dedup: only the first request of
+    every distinct row is exchanged (the default) vs every request."""
     ctx = mp.get_context("spawn")
     errq = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, port, errq, staged, world)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, port, errq, staged, world, dedup)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -232,6 +240,29 @@ def _worker_ckpt(rank, port, errq, tmpdir, WORLD=2):
         assert restore_checkpoint_state(fresh, state, torch.device("cpu")) == 9
         assert torch.equal(far.weight, g) and torch.equal(far.m, g + 0.25) and torch.equal(far.v, g + 0.5)
         assert torch.equal(fresh.vars["w"].data, store.vars["w"].data) and float(fresh.flat_v[0]) == 2.5
+
+        # ---- production order: attach BEFORE the build -> the arena is created as this rank's rows only, with the
+        # same initial values as the single-process arena, and a restore fills the shard from the whole-table file ----
+        whole, _ = _make_arena()
+        ar2, _ = _make_arena(materialize=False)
+        store2 = VariableStore("cpu", seed=7 + rank)
+        store2.get_variable("w", (6, 3))
+        store2.arenas[ar2.name] = ar2
+        est2 = types.SimpleNamespace(_built=False, _after_build=[], store=store2, grad_hook=None, loss_grad_scale=None)
+        P.attach_data_parallel(est2, dist, local_gather=cpu_gather, local_scatter_add=cpu_scatter_add,
+                               capacity_factor=None, planner=torch_exchange_plan, dedup=torch_dedup_rows)
+        store2.finalize()
+        for fn in est2._after_build:
+            fn()
+        assert ar2.weight.shape[0] == len(range(rank, rows, WORLD)) and ar2.m.shape == ar2.weight.shape
+        assert torch.equal(ar2.weight, whole.weight[rank::WORLD]), "sharded-at-build init != single-process init"
+        assert torch.equal(P.unshard_arena(ar2, "weight"), whole.weight)
+        w_all = [torch.empty_like(store2.flat) for _ in range(WORLD)]
+        dist.all_gather(w_all, store2.flat)
+        assert torch.equal(w_all[0], w_all[1]), "dense variables were not broadcast after the build"
+        assert restore_checkpoint_state(store2, state, torch.device("cpu")) == 9
+        assert torch.equal(ar2.weight, g[rank::WORLD]) and torch.equal(ar2.m, (g + 0.25)[rank::WORLD])
+        assert torch.equal(ar2.v, (g + 0.5)[rank::WORLD])
         dist.barrier()
         dist.destroy_process_group()
     except Exception:  # noqa: BLE001

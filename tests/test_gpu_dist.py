@@ -32,7 +32,7 @@ def pg():
     dist.destroy_process_group()
 
 
-def _make(model, dev, batch_norm=True):
+def _make(model, dev, batch_norm=True, before_build=None):
     spec = synth.SynthSpec(n_fields=8, max_vocab=300, seed=31, oov_frac=0.05,
                            with_history=(model == "din"), with_dense=(model == "din"))
     cats = [fc.categorical_column_with_identity(n, v) for n, v in zip(spec.names, spec.vocabs)]
@@ -60,6 +60,8 @@ def _make(model, dev, batch_norm=True):
                   "use_softmax": False}
     est = Estimator(fn, params, RunConfig(device=dev, seed=9, use_hip_graph=False))
     feats, labels, _ = synth.device_features(spec, 192, dev)
+    if before_build is not None:
+        before_build(est)
     est.build(feats, labels)
     # DIN's alpha = 1 makes dice/prelu the identity and the fcn stack affine: whole families of
     # gradients (biases and BN offsets ahead of the next BatchNorm) then vanish analytically and their
@@ -92,6 +94,37 @@ def test_sharded_single_rank_equals_plain(dev, pg, model):
     for name, ar in ref.store.arenas.items():
         full = unshard_arena(shd.store.arenas[name], "weight")
         assert_close(full, ar.weight, rtol=3e-4, what=f"{model} arena {name} after 3 steps", reduced=True)
+
+
+def test_attach_before_build_creates_the_arenas_sharded(dev, pg):
+    """The production order: attach_data_parallel on a not yet built Estimator -> the arenas are materialised as
+    this rank's rows only (here: all of them, world 1) with the single-process initial values, and training matches."""
+    from recalgorithm_amd.parallel import attach_data_parallel, unshard_arena
+    ref, feats, labels = _make("deepfm", dev)
+    shd, _, _ = _make("deepfm", dev, before_build=lambda est: attach_data_parallel(est, pg))
+    for name, ar in ref.store.arenas.items():
+        assert shd.store.arenas[name].sharding is not None
+        assert torch.equal(unshard_arena(shd.store.arenas[name], "weight"), ar.weight)
+    for step in range(2):
+        assert_close(shd.train_step(feats, labels), ref.train_step(feats, labels), what=f"loss step {step}")
+
+
+@pytest.mark.parametrize("M,vocab,oov", [(106496, 5000, 0.05), (4097, 50, 0.3), (1000, 1 << 40, 0.0), (64, 3, 0.5), (1, 1, 0.0),
+                                         (0, 1, 0.0)])
+def test_dedup_rows_kernel_against_torch(dev, M, vocab, oov):
+    """recalgo_dedup_rows (hash table, atomicCAS + atomicMin) vs the sort-based restatement: the representative of a
+    row is its SMALLEST request index, so the result does not depend on the arrival order — bit-identical."""
+    from recalgorithm_amd.parallel import hip_dedup_rows
+    from tests.dist_doubles import torch_dedup_rows
+    g = torch.Generator().manual_seed(M + 1)
+    rows = torch.randint(0, vocab, (M,), generator=g, dtype=torch.int64)
+    rows = torch.where(torch.rand(M, generator=g) < oov, torch.full_like(rows, -1), rows).to(dev)
+    for _ in range(2):                       # second call: fresh workspace contents must not matter
+        u, rep = hip_dedup_rows(rows)
+        u_ref, rep_ref = torch_dedup_rows(rows)
+        assert torch.equal(rep, rep_ref) and torch.equal(u, u_ref)
+    if M:
+        assert int((u >= 0).sum()) == int(torch.unique(rows[rows >= 0]).numel())
 
 
 def test_static_exchange_step_is_graph_capturable(dev, pg):

@@ -48,12 +48,13 @@ def _worker(rank, port, model, capacity_factor, errq):
 
         # (no BatchNorm: its batch statistics are per rank by design, as in any data-parallel job)
         ref, feats, labels = _make(model, dev, batch_norm=False)   # the 1-rank oracle, global batch
-        shd, _, _ = _make(model, dev, batch_norm=False)
+        # production order: sharded at construction (attach before the build), same initial values as the oracle
+        shd, _, _ = _make(model, dev, batch_norm=False,
+                          before_build=lambda e: P.attach_data_parallel(e, d, capacity_factor=capacity_factor))
         B = next(iter(labels.values())).shape[0]
         lo, hi = rank * B // WORLD, (rank + 1) * B // WORLD
         f_loc = {k: _slice(v, lo, hi) for k, v in feats.items()}
         l_loc = {k: _slice(v, lo, hi) for k, v in labels.items()}
-        P.attach_data_parallel(shd, d, capacity_factor=capacity_factor)
         for step in range(3):
             l0 = ref.train_step(feats, labels)
             l1 = shd.train_step(f_loc, l_loc).detach().clone()

@@ -126,7 +126,10 @@ def test_model_golden(name, tmp_path):
         if f"predict/{k}" in d:
             close(out[k], d[f"predict/{k}"], f"{name} {k}")
     # TRAIN: loss and every gradient
-    out = fn(P, feats, {"read_comment": labels}, params, training=True)
+    extra = {}
+    if "aux/dropout_mask_0" in d:       # NFM's hard-coded dropout: the keep mask the reference run drew is part of the golden
+        extra["dropout_masks"] = [torch.from_numpy(d["aux/dropout_mask_0"])]
+    out = fn(P, feats, {"read_comment": labels}, params, training=True, **extra)
     close(out["loss"], d["train/loss"], f"{name} loss")
     out["loss"].backward()
     gg = GU.golden_to_oracle_vars(name, GU.section(d, "grad/"), params)
@@ -148,9 +151,9 @@ def test_model_golden(name, tmp_path):
     assert checked >= 10
 
 
-def test_afm_golden_pins_the_oracle_ahead_of_its_kernels(tmp_path):
-    """AFM has no mirror / kernels yet; its oracle restatement is already pinned to the
-    golden obtained from the reference's afm.py, so that the kernels can be built against it next."""
+def test_afm_golden_pins_the_oracle_with_reference_side_params(tmp_path):
+    """AFM: the oracle restatement pinned to the golden obtained from the reference's afm.py, with
+    the params built here as the reference's main() builds them (independent of the mirror's parameter plumbing)."""
     import os
     from recalgorithm_amd import feature_column as fc
     from recalgorithm_amd.algorithm._common import DENSE_FEATURES
@@ -184,7 +187,7 @@ def test_afm_golden_pins_the_oracle_ahead_of_its_kernels(tmp_path):
     assert checked == len(P)
 
 
-def test_ffm_golden_pins_the_oracle_ahead_of_its_kernels(tmp_path):
+def test_ffm_golden_pins_the_oracle_with_reference_side_params(tmp_path):
     """FFM: oracle restatement pinned to the golden obtained from the reference's ffm.py
     (incl. its multi-hot `manual_tag_list` field: counts in the first-order term, distinct ids + mean in
     the field-aware lookups)."""
@@ -214,7 +217,7 @@ def test_ffm_golden_pins_the_oracle_ahead_of_its_kernels(tmp_path):
         close(got, g, f"ffm d({k})", tol=1e-9)
 
 
-def test_nfm_golden_pins_the_oracle_ahead_of_its_kernels(tmp_path):
+def test_nfm_golden_pins_the_oracle_with_reference_side_params(tmp_path):
     """NFM: oracle restatement pinned to the golden obtained from the reference's nfm.py,
     TRAIN mode included — the keep mask of its hard-coded 0.1 dropout is part of the golden."""
     import os

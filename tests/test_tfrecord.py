@@ -113,7 +113,8 @@ def _write_dataset(tmp_path, n=50, fields=5):
     return spec, vocab_dir, path
 
 
-def test_input_fns_batching_epochs_and_shuffle(tmp_path):
+def test_input_fns_batching_epochs_and_shuffle(tmp_path, monkeypatch):
+    monkeypatch.setenv("RECALGO_SHUFFLE_SEED", "11")       # (unset: a fresh order per run, like tf's unseeded shuffle)
     spec, vocab_dir, path = _write_dataset(tmp_path)
     cols = [fc.numeric_column("read_comment", default_value=0.0)] + \
            [fc.categorical_column_with_vocabulary_file(n, vocab_dir + n + ".txt") for n in spec.names]
