@@ -35,7 +35,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--model", default="dcn", choices=["dcn", "deepfm", "xdeepfm", "din", "fibinet", "pnn", "fwfm"])
+    ap.add_argument("--model", default="dcn", choices=["dcn", "deepfm", "xdeepfm", "din", "fibinet", "pnn", "fwfm", "nfm", "afm", "ffm"])
     ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch")
     ap.add_argument("--fields", type=int, default=26)
     ap.add_argument("--emb", type=int, default=16)
@@ -53,8 +53,9 @@ def parse_args(argv=None):
     ap.add_argument("--lazy-adam", action="store_true",
                     help="LazyAdamOptimizer on the embedding tables (rows without a gradient keep weights and moments): a "
                          "labelled DEVIATION from the reference's tf.train.AdamOptimizer (SURVEY.md §8f-1)")
-    ap.add_argument("--sweep-batches", type=int, default=192,
-                    help="optimizer-state sweep after the timed run: this many FRESH batches (one per step, never repeated) "
+    ap.add_argument("--sweep-batches", type=int, default=2048,
+                    help="optimizer-state sweep after the timed run: this many FRESH batches (one per step, never repeated; "
+                         "drawn on the device — models with history / dense inputs use the host generator and at most 192) "
                          "and a forced all-rows-live run; 0 = off")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -69,7 +70,8 @@ def build_estimator(args, device, rank=0, world=1, before_build=None):
     from recalgorithm_amd.io import synth
 
     spec = synth.SynthSpec(n_fields=args.fields, max_vocab=args.max_vocab,
-                           with_history=(args.model == "din"), history_len=50 if args.model == "din" else None)
+                           with_history=(args.model == "din"), history_len=50 if args.model == "din" else None,
+                           with_dense=args.model in ("nfm", "afm"))
     if args.big_table_rows:
         spec.vocabs[-1] = int(args.big_table_rows)
     cats = [fc.categorical_column_with_identity(n, v) for n, v in zip(spec.names, spec.vocabs)]
@@ -133,6 +135,27 @@ def build_estimator(args, device, rank=0, world=1, before_build=None):
                   "second_order_feature_columns": [fc.embedding_column(c, args.emb) for c in cats],
                   "embedding_dim": args.emb, "learning_rate": 0.005}
         workload = f"FwFM first order + field-pair-weighted second order; {args.fields} fields x emb{args.emb}; batch {args.batch}/GPU"
+    elif args.model in ("nfm", "afm"):      # §8f-3 siblings; both add a linear term over the 16 dense features
+        from recalgorithm_amd.algorithm._common import DENSE_FEATURES
+        params = {"dense_feature_columns": [fc.numeric_column(k, default_value=0.0) for k in DENSE_FEATURES],
+                  "category_feature_columns": [fc.embedding_column(c, args.emb) for c in cats], "learning_rate": 0.005}
+        if args.model == "nfm":
+            from recalgorithm_amd.algorithm.NFM.nfm import nfm_model_fn as model_fn
+            params.update({"hidden_units": hidden, "dropout_rate": 0.0, "batch_norm": True})
+            workload = (f"NFM bi-interaction pooling + BN + dropout 0.1 + MLP 512,256,128 (BN); {args.fields} fields x "
+                        f"emb{args.emb}; batch {args.batch}/GPU")
+        else:
+            from recalgorithm_amd.algorithm.AFM.afm import afm_model_fn as model_fn
+            params.update({"embedding_dim": args.emb, "attention_factor": 128})
+            workload = (f"AFM pair Hadamard products ({args.fields * (args.fields - 1) // 2} pairs) + attention net 128; "
+                        f"{args.fields} fields x emb{args.emb}; batch {args.batch}/GPU")
+    elif args.model == "ffm":               # §8f-3 sibling: F-1 sub-tables per field
+        from recalgorithm_amd.algorithm.FFM.ffm import ffm_model_fn as model_fn
+        cols = [fc.indicator_column(c) for c in cats]
+        params = {"one_hot_category_feature_columns": cols, "embedding_dim": args.emb, "learning_rate": 0.005,
+                  "fields_vocabulary_size_tuple": [(c.key, c.num_buckets) for c in cats]}
+        workload = (f"FFM first order + field-aware pair dots ({args.fields} fields x {args.fields - 1} sub-tables x "
+                    f"emb{args.emb}); batch {args.batch}/GPU")
     else:
         raise SystemExit(f"--model {args.model}: unknown")
     if args.lazy_adam:
@@ -186,7 +209,7 @@ def kernel_rooflines(args, est, feats, device):
     st = _Cur()
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     store = est.store
-    ar = next(iter(store.arenas.values()))
+    ar = next((a for a in store.arenas.values() if a.K == K), next(iter(store.arenas.values())))
     names = sorted(feats.keys())
     ids = torch.stack([feats[n] for n in names if isinstance(feats[n], torch.Tensor) and feats[n].dtype == torch.int64], 1).contiguous()
     rb = torch.tensor([ar.tables[t][0] for t in list(ar.tables)[:F]], dtype=torch.int64, device=device)
@@ -317,13 +340,35 @@ def kernel_rooflines(args, est, feats, device):
         th = torch.randn(D_, F, device=device) * 0.1
         om, dom = torch.empty(T_, D_, device=device), torch.randn(T_, D_, device=device)
         dE, dth = torch.empty_like(E), torch.empty_like(th)
-        add("pnn_features_fwd(IPNN)", lambda: lib.recalgo_pnn_features_fwd(p(E), B, F, K, 0, p(phi), st), B * (F * K + T_) * 4)
-        add("pnn_features_bwd(IPNN)", lambda: lib.recalgo_pnn_features_bwd(p(E), p(dphi), B, F, K, 0, p(dE), 0, st),
+        add("pnn_features_fwd(IPNN)", lambda: lib.recalgo_pnn_features_fwd(p(E), B, F, K, 0, p(phi), T_, st), B * (F * K + T_) * 4)
+        add("pnn_features_bwd(IPNN)", lambda: lib.recalgo_pnn_features_bwd(p(E), p(dphi), T_, B, F, K, 0, p(dE), 0, st),
             B * (2 * F * K + T_) * 4)
         if args.model == "pnn":
             add("pnn_weights_fwd(IPNN)", lambda: lib.recalgo_pnn_weights_fwd(p(th), D_, F, K, 0, p(om), st), (D_ * F + T_ * D_) * 4)
             add("pnn_weights_bwd(IPNN)", lambda: lib.recalgo_pnn_weights_bwd(p(th), p(dom), D_, F, K, 0, p(dth), st),
                 (2 * D_ * F + T_ * D_) * 4)
+    if args.model in ("nfm", "afm", "ffm"):          # §8f-3 sibling kernels (csrc/siblings.hip)
+        e = torch.randn(B, F, K, device=device)
+        if args.model == "nfm":
+            o, go, de = torch.empty(B, K, device=device), torch.randn(B, K, device=device), torch.empty_like(e)
+            add("bi_interaction_fwd", lambda: lib.recalgo_bi_interaction_fwd(p(e), B, F, K, p(o), st), B * (F * K + K) * 4)
+            add("bi_interaction_bwd", lambda: lib.recalgo_bi_interaction_bwd(p(e), p(go), B, F, K, p(de), st),
+                B * (2 * F * K + K) * 4)
+        elif args.model == "afm":
+            P_ = F * (F - 1) // 2
+            pr, att = torch.randn(B, P_, K, device=device), torch.randn(B, P_, device=device)
+            o, sc = torch.empty(B, K, device=device), torch.empty(B, P_, device=device)
+            go, dpr, datt = torch.randn(B, K, device=device), torch.empty_like(pr), torch.empty_like(att)
+            add("attention_pool_fwd", lambda: lib.recalgo_attention_pool_fwd(p(pr), p(att), B, P_, K, p(o), p(sc), st),
+                B * (P_ * K + 2 * P_ + K) * 4)
+            add("attention_pool_bwd", lambda: lib.recalgo_attention_pool_bwd(p(pr), p(sc), p(go), B, P_, K, p(dpr), p(datt), st),
+                B * (2 * P_ * K + 2 * P_ + K) * 4)
+        else:
+            xf = torch.randn(B, F, F - 1, K, device=device)
+            o, go, dxf = torch.empty(B, device=device), torch.randn(B, device=device), torch.empty_like(xf)
+            add("ffm_pairs_fwd", lambda: lib.recalgo_ffm_pairs_fwd(p(xf), B, F, K, p(o), st), B * (F * (F - 1) * K + 1) * 4)
+            add("ffm_pairs_bwd", lambda: lib.recalgo_ffm_pairs_bwd(p(xf), p(go), B, F, K, p(dxf), st),
+                B * (2 * F * (F - 1) * K + 1) * 4)
     # context MLP on the fp32 matrix cores (csrc/dense.hip): forward (bias + ReLU fused) and the merged backward launch
     # (input + weight gradient tiles, ReLU mask and bias gradient fused) of the three layers 416 -> 512 -> 256 -> 128
     from recalgorithm_amd import ops
@@ -392,10 +437,18 @@ def optimizer_state_sweep(args, r, device, rank, world):
         evs[-1].synchronize()
         per = sorted(x.elapsed_time(y) for x, y in zip(evs, evs[1:]))
         return per[len(per) // 2]
-    chunk, base = 32, 100_000 + rank
-    for c0 in range(0, args.sweep_batches, chunk):
-        n = min(chunk, args.sweep_batches - c0)
-        fresh = [synth.device_features(spec, args.batch, device, batch_index=base + world * (c0 + i))[:2] for i in range(n)]
+    base = 100_000 + rank
+    on_device = not (spec.with_history or spec.with_tags or spec.with_dense or max(spec.vocabs) > (1 << 24))
+    total = args.sweep_batches if on_device else min(args.sweep_batches, 192)   # (host generator: ~15 batches/s)
+    chunk = max(32, -(-total // 12))
+
+    def fresh_batches(c0, n):
+        if on_device:
+            return synth.device_fresh_batches(spec, args.batch, device, n, seed=base + 7919 * world * c0)
+        return [synth.device_features(spec, args.batch, device, batch_index=base + world * (c0 + i))[:2] for i in range(n)]
+    for c0 in range(0, total, chunk):
+        n = min(chunk, total - c0)
+        fresh = fresh_batches(c0, n)
         ms = timed(fresh)
         pts.append({"phase": f"fresh batches {c0}..{c0 + n - 1} (never repeated)", "live_fraction": round(live_fraction(est), 4),
                     "ms_per_step": round(ms, 4)})
@@ -403,7 +456,7 @@ def optimizer_state_sweep(args, r, device, rank, world):
     for a in est.store.arenas.values():
         if a.weight is not None and a.tracks_live_rows:
             a.force_all_live()
-    fresh = [synth.device_features(spec, args.batch, device, batch_index=base + world * (args.sweep_batches + i))[:2] for i in range(24)]
+    fresh = fresh_batches(total, 24)
     timed(fresh[:4])
     pts.append({"phase": "every row forced live (TF1 dense Adam at full cost)", "live_fraction": round(live_fraction(est), 4),
                 "ms_per_step": round(timed(fresh[4:]), 4)})

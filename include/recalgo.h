@@ -279,16 +279,20 @@ int recalgo_bilinear_bwd(const float* x0, const float* w0, const float* x1, cons
  *               IPNN: R = F, phi = <e_r, e_r'>;     OPNN: R = K, phi = s_r * s_r'
  *   omega[t, i] = c_t * theta[i,r] * theta[i,r']  |  c_t * W_i[r, r']   (c_t = 1 if r == r' else 2)
  * These entry points build phi / omega and their gradients; the caller runs the plain GEMM
- * relu(emb_flat @ linear_w + phi @ omega + bias) on hipBLASLt (pnn.py:139,175-181).
- *   emb [B, F, K];  product_w: IPNN [D, F], OPNN [D, K, K];  phi [B, T];  omega [T, D].
+ * relu(emb_flat @ linear_w + phi @ omega + bias) as ONE recalgo_dense_fwd launch with two operand pairs
+ * (pnn.py:139,175-181).
+ *   emb [B, F, K];  product_w: IPNN [D, F], OPNN [D, K, K];  phi [B, T] with row stride ld_phi >= T floats;
+ *   omega [T, D].  The features forward zero-fills the columns [T, ld_phi) of every row, so a caller that pads the
+ *   row stride to a multiple of 4 (T = 351 for 26 fields) hands the GEMM a float4-addressable operand whose padding
+ *   is inert; the backward reads dphi with its own row stride and ignores the padding columns.
  * ------------------------------------------------------------------------------------------ */
 #define RECALGO_PNN_IPNN 0
 #define RECALGO_PNN_OPNN 1
 int recalgo_pnn_feature_count(int F, int K, int method); /* T */
-int recalgo_pnn_features_fwd(const float* emb, int B, int F, int K, int method, float* phi,
+int recalgo_pnn_features_fwd(const float* emb, int B, int F, int K, int method, float* phi, int ld_phi,
                              recalgo_stream_t stream);
 /* d_emb (=|+=) d(phi)/d(emb)^T dphi  (IPNN / OPNN de_f). */
-int recalgo_pnn_features_bwd(const float* emb, const float* dphi, int B, int F, int K, int method,
+int recalgo_pnn_features_bwd(const float* emb, const float* dphi, int ld_dphi, int B, int F, int K, int method,
                              float* d_emb, int accumulate, recalgo_stream_t stream);
 int recalgo_pnn_weights_fwd(const float* product_w, int D, int F, int K, int method, float* omega,
                             recalgo_stream_t stream);

@@ -45,8 +45,8 @@ SIGNATURES = {
     "recalgo_bilinear_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "recalgo_bilinear_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P]),
     "recalgo_pnn_feature_count": (c_int, [c_int, c_int, c_int]),
-    "recalgo_pnn_features_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
-    "recalgo_pnn_features_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, P]),
+    "recalgo_pnn_features_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P]),
+    "recalgo_pnn_features_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
     "recalgo_pnn_weights_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
     "recalgo_pnn_weights_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
     "recalgo_mlp_width_supported": (c_int, [c_int]),

@@ -38,7 +38,7 @@ __host__ __device__ inline unsigned tab_floats(unsigned T) { return ((T * 2 + 15
 // IPNN features: phi[b, t(f,f')] = <e_f, e_f'>
 __global__ __launch_bounds__(kThreads) void ipnn_features_fwd_kernel(const float* __restrict__ emb, unsigned B,
                                                                      unsigned F, unsigned K,
-                                                                     float* __restrict__ phi) {
+                                                                     float* __restrict__ phi, unsigned ld) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const unsigned T = F * (F + 1) / 2, FK = F * K, KS = K + 1;
     unsigned short* tab = reinterpret_cast<unsigned short*>(smem);
@@ -62,15 +62,15 @@ __global__ __launch_bounds__(kThreads) void ipnn_features_fwd_kernel(const float
             }
         }
         __builtin_amdgcn_wave_barrier();
-        float* pr = phi + (size_t)b * T;
-        for (unsigned t = lane; t < T; t += 64) {
-            const unsigned rc = tab[t], r = rc & 255u, c = rc >> 8;
+        float* pr = phi + (size_t)b * ld;
+        for (unsigned t = lane; t < ld; t += 64) {            // columns [T, ld): zero padding of the row
+            const unsigned rc = tab[t < T ? t : 0], r = rc & 255u, c = rc >> 8;
             const float* xr = X + r * KS;
             const float* xc = X + c * KS;
             float acc = 0.f;
 #pragma unroll 8
             for (unsigned k = 0; k < K; ++k) acc = fmaf(xr[k], xc[k], acc);
-            pr[t] = acc;
+            pr[t] = t < T ? acc : 0.f;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kThreads) void ipnn_features_fwd_kernel(const float
 // d_emb[b,f,:] (=|+=) sum_f' dG[f,f'] e_f',  dG[f,f'] = dphi[t(f,f')] (f != f') | 2 dphi[t(f,f)]
 __global__ __launch_bounds__(kThreads) void ipnn_features_bwd_kernel(const float* __restrict__ emb,
                                                                      const float* __restrict__ dphi, unsigned B,
-                                                                     unsigned F, unsigned K,
+                                                                     unsigned F, unsigned K, unsigned ld,
                                                                      float* __restrict__ d_emb, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const unsigned T = F * (F + 1) / 2, FK = F * K;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kThreads) void ipnn_features_bwd_kernel(const float
     float* dP = X + FK;                                      // [T]
     for (unsigned b = blockIdx.x * kWaves + wib; b < B; b += gridDim.x * kWaves) {
         const float* er = emb + (size_t)b * FK;
-        const float* pr = dphi + (size_t)b * T;
+        const float* pr = dphi + (size_t)b * ld;
         for (unsigned i0 = 0; i0 < FK + T; i0 += 256) {       // X and dP are adjacent in LDS: one batched copy
             float t[4];
 #pragma unroll
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kThreads) void ipnn_features_bwd_kernel(const float
 // OPNN features: s = sum_f e_f ; phi[b, t(a,c)] = s_a s_c
 __global__ __launch_bounds__(kThreads) void opnn_features_fwd_kernel(const float* __restrict__ emb, unsigned B,
                                                                      unsigned F, unsigned K,
-                                                                     float* __restrict__ phi,
+                                                                     float* __restrict__ phi, unsigned ld,
                                                                      float* __restrict__ s_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const unsigned T = K * (K + 1) / 2, FK = F * K;
@@ -140,10 +140,10 @@ __global__ __launch_bounds__(kThreads) void opnn_features_fwd_kernel(const float
             if (s_out) s_out[(size_t)b * K + k] = acc;
         }
         __builtin_amdgcn_wave_barrier();
-        float* pr = phi + (size_t)b * T;
-        for (unsigned t = lane; t < T; t += 64) {
-            const unsigned rc = tab[t];
-            pr[t] = S[rc & 255u] * S[rc >> 8];
+        float* pr = phi + (size_t)b * ld;
+        for (unsigned t = lane; t < ld; t += 64) {
+            const unsigned rc = tab[t < T ? t : 0];
+            pr[t] = t < T ? S[rc & 255u] * S[rc >> 8] : 0.f;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kThreads) void opnn_features_fwd_kernel(const float
 // ds_a = sum_c dphi_sym[a,c] s_c ; d_emb[b,f,:] (=|+=) ds for every f
 __global__ __launch_bounds__(kThreads) void opnn_features_bwd_kernel(const float* __restrict__ emb,
                                                                      const float* __restrict__ dphi, unsigned B,
-                                                                     unsigned F, unsigned K,
+                                                                     unsigned F, unsigned K, unsigned ld,
                                                                      float* __restrict__ d_emb, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const unsigned T = K * (K + 1) / 2, FK = F * K;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kThreads) void opnn_features_bwd_kernel(const float
     float* dP = dS + K;
     for (unsigned b = blockIdx.x * kWaves + wib; b < B; b += gridDim.x * kWaves) {
         const float* er = emb + (size_t)b * FK;
-        const float* pr = dphi + (size_t)b * T;
+        const float* pr = dphi + (size_t)b * ld;
         for (unsigned k = lane; k < K; k += 64) {
             float acc = 0.f;
             for (unsigned f = 0; f < F; ++f) acc += er[f * K + k];
@@ -251,10 +251,11 @@ RECALGO_EXPORT int recalgo_pnn_feature_count(int F, int K, int method) {
     return 0;
 }
 
-RECALGO_EXPORT int recalgo_pnn_features_fwd(const float* emb, int B, int F, int K, int method, float* phi,
+RECALGO_EXPORT int recalgo_pnn_features_fwd(const float* emb, int B, int F, int K, int method, float* phi, int ld_phi,
                                             recalgo_stream_t stream) {
     RECALGO_REQUIRE(B >= 0 && F > 0 && K > 0 && (method == kIPNN || method == kOPNN));
     RECALGO_REQUIRE((method == kIPNN ? F : K) <= 255);
+    RECALGO_REQUIRE(ld_phi >= recalgo_pnn_feature_count(F, K, method));
     if (B == 0) return 0;
     hipStream_t st = as_stream(stream);
     if (method == kIPNN) {
@@ -262,21 +263,22 @@ RECALGO_EXPORT int recalgo_pnn_features_fwd(const float* emb, int B, int F, int 
         const size_t smem = ((size_t)tab_floats(T) + (size_t)kWaves * F * (K + 1)) * sizeof(float);
         ENSURE_SMEM(ipnn_features_fwd_kernel, smem);
         hipLaunchKernelGGL(ipnn_features_fwd_kernel, dim3(grid_for(B)), dim3(kThreads), smem, st, emb, (unsigned)B,
-                           (unsigned)F, (unsigned)K, phi);
+                           (unsigned)F, (unsigned)K, phi, (unsigned)ld_phi);
     } else {
         const unsigned T = (unsigned)K * (K + 1) / 2;
         const size_t smem = ((size_t)tab_floats(T) + (size_t)kWaves * K) * sizeof(float);
         ENSURE_SMEM(opnn_features_fwd_kernel, smem);
         hipLaunchKernelGGL(opnn_features_fwd_kernel, dim3(grid_for(B)), dim3(kThreads), smem, st, emb, (unsigned)B,
-                           (unsigned)F, (unsigned)K, phi, static_cast<float*>(nullptr));
+                           (unsigned)F, (unsigned)K, phi, (unsigned)ld_phi, static_cast<float*>(nullptr));
     }
     RECALGO_RETURN_LAST();
 }
 
-RECALGO_EXPORT int recalgo_pnn_features_bwd(const float* emb, const float* dphi, int B, int F, int K, int method,
+RECALGO_EXPORT int recalgo_pnn_features_bwd(const float* emb, const float* dphi, int ld_dphi, int B, int F, int K, int method,
                                             float* d_emb, int accumulate, recalgo_stream_t stream) {
     RECALGO_REQUIRE(B >= 0 && F > 0 && K > 0 && (method == kIPNN || method == kOPNN));
     RECALGO_REQUIRE((method == kIPNN ? F : K) <= 255);
+    RECALGO_REQUIRE(ld_dphi >= recalgo_pnn_feature_count(F, K, method));
     if (B == 0) return 0;
     hipStream_t st = as_stream(stream);
     if (method == kIPNN) {
@@ -284,13 +286,13 @@ RECALGO_EXPORT int recalgo_pnn_features_bwd(const float* emb, const float* dphi,
         const size_t smem = (size_t)kWaves * ((size_t)F * K + T) * sizeof(float);
         ENSURE_SMEM(ipnn_features_bwd_kernel, smem);
         hipLaunchKernelGGL(ipnn_features_bwd_kernel, dim3(grid_for(B)), dim3(kThreads), smem, st, emb, dphi,
-                           (unsigned)B, (unsigned)F, (unsigned)K, d_emb, accumulate);
+                           (unsigned)B, (unsigned)F, (unsigned)K, (unsigned)ld_dphi, d_emb, accumulate);
     } else {
         const unsigned T = (unsigned)K * (K + 1) / 2;
         const size_t smem = (size_t)kWaves * (2 * (size_t)K + T) * sizeof(float);
         ENSURE_SMEM(opnn_features_bwd_kernel, smem);
         hipLaunchKernelGGL(opnn_features_bwd_kernel, dim3(grid_for(B)), dim3(kThreads), smem, st, emb, dphi,
-                           (unsigned)B, (unsigned)F, (unsigned)K, d_emb, accumulate);
+                           (unsigned)B, (unsigned)F, (unsigned)K, (unsigned)ld_dphi, d_emb, accumulate);
     }
     RECALGO_RETURN_LAST();
 }

@@ -153,6 +153,46 @@ def device_features(spec: SynthSpec, B: int, device, batch_index: int = 0, sorte
     return feats, lab, feats_meta
 
 
+_ZIPF_CDF_DEV: Dict[tuple, torch.Tensor] = {}
+
+
+def device_fresh_batches(spec: SynthSpec, B: int, device, n: int, seed: int):
+    """n batches of the same distribution as make_id_batch (truncated Zipf(1.05) ids per field, oov_frac, 3.56 %
+    positives) drawn ON the device — a long optimizer-state sweep needs thousands of never-repeated batches and the
+    host generator makes ~15 per second.  Single-valued id fields only (no history / tags / dense features), vocabularies
+    up to 2^24.  -> list of (features, labels) laid out exactly like device_features (one allocation per batch: id
+    matrix followed by the labels), from its own random stream (not the host generator's)."""
+    if spec.with_history or spec.with_tags or spec.with_dense or max(spec.vocabs) > (1 << 24):
+        raise ValueError("device_fresh_batches: single-valued id fields with vocabularies <= 2^24 only")
+    names = sorted(spec.names)
+    vmap = dict(zip(spec.names, spec.vocabs))
+    F = len(names)
+    gen = torch.Generator(device=device).manual_seed(int(seed))
+    ids = torch.empty(n, B, F, dtype=torch.int64, device=device)
+    for j, nm in enumerate(names):
+        V = vmap[nm]
+        cdf = _ZIPF_CDF_DEV.get((V, str(device)))
+        if cdf is None:
+            ranks = torch.arange(1, V + 1, dtype=torch.float64, device=device)
+            cdf = torch.cumsum(ranks.pow(-1.05), 0)
+            cdf = _ZIPF_CDF_DEV[(V, str(device))] = cdf / cdf[-1]
+        u = torch.rand(n * B, dtype=torch.float64, device=device, generator=gen)
+        col = torch.searchsorted(cdf, u).clamp_(max=V - 1)
+        if spec.oov_frac > 0:
+            col = torch.where(torch.rand(n * B, device=device, generator=gen) < spec.oov_frac, torch.full_like(col, -1), col)
+        ids[:, :, j] = col.view(n, B)
+    labels = (torch.rand(n, B, device=device, generator=gen) < 0.0356).to(torch.float32)
+    nid = B * F * 8
+    out = []
+    for i in range(n):
+        buf = torch.empty(nid + B * 4, dtype=torch.uint8, device=device)
+        buf[:nid] = ids[i].reshape(-1).view(torch.uint8)
+        buf[nid:] = labels[i].view(torch.uint8)
+        mat = buf[:nid].view(torch.int64).view(B, F)
+        out.append(({nm: mat[:, j] for j, nm in enumerate(names)}, {"read_comment": buf[nid:].view(torch.float32).view(B, 1)}))
+    return out
+
+
 # ---- on-disk form: vocabulary files + TFRecord ------------------------------------------------
 def key_of(name: str, i: int) -> bytes:
     return f"{name}_{i}".encode()

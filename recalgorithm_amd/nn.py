@@ -21,11 +21,16 @@ def _hip(x: torch.Tensor, C: int) -> bool:
     return x.is_cuda and x.dtype == torch.float32 and ops.mlp_width_supported(C)
 
 
-def _mfma_dense() -> bool:
+def _mfma_dense(in_features: int = 0) -> bool:
     """RECALGO_DENSE=blas keeps the library GEMMs (hipBLASLt through torch) for A/B measurements; the default is the
-    hand-written fp32-MFMA kernels with fused epilogues (csrc/dense.hip)."""
+    hand-written fp32-MFMA kernels with fused epilogues (csrc/dense.hip) for layers up to RECALGO_DENSE_MAX_K input
+    features (default 4096).  Wider layers are plain large GEMMs where the 64 x 64 tile is no longer the right shape:
+    FiBiNET's 9600 -> 512 layer runs 104 TFLOP/s on the hand-written kernel and the step is 10 % faster with the
+    library's TunableOp pick (1.42 vs 1.57 ms, profiles/r02o_fibinet_kernel_stats.md) — those go to hipBLASLt."""
     import os
-    return os.environ.get("RECALGO_DENSE", "mfma") != "blas"
+    if os.environ.get("RECALGO_DENSE", "mfma") == "blas":
+        return False
+    return in_features <= int(os.environ.get("RECALGO_DENSE_MAX_K", "4096"))
 
 
 class GradJoin:
@@ -68,7 +73,7 @@ class _DenseFn(Function):
         ctx.input_l2 = float(input_l2)
         ctx.grad_join = grad_join
         x2 = x.reshape(-1, x.shape[-1])
-        ctx.hip = x2.is_cuda and x2.dtype == torch.float32 and _mfma_dense()
+        ctx.hip = x2.is_cuda and x2.dtype == torch.float32 and _mfma_dense(x2.shape[1])
         if ctx.hip:
             from . import ops
             if x2.stride(1) != 1:

@@ -676,10 +676,11 @@ class _PnnProductFn(Function):
         D = linear_w.data.shape[1]
         lib = _lib_()
         T = lib.recalgo_pnn_feature_count(F, K, method)
+        T4 = (T + 3) // 4 * 4          # row stride of phi / row count of omega: float4-addressable GEMM operands
         st = _stream(emb_flat)
-        phi = torch.empty(B, T, device=emb_flat.device, dtype=torch.float32)
-        omega = torch.empty(T, D, device=emb_flat.device, dtype=torch.float32)
-        _lib.check(lib.recalgo_pnn_features_fwd(_p(emb_flat), B, F, K, method, _p(phi), st), "recalgo_pnn_features_fwd")
+        phi = torch.empty(B, T4, device=emb_flat.device, dtype=torch.float32)      # padding columns zeroed by the kernel
+        omega = _pnn_omega(product_w, T4, D)                                        # padding rows stay zero
+        _lib.check(lib.recalgo_pnn_features_fwd(_p(emb_flat), B, F, K, method, _p(phi), T4, st), "recalgo_pnn_features_fwd")
         _lib.check(lib.recalgo_pnn_weights_fwd(_p(product_w.data), D, F, K, method, _p(omega), st),
                    "recalgo_pnn_weights_fwd")
         # lz + lp + bias, ReLU  (pnn.py:139,175,178,181)
@@ -695,20 +696,37 @@ class _PnnProductFn(Function):
         F, K, method = ctx.dims
         emb_flat, phi, omega, y = ctx.saved_tensors
         B, D = y.shape
+        T4 = phi.shape[1]
         lib = _lib_()
         st = _stream(emb_flat)
         g = g.contiguous()
-        # gz = g * [y > 0] is applied inside the kernels (never materialised)
-        dense_bwd_weights(emb_flat, g, y, linear_w.grad.view(-1, D), bias.grad.view(-1), defer=True)
+        # gz = g * [y > 0] is applied inside the kernels (never materialised); each operand pair's input and weight
+        # gradients are one merged launch.  The omega gradient is needed right away (pnn_weights_bwd), so its split
+        # sum is not deferred to the end of the step
         domega = torch.empty_like(omega)
-        dense_bwd_weights(phi, g, y, domega, None)
-        d_emb = dense_bwd_input(g, y, linear_w.data.reshape(-1, D))
-        dphi = dense_bwd_input(g, y, omega)
-        _lib.check(lib.recalgo_pnn_features_bwd(_p(emb_flat), _p(dphi), B, F, K, method, _p(d_emb), 1, st),
+        dphi = dense_bwd(phi, g, y, omega, domega, None)
+        d_emb = dense_bwd(emb_flat, g, y, linear_w.data.reshape(-1, D), linear_w.grad.view(-1, D), bias.grad.view(-1),
+                          defer=True)
+        _lib.check(lib.recalgo_pnn_features_bwd(_p(emb_flat), _p(dphi), T4, B, F, K, method, _p(d_emb), 1, st),
                    "recalgo_pnn_features_bwd")
         _lib.check(lib.recalgo_pnn_weights_bwd(_p(product_w.data), _p(domega), D, F, K, method, _p(product_w.grad), st),
                    "recalgo_pnn_weights_bwd")
         return None, d_emb, None, None, None, None, None, None
+
+
+_pnn_omega_cache = {}
+
+
+def _pnn_omega(product_w: Variable, T4: int, D: int) -> torch.Tensor:
+    """The [T4, D] omega buffer of one product layer, allocated once (zeros): recalgo_pnn_weights_fwd rewrites its first
+    T rows every step, the padding rows stay zero."""
+    key = (product_w.data.data_ptr(), T4, D)
+    t = _pnn_omega_cache.get(key)
+    if t is None:
+        if len(_pnn_omega_cache) > 16:
+            _pnn_omega_cache.clear()
+        t = _pnn_omega_cache[key] = torch.zeros(T4, D, device=product_w.data.device, dtype=torch.float32)
+    return t
 
 
 def pnn_product_layer(store, emb_flat: torch.Tensor, linear_w: Variable, product_w: Variable, bias: Variable,
@@ -734,7 +752,7 @@ class _FieldPairLogitFn(Function):
         T = lib.recalgo_pnn_feature_count(F, K, 0)
         dev = emb_flat.device
         phi = torch.empty(B, T, device=dev, dtype=torch.float32)
-        _lib.check(lib.recalgo_pnn_features_fwd(_p(emb_flat), B, F, K, 0, _p(phi), _stream(emb_flat)),
+        _lib.check(lib.recalgo_pnn_features_fwd(_p(emb_flat), B, F, K, 0, _p(phi), T, _stream(emb_flat)),
                    "recalgo_pnn_features_fwd")
         idx = _pair_index(F, dev)
         w = torch.zeros(T, 1, device=dev, dtype=torch.float32)
@@ -753,7 +771,7 @@ class _FieldPairLogitFn(Function):
         dense1_bwd([phi], w, g.contiguous(), [dphi], dw, None)
         ctx.r.grad.copy_(dw.reshape(-1).index_select(0, idx).reshape(ctx.r.grad.shape))
         d_emb = torch.empty_like(emb_flat)
-        _lib.check(_lib_().recalgo_pnn_features_bwd(_p(emb_flat), _p(dphi), B, F, K, 0, _p(d_emb), 0, _stream(emb_flat)),
+        _lib.check(_lib_().recalgo_pnn_features_bwd(_p(emb_flat), _p(dphi), phi.shape[1], B, F, K, 0, _p(d_emb), 0, _stream(emb_flat)),
                    "recalgo_pnn_features_bwd")
         return None, d_emb, None, None, None
 

@@ -18,7 +18,9 @@ Per step and arena lookup (`ExchangePlan`)
   3. the unchanged single-GPU kernels (gather, fused DeepFM sparse path, bag mean, sequence
      gather) run on the staged arena with identity ids;
   4. backward: the kernels scatter into the staged gradient, which is all_to_all'ed back to the
-     owners and scatter-added into the shard's gradient (HIP kernel).
+     owners and scatter-added into the shard's gradient (HIP kernel).  This push runs on a second HIP stream
+     (fork / join by events, capturable): the rest of the backward pass, the deferred weight-gradient sums and
+     the dense all-reduce proceed on the main stream; the optimizer launch joins.
 Two exchange plans implement steps 1-4:
   * `ExchangePlan`: exact bucket sizes (data-dependent all_to_all splits -> one small host sync per
     lookup; steps must be launched eagerly);
@@ -276,8 +278,45 @@ class StagedArena:
     def flush_grad(self):
         if self._grad is not None:
             sd: Sharding = self.arena.sharding
-            self.plan.push_grad(self._grad, self.arena, sd.local_scatter_add)
-            self._grad = None
+            g, self._grad = self._grad, None
+            if g.is_cuda and push_overlap():
+                # the push (all_to_all of the staged gradient + owner scatter-add) leaves the main stream: the rest of
+                # the backward pass, the deferred weight-gradient sums and the dense all-reduce run beside it; the
+                # optimizer joins (join_push_streams, called by the gradient hook after the all-reduce)
+                dev = g.device
+                side = _push_stream(dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    self.plan.push_grad(g, self.arena, sd.local_scatter_add)
+                _push_pending.append((dev, g))          # keeps the staged gradient alive until the join
+            else:
+                self.plan.push_grad(g, self.arena, sd.local_scatter_add)
+
+
+_push_streams = {}
+_push_pending = []
+
+
+def push_overlap() -> bool:
+    """RECALGO_DP_OVERLAP=0 keeps the gradient push on the main stream (bring-up / bisecting aid)."""
+    import os
+    return os.environ.get("RECALGO_DP_OVERLAP", "1") != "0"
+
+
+def _push_stream(device) -> "torch.cuda.Stream":
+    key = (device.type, device.index)
+    st = _push_streams.get(key)
+    if st is None:
+        st = _push_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def join_push_streams() -> None:
+    """The current stream waits for every gradient push issued since the last join (arena.grad and the live-row
+    lists of the shards are complete after this)."""
+    for dev in {d for d, _ in _push_pending}:
+        torch.cuda.current_stream(dev).wait_stream(_push_stream(dev))
+    _push_pending.clear()
 
 
 def global_rows(ids: torch.Tensor, row_base: torch.Tensor) -> torch.Tensor:
@@ -368,6 +407,7 @@ def attach_data_parallel(est, dist=None, group=None, local_gather=hip_local_gath
     def grad_hook(store):
         if store.flat_grad is not None and store.flat_grad.numel():
             dist.all_reduce(store.flat_grad, op=dist.ReduceOp.SUM, group=group)
+        join_push_streams()          # the gradient pushes ran beside the tail of the backward pass and the all-reduce
     est.grad_hook = grad_hook
     est.loss_grad_scale = 1.0 / world
     est.shard_spec = sh

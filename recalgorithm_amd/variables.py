@@ -247,8 +247,9 @@ class VariableStore:
 
 def named_grads(store: VariableStore) -> Dict[str, torch.Tensor]:
     """name -> gradient tensor, same keys as VariableStore.named_arrays()."""
-    from . import nn
+    from . import nn, parallel
     nn.apply_parked_grads()
+    parallel.join_push_streams()
     out = {n: v.grad for n, v in store.vars.items() if v.grad is not None}
     for ar in store.arenas.values():
         for tn, (rb, vocab) in ar.tables.items():

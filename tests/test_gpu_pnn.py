@@ -40,9 +40,17 @@ def test_pnn_product_layer_pieces(dev, method, B, F, K, D):
     T = lib.recalgo_pnn_feature_count(F, K, m)
     assert T == (F * (F + 1) // 2 if method == "IPNN" else K * (K + 1) // 2)
     eg, pg, gg = emb.to(dev), pw.to(dev), g.to(dev)
-    phi = torch.empty(B, T, device=dev)
+    # phi with a padded row stride (what ops._PnnProductFn does: float4-addressable GEMM operand): the kernel zero-fills
+    # the padding columns, the backward skips them
+    ld = (T + 3) // 4 * 4 + 4
+    phi_pad = torch.full((B, ld), float("nan"), device=dev)
     omega = torch.empty(T, D, device=dev)
-    _lib.check(lib.recalgo_pnn_features_fwd(_p(eg), B, F, K, m, _p(phi), _st()), "features fwd")
+    _lib.check(lib.recalgo_pnn_features_fwd(_p(eg), B, F, K, m, _p(phi_pad), ld, _st()), "features fwd")
+    assert float(phi_pad[:, T:].abs().max()) == 0.0
+    phi = phi_pad[:, :T].contiguous()
+    phi_t = torch.empty(B, T, device=dev)
+    _lib.check(lib.recalgo_pnn_features_fwd(_p(eg), B, F, K, m, _p(phi_t), T, _st()), "features fwd (dense rows)")
+    assert torch.equal(phi, phi_t)
     _lib.check(lib.recalgo_pnn_weights_fwd(_p(pg), D, F, K, m, _p(omega), _st()), "weights fwd")
     lp = phi.double() @ omega.double()
     assert_close(lp, lp_ref, what=f"{method} lp = phi @ omega")
@@ -50,10 +58,12 @@ def test_pnn_product_layer_pieces(dev, method, B, F, K, D):
     dphi = (gg.double() @ omega.double().t()).float()
     domega = (phi.double().t() @ gg.double()).float()
     d_emb = torch.full((B, F * K), 0.25, device=dev)
-    _lib.check(lib.recalgo_pnn_features_bwd(_p(eg), _p(dphi), B, F, K, m, _p(d_emb), 1, _st()), "features bwd")
+    dphi_pad = torch.full((B, ld), float("nan"), device=dev)
+    dphi_pad[:, :T] = dphi
+    _lib.check(lib.recalgo_pnn_features_bwd(_p(eg), _p(dphi_pad), ld, B, F, K, m, _p(d_emb), 1, _st()), "features bwd")
     assert_close(d_emb - 0.25, ed.grad, what=f"{method} d_emb (accumulate)", reduced=True)
     d_emb2 = torch.empty_like(d_emb)
-    _lib.check(lib.recalgo_pnn_features_bwd(_p(eg), _p(dphi), B, F, K, m, _p(d_emb2), 0, _st()), "features bwd")
+    _lib.check(lib.recalgo_pnn_features_bwd(_p(eg), _p(dphi), T, B, F, K, m, _p(d_emb2), 0, _st()), "features bwd")
     assert_close(d_emb2, ed.grad, what=f"{method} d_emb", reduced=True)
     dpw = torch.empty_like(pg)
     _lib.check(lib.recalgo_pnn_weights_bwd(_p(pg), _p(domega), D, F, K, m, _p(dpw), _st()), "weights bwd")
@@ -71,7 +81,7 @@ def test_ipnn_identity(dev):
     th = torch.randn(D, F, generator=gen)
     phi = torch.empty(B, F * (F + 1) // 2, device=dev)
     omega = torch.empty(F * (F + 1) // 2, D, device=dev)
-    _lib.check(lib.recalgo_pnn_features_fwd(_p(E.to(dev)), B, F, K, 0, _p(phi), _st()), "f")
+    _lib.check(lib.recalgo_pnn_features_fwd(_p(E.to(dev)), B, F, K, 0, _p(phi), phi.shape[1], _st()), "f")
     _lib.check(lib.recalgo_pnn_weights_fwd(_p(th.to(dev)), D, F, K, 0, _p(omega), _st()), "w")
     gram = torch.einsum("bfk,bgk->bfg", E.double(), E.double())
     brute = torch.einsum("if,ig,bfg->bi", th.double(), th.double(), gram)
