@@ -249,7 +249,7 @@ def kernel_rooflines(args, est, feats, device):
         dw, db, dx0 = torch.empty_like(w), torch.empty_like(b), torch.empty_like(x0)
         ws = torch.empty(lib.recalgo_cross_bwd_workspace_bytes(B, d, L), dtype=torch.uint8, device=device)
         add("cross_fwd", lambda: lib.recalgo_cross_fwd(p(x0), d, p(w), p(b), B, d, L, p(out), d, st), B * 2 * d * 4)
-        add("cross_bwd", lambda: lib.recalgo_cross_bwd(p(x0), d, p(w), p(b), p(g), d, None, B, d, L, p(dx0), p(dw), p(db), p(ws), st),
+        add("cross_bwd", lambda: lib.recalgo_cross_bwd(p(x0), d, p(w), p(b), p(g), d, None, B, d, L, p(dx0), p(dw), p(db), p(ws), 0, st),
             B * 3 * d * 4)
     if args.model == "xdeepfm":
         m, D = F, K

@@ -152,8 +152,15 @@ int recalgo_cross_fwd(const float* x0, int x_stride, const float* w, const float
  *   g    [B, d] (row stride g_stride) upstream gradient of `out`
  *   g_x0_extra  optional [B, d] (row stride x_stride) added into dx0 (the DNN branch's dx0)
  *   dx0  [B, d] (row stride x_stride);  dw, db [L, d] (overwritten, deterministic two-pass)
- *   workspace: recalgo_cross_bwd_workspace_bytes(B, d, L) bytes. */
+ *   workspace: recalgo_cross_bwd_workspace_bytes(B, d, L) bytes.
+ * Every workgroup leaves its share of the final dw / db as one partial row [dw_0..dw_{L-1} | db_0..db_{L-1}]
+ * (2*L*d floats, recalgo_cross_bwd_partial_rows(B) rows) in the workspace; dw / db are the column sums of those rows.
+ * defer_reduce = 0: the sum is a second launch of this call.  defer_reduce != 0: it is left to the step's
+ * deferred-sum launch — pass {workspace, dw, rows, 2*L*d, L*d} and {workspace + L*d floats, db, rows, 2*L*d, L*d} as
+ * recalgo_colsum_t jobs to recalgo_dense_bwd_weights_reduce; the workspace must stay untouched until then and dw / db
+ * may be NULL here. */
 int64_t recalgo_cross_bwd_workspace_bytes(int B, int d, int L);
+int recalgo_cross_bwd_partial_rows(int B);
 /* Single layer with the reference's exact signature cross_layer(x0, xl, index)
  * (algorithm/DCN/cross_layer.py:4): out = x0 * (xl . w) + b + xl, xl distinct from x0.
  * w, b [d].  Backward also returns dxl; workspace as recalgo_cross_bwd_workspace_bytes(B,d,1). */
@@ -166,7 +173,7 @@ int recalgo_cross_layer_bwd(const float* x0, const float* xl, int x_stride, cons
                             recalgo_stream_t stream);
 int recalgo_cross_bwd(const float* x0, int x_stride, const float* w, const float* b, const float* g,
                       int g_stride, const float* g_x0_extra, int B, int d, int L, float* dx0,
-                      float* dw, float* db, void* workspace, recalgo_stream_t stream);
+                      float* dw, float* db, void* workspace, int defer_reduce, recalgo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K5  xDeepFM CIN layer on the fp32 matrix cores (implicit GEMM, outer product never stored).

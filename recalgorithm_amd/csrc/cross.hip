@@ -101,8 +101,9 @@ __global__ __launch_bounds__(kFwdThreads) void cross_stack_fwd_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // fused stack, backward.  Per-wave register accumulators (A_l, G, T_l) -> fixed-order LDS
-// reduction per workgroup -> partial row in global -> cross_stack_finalize_kernel.
-// partial row layout: [A_0 .. A_{L-1} | G | T_0 .. T_{L-1}]   ((L+1)*d + L floats)
+// reduction per workgroup -> this workgroup's share of dw / db as one partial row in global -> column sum
+// (colsum4_kernel here, or a job of the step's deferred-sum launch: recalgo_dense_bwd_weights_reduce).
+// partial row layout: [dw_0 .. dw_{L-1} | db_0 .. db_{L-1}]   (2*L*d floats)
 // ---------------------------------------------------------------------------------------------
 template <int NV, int L>
 __global__ __launch_bounds__(kBwdThreads) void cross_stack_bwd_kernel(
@@ -205,9 +206,29 @@ __global__ __launch_bounds__(kBwdThreads) void cross_stack_bwd_kernel(
         }
     }
 
-    // workgroup reduction in fixed wave order (deterministic)
-    const unsigned row_len = (L + 1) * d + ((L + 3) & ~3);   // padded: rows stay 16-byte aligned
+    // workgroup reduction in fixed wave order (deterministic).  The partial row already holds this workgroup's share of
+    // the FINAL gradients — dw_l = A_l + T_l * B_l (B_l = sum_{j<l} b_j), db_j = G + sum_{l>j} T_l * w_l are linear in
+    // (A, G, T) — so what remains is a plain column sum over the partial rows (colsum4_kernel, or one job of the
+    // step's deferred-sum launch).  Row layout: [dw_0 .. dw_{L-1} | db_0 .. db_{L-1}]  (2*L*d floats).
+    const unsigned row_len = 2 * L * d;
     float* prow = partials + (size_t)blockIdx.x * row_len;
+    float* sT = smem + (size_t)kBwdWaves * d;                 // [kBwdWaves][L] per-wave T, then [L] their sum
+    const float* wf = reinterpret_cast<const float*>(w);
+    const float* bf = reinterpret_cast<const float*>(b);
+    if (lane == 0) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) sT[wib * L + l] = T[l];   // T is wave-uniform
+    }
+    __syncthreads();
+    if (threadIdx.x < L) {
+        float acc = 0.f;
+        for (int wv_ = 0; wv_ < kBwdWaves; ++wv_) acc += sT[wv_ * L + threadIdx.x];
+        sT[kBwdWaves * L + threadIdx.x] = acc;
+    }
+    __syncthreads();
+    float Tw[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) Tw[l] = sT[kBwdWaves * L + l];
 #pragma unroll
     for (int vec = 0; vec <= L; ++vec) {
         __syncthreads();
@@ -227,84 +248,24 @@ __global__ __launch_bounds__(kBwdThreads) void cross_stack_bwd_kernel(
             float acc = 0.f;
 #pragma unroll
             for (int wv_ = 0; wv_ < kBwdWaves; ++wv_) acc += smem[(size_t)wv_ * d + j];
-            prow[(size_t)vec * d + j] = acc;
-        }
-    }
-    __syncthreads();
-    if (lane == 0) {
+            if (vec < L) {
+                float Bl = 0.f;                               // B_vec[j] = sum_{jj < vec} b_jj[j]
 #pragma unroll
-        for (int l = 0; l < L; ++l) smem[wib * L + l] = T[l];   // T is wave-uniform
-    }
-    __syncthreads();
-    if (threadIdx.x < L) {
-        float acc = 0.f;
-        for (int wv_ = 0; wv_ < kBwdWaves; ++wv_) acc += smem[wv_ * L + threadIdx.x];
-        prow[(size_t)(L + 1) * d + threadIdx.x] = acc;
-    }
-}
-
-// sum the partial rows and apply  dw_l = A_l + T_l*B_l,  db_j = G + sum_{l>j} T_l*w_l.
-// grid (ceil(d/64), L+1): workgroup (cb, vec) sums vector `vec` (A_vec, or G when vec == L) over
-// the partial rows for 64 columns — 16 float4 column lanes x 16 row slices — and writes dw_vec
-// (vec < L) or every db_j (vec == L).  Each workgroup reduces the L scalars T_l itself.
-template <int L>
-__global__ __launch_bounds__(256) void cross_stack_finalize_kernel(
-    const float* __restrict__ partials, unsigned nrows, unsigned d, const float* __restrict__ w,
-    const float* __restrict__ b, float* __restrict__ dw, float* __restrict__ db) {
-    __shared__ float4 sh[16][16];
-    __shared__ float shT[L][4];
-    const unsigned cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
-    const unsigned col4 = blockIdx.x * 16 + cl;          // float4 column
-    const unsigned vec = blockIdx.y;
-    const unsigned row_len = (L + 1) * d + ((L + 3) & ~3);
-    const unsigned d4 = d / 4;
-    float4 acc = f4_zero();
-    if (col4 < d4) {
-#pragma unroll 8
-        for (unsigned r = slice; r < nrows; r += 16)
-            acc = f4_add(acc, *reinterpret_cast<const float4*>(partials + (size_t)r * row_len + (size_t)vec * d + col4 * 4));
-    }
-    sh[slice][cl] = acc;
-    {   // T_l = sum over rows, one wave-level reduction per workgroup
-        float t[L];
+                for (int jj = 0; jj < L; ++jj)
+                    if (jj < vec) Bl += bf[(size_t)jj * d + j];
+                prow[(size_t)vec * d + j] = fmaf(Bl, Tw[vec], acc);
+            } else {
+                float tail = 0.f;                             // db_jj = G + sum_{l > jj} T_l * w_l[j], built from the top
 #pragma unroll
-        for (int l = 0; l < L; ++l) t[l] = 0.f;
-        for (unsigned r = threadIdx.x; r < nrows; r += 256)
-#pragma unroll
-            for (int l = 0; l < L; ++l) t[l] += partials[(size_t)r * row_len + (size_t)(L + 1) * d + l];
-        wave_sum_n<L>(t);
-        if ((threadIdx.x & 63) == 0)
-#pragma unroll
-            for (int l = 0; l < L; ++l) shT[l][threadIdx.x >> 6] = t[l];
-    }
-    __syncthreads();
-    if (slice == 0 && col4 < d4) {
-        float4 S = f4_zero();
-#pragma unroll
-        for (int s = 0; s < 16; ++s) S = f4_add(S, sh[s][cl]);
-        float T[L];
-#pragma unroll
-        for (int l = 0; l < L; ++l) T[l] = (shT[l][0] + shT[l][1]) + (shT[l][2] + shT[l][3]);
-        const float4* b4 = reinterpret_cast<const float4*>(b);
-        const float4* w4 = reinterpret_cast<const float4*>(w);
-        if (vec < (unsigned)L) {
-            float4 Bl = f4_zero();               // B_vec[col] = sum_{j<vec} b_j
-            for (unsigned j = 0; j < vec; ++j) Bl = f4_add(Bl, b4[(size_t)j * d4 + col4]);
-            float Tv = 0.f;
-#pragma unroll
-            for (int l = 0; l < L; ++l)
-                if ((unsigned)l == vec) Tv = T[l];
-            reinterpret_cast<float4*>(dw)[(size_t)vec * d4 + col4] = f4_fma(Bl, Tv, S);
-        } else {
-            float4 tail = f4_zero();             // sum_{l>j} T_l * w_l[col]
-#pragma unroll
-            for (int j = L - 1; j >= 0; --j) {
-                reinterpret_cast<float4*>(db)[(size_t)j * d4 + col4] = f4_add(S, tail);
-                tail = f4_fma(w4[(size_t)j * d4 + col4], T[j], tail);
+                for (int jj = L - 1; jj >= 0; --jj) {
+                    prow[(size_t)(L + jj) * d + j] = acc + tail;
+                    tail = fmaf(Tw[jj], wf[(size_t)jj * d + j], tail);
+                }
             }
         }
     }
 }
+
 
 // ---------------------------------------------------------------------------------------------
 // single layer, direct form (xl distinct from x0)
@@ -442,7 +403,7 @@ inline int bwd_grid(int B) {
 template <int NV, int L>
 int launch_stack(bool fwd, const float* x0, int x_stride, const float* w, const float* b, const float* g,
                  int g_stride, const float* gx, int B, int d, float* out, int out_stride, float* dw,
-                 float* db, float* partials, hipStream_t st) {
+                 float* db, float* partials, hipStream_t st, int defer) {
     const float4* w4 = reinterpret_cast<const float4*>(w);
     const float4* b4 = reinterpret_cast<const float4*>(b);
     if (fwd) {
@@ -452,27 +413,27 @@ int launch_stack(bool fwd, const float* x0, int x_stride, const float* w, const 
         return (int)hipGetLastError();
     }
     const int grid = bwd_grid(B);
-    size_t smem = (size_t)kBwdWaves * d * sizeof(float);
-    if (smem < (size_t)kBwdWaves * L * sizeof(float)) smem = (size_t)kBwdWaves * L * sizeof(float);
+    const size_t smem = ((size_t)kBwdWaves * d + (size_t)(kBwdWaves + 1) * L) * sizeof(float);
     hipLaunchKernelGGL((cross_stack_bwd_kernel<NV, L>), dim3(grid), dim3(kBwdThreads), smem, st, x0,
                        (unsigned)x_stride, w4, b4, g, (unsigned)g_stride, gx, (unsigned)B, (unsigned)(d / 4),
                        out, partials);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((cross_stack_finalize_kernel<L>), dim3(cdiv(d, 64), L + 1), dim3(256), 0, st, partials,
-                       (unsigned)grid, (unsigned)d, w, b, dw, db);
+    if (e != hipSuccess || defer) return (int)e;
+    const unsigned ncols = 2u * L * d;
+    hipLaunchKernelGGL(colsum4_kernel, dim3(cdiv((int64_t)ncols, 64)), dim3(256), 0, st, partials, (unsigned)grid, ncols, dw,
+                       db, (unsigned)(L * d));
     return (int)hipGetLastError();
 }
 
 template <int NV>
 int dispatch_stack_L(int L, bool fwd, const float* x0, int x_stride, const float* w, const float* b,
                      const float* g, int g_stride, const float* gx, int B, int d, float* out,
-                     int out_stride, float* dw, float* db, float* partials, hipStream_t st) {
+                     int out_stride, float* dw, float* db, float* partials, hipStream_t st, int defer) {
     switch (L) {
 #define CASE_L(LL)                                                                                      \
     case LL:                                                                                            \
         return launch_stack<NV, LL>(fwd, x0, x_stride, w, b, g, g_stride, gx, B, d, out, out_stride, dw, \
-                                    db, partials, st);
+                                    db, partials, st, defer);
         CASE_L(1) CASE_L(2) CASE_L(3) CASE_L(4) CASE_L(5) CASE_L(6)
 #undef CASE_L
         default: return (int)hipErrorInvalidValue;
@@ -481,11 +442,11 @@ int dispatch_stack_L(int L, bool fwd, const float* x0, int x_stride, const float
 
 int dispatch_stack(int L, bool fwd, const float* x0, int x_stride, const float* w, const float* b,
                    const float* g, int g_stride, const float* gx, int B, int d, float* out, int out_stride,
-                   float* dw, float* db, float* partials, hipStream_t st) {
+                   float* dw, float* db, float* partials, hipStream_t st, int defer = 0) {
     const int nv = cdiv(d / 4, 64);
-    if (nv <= 1) return dispatch_stack_L<1>(L, fwd, x0, x_stride, w, b, g, g_stride, gx, B, d, out, out_stride, dw, db, partials, st);
-    if (nv <= 2) return dispatch_stack_L<2>(L, fwd, x0, x_stride, w, b, g, g_stride, gx, B, d, out, out_stride, dw, db, partials, st);
-    if (nv <= 4) return dispatch_stack_L<4>(L, fwd, x0, x_stride, w, b, g, g_stride, gx, B, d, out, out_stride, dw, db, partials, st);
+    if (nv <= 1) return dispatch_stack_L<1>(L, fwd, x0, x_stride, w, b, g, g_stride, gx, B, d, out, out_stride, dw, db, partials, st, defer);
+    if (nv <= 2) return dispatch_stack_L<2>(L, fwd, x0, x_stride, w, b, g, g_stride, gx, B, d, out, out_stride, dw, db, partials, st, defer);
+    if (nv <= 4) return dispatch_stack_L<4>(L, fwd, x0, x_stride, w, b, g, g_stride, gx, B, d, out, out_stride, dw, db, partials, st, defer);
     return (int)hipErrorInvalidValue;
 }
 
@@ -506,20 +467,20 @@ RECALGO_EXPORT int recalgo_cross_fwd(const float* x0, int x_stride, const float*
 
 RECALGO_EXPORT int64_t recalgo_cross_bwd_workspace_bytes(int B, int d, int L) {
     if (B <= 0 || d <= 0 || L <= 0) return 0;
-    int64_t row = (int64_t)(L + 1) * d + ((L + 3) & ~3);
-    if (row < 2 * (int64_t)d) row = 2 * (int64_t)d;
-    return (int64_t)bwd_grid(B) * row * (int64_t)sizeof(float);
+    return (int64_t)bwd_grid(B) * 2 * L * d * (int64_t)sizeof(float);
 }
+
+RECALGO_EXPORT int recalgo_cross_bwd_partial_rows(int B) { return B > 0 ? bwd_grid(B) : 0; }
 
 RECALGO_EXPORT int recalgo_cross_bwd(const float* x0, int x_stride, const float* w, const float* b,
                                      const float* g, int g_stride, const float* g_x0_extra, int B,
                                      int d, int L, float* dx0, float* dw, float* db, void* workspace,
-                                     recalgo_stream_t stream) {
+                                     int defer_reduce, recalgo_stream_t stream) {
     RECALGO_REQUIRE(B > 0 && d > 0 && d % 4 == 0 && d <= 1024 && L >= 1 && L <= 6);
     RECALGO_REQUIRE(x_stride % 4 == 0 && g_stride % 4 == 0 && x_stride >= d && g_stride >= d);
-    RECALGO_REQUIRE(workspace != nullptr);
+    RECALGO_REQUIRE(workspace != nullptr && (defer_reduce || (dw != nullptr && db != nullptr)));
     return dispatch_stack(L, false, x0, x_stride, w, b, g, g_stride, g_x0_extra, B, d, dx0, x_stride, dw, db,
-                          static_cast<float*>(workspace), as_stream(stream));
+                          static_cast<float*>(workspace), as_stream(stream), defer_reduce);
 }
 
 RECALGO_EXPORT int recalgo_cross_layer_fwd(const float* x0, const float* xl, int x_stride,

@@ -357,7 +357,17 @@ class _CrossFn(Function):
         L = w.data.shape[0]
         g = _pad4(g).contiguous()
         lib = _lib_()
-        ws = _workspace(lib.recalgo_cross_bwd_workspace_bytes(B, dp, L), x0p.device)
+        # unpadded width: the column sum of the partial rows joins the step's deferred-sum launch (its own scratch: the
+        # rows are read after later kernels have run)
+        defer = dp == d
+        nbytes = int(lib.recalgo_cross_bwd_workspace_bytes(B, dp, L))
+        if defer:
+            key = ("cross", x0p.device.type, x0p.device.index, B, dp, L, w.grad.data_ptr())
+            ws = _dense_ws.get(key)
+            if ws is None:
+                ws = _dense_ws[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x0p.device)
+        else:
+            ws = _workspace(nbytes, x0p.device)
         dx0 = torch.empty_like(x0p)
         if dp == d:
             wp, bp, dw, db = w.data, b.data, w.grad, b.grad
@@ -369,7 +379,11 @@ class _CrossFn(Function):
         fused_extra = extra is not None and dp == d and extra.is_contiguous() and tuple(extra.shape) == (B, d)
         _lib.check(lib.recalgo_cross_bwd(
             _p(x0p), dp, _p(wp), _p(bp), _p(g), dp, _p(extra) if fused_extra else None, B, dp, L, _p(dx0), _p(dw),
-            _p(db), _p(ws), _stream(x0p)), "recalgo_cross_bwd")
+            _p(db), _p(ws), int(defer), _stream(x0p)), "recalgo_cross_bwd")
+        if defer:
+            rows, wsf = int(lib.recalgo_cross_bwd_partial_rows(B)), ws.view(torch.float32)
+            _colsum_pending.append((wsf, 0, rows, 2 * L * dp, L * dp, dw))
+            _colsum_pending.append((wsf, L * dp, rows, 2 * L * dp, L * dp, db))
         if dp != d:
             w.grad.copy_(dw[:, :d].reshape(w.grad.shape))
             b.grad.copy_(db[:, :d].reshape(b.grad.shape))

@@ -44,6 +44,8 @@ def _layer(dev, name, fn, scope=None, var_names=None):
         out = call()
     assert_close(out, torch.from_numpy(d["out"]), what=f"{name} out")
     out.backward(torch.from_numpy(d["G"]).float().to(dev))
+    from recalgorithm_amd import nn as _nn
+    _nn.apply_parked_grads()          # deferred sums (weight-gradient splits, CrossNet's partial rows): what the optimizer does
     for k, g in GU.section(d, "grad_in/").items():
         assert_close(ins[k].grad, torch.from_numpy(g), what=f"{name} d(in {k})", reduced=True)
     for vn, g in GU.section(d, "grad_var/").items():
