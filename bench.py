@@ -373,6 +373,7 @@ def kernel_rooflines(args, est, feats, device):
     # (input + weight gradient tiles, ReLU mask and bias gradient fused) of the three layers 416 -> 512 -> 256 -> 128
     from recalgorithm_amd import ops
     widths = [d, 512, 256, 128]
+    keep, slab_bytes = [], 0
     for li in range(3):
         Kd, Nd = widths[li], widths[li + 1]
         xd = torch.randn(B, Kd, device=device)
@@ -383,8 +384,23 @@ def kernel_rooflines(args, est, feats, device):
         dwd, dbd = torch.empty_like(wd), torch.empty_like(bd)
         fl = 2.0 * B * Kd * Nd
         add(f"dense_fwd({Kd}->{Nd})", lambda: ops.dense_fwd(xd, wd, bd, True), (B * (Kd + Nd) + Kd * Nd) * 4, fl)
-        add(f"dense_bwd({Kd}->{Nd})", lambda: ops.dense_bwd(xd, gd, yd, wd, dwd, dbd),
-            (B * (2 * Kd + 2 * Nd) + 2 * Kd * Nd) * 4, 2.0 * fl)
+        # (the ONE merged launch, as in the step: the fixed-order sum of the batch-split slabs is a job of the step's
+        #  deferred-sum launch, listed below — not a second launch per layer)
+        def bwd_once():
+            ops.dense_bwd(xd, gd, yd, wd, dwd, dbd, defer=True)
+            ops._dense_pending.clear()
+        add(f"dense_bwd({Kd}->{Nd})", bwd_once, (B * (2 * Kd + 2 * Nd) + 2 * Kd * Nd) * 4, 2.0 * fl)
+        ops.dense_bwd(xd, gd, yd, wd, dwd, dbd, defer=True)          # leaves this layer's split slabs + its pending entry
+        keep.append((xd, gd, yd, wd, dwd, dbd))
+        slab_bytes += int(lib.recalgo_dense_bwd_weights_workspace_bytes(B, Kd, Nd)) + (Kd * Nd + Nd) * 4
+    # the step's deferred-sum launch: fixed-order sums of the three layers' split slabs (in the step it also sums the
+    # loss tail's and CrossNet's partial rows and advances the optimizer's step counter)
+    pending = list(ops._dense_pending)
+
+    def sums_once():
+        ops._dense_pending[:] = pending
+        ops.flush_dense_splits()
+    add("deferred_sums(3 layers' weight-gradient slabs)", sums_once, slab_bytes)
     # The optimizer launch (recalgo_adam_tf1_step: TF1 dense Adam over the flat dense buffer + over the arena's live-row
     # list; state as left by the timed steps; lr = 0 so that the repeated launches do not move the weights).  Rows no
     # gradient has ever reached have g = m = v = 0, for which the dense update is the identity.

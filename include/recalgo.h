@@ -394,7 +394,8 @@ int recalgo_dense_bwd_weights_reduce(const recalgo_dense_split_t* jobs, int n_jo
  *   moving_mean/var <- moving * momentum + batch * (1 - momentum)   (updated in place; may be NULL)
  *   save_mean, save_rstd [C] are kept for the backward, which returns
  *   dbeta = colsum(g), dgamma = colsum(g * xhat), dx = gamma * rstd / rows * (rows*g - dbeta - xhat*dgamma).
- * workspace: recalgo_batchnorm_workspace_bytes(rows, C) for both directions. */
+ * workspace: recalgo_batchnorm_workspace_bytes(rows, C) for both directions.  C % 4 == 0; x, y, g, dx and every [C]
+ * vector 16-byte aligned.  Two launches each way (per-tile moments / partial sums, then merge + apply). */
 int64_t recalgo_batchnorm_workspace_bytes(int rows, int C);
 int recalgo_batchnorm_train_fwd(const float* x, const float* gamma, const float* beta, int rows, int C,
                                 float eps, float momentum, float* moving_mean, float* moving_var,

@@ -5,9 +5,11 @@
 //   relu_bwd_bias        g2 = g * [y > 0],  dbias = colsum(g2)                      (dense backward)
 //   batchnorm_train_fwd  batch mean / biased variance (Chan-merged per-block moments, as accurate
 //                        as tf.nn.moments' two-pass form), moving-stat update (momentum 0.99),
-//                        y = (x - mean) * rsqrt(var + eps) * gamma + beta
+//                        y = (x - mean) * rsqrt(var + eps) * gamma + beta                      (2 launches)
 //   batchnorm_train_bwd  dbeta = colsum(g), dgamma = colsum(g * xhat),
-//                        dx = gamma * rstd / B * (B*g - dbeta - xhat * dgamma)
+//                        dx = gamma * rstd / B * (B*g - dbeta - xhat * dgamma)                (2 launches)
+// (BatchNorm first ran as 3 + 3 launches — moments, merge, apply / partial sums, column sums, apply; the second stages
+//  now ride in the prologue of the apply kernels: at 4-5 us per launch they were a tenth of the DeepFM step.)
 // All three are HBM-bound streams over [rows, C] fp32 with column reductions.  Tile = 64 rows x 64
 // columns per workgroup (16 float4 column groups x 16 row lanes, 4 rows per thread, held in
 // registers): a [4096, 512] layer is 512 workgroups, and only rows/64 partial rows per column are
@@ -105,67 +107,68 @@ __global__ __launch_bounds__(kThreads) void bn_moments_kernel(const float4* __re
     }
 }
 
-// Chan merge of the block moments (fixed order: 16 interleaved block groups, then the groups) ->
-// mean, rstd; moving-stat update.  256 threads = 16 columns x 16 block groups.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, unsigned nblk,
-                                                          unsigned rows, unsigned C, float eps, float momentum,
-                                                          float* __restrict__ moving_mean,
-                                                          float* __restrict__ moving_var,
-                                                          float* __restrict__ save_mean,
-                                                          float* __restrict__ save_rstd) {
-    __shared__ float sh[16][17];
-    const unsigned cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
-    const unsigned c = blockIdx.x * 16 + cl;
-    const bool ok = c < C;
-    float acc = 0.f;
+// Chan merge of the block moments (fixed order: 16 interleaved block groups, then the groups) -> mean, rstd of the
+// 64 columns of this workgroup, then y = (x - mean) * rstd * gamma + beta on its 64 x 64 tile.  Every workgroup of a
+// column block repeats the merge (nblk x 2 x 64 floats of L2-resident partials — cheaper than a launch in between);
+// the workgroups of tile row 0 record mean / rstd for the backward pass and update the moving statistics.
+__global__ __launch_bounds__(kThreads) void bn_finalize_apply_kernel(
+    const float4* __restrict__ x, const float4* __restrict__ gamma, const float4* __restrict__ beta,
+    const float4* __restrict__ partials, unsigned nblk, unsigned rows, unsigned C4, float eps, float momentum,
+    float4* __restrict__ moving_mean, float4* __restrict__ moving_var, float4* __restrict__ save_mean,
+    float4* __restrict__ save_rstd, float4* __restrict__ y) {
+    __shared__ float4 sh[16][17];
+    const unsigned cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const unsigned c4 = blockIdx.x * 16 + cl;
+    const bool ok = c4 < C4;
+    const float inv_rows = 1.0f / (float)rows;
+    float4 acc = f4_zero();
     if (ok)
-        for (unsigned b = rg; b < nblk; b += 16) {
+        for (unsigned b = rl; b < nblk; b += 16) {
             const float nb = (float)(min(rows, (b + 1) * kTileRows) - b * kTileRows);
-            acc += nb * partials[(size_t)b * 2 * C + c];
+            acc = f4_fma(partials[(size_t)b * 2 * C4 + c4], nb, acc);
         }
-    sh[rg][cl] = acc;
+    sh[rl][cl] = acc;
     __syncthreads();
-    float mean = 0.f;
+    float4 mean = sh[0][cl];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) mean += sh[g][cl];
-    mean /= (float)rows;
+    for (int g = 1; g < 16; ++g) mean = f4_add(mean, sh[g][cl]);
+    mean = f4_scale(mean, inv_rows);
     __syncthreads();
-    acc = 0.f;
+    acc = f4_zero();
     if (ok)
-        for (unsigned b = rg; b < nblk; b += 16) {
+        for (unsigned b = rl; b < nblk; b += 16) {
             const float nb = (float)(min(rows, (b + 1) * kTileRows) - b * kTileRows);
-            const float d = partials[(size_t)b * 2 * C + c] - mean;
-            acc += partials[(size_t)b * 2 * C + C + c] + nb * d * d;
+            const float4 d = f4_sub(partials[(size_t)b * 2 * C4 + c4], mean);
+            acc = f4_add(acc, f4_fma(f4_mul(d, d), nb, partials[(size_t)b * 2 * C4 + C4 + c4]));
         }
-    sh[rg][cl] = acc;
+    sh[rl][cl] = acc;
     __syncthreads();
-    if (rg == 0 && ok) {
-        float m2 = 0.f;
+    float4 var = sh[0][cl];
 #pragma unroll
-        for (int g = 0; g < 16; ++g) m2 += sh[g][cl];
-        const float var = m2 / (float)rows;                    // biased (tf.nn.moments)
-        save_mean[c] = mean;
-        save_rstd[c] = rsqrtf(var + eps);
+    for (int g = 1; g < 16; ++g) var = f4_add(var, sh[g][cl]);
+    var = f4_scale(var, inv_rows);                              // biased (tf.nn.moments)
+    const float4 rstd = make_float4(rsqrtf(var.x + eps), rsqrtf(var.y + eps), rsqrtf(var.z + eps), rsqrtf(var.w + eps));
+    if (!ok) return;
+    if (blockIdx.y == 0 && rl == 0) {
+        save_mean[c4] = mean;
+        save_rstd[c4] = rstd;
         if (moving_mean) {                                      // assign_moving_average, decay = momentum
-            moving_mean[c] = moving_mean[c] * momentum + mean * (1.f - momentum);
-            moving_var[c] = moving_var[c] * momentum + var * (1.f - momentum);
+            const float k = 1.f - momentum;
+            moving_mean[c4] = f4_fma(mean, k, f4_scale(moving_mean[c4], momentum));
+            moving_var[c4] = f4_fma(var, k, f4_scale(moving_var[c4], momentum));
         }
     }
-}
-
-__global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float4* __restrict__ x,
-                                                            const float4* __restrict__ gamma,
-                                                            const float4* __restrict__ beta,
-                                                            const float4* __restrict__ mean,
-                                                            const float4* __restrict__ rstd, size_t total4,
-                                                            unsigned C4, float4* __restrict__ y) {
-    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
-    if (i >= total4) return;
-    const unsigned c4 = (unsigned)(i % C4);
-    const float4 sc = f4_mul(rstd[c4], gamma[c4]);
-    const float4 xh = f4_sub(x[i], mean[c4]);
-    const float4 b = beta[c4];
-    y[i] = make_float4(fmaf(xh.x, sc.x, b.x), fmaf(xh.y, sc.y, b.y), fmaf(xh.z, sc.z, b.z), fmaf(xh.w, sc.w, b.w));
+    const float4 sc = f4_mul(rstd, gamma[c4]), bt = beta[c4];
+    const unsigned r0 = blockIdx.y * kTileRows;
+#pragma unroll
+    for (unsigned k = 0; k < kTileRows / 16; ++k) {
+        const unsigned r = r0 + rl + 16 * k;
+        if (r < rows) {
+            const float4 xh = f4_sub(x[(size_t)r * C4 + c4], mean);
+            y[(size_t)r * C4 + c4] = make_float4(fmaf(xh.x, sc.x, bt.x), fmaf(xh.y, sc.y, bt.y), fmaf(xh.z, sc.z, bt.z),
+                                                 fmaf(xh.w, sc.w, bt.w));
+        }
+    }
 }
 
 // partial[blk][0:C] = colsum(g), [C:2C] = colsum(g * xhat)
@@ -200,19 +203,53 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float4* _
     }
 }
 
-__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
+// dbeta / dgamma = fixed-order column sums of the partial rows (16 interleaved row groups, then the groups), repeated by
+// every workgroup of a column block (see bn_finalize_apply_kernel) and recorded by tile row 0; then
+// dx = gamma * rstd * (g - (dbeta + xhat * dgamma) / rows) on the 64 x 64 tile.
+__global__ __launch_bounds__(kThreads) void bn_bwd_sum_apply_kernel(
     const float4* __restrict__ x, const float4* __restrict__ g, const float4* __restrict__ gamma,
-    const float4* __restrict__ mean, const float4* __restrict__ rstd, const float4* __restrict__ dbeta,
-    const float4* __restrict__ dgamma, size_t total4, unsigned C4, float inv_rows, float4* __restrict__ dx) {
-    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
-    if (i >= total4) return;
-    const unsigned c4 = (unsigned)(i % C4);
-    const float4 rs4 = rstd[c4];
-    const float4 xh = f4_mul(f4_sub(x[i], mean[c4]), rs4);
+    const float4* __restrict__ mean, const float4* __restrict__ rstd, const float4* __restrict__ partials,
+    unsigned nblk, unsigned rows, unsigned C4, float4* __restrict__ dbeta, float4* __restrict__ dgamma,
+    float4* __restrict__ dx) {
+    __shared__ float4 sh[2][16][17];
+    const unsigned cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const unsigned c4 = blockIdx.x * 16 + cl;
+    const bool ok = c4 < C4;
+    float4 sb = f4_zero(), sg = f4_zero();
+    if (ok)
+        for (unsigned b = rl; b < nblk; b += 16) {
+            sb = f4_add(sb, partials[(size_t)b * 2 * C4 + c4]);
+            sg = f4_add(sg, partials[(size_t)b * 2 * C4 + C4 + c4]);
+        }
+    sh[0][rl][cl] = sb;
+    sh[1][rl][cl] = sg;
+    __syncthreads();
+    if (!ok) return;
+    float4 db = sh[0][0][cl], dg = sh[1][0][cl];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) {
+        db = f4_add(db, sh[0][q][cl]);
+        dg = f4_add(dg, sh[1][q][cl]);
+    }
+    if (blockIdx.y == 0 && rl == 0) {
+        dbeta[c4] = db;
+        dgamma[c4] = dg;
+    }
+    const float inv_rows = 1.0f / (float)rows;
+    const float4 mu = mean[c4], rs4 = rstd[c4];
     const float4 k = f4_mul(gamma[c4], rs4);
-    const float4 db = dbeta[c4], dg = dgamma[c4], gv = g[i];
-    dx[i] = make_float4(k.x * (gv.x - inv_rows * (db.x + xh.x * dg.x)), k.y * (gv.y - inv_rows * (db.y + xh.y * dg.y)),
-                        k.z * (gv.z - inv_rows * (db.z + xh.z * dg.z)), k.w * (gv.w - inv_rows * (db.w + xh.w * dg.w)));
+    const unsigned r0 = blockIdx.y * kTileRows;
+#pragma unroll
+    for (unsigned t = 0; t < kTileRows / 16; ++t) {
+        const unsigned r = r0 + rl + 16 * t;
+        if (r < rows) {
+            const float4 xh = f4_mul(f4_sub(x[(size_t)r * C4 + c4], mu), rs4);
+            const float4 gv = g[(size_t)r * C4 + c4];
+            dx[(size_t)r * C4 + c4] =
+                make_float4(k.x * (gv.x - inv_rows * (db.x + xh.x * dg.x)), k.y * (gv.y - inv_rows * (db.y + xh.y * dg.y)),
+                            k.z * (gv.z - inv_rows * (db.z + xh.z * dg.z)), k.w * (gv.w - inv_rows * (db.w + xh.w * dg.w)));
+        }
+    }
 }
 
 inline bool width_ok(int C) { return C >= 4 && C % 4 == 0; }
@@ -500,13 +537,12 @@ RECALGO_EXPORT int recalgo_batchnorm_train_fwd(const float* x, const float* gamm
     float* partials = static_cast<float*>(workspace);
     hipLaunchKernelGGL(bn_moments_kernel, dim3(cdiv(C4, 16), nb), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
                        (unsigned)rows, C4, reinterpret_cast<float4*>(partials));
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, partials, (unsigned)nb, (unsigned)rows,
-                       (unsigned)C, eps, momentum, moving_mean, moving_var, save_mean, save_rstd);
-    const size_t total4 = (size_t)rows * C4;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv((int64_t)total4, kThreads)), dim3(kThreads), 0, st,
+    hipLaunchKernelGGL(bn_finalize_apply_kernel, dim3(cdiv(C4, 16), nb), dim3(kThreads), 0, st,
                        reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(gamma),
-                       reinterpret_cast<const float4*>(beta), reinterpret_cast<const float4*>(save_mean),
-                       reinterpret_cast<const float4*>(save_rstd), total4, C4, reinterpret_cast<float4*>(y));
+                       reinterpret_cast<const float4*>(beta), reinterpret_cast<const float4*>(partials), (unsigned)nb,
+                       (unsigned)rows, C4, eps, momentum, reinterpret_cast<float4*>(moving_mean),
+                       reinterpret_cast<float4*>(moving_var), reinterpret_cast<float4*>(save_mean),
+                       reinterpret_cast<float4*>(save_rstd), reinterpret_cast<float4*>(y));
     RECALGO_RETURN_LAST();
 }
 
@@ -524,13 +560,11 @@ RECALGO_EXPORT int recalgo_batchnorm_train_bwd(const float* x, const float* gamm
                        reinterpret_cast<const float4*>(g), reinterpret_cast<const float4*>(save_mean),
                        reinterpret_cast<const float4*>(save_rstd), (unsigned)rows, C4,
                        reinterpret_cast<float4*>(partials));
-    launch_colsum16(partials, (unsigned)nb, (unsigned)(2 * C), dbeta, (unsigned)C, dgamma, st);
-    const size_t total4 = (size_t)rows * C4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv((int64_t)total4, kThreads)), dim3(kThreads), 0, st,
+    hipLaunchKernelGGL(bn_bwd_sum_apply_kernel, dim3(cdiv(C4, 16), nb), dim3(kThreads), 0, st,
                        reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(g),
                        reinterpret_cast<const float4*>(gamma), reinterpret_cast<const float4*>(save_mean),
-                       reinterpret_cast<const float4*>(save_rstd), reinterpret_cast<const float4*>(dbeta),
-                       reinterpret_cast<const float4*>(dgamma), total4, C4, 1.0f / (float)rows,
+                       reinterpret_cast<const float4*>(save_rstd), reinterpret_cast<const float4*>(partials), (unsigned)nb,
+                       (unsigned)rows, C4, reinterpret_cast<float4*>(dbeta), reinterpret_cast<float4*>(dgamma),
                        reinterpret_cast<float4*>(dx));
     RECALGO_RETURN_LAST();
 }

@@ -1,17 +1,25 @@
 #!/bin/bash
-# Round-end evidence on the GPU box (via gpurun): full GPU test suite, smoke, the default bench line,
-# per-model bench lines + rocprofv3 kernel stats + PMC passes, the full-run PMC of the default
-# model, and the 100 M-row table run.  Leaves only text summaries under gpurun_out/.
+# Round-end evidence on the GPU box (via gpurun): full GPU test suite, smoke, the default bench line, per-model bench
+# lines + rocprofv3 kernel stats, the PMC passes of the default model (HBM traffic over a full run; SQ / MFMA counters)
+# and the 100 M-row table run.  Leaves only text summaries under gpurun_out/.
 # usage: scripts/gpu_round_final.sh <tag>
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$PWD; O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
-timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/${TAG}_pytest_gpu.log
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | grep -v "^| tests" | tail -12 > $O/${TAG}_pytest_gpu.log
+cp $O/strict_parity.md $O/${TAG}_strict_parity_all_gpu_tests.md 2>/dev/null
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/${TAG}_smoke.log 2>&1
 timeout 400 python bench.py > $O/bench_${TAG}_default.json 2> $O/bench_${TAG}_default.err
-bash scripts/gpu_bench_all.sh $TAG --pmc dcn deepfm xdeepfm din fibinet pnn > $O/${TAG}_bench_all.log 2>&1
+# rocprofv3 --kernel-trace --stats of THE SAME default command (agreement with the live HIP-event roofline numbers)
+D=/tmp/prof_${TAG}_default
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $D -o dcn -- python $R/bench.py --no-cpu-baseline > $O/prof_${TAG}_default.log 2>&1)
+DB=$(find $D -name "*_results.db" | head -1)
+if [ -n "$DB" ]; then python $R/scripts/rocpd_stats.py $DB 40 > $O/${TAG}_default_kernel_stats.md; fi
+tail -c 1200 $O/prof_${TAG}_default.log > $O/prof_${TAG}_default.tail; rm -rf $O/prof_${TAG}_default.log $D
+bash scripts/gpu_bench_all.sh $TAG > $O/${TAG}_bench_all.log 2>&1
 bash scripts/gpu_pmc_bench.sh $TAG dcn 64 > $O/${TAG}_pmc_fullrun.log 2>&1
-timeout 400 python bench.py --model deepfm --big-table-rows 100000000 --no-cpu-baseline > $O/bench_${TAG}_deepfm_100M.json 2> $O/bench_${TAG}_deepfm_100M.err
-tail -3 $O/${TAG}_pytest_gpu.log; cat $O/${TAG}_smoke.log | tail -2
+bash scripts/gpu_pmc_sq.sh $TAG dcn SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE > $O/${TAG}_pmc_sq.log 2>&1
+timeout 400 python bench.py --model deepfm --big-table-rows 100000000 --no-cpu-baseline --sweep-batches 0 > $O/bench_${TAG}_deepfm_100M.json 2> $O/bench_${TAG}_deepfm_100M.err
+tail -3 $O/${TAG}_pytest_gpu.log; tail -2 $O/${TAG}_smoke.log
 for f in $O/bench_${TAG}_*.json; do python - "$f" <<'PY'
 import json, sys
 try:

@@ -2,7 +2,10 @@
 """Record the PMC traffic of one kernel (max over the dispatches of a full-run summary written by
 scripts/pmc_summary.py) in profiles/pmc_traffic.json, the file bench.py reads `roofline.traffic` from.
 
-    python scripts/pmc_traffic_json.py <fullrun.md> <model> <kernel-substring> <bench kernel name> <source path>
+    python scripts/pmc_traffic_json.py <fullrun.md> <model> <kernel-substring> <bench kernel name> <source path> <alg_bytes>
+
+alg_bytes = the algorithmic bytes per launch bench.py reports for that kernel in the measured state; bench.py only
+quotes the traffic while its own figure is within 10 % of it (same shapes / same optimizer state).
 """
 import json
 import os
@@ -11,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def main(md, model, needle, bench_name, source):
+def main(md, model, needle, bench_name, source, alg_bytes=0):
     hdr, row = None, None
     for line in open(md):
         cells = [c.strip() for c in line.strip().strip("|").split("|")]
@@ -26,10 +29,11 @@ def main(md, model, needle, bench_name, source):
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     data = json.load(open(path)) if os.path.exists(path) else {}
     data.setdefault(model, {})[bench_name] = {"fetch_size_kb": float(row[col["max FETCH_SIZE"]]),
-                                               "write_size_kb": float(row[col["max WRITE_SIZE"]]), "source": source}
+                                               "write_size_kb": float(row[col["max WRITE_SIZE"]]), "source": source,
+                                               "alg_bytes": int(float(alg_bytes))}
     json.dump(data, open(path, "w"), indent=1)
     print(model, bench_name, data[model][bench_name])
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:6])
+    main(*sys.argv[1:7])

@@ -23,6 +23,21 @@ def main(path, top=40):
     for r in rows[:top]:
         n = r[0] if len(r[0]) < 110 else r[0][:107] + "..."
         print(f"| `{n}` | {r[1]} | {r[2]} | {r[3]:.0f} | {r[4]} | {r[5]} | {100.0 * r[2] / tot:.2f} |")
+    # one kernel name can serve several shapes (the dense kernels run the three MLP layers): the same statistics per
+    # (kernel, grid size), so that a per-shape bench row can be compared with the dispatches of exactly that shape
+    gx = next((c_ for c_ in cols if c_.lower() in ("grid_size_x", "grid_x", "grid_size")), None)
+    if gx is None:
+        return
+    rows = c.execute(f"select {name}, {gx}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
+                     f"from kernels where {name} like '%dense_%' or {name} like '%cin_%' group by {name}, {gx} "
+                     f"order by 1, 2").fetchall()
+    if rows:
+        print("\nper launch shape (kernel, grid size):\n")
+        print("| kernel | grid | calls | avg_ns | min_ns | max_ns |")
+        print("|---|---:|---:|---:|---:|---:|")
+        for r in rows:
+            n = r[0] if len(r[0]) < 90 else r[0][:87] + "..."
+            print(f"| `{n}` | {r[1]} | {r[2]} | {r[4]:.0f} | {r[5]} | {r[6]} |")
 
 
 if __name__ == "__main__":

@@ -97,10 +97,10 @@ def test_dense_matches_exact_fmaf_order(dev):
 
 @pytest.mark.parametrize("M,K,N", [(4096, 416, 512), (4096, 256, 128), (2048, 100, 36)])
 def test_dense_wgrad_split_handoff_stress(dev, M, K, N):
-    """The split partials of the weight gradient are summed by the last-arriving workgroup of each tile (agent-scope
-    release / ticket / acquire).  Re-using ONE workspace over many launches with fresh data makes every consumer
-    read lines it has cached from earlier launches: a missing release or acquire shows up as a stale partial, i.e.
-    an O(1) relative error.  Also: bit-identical to itself (fixed summation order, whoever arrives last)."""
+    """The batch-split partials of the weight gradient go through a workspace and are summed in fixed order by a
+    second launch.  Re-using ONE workspace over many launches with fresh data: a partial read before its producer's
+    launch has completed, or a stale line, shows up as an O(1) relative error.  Also: bit-identical to itself
+    (fixed summation order, no atomics)."""
     gen = torch.Generator(device=dev).manual_seed(123)
     dw, db = torch.empty(K, N, device=dev), torch.empty(N, device=dev)
     dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
