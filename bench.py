@@ -663,7 +663,10 @@ def main():
                                  "TF1 Adam, dense semantics over all tables (only rows a gradient has ever reached are visited: "
                                  "identity update elsewhere)"),
                    "launch": launch,
-                   "gemm_selection": "TunableOp" if args.tunable else "hipBLASLt default",
+                   "dense_layers": ("hipBLASLt (RECALGO_DENSE=blas), " + ("TunableOp" if args.tunable else "default selection")
+                                    if os.environ.get("RECALGO_DENSE") == "blas" else
+                                    "hand-written fp32 MFMA (csrc/dense.hip); layers wider than 4096 inputs on hipBLASLt, "
+                                    + ("TunableOp" if args.tunable else "default selection")),
                    "parallelism": (f"dp{world} + embedding rows sharded r % {world} (RCCL all_to_all), dense grads all-reduced"
                                    + (" [gloo_staged bring-up mode: NOT a benchmark]" if staged else "")
                                    if world > 1 else "single")},

@@ -31,8 +31,10 @@ void recalgo_vocab_close(void* vocab);
 void* recalgo_reader_open(const char* path, int verify_crc);
 void recalgo_reader_close(void* reader);
 int recalgo_reader_rewind(void* reader);
-/* dataset.repeat(num_epochs) (< 0: forever) and dataset.shuffle(buffer_size) (0: off; tf.data's
- * buffer semantics, own seeded generator); call before the first recalgo_reader_next_batch. */
+/* dataset.shuffle(buffer_size).repeat(num_epochs), the reference's order (algorithm/utils.py:19-21): the shuffle buffer
+ * is drained at every epoch boundary, so records of adjacent epochs never mix.  num_epochs < 0: forever;
+ * buffer_size 0: no shuffle; tf.data's buffer semantics, own generator seeded with `seed`.  Call before the first
+ * recalgo_reader_next_batch. */
 void recalgo_reader_configure(void* reader, int64_t num_epochs, int64_t shuffle_buffer_size, uint64_t seed);
 const char* recalgo_reader_error(const void* reader);
 /* Read up to max_records records; returns the count (0 = end of file, -1 = error). */

@@ -12,18 +12,21 @@
 // is never materialised); the bias gradient accumulated from the staged gradient tiles of the wgrad; the
 // `beta * C` term of the first DIN layer's mini-batch-aware regulariser in the dgrad store.
 //
-// Tile engine: workgroup = 4 waves = 64 x 64 output tile (one 32 x 32 MFMA accumulator per wave: the
-// dependent-accumulator latency of v_mfma_f32_32x32x2_f32 equals its issue interval, 64 cycles, so one chain
-// per wave already issues back to back), reduction chunks of 32 double-buffered through LDS (global ->
-// registers for chunk c+1 is in flight under the 16 MFMAs of chunk c; one barrier per chunk).  LDS layouts
-// are chosen per operand form so that every MFMA operand read is a conflict-free ds_read_b32:
+// Tile engine: workgroup = 4 waves = 64 x 64 output tile, one 32 x 32 sub-tile per wave held as TWO interleaved
+// accumulator chains (even / odd reduction steps, summed in the epilogue), reduction chunks of 32 through a 3-slot LDS
+// ring with one barrier per chunk; every piece of non-MFMA work of an iteration (global loads three chunks ahead,
+// LDS -> operand registers of the next chunk, registers -> LDS of the chunk after) is issued in the shadow of the
+// iteration's own 16 MFMAs at fixed slots (see tile_mainloop_impl).  LDS layouts are chosen per operand form so that
+// every MFMA operand read is a conflict-free ds_read_b32:
 //   red-contiguous operand ([idx][red] in memory): LDS [64 idx][32 red], row stride 33 (odd): lane l reads
 //       [idx0 + (l & 31)][kk + (l >> 5)] -> 32 distinct banks per half wave; staged by 4 scalar stores;
 //   red-major operand ([red][idx] in memory): LDS [32 red][64 idx], row stride 64: lanes read 32 consecutive
 //       floats; staged by one ds_write_b128.
-// A [4096 x 512 x 416] layer is 512 workgroups (2 per CU, 2 waves per SIMD: one wave's staging and barrier
-// hide under the other's MFMAs).  blockIdx -> tile is XCD-aware: the 8 XCDs (block b runs on XCD b % 8) each
-// own a contiguous range of row tiles, so an XCD's L2 holds its own 1/8 of X plus the (small) W.
+// A [4096 x 512 x 416] layer is 512 workgroups (2 per CU).  blockIdx -> tile is XCD-aware: the 8 XCDs (block b runs
+// on XCD b % 8) each own a contiguous range of row tiles, so an XCD's L2 holds its own 1/8 of X plus the (small) W.
+// The weight gradient is split over the batch into deterministic slabs (summed in fixed order by
+// dense_sum_slabs_kernel — per layer, or once per training step for all layers: recalgo_dense_bwd_weights_reduce);
+// recalgo_dense_bwd runs a layer's input- and weight-gradient tiles in ONE grid.
 #include <cstdlib>
 
 #include "common.h"
