@@ -414,6 +414,7 @@ int recalgo_batchnorm_train_bwd(const float* x, const float* gamma, const float*
  *       kernel with W = I), att [B, P] (the attention MLP's scores: the dense kernels) ->
  *       score = softmax over P, out[b, :] = sum_p score[b, p] * pairs[b, p, :];  score [B, P] is saved for
  *       bwd: d_pairs[b, p, :] = score * g[b, :], d_att = score * (<g, pairs_p> - sum_q score_q <g, pairs_q>)
+ *       (K <= 64; the backward parks <g, pairs_p> in LDS: P <= 4096)
  *   FFM field-aware pair dots (algorithm/FFM/ffm.py:146-160): x [B, F, F-1, K], row (i, s) = field i looked up in
  *       its s-th sub-table -> out[b] = sum_{i<j} <x[b, i, j-1, :], x[b, j, i, :]>
  *       bwd: dx[b, a, s, :] = g[b] * x[b, partner(a, s), :]

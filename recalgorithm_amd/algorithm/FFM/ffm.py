@@ -99,40 +99,51 @@ def ffm_model_fn(features, labels, mode, params):
 
     ids = [c.categorical_column.ids(features, dev) for c in cols]
     vocab = [int(v) for _, v in params["fields_vocabulary_size_tuple"]]
+    single = [i for i, x in enumerate(ids) if not isinstance(x, Ragged)]
     # ---- first order ------------------------------------------------------------------------------------------
     first = None
+    if single:                                                   # every single-valued column in ONE gather of (B, n) weights
+        rb1 = store.row_base_tensor(w1, [kprefix + cols[i].key for i in single])
+        id1 = torch.stack([ids[i] for i in single], 1).contiguous()
+        first = ops.embedding_gather(store, id1, w1, rb1).sum(dim=1, keepdim=True)                   # (B, 1)
     for c, x in zip(cols, ids):
+        if not isinstance(x, Ragged):
+            continue
         tn = kprefix + c.key
-        if isinstance(x, Ragged):
-            mean = ops.embedding_bag_mean(store, x.values, x.offsets, w1, tn)                        # (B, 1)
-            lens = x.offsets[1:] - x.offsets[:-1]
-            bag = torch.repeat_interleave(torch.arange(B, device=dev), lens)
-            cnt = torch.zeros(B, device=dev).index_add_(0, bag, (x.values >= 0).float())
-            term = mean * cnt.unsqueeze(1)                       # counts: a repeated id counts twice (A-5)
-        else:
-            rb = store.row_base_tensor(w1, [tn])
-            term = ops.embedding_gather(store, x.reshape(-1, 1).contiguous(), w1, rb)                # (B, 1)
+        mean = ops.embedding_bag_mean(store, x.values, x.offsets, w1, tn)                            # (B, 1)
+        lens = x.offsets[1:] - x.offsets[:-1]
+        bag = torch.repeat_interleave(torch.arange(B, device=dev), lens)
+        cnt = torch.zeros(B, device=dev).index_add_(0, bag, (x.values >= 0).float())
+        term = mean * cnt.unsqueeze(1)                           # counts: a repeated id counts twice (A-5)
         first = term if first is None else first + term
     first = first + bias.data                                    # (the bias gradient: sum of d logit, below)
     # ---- field-aware lookups: X [B, F, F-1, K] ------------------------------------------------------------------
-    blocks = []
-    single = [i for i, x in enumerate(ids) if not isinstance(x, Ragged)]
     if single:
         s_off = torch.arange(F - 1, device=dev, dtype=torch.int64)
         idv = torch.stack([torch.where(ids[i].unsqueeze(1) >= 0, ids[i].unsqueeze(1) + s_off * vocab[i],
                                        torch.full((1, 1), -1, device=dev, dtype=torch.int64)) for i in single], 1)
         rbv = store.row_base_tensor(arena, [tnames[i] for i in single for _ in range(F - 1)])
         got = ops.embedding_gather(store, idv.reshape(B, -1).contiguous(), arena, rbv)               # (B, n_single*(F-1)*K)
-        got = got.reshape(B, len(single), (F - 1) * K)
-    for i, x in enumerate(ids):
-        if isinstance(x, Ragged):
-            d = _distinct_bags(x)
-            subs = [ops.embedding_bag_mean(store, torch.where(d.values >= 0, d.values + s * vocab[i], d.values), d.offsets,
-                                           arena, tnames[i]) for s in range(F - 1)]
-            blocks.append(torch.cat(subs, dim=1))
-        else:
-            blocks.append(got[:, single.index(i), :])
-    X = torch.cat(blocks, dim=1).contiguous()                    # (B, F*(F-1)*K)
+    if len(single) == F:
+        X = got                                                  # all fields single-valued: the gather output IS X
+    else:
+        # runs of consecutive single-valued fields are one slice of the gather output each; a multi-valued field is F-1
+        # bag-mean lookups over its distinct ids
+        blocks, i, W = [], 0, (F - 1) * K
+        while i < F:
+            if isinstance(ids[i], Ragged):
+                d = _distinct_bags(ids[i])
+                blocks += [ops.embedding_bag_mean(store, torch.where(d.values >= 0, d.values + s * vocab[i], d.values),
+                                                  d.offsets, arena, tnames[i]) for s in range(F - 1)]
+                i += 1
+            else:
+                j = i
+                while j < F and not isinstance(ids[j], Ragged):
+                    j += 1
+                a = single.index(i)
+                blocks.append(got[:, a * W:(a + j - i) * W])
+                i = j
+        X = torch.cat(blocks, dim=1).contiguous()                # (B, F*(F-1)*K)
     second = ops.ffm_pairs(X, F, K)                              # (B, 1)
     total_logit = _BiasGrad.apply(first, bias) + second
     return finish_model_fn(mode, total_logit, labels, params,

@@ -292,45 +292,55 @@ __global__ __launch_bounds__(256) void dense1_fwd_kernel(HeadParts P, int B, con
 // accumulated in the same pass over x (8 independent loads in flight per thread).  Per-tile partial
 // rows of dw (and of db in column C) are summed in fixed order by colsum16.
 constexpr int kHeadRows = 32;
-__global__ __launch_bounds__(256) void dense1_bwd_kernel(HeadParts P, int B, int C, const float* __restrict__ w,
-                                                         const float* __restrict__ g, float* __restrict__ partials) {
+constexpr int kHeadMaxPartialRows = 1024;     // the fixed-order column sum behind walks partial rows / 16 per thread
+// rows per workgroup: one 32-row tile up to 32 K examples, more tiles per workgroup beyond (AFM's attention net runs this
+// head over B * pairs = 1.3 M rows: 41 K partial rows made the column sum 330 us)
+inline int head_rows_per_block(int B) {
+    const int tiles = cdiv(B > 0 ? B : 1, kHeadRows);
+    return cdiv(tiles, kHeadMaxPartialRows) * kHeadRows;
+}
+__global__ __launch_bounds__(256) void dense1_bwd_kernel(HeadParts P, int B, int C, int rows_per_block,
+                                                         const float* __restrict__ w, const float* __restrict__ g,
+                                                         float* __restrict__ partials) {
     __shared__ float gs[kHeadRows];
-    const int b0 = blockIdx.y * kHeadRows;
-    const int nb = min(kHeadRows, B - b0);
-    if ((int)threadIdx.x < kHeadRows) gs[threadIdx.x] = (int)threadIdx.x < nb ? g[b0 + threadIdx.x] : 0.f;
-    __syncthreads();
-    float* __restrict__ prow = partials + (size_t)blockIdx.y * (C + 1);
     const int c = blockIdx.x * 256 + threadIdx.x;          // column of the concat
-    if (c < C) {
-        int p = 0, off = 0;
+    int p = 0, off = 0;
+    if (c < C)
         while (c >= off + P.width[p]) off += P.width[p++];
-        const int W = P.width[p], j = c - off;
-        const float* __restrict__ xp = P.x[p] + (size_t)b0 * W + j;
-        float* __restrict__ dxp = P.dx[p] ? P.dx[p] + (size_t)b0 * W + j : nullptr;
-        const float wj = w[c];
-        float acc = 0.f;
-        int r = 0;
-        for (; r + 8 <= nb; r += 8) {
-            float xv[8];
+    const int W = c < C ? P.width[p] : 1, j = c - off;
+    const float wj = c < C ? w[c] : 0.f;
+    float acc = 0.f, sgs = 0.f;
+    const int row_end = min(B, (int)(blockIdx.y + 1) * rows_per_block);
+    for (int b0 = blockIdx.y * rows_per_block; b0 < row_end; b0 += kHeadRows) {
+        const int nb = min(kHeadRows, row_end - b0);
+        __syncthreads();
+        if ((int)threadIdx.x < kHeadRows) gs[threadIdx.x] = (int)threadIdx.x < nb ? g[b0 + threadIdx.x] : 0.f;
+        __syncthreads();
+        if (c < C) {
+            const float* __restrict__ xp = P.x[p] + (size_t)b0 * W + j;
+            float* __restrict__ dxp = P.dx[p] ? P.dx[p] + (size_t)b0 * W + j : nullptr;
+            int r = 0;
+            for (; r + 8 <= nb; r += 8) {
+                float xv[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) xv[k] = xp[(size_t)(r + k) * W];
+                for (int k = 0; k < 8; ++k) xv[k] = xp[(size_t)(r + k) * W];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                acc = fmaf(gs[r + k], xv[k], acc);
-                if (dxp) dxp[(size_t)(r + k) * W] = gs[r + k] * wj;
+                for (int k = 0; k < 8; ++k) {
+                    acc = fmaf(gs[r + k], xv[k], acc);
+                    if (dxp) dxp[(size_t)(r + k) * W] = gs[r + k] * wj;
+                }
+            }
+            for (; r < nb; ++r) {
+                acc = fmaf(gs[r], xp[(size_t)r * W], acc);
+                if (dxp) dxp[(size_t)r * W] = gs[r] * wj;
             }
         }
-        for (; r < nb; ++r) {
-            acc = fmaf(gs[r], xp[(size_t)r * W], acc);
-            if (dxp) dxp[(size_t)r * W] = gs[r] * wj;
-        }
-        prow[c] = acc;
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            for (int r = 0; r < nb; ++r) sgs += gs[r];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        float sgs = 0.f;
-        for (int r = 0; r < nb; ++r) sgs += gs[r];
-        prow[C] = sgs;
-    }
+    float* __restrict__ prow = partials + (size_t)blockIdx.y * (C + 1);
+    if (c < C) prow[c] = acc;
+    if (blockIdx.x == 0 && threadIdx.x == 0) prow[C] = sgs;
 }
 
 
@@ -491,9 +501,10 @@ RECALGO_EXPORT int recalgo_dense1_bwd(const float* const* x_parts, const int* wi
         RECALGO_RETURN_LAST();
     }
     RECALGO_REQUIRE(g != nullptr && workspace != nullptr);
-    const int blocks = cdiv(B, kHeadRows);
+    const int rpb = head_rows_per_block(B);
+    const int blocks = cdiv(B, rpb);
     float* partials = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(dense1_bwd_kernel, dim3(cdiv(C, 256), blocks), dim3(256), 0, st, P, B, C, w, g, partials);
+    hipLaunchKernelGGL(dense1_bwd_kernel, dim3(cdiv(C, 256), blocks), dim3(256), 0, st, P, B, C, rpb, w, g, partials);
     // columns [0, C) -> dw, column C -> dbias (or the scratch float behind the partial rows)
     launch_colsum16(partials, (unsigned)blocks, (unsigned)(C + 1), dw, (unsigned)C,
                     dbias ? dbias : partials + (size_t)blocks * (C + 1), st);

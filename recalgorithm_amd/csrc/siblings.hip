@@ -68,31 +68,40 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const float* __restr
     if (grp == 0 && k < K) out[(size_t)b * K + k] = acc;
 }
 // d att[p] = score[p] * (dalpha[p] - sum_q score[q] dalpha[q]), dalpha[p] = <g, pairs[p,:]>;  d pairs[p,k] = score[p] * g[k]
+// One wave per example, lanes = (pair group, k) as in the forward: a wave instruction reads / writes 64 / KL whole
+// pair rows (contiguous).  Pass 1 reads the pairs once and parks dalpha in LDS; pass 2 only writes.
 __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const float* __restrict__ pairs, const float* __restrict__ score,
                                                             const float* __restrict__ g, unsigned B, unsigned P, unsigned K,
-                                                            float* __restrict__ d_pairs, float* __restrict__ d_att) {
-    const unsigned b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+                                                            unsigned KL, float* __restrict__ d_pairs,
+                                                            float* __restrict__ d_att) {
+    extern __shared__ float smem[];                                  // [4 waves][P] dalpha
+    const unsigned wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned b = blockIdx.x * 4 + wib;
     if (b >= B) return;
+    float* da = smem + (size_t)wib * P;
     const float* sc = score + (size_t)b * P;
-    const float* gb = g + (size_t)b * K;
+    const unsigned G = 64 / KL, grp = lane / KL, k = lane % KL;
+    const float gk = k < K ? g[(size_t)b * K + k] : 0.f;
     float dot = 0.f;
-    for (unsigned p = lane; p < P; p += 64) {
-        const float* pr = pairs + ((size_t)b * P + p) * K;
-        float da = 0.f;
-        for (unsigned k = 0; k < K; ++k) da = fmaf(gb[k], pr[k], da);
-        dot = fmaf(sc[p], da, dot);
+    for (unsigned p0 = 0; p0 < P; p0 += G) {
+        const unsigned p = p0 + grp;
+        float v = (p < P && k < K) ? gk * pairs[((size_t)b * P + p) * K + k] : 0.f;
+        for (unsigned o = 1; o < KL; o <<= 1) v += __shfl_xor(v, o, 64);      // sum over k inside the pair group
+        if (p < P && k == 0) {
+            da[p] = v;
+            dot = fmaf(sc[p], v, dot);
+        }
     }
     dot = wave_sum(dot);
-    for (unsigned p = lane; p < P; p += 64) {
-        const float* pr = pairs + ((size_t)b * P + p) * K;
-        float* dp = d_pairs + ((size_t)b * P + p) * K;
-        float da = 0.f;
-        const float s = sc[p];
-        for (unsigned k = 0; k < K; ++k) {
-            da = fmaf(gb[k], pr[k], da);
-            dp[k] = s * gb[k];
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    for (unsigned p0 = 0; p0 < P; p0 += G) {
+        const unsigned p = p0 + grp;
+        if (p < P) {
+            const float s = sc[p];
+            if (k < K) d_pairs[((size_t)b * P + p) * K + k] = s * gk;
+            if (k == 0) d_att[(size_t)b * P + p] = s * (da[p] - dot);
         }
-        d_att[(size_t)b * P + p] = s * (da - dot);
     }
 }
 
@@ -166,8 +175,12 @@ RECALGO_EXPORT int recalgo_attention_pool_bwd(const float* pairs, const float* s
                                               float* d_pairs, float* d_att, recalgo_stream_t stream) {
     RECALGO_REQUIRE(B >= 0 && P >= 1 && K >= 1 && K <= 64);
     if (B == 0) return 0;
-    hipLaunchKernelGGL(attn_pool_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, as_stream(stream), pairs, score, g, (unsigned)B,
-                       (unsigned)P, (unsigned)K, d_pairs, d_att);
+    unsigned KL = 1;
+    while ((int)KL < K) KL <<= 1;
+    const size_t smem = (size_t)4 * P * sizeof(float);
+    RECALGO_REQUIRE(smem <= 64 * 1024);
+    hipLaunchKernelGGL(attn_pool_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), smem, as_stream(stream), pairs, score, g, (unsigned)B,
+                       (unsigned)P, (unsigned)K, KL, d_pairs, d_att);
     RECALGO_RETURN_LAST();
 }
 
