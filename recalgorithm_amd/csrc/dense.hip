@@ -350,31 +350,38 @@ struct DgradArgs {
     int lddx;
     int M, K;              // output is [M][K]
     int accumulate;        // dx += result (the second operand pair of the PNN layer)
+    int tiles_per_block;   // consecutive output tiles one workgroup computes (>= 1; see bwd_balance)
 };
 
 template <bool FAST, bool MASK>
 __device__ __forceinline__ void dgrad_tile(const DgradArgs& P, int block, int nblocks, float* As, float* Bs) {
     const int tn_count = (P.K + BN - 1) / BN;
-    const int tile = xcd_swizzle(block, nblocks);
-    const int m0 = (tile / tn_count) * BM, n0 = (tile % tn_count) * BN;
-    f32x16 acc, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
-    float4 unused = f4_zero();
-    tile_mainloop<true, true, FAST, MASK, false, false>(P.seg, m0, n0, P.M, P.K, 0, P.seg.n_red, As, Bs, acc, acc1, unused);
-    acc += acc1;
+    const int total = ((P.M + BM - 1) / BM) * tn_count;
+    const int first = xcd_swizzle(block, nblocks) * P.tiles_per_block;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hi = lane >> 5, l32 = lane & 31;
-    const int col = n0 + (wave & 1) * 32 + l32;
-    if (col >= P.K) return;
+    for (int t = 0; t < P.tiles_per_block; ++t) {
+        const int tile = first + t;                       // consecutive tiles: same gradient rows, adjacent columns
+        if (tile >= total) break;                         // (workgroup-uniform)
+        const int m0 = (tile / tn_count) * BM, n0 = (tile % tn_count) * BN;
+        f32x16 acc, acc1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = m0 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (row < P.M) {
-            float v = acc[r];
-            if (P.c_in) v = fmaf(P.beta, P.c_in[(size_t)row * P.ldc + col], v);
-            float* o = P.dx + (size_t)row * P.lddx + col;
-            *o = P.accumulate ? *o + v : v;
+        for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
+        float4 unused = f4_zero();
+        tile_mainloop<true, true, FAST, MASK, false, false>(P.seg, m0, n0, P.M, P.K, 0, P.seg.n_red, As, Bs, acc, acc1, unused);
+        acc += acc1;
+        const int col = n0 + (wave & 1) * 32 + l32;
+        if (col < P.K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (row < P.M) {
+                    float v = acc[r];
+                    if (P.c_in) v = fmaf(P.beta, P.c_in[(size_t)row * P.ldc + col], v);
+                    float* o = P.dx + (size_t)row * P.lddx + col;
+                    *o = P.accumulate ? *o + v : v;
+                }
+            }
         }
     }
 }
@@ -546,18 +553,42 @@ inline Operand operand(const float* p, const float* mask, int ld, int64_t rows, 
 inline bool fast_rc(const Operand& o, int n_red) { return o.p == nullptr || (o.vec && o.bytes > 0 && n_red % 4 == 0); }
 inline bool fast_rm(const Operand& o, int n_idx) { return o.p == nullptr || (o.vec && o.bytes > 0 && n_idx % 4 == 0); }
 
-// workgroups a weight-gradient grid aims for (it shares its launch with the 64-256 input-gradient workgroups of the
-// same layer); RECALGO_DENSE_WGRAD_BLOCKS overrides (tuning knob)
-static const int kWgradTargetBlocks = [] { const char* e = getenv("RECALGO_DENSE_WGRAD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+// Balance of a layer's backward launch (recalgo_dense_bwd: input- and weight-gradient tiles in one grid).  The tile engine
+// needs 122-162 VGPRs + 32 AGPRs: two workgroups (8 waves) are resident per CU, 512 on the chip.  A grid of 896 equal
+// workgroups (the first version: 448 dgrad tiles + 56 wgrad tiles x 8 batch splits for 416 -> 512) therefore runs as two
+// rounds, the second 3/4 full, and pays the launch ramp + pipeline fill + epilogue (~6 us) twice: 42 us for 22 us of
+// matrix work.  Instead the grid is sized to ONE resident round with equal work per workgroup: u = total chunk-tiles /
+// resident; a dgrad workgroup takes round(u / chunks per tile) consecutive output tiles, the weight gradient is split over
+// the batch into as many slabs as fill the rest of the round.  RECALGO_DENSE_RESIDENT_BLOCKS overrides the 512
+// (RECALGO_DENSE_WGRAD_BLOCKS: a fixed wgrad block target instead, the old policy).
+static const int kResidentBlocks = [] { const char* e = getenv("RECALGO_DENSE_RESIDENT_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+static const int kWgradTargetBlocks = [] { const char* e = getenv("RECALGO_DENSE_WGRAD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
 
-inline int wgrad_splits(int M, int K, int N) {
-    const int ntiles = cdiv(K, BM) * cdiv(N, BN);
-    int want = cdiv(kWgradTargetBlocks, ntiles);
-    const int max_s = cdiv(M, 4 * BK);                  // at least four chunks per split
-    if (want > max_s) want = max_s;
-    if (want >= 8) want = want / 8 * 8;                 // whole XCD groups
-    return want < 1 ? 1 : want;
+struct BwdBalance {
+    int tiles_per_block;   // dgrad
+    int splits;            // wgrad
+};
+inline BwdBalance bwd_balance(int M, int K, int N) {
+    const int gd = cdiv(M, BM) * cdiv(K, BN), cd = cdiv(N, BK);           // dgrad: tiles, chunks per tile
+    const int tw = cdiv(K, BM) * cdiv(N, BN), cw = cdiv(M, BK);           // wgrad: tiles, chunks per tile over the whole batch
+    const int max_s = cdiv(M, 4 * BK) < 1 ? 1 : cdiv(M, 4 * BK);         // at least four chunks per split
+    BwdBalance b{1, 1};
+    if (kWgradTargetBlocks > 0) {
+        int want = cdiv(kWgradTargetBlocks, tw);
+        if (want >= 8) want = want / 8 * 8;
+        b.splits = want > max_s ? max_s : (want < 1 ? 1 : want);
+        return b;
+    }
+    const double u = ((double)gd * cd + (double)tw * cw) / kResidentBlocks;   // chunk-tiles per workgroup
+    int tpb = (int)(u / cd + 0.5);
+    b.tiles_per_block = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
+    const int left = kResidentBlocks - cdiv(gd, b.tiles_per_block);
+    int s = left / tw;
+    if (s > max_s) s = max_s;
+    b.splits = s < 1 ? 1 : s;
+    return b;
 }
+inline int wgrad_splits(int M, int K, int N) { return bwd_balance(M, K, N).splits; }
 inline size_t wgrad_slab(int K, int N) { return ((size_t)K * N + N + 3) / 4 * 4; }
 
 }  // namespace
@@ -591,6 +622,7 @@ static bool build_dgrad(DgradArgs& P, const float* g, int ldg, const float* y_ma
     if (!(c_in == nullptr || ldc >= K)) return false;
     P.seg = Segment{operand(g, y_mask, ldg, M, N), operand(w, nullptr, N, K, N), N};
     P.c_in = c_in; P.beta = beta; P.ldc = ldc; P.dx = dx; P.lddx = lddx; P.M = M; P.K = K; P.accumulate = accumulate;
+    P.tiles_per_block = 1;
     return true;
 }
 static bool dgrad_fast(const DgradArgs& P) { return fast_rc(P.seg.a, P.seg.n_red) && fast_rc(P.seg.b, P.seg.n_red); }
@@ -693,7 +725,8 @@ RECALGO_EXPORT int recalgo_dense_bwd(const float* x, int ldx, const float* g, in
     const int S = build_wgrad(W, x, ldx, g, ldg, y_mask, M, K, N, dw, dbias, workspace);
     RECALGO_REQUIRE(S >= 1);
     hipStream_t st = as_stream(stream);
-    const int gd = cdiv(M, BM) * cdiv(K, BN), gw = cdiv(K, BM) * cdiv(N, BN) * S;
+    D.tiles_per_block = bwd_balance(M, K, N).tiles_per_block;
+    const int gd = cdiv(cdiv(M, BM) * cdiv(K, BN), D.tiles_per_block), gw = cdiv(K, BM) * cdiv(N, BN) * S;
     const bool fast = dgrad_fast(D) && wgrad_fast(W);
     if (fast && y_mask) hipLaunchKernelGGL((dense_bwd_kernel<true, true>), dim3(gd + gw), dim3(kThreads), 0, st, D, W, gd);
     else if (fast) hipLaunchKernelGGL((dense_bwd_kernel<true, false>), dim3(gd + gw), dim3(kThreads), 0, st, D, W, gd);
