@@ -444,10 +444,12 @@ def test_order_live_list_matches_nonzero(dev, rows, density):
 
 @pytest.mark.parametrize("B,widths,bias,skip_dx", [(4096, (416, 128), True, None), (1000, (82,), True, None), (15, (1,), False, None),
                                                    (257, (7, 130, 3, 64), True, 1), (1, (300, 20), False, 0), (0, (16, 8), True, None),
-                                                   (513, (2048,), True, None)])
+                                                   (513, (2048,), True, None), (100_003, (128,), True, None),
+                                                   (70_000, (33, 4), False, 1)])
 def test_dense1_head_against_torch(dev, B, widths, bias, skip_dx):
     """recalgo_dense1_{fwd,bwd} == concat + matmul (fp64 reference), incl. unaligned widths, missing
-    bias, a part that needs no input gradient, an empty batch."""
+    bias, a part that needs no input gradient, an empty batch, and batches beyond 32 K rows (AFM runs this head over
+    B x pairs rows: a workgroup then walks several 32-row tiles so that at most 1024 partial rows are left)."""
     g = torch.Generator().manual_seed(B + sum(widths))
     parts = [torch.randn(B, w, generator=g).to(dev) for w in widths]
     C = sum(widths)
