@@ -559,7 +559,7 @@ inline bool fast_rm(const Operand& o, int n_idx) { return o.p == nullptr || (o.v
 // rounds, the second 3/4 full, and pays the launch ramp + pipeline fill + epilogue (~6 us) twice: 42 us for 22 us of
 // matrix work.  Instead the grid is sized to ONE resident round with equal work per workgroup: u = total chunk-tiles /
 // resident; a dgrad workgroup takes round(u / chunks per tile) consecutive output tiles, the weight gradient is split over
-// the batch into as many slabs as fill the rest of the round.  RECALGO_DENSE_RESIDENT_BLOCKS overrides the 512
+// the batch into slabs of ~u chunks.  RECALGO_DENSE_RESIDENT_BLOCKS overrides the 512
 // (RECALGO_DENSE_WGRAD_BLOCKS: a fixed wgrad block target instead, the old policy).
 static const int kResidentBlocks = [] { const char* e = getenv("RECALGO_DENSE_RESIDENT_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
 static const int kWgradTargetBlocks = [] { const char* e = getenv("RECALGO_DENSE_WGRAD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
@@ -579,11 +579,14 @@ inline BwdBalance bwd_balance(int M, int K, int N) {
         b.splits = want > max_s ? max_s : (want < 1 ? 1 : want);
         return b;
     }
-    const double u = ((double)gd * cd + (double)tw * cw) / kResidentBlocks;   // chunk-tiles per workgroup
-    int tpb = (int)(u / cd + 0.5);
+    // chunk-tiles per workgroup for one resident round; a layer too large for one round (AFM's attention net: 1.3 M rows)
+    // runs several rounds of workgroups of at most 64 chunks
+    double u = ((double)gd * cd + (double)tw * cw) / kResidentBlocks;
+    if (u > 64.0) u = 64.0;
+    if (u < 1.0) u = 1.0;
+    const int tpb = (int)(u / cd + 0.5);
     b.tiles_per_block = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
-    const int left = kResidentBlocks - cdiv(gd, b.tiles_per_block);
-    int s = left / tw;
+    int s = (int)(cw / u + 0.5);                        // every batch split of a weight-gradient tile: ~u chunks
     if (s > max_s) s = max_s;
     b.splits = s < 1 ? 1 : s;
     return b;

@@ -5,7 +5,7 @@
 # usage: scripts/gpu_round_final.sh <tag>
 TAG=${1:-r02}
 R=$PWD; O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
-timeout 1200 python -m pytest tests -m gpu -q 2>&1 | grep -v "^| tests" | tail -12 > $O/${TAG}_pytest_gpu.log
+timeout 1200 python -m pytest tests -m gpu -q > $O/${TAG}_pytest_gpu_full.log 2>&1; grep -v "^| tests" $O/${TAG}_pytest_gpu_full.log | tail -40 > $O/${TAG}_pytest_gpu.log
 cp $O/strict_parity.md $O/${TAG}_strict_parity_all_gpu_tests.md 2>/dev/null
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/${TAG}_smoke.log 2>&1
 timeout 400 python bench.py > $O/bench_${TAG}_default.json 2> $O/bench_${TAG}_default.err

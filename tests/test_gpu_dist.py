@@ -29,6 +29,11 @@ def pg():
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     yield dist
+    # captured graphs that hold RCCL kernel nodes, and work still queued on the push stream, must be gone before the
+    # communicator is
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
     dist.destroy_process_group()
 
 
