@@ -414,8 +414,11 @@ __device__ __forceinline__ void wgrad_tile(const WgradArgs& P, int block, float*
         split = x + 8 * (j / ntiles);
         tile = j % ntiles;
     } else {
-        split = block / ntiles;
-        tile = block % ntiles;
+        // any other split count: every XCD takes a contiguous range of the split-major (split, tile) list, so the rows of a
+        // split are read by one or two XCDs instead of all eight
+        const int l = xcd_swizzle(block, ntiles * P.splits);
+        split = l / ntiles;
+        tile = l % ntiles;
     }
     const int m0 = (tile / tn_count) * BM, n0 = (tile % tn_count) * BN;
     const int r_begin = split * P.rows_per_split;
@@ -588,6 +591,7 @@ inline BwdBalance bwd_balance(int M, int K, int N) {
     b.tiles_per_block = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
     int s = (int)(cw / u + 0.5);                        // every batch split of a weight-gradient tile: ~u chunks
     if (s > max_s) s = max_s;
+    if (s >= 16) s = s / 8 * 8;                         // many splits: whole XCD groups (a split's rows stay in one XCD's L2)
     b.splits = s < 1 ? 1 : s;
     return b;
 }
