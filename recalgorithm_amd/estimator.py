@@ -705,6 +705,16 @@ def _with_labels(it):
 
 
 def train_and_evaluate(estimator: Estimator, train_spec: TrainSpec, eval_spec: EvalSpec):
-    """tf.estimator.train_and_evaluate (deepfm.py:323): train to max_steps, then evaluate."""
+    """tf.estimator.train_and_evaluate (deepfm.py:323): train to max_steps, evaluate, then hand the evaluation result to
+    the EvalSpec's exporters (deepfm.py:309-321: BestExporter -> <model_dir>/export/<name>/<timestamp>)."""
     estimator.train(train_spec.input_fn, max_steps=train_spec.max_steps)
-    return estimator.evaluate(eval_spec.input_fn, steps=eval_spec.steps)
+    result = estimator.evaluate(eval_spec.input_fn, steps=eval_spec.steps)
+    exporters = eval_spec.exporters or []
+    if not isinstance(exporters, (list, tuple)):
+        exporters = [exporters]
+    base = estimator.config.model_dir
+    for ex in exporters:
+        if base is None:
+            raise ValueError("train_and_evaluate: exporters need RunConfig(model_dir=...)")
+        ex.export(estimator, os.path.join(base, "export", ex.name), estimator._ckpt_path(), result, True)
+    return result
