@@ -581,6 +581,31 @@ class Estimator:
             a.live = None                    # liveness is rebuilt from the (unchanged) moments on next use
         return sorted(done)
 
+    def load_tf_checkpoint(self, path: str, strict: bool = True):
+        """Load the variables of a TensorFlow checkpoint written by the reference script — `path` is a model_dir (its
+        `checkpoint` state file names the newest one) or a checkpoint prefix (`.../model.ckpt-10000`) — read natively
+        (io/tf_checkpoint.py: no TensorFlow needed; format restated, see its header).  Returns the global step stored
+        in the file (0 if none); optimizer slots are ignored, as in load_variables."""
+        from .io import tf_checkpoint
+        prefix = path
+        if os.path.isdir(path):
+            prefix = tf_checkpoint.latest_checkpoint(path)
+            if prefix is None:
+                raise FileNotFoundError(f"load_tf_checkpoint: no `checkpoint` state file in {path}")
+        values = tf_checkpoint.read_checkpoint(prefix)
+        self.load_variables(values, strict=strict)
+        return int(values["global_step"]) if "global_step" in values else 0
+
+    def save_tf_checkpoint(self, prefix: str) -> str:
+        """Write the model's variables (reference names / shapes) + global_step as a TensorFlow V2 checkpoint
+        (`<prefix>.index`, `<prefix>.data-00000-of-00001`, `checkpoint`): the hand-back to the reference's tooling."""
+        import numpy as np
+        from .io import tf_checkpoint
+        arrays = dict(self.export_variables())
+        arrays["global_step"] = np.array(int(self.global_step), dtype=np.int64)
+        tf_checkpoint.write_checkpoint(prefix, arrays)
+        return prefix
+
     def _maybe_restore(self):
         md = self.config.model_dir
         if not md or not os.path.exists(self._ckpt_path()):

@@ -126,6 +126,27 @@ def test_load_and_export_variables_by_reference_names(name, tmp_path):
         est.load_variables({k: (v[:-1] if v.ndim and v.shape[0] > 1 else v) for k, v in ref.items()})
     with pytest.raises(KeyError):
         est.load_variables(dict(ref, **{"no/such/variable": np.zeros(2)}))
+    # the same through TensorFlow checkpoint FILES (io/tf_checkpoint.py): what a reference model_dir holds — variables,
+    # Adam slots, counters — is written in TF's V2 bundle format, and a fresh estimator loads the model_dir natively
+    from recalgorithm_amd.io import tf_checkpoint
+    ckpt = {k: v.astype(np.float32) for k, v in ref.items()}
+    ckpt.update({next(iter(ref)) + "/Adam": np.zeros(3, np.float32), "global_step": np.array(4321, np.int64),
+                 "beta1_power": np.array(0.5, np.float32), "beta2_power": np.array(0.9, np.float32)})
+    model_dir = str(tmp_path / "reference_model_dir")
+    tf_checkpoint.write_checkpoint(model_dir + "/model.ckpt-4321", ckpt)
+    est2 = Estimator(model_fn, params, RunConfig(device="cpu", seed=6, use_hip_graph=False))
+    est2.build(feats, {"read_comment": labels.float()})
+    assert est2.load_tf_checkpoint(model_dir) == 4321
+    back2 = est2.export_variables()
+    for k, v in ref.items():
+        np.testing.assert_array_equal(back2[k], v.astype(np.float32).reshape(back2[k].shape))
+    # and back out: save_tf_checkpoint -> read_checkpoint gives the reference-named arrays
+    est2.global_step = 99
+    out = est2.save_tf_checkpoint(str(tmp_path / "handback" / "model.ckpt-99"))
+    again = tf_checkpoint.read_checkpoint(out)
+    assert int(again["global_step"]) == 99
+    for k, v in ref.items():
+        np.testing.assert_array_equal(again[k], v.astype(np.float32).reshape(again[k].shape))
 
 
 def test_host_columns_are_packed_into_one_matrix_per_kind():
