@@ -290,3 +290,75 @@ def test_checkpoint_of_row_sharded_arenas_two_ranks(tmp_path):
             errs.append("worker timed out")
     assert not errs, "\n".join(errs)
     assert all(p.exitcode == 0 for p in procs)
+
+
+def _worker_estimator(rank, port, errq, WORLD=2):
+    """The production order on a REAL Estimator (mirrored DCN model_fn, CPU registration pass): attach_data_parallel
+    before the build -> every arena is created as this rank's rows only, with the single-process initial values; the
+    dense variables are broadcast after the build; the hooks are installed."""
+    try:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+        from recalgorithm_amd import feature_column as fc
+        from recalgorithm_amd import parallel as P
+        from recalgorithm_amd.algorithm.DCN.dcn import dcn_model_fn
+        from recalgorithm_amd.estimator import Estimator, RunConfig
+        from recalgorithm_amd.io import synth
+        spec = synth.SynthSpec(n_fields=6, max_vocab=300, seed=31)
+        cats = [fc.categorical_column_with_identity(n, v) for n, v in zip(spec.names, spec.vocabs)]
+
+        def make(seed):
+            params = {"category_feature_columns": [fc.embedding_column(c, 8) for c in cats], "dense_feature_columns": [],
+                      "hidden_units": ["16", "8"], "num_cross_layer": 2, "learning_rate": 0.005}
+            return Estimator(dcn_model_fn, params, RunConfig(device="cpu", seed=seed, use_hip_graph=False))
+        feats, labels, _ = synth.device_features(spec, 32, torch.device("cpu"))
+        whole = make(9)
+        whole.build(feats, labels)                                   # the single-process model
+        est = make(9)
+        P.attach_data_parallel(est, dist, local_gather=cpu_gather, local_scatter_add=cpu_scatter_add,
+                               planner=torch_exchange_plan, dedup=torch_dedup_rows)
+        assert not est._built and est.store.shard_at_build is not None
+        est.build(feats, labels)
+        assert est.loss_grad_scale == 1.0 / WORLD and est.grad_hook is not None and est.shard_spec.rank == rank
+        for name, ar in whole.store.arenas.items():
+            sar = est.store.arenas[name]
+            assert sar.sharding is not None and sar.sharding.global_rows == ar.weight.shape[0]
+            assert sar.weight.shape[0] == len(range(rank, ar.weight.shape[0], WORLD))
+            assert sar.grad.shape == sar.m.shape == sar.v.shape == sar.weight.shape
+            assert torch.equal(sar.weight, ar.weight[rank::WORLD])
+            assert torch.equal(P.unshard_arena(sar, "weight"), ar.weight)
+        assert torch.equal(est.store.flat, whole.store.flat)          # same seed -> identical dense init ...
+        est2 = make(100 + rank)                                       # ... and with different seeds: rank 0's is broadcast
+        P.attach_data_parallel(est2, dist, local_gather=cpu_gather, local_scatter_add=cpu_scatter_add,
+                               planner=torch_exchange_plan, dedup=torch_dedup_rows)
+        est2.build(feats, labels)
+        flats = [torch.empty_like(est2.store.flat) for _ in range(WORLD)]
+        dist.all_gather(flats, est2.store.flat)
+        assert all(torch.equal(flats[0], f) for f in flats[1:])
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        import traceback
+        errq.put(f"rank {rank}:\n{traceback.format_exc()}")
+        raise
+
+
+@pytest.mark.timeout(180)
+def test_attach_before_build_on_a_real_estimator_two_ranks():
+    ctx = mp.get_context("spawn")
+    errq = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_estimator, args=(r, port, errq)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(150)
+    errs = []
+    while not errq.empty():
+        errs.append(errq.get())
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+            errs.append("worker timed out")
+    assert not errs, "\n".join(errs)
+    assert all(p.exitcode == 0 for p in procs)
