@@ -72,7 +72,11 @@ struct Span {
     const uint8_t* p = nullptr;
     size_t n = 0;
 };
-bool read_varint(const uint8_t*& p, const uint8_t* end, uint64_t& v) {
+inline bool read_varint(const uint8_t*& p, const uint8_t* end, uint64_t& v) {
+    if (p < end && !(*p & 0x80)) {                         // one byte: every tag and almost every length of an Example
+        v = *p++;
+        return true;
+    }
     v = 0;
     for (int shift = 0; p < end && shift < 70; shift += 7) {
         uint8_t b = *p++;
@@ -119,12 +123,15 @@ bool for_fields(Span s, Fn&& f) {
 // memcmp only on a hash match — about 3x faster than std::unordered_map<string_view> on 10^5..10^6-key
 // vocabularies, and the lookups are where a record's decode time goes (26 of them per record).
 struct Vocab {
-    std::string blob;
-    struct Slot {
-        uint64_t hash = 0;
-        uint32_t off = 0, len = 0;
-        int64_t id = -1;                                   // -1 = empty slot
+    std::string blob;                                      // the file's bytes (keys longer than kInline are compared here)
+    static constexpr uint32_t kInline = 22;
+    struct Slot {                                          // 32 bytes: half a cache line, no second miss for short keys
+        int32_t id = -1;                                   // -1 = empty slot
+        uint32_t tag = 0;                                  // upper half of the key's hash
+        uint8_t len = 0;                                   // key length when <= kInline, else 255 and key = {off, len} in blob
+        char key[23] = {0};
     };
+    static_assert(sizeof(Slot) == 32, "vocabulary slot layout");
     std::vector<Slot> slots;
     uint64_t mask = 0;
     size_t count = 0;
@@ -145,7 +152,7 @@ struct Vocab {
         h ^= h >> 33;
         h *= 0xff51afd7ed558ccdull;
         h ^= h >> 33;
-        return h | 1ull;                                   // never 0 (kept for clarity; emptiness is id < 0)
+        return h;
     }
     void reserve(size_t keys) {
         size_t cap = 16;
@@ -153,30 +160,46 @@ struct Vocab {
         slots.assign(cap, Slot{});
         mask = cap - 1;
     }
+    bool equal(const Slot& s, std::string_view k) const {
+        if (s.len != 255) return s.len == k.size() && memcmp(s.key, k.data(), s.len) == 0;
+        uint32_t off, len;
+        memcpy(&off, s.key, 4);
+        memcpy(&len, s.key + 4, 4);
+        return len == k.size() && memcmp(blob.data() + off, k.data(), len) == 0;
+    }
     void insert_first(std::string_view k, int64_t id) {   // the first occurrence of a key wins
         const uint64_t h = hash_of(k.data(), k.size());
+        const uint32_t tag = (uint32_t)(h >> 32);
         for (uint64_t i = h & mask;; i = (i + 1) & mask) {
             Slot& s = slots[i];
             if (s.id < 0) {
-                s.hash = h;
-                s.off = (uint32_t)(k.data() - blob.data());
-                s.len = (uint32_t)k.size();
-                s.id = id;
+                s.id = (int32_t)id;
+                s.tag = tag;
+                if (k.size() <= kInline) {
+                    s.len = (uint8_t)k.size();
+                    memcpy(s.key, k.data(), k.size());
+                } else {
+                    const uint32_t off = (uint32_t)(k.data() - blob.data()), len = (uint32_t)k.size();
+                    s.len = 255;
+                    memcpy(s.key, &off, 4);
+                    memcpy(s.key + 4, &len, 4);
+                }
                 ++count;
                 return;
             }
-            if (s.hash == h && s.len == k.size() && memcmp(blob.data() + s.off, k.data(), s.len) == 0) return;
+            if (s.tag == tag && equal(s, k)) return;
         }
     }
-    int64_t find(std::string_view k) const {
+    int64_t find_hashed(std::string_view k, uint64_t h) const {
         if (slots.empty()) return -1;
-        const uint64_t h = hash_of(k.data(), k.size());
+        const uint32_t tag = (uint32_t)(h >> 32);
         for (uint64_t i = h & mask;; i = (i + 1) & mask) {
             const Slot& s = slots[i];
             if (s.id < 0) return -1;
-            if (s.hash == h && s.len == k.size() && memcmp(blob.data() + s.off, k.data(), s.len) == 0) return s.id;
+            if (s.tag == tag && equal(s, k)) return s.id;
         }
     }
+    int64_t find(std::string_view k) const { return find_hashed(k, hash_of(k.data(), k.size())); }
 };
 
 // ---- a small persistent worker pool: decode is per-record independent ------------------------------
@@ -296,8 +319,21 @@ struct Reader {
     // (protobuf map semantics; resolved while the index is built).
     std::vector<std::vector<Entry>> index;
     bool indexed = false;
+    int scans = 0;                                         // accessor calls served by a direct scan since the batch was read
     std::string error;
 };
+
+// cheap hash of a feature name: length, first and last (up to) 8 bytes
+inline uint64_t name_hash(std::string_view k) {
+    uint64_t a = 0, b = 0;
+    const size_t n = k.size(), m = n < 8 ? n : 8;
+    if (m) {                                               // (an empty name has a null data pointer)
+        memcpy(&a, k.data(), m);
+        memcpy(&b, k.data() + n - m, m);
+    }
+    uint64_t h = (a ^ (b * 0x9E3779B97F4A7C15ull) ^ (n * 0xff51afd7ed558ccdull)) * 0x100000001b3ull;
+    return h ^ (h >> 29);
+}
 
 const Span* find_feature(const std::vector<Entry>& idx, std::string_view k, size_t& hint) {
     const size_t n = idx.size();
@@ -310,6 +346,40 @@ const Span* find_feature(const std::vector<Entry>& idx, std::string_view k, size
     return nullptr;
 }
 
+// One feature of one record WITHOUT the index: walk the map entries, compare names (length first), keep the LAST match
+// (protobuf map semantics).  ~10 ns per entry — cheaper than building the index when a batch is asked for one or two
+// features besides the id matrix (the label); from the third such call on the index is built (feature_of).
+bool scan_feature(Span rec, std::string_view k, Span& out, bool& ok) {
+    bool found = false;
+    ok = for_fields(rec, [&](uint32_t field, uint32_t wt, Span features, uint64_t) {
+        if (field != 1 || wt != 2) return;
+        for_fields(features, [&](uint32_t f2, uint32_t w2, Span entry, uint64_t) {
+            if (f2 != 1 || w2 != 2) return;
+            bool is_key = false;
+            Span feat;
+            for_fields(entry, [&](uint32_t f3, uint32_t w3, Span pl, uint64_t) {
+                if (w3 != 2) return;
+                if (f3 == 1) is_key = pl.n == k.size() && memcmp(pl.p, k.data(), pl.n) == 0;
+                else if (f3 == 2) feat = pl;
+            });
+            if (is_key) {
+                out = feat;
+                found = true;
+            }
+        });
+    });
+    return found && ok;
+}
+
+bool index_batch(Reader& r);
+
+// how an accessor reads a feature of the current batch: direct scans for the first two calls, the index afterwards
+// -> false when the index had to be built and the batch is malformed
+bool prepare_access(Reader& r, bool& use_index) {
+    use_index = r.indexed || ++r.scans > 2;
+    return !use_index || r.indexed || index_batch(r);
+}
+
 bool index_batch(Reader& r) {
     const size_t B = r.recs.size();
     r.index.resize(B);
@@ -319,6 +389,7 @@ bool index_batch(Reader& r) {
             const Span rec = r.recs[i];
             auto& idx = r.index[i];
             idx.clear();
+            uint64_t seen = 0;                                 // bloom over the names met so far in this record
             bool ok = for_fields(rec, [&](uint32_t field, uint32_t wt, Span features, uint64_t) {
                 if (field != 1 || wt != 2) return;             // SequenceExample.feature_lists (2) is skipped
                 for_fields(features, [&](uint32_t f2, uint32_t w2, Span entry, uint64_t) {
@@ -330,12 +401,15 @@ bool index_batch(Reader& r) {
                         else if (f3 == 2) e.feat = pl;
                     });
                     bool dup = false;                          // a repeated map key: the last entry wins
-                    for (auto& old : idx)
-                        if (old.name == e.name) {
-                            old.feat = e.feat;
-                            dup = true;
-                            break;
-                        }
+                    const uint64_t bit = 1ull << (name_hash(e.name) & 63);
+                    if (seen & bit)                            // (only then can the name have occurred before)
+                        for (auto& old : idx)
+                            if (old.name == e.name) {
+                                old.feat = e.feat;
+                                dup = true;
+                                break;
+                            }
+                    seen |= bit;
                     if (!dup) idx.push_back(e);
                 });
             });
@@ -531,6 +605,7 @@ EXPORT int64_t recalgo_reader_next_batch(void* reader, int64_t max_records) {
     auto* r = (Reader*)reader;
     r->recs.clear();
     r->indexed = false;
+    r->scans = 0;
     r->error.clear();
     for (int64_t i = 0; i < max_records; ++i) {
         Span rec;
@@ -557,16 +632,25 @@ EXPORT void recalgo_reader_configure(void* reader, int64_t num_epochs, int64_t s
 EXPORT int recalgo_reader_float_feature(void* reader, const char* key, int n, float default_value, int has_default,
                                         float* out) {
     auto* r = (Reader*)reader;
-    if (!r->indexed && !index_batch(*r)) return -1;
+    bool use_index;
+    if (!prepare_access(*r, use_index)) return -1;
     const std::string_view k(key);
     const size_t B = r->recs.size();
-    std::atomic<long> missing{-1};
+    std::atomic<long> missing{-1}, bad{-1};
     Pool::get().parallel_for((B + kChunk - 1) / kChunk, [&](size_t c) {
         size_t hint = 0;
         for (size_t i = c * kChunk; i < std::min(B, (c + 1) * kChunk); ++i) {
             float* o = out + i * (size_t)n;
             int filled = 0;
-            if (const Span* feat = find_feature(r->index[i], k, hint)) {
+            Span scanned;
+            const Span* feat = nullptr;
+            if (use_index) feat = find_feature(r->index[i], k, hint);
+            else {
+                bool ok = true;
+                if (scan_feature(r->recs[i], k, scanned, ok)) feat = &scanned;
+                if (!ok) bad.store((long)i);
+            }
+            if (feat) {
                 for_fields(*feat, [&](uint32_t field, uint32_t wt, Span list, uint64_t) {
                     if (field != 2 || wt != 2) return;                       // FloatList
                     for_fields(list, [&](uint32_t f2, uint32_t w2, Span pl, uint64_t) {
@@ -589,6 +673,10 @@ EXPORT int recalgo_reader_float_feature(void* reader, const char* key, int n, fl
             }
         }
     });
+    if (bad.load() >= 0) {
+        r->error = "malformed Example in record " + std::to_string(bad.load());
+        return -1;
+    }
     if (missing.load() >= 0) {
         r->error = std::string("feature ") + key + " is required but missing in record " + std::to_string(missing.load());
         return -1;
@@ -601,14 +689,24 @@ EXPORT int recalgo_reader_float_feature(void* reader, const char* key, int n, fl
 EXPORT int64_t recalgo_reader_id_feature(void* reader, const char* key, const void* vocab, int64_t* offsets,
                                          int64_t* values, int64_t values_cap) {
     auto* r = (Reader*)reader;
-    if (!r->indexed && !index_batch(*r)) return -1;
+    bool use_index;
+    if (!prepare_access(*r, use_index)) return -1;
     const Vocab& vm = *(const Vocab*)vocab;
     const std::string_view k(key);
     const size_t B = r->recs.size();
     const size_t chunks = (B + kChunk - 1) / kChunk;
+    std::atomic<long> bad{-1};
     // visit the byte strings of record i's feature
     auto each_value = [&](size_t i, size_t& hint, auto&& fn) {
-        if (const Span* feat = find_feature(r->index[i], k, hint)) {
+        Span scanned;
+        const Span* feat = nullptr;
+        if (use_index) feat = find_feature(r->index[i], k, hint);
+        else {
+            bool ok = true;
+            if (scan_feature(r->recs[i], k, scanned, ok)) feat = &scanned;
+            if (!ok) bad.store((long)i);
+        }
+        if (feat) {
             for_fields(*feat, [&](uint32_t field, uint32_t wt, Span list, uint64_t) {
                 if (field != 1 || wt != 2) return;                           // BytesList
                 for_fields(list, [&](uint32_t f2, uint32_t w2, Span pl, uint64_t) {
@@ -627,6 +725,10 @@ EXPORT int64_t recalgo_reader_id_feature(void* reader, const char* key, const vo
             offsets[i + 1] = cnt;
         }
     });
+    if (bad.load() >= 0) {
+        r->error = "malformed Example in record " + std::to_string(bad.load());
+        return -1;
+    }
     for (size_t i = 0; i < B; ++i) offsets[i + 1] += offsets[i];
     const int64_t nnz = offsets[B];
     if (nnz > values_cap) return nnz;
@@ -648,40 +750,125 @@ EXPORT int64_t recalgo_reader_id_feature(void* reader, const char* key, const vo
 // then holds the first value; use recalgo_reader_id_feature for that key).  Returns 0, -1 on a malformed batch.
 EXPORT int recalgo_reader_id_matrix(void* reader, int n_keys, const char* const* keys, const void* const* vocabs,
                                     int64_t* out, int32_t* multi) {
+    // ONE pass over the wire bytes of every record (no per-record index): each map entry's name is matched against
+    // the requested keys through a small hash table, the first byte string of its BytesList is hashed and the
+    // vocabulary slot it maps to is PREFETCHED; the probes of a group of records are resolved afterwards, so the
+    // cache misses of the 26 lookups x kGroup records overlap instead of queueing (the slot holds the key bytes
+    // inline, so a lookup in a 10^6-key vocabulary is ONE miss).
     auto* r = (Reader*)reader;
     if (n_keys < 0 || (n_keys > 0 && (!keys || !vocabs || !out || !multi))) return -1;
-    if (!r->indexed && !index_batch(*r)) return -1;
     const size_t B = r->recs.size(), F = (size_t)n_keys;
     std::vector<std::string_view> ks(F);
     for (size_t f = 0; f < F; ++f) {
         ks[f] = std::string_view(keys[f]);
         multi[f] = 0;
     }
+    // name -> column: open addressing, load <= 1/4; a key given twice maps to its first column (the others stay -1)
+    size_t tcap = 16;
+    while (tcap < 4 * F + 4) tcap <<= 1;
+    std::vector<int> ntab(tcap, -1);
+    for (size_t f = 0; f < F; ++f) {
+        size_t i = name_hash(ks[f]) & (tcap - 1);
+        while (ntab[i] >= 0 && ks[(size_t)ntab[i]] != ks[f]) i = (i + 1) & (tcap - 1);
+        if (ntab[i] < 0) ntab[i] = (int)f;
+    }
     std::vector<std::atomic<int>> mflag(F);
     for (auto& m : mflag) m.store(0);
+    std::atomic<long> bad{-1};
+    constexpr size_t kGroup = 8;                               // records whose lookups are in flight together
+    struct Pending {
+        const char* p;
+        uint32_t len;
+        uint32_t col;                                          // out index (record * F + column)
+        uint64_t h;
+        const Vocab* vm;
+    };
     Pool::get().parallel_for((B + kChunk - 1) / kChunk, [&](size_t c) {
-        std::vector<size_t> hint(F, 0);
-        for (size_t i = c * kChunk; i < std::min(B, (c + 1) * kChunk); ++i) {
+        std::vector<Pending> pend;
+        pend.reserve(kGroup * F);
+        std::vector<int> slot_of(F);                           // this record's pending entry per column (-1 none)
+        std::vector<int> order;                                // column of the j-th map entry of the previous record (-1: not
+                                                               // requested): one writer lists its features in one order
+        const size_t i_end = std::min(B, (c + 1) * kChunk);
+        auto resolve = [&]() {                               // the slots were prefetched while the records were parsed
+            for (auto& q : pend) out[q.col] = q.vm->find_hashed(std::string_view(q.p, q.len), q.h);
+            pend.clear();
+        };
+        for (size_t i = c * kChunk; i < i_end; ++i) {
             for (size_t f = 0; f < F; ++f) {
-                int64_t id = -1;
-                int n = 0;
-                if (const Span* feat = find_feature(r->index[i], ks[f], hint[f])) {
-                    const Vocab& vm = *(const Vocab*)vocabs[f];
-                    for_fields(*feat, [&](uint32_t field, uint32_t wt, Span list, uint64_t) {
-                        if (field != 1 || wt != 2) return;                       // BytesList
-                        for_fields(list, [&](uint32_t f2, uint32_t w2, Span pl, uint64_t) {
-                            if (f2 != 1 || w2 != 2) return;
-                            if (n++ == 0) {
-                                id = vm.find(std::string_view((const char*)pl.p, pl.n));
-                            }
+                out[i * F + f] = -1;
+                slot_of[f] = -1;
+            }
+            const uint8_t* p = r->recs[i].p;
+            const uint8_t* end = p + r->recs[i].n;
+            bool ok = true;
+            size_t j = 0;                                      // map entry counter of this record
+            // Example { features = 1 }  (SequenceExample.feature_lists = 2 and anything else is skipped)
+            ok = for_fields(Span{p, (size_t)(end - p)}, [&](uint32_t field, uint32_t wt, Span features, uint64_t) {
+                if (field != 1 || wt != 2) return;
+                ok = for_fields(features, [&](uint32_t f2, uint32_t w2, Span entry, uint64_t) {
+                    if (f2 != 1 || w2 != 2) return;
+                    std::string_view name;
+                    Span feat;
+                    for_fields(entry, [&](uint32_t f3, uint32_t w3, Span pl, uint64_t) {
+                        if (w3 != 2) return;
+                        if (f3 == 1) name = std::string_view((const char*)pl.p, pl.n);
+                        else if (f3 == 2) feat = pl;
+                    });
+                    const size_t pos = j++;
+                    int col;
+                    if (pos < order.size() && order[pos] >= 0 && ks[(size_t)order[pos]] == name) {
+                        col = order[pos];
+                    } else {
+                        size_t t = name_hash(name) & (tcap - 1);
+                        while (ntab[t] >= 0 && ks[(size_t)ntab[t]] != name) t = (t + 1) & (tcap - 1);
+                        col = ntab[t];
+                        if (pos >= order.size()) order.resize(pos + 1, -1);
+                        order[pos] = col;
+                    }
+                    if (col < 0) return;                       // not a requested key
+                    const size_t f = (size_t)col;
+                    int n = 0;
+                    Span first;
+                    for_fields(feat, [&](uint32_t f4, uint32_t w4, Span list, uint64_t) {
+                        if (f4 != 1 || w4 != 2) return;                           // BytesList
+                        for_fields(list, [&](uint32_t f5, uint32_t w5, Span pl, uint64_t) {
+                            if (f5 != 1 || w5 != 2) return;
+                            if (n++ == 0) first = pl;
                         });
                     });
-                }
-                if (n > 1) mflag[f].store(1, std::memory_order_relaxed);
-                out[i * F + f] = id;
+                    if (n > 1) mflag[f].store(1, std::memory_order_relaxed);
+                    // a repeated map key: the last entry wins (protobuf map semantics) -> overwrite this column's entry
+                    if (n == 0) {
+                        if (slot_of[f] >= 0) pend[(size_t)slot_of[f]].vm = nullptr;
+                        slot_of[f] = -1;
+                        out[i * F + f] = -1;
+                        return;
+                    }
+                    const Vocab* vm = (const Vocab*)vocabs[f];
+                    Pending q{(const char*)first.p, (uint32_t)first.n, (uint32_t)(i * F + f),
+                              Vocab::hash_of((const char*)first.p, first.n), vm};
+                    if (!vm->slots.empty()) __builtin_prefetch(&vm->slots[q.h & vm->mask]);
+                    if (slot_of[f] >= 0) pend[(size_t)slot_of[f]] = q;
+                    else {
+                        slot_of[f] = (int)pend.size();
+                        pend.push_back(q);
+                    }
+                }) && ok;
+            }) && ok;
+            if (!ok) bad.store((long)i);
+            if ((i + 1 - c * kChunk) % kGroup == 0) {
+                pend.erase(std::remove_if(pend.begin(), pend.end(), [](const Pending& q) { return q.vm == nullptr; }), pend.end());
+                resolve();
             }
         }
+        pend.erase(std::remove_if(pend.begin(), pend.end(), [](const Pending& q) { return q.vm == nullptr; }), pend.end());
+        resolve();
     });
+    if (bad.load() >= 0) {
+        r->error = "malformed Example in record " + std::to_string(bad.load());
+        return -1;
+    }
     for (size_t f = 0; f < F; ++f) multi[f] = mflag[f].load();
     return 0;
 }

@@ -271,3 +271,51 @@ def test_host_header_arg_types_match_binding():
             got = ctype_of(decl)
             # byte buffers are passed as c_void_p / c_char_p interchangeably
             assert got is bound or {got, bound} == {c_char_p, c_void_p}, f"{name} arg {i} `{decl.strip()}`: binding {bound.__name__}"
+
+
+def test_id_matrix_map_semantics_on_hand_encoded_records(tmp_path):
+    """The fused one-pass decoder (recalgo_reader_id_matrix) against records written entry by entry: a repeated map
+    key keeps its LAST entry (protobuf map semantics), an empty BytesList and a missing key give -1, features nobody
+    asked for are skipped, the entries may come in any order (the position hint must not be trusted blindly), an
+    unknown vocabulary key gives -1, and the direct-scan float accessor agrees with the indexed one."""
+    vd = tmp_path / "v"
+    vd.mkdir()
+    (vd / "a.txt").write_bytes(b"a_0\na_1\na_2\n")
+    (vd / "b.txt").write_bytes(b"b_0\nb_1\nkey_longer_than_the_inline_slot_of_the_table_0\n")
+    ld, ent = T._ld, lambda name, feat: T._ld(1, T._ld(1, name) + T._ld(2, feat))
+    blist = lambda *vals: T._ld(1, b"".join(T._ld(1, v) for v in vals))
+    flist = lambda *vals: T._ld(2, T._ld(1, b"".join(np.float32(v).tobytes() for v in vals)))       # packed
+    recs = [
+        ld(1, ent(b"a", blist(b"a_1")) + ent(b"b", blist(b"b_0")) + ent(b"y", flist(1.0))),
+        ld(1, ent(b"b", blist(b"b_1")) + ent(b"zzz", blist(b"ignored")) + ent(b"a", blist(b"a_2")) + ent(b"y", flist(0.0))),   # reordered + extra
+        ld(1, ent(b"a", blist(b"a_0")) + ent(b"a", blist(b"a_2")) + ent(b"b", blist(b"nope")) + ent(b"y", flist(1.0))),          # repeated key: last wins
+        ld(1, ent(b"a", blist(b"a_1")) + ent(b"a", blist()) + ent(b"y", flist(0.0))),                                              # last entry empty -> -1; b missing
+        ld(1, ent(b"b", blist(b"key_longer_than_the_inline_slot_of_the_table_0")) + ent(b"a", blist(b"a_0", b"a_1"))),           # long key; two values; y missing
+    ]
+    path = str(tmp_path / "hand.tfrecord")
+    T.write_records(path, recs)
+    lib = native.load()
+    va, vb = native.Vocabulary(str(vd / "a.txt")), native.Vocabulary(str(vd / "b.txt"))
+    rd = ctypes.c_void_p(lib.recalgo_reader_open(path.encode(), 1))
+    assert lib.recalgo_reader_next_batch(rd, 16) == 5
+    keys = (ctypes.c_char_p * 2)(b"a", b"b")
+    vs = (ctypes.c_void_p * 2)(va.h, vb.h)
+    out, multi = np.full((5, 2), 99, np.int64), np.zeros(2, np.int32)
+    yv = np.zeros((5, 1), np.float32)
+    # float accessor BEFORE the id matrix: served by the direct scan (no index yet) ...
+    assert lib.recalgo_reader_float_feature(rd, b"y", 1, ctypes.c_float(-7.0), 1, yv.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert yv.reshape(-1).tolist() == [1.0, 0.0, 1.0, 0.0, -7.0]
+    assert lib.recalgo_reader_id_matrix(rd, 2, keys, vs, out.ctypes.data_as(ctypes.c_void_p), multi.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert out.tolist() == [[1, 0], [2, 1], [2, -1], [-1, -1], [0, 2]]
+    assert multi.tolist() == [1, 0]
+    # ... and after two more accessor calls by the index: same answers
+    for _ in range(3):
+        y2 = np.zeros((5, 1), np.float32)
+        assert lib.recalgo_reader_float_feature(rd, b"y", 1, ctypes.c_float(-7.0), 1, y2.ctypes.data_as(ctypes.c_void_p)) == 0
+        assert np.array_equal(y2, yv)
+    offs, vals = np.zeros(6, np.int64), np.zeros(8, np.int64)
+    nnz = lib.recalgo_reader_id_feature(rd, b"a", va.h, offs.ctypes.data_as(ctypes.c_void_p), vals.ctypes.data_as(ctypes.c_void_p), 8)
+    assert nnz == 5 and offs.tolist() == [0, 1, 2, 3, 3, 5] and vals[:5].tolist() == [1, 2, 2, 0, 1]
+    # a required float feature missing in a record is an error, not a silent zero
+    assert lib.recalgo_reader_float_feature(rd, b"y", 1, ctypes.c_float(0.0), 0, yv.ctypes.data_as(ctypes.c_void_p)) == -1
+    lib.recalgo_reader_close(rd)
