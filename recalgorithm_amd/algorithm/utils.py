@@ -80,7 +80,62 @@ class _Dataset:
             yield self.parser(batch)
 
 
+class _Prefetch:
+    """dataset.prefetch(n) (utils.py:24,43): a background thread runs the upstream pipeline up to n batches ahead of the
+    consumer, so decoding batch i+1 overlaps the host side of step i (packing, the host-to-device copy, the launches; the
+    native decoder releases the GIL, and the device runs asynchronously anyway).  RECALGO_PREFETCH=0 iterates inline.
+    Still an iterable of batches: type checks on the dataset itself look at `.upstream`."""
+    _END = object()
+
+    def __init__(self, upstream, n: int = 1):
+        self.upstream, self.n = upstream, max(int(n), 1)
+
+    def __iter__(self):
+        import os
+        import queue
+        import threading
+        if os.environ.get("RECALGO_PREFETCH", "1") == "0":
+            yield from self.upstream
+            return
+        q: "queue.Queue" = queue.Queue(maxsize=self.n)
+        stop = threading.Event()
+
+        def put(item) -> bool:
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
+        def work():
+            try:
+                for item in self.upstream:
+                    if not put(item):
+                        return
+                put(self._END)
+            except BaseException as e:  # noqa: BLE001   (delivered to the consumer, which re-raises it)
+                put(e)
+        t = threading.Thread(target=work, name="recalgo-prefetch", daemon=True)
+        t.start()
+        try:
+            while True:
+                item = q.get()
+                if item is self._END:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            stop.set()                   # a consumer that stops early (steps=..., an error) releases the producer
+
+
 def _dataset(filepath, example_parser, batch_size, num_epochs, shuffle_buffer_size):
+    return _Prefetch(_dataset_inline(filepath, example_parser, batch_size, num_epochs, shuffle_buffer_size), 1)
+
+
+def _dataset_inline(filepath, example_parser, batch_size, num_epochs, shuffle_buffer_size):
     """The native (C++) reader/decoder serves parsers that declare their feature columns
     (`example_parser.columns_getter`, set by the model scripts) over a single file; anything else —
     an arbitrary parser callable, a list of files — takes the pure-Python path.  Both yield the same

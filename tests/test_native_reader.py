@@ -91,7 +91,7 @@ def _encoded(cols, feats):
 def test_native_batches_equal_python_batches(tmp_path, seq_example):
     spec, path, cols, labels, parser = _dataset(tmp_path, seq_example=seq_example)
     nat = eval_input_fn(path, parser, 64)
-    assert isinstance(nat, native.NativeDataset)
+    assert isinstance(nat.upstream, native.NativeDataset)          # (behind the prefetch stage)
     py = _Dataset(path, parser, 64, 1, 0)
     nb, pb = list(nat), list(py)
     assert [b[1]["read_comment"].shape[0] for b in nb] == [64, 64, 64, 64, 44] == [b[1]["read_comment"].shape[0] for b in pb]

@@ -138,3 +138,37 @@ def test_input_fns_batching_epochs_and_shuffle(tmp_path, monkeypatch):
         got = col.ids({nm: f0[nm]}, torch.device("cpu"))
         assert got.tolist() == ids[:, j].tolist()
     assert l0["read_comment"].flatten().tolist() == labels[:, 0].tolist()
+
+
+def test_prefetch_stage_order_errors_and_early_stop(monkeypatch):
+    """dataset.prefetch(1) (utils.py:24): same batches in the same order, upstream errors reach the consumer, a consumer
+    that stops early does not leave the producer blocked, RECALGO_PREFETCH=0 iterates inline."""
+    import threading
+    import time
+    from recalgorithm_amd.algorithm.utils import _Prefetch
+    assert list(_Prefetch(range(50), 1)) == list(range(50))
+    assert list(_Prefetch([], 1)) == []
+
+    def broken():
+        yield 1
+        raise ValueError("decode failed")
+    it = iter(_Prefetch(broken(), 1))
+    assert next(it) == 1
+    with pytest.raises(ValueError, match="decode failed"):
+        next(it)
+    produced = []
+
+    def slow():
+        for i in range(1000):
+            produced.append(i)
+            yield i
+    g = iter(_Prefetch(slow(), 1))
+    assert [next(g), next(g)] == [0, 1]
+    g.close()                                         # consumer gives up
+    time.sleep(0.3)
+    n = len(produced)
+    time.sleep(0.2)
+    assert len(produced) == n and n <= 5              # the producer stopped, at most the prefetch depth ahead
+    assert not [t for t in threading.enumerate() if t.name == "recalgo-prefetch" and t.is_alive()]
+    monkeypatch.setenv("RECALGO_PREFETCH", "0")
+    assert list(_Prefetch(range(5), 1)) == [0, 1, 2, 3, 4]
