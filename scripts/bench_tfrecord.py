@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""End-to-end rate of the reference's own entry path: TFRecord file of tf.train.Example protos with STRING keys +
+vocabulary files -> train_input_fn (native reader, prefetch(1)) -> Estimator.train (hipGraph replay) -> loss.
+BASELINE.json configs[0]'s plumbing at the throughput batch size: what `python dcn.py --train_data=...` gets, as
+opposed to bench.py's device-resident batches.
+
+    python scripts/bench_tfrecord.py [--examples 65536] [--epochs 4] [--batch 4096]      # one JSON line
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--examples", type=int, default=65536)
+    ap.add_argument("--epochs", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--fields", type=int, default=26)
+    ap.add_argument("--max-vocab", type=int, default=1_000_000)
+    a = ap.parse_args()
+    from recalgorithm_amd import feature_column as fc
+    from recalgorithm_amd.algorithm.DCN.dcn import dcn_model_fn
+    from recalgorithm_amd.algorithm.utils import eval_input_fn, parse_example, train_input_fn
+    from recalgorithm_amd.estimator import Estimator, RunConfig
+    from recalgorithm_amd.io import synth
+    d = tempfile.mkdtemp(prefix="recalgo_tfrecord_")
+    spec = synth.SynthSpec(n_fields=a.fields, max_vocab=a.max_vocab, seed=9)
+    vd, path = d + "/vocabulary/", d + "/train.tfrecord"
+    t0 = time.perf_counter()
+    synth.write_vocabularies(spec, vd)
+    synth.write_tfrecord(spec, path, a.examples)
+    t_write = time.perf_counter() - t0
+    cats = [fc.categorical_column_with_vocabulary_file(n, vd + n + ".txt") for n in spec.names]
+    cols = [fc.embedding_column(c, 16) for c in cats]
+    labels = [fc.numeric_column("read_comment", default_value=0.0)]
+
+    def parser(serialized):
+        f = parse_example(serialized, fc.make_parse_example_spec(cols + labels))
+        y = f.pop("read_comment")
+        return f, {"read_comment": y}
+    parser.columns_getter = lambda: (cols, labels)
+    params = {"category_feature_columns": cols, "dense_feature_columns": [], "hidden_units": ["512", "256", "128"],
+              "num_cross_layer": 3, "learning_rate": 0.005}
+    # reader alone (decode + vocabulary lookup, no device work)
+    list(eval_input_fn(path, parser, a.batch))                                          # page cache + vocabularies warm
+    t0 = time.perf_counter()
+    n = sum(l["read_comment"].shape[0] for _, l in eval_input_fn(path, parser, a.batch))
+    reader_rate = n / (time.perf_counter() - t0)
+    est = Estimator(dcn_model_fn, params, RunConfig(device="cuda", seed=3))
+    est.train(lambda: train_input_fn(path, parser, a.batch, 1, 0), log_every=0)           # warm-up epoch: build, capture
+    torch.cuda.synchronize()
+    s0 = est.global_step
+    t0 = time.perf_counter()
+    est.train(lambda: train_input_fn(path, parser, a.batch, a.epochs, 10000), log_every=0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    steps = est.global_step - s0
+    print(json.dumps({
+        "metric": "CTR examples/sec from TFRecord bytes (string keys) to the training step, DCN, batch %d" % a.batch,
+        "value": round(a.examples * a.epochs / dt, 1), "unit": "examples/s", "steps": steps,
+        "ms_per_step": round(dt / max(steps, 1) * 1e3, 3), "reader_only_examples_per_s": round(reader_rate, 1),
+        "host_threads": os.cpu_count(), "examples": a.examples, "epochs": a.epochs, "shuffle_buffer": 10000,
+        "synthetic_write_seconds": round(t_write, 1),
+        "note": "host-bound: the GPU step of this model takes ~0.24 ms (bench.py); the rate is the decoder's"}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
