@@ -323,13 +323,47 @@ class Estimator:
         self.grad_hook = None     # set by parallel wrappers (dense-grad all-reduce)
         self.loss_grad_scale = None   # 1/world under data parallelism (parallel.attach_data_parallel)
         self._seed_grad, self._seed_value = None, None
+        self._pinned = {}                # (shape, dtype) -> ring of pinned staging buffers (_h2d)
 
     # -- plumbing -------------------------------------------------------------------------
+    _STAGING_RING = 8
+
+    def _h2d(self, fill, shape, dtype) -> torch.Tensor:
+        """Host -> device through a small ring of PERSISTENT pinned staging buffers (one ring per dtype, buffers grow to
+        the largest batch seen): `fill(view)` writes the batch into a view of a pinned buffer, the copy to the device is
+        asynchronous.  (tensor.pin_memory() per batch allocates and frees page-locked memory every step — on this stack
+        milliseconds per call, an order of magnitude more than the step; a pageable source makes the copy synchronous.)
+        A buffer is reused only after the copy that read it last has completed (its event)."""
+        shape = tuple(int(d) for d in shape)
+        numel = 1
+        for d in shape:
+            numel *= d
+        ring = self._pinned.get(dtype)
+        if ring is None:
+            ring = self._pinned[dtype] = {"bufs": [None] * self._STAGING_RING, "events": [None] * self._STAGING_RING, "i": 0}
+        i = ring["i"]
+        ring["i"] = (i + 1) % self._STAGING_RING
+        if ring["events"][i] is not None:
+            ring["events"][i].synchronize()
+        buf = ring["bufs"][i]
+        if buf is None or buf.numel() < numel:
+            cap = 1 << max(int(numel - 1).bit_length(), 10)
+            buf = ring["bufs"][i] = torch.empty(cap, dtype=dtype, pin_memory=True)
+        view = buf[:numel].view(shape)
+        fill(view)
+        dev = view.to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        ring["events"][i] = ev
+        return dev
+
     def _to_device(self, features, labels):
         from .feature_column import Ragged
 
         def mv(x):
             if isinstance(x, torch.Tensor):
+                if x.device.type == "cpu" and self.device.type == "cuda" and x.numel() and not x.is_pinned():
+                    return self._h2d(lambda buf: buf.copy_(x), x.shape, x.dtype)
                 return x.to(self.device, non_blocking=True)
             if isinstance(x, Ragged):
                 return Ragged(mv(x.values), mv(x.offsets))
@@ -365,11 +399,16 @@ class Estimator:
             keys = [k for k in keys if features[k].shape[0] == features[keys[0]].shape[0]]
             if len(keys) < 2:
                 continue
-            if kind == "ids":
-                host = torch.stack([features[k] for k in keys], dim=1)                 # [B, F]
+            cols_ = [features[k] for k in keys]
+            B_ = cols_[0].shape[0]
+            if self.device.type == "cuda":
+                if kind == "ids":                                                          # [B, F]
+                    dev = self._h2d(lambda buf: torch.stack(cols_, dim=1, out=buf), (B_, len(cols_)), torch.int64)
+                else:                                                                      # [B, n]
+                    dev = self._h2d(lambda buf: torch.cat(cols_, dim=1, out=buf), (B_, len(cols_)), torch.float32)
             else:
-                host = torch.cat([features[k] for k in keys], dim=1)                   # [B, n]
-            dev = host.pin_memory().to(self.device, non_blocking=True) if self.device.type == "cuda" else host.to(self.device)
+                host = torch.stack(cols_, dim=1) if kind == "ids" else torch.cat(cols_, dim=1)
+                dev = host.to(self.device)
             for j, k in enumerate(keys):
                 out[k] = dev[:, j] if kind == "ids" else dev[:, j:j + 1]
         return out
