@@ -111,10 +111,16 @@ def main(unused_argv):
                                         batch_size=FLAGS.batch_size, num_epochs=FLAGS.num_epochs,
                                         shuffle_buffer_size=FLAGS.shuffle_buffer_size),
         max_steps=FLAGS.train_steps)
+    # deepfm.py: feature_spec / build_parsing_serving_input_receiver_fn / BestExporter(exports_to_keep=5)
+    from ...export import BestExporter, build_parsing_serving_input_receiver_fn
+    feature_spec = fc.make_parse_example_spec(total_feature_columns)
+    exporters = [BestExporter(name="best_exporter",
+                              serving_input_receiver_fn=build_parsing_serving_input_receiver_fn(feature_spec),
+                              exports_to_keep=5)]
     eval_spec = EvalSpec(
         input_fn=lambda: eval_input_fn(filepath=FLAGS.eval_data, example_parser=example_parser,
                                        batch_size=FLAGS.batch_size),
-        throttle_secs=600, steps=None)
+        throttle_secs=600, steps=None, exporters=exporters)
     train_and_evaluate(estimator, train_spec, eval_spec)
     metrics = estimator.evaluate(input_fn=lambda: eval_input_fn(
         filepath=FLAGS.eval_data, example_parser=example_parser, batch_size=FLAGS.batch_size))
