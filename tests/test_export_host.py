@@ -66,3 +66,26 @@ def test_parsing_receiver_and_spec_round_trip(tmp_path):
     f = E.build_parsing_serving_input_receiver_fn(back)(recs)
     assert f["userid"] == [[b"userid_1"], [b"nobody"]]
     assert f["videoplayseconds"].tolist() == [[2.5], [0.0]]
+
+
+def test_train_and_evaluate_runs_the_eval_specs_exporters(tmp_path):
+    """tf.estimator.train_and_evaluate hands the evaluation result to EvalSpec.exporters (deepfm.py:309-321):
+    <model_dir>/export/<exporter name>/<timestamp>/."""
+    from recalgorithm_amd.estimator import EvalSpec, TrainSpec, train_and_evaluate
+    calls = []
+    est = _stub(7, 7.0)
+    est.config = types.SimpleNamespace(model_dir=str(tmp_path / "model_dir"))
+    est._ckpt_path = lambda: os.path.join(est.config.model_dir, "model.ckpt.pt")
+    est.train = lambda input_fn, max_steps=None: calls.append(("train", max_steps))
+    est.evaluate = lambda input_fn, steps=None: {"loss": 0.25, "eval_auc": 0.7, "global_step": 7}
+    recv = E.build_parsing_serving_input_receiver_fn(_spec(tmp_path))
+    ex = E.BestExporter(name="best_exporter", serving_input_receiver_fn=recv, exports_to_keep=5)
+    out = train_and_evaluate(est, TrainSpec(lambda: iter(()), max_steps=100), EvalSpec(lambda: iter(()), exporters=[ex]))
+    assert out["loss"] == 0.25 and calls == [("train", 100)]
+    base = os.path.join(est.config.model_dir, "export", "best_exporter")
+    exports = E.list_exports(base)
+    assert len(exports) == 1 and json.load(open(os.path.join(exports[0], "serving.json")))["eval_result"]["eval_auc"] == 0.7
+    # a single exporter (not a list) is accepted like tf does; no exporters -> nothing written
+    train_and_evaluate(est, TrainSpec(lambda: iter(())), EvalSpec(lambda: iter(()), exporters=ex))     # same loss: not better
+    assert len(E.list_exports(base)) == 1
+    train_and_evaluate(est, TrainSpec(lambda: iter(())), EvalSpec(lambda: iter(())))
