@@ -39,7 +39,8 @@ def run(model: str, batch=4096, fields=26, emb=16, max_vocab=1_000_000, seconds=
 
     # xDeepFM's reference graph materialises the (B, D, Hk*m) outer product (872 MB at B=4096):
     # the CPU sample uses a quarter batch to stay inside a bounded memory / time budget
-    cpu_batch = min(batch, 1024) if model == "xdeepfm" else batch
+    # (AFM: the pair tensor + attention net over B x 325 rows; FFM: the oracle walks bags in Python — bounded samples)
+    cpu_batch = {"xdeepfm": min(batch, 1024), "afm": min(batch, 512), "ffm": min(batch, 64)}.get(model, batch)
     args = bench.parse_args(["--model", model, "--batch", str(cpu_batch), "--fields", str(fields), "--emb", str(emb),
                              "--max-vocab", str(max_vocab)])
     est, spec, feats, labels, workload = bench.build_estimator(args, torch.device("cpu"))
@@ -51,10 +52,16 @@ def run(model: str, batch=4096, fields=26, emb=16, max_vocab=1_000_000, seconds=
     rows = int(sum(a.weight.shape[0] for a in est.store.arenas.values()))
     lr = float(est.params["learning_rate"])
 
+    extra = {}
+    if model == "nfm":          # its hard-coded dropout (nfm.py:170): a fixed keep mask stands in for TF's random stream
+        gen = torch.Generator().manual_seed(1)
+        K = int(est.params["category_feature_columns"][0].dimension)
+        extra["dropout_masks"] = [(torch.rand(cpu_batch, K, generator=gen) < 0.9).float()]
+
     def step(t):
         for p in P.values():
             p.grad = None
-        out = fn(P, cf, labels, est.params, training=True)
+        out = fn(P, cf, labels, est.params, training=True, **extra)
         out["loss"].backward()
         with torch.no_grad():
             for k, p in P.items():
