@@ -35,12 +35,14 @@ constexpr int kQC = 32;           // q rows of F staged per slab
 // generalised contraction
 // ---------------------------------------------------------------------------------------------
 template <int D, int NT>
-__global__ __launch_bounds__(kThreads) void cin_contract_kernel(
+__global__ __launch_bounds__(kThreads, 3) void cin_contract_kernel(
     const float* __restrict__ P, const float* __restrict__ Q, const float* __restrict__ F,
     unsigned B, unsigned HP, unsigned HQ, unsigned C, float* __restrict__ out, int accumulate,
     float* __restrict__ pool, unsigned pool_stride, unsigned pool_col) {
     constexpr unsigned EX = kTM / D;           // examples per workgroup
     constexpr unsigned CS = NT * 32;           // LDS row stride of an F slab (cols zero padded)
+    const unsigned c0 = blockIdx.y * CS;       // first output column of this workgroup (column chunks of NT tiles)
+    const unsigned Cl = min(CS, C - c0);       // columns of this chunk
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const unsigned HQp = (HQ + 1) & ~1u;
     const unsigned QS = HQp * D + 16;          // +16: the two examples of a 32-lane group hit disjoint banks
@@ -73,22 +75,23 @@ __global__ __launch_bounds__(kThreads) void cin_contract_kernel(
     auto slab_rows = [&](unsigned s) { unsigned qc = s % nqc; return min((unsigned)kQC, HQ - qc * kQC); };
     auto slab_src = [&](unsigned s) { unsigned p = s / nqc, qc = s % nqc; return F + ((size_t)p * HQ + (size_t)qc * kQC) * C; };
     auto stage_load = [&](unsigned s) {
-        const float* src = slab_src(s);
-        const unsigned n = slab_rows(s) * C;
+        const float* src = slab_src(s) + c0;
+        const unsigned n = slab_rows(s) * Cl;
 #pragma unroll
         for (unsigned k = 0; k < kStg; ++k) {
             unsigned e = tid + k * kThreads;
-            stg[k] = e < n ? src[e] : 0.f;
+            unsigned q = e / Cl, c = e - q * Cl;
+            stg[k] = e < n ? src[(size_t)q * C + c] : 0.f;
         }
     };
     auto stage_store = [&](unsigned s, unsigned buf) {
-        const unsigned n = slab_rows(s) * C;
+        const unsigned n = slab_rows(s) * Cl;
         float* dst = Fs + buf * kQC * CS;
 #pragma unroll
         for (unsigned k = 0; k < kStg; ++k) {
             unsigned e = tid + k * kThreads;
             if (e < n) {
-                unsigned q = e / C, c = e - q * C;
+                unsigned q = e / Cl, c = e - q * Cl;
                 dst[q * CS + c] = stg[k];
             }
         }
@@ -97,11 +100,21 @@ __global__ __launch_bounds__(kThreads) void cin_contract_kernel(
     stage_store(0, 0);
     __syncthreads();
 
-    f32x16 acc[NT];
+    // Two-level accumulation.  The reduction over (p, q) is HP * HQ terms long (3328 for the second layer of the
+    // BASELINE configuration); one MFMA chain per output adds them strictly in order, i.e. with the rounding error of a
+    // 3328-term sequential fp32 sum — 2-4 x more elements outside 1e-5 relative than the blocked GEMM of the reference's
+    // CPU path leaves (profiles/r02z_strict_parity_all_gpu_tests.md).  The chain is cut every `flush_every` slabs
+    // (~ 56 terms): the chunk sum goes to `tot` and a new chain starts from zero — error ~ sqrt(chunk) + sqrt(n / chunk)
+    // instead of sqrt(n).  (`tot` doubles the accumulator registers: a workgroup covers NT <= 2 column tiles, wider
+    // layers are column chunks over blockIdx.y.)
+    f32x16 acc[NT], tot[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[nt][r] = tot[nt][r] = 0.f;
+    const unsigned rows_per_slab = min(HQ, (unsigned)kQC);
+    const unsigned flush_every = max(1u, (56u + rows_per_slab / 2) / rows_per_slab);
+    unsigned since_flush = 0;
 
     const float* Pp = P + ((size_t)b * HP) * D + dd;       // P[b, p, dd] at stride D
     float a_p = valid ? Pp[0] : 0.f;
@@ -129,15 +142,27 @@ __global__ __launch_bounds__(kThreads) void cin_contract_kernel(
             // the other buffer was last read in iteration s-1, i.e. before the previous barrier
             stage_store(s + 1, buf ^ 1);
         }
+        if (++since_flush == flush_every || !more) {       // uniform over the workgroup
+            since_flush = 0;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    tot[nt][r] += acc[nt][r];
+                    acc[nt][r] = 0.f;
+                }
+        }
         a_p = a_next;
         __syncthreads();
     }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = tot[nt];
 
     // ---- epilogue: out[b, c, d] (float4 of 4 consecutive d) and the sum-pooling over d --------
     const unsigned R0 = blockIdx.x * kTM + wave * 32;      // first (b,d) row of this wave's tile
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const unsigned c = nt * 32 + l32;
+        const unsigned c = c0 + nt * 32 + l32;
         const bool cok = c < C;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -337,7 +362,7 @@ constexpr int kRC = 64;        // reduction rows (b,d) staged per chunk
 constexpr int kPW = 34;        // >= distinct p values touched by the 128 kk rows of a workgroup (m >= 4)
 
 template <int D, int NT, int QI>
-__global__ __launch_bounds__(kThreads) void cin_filter_grad_kernel(
+__global__ __launch_bounds__(kThreads, 2) void cin_filter_grad_kernel(
     const float* __restrict__ P, const float* __restrict__ Q, const float* __restrict__ G, unsigned B,
     unsigned HP, unsigned HQ, unsigned C, unsigned ex_per_split, float* __restrict__ partials) {
     constexpr unsigned EXC = kRC / D;            // examples per chunk
@@ -351,6 +376,8 @@ __global__ __launch_bounds__(kThreads) void cin_filter_grad_kernel(
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned hi = lane >> 5, l32 = lane & 31;
     const unsigned Kdim = HP * HQ;
+    const unsigned c0 = blockIdx.z * NT * 32;               // column chunk of this workgroup
+    const unsigned Cl = min((unsigned)NT * 32, C - c0);
     const unsigned kk0 = blockIdx.x * 128;                  // first kk row of the workgroup
     const unsigned kk = kk0 + wave * 32 + l32;              // this lane's A' row
     const bool kok = kk < Kdim;
@@ -359,11 +386,13 @@ __global__ __launch_bounds__(kThreads) void cin_filter_grad_kernel(
     const unsigned pp_lane = p_lane - p_first;              // column in Ps
     unsigned p_cnt = min(HP, (min(kk0 + 128, Kdim) - 1) / HQ + 1) - p_first;   // p values staged
 
-    f32x16 acc[NT];
+    // two-level accumulation (see cin_contract_kernel): one chain per staged chunk of kRC reduction rows, the chunk sums
+    // added to `tot` — a split otherwise adds B * D / splits (3456 at the BASELINE shape) terms in one chain
+    f32x16 acc[NT], tot[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[nt][r] = tot[nt][r] = 0.f;
 
     const unsigned ex_begin = blockIdx.y * ex_per_split;
     const unsigned ex_end = min(B, ex_begin + ex_per_split);
@@ -374,15 +403,17 @@ __global__ __launch_bounds__(kThreads) void cin_filter_grad_kernel(
     constexpr unsigned GI4 = GI / 4;
     float4 gst[GI4], qst[QI];
     float pst[PI];
-    const unsigned nG4 = EXC * C * D / 4, nQ4 = EXC * HQ * D / 4, nP = EXC * p_cnt * D;
+    const unsigned per_ex4 = Cl * D / 4;                     // float4s of one example's column chunk (contiguous)
+    const unsigned nG4 = EXC * per_ex4, nQ4 = EXC * HQ * D / 4, nP = EXC * p_cnt * D;
     auto prefetch = [&](unsigned e0) {
         const unsigned nex = min(EXC, ex_end - e0);
-        const float4* gsrc = reinterpret_cast<const float4*>(G + (size_t)e0 * C * D);
+        const float4* gsrc = reinterpret_cast<const float4*>(G + ((size_t)e0 * C + c0) * D);
         const float4* qsrc = reinterpret_cast<const float4*>(Q + (size_t)e0 * HQ * D);
 #pragma unroll
         for (unsigned k = 0; k < GI4; ++k) {
             const unsigned e = tid + k * kThreads;
-            gst[k] = e < nex * C * D / 4 ? gsrc[e] : f4_zero();
+            const unsigned ex = e / per_ex4, rem = e - ex * per_ex4;
+            gst[k] = ex < nex ? gsrc[(size_t)ex * (C * D / 4) + rem] : f4_zero();
         }
 #pragma unroll
         for (unsigned k = 0; k < QI; ++k) {
@@ -401,7 +432,7 @@ __global__ __launch_bounds__(kThreads) void cin_filter_grad_kernel(
         for (unsigned k = 0; k < GI4; ++k) {
             const unsigned e4 = tid + k * kThreads;
             if (e4 < nG4) {
-                const unsigned e = e4 * 4, d = e % D, t = e / D, c = t % C, ex = t / C;
+                const unsigned e = e4 * 4, d = e % D, t = e / D, c = t % Cl, ex = t / Cl;
                 float* dst = Gs + (ex * D + d) * GS + c;
                 dst[0] = gst[k].x; dst[GS] = gst[k].y; dst[2 * GS] = gst[k].z; dst[3 * GS] = gst[k].w;
             }
@@ -442,12 +473,21 @@ __global__ __launch_bounds__(kThreads) void cin_filter_grad_kernel(
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf, acc[nt], 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                tot[nt][r] += acc[nt][r];
+                acc[nt][r] = 0.f;
+            }
     }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = tot[nt];
     // ---- write the partial tile: rows kk0 + wave*32 + (r&3) + 8*(r>>2) + 4*hi, col nt*32 + l32 ----
     float* pout = partials + (size_t)blockIdx.y * Kdim * C;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const unsigned c = nt * 32 + l32;
+        const unsigned c = c0 + nt * 32 + l32;
         if (c >= C) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -484,8 +524,8 @@ int launch_contract_DN(const float* P, const float* Q, const float* F, int B, in
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    int grid = cdiv((int64_t)B * D, kTM);
-    hipLaunchKernelGGL((cin_contract_kernel<D, NT>), dim3(grid), dim3(kThreads), smem, st, P, Q, F, (unsigned)B,
+    dim3 grid(cdiv((int64_t)B * D, kTM), cdiv(C, NT * 32));
+    hipLaunchKernelGGL((cin_contract_kernel<D, NT>), grid, dim3(kThreads), smem, st, P, Q, F, (unsigned)B,
                        (unsigned)HP, (unsigned)HQ, (unsigned)C, out, accumulate, pool, (unsigned)pool_stride,
                        (unsigned)pool_col);
     return (int)hipGetLastError();
@@ -494,13 +534,8 @@ int launch_contract_DN(const float* P, const float* Q, const float* F, int B, in
 template <int D>
 int launch_contract_D(int NT, const float* P, const float* Q, const float* F, int B, int HP, int HQ, int C,
                       float* out, int accumulate, float* pool, int pool_stride, int pool_col, hipStream_t st) {
-    switch (NT) {
-        case 1: return launch_contract_DN<D, 1>(P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);
-        case 2: return launch_contract_DN<D, 2>(P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);
-        case 3: return launch_contract_DN<D, 3>(P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);
-        case 4: return launch_contract_DN<D, 4>(P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);
-        default: return (int)hipErrorInvalidValue;
-    }
+    if (NT == 1) return launch_contract_DN<D, 1>(P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);
+    return launch_contract_DN<D, 2>(P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);
 }
 
 // out[b, c0:c0+C', d] for C' <= 128 per launch (column chunks of the filter are strided views, so
@@ -554,8 +589,8 @@ int launch_input_grad(const float* x0, const float* xk, const float* W, const fl
     }
 }
 
-inline int filter_grad_splits(int B, int D, int Kdim) {
-    int row_blocks = cdiv(Kdim, 128);
+inline int filter_grad_splits(int B, int D, int Kdim, int C) {
+    int row_blocks = cdiv(Kdim, 128) * cdiv(C, 64);         // x column chunks of <= 2 tiles
     int want = 512 / row_blocks;                            // <= 2 workgroups per CU (VGPR-bound occupancy): no tail round
     int exc = kRC / D;
     int max_s = cdiv(B, exc);
@@ -575,7 +610,7 @@ int launch_filter_grad_DNQ(const float* P, const float* Q, const float* G, int B
     }
     const int exc = kRC / D;
     int ex_per_split = cdiv(cdiv(B, S), exc) * exc;
-    dim3 grid(cdiv(HP * HQ, 128), S);
+    dim3 grid(cdiv(HP * HQ, 128), S, cdiv(C, NT * 32));
     hipLaunchKernelGGL((cin_filter_grad_kernel<D, NT, QI>), grid, dim3(kThreads), smem, st, P, Q, G, (unsigned)B,
                        (unsigned)HP, (unsigned)HQ, (unsigned)C, (unsigned)ex_per_split, partials);
     return (int)hipGetLastError();
@@ -592,13 +627,8 @@ int launch_filter_grad_DN(const float* P, const float* Q, const float* G, int B,
 template <int D>
 int launch_filter_grad_D(int NT, const float* P, const float* Q, const float* G, int B, int HP, int HQ, int C, int S,
                          float* partials, hipStream_t st) {
-    switch (NT) {
-        case 1: return launch_filter_grad_DN<D, 1>(P, Q, G, B, HP, HQ, C, S, partials, st);
-        case 2: return launch_filter_grad_DN<D, 2>(P, Q, G, B, HP, HQ, C, S, partials, st);
-        case 3: return launch_filter_grad_DN<D, 3>(P, Q, G, B, HP, HQ, C, S, partials, st);
-        case 4: return launch_filter_grad_DN<D, 4>(P, Q, G, B, HP, HQ, C, S, partials, st);
-        default: return (int)hipErrorInvalidValue;
-    }
+    if (NT == 1) return launch_filter_grad_DN<D, 1>(P, Q, G, B, HP, HQ, C, S, partials, st);
+    return launch_filter_grad_DN<D, 2>(P, Q, G, B, HP, HQ, C, S, partials, st);
 }
 
 struct BwdWs {
@@ -613,7 +643,7 @@ inline BwdWs bwd_ws(int B, int m, int Hk, int N, int D) {
     w.wp = off;   off += al(kdim * N * sizeof(float));
     w.wpp = off;  off += al(kdim * N * sizeof(float));
     w.partials = off;
-    off += al((size_t)filter_grad_splits(B, D, (int)kdim) * kdim * N * sizeof(float));
+    off += al((size_t)filter_grad_splits(B, D, (int)kdim, N) * kdim * N * sizeof(float));
     w.total = off;
     return w;
 }
@@ -684,7 +714,7 @@ RECALGO_EXPORT int recalgo_cin_layer_bwd(const float* x0, const float* xk, const
         if (rc) return rc;
     }
     // dW
-    const int S = filter_grad_splits(B, D, Hk * m);
+    const int S = filter_grad_splits(B, D, Hk * m, N);
     const int NT = cdiv(N, 32);
     switch (D) {
         case 4: rc = launch_filter_grad_D<4>(NT, xk, x0, G, B, Hk, m, N, S, partials, st); break;
