@@ -567,6 +567,82 @@ int recalgo_activation_bwd(const float* x, const float* alpha, const float* gy, 
                            int kind, float* dx, float* dalpha, void* workspace,
                            recalgo_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * a15 / a16 / f1  Row-gradient scatter without float atomics, fused with the sparse optimizer.
+ * Replaces, for every embedding variable, TF autodiff's IndexedSlices gradient of the lookup plus
+ * tf.train.AdamOptimizer(...).minimize (algorithm/DeepFM/deepfm.py:246-250, same in all six hot-path models;
+ * dense semantics on embedding variables: SURVEY.md A-10) or tf.contrib.opt.LazyAdamOptimizer
+ * (algorithm/DIEN/dien.py:328).
+ *
+ * A `source` is one lookup's request list and (for `apply`) its per-request gradient rows:
+ *   dense id matrix   ids [n_ex, F] int64 (< 0: no row), offsets = NULL:
+ *                     request (e, f) -> arena row  ids[e, f] + base + (row_base ? row_base[f] : 0)
+ *   ragged sequences  ids = values [nnz], offsets [n_ex + 1]: request (e, f), f < min(len_e, F) ->
+ *                     values[offsets[e] + f] + base                                  (din.py:207-214, F = T)
+ *   gradient row of request (e, f): K floats at  g + e * g_stride + g_col + f * g_fmul
+ *                     (g_fmul = K for a [n_ex, F * K] matrix, 0 when all fields of an example share one row).
+ * All requests of a step that address one arena form a PLAN (<= RECALGO_SCATTER_MAX_SOURCES sources, < 2^31
+ * requests, arena rows < 2^31):
+ *   recalgo_scatter_prepare  once per source, any time before `apply` (normally right before the lookup's forward
+ *                            kernel): adds the source's requests to the plan's bucket counts, and — with `deferred` —
+ *                            first brings every requested row's (w, m, v) up to step  step_dev[0] + step_offset.
+ *                            plan_workspace may be NULL (catch-up only).
+ *   recalgo_scatter_apply    once per plan, with the SAME sources in the SAME order (their g now set): two launches.
+ *                            Requests are grouped by row (hash buckets, sorted inside a bucket by (row, request
+ *                            index)); the owner of a row adds its gradient rows in request order — no atomics,
+ *                            bit-reproducible — and finishes, by `mode`:
+ *     RECALGO_SCATTER_GRAD       grad[row, :] += sum            (+ `live`: the row joins the live-row list)
+ *     RECALGO_SCATTER_ADAM       TF1 Adam with dense semantics, evaluated lazily but EXACTLY: (w, m, v)[row] first
+ *                                replay the g = 0 updates of the steps since last_step[row], then take this step's
+ *                                update with lr_t(t), t = step_dev[0] + step_offset; last_step[row] = t.  The same
+ *                                call sweeps rows [c*ceil(rows/P), ...), c = (t-1) % P, P = sweep_period, up to
+ *                                step t - 1, so that no row lags more than P + 1 steps, and records lr_t(t) in
+ *                                deferred->lr_ring.  Bit-identical to recalgo_adam_tf1_dense over the whole arena
+ *                                once recalgo_adam_deferred_sweep has flushed it.
+ *     RECALGO_SCATTER_LAZY_ADAM  LazyAdamOptimizer: exactly the rows of this step's requests take the Adam update
+ *                                (whole rows, also rows whose summed gradient is 0); all other rows keep w, m, v.
+ *                            In the ADAM modes a non-NULL `grad` gets the touched rows zeroed (a gradient arena
+ *                            that an earlier GRAD call of the same plan filled).  The plan workspace comes back
+ *                            cleared for the next step.
+ *   recalgo_adam_deferred_sweep  rows [row_begin, row_end) brought to step_dev[0] + step_offset: the flush before
+ *                            EVAL / PREDICT / checkpoint / export, and after the last training step.
+ * The workspace (recalgo_scatter_plan_workspace_bytes(plan_requests, nb_log2), nb_log2 =
+ * recalgo_scatter_plan_buckets_log2(plan_requests)) must be zero-filled once before its first use.
+ * ------------------------------------------------------------------------------------------ */
+#define RECALGO_SCATTER_MAX_SOURCES 4
+#define RECALGO_LR_RING 1024
+#define RECALGO_SCATTER_GRAD 0
+#define RECALGO_SCATTER_ADAM 1
+#define RECALGO_SCATTER_LAZY_ADAM 2
+typedef struct {
+    const int64_t* ids;
+    const int64_t* offsets;
+    const int64_t* row_base;
+    int64_t base;
+    int n_ex, F;
+    const float* g;
+    int64_t g_stride;
+    int g_col, g_fmul;
+} recalgo_scatter_source_t;
+typedef struct {
+    float* w; float* m; float* v;   /* [rows, K] */
+    int* last_step;                 /* [rows] int32: 0 = never touched, s > 0 = state valid for optimizer step s */
+    float* lr_ring;                 /* [RECALGO_LR_RING] fp32: lr_t(j) at j % RECALGO_LR_RING */
+    float beta1, beta2, eps;
+} recalgo_deferred_adam_t;
+int recalgo_scatter_plan_buckets_log2(int64_t n_requests);
+int64_t recalgo_scatter_plan_workspace_bytes(int64_t n_requests, int nb_log2);
+int recalgo_scatter_prepare(const recalgo_scatter_source_t* source, int K, void* plan_workspace, int64_t plan_requests,
+                            int nb_log2, const recalgo_deferred_adam_t* deferred, const int64_t* step_dev,
+                            int step_offset, recalgo_stream_t stream);
+int recalgo_scatter_apply(const recalgo_scatter_source_t* sources, int n_sources, int K, void* plan_workspace,
+                          int64_t plan_requests, int nb_log2, int mode, float* w, float* m, float* v, float* grad,
+                          const recalgo_deferred_adam_t* deferred, int64_t rows, int sweep_period,
+                          const recalgo_live_t* live, const int64_t* step_dev, int step_offset, float lr, float beta1,
+                          float beta2, float eps, recalgo_stream_t stream);
+int recalgo_adam_deferred_sweep(const recalgo_deferred_adam_t* deferred, int K, int64_t row_begin, int64_t row_end,
+                                const int64_t* step_dev, int step_offset, recalgo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

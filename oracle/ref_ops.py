@@ -375,6 +375,34 @@ def adam_tf1_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: flo
     p.sub_(lr_t * m / (v.sqrt() + eps))
 
 
+def lazy_adam_step(p: Tensor, indices: Tensor, values: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
+                   beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8) -> None:
+    """[TF-ext] tf.contrib.opt.LazyAdamOptimizer — the optimizer of algorithm/DIEN/dien.py:328 — applied to ONE
+    embedding variable's IndexedSlices gradient (indices [n] int64, values [n, K]), in place.  `step` is 1-based.
+
+    TF 1.14 (documented behaviour, restated):
+      * Optimizer._apply_sparse_duplicate_indices first de-duplicates the slices: unique indices, values of
+        duplicates summed (tf.unsorted_segment_sum) — so a row that appears several times in a batch takes ONE update
+        with the summed gradient;
+      * LazyAdamOptimizer._apply_sparse then touches only those rows:
+            m[i] = beta1 * m[i] + (1 - beta1) * g_i
+            v[i] = beta2 * v[i] + (1 - beta2) * g_i^2
+            var[i] -= lr_t * m[i] / (sqrt(v[i]) + eps),   lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
+        A row that is IN the slices with a summed gradient of exactly zero is still updated (its m, v decay and the
+        variable moves); every row NOT in the slices keeps var, m and v unchanged — the difference to
+        tf.train.AdamOptimizer (adam_tf1_step above), whose m, v decay for all rows."""
+    f32 = lambda x: float(torch.tensor(x, dtype=torch.float32))
+    lr, beta1, beta2, eps = f32(lr), f32(beta1), f32(beta2), f32(eps)
+    lr_t = lr * math.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step)
+    uniq, inv = torch.unique(indices, return_inverse=True)
+    g = torch.zeros(uniq.numel(), values.shape[1], dtype=values.dtype).index_add_(0, inv, values)
+    m_t = beta1 * m[uniq] + (1.0 - beta1) * g
+    v_t = beta2 * v[uniq] + (1.0 - beta2) * g * g
+    m[uniq] = m_t
+    v[uniq] = v_t
+    p[uniq] = p[uniq] - lr_t * m_t / (v_t.sqrt() + eps)
+
+
 # --------------------------------------------------------------------------- #
 # utils.py
 # --------------------------------------------------------------------------- #

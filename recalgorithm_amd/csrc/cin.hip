@@ -21,6 +21,8 @@
 // Fragment maps of v_mfma_f32_32x32x2_f32 (guides: cdna_hip_programming.md §3): lane l supplies
 // A[row = l&31][k = l>>5] and B[k = l>>5][col = l&31]; acc reg r holds C[row = (r&3) + 8*(r>>2) +
 // 4*(l>>5)][col = l&31].
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -35,7 +37,7 @@ constexpr int kQC = 32;           // q rows of F staged per slab
 // generalised contraction
 // ---------------------------------------------------------------------------------------------
 template <int D, int NT>
-__global__ __launch_bounds__(kThreads, 3) void cin_contract_kernel(
+__global__ __launch_bounds__(kThreads, NT <= 2 ? 3 : 2) void cin_contract_kernel(
     const float* __restrict__ P, const float* __restrict__ Q, const float* __restrict__ F,
     unsigned B, unsigned HP, unsigned HQ, unsigned C, float* __restrict__ out, int accumulate,
     float* __restrict__ pool, unsigned pool_stride, unsigned pool_col) {
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(kThreads, 3) void cin_contract_kernel(
     // BASELINE configuration); one MFMA chain per output adds them strictly in order, i.e. with the rounding error of a
     // 3328-term sequential fp32 sum — 2-4 x more elements outside 1e-5 relative than the blocked GEMM of the reference's
     // CPU path leaves (profiles/r02z_strict_parity_all_gpu_tests.md).  The chain is cut every `flush_every` slabs
-    // (~ 56 terms): the chunk sum goes to `tot` and a new chain starts from zero — error ~ sqrt(chunk) + sqrt(n / chunk)
+    // (~ 208 terms): the chunk sum goes to `tot` and a new chain starts from zero — error ~ sqrt(chunk) + sqrt(n / chunk)
     // instead of sqrt(n).  (`tot` doubles the accumulator registers: a workgroup covers NT <= 2 column tiles, wider
     // layers are column chunks over blockIdx.y.)
     f32x16 acc[NT], tot[NT];
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(kThreads, 3) void cin_contract_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] = tot[nt][r] = 0.f;
     const unsigned rows_per_slab = min(HQ, (unsigned)kQC);
-    const unsigned flush_every = max(1u, (56u + rows_per_slab / 2) / rows_per_slab);
+    const unsigned flush_every = max(1u, (208u + rows_per_slab / 2) / rows_per_slab);
     unsigned since_flush = 0;
 
     const float* Pp = P + ((size_t)b * HP) * D + dd;       // P[b, p, dd] at stride D
@@ -240,12 +242,12 @@ __global__ __launch_bounds__(kThreads) void cin_input_grad_kernel(
         Breg[s] = (valid && n < N) ? G[((size_t)b * N + n) * D + dd] : 0.f;
     }
     // X^0[b, j = acc_row(r, hi), dd] for this lane's column
-    float x0v[16], dx0acc[16];
+    float x0v[16], dx0acc[16], dx0tot[16];            // (sum over i in chunks of 16: two-level, see cin_contract_kernel)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const unsigned j = (r & 3) + 8 * (r >> 2) + 4 * hi;
         x0v[r] = (valid && j < m) ? x0[((size_t)b * m + j) * D + dd] : 0.f;
-        dx0acc[r] = 0.f;
+        dx0acc[r] = dx0tot[r] = 0.f;
     }
     const unsigned tileN = m * N;                    // floats of one W tile (rows j < m, contiguous in W)
     constexpr unsigned kStg = (32 * 128 + kThreads - 1) / kThreads;
@@ -305,6 +307,13 @@ __global__ __launch_bounds__(kThreads) void cin_input_grad_kernel(
             *p = dxk_accumulate ? *p + dk : dk;
         }
         if (more) stage_store(buf ^ 1);              // last read before the previous barrier
+        if ((i & 15) == 15 || !more) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dx0tot[r] += dx0acc[r];
+                dx0acc[r] = 0.f;
+            }
+        }
         xkv = xkv_next;
         __syncthreads();
     }
@@ -314,7 +323,7 @@ __global__ __launch_bounds__(kThreads) void cin_input_grad_kernel(
             const unsigned j = (r & 3) + 8 * (r >> 2) + 4 * hi;
             if (j < m) {
                 float* p = dx0 + ((size_t)b * m + j) * D + dd;
-                *p = dx0_accumulate ? *p + dx0acc[r] : dx0acc[r];
+                *p = dx0_accumulate ? *p + dx0tot[r] : dx0tot[r];
             }
         }
     }
@@ -358,21 +367,21 @@ __global__ __launch_bounds__(256) void cin_combine_grad_kernel(const float* __re
 // workgroup = 128 rows kk (one 32-row MFMA tile per wave) x all C columns, over a slab of the
 // batch (split-K over blockIdx.y); partial sums go to `partials[blockIdx.y][Kdim][C]`.
 // ---------------------------------------------------------------------------------------------
-constexpr int kRC = 64;        // reduction rows (b,d) staged per chunk
+// reduction rows (b,d) staged per chunk: RC = 128 when the Q tile is narrow (HQ <= 32: the BASELINE shapes), else 64
 constexpr int kPW = 34;        // >= distinct p values touched by the 128 kk rows of a workgroup (m >= 4)
 
-template <int D, int NT, int QI>
+template <int D, int NT, int QI, int RC>
 __global__ __launch_bounds__(kThreads, 2) void cin_filter_grad_kernel(
     const float* __restrict__ P, const float* __restrict__ Q, const float* __restrict__ G, unsigned B,
     unsigned HP, unsigned HQ, unsigned C, unsigned ex_per_split, float* __restrict__ partials) {
-    constexpr unsigned EXC = kRC / D;            // examples per chunk
+    constexpr unsigned EXC = RC / D;            // examples per chunk
     constexpr unsigned GS = NT * 32 + 4;         // LDS row strides
-    constexpr unsigned GI = kRC * NT * 32 / kThreads;          // staged G floats per thread
-    constexpr unsigned PI = (kRC * kPW + kThreads - 1) / kThreads;
+    constexpr unsigned GI = RC * NT * 32 / kThreads;          // staged G floats per thread
+    constexpr unsigned PI = (RC * kPW + kThreads - 1) / kThreads;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Gs = smem;                            // [kRC][GS]
-    float* Ps = Gs + kRC * GS;                   // [kRC][kPW]
-    float* Qs = Ps + kRC * kPW;                  // [kRC][HQ]
+    float* Gs = smem;                            // [RC][GS]
+    float* Ps = Gs + RC * GS;                   // [RC][kPW]
+    float* Qs = Ps + RC * kPW;                  // [RC][HQ]
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned hi = lane >> 5, l32 = lane & 31;
     const unsigned Kdim = HP * HQ;
@@ -386,7 +395,7 @@ __global__ __launch_bounds__(kThreads, 2) void cin_filter_grad_kernel(
     const unsigned pp_lane = p_lane - p_first;              // column in Ps
     unsigned p_cnt = min(HP, (min(kk0 + 128, Kdim) - 1) / HQ + 1) - p_first;   // p values staged
 
-    // two-level accumulation (see cin_contract_kernel): one chain per staged chunk of kRC reduction rows, the chunk sums
+    // two-level accumulation (see cin_contract_kernel): one chain per staged chunk of RC reduction rows, the chunk sums
     // added to `tot` — a split otherwise adds B * D / splits (3456 at the BASELINE shape) terms in one chain
     f32x16 acc[NT], tot[NT];
 #pragma unroll
@@ -456,6 +465,7 @@ __global__ __launch_bounds__(kThreads, 2) void cin_filter_grad_kernel(
         }
     };
     if (ex_begin < ex_end) prefetch(ex_begin);
+    unsigned chunks = 0;
     for (unsigned e0 = ex_begin; e0 < ex_end; e0 += EXC) {
         __syncthreads();                                    // previous chunk fully consumed
         commit();
@@ -465,7 +475,7 @@ __global__ __launch_bounds__(kThreads, 2) void cin_filter_grad_kernel(
         const float* Ql = Qs + hi * HQ + q_lane;
         const float* Gl = Gs + hi * GS + l32;
 #pragma unroll 4
-        for (unsigned st = 0; st < kRC / 2; ++st) {
+        for (unsigned st = 0; st < RC / 2; ++st) {
             float a = kok ? Pl[(2 * st) * kPW] * Ql[(2 * st) * HQ] : 0.f;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -473,13 +483,15 @@ __global__ __launch_bounds__(kThreads, 2) void cin_filter_grad_kernel(
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf, acc[nt], 0, 0, 0);
             }
         }
+        if ((++chunks & 3) == 0 || e0 + EXC >= ex_end) {     // chain length 4 chunks = 256 terms (uniform over the workgroup)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                tot[nt][r] += acc[nt][r];
-                acc[nt][r] = 0.f;
-            }
+                for (int r = 0; r < 16; ++r) {
+                    tot[nt][r] += acc[nt][r];
+                    acc[nt][r] = 0.f;
+                }
+        }
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = tot[nt];
@@ -534,7 +546,12 @@ int launch_contract_DN(const float* P, const float* Q, const float* F, int B, in
 template <int D>
 int launch_contract_D(int NT, const float* P, const float* Q, const float* F, int B, int HP, int HQ, int C,
                       float* out, int accumulate, float* pool, int pool_stride, int pool_col, hipStream_t st) {
+    // column tiles per workgroup: 2 (128 registers, 4 waves / SIMD) or — RECALGO_CIN_NT=4, tuning knob — up to 4 (one
+    // workgroup covers N <= 128: fewer barriers per MFMA, but 256 registers with the two-level accumulators)
+    static const int nt_max = [] { const char* e = getenv("RECALGO_CIN_NT"); return e && atoi(e) == 4 ? 4 : 2; }();
     if (NT == 1) return launch_contract_DN<D, 1>(P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);
+    if (nt_max == 4 && NT == 3) return launch_contract_DN<D, 3>(P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);
+    if (nt_max == 4 && NT == 4) return launch_contract_DN<D, 4>(P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);
     return launch_contract_DN<D, 2>(P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);
 }
 
@@ -589,39 +606,40 @@ int launch_input_grad(const float* x0, const float* xk, const float* W, const fl
     }
 }
 
-inline int filter_grad_splits(int B, int D, int Kdim, int C) {
+inline int filter_rc(int /*HQ*/) { return 64; }          // (RC = 128 spills at NT = 2: 27 VGPRs, measured slower)
+inline int filter_grad_splits(int B, int D, int Kdim, int C, int HQ) {
     int row_blocks = cdiv(Kdim, 128) * cdiv(C, 64);         // x column chunks of <= 2 tiles
     int want = 512 / row_blocks;                            // <= 2 workgroups per CU (VGPR-bound occupancy): no tail round
-    int exc = kRC / D;
+    int exc = filter_rc(HQ) / D;
     int max_s = cdiv(B, exc);
     int S = want < 1 ? 1 : (want > max_s ? max_s : want);
     return S > 64 ? 64 : S;
 }
 
-template <int D, int NT, int QI>
+template <int D, int NT, int QI, int RC>
 int launch_filter_grad_DNQ(const float* P, const float* Q, const float* G, int B, int HP, int HQ, int C, int S,
                            float* partials, hipStream_t st) {
-    size_t smem = ((size_t)kRC * (NT * 32 + 4) + (size_t)kRC * kPW + (size_t)kRC * HQ) * sizeof(float);
+    size_t smem = ((size_t)RC * (NT * 32 + 4) + (size_t)RC * kPW + (size_t)RC * HQ) * sizeof(float);
     if (smem > 160 * 1024) return (int)hipErrorInvalidValue;
     if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_filter_grad_kernel<D, NT, QI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_filter_grad_kernel<D, NT, QI, RC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    const int exc = kRC / D;
+    const int exc = RC / D;
     int ex_per_split = cdiv(cdiv(B, S), exc) * exc;
     dim3 grid(cdiv(HP * HQ, 128), S, cdiv(C, NT * 32));
-    hipLaunchKernelGGL((cin_filter_grad_kernel<D, NT, QI>), grid, dim3(kThreads), smem, st, P, Q, G, (unsigned)B,
+    hipLaunchKernelGGL((cin_filter_grad_kernel<D, NT, QI, RC>), grid, dim3(kThreads), smem, st, P, Q, G, (unsigned)B,
                        (unsigned)HP, (unsigned)HQ, (unsigned)C, (unsigned)ex_per_split, partials);
     return (int)hipGetLastError();
 }
 template <int D, int NT>
 int launch_filter_grad_DN(const float* P, const float* Q, const float* G, int B, int HP, int HQ, int C, int S,
                           float* partials, hipStream_t st) {
-    const int qi = cdiv(kRC * HQ, 4 * kThreads);          // staged Q float4s per thread: HQ <= 32 | 64 | 128
-    if (qi <= 2) return launch_filter_grad_DNQ<D, NT, 2>(P, Q, G, B, HP, HQ, C, S, partials, st);
-    if (qi <= 4) return launch_filter_grad_DNQ<D, NT, 4>(P, Q, G, B, HP, HQ, C, S, partials, st);
-    return launch_filter_grad_DNQ<D, NT, 8>(P, Q, G, B, HP, HQ, C, S, partials, st);
+    const int qi = cdiv(64 * HQ, 4 * kThreads);             // staged Q float4s per thread: HQ <= 32 | 64 | 128
+    if (qi <= 2) return launch_filter_grad_DNQ<D, NT, 2, 64>(P, Q, G, B, HP, HQ, C, S, partials, st);
+    if (qi <= 4) return launch_filter_grad_DNQ<D, NT, 4, 64>(P, Q, G, B, HP, HQ, C, S, partials, st);
+    return launch_filter_grad_DNQ<D, NT, 8, 64>(P, Q, G, B, HP, HQ, C, S, partials, st);
 }
 
 template <int D>
@@ -643,7 +661,7 @@ inline BwdWs bwd_ws(int B, int m, int Hk, int N, int D) {
     w.wp = off;   off += al(kdim * N * sizeof(float));
     w.wpp = off;  off += al(kdim * N * sizeof(float));
     w.partials = off;
-    off += al((size_t)filter_grad_splits(B, D, (int)kdim, N) * kdim * N * sizeof(float));
+    off += al((size_t)filter_grad_splits(B, D, (int)kdim, N, m) * kdim * N * sizeof(float));
     w.total = off;
     return w;
 }
@@ -714,7 +732,7 @@ RECALGO_EXPORT int recalgo_cin_layer_bwd(const float* x0, const float* xk, const
         if (rc) return rc;
     }
     // dW
-    const int S = filter_grad_splits(B, D, Hk * m, N);
+    const int S = filter_grad_splits(B, D, Hk * m, N, m);
     const int NT = cdiv(N, 32);
     switch (D) {
         case 4: rc = launch_filter_grad_D<4>(NT, xk, x0, G, B, Hk, m, N, S, partials, st); break;

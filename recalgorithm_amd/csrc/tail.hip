@@ -735,6 +735,10 @@ RECALGO_EXPORT int recalgo_adam_tf1_step(float* p, float* g, float* m, float* v,
         if ((a.K & 3) == 0)
             for (int sft = 0; sft < 16; ++sft)
                 if ((a.K >> 2) == (1 << sft)) R.k4_shift = sft;
+        // the lazy vote of this (live-list) path is per row only when the K/4 lanes of a row are an aligned power-of-two
+        // group of one wave; other widths would vote per float4 / per element, which is not LazyAdam (the owner-computes
+        // path, recalgo_scatter_apply RECALGO_SCATTER_LAZY_ADAM, has no such limit and is what the host uses)
+        RECALGO_REQUIRE(!a.lazy || (R.k4_shift >= 0 && (a.K >> 2) <= 64));
         // sized for the largest possible list (graph replayable); surplus workgroups find nothing to do
         const int64_t per = (a.K & 3) == 0 ? a.max_rows * (a.K / 4) : a.max_rows * a.K;
         const int64_t w = (per + 255) / 256;

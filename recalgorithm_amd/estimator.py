@@ -84,8 +84,12 @@ class AdamOptimizer:
                 "step": torch.zeros(1, dtype=torch.int64, device=store.device),
                 "lr_t": torch.zeros(1, dtype=torch.float32, device=store.device),
             }
-        from . import nn
+        from . import nn, sparse
         arenas = [ar for ar in store.arenas.values() if ar.weight is not None and ar.trainable]
+        # arenas on the owner-computes path (sparse.py): their optimizer step is fused with the row-gradient scatter
+        # (recalgo_scatter_apply) — TF1 Adam with dense semantics evaluated lazily but exactly, or LazyAdam
+        owned = [ar for ar in arenas if sparse.has_work(ar)]
+        arenas = [ar for ar in arenas if not sparse.has_work(ar)]
         fused = all(ar.tracks_live_rows for ar in arenas) and len(arenas) <= 4 and store.device.type == "cuda"
         # parked gradients: deferred weight-gradient split sums (+ the step counter, advanced by the same launch),
         # l2-regulariser contributions (PNN weight_regularizer)
@@ -97,10 +101,14 @@ class AdamOptimizer:
             # reached (the update is the identity for all others); lr_t derived on the device from the step counter
             ops.adam_tf1_step_(store.flat, store.flat_grad, store.flat_m, store.flat_v, arenas, st["step"], None,
                                self.lr, self.beta1, self.beta2, self.eps, lazy=self.lazy_embeddings)
+            for ar in owned:
+                sparse.apply(ar, self.lazy_embeddings, st["step"], self.lr, self.beta1, self.beta2, self.eps)
             return
-        if self.lazy_embeddings:
+        if self.lazy_embeddings and arenas:
             raise NotImplementedError("LazyAdamOptimizer needs the fused optimizer launch (HIP device, <= 4 arenas)")
         ops.adam_tf1_advance_(st["step"], st["lr_t"], self.lr, self.beta1, self.beta2)
+        for ar in owned:
+            sparse.apply(ar, self.lazy_embeddings, st["step"], self.lr, self.beta1, self.beta2, self.eps)
         kw = dict(step=-1, lr=self.lr, beta1=self.beta1, beta2=self.beta2, eps=self.eps,
                   zero_grad=True, lr_t_dev=st["lr_t"])
         if store.flat is not None and store.flat.numel():
@@ -671,7 +679,7 @@ def collect_checkpoint_state(store: VariableStore, global_step: int):
     weight / m / v shards are all_gather'ed back into whole tables, so the file is independent of the number of ranks
     (restore happens before re-sharding); only rank 0 writes."""
     from . import parallel
-    variables = {k: v.detach().cpu() for k, v in store.named_arrays(gather=True).items()}
+    variables = {k: v.detach().cpu() for k, v in store.named_arrays(gather=True).items()}   # (flushes deferred Adam first)
     arena_m, arena_v, writer = {}, {}, True
     for n, a in store.arenas.items():
         sd = getattr(a, "sharding", None)
@@ -747,6 +755,8 @@ def restore_checkpoint_state(store: VariableStore, state: dict, device, where: s
             a.m[:n_local].copy_(state["arena_m"][n][rank::world])
             a.v[:n_local].copy_(state["arena_v"][n][rank::world])
             a.live = None            # rebuilt from the restored moments on next use
+            from . import sparse
+            sparse.reset(a)          # (deferred-Adam bookkeeping likewise)
     if state.get("opt_step") is not None:
         store.opt_state = {
             "step": torch.tensor([state["opt_step"]], dtype=torch.int64, device=device),

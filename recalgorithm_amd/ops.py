@@ -15,7 +15,7 @@ from typing import Optional, Tuple
 import torch
 from torch.autograd import Function
 
-from . import _lib
+from . import _lib, sparse
 from .variables import EmbeddingArena, Variable, VariableStore
 
 _ACT = {"prelu": 0, "dice": 1}
@@ -56,6 +56,12 @@ def arena_row_base(arena, table_name: str, device) -> torch.Tensor:
     return t
 
 
+def anchor_store(anchor):
+    """The VariableStore whose autograd anchor was passed to a lookup (its optimizer state holds the step counter the
+    deferred-Adam catch-up needs)."""
+    return getattr(anchor, "_recalgo_store", None)
+
+
 def _flush(arena) -> None:
     """Row-sharded deployment (parallel.py): the kernel scattered into a staged gradient; send it
     to the rows' owners now."""
@@ -88,10 +94,9 @@ def _live(arena, row_offset: int = 0):
 
 
 def _sorted_scatter() -> bool:
-    """RECALGO_SCATTER=sorted: the row-gradient scatters run as stable sort + ordered segment sums (no float atomics):
-    bit-reproducible steps for parity and checkpoint-resume runs; slower than the LDS-aggregated atomic kernels."""
-    import os
-    return os.environ.get("RECALGO_SCATTER", "atomic") == "sorted"
+    """RECALGO_SPARSE=sorted (or the older RECALGO_SCATTER=sorted): the round-2 deterministic scatter — stable torch.sort +
+    ordered segment sums, live-row-list optimizer.  The default (owner) path is deterministic as well (sparse.py)."""
+    return sparse.scatter_mode() == "sorted"
 
 
 def scatter_rows_sorted(arena, rows: torch.Tensor, vals: torch.Tensor) -> None:
@@ -133,6 +138,8 @@ class _GatherFn(Function):
         B, F = ids.shape
         K = arena.K
         out = torch.empty(B, F * K, device=ids.device, dtype=torch.float32)
+        # owner-computes scatter (sparse.py): the lookup joins the arena's plan; deferred-Adam rows are caught up first
+        ctx.src = sparse.begin_lookup(arena, anchor_store(anchor), ids, None, row_base, 0, B, F)
         _lib.check(_lib_().recalgo_embedding_gather_fwd(
             _p(ids), _p(arena.weight), _p(row_base), B, F, K, _p(out), F * K, 0, _stream(ids)),
             "recalgo_embedding_gather_fwd")
@@ -143,6 +150,9 @@ class _GatherFn(Function):
     def backward(ctx, g):
         ids, arena = ctx.ids, ctx.arena
         B, F = ids.shape
+        if ctx.src is not None:
+            ctx.src.set_grad(g)              # summed per row (and applied) by the optimizer's recalgo_scatter_apply
+            return None, None, None, None
         g = g.contiguous()
         if _sorted_scatter():
             rows = torch.where(ids >= 0, ids + ctx.row_base.unsqueeze(0), torch.full_like(ids, -1))
@@ -175,6 +185,11 @@ class _BagMeanFn(Function):
         K = arena.K
         table = arena.table_view(table_name)
         out = torch.empty(B, K, device=values.device, dtype=torch.float32)
+        ctx.src = None
+        if table_name != "__staged__" and values.numel():
+            # one request per bag entry; its gradient row (g[bag] / count) is expanded in the backward
+            ctx.src = sparse.begin_lookup(arena, anchor_store(anchor), values, None, None, arena.tables[table_name][0],
+                                          values.numel(), 1)
         _lib.check(_lib_().recalgo_embedding_bag_mean_fwd(
             _p(values), _p(offsets), _p(table), B, K, _p(out), K, 0, _stream(offsets)),
             "recalgo_embedding_bag_mean_fwd")
@@ -188,11 +203,14 @@ class _BagMeanFn(Function):
         rb, vocab = arena.tables[table_name]
         gt = arena.grad[rb:rb + vocab]
         g = g.contiguous()
-        if _sorted_scatter():
+        if ctx.src is not None or _sorted_scatter():
             lens = offsets[1:] - offsets[:-1]
             bag = torch.repeat_interleave(torch.arange(B, device=values.device), lens)
             cnt = torch.zeros(B, device=values.device).index_add_(0, bag, (values >= 0).float()).clamp_(min=1.0)
             vals = g[bag] / cnt[bag].unsqueeze(1)
+            if ctx.src is not None:
+                ctx.src.set_grad(vals)
+                return None, None, None, None, None
             scatter_rows_sorted(arena, torch.where(values >= 0, values + rb, torch.full_like(values, -1)), vals)
             _flush(arena)
             return None, None, None, None, None
@@ -221,6 +239,9 @@ class _SeqGatherFn(Function):
         table = arena.table_view(table_name)
         out = torch.empty(B, T, K, device=offsets.device, dtype=torch.float32)
         seq_len = torch.empty(B, device=offsets.device, dtype=torch.int32)
+        ctx.src = None
+        if table_name != "__staged__":
+            ctx.src = sparse.begin_lookup(arena, anchor_store(anchor), values, offsets, None, arena.tables[table_name][0], B, T)
         _lib.check(_lib_().recalgo_sequence_gather_fwd(
             _p(values), _p(offsets), _p(table), B, T, K, _p(out), _p(seq_len), _stream(offsets)),
             "recalgo_sequence_gather_fwd")
@@ -234,6 +255,9 @@ class _SeqGatherFn(Function):
         B = offsets.numel() - 1
         rb, vocab = arena.tables[table_name]
         gt = arena.grad[rb:rb + vocab]
+        if ctx.src is not None:
+            ctx.src.set_grad(g)
+            return None, None, None, None, None, None
         g = g.contiguous()
         if _sorted_scatter():
             lens = (offsets[1:] - offsets[:-1]).clamp(max=T)
@@ -273,6 +297,9 @@ class _DeepFMSparseFn(Function):
         fm1 = torch.empty(B, 1, device=ids.device, dtype=torch.float32)
         fm2 = torch.empty(B, 1, device=ids.device, dtype=torch.float32)
         fsum = torch.empty(B, K, device=ids.device, dtype=torch.float32)
+        st = anchor_store(anchor)
+        ctx.src = sparse.begin_lookup(arena, st, ids, None, row_base, 0, B, F)
+        ctx.src1 = sparse.begin_lookup(w1, st, ids, None, row_base, 0, B, F) if ctx.src is not None else None
         _lib.check(_lib_().recalgo_deepfm_sparse_fwd(
             _p(ids), _p(arena.weight), _p(w1.weight), _p(bias.data), _p(row_base), B, F, K,
             _p(emb), _p(fm1), _p(fm2), _p(fsum), _stream(ids)), "recalgo_deepfm_sparse_fwd")
@@ -286,6 +313,14 @@ class _DeepFMSparseFn(Function):
         emb, fsum = ctx.saved_tensors
         B, F = ids.shape
         g_emb, g_fm1, g_fm2 = g_emb.contiguous(), g_fm1.contiguous(), g_fm2.contiguous()
+        if ctx.src is not None and ctx.src1 is not None:
+            K = arena.K
+            e3, s3 = emb.reshape(B, F, K), fsum.reshape(B, 1, K)
+            vals = torch.addcmul(g_emb.reshape(B, F, K), g_fm2.reshape(B, 1, 1), s3 - e3)     # g_emb + g_fm2 * (S - e)
+            ctx.src.set_grad(vals)
+            ctx.src1.set_grad(g_fm1.reshape(B, 1), fmul=0)      # every field of example b adds g_fm1[b] to its w1 row
+            torch.sum(g_fm1, dim=0, out=bias.grad.view(1))
+            return None, None, None, None, None, None
         if _sorted_scatter():
             K = arena.K
             rows = torch.where(ids >= 0, ids + row_base.unsqueeze(0), torch.full_like(ids, -1))

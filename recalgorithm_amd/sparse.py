@@ -1,0 +1,303 @@
+"""Host side of csrc/sparse.hip: the per-arena request PLAN of a training step (row-gradient scatter without float
+atomics, fused with the sparse optimizer) and the deferred-exact TF1 Adam state.
+
+    forward of a lookup   begin_lookup(arena, ...)    registers the lookup's requests as a `Source`, launches
+                                                      recalgo_scatter_prepare (bucket counts + catch-up of the rows)
+    backward of a lookup  Source.set_grad(g)          records where the per-request gradient rows are
+    optimizer             apply(arena, mode, ...)     recalgo_scatter_apply over all sources of the arena: TF1 Adam with
+                                                      dense semantics evaluated lazily but exactly (tf.train.AdamOptimizer,
+                                                      /root/reference algorithm/DeepFM/deepfm.py:246-250) or
+                                                      tf.contrib.opt.LazyAdamOptimizer (algorithm/DIEN/dien.py:328)
+    anyone reading whole  sync(arena) / sync_store    recalgo_adam_deferred_sweep: every row brought to the current step
+    tables                                            (named_arrays, checkpoints, export)
+    tests / tools         materialize_grads(store)    the summed row gradients written to arena.grad (GRAD mode)
+
+RECALGO_SPARSE=owner (default) selects this path for local (not row-sharded) arenas; `atomic` / `sorted` keep the
+round-2 kernels (LDS-aggregated float atomics / torch.sort + ordered segment sums) with the live-row-list optimizer.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+
+MODE_GRAD, MODE_ADAM, MODE_LAZY_ADAM = 0, 1, 2
+MAX_SOURCES = 4
+LR_RING = 1024
+
+
+def scatter_mode() -> str:
+    m = os.environ.get("RECALGO_SPARSE")
+    if m is None:
+        m = {"atomic": "atomic", "sorted": "sorted"}.get(os.environ.get("RECALGO_SCATTER", ""), "owner")
+    if m not in ("owner", "atomic", "sorted"):
+        raise ValueError(f"RECALGO_SPARSE={m}: expected owner | atomic | sorted")
+    return m
+
+
+def sweep_period() -> int:
+    """Deferred Adam: 1/P of every arena is brought up to date per step (no row lags more than P + 1 steps)."""
+    p = int(os.environ.get("RECALGO_ADAM_SWEEP_PERIOD", "32"))
+    if not 1 <= p <= LR_RING - 8:
+        raise ValueError(f"RECALGO_ADAM_SWEEP_PERIOD={p}: expected 1 .. {LR_RING - 8}")
+    return p
+
+
+class _CSource(ctypes.Structure):            # include/recalgo.h recalgo_scatter_source_t
+    _fields_ = [("ids", ctypes.c_void_p), ("offsets", ctypes.c_void_p), ("row_base", ctypes.c_void_p), ("base", ctypes.c_int64),
+                ("n_ex", ctypes.c_int), ("F", ctypes.c_int), ("g", ctypes.c_void_p), ("g_stride", ctypes.c_int64),
+                ("g_col", ctypes.c_int), ("g_fmul", ctypes.c_int)]
+
+
+class _CDeferred(ctypes.Structure):          # include/recalgo.h recalgo_deferred_adam_t
+    _fields_ = [("w", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p), ("last_step", ctypes.c_void_p),
+                ("lr_ring", ctypes.c_void_p), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float)]
+
+
+class Source:
+    """One lookup's requests: ids [n_ex, F] (offsets None) or ragged (values, offsets) with F steps per example."""
+
+    def __init__(self, ids, offsets, row_base, base: int, n_ex: int, F: int):
+        self.ids, self.offsets, self.row_base, self.base, self.n_ex, self.F = ids, offsets, row_base, int(base), int(n_ex), int(F)
+        self.g = None
+        self.g_stride = self.g_col = self.g_fmul = 0
+        self.keep = None                       # tensors the gradient view depends on
+
+    @property
+    def n(self) -> int:
+        return self.n_ex * self.F
+
+    def set_grad(self, g: torch.Tensor, fmul: Optional[int] = None):
+        """g: [n_ex, F * K] / [n_ex, F, K] / [n_ex, K'] with the last dimension contiguous; request (e, f) reads its K
+        floats at g[e].flat[f * fmul : f * fmul + K] (fmul defaults to K = row width; 0: all fields share the row)."""
+        if g.dim() == 3:
+            g = g.reshape(g.shape[0], -1) if g.is_contiguous() else g.contiguous().view(g.shape[0], -1)
+        if g.dim() != 2 or (g.shape[1] > 1 and g.stride(1) != 1) or g.shape[0] != self.n_ex:
+            g = g.contiguous().view(self.n_ex, -1)
+        self.g = g
+        self.g_stride = int(g.stride(0)) if g.shape[0] > 1 else int(g.shape[1])
+        self.g_col = 0
+        self.g_fmul = fmul
+
+    def c_struct(self, K: int) -> _CSource:
+        p = lambda t: None if t is None else t.data_ptr()
+        fm = K if self.g_fmul is None else int(self.g_fmul)
+        return _CSource(p(self.ids), p(self.offsets), p(self.row_base), self.base, self.n_ex, self.F, p(self.g),
+                        self.g_stride, self.g_col, fm)
+
+
+class ArenaPlan:
+    """Per-arena state of the owner-computes path (attached as `arena.sparse`)."""
+
+    def __init__(self, arena):
+        self.arena = arena
+        self.sources: List[Source] = []
+        self.ws: Optional[torch.Tensor] = None
+        self.capacity = 0                      # requests the workspace was sized for
+        self.nb_log2 = 10
+        self.counted = None                    # signature of what the workspace's bucket counts currently hold
+        self.last_step: Optional[torch.Tensor] = None     # deferred-Adam: int32 [rows]
+        self.lr_ring: Optional[torch.Tensor] = None
+        self.betas = (0.9, 0.999, 1e-8)
+        self.grad_materialized = False
+
+    # -- workspace ------------------------------------------------------------------------------
+    def _ensure_ws(self, n_requests: int):
+        """Grow-only: the bucket count is fixed when the workspace is allocated (re-allocating invalidates the counts)."""
+        if self.ws is not None and n_requests <= self.capacity:
+            return
+        lib = _lib.load()
+        cap = max(n_requests, 1)
+        self.nb_log2 = int(lib.recalgo_scatter_plan_buckets_log2(cap))
+        self.capacity = cap
+        nbytes = int(lib.recalgo_scatter_plan_workspace_bytes(cap, self.nb_log2))
+        self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.arena.weight.device)
+        self.counted = None
+
+    def _signature(self, sources):
+        return (self.ws.data_ptr(), self.nb_log2, tuple(id(s) for s in sources))
+
+    def _deferred_struct(self):
+        if self.last_step is None:
+            return None
+        a = self.arena
+        b1, b2, eps = self.betas
+        return _CDeferred(a.weight.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), self.last_step.data_ptr(),
+                          self.lr_ring.data_ptr(), b1, b2, eps)
+
+
+def _stream(t: torch.Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _supported(arena) -> bool:
+    from .variables import EmbeddingArena
+    if type(arena) is not EmbeddingArena or arena.weight is None or not arena.weight.is_cuda:
+        return False
+    if getattr(arena, "sharding", None) is not None:
+        return False                           # row-sharded arenas keep the round-2 owner-side scatter (parallel.py)
+    K = arena.K
+    return arena.weight.shape[0] < (1 << 31) and ((K % 4 == 0 and K // 4 <= 64) or K <= 64)
+
+
+def plan_of(arena) -> Optional[ArenaPlan]:
+    return getattr(arena, "sparse", None)
+
+
+def begin_lookup(arena, store, ids: torch.Tensor, offsets: Optional[torch.Tensor], row_base: Optional[torch.Tensor],
+                 base: int, n_ex: int, F: int) -> Optional[Source]:
+    """Called by a lookup's forward BEFORE its gather kernel.  Returns the Source to attach the gradient to (training,
+    owner mode), or None.  Whatever the mode of the call: on an arena with deferred-Adam state the requested rows are
+    brought up to date first, so every forward reads current weights."""
+    plan = plan_of(arena)
+    training = torch.is_grad_enabled() and getattr(arena, "trainable", True)
+    if plan is None:
+        if not (training and scatter_mode() == "owner" and _supported(arena)):
+            return None
+        plan = arena.sparse = ArenaPlan(arena)
+    elif not _supported(arena):                # (an arena that was re-sharded after its first steps)
+        return None
+    register = training and scatter_mode() == "owner"
+    if not register and plan.last_step is None:
+        return None
+    src = Source(ids, offsets, row_base, base, n_ex, F)
+    if src.n == 0:
+        if register:
+            plan.sources.append(src)
+        return src if register else None
+    lib = _lib.load()
+    ws_ptr = None
+    if register:
+        if len(plan.sources) >= MAX_SOURCES:
+            raise NotImplementedError(f"more than {MAX_SOURCES} lookups into arena {arena.name} in one step")
+        plan._ensure_ws(sum(s.n for s in plan.sources) + src.n)
+        if plan.counted is None or plan.counted[:2] != (plan.ws.data_ptr(), plan.nb_log2):
+            plan.ws[: 8 << plan.nb_log2].zero_()           # cnt + cursor
+            plan.counted = (plan.ws.data_ptr(), plan.nb_log2, ())
+        ws_ptr = ctypes.c_void_p(plan.ws.data_ptr())
+    d = plan._deferred_struct()
+    step = None if d is None else store.opt_state["step"]
+    cs = src.c_struct(arena.K)
+    _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), arena.K, ws_ptr, plan.capacity, plan.nb_log2,
+                                           None if d is None else ctypes.byref(d),
+                                           None if step is None else ctypes.c_void_p(step.data_ptr()), 0,
+                                           _stream(arena.weight)), "recalgo_scatter_prepare")
+    if register:
+        plan.sources.append(src)
+        plan.counted = plan.counted[:2] + (plan.counted[2] + (id(src),),)
+        return src
+    return None
+
+
+def new_forward(store) -> None:
+    """A model_fn invocation starts: sources of an earlier forward that never reached the optimizer are stale."""
+    for ar in store.arenas.values():
+        plan = plan_of(ar)
+        if plan is not None and plan.sources:
+            plan.sources = []
+            plan.counted = None
+            plan.grad_materialized = False
+
+
+def has_work(arena) -> bool:
+    plan = plan_of(arena)
+    return plan is not None and (bool(plan.sources) or plan.last_step is not None)
+
+
+def _run(plan: ArenaPlan, sources: List[Source], mode: int, step_dev, step_offset: int, lr: float, live=None):
+    lib = _lib.load()
+    a = plan.arena
+    plan._ensure_ws(sum(s.n for s in sources))
+    if plan.counted != plan._signature([s for s in sources if s.n]):
+        # the counts in the workspace are not those of exactly these sources (first step, a forward without a backward, a
+        # GRAD pass before the optimizer, a re-sized workspace): count again
+        plan.ws[: 8 << plan.nb_log2].zero_()
+        for s in sources:
+            if s.n:
+                cs = s.c_struct(a.K)
+                _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), a.K, ctypes.c_void_p(plan.ws.data_ptr()), plan.capacity,
+                                                       plan.nb_log2, None, None, 0, _stream(a.weight)), "recalgo_scatter_prepare")
+    srcs = [s for s in sources if s.n]
+    if not srcs:                               # (the sweep and the lr ring still need the launch)
+        dummy = Source(a.weight, None, None, 0, 0, 1)
+        dummy.g, dummy.g_fmul = a.weight, a.K
+        srcs = [dummy]
+    arr = (_CSource * len(srcs))(*[s.c_struct(a.K) for s in srcs])
+    d = plan._deferred_struct() if mode == MODE_ADAM else None
+    b1, b2, eps = plan.betas
+    p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    grad = a.grad if (mode == MODE_GRAD or plan.grad_materialized) else None
+    _lib.check(lib.recalgo_scatter_apply(arr, len(srcs), a.K, p(plan.ws), plan.capacity, plan.nb_log2, mode, p(a.weight), p(a.m),
+                                         p(a.v), p(grad), None if d is None else ctypes.byref(d), a.weight.shape[0],
+                                         sweep_period(), live, p(step_dev), step_offset, lr, b1, b2, eps, _stream(a.weight)),
+               "recalgo_scatter_apply")
+    plan.counted = plan._signature([])         # `apply` leaves the counters cleared
+
+
+def apply(arena, lazy: bool, step_dev: torch.Tensor, lr: float, beta1: float, beta2: float, eps: float) -> None:
+    """The optimizer step of one arena (step_dev already advanced to this step)."""
+    plan = plan_of(arena)
+    sources = [s for s in plan.sources if s.g is not None]
+    plan.betas = (float(beta1), float(beta2), float(eps))
+    if lazy:
+        if plan.last_step is not None:
+            sync(arena, step_dev, -1)          # (switching optimizers mid-run: finish the deferred updates first)
+            plan.last_step = None
+        if sources:
+            _run(plan, sources, MODE_LAZY_ADAM, step_dev, 0, lr)
+    else:
+        if plan.last_step is None:
+            # rows with state (m, v) are valid for the step before this one; untouched rows are marked 0
+            alive = ((arena.m != 0) | (arena.v != 0)).any(dim=1)
+            plan.last_step = (alive.to(torch.int64) * (step_dev - 1)).to(torch.int32)
+            plan.lr_ring = torch.zeros(LR_RING, dtype=torch.float32, device=arena.weight.device)
+        _run(plan, sources, MODE_ADAM, step_dev, 0, lr)
+    plan.sources = []
+    plan.grad_materialized = False
+
+
+def materialize_grads(store) -> None:
+    """arena.grad += the summed row gradients of the pending sources (tests, tools; the optimizer does not need it)."""
+    for ar in store.arenas.values():
+        plan = plan_of(ar)
+        if plan is None or plan.grad_materialized:
+            continue
+        sources = [s for s in plan.sources if s.g is not None]
+        if not sources:
+            continue
+        _run(plan, sources, MODE_GRAD, None, 0, 0.0)
+        plan.grad_materialized = True
+
+
+def sync(arena, step_dev: Optional[torch.Tensor], step_offset: int = 0) -> None:
+    """Deferred Adam: bring EVERY row of the arena to step_dev[0] + step_offset (no-op without deferred state)."""
+    plan = plan_of(arena)
+    if plan is None or plan.last_step is None or step_dev is None:
+        return
+    d = plan._deferred_struct()
+    _lib.check(_lib.load().recalgo_adam_deferred_sweep(ctypes.byref(d), arena.K, 0, arena.weight.shape[0],
+                                                      ctypes.c_void_p(step_dev.data_ptr()), step_offset, _stream(arena.weight)),
+               "recalgo_adam_deferred_sweep")
+
+
+def sync_store(store) -> None:
+    """Every arena of the store reflects all completed optimizer steps (named_arrays, checkpoints, export)."""
+    st = getattr(store, "opt_state", None)
+    if st is None:
+        return
+    for ar in store.arenas.values():
+        sync(ar, st["step"], 0)
+
+
+def reset(arena) -> None:
+    """Forget the deferred state (the arena's w / m / v were replaced: restore, load_variables, re-sharding)."""
+    plan = plan_of(arena)
+    if plan is not None:
+        plan.last_step = None
+        plan.sources = []
+        plan.counted = None
+        plan.grad_materialized = False

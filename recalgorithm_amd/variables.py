@@ -94,6 +94,7 @@ class VariableStore:
         # autograd anchor: makes parameter-owning ops differentiable even when none of their
         # tensor inputs requires grad (their parameter grads are written as side effects)
         self.anchor = torch.zeros(1, device=self.device, requires_grad=True)
+        self.anchor._recalgo_store = self         # (ops.anchor_store: lookups find the optimizer state through the anchor)
         self.arenas: Dict[str, "EmbeddingArena"] = {}
         self.seed = seed
         # building == True: a dry model_fn pass that only registers variables / tables
@@ -136,6 +137,8 @@ class VariableStore:
         """A model_fn invocation == a fresh TF graph: auto-naming counters restart."""
         self._auto.clear()
         self._scope.clear()
+        from . import sparse
+        sparse.new_forward(self)
 
     def scope_name(self) -> str:
         return "/".join(self._scope)
@@ -232,6 +235,8 @@ class VariableStore:
     def named_arrays(self, gather: bool = False) -> Dict[str, torch.Tensor]:
         """name -> tensor of every variable and embedding table.  Tables of a row-sharded arena are not local views:
         with `gather` they are all_gather'ed (a COLLECTIVE: every rank must call), without it they raise."""
+        from . import sparse
+        sparse.sync_store(self)               # deferred Adam: whole tables are about to be read
         out = {n: self.vars[n].data for n in self.vars}
         for ar in self.arenas.values():
             if gather and getattr(ar, "sharding", None) is not None:
@@ -247,9 +252,10 @@ class VariableStore:
 
 def named_grads(store: VariableStore) -> Dict[str, torch.Tensor]:
     """name -> gradient tensor, same keys as VariableStore.named_arrays()."""
-    from . import nn, parallel
+    from . import nn, parallel, sparse
     nn.apply_parked_grads()
     parallel.join_push_streams()
+    sparse.materialize_grads(store)
     out = {n: v.grad for n, v in store.vars.items() if v.grad is not None}
     for ar in store.arenas.values():
         for tn, (rb, vocab) in ar.tables.items():
