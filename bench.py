@@ -62,7 +62,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-extra-models", action="store_true",
+                    help="default run (--model dcn, N = 1): skip the DeepFM / xDeepFM / DIN lines appended under `models`")
     return ap.parse_args(argv)
 
 
@@ -241,9 +243,50 @@ def kernel_rooflines(args, est, feats, device):
 
     add("gather_fwd", lambda: lib.recalgo_embedding_gather_fwd(p(ids), p(ar.weight), p(rb), B, F, K, p(x0), d, 0, st),
         B * (F * 8 + 2 * d * 4))
-    add("gather_bwd", lambda: lib.recalgo_embedding_gather_bwd(p(ids), p(g), p(rb), B, F, K, d, 0, p(ar.grad), None, st),
-        B * (F * 8 + 2 * d * 4))
-    ar.grad.zero_()
+    from recalgorithm_amd import sparse as sp
+    owner = sp.plan_of(ar) is not None
+    if not owner:
+        add("gather_bwd", lambda: lib.recalgo_embedding_gather_bwd(p(ids), p(g), p(rb), B, F, K, d, 0, p(ar.grad), None, st),
+            B * (F * 8 + 2 * d * 4))
+        ar.grad.zero_()
+    else:
+        # owner-computes scatter fused with the optimizer (csrc/sparse.hip): `prepare` (bucket counts + deferred-Adam
+        # catch-up of the batch's rows; before the forward gather) and `place` + `apply` (keys into buckets, LDS sort,
+        # per-row sums in request order, TF1 Adam on the owned rows; + the sweep of 1/P of the arena).  Timed on a scratch
+        # copy of the arena's state in the state the timed steps left it in; lr = 0.
+        import copy
+        sc = copy.copy(ar)
+        sc.weight, sc.m, sc.v, sc.grad = ar.weight.clone(), ar.m.clone(), ar.v.clone(), ar.grad
+        pl0 = sp.plan_of(ar)
+        sc.sparse = sp.ArenaPlan(sc)
+        if pl0.last_step is not None:
+            sc.sparse.last_step, sc.sparse.lr_ring = pl0.last_step.clone(), pl0.lr_ring.clone()
+        sc.sparse.betas = pl0.betas
+        lazy = pl0.last_step is None
+        step_dev = store.opt_state["step"]
+        distinct = int(torch.unique((ids + rb.unsqueeze(0))[ids >= 0]).numel())
+
+        def prep_only():
+            with torch.enable_grad():
+                sp.begin_lookup(sc, store, ids, None, rb, 0, B, F)
+            sc.sparse.sources = []                  # (the counts stay: they are never consumed by this loop)
+
+        def sparse_step():
+            with torch.enable_grad():
+                src = sp.begin_lookup(sc, store, ids, None, rb, 0, B, F)
+            src.set_grad(g)
+            sp.apply(sc, lazy, step_dev, 0.0, 0.9, 0.999, 1e-8)
+        sparse_step()
+        n_req = B * F
+        rows_sweep = 0 if lazy else -(-ar.weight.shape[0] // sp.sweep_period())
+        alg_prep = n_req * 8 + n_req * 4
+        alg_apply = n_req * (8 + 8 + 8) + n_req * K * 4 + distinct * (6 * K * 4 + 8) + rows_sweep * 4
+        add("scatter_prepare(bucket counts + deferred-Adam catch-up)", prep_only, alg_prep)
+        sc.sparse.counted = None
+        add("scatter_prepare+place+apply(sort, row sums, Adam on owned rows, sweep)", sparse_step, alg_prep + alg_apply)
+        res[-1]["distinct_rows"] = distinct
+        res[-1]["requests"] = n_req
+        del sc
     if args.model == "dcn":
         L = 3
         w = torch.randn(L, d, device=device) * 0.05
@@ -371,6 +414,27 @@ def kernel_rooflines(args, est, feats, device):
             add("ffm_pairs_fwd", lambda: lib.recalgo_ffm_pairs_fwd(p(xf), B, F, K, p(o), st), B * (F * (F - 1) * K + 1) * 4)
             add("ffm_pairs_bwd", lambda: lib.recalgo_ffm_pairs_bwd(p(xf), p(go), B, F, K, p(dxf), st),
                 B * (2 * F * (F - 1) * K + 1) * 4)
+    # the fused logit head + sigmoid + cross-entropy + head backward launch (csrc/mlp.hip) on this model's head shape
+    # (DCN: concat[cross out d, dnn out 128]; the others: the last hidden layer) and the step's one input copy
+    import ctypes as _ct
+    head_parts = [torch.randn(B, d, device=device), torch.randn(B, 128, device=device)] if args.model == "dcn" else \
+        [torch.randn(B, 128, device=device)]
+    hw = [torch.randn(t.shape[1], device=device) * 0.05 for t in head_parts]
+    hb = torch.zeros(1, device=device)
+    lbl = (torch.rand(B, device=device) < 0.04).float()
+    Ch = sum(t.shape[1] for t in head_parts)
+    rows_p = int(lib.recalgo_logit_loss_partial_rows(B))
+    partials = torch.empty(rows_p, Ch + 2, device=device)
+    lg, pr, dl = torch.empty(B, 1, device=device), torch.empty(B, 1, device=device), torch.empty(B, 1, device=device)
+    hdx = [torch.empty_like(t) for t in head_parts]
+    ptrs = lambda ts: (_ct.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    wi = (_ct.c_int * len(head_parts))(*[t.shape[1] for t in head_parts])
+    pa, pw, pdx = ptrs(head_parts), ptrs(hw), ptrs(hdx)
+    add("logit_loss(head + sigmoid + CE + head backward)",
+        lambda: lib.recalgo_logit_loss_fwd_bwd(pa, pw, wi, len(head_parts), p(hb), None, None, p(lbl), None, B, 1.0, p(lg), p(pr),
+                                               p(dl), pdx, p(partials), st), B * (2 * Ch * 4 + 16) + rows_p * (Ch + 2) * 4)
+    src_b, dst_b = torch.empty(B * F * 8 + B * 4, dtype=torch.uint8, device=device), torch.empty(B * F * 8 + B * 4, dtype=torch.uint8, device=device)
+    add("input_copy(batch -> the graph's static buffers)", lambda: dst_b.copy_(src_b), 2 * src_b.numel())
     # context MLP on the fp32 matrix cores (csrc/dense.hip): forward (bias + ReLU fused) and the merged backward launch
     # (input + weight gradient tiles, ReLU mask and bias gradient fused) of the three layers 416 -> 512 -> 256 -> 128
     from recalgorithm_amd import ops
@@ -408,27 +472,31 @@ def kernel_rooflines(args, est, feats, device):
     # gradient has ever reached have g = m = v = 0, for which the dense update is the identity.
     # Algorithmic bytes: 28 B per parameter of a live row (g, m, v, p in; p, m, v out) + 4 B per list entry + 28 B per
     # dense parameter.
-    n = ar.weight.numel()
-    _, lst, cnt = ar.live_state()
-    n_rows_live = int(cnt.item())
-    arenas = [a for a in store.arenas.values() if a.weight is not None]
+    arenas = [a for a in store.arenas.values() if a.weight is not None and sp.plan_of(a) is None]
     n_dense = 0 if store.flat is None else store.flat.numel()
     live_bytes = sum(int(a.live_state()[2].item()) * (a.K * 28 + 4) for a in arenas)
-    add("adam_tf1_step(dense + arenas)", lambda: ops.adam_tf1_step_(store.flat, store.flat_grad, store.flat_m, store.flat_v, arenas,
-                                                                     store.opt_state["step"], None, 0.0, lazy=args.lazy_adam),
+    add("adam_tf1_step(dense variables" + (" + live-list arenas)" if arenas else ")"),
+        lambda: ops.adam_tf1_step_(store.flat, store.flat_grad, store.flat_m, store.flat_v, arenas,
+                                   store.opt_state["step"], None, 0.0, lazy=args.lazy_adam),
         live_bytes + n_dense * 28)
-    res[-1]["live_fraction"] = round(n_rows_live * K / max(n, 1), 4)
+    res[-1]["live_fraction"] = round(live_fraction(est), 4)
     return res
 
 
 def live_fraction(est) -> float:
     """Fraction of the embedding parameters whose row a gradient has reached (= what the optimizer walks every step)."""
+    from recalgorithm_amd import sparse as sp
     tot = live = 0
     for a in est.store.arenas.values():
         if a.weight is None:
             continue
         tot += a.weight.numel()
-        live += int(a.live_state()[2].item()) * a.K
+        pl = sp.plan_of(a)
+        if pl is not None:          # owner path: a row is live once it carries Adam state
+            n_live = int((pl.last_step != 0).sum()) if pl.last_step is not None else int(((a.m != 0) | (a.v != 0)).any(dim=1).sum())
+        else:
+            n_live = int(a.live_state()[2].item())
+        live += n_live * a.K
     return live / max(tot, 1)
 
 
@@ -471,12 +539,24 @@ def optimizer_state_sweep(args, r, device, rank, world):
         pts.append({"phase": f"fresh batches {c0}..{c0 + n - 1} (never repeated)", "live_fraction": round(live_fraction(est), 4),
                     "ms_per_step": round(ms, 4)})
         del fresh
+    from recalgorithm_amd import sparse as sp
     for a in est.store.arenas.values():
-        if a.weight is not None and a.tracks_live_rows:
+        if a.weight is None:
+            continue
+        pl = sp.plan_of(a)
+        if pl is not None and pl.last_step is not None:
+            # deferred-exact Adam: every row carries optimizer state (as after a long run) and is current — from here on
+            # the sweep and the catch-ups replay real updates for all of them
+            sp.sync(a, est.store.opt_state["step"], 0)
+            never = pl.last_step == 0
+            a.m[never] = 1e-3
+            a.v[never] = 1e-6
+            pl.last_step.copy_(est.store.opt_state["step"].to(torch.int32).expand_as(pl.last_step))
+        elif pl is None and a.tracks_live_rows:
             a.force_all_live()
     fresh = fresh_batches(total, 24)
     timed(fresh[:4])
-    pts.append({"phase": "every row forced live (TF1 dense Adam at full cost)", "live_fraction": round(live_fraction(est), 4),
+    pts.append({"phase": "every row forced live (TF1 dense Adam semantics over the whole table)", "live_fraction": round(live_fraction(est), 4),
                 "ms_per_step": round(timed(fresh[4:]), 4)})
     return pts
 
@@ -591,7 +671,27 @@ def timed_run(args, device, rank, world, dist, capacity_factor):
         dist.all_reduce(ovf)
         overflow = float(ovf) > 0
     return {"est": est, "spec": spec, "feats": feats, "workload": workload, "dt": dt, "loss": float(loss), "graphed": graphed,
-            "launch": launch, "overflow": overflow, "chunk_ms": chunk_ms}
+            "launch": launch, "overflow": overflow, "chunk_ms": chunk_ms, "step_fn": step}
+
+
+def extra_model(a, name, steps, device):
+    """One more model of the target list in the same process: build, capture, warm up, time `steps` steps, per-kernel
+    table; returns the compact entry of the bench line's `models` list."""
+    a.model, a.steps, a.warmup, a.sweep_batches = name, steps, 10, 0
+    r = timed_run(a, device, 0, 1, None, a.capacity_factor)
+    e = {"model": name, "workload": r["workload"], "examples_per_s": round(a.batch * steps / r["dt"], 1),
+         "ms_per_step": round(r["dt"] / steps * 1e3, 4), "steps": steps, "launch": r["launch"], "final_loss": round(r["loss"], 6),
+         "live_fraction": round(live_fraction(r["est"]), 4)}
+    cs = sorted(r["chunk_ms"])
+    if cs:
+        e["ms_per_step_p10_p50_p90"] = [cs[min(len(cs) - 1, int(q * len(cs)))] for q in (0.1, 0.5, 0.9)]
+    if not a.no_kernel_timing:
+        ks = kernel_rooflines(a, r["est"], r["feats"], device)
+        dom = max(ks, key=lambda k: k["avg_us"])
+        e["roofline"] = {"kernel": dom["kernel"], "bound": dom["bound"], "frac": dom["frac"], "avg_us": dom["avg_us"],
+                         "achieved": dom.get("achieved_TFLOPs", dom["achieved_GBs"]), "unit": "TFLOP/s" if dom["bound"] == "mfma" else "GB/s"}
+        e["kernels"] = [{"kernel": k["kernel"], "avg_us": k["avg_us"], "bound": k["bound"], "frac": k["frac"]} for k in ks]
+    return e
 
 
 def main():
@@ -666,8 +766,9 @@ def main():
                    "emb_dim": args.emb, "embedding_rows": int(sum(spec.vocabs)),
                    "optimizer": ("LazyAdam on the embedding tables (DEVIATION from the reference's tf.train.AdamOptimizer: rows without a "
                                  "gradient in a step keep weights and moments), Adam on the dense variables" if args.lazy_adam else
-                                 "TF1 Adam, dense semantics over all tables (only rows a gradient has ever reached are visited: "
-                                 "identity update elsewhere)"),
+                                 "TF1 Adam, dense semantics over all tables, evaluated lazily but EXACTLY (csrc/sparse.hip: a row's g = 0 "
+                                 "updates are replayed bit-identically when the row is next read, swept or flushed), fused with the "
+                                 "row-gradient scatter"),
                    "launch": launch,
                    "dense_layers": ("hipBLASLt (RECALGO_DENSE=blas), " + ("TunableOp" if args.tunable else "default selection")
                                     if os.environ.get("RECALGO_DENSE") == "blas" else
@@ -698,6 +799,22 @@ def main():
         if fm is not None:
             est.store.flat_m.copy_(fm); est.store.flat_v.copy_(fv)
         del snap, fm, fv
+    if world == 1 and r["graphed"] is not None:
+        # real percentiles for the headline state (the driver's --steps 20 is ONE chunk): 400 more steps on the same
+        # rotating batches, a HIP event after every step
+        try:
+            step_fn = r["step_fn"]
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(401)]
+            torch.cuda.synchronize()
+            evs[0].record()
+            for i in range(400):
+                step_fn(i)
+                evs[i + 1].record()
+            evs[-1].synchronize()
+            per = sorted(x.elapsed_time(y) for x, y in zip(evs, evs[1:]))
+            out["headline_state_400_steps_ms_p10_p50_p90"] = [round(per[40], 4), round(per[200], 4), round(per[360], 4)]
+        except Exception as e:
+            print(f"[bench] percentile run failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
     sweep = None
     if args.sweep_batches > 0 and world == 1:
         try:
@@ -706,6 +823,11 @@ def main():
             print(f"[bench] optimizer-state sweep failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
     if sweep:
         out["optimizer_state_sweep"] = sweep
+        last = sweep[-1]
+        # what a long training run converges to: every row carries optimizer state
+        out["steady_state"] = {"live_fraction": last["live_fraction"], "ms_per_step": last["ms_per_step"],
+                               "examples_per_s": round(world * args.batch / (last["ms_per_step"] * 1e-3), 1),
+                               "phase": last["phase"]}
     if rank == 0:
         if ks:
             dom = max(ks, key=lambda k: k["avg_us"])
@@ -738,6 +860,19 @@ def main():
             out["step_hbm"] = {"alg_bytes_hot_path_kernels": int(hb), "ms_per_step": out["ms_per_step"],
                                "achieved_GBs": round(hb / (out["ms_per_step"] * 1e-3) / 1e9, 1),
                                "frac_of_peak": round(hb / (out["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if args.model == "dcn" and world == 1 and not args.no_extra_models and not args.big_table_rows:
+            # the other three models BASELINE.json's target names, each its own build / capture / timed run in this process
+            del est, r
+            torch.cuda.empty_cache()
+            out["models"] = [{"model": "dcn", "examples_per_s": out["value"], "ms_per_step": out["ms_per_step"],
+                              "roofline": {k: out["roofline"][k] for k in ("kernel", "bound", "frac", "avg_us")} if "roofline" in out else None}]
+            import copy
+            for name, steps in (("deepfm", 300), ("xdeepfm", 60), ("din", 200)):
+                try:
+                    out["models"].append(extra_model(copy.copy(args), name, steps, device))
+                except Exception as e:      # never take the headline line down
+                    out["models"].append({"model": name, "error": f"{type(e).__name__}: {e}"})
+                torch.cuda.empty_cache()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(out), flush=True)

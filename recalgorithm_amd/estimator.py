@@ -219,19 +219,50 @@ def _tree_tensors(obj, prefix=""):
             yield from _tree_tensors(obj[k], f"{prefix}/{k}")
 
 
+def _byte_span(t: torch.Tensor):
+    """[lo, hi) byte range of the storage that tensor t covers."""
+    lo = t.storage_offset() * t.element_size()
+    if t.numel() == 0:
+        return lo, lo
+    last = sum((d - 1) * st for d, st in zip(t.shape, t.stride()))
+    return lo, lo + (last + 1) * t.element_size()
+
+
 def _clone_tree(obj):
     """Deep copy of a (features, labels) tree of tensors / Ragged / dicts that preserves storage sharing: tensors that
-    are views of one allocation become views (same offset / strides) of ONE cloned allocation."""
+    are views of one allocation become views (same relative offsets / strides) of ONE cloned allocation — of the byte
+    span the views cover, not of the whole storage (a batch that is a slice of a device-resident dataset must not
+    duplicate the dataset)."""
     from .feature_column import Ragged
+    spans = {}
+
+    def scan(o):
+        if isinstance(o, torch.Tensor):
+            lo, hi = _byte_span(o)
+            key = o.untyped_storage().data_ptr()
+            a, b = spans.get(key, (lo, hi))
+            spans[key] = (min(a, lo), max(b, hi))
+        elif isinstance(o, Ragged):
+            scan(o.values); scan(o.offsets)
+        elif isinstance(o, dict):
+            for v in o.values():
+                scan(v)
+        elif isinstance(o, (tuple, list)):
+            for v in o:
+                scan(v)
+    scan(obj)
     storages = {}
 
     def cl(t):
         st = t.untyped_storage()
         key = st.data_ptr()
+        lo, hi = spans[key]
+        lo -= lo % 16                                           # keep every view's alignment
         if key not in storages:
-            whole = torch.empty(0, dtype=torch.uint8, device=t.device).set_(st, 0, (st.nbytes(),), (1,))
-            storages[key] = whole.clone().untyped_storage()
-        return torch.empty(0, dtype=t.dtype, device=t.device).set_(storages[key], t.storage_offset(), t.shape, t.stride())
+            part = torch.empty(0, dtype=torch.uint8, device=t.device).set_(st, lo, (max(hi - lo, 0),), (1,))
+            storages[key] = part.clone().untyped_storage()
+        off = t.storage_offset() - lo // t.element_size()
+        return torch.empty(0, dtype=t.dtype, device=t.device).set_(storages[key], off, t.shape, t.stride())
 
     def walk(o):
         if isinstance(o, torch.Tensor):
@@ -285,21 +316,27 @@ class GraphedTrainStep:
         allocation with the same layout on both sides (the 26 id columns of one [B, F] matrix)
         are moved by a single whole-allocation copy."""
         new = list(_tree_tensors(features, "f")) + list(_tree_tensors(labels, "l"))
-        whole = {}
+        groups = {}
         for (k0, dst), (k1, src) in zip(self._static, new):
             if k0 != k1 or dst.shape != src.shape:
                 raise ValueError(f"graphed step: input {k1} changed shape/structure")
-            ds, ss = dst.untyped_storage(), src.untyped_storage()
-            if (dst.dtype == src.dtype and dst.stride() == src.stride() and ds.nbytes() == ss.nbytes()
-                    and dst.storage_offset() == src.storage_offset() and src.device == dst.device):
-                whole.setdefault((ds.data_ptr(), ss.data_ptr()), (dst, src))
+            if dst.dtype == src.dtype and dst.stride() == src.stride() and src.device == dst.device:
+                groups.setdefault((dst.untyped_storage().data_ptr(), src.untyped_storage().data_ptr()), []).append((dst, src))
             else:
                 dst.copy_(src, non_blocking=True)
-        for dst, src in whole.values():
-            n = dst.untyped_storage().nbytes() // dst.element_size()
-            d = torch.empty(0, dtype=dst.dtype, device=dst.device).set_(dst.untyped_storage(), 0, (n,), (1,))
-            s_ = torch.empty(0, dtype=src.dtype, device=src.device).set_(src.untyped_storage(), 0, (n,), (1,))
-            d.copy_(s_, non_blocking=True)
+        for pairs in groups.values():
+            # views of one allocation on both sides with the same relative layout: ONE copy of the byte span they cover
+            d_lo = min(_byte_span(d)[0] for d, _ in pairs); d_hi = max(_byte_span(d)[1] for d, _ in pairs)
+            s_lo = min(_byte_span(s_)[0] for _, s_ in pairs); s_hi = max(_byte_span(s_)[1] for _, s_ in pairs)
+            same = d_hi - d_lo == s_hi - s_lo and all(_byte_span(d)[0] - d_lo == _byte_span(s_)[0] - s_lo for d, s_ in pairs)
+            if len(pairs) > 1 and same and d_hi > d_lo:
+                d0, s0 = pairs[0]
+                dv = torch.empty(0, dtype=torch.uint8, device=d0.device).set_(d0.untyped_storage(), d_lo, (d_hi - d_lo,), (1,))
+                sv = torch.empty(0, dtype=torch.uint8, device=s0.device).set_(s0.untyped_storage(), s_lo, (s_hi - s_lo,), (1,))
+                dv.copy_(sv, non_blocking=True)
+            else:
+                for d, s_ in pairs:
+                    d.copy_(s_, non_blocking=True)
 
     def __call__(self, features=None, labels=None):
         if features is not None:
@@ -639,7 +676,10 @@ class Estimator:
             prefix = tf_checkpoint.latest_checkpoint(path)
             if prefix is None:
                 raise FileNotFoundError(f"load_tf_checkpoint: no `checkpoint` state file in {path}")
-        values = tf_checkpoint.read_checkpoint(prefix)
+        # optimizer slots (3x the embedding tables in host memory) are never read: load_variables ignores them anyway
+        names = [n for n in tf_checkpoint.list_variables(prefix)
+                 if not (n.endswith("/Adam") or n.endswith("/Adam_1") or n in ("beta1_power", "beta2_power"))]
+        values = tf_checkpoint.read_checkpoint(prefix, names=names)
         self.load_variables(values, strict=strict)
         return int(values["global_step"]) if "global_step" in values else 0
 
@@ -676,19 +716,29 @@ class Estimator:
 
 def collect_checkpoint_state(store: VariableStore, global_step: int):
     """-> (state dict, this rank writes it).  COLLECTIVE when arenas are row-sharded (parallel.attach_data_parallel): the
-    weight / m / v shards are all_gather'ed back into whole tables, so the file is independent of the number of ranks
-    (restore happens before re-sharding); only rank 0 writes."""
-    from . import parallel
-    variables = {k: v.detach().cpu() for k, v in store.named_arrays(gather=True).items()}   # (flushes deferred Adam first)
-    arena_m, arena_v, writer = {}, {}, True
+    weight / m / v shards are assembled into whole tables in the HOST memory of rank 0 only, through a bounded device
+    window (parallel.gather_arena_to_host) — no rank ever holds a whole table on its GPU and the other ranks copy nothing
+    to their hosts; the file is independent of the number of ranks (restore happens before re-sharding)."""
+    from . import parallel, sparse
+    sparse.sync_store(store)                                   # deferred Adam: every row reflects all completed steps
+    sharded = {n: a for n, a in store.arenas.items() if getattr(a, "sharding", None) is not None}
+    writer = all(a.sharding.sh.rank == 0 for a in sharded.values())
+    variables = {n: v.data.detach().cpu() for n, v in store.vars.items()} if writer else {}
+    arena_m, arena_v = {}, {}
     for n, a in store.arenas.items():
-        sd = getattr(a, "sharding", None)
-        if sd is not None:
-            arena_m[n] = parallel.unshard_arena(a, "m").cpu()
-            arena_v[n] = parallel.unshard_arena(a, "v").cpu()
-            writer = writer and sd.sh.rank == 0
+        if n in sharded:
+            full = {what: parallel.gather_arena_to_host(a, what, 0) for what in ("weight", "m", "v")}
+            if writer:
+                for tn, (rb, vocab) in a.tables.items():
+                    variables[tn] = a.shaped(tn, full["weight"][rb:rb + vocab])
+                arena_m[n], arena_v[n] = full["m"], full["v"]
         else:
-            arena_m[n], arena_v[n] = a.m.cpu(), a.v.cpu()
+            if writer:
+                for tn in a.tables:
+                    variables[tn] = a.table_view(tn).detach().cpu()
+                arena_m[n], arena_v[n] = a.m.cpu(), a.v.cpu()
+    if not writer:
+        return None, False
     state = {
         "global_step": int(global_step),
         "variables": variables,
@@ -697,7 +747,7 @@ def collect_checkpoint_state(store: VariableStore, global_step: int):
         "arena_m": arena_m, "arena_v": arena_v,
         "opt_step": None if store.opt_state is None else int(store.opt_state["step"]),
     }
-    return state, writer
+    return state, True
 
 
 def restore_checkpoint_state(store: VariableStore, state: dict, device, where: str = "checkpoint") -> int:

@@ -202,7 +202,7 @@ def read_checkpoint(prefix: str, names: Optional[List[str]] = None, verify_crc: 
             raise ValueError(f"tf checkpoint: {name}: data file is shorter than the index says")
         if verify_data_crc and e["crc32c"] is not None and _mask(crc32c(raw.tobytes())) != e["crc32c"]:
             raise ValueError(f"tf checkpoint: {name}: tensor checksum mismatch")
-        out[name] = np.frombuffer(raw.tobytes(), dtype=dt).reshape(e["shape"]).copy()
+        out[name] = np.array(raw.view(dt).reshape(e["shape"]))          # one copy, straight off the memmap slice
     if want is not None and want - set(out):
         raise KeyError(f"tf checkpoint: not in {prefix}: {sorted(want - set(out))[:5]}")
     return out

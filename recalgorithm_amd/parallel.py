@@ -363,6 +363,39 @@ def unshard_arena(arena: EmbeddingArena, what: str = "weight") -> torch.Tensor:
     return full
 
 
+def gather_arena_to_host(arena: EmbeddingArena, what: str = "weight", dst_rank: int = 0,
+                         window_rows: int = 1 << 20) -> Optional[torch.Tensor]:
+    """COLLECTIVE.  The [global_rows, K] tensor of a row-sharded arena assembled in HOST memory on `dst_rank` only (None on
+    the other ranks), through a bounded device window: per round every rank contributes at most `window_rows` of its local
+    rows (64 MB at K = 16), the rounds are all_gather'ed (the one collective every backend in use here offers) and only the
+    writer copies them out.  No rank ever holds a whole table on its GPU — the point of sharding at construction; the
+    all_gather of whole padded shards (unshard_arena) needs ~2x the table per GPU and the same again per rank on the host."""
+    sd: Sharding = arena.sharding
+    sh = sd.sh
+    local = getattr(arena, what)
+    K = local.shape[1]
+    n_max = (sd.global_rows + sh.world - 1) // sh.world
+    writer = sh.rank == dst_rank
+    full = torch.empty(sd.global_rows, K, dtype=local.dtype) if writer else None
+    for r0 in range(0, n_max, window_rows):
+        n = min(window_rows, n_max - r0)
+        piece = torch.zeros(n, K, dtype=local.dtype, device=local.device)
+        have = max(0, min(n, local.shape[0] - r0))
+        if have:
+            piece[:have] = local[r0:r0 + have]
+        parts = [torch.empty_like(piece) for _ in range(sh.world)]
+        sh.dist.all_gather(parts, piece, group=sh.group)
+        if writer:
+            for r, part in enumerate(parts):
+                n_r = (sd.global_rows - r + sh.world - 1) // sh.world          # local rows of rank r
+                cnt = max(0, min(n, n_r - r0))
+                if cnt:
+                    # local row l of rank r is global row l * world + r
+                    full[(r0 * sh.world + r)::sh.world][:cnt] = part[:cnt].cpu()
+        del parts, piece
+    return full
+
+
 class _ShardAtBuild:
     """Carried by the VariableStore from attach_data_parallel to the end of the build: every arena is materialised
     as this rank's rows only (EmbeddingArena.materialize(shard=...)) and gets its Sharding."""
@@ -415,9 +448,19 @@ def attach_data_parallel(est, dist=None, group=None, local_gather=hip_local_gath
 
 
 def exchange_overflowed(est) -> bool:
-    """True if any static exchange bucket overflowed since attach (reads the device flags)."""
-    return any(bool(a.sharding.overflow.item()) for a in est.store.arenas.values()
-               if getattr(a, "sharding", None) is not None and a.sharding.overflow is not None)
+    """True if any static exchange bucket overflowed ON ANY RANK since attach.  COLLECTIVE (every rank must call it at
+    the same point): the per-rank device flags are max-reduced over the group first, so that all ranks see the same
+    answer and raise — or carry on — together; a rank that raised alone would leave its peers blocked in their next
+    all_to_all / all_gather until the RCCL timeout."""
+    flags = [a.sharding.overflow for a in est.store.arenas.values()
+             if getattr(a, "sharding", None) is not None and a.sharding.overflow is not None]
+    if not flags:
+        return False
+    sh = next((getattr(a.sharding, "sh", None) for a in est.store.arenas.values() if getattr(a, "sharding", None) is not None), None)
+    any_flag = torch.stack([f.reshape(-1)[0].to(torch.int32) for f in flags]).max().reshape(1)
+    if sh is not None and sh.world > 1:
+        sh.dist.all_reduce(any_flag, op=sh.dist.ReduceOp.MAX, group=sh.group)
+    return bool(any_flag.item())
 
 
 class HostStagedCollectives:

@@ -235,6 +235,22 @@ def _worker_ckpt(rank, port, errq, tmpdir, WORLD=2):
         Estimator.save_checkpoint(stub)
         files = sorted(os.listdir(tmpdir))
         assert files == ["model.ckpt.pt"], files                                   # no stray tmp file, one writer
+        # the gather behind it: whole tables only in the HOST memory of rank 0, through a bounded window (every
+        # rank used to all_gather 2x the table onto its GPU and copy all of it to its host)
+        for win in (3, 1 << 20):
+            got = P.gather_arena_to_host(ar, "m", 0, window_rows=win)
+            assert (got is None) == (rank != 0)
+            if rank == 0:
+                assert got.device.type == "cpu" and torch.equal(got, g + 0.25)
+        # the overflow poll is collective: a flag raised on ONE rank is seen by every rank (the rank that raised
+        # alone left its peers blocked in the next collective)
+        sd = ar.sharding
+        had = sd.overflow
+        sd.overflow = torch.tensor([rank == 1])
+        assert P.exchange_overflowed(est) is True
+        sd.overflow = torch.tensor([False])
+        assert P.exchange_overflowed(est) is False
+        sd.overflow = had
         state = torch.load(os.path.join(tmpdir, "model.ckpt.pt"), weights_only=True)
         fresh, far = build()                                                       # unsharded, single process
         assert restore_checkpoint_state(fresh, state, torch.device("cpu")) == 9

@@ -111,6 +111,14 @@ ADAM_P2 = np.array([ADAM_P1[0] - _LRT2 * 0.5 / (math.sqrt(0.75) + 0.125),
                     1.0 - _LRT2 * 2.0 / (2.0 + 0.125),
                     1.0])
 
+# LazyAdamOptimizer (tf.contrib.opt; the reference's DIEN, dien.py:328), same hyper-parameters, slices instead of dense g:
+# step 1: slices {row 0: 2.0}                         -> as ADAM_P1 (rows 1, 2 untouched)
+# step 2: slices {row 1: 1.0, row 1: 3.0, row 0: 0.0} -> duplicates are summed first (row 1: g = 4, ONE update);
+#         row 0 is IN the slices with g = 0: it takes the update (m = .5, v = .75, moves like the dense form);
+#         had row 0 NOT been in the slices it would have kept p, m, v — the only difference to the dense optimizer.
+LAZY_P2_ROW0_IN = ADAM_P2.copy()
+LAZY_P2_ROW0_OUT = np.array([ADAM_P1[0], ADAM_P2[1], 1.0])
+
 # A-11  tf.nn.conv1d(value (B, W, C), filters (1, C, N), stride 1, VALID) == value[b, w, :] @ filters[0]
 CONV_V = np.array([[[1., 2., 3.], [4., 5., 6.]]])                            # (1, 2, 3)
 CONV_F = np.array([[[1., 0.], [0., 1.], [2., -1.]]])                         # (1, 3, 2)
@@ -351,6 +359,23 @@ def test_a10_adam_oracle():
     R.adam_tf1_step(p, torch.from_numpy(ADAM_G2), m, v, 2, ADAM["lr"], ADAM["beta1"], ADAM["beta2"], ADAM["eps"])
     np.testing.assert_allclose(p.numpy(), ADAM_P2, rtol=1e-15)
     assert float(p[0]) != ADAM_P1[0] and float(p[2]) == 1.0               # dense decay moves row 0; row 2 is inert
+
+
+def test_a10_lazy_adam_oracle():
+    """oracle.ref_ops.lazy_adam_step against the hand-derived answers above."""
+    for row0_in, want in ((True, LAZY_P2_ROW0_IN), (False, LAZY_P2_ROW0_OUT)):
+        p = torch.from_numpy(ADAM_P0.copy()).reshape(3, 1)
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        R.lazy_adam_step(p, torch.tensor([0]), torch.tensor([[2.0]], dtype=torch.float64), m, v, 1,
+                         ADAM["lr"], ADAM["beta1"], ADAM["beta2"], ADAM["eps"])
+        np.testing.assert_allclose(p.numpy().ravel(), ADAM_P1, rtol=1e-15)
+        idx = [1, 1] + ([0] if row0_in else [])
+        val = [[1.0], [3.0]] + ([[0.0]] if row0_in else [])
+        R.lazy_adam_step(p, torch.tensor(idx), torch.tensor(val, dtype=torch.float64), m, v, 2,
+                         ADAM["lr"], ADAM["beta1"], ADAM["beta2"], ADAM["eps"])
+        np.testing.assert_allclose(p.numpy().ravel(), want, rtol=1e-15)
+        np.testing.assert_allclose(m.numpy().ravel(), [0.5 if row0_in else 1.0, 2.0, 0.0], rtol=1e-15)
+        np.testing.assert_allclose(v.numpy().ravel(), [0.75 if row0_in else 1.0, 4.0, 0.0], rtol=1e-15)
 
 
 def test_a10_adam_shim(tf):
