@@ -134,12 +134,12 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 # =============================================================================================
 class _GatherFn(Function):
     @staticmethod
-    def forward(ctx, anchor, ids, arena: EmbeddingArena, row_base):
+    def forward(ctx, anchor, ids, arena: EmbeddingArena, row_base, training=False):
         B, F = ids.shape
         K = arena.K
         out = torch.empty(B, F * K, device=ids.device, dtype=torch.float32)
         # owner-computes scatter (sparse.py): the lookup joins the arena's plan; deferred-Adam rows are caught up first
-        ctx.src = sparse.begin_lookup(arena, anchor_store(anchor), ids, None, row_base, 0, B, F)
+        ctx.src = sparse.begin_lookup(arena, anchor_store(anchor), ids, None, row_base, 0, B, F, training)
         _lib.check(_lib_().recalgo_embedding_gather_fwd(
             _p(ids), _p(arena.weight), _p(row_base), B, F, K, _p(out), F * K, 0, _stream(ids)),
             "recalgo_embedding_gather_fwd")
@@ -152,18 +152,18 @@ class _GatherFn(Function):
         B, F = ids.shape
         if ctx.src is not None:
             ctx.src.set_grad(g)              # summed per row (and applied) by the optimizer's recalgo_scatter_apply
-            return None, None, None, None
+            return None, None, None, None, None
         g = g.contiguous()
         if _sorted_scatter():
             rows = torch.where(ids >= 0, ids + ctx.row_base.unsqueeze(0), torch.full_like(ids, -1))
             scatter_rows_sorted(arena, rows, g.reshape(B * F, arena.K))
             _flush(arena)
-            return None, None, None, None
+            return None, None, None, None, None
         _lib.check(_lib_().recalgo_embedding_gather_bwd(
             _p(ids), _p(g), _p(ctx.row_base), B, F, arena.K, F * arena.K, 0, _p(arena.grad), _live(arena),
             _stream(ids)), "recalgo_embedding_gather_bwd")
         _flush(arena)
-        return None, None, None, None
+        return None, None, None, None, None
 
 
 def embedding_gather(store: VariableStore, ids: torch.Tensor, arena: EmbeddingArena,
@@ -174,13 +174,13 @@ def embedding_gather(store: VariableStore, ids: torch.Tensor, arena: EmbeddingAr
     if getattr(arena, "sharding", None) is not None:
         from . import parallel
         _, staged, ident = _staged(arena, parallel.global_rows(ids, row_base))
-        return _GatherFn.apply(store.anchor, ident.reshape(ids.shape), staged, torch.zeros_like(row_base))
-    return _GatherFn.apply(store.anchor, ids, arena, row_base)
+        return _GatherFn.apply(store.anchor, ident.reshape(ids.shape), staged, torch.zeros_like(row_base), False)
+    return _GatherFn.apply(store.anchor, ids, arena, row_base, torch.is_grad_enabled())
 
 
 class _BagMeanFn(Function):
     @staticmethod
-    def forward(ctx, anchor, values, offsets, arena: EmbeddingArena, table_name):
+    def forward(ctx, anchor, values, offsets, arena: EmbeddingArena, table_name, training=False):
         B = offsets.numel() - 1
         K = arena.K
         table = arena.table_view(table_name)
@@ -189,7 +189,7 @@ class _BagMeanFn(Function):
         if table_name != "__staged__" and values.numel():
             # one request per bag entry; its gradient row (g[bag] / count) is expanded in the backward
             ctx.src = sparse.begin_lookup(arena, anchor_store(anchor), values, None, None, arena.tables[table_name][0],
-                                          values.numel(), 1)
+                                          values.numel(), 1, training)
         _lib.check(_lib_().recalgo_embedding_bag_mean_fwd(
             _p(values), _p(offsets), _p(table), B, K, _p(out), K, 0, _stream(offsets)),
             "recalgo_embedding_bag_mean_fwd")
@@ -210,15 +210,15 @@ class _BagMeanFn(Function):
             vals = g[bag] / cnt[bag].unsqueeze(1)
             if ctx.src is not None:
                 ctx.src.set_grad(vals)
-                return None, None, None, None, None
+                return None, None, None, None, None, None
             scatter_rows_sorted(arena, torch.where(values >= 0, values + rb, torch.full_like(values, -1)), vals)
             _flush(arena)
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         _lib.check(_lib_().recalgo_embedding_bag_mean_bwd(
             _p(values), _p(offsets), _p(g), B, arena.K, arena.K, 0, _p(gt), _live(arena, rb), _stream(offsets)),
             "recalgo_embedding_bag_mean_bwd")
         _flush(arena)
-        return None, None, None, None, None
+        return None, None, None, None, None, None
 
 
 def embedding_bag_mean(store, values, offsets, arena, table_name) -> torch.Tensor:
@@ -227,13 +227,13 @@ def embedding_bag_mean(store, values, offsets, arena, table_name) -> torch.Tenso
     if getattr(arena, "sharding", None) is not None:
         rows = torch.where(values >= 0, values + arena.tables[table_name][0], torch.full_like(values, -1))
         _, staged, ident = _staged(arena, rows)
-        return _BagMeanFn.apply(store.anchor, ident, offsets, staged, "__staged__")
-    return _BagMeanFn.apply(store.anchor, values, offsets, arena, table_name)
+        return _BagMeanFn.apply(store.anchor, ident, offsets, staged, "__staged__", False)
+    return _BagMeanFn.apply(store.anchor, values, offsets, arena, table_name, torch.is_grad_enabled())
 
 
 class _SeqGatherFn(Function):
     @staticmethod
-    def forward(ctx, anchor, values, offsets, arena: EmbeddingArena, table_name, T):
+    def forward(ctx, anchor, values, offsets, arena: EmbeddingArena, table_name, T, training=False):
         B = offsets.numel() - 1
         K = arena.K
         table = arena.table_view(table_name)
@@ -241,7 +241,7 @@ class _SeqGatherFn(Function):
         seq_len = torch.empty(B, device=offsets.device, dtype=torch.int32)
         ctx.src = None
         if table_name != "__staged__":
-            ctx.src = sparse.begin_lookup(arena, anchor_store(anchor), values, offsets, None, arena.tables[table_name][0], B, T)
+            ctx.src = sparse.begin_lookup(arena, anchor_store(anchor), values, offsets, None, arena.tables[table_name][0], B, T, training)
         _lib.check(_lib_().recalgo_sequence_gather_fwd(
             _p(values), _p(offsets), _p(table), B, T, K, _p(out), _p(seq_len), _stream(offsets)),
             "recalgo_sequence_gather_fwd")
@@ -257,7 +257,7 @@ class _SeqGatherFn(Function):
         gt = arena.grad[rb:rb + vocab]
         if ctx.src is not None:
             ctx.src.set_grad(g)
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         g = g.contiguous()
         if _sorted_scatter():
             lens = (offsets[1:] - offsets[:-1]).clamp(max=T)
@@ -267,12 +267,12 @@ class _SeqGatherFn(Function):
             ids_bt = torch.where(valid, values[src] if values.numel() else torch.full_like(src, -1), torch.full_like(src, -1))
             scatter_rows_sorted(arena, torch.where(ids_bt >= 0, ids_bt + rb, torch.full_like(ids_bt, -1)), g.reshape(B * T, arena.K))
             _flush(arena)
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         _lib.check(_lib_().recalgo_sequence_gather_bwd(
             _p(values), _p(offsets), _p(g), B, T, arena.K, _p(gt), _live(arena, rb), _stream(offsets)),
             "recalgo_sequence_gather_bwd")
         _flush(arena)
-        return None, None, None, None, None, None
+        return None, None, None, None, None, None, None
 
 
 def sequence_gather(store, values, offsets, arena, table_name, T) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -281,8 +281,8 @@ def sequence_gather(store, values, offsets, arena, table_name, T) -> Tuple[torch
     if getattr(arena, "sharding", None) is not None:
         rows = torch.where(values >= 0, values + arena.tables[table_name][0], torch.full_like(values, -1))
         _, staged, ident = _staged(arena, rows)
-        return _SeqGatherFn.apply(store.anchor, ident, offsets, staged, "__staged__", int(T))
-    return _SeqGatherFn.apply(store.anchor, values, offsets, arena, table_name, int(T))
+        return _SeqGatherFn.apply(store.anchor, ident, offsets, staged, "__staged__", int(T), False)
+    return _SeqGatherFn.apply(store.anchor, values, offsets, arena, table_name, int(T), torch.is_grad_enabled())
 
 
 # =============================================================================================
@@ -290,7 +290,7 @@ def sequence_gather(store, values, offsets, arena, table_name, T) -> Tuple[torch
 # =============================================================================================
 class _DeepFMSparseFn(Function):
     @staticmethod
-    def forward(ctx, anchor, ids, arena: EmbeddingArena, w1: EmbeddingArena, bias: Variable, row_base):
+    def forward(ctx, anchor, ids, arena: EmbeddingArena, w1: EmbeddingArena, bias: Variable, row_base, training=False):
         B, F = ids.shape
         K = arena.K
         emb = torch.empty(B, F * K, device=ids.device, dtype=torch.float32)
@@ -298,8 +298,8 @@ class _DeepFMSparseFn(Function):
         fm2 = torch.empty(B, 1, device=ids.device, dtype=torch.float32)
         fsum = torch.empty(B, K, device=ids.device, dtype=torch.float32)
         st = anchor_store(anchor)
-        ctx.src = sparse.begin_lookup(arena, st, ids, None, row_base, 0, B, F)
-        ctx.src1 = sparse.begin_lookup(w1, st, ids, None, row_base, 0, B, F) if ctx.src is not None else None
+        ctx.src = sparse.begin_lookup(arena, st, ids, None, row_base, 0, B, F, training)
+        ctx.src1 = sparse.begin_lookup(w1, st, ids, None, row_base, 0, B, F, training) if ctx.src is not None else None
         _lib.check(_lib_().recalgo_deepfm_sparse_fwd(
             _p(ids), _p(arena.weight), _p(w1.weight), _p(bias.data), _p(row_base), B, F, K,
             _p(emb), _p(fm1), _p(fm2), _p(fsum), _stream(ids)), "recalgo_deepfm_sparse_fwd")
@@ -320,7 +320,7 @@ class _DeepFMSparseFn(Function):
             ctx.src.set_grad(vals)
             ctx.src1.set_grad(g_fm1.reshape(B, 1), fmul=0)      # every field of example b adds g_fm1[b] to its w1 row
             torch.sum(g_fm1, dim=0, out=bias.grad.view(1))
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         if _sorted_scatter():
             K = arena.K
             rows = torch.where(ids >= 0, ids + row_base.unsqueeze(0), torch.full_like(ids, -1))
@@ -331,14 +331,14 @@ class _DeepFMSparseFn(Function):
             _flush(arena)
             _flush(w1)
             torch.sum(g_fm1, dim=0, out=bias.grad.view(1))
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         _lib.check(_lib_().recalgo_deepfm_sparse_bwd(
             _p(ids), _p(emb), _p(fsum), _p(g_emb), _p(g_fm1), _p(g_fm2), _p(row_base), B, F, arena.K,
             _p(arena.grad), _p(w1.grad), _live(arena), _live(w1), _stream(ids)), "recalgo_deepfm_sparse_bwd")
         _flush(arena)
         _flush(w1)
         torch.sum(g_fm1, dim=0, out=bias.grad.view(1))
-        return None, None, None, None, None, None
+        return None, None, None, None, None, None, None
 
 
 def deepfm_sparse(store, ids, arena, w1_arena, bias, row_base):
@@ -350,8 +350,8 @@ def deepfm_sparse(store, ids, arena, w1_arena, bias, row_base):
         plan, staged, ident = _staged(arena, parallel.global_rows(ids, row_base))
         staged_w1 = parallel.StagedArena(plan, w1_arena)
         return _DeepFMSparseFn.apply(store.anchor, ident.reshape(ids.shape), staged, staged_w1, bias,
-                                     torch.zeros_like(row_base))
-    return _DeepFMSparseFn.apply(store.anchor, ids, arena, w1_arena, bias, row_base)
+                                     torch.zeros_like(row_base), False)
+    return _DeepFMSparseFn.apply(store.anchor, ids, arena, w1_arena, bias, row_base, torch.is_grad_enabled())
 
 
 # =============================================================================================

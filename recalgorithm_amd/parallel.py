@@ -343,6 +343,7 @@ def shard_arena_(arena: EmbeddingArena, sh: ShardSpec, local_gather=hip_local_ga
     take = lambda t: t[sh.rank::sh.world].contiguous().clone()
     arena.weight, arena.grad, arena.m, arena.v = take(arena.weight), take(arena.grad), take(arena.m), take(arena.v)
     arena.live = None           # live-row bookkeeping is rebuilt for the shard on next use
+    arena.__dict__.pop("sparse", None)   # (owner-computes plan of the unsharded arena: callers sync it before re-sharding)
     arena.sharding = Sharding(sh, rows, local_gather, local_scatter_add, capacity_factor, planner, dedup)
 
 
@@ -431,6 +432,8 @@ def attach_data_parallel(est, dist=None, group=None, local_gather=hip_local_gath
 
     if est._built:
         sync_dense()
+        from . import sparse
+        sparse.sync_store(est.store)          # deferred Adam of the unsharded arenas: finish it before slicing w / m / v
         for ar in est.store.arenas.values():
             shard_arena_(ar, sh, **kw)
     else:

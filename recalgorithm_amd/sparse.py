@@ -149,12 +149,14 @@ def plan_of(arena) -> Optional[ArenaPlan]:
 
 
 def begin_lookup(arena, store, ids: torch.Tensor, offsets: Optional[torch.Tensor], row_base: Optional[torch.Tensor],
-                 base: int, n_ex: int, F: int) -> Optional[Source]:
+                 base: int, n_ex: int, F: int, training: Optional[bool] = None) -> Optional[Source]:
     """Called by a lookup's forward BEFORE its gather kernel.  Returns the Source to attach the gradient to (training,
     owner mode), or None.  Whatever the mode of the call: on an arena with deferred-Adam state the requested rows are
     brought up to date first, so every forward reads current weights."""
     plan = plan_of(arena)
-    training = torch.is_grad_enabled() and getattr(arena, "trainable", True)
+    if training is None:                       # (inside an autograd Function's forward grad mode is always off: callers
+        training = torch.is_grad_enabled()     #  there pass the mode of the CALL)
+    training = bool(training) and getattr(arena, "trainable", True)
     if plan is None:
         if not (training and scatter_mode() == "owner" and _supported(arena)):
             return None
@@ -230,7 +232,7 @@ def _run(plan: ArenaPlan, sources: List[Source], mode: int, step_dev, step_offse
     d = plan._deferred_struct() if mode == MODE_ADAM else None
     b1, b2, eps = plan.betas
     p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
-    grad = a.grad if (mode == MODE_GRAD or plan.grad_materialized) else None
+    grad = a._grad if (mode == MODE_GRAD or plan.grad_materialized) else None
     _lib.check(lib.recalgo_scatter_apply(arr, len(srcs), a.K, p(plan.ws), plan.capacity, plan.nb_log2, mode, p(a.weight), p(a.m),
                                          p(a.v), p(grad), None if d is None else ctypes.byref(d), a.weight.shape[0],
                                          sweep_period(), live, p(step_dev), step_offset, lr, b1, b2, eps, _stream(a.weight)),
@@ -260,17 +262,22 @@ def apply(arena, lazy: bool, step_dev: torch.Tensor, lr: float, beta1: float, be
     plan.grad_materialized = False
 
 
+def materialize_arena(arena) -> None:
+    """arena.grad += the summed row gradients of the pending sources (what reading `arena.grad` triggers; the optimizer
+    does not need it)."""
+    plan = plan_of(arena)
+    if plan is None or plan.grad_materialized:
+        return
+    sources = [s for s in plan.sources if s.g is not None]
+    if not sources:
+        return
+    plan.grad_materialized = True              # (set first: _run reads the raw arena._grad, never the property)
+    _run(plan, sources, MODE_GRAD, None, 0, 0.0)
+
+
 def materialize_grads(store) -> None:
-    """arena.grad += the summed row gradients of the pending sources (tests, tools; the optimizer does not need it)."""
     for ar in store.arenas.values():
-        plan = plan_of(ar)
-        if plan is None or plan.grad_materialized:
-            continue
-        sources = [s for s in plan.sources if s.g is not None]
-        if not sources:
-            continue
-        _run(plan, sources, MODE_GRAD, None, 0, 0.0)
-        plan.grad_materialized = True
+        materialize_arena(ar)
 
 
 def sync(arena, step_dev: Optional[torch.Tensor], step_offset: int = 0) -> None:

@@ -303,11 +303,26 @@ class EmbeddingArena:
         self._init: Dict[str, torch.Tensor] = {}
         self.rows = 0
         self._gen = torch.Generator().manual_seed(seed)
-        self.weight = self.grad = self.m = self.v = None
+        self.weight = self._grad = self.m = self.v = None
         self.live = self.live_list = self.live_count = None   # live-row bookkeeping (see live_state)
         self._live_rows = -1
         self._order_ws = None                                  # order_live_list's scratch
         self.trainable = True
+
+    @property
+    def grad(self) -> Optional[torch.Tensor]:
+        """The gradient arena [rows, K].  On the owner-computes path (sparse.py) the row gradients of a backward pass stay
+        with the lookups' gradient matrices until the optimizer consumes them; whoever READS this attribute before that
+        (tests, tools, named_grads) gets them summed into the arena first (recalgo_scatter_apply, GRAD mode)."""
+        plan = self.__dict__.get("sparse")
+        if plan is not None and plan.sources and not plan.grad_materialized:
+            from . import sparse
+            sparse.materialize_arena(self)
+        return self._grad
+
+    @grad.setter
+    def grad(self, value) -> None:
+        self._grad = value
 
     def add_table(self, name: str, vocab: int, init: Optional[torch.Tensor] = None,
                   view_shape: Optional[Sequence[int]] = None) -> int:

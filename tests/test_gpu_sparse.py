@@ -263,6 +263,7 @@ def test_models_train_identically_on_the_owner_and_the_sorted_paths(dev, monkeyp
     """DCN, three steps: the owner-computes path (deferred Adam) and the round-2 deterministic path (sorted scatter +
     live-list dense Adam) agree — the same arithmetic, summed in a different order."""
     from recalgorithm_amd import feature_column as fc
+    from recalgorithm_amd import sparse
     from recalgorithm_amd.algorithm.DCN.dcn import dcn_model_fn
     from recalgorithm_amd.estimator import Estimator, RunConfig
     from recalgorithm_amd.io import synth
@@ -279,6 +280,12 @@ def test_models_train_identically_on_the_owner_and_the_sorted_paths(dev, monkeyp
             feats, labels, _ = synth.device_features(spec, 128, dev, batch_index=i)
             est.build(feats, labels)
             losses.append(float(est.train_step(feats, labels)))
+        plans = [sparse.plan_of(a) for a in est.store.arenas.values()]
+        if mode == "owner":                    # the path under test really ran: deferred state exists, no live list was built
+            assert all(pl is not None and pl.last_step is not None for pl in plans)
+            assert all(a.live is None for a in est.store.arenas.values())
+        else:
+            assert all(pl is None for pl in plans)
         results[mode] = (losses, {k: v.detach().cpu().double() for k, v in est.store.named_arrays().items()})
     for a, b in zip(*[results[m][0] for m in ("owner", "sorted")]):
         assert abs(a - b) <= 1e-5 * abs(b)
