@@ -586,7 +586,10 @@ int recalgo_activation_bwd(const float* x, const float* alpha, const float* gy, 
  *   recalgo_scatter_prepare  once per source, any time before `apply` (normally right before the lookup's forward
  *                            kernel): adds the source's requests to the plan's bucket counts, and — with `deferred` —
  *                            first brings every requested row's (w, m, v) up to step  step_dev[0] + step_offset.
- *                            plan_workspace may be NULL (catch-up only).
+ *                            plan_workspace may be NULL (catch-up only).  first_request = the source's position in the
+ *                            plan's request space: source k of `apply` starts at the sum over the sources before it of
+ *                            recalgo_scatter_plan_padded_requests(n_ex * F) (each source padded to a whole number of
+ *                            workgroups); plan_requests counts the padded space.
  *   recalgo_scatter_apply    once per plan, with the SAME sources in the SAME order (their g now set): two launches.
  *                            Requests are grouped by row (hash buckets, sorted inside a bucket by (row, request
  *                            index)); the owner of a row adds its gradient rows in request order — no atomics,
@@ -609,7 +612,7 @@ int recalgo_activation_bwd(const float* x, const float* alpha, const float* gy, 
  * The workspace (recalgo_scatter_plan_workspace_bytes(plan_requests, nb_log2), nb_log2 =
  * recalgo_scatter_plan_buckets_log2(plan_requests)) must be zero-filled once before its first use.
  * ------------------------------------------------------------------------------------------ */
-#define RECALGO_SCATTER_MAX_SOURCES 4
+#define RECALGO_SCATTER_MAX_SOURCES 16
 #define RECALGO_LR_RING 1024
 #define RECALGO_SCATTER_GRAD 0
 #define RECALGO_SCATTER_ADAM 1
@@ -632,9 +635,10 @@ typedef struct {
 } recalgo_deferred_adam_t;
 int recalgo_scatter_plan_buckets_log2(int64_t n_requests);
 int64_t recalgo_scatter_plan_workspace_bytes(int64_t n_requests, int nb_log2);
+int64_t recalgo_scatter_plan_padded_requests(int64_t n_requests);
 int recalgo_scatter_prepare(const recalgo_scatter_source_t* source, int K, void* plan_workspace, int64_t plan_requests,
-                            int nb_log2, const recalgo_deferred_adam_t* deferred, const int64_t* step_dev,
-                            int step_offset, recalgo_stream_t stream);
+                            int nb_log2, int64_t first_request, const recalgo_deferred_adam_t* deferred,
+                            const int64_t* step_dev, int step_offset, recalgo_stream_t stream);
 int recalgo_scatter_apply(const recalgo_scatter_source_t* sources, int n_sources, int K, void* plan_workspace,
                           int64_t plan_requests, int nb_log2, int mode, float* w, float* m, float* v, float* grad,
                           const recalgo_deferred_adam_t* deferred, int64_t rows, int sweep_period,

@@ -1,24 +1,30 @@
-// Row-gradient scatter WITHOUT float atomics, fused with the sparse optimizer, gfx950.
+// Row-gradient scatter WITHOUT atomics, fused with the sparse optimizer, gfx950.
 //
 // The backward of every embedding lookup is  dTable[row] += g[request]  over the requests (b, f) of the batch
-// (Appendix D "Gather"); CTR ids are Zipf distributed, so thousands of requests hit the same row.  Rounds 1-2 combined
-// duplicates in an LDS hash table per workgroup and then issued one device-scope float atomic per (distinct row, float,
-// workgroup) — ~1.1 M fabric atomics per DCN step, the weakest kernel of every model (0.08 of HBM in the step), order
-// non-deterministic, and the summed gradient arena was then re-read (and zeroed) by the optimizer launch.
+// (Appendix D "Gather"); CTR ids are Zipf distributed and real tables include two-valued fields, so one row can own
+// two thirds of a batch's requests of its field.  Rounds 1-2 combined duplicates in an LDS hash table per workgroup and
+// then issued one device-scope float atomic per (distinct row, float, workgroup) — ~1.1 M fabric atomics per DCN step,
+// the weakest kernel of every model (0.08 of HBM in the step), order non-deterministic, and the summed gradient arena was
+// then re-read (and zeroed) by the optimizer launch.
 //
-// Here the scatter is OWNER-COMPUTES:
-//   1. `prepare` (one launch per lookup, before its forward gather): counts the requests per bucket
-//      (bucket = hash(row), kNB .. 4*kNB buckets) and — deferred Adam only — brings every requested row's (w, m, v) up to
-//      date (see "deferred exact Adam" below) so that the unchanged forward kernels read current weights;
-//   2. `place` (one launch per arena and step, after the backward pass): exclusive scan of the bucket counts, every
-//      request is written as a (row << 32 | request index) key into its bucket's range; extra workgroups of the same
+// Here the scatter is OWNER-COMPUTES, built on a deterministic STABLE MULTISPLIT of the requests by bucket = hash(row)
+// (no atomics on global memory anywhere, no sort):
+//   1. `prepare` (one launch per lookup, before its forward gather): workgroup w of the plan's request space (256
+//      consecutive requests) writes its bucket histogram as row w of a count matrix C[W][nb] (plain stores) and —
+//      deferred Adam only — brings every requested row's (w, m, v) up to date (see below), so that the unchanged forward
+//      kernels read current weights;
+//   2. `scan` (one launch per arena and step, after the backward pass): exclusive prefix of every column of C over the
+//      workgroups, and the bucket totals;
+//   3. `place`: request i of workgroup w goes to  offs[b] + Cp[w][b] + (number of earlier requests of w in bucket b):
+//      every bucket receives its requests IN REQUEST ORDER, independent of scheduling.  Extra workgroups of the same
 //      launch run the deferred-Adam sweep;
-//   3. `apply` (one workgroup per bucket): sorts the bucket's keys in LDS (bitonic; oversize buckets: LDS-sorted runs +
-//      merge passes in global memory), so that all requests of a row are adjacent and in request order; a group of
-//      K/4 lanes owns a row: it adds the row's gradient rows IN REQUEST ORDER (bit-reproducible), and — the row being
-//      exclusively its own — finishes the job in registers: TF1 Adam (dense semantics, exact), LazyAdam, or a plain
-//      `grad[row] += sum` store for callers that want the gradient arena.  No float atomics anywhere, no gradient arena
-//      round trip, no live-row list.
+//   4. `apply` (one workgroup per bucket): a STABLE group-by-row of the bucket (small buckets: rank by comparison; large
+//      ones: LDS hash of the distinct rows + stable counting scatter), after which all requests of a row are adjacent and
+//      still in request order.  A group of K/4 lanes owns a row: it adds the row's gradient rows IN REQUEST ORDER
+//      (bit-reproducible; rows with many requests are summed by the whole workgroup in a fixed strided order), and — the
+//      row being exclusively its own — finishes the job in registers: TF1 Adam (dense semantics, exact), LazyAdam, or a
+//      plain `grad[row] += sum` store for callers that want the gradient arena.  No gradient arena round trip, no
+//      live-row list.
 //
 // Deferred exact Adam.  tf.train.AdamOptimizer applies a DENSE update to embedding variables: m, v of every row decay
 // and w moves every step, gradient or not (deepfm.py:246-250).  Rounds 1-2 walked every row a gradient
@@ -30,6 +36,7 @@
 // pass (tests/test_gpu_sparse.py), at the cost of the batch's rows.  lr_t of recent steps comes from a small ring
 // written by the optimizer launch; the sweep (1/P of the arena per step, contiguous rows) bounds every row's lag to
 // P + 1 steps so that the ring and the replay loops stay short.
+#include <cstddef>
 #include <cstdlib>
 
 #include "common.h"
@@ -38,12 +45,14 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxSources = RECALGO_SCATTER_MAX_SOURCES;
-static_assert(kMaxSources == 4, "load_g / place select among exactly four sources");
 constexpr unsigned kLrRing = RECALGO_LR_RING;           // power of two
-constexpr unsigned kSortCap = 2048;                     // keys sorted in LDS per run (16 KB)
+constexpr unsigned kLdsKeys = 2048;                     // grouped keys kept in LDS (16 KB); larger buckets go through global memory
+constexpr unsigned kSlots = 512;                        // LDS hash of the distinct rows of a large bucket
+constexpr unsigned kMaxSeg = 512;                       // rows (segments) of a bucket listed in LDS
 constexpr unsigned kLongSeg = 48;                       // requests per row above which the whole workgroup sums it
 constexpr unsigned kMaxLong = 64;                       // long rows remembered per bucket (more: summed by one group)
 constexpr unsigned long long kPadKey = ~0ull;
+constexpr unsigned kEmptyRow = 0xffffffffu;
 
 struct SrcDev {
     const int64_t* ids;
@@ -55,6 +64,19 @@ struct SrcDev {
     long long g_stride;
     unsigned g_col, g_fmul;
 };
+
+// Copy `bytes` of the kernel's (single, by-value) argument struct, starting at byte `offset`, into LDS — one dword per
+// thread, read straight from the kernarg segment.  (Indexing a by-value kernel-argument array with a data-dependent
+// index makes the compiler copy the array to scratch first.)
+__device__ __forceinline__ void copy_kernarg_words(unsigned* dst, size_t offset, size_t bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using ka_ptr = const unsigned __attribute__((address_space(4)))*;
+    ka_ptr ka = (ka_ptr)__builtin_amdgcn_kernarg_segment_ptr() + offset / 4;
+    for (unsigned w = threadIdx.x; w < bytes / 4; w += kThreads) dst[w] = ka[w];
+#else
+    (void)dst; (void)offset; (void)bytes;
+#endif
+}
 
 // arena row of local request i of source S, -1: no row (OOV id, beyond the sequence's length)
 __device__ __forceinline__ long long src_row(const SrcDev& S, unsigned i) {
@@ -162,11 +184,11 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned* sh, un
 }
 
 // ---------------------------------------------------------------------------------------------
-// 1. prepare: bucket counts of one lookup's requests (+ deferred-Adam catch-up of the requested rows)
+// 1. prepare: row w of the count matrix for one lookup's workgroups (+ deferred-Adam catch-up of the requested rows)
 // ---------------------------------------------------------------------------------------------
 struct PrepareArgs {
-    SrcDev S;
-    int* cnt;                      // [nb] bucket counts of the plan being assembled (nullptr: catch-up only)
+    SrcDev S;                      // S.first = the source's first request in the plan (a multiple of kThreads)
+    unsigned short* C;             // [W][nb] request counts per (workgroup, bucket); nullptr: catch-up only
     unsigned nb_log2;
     Deferred D;                    // D.last_step == nullptr: no catch-up
     const long long* step;         // catch-up target = step[0] + step_off
@@ -182,7 +204,7 @@ __global__ __launch_bounds__(kThreads) void sparse_prepare_kernel(PrepareArgs A)
     long long* stale_row = reinterpret_cast<long long*>(lds_u + nb);   // [kThreads]
     int* stale_s = reinterpret_cast<int*>(stale_row + kThreads);        // [kThreads]
     unsigned* n_stale = reinterpret_cast<unsigned*>(stale_s + kThreads);
-    if (A.cnt)
+    if (A.C)
         for (unsigned b = threadIdx.x; b < nb; b += kThreads) hist[b] = 0;
     if (threadIdx.x == 0) *n_stale = 0;
     __syncthreads();
@@ -190,7 +212,7 @@ __global__ __launch_bounds__(kThreads) void sparse_prepare_kernel(PrepareArgs A)
     const long long row = i < A.S.n ? src_row(A.S, i) : -1;
     const int target = A.D.last_step ? (int)(A.step[0] + A.step_off) : 0;
     if (row >= 0) {
-        if (A.cnt) atomicAdd(&hist[bucket_of((unsigned)row, A.nb_log2)], 1u);
+        if (A.C) atomicAdd(&hist[bucket_of((unsigned)row, A.nb_log2)], 1u);     // (LDS)
         if (A.D.last_step) {
             // hot rows are current (their last_step is the previous step): only stale rows cost an atomic, and exactly one
             // of the requests of a stale row wins the claim
@@ -203,24 +225,52 @@ __global__ __launch_bounds__(kThreads) void sparse_prepare_kernel(PrepareArgs A)
         }
     }
     __syncthreads();
-    if (A.cnt)
-        for (unsigned b = threadIdx.x; b < nb; b += kThreads) {
-            const unsigned h = hist[b];
-            if (h) atomicAdd(&A.cnt[b], (int)h);
-        }
+    if (A.C) {
+        unsigned short* crow = A.C + ((size_t)(A.S.first / kThreads) + blockIdx.x) * nb;
+        for (unsigned b = threadIdx.x; b < nb; b += kThreads) crow[b] = (unsigned short)hist[b];
+    }
     const unsigned ns = *n_stale;
     const unsigned q = threadIdx.x & (A.L - 1), grp = threadIdx.x / A.L, ngrp = kThreads / A.L;
     for (unsigned k = grp; k < ns; k += ngrp) catch_up_row<VEC>(A.D, stale_row[k], stale_s[k], target, q, A.KV);
 }
 
 // ---------------------------------------------------------------------------------------------
-// 2. place: keys into bucket ranges (+ the deferred-Adam sweep in extra workgroups)
+// 2. scan: Cp[w][b] = sum_{w' < w} C[w'][b],  total[b] = sum_w C[w][b]
+//    workgroup = 16 columns x 16 row lanes; a lane owns a contiguous range of the W rows
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void sparse_scan_kernel(const unsigned short* __restrict__ C, unsigned* __restrict__ Cp,
+                                                               unsigned* __restrict__ total, unsigned W, unsigned nb) {
+    __shared__ unsigned part[16][17];
+    const unsigned c = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const unsigned col = blockIdx.x * 16 + c;
+    const unsigned Q = (W + 15) / 16;
+    const unsigned r0 = min(W, r * Q), r1 = min(W, r0 + Q);
+    unsigned s = 0;
+#pragma unroll 8
+    for (unsigned row = r0; row < r1; ++row) s += C[(size_t)row * nb + col];
+    part[r][c] = s;
+    __syncthreads();
+    unsigned run = 0;
+#pragma unroll
+    for (unsigned k = 0; k < 16; ++k)
+        if (k < r) run += part[k][c];
+    if (r == 15) total[col] = run + s;
+#pragma unroll 8
+    for (unsigned row = r0; row < r1; ++row) {
+        const unsigned v = C[(size_t)row * nb + col];
+        Cp[(size_t)row * nb + col] = run;
+        run += v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3. place: keys into bucket ranges in request order (+ the deferred-Adam sweep in extra workgroups)
 // ---------------------------------------------------------------------------------------------
 struct PlaceArgs {
     SrcDev src[kMaxSources];
     int n_src;
     unsigned n_total, req_blocks;
-    int* cnt; int* cursor; int* offs;          // [nb], [nb], [nb + 1]
+    const unsigned* total; const unsigned* Cp; unsigned* offs;      // [nb], [W][nb], [nb + 1]
     unsigned long long* keys;                  // [n_total]
     unsigned nb_log2;
     // sweep (deferred Adam): rows [c * chunk, (c + 1) * chunk), c = target % period, are brought to `target`
@@ -238,9 +288,9 @@ __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
         const int target = (int)(A.step[0] + A.step_off);
         if (target <= 0) return;
         const long long c0 = (long long)(target % A.period) * A.chunk;
-        const long long idx = (long long)(blockIdx.x - A.req_blocks) * kThreads + threadIdx.x;
+        const unsigned idx = (blockIdx.x - A.req_blocks) * kThreads + threadIdx.x;
         const long long row = c0 + idx / A.L;
-        const unsigned q = (unsigned)(idx & (A.L - 1));
+        const unsigned q = idx & (A.L - 1);
         if (row >= A.rows || row >= c0 + A.chunk) return;
         const int s = A.D.last_step[row];
         if (s > 0 && s < target) catch_up_row<VEC>(A.D, row, s, target, q, A.KV);
@@ -249,55 +299,54 @@ __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
     extern __shared__ unsigned lds_u[];
     const unsigned nb = 1u << A.nb_log2, bpt = nb / kThreads;   // nb is a multiple of kThreads
     unsigned* offs = lds_u;                                   // [nb]
-    unsigned* hist = offs + nb;                               // [nb]
-    unsigned* base = hist + nb;                               // [nb]
-    unsigned* sh = base + nb;                                 // [8]
+    unsigned* bk = offs + nb;                                 // [kThreads] bucket of every request of this workgroup
+    unsigned* sh = bk + kThreads;                             // [8]
+    // the source descriptors go to LDS: a data-dependent index into the kernel-argument array would go through scratch
+    SrcDev* lsrc = reinterpret_cast<SrcDev*>(sh + 8);         // [kMaxSources]
+    copy_kernarg_words(reinterpret_cast<unsigned*>(lsrc), offsetof(PlaceArgs, src), sizeof(SrcDev) * kMaxSources);
     {
         unsigned sum = 0;
-        for (unsigned k = 0; k < bpt; ++k) sum += (unsigned)A.cnt[threadIdx.x * bpt + k];
+        for (unsigned k = 0; k < bpt; ++k) sum += A.total[threadIdx.x * bpt + k];
         unsigned total;
         unsigned run = block_excl_scan(sum, sh, total);
         for (unsigned k = 0; k < bpt; ++k) {
             const unsigned b = threadIdx.x * bpt + k;
             offs[b] = run;
-            hist[b] = 0;
-            if (blockIdx.x == 0) A.offs[b] = (int)run;
-            run += (unsigned)A.cnt[b];
+            if (blockIdx.x == 0) A.offs[b] = run;
+            run += A.total[b];
         }
-        if (blockIdx.x == 0 && threadIdx.x == kThreads - 1) A.offs[nb] = (int)total;
+        if (blockIdx.x == 0 && threadIdx.x == kThreads - 1) A.offs[nb] = total;
     }
     __syncthreads();
     const unsigned i = blockIdx.x * kThreads + threadIdx.x;
     long long row = -1;
     if (i < A.n_total) {
-        int s = 0;
+        unsigned si = 0;                                      // (unused sources have first = 0xffffffff)
 #pragma unroll
-        for (int k = 1; k < kMaxSources; ++k)
-            if (k < A.n_src && i >= A.src[k].first) s = k;
-        SrcDev S = A.src[0];
-#pragma unroll
-        for (int k = 1; k < kMaxSources; ++k)
-            if (s == k) S = A.src[k];
-        row = src_row(S, i - S.first);
+        for (int k = 1; k < kMaxSources; ++k) si += i >= lsrc[k].first;
+        const SrcDev S = lsrc[si];
+        if (i - S.first < S.n) row = src_row(S, i - S.first);     // (the padding between two sources holds no request)
     }
-    const unsigned b = row >= 0 ? bucket_of((unsigned)row, A.nb_log2) : 0;
-    if (row >= 0) atomicAdd(&hist[b], 1u);
-    __syncthreads();
-    for (unsigned k = 0; k < bpt; ++k) {
-        const unsigned bin = threadIdx.x * bpt + k;
-        const unsigned h = hist[bin];
-        base[bin] = h ? (unsigned)atomicAdd(&A.cursor[bin], (int)h) : 0u;
-        hist[bin] = 0;
-    }
+    const unsigned b = row >= 0 ? bucket_of((unsigned)row, A.nb_log2) : 0xffffffffu;
+    bk[threadIdx.x] = b;
     __syncthreads();
     if (row >= 0) {
-        const unsigned r = atomicAdd(&hist[b], 1u);           // order inside a bucket is arbitrary: `apply` sorts
-        A.keys[offs[b] + base[b] + r] = ((unsigned long long)row << 32) | i;
+        // stable: the number of EARLIER requests of this workgroup that go to the same bucket
+        unsigned r = 0;
+        const uint4* bk4 = reinterpret_cast<const uint4*>(bk);
+#pragma unroll 16                                              // (16 LDS reads in flight: the loop is latency bound otherwise)
+        for (unsigned j4 = 0; j4 < kThreads / 4; ++j4) {
+            const uint4 v = bk4[j4];
+            const unsigned j = 4 * j4;
+            r += (v.x == b && j < threadIdx.x) + (v.y == b && j + 1 < threadIdx.x) + (v.z == b && j + 2 < threadIdx.x) +
+                 (v.w == b && j + 3 < threadIdx.x);
+        }
+        A.keys[offs[b] + A.Cp[(size_t)blockIdx.x * nb + b] + r] = ((unsigned long long)row << 32) | i;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// 3. apply
+// 4. apply
 // ---------------------------------------------------------------------------------------------
 struct GSrc {                      // what `apply` needs of a source: where the gradient row of a request is
     const float* g;
@@ -307,8 +356,8 @@ struct GSrc {                      // what `apply` needs of a source: where the 
 struct ApplyArgs {
     GSrc src[kMaxSources];
     int n_src;
-    int* cnt; int* cursor; const int* offs;
-    unsigned long long* keys; unsigned long long* keys_alt;   // keys_alt: scratch of the same size (oversize buckets)
+    const unsigned* offs;
+    const unsigned long long* keys; unsigned long long* keys_alt;   // keys_alt: scratch of the same size (large buckets)
     int mode;                      // RECALGO_SCATTER_GRAD / _ADAM / _LAZY_ADAM
     float* w; float* m; float* v; float* grad;                // grad: GRAD target; ADAM modes: rows zeroed when non-null
     int* last_step;                // ADAM (deferred-exact) only
@@ -318,19 +367,31 @@ struct ApplyArgs {
     float lr, b1, b2, eps;
     unsigned K, KV, L;
     unsigned* live_words; int* live_list; int* live_count;    // GRAD mode: live-row bookkeeping of the old optimizer path
+    unsigned long long* dbg_buf;
 };
 
 __device__ __forceinline__ unsigned key_row(unsigned long long k) { return (unsigned)(k >> 32); }
 
-// bitonic sort of m (power of two) keys in LDS by all threads of the workgroup
+// bitonic sort of m (power of two) keys in LDS by all threads of the workgroup (fallback of `apply` only)
 __device__ __forceinline__ void lds_bitonic(unsigned long long* keys, unsigned m) {
+    const unsigned half = m >> 1;
     for (unsigned k = 2; k <= m; k <<= 1)
         for (unsigned j = k >> 1; j > 0; j >>= 1) {
-            for (unsigned t = threadIdx.x; t < (m >> 1); t += kThreads) {
-                const unsigned lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
-                const unsigned long long a = keys[lo], c = keys[hi];
-                const bool up = (lo & k) == 0;
-                if ((a > c) == up) { keys[lo] = c; keys[hi] = a; }
+            for (unsigned t0 = threadIdx.x; t0 < half; t0 += 4 * kThreads) {
+                unsigned lo[4];
+                unsigned long long a[4], c[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned t = t0 + u * kThreads;
+                    lo[u] = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    if (t < half) { a[u] = keys[lo[u]]; c[u] = keys[lo[u] | j]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned t = t0 + u * kThreads;
+                    const bool up = (lo[u] & k) == 0;
+                    if (t < half && (a[u] > c[u]) == up) { keys[lo[u]] = c[u]; keys[lo[u] | j] = a[u]; }
+                }
             }
             __syncthreads();
         }
@@ -338,30 +399,47 @@ __device__ __forceinline__ void lds_bitonic(unsigned long long* keys, unsigned m
 
 // gradient piece q of the request a key refers to
 template <int VEC>
-__device__ __forceinline__ typename Vec<VEC>::T load_g(const ApplyArgs& A, const GSrc* lsrc, unsigned long long key, unsigned q) {
+__device__ __forceinline__ typename Vec<VEC>::T load_g(const GSrc* lsrc, unsigned long long key, unsigned q) {
     using V = typename Vec<VEC>::T;
     const unsigned ref = (unsigned)key;
-    // (the descriptors live in LDS: a data-dependent index into the kernel-argument array would go through scratch;
-    //  unused sources have first = 0xffffffff)
-    const unsigned si = (ref >= A.src[1].first) + (ref >= A.src[2].first) + (ref >= A.src[3].first);
+    unsigned si = 0;                                          // (unused sources have first = 0xffffffff)
+#pragma unroll
+    for (int k = 1; k < kMaxSources; ++k) si += ref >= lsrc[k].first;
     const GSrc S = lsrc[si];
-    const float* g = S.g;
-    const long long stride = S.g_stride;
-    const unsigned col = S.g_col, fmul = S.g_fmul, F = S.F, first = S.first;
-    const unsigned i = ref - first, e = i / F, f = i - e * F;
-    return *reinterpret_cast<const V*>(g + (size_t)e * stride + col + (size_t)f * fmul + q * VEC);
+    const unsigned i = ref - S.first, e = i / S.F, f = i - e * S.F;
+    return *reinterpret_cast<const V*>(S.g + (size_t)e * S.g_stride + S.g_col + (size_t)f * S.g_fmul + q * VEC);
+}
+
+template <int VEC> struct RowState { typename Vec<VEC>::T w, m, v; int s; };
+
+// the owner's loads of a row's state, issued BEFORE the gradient rows are summed (one memory round trip, not two)
+template <int VEC>
+__device__ __forceinline__ RowState<VEC> load_state(const ApplyArgs& A, unsigned row, unsigned q) {
+    using V = typename Vec<VEC>::T;
+    RowState<VEC> st{vz<VEC>(), vz<VEC>(), vz<VEC>(), 0};
+    if (q >= A.KV) return st;
+    const size_t o = (size_t)row * A.KV + q;
+    if (A.mode == RECALGO_SCATTER_GRAD) {
+        st.w = reinterpret_cast<const V*>(A.grad)[o];
+    } else {
+        st.w = reinterpret_cast<const V*>(A.w)[o];
+        st.m = reinterpret_cast<const V*>(A.m)[o];
+        st.v = reinterpret_cast<const V*>(A.v)[o];
+        if (A.mode == RECALGO_SCATTER_ADAM) st.s = A.last_step[row];
+    }
+    return st;
 }
 
 // what the owner of a row does with the row's summed gradient
 template <int VEC>
-__device__ __forceinline__ void finish_row(const ApplyArgs& A, unsigned row, typename Vec<VEC>::T acc, unsigned q, int t, float lr_t) {
+__device__ __forceinline__ void finish_row(const ApplyArgs& A, unsigned row, RowState<VEC> st, typename Vec<VEC>::T acc, unsigned q,
+                                           int t, float lr_t) {
     using V = typename Vec<VEC>::T;
     const size_t o = (size_t)row * A.KV + q;
     if (A.mode == RECALGO_SCATTER_GRAD) {
         if (q < A.KV) {
-            V cur = reinterpret_cast<V*>(A.grad)[o];
-            vadd(cur, acc);
-            reinterpret_cast<V*>(A.grad)[o] = cur;
+            vadd(st.w, acc);
+            reinterpret_cast<V*>(A.grad)[o] = st.w;
         }
         if (q == 0 && A.live_words) {                         // first touch: the row joins the arena's live list
             const unsigned bit = 1u << (8 * (row & 3));
@@ -374,24 +452,106 @@ __device__ __forceinline__ void finish_row(const ApplyArgs& A, unsigned row, typ
         return;
     }
     if (q < A.KV) {
-        V w = reinterpret_cast<V*>(A.w)[o], m = reinterpret_cast<V*>(A.m)[o], v = reinterpret_cast<V*>(A.v)[o];
-        if (A.mode == RECALGO_SCATTER_ADAM) {
-            const int s = A.last_step[row];
-            if (s > 0 && s < t - 1) {                         // (normally done by `prepare`; kept for lookups without one)
-                Deferred D{A.w, A.m, A.v, A.last_step, A.lr_ring, A.b1, A.b2, A.eps};
-                replay<VEC>(w, m, v, s, t - 1, D);
-            }
+        if (A.mode == RECALGO_SCATTER_ADAM && st.s > 0 && st.s < t - 1) {     // (normally done by `prepare`; kept for lookups
+            Deferred D{A.w, A.m, A.v, A.last_step, A.lr_ring, A.b1, A.b2, A.eps};   //  that were registered without one)
+            replay<VEC>(st.w, st.m, st.v, st.s, t - 1, D);
         }
-        vadam(w, acc, m, v, lr_t, A.b1, A.b2, A.eps);
-        reinterpret_cast<V*>(A.w)[o] = w;
-        reinterpret_cast<V*>(A.m)[o] = m;
-        reinterpret_cast<V*>(A.v)[o] = v;
+        vadam(st.w, acc, st.m, st.v, lr_t, A.b1, A.b2, A.eps);
+        reinterpret_cast<V*>(A.w)[o] = st.w;
+        reinterpret_cast<V*>(A.m)[o] = st.m;
+        reinterpret_cast<V*>(A.v)[o] = st.v;
         if (A.grad) reinterpret_cast<V*>(A.grad)[o] = vz<VEC>();
     }
     if (q == 0 && A.mode == RECALGO_SCATTER_ADAM) A.last_step[row] = t;
 }
 
-// first index in [lo, n) whose row differs from `row` (keys sorted)
+// one row (segment [lo, hi) of the grouped keys) by one group of L lanes: gradient rows added in request order
+template <int VEC>
+__device__ __forceinline__ void short_row(const ApplyArgs& A, const GSrc* lsrc, const unsigned long long* keys, unsigned lo,
+                                          unsigned hi, unsigned q, int t, float lr_t) {
+    using V = typename Vec<VEC>::T;
+    const unsigned row = key_row(keys[lo]);
+    const RowState<VEC> st = load_state<VEC>(A, row, q);
+    V acc = vz<VEC>();
+    if (q < A.KV) {
+        unsigned j = lo;
+        for (; j + 4 <= hi; j += 4) {                         // four row loads in flight, added in request order
+            const V g0 = load_g<VEC>(lsrc, keys[j], q), g1 = load_g<VEC>(lsrc, keys[j + 1], q);
+            const V g2 = load_g<VEC>(lsrc, keys[j + 2], q), g3 = load_g<VEC>(lsrc, keys[j + 3], q);
+            vadd(acc, g0); vadd(acc, g1); vadd(acc, g2); vadd(acc, g3);
+        }
+        for (; j < hi; ++j) vadd(acc, load_g<VEC>(lsrc, keys[j], q));
+    }
+    finish_row<VEC>(A, row, st, acc, q, t, lr_t);
+}
+
+// rows with many requests: all groups of the workgroup sum strided slices, fixed-order combination through LDS
+template <int VEC>
+__device__ __forceinline__ void long_rows(const ApplyArgs& A, const GSrc* lsrc, const unsigned long long* keys,
+                                          const unsigned* long_list, unsigned nl, float* red, int t, float lr_t) {
+    using V = typename Vec<VEC>::T;
+    const unsigned L = A.L, q = threadIdx.x & (L - 1), grp = threadIdx.x / L, ngrp = kThreads / L;
+    for (unsigned k = 0; k < nl; ++k) {
+        const unsigned lo = long_list[2 * k], hi = long_list[2 * k + 1];
+        const unsigned row = key_row(keys[lo]);
+        RowState<VEC> st{vz<VEC>(), vz<VEC>(), vz<VEC>(), 0};
+        if (grp == 0) st = load_state<VEC>(A, row, q);
+        V acc = vz<VEC>();
+        if (q < A.KV) {
+            constexpr int kU = 6;                             // row loads in flight (register budget: 4 workgroups / CU)
+            unsigned j = lo + grp;
+            for (; j + (kU - 1) * ngrp < hi; j += kU * ngrp) {
+                V gq[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) gq[u] = load_g<VEC>(lsrc, keys[j + u * ngrp], q);
+#pragma unroll
+                for (int u = 0; u < kU; ++u) vadd(acc, gq[u]);
+            }
+            V gq[kU];
+            unsigned cnt = 0;
+#pragma unroll
+            for (int u = 0; u < kU; ++u)
+                if (j + u * ngrp < hi) { gq[u] = load_g<VEC>(lsrc, keys[j + u * ngrp], q); cnt = u + 1; }
+#pragma unroll
+            for (int u = 0; u < kU; ++u)
+                if ((unsigned)u < cnt) vadd(acc, gq[u]);
+            reinterpret_cast<V*>(red)[grp * A.KV + q] = acc;
+        }
+        __syncthreads();
+        if (grp == 0) {
+            V tot = vz<VEC>();
+            if (q < A.KV)
+                for (unsigned g2 = 0; g2 < ngrp; ++g2) vadd(tot, reinterpret_cast<const V*>(red)[g2 * A.KV + q]);
+            finish_row<VEC>(A, row, st, tot, q, t, lr_t);
+        }
+        __syncthreads();
+    }
+}
+
+// segments listed in LDS (seg_lo / seg_n): groups take them round robin; long rows are deferred to long_rows()
+template <int VEC>
+__device__ __forceinline__ void process_segments(const ApplyArgs& A, const GSrc* lsrc, const unsigned long long* keys,
+                                                 const unsigned* seg_lo, const unsigned* seg_n, unsigned nseg,
+                                                 unsigned* long_list, unsigned* n_long, float* red, int t, float lr_t) {
+    const unsigned L = A.L, q = threadIdx.x & (L - 1), grp = threadIdx.x / L, ngrp = kThreads / L;
+    for (unsigned h = grp; h < nseg; h += ngrp) {
+        const unsigned lo = seg_lo[h], len = seg_n[h];
+        if (len > kLongSeg) {
+            unsigned slot = kMaxLong;
+            if (q == 0) slot = atomicAdd(n_long, 1u);
+            slot = __shfl(slot, (int)((threadIdx.x & 63) & ~(L - 1)), 64);
+            if (slot < kMaxLong) {
+                if (q == 0) { long_list[2 * slot] = lo; long_list[2 * slot + 1] = lo + len; }
+                continue;
+            }
+        }
+        short_row<VEC>(A, lsrc, keys, lo, lo + len, q, t, lr_t);
+    }
+    __syncthreads();
+    long_rows<VEC>(A, lsrc, keys, long_list, min(*n_long, kMaxLong), red, t, lr_t);
+}
+
+// first index in [lo, n) whose row differs from `row` (keys grouped)
 __device__ __forceinline__ unsigned seg_end(const unsigned long long* keys, unsigned lo, unsigned n, unsigned row) {
 #pragma unroll 1
     for (unsigned k = 1; k <= 4; ++k) {                       // short rows: linear peek
@@ -405,12 +565,12 @@ __device__ __forceinline__ unsigned seg_end(const unsigned long long* keys, unsi
     return b;
 }
 
+// fallback form of process_segments for SORTED keys whose rows were not listed: every group scans a contiguous block of
+// entries for row heads and owns the rows that START in its block
 template <int VEC>
-__device__ __forceinline__ void process_sorted(const ApplyArgs& A, const GSrc* lsrc, const unsigned long long* keys, unsigned n, unsigned* long_list,
-                               unsigned* n_long, float* red, int t, float lr_t) {
-    using V = typename Vec<VEC>::T;
+__device__ __forceinline__ void process_sorted_scan(const ApplyArgs& A, const GSrc* lsrc, const unsigned long long* keys, unsigned n,
+                                                    unsigned* long_list, unsigned* n_long, float* red, int t, float lr_t) {
     const unsigned L = A.L, q = threadIdx.x & (L - 1), grp = threadIdx.x / L, ngrp = kThreads / L;
-    // every group scans a contiguous block of entries for row heads and owns the rows that START in its block
     const unsigned per = (n + ngrp - 1) / ngrp;
     unsigned i = grp * per;
     const unsigned stop = min(n, i + per);
@@ -428,54 +588,28 @@ __device__ __forceinline__ void process_sorted(const ApplyArgs& A, const GSrc* l
                 continue;
             }
         }
-        V acc = vz<VEC>();
-        if (q < A.KV) {
-            unsigned j = i;
-            for (; j + 4 <= end; j += 4) {                    // four row loads in flight, added in request order
-                const V g0 = load_g<VEC>(A, lsrc, keys[j], q), g1 = load_g<VEC>(A, lsrc, keys[j + 1], q);
-                const V g2 = load_g<VEC>(A, lsrc, keys[j + 2], q), g3 = load_g<VEC>(A, lsrc, keys[j + 3], q);
-                vadd(acc, g0); vadd(acc, g1); vadd(acc, g2); vadd(acc, g3);
-            }
-            for (; j < end; ++j) vadd(acc, load_g<VEC>(A, lsrc, keys[j], q));
-        }
-        finish_row<VEC>(A, row, acc, q, t, lr_t);
+        short_row<VEC>(A, lsrc, keys, i, end, q, t, lr_t);
         i = end;
     }
     __syncthreads();
-    // long rows: all groups of the workgroup sum strided slices, fixed-order combination through LDS
-    const unsigned nl = min(*n_long, kMaxLong);
-    for (unsigned k = 0; k < nl; ++k) {
-        const unsigned lo = long_list[2 * k], hi = long_list[2 * k + 1];
-        V acc = vz<VEC>();
-        if (q < A.KV)
-            for (unsigned j = lo + grp; j < hi; j += ngrp) vadd(acc, load_g<VEC>(A, lsrc, keys[j], q));
-        if (q < A.KV) reinterpret_cast<V*>(red)[grp * A.KV + q] = acc;
-        __syncthreads();
-        if (grp == 0) {
-            V tot = vz<VEC>();
-            if (q < A.KV)
-                for (unsigned g2 = 0; g2 < ngrp; ++g2) vadd(tot, reinterpret_cast<const V*>(red)[g2 * A.KV + q]);
-            finish_row<VEC>(A, key_row(keys[lo]), tot, q, t, lr_t);
-        }
-        __syncthreads();
-    }
+    long_rows<VEC>(A, lsrc, keys, long_list, min(*n_long, kMaxLong), red, t, lr_t);
 }
 
-// oversize bucket: sort runs of kSortCap keys in LDS, then merge passes between `a` and `b` in global memory; returns
-// the buffer holding the sorted keys
+// fallback: sort runs of kLdsKeys keys in LDS, then merge passes between `a` and `b` in global memory; returns the buffer
+// holding the sorted keys
 __device__ __forceinline__ unsigned long long* global_merge_sort(unsigned long long* a, unsigned long long* b, unsigned n,
-                                                 unsigned long long* lds_keys) {
-    for (unsigned r0 = 0; r0 < n; r0 += kSortCap) {
-        const unsigned cnt = min(kSortCap, n - r0);
-        for (unsigned k = threadIdx.x; k < kSortCap; k += kThreads) lds_keys[k] = k < cnt ? a[r0 + k] : kPadKey;
+                                                                 unsigned long long* lds_keys) {
+    for (unsigned r0 = 0; r0 < n; r0 += kLdsKeys) {
+        const unsigned cnt = min(kLdsKeys, n - r0);
+        for (unsigned k = threadIdx.x; k < kLdsKeys; k += kThreads) lds_keys[k] = k < cnt ? a[r0 + k] : kPadKey;
         __syncthreads();
-        lds_bitonic(lds_keys, kSortCap);
+        lds_bitonic(lds_keys, kLdsKeys);
         for (unsigned k = threadIdx.x; k < cnt; k += kThreads) a[r0 + k] = lds_keys[k];
         __syncthreads();
     }
     unsigned long long* src = a;
     unsigned long long* dst = b;
-    for (unsigned width = kSortCap; width < n; width <<= 1) {
+    for (unsigned width = kLdsKeys; width < n; width <<= 1) {
         for (unsigned lo = 0; lo < n; lo += 2 * width) {
             const unsigned mid = min(n, lo + width), hi = min(n, lo + 2 * width);
             const unsigned na = mid - lo, nbb = hi - mid, tot = hi - lo;
@@ -501,19 +635,40 @@ __device__ __forceinline__ unsigned long long* global_merge_sort(unsigned long l
     return src;
 }
 
+// slot of `row` in the LDS hash of a large bucket's distinct rows (insert = true: claims an empty slot); kSlots if full
+__device__ __forceinline__ unsigned hash_slot(unsigned* hrow, unsigned row, bool insert) {
+    unsigned h = (row * 0x85EBCA6Bu) >> (32 - 9);             // kSlots = 512
+#pragma unroll 1
+    for (unsigned probe = 0; probe < kSlots; ++probe) {
+        const unsigned k = hrow[h];
+        if (k == row) return h;
+        if (k == kEmptyRow) {
+            if (!insert) return kSlots;
+            const unsigned old = atomicCAS(&hrow[h], kEmptyRow, row);
+            if (old == kEmptyRow || old == row) return h;
+        }
+        h = (h + 1) & (kSlots - 1);
+    }
+    return kSlots;
+}
+
 template <int VEC>
-__global__ __launch_bounds__(kThreads) void sparse_apply_kernel(ApplyArgs A) {
-    __shared__ unsigned long long lds_keys[kSortCap];
+__global__ __launch_bounds__(kThreads, 4) void sparse_apply_kernel(ApplyArgs A) {     // 1024 workgroups resident at once
+    __shared__ unsigned long long lds_keys[kLdsKeys];         // grouped keys of buckets up to kLdsKeys requests
+    __shared__ unsigned hrow[kSlots], hcnt[kSlots], hbase[kSlots], hrun[kSlots];
+    __shared__ unsigned seg_lo[kMaxSeg], seg_n[kMaxSeg];
+    __shared__ unsigned cs[kThreads];                         // rows (small bucket) / hash slots (a chunk of a large one)
     __shared__ unsigned long_list[2 * kMaxLong];
-    __shared__ unsigned n_long;
+    __shared__ unsigned n_long, n_seg, overflow, sh[8];
     __shared__ float red[kThreads * 4];
     __shared__ float s_lr_t;
     __shared__ GSrc lsrc[kMaxSources];
     const unsigned b = blockIdx.x;
     const int t = (int)(A.step[0] + A.step_off);
+#define DBG_T(k) do { if (A.dbg_buf && threadIdx.x == 0) A.dbg_buf[(size_t)b * 8 + (k)] = wall_clock64(); } while (0)
+    DBG_T(0);
     if (threadIdx.x == 0) {
-        lsrc[0] = A.src[0]; lsrc[1] = A.src[1]; lsrc[2] = A.src[2]; lsrc[3] = A.src[3];
-        n_long = 0;
+        n_long = 0; n_seg = 0; overflow = 0;
         float lr_t = 0.f;
         if (A.mode != RECALGO_SCATTER_GRAD) {
             lr_t = lr_t_of(A.lr, A.b1, A.b2, t);
@@ -521,26 +676,130 @@ __global__ __launch_bounds__(kThreads) void sparse_apply_kernel(ApplyArgs A) {
         }
         s_lr_t = lr_t;
     }
-    const unsigned beg = (unsigned)A.offs[b], n = (unsigned)A.offs[b + 1] - beg;
+    copy_kernarg_words(reinterpret_cast<unsigned*>(lsrc), offsetof(ApplyArgs, src), sizeof(GSrc) * kMaxSources);
+    const unsigned beg = A.offs[b], n = A.offs[b + 1] - beg;
+    const unsigned long long* in = A.keys + beg;              // the bucket's keys, in request order
     __syncthreads();
     const float lr_t = s_lr_t;
-    if (n) {
-        if (n <= kSortCap) {
-            unsigned m = 2;
-            while (m < n) m <<= 1;
-            for (unsigned k = threadIdx.x; k < m; k += kThreads) lds_keys[k] = k < n ? A.keys[beg + k] : kPadKey;
-            __syncthreads();
-            lds_bitonic(lds_keys, m);
-            process_sorted<VEC>(A, lsrc, lds_keys, n, long_list, &n_long, red, t, lr_t);
-        } else {
-            const unsigned long long* sorted = global_merge_sort(A.keys + beg, A.keys_alt + beg, n, lds_keys);
-            process_sorted<VEC>(A, lsrc, sorted, n, long_list, &n_long, red, t, lr_t);
+    if (n == 0) return;
+    if (n <= kThreads) {
+        // ---- small bucket: stable rank by comparison (one request per thread) -------------------------------
+        const unsigned long long key = threadIdx.x < n ? in[threadIdx.x] : kPadKey;
+        const unsigned row = key_row(key);                    // (padding: 0xffffffff, greater than every row)
+        cs[threadIdx.x] = row;
+        __syncthreads();
+        if (threadIdx.x < n) {
+            unsigned less = 0, same_before = 0, same = 0;
+            const uint4* r4 = reinterpret_cast<const uint4*>(cs);
+#pragma unroll 8
+            for (unsigned j4 = 0; j4 < (n + 3) / 4; ++j4) {
+                const uint4 v = r4[j4];
+                const unsigned j = 4 * j4;
+                less += (v.x < row) + (v.y < row) + (v.z < row) + (v.w < row);
+                same += (v.x == row) + (v.y == row) + (v.z == row) + (v.w == row);
+                same_before += (v.x == row && j < threadIdx.x) + (v.y == row && j + 1 < threadIdx.x) +
+                               (v.z == row && j + 2 < threadIdx.x) + (v.w == row && j + 3 < threadIdx.x);
+            }
+            lds_keys[less + same_before] = key;
+            if (same_before == 0) {                           // the row's first request lists the row
+                const unsigned k = atomicAdd(&n_seg, 1u);
+                seg_lo[k] = less;
+                seg_n[k] = same;
+            }
+        }
+        __syncthreads();
+        DBG_T(2);
+        process_segments<VEC>(A, lsrc, lds_keys, seg_lo, seg_n, n_seg, long_list, &n_long, red, t, lr_t);
+        DBG_T(3);
+        if (A.dbg_buf && threadIdx.x == 0) { A.dbg_buf[(size_t)b * 8 + 4] = n; A.dbg_buf[(size_t)b * 8 + 5] = n_long; A.dbg_buf[(size_t)b * 8 + 1] = A.dbg_buf[(size_t)b * 8 + 0]; }
+        return;
+    }
+    // ---- large bucket: the distinct rows in an LDS hash, then a stable counting scatter ------------------------------
+    unsigned long long* out = n <= kLdsKeys ? lds_keys : A.keys_alt + beg;
+    for (unsigned k = threadIdx.x; k < kSlots; k += kThreads) { hrow[k] = kEmptyRow; hcnt[k] = 0; hrun[k] = 0; }
+    __syncthreads();
+    unsigned long long key1 = threadIdx.x < n ? in[threadIdx.x] : kPadKey;
+    for (unsigned i0 = 0; i0 < n; i0 += kThreads) {           // pass 1: requests per distinct row (next chunk in flight)
+        const unsigned i = i0 + threadIdx.x;
+        const unsigned long long cur1 = key1;
+        if (i0 + kThreads < n) key1 = i + kThreads < n ? in[i + kThreads] : kPadKey;
+        if (i < n) {
+            const unsigned row = key_row(cur1);
+            const unsigned slot = hash_slot(hrow, row, true);
+            if (slot >= kSlots) {
+                overflow = 1;
+            } else {
+                // the lanes of this wave that hold the first active lane's row (a hot row: most of them) add once
+                const unsigned first = __builtin_amdgcn_readfirstlane(row);
+                const unsigned long long same = __ballot(row == first);
+                if (row == first) {
+                    if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)same) - 1) atomicAdd(&hcnt[slot], (unsigned)__popcll(same));
+                } else {
+                    atomicAdd(&hcnt[slot], 1u);
+                }
+            }
         }
     }
-    if (threadIdx.x == 0) {                                   // the plan's counters are clean for the next step
-        A.cnt[b] = 0;
-        A.cursor[b] = 0;
+    __syncthreads();
+    DBG_T(1);
+    if (overflow) {
+        // more distinct rows than the hash holds (cannot happen at ~100 requests per bucket; kept correct): full sort
+        const unsigned long long* sorted;
+        if (n <= kLdsKeys) {
+            unsigned m = 2;
+            while (m < n) m <<= 1;
+            for (unsigned k = threadIdx.x; k < m; k += kThreads) lds_keys[k] = k < n ? in[k] : kPadKey;
+            __syncthreads();
+            lds_bitonic(lds_keys, m);
+            sorted = lds_keys;
+        } else {
+            // (sorts the bucket's range of `keys` in place: it is not read again)
+            sorted = global_merge_sort(const_cast<unsigned long long*>(in), A.keys_alt + beg, n, lds_keys);
+        }
+        process_sorted_scan<VEC>(A, lsrc, sorted, n, long_list, &n_long, red, t, lr_t);
+        return;
     }
+    {   // first slot of every row's segment: exclusive scan of the counts in slot order (two slots per thread)
+        const unsigned c0 = hcnt[2 * threadIdx.x], c1 = hcnt[2 * threadIdx.x + 1];
+        unsigned total;
+        const unsigned run = block_excl_scan(c0 + c1, sh, total);
+        hbase[2 * threadIdx.x] = run;
+        hbase[2 * threadIdx.x + 1] = run + c0;
+        if (c0) { const unsigned k = atomicAdd(&n_seg, 1u); seg_lo[k] = run; seg_n[k] = c0; }
+        if (c1) { const unsigned k = atomicAdd(&n_seg, 1u); seg_lo[k] = run + c0; seg_n[k] = c1; }
+    }
+    __syncthreads();
+    {   // pass 2: stable scatter, 256 requests at a time (the next chunk's keys are in flight meanwhile)
+        unsigned long long key = threadIdx.x < n ? in[threadIdx.x] : kPadKey;
+        for (unsigned i0 = 0; i0 < n; i0 += kThreads) {
+            const unsigned i = i0 + threadIdx.x;
+            const unsigned long long cur = key;
+            if (i0 + kThreads < n) key = i + kThreads < n ? in[i + kThreads] : kPadKey;
+            const unsigned slot = i < n ? hash_slot(hrow, key_row(cur), false) : 0xffffffffu;
+            cs[threadIdx.x] = slot;
+            __syncthreads();
+            unsigned same_before = 0, same = 0;
+            if (i < n) {
+                const uint4* c4 = reinterpret_cast<const uint4*>(cs);
+#pragma unroll 16
+                for (unsigned j4 = 0; j4 < kThreads / 4; ++j4) {
+                    const uint4 v = c4[j4];
+                    const unsigned j = 4 * j4;
+                    same += (v.x == slot) + (v.y == slot) + (v.z == slot) + (v.w == slot);
+                    same_before += (v.x == slot && j < threadIdx.x) + (v.y == slot && j + 1 < threadIdx.x) +
+                                   (v.z == slot && j + 2 < threadIdx.x) + (v.w == slot && j + 3 < threadIdx.x);
+                }
+                out[hbase[slot] + hrun[slot] + same_before] = cur;
+            }
+            __syncthreads();
+            if (i < n && same_before + 1 == same) hrun[slot] += same;      // the row's last request of this chunk
+            __syncthreads();
+        }
+    }
+    DBG_T(2);
+    process_segments<VEC>(A, lsrc, out, seg_lo, seg_n, n_seg, long_list, &n_long, red, t, lr_t);
+    DBG_T(3);
+    if (A.dbg_buf && threadIdx.x == 0) { A.dbg_buf[(size_t)b * 8 + 4] = n; A.dbg_buf[(size_t)b * 8 + 5] = n_long; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -584,6 +843,7 @@ inline bool geometry(int K, const recalgo_scatter_source_t* src, int n_src, Geom
 
 inline bool to_dev(const recalgo_scatter_source_t* src, int n_src, SrcDev* out, unsigned* n_total, bool need_g) {
     unsigned first = 0;
+    *n_total = 0;
     for (int i = 0; i < kMaxSources; ++i) out[i] = SrcDev{nullptr, nullptr, nullptr, 0, 0, 1, 0xffffffffu, 0, nullptr, 0, 0, 0};
     for (int i = 0; i < n_src; ++i) {
         const recalgo_scatter_source_t& s = src[i];
@@ -592,9 +852,11 @@ inline bool to_dev(const recalgo_scatter_source_t* src, int n_src, SrcDev* out, 
         if ((int64_t)first + n >= (1ll << 31)) return false;
         out[i] = SrcDev{s.ids, s.offsets, s.row_base, (long long)s.base, (unsigned)s.n_ex, (unsigned)s.F, first, (unsigned)n,
                         s.g, (long long)s.g_stride, (unsigned)s.g_col, (unsigned)s.g_fmul};
-        first += (unsigned)n;
+        *n_total = first + (unsigned)n;
+        // every source starts on a workgroup boundary of the request space: row w of the count matrix is written by the
+        // `prepare` launch of exactly one source
+        first = (first + (unsigned)n + kThreads - 1) / kThreads * kThreads;
     }
-    *n_total = first;
     return true;
 }
 
@@ -604,41 +866,49 @@ inline Deferred deferred_of(const recalgo_deferred_adam_t* d) {
 }
 inline bool nb_ok(int nb_log2) { return nb_log2 >= 8 && nb_log2 <= 13; }
 
+struct Ws { unsigned* total; unsigned* offs; unsigned* Cp; unsigned short* C; unsigned long long* keys; unsigned long long* keys_alt; };
+inline Ws carve(void* ws, int64_t cap, int nb_log2) {
+    const int64_t nb = 1ll << nb_log2, W = cap / kThreads;
+    char* p = static_cast<char*>(ws);
+    Ws w;
+    w.total = reinterpret_cast<unsigned*>(p);               // [nb]
+    w.offs = w.total + nb;                                  // [nb + 8]
+    w.Cp = w.offs + nb + 8;                                 // [W][nb]
+    w.C = reinterpret_cast<unsigned short*>(w.Cp + W * nb); // [W][nb]
+    uintptr_t k = (reinterpret_cast<uintptr_t>(w.C + W * nb) + 15) & ~(uintptr_t)15;
+    w.keys = reinterpret_cast<unsigned long long*>(k);
+    w.keys_alt = w.keys + cap;
+    return w;
+}
+
 }  // namespace
 
 RECALGO_EXPORT int recalgo_scatter_plan_buckets_log2(int64_t n_requests) {
-    // ~100 requests per bucket (one workgroup each in `apply`), 1024 .. 8192 buckets
+    // ~100-160 requests per bucket (one workgroup each in `apply`), 1024 .. 8192 buckets; the count matrix is
+    // [requests / 256][buckets] 16-bit words, so the bucket count grows slower than the requests
     int l = 10;
-    while (l < 13 && (n_requests >> l) > 128) ++l;
+    while (l < 13 && (n_requests >> l) > 160) ++l;
     return l;
+}
+
+RECALGO_EXPORT int64_t recalgo_scatter_plan_padded_requests(int64_t n_requests) {
+    return n_requests <= 0 ? 0 : (n_requests + kThreads - 1) / kThreads * kThreads;
 }
 
 RECALGO_EXPORT int64_t recalgo_scatter_plan_workspace_bytes(int64_t n_requests, int nb_log2) {
     if (n_requests < 0 || !nb_ok(nb_log2)) return 0;
     const int64_t nb = 1ll << nb_log2;
-    return (3 * nb + 8) * (int64_t)sizeof(int) + 2 * ((n_requests + 1) & ~1ll) * (int64_t)sizeof(unsigned long long) + 64;
+    const int64_t cap = recalgo_scatter_plan_padded_requests(n_requests > 0 ? n_requests : 1), W = cap / kThreads;
+    return (2 * nb + 8) * (int64_t)sizeof(unsigned) + W * nb * (int64_t)(sizeof(unsigned) + sizeof(unsigned short)) +
+           2 * cap * (int64_t)sizeof(unsigned long long) + 64;
 }
-
-namespace {
-struct Ws { int* cnt; int* cursor; int* offs; unsigned long long* keys; unsigned long long* keys_alt; };
-inline Ws carve(void* ws, int64_t n_requests, int nb_log2) {
-    const int64_t nb = 1ll << nb_log2;
-    char* p = static_cast<char*>(ws);
-    Ws w;
-    w.cnt = reinterpret_cast<int*>(p);
-    w.cursor = w.cnt + nb;
-    w.offs = w.cursor + nb;
-    uintptr_t k = (reinterpret_cast<uintptr_t>(w.offs + nb + 8) + 15) & ~(uintptr_t)15;
-    w.keys = reinterpret_cast<unsigned long long*>(k);
-    w.keys_alt = w.keys + ((n_requests + 1) & ~1ll);
-    return w;
-}
-}  // namespace
 
 RECALGO_EXPORT int recalgo_scatter_prepare(const recalgo_scatter_source_t* source, int K, void* plan_workspace,
-                                           int64_t plan_requests, int nb_log2, const recalgo_deferred_adam_t* deferred,
-                                           const int64_t* step_dev, int step_offset, recalgo_stream_t stream) {
+                                           int64_t plan_requests, int nb_log2, int64_t first_request,
+                                           const recalgo_deferred_adam_t* deferred, const int64_t* step_dev, int step_offset,
+                                           recalgo_stream_t stream) {
     RECALGO_REQUIRE(source != nullptr && nb_ok(nb_log2));
+    RECALGO_REQUIRE(first_request >= 0 && first_request % kThreads == 0 && first_request < (1ll << 31));
     RECALGO_REQUIRE(plan_workspace != nullptr || (deferred != nullptr && deferred->last_step != nullptr));
     SrcDev S[kMaxSources];
     unsigned n = 0;
@@ -648,7 +918,13 @@ RECALGO_EXPORT int recalgo_scatter_prepare(const recalgo_scatter_source_t* sourc
     RECALGO_REQUIRE(geometry(K, nullptr, 0, &G));
     PrepareArgs A;
     A.S = S[0];
-    A.cnt = plan_workspace ? carve(plan_workspace, plan_requests, nb_log2).cnt : nullptr;
+    A.S.first = (unsigned)first_request;
+    A.C = nullptr;
+    if (plan_workspace) {
+        const int64_t cap = recalgo_scatter_plan_padded_requests(plan_requests);
+        RECALGO_REQUIRE(first_request + recalgo_scatter_plan_padded_requests(n) <= cap);
+        A.C = carve(plan_workspace, cap, nb_log2).C;
+    }
     A.nb_log2 = (unsigned)nb_log2;
     A.D = deferred_of(deferred);
     RECALGO_REQUIRE(A.D.last_step == nullptr || (step_dev != nullptr && A.D.lr_ring != nullptr));
@@ -671,7 +947,7 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
                                          int step_offset, float lr, float beta1, float beta2, float eps,
                                          recalgo_stream_t stream) {
     RECALGO_REQUIRE(sources != nullptr && n_sources >= 1 && n_sources <= kMaxSources && plan_workspace != nullptr);
-    RECALGO_REQUIRE(nb_ok(nb_log2) && rows >= 0);
+    RECALGO_REQUIRE(nb_ok(nb_log2) && rows >= 0 && rows < (1ll << 31));
     RECALGO_REQUIRE(mode == RECALGO_SCATTER_GRAD || mode == RECALGO_SCATTER_ADAM || mode == RECALGO_SCATTER_LAZY_ADAM);
     RECALGO_REQUIRE(mode != RECALGO_SCATTER_GRAD ? (w && m && v && step_dev) : grad != nullptr);
     RECALGO_REQUIRE(mode != RECALGO_SCATTER_ADAM || (deferred && deferred->last_step && deferred->lr_ring && sweep_period >= 1 &&
@@ -681,14 +957,17 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
     PlaceArgs P;
     unsigned n_total = 0;
     RECALGO_REQUIRE(to_dev(sources, n_sources, P.src, &n_total, true));
-    RECALGO_REQUIRE((int64_t)n_total <= plan_requests);
-    const Ws ws = carve(plan_workspace, plan_requests, nb_log2);
+    const int64_t cap = recalgo_scatter_plan_padded_requests(plan_requests);
+    RECALGO_REQUIRE((int64_t)n_total <= cap);
+    const Ws ws = carve(plan_workspace, cap, nb_log2);
     hipStream_t st = as_stream(stream);
+    const unsigned nb = 1u << nb_log2;
+    const unsigned W = (unsigned)cdiv(n_total, kThreads);     // rows of the count matrix in use (written by `prepare`)
+    hipLaunchKernelGGL(sparse_scan_kernel, dim3(nb / 16), dim3(kThreads), 0, st, ws.C, ws.Cp, ws.total, W, nb);
     P.n_src = n_sources;
     P.n_total = n_total;
-    P.req_blocks = (unsigned)cdiv(n_total, kThreads);
-    if (P.req_blocks == 0) P.req_blocks = 1;                  // the scan of (all-zero) counts still publishes offs[]
-    P.cnt = ws.cnt; P.cursor = ws.cursor; P.offs = ws.offs; P.keys = ws.keys;
+    P.req_blocks = W ? W : 1;                                 // (the scan of all-zero totals still publishes offs[])
+    P.total = ws.total; P.Cp = ws.Cp; P.offs = ws.offs; P.keys = ws.keys;
     P.nb_log2 = (unsigned)nb_log2;
     P.D = mode == RECALGO_SCATTER_ADAM ? deferred_of(deferred) : deferred_of(nullptr);
     P.step = reinterpret_cast<const long long*>(step_dev);
@@ -699,14 +978,7 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
     P.chunk = (rows + P.period - 1) / P.period;
     unsigned sweep_blocks = 0;
     if (P.D.last_step) sweep_blocks = (unsigned)cdiv(P.chunk * G.L, kThreads);
-    const size_t smem = (3 * ((size_t)1 << nb_log2) + 8) * sizeof(unsigned);
-    if (smem > 64 * 1024) {
-        hipError_t e = G.vec == 4 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_place_kernel<4>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
-                                  : hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_place_kernel<1>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-    }
+    const size_t smem = ((size_t)nb + kThreads + 8) * sizeof(unsigned) + kMaxSources * sizeof(SrcDev);
     if (G.vec == 4)
         hipLaunchKernelGGL(sparse_place_kernel<4>, dim3(P.req_blocks + sweep_blocks), dim3(kThreads), smem, st, P);
     else
@@ -715,7 +987,7 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
     for (int i = 0; i < kMaxSources; ++i)
         A.src[i] = GSrc{P.src[i].g, P.src[i].g_stride, P.src[i].g_col, P.src[i].g_fmul, P.src[i].F, P.src[i].first};
     A.n_src = n_sources;
-    A.cnt = ws.cnt; A.cursor = ws.cursor; A.offs = ws.offs; A.keys = ws.keys; A.keys_alt = ws.keys_alt;
+    A.offs = ws.offs; A.keys = ws.keys; A.keys_alt = ws.keys_alt;
     A.mode = mode;
     A.w = w; A.m = m; A.v = v; A.grad = grad;
     A.last_step = mode == RECALGO_SCATTER_ADAM ? deferred->last_step : nullptr;
@@ -725,18 +997,21 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
     A.lr = lr; A.b1 = beta1; A.b2 = beta2; A.eps = eps;
     A.K = (unsigned)K; A.KV = G.KV; A.L = G.L;
     A.live_words = nullptr; A.live_list = nullptr; A.live_count = nullptr;
+    { const char* e = getenv("RECALGO_SPARSE_DBG_BUF"); A.dbg_buf = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr; }
     if (mode == RECALGO_SCATTER_GRAD && live && live->row_live) {
         RECALGO_REQUIRE((reinterpret_cast<uintptr_t>(live->row_live) & 3) == 0 && live->row_offset == 0);
         A.live_words = reinterpret_cast<unsigned*>(live->row_live);
         A.live_list = live->live_list;
         A.live_count = live->live_count;
     }
-    if (A.step == nullptr) { RECALGO_REQUIRE(mode == RECALGO_SCATTER_GRAD); A.step = reinterpret_cast<const long long*>(ws.offs); A.step_off = 0; }
-    const dim3 grid(1u << nb_log2);
+    if (A.step == nullptr) {                                  // GRAD mode without a step counter: t is not used
+        A.step = reinterpret_cast<const long long*>(ws.total);
+        A.step_off = 0;
+    }
     if (G.vec == 4)
-        hipLaunchKernelGGL(sparse_apply_kernel<4>, grid, dim3(kThreads), 0, st, A);
+        hipLaunchKernelGGL(sparse_apply_kernel<4>, dim3(nb), dim3(kThreads), 0, st, A);
     else
-        hipLaunchKernelGGL(sparse_apply_kernel<1>, grid, dim3(kThreads), 0, st, A);
+        hipLaunchKernelGGL(sparse_apply_kernel<1>, dim3(nb), dim3(kThreads), 0, st, A);
     RECALGO_RETURN_LAST();
 }
 

@@ -201,7 +201,6 @@ class _BagMeanFn(Function):
         values, offsets, arena, table_name = ctx.args
         B = offsets.numel() - 1
         rb, vocab = arena.tables[table_name]
-        gt = arena.grad[rb:rb + vocab]
         g = g.contiguous()
         if ctx.src is not None or _sorted_scatter():
             lens = offsets[1:] - offsets[:-1]
@@ -214,6 +213,7 @@ class _BagMeanFn(Function):
             scatter_rows_sorted(arena, torch.where(values >= 0, values + rb, torch.full_like(values, -1)), vals)
             _flush(arena)
             return None, None, None, None, None, None
+        gt = arena.grad[rb:rb + vocab]
         _lib.check(_lib_().recalgo_embedding_bag_mean_bwd(
             _p(values), _p(offsets), _p(g), B, arena.K, arena.K, 0, _p(gt), _live(arena, rb), _stream(offsets)),
             "recalgo_embedding_bag_mean_bwd")
@@ -254,9 +254,8 @@ class _SeqGatherFn(Function):
         values, offsets, arena, table_name, T = ctx.args
         B = offsets.numel() - 1
         rb, vocab = arena.tables[table_name]
-        gt = arena.grad[rb:rb + vocab]
         if ctx.src is not None:
-            ctx.src.set_grad(g)
+            ctx.src.set_grad(g)              # (no `arena.grad` access here: reading it would sum the pending sources now)
             return None, None, None, None, None, None, None
         g = g.contiguous()
         if _sorted_scatter():
@@ -268,6 +267,7 @@ class _SeqGatherFn(Function):
             scatter_rows_sorted(arena, torch.where(ids_bt >= 0, ids_bt + rb, torch.full_like(ids_bt, -1)), g.reshape(B * T, arena.K))
             _flush(arena)
             return None, None, None, None, None, None, None
+        gt = arena.grad[rb:rb + vocab]
         _lib.check(_lib_().recalgo_sequence_gather_bwd(
             _p(values), _p(offsets), _p(g), B, T, arena.K, _p(gt), _live(arena, rb), _stream(offsets)),
             "recalgo_sequence_gather_bwd")
@@ -299,7 +299,7 @@ class _DeepFMSparseFn(Function):
         fsum = torch.empty(B, K, device=ids.device, dtype=torch.float32)
         st = anchor_store(anchor)
         ctx.src = sparse.begin_lookup(arena, st, ids, None, row_base, 0, B, F, training)
-        ctx.src1 = sparse.begin_lookup(w1, st, ids, None, row_base, 0, B, F, training) if ctx.src is not None else None
+        ctx.src1 = sparse.begin_lookup(w1, st, ids, None, row_base, 0, B, F, training)
         _lib.check(_lib_().recalgo_deepfm_sparse_fwd(
             _p(ids), _p(arena.weight), _p(w1.weight), _p(bias.data), _p(row_base), B, F, K,
             _p(emb), _p(fm1), _p(fm2), _p(fsum), _stream(ids)), "recalgo_deepfm_sparse_fwd")

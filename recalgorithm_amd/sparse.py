@@ -26,7 +26,7 @@ import torch
 from . import _lib
 
 MODE_GRAD, MODE_ADAM, MODE_LAZY_ADAM = 0, 1, 2
-MAX_SOURCES = 4
+MAX_SOURCES = 16
 LR_RING = 1024
 
 
@@ -56,6 +56,11 @@ class _CSource(ctypes.Structure):            # include/recalgo.h recalgo_scatter
 class _CDeferred(ctypes.Structure):          # include/recalgo.h recalgo_deferred_adam_t
     _fields_ = [("w", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p), ("last_step", ctypes.c_void_p),
                 ("lr_ring", ctypes.c_void_p), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float)]
+
+
+def _pad(n: int) -> int:
+    """A source occupies a whole number of 256-request workgroups of the plan's request space."""
+    return (n + 255) // 256 * 256
 
 
 class Source:
@@ -115,7 +120,7 @@ class ArenaPlan:
         self.nb_log2 = int(lib.recalgo_scatter_plan_buckets_log2(cap))
         self.capacity = cap
         nbytes = int(lib.recalgo_scatter_plan_workspace_bytes(cap, self.nb_log2))
-        self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.arena.weight.device)
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.arena.weight.device)
         self.counted = None
 
     def _signature(self, sources):
@@ -174,17 +179,15 @@ def begin_lookup(arena, store, ids: torch.Tensor, offsets: Optional[torch.Tensor
     lib = _lib.load()
     ws_ptr = None
     if register:
-        if len(plan.sources) >= MAX_SOURCES:
-            raise NotImplementedError(f"more than {MAX_SOURCES} lookups into arena {arena.name} in one step")
-        plan._ensure_ws(sum(s.n for s in plan.sources) + src.n)
+        first = sum(_pad(s.n) for s in plan.sources)
+        plan._ensure_ws(first + _pad(src.n))
         if plan.counted is None or plan.counted[:2] != (plan.ws.data_ptr(), plan.nb_log2):
-            plan.ws[: 8 << plan.nb_log2].zero_()           # cnt + cursor
             plan.counted = (plan.ws.data_ptr(), plan.nb_log2, ())
         ws_ptr = ctypes.c_void_p(plan.ws.data_ptr())
     d = plan._deferred_struct()
     step = None if d is None else store.opt_state["step"]
     cs = src.c_struct(arena.K)
-    _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), arena.K, ws_ptr, plan.capacity, plan.nb_log2,
+    _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), arena.K, ws_ptr, plan.capacity, plan.nb_log2, first if register else 0,
                                            None if d is None else ctypes.byref(d),
                                            None if step is None else ctypes.c_void_p(step.data_ptr()), 0,
                                            _stream(arena.weight)), "recalgo_scatter_prepare")
@@ -210,20 +213,49 @@ def has_work(arena) -> bool:
     return plan is not None and (bool(plan.sources) or plan.last_step is not None)
 
 
+def _merge_dense(sources: List[Source], K: int) -> List[Source]:
+    """More lookups into one arena than recalgo_scatter_apply takes sources (a model whose columns are looked up one by
+    one): the id-matrix sources are folded into ONE source of explicit arena rows with their gradient rows concatenated
+    (two torch.cat per step — the fused id-matrix path of the benchmark models never gets here)."""
+    dense = [s for s in sources if s.offsets is None and s.n]
+    rest = [s for s in sources if s.offsets is not None and s.n]
+    if len(rest) + 1 > MAX_SOURCES:
+        raise NotImplementedError(f"more than {MAX_SOURCES - 1} ragged lookups into one arena in one step")
+    rows, grads = [], []
+    for s in dense:
+        ids = s.ids.reshape(s.n_ex, s.F)
+        r = ids + s.base
+        if s.row_base is not None:
+            r = r + s.row_base.reshape(1, -1)
+        rows.append(torch.where(ids >= 0, r, torch.full_like(r, -1)).reshape(-1))
+        fm = K if s.g_fmul is None else int(s.g_fmul)
+        if fm == 0:
+            g = s.g[:, :K].unsqueeze(1).expand(s.n_ex, s.F, K)
+        else:
+            g = torch.as_strided(s.g, (s.n_ex, s.F, K), (s.g.stride(0) if s.n_ex > 1 else s.F * fm, fm, 1))
+        grads.append(g.reshape(-1, K))
+    allrows = torch.cat(rows).reshape(-1, 1).contiguous()
+    merged = Source(allrows, None, None, 0, allrows.shape[0], 1)
+    merged.set_grad(torch.cat(grads).contiguous())
+    return rest + [merged]
+
+
 def _run(plan: ArenaPlan, sources: List[Source], mode: int, step_dev, step_offset: int, lr: float, live=None):
     lib = _lib.load()
     a = plan.arena
-    plan._ensure_ws(sum(s.n for s in sources))
-    if plan.counted != plan._signature([s for s in sources if s.n]):
+    if len([s for s in sources if s.n]) > MAX_SOURCES:
+        sources = _merge_dense(sources, a.K)
+    srcs = [s for s in sources if s.n]
+    plan._ensure_ws(sum(_pad(s.n) for s in srcs))
+    if plan.counted != plan._signature(srcs):
         # the counts in the workspace are not those of exactly these sources (first step, a forward without a backward, a
         # GRAD pass before the optimizer, a re-sized workspace): count again
-        plan.ws[: 8 << plan.nb_log2].zero_()
-        for s in sources:
-            if s.n:
-                cs = s.c_struct(a.K)
-                _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), a.K, ctypes.c_void_p(plan.ws.data_ptr()), plan.capacity,
-                                                       plan.nb_log2, None, None, 0, _stream(a.weight)), "recalgo_scatter_prepare")
-    srcs = [s for s in sources if s.n]
+        first = 0
+        for s in srcs:
+            cs = s.c_struct(a.K)
+            _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), a.K, ctypes.c_void_p(plan.ws.data_ptr()), plan.capacity,
+                                                   plan.nb_log2, first, None, None, 0, _stream(a.weight)), "recalgo_scatter_prepare")
+            first += _pad(s.n)
     if not srcs:                               # (the sweep and the lr ring still need the launch)
         dummy = Source(a.weight, None, None, 0, 0, 1)
         dummy.g, dummy.g_fmul = a.weight, a.K
@@ -237,7 +269,7 @@ def _run(plan: ArenaPlan, sources: List[Source], mode: int, step_dev, step_offse
                                          p(a.v), p(grad), None if d is None else ctypes.byref(d), a.weight.shape[0],
                                          sweep_period(), live, p(step_dev), step_offset, lr, b1, b2, eps, _stream(a.weight)),
                "recalgo_scatter_apply")
-    plan.counted = plan._signature([])         # `apply` leaves the counters cleared
+    plan.counted = plan._signature([])         # (the next step's `prepare` launches overwrite their rows of the count matrix)
 
 
 def apply(arena, lazy: bool, step_dev: torch.Tensor, lr: float, beta1: float, beta2: float, eps: float) -> None:
