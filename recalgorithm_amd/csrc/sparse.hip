@@ -59,11 +59,13 @@ struct SrcDev {
     const int64_t* offsets;
     const int64_t* row_base;
     long long base;
-    unsigned n_ex, F, first, n;        // n = n_ex * F requests; `first` = index of request 0 in the plan
+    unsigned n_ex, F, first, n;        // n = SLOTS of the source in the plan's slot space; `first` = its first slot
+    unsigned e256, pad_;               // dense sources: examples per field rounded up to whole tiles
     const float* g;
     long long g_stride;
     unsigned g_col, g_fmul;
 };
+constexpr unsigned kPartialBit = 0x80000000u;   // key.ref: the gradient row is a tile's partial sum, not a request's row
 
 // Copy `bytes` of the kernel's (single, by-value) argument struct, starting at byte `offset`, into LDS — one dword per
 // thread, read straight from the kernarg segment.  (Indexing a by-value kernel-argument array with a data-dependent
@@ -78,22 +80,49 @@ __device__ __forceinline__ void copy_kernarg_words(unsigned* dst, size_t offset,
 #endif
 }
 
-// arena row of local request i of source S, -1: no row (OOV id, beyond the sequence's length)
-__device__ __forceinline__ long long src_row(const SrcDev& S, unsigned i) {
+// The plan's SLOT space.  Workgroup ("tile") w of prepare / place owns slots [256 w, 256 w + 256).  An id matrix
+// [n_ex, F] is laid out FIELD-MAJOR: slot f * e256 + e  (e256 = n_ex rounded up to 256), so that a tile is 256 consecutive
+// examples of ONE field — where the duplicates of a batch are (all requests of a hot row of that field meet in B / 256
+// tiles).  Ragged sources stay row-major (e * F + f).  -> arena row (-1: empty slot, OOV id, beyond the sequence's
+// length) and the request's index e * F + f inside its source (what the gradient row is addressed by).
+__device__ __forceinline__ long long slot_row(const SrcDev& S, unsigned li, unsigned* ref_local) {
     long long id;
-    unsigned f;
+    unsigned e, f;
     if (S.offsets) {
-        const unsigned e = i / S.F;
-        f = i - e * S.F;
+        e = li / S.F;
+        f = li - e * S.F;
+        if (e >= S.n_ex) return -1;
         const long long beg = S.offsets[e], len = S.offsets[e + 1] - beg;
         if ((long long)f >= len) return -1;
         id = S.ids[beg + f];
     } else {
-        id = S.ids[i];
-        f = S.row_base ? i % S.F : 0;
+        f = li / S.e256;
+        e = li - f * S.e256;
+        if (e >= S.n_ex) return -1;
+        id = S.ids[(size_t)e * S.F + f];
     }
+    *ref_local = e * S.F + f;
     if (id < 0) return -1;
     return id + S.base + (S.row_base ? S.row_base[f] : 0);
+}
+
+// Duplicates inside a tile: rows[] (LDS, one per thread, 0xffffffff = none).  -> number of threads with the same row,
+// how many of them come before this thread, and the first of them (the row's LEADER in this tile)
+struct TileDup { unsigned same, before, leader; };
+__device__ __forceinline__ TileDup tile_dups(const unsigned* rows, unsigned row) {
+    TileDup d{0, 0, 0xffffffffu};
+    const uint4* r4 = reinterpret_cast<const uint4*>(rows);
+#pragma unroll 16
+    for (unsigned j4 = 0; j4 < kThreads / 4; ++j4) {
+        const uint4 v = r4[j4];
+        const unsigned j = 4 * j4;
+        const unsigned e0 = v.x == row, e1 = v.y == row, e2 = v.z == row, e3 = v.w == row;
+        d.same += e0 + e1 + e2 + e3;
+        d.before += (e0 && j < threadIdx.x) + (e1 && j + 1 < threadIdx.x) + (e2 && j + 2 < threadIdx.x) + (e3 && j + 3 < threadIdx.x);
+        const unsigned fm = e0 ? j : (e1 ? j + 1 : (e2 ? j + 2 : (e3 ? j + 3 : 0xffffffffu)));
+        d.leader = min(d.leader, fm);
+    }
+    return d;
 }
 
 __device__ __forceinline__ unsigned bucket_of(unsigned row, unsigned nb_log2) {
@@ -200,22 +229,26 @@ template <int VEC>
 __global__ __launch_bounds__(kThreads) void sparse_prepare_kernel(PrepareArgs A) {
     extern __shared__ unsigned lds_u[];
     const unsigned nb = 1u << A.nb_log2;
-    unsigned* hist = lds_u;                                   // [nb]
-    long long* stale_row = reinterpret_cast<long long*>(lds_u + nb);   // [kThreads]
+    unsigned* rows = lds_u;                                   // [kThreads] the tile's rows
+    unsigned* hist = rows + kThreads;                         // [nb]
+    long long* stale_row = reinterpret_cast<long long*>(hist + nb);    // [kThreads]
     int* stale_s = reinterpret_cast<int*>(stale_row + kThreads);        // [kThreads]
     unsigned* n_stale = reinterpret_cast<unsigned*>(stale_s + kThreads);
     if (A.C)
         for (unsigned b = threadIdx.x; b < nb; b += kThreads) hist[b] = 0;
     if (threadIdx.x == 0) *n_stale = 0;
-    __syncthreads();
-    const unsigned i = blockIdx.x * kThreads + threadIdx.x;
-    const long long row = i < A.S.n ? src_row(A.S, i) : -1;
+    const unsigned li = blockIdx.x * kThreads + threadIdx.x;
+    unsigned refl = 0;
+    const long long row = li < A.S.n ? slot_row(A.S, li, &refl) : -1;
+    rows[threadIdx.x] = row >= 0 ? (unsigned)row : 0xffffffffu;
     const int target = A.D.last_step ? (int)(A.step[0] + A.step_off) : 0;
-    if (row >= 0) {
+    __syncthreads();
+    // one entry per DISTINCT row of the tile (its first request, the leader) — `place` sums the tile's duplicates
+    if (row >= 0 && tile_dups(rows, (unsigned)row).before == 0) {
         if (A.C) atomicAdd(&hist[bucket_of((unsigned)row, A.nb_log2)], 1u);     // (LDS)
         if (A.D.last_step) {
             // hot rows are current (their last_step is the previous step): only stale rows cost an atomic, and exactly one
-            // of the requests of a stale row wins the claim
+            // of the tiles that request a stale row wins the claim
             const int s = __hip_atomic_load(&A.D.last_step[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (s > 0 && s < target && atomicCAS(&A.D.last_step[row], s, -s) == s) {
                 const unsigned k = atomicAdd(n_stale, 1u);
@@ -272,6 +305,7 @@ struct PlaceArgs {
     unsigned n_total, req_blocks;
     const unsigned* total; const unsigned* Cp; unsigned* offs;      // [nb], [W][nb], [nb + 1]
     unsigned long long* keys;                  // [n_total]
+    float* partials;                           // [n_total][K]: the summed gradient rows of a tile's duplicated rows
     unsigned nb_log2;
     // sweep (deferred Adam): rows [c * chunk, (c + 1) * chunk), c = target % period, are brought to `target`
     Deferred D;
@@ -282,8 +316,25 @@ struct PlaceArgs {
     int period;
 };
 
+constexpr unsigned kTileLong = 24;             // duplicates of a row in a tile above which the whole workgroup sums them
+
+// gradient piece q of the request `ref` (= its source's first slot + e * F + f)
+template <int VEC>
+__device__ __forceinline__ typename Vec<VEC>::T load_g_src(const SrcDev* lsrc, unsigned ref, unsigned q) {
+    using V = typename Vec<VEC>::T;
+    unsigned si = 0;                                          // (unused sources have first = 0xffffffff)
+#pragma unroll
+    for (int k = 1; k < kMaxSources; ++k) si += ref >= lsrc[k].first;
+    const unsigned first = lsrc[si].first, F = lsrc[si].F, col = lsrc[si].g_col, fmul = lsrc[si].g_fmul;
+    const float* g = lsrc[si].g;
+    const long long stride = lsrc[si].g_stride;
+    const unsigned i = ref - first, e = i / F, f = i - e * F;
+    return *reinterpret_cast<const V*>(g + (size_t)e * stride + col + (size_t)f * fmul + q * VEC);
+}
+
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
+    using V = typename Vec<VEC>::T;
     if (blockIdx.x >= A.req_blocks) {                         // ---- sweep workgroups -------------------------------
         const int target = (int)(A.step[0] + A.step_off);
         if (target <= 0) return;
@@ -298,12 +349,21 @@ __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
     }
     extern __shared__ unsigned lds_u[];
     const unsigned nb = 1u << A.nb_log2, bpt = nb / kThreads;   // nb is a multiple of kThreads
-    unsigned* offs = lds_u;                                   // [nb]
-    unsigned* bk = offs + nb;                                 // [kThreads] bucket of every request of this workgroup
-    unsigned* sh = bk + kThreads;                             // [8]
+    unsigned* rows = lds_u;                                   // [kThreads] the tile's rows
+    unsigned* bk = rows + kThreads;                           // [kThreads] bucket of the tile's leaders (else none)
+    unsigned* samec = bk + kThreads;                          // [kThreads] requests of the thread's row in the tile
+    unsigned* mbase = samec + kThreads;                       // [kThreads] (leaders of duplicated rows) first entry in mlist
+    unsigned* mlist = mbase + kThreads;                       // [kThreads] member threads of the duplicated rows, in order
+    unsigned* grefs = mlist + kThreads;                       // [kThreads] gradient reference of every thread's request
+    unsigned* jobs = grefs + kThreads;                        // [kThreads] leaders of the duplicated rows
+    float* red = reinterpret_cast<float*>(jobs + kThreads);   // [kThreads * 4]
+    unsigned* offs = reinterpret_cast<unsigned*>(red + kThreads * 4);   // [nb]
+    unsigned* sh = offs + nb;                                 // [8]; sh[6] = number of jobs, sh[7] = number of long jobs
     // the source descriptors go to LDS: a data-dependent index into the kernel-argument array would go through scratch
-    SrcDev* lsrc = reinterpret_cast<SrcDev*>(sh + 8);         // [kMaxSources]
+    unsigned* ljobs = sh + 8;                                 // [16] leaders of the rows with > kTileLong duplicates (<= 10)
+    SrcDev* lsrc = reinterpret_cast<SrcDev*>(ljobs + 16);     // [kMaxSources]
     copy_kernarg_words(reinterpret_cast<unsigned*>(lsrc), offsetof(PlaceArgs, src), sizeof(SrcDev) * kMaxSources);
+    if (threadIdx.x == 0) { sh[6] = 0; sh[7] = 0; }
     {
         unsigned sum = 0;
         for (unsigned k = 0; k < bpt; ++k) sum += A.total[threadIdx.x * bpt + k];
@@ -318,30 +378,86 @@ __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
         if (blockIdx.x == 0 && threadIdx.x == kThreads - 1) A.offs[nb] = total;
     }
     __syncthreads();
-    const unsigned i = blockIdx.x * kThreads + threadIdx.x;
+    const unsigned i = blockIdx.x * kThreads + threadIdx.x;   // this thread's slot
     long long row = -1;
+    unsigned gref = 0;
     if (i < A.n_total) {
         unsigned si = 0;                                      // (unused sources have first = 0xffffffff)
 #pragma unroll
         for (int k = 1; k < kMaxSources; ++k) si += i >= lsrc[k].first;
         const SrcDev S = lsrc[si];
-        if (i - S.first < S.n) row = src_row(S, i - S.first);     // (the padding between two sources holds no request)
+        unsigned refl = 0;
+        if (i - S.first < S.n) row = slot_row(S, i - S.first, &refl);     // (padding between two sources: no request)
+        gref = S.first + refl;
     }
-    const unsigned b = row >= 0 ? bucket_of((unsigned)row, A.nb_log2) : 0xffffffffu;
-    bk[threadIdx.x] = b;
+    rows[threadIdx.x] = row >= 0 ? (unsigned)row : 0xffffffffu;
+    grefs[threadIdx.x] = gref;
     __syncthreads();
-    if (row >= 0) {
-        // stable: the number of EARLIER requests of this workgroup that go to the same bucket
+    TileDup d{0, 0, 0};
+    if (row >= 0) d = tile_dups(rows, (unsigned)row);
+    const bool leader = row >= 0 && d.before == 0, dupl = leader && d.same > 1;
+    const unsigned b = leader ? bucket_of((unsigned)row, A.nb_log2) : 0xffffffffu;
+    bk[threadIdx.x] = b;
+    samec[threadIdx.x] = d.same;
+    {
+        unsigned total;
+        mbase[threadIdx.x] = block_excl_scan(dupl ? d.same : 0u, sh, total);
+    }
+    if (dupl) jobs[atomicAdd(&sh[6], 1u)] = threadIdx.x;
+    __syncthreads();
+    if (row >= 0 && d.same > 1) mlist[mbase[d.leader] + d.before] = threadIdx.x;
+    if (leader) {
+        // stable: the number of EARLIER leaders of this tile that go to the same bucket
         unsigned r = 0;
         const uint4* bk4 = reinterpret_cast<const uint4*>(bk);
-#pragma unroll 16                                              // (16 LDS reads in flight: the loop is latency bound otherwise)
+#pragma unroll 16
         for (unsigned j4 = 0; j4 < kThreads / 4; ++j4) {
             const uint4 v = bk4[j4];
             const unsigned j = 4 * j4;
             r += (v.x == b && j < threadIdx.x) + (v.y == b && j + 1 < threadIdx.x) + (v.z == b && j + 2 < threadIdx.x) +
                  (v.w == b && j + 3 < threadIdx.x);
         }
-        A.keys[offs[b] + A.Cp[(size_t)blockIdx.x * nb + b] + r] = ((unsigned long long)row << 32) | i;
+        // a duplicated row's entry refers to the tile's partial sum (written below), a single request to its own row
+        A.keys[offs[b] + A.Cp[(size_t)blockIdx.x * nb + b] + r] = ((unsigned long long)row << 32) | (dupl ? (kPartialBit | i) : gref);
+    }
+    __syncthreads();
+    // ---- the duplicated rows of the tile: gradient rows added in request order ---------------------------------------
+    const unsigned L = A.L, q = threadIdx.x & (L - 1), grp = threadIdx.x / L, ngrp = kThreads / L;
+    const unsigned njobs = sh[6];
+    for (unsigned k = grp; k < njobs; k += ngrp) {
+        const unsigned ld = jobs[k], c = samec[ld], bs = mbase[ld];
+        if (c > kTileLong) {                                  // (at most 256 / 25 = 10 of them per tile)
+            if (q == 0) ljobs[atomicAdd(&sh[7], 1u)] = ld;
+            continue;
+        }
+        V acc = vz<VEC>();
+        if (q < A.KV) {
+            unsigned m = 0;
+            for (; m + 4 <= c; m += 4) {
+                const V g0 = load_g_src<VEC>(lsrc, grefs[mlist[bs + m]], q), g1 = load_g_src<VEC>(lsrc, grefs[mlist[bs + m + 1]], q);
+                const V g2 = load_g_src<VEC>(lsrc, grefs[mlist[bs + m + 2]], q), g3 = load_g_src<VEC>(lsrc, grefs[mlist[bs + m + 3]], q);
+                vadd(acc, g0); vadd(acc, g1); vadd(acc, g2); vadd(acc, g3);
+            }
+            for (; m < c; ++m) vadd(acc, load_g_src<VEC>(lsrc, grefs[mlist[bs + m]], q));
+            reinterpret_cast<V*>(A.partials)[((size_t)blockIdx.x * kThreads + ld) * A.KV + q] = acc;
+        }
+    }
+    __syncthreads();
+    const unsigned nlong = sh[7];
+    for (unsigned k = 0; k < nlong; ++k) {                    // hot rows: all groups sum strided slices, fixed-order combination
+        const unsigned ld = ljobs[k], c = samec[ld], bs = mbase[ld];
+        V acc = vz<VEC>();
+        if (q < A.KV) {
+            for (unsigned m = grp; m < c; m += ngrp) vadd(acc, load_g_src<VEC>(lsrc, grefs[mlist[bs + m]], q));
+            reinterpret_cast<V*>(red)[grp * A.KV + q] = acc;
+        }
+        __syncthreads();
+        if (grp == 0 && q < A.KV) {
+            V tot = vz<VEC>();
+            for (unsigned g2 = 0; g2 < ngrp; ++g2) vadd(tot, reinterpret_cast<const V*>(red)[g2 * A.KV + q]);
+            reinterpret_cast<V*>(A.partials)[((size_t)blockIdx.x * kThreads + ld) * A.KV + q] = tot;
+        }
+        __syncthreads();
     }
 }
 
@@ -358,6 +474,7 @@ struct ApplyArgs {
     int n_src;
     const unsigned* offs;
     const unsigned long long* keys; unsigned long long* keys_alt;   // keys_alt: scratch of the same size (large buckets)
+    const float* partials;         // [slots][K]: gradient rows of the entries whose ref has kPartialBit set
     int mode;                      // RECALGO_SCATTER_GRAD / _ADAM / _LAZY_ADAM
     float* w; float* m; float* v; float* grad;                // grad: GRAD target; ADAM modes: rows zeroed when non-null
     int* last_step;                // ADAM (deferred-exact) only
@@ -399,9 +516,11 @@ __device__ __forceinline__ void lds_bitonic(unsigned long long* keys, unsigned m
 
 // gradient piece q of the request a key refers to
 template <int VEC>
-__device__ __forceinline__ typename Vec<VEC>::T load_g(const GSrc* lsrc, unsigned long long key, unsigned q) {
+__device__ __forceinline__ typename Vec<VEC>::T load_g(const ApplyArgs& A, const GSrc* lsrc, unsigned long long key, unsigned q) {
     using V = typename Vec<VEC>::T;
     const unsigned ref = (unsigned)key;
+    if (ref & kPartialBit)                                    // the summed duplicates of a tile (written by `place`)
+        return reinterpret_cast<const V*>(A.partials)[(size_t)(ref & ~kPartialBit) * A.KV + q];
     unsigned si = 0;                                          // (unused sources have first = 0xffffffff)
 #pragma unroll
     for (int k = 1; k < kMaxSources; ++k) si += ref >= lsrc[k].first;
@@ -476,11 +595,11 @@ __device__ __forceinline__ void short_row(const ApplyArgs& A, const GSrc* lsrc, 
     if (q < A.KV) {
         unsigned j = lo;
         for (; j + 4 <= hi; j += 4) {                         // four row loads in flight, added in request order
-            const V g0 = load_g<VEC>(lsrc, keys[j], q), g1 = load_g<VEC>(lsrc, keys[j + 1], q);
-            const V g2 = load_g<VEC>(lsrc, keys[j + 2], q), g3 = load_g<VEC>(lsrc, keys[j + 3], q);
+            const V g0 = load_g<VEC>(A, lsrc, keys[j], q), g1 = load_g<VEC>(A, lsrc, keys[j + 1], q);
+            const V g2 = load_g<VEC>(A, lsrc, keys[j + 2], q), g3 = load_g<VEC>(A, lsrc, keys[j + 3], q);
             vadd(acc, g0); vadd(acc, g1); vadd(acc, g2); vadd(acc, g3);
         }
-        for (; j < hi; ++j) vadd(acc, load_g<VEC>(lsrc, keys[j], q));
+        for (; j < hi; ++j) vadd(acc, load_g<VEC>(A, lsrc, keys[j], q));
     }
     finish_row<VEC>(A, row, st, acc, q, t, lr_t);
 }
@@ -503,7 +622,7 @@ __device__ __forceinline__ void long_rows(const ApplyArgs& A, const GSrc* lsrc, 
             for (; j + (kU - 1) * ngrp < hi; j += kU * ngrp) {
                 V gq[kU];
 #pragma unroll
-                for (int u = 0; u < kU; ++u) gq[u] = load_g<VEC>(lsrc, keys[j + u * ngrp], q);
+                for (int u = 0; u < kU; ++u) gq[u] = load_g<VEC>(A, lsrc, keys[j + u * ngrp], q);
 #pragma unroll
                 for (int u = 0; u < kU; ++u) vadd(acc, gq[u]);
             }
@@ -511,7 +630,7 @@ __device__ __forceinline__ void long_rows(const ApplyArgs& A, const GSrc* lsrc, 
             unsigned cnt = 0;
 #pragma unroll
             for (int u = 0; u < kU; ++u)
-                if (j + u * ngrp < hi) { gq[u] = load_g<VEC>(lsrc, keys[j + u * ngrp], q); cnt = u + 1; }
+                if (j + u * ngrp < hi) { gq[u] = load_g<VEC>(A, lsrc, keys[j + u * ngrp], q); cnt = u + 1; }
 #pragma unroll
             for (int u = 0; u < kU; ++u)
                 if ((unsigned)u < cnt) vadd(acc, gq[u]);
@@ -718,24 +837,31 @@ __global__ __launch_bounds__(kThreads, 4) void sparse_apply_kernel(ApplyArgs A) 
     unsigned long long* out = n <= kLdsKeys ? lds_keys : A.keys_alt + beg;
     for (unsigned k = threadIdx.x; k < kSlots; k += kThreads) { hrow[k] = kEmptyRow; hcnt[k] = 0; hrun[k] = 0; }
     __syncthreads();
-    unsigned long long key1 = threadIdx.x < n ? in[threadIdx.x] : kPadKey;
-    for (unsigned i0 = 0; i0 < n; i0 += kThreads) {           // pass 1: requests per distinct row (next chunk in flight)
-        const unsigned i = i0 + threadIdx.x;
-        const unsigned long long cur1 = key1;
-        if (i0 + kThreads < n) key1 = i + kThreads < n ? in[i + kThreads] : kPadKey;
-        if (i < n) {
-            const unsigned row = key_row(cur1);
-            const unsigned slot = hash_slot(hrow, row, true);
-            if (slot >= kSlots) {
-                overflow = 1;
-            } else {
-                // the lanes of this wave that hold the first active lane's row (a hot row: most of them) add once
-                const unsigned first = __builtin_amdgcn_readfirstlane(row);
-                const unsigned long long same = __ballot(row == first);
-                if (row == first) {
-                    if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)same) - 1) atomicAdd(&hcnt[slot], (unsigned)__popcll(same));
+    constexpr unsigned kStage = 8;                            // chunks of 256 keys staged in registers per round trip
+    for (unsigned s0 = 0; s0 < n; s0 += kStage * kThreads) {  // pass 1: requests per distinct row
+        unsigned long long kreg[kStage];
+#pragma unroll
+        for (unsigned u = 0; u < kStage; ++u) {
+            const unsigned i = s0 + u * kThreads + threadIdx.x;
+            kreg[u] = i < n ? in[i] : kPadKey;
+        }
+#pragma unroll
+        for (unsigned u = 0; u < kStage; ++u) {
+            const unsigned i = s0 + u * kThreads + threadIdx.x;
+            if (i < n) {
+                const unsigned row = key_row(kreg[u]);
+                const unsigned slot = hash_slot(hrow, row, true);
+                if (slot >= kSlots) {
+                    overflow = 1;
                 } else {
-                    atomicAdd(&hcnt[slot], 1u);
+                    // the lanes of this wave that hold the first active lane's row (a hot row: most of them) add once
+                    const unsigned first = __builtin_amdgcn_readfirstlane(row);
+                    const unsigned long long same = __ballot(row == first);
+                    if (row == first) {
+                        if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)same) - 1) atomicAdd(&hcnt[slot], (unsigned)__popcll(same));
+                    } else {
+                        atomicAdd(&hcnt[slot], 1u);
+                    }
                 }
             }
         }
@@ -769,12 +895,18 @@ __global__ __launch_bounds__(kThreads, 4) void sparse_apply_kernel(ApplyArgs A) 
         if (c1) { const unsigned k = atomicAdd(&n_seg, 1u); seg_lo[k] = run + c0; seg_n[k] = c1; }
     }
     __syncthreads();
-    {   // pass 2: stable scatter, 256 requests at a time (the next chunk's keys are in flight meanwhile)
-        unsigned long long key = threadIdx.x < n ? in[threadIdx.x] : kPadKey;
-        for (unsigned i0 = 0; i0 < n; i0 += kThreads) {
-            const unsigned i = i0 + threadIdx.x;
-            const unsigned long long cur = key;
-            if (i0 + kThreads < n) key = i + kThreads < n ? in[i + kThreads] : kPadKey;
+    for (unsigned s0 = 0; s0 < n; s0 += kStage * kThreads) {  // pass 2: stable scatter, 256 requests at a time
+        unsigned long long kreg[kStage];
+#pragma unroll
+        for (unsigned u = 0; u < kStage; ++u) {
+            const unsigned i = s0 + u * kThreads + threadIdx.x;
+            kreg[u] = i < n ? in[i] : kPadKey;
+        }
+#pragma unroll
+        for (unsigned u = 0; u < kStage; ++u) {
+            if (s0 + u * kThreads >= n) break;                // (uniform over the workgroup)
+            const unsigned i = s0 + u * kThreads + threadIdx.x;
+            const unsigned long long cur = kreg[u];
             const unsigned slot = i < n ? hash_slot(hrow, key_row(cur), false) : 0xffffffffu;
             cs[threadIdx.x] = slot;
             __syncthreads();
@@ -841,21 +973,29 @@ inline bool geometry(int K, const recalgo_scatter_source_t* src, int n_src, Geom
     return true;
 }
 
+}  // namespace
+RECALGO_EXPORT int64_t recalgo_scatter_source_slots(int n_ex, int F, int ragged) {
+    if (n_ex <= 0 || F <= 0) return 0;
+    const int64_t pad = [](int64_t x) { return (x + kThreads - 1) / kThreads * kThreads; }((int64_t)(ragged ? (int64_t)n_ex * F : n_ex));
+    return ragged ? pad : pad * F;                          // id matrices: F fields x (examples rounded up to whole tiles)
+}
+namespace {
 inline bool to_dev(const recalgo_scatter_source_t* src, int n_src, SrcDev* out, unsigned* n_total, bool need_g) {
     unsigned first = 0;
     *n_total = 0;
-    for (int i = 0; i < kMaxSources; ++i) out[i] = SrcDev{nullptr, nullptr, nullptr, 0, 0, 1, 0xffffffffu, 0, nullptr, 0, 0, 0};
+    for (int i = 0; i < kMaxSources; ++i) out[i] = SrcDev{nullptr, nullptr, nullptr, 0, 0, 1, 0xffffffffu, 0, kThreads, 0, nullptr, 0, 0, 0};
     for (int i = 0; i < n_src; ++i) {
         const recalgo_scatter_source_t& s = src[i];
         if (!s.ids || s.n_ex < 0 || s.F < 1 || (need_g && !s.g)) return false;
-        const int64_t n = (int64_t)s.n_ex * s.F;
+        const int64_t n = recalgo_scatter_source_slots(s.n_ex, s.F, s.offsets != nullptr);
         if ((int64_t)first + n >= (1ll << 31)) return false;
+        const unsigned e256 = ((unsigned)s.n_ex + kThreads - 1) / kThreads * kThreads;
         out[i] = SrcDev{s.ids, s.offsets, s.row_base, (long long)s.base, (unsigned)s.n_ex, (unsigned)s.F, first, (unsigned)n,
-                        s.g, (long long)s.g_stride, (unsigned)s.g_col, (unsigned)s.g_fmul};
-        *n_total = first + (unsigned)n;
-        // every source starts on a workgroup boundary of the request space: row w of the count matrix is written by the
-        // `prepare` launch of exactly one source
-        first = (first + (unsigned)n + kThreads - 1) / kThreads * kThreads;
+                        e256 ? e256 : kThreads, 0, s.g, (long long)s.g_stride, (unsigned)s.g_col, (unsigned)s.g_fmul};
+        // every source is a whole number of tiles: row w of the count matrix is written by the `prepare` launch of exactly
+        // one source
+        first += (unsigned)n;
+        *n_total = first;
     }
     return true;
 }
@@ -866,7 +1006,7 @@ inline Deferred deferred_of(const recalgo_deferred_adam_t* d) {
 }
 inline bool nb_ok(int nb_log2) { return nb_log2 >= 8 && nb_log2 <= 13; }
 
-struct Ws { unsigned* total; unsigned* offs; unsigned* Cp; unsigned short* C; unsigned long long* keys; unsigned long long* keys_alt; };
+struct Ws { unsigned* total; unsigned* offs; unsigned* Cp; unsigned short* C; unsigned long long* keys; unsigned long long* keys_alt; float* partials; };
 inline Ws carve(void* ws, int64_t cap, int nb_log2) {
     const int64_t nb = 1ll << nb_log2, W = cap / kThreads;
     char* p = static_cast<char*>(ws);
@@ -878,6 +1018,7 @@ inline Ws carve(void* ws, int64_t cap, int nb_log2) {
     uintptr_t k = (reinterpret_cast<uintptr_t>(w.C + W * nb) + 15) & ~(uintptr_t)15;
     w.keys = reinterpret_cast<unsigned long long*>(k);
     w.keys_alt = w.keys + cap;
+    w.partials = reinterpret_cast<float*>(w.keys_alt + cap);   // [cap][K]
     return w;
 }
 
@@ -891,16 +1032,12 @@ RECALGO_EXPORT int recalgo_scatter_plan_buckets_log2(int64_t n_requests) {
     return l;
 }
 
-RECALGO_EXPORT int64_t recalgo_scatter_plan_padded_requests(int64_t n_requests) {
-    return n_requests <= 0 ? 0 : (n_requests + kThreads - 1) / kThreads * kThreads;
-}
-
-RECALGO_EXPORT int64_t recalgo_scatter_plan_workspace_bytes(int64_t n_requests, int nb_log2) {
-    if (n_requests < 0 || !nb_ok(nb_log2)) return 0;
+RECALGO_EXPORT int64_t recalgo_scatter_plan_workspace_bytes(int64_t n_slots, int nb_log2, int K) {
+    if (n_slots < 0 || n_slots % kThreads != 0 || !nb_ok(nb_log2) || K < 1) return 0;
     const int64_t nb = 1ll << nb_log2;
-    const int64_t cap = recalgo_scatter_plan_padded_requests(n_requests > 0 ? n_requests : 1), W = cap / kThreads;
+    const int64_t cap = n_slots > 0 ? n_slots : kThreads, W = cap / kThreads;
     return (2 * nb + 8) * (int64_t)sizeof(unsigned) + W * nb * (int64_t)(sizeof(unsigned) + sizeof(unsigned short)) +
-           2 * cap * (int64_t)sizeof(unsigned long long) + 64;
+           2 * cap * (int64_t)sizeof(unsigned long long) + cap * (int64_t)K * (int64_t)sizeof(float) + 64;
 }
 
 RECALGO_EXPORT int recalgo_scatter_prepare(const recalgo_scatter_source_t* source, int K, void* plan_workspace,
@@ -909,6 +1046,7 @@ RECALGO_EXPORT int recalgo_scatter_prepare(const recalgo_scatter_source_t* sourc
                                            recalgo_stream_t stream) {
     RECALGO_REQUIRE(source != nullptr && nb_ok(nb_log2));
     RECALGO_REQUIRE(first_request >= 0 && first_request % kThreads == 0 && first_request < (1ll << 31));
+    RECALGO_REQUIRE(plan_requests >= 0 && plan_requests % kThreads == 0);
     RECALGO_REQUIRE(plan_workspace != nullptr || (deferred != nullptr && deferred->last_step != nullptr));
     SrcDev S[kMaxSources];
     unsigned n = 0;
@@ -921,9 +1059,8 @@ RECALGO_EXPORT int recalgo_scatter_prepare(const recalgo_scatter_source_t* sourc
     A.S.first = (unsigned)first_request;
     A.C = nullptr;
     if (plan_workspace) {
-        const int64_t cap = recalgo_scatter_plan_padded_requests(plan_requests);
-        RECALGO_REQUIRE(first_request + recalgo_scatter_plan_padded_requests(n) <= cap);
-        A.C = carve(plan_workspace, cap, nb_log2).C;
+        RECALGO_REQUIRE(first_request + (int64_t)n <= plan_requests);
+        A.C = carve(plan_workspace, plan_requests, nb_log2).C;
     }
     A.nb_log2 = (unsigned)nb_log2;
     A.D = deferred_of(deferred);
@@ -931,7 +1068,7 @@ RECALGO_EXPORT int recalgo_scatter_prepare(const recalgo_scatter_source_t* sourc
     A.step = reinterpret_cast<const long long*>(step_dev);
     A.step_off = step_offset;
     A.KV = G.KV; A.L = G.L;
-    const size_t smem = ((size_t)1 << nb_log2) * sizeof(unsigned) + kThreads * (sizeof(long long) + sizeof(int)) + 16;
+    const size_t smem = (((size_t)1 << nb_log2) + kThreads) * sizeof(unsigned) + kThreads * (sizeof(long long) + sizeof(int)) + 16;
     const dim3 grid(cdiv(n, kThreads));
     if (G.vec == 4)
         hipLaunchKernelGGL(sparse_prepare_kernel<4>, grid, dim3(kThreads), smem, as_stream(stream), A);
@@ -957,9 +1094,8 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
     PlaceArgs P;
     unsigned n_total = 0;
     RECALGO_REQUIRE(to_dev(sources, n_sources, P.src, &n_total, true));
-    const int64_t cap = recalgo_scatter_plan_padded_requests(plan_requests);
-    RECALGO_REQUIRE((int64_t)n_total <= cap);
-    const Ws ws = carve(plan_workspace, cap, nb_log2);
+    RECALGO_REQUIRE(plan_requests % kThreads == 0 && (int64_t)n_total <= plan_requests);
+    const Ws ws = carve(plan_workspace, plan_requests, nb_log2);
     hipStream_t st = as_stream(stream);
     const unsigned nb = 1u << nb_log2;
     const unsigned W = (unsigned)cdiv(n_total, kThreads);     // rows of the count matrix in use (written by `prepare`)
@@ -967,7 +1103,7 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
     P.n_src = n_sources;
     P.n_total = n_total;
     P.req_blocks = W ? W : 1;                                 // (the scan of all-zero totals still publishes offs[])
-    P.total = ws.total; P.Cp = ws.Cp; P.offs = ws.offs; P.keys = ws.keys;
+    P.total = ws.total; P.Cp = ws.Cp; P.offs = ws.offs; P.keys = ws.keys; P.partials = ws.partials;
     P.nb_log2 = (unsigned)nb_log2;
     P.D = mode == RECALGO_SCATTER_ADAM ? deferred_of(deferred) : deferred_of(nullptr);
     P.step = reinterpret_cast<const long long*>(step_dev);
@@ -978,7 +1114,7 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
     P.chunk = (rows + P.period - 1) / P.period;
     unsigned sweep_blocks = 0;
     if (P.D.last_step) sweep_blocks = (unsigned)cdiv(P.chunk * G.L, kThreads);
-    const size_t smem = ((size_t)nb + kThreads + 8) * sizeof(unsigned) + kMaxSources * sizeof(SrcDev);
+    const size_t smem = ((size_t)nb + 7 * kThreads + 8 + 16) * sizeof(unsigned) + kThreads * 4 * sizeof(float) + kMaxSources * sizeof(SrcDev);
     if (G.vec == 4)
         hipLaunchKernelGGL(sparse_place_kernel<4>, dim3(P.req_blocks + sweep_blocks), dim3(kThreads), smem, st, P);
     else
@@ -987,7 +1123,7 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
     for (int i = 0; i < kMaxSources; ++i)
         A.src[i] = GSrc{P.src[i].g, P.src[i].g_stride, P.src[i].g_col, P.src[i].g_fmul, P.src[i].F, P.src[i].first};
     A.n_src = n_sources;
-    A.offs = ws.offs; A.keys = ws.keys; A.keys_alt = ws.keys_alt;
+    A.offs = ws.offs; A.keys = ws.keys; A.keys_alt = ws.keys_alt; A.partials = ws.partials;
     A.mode = mode;
     A.w = w; A.m = m; A.v = v; A.grad = grad;
     A.last_step = mode == RECALGO_SCATTER_ADAM ? deferred->last_step : nullptr;

@@ -58,11 +58,6 @@ class _CDeferred(ctypes.Structure):          # include/recalgo.h recalgo_deferre
                 ("lr_ring", ctypes.c_void_p), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float)]
 
 
-def _pad(n: int) -> int:
-    """A source occupies a whole number of 256-request workgroups of the plan's request space."""
-    return (n + 255) // 256 * 256
-
-
 class Source:
     """One lookup's requests: ids [n_ex, F] (offsets None) or ragged (values, offsets) with F steps per example."""
 
@@ -75,6 +70,15 @@ class Source:
     @property
     def n(self) -> int:
         return self.n_ex * self.F
+
+    @property
+    def slots(self) -> int:
+        """Size of the source in the plan's slot space (include/recalgo.h recalgo_scatter_source_slots): whole tiles of 256;
+        an id matrix takes F fields x (examples rounded up to 256), a ragged source its n_ex * F requests rounded up."""
+        if self.n == 0:
+            return 0
+        pad = lambda x: (x + 255) // 256 * 256
+        return pad(self.n) if self.offsets is not None else pad(self.n_ex) * self.F
 
     def set_grad(self, g: torch.Tensor, fmul: Optional[int] = None):
         """g: [n_ex, F * K] / [n_ex, F, K] / [n_ex, K'] with the last dimension contiguous; request (e, f) reads its K
@@ -116,10 +120,10 @@ class ArenaPlan:
         if self.ws is not None and n_requests <= self.capacity:
             return
         lib = _lib.load()
-        cap = max(n_requests, 1)
+        cap = max((n_requests + 255) // 256 * 256, 256)          # slots (whole tiles)
         self.nb_log2 = int(lib.recalgo_scatter_plan_buckets_log2(cap))
         self.capacity = cap
-        nbytes = int(lib.recalgo_scatter_plan_workspace_bytes(cap, self.nb_log2))
+        nbytes = int(lib.recalgo_scatter_plan_workspace_bytes(cap, self.nb_log2, self.arena.K))
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.arena.weight.device)
         self.counted = None
 
@@ -179,8 +183,8 @@ def begin_lookup(arena, store, ids: torch.Tensor, offsets: Optional[torch.Tensor
     lib = _lib.load()
     ws_ptr = None
     if register:
-        first = sum(_pad(s.n) for s in plan.sources)
-        plan._ensure_ws(first + _pad(src.n))
+        first = sum(s.slots for s in plan.sources)
+        plan._ensure_ws(first + src.slots)
         if plan.counted is None or plan.counted[:2] != (plan.ws.data_ptr(), plan.nb_log2):
             plan.counted = (plan.ws.data_ptr(), plan.nb_log2, ())
         ws_ptr = ctypes.c_void_p(plan.ws.data_ptr())
@@ -246,7 +250,7 @@ def _run(plan: ArenaPlan, sources: List[Source], mode: int, step_dev, step_offse
     if len([s for s in sources if s.n]) > MAX_SOURCES:
         sources = _merge_dense(sources, a.K)
     srcs = [s for s in sources if s.n]
-    plan._ensure_ws(sum(_pad(s.n) for s in srcs))
+    plan._ensure_ws(sum(s.slots for s in srcs))
     if plan.counted != plan._signature(srcs):
         # the counts in the workspace are not those of exactly these sources (first step, a forward without a backward, a
         # GRAD pass before the optimizer, a re-sized workspace): count again
@@ -255,7 +259,7 @@ def _run(plan: ArenaPlan, sources: List[Source], mode: int, step_dev, step_offse
             cs = s.c_struct(a.K)
             _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), a.K, ctypes.c_void_p(plan.ws.data_ptr()), plan.capacity,
                                                    plan.nb_log2, first, None, None, 0, _stream(a.weight)), "recalgo_scatter_prepare")
-            first += _pad(s.n)
+            first += s.slots
     if not srcs:                               # (the sweep and the lr ring still need the launch)
         dummy = Source(a.weight, None, None, 0, 0, 1)
         dummy.g, dummy.g_fmul = a.weight, a.K

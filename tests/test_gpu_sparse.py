@@ -1,8 +1,8 @@
 """Owner-computes row-gradient scatter + fused sparse optimizer (csrc/sparse.hip, recalgorithm_amd/sparse.py).
 
-  * GRAD mode: the per-row sums equal the request-order fp32 sum bit for bit (rows up to 48 requests), equal the fp64
-    sum within fp32 rounding everywhere (hot rows, oversize buckets that take the global merge sort), and are
-    bit-reproducible from run to run;
+  * GRAD mode: the per-row sums equal the fp32 sum in the kernels' documented order bit for bit (tiles of 256 examples of
+    a field in example order, then the tiles in order; rows up to 24 requests per tile / 48 tiles), equal the fp64 sum
+    within fp32 rounding everywhere (hot rows, large buckets), and are bit-reproducible from run to run;
   * ADAM mode (deferred-exact TF1 Adam): after the flush, weights and both moments are BIT-IDENTICAL to the dense
     TF1 Adam pass over the whole arena (tf.train.AdamOptimizer semantics, /root/reference algorithm/DeepFM/deepfm.py:246-250),
     and every forward reads the same weights the dense pass would have produced;
@@ -41,13 +41,22 @@ def _skewed_ids(gen, n_ex, F, rows, hot=0.3, oov=0.05):
 
 
 def _request_order_sum(ids, g, rows, K):
-    """fp32 sums in request order (numpy float32 adds, one row at a time)."""
+    """The fp32 sum in the kernels' (fixed) order, with numpy float32 adds: an id matrix is walked FIELD-MAJOR in tiles of
+    256 examples; the requests of a row inside a tile are added in example order (the tile's partial sum, csrc/sparse.hip
+    `place`), the tiles' partial sums of a row in tile order (`apply`)."""
     out = np.zeros((rows, K), dtype=np.float32)
-    flat = ids.reshape(-1).numpy()
-    gv = g.reshape(-1, K).numpy().astype(np.float32)
-    for i, r in enumerate(flat):
-        if r >= 0:
-            out[r] = out[r] + gv[i]
+    idn = ids.numpy()
+    gv = g.reshape(ids.shape[0], ids.shape[1], K).numpy().astype(np.float32)
+    n_ex, F = idn.shape
+    for f in range(F):
+        for e0 in range(0, n_ex, 256):
+            part = {}
+            for e in range(e0, min(n_ex, e0 + 256)):
+                r = int(idn[e, f])
+                if r >= 0:
+                    part[r] = gv[e, f].copy() if r not in part else part[r] + gv[e, f]
+            for r, p_ in part.items():
+                out[r] = out[r] + p_
     return torch.from_numpy(out)
 
 
