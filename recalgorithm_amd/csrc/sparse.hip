@@ -314,6 +314,7 @@ struct PlaceArgs {
     unsigned KV, L;
     long long rows, chunk;
     int period;
+    int stage_ok;                              // the tile's duplicated gradient rows fit the LDS staging area ([256][K] floats)
 };
 
 constexpr unsigned kTileLong = 24;             // duplicates of a row in a tile above which the whole workgroup sums them
@@ -364,6 +365,20 @@ __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
     SrcDev* lsrc = reinterpret_cast<SrcDev*>(ljobs + 16);     // [kMaxSources]
     copy_kernarg_words(reinterpret_cast<unsigned*>(lsrc), offsetof(PlaceArgs, src), sizeof(SrcDev) * kMaxSources);
     if (threadIdx.x == 0) { sh[6] = 0; sh[7] = 0; }
+    __syncthreads();
+    // this thread's slot: its row first (ids / row bases from memory), the scan of the bucket totals runs in its shadow
+    const unsigned i = blockIdx.x * kThreads + threadIdx.x;
+    long long row = -1;
+    unsigned gref = 0;
+    if (i < A.n_total) {
+        unsigned si = 0;                                      // (unused sources have first = 0xffffffff)
+#pragma unroll
+        for (int k = 1; k < kMaxSources; ++k) si += i >= lsrc[k].first;
+        const SrcDev S = lsrc[si];
+        unsigned refl = 0;
+        if (i - S.first < S.n) row = slot_row(S, i - S.first, &refl);     // (padding between two sources: no request)
+        gref = S.first + refl;
+    }
     {
         unsigned sum = 0;
         for (unsigned k = 0; k < bpt; ++k) sum += A.total[threadIdx.x * bpt + k];
@@ -376,19 +391,6 @@ __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
             run += A.total[b];
         }
         if (blockIdx.x == 0 && threadIdx.x == kThreads - 1) A.offs[nb] = total;
-    }
-    __syncthreads();
-    const unsigned i = blockIdx.x * kThreads + threadIdx.x;   // this thread's slot
-    long long row = -1;
-    unsigned gref = 0;
-    if (i < A.n_total) {
-        unsigned si = 0;                                      // (unused sources have first = 0xffffffff)
-#pragma unroll
-        for (int k = 1; k < kMaxSources; ++k) si += i >= lsrc[k].first;
-        const SrcDev S = lsrc[si];
-        unsigned refl = 0;
-        if (i - S.first < S.n) row = slot_row(S, i - S.first, &refl);     // (padding between two sources: no request)
-        gref = S.first + refl;
     }
     rows[threadIdx.x] = row >= 0 ? (unsigned)row : 0xffffffffu;
     grefs[threadIdx.x] = gref;
@@ -420,10 +422,42 @@ __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
         // a duplicated row's entry refers to the tile's partial sum (written below), a single request to its own row
         A.keys[offs[b] + A.Cp[(size_t)blockIdx.x * nb + b] + r] = ((unsigned long long)row << 32) | (dupl ? (kPartialBit | i) : gref);
     }
-    __syncthreads();
+    // (no barrier here: the staging loads below only need what was written before the last one, and overlap the Cp load)
     // ---- the duplicated rows of the tile: gradient rows added in request order ---------------------------------------
     const unsigned L = A.L, q = threadIdx.x & (L - 1), grp = threadIdx.x / L, ngrp = kThreads / L;
     const unsigned njobs = sh[6];
+    if (njobs == 0) return;                                   // (uniform)
+    if (A.stage_ok) {
+        // ONE round trip to memory: every duplicated request's gradient row goes to LDS (a group of L lanes per row, all
+        // loads of a thread in flight together), then each duplicated row is summed from LDS, in request order
+        V* stage = reinterpret_cast<V*>(lsrc + kMaxSources);  // [kThreads][KV]
+        V gq[4];
+        for (unsigned r0 = 0; r0 < L; r0 += 4) {              // a group owns the member threads grp, grp + ngrp, ...
+#pragma unroll
+            for (unsigned u = 0; u < 4; ++u) {
+                const unsigned tm = grp + (r0 + u) * ngrp;
+                gq[u] = vz<VEC>();
+                if (r0 + u < L && q < A.KV && samec[tm] > 1 && rows[tm] != 0xffffffffu) gq[u] = load_g_src<VEC>(lsrc, grefs[tm], q);
+            }
+#pragma unroll
+            for (unsigned u = 0; u < 4; ++u) {
+                const unsigned tm = grp + (r0 + u) * ngrp;
+                if (r0 + u < L && q < A.KV) stage[tm * A.KV + q] = gq[u];
+            }
+        }
+        __syncthreads();
+        for (unsigned k = grp; k < njobs; k += ngrp) {
+            const unsigned ld = jobs[k], c = samec[ld], bs = mbase[ld];
+            if (q < A.KV) {
+                V acc = vz<VEC>();
+                for (unsigned m = 0; m < c; ++m) vadd(acc, stage[mlist[bs + m] * A.KV + q]);
+                reinterpret_cast<V*>(A.partials)[((size_t)blockIdx.x * kThreads + ld) * A.KV + q] = acc;
+            }
+        }
+        return;
+    }
+    // wide rows (the staging tile would not fit): gradient rows straight from memory
+    __syncthreads();
     for (unsigned k = grp; k < njobs; k += ngrp) {
         const unsigned ld = jobs[k], c = samec[ld], bs = mbase[ld];
         if (c > kTileLong) {                                  // (at most 256 / 25 = 10 of them per tile)
@@ -1114,7 +1148,16 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
     P.chunk = (rows + P.period - 1) / P.period;
     unsigned sweep_blocks = 0;
     if (P.D.last_step) sweep_blocks = (unsigned)cdiv(P.chunk * G.L, kThreads);
-    const size_t smem = ((size_t)nb + 7 * kThreads + 8 + 16) * sizeof(unsigned) + kThreads * 4 * sizeof(float) + kMaxSources * sizeof(SrcDev);
+    P.stage_ok = (size_t)K * kThreads * sizeof(float) <= 32 * 1024;
+    const size_t smem = ((size_t)nb + 7 * kThreads + 8 + 16) * sizeof(unsigned) + kThreads * 4 * sizeof(float) + kMaxSources * sizeof(SrcDev) +
+                        (P.stage_ok ? (size_t)K * kThreads * sizeof(float) : 0);
+    if (smem > 64 * 1024) {
+        hipError_t e = G.vec == 4 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_place_kernel<4>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
+                                  : hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_place_kernel<1>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
     if (G.vec == 4)
         hipLaunchKernelGGL(sparse_place_kernel<4>, dim3(P.req_blocks + sweep_blocks), dim3(kThreads), smem, st, P);
     else
