@@ -47,8 +47,8 @@ constexpr int kThreads = 256;
 constexpr int kMaxSources = RECALGO_SCATTER_MAX_SOURCES;
 constexpr unsigned kLrRing = RECALGO_LR_RING;           // power of two
 constexpr unsigned kLdsKeys = 2048;                     // grouped keys kept in LDS (16 KB); larger buckets go through global memory
-constexpr unsigned kSlots = 512;                        // LDS hash of the distinct rows of a large bucket
 constexpr unsigned kMaxSeg = 512;                       // rows (segments) of a bucket listed in LDS
+constexpr unsigned kSlots = 512;                        // LDS hash of the distinct rows of a large bucket
 constexpr unsigned kLongSeg = 48;                       // requests per row above which the whole workgroup sums it
 constexpr unsigned kMaxLong = 64;                       // long rows remembered per bucket (more: summed by one group)
 constexpr unsigned long long kPadKey = ~0ull;
@@ -106,23 +106,62 @@ __device__ __forceinline__ long long slot_row(const SrcDev& S, unsigned li, unsi
     return id + S.base + (S.row_base ? S.row_base[f] : 0);
 }
 
-// Duplicates inside a tile: rows[] (LDS, one per thread, 0xffffffff = none).  -> number of threads with the same row,
-// how many of them come before this thread, and the first of them (the row's LEADER in this tile)
-struct TileDup { unsigned same, before, leader; };
-__device__ __forceinline__ TileDup tile_dups(const unsigned* rows, unsigned row) {
-    TileDup d{0, 0, 0xffffffffu};
-    const uint4* r4 = reinterpret_cast<const uint4*>(rows);
-#pragma unroll 16
-    for (unsigned j4 = 0; j4 < kThreads / 4; ++j4) {
-        const uint4 v = r4[j4];
-        const unsigned j = 4 * j4;
-        const unsigned e0 = v.x == row, e1 = v.y == row, e2 = v.z == row, e3 = v.w == row;
-        d.same += e0 + e1 + e2 + e3;
-        d.before += (e0 && j < threadIdx.x) + (e1 && j + 1 < threadIdx.x) + (e2 && j + 2 < threadIdx.x) + (e3 && j + 3 < threadIdx.x);
-        const unsigned fm = e0 ? j : (e1 ? j + 1 : (e2 ? j + 2 : (e3 ? j + 3 : 0xffffffffu)));
-        d.leader = min(d.leader, fm);
+// slot of `key` in an LDS open-addressing table of kSlots words (insert = true: claims an empty slot); kSlots if full
+__device__ __forceinline__ unsigned hash_slot(unsigned* hkey, unsigned key, bool insert) {
+    unsigned h = (key * 0x85EBCA6Bu) >> (32 - 9);             // kSlots = 512
+#pragma unroll 1
+    for (unsigned probe = 0; probe < kSlots; ++probe) {
+        const unsigned k = hkey[h];
+        if (k == key) return h;
+        if (k == kEmptyRow) {
+            if (!insert) return kSlots;
+            const unsigned old = atomicCAS(&hkey[h], kEmptyRow, key);
+            if (old == kEmptyRow || old == key) return h;
+        }
+        h = (h + 1) & (kSlots - 1);
     }
-    return d;
+    return kSlots;
+}
+
+// Equal keys among the 256 threads of a workgroup, in thread order — without the 256 x 256 comparisons (measured: two such
+// loops were half of `place`): every thread sets its bit in the 256-bit member mask of its key's hash slot; the number of
+// equal keys, how many of them come before this thread and the first of them (the LEADER) are popcounts of that mask.
+// mask: LDS [kSlots][8]; all threads call (barriers inside); key 0xffffffff = none (slot = kSlots).
+struct EqInfo { unsigned same, before, leader; };
+__device__ __forceinline__ void eq_masks_clear(unsigned* mask) {
+    uint4* m4 = reinterpret_cast<uint4*>(mask);
+    for (unsigned k = threadIdx.x; k < kSlots * 2; k += kThreads) m4[k] = make_uint4(0, 0, 0, 0);
+}
+__device__ __forceinline__ EqInfo eq_from_mask(const unsigned* mask, unsigned slot) {
+    EqInfo e{0, 0, 0};
+    if (slot >= kSlots) return e;
+    const uint4 a = reinterpret_cast<const uint4*>(mask)[slot * 2], b = reinterpret_cast<const uint4*>(mask)[slot * 2 + 1];
+    const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const unsigned mw = threadIdx.x >> 5, lowm = (1u << (threadIdx.x & 31)) - 1u;
+    unsigned leader = 0xffffffffu;
+#pragma unroll
+    for (int k = 7; k >= 0; --k) {
+        e.same += __popc(w[k]);
+        e.before += (unsigned)k < mw ? __popc(w[k]) : ((unsigned)k == mw ? __popc(w[k] & lowm) : 0u);
+        if (w[k]) leader = 32u * k + (unsigned)__ffs((int)w[k]) - 1u;
+    }
+    e.leader = leader;
+    return e;
+}
+// table hkey [kSlots] + mask [kSlots][8] (both cleared here); returns the thread's slot through *slot_out
+__device__ __forceinline__ EqInfo tile_equal(unsigned key, unsigned* hkey, unsigned* mask, unsigned* slot_out) {
+    __syncthreads();                                          // (the tables may still be read from an earlier call)
+    for (unsigned k = threadIdx.x; k < kSlots; k += kThreads) hkey[k] = kEmptyRow;
+    eq_masks_clear(mask);
+    __syncthreads();
+    unsigned slot = kSlots;
+    if (key != 0xffffffffu) {
+        slot = hash_slot(hkey, key, true);                    // (<= 256 distinct keys in 512 slots: always finds one)
+        atomicOr(&mask[slot * 8 + (threadIdx.x >> 5)], 1u << (threadIdx.x & 31));
+    }
+    __syncthreads();
+    *slot_out = slot;
+    return eq_from_mask(mask, slot);
 }
 
 __device__ __forceinline__ unsigned bucket_of(unsigned row, unsigned nb_log2) {
@@ -229,8 +268,9 @@ template <int VEC>
 __global__ __launch_bounds__(kThreads) void sparse_prepare_kernel(PrepareArgs A) {
     extern __shared__ unsigned lds_u[];
     const unsigned nb = 1u << A.nb_log2;
-    unsigned* rows = lds_u;                                   // [kThreads] the tile's rows
-    unsigned* hist = rows + kThreads;                         // [nb]
+    unsigned* hkey = lds_u;                                   // [kSlots]     the tile's distinct rows ...
+    unsigned* mask = hkey + kSlots;                           // [kSlots][8]  ... and which threads request them
+    unsigned* hist = mask + kSlots * 8;                       // [nb]
     long long* stale_row = reinterpret_cast<long long*>(hist + nb);    // [kThreads]
     int* stale_s = reinterpret_cast<int*>(stale_row + kThreads);        // [kThreads]
     unsigned* n_stale = reinterpret_cast<unsigned*>(stale_s + kThreads);
@@ -240,11 +280,11 @@ __global__ __launch_bounds__(kThreads) void sparse_prepare_kernel(PrepareArgs A)
     const unsigned li = blockIdx.x * kThreads + threadIdx.x;
     unsigned refl = 0;
     const long long row = li < A.S.n ? slot_row(A.S, li, &refl) : -1;
-    rows[threadIdx.x] = row >= 0 ? (unsigned)row : 0xffffffffu;
     const int target = A.D.last_step ? (int)(A.step[0] + A.step_off) : 0;
-    __syncthreads();
+    unsigned slot;
+    const EqInfo eq = tile_equal(row >= 0 ? (unsigned)row : 0xffffffffu, hkey, mask, &slot);
     // one entry per DISTINCT row of the tile (its first request, the leader) — `place` sums the tile's duplicates
-    if (row >= 0 && tile_dups(rows, (unsigned)row).before == 0) {
+    if (row >= 0 && eq.before == 0) {
         if (A.C) atomicAdd(&hist[bucket_of((unsigned)row, A.nb_log2)], 1u);     // (LDS)
         if (A.D.last_step) {
             // hot rows are current (their last_step is the previous step): only stale rows cost an atomic, and exactly one
@@ -362,7 +402,9 @@ __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
     unsigned* sh = offs + nb;                                 // [8]; sh[6] = number of jobs, sh[7] = number of long jobs
     // the source descriptors go to LDS: a data-dependent index into the kernel-argument array would go through scratch
     unsigned* ljobs = sh + 8;                                 // [16] leaders of the rows with > kTileLong duplicates (<= 10)
-    SrcDev* lsrc = reinterpret_cast<SrcDev*>(ljobs + 16);     // [kMaxSources]
+    unsigned* hkey = ljobs + 16;                              // [kSlots]     equal-key bookkeeping (tile_equal)
+    unsigned* mask = hkey + kSlots;                           // [kSlots][8]
+    SrcDev* lsrc = reinterpret_cast<SrcDev*>(mask + kSlots * 8);     // [kMaxSources]
     copy_kernarg_words(reinterpret_cast<unsigned*>(lsrc), offsetof(PlaceArgs, src), sizeof(SrcDev) * kMaxSources);
     if (threadIdx.x == 0) { sh[6] = 0; sh[7] = 0; }
     __syncthreads();
@@ -394,9 +436,8 @@ __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
     }
     rows[threadIdx.x] = row >= 0 ? (unsigned)row : 0xffffffffu;
     grefs[threadIdx.x] = gref;
-    __syncthreads();
-    TileDup d{0, 0, 0};
-    if (row >= 0) d = tile_dups(rows, (unsigned)row);
+    unsigned slot;
+    const EqInfo d = tile_equal(row >= 0 ? (unsigned)row : 0xffffffffu, hkey, mask, &slot);
     const bool leader = row >= 0 && d.before == 0, dupl = leader && d.same > 1;
     const unsigned b = leader ? bucket_of((unsigned)row, A.nb_log2) : 0xffffffffu;
     bk[threadIdx.x] = b;
@@ -408,17 +449,10 @@ __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
     if (dupl) jobs[atomicAdd(&sh[6], 1u)] = threadIdx.x;
     __syncthreads();
     if (row >= 0 && d.same > 1) mlist[mbase[d.leader] + d.before] = threadIdx.x;
+    // stable: the number of EARLIER leaders of this tile that go to the same bucket
+    unsigned slot_b;
+    const unsigned r = tile_equal(b, hkey, mask, &slot_b).before;
     if (leader) {
-        // stable: the number of EARLIER leaders of this tile that go to the same bucket
-        unsigned r = 0;
-        const uint4* bk4 = reinterpret_cast<const uint4*>(bk);
-#pragma unroll 16
-        for (unsigned j4 = 0; j4 < kThreads / 4; ++j4) {
-            const uint4 v = bk4[j4];
-            const unsigned j = 4 * j4;
-            r += (v.x == b && j < threadIdx.x) + (v.y == b && j + 1 < threadIdx.x) + (v.z == b && j + 2 < threadIdx.x) +
-                 (v.w == b && j + 3 < threadIdx.x);
-        }
         // a duplicated row's entry refers to the tile's partial sum (written below), a single request to its own row
         A.keys[offs[b] + A.Cp[(size_t)blockIdx.x * nb + b] + r] = ((unsigned long long)row << 32) | (dupl ? (kPartialBit | i) : gref);
     }
@@ -518,7 +552,6 @@ struct ApplyArgs {
     float lr, b1, b2, eps;
     unsigned K, KV, L;
     unsigned* live_words; int* live_list; int* live_count;    // GRAD mode: live-row bookkeeping of the old optimizer path
-    unsigned long long* dbg_buf;
 };
 
 __device__ __forceinline__ unsigned key_row(unsigned long long k) { return (unsigned)(k >> 32); }
@@ -651,7 +684,7 @@ __device__ __forceinline__ void long_rows(const ApplyArgs& A, const GSrc* lsrc, 
         if (grp == 0) st = load_state<VEC>(A, row, q);
         V acc = vz<VEC>();
         if (q < A.KV) {
-            constexpr int kU = 6;                             // row loads in flight (register budget: 4 workgroups / CU)
+            constexpr int kU = 4;                             // row loads in flight (register budget: 4 workgroups / CU)
             unsigned j = lo + grp;
             for (; j + (kU - 1) * ngrp < hi; j += kU * ngrp) {
                 V gq[kU];
@@ -788,23 +821,6 @@ __device__ __forceinline__ unsigned long long* global_merge_sort(unsigned long l
     return src;
 }
 
-// slot of `row` in the LDS hash of a large bucket's distinct rows (insert = true: claims an empty slot); kSlots if full
-__device__ __forceinline__ unsigned hash_slot(unsigned* hrow, unsigned row, bool insert) {
-    unsigned h = (row * 0x85EBCA6Bu) >> (32 - 9);             // kSlots = 512
-#pragma unroll 1
-    for (unsigned probe = 0; probe < kSlots; ++probe) {
-        const unsigned k = hrow[h];
-        if (k == row) return h;
-        if (k == kEmptyRow) {
-            if (!insert) return kSlots;
-            const unsigned old = atomicCAS(&hrow[h], kEmptyRow, row);
-            if (old == kEmptyRow || old == row) return h;
-        }
-        h = (h + 1) & (kSlots - 1);
-    }
-    return kSlots;
-}
-
 template <int VEC>
 __global__ __launch_bounds__(kThreads, 4) void sparse_apply_kernel(ApplyArgs A) {     // 1024 workgroups resident at once
     __shared__ unsigned long long lds_keys[kLdsKeys];         // grouped keys of buckets up to kLdsKeys requests
@@ -818,8 +834,6 @@ __global__ __launch_bounds__(kThreads, 4) void sparse_apply_kernel(ApplyArgs A) 
     __shared__ GSrc lsrc[kMaxSources];
     const unsigned b = blockIdx.x;
     const int t = (int)(A.step[0] + A.step_off);
-#define DBG_T(k) do { if (A.dbg_buf && threadIdx.x == 0) A.dbg_buf[(size_t)b * 8 + (k)] = wall_clock64(); } while (0)
-    DBG_T(0);
     if (threadIdx.x == 0) {
         n_long = 0; n_seg = 0; overflow = 0;
         float lr_t = 0.f;
@@ -861,10 +875,7 @@ __global__ __launch_bounds__(kThreads, 4) void sparse_apply_kernel(ApplyArgs A) 
             }
         }
         __syncthreads();
-        DBG_T(2);
         process_segments<VEC>(A, lsrc, lds_keys, seg_lo, seg_n, n_seg, long_list, &n_long, red, t, lr_t);
-        DBG_T(3);
-        if (A.dbg_buf && threadIdx.x == 0) { A.dbg_buf[(size_t)b * 8 + 4] = n; A.dbg_buf[(size_t)b * 8 + 5] = n_long; A.dbg_buf[(size_t)b * 8 + 1] = A.dbg_buf[(size_t)b * 8 + 0]; }
         return;
     }
     // ---- large bucket: the distinct rows in an LDS hash, then a stable counting scatter ------------------------------
@@ -901,7 +912,6 @@ __global__ __launch_bounds__(kThreads, 4) void sparse_apply_kernel(ApplyArgs A) 
         }
     }
     __syncthreads();
-    DBG_T(1);
     if (overflow) {
         // more distinct rows than the hash holds (cannot happen at ~100 requests per bucket; kept correct): full sort
         const unsigned long long* sorted;
@@ -962,10 +972,7 @@ __global__ __launch_bounds__(kThreads, 4) void sparse_apply_kernel(ApplyArgs A) 
             __syncthreads();
         }
     }
-    DBG_T(2);
     process_segments<VEC>(A, lsrc, out, seg_lo, seg_n, n_seg, long_list, &n_long, red, t, lr_t);
-    DBG_T(3);
-    if (A.dbg_buf && threadIdx.x == 0) { A.dbg_buf[(size_t)b * 8 + 4] = n; A.dbg_buf[(size_t)b * 8 + 5] = n_long; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1102,7 +1109,7 @@ RECALGO_EXPORT int recalgo_scatter_prepare(const recalgo_scatter_source_t* sourc
     A.step = reinterpret_cast<const long long*>(step_dev);
     A.step_off = step_offset;
     A.KV = G.KV; A.L = G.L;
-    const size_t smem = (((size_t)1 << nb_log2) + kThreads) * sizeof(unsigned) + kThreads * (sizeof(long long) + sizeof(int)) + 16;
+    const size_t smem = (((size_t)1 << nb_log2) + kSlots * 9) * sizeof(unsigned) + kThreads * (sizeof(long long) + sizeof(int)) + 16;
     const dim3 grid(cdiv(n, kThreads));
     if (G.vec == 4)
         hipLaunchKernelGGL(sparse_prepare_kernel<4>, grid, dim3(kThreads), smem, as_stream(stream), A);
@@ -1149,7 +1156,7 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
     unsigned sweep_blocks = 0;
     if (P.D.last_step) sweep_blocks = (unsigned)cdiv(P.chunk * G.L, kThreads);
     P.stage_ok = (size_t)K * kThreads * sizeof(float) <= 32 * 1024;
-    const size_t smem = ((size_t)nb + 7 * kThreads + 8 + 16) * sizeof(unsigned) + kThreads * 4 * sizeof(float) + kMaxSources * sizeof(SrcDev) +
+    const size_t smem = ((size_t)nb + 7 * kThreads + 8 + 16 + kSlots * 9) * sizeof(unsigned) + kThreads * 4 * sizeof(float) + kMaxSources * sizeof(SrcDev) +
                         (P.stage_ok ? (size_t)K * kThreads * sizeof(float) : 0);
     if (smem > 64 * 1024) {
         hipError_t e = G.vec == 4 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_place_kernel<4>),
@@ -1176,7 +1183,6 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
     A.lr = lr; A.b1 = beta1; A.b2 = beta2; A.eps = eps;
     A.K = (unsigned)K; A.KV = G.KV; A.L = G.L;
     A.live_words = nullptr; A.live_list = nullptr; A.live_count = nullptr;
-    { const char* e = getenv("RECALGO_SPARSE_DBG_BUF"); A.dbg_buf = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr; }
     if (mode == RECALGO_SCATTER_GRAD && live && live->row_live) {
         RECALGO_REQUIRE((reinterpret_cast<uintptr_t>(live->row_live) & 3) == 0 && live->row_offset == 0);
         A.live_words = reinterpret_cast<unsigned*>(live->row_live);
