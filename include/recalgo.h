@@ -633,6 +633,28 @@ typedef struct {
     float* lr_ring;                 /* [RECALGO_LR_RING] fp32: lr_t(j) at j % RECALGO_LR_RING */
     float beta1, beta2, eps;
 } recalgo_deferred_adam_t;
+/* The forward lookups on an arena with deferred-Adam state: identical to recalgo_embedding_gather_fwd /
+ * _embedding_bag_mean_fwd / _sequence_gather_fwd / _deepfm_sparse_fwd, except that a row whose state lags
+ * (last_step[row] < step_dev[0] + step_offset) is read AS OF that step: the missed g = 0 updates are replayed in registers
+ * (bit-identical to the dense optimizer pass) and nothing is written back — the optimizer's `apply` / the sweep do the real
+ * catch-up.  deferred = NULL: the plain lookup.  table_row_base = arena row of row 0 of `table` (m, v, last_step are arena
+ * based). */
+int recalgo_embedding_gather_fwd_deferred(const int64_t* ids, const float* arena, const int64_t* row_base, int B, int F, int K,
+                                          float* out, int out_stride, int out_col, const recalgo_deferred_adam_t* deferred,
+                                          const int64_t* step_dev, int step_offset, recalgo_stream_t stream);
+int recalgo_embedding_bag_mean_fwd_deferred(const int64_t* values, const int64_t* offsets, const float* table, int B, int K,
+                                            float* out, int out_stride, int out_col, const recalgo_deferred_adam_t* deferred,
+                                            int64_t table_row_base, const int64_t* step_dev, int step_offset,
+                                            recalgo_stream_t stream);
+int recalgo_sequence_gather_fwd_deferred(const int64_t* values, const int64_t* offsets, const float* table, int B, int T, int K,
+                                         float* out, int32_t* seq_len, const recalgo_deferred_adam_t* deferred,
+                                         int64_t table_row_base, const int64_t* step_dev, int step_offset,
+                                         recalgo_stream_t stream);
+int recalgo_deepfm_sparse_fwd_deferred(const int64_t* ids, const float* arena, const float* w1, const float* bias,
+                                       const int64_t* row_base, int B, int F, int K, float* emb, float* fm1, float* fm2,
+                                       float* field_sum, const recalgo_deferred_adam_t* deferred,
+                                       const recalgo_deferred_adam_t* deferred_w1, const int64_t* step_dev, int step_offset,
+                                       recalgo_stream_t stream);
 int recalgo_scatter_plan_buckets_log2(int64_t n_requests);
 int64_t recalgo_scatter_source_slots(int n_ex, int F, int ragged);
 int64_t recalgo_scatter_plan_workspace_bytes(int64_t n_slots, int nb_log2, int K);

@@ -90,6 +90,10 @@ SIGNATURES = {
     "recalgo_activation_fwd": (c_int, [P, P, c_int, c_int, c_int, P, P]),
     "recalgo_activation_bwd_workspace_bytes": (c_int64, [c_int, c_int]),
     "recalgo_activation_bwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, P]),
+    "recalgo_embedding_gather_fwd_deferred": (c_int, [P, P, P, c_int, c_int, c_int, P, c_int, c_int, P, P, c_int, P]),
+    "recalgo_embedding_bag_mean_fwd_deferred": (c_int, [P, P, P, c_int, c_int, P, c_int, c_int, P, c_int64, P, c_int, P]),
+    "recalgo_sequence_gather_fwd_deferred": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, c_int64, P, c_int, P]),
+    "recalgo_deepfm_sparse_fwd_deferred": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, P]),
     "recalgo_scatter_plan_buckets_log2": (c_int, [c_int64]),
     "recalgo_scatter_plan_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
     "recalgo_scatter_source_slots": (c_int64, [c_int, c_int, c_int]),

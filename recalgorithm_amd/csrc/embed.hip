@@ -13,7 +13,7 @@
 // that duplicates meet in the same table.
 #include <cstdlib>
 
-#include "common.h"
+#include "deferred.h"
 
 namespace {
 
@@ -174,7 +174,7 @@ template <int VEC>
 __global__ __launch_bounds__(kThreads) void gather_fwd_kernel(
     const int64_t* __restrict__ ids, const float* __restrict__ arena,
     const int64_t* __restrict__ row_base, unsigned total, unsigned F, unsigned KV,
-    float* __restrict__ out, unsigned out_stride, unsigned out_col) {
+    float* __restrict__ out, unsigned out_stride, unsigned out_col, recalgo_deferred::ReadView D) {
     using V = typename VecT<VEC>::type;
     unsigned i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= total) return;
@@ -184,7 +184,10 @@ __global__ __launch_bounds__(kThreads) void gather_fwd_kernel(
     unsigned f = row - b * F;
     int64_t id = ids[row];
     V v = vzero<VEC>();
-    if (id >= 0) v = reinterpret_cast<const V*>(arena)[(row_base[f] + id) * KV + q];
+    if (id >= 0) {
+        const int64_t ar = row_base[f] + id;
+        v = recalgo_deferred::current_piece(D, reinterpret_cast<const V*>(arena)[ar * KV + q], ar, q, KV);   // (deferred Adam)
+    }
     *reinterpret_cast<V*>(out + (size_t)b * out_stride + out_col + (f * KV + q) * VEC) = v;
 }
 
@@ -243,7 +246,7 @@ template <int VEC>
 __global__ __launch_bounds__(kThreads) void bag_mean_fwd_kernel(
     const int64_t* __restrict__ values, const int64_t* __restrict__ offsets,
     const float* __restrict__ table, unsigned total, unsigned KV, float* __restrict__ out,
-    unsigned out_stride, unsigned out_col) {
+    unsigned out_stride, unsigned out_col, recalgo_deferred::ReadView D) {
     using V = typename VecT<VEC>::type;
     unsigned i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= total) return;
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(kThreads) void bag_mean_fwd_kernel(
     for (int64_t j = beg; j < end; ++j) {
         int64_t id = values[j];
         if (id >= 0) {
-            V r = reinterpret_cast<const V*>(table)[id * KV + q];
+            V r = recalgo_deferred::current_piece(D, reinterpret_cast<const V*>(table)[id * KV + q], id, q, KV);
             const float* rp = reinterpret_cast<const float*>(&r);
 #pragma unroll
             for (int c = 0; c < VEC; ++c) acc[c] += rp[c];
@@ -312,7 +315,7 @@ template <int VEC>
 __global__ __launch_bounds__(kThreads) void seq_gather_fwd_kernel(
     const int64_t* __restrict__ values, const int64_t* __restrict__ offsets,
     const float* __restrict__ table, unsigned total, unsigned T, unsigned KV,
-    float* __restrict__ out, int32_t* __restrict__ seq_len) {
+    float* __restrict__ out, int32_t* __restrict__ seq_len, recalgo_deferred::ReadView D) {
     using V = typename VecT<VEC>::type;
     unsigned i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= total) return;
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(kThreads) void seq_gather_fwd_kernel(
     V v = vzero<VEC>();
     if ((int64_t)t < len) {
         int64_t id = values[beg + t];
-        if (id >= 0) v = reinterpret_cast<const V*>(table)[id * KV + q];
+        if (id >= 0) v = recalgo_deferred::current_piece(D, reinterpret_cast<const V*>(table)[id * KV + q], id, q, KV);
     }
     reinterpret_cast<V*>(out)[i] = v;
 }
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(kThreads) void deepfm_sparse_fwd_kernel(
     const float* __restrict__ w1, const float* __restrict__ bias,
     const int64_t* __restrict__ row_base, unsigned B, unsigned F, unsigned K4,
     float4* __restrict__ emb, float* __restrict__ fm1, float* __restrict__ fm2,
-    float* __restrict__ fsum) {
+    float* __restrict__ fsum, recalgo_deferred::ReadView D, recalgo_deferred::ReadView D1) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const unsigned K = K4 * 4;
     const unsigned FK = F * K;
@@ -398,11 +401,11 @@ __global__ __launch_bounds__(kThreads) void deepfm_sparse_fwd_kernel(
         int64_t arow = 0;
         if (id >= 0) {
             arow = row_base[f] + id;
-            v = arena[arow * K4 + q];
+            v = recalgo_deferred::current_piece(D, arena[arow * K4 + q], arow, q, K4);
         }
         emb[grow * K4 + q] = v;
         *reinterpret_cast<float4*>(tile + e * ex_stride + r * 4) = v;
-        if (q == 0) w1s[e * F + f] = (id >= 0) ? w1[arow] : 0.f;
+        if (q == 0) w1s[e * F + f] = (id >= 0) ? recalgo_deferred::current_piece(D1, w1[arow], arow, 0u, 1u) : 0.f;
     }
     __syncthreads();
 
@@ -542,10 +545,29 @@ inline int vec_of(int K, int stride, int col) { return (K % 4 == 0 && stride % 4
 // =============================================================================================
 // C-ABI
 // =============================================================================================
+namespace {
+// the read view of an arena's deferred-Adam state for a forward lookup (nullptr / no state: plain lookup)
+inline recalgo_deferred::ReadView read_view(const recalgo_deferred_adam_t* d, const int64_t* step_dev, int step_offset,
+                                            int64_t row_offset) {
+    if (!d || !d->last_step || !step_dev)
+        return recalgo_deferred::ReadView{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0.f, 0.f, 0};
+    return recalgo_deferred::ReadView{d->m, d->v, d->last_step, d->lr_ring, reinterpret_cast<const long long*>(step_dev), step_offset,
+                                      d->beta1, d->beta2, d->eps, (long long)row_offset};
+}
+}  // namespace
+
 RECALGO_EXPORT int recalgo_embedding_gather_fwd(const int64_t* ids, const float* arena,
                                                 const int64_t* row_base, int B, int F, int K,
                                                 float* out, int out_stride, int out_col,
                                                 recalgo_stream_t stream) {
+    return recalgo_embedding_gather_fwd_deferred(ids, arena, row_base, B, F, K, out, out_stride, out_col, nullptr, nullptr, 0, stream);
+}
+
+RECALGO_EXPORT int recalgo_embedding_gather_fwd_deferred(const int64_t* ids, const float* arena, const int64_t* row_base, int B,
+                                                         int F, int K, float* out, int out_stride, int out_col,
+                                                         const recalgo_deferred_adam_t* deferred, const int64_t* step_dev,
+                                                         int step_offset, recalgo_stream_t stream) {
+    const recalgo_deferred::ReadView D = read_view(deferred, step_dev, step_offset, 0);
     RECALGO_REQUIRE(B >= 0 && F > 0 && K > 0 && out_stride >= out_col + F * K);
     const int vec = vec_of(K, out_stride, out_col);
     int64_t total = (int64_t)B * F * (K / vec);
@@ -554,11 +576,11 @@ RECALGO_EXPORT int recalgo_embedding_gather_fwd(const int64_t* ids, const float*
     if (vec == 4)
         hipLaunchKernelGGL(gather_fwd_kernel<4>, dim3(cdiv(total, kThreads)), dim3(kThreads), 0, as_stream(stream),
                            ids, arena, row_base, (unsigned)total, (unsigned)F, (unsigned)(K / 4), out,
-                           (unsigned)out_stride, (unsigned)out_col);
+                           (unsigned)out_stride, (unsigned)out_col, D);
     else
         hipLaunchKernelGGL(gather_fwd_kernel<1>, dim3(cdiv(total, kThreads)), dim3(kThreads), 0, as_stream(stream),
                            ids, arena, row_base, (unsigned)total, (unsigned)F, (unsigned)K, out,
-                           (unsigned)out_stride, (unsigned)out_col);
+                           (unsigned)out_stride, (unsigned)out_col, D);
     RECALGO_RETURN_LAST();
 }
 
@@ -590,6 +612,14 @@ RECALGO_EXPORT int recalgo_embedding_bag_mean_fwd(const int64_t* values, const i
                                                   const float* table, int B, int K, float* out,
                                                   int out_stride, int out_col,
                                                   recalgo_stream_t stream) {
+    return recalgo_embedding_bag_mean_fwd_deferred(values, offsets, table, B, K, out, out_stride, out_col, nullptr, 0, nullptr, 0, stream);
+}
+
+RECALGO_EXPORT int recalgo_embedding_bag_mean_fwd_deferred(const int64_t* values, const int64_t* offsets, const float* table, int B,
+                                                           int K, float* out, int out_stride, int out_col,
+                                                           const recalgo_deferred_adam_t* deferred, int64_t table_row_base,
+                                                           const int64_t* step_dev, int step_offset, recalgo_stream_t stream) {
+    const recalgo_deferred::ReadView D = read_view(deferred, step_dev, step_offset, table_row_base);
     RECALGO_REQUIRE(B >= 0 && K > 0 && out_stride >= out_col + K);
     const int vec = vec_of(K, out_stride, out_col);
     int64_t total = (int64_t)B * (K / vec);
@@ -598,11 +628,11 @@ RECALGO_EXPORT int recalgo_embedding_bag_mean_fwd(const int64_t* values, const i
     if (vec == 4)
         hipLaunchKernelGGL(bag_mean_fwd_kernel<4>, dim3(cdiv(total, kThreads)), dim3(kThreads), 0, as_stream(stream),
                            values, offsets, table, (unsigned)total, (unsigned)(K / 4), out, (unsigned)out_stride,
-                           (unsigned)out_col);
+                           (unsigned)out_col, D);
     else
         hipLaunchKernelGGL(bag_mean_fwd_kernel<1>, dim3(cdiv(total, kThreads)), dim3(kThreads), 0, as_stream(stream),
                            values, offsets, table, (unsigned)total, (unsigned)K, out, (unsigned)out_stride,
-                           (unsigned)out_col);
+                           (unsigned)out_col, D);
     RECALGO_RETURN_LAST();
 }
 
@@ -631,6 +661,14 @@ RECALGO_EXPORT int recalgo_embedding_bag_mean_bwd(const int64_t* values, const i
 RECALGO_EXPORT int recalgo_sequence_gather_fwd(const int64_t* values, const int64_t* offsets,
                                                const float* table, int B, int T, int K, float* out,
                                                int32_t* seq_len, recalgo_stream_t stream) {
+    return recalgo_sequence_gather_fwd_deferred(values, offsets, table, B, T, K, out, seq_len, nullptr, 0, nullptr, 0, stream);
+}
+
+RECALGO_EXPORT int recalgo_sequence_gather_fwd_deferred(const int64_t* values, const int64_t* offsets, const float* table, int B,
+                                                        int T, int K, float* out, int32_t* seq_len,
+                                                        const recalgo_deferred_adam_t* deferred, int64_t table_row_base,
+                                                        const int64_t* step_dev, int step_offset, recalgo_stream_t stream) {
+    const recalgo_deferred::ReadView D = read_view(deferred, step_dev, step_offset, table_row_base);
     RECALGO_REQUIRE(B >= 0 && T > 0 && K > 0);
     const int vec = K % 4 == 0 ? 4 : 1;
     int64_t total = (int64_t)B * T * (K / vec);
@@ -639,11 +677,11 @@ RECALGO_EXPORT int recalgo_sequence_gather_fwd(const int64_t* values, const int6
     if (vec == 4)
         hipLaunchKernelGGL(seq_gather_fwd_kernel<4>, dim3(cdiv(total, kThreads)), dim3(kThreads), 0,
                            as_stream(stream), values, offsets, table, (unsigned)total, (unsigned)T,
-                           (unsigned)(K / 4), out, seq_len);
+                           (unsigned)(K / 4), out, seq_len, D);
     else
         hipLaunchKernelGGL(seq_gather_fwd_kernel<1>, dim3(cdiv(total, kThreads)), dim3(kThreads), 0,
                            as_stream(stream), values, offsets, table, (unsigned)total, (unsigned)T, (unsigned)K,
-                           out, seq_len);
+                           out, seq_len, D);
     RECALGO_RETURN_LAST();
 }
 
@@ -678,6 +716,17 @@ RECALGO_EXPORT int recalgo_deepfm_sparse_fwd(const int64_t* ids, const float* ar
                                              const int64_t* row_base, int B, int F, int K,
                                              float* emb, float* fm1, float* fm2, float* field_sum,
                                              recalgo_stream_t stream) {
+    return recalgo_deepfm_sparse_fwd_deferred(ids, arena, w1, bias, row_base, B, F, K, emb, fm1, fm2, field_sum, nullptr, nullptr,
+                                              nullptr, 0, stream);
+}
+
+RECALGO_EXPORT int recalgo_deepfm_sparse_fwd_deferred(const int64_t* ids, const float* arena, const float* w1, const float* bias,
+                                                      const int64_t* row_base, int B, int F, int K, float* emb, float* fm1,
+                                                      float* fm2, float* field_sum, const recalgo_deferred_adam_t* deferred,
+                                                      const recalgo_deferred_adam_t* deferred_w1, const int64_t* step_dev,
+                                                      int step_offset, recalgo_stream_t stream) {
+    const recalgo_deferred::ReadView D = read_view(deferred, step_dev, step_offset, 0);
+    const recalgo_deferred::ReadView D1 = read_view(deferred_w1, step_dev, step_offset, 0);
     RECALGO_REQUIRE(B >= 0 && F > 0 && K > 0 && K % 4 == 0 && K <= 64 && field_sum != nullptr);
     if (B == 0) return 0;
     size_t smem = (size_t)kDeepfmEB * (F * K + 16 + F) * sizeof(float);
@@ -685,7 +734,7 @@ RECALGO_EXPORT int recalgo_deepfm_sparse_fwd(const int64_t* ids, const float* ar
     hipLaunchKernelGGL(deepfm_sparse_fwd_kernel<kDeepfmEB>, dim3(cdiv(B, kDeepfmEB)),
                        dim3(kThreads), smem, as_stream(stream), ids,
                        reinterpret_cast<const float4*>(arena), w1, bias, row_base, (unsigned)B,
-                       (unsigned)F, (unsigned)(K / 4), reinterpret_cast<float4*>(emb), fm1, fm2, field_sum);
+                       (unsigned)F, (unsigned)(K / 4), reinterpret_cast<float4*>(emb), fm1, fm2, field_sum, D, D1);
     RECALGO_RETURN_LAST();
 }
 

@@ -39,13 +39,13 @@
 #include <cstddef>
 #include <cstdlib>
 
-#include "common.h"
+#include "deferred.h"
 
 namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxSources = RECALGO_SCATTER_MAX_SOURCES;
-constexpr unsigned kLrRing = RECALGO_LR_RING;           // power of two
+using recalgo_deferred::kLrRing;
 constexpr unsigned kLdsKeys = 2048;                     // grouped keys kept in LDS (16 KB); larger buckets go through global memory
 constexpr unsigned kMaxSeg = 512;                       // rows (segments) of a bucket listed in LDS
 constexpr unsigned kSlots = 512;                        // LDS hash of the distinct rows of a large bucket
@@ -174,11 +174,7 @@ __device__ __forceinline__ float lr_t_of(float lr, float b1, float b2, long long
     return (float)((double)lr * sqrt(1.0 - pow((double)b2, td)) / (1.0 - pow((double)b1, td)));
 }
 
-__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float lr_t, float b1, float b2, float eps) {
-    m = fmaf(b1, m, (1.f - b1) * g);
-    v = fmaf(b2, v, (1.f - b2) * g * g);
-    p -= lr_t * m / (sqrtf(v) + eps);
-}
+using recalgo_deferred::vadam;
 
 // ---- row state access: VEC = 4 (K % 4 == 0: lane q of a group holds floats 4q .. 4q+3) or 1 ---------------------
 template <int VEC> struct Vec;
@@ -189,16 +185,6 @@ template <> __device__ __forceinline__ float4 vz<4>() { return f4_zero(); }
 template <> __device__ __forceinline__ float vz<1>() { return 0.f; }
 __device__ __forceinline__ void vadd(float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 __device__ __forceinline__ void vadd(float& a, const float b) { a += b; }
-__device__ __forceinline__ void vadam(float4& p, const float4 g, float4& m, float4& v, float lr_t, float b1, float b2, float eps) {
-    adam1(p.x, g.x, m.x, v.x, lr_t, b1, b2, eps);
-    adam1(p.y, g.y, m.y, v.y, lr_t, b1, b2, eps);
-    adam1(p.z, g.z, m.z, v.z, lr_t, b1, b2, eps);
-    adam1(p.w, g.w, m.w, v.w, lr_t, b1, b2, eps);
-}
-__device__ __forceinline__ void vadam(float& p, const float g, float& m, float& v, float lr_t, float b1, float b2, float eps) {
-    adam1(p, g, m, v, lr_t, b1, b2, eps);
-}
-
 struct Deferred {                  // deferred-Adam state of one arena
     float* w; float* m; float* v;
     int* last_step;                // [rows]: 0 = never touched (m = v = 0), s > 0 = (w, m, v) valid for step s, < 0 = claimed
@@ -210,7 +196,7 @@ struct Deferred {                  // deferred-Adam state of one arena
 template <int VEC>
 __device__ __forceinline__ void replay(typename Vec<VEC>::T& w, typename Vec<VEC>::T& m, typename Vec<VEC>::T& v, int s,
                                        int target, const Deferred& D) {
-    for (int j = s + 1; j <= target; ++j) vadam(w, vz<VEC>(), m, v, D.lr_ring[(unsigned)j & (kLrRing - 1)], D.b1, D.b2, D.eps);
+    recalgo_deferred::replay(w, m, v, s, target, D.lr_ring, D.b1, D.b2, D.eps);
 }
 
 // bring row `row` (state valid for step s) to `target`; the L lanes of a group call this together (q = lane in group)
@@ -311,8 +297,37 @@ __global__ __launch_bounds__(kThreads) void sparse_prepare_kernel(PrepareArgs A)
 // 2. scan: Cp[w][b] = sum_{w' < w} C[w'][b],  total[b] = sum_w C[w][b]
 //    workgroup = 16 columns x 16 row lanes; a lane owns a contiguous range of the W rows
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void sparse_scan_kernel(const unsigned short* __restrict__ C, unsigned* __restrict__ Cp,
-                                                               unsigned* __restrict__ total, unsigned W, unsigned nb) {
+struct ScanArgs {
+    const unsigned short* C; unsigned* Cp; unsigned* total;
+    unsigned W, nb, scan_blocks;
+    // sweep (deferred Adam), in the extra workgroups of this launch: rows [c * chunk, (c + 1) * chunk), c = target % period,
+    // are brought to `target` — beside the scan's 64 workgroups the sweep has the chip to itself, and it touches neither
+    // the plan nor (before `apply`) any row another kernel of this launch sequence is working on
+    Deferred D;
+    const long long* step;
+    int step_off;
+    unsigned KV, L;
+    long long rows, chunk;
+    int period;
+};
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void sparse_scan_kernel(ScanArgs A) {
+    if (blockIdx.x >= A.scan_blocks) {                        // ---- sweep workgroups -------------------------------
+        const int target = (int)(A.step[0] + A.step_off);
+        if (target <= 0) return;
+        const long long c0 = (long long)(target % A.period) * A.chunk;
+        const unsigned idx = (blockIdx.x - A.scan_blocks) * kThreads + threadIdx.x;
+        const long long row = c0 + idx / A.L;
+        const unsigned q = idx & (A.L - 1);
+        if (row >= A.rows || row >= c0 + A.chunk) return;
+        const int s = A.D.last_step[row];
+        if (s > 0 && s < target) catch_up_row<VEC>(A.D, row, s, target, q, A.KV);
+        return;
+    }
+    const unsigned short* __restrict__ C = A.C;
+    unsigned* __restrict__ Cp = A.Cp;
+    const unsigned W = A.W, nb = A.nb;
     __shared__ unsigned part[16][17];
     const unsigned c = threadIdx.x & 15, r = threadIdx.x >> 4;
     const unsigned col = blockIdx.x * 16 + c;
@@ -327,7 +342,7 @@ __global__ __launch_bounds__(kThreads) void sparse_scan_kernel(const unsigned sh
 #pragma unroll
     for (unsigned k = 0; k < 16; ++k)
         if (k < r) run += part[k][c];
-    if (r == 15) total[col] = run + s;
+    if (r == 15) A.total[col] = run + s;
 #pragma unroll 8
     for (unsigned row = r0; row < r1; ++row) {
         const unsigned v = C[(size_t)row * nb + col];
@@ -347,13 +362,7 @@ struct PlaceArgs {
     unsigned long long* keys;                  // [n_total]
     float* partials;                           // [n_total][K]: the summed gradient rows of a tile's duplicated rows
     unsigned nb_log2;
-    // sweep (deferred Adam): rows [c * chunk, (c + 1) * chunk), c = target % period, are brought to `target`
-    Deferred D;
-    const long long* step;
-    int step_off;
     unsigned KV, L;
-    long long rows, chunk;
-    int period;
     int stage_ok;                              // the tile's duplicated gradient rows fit the LDS staging area ([256][K] floats)
 };
 
@@ -376,18 +385,6 @@ __device__ __forceinline__ typename Vec<VEC>::T load_g_src(const SrcDev* lsrc, u
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
     using V = typename Vec<VEC>::T;
-    if (blockIdx.x >= A.req_blocks) {                         // ---- sweep workgroups -------------------------------
-        const int target = (int)(A.step[0] + A.step_off);
-        if (target <= 0) return;
-        const long long c0 = (long long)(target % A.period) * A.chunk;
-        const unsigned idx = (blockIdx.x - A.req_blocks) * kThreads + threadIdx.x;
-        const long long row = c0 + idx / A.L;
-        const unsigned q = idx & (A.L - 1);
-        if (row >= A.rows || row >= c0 + A.chunk) return;
-        const int s = A.D.last_step[row];
-        if (s > 0 && s < target) catch_up_row<VEC>(A.D, row, s, target, q, A.KV);
-        return;
-    }
     extern __shared__ unsigned lds_u[];
     const unsigned nb = 1u << A.nb_log2, bpt = nb / kThreads;   // nb is a multiple of kThreads
     unsigned* rows = lds_u;                                   // [kThreads] the tile's rows
@@ -1140,22 +1137,28 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
     hipStream_t st = as_stream(stream);
     const unsigned nb = 1u << nb_log2;
     const unsigned W = (unsigned)cdiv(n_total, kThreads);     // rows of the count matrix in use (written by `prepare`)
-    hipLaunchKernelGGL(sparse_scan_kernel, dim3(nb / 16), dim3(kThreads), 0, st, ws.C, ws.Cp, ws.total, W, nb);
+    {
+        ScanArgs S;
+        S.C = ws.C; S.Cp = ws.Cp; S.total = ws.total; S.W = W; S.nb = nb; S.scan_blocks = nb / 16;
+        S.D = mode == RECALGO_SCATTER_ADAM ? deferred_of(deferred) : deferred_of(nullptr);
+        S.step = reinterpret_cast<const long long*>(step_dev);
+        S.step_off = step_offset - 1;                         // the sweep (like `prepare`) targets the step BEFORE this one
+        S.KV = G.KV; S.L = G.L;
+        S.rows = rows;
+        S.period = sweep_period < 1 ? 1 : sweep_period;
+        S.chunk = (rows + S.period - 1) / S.period;
+        const unsigned sweep_blocks = S.D.last_step ? (unsigned)cdiv(S.chunk * G.L, kThreads) : 0u;
+        if (G.vec == 4)
+            hipLaunchKernelGGL(sparse_scan_kernel<4>, dim3(S.scan_blocks + sweep_blocks), dim3(kThreads), 0, st, S);
+        else
+            hipLaunchKernelGGL(sparse_scan_kernel<1>, dim3(S.scan_blocks + sweep_blocks), dim3(kThreads), 0, st, S);
+    }
     P.n_src = n_sources;
     P.n_total = n_total;
     P.req_blocks = W ? W : 1;                                 // (the scan of all-zero totals still publishes offs[])
     P.total = ws.total; P.Cp = ws.Cp; P.offs = ws.offs; P.keys = ws.keys; P.partials = ws.partials;
     P.nb_log2 = (unsigned)nb_log2;
-    P.D = mode == RECALGO_SCATTER_ADAM ? deferred_of(deferred) : deferred_of(nullptr);
-    P.step = reinterpret_cast<const long long*>(step_dev);
-    P.step_off = step_offset - 1;                             // the sweep (like `prepare`) targets the step BEFORE this one
     P.KV = G.KV; P.L = G.L;
-    P.rows = rows;
-    P.period = sweep_period < 1 ? 1 : sweep_period;
-    P.chunk = (rows + P.period - 1) / P.period;
-    unsigned sweep_blocks = 0;
-    if (P.D.last_step) sweep_blocks = (unsigned)cdiv(P.chunk * G.L, kThreads);
-    P.stage_ok = (size_t)K * kThreads * sizeof(float) <= 32 * 1024;
     const size_t smem = ((size_t)nb + 7 * kThreads + 8 + 16 + kSlots * 9) * sizeof(unsigned) + kThreads * 4 * sizeof(float) + kMaxSources * sizeof(SrcDev) +
                         (P.stage_ok ? (size_t)K * kThreads * sizeof(float) : 0);
     if (smem > 64 * 1024) {
@@ -1166,9 +1169,9 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
         if (e != hipSuccess) return (int)e;
     }
     if (G.vec == 4)
-        hipLaunchKernelGGL(sparse_place_kernel<4>, dim3(P.req_blocks + sweep_blocks), dim3(kThreads), smem, st, P);
+        hipLaunchKernelGGL(sparse_place_kernel<4>, dim3(P.req_blocks), dim3(kThreads), smem, st, P);
     else
-        hipLaunchKernelGGL(sparse_place_kernel<1>, dim3(P.req_blocks + sweep_blocks), dim3(kThreads), smem, st, P);
+        hipLaunchKernelGGL(sparse_place_kernel<1>, dim3(P.req_blocks), dim3(kThreads), smem, st, P);
     ApplyArgs A;
     for (int i = 0; i < kMaxSources; ++i)
         A.src[i] = GSrc{P.src[i].g, P.src[i].g_stride, P.src[i].g_col, P.src[i].g_fmul, P.src[i].F, P.src[i].first};

@@ -157,49 +157,46 @@ def plan_of(arena) -> Optional[ArenaPlan]:
     return getattr(arena, "sparse", None)
 
 
+def deferred_view(arena, store):
+    """(recalgo_deferred_adam_t by reference, step counter pointer) of an arena with deferred-Adam state, for the
+    `_deferred` forward lookups (rows whose state lags are read as of the current step, nothing is written back);
+    (None, None) for an arena without such state: the plain lookup."""
+    plan = plan_of(arena)
+    if plan is None or plan.last_step is None or store is None or getattr(store, "opt_state", None) is None:
+        return None, None
+    d = plan._deferred_struct()
+    plan._view = d                              # (keeps the struct alive for the duration of the call)
+    return ctypes.byref(d), ctypes.c_void_p(store.opt_state["step"].data_ptr())
+
+
 def begin_lookup(arena, store, ids: torch.Tensor, offsets: Optional[torch.Tensor], row_base: Optional[torch.Tensor],
                  base: int, n_ex: int, F: int, training: Optional[bool] = None) -> Optional[Source]:
-    """Called by a lookup's forward BEFORE its gather kernel.  Returns the Source to attach the gradient to (training,
-    owner mode), or None.  Whatever the mode of the call: on an arena with deferred-Adam state the requested rows are
-    brought up to date first, so every forward reads current weights."""
+    """Called by a lookup's forward in TRAIN mode.  Returns the Source to attach the gradient to (owner mode), or None.
+    Launches recalgo_scatter_prepare: the lookup's tiles are counted into the arena's plan.  (Rows whose deferred-Adam
+    state lags are handled by the lookup kernel itself, see deferred_view.)"""
     plan = plan_of(arena)
     if training is None:                       # (inside an autograd Function's forward grad mode is always off: callers
         training = torch.is_grad_enabled()     #  there pass the mode of the CALL)
     training = bool(training) and getattr(arena, "trainable", True)
+    if not (training and scatter_mode() == "owner" and _supported(arena)):
+        return None
     if plan is None:
-        if not (training and scatter_mode() == "owner" and _supported(arena)):
-            return None
         plan = arena.sparse = ArenaPlan(arena)
-    elif not _supported(arena):                # (an arena that was re-sharded after its first steps)
-        return None
-    register = training and scatter_mode() == "owner"
-    if not register and plan.last_step is None:
-        return None
     src = Source(ids, offsets, row_base, base, n_ex, F)
     if src.n == 0:
-        if register:
-            plan.sources.append(src)
-        return src if register else None
-    lib = _lib.load()
-    ws_ptr = None
-    if register:
-        first = sum(s.slots for s in plan.sources)
-        plan._ensure_ws(first + src.slots)
-        if plan.counted is None or plan.counted[:2] != (plan.ws.data_ptr(), plan.nb_log2):
-            plan.counted = (plan.ws.data_ptr(), plan.nb_log2, ())
-        ws_ptr = ctypes.c_void_p(plan.ws.data_ptr())
-    d = plan._deferred_struct()
-    step = None if d is None else store.opt_state["step"]
-    cs = src.c_struct(arena.K)
-    _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), arena.K, ws_ptr, plan.capacity, plan.nb_log2, first if register else 0,
-                                           None if d is None else ctypes.byref(d),
-                                           None if step is None else ctypes.c_void_p(step.data_ptr()), 0,
-                                           _stream(arena.weight)), "recalgo_scatter_prepare")
-    if register:
         plan.sources.append(src)
-        plan.counted = plan.counted[:2] + (plan.counted[2] + (id(src),),)
         return src
-    return None
+    lib = _lib.load()
+    first = sum(s.slots for s in plan.sources)
+    plan._ensure_ws(first + src.slots)
+    if plan.counted is None or plan.counted[:2] != (plan.ws.data_ptr(), plan.nb_log2):
+        plan.counted = (plan.ws.data_ptr(), plan.nb_log2, ())
+    cs = src.c_struct(arena.K)
+    _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), arena.K, ctypes.c_void_p(plan.ws.data_ptr()), plan.capacity, plan.nb_log2,
+                                           first, None, None, 0, _stream(arena.weight)), "recalgo_scatter_prepare")
+    plan.sources.append(src)
+    plan.counted = plan.counted[:2] + (plan.counted[2] + (id(src),),)
+    return src
 
 
 def new_forward(store) -> None:

@@ -178,7 +178,10 @@ def test_deferred_adam_is_bit_identical_to_dense_tf1_adam(dev, rows, K, F, perio
     """N steps of (lookup -> row gradients -> optimizer) on two copies of an arena: copy A takes the summed gradients
     (GRAD mode) and the DENSE TF1 Adam pass over every row; copy B the fused deferred-exact path.  Every step the rows the
     lookup reads are bit-identical, and after the flush so are all of w, m, v."""
-    from recalgorithm_amd import ops, sparse
+    import ctypes
+    from recalgorithm_amd import _lib, ops, sparse
+    lib = _lib.load()
+    rb0 = torch.zeros(F, dtype=torch.int64, device=dev)
     monkeypatch.setenv("RECALGO_ADAM_SWEEP_PERIOD", str(period))
     gen = torch.Generator().manual_seed(rows * 7 + K)
     A, Bn = _arena(dev, rows, K, seed=9, name="a"), _arena(dev, rows, K, seed=9, name="b")
@@ -200,10 +203,18 @@ def test_deferred_adam_is_bit_identical_to_dense_tf1_adam(dev, rows, K, F, perio
         g[0, :K] = 0.0 if step % 2 else g[0, :K]                           # ... sometimes with a zero gradient
         ids_d, g_d = ids.to(dev), g.to(dev)
         with torch.enable_grad():
-            sB = sparse.begin_lookup(Bn, stB, ids_d, None, None, 0, n_ex, F)   # catches the requested rows up
+            sB = sparse.begin_lookup(Bn, stB, ids_d, None, None, 0, n_ex, F)
             sA = sparse.begin_lookup(A, stA, ids_d, None, None, 0, n_ex, F)
-        req = ids[ids >= 0].unique().to(dev)
-        assert_bit_exact(Bn.weight[req], A.weight[req], f"step {step}: the rows the forward reads")
+        # the forward lookup on the deferred arena reads every row as of this step (lagging rows replayed in registers,
+        # nothing written back): bit-identical to the lookup on the densely updated copy
+        outA, outB = torch.empty(n_ex, F * K, device=dev), torch.empty(n_ex, F * K, device=dev)
+        dvB, stpB = sparse.deferred_view(Bn, stB)
+        pp = lambda t_: ctypes.c_void_p(t_.data_ptr())
+        st_ = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.recalgo_embedding_gather_fwd_deferred(pp(ids_d), pp(Bn.weight), pp(rb0), n_ex, F, K, pp(outB), F * K, 0,
+                                                             dvB, stpB, 0, st_), "gather deferred")
+        _lib.check(lib.recalgo_embedding_gather_fwd(pp(ids_d), pp(A.weight), pp(rb0), n_ex, F, K, pp(outA), F * K, 0, st_), "gather")
+        assert_bit_exact(outB, outA, f"step {step}: what the forward reads")
         sA.set_grad(g_d)
         sB.set_grad(g_d)
         sparse.materialize_grads(stA)                                      # A.grad = summed rows (same order as B's)
