@@ -214,6 +214,20 @@ __device__ __forceinline__ void catch_up_row(const Deferred& D, long long row, i
     if (q == 0) D.last_step[row] = target;
 }
 
+// the same with ONE float per lane (K lanes of a group of L1 >= K own the row): a lane's replay is a dependent chain of
+// ~25 instructions per missed step, so four times as many, four times shorter chains finish sooner than float4 lanes
+__device__ __forceinline__ void catch_up_row_scalar(const Deferred& D, long long row, int s, int target, unsigned lane, unsigned K) {
+    if (lane < K) {
+        const size_t o = (size_t)row * K + lane;
+        float w = D.w[o], m = D.m[o], v = D.v[o];
+        recalgo_deferred::replay(w, m, v, s, target, D.lr_ring, D.b1, D.b2, D.eps);
+        D.w[o] = w;
+        D.m[o] = m;
+        D.v[o] = v;
+    }
+    if (lane == 0) D.last_step[row] = target;
+}
+
 // 256-thread exclusive scan of one value per thread; sh: 8 unsigned of LDS; returns the exclusive prefix, total in `total`
 __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned* sh, unsigned& total) {
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -248,6 +262,7 @@ struct PrepareArgs {
     const long long* step;         // catch-up target = step[0] + step_off
     int step_off;
     unsigned KV, L;                // row = KV pieces of VEC floats, owned by L >= KV lanes (L a power of two <= 64)
+    unsigned L1;                   // lanes of a one-float-per-lane group: the power of two >= K (<= 256)
 };
 
 template <int VEC>
@@ -289,8 +304,8 @@ __global__ __launch_bounds__(kThreads) void sparse_prepare_kernel(PrepareArgs A)
         for (unsigned b = threadIdx.x; b < nb; b += kThreads) crow[b] = (unsigned short)hist[b];
     }
     const unsigned ns = *n_stale;
-    const unsigned q = threadIdx.x & (A.L - 1), grp = threadIdx.x / A.L, ngrp = kThreads / A.L;
-    for (unsigned k = grp; k < ns; k += ngrp) catch_up_row<VEC>(A.D, stale_row[k], stale_s[k], target, q, A.KV);
+    const unsigned K = A.KV * VEC, lane = threadIdx.x & (A.L1 - 1), grp = threadIdx.x / A.L1, ngrp = kThreads / A.L1;
+    for (unsigned k = grp; k < ns; k += ngrp) catch_up_row_scalar(A.D, stale_row[k], stale_s[k], target, lane, K);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -306,7 +321,7 @@ struct ScanArgs {
     Deferred D;
     const long long* step;
     int step_off;
-    unsigned KV, L;
+    unsigned KV, L, L1;
     long long rows, chunk;
     int period;
 };
@@ -318,11 +333,11 @@ __global__ __launch_bounds__(kThreads) void sparse_scan_kernel(ScanArgs A) {
         if (target <= 0) return;
         const long long c0 = (long long)(target % A.period) * A.chunk;
         const unsigned idx = (blockIdx.x - A.scan_blocks) * kThreads + threadIdx.x;
-        const long long row = c0 + idx / A.L;
-        const unsigned q = idx & (A.L - 1);
+        const long long row = c0 + idx / A.L1;
+        const unsigned lane = idx & (A.L1 - 1);
         if (row >= A.rows || row >= c0 + A.chunk) return;
         const int s = A.D.last_step[row];
-        if (s > 0 && s < target) catch_up_row<VEC>(A.D, row, s, target, q, A.KV);
+        if (s > 0 && s < target) catch_up_row_scalar(A.D, row, s, target, lane, A.KV * VEC);
         return;
     }
     const unsigned short* __restrict__ C = A.C;
@@ -979,22 +994,22 @@ struct SweepArgs {
     Deferred D;
     const long long* step;
     int step_off;
-    unsigned KV, L;
+    unsigned KV, L, L1;
     long long row0, row1;
 };
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void sparse_sweep_kernel(SweepArgs A) {
     const int target = (int)(A.step[0] + A.step_off);
     const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
-    const long long row = A.row0 + idx / A.L;
-    const unsigned q = (unsigned)(idx & (A.L - 1));
+    const long long row = A.row0 + idx / A.L1;
+    const unsigned lane = (unsigned)(idx & (A.L1 - 1));
     if (row >= A.row1) return;
     const int s = A.D.last_step[row];
-    if (s > 0 && s < target) catch_up_row<VEC>(A.D, row, s, target, q, A.KV);
+    if (s > 0 && s < target) catch_up_row_scalar(A.D, row, s, target, lane, A.KV * VEC);
 }
 
 // ---- host helpers -----------------------------------------------------------------------------
-struct Geometry { int vec; unsigned KV, L; };
+struct Geometry { int vec; unsigned KV, L, L1; };
 inline bool geometry(int K, const recalgo_scatter_source_t* src, int n_src, Geometry* G) {
     if (K < 1 || K > 256) return false;
     bool v4 = (K & 3) == 0 && K / 4 <= 64;
@@ -1008,6 +1023,9 @@ inline bool geometry(int K, const recalgo_scatter_source_t* src, int n_src, Geom
     unsigned L = 1;
     while (L < G->KV) L <<= 1;
     G->L = L;
+    unsigned L1 = 1;
+    while (L1 < (unsigned)K) L1 <<= 1;
+    G->L1 = L1;                                             // (K <= 256: a row never needs more than a workgroup)
     return true;
 }
 
@@ -1105,7 +1123,7 @@ RECALGO_EXPORT int recalgo_scatter_prepare(const recalgo_scatter_source_t* sourc
     RECALGO_REQUIRE(A.D.last_step == nullptr || (step_dev != nullptr && A.D.lr_ring != nullptr));
     A.step = reinterpret_cast<const long long*>(step_dev);
     A.step_off = step_offset;
-    A.KV = G.KV; A.L = G.L;
+    A.KV = G.KV; A.L = G.L; A.L1 = G.L1;
     const size_t smem = (((size_t)1 << nb_log2) + kSlots * 9) * sizeof(unsigned) + kThreads * (sizeof(long long) + sizeof(int)) + 16;
     const dim3 grid(cdiv(n, kThreads));
     if (G.vec == 4)
@@ -1143,11 +1161,11 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
         S.D = mode == RECALGO_SCATTER_ADAM ? deferred_of(deferred) : deferred_of(nullptr);
         S.step = reinterpret_cast<const long long*>(step_dev);
         S.step_off = step_offset - 1;                         // the sweep (like `prepare`) targets the step BEFORE this one
-        S.KV = G.KV; S.L = G.L;
+        S.KV = G.KV; S.L = G.L; S.L1 = G.L1;
         S.rows = rows;
         S.period = sweep_period < 1 ? 1 : sweep_period;
         S.chunk = (rows + S.period - 1) / S.period;
-        const unsigned sweep_blocks = S.D.last_step ? (unsigned)cdiv(S.chunk * G.L, kThreads) : 0u;
+        const unsigned sweep_blocks = S.D.last_step ? (unsigned)cdiv(S.chunk * G.L1, kThreads) : 0u;
         if (G.vec == 4)
             hipLaunchKernelGGL(sparse_scan_kernel<4>, dim3(S.scan_blocks + sweep_blocks), dim3(kThreads), 0, st, S);
         else
@@ -1213,9 +1231,9 @@ RECALGO_EXPORT int recalgo_adam_deferred_sweep(const recalgo_deferred_adam_t* de
     A.D = deferred_of(deferred);
     A.step = reinterpret_cast<const long long*>(step_dev);
     A.step_off = step_offset;
-    A.KV = G.KV; A.L = G.L;
+    A.KV = G.KV; A.L = G.L; A.L1 = G.L1;
     A.row0 = row_begin; A.row1 = row_end;
-    const int64_t threads = (row_end - row_begin) * G.L;
+    const int64_t threads = (row_end - row_begin) * G.L1;
     const dim3 grid((unsigned)((threads + kThreads - 1) / kThreads));
     if (G.vec == 4)
         hipLaunchKernelGGL(sparse_sweep_kernel<4>, grid, dim3(kThreads), 0, as_stream(stream), A);

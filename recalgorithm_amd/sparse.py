@@ -172,8 +172,9 @@ def deferred_view(arena, store):
 def begin_lookup(arena, store, ids: torch.Tensor, offsets: Optional[torch.Tensor], row_base: Optional[torch.Tensor],
                  base: int, n_ex: int, F: int, training: Optional[bool] = None) -> Optional[Source]:
     """Called by a lookup's forward in TRAIN mode.  Returns the Source to attach the gradient to (owner mode), or None.
-    Launches recalgo_scatter_prepare: the lookup's tiles are counted into the arena's plan.  (Rows whose deferred-Adam
-    state lags are handled by the lookup kernel itself, see deferred_view.)"""
+    Launches recalgo_scatter_prepare: the lookup's tiles are counted into the arena's plan and — deferred Adam — its
+    rows are brought up to date.  (Lookups that are NOT registered — EVAL / PREDICT — read lagging rows through
+    deferred_view instead: replayed in registers, nothing written.)"""
     plan = plan_of(arena)
     if training is None:                       # (inside an autograd Function's forward grad mode is always off: callers
         training = torch.is_grad_enabled()     #  there pass the mode of the CALL)
@@ -192,8 +193,14 @@ def begin_lookup(arena, store, ids: torch.Tensor, offsets: Optional[torch.Tensor
     if plan.counted is None or plan.counted[:2] != (plan.ws.data_ptr(), plan.nb_log2):
         plan.counted = (plan.ws.data_ptr(), plan.nb_log2, ())
     cs = src.c_struct(arena.K)
+    # deferred Adam: the launch also brings the lookup's distinct rows up to date (once per row, written back), so that the
+    # forward kernel that follows — and `apply` at the end of the step — find them current
+    d = plan._deferred_struct()
+    step = None if d is None else store.opt_state["step"]
     _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), arena.K, ctypes.c_void_p(plan.ws.data_ptr()), plan.capacity, plan.nb_log2,
-                                           first, None, None, 0, _stream(arena.weight)), "recalgo_scatter_prepare")
+                                           first, None if d is None else ctypes.byref(d),
+                                           None if step is None else ctypes.c_void_p(step.data_ptr()), 0, _stream(arena.weight)),
+               "recalgo_scatter_prepare")
     plan.sources.append(src)
     plan.counted = plan.counted[:2] + (plan.counted[2] + (id(src),),)
     return src
