@@ -659,7 +659,7 @@ int recalgo_scatter_plan_buckets_log2(int64_t n_requests);
 int64_t recalgo_scatter_source_slots(int n_ex, int F, int ragged);
 int64_t recalgo_scatter_plan_workspace_bytes(int64_t n_slots, int nb_log2, int K);
 int recalgo_scatter_prepare(const recalgo_scatter_source_t* source, int K, void* plan_workspace, int64_t plan_requests,
-                            int nb_log2, int64_t first_request, const recalgo_deferred_adam_t* deferred,
+                            int nb_log2, int64_t first_request, int lookup_index, const recalgo_deferred_adam_t* deferred,
                             const int64_t* step_dev, int step_offset, recalgo_stream_t stream);
 int recalgo_scatter_apply(const recalgo_scatter_source_t* sources, int n_sources, int K, void* plan_workspace,
                           int64_t plan_requests, int nb_log2, int mode, float* w, float* m, float* v, float* grad,

@@ -32,6 +32,17 @@ __device__ __forceinline__ void replay(V& w, V& m, V& v, int s, int target, cons
     for (int j = s + 1; j <= target; ++j)
         vadam(w, vzero(static_cast<const V*>(nullptr)), m, v, lr_ring[(unsigned)j & (kLrRing - 1)], b1, b2, eps);
 }
+// the same for one float, with the two addends of adam1 that vanish for g = 0 evaluated once: (1 - b1) * 0 and
+// (1 - b2) * 0 * 0 are the SAME values adam1 forms each step, so every fma below has adam1's operands bit for bit
+__device__ __forceinline__ void replay1(float& w, float& m, float& v, int s, int target, const float* lr_ring, float b1, float b2, float eps) {
+    const float z = 0.f;
+    const float c1 = (1.f - b1) * z, c2 = (1.f - b2) * z * z;
+    for (int j = s + 1; j <= target; ++j) {
+        m = fmaf(b1, m, c1);
+        v = fmaf(b2, v, c2);
+        w -= lr_ring[(unsigned)j & (kLrRing - 1)] * m / (sqrtf(v) + eps);
+    }
+}
 
 // Read-only view for the forward lookups: a lookup that meets a row whose state lags replays the missed steps in
 // registers and uses the result WITHOUT writing it back (the optimizer's `apply` / the sweep do the real catch-up).

@@ -220,7 +220,7 @@ __device__ __forceinline__ void catch_up_row_scalar(const Deferred& D, long long
     if (lane < K) {
         const size_t o = (size_t)row * K + lane;
         float w = D.w[o], m = D.m[o], v = D.v[o];
-        recalgo_deferred::replay(w, m, v, s, target, D.lr_ring, D.b1, D.b2, D.eps);
+        recalgo_deferred::replay1(w, m, v, s, target, D.lr_ring, D.b1, D.b2, D.eps);
         D.w[o] = w;
         D.m[o] = m;
         D.v[o] = v;
@@ -263,6 +263,8 @@ struct PrepareArgs {
     int step_off;
     unsigned KV, L;                // row = KV pieces of VEC floats, owned by L >= KV lanes (L a power of two <= 64)
     unsigned L1;                   // lanes of a one-float-per-lane group: the power of two >= K (<= 256)
+    int* stale_rows; int* stale_s; // the rows this launch claimed for the catch-up kernel, and the step they are valid for
+    unsigned* stale_n;             // this lookup's entry count (cleared by the step's `scan` launch)
 };
 
 template <int VEC>
@@ -303,9 +305,42 @@ __global__ __launch_bounds__(kThreads) void sparse_prepare_kernel(PrepareArgs A)
         unsigned short* crow = A.C + ((size_t)(A.S.first / kThreads) + blockIdx.x) * nb;
         for (unsigned b = threadIdx.x; b < nb; b += kThreads) crow[b] = (unsigned short)hist[b];
     }
+    // the claimed rows go to the plan's global list: whichever tile meets a row first claims it, so the early tiles of a
+    // field hold most of the claims — the catch-up itself is a separate, evenly spread launch (sparse_catchup_kernel)
     const unsigned ns = *n_stale;
-    const unsigned K = A.KV * VEC, lane = threadIdx.x & (A.L1 - 1), grp = threadIdx.x / A.L1, ngrp = kThreads / A.L1;
-    for (unsigned k = grp; k < ns; k += ngrp) catch_up_row_scalar(A.D, stale_row[k], stale_s[k], target, lane, K);
+    __syncthreads();                                          // (every wave has read the count before it is overwritten)
+    if (ns) {
+        if (threadIdx.x == 0) *n_stale = A.S.first + atomicAdd(A.stale_n, ns);     // (this lookup's part of the list)
+        __syncthreads();
+        const unsigned base = *n_stale;
+        for (unsigned k = threadIdx.x; k < ns; k += kThreads) {
+            A.stale_rows[base + k] = (int)stale_row[k];
+            A.stale_s[base + k] = stale_s[k];
+        }
+    }
+}
+
+// catch-up of the rows `prepare` claimed: one float per task, tasks (row, element) spread over the whole grid
+struct CatchupArgs {
+    Deferred D;
+    const int* stale_rows; const int* stale_s;               // this lookup's part of the list
+    const unsigned* stale_n;
+    const long long* step;
+    int step_off;
+    unsigned K;
+};
+__global__ __launch_bounds__(kThreads) void sparse_catchup_kernel(CatchupArgs A) {
+    const unsigned ns = A.stale_n[0];
+    const int target = (int)(A.step[0] + A.step_off);
+    const unsigned ntask = ns * A.K;
+    for (unsigned task = blockIdx.x * kThreads + threadIdx.x; task < ntask; task += gridDim.x * kThreads) {
+        const unsigned k = task / A.K, e = task - k * A.K;
+        const size_t o = (size_t)A.stale_rows[k] * A.K + e;
+        float w = A.D.w[o], m = A.D.m[o], v = A.D.v[o];
+        recalgo_deferred::replay1(w, m, v, A.stale_s[k], target, A.D.lr_ring, A.D.b1, A.D.b2, A.D.eps);
+        A.D.w[o] = w; A.D.m[o] = m; A.D.v[o] = v;
+        if (e == 0) A.D.last_step[A.stale_rows[k]] = target;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -313,7 +348,7 @@ __global__ __launch_bounds__(kThreads) void sparse_prepare_kernel(PrepareArgs A)
 //    workgroup = 16 columns x 16 row lanes; a lane owns a contiguous range of the W rows
 // ---------------------------------------------------------------------------------------------
 struct ScanArgs {
-    const unsigned short* C; unsigned* Cp; unsigned* total;
+    const unsigned short* C; unsigned* Cp; unsigned* total; unsigned* stale_n;
     unsigned W, nb, scan_blocks;
     // sweep (deferred Adam), in the extra workgroups of this launch: rows [c * chunk, (c + 1) * chunk), c = target % period,
     // are brought to `target` — beside the scan's 64 workgroups the sweep has the chip to itself, and it touches neither
@@ -340,6 +375,7 @@ __global__ __launch_bounds__(kThreads) void sparse_scan_kernel(ScanArgs A) {
         if (s > 0 && s < target) catch_up_row_scalar(A.D, row, s, target, lane, A.KV * VEC);
         return;
     }
+    if (blockIdx.x == 0 && threadIdx.x < 16 && A.stale_n) A.stale_n[threadIdx.x] = 0;   // the step's catch-up lists are consumed
     const unsigned short* __restrict__ C = A.C;
     unsigned* __restrict__ Cp = A.Cp;
     const unsigned W = A.W, nb = A.nb;
@@ -1062,19 +1098,23 @@ inline Deferred deferred_of(const recalgo_deferred_adam_t* d) {
 }
 inline bool nb_ok(int nb_log2) { return nb_log2 >= 8 && nb_log2 <= 13; }
 
-struct Ws { unsigned* total; unsigned* offs; unsigned* Cp; unsigned short* C; unsigned long long* keys; unsigned long long* keys_alt; float* partials; };
+struct Ws { unsigned* total; unsigned* offs; unsigned* Cp; unsigned short* C; unsigned long long* keys; unsigned long long* keys_alt; float* partials;
+            unsigned* stale_n; int* stale_rows; int* stale_s; };
 inline Ws carve(void* ws, int64_t cap, int nb_log2) {
     const int64_t nb = 1ll << nb_log2, W = cap / kThreads;
     char* p = static_cast<char*>(ws);
     Ws w;
-    w.total = reinterpret_cast<unsigned*>(p);               // [nb]
+    w.stale_n = reinterpret_cast<unsigned*>(p);             // [16]: zero-filled once by the caller, kept clean by the kernels
+    w.total = w.stale_n + 16;                               // [nb]
     w.offs = w.total + nb;                                  // [nb + 8]
     w.Cp = w.offs + nb + 8;                                 // [W][nb]
     w.C = reinterpret_cast<unsigned short*>(w.Cp + W * nb); // [W][nb]
     uintptr_t k = (reinterpret_cast<uintptr_t>(w.C + W * nb) + 15) & ~(uintptr_t)15;
     w.keys = reinterpret_cast<unsigned long long*>(k);
     w.keys_alt = w.keys + cap;
-    w.partials = reinterpret_cast<float*>(w.keys_alt + cap);   // [cap][K]
+    w.stale_rows = reinterpret_cast<int*>(w.keys_alt + cap);   // [cap]
+    w.stale_s = w.stale_rows + cap;                             // [cap]
+    w.partials = reinterpret_cast<float*>(w.stale_s + cap);    // [cap][K]
     return w;
 }
 
@@ -1092,18 +1132,18 @@ RECALGO_EXPORT int64_t recalgo_scatter_plan_workspace_bytes(int64_t n_slots, int
     if (n_slots < 0 || n_slots % kThreads != 0 || !nb_ok(nb_log2) || K < 1) return 0;
     const int64_t nb = 1ll << nb_log2;
     const int64_t cap = n_slots > 0 ? n_slots : kThreads, W = cap / kThreads;
-    return (2 * nb + 8) * (int64_t)sizeof(unsigned) + W * nb * (int64_t)(sizeof(unsigned) + sizeof(unsigned short)) +
-           2 * cap * (int64_t)sizeof(unsigned long long) + cap * (int64_t)K * (int64_t)sizeof(float) + 64;
+    return (2 * nb + 8 + 16) * (int64_t)sizeof(unsigned) + W * nb * (int64_t)(sizeof(unsigned) + sizeof(unsigned short)) +
+           2 * cap * (int64_t)sizeof(unsigned long long) + 2 * cap * (int64_t)sizeof(int) + cap * (int64_t)K * (int64_t)sizeof(float) + 64;
 }
 
 RECALGO_EXPORT int recalgo_scatter_prepare(const recalgo_scatter_source_t* source, int K, void* plan_workspace,
-                                           int64_t plan_requests, int nb_log2, int64_t first_request,
+                                           int64_t plan_requests, int nb_log2, int64_t first_request, int lookup_index,
                                            const recalgo_deferred_adam_t* deferred, const int64_t* step_dev, int step_offset,
                                            recalgo_stream_t stream) {
-    RECALGO_REQUIRE(source != nullptr && nb_ok(nb_log2));
+    RECALGO_REQUIRE(source != nullptr && nb_ok(nb_log2) && lookup_index >= 0 && lookup_index < kMaxSources);
     RECALGO_REQUIRE(first_request >= 0 && first_request % kThreads == 0 && first_request < (1ll << 31));
     RECALGO_REQUIRE(plan_requests >= 0 && plan_requests % kThreads == 0);
-    RECALGO_REQUIRE(plan_workspace != nullptr || (deferred != nullptr && deferred->last_step != nullptr));
+    RECALGO_REQUIRE(plan_workspace != nullptr);
     SrcDev S[kMaxSources];
     unsigned n = 0;
     RECALGO_REQUIRE(to_dev(source, 1, S, &n, false));
@@ -1114,13 +1154,16 @@ RECALGO_EXPORT int recalgo_scatter_prepare(const recalgo_scatter_source_t* sourc
     A.S = S[0];
     A.S.first = (unsigned)first_request;
     A.C = nullptr;
+    A.stale_rows = nullptr; A.stale_s = nullptr; A.stale_n = nullptr;
     if (plan_workspace) {
         RECALGO_REQUIRE(first_request + (int64_t)n <= plan_requests);
-        A.C = carve(plan_workspace, plan_requests, nb_log2).C;
+        const Ws ws = carve(plan_workspace, plan_requests, nb_log2);
+        A.C = ws.C;
+        A.stale_rows = ws.stale_rows; A.stale_s = ws.stale_s; A.stale_n = ws.stale_n + lookup_index;
     }
     A.nb_log2 = (unsigned)nb_log2;
     A.D = deferred_of(deferred);
-    RECALGO_REQUIRE(A.D.last_step == nullptr || (step_dev != nullptr && A.D.lr_ring != nullptr));
+    RECALGO_REQUIRE(A.D.last_step == nullptr || (step_dev != nullptr && A.D.lr_ring != nullptr && plan_workspace != nullptr));
     A.step = reinterpret_cast<const long long*>(step_dev);
     A.step_off = step_offset;
     A.KV = G.KV; A.L = G.L; A.L1 = G.L1;
@@ -1130,6 +1173,15 @@ RECALGO_EXPORT int recalgo_scatter_prepare(const recalgo_scatter_source_t* sourc
         hipLaunchKernelGGL(sparse_prepare_kernel<4>, grid, dim3(kThreads), smem, as_stream(stream), A);
     else
         hipLaunchKernelGGL(sparse_prepare_kernel<1>, grid, dim3(kThreads), smem, as_stream(stream), A);
+    if (A.D.last_step) {
+        CatchupArgs Cu;
+        Cu.D = A.D; Cu.stale_rows = A.stale_rows + first_request; Cu.stale_s = A.stale_s + first_request; Cu.stale_n = A.stale_n;
+        Cu.step = A.step; Cu.step_off = A.step_off; Cu.K = (unsigned)K;
+        // at most one claim per distinct row of the lookup; the grid covers n / 4 rows x K floats in one pass
+        const int64_t want = ((int64_t)n / 4 * K + kThreads - 1) / kThreads;
+        const unsigned blocks = (unsigned)(want < 64 ? 64 : (want > 2048 ? 2048 : want));
+        hipLaunchKernelGGL(sparse_catchup_kernel, dim3(blocks), dim3(kThreads), 0, as_stream(stream), Cu);
+    }
     RECALGO_RETURN_LAST();
 }
 
@@ -1157,7 +1209,7 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
     const unsigned W = (unsigned)cdiv(n_total, kThreads);     // rows of the count matrix in use (written by `prepare`)
     {
         ScanArgs S;
-        S.C = ws.C; S.Cp = ws.Cp; S.total = ws.total; S.W = W; S.nb = nb; S.scan_blocks = nb / 16;
+        S.C = ws.C; S.Cp = ws.Cp; S.total = ws.total; S.stale_n = ws.stale_n; S.W = W; S.nb = nb; S.scan_blocks = nb / 16;
         S.D = mode == RECALGO_SCATTER_ADAM ? deferred_of(deferred) : deferred_of(nullptr);
         S.step = reinterpret_cast<const long long*>(step_dev);
         S.step_off = step_offset - 1;                         // the sweep (like `prepare`) targets the step BEFORE this one

@@ -141,7 +141,7 @@ class _GatherFn(Function):
         # owner-computes scatter (sparse.py): the lookup joins the arena's plan; deferred-Adam rows are caught up first
         ctx.src = sparse.begin_lookup(arena, anchor_store(anchor), ids, None, row_base, 0, B, F, training)
         # deferred Adam: a registered (TRAIN) lookup's rows were just caught up; any other lookup reads lagging rows as of now
-        dv, stp = (None, None) if ctx.src is not None else sparse.deferred_view(arena, anchor_store(anchor))
+        dv, stp = sparse.view_for(ctx.src, arena, anchor_store(anchor))
         _lib.check(_lib_().recalgo_embedding_gather_fwd_deferred(
             _p(ids), _p(arena.weight), _p(row_base), B, F, K, _p(out), F * K, 0, dv, stp, 0, _stream(ids)),
             "recalgo_embedding_gather_fwd")
@@ -192,7 +192,7 @@ class _BagMeanFn(Function):
             # one request per bag entry; its gradient row (g[bag] / count) is expanded in the backward
             ctx.src = sparse.begin_lookup(arena, anchor_store(anchor), values, None, None, arena.tables[table_name][0],
                                           values.numel(), 1, training)
-        dv, stp = (None, None) if (table_name == "__staged__" or ctx.src is not None) else sparse.deferred_view(arena, anchor_store(anchor))
+        dv, stp = (None, None) if table_name == "__staged__" else sparse.view_for(ctx.src, arena, anchor_store(anchor))
         rb0 = 0 if table_name == "__staged__" else arena.tables[table_name][0]
         _lib.check(_lib_().recalgo_embedding_bag_mean_fwd_deferred(
             _p(values), _p(offsets), _p(table), B, K, _p(out), K, 0, dv, rb0, stp, 0, _stream(offsets)),
@@ -246,7 +246,7 @@ class _SeqGatherFn(Function):
         ctx.src = None
         if table_name != "__staged__":
             ctx.src = sparse.begin_lookup(arena, anchor_store(anchor), values, offsets, None, arena.tables[table_name][0], B, T, training)
-        dv, stp = (None, None) if (table_name == "__staged__" or ctx.src is not None) else sparse.deferred_view(arena, anchor_store(anchor))
+        dv, stp = (None, None) if table_name == "__staged__" else sparse.view_for(ctx.src, arena, anchor_store(anchor))
         rb0 = 0 if table_name == "__staged__" else arena.tables[table_name][0]
         _lib.check(_lib_().recalgo_sequence_gather_fwd_deferred(
             _p(values), _p(offsets), _p(table), B, T, K, _p(out), _p(seq_len), dv, rb0, stp, 0, _stream(offsets)),
@@ -306,8 +306,8 @@ class _DeepFMSparseFn(Function):
         st = anchor_store(anchor)
         ctx.src = sparse.begin_lookup(arena, st, ids, None, row_base, 0, B, F, training)
         ctx.src1 = sparse.begin_lookup(w1, st, ids, None, row_base, 0, B, F, training)
-        dv, stp = (None, None) if ctx.src is not None else sparse.deferred_view(arena, st)
-        dv1, stp1 = (None, None) if ctx.src1 is not None else sparse.deferred_view(w1, st)
+        dv, stp = sparse.view_for(ctx.src, arena, st)
+        dv1, stp1 = sparse.view_for(ctx.src1, w1, st)
         _lib.check(_lib_().recalgo_deepfm_sparse_fwd_deferred(
             _p(ids), _p(arena.weight), _p(w1.weight), _p(bias.data), _p(row_base), B, F, K,
             _p(emb), _p(fm1), _p(fm2), _p(fsum), dv, dv1, stp if stp is not None else stp1, 0, _stream(ids)),

@@ -65,7 +65,7 @@ class Source:
         self.ids, self.offsets, self.row_base, self.base, self.n_ex, self.F = ids, offsets, row_base, int(base), int(n_ex), int(F)
         self.g = None
         self.g_stride = self.g_col = self.g_fmul = 0
-        self.keep = None                       # tensors the gradient view depends on
+        self.caught_up = True                  # the lookup's rows are current when its forward kernel runs
 
     @property
     def n(self) -> int:
@@ -125,6 +125,7 @@ class ArenaPlan:
         self.capacity = cap
         nbytes = int(lib.recalgo_scatter_plan_workspace_bytes(cap, self.nb_log2, self.arena.K))
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.arena.weight.device)
+        self.ws[:64].zero_()                   # the catch-up list's counter and ticket (kept clean by the kernels afterwards)
         self.counted = None
 
     def _signature(self, sources):
@@ -155,6 +156,13 @@ def _supported(arena) -> bool:
 
 def plan_of(arena) -> Optional[ArenaPlan]:
     return getattr(arena, "sparse", None)
+
+
+def view_for(src, arena, store):
+    """The read view a lookup's forward kernel needs: none when the lookup was registered and its rows caught up."""
+    if src is not None and src.caught_up:
+        return None, None
+    return deferred_view(arena, store)
 
 
 def deferred_view(arena, store):
@@ -195,10 +203,12 @@ def begin_lookup(arena, store, ids: torch.Tensor, offsets: Optional[torch.Tensor
     cs = src.c_struct(arena.K)
     # deferred Adam: the launch also brings the lookup's distinct rows up to date (once per row, written back), so that the
     # forward kernel that follows — and `apply` at the end of the step — find them current
-    d = plan._deferred_struct()
+    idx = len(plan.sources)
+    d = plan._deferred_struct() if idx < MAX_SOURCES else None     # (one catch-up list per lookup; later lookups of a model
+    src.caught_up = d is not None or plan.last_step is None        #  that makes more than 16 read lagging rows through the view)
     step = None if d is None else store.opt_state["step"]
     _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), arena.K, ctypes.c_void_p(plan.ws.data_ptr()), plan.capacity, plan.nb_log2,
-                                           first, None if d is None else ctypes.byref(d),
+                                           first, min(idx, MAX_SOURCES - 1), None if d is None else ctypes.byref(d),
                                            None if step is None else ctypes.c_void_p(step.data_ptr()), 0, _stream(arena.weight)),
                "recalgo_scatter_prepare")
     plan.sources.append(src)
@@ -214,6 +224,8 @@ def new_forward(store) -> None:
             plan.sources = []
             plan.counted = None
             plan.grad_materialized = False
+            if plan.ws is not None:
+                plan.ws[:64].zero_()           # (the abandoned forward's catch-up lists: normally cleared by the optimizer launch)
 
 
 def has_work(arena) -> bool:
@@ -262,7 +274,7 @@ def _run(plan: ArenaPlan, sources: List[Source], mode: int, step_dev, step_offse
         for s in srcs:
             cs = s.c_struct(a.K)
             _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), a.K, ctypes.c_void_p(plan.ws.data_ptr()), plan.capacity,
-                                                   plan.nb_log2, first, None, None, 0, _stream(a.weight)), "recalgo_scatter_prepare")
+                                                   plan.nb_log2, first, 0, None, None, 0, _stream(a.weight)), "recalgo_scatter_prepare")
             first += s.slots
     if not srcs:                               # (the sweep and the lr ring still need the launch)
         dummy = Source(a.weight, None, None, 0, 0, 1)
