@@ -250,10 +250,11 @@ def kernel_rooflines(args, est, feats, device):
             B * (F * 8 + 2 * d * 4))
         ar.grad.zero_()
     else:
-        # owner-computes scatter fused with the optimizer (csrc/sparse.hip): `prepare` (bucket counts + deferred-Adam
-        # catch-up of the batch's rows; before the forward gather) and `place` + `apply` (keys into buckets, LDS sort,
-        # per-row sums in request order, TF1 Adam on the owned rows; + the sweep of 1/P of the arena).  Timed on a scratch
-        # copy of the arena's state in the state the timed steps left it in; lr = 0.
+        # owner-computes scatter fused with the optimizer (csrc/sparse.hip): `prepare` (+ catch-up) before the forward
+        # gather, `scan` (+ sweep of 1/P of the arena), `place` (stable multisplit, duplicates of a tile summed) and `apply`
+        # (per-row sums in request order, TF1 Adam on the owned rows) after the backward pass.  Timed on a scratch copy of
+        # the arena's state in the state the timed steps left it in; lr = 0; the step counter does not advance, so the
+        # replay loops of the deferred Adam have nothing to do here (the in-step rocprofv3 averages include them)
         import copy
         sc = copy.copy(ar)
         sc.weight, sc.m, sc.v, sc.grad = ar.weight.clone(), ar.m.clone(), ar.v.clone(), ar.grad
@@ -279,11 +280,12 @@ def kernel_rooflines(args, est, feats, device):
         sparse_step()
         n_req = B * F
         rows_sweep = 0 if lazy else -(-ar.weight.shape[0] // sp.sweep_period())
-        alg_prep = n_req * 8 + n_req * 4
-        alg_apply = n_req * (8 + 8 + 8) + n_req * K * 4 + distinct * (6 * K * 4 + 8) + rows_sweep * 4
-        add("scatter_prepare(bucket counts + deferred-Adam catch-up)", prep_only, alg_prep)
+        tiles = -(-n_req // 256)
+        alg_prep = n_req * 8 + tiles * 1024 * 2                                  # ids + a row of the count matrix per tile
+        alg_apply = tiles * 1024 * (2 + 4) + n_req * (8 + 8 + 8) + n_req * K * 4 + distinct * (6 * K * 4 + 8) + rows_sweep * 4
+        add("sparse_prepare(tile counts; + catch-up launch: none pending in this loop)", prep_only, alg_prep)
         sc.sparse.counted = None
-        add("scatter_prepare+place+apply(sort, row sums, Adam on owned rows, sweep)", sparse_step, alg_prep + alg_apply)
+        add("sparse_step(prepare + scan/sweep + place + apply: row sums, Adam on owned rows)", sparse_step, alg_prep + alg_apply)
         res[-1]["distinct_rows"] = distinct
         res[-1]["requests"] = n_req
         del sc
