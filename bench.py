@@ -288,6 +288,7 @@ def kernel_rooflines(args, est, feats, device):
         add("sparse_step(prepare + scan/sweep + place + apply: row sums, Adam on owned rows)", sparse_step, alg_prep + alg_apply)
         res[-1]["distinct_rows"] = distinct
         res[-1]["requests"] = n_req
+        res[-1]["launches"] = 5                  # a SEQUENCE of launches (per-kernel times: profiles/*_kernel_stats.md): never `roofline`
         del sc
     if args.model == "dcn":
         L = 3
@@ -689,7 +690,7 @@ def extra_model(a, name, steps, device):
         e["ms_per_step_p10_p50_p90"] = [cs[min(len(cs) - 1, int(q * len(cs)))] for q in (0.1, 0.5, 0.9)]
     if not a.no_kernel_timing:
         ks = kernel_rooflines(a, r["est"], r["feats"], device)
-        dom = max(ks, key=lambda k: k["avg_us"])
+        dom = max((k for k in ks if k.get("launches", 1) == 1), key=lambda k: k["avg_us"])
         e["roofline"] = {"kernel": dom["kernel"], "bound": dom["bound"], "frac": dom["frac"], "avg_us": dom["avg_us"],
                          "achieved": dom.get("achieved_TFLOPs", dom["achieved_GBs"]), "unit": "TFLOP/s" if dom["bound"] == "mfma" else "GB/s"}
         e["kernels"] = [{"kernel": k["kernel"], "avg_us": k["avg_us"], "bound": k["bound"], "frac": k["frac"]} for k in ks]
@@ -832,7 +833,7 @@ def main():
                                "phase": last["phase"]}
     if rank == 0:
         if ks:
-            dom = max(ks, key=lambda k: k["avg_us"])
+            dom = max((k for k in ks if k.get("launches", 1) == 1), key=lambda k: k["avg_us"])     # the dominant single KERNEL
             if dom["bound"] == "mfma":
                 out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_TFLOPs"],
                                    "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],

@@ -582,18 +582,21 @@ int recalgo_activation_bwd(const float* x, const float* alpha, const float* gy, 
  *   gradient row of request (e, f): K floats at  g + e * g_stride + g_col + f * g_fmul
  *                     (g_fmul = K for a [n_ex, F * K] matrix, 0 when all fields of an example share one row).
  * All requests of a step that address one arena form a PLAN (<= RECALGO_SCATTER_MAX_SOURCES sources, < 2^31
- * requests, arena rows < 2^31):
+ * slots, arena rows < 2^31).  The plan lives in a SLOT space cut into tiles of 256: a source takes
+ * recalgo_scatter_source_slots(n_ex, F, ragged) slots (id matrix: field-major, F x (n_ex rounded up to 256), so that a
+ * tile is 256 consecutive examples of one field; ragged: n_ex * F rounded up), source k starts at the sum of the slots
+ * of the sources before it (`first_request`), and plan_requests is the slot capacity the workspace was sized for.
  *   recalgo_scatter_prepare  once per source, any time before `apply` (normally right before the lookup's forward
- *                            kernel): adds the source's requests to the plan's bucket counts, and — with `deferred` —
- *                            first brings every requested row's (w, m, v) up to step  step_dev[0] + step_offset.
- *                            plan_workspace may be NULL (catch-up only).  first_request = the source's position in the
- *                            plan's request space: source k of `apply` starts at the sum over the sources before it of
- *                            recalgo_scatter_plan_padded_requests(n_ex * F) (each source padded to a whole number of
- *                            workgroups); plan_requests counts the padded space.
- *   recalgo_scatter_apply    once per plan, with the SAME sources in the SAME order (their g now set): two launches.
- *                            Requests are grouped by row (hash buckets, sorted inside a bucket by (row, request
- *                            index)); the owner of a row adds its gradient rows in request order — no atomics,
- *                            bit-reproducible — and finishes, by `mode`:
+ *                            kernel): the source's tiles write their rows of the plan's (tile x bucket) count matrix —
+ *                            one entry per DISTINCT row of a tile — and, with `deferred`, every requested row whose
+ *                            (w, m, v) lags is claimed and brought up to step  step_dev[0] + step_offset  (second
+ *                            launch; lookup_index < 16 selects the lookup's claim list).  plan_workspace is required.
+ *   recalgo_scatter_apply    once per plan, with the SAME sources in the SAME order (their g now set): three launches
+ *                            (column scan of the count matrix + the deferred sweep; stable placement of the entries
+ *                            into their hash bucket, the duplicates of a tile summed in request order into one
+ *                            partial row; one workgroup per bucket groups its entries by row, still in request order).
+ *                            The owner of a row adds its gradient rows in that fixed order — no atomics on global
+ *                            memory, bit-reproducible — and finishes, by `mode`:
  *     RECALGO_SCATTER_GRAD       grad[row, :] += sum            (+ `live`: the row joins the live-row list)
  *     RECALGO_SCATTER_ADAM       TF1 Adam with dense semantics, evaluated lazily but EXACTLY: (w, m, v)[row] first
  *                                replay the g = 0 updates of the steps since last_step[row], then take this step's
@@ -605,12 +608,21 @@ int recalgo_activation_bwd(const float* x, const float* alpha, const float* gy, 
  *     RECALGO_SCATTER_LAZY_ADAM  LazyAdamOptimizer: exactly the rows of this step's requests take the Adam update
  *                                (whole rows, also rows whose summed gradient is 0); all other rows keep w, m, v.
  *                            In the ADAM modes a non-NULL `grad` gets the touched rows zeroed (a gradient arena
- *                            that an earlier GRAD call of the same plan filled).  The plan workspace comes back
- *                            cleared for the next step.
+ *                            that an earlier GRAD call of the same plan filled).
+ *                            `companion` (NULL, or a recalgo_scatter_companion_t; K <= 32): a second arena of ONE
+ *                            float per row that was looked up with exactly these requests (DeepFM's first-order
+ *                            weights, deepfm.py:125-141).  It gets its row sums and optimizer step from the SAME placed
+ *                            entries: `place` also sums the scalar gradients of a tile's duplicates, one more
+ *                            per-bucket launch walks the entries for the second arena, and its share of the sweep
+ *                            rides in the scan launch — no second prepare / scan / place.  companion->sources[k]: only
+ *                            g / g_stride / g_col / g_fmul are read (g = NULL: that lookup had no companion and adds
+ *                            nothing).  recalgo_scatter_prepare's companion_deferred brings the claimed rows of the
+ *                            second arena up to date along with the first's.
  *   recalgo_adam_deferred_sweep  rows [row_begin, row_end) brought to step_dev[0] + step_offset: the flush before
  *                            EVAL / PREDICT / checkpoint / export, and after the last training step.
- * The workspace (recalgo_scatter_plan_workspace_bytes(plan_requests, nb_log2), nb_log2 =
- * recalgo_scatter_plan_buckets_log2(plan_requests)) must be zero-filled once before its first use.
+ * The workspace (recalgo_scatter_plan_workspace_bytes(plan_requests, nb_log2, K), nb_log2 =
+ * recalgo_scatter_plan_buckets_log2(plan_requests)) needs its first 64 bytes zero-filled once before its first use
+ * (the claim counters; the kernels keep them clean afterwards).
  * ------------------------------------------------------------------------------------------ */
 #define RECALGO_SCATTER_MAX_SOURCES 16
 #define RECALGO_LR_RING 1024
@@ -633,6 +645,13 @@ typedef struct {
     float* lr_ring;                 /* [RECALGO_LR_RING] fp32: lr_t(j) at j % RECALGO_LR_RING */
     float beta1, beta2, eps;
 } recalgo_deferred_adam_t;
+typedef struct {
+    const recalgo_scatter_source_t* sources;   /* [n_sources], parallel to `sources` of the call */
+    float* w; float* m; float* v;              /* [rows, 1] (ADAM modes) */
+    float* grad;                               /* GRAD: the target; ADAM modes: touched rows zeroed when non-NULL */
+    const recalgo_deferred_adam_t* deferred;   /* RECALGO_SCATTER_ADAM: the second arena's own last_step / lr ring */
+    int64_t rows;
+} recalgo_scatter_companion_t;
 /* The forward lookups on an arena with deferred-Adam state: identical to recalgo_embedding_gather_fwd /
  * _embedding_bag_mean_fwd / _sequence_gather_fwd / _deepfm_sparse_fwd, except that a row whose state lags
  * (last_step[row] < step_dev[0] + step_offset) is read AS OF that step: the missed g = 0 updates are replayed in registers
@@ -660,10 +679,11 @@ int64_t recalgo_scatter_source_slots(int n_ex, int F, int ragged);
 int64_t recalgo_scatter_plan_workspace_bytes(int64_t n_slots, int nb_log2, int K);
 int recalgo_scatter_prepare(const recalgo_scatter_source_t* source, int K, void* plan_workspace, int64_t plan_requests,
                             int nb_log2, int64_t first_request, int lookup_index, const recalgo_deferred_adam_t* deferred,
-                            const int64_t* step_dev, int step_offset, recalgo_stream_t stream);
-int recalgo_scatter_apply(const recalgo_scatter_source_t* sources, int n_sources, int K, void* plan_workspace,
-                          int64_t plan_requests, int nb_log2, int mode, float* w, float* m, float* v, float* grad,
-                          const recalgo_deferred_adam_t* deferred, int64_t rows, int sweep_period,
+                            const recalgo_deferred_adam_t* companion_deferred, const int64_t* step_dev, int step_offset,
+                            recalgo_stream_t stream);
+int recalgo_scatter_apply(const recalgo_scatter_source_t* sources, int n_sources, const recalgo_scatter_companion_t* companion,
+                          int K, void* plan_workspace, int64_t plan_requests, int nb_log2, int mode, float* w, float* m,
+                          float* v, float* grad, const recalgo_deferred_adam_t* deferred, int64_t rows, int sweep_period,
                           const recalgo_live_t* live, const int64_t* step_dev, int step_offset, float lr, float beta1,
                           float beta2, float eps, recalgo_stream_t stream);
 int recalgo_adam_deferred_sweep(const recalgo_deferred_adam_t* deferred, int K, int64_t row_begin, int64_t row_end,

@@ -532,8 +532,18 @@ __global__ __launch_bounds__(256) void dense_sum_slabs_kernel(SplitJobs J) {
     if (jb.vec) {
         const size_t i = t * 4;
         if (i >= jb.n) return;
-        float4 acc = *reinterpret_cast<const float4*>(jb.partials + i);
-        for (int s = 1; s < jb.S; ++s) acc = f4_add(acc, *reinterpret_cast<const float4*>(jb.partials + (size_t)s * jb.slab + i));
+        // the slab loads are independent: four in flight per thread, added in slab order (the sum's order is fixed)
+        const float* base = jb.partials + i;
+        float4 acc = *reinterpret_cast<const float4*>(base);
+        int s = 1;
+        for (; s + 4 <= jb.S; s += 4) {
+            const float4 a0 = *reinterpret_cast<const float4*>(base + (size_t)s * jb.slab);
+            const float4 a1 = *reinterpret_cast<const float4*>(base + (size_t)(s + 1) * jb.slab);
+            const float4 a2 = *reinterpret_cast<const float4*>(base + (size_t)(s + 2) * jb.slab);
+            const float4 a3 = *reinterpret_cast<const float4*>(base + (size_t)(s + 3) * jb.slab);
+            acc = f4_add(f4_add(f4_add(f4_add(acc, a0), a1), a2), a3);
+        }
+        for (; s < jb.S; ++s) acc = f4_add(acc, *reinterpret_cast<const float4*>(base + (size_t)s * jb.slab));
         *reinterpret_cast<float4*>(i < jb.n0 ? jb.out0 + i : jb.out1 + (i - jb.n0)) = acc;
     } else {
         if (t >= jb.n) return;

@@ -64,6 +64,11 @@ struct SrcDev {
     const float* g;
     long long g_stride;
     unsigned g_col, g_fmul;
+    // companion (a second arena of ONE float per row that is looked up with exactly these requests: DeepFM's first-order
+    // weights): where the request's scalar gradient is; nullptr: none
+    const float* g1;
+    long long g1_stride;
+    unsigned g1_col, g1_fmul;
 };
 constexpr unsigned kPartialBit = 0x80000000u;   // key.ref: the gradient row is a tile's partial sum, not a request's row
 
@@ -323,6 +328,7 @@ __global__ __launch_bounds__(kThreads) void sparse_prepare_kernel(PrepareArgs A)
 // catch-up of the rows `prepare` claimed: one float per task, tasks (row, element) spread over the whole grid
 struct CatchupArgs {
     Deferred D;
+    Deferred D1;                   // the companion arena (one float per row, its own last_step); last_step == nullptr: none
     const int* stale_rows; const int* stale_s;               // this lookup's part of the list
     const unsigned* stale_n;
     const long long* step;
@@ -332,9 +338,21 @@ struct CatchupArgs {
 __global__ __launch_bounds__(kThreads) void sparse_catchup_kernel(CatchupArgs A) {
     const unsigned ns = A.stale_n[0];
     const int target = (int)(A.step[0] + A.step_off);
-    const unsigned ntask = ns * A.K;
+    const unsigned per_row = A.K + (A.D1.last_step ? 1u : 0u);
+    const unsigned ntask = ns * per_row;
     for (unsigned task = blockIdx.x * kThreads + threadIdx.x; task < ntask; task += gridDim.x * kThreads) {
-        const unsigned k = task / A.K, e = task - k * A.K;
+        const unsigned k = task / per_row, e = task - k * per_row;
+        if (e == A.K) {                                       // the same row of the companion arena
+            const int row = A.stale_rows[k];
+            const int s1 = A.D1.last_step[row];
+            if (s1 > 0 && s1 < target) {
+                float w = A.D1.w[row], m = A.D1.m[row], v = A.D1.v[row];
+                recalgo_deferred::replay1(w, m, v, s1, target, A.D1.lr_ring, A.D1.b1, A.D1.b2, A.D1.eps);
+                A.D1.w[row] = w; A.D1.m[row] = m; A.D1.v[row] = v;
+                A.D1.last_step[row] = target;
+            }
+            continue;
+        }
         const size_t o = (size_t)A.stale_rows[k] * A.K + e;
         float w = A.D.w[o], m = A.D.m[o], v = A.D.v[o];
         recalgo_deferred::replay1(w, m, v, A.stale_s[k], target, A.D.lr_ring, A.D.b1, A.D.b2, A.D.eps);
@@ -359,10 +377,24 @@ struct ScanArgs {
     unsigned KV, L, L1;
     long long rows, chunk;
     int period;
+    // the companion arena's share of the sweep (one float per row): workgroups from comp_first on
+    Deferred D1;
+    long long rows1, chunk1;
+    unsigned comp_first;
 };
 
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void sparse_scan_kernel(ScanArgs A) {
+    if (blockIdx.x >= A.comp_first) {                         // ---- sweep of the companion arena -------------------
+        const int target = (int)(A.step[0] + A.step_off);
+        if (target <= 0) return;
+        const long long c0 = (long long)(target % A.period) * A.chunk1;
+        const long long row = c0 + (long long)(blockIdx.x - A.comp_first) * kThreads + threadIdx.x;
+        if (row >= A.rows1 || row >= c0 + A.chunk1) return;
+        const int s = A.D1.last_step[row];
+        if (s > 0 && s < target) catch_up_row_scalar(A.D1, row, s, target, 0, 1);
+        return;
+    }
     if (blockIdx.x >= A.scan_blocks) {                        // ---- sweep workgroups -------------------------------
         const int target = (int)(A.step[0] + A.step_off);
         if (target <= 0) return;
@@ -410,8 +442,10 @@ struct PlaceArgs {
     int n_src;
     unsigned n_total, req_blocks;
     const unsigned* total; const unsigned* Cp; unsigned* offs;      // [nb], [W][nb], [nb + 1]
+    unsigned* order;                           // [nb]: the buckets in the order `apply` takes them (the heavy ones first)
     unsigned long long* keys;                  // [n_total]
     float* partials;                           // [n_total][K]: the summed gradient rows of a tile's duplicated rows
+    float* partials1;                          // [n_total]: the same for the companion's scalar gradients (nullptr: no companion)
     unsigned nb_log2;
     unsigned KV, L;
     int stage_ok;                              // the tile's duplicated gradient rows fit the LDS staging area ([256][K] floats)
@@ -431,6 +465,17 @@ __device__ __forceinline__ typename Vec<VEC>::T load_g_src(const SrcDev* lsrc, u
     const long long stride = lsrc[si].g_stride;
     const unsigned i = ref - first, e = i / F, f = i - e * F;
     return *reinterpret_cast<const V*>(g + (size_t)e * stride + col + (size_t)f * fmul + q * VEC);
+}
+
+// the companion's scalar gradient of the request `ref` (0 for a source without one)
+__device__ __forceinline__ float load_g1_src(const SrcDev* lsrc, unsigned ref) {
+    unsigned si = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxSources; ++k) si += ref >= lsrc[k].first;
+    const float* g1 = lsrc[si].g1;
+    if (!g1) return 0.f;
+    const unsigned i = ref - lsrc[si].first, F = lsrc[si].F, e = i / F, f = i - e * F;
+    return g1[(size_t)e * lsrc[si].g1_stride + lsrc[si].g1_col + (size_t)f * lsrc[si].g1_fmul];
 }
 
 template <int VEC>
@@ -481,6 +526,20 @@ __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
             run += A.total[b];
         }
         if (blockIdx.x == 0 && threadIdx.x == kThreads - 1) A.offs[nb] = total;
+        if (blockIdx.x == 0) {
+            // `apply` runs one workgroup per bucket, more of them than fit the chip at once for large plans: the buckets that
+            // hold a hot row (many entries: a long tail of the launch when they start late) are dispatched first
+            const unsigned heavy_min = 2u * (total >> A.nb_log2) + 64u;
+            unsigned nh = 0;
+            for (unsigned k = 0; k < bpt; ++k) nh += A.total[threadIdx.x * bpt + k] >= heavy_min;
+            unsigned n_heavy;
+            unsigned hrun = block_excl_scan(nh, sh, n_heavy);
+            for (unsigned k = 0; k < bpt; ++k) {
+                const unsigned b = threadIdx.x * bpt + k;
+                if (A.total[b] >= heavy_min) A.order[hrun++] = b;
+                else A.order[n_heavy + b - hrun] = b;       // (b - hrun = the light buckets before b)
+            }
+        }
     }
     rows[threadIdx.x] = row >= 0 ? (unsigned)row : 0xffffffffu;
     grefs[threadIdx.x] = gref;
@@ -513,6 +572,11 @@ __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
         // ONE round trip to memory: every duplicated request's gradient row goes to LDS (a group of L lanes per row, all
         // loads of a thread in flight together), then each duplicated row is summed from LDS, in request order
         V* stage = reinterpret_cast<V*>(lsrc + kMaxSources);  // [kThreads][KV]
+        float* stage1 = reinterpret_cast<float*>(stage + (size_t)kThreads * A.KV);      // [kThreads] (companion only)
+        if (A.partials1) {
+            const unsigned tm = threadIdx.x;
+            stage1[tm] = (samec[tm] > 1 && rows[tm] != 0xffffffffu) ? load_g1_src(lsrc, grefs[tm]) : 0.f;
+        }
         V gq[4];
         for (unsigned r0 = 0; r0 < L; r0 += 4) {              // a group owns the member threads grp, grp + ngrp, ...
 #pragma unroll
@@ -534,6 +598,11 @@ __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
                 V acc = vz<VEC>();
                 for (unsigned m = 0; m < c; ++m) vadd(acc, stage[mlist[bs + m] * A.KV + q]);
                 reinterpret_cast<V*>(A.partials)[((size_t)blockIdx.x * kThreads + ld) * A.KV + q] = acc;
+            }
+            if (A.partials1 && q == 0) {                      // the companion's scalars of the same requests, same order
+                float a1 = 0.f;
+                for (unsigned m = 0; m < c; ++m) a1 += stage1[mlist[bs + m]];
+                A.partials1[(size_t)blockIdx.x * kThreads + ld] = a1;
             }
         }
         return;
@@ -589,6 +658,7 @@ struct ApplyArgs {
     GSrc src[kMaxSources];
     int n_src;
     const unsigned* offs;
+    const unsigned* order;         // [nb]: workgroup i takes bucket order[i]
     const unsigned long long* keys; unsigned long long* keys_alt;   // keys_alt: scratch of the same size (large buckets)
     const float* partials;         // [slots][K]: gradient rows of the entries whose ref has kPartialBit set
     int mode;                      // RECALGO_SCATTER_GRAD / _ADAM / _LAZY_ADAM
@@ -640,6 +710,7 @@ __device__ __forceinline__ typename Vec<VEC>::T load_g(const ApplyArgs& A, const
 #pragma unroll
     for (int k = 1; k < kMaxSources; ++k) si += ref >= lsrc[k].first;
     const GSrc S = lsrc[si];
+    if (!S.g) return vz<VEC>();                               // (companion pass: a lookup that had no companion adds nothing)
     const unsigned i = ref - S.first, e = i / S.F, f = i - e * S.F;
     return *reinterpret_cast<const V*>(S.g + (size_t)e * S.g_stride + S.g_col + (size_t)f * S.g_fmul + q * VEC);
 }
@@ -880,14 +951,14 @@ __global__ __launch_bounds__(kThreads, 4) void sparse_apply_kernel(ApplyArgs A) 
     __shared__ float red[kThreads * 4];
     __shared__ float s_lr_t;
     __shared__ GSrc lsrc[kMaxSources];
-    const unsigned b = blockIdx.x;
+    const unsigned b = A.order[blockIdx.x];
     const int t = (int)(A.step[0] + A.step_off);
     if (threadIdx.x == 0) {
         n_long = 0; n_seg = 0; overflow = 0;
         float lr_t = 0.f;
         if (A.mode != RECALGO_SCATTER_GRAD) {
             lr_t = lr_t_of(A.lr, A.b1, A.b2, t);
-            if (b == 0 && A.lr_ring) A.lr_ring[(unsigned)t & (kLrRing - 1)] = lr_t;
+            if (blockIdx.x == 0 && A.lr_ring) A.lr_ring[(unsigned)t & (kLrRing - 1)] = lr_t;
         }
         s_lr_t = lr_t;
     }
@@ -1032,14 +1103,17 @@ struct SweepArgs {
     int step_off;
     unsigned KV, L, L1;
     long long row0, row1;
+    int period; long long chunk;   // period > 0: the round-robin chunk of the target step, rows [c * chunk, (c + 1) * chunk) below row1
 };
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void sparse_sweep_kernel(SweepArgs A) {
     const int target = (int)(A.step[0] + A.step_off);
+    if (target <= 0) return;
     const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
-    const long long row = A.row0 + idx / A.L1;
+    const long long c0 = A.period > 0 ? (long long)(target % A.period) * A.chunk : A.row0;
+    const long long row = c0 + idx / A.L1;
     const unsigned lane = (unsigned)(idx & (A.L1 - 1));
-    if (row >= A.row1) return;
+    if (row >= A.row1 || (A.period > 0 && row >= c0 + A.chunk)) return;
     const int s = A.D.last_step[row];
     if (s > 0 && s < target) catch_up_row_scalar(A.D, row, s, target, lane, A.KV * VEC);
 }
@@ -1072,10 +1146,12 @@ RECALGO_EXPORT int64_t recalgo_scatter_source_slots(int n_ex, int F, int ragged)
     return ragged ? pad : pad * F;                          // id matrices: F fields x (examples rounded up to whole tiles)
 }
 namespace {
-inline bool to_dev(const recalgo_scatter_source_t* src, int n_src, SrcDev* out, unsigned* n_total, bool need_g) {
+inline bool to_dev(const recalgo_scatter_source_t* src, int n_src, SrcDev* out, unsigned* n_total, bool need_g,
+                   const recalgo_scatter_source_t* comp = nullptr) {
     unsigned first = 0;
     *n_total = 0;
-    for (int i = 0; i < kMaxSources; ++i) out[i] = SrcDev{nullptr, nullptr, nullptr, 0, 0, 1, 0xffffffffu, 0, kThreads, 0, nullptr, 0, 0, 0};
+    for (int i = 0; i < kMaxSources; ++i)
+        out[i] = SrcDev{nullptr, nullptr, nullptr, 0, 0, 1, 0xffffffffu, 0, kThreads, 0, nullptr, 0, 0, 0, nullptr, 0, 0, 0};
     for (int i = 0; i < n_src; ++i) {
         const recalgo_scatter_source_t& s = src[i];
         if (!s.ids || s.n_ex < 0 || s.F < 1 || (need_g && !s.g)) return false;
@@ -1083,7 +1159,9 @@ inline bool to_dev(const recalgo_scatter_source_t* src, int n_src, SrcDev* out, 
         if ((int64_t)first + n >= (1ll << 31)) return false;
         const unsigned e256 = ((unsigned)s.n_ex + kThreads - 1) / kThreads * kThreads;
         out[i] = SrcDev{s.ids, s.offsets, s.row_base, (long long)s.base, (unsigned)s.n_ex, (unsigned)s.F, first, (unsigned)n,
-                        e256 ? e256 : kThreads, 0, s.g, (long long)s.g_stride, (unsigned)s.g_col, (unsigned)s.g_fmul};
+                        e256 ? e256 : kThreads, 0, s.g, (long long)s.g_stride, (unsigned)s.g_col, (unsigned)s.g_fmul,
+                        comp ? comp[i].g : nullptr, comp ? (long long)comp[i].g_stride : 0, comp ? (unsigned)comp[i].g_col : 0u,
+                        comp ? (unsigned)comp[i].g_fmul : 0u};
         // every source is a whole number of tiles: row w of the count matrix is written by the `prepare` launch of exactly
         // one source
         first += (unsigned)n;
@@ -1098,8 +1176,8 @@ inline Deferred deferred_of(const recalgo_deferred_adam_t* d) {
 }
 inline bool nb_ok(int nb_log2) { return nb_log2 >= 8 && nb_log2 <= 13; }
 
-struct Ws { unsigned* total; unsigned* offs; unsigned* Cp; unsigned short* C; unsigned long long* keys; unsigned long long* keys_alt; float* partials;
-            unsigned* stale_n; int* stale_rows; int* stale_s; };
+struct Ws { unsigned* total; unsigned* offs; unsigned* order; unsigned* Cp; unsigned short* C; unsigned long long* keys; unsigned long long* keys_alt; float* partials;
+            float* partials1; unsigned* stale_n; int* stale_rows; int* stale_s; };
 inline Ws carve(void* ws, int64_t cap, int nb_log2) {
     const int64_t nb = 1ll << nb_log2, W = cap / kThreads;
     char* p = static_cast<char*>(ws);
@@ -1107,14 +1185,16 @@ inline Ws carve(void* ws, int64_t cap, int nb_log2) {
     w.stale_n = reinterpret_cast<unsigned*>(p);             // [16]: zero-filled once by the caller, kept clean by the kernels
     w.total = w.stale_n + 16;                               // [nb]
     w.offs = w.total + nb;                                  // [nb + 8]
-    w.Cp = w.offs + nb + 8;                                 // [W][nb]
+    w.order = w.offs + nb + 8;                              // [nb]
+    w.Cp = w.order + nb;                                    // [W][nb]
     w.C = reinterpret_cast<unsigned short*>(w.Cp + W * nb); // [W][nb]
     uintptr_t k = (reinterpret_cast<uintptr_t>(w.C + W * nb) + 15) & ~(uintptr_t)15;
     w.keys = reinterpret_cast<unsigned long long*>(k);
     w.keys_alt = w.keys + cap;
     w.stale_rows = reinterpret_cast<int*>(w.keys_alt + cap);   // [cap]
     w.stale_s = w.stale_rows + cap;                             // [cap]
-    w.partials = reinterpret_cast<float*>(w.stale_s + cap);    // [cap][K]
+    w.partials1 = reinterpret_cast<float*>(w.stale_s + cap);   // [cap]
+    w.partials = w.partials1 + cap;                             // [cap][K]
     return w;
 }
 
@@ -1132,14 +1212,15 @@ RECALGO_EXPORT int64_t recalgo_scatter_plan_workspace_bytes(int64_t n_slots, int
     if (n_slots < 0 || n_slots % kThreads != 0 || !nb_ok(nb_log2) || K < 1) return 0;
     const int64_t nb = 1ll << nb_log2;
     const int64_t cap = n_slots > 0 ? n_slots : kThreads, W = cap / kThreads;
-    return (2 * nb + 8 + 16) * (int64_t)sizeof(unsigned) + W * nb * (int64_t)(sizeof(unsigned) + sizeof(unsigned short)) +
-           2 * cap * (int64_t)sizeof(unsigned long long) + 2 * cap * (int64_t)sizeof(int) + cap * (int64_t)K * (int64_t)sizeof(float) + 64;
+    return (3 * nb + 8 + 16) * (int64_t)sizeof(unsigned) + W * nb * (int64_t)(sizeof(unsigned) + sizeof(unsigned short)) +
+           2 * cap * (int64_t)sizeof(unsigned long long) + 2 * cap * (int64_t)sizeof(int) + cap * (int64_t)(K + 1) * (int64_t)sizeof(float) + 64;
 }
 
 RECALGO_EXPORT int recalgo_scatter_prepare(const recalgo_scatter_source_t* source, int K, void* plan_workspace,
                                            int64_t plan_requests, int nb_log2, int64_t first_request, int lookup_index,
-                                           const recalgo_deferred_adam_t* deferred, const int64_t* step_dev, int step_offset,
-                                           recalgo_stream_t stream) {
+                                           const recalgo_deferred_adam_t* deferred,
+                                           const recalgo_deferred_adam_t* companion_deferred, const int64_t* step_dev,
+                                           int step_offset, recalgo_stream_t stream) {
     RECALGO_REQUIRE(source != nullptr && nb_ok(nb_log2) && lookup_index >= 0 && lookup_index < kMaxSources);
     RECALGO_REQUIRE(first_request >= 0 && first_request % kThreads == 0 && first_request < (1ll << 31));
     RECALGO_REQUIRE(plan_requests >= 0 && plan_requests % kThreads == 0);
@@ -1175,17 +1256,18 @@ RECALGO_EXPORT int recalgo_scatter_prepare(const recalgo_scatter_source_t* sourc
         hipLaunchKernelGGL(sparse_prepare_kernel<1>, grid, dim3(kThreads), smem, as_stream(stream), A);
     if (A.D.last_step) {
         CatchupArgs Cu;
-        Cu.D = A.D; Cu.stale_rows = A.stale_rows + first_request; Cu.stale_s = A.stale_s + first_request; Cu.stale_n = A.stale_n;
+        Cu.D = A.D; Cu.D1 = deferred_of(companion_deferred); Cu.stale_rows = A.stale_rows + first_request; Cu.stale_s = A.stale_s + first_request; Cu.stale_n = A.stale_n;
         Cu.step = A.step; Cu.step_off = A.step_off; Cu.K = (unsigned)K;
         // at most one claim per distinct row of the lookup; the grid covers n / 4 rows x K floats in one pass
-        const int64_t want = ((int64_t)n / 4 * K + kThreads - 1) / kThreads;
+        const int64_t want = ((int64_t)n / 4 * (K + (Cu.D1.last_step ? 1 : 0)) + kThreads - 1) / kThreads;
         const unsigned blocks = (unsigned)(want < 64 ? 64 : (want > 2048 ? 2048 : want));
         hipLaunchKernelGGL(sparse_catchup_kernel, dim3(blocks), dim3(kThreads), 0, as_stream(stream), Cu);
     }
     RECALGO_RETURN_LAST();
 }
 
-RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources, int n_sources, int K, void* plan_workspace,
+RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources, int n_sources,
+                                         const recalgo_scatter_companion_t* companion, int K, void* plan_workspace,
                                          int64_t plan_requests, int nb_log2, int mode, float* w, float* m, float* v,
                                          float* grad, const recalgo_deferred_adam_t* deferred, int64_t rows,
                                          int sweep_period, const recalgo_live_t* live, const int64_t* step_dev,
@@ -1197,11 +1279,18 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
     RECALGO_REQUIRE(mode != RECALGO_SCATTER_GRAD ? (w && m && v && step_dev) : grad != nullptr);
     RECALGO_REQUIRE(mode != RECALGO_SCATTER_ADAM || (deferred && deferred->last_step && deferred->lr_ring && sweep_period >= 1 &&
                                                      sweep_period <= (int)kLrRing - 8));
+    if (companion) {
+        RECALGO_REQUIRE(companion->sources != nullptr && companion->rows >= 0 && companion->rows < (1ll << 31));
+        RECALGO_REQUIRE((size_t)K * kThreads * sizeof(float) <= 32 * 1024);
+        RECALGO_REQUIRE(mode != RECALGO_SCATTER_GRAD ? (companion->w && companion->m && companion->v) : companion->grad != nullptr);
+        RECALGO_REQUIRE(mode != RECALGO_SCATTER_ADAM || (companion->deferred && companion->deferred->last_step &&
+                                                         companion->deferred->lr_ring));
+    }
     Geometry G;
     RECALGO_REQUIRE(geometry(K, sources, n_sources, &G));
     PlaceArgs P;
     unsigned n_total = 0;
-    RECALGO_REQUIRE(to_dev(sources, n_sources, P.src, &n_total, true));
+    RECALGO_REQUIRE(to_dev(sources, n_sources, P.src, &n_total, true, companion ? companion->sources : nullptr));
     RECALGO_REQUIRE(plan_requests % kThreads == 0 && (int64_t)n_total <= plan_requests);
     const Ws ws = carve(plan_workspace, plan_requests, nb_log2);
     hipStream_t st = as_stream(stream);
@@ -1218,19 +1307,26 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
         S.period = sweep_period < 1 ? 1 : sweep_period;
         S.chunk = (rows + S.period - 1) / S.period;
         const unsigned sweep_blocks = S.D.last_step ? (unsigned)cdiv(S.chunk * G.L1, kThreads) : 0u;
+        S.D1 = (companion && mode == RECALGO_SCATTER_ADAM) ? deferred_of(companion->deferred) : deferred_of(nullptr);
+        S.rows1 = companion ? companion->rows : 0;
+        S.chunk1 = (S.rows1 + S.period - 1) / S.period;
+        S.comp_first = S.scan_blocks + sweep_blocks;
+        const unsigned comp_blocks = S.D1.last_step ? (unsigned)cdiv(S.chunk1, kThreads) : 0u;
         if (G.vec == 4)
-            hipLaunchKernelGGL(sparse_scan_kernel<4>, dim3(S.scan_blocks + sweep_blocks), dim3(kThreads), 0, st, S);
+            hipLaunchKernelGGL(sparse_scan_kernel<4>, dim3(S.comp_first + comp_blocks), dim3(kThreads), 0, st, S);
         else
-            hipLaunchKernelGGL(sparse_scan_kernel<1>, dim3(S.scan_blocks + sweep_blocks), dim3(kThreads), 0, st, S);
+            hipLaunchKernelGGL(sparse_scan_kernel<1>, dim3(S.comp_first + comp_blocks), dim3(kThreads), 0, st, S);
     }
     P.n_src = n_sources;
     P.n_total = n_total;
     P.req_blocks = W ? W : 1;                                 // (the scan of all-zero totals still publishes offs[])
-    P.total = ws.total; P.Cp = ws.Cp; P.offs = ws.offs; P.keys = ws.keys; P.partials = ws.partials;
+    P.total = ws.total; P.Cp = ws.Cp; P.offs = ws.offs; P.order = ws.order; P.keys = ws.keys; P.partials = ws.partials;
+    P.partials1 = companion ? ws.partials1 : nullptr;
     P.nb_log2 = (unsigned)nb_log2;
     P.KV = G.KV; P.L = G.L;
+    P.stage_ok = (size_t)K * kThreads * sizeof(float) <= 32 * 1024;      // (K <= 32: every model of the reference)
     const size_t smem = ((size_t)nb + 7 * kThreads + 8 + 16 + kSlots * 9) * sizeof(unsigned) + kThreads * 4 * sizeof(float) + kMaxSources * sizeof(SrcDev) +
-                        (P.stage_ok ? (size_t)K * kThreads * sizeof(float) : 0);
+                        (P.stage_ok ? (size_t)(K + 1) * kThreads * sizeof(float) : 0);
     if (smem > 64 * 1024) {
         hipError_t e = G.vec == 4 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_place_kernel<4>),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
@@ -1246,7 +1342,7 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
     for (int i = 0; i < kMaxSources; ++i)
         A.src[i] = GSrc{P.src[i].g, P.src[i].g_stride, P.src[i].g_col, P.src[i].g_fmul, P.src[i].F, P.src[i].first};
     A.n_src = n_sources;
-    A.offs = ws.offs; A.keys = ws.keys; A.keys_alt = ws.keys_alt; A.partials = ws.partials;
+    A.offs = ws.offs; A.order = ws.order; A.keys = ws.keys; A.keys_alt = ws.keys_alt; A.partials = ws.partials;
     A.mode = mode;
     A.w = w; A.m = m; A.v = v; A.grad = grad;
     A.last_step = mode == RECALGO_SCATTER_ADAM ? deferred->last_step : nullptr;
@@ -1270,6 +1366,21 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
         hipLaunchKernelGGL(sparse_apply_kernel<4>, dim3(nb), dim3(kThreads), 0, st, A);
     else
         hipLaunchKernelGGL(sparse_apply_kernel<1>, dim3(nb), dim3(kThreads), 0, st, A);
+    if (companion) {
+        // the second arena: the same placed entries, bucket by bucket; only the gradient (a scalar per request, the tile
+        // partial sums `place` wrote beside the main ones) and the arena differ
+        for (int i = 0; i < kMaxSources; ++i) {
+            A.src[i].g = P.src[i].g1; A.src[i].g_stride = P.src[i].g1_stride;
+            A.src[i].g_col = P.src[i].g1_col; A.src[i].g_fmul = P.src[i].g1_fmul;
+        }
+        A.partials = ws.partials1;
+        A.w = companion->w; A.m = companion->m; A.v = companion->v; A.grad = companion->grad;
+        A.last_step = mode == RECALGO_SCATTER_ADAM ? companion->deferred->last_step : nullptr;
+        A.lr_ring = mode == RECALGO_SCATTER_ADAM ? companion->deferred->lr_ring : nullptr;
+        A.K = 1; A.KV = 1; A.L = 1;
+        A.live_words = nullptr; A.live_list = nullptr; A.live_count = nullptr;
+        hipLaunchKernelGGL(sparse_apply_kernel<1>, dim3(nb), dim3(kThreads), 0, st, A);
+    }
     RECALGO_RETURN_LAST();
 }
 
@@ -1285,6 +1396,7 @@ RECALGO_EXPORT int recalgo_adam_deferred_sweep(const recalgo_deferred_adam_t* de
     A.step_off = step_offset;
     A.KV = G.KV; A.L = G.L; A.L1 = G.L1;
     A.row0 = row_begin; A.row1 = row_end;
+    A.period = 0; A.chunk = 0;
     const int64_t threads = (row_end - row_begin) * G.L1;
     const dim3 grid((unsigned)((threads + kThreads - 1) / kThreads));
     if (G.vec == 4)

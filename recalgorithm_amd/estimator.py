@@ -89,6 +89,7 @@ class AdamOptimizer:
         # arenas on the owner-computes path (sparse.py): their optimizer step is fused with the row-gradient scatter
         # (recalgo_scatter_apply) — TF1 Adam with dense semantics evaluated lazily but exactly, or LazyAdam
         owned = [ar for ar in arenas if sparse.has_work(ar)]
+        owned.sort(key=sparse.has_companions)     # (an arena whose lookups ride on another arena's plan comes after it)
         arenas = [ar for ar in arenas if not sparse.has_work(ar)]
         fused = all(ar.tracks_live_rows for ar in arenas) and len(arenas) <= 4 and store.device.type == "cuda"
         # parked gradients: deferred weight-gradient split sums (+ the step counter, advanced by the same launch),

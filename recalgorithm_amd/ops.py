@@ -304,8 +304,8 @@ class _DeepFMSparseFn(Function):
         fm2 = torch.empty(B, 1, device=ids.device, dtype=torch.float32)
         fsum = torch.empty(B, K, device=ids.device, dtype=torch.float32)
         st = anchor_store(anchor)
-        ctx.src = sparse.begin_lookup(arena, st, ids, None, row_base, 0, B, F, training)
-        ctx.src1 = sparse.begin_lookup(w1, st, ids, None, row_base, 0, B, F, training)
+        # the first-order arena is looked up with the same requests: it rides on the embedding arena's plan
+        ctx.src, ctx.src1 = sparse.begin_lookup_pair(arena, w1, st, ids, row_base, B, F, training)
         dv, stp = sparse.view_for(ctx.src, arena, st)
         dv1, stp1 = sparse.view_for(ctx.src1, w1, st)
         _lib.check(_lib_().recalgo_deepfm_sparse_fwd_deferred(

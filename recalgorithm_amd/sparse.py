@@ -53,6 +53,11 @@ class _CSource(ctypes.Structure):            # include/recalgo.h recalgo_scatter
                 ("g_col", ctypes.c_int), ("g_fmul", ctypes.c_int)]
 
 
+class _CCompanion(ctypes.Structure):         # include/recalgo.h recalgo_scatter_companion_t
+    _fields_ = [("sources", ctypes.c_void_p), ("w", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
+                ("grad", ctypes.c_void_p), ("deferred", ctypes.c_void_p), ("rows", ctypes.c_int64)]
+
+
 class _CDeferred(ctypes.Structure):          # include/recalgo.h recalgo_deferred_adam_t
     _fields_ = [("w", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p), ("last_step", ctypes.c_void_p),
                 ("lr_ring", ctypes.c_void_p), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float)]
@@ -63,9 +68,11 @@ class Source:
 
     def __init__(self, ids, offsets, row_base, base: int, n_ex: int, F: int):
         self.ids, self.offsets, self.row_base, self.base, self.n_ex, self.F = ids, offsets, row_base, int(base), int(n_ex), int(F)
+        self.arena = None                      # set by begin_lookup
         self.g = None
         self.g_stride = self.g_col = self.g_fmul = 0
         self.caught_up = True                  # the lookup's rows are current when its forward kernel runs
+        self.companion: Optional["CompanionSource"] = None     # a one-float-per-row arena looked up with the same requests
 
     @property
     def n(self) -> int:
@@ -99,6 +106,37 @@ class Source:
                         self.g_stride, self.g_col, fm)
 
 
+class CompanionSource:
+    """The lookup of a SECOND arena of one float per row made with exactly the requests of `main` (DeepFM's first-order
+    weights beside its embeddings, /root/reference algorithm/DeepFM/deepfm.py:125-141).  It has no plan of its own: the
+    main arena's `place` also sums the scalar gradients of a tile's duplicates, and recalgo_scatter_apply_companion
+    walks the same placed entries for this arena — no second prepare / scan / place."""
+
+    def __init__(self, main: Source, arena):
+        self.main, self.arena = main, arena
+        self.caught_up = False                 # its forward reads lagging rows through the deferred view
+        self.g = None
+        self.g_stride = self.g_col = self.g_fmul = 0
+        self.regular: Optional[Source] = None  # set when the pairing was dissolved (see _dissolve)
+
+    def set_grad(self, g: torch.Tensor, fmul: Optional[int] = None):
+        """g: [n_ex, 1] (fmul = 0: every field of an example adds the same scalar) or [n_ex, F] (fmul = 1)."""
+        if self.regular is not None:
+            return self.regular.set_grad(g, fmul)
+        g = g.reshape(self.main.n_ex, -1)
+        if g.shape[1] > 1 and g.stride(1) != 1:
+            g = g.contiguous()
+        self.g = g
+        self.g_stride = int(g.stride(0)) if g.shape[0] > 1 else int(g.shape[1])
+        self.g_col = 0
+        self.g_fmul = 1 if fmul is None else int(fmul)
+
+    def c_struct(self) -> _CSource:
+        m = self.main
+        p = lambda t: None if t is None else t.data_ptr()
+        return _CSource(p(m.ids), p(m.offsets), p(m.row_base), m.base, m.n_ex, m.F, p(self.g), self.g_stride, self.g_col, self.g_fmul)
+
+
 class ArenaPlan:
     """Per-arena state of the owner-computes path (attached as `arena.sparse`)."""
 
@@ -113,6 +151,8 @@ class ArenaPlan:
         self.lr_ring: Optional[torch.Tensor] = None
         self.betas = (0.9, 0.999, 1e-8)
         self.grad_materialized = False
+        self.companions: List[CompanionSource] = []       # this arena is the SECOND arena of these lookups (this step)
+        self.served = False                    # ... and the main arena's optimizer call has already applied them
 
     # -- workspace ------------------------------------------------------------------------------
     def _ensure_ws(self, n_requests: int):
@@ -178,7 +218,7 @@ def deferred_view(arena, store):
 
 
 def begin_lookup(arena, store, ids: torch.Tensor, offsets: Optional[torch.Tensor], row_base: Optional[torch.Tensor],
-                 base: int, n_ex: int, F: int, training: Optional[bool] = None) -> Optional[Source]:
+                 base: int, n_ex: int, F: int, training: Optional[bool] = None, companion_arena=None) -> Optional[Source]:
     """Called by a lookup's forward in TRAIN mode.  Returns the Source to attach the gradient to (owner mode), or None.
     Launches recalgo_scatter_prepare: the lookup's tiles are counted into the arena's plan and — deferred Adam — its
     rows are brought up to date.  (Lookups that are NOT registered — EVAL / PREDICT — read lagging rows through
@@ -191,7 +231,10 @@ def begin_lookup(arena, store, ids: torch.Tensor, offsets: Optional[torch.Tensor
         return None
     if plan is None:
         plan = arena.sparse = ArenaPlan(arena)
+    if plan.companions:
+        _dissolve(plan)                        # (the arena is also looked up on its own this step: it needs its own plan)
     src = Source(ids, offsets, row_base, base, n_ex, F)
+    src.arena = arena
     if src.n == 0:
         plan.sources.append(src)
         return src
@@ -207,8 +250,12 @@ def begin_lookup(arena, store, ids: torch.Tensor, offsets: Optional[torch.Tensor
     d = plan._deferred_struct() if idx < MAX_SOURCES else None     # (one catch-up list per lookup; later lookups of a model
     src.caught_up = d is not None or plan.last_step is None        #  that makes more than 16 read lagging rows through the view)
     step = None if d is None else store.opt_state["step"]
+    d1 = None
+    if companion_arena is not None and _pair(src, arena, companion_arena) and d is not None:
+        d1 = plan_of(companion_arena)._deferred_struct()          # (the second arena's rows are caught up by the same launch)
     _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), arena.K, ctypes.c_void_p(plan.ws.data_ptr()), plan.capacity, plan.nb_log2,
                                            first, min(idx, MAX_SOURCES - 1), None if d is None else ctypes.byref(d),
+                                           None if d1 is None else ctypes.byref(d1),
                                            None if step is None else ctypes.c_void_p(step.data_ptr()), 0, _stream(arena.weight)),
                "recalgo_scatter_prepare")
     plan.sources.append(src)
@@ -216,10 +263,60 @@ def begin_lookup(arena, store, ids: torch.Tensor, offsets: Optional[torch.Tensor
     return src
 
 
+def companion_enabled() -> bool:
+    return os.environ.get("RECALGO_SPARSE_COMPANION", "1") != "0"
+
+
+def _pair(main: Source, main_arena, arena) -> bool:
+    """Try to make `arena` (one float per row) the companion of the lookup `main` of `main_arena`."""
+    plan = plan_of(arena)
+    ok = (main.n > 0 and companion_enabled() and _supported(arena) and arena.K == 1 and
+          main_arena.K * 256 * 4 <= 32 * 1024 and getattr(arena, "trainable", True) and
+          (plan is None or not plan.sources))
+    if ok:
+        others = {id(s.companion.arena) for s in plan_of(main_arena).sources if s.companion is not None}
+        ok = not others or others == {id(arena)}
+    if not ok:
+        return False
+    if plan is None:
+        plan = arena.sparse = ArenaPlan(arena)
+    cs = CompanionSource(main, arena)
+    main.companion = cs
+    plan.companions.append(cs)
+    return True
+
+
+def begin_lookup_pair(main_arena, arena, store, ids, row_base, n_ex: int, F: int, training=None):
+    """The two lookups of DeepFM's sparse part: `main_arena` [rows, K] and `arena` [rows, 1] with the SAME ids / row_base.
+    -> (Source of the main lookup or None, CompanionSource / Source / None of the second)."""
+    main = begin_lookup(main_arena, store, ids, None, row_base, 0, n_ex, F, training, companion_arena=arena)
+    if main is not None and main.companion is not None:
+        return main, main.companion
+    return main, begin_lookup(arena, store, ids, None, row_base, 0, n_ex, F, training)
+
+
+def _dissolve(plan: ArenaPlan) -> None:
+    """The companions registered on this arena become lookups of its own plan (counted again by the optimizer's launch)."""
+    for cs in plan.companions:
+        m = cs.main
+        r = Source(m.ids, m.offsets, m.row_base, m.base, m.n_ex, m.F)
+        r.caught_up = False
+        if cs.g is not None:
+            r.g, r.g_stride, r.g_col, r.g_fmul = cs.g, cs.g_stride, cs.g_col, cs.g_fmul
+        cs.regular = r
+        m.companion = None
+        plan.sources.append(r)
+    plan.companions = []
+    plan.counted = None
+
+
 def new_forward(store) -> None:
     """A model_fn invocation starts: sources of an earlier forward that never reached the optimizer are stale."""
     for ar in store.arenas.values():
         plan = plan_of(ar)
+        if plan is not None and plan.companions:
+            plan.companions = []
+            plan.grad_materialized = False
         if plan is not None and plan.sources:
             plan.sources = []
             plan.counted = None
@@ -230,7 +327,14 @@ def new_forward(store) -> None:
 
 def has_work(arena) -> bool:
     plan = plan_of(arena)
-    return plan is not None and (bool(plan.sources) or plan.last_step is not None)
+    return plan is not None and (bool(plan.sources) or bool(plan.companions) or plan.last_step is not None)
+
+
+def has_companions(arena) -> bool:
+    """The arena's lookups of this step ride on another arena's plan: that arena's optimizer call serves it (the
+    Estimator applies arenas with companions LAST)."""
+    plan = plan_of(arena)
+    return plan is not None and bool(plan.companions)
 
 
 def _merge_dense(sources: List[Source], K: int) -> List[Source]:
@@ -263,7 +367,11 @@ def _merge_dense(sources: List[Source], K: int) -> List[Source]:
 def _run(plan: ArenaPlan, sources: List[Source], mode: int, step_dev, step_offset: int, lr: float, live=None):
     lib = _lib.load()
     a = plan.arena
+    comp_arena = _companion_arena(sources, mode)
     if len([s for s in sources if s.n]) > MAX_SOURCES:
+        if comp_arena is not None:
+            _dissolve(plan_of(comp_arena))
+            comp_arena = None
         sources = _merge_dense(sources, a.K)
     srcs = [s for s in sources if s.n]
     plan._ensure_ws(sum(s.slots for s in srcs))
@@ -274,7 +382,7 @@ def _run(plan: ArenaPlan, sources: List[Source], mode: int, step_dev, step_offse
         for s in srcs:
             cs = s.c_struct(a.K)
             _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), a.K, ctypes.c_void_p(plan.ws.data_ptr()), plan.capacity,
-                                                   plan.nb_log2, first, 0, None, None, 0, _stream(a.weight)), "recalgo_scatter_prepare")
+                                                   plan.nb_log2, first, 0, None, None, None, 0, _stream(a.weight)), "recalgo_scatter_prepare")
             first += s.slots
     if not srcs:                               # (the sweep and the lr ring still need the launch)
         dummy = Source(a.weight, None, None, 0, 0, 1)
@@ -284,17 +392,73 @@ def _run(plan: ArenaPlan, sources: List[Source], mode: int, step_dev, step_offse
     d = plan._deferred_struct() if mode == MODE_ADAM else None
     b1, b2, eps = plan.betas
     p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    comp = None
+    if comp_arena is not None:
+        # the second arena: same placed entries, its own rows / optimizer state.  Sources without a companion (or whose
+        # companion never got a gradient) contribute nothing to it
+        c, cp = comp_arena, plan_of(comp_arena)
+        cp.betas = plan.betas
+        if mode == MODE_ADAM and cp.last_step is None:
+            _init_deferred(cp, step_dev)
+        if mode == MODE_LAZY_ADAM and cp.last_step is not None:
+            sync(c, step_dev, -1)
+            cp.last_step = None
+        if mode == MODE_GRAD:
+            cp.grad_materialized = True
+        cstructs = [s.companion.c_struct() if (s.companion is not None and s.companion.g is not None) else
+                    _CSource(s.ids.data_ptr(), None if s.offsets is None else s.offsets.data_ptr(),
+                             None if s.row_base is None else s.row_base.data_ptr(), s.base, s.n_ex, s.F, None, 0, 0, 0)
+                    for s in srcs]
+        carr = (_CSource * len(srcs))(*cstructs)
+        dc = cp._deferred_struct() if mode == MODE_ADAM else None
+        cgrad = c._grad if (mode == MODE_GRAD or cp.grad_materialized) else None
+        ptr = lambda t: None if t is None else t.data_ptr()
+        comp = _CCompanion(ctypes.addressof(carr), ptr(c.weight), ptr(c.m), ptr(c.v), ptr(cgrad),
+                           None if dc is None else ctypes.addressof(dc), c.weight.shape[0])
     grad = a._grad if (mode == MODE_GRAD or plan.grad_materialized) else None
-    _lib.check(lib.recalgo_scatter_apply(arr, len(srcs), a.K, p(plan.ws), plan.capacity, plan.nb_log2, mode, p(a.weight), p(a.m),
-                                         p(a.v), p(grad), None if d is None else ctypes.byref(d), a.weight.shape[0],
+    _lib.check(lib.recalgo_scatter_apply(arr, len(srcs), None if comp is None else ctypes.byref(comp), a.K, p(plan.ws), plan.capacity,
+                                         plan.nb_log2, mode, p(a.weight), p(a.m), p(a.v), p(grad),
+                                         None if d is None else ctypes.byref(d), a.weight.shape[0],
                                          sweep_period(), live, p(step_dev), step_offset, lr, b1, b2, eps, _stream(a.weight)),
                "recalgo_scatter_apply")
+    if comp_arena is not None and mode != MODE_GRAD:
+        cp.companions = []
+        cp.grad_materialized = False
+        cp.served = True
     plan.counted = plan._signature([])         # (the next step's `prepare` launches overwrite their rows of the count matrix)
+
+
+def _companion_arena(sources: List[Source], mode: int):
+    """The second arena served by this plan's launches, or None.  LazyAdam must touch exactly the rows of the second arena's
+    own lookups: a plan in which only SOME lookups carry a companion gives it up (the arenas then run separately)."""
+    comps = [s.companion for s in sources if s.n and s.companion is not None]
+    if not comps:
+        return None
+    arena = comps[0].arena
+    if mode == MODE_LAZY_ADAM and len(comps) != len([s for s in sources if s.n]):
+        _dissolve(plan_of(arena))
+        return None
+    return arena
+
+
+def _init_deferred(plan: ArenaPlan, step_dev: torch.Tensor) -> None:
+    # rows with state (m, v) are valid for the step before this one; untouched rows are marked 0
+    arena = plan.arena
+    alive = ((arena.m != 0) | (arena.v != 0)).any(dim=1)
+    plan.last_step = (alive.to(torch.int64) * (step_dev - 1)).to(torch.int32)
+    plan.lr_ring = torch.zeros(LR_RING, dtype=torch.float32, device=arena.weight.device)
 
 
 def apply(arena, lazy: bool, step_dev: torch.Tensor, lr: float, beta1: float, beta2: float, eps: float) -> None:
     """The optimizer step of one arena (step_dev already advanced to this step)."""
     plan = plan_of(arena)
+    if plan.companions:
+        raise RuntimeError(f"arena {getattr(arena, 'name', '?')}: its lookups ride on another arena's plan, whose optimizer call "
+                           "has not run yet (apply arenas with sparse.has_companions() last)")
+    if plan.served and not plan.sources:       # (this step's update of the arena ran with the main arena's launches)
+        plan.served = False
+        return
+    plan.served = False
     sources = [s for s in plan.sources if s.g is not None]
     plan.betas = (float(beta1), float(beta2), float(eps))
     if lazy:
@@ -305,11 +469,12 @@ def apply(arena, lazy: bool, step_dev: torch.Tensor, lr: float, beta1: float, be
             _run(plan, sources, MODE_LAZY_ADAM, step_dev, 0, lr)
     else:
         if plan.last_step is None:
-            # rows with state (m, v) are valid for the step before this one; untouched rows are marked 0
-            alive = ((arena.m != 0) | (arena.v != 0)).any(dim=1)
-            plan.last_step = (alive.to(torch.int64) * (step_dev - 1)).to(torch.int32)
-            plan.lr_ring = torch.zeros(LR_RING, dtype=torch.float32, device=arena.weight.device)
+            _init_deferred(plan, step_dev)
         _run(plan, sources, MODE_ADAM, step_dev, 0, lr)
+    for s in plan.sources:                     # companions whose main lookup never got a gradient: nothing to apply
+        if s.companion is not None:
+            cp = plan_of(s.companion.arena)
+            cp.companions = [c for c in cp.companions if c is not s.companion]
     plan.sources = []
     plan.grad_materialized = False
 
@@ -319,6 +484,10 @@ def materialize_arena(arena) -> None:
     does not need it)."""
     plan = plan_of(arena)
     if plan is None or plan.grad_materialized:
+        return
+    if plan.companions:                        # the second arena of a pairing: the main arena's launch fills both
+        for ma in {id(c.main.arena): c.main.arena for c in plan.companions}.values():
+            materialize_arena(ma)
         return
     sources = [s for s in plan.sources if s.g is not None]
     if not sources:

@@ -279,12 +279,15 @@ def test_lazy_adam_matches_tf_lazy_adam(dev, rows, K):
     assert sparse.plan_of(ar).last_step is None
 
 
-def test_models_train_identically_on_the_owner_and_the_sorted_paths(dev, monkeypatch):
-    """DCN, three steps: the owner-computes path (deferred Adam) and the round-2 deterministic path (sorted scatter +
-    live-list dense Adam) agree — the same arithmetic, summed in a different order."""
+@pytest.mark.parametrize("model", ["dcn", "deepfm"])
+def test_models_train_identically_on_the_owner_and_the_sorted_paths(dev, model, monkeypatch):
+    """DCN / DeepFM, three steps: the owner-computes path (deferred Adam; DeepFM's first-order arena as the companion of its
+    embedding arena) and the round-2 deterministic path (sorted scatter + live-list dense Adam) agree — the same
+    arithmetic, summed in a different order."""
     from recalgorithm_amd import feature_column as fc
     from recalgorithm_amd import sparse
     from recalgorithm_amd.algorithm.DCN.dcn import dcn_model_fn
+    from recalgorithm_amd.algorithm.DeepFM.deepfm import deepfm_model_fn
     from recalgorithm_amd.estimator import Estimator, RunConfig
     from recalgorithm_amd.io import synth
     spec = synth.SynthSpec(n_fields=6, max_vocab=300, seed=11)
@@ -292,9 +295,16 @@ def test_models_train_identically_on_the_owner_and_the_sorted_paths(dev, monkeyp
     for mode in ("owner", "sorted"):
         monkeypatch.setenv("RECALGO_SPARSE", mode)
         cats = [fc.categorical_column_with_identity(n, v) for n, v in zip(spec.names, spec.vocabs)]
-        params = {"category_feature_columns": [fc.embedding_column(c, 16) for c in cats], "dense_feature_columns": [],
-                  "hidden_units": ["32", "16"], "num_cross_layer": 2, "learning_rate": 0.01}
-        est = Estimator(dcn_model_fn, params, RunConfig(device=dev, seed=5))
+        if model == "dcn":
+            fn = dcn_model_fn
+            params = {"category_feature_columns": [fc.embedding_column(c, 16) for c in cats], "dense_feature_columns": [],
+                      "hidden_units": ["32", "16"], "num_cross_layer": 2, "learning_rate": 0.01}
+        else:
+            fn = deepfm_model_fn
+            params = {"first_order_feature_columns": [fc.indicator_column(c) for c in cats],
+                      "second_order_feature_columns": [fc.embedding_column(c, 16) for c in cats],
+                      "hidden_units": ["32", "16"], "dropout_rate": 0.0, "batch_norm": True, "learning_rate": 0.01}
+        est = Estimator(fn, params, RunConfig(device=dev, seed=5))
         losses = []
         for i in range(3):
             feats, labels, _ = synth.device_features(spec, 128, dev, batch_index=i)
@@ -311,3 +321,81 @@ def test_models_train_identically_on_the_owner_and_the_sorted_paths(dev, monkeyp
         assert abs(a - b) <= 1e-5 * abs(b)
     for k, ref in results["sorted"][1].items():
         assert_close(results["owner"][1][k], ref, what=f"owner vs sorted path: {k}", rtol=1e-4, reduced=True)
+
+
+@pytest.mark.parametrize("lazy", [False, True])
+def test_companion_arena_equals_its_own_plan_bit_for_bit(dev, lazy, monkeypatch):
+    """DeepFM's first-order arena (one float per row, looked up with the embedding arena's requests, deepfm.py:125-141)
+    rides on the embedding arena's plan: `place` also sums the scalar gradients of a tile's duplicates and
+    recalgo_scatter_apply_companion walks the same placed entries.  Same entries, same order, same arithmetic as a plan
+    of its own: weights, both moments and the materialised gradient are bit-identical — deferred Adam and LazyAdam."""
+    from recalgorithm_amd import sparse
+    monkeypatch.setenv("RECALGO_ADAM_SWEEP_PERIOD", "3")
+    rows, K, F, n_ex = 4000, 16, 3, 700
+    out = {}
+    for companion in ("1", "0"):
+        monkeypatch.setenv("RECALGO_SPARSE_COMPANION", companion)
+        gen = torch.Generator().manual_seed(77)
+        E, W = _arena(dev, rows, K, seed=3, name="e"), _arena(dev, rows, 1, seed=4, name="w")
+        store = _Store(dev)
+        store.arenas["e"], store.arenas["w"] = E, W
+        grads = None
+        for step in range(1, 9):
+            lo = (step * 301) % (rows - 600)
+            ids = lo + torch.randint(0, 600, (n_ex, F), generator=gen)
+            ids[torch.rand(n_ex, F, generator=gen) < 0.3] = 3             # a hot row: duplicates inside every tile
+            ids[torch.rand(n_ex, F, generator=gen) < 0.05] = -1
+            g = torch.randn(n_ex, F * K, generator=gen).to(dev)
+            g1 = torch.randn(n_ex, 1, generator=gen).to(dev)
+            ids_d = ids.to(dev)
+            sparse.new_forward(store)
+            with torch.enable_grad():
+                s, s1 = sparse.begin_lookup_pair(E, W, store, ids_d, None, n_ex, F)
+            assert isinstance(s1, sparse.CompanionSource) == (companion == "1")
+            s.set_grad(g)
+            s1.set_grad(g1, fmul=0)
+            if step == 2:                                                  # the gradient arenas on request (named_grads)
+                grads = (E.grad.clone(), W.grad.clone())
+                ref1 = torch.zeros(rows, 1, dtype=torch.float64)
+                ok = ids >= 0
+                ref1.index_add_(0, ids[ok], g1.cpu().double().expand(n_ex, F)[ok].reshape(-1, 1))
+                assert_close(grads[1], ref1, what="companion GRAD vs fp64 sum", reduced=True)
+            store.opt_state["step"] += 1
+            for ar in sorted((E, W), key=sparse.has_companions):
+                sparse.apply(ar, lazy, store.opt_state["step"], 0.01, 0.9, 0.999, 1e-8)
+            assert float(W.grad.abs().sum()) == 0.0 and float(E.grad.abs().sum()) == 0.0
+        if not lazy:
+            lag = int(store.opt_state["step"]) - sparse.plan_of(W).last_step
+            assert int(lag[sparse.plan_of(W).last_step > 0].max()) <= 3 + 1, "the companion arena is swept too"
+        sparse.sync_store(store)
+        out[companion] = (grads, [t.clone() for t in (E.weight, E.m, E.v, W.weight, W.m, W.v)])
+    for a, b, nm in zip(out["1"][0], out["0"][0], ("E.grad", "W.grad")):
+        assert_bit_exact(a, b, f"companion vs own plan: {nm}")
+    for a, b, nm in zip(out["1"][1], out["0"][1], ("E.w", "E.m", "E.v", "W.w", "W.m", "W.v")):
+        assert_bit_exact(a, b, f"companion vs own plan: {nm}")
+    assert float((out["1"][1][3] - _arena(dev, rows, 1, seed=4).weight).abs().max()) > 0
+
+
+def test_companion_dissolves_when_the_arena_is_also_looked_up_alone(dev):
+    """An arena that rides on another one's plan AND is looked up on its own in the same step falls back to a plan of its
+    own (every request counted once)."""
+    from recalgorithm_amd import sparse
+    rows, K, F, n_ex = 900, 8, 2, 300
+    gen = torch.Generator().manual_seed(5)
+    E, W = _arena(dev, rows, K, seed=3, name="e"), _arena(dev, rows, 1, seed=4, name="w")
+    store = _Store(dev)
+    store.arenas["e"], store.arenas["w"] = E, W
+    ids = torch.randint(0, rows, (n_ex, F), generator=gen)
+    ids2 = torch.randint(0, rows, (50, 1), generator=gen)
+    g1, g2 = torch.randn(n_ex, 1, generator=gen), torch.randn(50, 1, generator=gen)
+    with torch.enable_grad():
+        s, s1 = sparse.begin_lookup_pair(E, W, store, ids.to(dev), None, n_ex, F)
+        s2 = sparse.begin_lookup(W, store, ids2.to(dev), None, None, 0, 50, 1)
+    assert s.companion is None and s1.regular is not None
+    s.set_grad(torch.randn(n_ex, F * K, generator=gen).to(dev))
+    s1.set_grad(g1.to(dev), fmul=0)
+    s2.set_grad(g2.to(dev))
+    ref = torch.zeros(rows, 1, dtype=torch.float64)
+    ref.index_add_(0, ids.reshape(-1), g1.double().expand(n_ex, F).reshape(-1, 1))
+    ref.index_add_(0, ids2.reshape(-1), g2.double())
+    assert_close(W.grad, ref, what="dissolved companion + own lookup", reduced=True)
