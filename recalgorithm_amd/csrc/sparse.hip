@@ -342,22 +342,22 @@ __global__ __launch_bounds__(kThreads) void sparse_catchup_kernel(CatchupArgs A)
     const unsigned ntask = ns * per_row;
     for (unsigned task = blockIdx.x * kThreads + threadIdx.x; task < ntask; task += gridDim.x * kThreads) {
         const unsigned k = task / per_row, e = task - k * per_row;
-        if (e == A.K) {                                       // the same row of the companion arena
-            const int row = A.stale_rows[k];
-            const int s1 = A.D1.last_step[row];
-            if (s1 > 0 && s1 < target) {
-                float w = A.D1.w[row], m = A.D1.m[row], v = A.D1.v[row];
-                recalgo_deferred::replay1(w, m, v, s1, target, A.D1.lr_ring, A.D1.b1, A.D1.b2, A.D1.eps);
-                A.D1.w[row] = w; A.D1.m[row] = m; A.D1.v[row] = v;
-                A.D1.last_step[row] = target;
-            }
-            continue;
-        }
-        const size_t o = (size_t)A.stale_rows[k] * A.K + e;
-        float w = A.D.w[o], m = A.D.m[o], v = A.D.v[o];
-        recalgo_deferred::replay1(w, m, v, A.stale_s[k], target, A.D.lr_ring, A.D.b1, A.D.b2, A.D.eps);
-        A.D.w[o] = w; A.D.m[o] = m; A.D.v[o] = v;
-        if (e == 0) A.D.last_step[A.stale_rows[k]] = target;
+        // ONE code path for both arenas (a divergent branch would run the two replay loops of a wave one after the other):
+        // lane e < K owns float e of the row, lane e == K the row's float in the companion arena
+        const int row = A.stale_rows[k];
+        const bool comp = e == A.K;
+        int s = A.stale_s[k];
+        if (comp) s = A.D1.last_step[row];
+        const bool live = !comp || (s > 0 && s < target);
+        if (!live) s = target;
+        float* pw = comp ? A.D1.w + row : A.D.w + (size_t)row * A.K + e;
+        float* pm = comp ? A.D1.m + row : A.D.m + (size_t)row * A.K + e;
+        float* pv = comp ? A.D1.v + row : A.D.v + (size_t)row * A.K + e;
+        float w = *pw, m = *pm, v = *pv;
+        recalgo_deferred::replay1(w, m, v, s, target, comp ? A.D1.lr_ring : A.D.lr_ring, A.D.b1, A.D.b2, A.D.eps);
+        if (live) { *pw = w; *pm = m; *pv = v; }
+        if (e == 0) A.D.last_step[row] = target;
+        if (comp && live) A.D1.last_step[row] = target;
     }
 }
 
@@ -1259,8 +1259,8 @@ RECALGO_EXPORT int recalgo_scatter_prepare(const recalgo_scatter_source_t* sourc
         Cu.D = A.D; Cu.D1 = deferred_of(companion_deferred); Cu.stale_rows = A.stale_rows + first_request; Cu.stale_s = A.stale_s + first_request; Cu.stale_n = A.stale_n;
         Cu.step = A.step; Cu.step_off = A.step_off; Cu.K = (unsigned)K;
         // at most one claim per distinct row of the lookup; the grid covers n / 4 rows x K floats in one pass
-        const int64_t want = ((int64_t)n / 4 * (K + (Cu.D1.last_step ? 1 : 0)) + kThreads - 1) / kThreads;
-        const unsigned blocks = (unsigned)(want < 64 ? 64 : (want > 2048 ? 2048 : want));
+        const int64_t want = ((int64_t)n / 3 * (K + (Cu.D1.last_step ? 1 : 0)) + kThreads - 1) / kThreads;
+        const unsigned blocks = (unsigned)(want < 64 ? 64 : (want > 4096 ? 4096 : want));   // (workgroups beyond the list exit at once)
         hipLaunchKernelGGL(sparse_catchup_kernel, dim3(blocks), dim3(kThreads), 0, as_stream(stream), Cu);
     }
     RECALGO_RETURN_LAST();

@@ -378,3 +378,70 @@ def test_attach_before_build_on_a_real_estimator_two_ranks():
             errs.append("worker timed out")
     assert not errs, "\n".join(errs)
     assert all(p.exitcode == 0 for p in procs)
+
+
+def _capacity_worker(rank, port, errq, world):
+    """The static exchange at the bench's capacity (0.75 x requests / world) on the bench's Zipf batches, B_local = 4096,
+    26 fields: with request de-duplication no owner bucket overflows, every staged row is the table row, and the
+    fullest bucket stays well under the capacity."""
+    try:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.set_num_threads(1)
+        from recalgorithm_amd import parallel as P
+        from recalgorithm_amd.io import synth
+        from recalgorithm_amd.variables import EmbeddingArena
+        spec = synth.SynthSpec(n_fields=26, max_vocab=60_000)
+        ar = EmbeddingArena("emb", 4, "cpu", seed=5)
+        names = sorted(spec.names)
+        for n in names:
+            ar.add_table(n, dict(zip(spec.names, spec.vocabs))[n])
+        ar.materialize()
+        W_full = ar.weight.clone()
+        rb = torch.tensor([ar.tables[n][0] for n in names], dtype=torch.int64)
+        P.shard_arena_(ar, P.ShardSpec(rank, world, None, dist), local_gather=cpu_gather, local_scatter_add=cpu_scatter_add, capacity_factor=0.75,
+                       planner=torch_exchange_plan, dedup=torch_dedup_rows)
+        worst = 0.0
+        for step in range(2):
+            feats, _, _ = synth.device_features(spec, 4096, "cpu", batch_index=step * world + rank)
+            ids = torch.stack([feats[n] for n in names], 1)
+            rows = P.global_rows(ids, rb)
+            plan = ar.sharding.plan(rows)
+            assert isinstance(plan, P.StaticExchangePlan)
+            staged = P.StagedArena(plan, ar)
+            sid = plan.staged_ids(rows, rows.shape)
+            ok = rows >= 0
+            assert bool((sid[ok] >= 0).all()), "a request lost its slot"
+            assert torch.equal(staged.weight[sid[ok]], W_full[rows[ok]]), "staged rows differ from the table rows"
+            assert not P.exchange_overflowed(types.SimpleNamespace(store=types.SimpleNamespace(arenas={"emb": ar}))), \
+                f"bucket overflow at capacity 0.75 x requests / {world}"
+            distinct = torch.unique(rows[ok])
+            fullest = int(torch.bincount(distinct % world, minlength=world).max())
+            worst = max(worst, fullest / (rows.numel() / world))
+        assert worst < 0.6, f"fullest owner bucket = {worst:.2f} x requests / world: the 0.75 capacity has no margin"
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        import traceback
+        errq.put(f"rank {rank}:\n{traceback.format_exc()}")
+        raise
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [4, 8])
+def test_static_exchange_capacity_on_zipf_batches(world):
+    """bench.py runs N > 1 with an exchange capacity of 0.75 x requests / world — checked here on the
+    bench's own id distribution at world 4 and 8 (gloo, CPU doubles for the owner-side kernels)."""
+    ctx = mp.get_context("spawn")
+    errq = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_capacity_worker, args=(r, port, errq, world)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(280)
+    errs = []
+    while not errq.empty():
+        errs.append(errq.get())
+    assert not errs, "\n".join(errs)
+    assert all(p.exitcode == 0 for p in procs)
