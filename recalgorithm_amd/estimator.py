@@ -282,6 +282,24 @@ HOUSEKEEPING_EVERY = 32      # steps between VariableStore.housekeeping() calls 
 OVERFLOW_POLL_EVERY = 64     # steps between reads of the static row-exchange overflow flag (N > 1; one host sync)
 
 
+def _quiesce_collectives() -> None:
+    """Before a capture that contains RCCL collectives: let torch.distributed's watchdog thread retire the EAGER collectives
+    issued so far.  It polls their completion events every 100 ms; HIP refuses an event query (hipErrorCapturedEvent:
+    'operation not permitted on an event last recorded in a capturing stream') once the communicator's internal stream —
+    on which those events were recorded — has joined a capture, and the watchdog then aborts the process (seen as a rare
+    crash of the warm-up-then-capture sequence).  All eager work is complete here (the caller has synchronised), so one
+    poll interval empties the watchdog's list."""
+    try:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl":
+            return
+    except Exception:            # (custom collectives objects, e.g. the host-staged bring-up adapter: no watchdog)
+        return
+    import time
+    torch.cuda.synchronize()
+    time.sleep(0.5)
+
+
 class GraphedTrainStep:
     """Capture `step_fn(features, labels)` (forward + backward + optimizer, everything enqueued
     on the current stream) into a hipGraph over static input buffers; `__call__` copies the new
@@ -302,6 +320,7 @@ class GraphedTrainStep:
                 self.out = step_fn(features, labels)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        _quiesce_collectives()
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: HIP calls of OTHER threads (the RCCL watchdog of torch.distributed polls events)
         # must not be treated as capture violations while this thread captures
