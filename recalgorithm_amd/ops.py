@@ -109,14 +109,15 @@ def scatter_rows_sorted(arena, rows: torch.Tensor, vals: torch.Tensor) -> None:
     mark_live_rows(arena, rows, None, 1)
 
 
-def _staged(arena, rows: torch.Tensor):
-    """(staged arena, identity ids [M]) for a row-sharded arena, or None when the arena is local."""
+def _staged(arena, rows: torch.Tensor, store=None):
+    """(plan, staged arena, identity ids [M]) for a row-sharded arena, or None when the arena is local.  `store`: the
+    owner side of the exchange joins the shard's owner-computes plan (sparse.py) when the call is a TRAIN forward."""
     sd = getattr(arena, "sharding", None)
     if sd is None:
         return None
     from . import parallel
     plan = sd.plan(rows)
-    return plan, parallel.StagedArena(plan, arena), plan.staged_ids(rows, rows.shape)
+    return plan, parallel.StagedArena(plan, arena, store, torch.is_grad_enabled()), plan.staged_ids(rows, rows.shape)
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
@@ -175,7 +176,7 @@ def embedding_gather(store: VariableStore, ids: torch.Tensor, arena: EmbeddingAr
     _chk(row_base, torch.int64, "row_base")
     if getattr(arena, "sharding", None) is not None:
         from . import parallel
-        _, staged, ident = _staged(arena, parallel.global_rows(ids, row_base))
+        _, staged, ident = _staged(arena, parallel.global_rows(ids, row_base), store)
         return _GatherFn.apply(store.anchor, ident.reshape(ids.shape), staged, torch.zeros_like(row_base), False)
     return _GatherFn.apply(store.anchor, ids, arena, row_base, torch.is_grad_enabled())
 
@@ -230,7 +231,7 @@ def embedding_bag_mean(store, values, offsets, arena, table_name) -> torch.Tenso
     _chk(offsets, torch.int64, "offsets")
     if getattr(arena, "sharding", None) is not None:
         rows = torch.where(values >= 0, values + arena.tables[table_name][0], torch.full_like(values, -1))
-        _, staged, ident = _staged(arena, rows)
+        _, staged, ident = _staged(arena, rows, store)
         return _BagMeanFn.apply(store.anchor, ident, offsets, staged, "__staged__", False)
     return _BagMeanFn.apply(store.anchor, values, offsets, arena, table_name, torch.is_grad_enabled())
 
@@ -286,7 +287,7 @@ def sequence_gather(store, values, offsets, arena, table_name, T) -> Tuple[torch
     _chk(offsets, torch.int64, "offsets")
     if getattr(arena, "sharding", None) is not None:
         rows = torch.where(values >= 0, values + arena.tables[table_name][0], torch.full_like(values, -1))
-        _, staged, ident = _staged(arena, rows)
+        _, staged, ident = _staged(arena, rows, store)
         return _SeqGatherFn.apply(store.anchor, ident, offsets, staged, "__staged__", int(T), False)
     return _SeqGatherFn.apply(store.anchor, values, offsets, arena, table_name, int(T), torch.is_grad_enabled())
 
@@ -356,8 +357,8 @@ def deepfm_sparse(store, ids, arena, w1_arena, bias, row_base):
     if getattr(arena, "sharding", None) is not None:
         # the first-order arena mirrors the embedding arena's row layout: one exchange plan, two fetches
         from . import parallel
-        plan, staged, ident = _staged(arena, parallel.global_rows(ids, row_base))
-        staged_w1 = parallel.StagedArena(plan, w1_arena)
+        plan, staged, ident = _staged(arena, parallel.global_rows(ids, row_base), store)
+        staged_w1 = parallel.StagedArena(plan, w1_arena, store, torch.is_grad_enabled())
         return _DeepFMSparseFn.apply(store.anchor, ident.reshape(ids.shape), staged, staged_w1, bias,
                                      torch.zeros_like(row_base), False)
     return _DeepFMSparseFn.apply(store.anchor, ids, arena, w1_arena, bias, row_base, torch.is_grad_enabled())

@@ -103,14 +103,19 @@ class ExchangePlan:
         flat = rows.reshape(-1)
         return torch.where(flat >= 0, self.rep, torch.full_like(self.rep, -1)).reshape(shape)
 
-    def push_grad(self, staged_grad: torch.Tensor, arena, local_scatter_add) -> None:
+    def push_grad(self, staged_grad: torch.Tensor, arena, local_scatter_add, owner_src=None) -> None:
         """arena.grad[owner rows] += staged_grad rows (duplicate requests were already summed into their
-        representative's staged row by the local scatter; without dedup they accumulate on the owner)."""
+        representative's staged row by the local scatter; without dedup they accumulate on the owner).  `owner_src`
+        (sparse.Source registered by the forward): the received rows become that lookup's gradient instead — summed per
+        row and applied by the shard's owner-computes optimizer launch."""
         K = staged_grad.shape[1]
         gsend = staged_grad.index_select(0, self.send_pos)
         grecv = torch.empty(sum(self.rc), K, dtype=staged_grad.dtype, device=staged_grad.device)
         self.sh.all_to_all(grecv, gsend, [c for c in self.rc], [c for c in self.sc])
-        local_scatter_add(arena, self.recv_local, grecv)
+        if owner_src is not None:
+            owner_src.set_grad(grecv)
+        else:
+            local_scatter_add(arena, self.recv_local, grecv)
 
 
 class StaticExchangePlan:
@@ -141,10 +146,13 @@ class StaticExchangePlan:
         self.sh.dist.all_to_all_single(back, rows_out, group=self.sh.group)
         return back
 
-    def push_grad(self, staged_grad: torch.Tensor, arena, local_scatter_add) -> None:
+    def push_grad(self, staged_grad: torch.Tensor, arena, local_scatter_add, owner_src=None) -> None:
         grecv = torch.empty_like(staged_grad)
         self.sh.dist.all_to_all_single(grecv, staged_grad, group=self.sh.group)
-        local_scatter_add(arena, self.recv_local, grecv)                         # id -1 is skipped
+        if owner_src is not None:
+            owner_src.set_grad(grecv)                                            # (see ExchangePlan.push_grad)
+        else:
+            local_scatter_add(arena, self.recv_local, grecv)                     # id -1 is skipped
 
 
 # ---- the two local kernels of the exchange (HIP; tests substitute CPU doubles) ------------------
@@ -191,7 +199,9 @@ def hip_dedup_rows(rows: torch.Tensor):
     return unique_rows, rep
 
 
-def hip_local_gather(shard_weight: torch.Tensor, local_rows: torch.Tensor) -> torch.Tensor:
+def hip_local_gather(shard_weight: torch.Tensor, local_rows: torch.Tensor, deferred=None, step_dev=None) -> torch.Tensor:
+    """Owner-side gather of the requested rows (id -1 -> zero row).  `deferred` / `step_dev` (sparse.deferred_view): rows
+    whose deferred-Adam state lags are read as of the current step."""
     import ctypes
     from . import _lib
     lib = _lib.load()
@@ -201,8 +211,8 @@ def hip_local_gather(shard_weight: torch.Tensor, local_rows: torch.Tensor) -> to
         zero = _zero(shard_weight.device)
         st = ctypes.c_void_p(torch.cuda.current_stream(shard_weight.device).cuda_stream)
         p = lambda t: ctypes.c_void_p(t.data_ptr())
-        _lib.check(lib.recalgo_embedding_gather_fwd(p(local_rows), p(shard_weight), p(zero), n, 1, K, p(out), K, 0, st),
-                   "recalgo_embedding_gather_fwd")
+        _lib.check(lib.recalgo_embedding_gather_fwd_deferred(p(local_rows), p(shard_weight), p(zero), n, 1, K, p(out), K, 0,
+                                                             deferred, step_dev, 0, st), "recalgo_embedding_gather_fwd")
     return out
 
 
@@ -258,11 +268,25 @@ class StagedArena:
     they scatter into `.grad` is pushed back to the owners by `flush_grad()` (called by the op's
     backward right after its kernel)."""
 
-    def __init__(self, plan: ExchangePlan, arena: EmbeddingArena):
+    def __init__(self, plan: ExchangePlan, arena: EmbeddingArena, store=None, training: bool = False):
         self.plan, self.arena, self.K = plan, arena, arena.K
         self.name = arena.name + "/staged"
         sd: Sharding = arena.sharding
-        self.weight = plan.fetch(arena.weight, sd.local_gather)
+        gather = sd.local_gather
+        # OWNER side on the owner-computes path (sparse.py): the rows the peers ask this rank for are one more lookup
+        # of the shard's request plan — [n, 1] local rows, -1 = unused bucket slot — caught up (deferred Adam) before the
+        # owner gather reads them; the gradient rows that come back in the backward become that lookup's gradient, summed
+        # per row in a fixed order and applied by the shard's optimizer launch (no float atomics on the owner either)
+        self.owner_src = None
+        if gather is hip_local_gather and store is not None:
+            from . import sparse
+            recv = plan.recv_local
+            if training:
+                self.owner_src = sparse.begin_lookup(arena, store, recv.reshape(-1, 1), None, None, 0, recv.numel(), 1, True)
+            dv, stp = sparse.view_for(self.owner_src, arena, store)
+            if dv is not None:                          # lagging rows are read as of the current step
+                gather = lambda w, rows, _dv=dv, _stp=stp: hip_local_gather(w, rows, _dv, _stp)
+        self.weight = plan.fetch(arena.weight, gather)
         self.tables = {"__staged__": (0, self.weight.shape[0])}
         self._grad: Optional[torch.Tensor] = None
 
@@ -287,10 +311,10 @@ class StagedArena:
                 side = _push_stream(dev)
                 side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):
-                    self.plan.push_grad(g, self.arena, sd.local_scatter_add)
+                    self.plan.push_grad(g, self.arena, sd.local_scatter_add, self.owner_src)
                 _push_pending.append((dev, g))          # keeps the staged gradient alive until the join
             else:
-                self.plan.push_grad(g, self.arena, sd.local_scatter_add)
+                self.plan.push_grad(g, self.arena, sd.local_scatter_add, self.owner_src)
 
 
 _push_streams = {}
@@ -351,6 +375,9 @@ def unshard_arena(arena: EmbeddingArena, what: str = "weight") -> torch.Tensor:
     """all_gather the shards back into the [global_rows, K] tensor (tests, checkpoints)."""
     sd: Sharding = arena.sharding
     sh = sd.sh
+    if what in ("weight", "m", "v"):
+        from . import sparse
+        sparse.sync_arena(arena)             # deferred Adam: every row reflects all completed optimizer steps
     local = getattr(arena, what)
     n_max = (sd.global_rows + sh.world - 1) // sh.world
     pad = torch.zeros(n_max, local.shape[1], dtype=local.dtype, device=local.device)
@@ -373,6 +400,9 @@ def gather_arena_to_host(arena: EmbeddingArena, what: str = "weight", dst_rank: 
     all_gather of whole padded shards (unshard_arena) needs ~2x the table per GPU and the same again per rank on the host."""
     sd: Sharding = arena.sharding
     sh = sd.sh
+    if what in ("weight", "m", "v"):
+        from . import sparse
+        sparse.sync_arena(arena)             # deferred Adam: every row reflects all completed optimizer steps
     local = getattr(arena, what)
     K = local.shape[1]
     n_max = (sd.global_rows + sh.world - 1) // sh.world

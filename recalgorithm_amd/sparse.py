@@ -151,6 +151,7 @@ class ArenaPlan:
         self.lr_ring: Optional[torch.Tensor] = None
         self.betas = (0.9, 0.999, 1e-8)
         self.grad_materialized = False
+        self.step_dev: Optional[torch.Tensor] = None      # the optimizer's device step counter (sync_arena)
         self.companions: List[CompanionSource] = []       # this arena is the SECOND arena of these lookups (this step)
         self.served = False                    # ... and the main arena's optimizer call has already applied them
 
@@ -188,8 +189,6 @@ def _supported(arena) -> bool:
     from .variables import EmbeddingArena
     if type(arena) is not EmbeddingArena or arena.weight is None or not arena.weight.is_cuda:
         return False
-    if getattr(arena, "sharding", None) is not None:
-        return False                           # row-sharded arenas keep the round-2 owner-side scatter (parallel.py)
     K = arena.K
     return arena.weight.shape[0] < (1 << 31) and ((K % 4 == 0 and K // 4 <= 64) or K <= 64)
 
@@ -452,6 +451,7 @@ def _init_deferred(plan: ArenaPlan, step_dev: torch.Tensor) -> None:
 def apply(arena, lazy: bool, step_dev: torch.Tensor, lr: float, beta1: float, beta2: float, eps: float) -> None:
     """The optimizer step of one arena (step_dev already advanced to this step)."""
     plan = plan_of(arena)
+    plan.step_dev = step_dev
     if plan.companions:
         raise RuntimeError(f"arena {getattr(arena, 'name', '?')}: its lookups ride on another arena's plan, whose optimizer call "
                            "has not run yet (apply arenas with sparse.has_companions() last)")
@@ -510,6 +510,13 @@ def sync(arena, step_dev: Optional[torch.Tensor], step_offset: int = 0) -> None:
     _lib.check(_lib.load().recalgo_adam_deferred_sweep(ctypes.byref(d), arena.K, 0, arena.weight.shape[0],
                                                       ctypes.c_void_p(step_dev.data_ptr()), step_offset, _stream(arena.weight)),
                "recalgo_adam_deferred_sweep")
+
+
+def sync_arena(arena) -> None:
+    """sync() with the step counter the arena's last optimizer call used (callers that have no store at hand)."""
+    plan = plan_of(arena)
+    if plan is not None and plan.last_step is not None and plan.step_dev is not None:
+        sync(arena, plan.step_dev, 0)
 
 
 def sync_store(store) -> None:

@@ -99,6 +99,10 @@ def test_sharded_single_rank_equals_plain(dev, pg, model):
         l0 = ref.train_step(feats, labels)
         l1 = shd.train_step(feats, labels)
         assert_close(l1, l0, what=f"{model} loss step {step}")
+    # the OWNER side of the exchange ran on the owner-computes path: the shard has deferred-Adam state, no live-row list
+    from recalgorithm_amd import sparse
+    for a in shd.store.arenas.values():
+        assert sparse.plan_of(a) is not None and sparse.plan_of(a).last_step is not None and a.live is None
     a0, a1 = ref.store.named_arrays(), shd.store.named_arrays(gather=True)       # (tables of a sharded arena: collective gather)
     for k in a0:
         if "embedding_weights" in k or "kernel/" in k:
