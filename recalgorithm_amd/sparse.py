@@ -12,7 +12,8 @@ atomics, fused with the sparse optimizer) and the deferred-exact TF1 Adam state.
     tables                                            (named_arrays, checkpoints, export)
     tests / tools         materialize_grads(store)    the summed row gradients written to arena.grad (GRAD mode)
 
-RECALGO_SPARSE=owner (default) selects this path for local (not row-sharded) arenas; `atomic` / `sorted` keep the
+RECALGO_SPARSE=owner (default) selects this path — for local arenas, and for the OWNER side of a row-sharded arena's
+exchange (parallel.StagedArena: the rows the peers request are a lookup of the shard's plan); `atomic` / `sorted` keep the
 round-2 kernels (LDS-aggregated float atomics / torch.sort + ordered segment sums) with the live-row-list optimizer.
 """
 from __future__ import annotations
