@@ -404,6 +404,23 @@ int recalgo_batchnorm_train_fwd(const float* x, const float* gamma, const float*
 int recalgo_batchnorm_train_bwd(const float* x, const float* gamma, const float* save_mean,
                                 const float* save_rstd, const float* g, int rows, int C, float* dx,
                                 float* dgamma, float* dbeta, void* workspace, recalgo_stream_t stream);
+/* Sync-BatchNorm building blocks (data parallel, N > 1, `sync_batch_norm`): the two launches of each direction as separate
+ * entry points, so that the per-tile partials of all ranks — [recalgo_batchnorm_partial_rows(rows)][2][C] floats per rank:
+ * (tile mean | tile M2) forward, (colsum g | colsum g * xhat) backward — can be all-gathered rank-major in between.
+ * `partials` of _apply / _bwd_apply: [world][partial_rows][2][C]; every rank holds `rows` examples; the statistics are those
+ * of the world * rows examples (== tf.layers.batch_normalization on the concatenated batch, bit-identical to the one-rank
+ * kernels on it when rows % 64 == 0).  _bwd_apply: dx uses the sums over all ranks, dgamma / dbeta receive THIS rank's
+ * share (the data-parallel all-reduce of the dense gradients adds the ranks up).  world = 1 == the fused entry points. */
+int recalgo_batchnorm_partial_rows(int rows);
+int recalgo_batchnorm_moments(const float* x, int rows, int C, float* partials, recalgo_stream_t stream);
+int recalgo_batchnorm_apply(const float* x, const float* gamma, const float* beta, const float* partials, int world, int rows,
+                            int C, float eps, float momentum, float* moving_mean, float* moving_var, float* y,
+                            float* save_mean, float* save_rstd, recalgo_stream_t stream);
+int recalgo_batchnorm_bwd_sums(const float* x, const float* save_mean, const float* save_rstd, const float* g, int rows, int C,
+                               float* partials, recalgo_stream_t stream);
+int recalgo_batchnorm_bwd_apply(const float* x, const float* gamma, const float* save_mean, const float* save_rstd,
+                                const float* g, const float* partials, int world, int rank, int rows, int C, float* dx,
+                                float* dgamma, float* dbeta, recalgo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sibling models on the same kernels: their remaining interaction steps.

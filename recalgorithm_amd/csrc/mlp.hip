@@ -113,18 +113,21 @@ __global__ __launch_bounds__(kThreads) void bn_moments_kernel(const float4* __re
 // the workgroups of tile row 0 record mean / rstd for the backward pass and update the moving statistics.
 __global__ __launch_bounds__(kThreads) void bn_finalize_apply_kernel(
     const float4* __restrict__ x, const float4* __restrict__ gamma, const float4* __restrict__ beta,
-    const float4* __restrict__ partials, unsigned nblk, unsigned rows, unsigned C4, float eps, float momentum,
-    float4* __restrict__ moving_mean, float4* __restrict__ moving_var, float4* __restrict__ save_mean,
+    const float4* __restrict__ partials, unsigned nblk, unsigned nblk_local, unsigned rows, unsigned C4, float eps,
+    float momentum, float4* __restrict__ moving_mean, float4* __restrict__ moving_var, float4* __restrict__ save_mean,
     float4* __restrict__ save_rstd, float4* __restrict__ y) {
+    // nblk = world * nblk_local partial rows (Sync-BatchNorm: the tiles of all ranks, rank major; every rank holds `rows`
+    // examples); world = 1: nblk == nblk_local
     __shared__ float4 sh[16][17];
     const unsigned cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const unsigned c4 = blockIdx.x * 16 + cl;
     const bool ok = c4 < C4;
-    const float inv_rows = 1.0f / (float)rows;
+    const float inv_rows = 1.0f / ((float)rows * (float)(nblk / nblk_local));
     float4 acc = f4_zero();
     if (ok)
         for (unsigned b = rl; b < nblk; b += 16) {
-            const float nb = (float)(min(rows, (b + 1) * kTileRows) - b * kTileRows);
+            const unsigned bl = b % nblk_local;
+            const float nb = (float)(min(rows, (bl + 1) * kTileRows) - bl * kTileRows);
             acc = f4_fma(partials[(size_t)b * 2 * C4 + c4], nb, acc);
         }
     sh[rl][cl] = acc;
@@ -137,7 +140,8 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_apply_kernel(
     acc = f4_zero();
     if (ok)
         for (unsigned b = rl; b < nblk; b += 16) {
-            const float nb = (float)(min(rows, (b + 1) * kTileRows) - b * kTileRows);
+            const unsigned bl = b % nblk_local;
+            const float nb = (float)(min(rows, (bl + 1) * kTileRows) - bl * kTileRows);
             const float4 d = f4_sub(partials[(size_t)b * 2 * C4 + c4], mean);
             acc = f4_add(acc, f4_fma(f4_mul(d, d), nb, partials[(size_t)b * 2 * C4 + C4 + c4]));
         }
@@ -209,8 +213,10 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float4* _
 __global__ __launch_bounds__(kThreads) void bn_bwd_sum_apply_kernel(
     const float4* __restrict__ x, const float4* __restrict__ g, const float4* __restrict__ gamma,
     const float4* __restrict__ mean, const float4* __restrict__ rstd, const float4* __restrict__ partials,
-    unsigned nblk, unsigned rows, unsigned C4, float4* __restrict__ dbeta, float4* __restrict__ dgamma,
-    float4* __restrict__ dx) {
+    unsigned nblk, unsigned nblk_local, unsigned rank, unsigned rows, unsigned C4, float4* __restrict__ dbeta,
+    float4* __restrict__ dgamma, float4* __restrict__ dx) {
+    // nblk = world * nblk_local partial rows (see bn_finalize_apply_kernel).  dx uses the sums over ALL ranks' tiles;
+    // dbeta / dgamma get THIS rank's share (the data-parallel all-reduce of the dense gradients adds the ranks up)
     __shared__ float4 sh[2][16][17];
     const unsigned cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const unsigned c4 = blockIdx.x * 16 + cl;
@@ -224,18 +230,41 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_sum_apply_kernel(
     sh[0][rl][cl] = sb;
     sh[1][rl][cl] = sg;
     __syncthreads();
-    if (!ok) return;
     float4 db = sh[0][0][cl], dg = sh[1][0][cl];
 #pragma unroll
     for (int q = 1; q < 16; ++q) {
         db = f4_add(db, sh[0][q][cl]);
         dg = f4_add(dg, sh[1][q][cl]);
     }
-    if (blockIdx.y == 0 && rl == 0) {
-        dbeta[c4] = db;
-        dgamma[c4] = dg;
+    if (nblk == nblk_local) {
+        if (ok && blockIdx.y == 0 && rl == 0) {
+            dbeta[c4] = db;
+            dgamma[c4] = dg;
+        }
+    } else if (blockIdx.y == 0) {                              // (uniform over the workgroup)
+        __syncthreads();
+        float4 lb = f4_zero(), lg = f4_zero();
+        if (ok)
+            for (unsigned b = rank * nblk_local + rl; b < (rank + 1) * nblk_local; b += 16) {
+                lb = f4_add(lb, partials[(size_t)b * 2 * C4 + c4]);
+                lg = f4_add(lg, partials[(size_t)b * 2 * C4 + C4 + c4]);
+            }
+        sh[0][rl][cl] = lb;
+        sh[1][rl][cl] = lg;
+        __syncthreads();
+        if (ok && rl == 0) {
+            float4 tb = sh[0][0][cl], tg = sh[1][0][cl];
+#pragma unroll
+            for (int q = 1; q < 16; ++q) {
+                tb = f4_add(tb, sh[0][q][cl]);
+                tg = f4_add(tg, sh[1][q][cl]);
+            }
+            dbeta[c4] = tb;
+            dgamma[c4] = tg;
+        }
     }
-    const float inv_rows = 1.0f / (float)rows;
+    if (!ok) return;
+    const float inv_rows = 1.0f / ((float)rows * (float)(nblk / nblk_local));
     const float4 mu = mean[c4], rs4 = rstd[c4];
     const float4 k = f4_mul(gamma[c4], rs4);
     const unsigned r0 = blockIdx.y * kTileRows;
@@ -551,7 +580,7 @@ RECALGO_EXPORT int recalgo_batchnorm_train_fwd(const float* x, const float* gamm
     hipLaunchKernelGGL(bn_finalize_apply_kernel, dim3(cdiv(C4, 16), nb), dim3(kThreads), 0, st,
                        reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(gamma),
                        reinterpret_cast<const float4*>(beta), reinterpret_cast<const float4*>(partials), (unsigned)nb,
-                       (unsigned)rows, C4, eps, momentum, reinterpret_cast<float4*>(moving_mean),
+                       (unsigned)nb, (unsigned)rows, C4, eps, momentum, reinterpret_cast<float4*>(moving_mean),
                        reinterpret_cast<float4*>(moving_var), reinterpret_cast<float4*>(save_mean),
                        reinterpret_cast<float4*>(save_rstd), reinterpret_cast<float4*>(y));
     RECALGO_RETURN_LAST();
@@ -575,8 +604,64 @@ RECALGO_EXPORT int recalgo_batchnorm_train_bwd(const float* x, const float* gamm
                        reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(g),
                        reinterpret_cast<const float4*>(gamma), reinterpret_cast<const float4*>(save_mean),
                        reinterpret_cast<const float4*>(save_rstd), reinterpret_cast<const float4*>(partials), (unsigned)nb,
-                       (unsigned)rows, C4, reinterpret_cast<float4*>(dbeta), reinterpret_cast<float4*>(dgamma),
+                       (unsigned)nb, 0u, (unsigned)rows, C4, reinterpret_cast<float4*>(dbeta), reinterpret_cast<float4*>(dgamma),
                        reinterpret_cast<float4*>(dx));
+    RECALGO_RETURN_LAST();
+}
+
+// ---- Sync-BatchNorm building blocks: the two launches of each direction as separate entry points, so that the per-tile
+// partials of all ranks can be all-gathered in between (include/recalgo.h) ---------------------------------------------
+RECALGO_EXPORT int recalgo_batchnorm_partial_rows(int rows) { return rows > 0 ? nblk_of(rows) : 0; }
+
+RECALGO_EXPORT int recalgo_batchnorm_moments(const float* x, int rows, int C, float* partials, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(rows > 0 && width_ok(C) && x && partials);
+    const unsigned C4 = C / 4;
+    hipLaunchKernelGGL(bn_moments_kernel, dim3(cdiv(C4, 16), nblk_of(rows)), dim3(kThreads), 0, as_stream(stream),
+                       reinterpret_cast<const float4*>(x), (unsigned)rows, C4, reinterpret_cast<float4*>(partials));
+    RECALGO_RETURN_LAST();
+}
+
+RECALGO_EXPORT int recalgo_batchnorm_apply(const float* x, const float* gamma, const float* beta, const float* partials,
+                                           int world, int rows, int C, float eps, float momentum, float* moving_mean,
+                                           float* moving_var, float* y, float* save_mean, float* save_rstd,
+                                           recalgo_stream_t stream) {
+    RECALGO_REQUIRE(rows > 0 && world >= 1 && width_ok(C) && x && gamma && beta && partials && y && save_mean && save_rstd);
+    RECALGO_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr));
+    const int nb = nblk_of(rows);
+    const unsigned C4 = C / 4;
+    hipLaunchKernelGGL(bn_finalize_apply_kernel, dim3(cdiv(C4, 16), nb), dim3(kThreads), 0, as_stream(stream),
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(gamma),
+                       reinterpret_cast<const float4*>(beta), reinterpret_cast<const float4*>(partials),
+                       (unsigned)(nb * world), (unsigned)nb, (unsigned)rows, C4, eps, momentum,
+                       reinterpret_cast<float4*>(moving_mean), reinterpret_cast<float4*>(moving_var),
+                       reinterpret_cast<float4*>(save_mean), reinterpret_cast<float4*>(save_rstd), reinterpret_cast<float4*>(y));
+    RECALGO_RETURN_LAST();
+}
+
+RECALGO_EXPORT int recalgo_batchnorm_bwd_sums(const float* x, const float* save_mean, const float* save_rstd, const float* g,
+                                              int rows, int C, float* partials, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(rows > 0 && width_ok(C) && x && save_mean && save_rstd && g && partials);
+    const unsigned C4 = C / 4;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C4, 16), nblk_of(rows)), dim3(kThreads), 0, as_stream(stream),
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(g),
+                       reinterpret_cast<const float4*>(save_mean), reinterpret_cast<const float4*>(save_rstd), (unsigned)rows, C4,
+                       reinterpret_cast<float4*>(partials));
+    RECALGO_RETURN_LAST();
+}
+
+RECALGO_EXPORT int recalgo_batchnorm_bwd_apply(const float* x, const float* gamma, const float* save_mean, const float* save_rstd,
+                                               const float* g, const float* partials, int world, int rank, int rows, int C,
+                                               float* dx, float* dgamma, float* dbeta, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(rows > 0 && world >= 1 && rank >= 0 && rank < world && width_ok(C));
+    RECALGO_REQUIRE(x && gamma && save_mean && save_rstd && g && partials && dx && dgamma && dbeta);
+    const int nb = nblk_of(rows);
+    const unsigned C4 = C / 4;
+    hipLaunchKernelGGL(bn_bwd_sum_apply_kernel, dim3(cdiv(C4, 16), nb), dim3(kThreads), 0, as_stream(stream),
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(g),
+                       reinterpret_cast<const float4*>(gamma), reinterpret_cast<const float4*>(save_mean),
+                       reinterpret_cast<const float4*>(save_rstd), reinterpret_cast<const float4*>(partials),
+                       (unsigned)(nb * world), (unsigned)nb, (unsigned)rank, (unsigned)rows, C4,
+                       reinterpret_cast<float4*>(dbeta), reinterpret_cast<float4*>(dgamma), reinterpret_cast<float4*>(dx));
     RECALGO_RETURN_LAST();
 }
 

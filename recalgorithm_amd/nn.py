@@ -289,9 +289,16 @@ class _BatchNormTrainFn(Function):
                 momentum: float, eps: float):
         ctx.vars = (gamma, beta)
         ctx.hip = x.dim() == 2 and x.is_contiguous() and _hip(x, x.shape[1])
+        # Sync-BatchNorm (parallel.attach_data_parallel(sync_batch_norm=True)): statistics over the GLOBAL batch
+        ctx.sync = getattr(getattr(anchor, "_recalgo_store", None), "sync_bn", None)
+        if ctx.sync is not None and not ctx.hip:
+            raise NotImplementedError("sync_batch_norm needs the HIP BatchNorm kernels (2-D contiguous input, C % 4 == 0)")
         if ctx.hip:
             from . import ops
-            y, mean, rstd = ops.batchnorm_train_fwd(x, gamma.data, beta.data, mmean.data, mvar.data, momentum, eps)
+            if ctx.sync is not None:
+                y, mean, rstd = ops.batchnorm_sync_fwd(x, gamma.data, beta.data, mmean.data, mvar.data, momentum, eps, ctx.sync)
+            else:
+                y, mean, rstd = ops.batchnorm_train_fwd(x, gamma.data, beta.data, mmean.data, mvar.data, momentum, eps)
             ctx.save_for_backward(x, mean, rstd)
             return y
         mean = x.mean(dim=0)
@@ -312,7 +319,10 @@ class _BatchNormTrainFn(Function):
         if ctx.hip:
             from . import ops
             x, mean, rstd = ctx.saved_tensors
-            dx = ops.batchnorm_train_bwd(x, gamma.data, mean, rstd, g.contiguous(), gamma.grad, beta.grad)
+            if ctx.sync is not None:
+                dx = ops.batchnorm_sync_bwd(x, gamma.data, mean, rstd, g.contiguous(), gamma.grad, beta.grad, ctx.sync)
+            else:
+                dx = ops.batchnorm_train_bwd(x, gamma.data, mean, rstd, g.contiguous(), gamma.grad, beta.grad)
             return None, dx, None, None, None, None, None, None
         xhat, rstd = ctx.saved_tensors
         B = g.shape[0]

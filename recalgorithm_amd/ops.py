@@ -1167,6 +1167,42 @@ def batchnorm_train_fwd(x, gamma, beta, moving_mean, moving_var, momentum: float
     return y, mean, rstd
 
 
+def batchnorm_sync_fwd(x, gamma, beta, moving_mean, moving_var, momentum: float, eps: float, sync):
+    """Sync-BatchNorm forward (include/recalgo.h "Sync-BatchNorm building blocks"): per-tile moments -> all_gather of the
+    partial rows over the data-parallel group -> merge + apply.  sync = (world, rank, all_gather(out [world, n], in [n]))."""
+    world, _, all_gather = sync
+    rows, C = x.shape
+    lib = _lib_()
+    nb = int(lib.recalgo_batchnorm_partial_rows(rows))
+    local = torch.empty(nb * 2 * C, device=x.device, dtype=torch.float32)
+    _lib.check(lib.recalgo_batchnorm_moments(_p(x), rows, C, _p(local), _stream(x)), "recalgo_batchnorm_moments")
+    parts = torch.empty(world, nb * 2 * C, device=x.device, dtype=torch.float32)
+    all_gather(parts, local)
+    y = torch.empty_like(x)
+    mean = torch.empty(C, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(C, device=x.device, dtype=torch.float32)
+    _lib.check(lib.recalgo_batchnorm_apply(_p(x), _p(gamma), _p(beta), _p(parts), world, rows, C, eps, momentum,
+                                           _p(moving_mean), _p(moving_var), _p(y), _p(mean), _p(rstd), _stream(x)),
+               "recalgo_batchnorm_apply")
+    return y, mean, rstd
+
+
+def batchnorm_sync_bwd(x, gamma, mean, rstd, g, dgamma, dbeta, sync) -> torch.Tensor:
+    world, rank, all_gather = sync
+    rows, C = x.shape
+    lib = _lib_()
+    nb = int(lib.recalgo_batchnorm_partial_rows(rows))
+    local = torch.empty(nb * 2 * C, device=x.device, dtype=torch.float32)
+    _lib.check(lib.recalgo_batchnorm_bwd_sums(_p(x), _p(mean), _p(rstd), _p(g), rows, C, _p(local), _stream(x)),
+               "recalgo_batchnorm_bwd_sums")
+    parts = torch.empty(world, nb * 2 * C, device=x.device, dtype=torch.float32)
+    all_gather(parts, local)
+    dx = torch.empty_like(x)
+    _lib.check(lib.recalgo_batchnorm_bwd_apply(_p(x), _p(gamma), _p(mean), _p(rstd), _p(g), _p(parts), world, rank, rows, C,
+                                               _p(dx), _p(dgamma), _p(dbeta), _stream(x)), "recalgo_batchnorm_bwd_apply")
+    return dx
+
+
 def batchnorm_train_bwd(x, gamma, mean, rstd, g, dgamma, dbeta) -> torch.Tensor:
     rows, C = x.shape
     lib = _lib_()

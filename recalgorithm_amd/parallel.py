@@ -441,17 +441,28 @@ class _ShardAtBuild:
 
 def attach_data_parallel(est, dist=None, group=None, local_gather=hip_local_gather,
                          local_scatter_add=hip_local_scatter_add, capacity_factor: Optional[float] = 1.5,
-                         planner=hip_exchange_plan, dedup=hip_dedup_rows):
+                         planner=hip_exchange_plan, dedup=hip_dedup_rows, sync_batch_norm: bool = False):
     """Make an Estimator one rank of an N-rank job: shard every embedding arena row-wise, all-reduce the flat dense
     gradient before the optimizer, scale the loss gradient by 1/N.  Call it BEFORE the first build / train call:
     the arenas are then created sharded (no rank ever holds a whole table).  Called on an already built Estimator
     it re-shards the replicated arenas in place (every rank must have built them from the same seed).
     `capacity_factor` selects the static (graph-capturable) exchange — buckets of capacity_factor x the mean number
-    of DISTINCT-row requests per owner; None = exact dynamic buckets.  `dedup` = None sends every request."""
+    of DISTINCT-row requests per owner; None = exact dynamic buckets.  `dedup` = None sends every request.
+    `sync_batch_norm`: training-mode BatchNorm normalises with the statistics of the GLOBAL batch (the per-tile moment
+    partials of all ranks are all-gathered between the two BatchNorm launches, forward and backward) — N ranks then equal
+    the reference's single-device BatchNorm on the concatenated batch; the default keeps per-replica statistics."""
     if dist is None:
         import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     sh = ShardSpec(rank, world, group, dist)
+    if sync_batch_norm and world > 1:
+        def _all_gather(out: torch.Tensor, inp: torch.Tensor):          # out [world, n] <- inp [n] of every rank
+            if hasattr(dist, "all_gather_into_tensor"):
+                dist.all_gather_into_tensor(out.view(-1), inp, group=group)
+            else:
+                parts = [out[r] for r in range(world)]
+                dist.all_gather(parts, inp, group=group)
+        est.store.sync_bn = (world, rank, _all_gather)
     kw = dict(local_gather=local_gather, local_scatter_add=local_scatter_add, capacity_factor=capacity_factor,
               planner=planner, dedup=dedup)
 
