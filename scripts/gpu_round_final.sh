@@ -20,6 +20,7 @@ bash scripts/gpu_pmc_bench.sh $TAG dcn 64 > $O/${TAG}_pmc_fullrun.log 2>&1
 bash scripts/gpu_pmc_sq.sh $TAG dcn SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE > $O/${TAG}_pmc_sq.log 2>&1
 timeout 400 python bench.py --model deepfm --big-table-rows 100000000 --no-cpu-baseline --sweep-batches 0 > $O/bench_${TAG}_deepfm_100M.json 2> $O/bench_${TAG}_deepfm_100M.err
 timeout 300 python scripts/bench_tfrecord.py > $O/bench_${TAG}_tfrecord_e2e.json 2> $O/bench_${TAG}_tfrecord_e2e.err
+RECALGO_READER_THREADS=32 timeout 300 python scripts/bench_tfrecord.py > $O/bench_${TAG}_tfrecord_e2e_32threads.json 2> $O/bench_${TAG}_tfrecord_e2e_32threads.err
 tail -3 $O/${TAG}_pytest_gpu.log; tail -2 $O/${TAG}_smoke.log
 for f in $O/bench_${TAG}_*.json; do python - "$f" <<'PY'
 import json, sys
