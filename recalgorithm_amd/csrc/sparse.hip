@@ -233,6 +233,29 @@ __device__ __forceinline__ void catch_up_row_scalar(const Deferred& D, long long
     if (lane == 0) D.last_step[row] = target;
 }
 
+// The sweep's unit of work: one group of L1 lanes walks R CONSECUTIVE rows — last_step first (four loads in flight), the
+// replay only for rows that lag.  R = 1 for tables of the benchmark's size (most parallel slack for the replay chains);
+// for 100 M-row tables, where nearly every row of a chunk is untouched, R = 32 cuts the launch from 200 k workgroups
+// (dispatch-bound: ~90 us per step) to 6 k.
+__device__ __forceinline__ void sweep_rows(const Deferred& D, long long row0, long long end, unsigned R, int target, unsigned lane,
+                                           unsigned K) {
+    for (unsigned r0 = 0; r0 < R; r0 += 4) {
+        int sv[4];
+#pragma unroll
+        for (unsigned u = 0; u < 4; ++u) {
+            const long long row = row0 + r0 + u;
+            sv[u] = (r0 + u < R && row < end) ? D.last_step[row] : 0;
+        }
+#pragma unroll
+        for (unsigned u = 0; u < 4; ++u)
+            if (sv[u] > 0 && sv[u] < target) catch_up_row_scalar(D, row0 + r0 + u, sv[u], target, lane, K);
+    }
+}
+inline unsigned sweep_rows_per_group(long long rows_in_launch) {
+    const long long r = rows_in_launch / 65536;
+    return (unsigned)(r < 1 ? 1 : (r > 32 ? 32 : r));
+}
+
 // 256-thread exclusive scan of one value per thread; sh: 8 unsigned of LDS; returns the exclusive prefix, total in `total`
 __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned* sh, unsigned& total) {
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -377,10 +400,11 @@ struct ScanArgs {
     unsigned KV, L, L1;
     long long rows, chunk;
     int period;
+    unsigned R;                    // consecutive rows per group of L1 lanes (sweep_rows)
     // the companion arena's share of the sweep (one float per row): workgroups from comp_first on
     Deferred D1;
     long long rows1, chunk1;
-    unsigned comp_first;
+    unsigned comp_first, R1;
 };
 
 template <int VEC>
@@ -389,10 +413,8 @@ __global__ __launch_bounds__(kThreads) void sparse_scan_kernel(ScanArgs A) {
         const int target = (int)(A.step[0] + A.step_off);
         if (target <= 0) return;
         const long long c0 = (long long)(target % A.period) * A.chunk1;
-        const long long row = c0 + (long long)(blockIdx.x - A.comp_first) * kThreads + threadIdx.x;
-        if (row >= A.rows1 || row >= c0 + A.chunk1) return;
-        const int s = A.D1.last_step[row];
-        if (s > 0 && s < target) catch_up_row_scalar(A.D1, row, s, target, 0, 1);
+        const long long row0 = c0 + ((long long)(blockIdx.x - A.comp_first) * kThreads + threadIdx.x) * A.R1;
+        sweep_rows(A.D1, row0, min(A.rows1, c0 + A.chunk1), A.R1, target, 0, 1);
         return;
     }
     if (blockIdx.x >= A.scan_blocks) {                        // ---- sweep workgroups -------------------------------
@@ -400,11 +422,8 @@ __global__ __launch_bounds__(kThreads) void sparse_scan_kernel(ScanArgs A) {
         if (target <= 0) return;
         const long long c0 = (long long)(target % A.period) * A.chunk;
         const unsigned idx = (blockIdx.x - A.scan_blocks) * kThreads + threadIdx.x;
-        const long long row = c0 + idx / A.L1;
-        const unsigned lane = idx & (A.L1 - 1);
-        if (row >= A.rows || row >= c0 + A.chunk) return;
-        const int s = A.D.last_step[row];
-        if (s > 0 && s < target) catch_up_row_scalar(A.D, row, s, target, lane, A.KV * VEC);
+        const long long row0 = c0 + (long long)(idx / A.L1) * A.R;
+        sweep_rows(A.D, row0, min(A.rows, c0 + A.chunk), A.R, target, idx & (A.L1 - 1), A.KV * VEC);
         return;
     }
     if (blockIdx.x == 0 && threadIdx.x < 16 && A.stale_n) A.stale_n[threadIdx.x] = 0;   // the step's catch-up lists are consumed
@@ -1101,21 +1120,16 @@ struct SweepArgs {
     Deferred D;
     const long long* step;
     int step_off;
-    unsigned KV, L, L1;
+    unsigned KV, L, L1, R;
     long long row0, row1;
-    int period; long long chunk;   // period > 0: the round-robin chunk of the target step, rows [c * chunk, (c + 1) * chunk) below row1
 };
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void sparse_sweep_kernel(SweepArgs A) {
     const int target = (int)(A.step[0] + A.step_off);
     if (target <= 0) return;
     const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
-    const long long c0 = A.period > 0 ? (long long)(target % A.period) * A.chunk : A.row0;
-    const long long row = c0 + idx / A.L1;
-    const unsigned lane = (unsigned)(idx & (A.L1 - 1));
-    if (row >= A.row1 || (A.period > 0 && row >= c0 + A.chunk)) return;
-    const int s = A.D.last_step[row];
-    if (s > 0 && s < target) catch_up_row_scalar(A.D, row, s, target, lane, A.KV * VEC);
+    const long long row0 = A.row0 + (idx / A.L1) * A.R;
+    sweep_rows(A.D, row0, A.row1, A.R, target, (unsigned)(idx & (A.L1 - 1)), A.KV * VEC);
 }
 
 // ---- host helpers -----------------------------------------------------------------------------
@@ -1306,12 +1320,14 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
         S.rows = rows;
         S.period = sweep_period < 1 ? 1 : sweep_period;
         S.chunk = (rows + S.period - 1) / S.period;
-        const unsigned sweep_blocks = S.D.last_step ? (unsigned)cdiv(S.chunk * G.L1, kThreads) : 0u;
+        S.R = sweep_rows_per_group(S.chunk);
+        const unsigned sweep_blocks = S.D.last_step ? (unsigned)cdiv(cdiv(S.chunk, (long long)S.R) * G.L1, kThreads) : 0u;
         S.D1 = (companion && mode == RECALGO_SCATTER_ADAM) ? deferred_of(companion->deferred) : deferred_of(nullptr);
         S.rows1 = companion ? companion->rows : 0;
         S.chunk1 = (S.rows1 + S.period - 1) / S.period;
         S.comp_first = S.scan_blocks + sweep_blocks;
-        const unsigned comp_blocks = S.D1.last_step ? (unsigned)cdiv(S.chunk1, kThreads) : 0u;
+        S.R1 = sweep_rows_per_group(S.chunk1);
+        const unsigned comp_blocks = S.D1.last_step ? (unsigned)cdiv(cdiv(S.chunk1, (long long)S.R1), kThreads) : 0u;
         if (G.vec == 4)
             hipLaunchKernelGGL(sparse_scan_kernel<4>, dim3(S.comp_first + comp_blocks), dim3(kThreads), 0, st, S);
         else
@@ -1396,8 +1412,8 @@ RECALGO_EXPORT int recalgo_adam_deferred_sweep(const recalgo_deferred_adam_t* de
     A.step_off = step_offset;
     A.KV = G.KV; A.L = G.L; A.L1 = G.L1;
     A.row0 = row_begin; A.row1 = row_end;
-    A.period = 0; A.chunk = 0;
-    const int64_t threads = (row_end - row_begin) * G.L1;
+    A.R = sweep_rows_per_group(row_end - row_begin);
+    const int64_t threads = cdiv(row_end - row_begin, (int64_t)A.R) * G.L1;
     const dim3 grid((unsigned)((threads + kThreads - 1) / kThreads));
     if (G.vec == 4)
         hipLaunchKernelGGL(sparse_sweep_kernel<4>, grid, dim3(kThreads), 0, as_stream(stream), A);

@@ -336,27 +336,44 @@ class GraphedTrainStep:
         allocation with the same layout on both sides (the 26 id columns of one [B, F] matrix)
         are moved by a single whole-allocation copy."""
         new = list(_tree_tensors(features, "f")) + list(_tree_tensors(labels, "l"))
+        if len(new) != len(self._static):
+            raise ValueError("graphed step: the input structure changed")
+        spans = self._static_spans()
         groups = {}
-        for (k0, dst), (k1, src) in zip(self._static, new):
+        for i, ((k0, dst), (k1, src)) in enumerate(zip(self._static, new)):
             if k0 != k1 or dst.shape != src.shape:
                 raise ValueError(f"graphed step: input {k1} changed shape/structure")
             if dst.dtype == src.dtype and dst.stride() == src.stride() and src.device == dst.device:
-                groups.setdefault((dst.untyped_storage().data_ptr(), src.untyped_storage().data_ptr()), []).append((dst, src))
+                # (same shape, strides and dtype: the source covers a byte span of the same length as the destination's)
+                groups.setdefault((spans[i][0], src.untyped_storage().data_ptr()), []).append((i, src.storage_offset() * spans[i][3]))
             else:
                 dst.copy_(src, non_blocking=True)
-        for pairs in groups.values():
+        for items in groups.values():
             # views of one allocation on both sides with the same relative layout: ONE copy of the byte span they cover
-            d_lo = min(_byte_span(d)[0] for d, _ in pairs); d_hi = max(_byte_span(d)[1] for d, _ in pairs)
-            s_lo = min(_byte_span(s_)[0] for _, s_ in pairs); s_hi = max(_byte_span(s_)[1] for _, s_ in pairs)
-            same = d_hi - d_lo == s_hi - s_lo and all(_byte_span(d)[0] - d_lo == _byte_span(s_)[0] - s_lo for d, s_ in pairs)
-            if len(pairs) > 1 and same and d_hi > d_lo:
-                d0, s0 = pairs[0]
-                dv = torch.empty(0, dtype=torch.uint8, device=d0.device).set_(d0.untyped_storage(), d_lo, (d_hi - d_lo,), (1,))
-                sv = torch.empty(0, dtype=torch.uint8, device=s0.device).set_(s0.untyped_storage(), s_lo, (s_hi - s_lo,), (1,))
-                dv.copy_(sv, non_blocking=True)
-            else:
-                for d, s_ in pairs:
-                    d.copy_(s_, non_blocking=True)
+            if len(items) > 1:
+                d_lo = min(spans[i][1] for i, _ in items)
+                d_hi = max(spans[i][2] for i, _ in items)
+                s_lo = min(lo for _, lo in items)
+                if d_hi > d_lo and all(spans[i][1] - d_lo == lo - s_lo for i, lo in items):
+                    d0, s0 = self._static[items[0][0]][1], new[items[0][0]][1]
+                    dv = self._dst_views.get((spans[items[0][0]][0], d_lo, d_hi))
+                    if dv is None:
+                        dv = torch.empty(0, dtype=torch.uint8, device=d0.device).set_(d0.untyped_storage(), d_lo, (d_hi - d_lo,), (1,))
+                        self._dst_views[(spans[items[0][0]][0], d_lo, d_hi)] = dv
+                    sv = torch.empty(0, dtype=torch.uint8, device=s0.device).set_(s0.untyped_storage(), s_lo, (d_hi - d_lo,), (1,))
+                    dv.copy_(sv, non_blocking=True)
+                    continue
+            for i, _ in items:
+                self._static[i][1].copy_(new[i][1], non_blocking=True)
+
+    def _static_spans(self):
+        """Per static input: (storage pointer, first byte, end byte, element size) — computed once: the per-step path of a
+        host-fed training loop is Python, and every tensor method call in it costs as much as a tenth of the GPU step."""
+        sp = self.__dict__.get("_spans")
+        if sp is None:
+            sp = self._spans = [(t.untyped_storage().data_ptr(),) + _byte_span(t) + (t.element_size(),) for _, t in self._static]
+            self._dst_views = {}
+        return sp
 
     def __call__(self, features=None, labels=None):
         if features is not None:

@@ -173,7 +173,7 @@ def test_scatter_sources_ragged_and_broadcast(dev):
 
 
 @pytest.mark.parametrize("rows,K,F,period", [(3001, 16, 3, 4), (777, 8, 1, 3), (2000, 2, 2, 5), (1500, 1, 2, 4), (300, 64, 1, 2),
-                                             (40000, 16, 4, 32)])
+                                             (40000, 16, 4, 32), (3_000_000, 4, 1, 2)])     # (the last: sweep groups walk 16 rows each)
 def test_deferred_adam_is_bit_identical_to_dense_tf1_adam(dev, rows, K, F, period, monkeypatch):
     """N steps of (lookup -> row gradients -> optimizer) on two copies of an arena: copy A takes the summed gradients
     (GRAD mode) and the DENSE TF1 Adam pass over every row; copy B the fused deferred-exact path.  Every step the rows the
