@@ -8,23 +8,28 @@
 // then re-read (and zeroed) by the optimizer launch.
 //
 // Here the scatter is OWNER-COMPUTES, built on a deterministic STABLE MULTISPLIT of the requests by bucket = hash(row)
-// (no atomics on global memory anywhere, no sort):
-//   1. `prepare` (one launch per lookup, before its forward gather): workgroup w of the plan's request space (256
-//      consecutive requests) writes its bucket histogram as row w of a count matrix C[W][nb] (plain stores) and —
-//      deferred Adam only — brings every requested row's (w, m, v) up to date (see below), so that the unchanged forward
-//      kernels read current weights;
+// (no float atomics and no sort; the only atomics on global memory are the deferred-Adam claims: one integer CAS per lagging
+// row and one counter add per tile that found any):
+//   1. `prepare` (one launch per lookup, before its forward gather): the plan's slot space is cut into tiles of 256 (an id
+//      matrix field-major: a tile is 256 consecutive examples of ONE field).  Workgroup w finds the distinct rows of its
+//      tile (LDS hash + 256-bit member masks) and writes, one entry per DISTINCT row, its bucket histogram as row w of a
+//      count matrix C[W][nb] (plain stores).  Deferred Adam only: rows whose state lags are claimed (one CAS per stale
+//      row) and listed; `catchup`, a second, evenly spread launch, replays their missed updates so that the unchanged
+//      forward kernels read current weights;
 //   2. `scan` (one launch per arena and step, after the backward pass): exclusive prefix of every column of C over the
-//      workgroups, and the bucket totals;
-//   3. `place`: request i of workgroup w goes to  offs[b] + Cp[w][b] + (number of earlier requests of w in bucket b):
-//      every bucket receives its requests IN REQUEST ORDER, independent of scheduling.  Extra workgroups of the same
-//      launch run the deferred-Adam sweep;
-//   4. `apply` (one workgroup per bucket): a STABLE group-by-row of the bucket (small buckets: rank by comparison; large
-//      ones: LDS hash of the distinct rows + stable counting scatter), after which all requests of a row are adjacent and
-//      still in request order.  A group of K/4 lanes owns a row: it adds the row's gradient rows IN REQUEST ORDER
-//      (bit-reproducible; rows with many requests are summed by the whole workgroup in a fixed strided order), and — the
-//      row being exclusively its own — finishes the job in registers: TF1 Adam (dense semantics, exact), LazyAdam, or a
-//      plain `grad[row] += sum` store for callers that want the gradient arena.  No gradient arena round trip, no
-//      live-row list.
+//      tiles, and the bucket totals.  Extra workgroups of the same launch run the deferred-Adam sweep;
+//   3. `place`: entry i of tile w goes to  offs[b] + Cp[w][b] + (number of earlier entries of w in bucket b):
+//      every bucket receives its entries IN SLOT ORDER, independent of scheduling.  The duplicates of a row inside a tile
+//      are summed in request order into ONE partial gradient row (a hot row of a field reaches its bucket as B / 256
+//      entries, not thousands);
+//   4. `apply` (one workgroup per bucket, heavy buckets dispatched first): a STABLE group-by-row of the bucket (small
+//      buckets: rank by comparison; large ones: LDS hash of the distinct rows + stable counting scatter), after which all
+//      entries of a row are adjacent and still in order.  A group of K/4 lanes owns a row: it adds the row's entries IN
+//      ORDER (bit-reproducible; rows with many entries are summed by the whole workgroup in a fixed strided order), and —
+//      the row being exclusively its own — finishes the job in registers: TF1 Adam (dense semantics, exact), LazyAdam, or
+//      a plain `grad[row] += sum` store for callers that want the gradient arena.  No gradient arena round trip, no
+//      live-row list.  A COMPANION arena (one float per row, looked up with the same requests: DeepFM's first-order
+//      weights) reuses the placed entries: `place` also sums its scalars, a second `apply` launch walks them.
 //
 // Deferred exact Adam.  tf.train.AdamOptimizer applies a DENSE update to embedding variables: m, v of every row decay
 // and w moves every step, gradient or not (deepfm.py:246-250).  Rounds 1-2 walked every row a gradient
@@ -454,7 +459,7 @@ __global__ __launch_bounds__(kThreads) void sparse_scan_kernel(ScanArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// 3. place: keys into bucket ranges in request order (+ the deferred-Adam sweep in extra workgroups)
+// 3. place: keys into bucket ranges in slot order, tile duplicates pre-combined
 // ---------------------------------------------------------------------------------------------
 struct PlaceArgs {
     SrcDev src[kMaxSources];

@@ -167,7 +167,7 @@ class ArenaPlan:
         self.capacity = cap
         nbytes = int(lib.recalgo_scatter_plan_workspace_bytes(cap, self.nb_log2, self.arena.K))
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.arena.weight.device)
-        self.ws[:64].zero_()                   # the catch-up list's counter and ticket (kept clean by the kernels afterwards)
+        self.ws[:64].zero_()                   # the per-lookup claim counters (kept clean by the kernels afterwards)
         self.counted = None
 
     def _signature(self, sources):
