@@ -517,8 +517,20 @@ __global__ __launch_bounds__(256) void dense_sum_slabs_kernel(SplitJobs J) {
         const unsigned cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
         const size_t c = (size_t)(blockIdx.x - jb.first_block) * 16 + cl;
         float acc = 0.f;
-        if (c < jb.n)
-            for (int r = rg; r < jb.S; r += 16) acc += jb.partials[(size_t)r * jb.slab + c];
+        if (c < jb.n) {
+            // the partial rows of a column are independent loads: eight in flight per thread, added in row order (a loop of
+            // load -> wait -> add over the 512 partial rows of the loss tail was most of this launch: ~13 us in the step)
+            const float* col = jb.partials + c;
+            int r = rg;
+            for (; r + 16 * 7 < jb.S; r += 16 * 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(r + 16 * u) * jb.slab];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; r < jb.S; r += 16) acc += col[(size_t)r * jb.slab];
+        }
         sh[rg][cl] = acc;
         __syncthreads();
         if (rg == 0 && c < jb.n) {

@@ -418,12 +418,43 @@ __global__ __launch_bounds__(256) void logit_loss_kernel(TailArgs P) {
         for (int p = 0; p < P.n; ++p) {
             const int W = P.width[p];
             for (int j = threadIdx.x; j < W; j += 256) wcat[off + j] = P.w[p][j];
+            if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(P.x[p]) & 15) == 0) {
+                // float4 rows, all of a wave's loads of a pass in flight before the first LDS store (a scalar
+                // load -> store loop over a 416-float row was 7 dependent round trips per row)
+                const int W4 = W >> 2;
+                const float4* __restrict__ x4 = reinterpret_cast<const float4*>(P.x[p]);
+                for (int j0 = (int)lane; j0 < W4; j0 += 128) {
+                    float4 v[RW][2];
 #pragma unroll
-            for (int i = 0; i < RW; ++i) {
-                const int r = wave + 4 * i;
-                if (r < nb) {
-                    const float* __restrict__ xr = P.x[p] + (size_t)(b0 + r) * W;
-                    for (int j = lane; j < W; j += 64) tile[r * C + off + j] = xr[j];
+                    for (int i = 0; i < RW; ++i)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int r = wave + 4 * i, j = j0 + 64 * u;
+                            v[i][u] = (r < nb && j < W4) ? x4[(size_t)(b0 + r) * W4 + j] : f4_zero();
+                        }
+#pragma unroll
+                    for (int i = 0; i < RW; ++i)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int r = wave + 4 * i, j = j0 + 64 * u;
+                            if (r < nb && j < W4) {
+                                float* d = tile + r * C + off + 4 * j;
+                                if (((r * C + off) & 3) == 0) {
+                                    *reinterpret_cast<float4*>(d) = v[i][u];
+                                } else {
+                                    d[0] = v[i][u].x; d[1] = v[i][u].y; d[2] = v[i][u].z; d[3] = v[i][u].w;
+                                }
+                            }
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < RW; ++i) {
+                    const int r = wave + 4 * i;
+                    if (r < nb) {
+                        const float* __restrict__ xr = P.x[p] + (size_t)(b0 + r) * W;
+                        for (int j = lane; j < W; j += 64) tile[r * C + off + j] = xr[j];
+                    }
                 }
             }
             off += W;
