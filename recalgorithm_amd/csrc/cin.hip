@@ -514,7 +514,13 @@ __global__ __launch_bounds__(256) void cin_sum_partials_kernel(const float* __re
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float acc = 0.f;
-    for (unsigned s = 0; s < S; ++s) acc += partials[(size_t)s * n + i];
+    unsigned s = 0;
+    for (; s + 4 <= S; s += 4) {                              // four independent loads in flight, added in split order
+        const float a0 = partials[(size_t)s * n + i], a1 = partials[(size_t)(s + 1) * n + i];
+        const float a2 = partials[(size_t)(s + 2) * n + i], a3 = partials[(size_t)(s + 3) * n + i];
+        acc = (((acc + a0) + a1) + a2) + a3;
+    }
+    for (; s < S; ++s) acc += partials[(size_t)s * n + i];
     out[i] = acc;
 }
 

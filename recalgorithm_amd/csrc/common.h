@@ -73,8 +73,19 @@ __global__ __launch_bounds__(256) void colsum16_kernel(const float* __restrict__
     const unsigned cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const unsigned c = blockIdx.x * 16 + cl;
     float acc = 0.f;
-    if (c < n)
-        for (unsigned r = rg; r < S; r += 16) acc += partials[(size_t)r * n + c];
+    if (c < n) {
+        // independent loads, eight in flight per thread, added in row order (see dense_sum_slabs_kernel)
+        const float* col = partials + c;
+        unsigned r = rg;
+        for (; r + 16 * 7 < S; r += 16 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(r + 16 * u) * n];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; r < S; r += 16) acc += col[(size_t)r * n];
+    }
     sh[rg][cl] = acc;
     __syncthreads();
     if (rg == 0 && c < n) {

@@ -124,12 +124,14 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_apply_kernel(
     const bool ok = c4 < C4;
     const float inv_rows = 1.0f / ((float)rows * (float)(nblk / nblk_local));
     float4 acc = f4_zero();
-    if (ok)
+    if (ok) {
+#pragma unroll 4                                                // (the partial rows are independent loads: several in flight)
         for (unsigned b = rl; b < nblk; b += 16) {
             const unsigned bl = b % nblk_local;
             const float nb = (float)(min(rows, (bl + 1) * kTileRows) - bl * kTileRows);
             acc = f4_fma(partials[(size_t)b * 2 * C4 + c4], nb, acc);
         }
+    }
     sh[rl][cl] = acc;
     __syncthreads();
     float4 mean = sh[0][cl];
@@ -138,13 +140,15 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_apply_kernel(
     mean = f4_scale(mean, inv_rows);
     __syncthreads();
     acc = f4_zero();
-    if (ok)
+    if (ok) {
+#pragma unroll 4
         for (unsigned b = rl; b < nblk; b += 16) {
             const unsigned bl = b % nblk_local;
             const float nb = (float)(min(rows, (bl + 1) * kTileRows) - bl * kTileRows);
             const float4 d = f4_sub(partials[(size_t)b * 2 * C4 + c4], mean);
             acc = f4_add(acc, f4_fma(f4_mul(d, d), nb, partials[(size_t)b * 2 * C4 + C4 + c4]));
         }
+    }
     sh[rl][cl] = acc;
     __syncthreads();
     float4 var = sh[0][cl];
@@ -222,11 +226,13 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_sum_apply_kernel(
     const unsigned c4 = blockIdx.x * 16 + cl;
     const bool ok = c4 < C4;
     float4 sb = f4_zero(), sg = f4_zero();
-    if (ok)
+    if (ok) {
+#pragma unroll 4
         for (unsigned b = rl; b < nblk; b += 16) {
             sb = f4_add(sb, partials[(size_t)b * 2 * C4 + c4]);
             sg = f4_add(sg, partials[(size_t)b * 2 * C4 + C4 + c4]);
         }
+    }
     sh[0][rl][cl] = sb;
     sh[1][rl][cl] = sg;
     __syncthreads();
