@@ -477,6 +477,18 @@ class Estimator:
             elif v.dtype == torch.float32 and v.dim() == 2 and v.shape[1] == 1:
                 groups["dense"].append(k)
         out = dict(features)
+        packed = getattr(features, "packed_ids", None)
+        if packed is not None and len(packed[1]) >= 2 and packed[1] == groups["ids"] and all(
+                features[k].data_ptr() == packed[0][:, j].data_ptr() and features[k].stride() == packed[0][:, j].stride()
+                for j, k in enumerate(packed[1])):
+            # the native reader already decoded the id features into ONE [B, F] matrix in this order (io/native.py
+            # PackedBatch): one contiguous copy instead of re-stacking F strided column views
+            mat = packed[0]
+            dev = self._h2d(lambda buf: buf.copy_(mat), tuple(mat.shape), torch.int64) if self.device.type == "cuda" \
+                else mat.to(self.device)
+            for j, k in enumerate(packed[1]):
+                out[k] = dev[:, j]
+            groups["ids"] = []
         for kind, keys in groups.items():
             keys = [k for k in keys if features[k].shape[0] == features[keys[0]].shape[0]]
             if len(keys) < 2:

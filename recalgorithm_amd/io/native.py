@@ -87,6 +87,14 @@ class Vocabulary:
         return int(load().recalgo_vocab_lookup(self.h, key, len(key)))
 
 
+class PackedBatch(dict):
+    """A decoded feature batch whose single-valued id features are column views of ONE contiguous [B, F] int64 matrix,
+    columns in SORTED key order (the order feature_column.input_layer consumes them in): `packed_ids = (matrix, keys)`.
+    Estimator._pack_host_columns then moves that matrix with one contiguous copy instead of re-stacking F strided
+    column views (26 passes over the matrix per batch on the training loop's thread)."""
+    packed_ids = None
+
+
 class NativeDataset:
     """TFRecordDataset(filepath)[.shuffle(buf)].repeat(epochs).batch(bs).map(parse) with the record
     framing, Example decoding and vocabulary lookup done in C++."""
@@ -131,7 +139,7 @@ class NativeDataset:
                     raise IOError(f"{self.filepath}: {lib.recalgo_reader_error(h).decode()}")
                 if B == 0:
                     return
-                feats: Dict[str, object] = {}
+                feats: Dict[str, object] = PackedBatch()
                 for c in self.numeric:
                     n = int(np.prod(c.shape))
                     out = np.empty((B, n), dtype=np.float32)
@@ -143,7 +151,8 @@ class NativeDataset:
                     feats[c.key] = torch.from_numpy(out.reshape((B,) + tuple(c.shape)))
                 # single-valued id features: one [B, F] matrix from one parallel pass; a key that turns out to
                 # hold several values per record (or is declared a sequence) goes through the ragged call
-                flat = [c for c in self.categorical if not c.is_sequence and c.key not in self._multi]
+                flat = sorted((c for c in self.categorical if not c.is_sequence and c.key not in self._multi),
+                              key=lambda c: c.key)
                 if flat:
                     keys = (ctypes.c_char_p * len(flat))(*[c.key.encode() for c in flat])
                     vh = (c_void_p * len(flat))(*[vocabs[c.key].h for c in flat])
@@ -158,6 +167,8 @@ class NativeDataset:
                             self._multi.add(c.key)
                         else:
                             feats[c.key] = tmat[:, j]
+                    if not multi.any():
+                        feats.packed_ids = (tmat, [c.key for c in flat])
                 for c in self.categorical:
                     if c.key in feats:
                         continue
@@ -178,6 +189,8 @@ class NativeDataset:
                     else:
                         feats[c.key] = Ragged(torch.from_numpy(vals.copy()), torch.from_numpy(offs))
                 labels = {k: feats.pop(k) for k in self.label_keys}
+                if feats.packed_ids is not None and any(k in self.label_keys for k in feats.packed_ids[1]):
+                    feats.packed_ids = None        # (a label that is an id column: the matrix no longer mirrors the features)
                 yield feats, labels
         finally:
             lib.recalgo_reader_close(h)

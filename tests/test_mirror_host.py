@@ -277,3 +277,38 @@ def test_train_loop_raises_on_row_exchange_overflow():
     with pytest.raises(RuntimeError, match="bucket overflow"):
         Estimator._check_exchange_overflow(stub)
     Estimator._check_exchange_overflow(types.SimpleNamespace())   # not data parallel: nothing to poll
+
+
+def test_packed_batches_of_the_native_reader_move_as_one_matrix(tmp_path):
+    """io.native.NativeDataset yields PackedBatch dicts: the single-valued id features are column views of ONE [B, F]
+    matrix in sorted key order, and Estimator._pack_host_columns takes that matrix whole (same result as the generic
+    re-stacking path: values, order, zero-copy _as_matrix)."""
+    from recalgorithm_amd import feature_column as fc
+    from recalgorithm_amd.estimator import Estimator, RunConfig
+    from recalgorithm_amd.io import native, synth
+    if not native.available():
+        pytest.skip("librecalgo_host.so not built")
+    spec = synth.SynthSpec(n_fields=5, max_vocab=40, seed=3)
+    vd, path = str(tmp_path / "vocabulary") + "/", str(tmp_path / "t.tfrecord")
+    synth.write_vocabularies(spec, vd)
+    synth.write_tfrecord(spec, path, 70)
+    # columns deliberately NOT in sorted order
+    names = list(reversed(spec.names))
+    cats = [fc.categorical_column_with_vocabulary_file(n, vd + n + ".txt") for n in names]
+    cols = [fc.embedding_column(c, 4) for c in cats]
+    label = fc.numeric_column("read_comment", default_value=0.0)
+    ds = native.NativeDataset(path, cols + [label], ["read_comment"], 32)
+    est = Estimator(lambda *a: None, {}, RunConfig(device="cpu"))
+    n_batches = 0
+    for feats, labels in ds:
+        n_batches += 1
+        assert isinstance(feats, native.PackedBatch) and feats.packed_ids is not None
+        mat, keys = feats.packed_ids
+        assert keys == sorted(names) and mat.is_contiguous() and mat.shape == (labels["read_comment"].shape[0], len(names))
+        fast = est._pack_host_columns(feats, force=True)
+        slow = est._pack_host_columns(dict(feats), force=True)             # a plain dict: the generic path
+        for k in names:
+            assert torch.equal(fast[k], slow[k]) and torch.equal(fast[k], feats[k])
+        m = fc._as_matrix([fast[k] for k in sorted(names)])
+        assert m.data_ptr() == mat.data_ptr() and m.is_contiguous()         # the reader's matrix itself, no copy on a CPU device
+    assert n_batches == 3
