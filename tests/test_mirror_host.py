@@ -312,3 +312,50 @@ def test_packed_batches_of_the_native_reader_move_as_one_matrix(tmp_path):
         m = fc._as_matrix([fast[k] for k in sorted(names)])
         assert m.data_ptr() == mat.data_ptr() and m.is_contiguous()         # the reader's matrix itself, no copy on a CPU device
     assert n_batches == 3
+
+
+def test_graphed_step_input_load_copies_views_of_one_allocation_at_once():
+    """GraphedTrainStep.load (the per-step host path of a graph-replayed training loop): inputs that are views of one
+    allocation with the same relative layout on both sides move as ONE copy of the byte span they cover; anything else
+    is copied tensor by tensor; a changed structure is refused.  (CPU tensors: the logic is device independent.)"""
+    from recalgorithm_amd.estimator import GraphedTrainStep, _tree_tensors
+    from recalgorithm_amd import feature_column as fc
+    B, F = 37, 5
+
+    def batch(seed, pad=0):
+        g = torch.Generator().manual_seed(seed)
+        base = torch.randint(0, 1000, (pad + B * F + B,), generator=g)
+        m = base[pad:pad + B * F].view(B, F)
+        feats = {f"f{i}": m[:, i] for i in range(F)}
+        feats["dense"] = torch.randn(B, 3, generator=g)
+        feats["seq"] = fc.Ragged(torch.arange(7) + seed, torch.tensor([0, 7] + [7] * (B - 1)))
+        return feats, {"y": base[pad + B * F:]}
+
+    f0, l0 = batch(0)
+    g = GraphedTrainStep.__new__(GraphedTrainStep)
+    g._static = list(_tree_tensors(f0, "f")) + list(_tree_tensors(l0, "l"))
+    static_ptrs = [t.data_ptr() for _, t in g._static]
+    for seed, pad in ((1, 0), (2, 11)):                      # the source may sit anywhere in its own allocation
+        f1, l1 = batch(seed, pad)
+        g.load(f1, l1)
+        for (k, dst), (_, src) in zip(g._static, list(_tree_tensors(f1, "f")) + list(_tree_tensors(l1, "l"))):
+            assert torch.equal(dst, src), k
+    assert [t.data_ptr() for _, t in g._static] == static_ptrs            # the static buffers themselves never move
+    # separately allocated columns on the source side: copied one by one, same result
+    f2, l2 = batch(3)
+    f2 = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in f2.items()}
+    g.load(f2, l2)
+    assert all(torch.equal(f0[k], f2[k]) for k in f2 if isinstance(f2[k], torch.Tensor))
+    # a different dtype is converted by the per-tensor path
+    f3, l3 = batch(4)
+    f3["dense"] = f3["dense"].double()
+    g.load(f3, l3)
+    assert torch.equal(f0["dense"], f3["dense"].float())
+    f4, l4 = batch(5)
+    f4.pop("f3")
+    with pytest.raises(ValueError):
+        g.load(f4, l4)
+    f5, l5 = batch(6)
+    f5["dense"] = torch.zeros(B, 4)
+    with pytest.raises(ValueError):
+        g.load(f5, l5)
