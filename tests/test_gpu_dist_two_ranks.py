@@ -1,8 +1,9 @@
 """-m gpu: TWO ranks of the row-sharded data-parallel step on the real HIP kernels, on the one GPU a
 test box has.  RCCL refuses two ranks on one device, so the collectives go through
 parallel.HostStagedCollectives (gloo via host memory); everything else is the production N > 1
-path: arenas sharded r % 2, fixed-capacity id/row exchange with -1 padding, owner-side HIP gather and
-scatter-add, live-row marking on the shard, list Adam on the shard, dense all-reduce, loss / N.
+path: arenas sharded r % 2, fixed-capacity id/row exchange with -1 padding, owner-side HIP gather, the
+received gradient rows as a lookup of the shard's owner-computes plan (deferred exact Adam on the shard), dense all-reduce,
+loss / N; optionally Sync-BatchNorm.
 Oracle: the single-process step on the concatenated global batch (same seeds) — N ranks == 1 rank.
 Also runs bench.py's N = 2 code path in the same mode (launch agreement, eager fallback, overflow
 retry, JSON line)."""
