@@ -126,7 +126,8 @@ def test_gather_and_sequence_gather_bit_exact_at_config_shapes(dev):
 
 
 # ------------------------------------------------------------------------------------------------------
-# model level: exactly bench.py's estimators (configs[1], [2], [3])
+# model level: exactly bench.py's estimators (configs[1], [2], [3]; DeepFM = configs[4]'s model with the companion
+# first-order arena at full size; FiBiNET and PNN = the two remaining north_star models at 26 x 16 x 4096)
 # ------------------------------------------------------------------------------------------------------
 def _bench_estimator(model, dev):
     args = bench.parse_args(["--model", model, "--batch", str(B), "--fields", str(F), "--emb", str(K),
@@ -143,7 +144,7 @@ def _oracle_inputs(est, feats, labels, dtype):
     return P, cf, cl
 
 
-@pytest.mark.parametrize("model", ["dcn", "xdeepfm", "din"])
+@pytest.mark.parametrize("model", ["dcn", "xdeepfm", "din", "deepfm", "fibinet", "pnn"])
 def test_model_step_at_baseline_config(dev, model):
     est, feats, labels, workload = _bench_estimator(model, dev)
     params = est.params
@@ -152,7 +153,7 @@ def test_model_step_at_baseline_config(dev, model):
         for name, v in est.store.vars.items():
             if "alpha" in name:
                 v.data.copy_((0.25 + 0.5 * torch.rand(v.data.shape, generator=g)).to(dev))
-    fn = {"dcn": M.dcn, "xdeepfm": M.xdeepfm, "din": M.din}[model]
+    fn = {"dcn": M.dcn, "xdeepfm": M.xdeepfm, "din": M.din, "deepfm": M.deepfm, "fibinet": M.fibinet, "pnn": M.pnn}[model]
     P, cf, cl = _oracle_inputs(est, feats, labels, torch.float64)
     ref = fn(P, cf, cl, params, training=True)
     ref["loss"].backward()

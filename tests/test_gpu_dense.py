@@ -15,12 +15,14 @@ SHAPES = [(4096, 416, 512), (4096, 512, 256), (4096, 256, 128), (37, 82, 50), (1
           (300, 48, 8), (65, 33, 65), (512, 9600, 64)]
 
 
-def _ref_fwd(x, w, b, relu, x2=None, w2=None):
-    y = x.double() @ w.double()
+def _ref_fwd(x, w, b, relu, x2=None, w2=None, dtype=torch.float64):
+    """tf.layers.dense restated; dtype = float32 gives the reference arithmetic's own rounding (the `ref32` of
+    tests/util.assert_close: the kernel may not leave materially more elements outside the strict bound than this)."""
+    y = x.to(dtype) @ w.to(dtype)
     if x2 is not None:
-        y = y + x2.double() @ w2.double()
+        y = y + x2.to(dtype) @ w2.to(dtype)
     if b is not None:
-        y = y + b.double()
+        y = y + b.to(dtype)
     return torch.relu(y) if relu else y
 
 
@@ -36,18 +38,19 @@ def test_dense_fwd_bwd(dev, M, K, N, relu, use_bias):
     bd = None if b is None else b.to(dev)
     y = ops.dense_fwd(xd, wd, bd, relu)
     ref = _ref_fwd(x, w, b, relu)
-    assert_close(y, ref, what=f"dense fwd {M}x{K}x{N}", reduced=True)
+    assert_close(y, ref, what=f"dense fwd {M}x{K}x{N}", reduced=True, ref32=_ref_fwd(x, w, b, relu, dtype=torch.float32))
     # backward with the mask taken from the kernel's own forward output (what nn._DenseFn does)
     mask = (y.cpu() > 0).double() if relu else torch.ones_like(ref)
     g2 = g.double() * mask
+    g2f = g2.float()
     dx = ops.dense_bwd_input(gd, y if relu else None, wd)
-    assert_close(dx, g2 @ w.double().t(), what="dense dgrad", reduced=True)
+    assert_close(dx, g2 @ w.double().t(), what="dense dgrad", reduced=True, ref32=g2f @ w.t())
     dw = torch.empty(K, N, device=dev)
     db = torch.empty(N, device=dev) if use_bias else None
     ops.dense_bwd_weights(xd, gd, y if relu else None, dw, db)
-    assert_close(dw, x.double().t() @ g2, what="dense wgrad", reduced=True)
+    assert_close(dw, x.double().t() @ g2, what="dense wgrad", reduced=True, ref32=x.t() @ g2f)
     if use_bias:
-        assert_close(db, g2.sum(0), what="dense dbias", reduced=True)
+        assert_close(db, g2.sum(0), what="dense dbias", reduced=True, ref32=g2f.sum(0))
     # deterministic: a second run is bit-identical (fixed-order split sum, no atomics)
     dw2 = torch.empty_like(dw)
     ops.dense_bwd_weights(xd, gd, y if relu else None, dw2, None)
@@ -63,11 +66,13 @@ def test_dense_two_operand_pairs_and_beta_c(dev):
     w, w2 = torch.randn(K, N, generator=gen) / K ** 0.5, torch.randn(K2, N, generator=gen) / K2 ** 0.5
     b = torch.randn(N, generator=gen)
     y = ops.dense_fwd(x.to(dev), w.to(dev), b.to(dev), True, x2=x2.to(dev), w2=w2.to(dev))
-    assert_close(y, _ref_fwd(x, w, b, True, x2, w2), what="two-pair fwd", reduced=True)
+    assert_close(y, _ref_fwd(x, w, b, True, x2, w2), what="two-pair fwd", reduced=True,
+                 ref32=_ref_fwd(x, w, b, True, x2, w2, dtype=torch.float32))
     g = torch.randn(M, N, generator=gen)
     c = torch.randn(M, K, generator=gen)
     dx = ops.dense_bwd_input(g.to(dev), None, w.to(dev), c_in=c.to(dev), beta=0.25)
-    assert_close(dx, g.double() @ w.double().t() + 0.25 * c.double(), what="dgrad + beta*C", reduced=True)
+    assert_close(dx, g.double() @ w.double().t() + 0.25 * c.double(), what="dgrad + beta*C", reduced=True,
+                 ref32=g @ w.t() + 0.25 * c)
     base = torch.randn(M, K, generator=gen)
     out = base.to(dev).clone()
     ops.dense_bwd_input(g.to(dev), None, w.to(dev), out=out, accumulate=True)

@@ -34,14 +34,17 @@ def test_din_attention(dev, B, T, H, is_softmax):
     store = VariableStore(dev)
     qd, kd = q.to(dev).requires_grad_(True), keys.to(dev).requires_grad_(True)
     out = ops.din_attention(store, qd, kd, lens.to(dev), vs, is_softmax)
+    g = torch.randn(B, H, generator=gen)
     a = [t.double().requires_grad_(True) for t in [q, keys] + ws]
     ref = R.din_attention(a[0], a[1], lens, *a[2:], is_softmax=is_softmax)
-    assert_close(out, ref, what="din fwd")
-    g = torch.randn(B, H, generator=gen)
-    out.backward(g.to(dev))
     ref.backward(g.double())
-    assert_close(qd.grad, a[0].grad, what="din dq")
-    assert_close(kd.grad, a[1].grad, what="din dkeys")
+    a32 = [t.clone().requires_grad_(True) for t in [q, keys] + ws]     # the oracle in float32 (strict-bound guard)
+    r32 = R.din_attention(a32[0], a32[1], lens, *a32[2:], is_softmax=is_softmax)
+    r32.backward(g)
+    assert_close(out, ref, what="din fwd", ref32=r32)
+    out.backward(g.to(dev))
+    assert_close(qd.grad, a[0].grad, what="din dq", ref32=a32[0].grad)
+    assert_close(kd.grad, a[1].grad, what="din dkeys", ref32=a32[1].grad)
     for i, nm in enumerate(["f1_w", "f1_b", "f2_w", "f2_b", "f3_w", "f3_b"]):
         if nm == "f3_b" and is_softmax:
             # softmax is shift invariant: d/d(f3 bias) = sum_t ds_t is exactly 0 in exact arithmetic
@@ -50,7 +53,7 @@ def test_din_attention(dev, B, T, H, is_softmax):
             scale = float(a[6].grad.abs().max())
             assert float((vs[i].grad.cpu().double() - a[7].grad).abs().max()) <= 1e-5 * max(scale, 1e-30)
             continue
-        assert_close(vs[i].grad, a[2 + i].grad, what=f"din d{nm}", reduced=True)
+        assert_close(vs[i].grad, a[2 + i].grad, what=f"din d{nm}", reduced=True, ref32=a32[2 + i].grad)
 
 
 def test_din_length_zero_edge_cases(dev):

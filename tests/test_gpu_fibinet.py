@@ -33,18 +33,22 @@ def test_senet_fwd_bwd(dev, B, F, K, ratio):
     Ed, w1d, w2d = (t.double().requires_grad_(True) for t in (E, w1, w2))
     ref = R.senet(Ed, w1d, w2d)
     ref.backward(g.double())
+    # the same oracle in float32: the reference arithmetic's own rounding (strict-bound regression guard, tests/util.py)
+    Ef, w1f, w2f = (t.clone().requires_grad_(True) for t in (E, w1, w2))
+    r32 = R.senet(Ef, w1f, w2f)
+    r32.backward(g)
     Eg, w1g, w2g, gg = (t.to(dev) for t in (E, w1, w2, g))
     v = torch.empty_like(Eg)
     a = torch.empty(B, F, device=dev)
     _lib.check(lib.recalgo_senet_fwd(_p(Eg), _p(w1g), _p(w2g), B, F, K, Rd, _p(v), _p(a), _st()), "senet fwd")
-    assert_close(v, ref, what="senet out")
+    assert_close(v, ref, what="senet out", ref32=r32)
     ws = torch.empty(lib.recalgo_senet_bwd_workspace_bytes(B, F, K, Rd), dtype=torch.uint8, device=dev)
     dE, dw1, dw2 = torch.empty_like(Eg), torch.empty_like(w1g), torch.empty_like(w2g)
     _lib.check(lib.recalgo_senet_bwd(_p(Eg), _p(w1g), _p(w2g), _p(gg), B, F, K, Rd, _p(dE), 0, _p(dw1), _p(dw2),
                                      _p(ws), _st()), "senet bwd")
-    assert_close(dE, Ed.grad, what="senet dE")
-    assert_close(dw1, w1d.grad, what="senet dw1", reduced=True)
-    assert_close(dw2, w2d.grad, what="senet dw2", reduced=True)
+    assert_close(dE, Ed.grad, what="senet dE", ref32=Ef.grad)
+    assert_close(dw1, w1d.grad, what="senet dw1", reduced=True, ref32=w1f.grad)
+    assert_close(dw2, w2d.grad, what="senet dw2", reduced=True, ref32=w2f.grad)
     # accumulate flag
     dE2 = torch.ones_like(Eg)
     _lib.check(lib.recalgo_senet_bwd(_p(Eg), _p(w1g), _p(w2g), _p(gg), B, F, K, Rd, _p(dE2), 1, _p(dw1), _p(dw2),
@@ -74,21 +78,25 @@ def test_bilinear_fwd_bwd(dev, btype, B, F, K, nv):
     ref = torch.cat([R.bilinear_interaction(x, w, btype) for x, w in zip(xd, wd)], dim=-1)
     assert ref.shape == (B, P, nv * K)
     ref.backward(g.double())
+    xf = [x.clone().requires_grad_(True) for x in xs]
+    wf = [w.clone().requires_grad_(True) for w in ws_]
+    r32 = torch.cat([R.bilinear_interaction(x, w, btype) for x, w in zip(xf, wf)], dim=-1)
+    r32.backward(g)
     xg = [x.to(dev) for x in xs] + [None] * (2 - nv)
     wg = [w.to(dev) for w in ws_] + [None] * (2 - nv)
     gg = g.to(dev)
     out = torch.empty(B, P, nv * K, device=dev)
     _lib.check(lib.recalgo_bilinear_fwd(_p(xg[0]), _p(wg[0]), _p(xg[1]), _p(wg[1]), B, F, K, T, _p(out), nv * K, 0,
                                         _st()), "bilinear fwd")
-    assert_close(out, ref, what=f"bilinear[{btype}] out")
+    assert_close(out, ref, what=f"bilinear[{btype}] out", ref32=r32)
     wsb = torch.empty(lib.recalgo_bilinear_bwd_workspace_bytes(B, F, K, nv, T), dtype=torch.uint8, device=dev)
     dx = [torch.empty_like(xg[0])] + ([torch.empty_like(xg[1])] if nv == 2 else [None])
     dw = [torch.zeros_like(wg[0])] + ([torch.zeros_like(wg[1])] if nv == 2 else [None])
     _lib.check(lib.recalgo_bilinear_bwd(_p(xg[0]), _p(wg[0]), _p(xg[1]), _p(wg[1]), _p(gg), nv * K, 0, B, F, K, T,
                                         _p(dx[0]), _p(dw[0]), _p(dx[1]), _p(dw[1]), _p(wsb), _st()), "bilinear bwd")
     for v in range(nv):
-        assert_close(dx[v], xd[v].grad, what=f"bilinear[{btype}] dx{v}")
-        assert_close(dw[v], wd[v].grad, what=f"bilinear[{btype}] dw{v}", reduced=True)
+        assert_close(dx[v], xd[v].grad, what=f"bilinear[{btype}] dx{v}", ref32=xf[v].grad)
+        assert_close(dw[v], wd[v].grad, what=f"bilinear[{btype}] dw{v}", reduced=True, ref32=wf[v].grad)
         # quirk B-3: the last field never participates -> exactly zero gradient
         assert float(dx[v][:, F - 1].abs().max()) == 0.0
 

@@ -42,11 +42,12 @@ def test_gather_fwd_bit_exact_and_bwd(dev, B, vocabs, K):
     # backward: dense-equivalent scatter-add
     g = torch.randn(B, len(vocabs) * K, generator=gen)
     out.backward(g.to(dev))
-    w64 = w.double().requires_grad_(True)
-    ref64 = torch.cat([R.embedding_lookup_single(ids[:, f], w64[rb[f].item():rb[f].item() + vocabs[f]])
-                       for f in range(len(vocabs))], dim=1)
-    ref64.backward(g.double())
-    assert_close(ar.grad, w64.grad, what="gather bwd", reduced=True)
+    def table_grad(dt):                # autograd of the lookup = dense scatter-add of the gradient rows, in `dt`
+        wt = w.to(dt).requires_grad_(True)
+        torch.cat([R.embedding_lookup_single(ids[:, f], wt[rb[f].item():rb[f].item() + vocabs[f]])
+                   for f in range(len(vocabs))], dim=1).backward(g.to(dt))
+        return wt.grad
+    assert_close(ar.grad, table_grad(torch.float64), what="gather bwd", reduced=True, ref32=table_grad(torch.float32))
 
 
 def test_gather_empty_batch(dev):
@@ -74,17 +75,18 @@ def test_bag_mean(dev, B, vocab, K, maxlen):
     out = ops.embedding_bag_mean(store, values.to(dev), offsets.to(dev), ar, "t1")
     tab = ar.table_view("t1").cpu()
     ref = R.embedding_lookup_mean(values, offsets, tab)
-    assert_close(out, R.embedding_lookup_mean(values, offsets, tab.double()), what="bag mean fwd")
+    assert_close(out, R.embedding_lookup_mean(values, offsets, tab.double()), what="bag mean fwd", ref32=ref)
     # bags of exactly one valid id are exact row copies
     lens = offsets[1:] - offsets[:-1]
     for b in torch.nonzero(lens == 1).flatten().tolist():
         assert torch.equal(out[b].cpu(), ref[b])
     g = torch.randn(B, K, generator=gen)
     out.backward(g.to(dev))
-    t64 = tab.double().requires_grad_(True)
+    t64, t32 = tab.double().requires_grad_(True), tab.clone().requires_grad_(True)
     R.embedding_lookup_mean(values, offsets, t64).backward(g.double())
+    R.embedding_lookup_mean(values, offsets, t32).backward(g)
     rb, v = ar.tables["t1"]
-    assert_close(ar.grad[rb:rb + v], t64.grad, what="bag mean bwd", reduced=True)
+    assert_close(ar.grad[rb:rb + v], t64.grad, what="bag mean bwd", reduced=True, ref32=t32.grad)
     assert float(ar.grad[:rb].abs().sum()) == 0.0
 
 
@@ -102,9 +104,10 @@ def test_sequence_gather(dev, B, T):
     assert torch.equal(sl.cpu().long(), lens)
     g = torch.randn(B, T, K, generator=gen)
     out.backward(g.to(dev))
-    t64 = tab.double().requires_grad_(True)
+    t64, t32 = tab.double().requires_grad_(True), tab.clone().requires_grad_(True)
     R.sequence_lookup(values, offsets, t64, T)[0].backward(g.double())
-    assert_close(ar.grad, t64.grad, what="sequence gather bwd", reduced=True)
+    R.sequence_lookup(values, offsets, t32, T)[0].backward(g)
+    assert_close(ar.grad, t64.grad, what="sequence gather bwd", reduced=True, ref32=t32.grad)
 
 
 @pytest.mark.parametrize("B,F,K", [(3, 2, 4), (130, 6, 8), (1024, 26, 16), (4096, 26, 16)])
@@ -131,19 +134,20 @@ def test_deepfm_sparse(dev, B, F, K):
         o2 = R.fm_second_order(fields)
         return W, W1, bb, torch.cat(fields, 1), o1, o2
 
-    _, _, _, e32, _, _ = oracle(torch.float32)
+    Wf, W1f, bbf, e32, o1f, o2f = oracle(torch.float32)
     assert_bit_exact(emb, e32.detach(), "deep_input")
     W, W1, bb, e64, o1, o2 = oracle(torch.float64)
-    assert_close(fm1, o1, what="fm first order")
-    assert_close(fm2, o2, what="fm second order")
+    assert_close(fm1, o1, what="fm first order", ref32=o1f)
+    assert_close(fm2, o2, what="fm second order", ref32=o2f)
     ge = torch.randn(B, F * K, generator=gen)
     g1 = torch.randn(B, 1, generator=gen)
     g2 = torch.randn(B, 1, generator=gen)
     torch.autograd.backward([emb, fm1, fm2], [ge.to(dev), g1.to(dev), g2.to(dev)])
     torch.autograd.backward([e64, o1, o2], [ge.double(), g1.double(), g2.double()])
-    assert_close(ar.grad, W.grad, what="deepfm d(table)", reduced=True)
-    assert_close(w1.grad.reshape(-1), W1.grad, what="deepfm d(w1)", reduced=True)
-    assert_close(bias.grad, bb.grad, what="deepfm d(bias)", reduced=True)
+    torch.autograd.backward([e32, o1f, o2f], [ge, g1, g2])
+    assert_close(ar.grad, W.grad, what="deepfm d(table)", reduced=True, ref32=Wf.grad)
+    assert_close(w1.grad.reshape(-1), W1.grad, what="deepfm d(w1)", reduced=True, ref32=W1f.grad)
+    assert_close(bias.grad, bb.grad, what="deepfm d(bias)", reduced=True, ref32=bbf.grad)
 
 
 def test_fm_identity_bruteforce(dev):
@@ -177,18 +181,21 @@ def test_cross_stack(dev, B, d, L):
     wv, bv = Variable("w", w.to(dev)), Variable("b", b.to(dev))
     x0d = x0.to(dev).requires_grad_(True)
     out = ops.cross_stack(store, x0d, wv, bv)
-    x64 = x0.double().requires_grad_(True)
-    w64 = w.double().requires_grad_(True)
-    b64 = b.double().requires_grad_(True)
-    ref = R.cross_stack(x64, [w64[l].unsqueeze(1) for l in range(L)], [b64[l].unsqueeze(1) for l in range(L)])
-    assert_close(out, ref, what="cross fwd")
     g = torch.randn(B, d, generator=gen)
+
+    def oracle(dt):
+        xx, ww, bb = (t.to(dt).requires_grad_(True) for t in (x0, w, b))
+        r = R.cross_stack(xx, [ww[l].unsqueeze(1) for l in range(L)], [bb[l].unsqueeze(1) for l in range(L)])
+        r.backward(g.to(dt))
+        return r.detach(), xx.grad, ww.grad, bb.grad
+    ref, gx, gw, gb = oracle(torch.float64)
+    r32, gx32, gw32, gb32 = oracle(torch.float32)
+    assert_close(out, ref, what="cross fwd", ref32=r32)
     out.backward(g.to(dev))
     ops.flush_dense_splits()          # dw / db: column sums of the partial rows, finished by the step's deferred-sum launch
-    ref.backward(g.double())
-    assert_close(x0d.grad, x64.grad, what="cross dx0")
-    assert_close(wv.grad, w64.grad, what="cross dw", reduced=True)
-    assert_close(bv.grad, b64.grad, what="cross db", reduced=True)
+    assert_close(x0d.grad, gx, what="cross dx0", ref32=gx32)
+    assert_close(wv.grad, gw, what="cross dw", reduced=True, ref32=gw32)
+    assert_close(bv.grad, gb, what="cross db", reduced=True, ref32=gb32)
 
 
 def test_cross_layer_separate_xl_and_identities(dev):
@@ -201,14 +208,15 @@ def test_cross_layer_separate_xl_and_identities(dev):
     x0d, xld = x0.to(dev).requires_grad_(True), xl.to(dev).requires_grad_(True)
     out = ops.cross_layer(store, x0d, xld, wv, bv)
     a64 = [t.double().requires_grad_(True) for t in (x0, xl, w, b)]
-    ref = R.cross_layer(*a64)
-    assert_close(out, ref, what="cross_layer fwd")
+    a32 = [t.clone().requires_grad_(True) for t in (x0, xl, w, b)]
+    ref, r32 = R.cross_layer(*a64), R.cross_layer(*a32)
+    assert_close(out, ref, what="cross_layer fwd", ref32=r32)
     g = torch.randn(B, d, generator=gen)
     out.backward(g.to(dev))
     ref.backward(g.double())
-    for got, want, nm in [(x0d.grad, a64[0].grad, "dx0"), (xld.grad, a64[1].grad, "dxl"),
-                          (wv.grad, a64[2].grad, "dw"), (bv.grad, a64[3].grad, "db")]:
-        assert_close(got, want, what=f"cross_layer {nm}", reduced=True)
+    r32.backward(g)
+    for got, k, nm in [(x0d.grad, 0, "dx0"), (xld.grad, 1, "dxl"), (wv.grad, 2, "dw"), (bv.grad, 3, "db")]:
+        assert_close(got, a64[k].grad, what=f"cross_layer {nm}", reduced=True, ref32=a32[k].grad)
     # w = 0  =>  out = xl + b    — exact
     wz = Variable("wz", torch.zeros(d, 1, device=dev))
     outz = ops.cross_layer(store, x0.to(dev), xl.to(dev), wz, bv)
@@ -230,13 +238,14 @@ def test_sigmoid_ce(dev, B):
         z[1] = 1.0
     xd = x.to(dev).requires_grad_(True)
     loss, prob = ops.sigmoid_cross_entropy(xd, z.to(dev))
-    x64 = x.double().requires_grad_(True)
-    ref = R.ce_loss(z.double(), x64)
-    assert_close(loss, ref, what="loss")
-    assert_close(prob, torch.sigmoid(x64), what="prob")
+    x64, x32 = x.double().requires_grad_(True), x.clone().requires_grad_(True)
+    ref, r32 = R.ce_loss(z.double(), x64), R.ce_loss(z, x32)
+    assert_close(loss, ref, what="loss", ref32=r32)
+    assert_close(prob, torch.sigmoid(x64), what="prob", ref32=torch.sigmoid(x32))
     (loss * 2.5).backward()
     (ref * 2.5).backward()
-    assert_close(xd.grad, x64.grad, what="dlogit")
+    (r32 * 2.5).backward()
+    assert_close(xd.grad, x64.grad, what="dlogit", ref32=x32.grad)
 
 
 @pytest.mark.parametrize("n", [1, 7, 4096, 1_000_003])
@@ -277,13 +286,16 @@ def test_activation(dev, kind, rows, C):
     xd = x.to(dev).requires_grad_(True)
     y = ops.activation(store, xd, av, kind)
     x64, a64 = x.double().requires_grad_(True), a.double().requires_grad_(True)
-    ref = (R.prelu if kind == "prelu" else R.dice)(x64, a64)
-    assert_close(y, ref, what=kind)
+    x32, a32 = x.clone().requires_grad_(True), a.clone().requires_grad_(True)
+    fn = R.prelu if kind == "prelu" else R.dice
+    ref, r32 = fn(x64, a64), fn(x32, a32)
+    assert_close(y, ref, what=kind, ref32=r32)
     g = torch.randn(rows, C, generator=gen)
     y.backward(g.to(dev))
     ref.backward(g.double())
-    assert_close(xd.grad, x64.grad, what=f"{kind} dx")
-    assert_close(av.grad, a64.grad, what=f"{kind} dalpha", reduced=True)
+    r32.backward(g)
+    assert_close(xd.grad, x64.grad, what=f"{kind} dx", ref32=x32.grad)
+    assert_close(av.grad, a64.grad, what=f"{kind} dalpha", reduced=True, ref32=a32.grad)
 
 
 def test_cpu_tensor_is_rejected():

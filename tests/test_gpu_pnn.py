@@ -36,6 +36,9 @@ def test_pnn_product_layer_pieces(dev, method, B, F, K, D):
     ed, lwd, pwd, bd = (t.double().requires_grad_(True) for t in (emb, lw, pw, bias))
     _, lp_ref, out_ref = R.pnn_product(ed, lwd, pwd, bd, F, K, method)        # the literal D-iteration loop
     lp_ref.backward(g.double())
+    ef, lwf, pwf, bf = (t.clone().requires_grad_(True) for t in (emb, lw, pw, bias))        # the oracle in float32
+    _, lp32, _ = R.pnn_product(ef, lwf, pwf, bf, F, K, method)
+    lp32.backward(g)
 
     T = lib.recalgo_pnn_feature_count(F, K, m)
     assert T == (F * (F + 1) // 2 if method == "IPNN" else K * (K + 1) // 2)
@@ -53,7 +56,7 @@ def test_pnn_product_layer_pieces(dev, method, B, F, K, D):
     assert torch.equal(phi, phi_t)
     _lib.check(lib.recalgo_pnn_weights_fwd(_p(pg), D, F, K, m, _p(omega), _st()), "weights fwd")
     lp = phi.double() @ omega.double()
-    assert_close(lp, lp_ref, what=f"{method} lp = phi @ omega")
+    assert_close(lp, lp_ref, what=f"{method} lp = phi @ omega", ref32=lp32)
     # backward pieces, chained in fp64 around the kernels
     dphi = (gg.double() @ omega.double().t()).float()
     domega = (phi.double().t() @ gg.double()).float()
@@ -64,10 +67,10 @@ def test_pnn_product_layer_pieces(dev, method, B, F, K, D):
     assert_close(d_emb - 0.25, ed.grad, what=f"{method} d_emb (accumulate)", reduced=True)
     d_emb2 = torch.empty_like(d_emb)
     _lib.check(lib.recalgo_pnn_features_bwd(_p(eg), _p(dphi), T, B, F, K, m, _p(d_emb2), 0, _st()), "features bwd")
-    assert_close(d_emb2, ed.grad, what=f"{method} d_emb", reduced=True)
+    assert_close(d_emb2, ed.grad, what=f"{method} d_emb", reduced=True, ref32=ef.grad)
     dpw = torch.empty_like(pg)
     _lib.check(lib.recalgo_pnn_weights_bwd(_p(pg), _p(domega), D, F, K, m, _p(dpw), _st()), "weights bwd")
-    assert_close(dpw, pwd.grad, what=f"{method} d_product_w", reduced=True)
+    assert_close(dpw, pwd.grad, what=f"{method} d_product_w", reduced=True, ref32=pwf.grad)
     if method == "OPNN":
         assert float(torch.tril(dpw, diagonal=-1).abs().max()) == 0.0        # quirk B-10
 
@@ -109,11 +112,19 @@ def test_field_pair_logit_against_reference_double_loop(dev, B, F, K):
             ref = ref + rd[index] * (fields[i] * fields[j]).sum(1, keepdim=True)
             index += 1
     ref.backward(g.double())
+    ef, rf = emb.clone().requires_grad_(True), r.clone().requires_grad_(True)              # the same loop in float32
+    r32 = torch.zeros(B, 1)
+    index = 0
+    for i in range(F - 1):
+        for j in range(i + 1, F):
+            r32 = r32 + rf[index] * (ef[:, i * K:(i + 1) * K] * ef[:, j * K:(j + 1) * K]).sum(1, keepdim=True)
+            index += 1
+    r32.backward(g)
     store = VariableStore(dev)
     rv = Variable("fields_pair_strength/fields_pair_strength_weight", r.to(dev))
     x = emb.to(dev).requires_grad_(True)
     out = ops.field_pair_logit(store, x, rv, F, K)
-    assert_close(out, ref.detach(), what="fwfm second-order logit")
+    assert_close(out, ref.detach(), what="fwfm second-order logit", ref32=r32)
     out.backward(g.to(dev))
-    assert_close(x.grad, ed.grad, what="fwfm d(embeddings)")
-    assert_close(rv.grad, rd.grad, what="fwfm d(pair strengths)", reduced=True)
+    assert_close(x.grad, ed.grad, what="fwfm d(embeddings)", ref32=ef.grad)
+    assert_close(rv.grad, rd.grad, what="fwfm d(pair strengths)", reduced=True, ref32=rf.grad)
