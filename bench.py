@@ -52,6 +52,10 @@ def parse_args(argv=None):
     ap.add_argument("--big-table-rows", type=int, default=0,
                     help="replace the vocabulary of the last field by a table of this many rows "
                          "(BASELINE configs[4]: one 100M x 16 table)")
+    ap.add_argument("--config5", action="store_true",
+                    help="BASELINE.json configs[4]: DeepFM with ONE 100 M-row x emb16 table among its fields, rows sharded r %% N "
+                         "over the N GPUs (RCCL all_to_all for the id buckets and rows), 4096 examples per GPU (global batch "
+                         "32 768 at N = 8); = --model deepfm --big-table-rows 100000000")
     ap.add_argument("--lazy-adam", action="store_true",
                     help="LazyAdamOptimizer on the embedding tables (rows without a gradient keep weights and moments): a "
                          "labelled DEVIATION from the reference's tf.train.AdamOptimizer (SURVEY.md §8f-1)")
@@ -65,7 +69,35 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-extra-models", action="store_true",
                     help="default run (--model dcn, N = 1): skip the DeepFM / xDeepFM / DIN lines appended under `models`")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.config5:
+        args.model = "deepfm"
+        args.big_table_rows = args.big_table_rows or 100_000_000
+    return args
+
+
+def self_launch(args) -> None:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): re-exec under
+    torch.distributed.run, one rank per GPU of this node, rendezvous on 127.0.0.1 — so the command is self-contained and
+    the line it prints says "n_gpus": N because N ranks really ran.  Fails loudly when the node has fewer than N GPUs
+    (RECALGO_DIST_BACKEND=gloo_staged, the bring-up mode in which ranks share devices, is exempt)."""
+    import socket
+    staged = os.environ.get("RECALGO_DIST_BACKEND", "nccl") == "gloo_staged"
+    have = torch.cuda.device_count()
+    if have < args.gpus and not staged:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this node exposes {have} HIP device(s); refusing to print a line for "
+                         f"{args.gpus} GPUs measured on fewer (set RECALGO_DIST_BACKEND=gloo_staged for the functional "
+                         "bring-up mode, whose numbers are not benchmark results)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs between processes on this stack
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execvpe(sys.executable, cmd, env)
 
 
 def build_estimator(args, device, rank=0, world=1, before_build=None):
@@ -164,6 +196,9 @@ def build_estimator(args, device, rank=0, world=1, before_build=None):
         raise SystemExit(f"--model {args.model}: unknown")
     if args.lazy_adam:
         params["lazy_adam"] = True
+    if args.big_table_rows:
+        workload += (f"; one {int(args.big_table_rows):,}-row table among the fields"
+                     + (f", rows sharded r % {world} (BASELINE.json configs[4])" if world > 1 else " (BASELINE.json configs[4] on one GPU)"))
     est = Estimator(model_fn=model_fn, params=params, config=RunConfig(device=device, seed=42))
     feats, labels, _ = synth.device_features(spec, args.batch, device, batch_index=rank)
     if before_build is not None:
@@ -699,13 +734,15 @@ def extra_model(a, name, steps, device):
 
 def main():
     args = parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)               # (does not return: the launcher's rank 0 prints the line)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line's n_gpus must be the number of ranks that ran")
     # RECALGO_DIST_BACKEND=gloo_staged: bring-up aid for boxes with fewer GPUs than ranks (ranks share
     # devices, collectives bounce through host memory; see parallel.HostStagedCollectives) — the
     # numbers it prints are not benchmark results.  Default: one rank per GPU over RCCL.

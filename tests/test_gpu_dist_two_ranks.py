@@ -132,3 +132,31 @@ def test_bench_two_rank_code_path(capacity_factor):
     assert "roofline" in out
     if capacity_factor == "0.1":
         assert re.search(r"overflow at capacity factor 0.1", r.stderr), r.stderr[-2000:]
+
+
+@pytest.mark.timeout(900)
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher around it (the shape of the driver's scaling command): bench.py
+    re-execs itself under torch.distributed.run and the line says n_gpus = 2 because two ranks ran.
+    On a 1-GPU test box the two ranks share the device through the host-staged bring-up collectives."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(RECALGO_DIST_BACKEND="gloo_staged", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "512", "--max-vocab", "20000",
+           "--data-batches", "3", "--no-tunable", "--no-cpu-baseline", "--no-kernel-timing", "--capacity-factor", "1.5"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 1024 and out["value"] > 0
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """Without the bring-up backend, asking for more GPUs than the node exposes is an error, not a 1-GPU line."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RECALGO_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "1", "--warmup", "1"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in r.stderr, (r.returncode, r.stderr[-1000:])
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
