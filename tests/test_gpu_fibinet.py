@@ -41,12 +41,12 @@ def test_senet_fwd_bwd(dev, B, F, K, ratio):
     v = torch.empty_like(Eg)
     a = torch.empty(B, F, device=dev)
     _lib.check(lib.recalgo_senet_fwd(_p(Eg), _p(w1g), _p(w2g), B, F, K, Rd, _p(v), _p(a), _st()), "senet fwd")
-    assert_close(v, ref, what="senet out", ref32=r32)
+    assert_close(v, ref, what="senet out", ref32=r32, strict_slack=4 * K)       # (one gate value scales K outputs)
     ws = torch.empty(lib.recalgo_senet_bwd_workspace_bytes(B, F, K, Rd), dtype=torch.uint8, device=dev)
     dE, dw1, dw2 = torch.empty_like(Eg), torch.empty_like(w1g), torch.empty_like(w2g)
     _lib.check(lib.recalgo_senet_bwd(_p(Eg), _p(w1g), _p(w2g), _p(gg), B, F, K, Rd, _p(dE), 0, _p(dw1), _p(dw2),
                                      _p(ws), _st()), "senet bwd")
-    assert_close(dE, Ed.grad, what="senet dE", ref32=Ef.grad)
+    assert_close(dE, Ed.grad, what="senet dE", ref32=Ef.grad, strict_slack=4 * K)
     assert_close(dw1, w1d.grad, what="senet dw1", reduced=True, ref32=w1f.grad)
     assert_close(dw2, w2d.grad, what="senet dw2", reduced=True, ref32=w2f.grad)
     # accumulate flag

@@ -46,7 +46,7 @@ def _record(what, a, ref, ref32=None):
     STRICT_LOG.append(rec)
 
 
-def assert_close(a, ref, rtol=RTOL, what="", reduced=False, floor=0.0, ref32=None):
+def assert_close(a, ref, rtol=RTOL, what="", reduced=False, floor=0.0, ref32=None, strict_slack=10):
     a = a.detach().double().cpu().reshape(-1)
     ref = ref.detach().double().cpu().reshape(-1)
     assert a.shape == ref.shape, f"{what}: shape {a.shape} vs {ref.shape}"
@@ -56,10 +56,12 @@ def assert_close(a, ref, rtol=RTOL, what="", reduced=False, floor=0.0, ref32=Non
         # regression guard: wherever the reference arithmetic's own fp32 rounding is known, the
         # HIP kernel may not leave materially more elements outside the STRICT §8c bound than the fp32 oracle does
         rec = STRICT_LOG[-1]
-        limit = 1.5 * rec["ref32_strict_fail"] + 10
+        # `strict_slack`: additive head room in ELEMENTS (default 10); outputs whose errors come in blocks (SENET scales a
+        # whole K-wide field row by one gate value) pass a few blocks' worth
+        limit = 1.5 * rec["ref32_strict_fail"] + strict_slack
         assert rec["strict_fail"] <= limit, (
             f"{what}: {rec['strict_fail']} elements outside the strict 1e-5*max(|a|,|b|,{STRICT_EPS:g}) bound, the fp32 "
-            f"oracle itself leaves {rec['ref32_strict_fail']} (limit 1.5x + 10 = {limit:.0f}): the kernel's summation is "
+            f"oracle itself leaves {rec['ref32_strict_fail']} (limit 1.5x + {strict_slack} = {limit:.0f}): the kernel's summation is "
             f"less accurate than the reference's fp32 arithmetic")
     rms = ref.pow(2).mean().sqrt() if ref.numel() else ref.new_zeros(())
     tol = rtol * (ref.abs() + rms)
