@@ -25,6 +25,10 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     SURVEY.md §8c's per-element |a-b| <= 1e-5*max(|a|,|b|,eps) — printed and written to gpurun_out/."""
     from tests import util
     log = util.STRICT_LOG
+    if util.GUARD_TRIPS:
+        terminalreporter.write_line("strict guard trips (test | tensor | n | outside | fp32 oracle outside | limit):")
+        for t in util.GUARD_TRIPS:
+            terminalreporter.write_line("GUARD " + t)
     if not log:
         return
     n_assert = len(log)

@@ -235,6 +235,11 @@ def test_model_step_at_baseline_config(dev, model):
     spec.loss.backward()
     grads = named_grads(est.store)
     tol_gs = {}
+    # strict guard: 1.5 x the fp32 oracle's count per tensor.  Two compositions get more room, measured and explained
+    # (profiles/r04*_strict*.md): FiBiNET's forward goes through the 9600-wide first layer on hipBLASLt, whose one long
+    # accumulation chain leaves ~3 x the rounding error of the oracle's blocked GEMM in every activation downstream (all
+    # gradients 3.0-3.5 x, uniformly); PNN's embedding gradients sum two K = 1024 dgrads (1.6 x)
+    factor = {"fibinet": 4.0, "pnn": 2.0}.get(model, 1.5)
     for name, p in P.items():
         if p.grad is None:
             continue
@@ -252,7 +257,7 @@ def test_model_step_at_baseline_config(dev, model):
             tol_gs[name] = tol_gs[name] + 1e-5 * scale
             continue
         # floor: 4x the deviation of the reference arithmetic itself in fp32 (batch sums of 4096 x up to 26 terms)
-        assert_close(grads[name], p.grad, what=f"{model} d({name})", reduced=True, floor=4 * noise, ref32=g32)
+        assert_close(grads[name], p.grad, what=f"{model} d({name})", reduced=True, floor=4 * noise, ref32=g32, strict_factor=factor)
 
     spec.train_op.optimizer.apply_gradients(est.store)
     after = est.store.named_arrays()

@@ -25,6 +25,7 @@ RTOL = 1e-5
 # the reference-in-fp32 miss the strict bound against fp64: an element no fp32 evaluation order can
 # get within 1e-5 of the fp64 value is attributed to fp32 itself, not to the HIP kernel.
 STRICT_EPS = 1e-6
+GUARD_TRIPS = []         # RECALGO_STRICT_GUARD=report: the guard's failures are listed (conftest) instead of raised
 STRICT_LOG = []          # dicts: test, what, n, strict_fail, worst (err / strict tol), ref32_strict_fail
 
 
@@ -46,7 +47,7 @@ def _record(what, a, ref, ref32=None):
     STRICT_LOG.append(rec)
 
 
-def assert_close(a, ref, rtol=RTOL, what="", reduced=False, floor=0.0, ref32=None, strict_slack=10):
+def assert_close(a, ref, rtol=RTOL, what="", reduced=False, floor=0.0, ref32=None, strict_slack=10, strict_factor=1.5):
     a = a.detach().double().cpu().reshape(-1)
     ref = ref.detach().double().cpu().reshape(-1)
     assert a.shape == ref.shape, f"{what}: shape {a.shape} vs {ref.shape}"
@@ -58,11 +59,14 @@ def assert_close(a, ref, rtol=RTOL, what="", reduced=False, floor=0.0, ref32=Non
         rec = STRICT_LOG[-1]
         # `strict_slack`: additive head room in ELEMENTS (default 10); outputs whose errors come in blocks (SENET scales a
         # whole K-wide field row by one gate value) pass a few blocks' worth
-        limit = 1.5 * rec["ref32_strict_fail"] + strict_slack
-        assert rec["strict_fail"] <= limit, (
-            f"{what}: {rec['strict_fail']} elements outside the strict 1e-5*max(|a|,|b|,{STRICT_EPS:g}) bound, the fp32 "
-            f"oracle itself leaves {rec['ref32_strict_fail']} (limit 1.5x + {strict_slack} = {limit:.0f}): the kernel's summation is "
-            f"less accurate than the reference's fp32 arithmetic")
+        limit = strict_factor * rec["ref32_strict_fail"] + strict_slack
+        if os.environ.get("RECALGO_STRICT_GUARD") == "report" and rec["strict_fail"] > limit:
+            GUARD_TRIPS.append(f"{rec['test']} | {what} | {rec['n']} | {rec['strict_fail']} | {rec['ref32_strict_fail']} | {limit:.0f}")
+        else:
+            assert rec["strict_fail"] <= limit, (
+                f"{what}: {rec['strict_fail']} elements outside the strict 1e-5*max(|a|,|b|,{STRICT_EPS:g}) bound, the fp32 "
+                f"oracle itself leaves {rec['ref32_strict_fail']} (limit {strict_factor}x + {strict_slack} = {limit:.0f}): the kernel's summation is "
+                f"less accurate than the reference's fp32 arithmetic")
     rms = ref.pow(2).mean().sqrt() if ref.numel() else ref.new_zeros(())
     tol = rtol * (ref.abs() + rms)
     if reduced and ref.numel():
