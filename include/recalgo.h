@@ -646,6 +646,8 @@ int recalgo_activation_bwd(const float* x, const float* alpha, const float* gy, 
 #define RECALGO_SCATTER_GRAD 0
 #define RECALGO_SCATTER_ADAM 1
 #define RECALGO_SCATTER_LAZY_ADAM 2
+#define RECALGO_PREPARE_COUNT 1      /* recalgo_scatter_prepare flags: add the source's entries to the plan's bucket totals */
+#define RECALGO_PREPARE_SWEEP 2      /* ... run this step's share of the deferred-Adam sweep of the arena(s) in the launch */
 typedef struct {
     const int64_t* ids;
     const int64_t* offsets;
@@ -655,6 +657,13 @@ typedef struct {
     const float* g;
     int64_t g_stride;
     int g_col, g_fmul;
+    /* FM second-order epilogue (DeepFM, deepfm.py:184-200; Appendix D "FM2"); fm_scale == NULL: none.  The gradient row of
+     * request (e, f) is  g[...] + fm_scale[e] * (fm_sum[e, 0:K] - fm_emb[e, f*K : (f+1)*K])  formed on load: fm_scale = the
+     * gradient of the second-order logit [n_ex], fm_sum = sum over the fields of the looked-up rows [n_ex, K], fm_emb = the
+     * looked-up rows themselves [n_ex, F*K] (both contiguous; 16-byte aligned for K % 4 == 0) */
+    const float* fm_scale;
+    const float* fm_sum;
+    const float* fm_emb;
 } recalgo_scatter_source_t;
 typedef struct {
     float* w; float* m; float* v;   /* [rows, K] */
@@ -694,13 +703,14 @@ int recalgo_deepfm_sparse_fwd_deferred(const int64_t* ids, const float* arena, c
 int recalgo_scatter_plan_buckets_log2(int64_t n_requests);
 int64_t recalgo_scatter_source_slots(int n_ex, int F, int ragged);
 int64_t recalgo_scatter_plan_workspace_bytes(int64_t n_slots, int nb_log2, int K);
+int64_t recalgo_scatter_plan_header_bytes(int nb_log2);
 int recalgo_scatter_prepare(const recalgo_scatter_source_t* source, int K, void* plan_workspace, int64_t plan_requests,
-                            int nb_log2, int64_t first_request, int lookup_index, const recalgo_deferred_adam_t* deferred,
-                            const recalgo_deferred_adam_t* companion_deferred, const int64_t* step_dev, int step_offset,
-                            recalgo_stream_t stream);
+                            int nb_log2, int64_t first_request, int flags, const recalgo_deferred_adam_t* deferred,
+                            const recalgo_deferred_adam_t* companion_deferred, int64_t rows, int64_t companion_rows,
+                            int sweep_period, const int64_t* step_dev, int step_offset, recalgo_stream_t stream);
 int recalgo_scatter_apply(const recalgo_scatter_source_t* sources, int n_sources, const recalgo_scatter_companion_t* companion,
                           int K, void* plan_workspace, int64_t plan_requests, int nb_log2, int mode, float* w, float* m,
-                          float* v, float* grad, const recalgo_deferred_adam_t* deferred, int64_t rows, int sweep_period,
+                          float* v, float* grad, const recalgo_deferred_adam_t* deferred, int64_t rows,
                           const recalgo_live_t* live, const int64_t* step_dev, int step_offset, float lr, float beta1,
                           float beta2, float eps, recalgo_stream_t stream);
 int recalgo_adam_deferred_sweep(const recalgo_deferred_adam_t* deferred, int K, int64_t row_begin, int64_t row_end,

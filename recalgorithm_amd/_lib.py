@@ -102,8 +102,9 @@ SIGNATURES = {
     "recalgo_scatter_plan_buckets_log2": (c_int, [c_int64]),
     "recalgo_scatter_plan_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
     "recalgo_scatter_source_slots": (c_int64, [c_int, c_int, c_int]),
-    "recalgo_scatter_prepare": (c_int, [P, c_int, P, c_int64, c_int, c_int64, c_int, P, P, P, c_int, P]),
-    "recalgo_scatter_apply": (c_int, [P, c_int, P, c_int, P, c_int64, c_int, c_int, P, P, P, P, P, c_int64, c_int, P, P, c_int,
+    "recalgo_scatter_plan_header_bytes": (c_int64, [c_int]),
+    "recalgo_scatter_prepare": (c_int, [P, c_int, P, c_int64, c_int, c_int64, c_int, P, P, c_int64, c_int64, c_int, P, c_int, P]),
+    "recalgo_scatter_apply": (c_int, [P, c_int, P, c_int, P, c_int64, c_int, c_int, P, P, P, P, P, c_int64, P, P, c_int,
                                       c_float, c_float, c_float, c_float, P]),
     "recalgo_adam_deferred_sweep": (c_int, [P, c_int, c_int64, c_int64, P, c_int, P]),
 }

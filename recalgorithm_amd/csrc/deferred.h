@@ -1,7 +1,15 @@
-// Deferred exact TF1 Adam (see sparse.hip): the pieces shared by the optimizer kernels (sparse.hip) and the forward
-// lookups (embed.hip).  A row whose state is valid for step s < target takes the g = 0 updates of steps s+1 .. target:
-//     m = b1 * m;  v = b2 * v;  w -= lr_t(j) * m / (sqrt(v) + eps)
-// with exactly the fp32 operations of the dense pass (recalgo_adam_tf1_dense / _step), so the replay is bit-identical to it.
+// TF1 Adam on one element, and the deferred-exact form of its dense semantics (see sparse.hip): the pieces shared by the
+// optimizer kernels (sparse.hip, tail.hip) and the forward lookups (embed.hip).
+//
+// The update (tf.train.AdamOptimizer; /root/reference algorithm/DeepFM/deepfm.py:246-250):
+//     m = b1 * m + (1 - b1) * g;  v = b2 * v + (1 - b2) * g * g;  p -= lr_t * m / (sqrt(v) + eps)
+// is evaluated as  p = fma(-(lr_t * m), rcp(sqrt(v) + eps), p)  with the hardware's v_sqrt_f32 / v_rcp_f32 (1 ulp each;
+// the step is within 3 ulp of the correctly rounded quotient, i.e. ~4e-7 relative on a quantity that moves p by ~lr —
+// far inside the 1e-5 the parity tests hold an Adam step to).  Why not IEEE division and sqrt: a row whose state is valid
+// for step s < target takes the g = 0 updates of steps s+1 .. target one after the other (no closed form reproduces the
+// fp32 roundings of the dense pass), and the correctly rounded forms cost 45 instructions per replayed step against 9 —
+// the replay of a DCN batch's ~35 k lagging rows was 12 us of pure VALU time per step.  EVERY Adam update of the
+// library goes through adam1(), so the deferred form stays bit-identical to the dense pass (tests/test_gpu_sparse.py).
 #pragma once
 #include "common.h"
 
@@ -12,7 +20,7 @@ constexpr unsigned kLrRing = RECALGO_LR_RING;           // power of two
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float lr_t, float b1, float b2, float eps) {
     m = fmaf(b1, m, (1.f - b1) * g);
     v = fmaf(b2, v, (1.f - b2) * g * g);
-    p -= lr_t * m / (sqrtf(v) + eps);
+    p = fmaf(-(lr_t * m), __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + eps), p);
 }
 __device__ __forceinline__ void vadam(float4& p, const float4 g, float4& m, float4& v, float lr_t, float b1, float b2, float eps) {
     adam1(p.x, g.x, m.x, v.x, lr_t, b1, b2, eps);
@@ -32,15 +40,37 @@ __device__ __forceinline__ void replay(V& w, V& m, V& v, int s, int target, cons
     for (int j = s + 1; j <= target; ++j)
         vadam(w, vzero(static_cast<const V*>(nullptr)), m, v, lr_ring[(unsigned)j & (kLrRing - 1)], b1, b2, eps);
 }
-// the same for one float, with the two addends of adam1 that vanish for g = 0 evaluated once: (1 - b1) * 0 and
-// (1 - b2) * 0 * 0 are the SAME values adam1 forms each step, so every fma below has adam1's operands bit for bit
 __device__ __forceinline__ void replay1(float& w, float& m, float& v, int s, int target, const float* lr_ring, float b1, float b2, float eps) {
-    const float z = 0.f;
-    const float c1 = (1.f - b1) * z, c2 = (1.f - b2) * z * z;
-    for (int j = s + 1; j <= target; ++j) {
-        m = fmaf(b1, m, c1);
-        v = fmaf(b2, v, c2);
-        w -= lr_ring[(unsigned)j & (kLrRing - 1)] * m / (sqrtf(v) + eps);
+    replay<float>(w, m, v, s, target, lr_ring, b1, b2, eps);
+}
+
+// The replay of a whole WAVE's rows: every lane brings (w, m, v) from its own s to `target` (s >= target: nothing to do).
+// The step index runs wave-uniformly from the smallest s of the wave — so lr_t(j) is ONE scalar per iteration, read from a
+// window of the ring held one entry per lane (v_readlane: no memory access inside the loop) — and a lane joins in when
+// the loop reaches its own s.  Same operations in the same order as replay(): bit-identical.
+struct LrWindow {
+    float win;             // lane i: lr_t(w0 + i)
+    int w0;
+};
+__device__ __forceinline__ LrWindow lr_window(const float* lr_ring, int target) {
+    LrWindow W;
+    W.w0 = target - 63;
+    const int j = W.w0 + (int)(threadIdx.x & 63);
+    W.win = j >= 1 ? lr_ring[(unsigned)j & (kLrRing - 1)] : 0.f;
+    return W;
+}
+__device__ __forceinline__ int wave_min_int(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ void replay_wave(float& w, float& m, float& v, int s, int target, const LrWindow& W, const float* lr_ring,
+                                            float b1, float b2, float eps) {
+    const int smin = __builtin_amdgcn_readfirstlane(wave_min_int(s < target ? s : target));
+    for (int j = smin + 1; j <= target; ++j) {
+        const float lr = j >= W.w0 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, W.win), j - W.w0))
+                                   : lr_ring[(unsigned)j & (kLrRing - 1)];
+        if (j > s) adam1(w, 0.f, m, v, lr, b1, b2, eps);
     }
 }
 

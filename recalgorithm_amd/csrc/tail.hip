@@ -1,5 +1,5 @@
 // Loss tail (a14), TF1 Adam (a15), DIN activations (a12) — small streaming kernels, gfx950.
-#include "common.h"
+#include "deferred.h"
 
 namespace {
 
@@ -43,12 +43,8 @@ __global__ __launch_bounds__(1024) void sigmoid_ce_kernel(
 // ---------------------------------------------------------------------------------------
 // TF1 Adam, dense.  Pure stream: 4 reads + 3 writes (+ sparse zeroing of g) per element.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void adam1(float& p, float& g, float& m, float& v, float lr_t, float b1,
-                                      float b2, float eps) {
-    m = fmaf(b1, m, (1.f - b1) * g);
-    v = fmaf(b2, v, (1.f - b2) * g * g);
-    p -= lr_t * m / (sqrtf(v) + eps);
-}
+// (the update itself: deferred.h adam1 — shared with the sparse optimizer so that the deferred form stays bit-identical)
+using recalgo_deferred::adam1;
 
 __global__ __launch_bounds__(256) void adam_tf1_kernel(float* __restrict__ p, float* __restrict__ g,
                                                        float* __restrict__ m, float* __restrict__ v,

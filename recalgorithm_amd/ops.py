@@ -323,13 +323,29 @@ class _DeepFMSparseFn(Function):
         emb, fsum = ctx.saved_tensors
         B, F = ids.shape
         g_emb, g_fm1, g_fm2 = g_emb.contiguous(), g_fm1.contiguous(), g_fm2.contiguous()
-        if ctx.src is not None and ctx.src1 is not None:
+        if ctx.src is not None or ctx.src1 is not None:
+            # owner-computes path (sparse.py).  The second-order term's gradient g_emb + g_fm2 * (S - e) (Appendix D "FM2") is
+            # the EPILOGUE of the embedding lookup's source: `place` / `apply` form it on load — no [B, F, K] tensor, no
+            # elementwise launches.  An arena that is NOT on the owner path (frozen, or an unsupported width) while the
+            # other one is keeps the deterministic sorted scatter for itself.
             K = arena.K
-            e3, s3 = emb.reshape(B, F, K), fsum.reshape(B, 1, K)
-            vals = torch.addcmul(g_emb.reshape(B, F, K), g_fm2.reshape(B, 1, 1), s3 - e3)     # g_emb + g_fm2 * (S - e)
-            ctx.src.set_grad(vals)
-            ctx.src1.set_grad(g_fm1.reshape(B, 1), fmul=0)      # every field of example b adds g_fm1[b] to its w1 row
-            torch.sum(g_fm1, dim=0, out=bias.grad.view(1))
+            rows = None
+            if ctx.src is not None:
+                ctx.src.set_grad(g_emb, fm=(g_fm2.reshape(B), fsum, emb))
+            elif getattr(arena, "trainable", True):
+                rows = torch.where(ids >= 0, ids + row_base.unsqueeze(0), torch.full_like(ids, -1))
+                e3, s3 = emb.reshape(B, F, K), fsum.reshape(B, 1, K)
+                scatter_rows_sorted(arena, rows, torch.addcmul(g_emb.reshape(B, F, K), g_fm2.reshape(B, 1, 1), s3 - e3))
+                _flush(arena)
+            if ctx.src1 is not None:
+                ctx.src1.set_grad(g_fm1.reshape(B, 1), fmul=0)      # every field of example b adds g_fm1[b] to its w1 row
+            elif getattr(w1, "trainable", True):
+                if rows is None:
+                    rows = torch.where(ids >= 0, ids + row_base.unsqueeze(0), torch.full_like(ids, -1))
+                scatter_rows_sorted(w1, rows, g_fm1.reshape(B, 1, 1).expand(B, F, 1))
+                _flush(w1)
+            if not colsum_of_dlogit(g_fm1, bias.grad.view(1)):      # (TRAIN step: a job of the step's deferred-sum launch)
+                torch.sum(g_fm1, dim=0, out=bias.grad.view(1))
             return None, None, None, None, None, None, None
         if _sorted_scatter():
             K = arena.K
@@ -1321,6 +1337,8 @@ class _LogitLossFn(Function):
         if bias is not None:
             _colsum_pending.append((partials, C, rows, C + 2, 1, bias.grad))
         _colsum_pending.append((partials, C + 1, rows, C + 2, 1, loss))
+        _dlogit_partials.clear()                     # sum_b dlogit[b] = column C of the partial rows (colsum_of_dlogit)
+        _dlogit_partials[dlogit.data_ptr()] = (partials, C, rows, C + 2, B)
         ctx.dxs, ctx.dlogit, ctx.n_addends = dxs, dlogit, n_addends
         ctx.mark_non_differentiable(prob, logit)
         return loss.view(()), prob, logit
@@ -1331,6 +1349,20 @@ class _LogitLossFn(Function):
             return (None,) * (6 + len(ctx.dxs) + ctx.n_addends)
         # the seed was baked into dlogit / dx by the forward launch (the caller promises to seed backward with it)
         return (None, None, None, None, None, None, *ctx.dxs, *([ctx.dlogit] * ctx.n_addends))
+
+
+_dlogit_partials = {}
+
+
+def colsum_of_dlogit(g: torch.Tensor, out: torch.Tensor) -> bool:
+    """out[0] = sum_b g[b] as ONE MORE JOB of the step's deferred-sum launch, when g is the d(loss)/d(logit) vector the fused
+    loss tail produced (a logit addend's gradient, e.g. DeepFM's first-order logit -> its bias): the tail's partial rows
+    already hold the per-workgroup sums.  False: g is something else — the caller sums it itself."""
+    e = _dlogit_partials.get(g.data_ptr())
+    if e is None or g.numel() != e[4] or not g.is_contiguous():
+        return False
+    _colsum_pending.append((e[0], e[1], e[2], e[3], 1, out))
+    return True
 
 
 def logit_loss_supported(parts, addends) -> bool:

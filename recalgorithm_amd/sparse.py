@@ -2,9 +2,10 @@
 atomics, fused with the sparse optimizer) and the deferred-exact TF1 Adam state.
 
     forward of a lookup   begin_lookup(arena, ...)    registers the lookup's requests as a `Source`, launches
-                                                      recalgo_scatter_prepare (bucket counts + catch-up of the rows)
+                                                      recalgo_scatter_prepare (ONE launch: bucket counts, catch-up of the
+                                                      lookup's lagging rows, the step's share of the deferred-Adam sweep)
     backward of a lookup  Source.set_grad(g)          records where the per-request gradient rows are
-    optimizer             apply(arena, mode, ...)     recalgo_scatter_apply over all sources of the arena: TF1 Adam with
+    optimizer             apply(arena, mode, ...)     recalgo_scatter_apply (two launches: place, apply) over all sources of the arena: TF1 Adam with
                                                       dense semantics evaluated lazily but exactly (tf.train.AdamOptimizer,
                                                       /root/reference algorithm/DeepFM/deepfm.py:246-250) or
                                                       tf.contrib.opt.LazyAdamOptimizer (algorithm/DIEN/dien.py:328)
@@ -27,6 +28,7 @@ import torch
 from . import _lib
 
 MODE_GRAD, MODE_ADAM, MODE_LAZY_ADAM = 0, 1, 2
+PREPARE_COUNT, PREPARE_SWEEP = 1, 2          # include/recalgo.h RECALGO_PREPARE_*
 MAX_SOURCES = 16
 LR_RING = 1024
 
@@ -51,7 +53,8 @@ def sweep_period() -> int:
 class _CSource(ctypes.Structure):            # include/recalgo.h recalgo_scatter_source_t
     _fields_ = [("ids", ctypes.c_void_p), ("offsets", ctypes.c_void_p), ("row_base", ctypes.c_void_p), ("base", ctypes.c_int64),
                 ("n_ex", ctypes.c_int), ("F", ctypes.c_int), ("g", ctypes.c_void_p), ("g_stride", ctypes.c_int64),
-                ("g_col", ctypes.c_int), ("g_fmul", ctypes.c_int)]
+                ("g_col", ctypes.c_int), ("g_fmul", ctypes.c_int),
+                ("fm_scale", ctypes.c_void_p), ("fm_sum", ctypes.c_void_p), ("fm_emb", ctypes.c_void_p)]
 
 
 class _CCompanion(ctypes.Structure):         # include/recalgo.h recalgo_scatter_companion_t
@@ -72,6 +75,7 @@ class Source:
         self.arena = None                      # set by begin_lookup
         self.g = None
         self.g_stride = self.g_col = self.g_fmul = 0
+        self.fm = None                         # FM second-order epilogue: (g_fm2 [n_ex], field sum [n_ex, K], embeddings [n_ex, F*K])
         self.caught_up = True                  # the lookup's rows are current when its forward kernel runs
         self.companion: Optional["CompanionSource"] = None     # a one-float-per-row arena looked up with the same requests
 
@@ -88,9 +92,16 @@ class Source:
         pad = lambda x: (x + 255) // 256 * 256
         return pad(self.n) if self.offsets is not None else pad(self.n_ex) * self.F
 
-    def set_grad(self, g: torch.Tensor, fmul: Optional[int] = None):
+    def set_grad(self, g: torch.Tensor, fmul: Optional[int] = None, fm=None):
         """g: [n_ex, F * K] / [n_ex, F, K] / [n_ex, K'] with the last dimension contiguous; request (e, f) reads its K
-        floats at g[e].flat[f * fmul : f * fmul + K] (fmul defaults to K = row width; 0: all fields share the row)."""
+        floats at g[e].flat[f * fmul : f * fmul + K] (fmul defaults to K = row width; 0: all fields share the row).
+        fm = (scale [n_ex], field_sum [n_ex, K], emb [n_ex, F * K]): the request's gradient row is
+        g + scale[e] * (field_sum[e] - emb[e, f]), formed by the kernels on load (DeepFM's second-order term)."""
+        self.fm = None
+        if fm is not None:
+            sc, fs, em = (t.contiguous() for t in fm)
+            assert sc.numel() == self.n_ex and fs.numel() * self.F == em.numel()
+            self.fm = (sc, fs, em)
         if g.dim() == 3:
             g = g.reshape(g.shape[0], -1) if g.is_contiguous() else g.contiguous().view(g.shape[0], -1)
         if g.dim() != 2 or (g.shape[1] > 1 and g.stride(1) != 1) or g.shape[0] != self.n_ex:
@@ -103,8 +114,9 @@ class Source:
     def c_struct(self, K: int) -> _CSource:
         p = lambda t: None if t is None else t.data_ptr()
         fm = K if self.g_fmul is None else int(self.g_fmul)
+        fs = self.fm if self.fm is not None else (None, None, None)
         return _CSource(p(self.ids), p(self.offsets), p(self.row_base), self.base, self.n_ex, self.F, p(self.g),
-                        self.g_stride, self.g_col, fm)
+                        self.g_stride, self.g_col, fm, p(fs[0]), p(fs[1]), p(fs[2]))
 
 
 class CompanionSource:
@@ -135,7 +147,8 @@ class CompanionSource:
     def c_struct(self) -> _CSource:
         m = self.main
         p = lambda t: None if t is None else t.data_ptr()
-        return _CSource(p(m.ids), p(m.offsets), p(m.row_base), m.base, m.n_ex, m.F, p(self.g), self.g_stride, self.g_col, self.g_fmul)
+        return _CSource(p(m.ids), p(m.offsets), p(m.row_base), m.base, m.n_ex, m.F, p(self.g), self.g_stride, self.g_col, self.g_fmul,
+                        None, None, None)
 
 
 class ArenaPlan:
@@ -147,7 +160,8 @@ class ArenaPlan:
         self.ws: Optional[torch.Tensor] = None
         self.capacity = 0                      # requests the workspace was sized for
         self.nb_log2 = 10
-        self.counted = None                    # signature of what the workspace's bucket counts currently hold
+        self.counted = None                    # signature of what the workspace's bucket totals currently hold
+        self.swept = False                     # this step's share of the deferred-Adam sweep has been launched
         self.last_step: Optional[torch.Tensor] = None     # deferred-Adam: int32 [rows]
         self.lr_ring: Optional[torch.Tensor] = None
         self.betas = (0.9, 0.999, 1e-8)
@@ -167,8 +181,14 @@ class ArenaPlan:
         self.capacity = cap
         nbytes = int(lib.recalgo_scatter_plan_workspace_bytes(cap, self.nb_log2, self.arena.K))
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.arena.weight.device)
-        self.ws[:64].zero_()                   # the per-lookup claim counters (kept clean by the kernels afterwards)
-        self.counted = None
+        self.header = int(lib.recalgo_scatter_plan_header_bytes(self.nb_log2))
+        self.clear_counts()
+
+    def clear_counts(self):
+        """Bucket totals and cursors back to zero (`apply` leaves them that way; needed on a fresh workspace and whenever
+        counted sources are dropped without having been applied)."""
+        self.ws[:self.header].zero_()
+        self.counted = (self.ws.data_ptr(), self.nb_log2, ())
 
     def _signature(self, sources):
         return (self.ws.data_ptr(), self.nb_log2, tuple(id(s) for s in sources))
@@ -221,7 +241,7 @@ def begin_lookup(arena, store, ids: torch.Tensor, offsets: Optional[torch.Tensor
                  base: int, n_ex: int, F: int, training: Optional[bool] = None, companion_arena=None) -> Optional[Source]:
     """Called by a lookup's forward in TRAIN mode.  Returns the Source to attach the gradient to (owner mode), or None.
     Launches recalgo_scatter_prepare: the lookup's tiles are counted into the arena's plan and — deferred Adam — its
-    rows are brought up to date.  (Lookups that are NOT registered — EVAL / PREDICT — read lagging rows through
+    lagging rows are brought up to date (and the arena's share of the sweep runs).  (Lookups that are NOT registered — EVAL / PREDICT — read lagging rows through
     deferred_view instead: replayed in registers, nothing written.)"""
     plan = plan_of(arena)
     if training is None:                       # (inside an autograd Function's forward grad mode is always off: callers
@@ -240,22 +260,32 @@ def begin_lookup(arena, store, ids: torch.Tensor, offsets: Optional[torch.Tensor
         return src
     lib = _lib.load()
     first = sum(s.slots for s in plan.sources)
-    plan._ensure_ws(first + src.slots)
+    if plan.ws is None or first + src.slots > plan.capacity:
+        # (a re-sized workspace starts with clean totals: the sources already counted are counted again by the optimizer's call)
+        plan._ensure_ws(first + src.slots)
     if plan.counted is None or plan.counted[:2] != (plan.ws.data_ptr(), plan.nb_log2):
-        plan.counted = (plan.ws.data_ptr(), plan.nb_log2, ())
+        plan.clear_counts()
     cs = src.c_struct(arena.K)
-    # deferred Adam: the launch also brings the lookup's distinct rows up to date (once per row, written back), so that the
-    # forward kernel that follows — and `apply` at the end of the step — find them current
-    idx = len(plan.sources)
-    d = plan._deferred_struct() if idx < MAX_SOURCES else None     # (one catch-up list per lookup; later lookups of a model
-    src.caught_up = d is not None or plan.last_step is None        #  that makes more than 16 read lagging rows through the view)
+    # deferred Adam: the launch also brings the lookup's lagging rows up to date (claimed once per row, written back), so that
+    # the forward kernel that follows — and `apply` at the end of the step — find them current; the first lookup of an arena
+    # in a step carries the step's share of the sweep
+    d = plan._deferred_struct()
+    src.caught_up = True
     step = None if d is None else store.opt_state["step"]
-    d1 = None
+    d1, c_rows = None, 0
     if companion_arena is not None and _pair(src, arena, companion_arena) and d is not None:
-        d1 = plan_of(companion_arena)._deferred_struct()          # (the second arena's rows are caught up by the same launch)
+        cp = plan_of(companion_arena)
+        d1 = cp._deferred_struct()             # (the second arena's rows are caught up, and swept, by the same launch)
+        c_rows = companion_arena.weight.shape[0] if d1 is not None else 0
+    flags = PREPARE_COUNT
+    if d is not None and not plan.swept:
+        flags |= PREPARE_SWEEP
+        plan.swept = True
+        if d1 is not None:
+            plan_of(companion_arena).swept = True
     _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), arena.K, ctypes.c_void_p(plan.ws.data_ptr()), plan.capacity, plan.nb_log2,
-                                           first, min(idx, MAX_SOURCES - 1), None if d is None else ctypes.byref(d),
-                                           None if d1 is None else ctypes.byref(d1),
+                                           first, flags, None if d is None else ctypes.byref(d),
+                                           None if d1 is None else ctypes.byref(d1), arena.weight.shape[0], c_rows, sweep_period(),
                                            None if step is None else ctypes.c_void_p(step.data_ptr()), 0, _stream(arena.weight)),
                "recalgo_scatter_prepare")
     plan.sources.append(src)
@@ -319,10 +349,9 @@ def new_forward(store) -> None:
             plan.grad_materialized = False
         if plan is not None and plan.sources:
             plan.sources = []
-            plan.counted = None
             plan.grad_materialized = False
-            if plan.ws is not None:
-                plan.ws[:64].zero_()           # (the abandoned forward's catch-up lists: normally cleared by the optimizer launch)
+            if plan.ws is not None and plan.counted is not None and plan.counted[2]:
+                plan.clear_counts()            # (the abandoned forward's entries: normally consumed and cleared by `apply`)
 
 
 def has_work(arena) -> bool:
@@ -376,13 +405,16 @@ def _run(plan: ArenaPlan, sources: List[Source], mode: int, step_dev, step_offse
     srcs = [s for s in sources if s.n]
     plan._ensure_ws(sum(s.slots for s in srcs))
     if plan.counted != plan._signature(srcs):
-        # the counts in the workspace are not those of exactly these sources (first step, a forward without a backward, a
+        # the totals in the workspace are not those of exactly these sources (first step, a forward without a backward, a
         # GRAD pass before the optimizer, a re-sized workspace): count again
+        if plan.counted is None or plan.counted[2] or plan.counted[:2] != (plan.ws.data_ptr(), plan.nb_log2):
+            plan.clear_counts()
         first = 0
         for s in srcs:
             cs = s.c_struct(a.K)
             _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), a.K, ctypes.c_void_p(plan.ws.data_ptr()), plan.capacity,
-                                                   plan.nb_log2, first, 0, None, None, None, 0, _stream(a.weight)), "recalgo_scatter_prepare")
+                                                   plan.nb_log2, first, PREPARE_COUNT, None, None, 0, 0, 1, None, 0, _stream(a.weight)),
+                       "recalgo_scatter_prepare")
             first += s.slots
     if not srcs:                               # (the sweep and the lr ring still need the launch)
         dummy = Source(a.weight, None, None, 0, 0, 1)
@@ -390,6 +422,21 @@ def _run(plan: ArenaPlan, sources: List[Source], mode: int, step_dev, step_offse
         srcs = [dummy]
     arr = (_CSource * len(srcs))(*[s.c_struct(a.K) for s in srcs])
     d = plan._deferred_struct() if mode == MODE_ADAM else None
+    if d is not None and not plan.swept:
+        # no lookup's launch carried this step's share of the sweep (a step without a TRAIN lookup into the arena, or the
+        # arena's first deferred step): its own launch, up to the step before this one
+        dc0 = None
+        if comp_arena is not None and plan_of(comp_arena).last_step is not None and not plan_of(comp_arena).swept:
+            dc0 = plan_of(comp_arena)._deferred_struct()
+        _lib.check(lib.recalgo_scatter_prepare(None, a.K, ctypes.c_void_p(plan.ws.data_ptr()), plan.capacity, plan.nb_log2, 0,
+                                               PREPARE_SWEEP, ctypes.byref(d), None if dc0 is None else ctypes.byref(dc0),
+                                               a.weight.shape[0], comp_arena.weight.shape[0] if dc0 is not None else 0, sweep_period(),
+                                               ctypes.c_void_p(step_dev.data_ptr()), step_offset - 1, _stream(a.weight)),
+                   "recalgo_scatter_prepare (sweep)")
+        if dc0 is not None:
+            plan_of(comp_arena).swept = True
+    if mode != MODE_GRAD:
+        plan.swept = False                     # (the next step's first lookup sweeps again)
     b1, b2, eps = plan.betas
     p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
     comp = None
@@ -419,13 +466,14 @@ def _run(plan: ArenaPlan, sources: List[Source], mode: int, step_dev, step_offse
     _lib.check(lib.recalgo_scatter_apply(arr, len(srcs), None if comp is None else ctypes.byref(comp), a.K, p(plan.ws), plan.capacity,
                                          plan.nb_log2, mode, p(a.weight), p(a.m), p(a.v), p(grad),
                                          None if d is None else ctypes.byref(d), a.weight.shape[0],
-                                         sweep_period(), live, p(step_dev), step_offset, lr, b1, b2, eps, _stream(a.weight)),
+                                         live, p(step_dev), step_offset, lr, b1, b2, eps, _stream(a.weight)),
                "recalgo_scatter_apply")
     if comp_arena is not None and mode != MODE_GRAD:
         cp.companions = []
         cp.grad_materialized = False
         cp.served = True
-    plan.counted = plan._signature([])         # (the next step's `prepare` launches overwrite their rows of the count matrix)
+        cp.swept = False
+    plan.counted = plan._signature([])         # (`apply` left the totals clean: the next step's `prepare` launches add to zero)
 
 
 def _companion_arena(sources: List[Source], mode: int):
@@ -536,4 +584,5 @@ def reset(arena) -> None:
         plan.last_step = None
         plan.sources = []
         plan.counted = None
+        plan.swept = False
         plan.grad_materialized = False

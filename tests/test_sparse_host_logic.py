@@ -22,13 +22,19 @@ class _FakeLib:
     def recalgo_scatter_plan_workspace_bytes(self, n, l, K):
         return 4096 + 64 * int(n)
 
-    def recalgo_scatter_prepare(self, src, K, ws, cap, nb, first, idx, deferred, comp_deferred, step, off, stream):
-        s = ctypes.cast(src, ctypes.POINTER(sparse._CSource)).contents if not isinstance(src, sparse._CSource) else src
-        self.calls.append(("prepare", {"K": K, "first": int(first), "lookup": int(idx), "deferred": deferred is not None,
-                                       "companion_deferred": comp_deferred is not None, "n_ex": s.n_ex, "F": s.F}))
+    def recalgo_scatter_plan_header_bytes(self, l):
+        return 64 + 8 * (1 << int(l))
+
+    def recalgo_scatter_prepare(self, src, K, ws, cap, nb, first, flags, deferred, comp_deferred, rows, comp_rows, period, step,
+                                off, stream):
+        n_ex, F = (src.n_ex, src.F) if src is not None else (0, 0)
+        self.calls.append(("prepare", {"K": K, "first": int(first), "count": bool(flags & sparse.PREPARE_COUNT),
+                                       "sweep": bool(flags & sparse.PREPARE_SWEEP), "deferred": deferred is not None,
+                                       "companion_deferred": comp_deferred is not None, "n_ex": n_ex, "F": F,
+                                       "rows": int(rows), "step_offset": int(off)}))
         return 0
 
-    def recalgo_scatter_apply(self, arr, n, comp, K, ws, cap, nb, mode, w, m, v, grad, deferred, rows, period, live, step, off,
+    def recalgo_scatter_apply(self, arr, n, comp, K, ws, cap, nb, mode, w, m, v, grad, deferred, rows, live, step, off,
                               lr, b1, b2, eps, stream):
         self.calls.append(("apply", {"n_sources": int(n), "companion": comp is not None, "K": K, "mode": int(mode),
                                      "deferred": deferred is not None, "grad": grad is not None, "rows": int(rows),
@@ -93,22 +99,27 @@ def test_lookups_join_one_plan_and_the_optimizer_applies_them_once(lib):
         sparse.apply(E, False, st.opt_state["step"], 0.01, 0.9, 0.999, 1e-8)
 
     # first step: the workspace grows with the second lookup (grow-only), which invalidates the first lookup's counts — the
-    # optimizer call takes them again
+    # optimizer call takes them again; no lookup's launch could carry the sweep (no optimizer state yet): its own launch,
+    # up to the step before this one
     step()
     kinds = [c[0] for c in lib.calls]
-    assert kinds == ["prepare", "prepare", "prepare", "prepare", "apply"]
+    assert kinds == ["prepare", "prepare", "prepare", "prepare", "prepare", "apply"]
     assert lib.calls[0][1]["first"] == 0 and lib.calls[1][1]["first"] == 5 * 512        # second source after the first's slots
-    assert (lib.calls[0][1]["lookup"], lib.calls[1][1]["lookup"]) == (0, 1)
+    assert all(c[1]["count"] and not c[1]["sweep"] for c in lib.calls[:4])
     assert not lib.calls[0][1]["deferred"]                                              # no optimizer state before the first step
+    sw = lib.calls[4][1]
+    assert sw["sweep"] and not sw["count"] and sw["n_ex"] == 0 and sw["deferred"] and sw["rows"] == 100 and sw["step_offset"] == -1
     a = lib.calls[-1][1]
     assert a["n_sources"] == 2 and a["mode"] == sparse.MODE_ADAM and a["deferred"] and not a["companion"]
     plan = sparse.plan_of(E)
     assert plan.sources == [] and plan.last_step is not None and int(plan.last_step.max()) == 0     # fresh arena: no row has state
-    # steady state: one prepare per lookup (each also bringing lagging rows up to date), one apply, no recount
+    # steady state: ONE launch per lookup (counts + catch-up of its lagging rows; the arena's first lookup of the step also
+    # carries the sweep), then the optimizer's place + apply: three launches for a one-lookup model, no recount
     n0 = len(lib.calls)
     step()
     assert [c[0] for c in lib.calls[n0:]] == ["prepare", "prepare", "apply"]
-    assert all(c[1]["deferred"] for c in lib.calls[n0:n0 + 2])
+    assert all(c[1]["deferred"] and c[1]["count"] for c in lib.calls[n0:n0 + 2])
+    assert [c[1]["sweep"] for c in lib.calls[n0:n0 + 2]] == [True, False]
 
 
 def test_lookups_outside_training_are_not_registered(lib):
@@ -169,8 +180,9 @@ def test_companion_is_dissolved_when_the_arena_is_also_looked_up_alone(lib):
     assert not lib.calls[-1][1]["companion"]
     n0 = len(lib.calls)
     sparse.apply(W, False, st.opt_state["step"], 0.01, 0.9, 0.999, 1e-8)
-    kinds = [c[0] for c in lib.calls[n0:]]
-    assert kinds == ["prepare", "prepare", "apply"] and lib.calls[-1][1]["n_sources"] == 2     # both lookups of W, recounted
+    kinds = [(c[0], c[1].get("count"), c[1].get("sweep")) for c in lib.calls[n0:]]
+    assert kinds == [("prepare", True, False), ("prepare", True, False), ("prepare", False, True), ("apply", None, None)]
+    assert lib.calls[-1][1]["n_sources"] == 2                                                  # both lookups of W, recounted
     assert sorted(x[:2] for x in lib.calls[-1][1]["sources"]) == [(10, 1), (64, 2)]
 
 
@@ -194,8 +206,7 @@ def test_more_lookups_than_sources_are_merged(lib):
     srcs = [sparse.begin_lookup(E, st, _ids(8, 1, seed=i), None, None, 0, 8, 1, True) for i in range(20)]
     for s in srcs:
         s.set_grad(torch.ones(8, 4))
-    assert [c[1]["lookup"] for c in lib.calls][-1] == sparse.MAX_SOURCES - 1             # claim lists: the last one is shared
-    assert not srcs[-1].caught_up or sparse.plan_of(E).last_step is None
+    assert all(s_.caught_up for s_ in srcs)                                              # every lookup's launch catches its rows up
     st.opt_state["step"] += 1
     sparse.apply(E, False, st.opt_state["step"], 0.01, 0.9, 0.999, 1e-8)
     a = lib.calls[-1][1]
@@ -215,7 +226,8 @@ def test_gradient_arena_on_request_then_optimizer(lib):
     assert sum(c[0] == "apply" for c in lib.calls) == 1
     st.opt_state["step"] += 1
     sparse.apply(E, False, st.opt_state["step"], 0.01, 0.9, 0.999, 1e-8)
-    assert [c[0] for c in lib.calls[-2:]] == ["prepare", "apply"] and lib.calls[-1][1]["grad"]
+    tail = [(c[0], c[1].get("count"), c[1].get("sweep")) for c in lib.calls[-3:]]
+    assert tail == [("prepare", True, False), ("prepare", False, True), ("apply", None, None)] and lib.calls[-1][1]["grad"]
 
 
 def test_whole_table_readers_flush_the_deferred_state(lib):
