@@ -648,6 +648,7 @@ int recalgo_activation_bwd(const float* x, const float* alpha, const float* gy, 
 #define RECALGO_SCATTER_LAZY_ADAM 2
 #define RECALGO_PREPARE_COUNT 1      /* recalgo_scatter_prepare flags: add the source's entries to the plan's bucket totals */
 #define RECALGO_PREPARE_SWEEP 2      /* ... run this step's share of the deferred-Adam sweep of the arena(s) in the launch */
+#define RECALGO_PREPARE_CATCHUP 4    /* ... bring the source's lagging rows (and the companion's) up to date: needs `deferred` */
 typedef struct {
     const int64_t* ids;
     const int64_t* offsets;

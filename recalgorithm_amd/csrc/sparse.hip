@@ -57,7 +57,7 @@ constexpr unsigned kMaxSeg = kThreads;                  // rows (segments) of a 
 constexpr unsigned kSlots = 512;                        // LDS hash of the distinct keys of a tile
 constexpr unsigned kLongSeg = 48;                       // entries per row above which the whole workgroup sums it
 constexpr unsigned kMaxLong = 64;                       // long rows remembered per bucket (more: summed by one group)
-constexpr unsigned kCatchReq = 64;                      // requests per catch-up workgroup
+constexpr unsigned kCatchReq = 128;                     // requests per catch-up workgroup
 constexpr unsigned long long kPadKey = ~0ull;
 constexpr unsigned kEmptyRow = 0xffffffffu;
 
@@ -280,19 +280,22 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned* sh, un
 // ---------------------------------------------------------------------------------------------
 struct PrepareArgs {
     SrcDev S;
-    unsigned* total;               // [nb] entries per bucket (count workgroups)
-    unsigned nb_log2;
+    unsigned* total;               // [nb << cs] entries per bucket (count workgroups), one counter every 1 << cs words
+    unsigned nb_log2, cs;
     Deferred D;                    // D.last_step == nullptr: no deferred state (no catch-up, no sweep)
     Deferred D1;                   // the companion arena (one float per row, its own last_step); last_step == nullptr: none
     const long long* step;         // catch-up / sweep target = step[0] + step_off
     int step_off;
-    unsigned K, G;                 // row width; lanes that share a row in the sweep: min(64, power of two >= K)
+    unsigned K;
     unsigned n_req;                // n_ex * F: the catch-up walks the requests in REQUEST order (every workgroup the same field mix)
     unsigned b_catch, b_comp, b_count, b_sweep;       // first block of: companion catch-up, count, sweep, companion sweep
-    long long rows, chunk;         // sweep: rows [c * chunk, (c + 1) * chunk), c = target % period
-    long long rows1, chunk1;
+    // sweep: the arena is cut into blocks of 256 rows; step `target` takes the blocks c, c + P, c + 2 P, ... (c = target % P):
+    // an even sample of every table each step (contiguous 1 / P ranges made the step time swing with the range's share of
+    // live rows: 2.5 .. 25 us), coalesced `last_step` reads
+    long long rows, rows1;
     int period;
-    unsigned R, R1;                // consecutive rows per lane group of the sweep
+    unsigned passes, passes1;      // a workgroup walks `passes` of the step's row blocks
+    int sweeping;                  // this launch carries the sweep: the catch-up leaves the rows of the step's blocks to it
 };
 
 // request r (request-major: e = r / F, f = r % F) -> arena row, -1 if none
@@ -312,108 +315,170 @@ __device__ __forceinline__ bool claim_row(int* last_step, long long row, int tar
     return false;
 }
 
-// The sweep's unit of work: a group of G lanes (G <= 64, inside one wave) walks R CONSECUTIVE rows — last_step first
-// (four loads in flight), claim + replay only for rows that lag; lane l owns floats l, l + G, ... of a row.  ALL lanes
-// of a wave must call this together (the replay loop is wave-uniform).  R = 1 for tables of the benchmark's size; for
-// 100 M-row tables, where nearly every row of a chunk is untouched, R = 32 keeps the launch small.
-__device__ __forceinline__ void sweep_rows(const Deferred& D, long long row0, long long end, unsigned R, int target, unsigned lane,
-                                           unsigned G, unsigned K, const recalgo_deferred::LrWindow& W) {
-    const unsigned passes = (K + G - 1) / G;
-    for (unsigned r0 = 0; r0 < R; r0 += 4) {
-        int sv[4];
+// A workgroup's list of rows to bring up to date, and their replay.  The replay is a chain of ~9 dependent instructions per
+// missed step and lane, 1 .. P + 1 steps long: the list is first ordered by lag (counting sort in LDS, longest first), so
+// that the 64 tasks of a wave — (row, float) pairs, one float per lane — run loops of the same length; the state of a
+// thread's next task is loaded before the current one is replayed.
+struct Claims {
+    int* row; int* s;              // [kThreads] as collected
+    int* row2; int* s2;            // [kThreads] ordered by lag
+    int* won;                      // [kThreads] (ordered) the claim was granted: its replay is written back
+    unsigned* hist;                // [64]
+    unsigned* n;
+};
+__device__ __forceinline__ Claims claims_carve(unsigned* lds) {
+    Claims C;
+    C.row = reinterpret_cast<int*>(lds);
+    C.s = C.row + kThreads;
+    C.row2 = C.s + kThreads;
+    C.s2 = C.row2 + kThreads;
+    C.won = C.s2 + kThreads;
+    C.hist = reinterpret_cast<unsigned*>(C.won + kThreads);
+    C.n = C.hist + 64;
+    return C;
+}
+constexpr size_t kClaimsLdsBytes = (5 * kThreads + 64 + 4) * sizeof(unsigned);
+
+// all threads call, after a barrier that made the collected list complete; ends with the list free for re-use.
+// The thread that listed entry `my_slot` (`listed`) passes the outcome of its claim as (old, expect): granted iff equal.
+// `old` may still be in flight (the compare-and-swap of catchup_requests): its round trip overlaps the sort and the first
+// state loads, it is only waited for where the winners are published, right before the first replay.  A claim that was not
+// granted is replayed for nothing and dropped.
+__device__ __forceinline__ void replay_claims(const Deferred& D, unsigned K, int target, const Claims& C,
+                                              const recalgo_deferred::LrWindow& W, bool listed, unsigned my_slot, int old, int expect) {
+    const unsigned n = *C.n;
+    if (n == 0) return;                                       // (uniform)
+    if (threadIdx.x < 64) C.hist[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned bkt = 0, pos = 0;
+    if (threadIdx.x < n) {
+        const int lag = target - C.s[threadIdx.x];
+        bkt = 63u - (unsigned)(lag > 63 ? 63 : lag);           // longest first
+        pos = atomicAdd(&C.hist[bkt], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                                   // exclusive prefix of the 64 lag buckets (one wave)
+        const unsigned v = C.hist[threadIdx.x];
+        unsigned inc = v;
 #pragma unroll
-        for (unsigned u = 0; u < 4; ++u) {
-            const long long row = row0 + r0 + u;
-            sv[u] = (r0 + u < R && row < end) ? D.last_step[row] : 0;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(inc, o, 64);
+            if ((threadIdx.x & 63) >= (unsigned)o) inc += t;
         }
-#pragma unroll
-        for (unsigned u = 0; u < 4; ++u) {
-            const long long row = row0 + r0 + u;
-            const bool lag = sv[u] > 0 && sv[u] < target;
-            if (__ballot(lag) == 0) continue;                 // (wave-uniform)
-            int s = target;
-            if (lag) {
-                int won = 0, sc = 0;
-                if (lane == 0) won = claim_row(D.last_step, row, target, &sc) ? 1 : 0;
-                won = __shfl(won, 0, (int)G);
-                sc = __shfl(sc, 0, (int)G);
-                if (won) s = sc;
-            }
-            for (unsigned p = 0; p < passes; ++p) {             // (wave-uniform trip count; rows wider than the group: more passes)
-                const unsigned j = lane + p * G;
-                const bool mine = s < target && j < K;
-                const size_t o = (size_t)row * K + j;
-                float w = 0.f, m = 0.f, v = 0.f;
-                if (mine) { w = D.w[o]; m = D.m[o]; v = D.v[o]; }
-                recalgo_deferred::replay_wave(w, m, v, mine ? s : target, target, W, D.lr_ring, D.b1, D.b2, D.eps);
-                if (mine) { D.w[o] = w; D.m[o] = m; D.v[o] = v; }
-            }
-            if (s < target && lane == 0) D.last_step[row] = target;
+        C.hist[threadIdx.x] = inc - v;
+    }
+    __syncthreads();
+    unsigned jsorted = 0;
+    if (threadIdx.x < n) {
+        jsorted = C.hist[bkt] + pos;
+        C.row2[jsorted] = C.row[threadIdx.x];
+        C.s2[jsorted] = C.s[threadIdx.x];
+        C.row[threadIdx.x] = (int)jsorted;                    // (entry -> its place in the order, for the claimant)
+    }
+    __syncthreads();
+    // whole waves walk the task list (the replay loop is wave-uniform); task = claim * K + float
+    const unsigned ntask = n * K, lane = threadIdx.x & 63;
+    unsigned t0 = threadIdx.x & ~63u;
+    bool mine = t0 + lane < ntask;
+    unsigned k = mine ? (t0 + lane) / K : 0, j = (t0 + lane) - k * K;
+    size_t o = (size_t)(mine ? C.row2[k] : 0) * K + j;
+    int sc = mine ? C.s2[k] : target;
+    float w = 0.f, m = 0.f, v = 0.f;
+    if (mine) { w = D.w[o]; m = D.m[o]; v = D.v[o]; }
+    if (listed) C.won[C.row[my_slot]] = old == expect ? 1 : 0; // (waits for the claim's outcome; the state loads are in flight)
+    __syncthreads();
+    while (t0 < ntask) {
+        const unsigned t1 = t0 + kThreads;
+        const bool mine1 = t1 + lane < ntask;
+        const unsigned k1 = mine1 ? (t1 + lane) / K : 0, j1 = (t1 + lane) - k1 * K;
+        const size_t o1 = (size_t)(mine1 ? C.row2[k1] : 0) * K + j1;
+        const int sc1 = mine1 ? C.s2[k1] : target;
+        float w1 = 0.f, m1 = 0.f, v1 = 0.f;
+        if (mine1) { w1 = D.w[o1]; m1 = D.m[o1]; v1 = D.v[o1]; }      // (the next task's state: in flight during the replay)
+        recalgo_deferred::replay_wave(w, m, v, sc, target, W, D.lr_ring, D.b1, D.b2, D.eps);
+        if (mine && C.won[k]) {
+            D.w[o] = w; D.m[o] = m; D.v[o] = v;
+            if (j == 0) D.last_step[C.row2[k]] = target;
+        }
+        t0 = t1; mine = mine1; k = k1; j = j1; o = o1; sc = sc1; w = w1; m = m1; v = v1;
+    }
+    __syncthreads();
+}
+
+// one pass of the sweep: kSweepRows consecutive rows (one per thread of the first wave), the lagging ones listed (no claim:
+// while a sweep runs, its rows are its own).  64 rows, not 256: a row block of a small, fully live table is 256 x K tasks —
+// sixteen replay rounds on one workgroup, the tail of the whole launch
+constexpr unsigned kSweepRows = 64;
+__device__ __forceinline__ void sweep_pass(const Deferred& D, unsigned K, long long row, long long end, int target, const Claims& C,
+                                           const recalgo_deferred::LrWindow& W) {
+    if (threadIdx.x == 0) *C.n = 0;
+    __syncthreads();
+    bool listed = false;
+    unsigned k = 0;
+    if (threadIdx.x < kSweepRows && row < end) {
+        const int s = D.last_step[row];
+        if (s > 0 && s < target) {
+            listed = true;
+            k = atomicAdd(C.n, 1u);
+            C.row[k] = (int)row;
+            C.s[k] = s;
         }
     }
+    __syncthreads();
+    replay_claims(D, K, target, C, W, listed, k, 0, 0);
 }
-inline unsigned sweep_rows_per_group(long long rows_in_launch) {
+// first row of unit u (64 rows) of the share of step index c: the row blocks (256 rows) c, c + P, c + 2 P, ..., four units each
+__device__ __forceinline__ long long sweep_unit_row(int c, int period, long long u) {
+    return ((long long)c + (long long)period * (u >> 2)) * kThreads + (u & 3) * kSweepRows;
+}
+inline unsigned sweep_passes(long long rows_in_launch) {
     const long long r = rows_in_launch / 65536;
     return (unsigned)(r < 1 ? 1 : (r > 32 ? 32 : r));
+}
+
+// the catch-up of up to kThreads requests: lagging rows claimed (one winner per row), listed, replayed
+__device__ __forceinline__ void catchup_requests(const PrepareArgs& A, const Deferred& D, unsigned K, unsigned r, bool active,
+                                                 long long n_rows, int cidx, int target, const Claims& C) {
+    if (threadIdx.x == 0) *C.n = 0;
+    __syncthreads();
+    // a lagging row is LISTED at once and claimed by a compare-and-swap whose outcome is not waited for here (one winner per
+    // row over all workgroups; hot rows are current: only stale rows cost the atomic)
+    int s = 0, old = 0;
+    bool lag = false;
+    long long row = -1;
+    if (active && r < A.n_req) {
+        row = request_row_linear(A.S, r);
+        // (rows of the blocks the same launch sweeps are the sweep's)
+        if (row >= 0 && row < n_rows && !(A.sweeping && (int)((row >> 8) % A.period) == cidx)) {
+            s = __hip_atomic_load(&D.last_step[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lag = s > 0 && s < target;
+        }
+    }
+    if (lag) old = atomicCAS(&D.last_step[row], s, -s);        // (in flight until replay_claims publishes the winners)
+    unsigned slot = 0;
+    if (lag) {
+        slot = atomicAdd(C.n, 1u);
+        C.row[slot] = (int)row;
+        C.s[slot] = s;
+    }
+    __syncthreads();
+    replay_claims(D, K, target, C, recalgo_deferred::lr_window(D.lr_ring, target), lag, slot, old, s);
 }
 
 __global__ __launch_bounds__(kThreads) void sparse_prepare_kernel(PrepareArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds_u[];
     const int target = A.D.last_step ? (int)(A.step[0] + A.step_off) : 0;
+    const int cidx = A.period > 0 ? target % A.period : 0;
     if (blockIdx.x < A.b_catch) {
-        // ---- catch-up: 64 requests, claims compacted in LDS, then one float per lane ---------------------------------
-        int* c_row = reinterpret_cast<int*>(lds_u);           // [kCatchReq]
-        int* c_s = c_row + kCatchReq;                         // [kCatchReq]
-        unsigned* n_claim = reinterpret_cast<unsigned*>(c_s + kCatchReq);
-        if (threadIdx.x == 0) *n_claim = 0;
-        __syncthreads();
-        if (threadIdx.x < kCatchReq) {
-            const unsigned r = blockIdx.x * kCatchReq + threadIdx.x;
-            const long long row = r < A.n_req ? request_row_linear(A.S, r) : -1;
-            int s;
-            if (row >= 0 && claim_row(A.D.last_step, row, target, &s)) {
-                const unsigned k = atomicAdd(n_claim, 1u);
-                c_row[k] = (int)row;
-                c_s[k] = s;
-            }
-        }
-        __syncthreads();
-        const unsigned ntask = *n_claim * A.K;
-        if (ntask == 0) return;
-        const recalgo_deferred::LrWindow W = recalgo_deferred::lr_window(A.D.lr_ring, target);
-        // whole waves walk the task list (the replay loop is wave-uniform); task = claim * K + float
-        for (unsigned t0 = (threadIdx.x & ~63u); t0 < ntask; t0 += kThreads) {
-            const unsigned task = t0 + (threadIdx.x & 63);
-            const bool mine = task < ntask;
-            const unsigned k = mine ? task / A.K : 0, j = task - k * A.K;
-            const size_t o = (size_t)(mine ? c_row[k] : 0) * A.K + j;
-            float w = 0.f, m = 0.f, v = 0.f;
-            if (mine) { w = A.D.w[o]; m = A.D.m[o]; v = A.D.v[o]; }
-            recalgo_deferred::replay_wave(w, m, v, mine ? c_s[k] : target, target, W, A.D.lr_ring, A.D.b1, A.D.b2, A.D.eps);
-            if (mine) {
-                A.D.w[o] = w; A.D.m[o] = m; A.D.v[o] = v;
-                if (j == 0) A.D.last_step[c_row[k]] = target;
-            }
-        }
+        // ---- catch-up: kCatchReq requests per workgroup, in request order ------------------------------------------------
+        catchup_requests(A, A.D, A.K, blockIdx.x * kCatchReq + threadIdx.x, threadIdx.x < kCatchReq, A.rows, cidx, target,
+                         claims_carve(lds_u));
         return;
     }
     if (blockIdx.x < A.b_comp) {
-        // ---- the companion arena's rows of the same requests: one request per lane ------------------------------------
-        const int target1 = (int)(A.step[0] + A.step_off);
-        const unsigned r = (blockIdx.x - A.b_catch) * kThreads + threadIdx.x;
-        const long long row = r < A.n_req ? request_row_linear(A.S, r) : -1;
-        int s = target1;
-        bool mine = false;
-        if (row >= 0 && row < A.rows1) mine = claim_row(A.D1.last_step, row, target1, &s);
-        if (__ballot(mine) == 0) return;                      // (wave-uniform)
-        const recalgo_deferred::LrWindow W = recalgo_deferred::lr_window(A.D1.lr_ring, target1);
-        float w = 0.f, m = 0.f, v = 0.f;
-        if (mine) { w = A.D1.w[row]; m = A.D1.m[row]; v = A.D1.v[row]; }
-        recalgo_deferred::replay_wave(w, m, v, mine ? s : target1, target1, W, A.D1.lr_ring, A.D1.b1, A.D1.b2, A.D1.eps);
-        if (mine) {
-            A.D1.w[row] = w; A.D1.m[row] = m; A.D1.v[row] = v;
-            A.D1.last_step[row] = target1;
-        }
+        // ---- the companion arena's rows of the same requests (one float per row) ---------------------------------------
+        catchup_requests(A, A.D1, 1, (blockIdx.x - A.b_catch) * kThreads + threadIdx.x, true, A.rows1, cidx, target,
+                         claims_carve(lds_u));
         return;
     }
     if (blockIdx.x < A.b_count) {
@@ -425,24 +490,24 @@ __global__ __launch_bounds__(kThreads) void sparse_prepare_kernel(PrepareArgs A)
         const long long row = li < A.S.n ? slot_row(A.S, li, &e, &f) : -1;
         unsigned slot;
         const EqInfo eq = tile_equal(row >= 0 ? (unsigned)row : 0xffffffffu, hkey, mask, &slot);
-        if (row >= 0 && eq.before == 0) atomicAdd(&A.total[bucket_of((unsigned)row, A.nb_log2)], 1u);
+        if (row >= 0 && eq.before == 0) atomicAdd(&A.total[(size_t)bucket_of((unsigned)row, A.nb_log2) << A.cs], 1u);
         return;
     }
     // ---- sweep (deferred Adam): rows [c * chunk, (c + 1) * chunk), c = target % period, brought to `target` -----------
     if (target <= 0) return;
+    const Claims C = claims_carve(lds_u);
     if (blockIdx.x < A.b_sweep) {
-        const long long c0 = (long long)(target % A.period) * A.chunk;
-        const unsigned idx = (blockIdx.x - A.b_count) * kThreads + threadIdx.x;
-        const long long row0 = c0 + (long long)(idx / A.G) * A.R;
         const recalgo_deferred::LrWindow W = recalgo_deferred::lr_window(A.D.lr_ring, target);
-        sweep_rows(A.D, row0, min(A.rows, c0 + A.chunk), A.R, target, idx & (A.G - 1), A.G, A.K, W);
+        const long long u0 = (long long)(blockIdx.x - A.b_count) * A.passes;       // this workgroup's first unit (64 rows) of the step's share
+        for (unsigned p = 0; p < A.passes; ++p)
+            sweep_pass(A.D, A.K, sweep_unit_row(cidx, A.period, u0 + p) + threadIdx.x, A.rows, target, C, W);
         return;
     }
     {
-        const long long c0 = (long long)(target % A.period) * A.chunk1;
-        const long long row0 = c0 + ((long long)(blockIdx.x - A.b_sweep) * kThreads + threadIdx.x) * A.R1;
         const recalgo_deferred::LrWindow W = recalgo_deferred::lr_window(A.D1.lr_ring, target);
-        sweep_rows(A.D1, row0, min(A.rows1, c0 + A.chunk1), A.R1, target, 0, 1, 1, W);
+        const long long u0 = (long long)(blockIdx.x - A.b_sweep) * A.passes1;
+        for (unsigned p = 0; p < A.passes1; ++p)
+            sweep_pass(A.D1, 1, sweep_unit_row(cidx, A.period, u0 + p) + threadIdx.x, A.rows1, target, C, W);
     }
 }
 
@@ -453,8 +518,14 @@ struct PlaceArgs {
     SrcDev src[kMaxSources];
     int n_src;
     unsigned n_total;
-    const unsigned* total; unsigned* cursor; unsigned* offs;        // [nb], [nb], [nb + 1]
-    unsigned* order;                           // [nb]: the buckets in the order `apply` takes them (the heavy ones first)
+    const unsigned* total; unsigned* cursor;   // [nb << cs], [nb << cs]
+    unsigned cs;
+    uint4* sched;                              // [nb]: (bucket, first entry, entries, -) in the order `apply` takes the buckets (the heavy ones first)
+    // workgroup 0 also evaluates this step's lr_t ONCE for `apply` (header word 0) and records it in the rings
+    float* hdr;
+    float* lr_ring; float* lr_ring1;           // nullptr: none
+    const long long* step; int step_off;       // t = step[0] + step_off (nullptr: no optimizer step, GRAD)
+    float lr, b1, b2;
     unsigned long long* keys;                  // [n_total]
     float* partials;                           // [n_total][K]: the summed gradient rows of a tile's duplicated rows
     float* partials1;                          // [n_total]: the same for the companion's scalar gradients (nullptr: no companion)
@@ -501,28 +572,35 @@ __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
     }
     {
         unsigned sum = 0;
-        for (unsigned k = 0; k < bpt; ++k) sum += A.total[threadIdx.x * bpt + k];
+        for (unsigned k = 0; k < bpt; ++k) sum += A.total[(size_t)(threadIdx.x * bpt + k) << A.cs];
         unsigned total;
         unsigned run = block_excl_scan(sum, sh, total);
         for (unsigned k = 0; k < bpt; ++k) {
             const unsigned b = threadIdx.x * bpt + k;
             offs[b] = run;
-            if (blockIdx.x == 0) A.offs[b] = run;
-            run += A.total[b];
+            run += A.total[(size_t)b << A.cs];
         }
-        if (blockIdx.x == 0 && threadIdx.x == kThreads - 1) A.offs[nb] = total;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && A.step != nullptr) {
+            const long long t = A.step[0] + A.step_off;
+            const float lr_t = lr_t_of(A.lr, A.b1, A.b2, t);
+            A.hdr[0] = lr_t;
+            if (A.lr_ring) A.lr_ring[(unsigned)t & (kLrRing - 1)] = lr_t;
+            if (A.lr_ring1) A.lr_ring1[(unsigned)t & (kLrRing - 1)] = lr_t;
+        }
         if (blockIdx.x == 0) {
             // `apply` runs one workgroup per bucket, more of them than fit the chip at once for large plans: the buckets that
             // hold a hot row (many entries: a long tail of the launch when they start late) are dispatched first
             const unsigned heavy_min = 2u * (total >> A.nb_log2) + 64u;
             unsigned nh = 0;
-            for (unsigned k = 0; k < bpt; ++k) nh += A.total[threadIdx.x * bpt + k] >= heavy_min;
+            for (unsigned k = 0; k < bpt; ++k) nh += A.total[(size_t)(threadIdx.x * bpt + k) << A.cs] >= heavy_min;
             unsigned n_heavy;
             unsigned hrun = block_excl_scan(nh, sh, n_heavy);
             for (unsigned k = 0; k < bpt; ++k) {
                 const unsigned b = threadIdx.x * bpt + k;
-                if (A.total[b] >= heavy_min) A.order[hrun++] = b;
-                else A.order[n_heavy + b - hrun] = b;       // (b - hrun = the light buckets before b)
+                const unsigned tb = A.total[(size_t)b << A.cs];
+                const uint4 rec = make_uint4(b, offs[b], tb, 0u);
+                if (tb >= heavy_min) A.sched[hrun++] = rec;
+                else A.sched[n_heavy + b - hrun] = rec;     // (b - hrun = the light buckets before b)
             }
         }
     }
@@ -542,10 +620,25 @@ __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
     if (dupl) jobs[atomicAdd(&sh[6], 1u)] = threadIdx.x;
     __syncthreads();
     if (row >= 0 && d.same > 1) mlist[mbase[d.leader] + d.before] = threadIdx.x;
+    // the gradient rows of the tile's duplicated requests are needed further down (summed per row in LDS): their loads are
+    // issued HERE, so that they are in flight during the bucket phase (a returning atomic + two barriers)
+    const unsigned L = A.L, q = threadIdx.x & (L - 1), grp = threadIdx.x / L, ngrp = kThreads / L;
+    V gq[4];
+    float g1s = 0.f;
+    if (A.stage_ok) {
+#pragma unroll
+        for (unsigned u = 0; u < 4; ++u) {
+            const unsigned tm = grp + u * ngrp;
+            gq[u] = vz<VEC>();
+            if (u < L && q < A.KV && samec[tm] > 1 && rows[tm] != 0xffffffffu)
+                gq[u] = load_req_g<VEC>(lsrc[req_s[tm]], req_e[tm], req_f[tm], q, A.KV);
+        }
+        if (A.partials1 && d.same > 1 && row >= 0) g1s = load_req_g1(lsrc[si], e, f);
+    }
     // the tile's entries of one bucket take consecutive positions: the first of them draws the range from the bucket's cursor
     unsigned slot_b;
     const EqInfo db = tile_equal(b, hkey, mask, &slot_b);
-    if (leader && db.before == 0) bbase[slot_b] = atomicAdd(&A.cursor[b], db.same);
+    if (leader && db.before == 0) bbase[slot_b] = atomicAdd(&A.cursor[(size_t)b << A.cs], db.same);
     __syncthreads();
     if (leader) {
         // a duplicated row's entry refers to the tile's partial sum (written below), a single request to its own row.  The key
@@ -553,7 +646,6 @@ __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
         A.keys[offs[b] + bbase[slot_b] + db.before] = ((unsigned long long)row << 32) | ((unsigned long long)i << 1) | (dupl ? 1u : 0u);
     }
     // ---- the duplicated rows of the tile: gradient rows added in request order ---------------------------------------
-    const unsigned L = A.L, q = threadIdx.x & (L - 1), grp = threadIdx.x / L, ngrp = kThreads / L;
     const unsigned njobs = sh[6];
     if (njobs == 0) return;                                   // (uniform)
     if (A.stage_ok) {
@@ -561,18 +653,16 @@ __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
         // loads of a thread in flight together), then each duplicated row is summed from LDS, in request order
         V* stage = reinterpret_cast<V*>(lsrc + kMaxSources);  // [kThreads][KV]
         float* stage1 = reinterpret_cast<float*>(stage + (size_t)kThreads * A.KV);      // [kThreads] (companion only)
-        if (A.partials1) {
-            const unsigned tm = threadIdx.x;
-            stage1[tm] = (samec[tm] > 1 && rows[tm] != 0xffffffffu) ? load_req_g1(lsrc[req_s[tm]], req_e[tm], req_f[tm]) : 0.f;
-        }
-        V gq[4];
+        if (A.partials1) stage1[threadIdx.x] = g1s;
         for (unsigned r0 = 0; r0 < L; r0 += 4) {              // a group owns the member threads grp, grp + ngrp, ...
+            if (r0 > 0) {                                     // (the first four were loaded above)
 #pragma unroll
-            for (unsigned u = 0; u < 4; ++u) {
-                const unsigned tm = grp + (r0 + u) * ngrp;
-                gq[u] = vz<VEC>();
-                if (r0 + u < L && q < A.KV && samec[tm] > 1 && rows[tm] != 0xffffffffu)
-                    gq[u] = load_req_g<VEC>(lsrc[req_s[tm]], req_e[tm], req_f[tm], q, A.KV);
+                for (unsigned u = 0; u < 4; ++u) {
+                    const unsigned tm = grp + (r0 + u) * ngrp;
+                    gq[u] = vz<VEC>();
+                    if (r0 + u < L && q < A.KV && samec[tm] > 1 && rows[tm] != 0xffffffffu)
+                        gq[u] = load_req_g<VEC>(lsrc[req_s[tm]], req_e[tm], req_f[tm], q, A.KV);
+                }
             }
 #pragma unroll
             for (unsigned u = 0; u < 4; ++u) {
@@ -641,9 +731,10 @@ __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
 struct ApplyArgs {
     SrcDev src[kMaxSources];
     int n_src;
-    const unsigned* offs;
-    const unsigned* order;         // [nb]: workgroup i takes bucket order[i]
+    const uint4* sched;            // [nb]: workgroup i takes bucket sched[i].x = entries [sched[i].y, + sched[i].z) of `keys`
+    const float* hdr;              // hdr[0] = lr_t of this step (written by `place`)
     unsigned* total; unsigned* cursor;                        // cleared per bucket for the next step
+    unsigned cs;
     const unsigned long long* keys; unsigned long long* keys_alt;   // keys_alt: scratch of the same size (large buckets)
     const float* partials;         // [slots][K]: gradient rows of the entries whose key has the partial bit set
     const float* partials1;        // [slots]: the companion's
@@ -799,25 +890,32 @@ __device__ __forceinline__ void short_row(const ApplyArgs& A, const SrcDev* lsrc
     using V = typename Vec<VEC>::T;
     const unsigned row = key_row(keys[lo]);
     const RowState<VEC> st = load_state<VEC>(A, row, q);
+    // up to eight gradient rows in flight per round trip (a hot row of a field arrives as B / 256 = 16 tile partials: a
+    // load -> wait -> add loop over them was most of this launch), added in key order
+    constexpr unsigned kU = 8;
     V acc = vz<VEC>();
     if (q < A.KV) {
-        unsigned j = lo;
-        for (; j + 4 <= hi; j += 4) {                         // four row loads in flight, added in key order
-            const V g0 = load_g<VEC>(A, lsrc, keys[j], q), g1 = load_g<VEC>(A, lsrc, keys[j + 1], q);
-            const V g2 = load_g<VEC>(A, lsrc, keys[j + 2], q), g3 = load_g<VEC>(A, lsrc, keys[j + 3], q);
-            vadd(acc, g0); vadd(acc, g1); vadd(acc, g2); vadd(acc, g3);
+        for (unsigned j = lo; j < hi; j += kU) {
+            V gq[kU];
+#pragma unroll
+            for (unsigned u = 0; u < kU; ++u)
+                if (j + u < hi) gq[u] = load_g<VEC>(A, lsrc, keys[j + u], q);
+#pragma unroll
+            for (unsigned u = 0; u < kU; ++u)
+                if (j + u < hi) vadd(acc, gq[u]);
         }
-        for (; j < hi; ++j) vadd(acc, load_g<VEC>(A, lsrc, keys[j], q));
     }
     float acc1 = 0.f;
     if (A.has1 && q == 0) {                                   // the companion's scalars of the same entries, same order
-        unsigned j = lo;
-        for (; j + 4 <= hi; j += 4) {
-            const float a0 = load_g1(A, lsrc, keys[j]), a1 = load_g1(A, lsrc, keys[j + 1]);
-            const float a2 = load_g1(A, lsrc, keys[j + 2]), a3 = load_g1(A, lsrc, keys[j + 3]);
-            acc1 += a0; acc1 += a1; acc1 += a2; acc1 += a3;
+        for (unsigned j = lo; j < hi; j += kU) {
+            float a[kU];
+#pragma unroll
+            for (unsigned u = 0; u < kU; ++u)
+                if (j + u < hi) a[u] = load_g1(A, lsrc, keys[j + u]);
+#pragma unroll
+            for (unsigned u = 0; u < kU; ++u)
+                if (j + u < hi) acc1 += a[u];
         }
-        for (; j < hi; ++j) acc1 += load_g1(A, lsrc, keys[j]);
     }
     finish_row<VEC>(A, row, st, acc, q, t, lr_t);
     if (A.has1 && q == 0) finish_row1(A, row, acc1, t, lr_t);
@@ -987,28 +1085,20 @@ __global__ __launch_bounds__(kThreads, 4) void sparse_apply_kernel(ApplyArgs A) 
     __shared__ unsigned n_long, n_seg;
     __shared__ float red[kThreads * 4];
     __shared__ float red1[kThreads];
-    __shared__ float s_lr_t;
     __shared__ SrcDev lsrc[kMaxSources];
-    const unsigned b = A.order[blockIdx.x];
+    const uint4 sc = A.sched[blockIdx.x];                     // (one 16-byte record: bucket, first entry, entries)
+    const unsigned b = sc.x, beg = sc.y, n = sc.z;
     const int t = (int)(A.step[0] + A.step_off);
+    const float lr_t = A.mode != RECALGO_SCATTER_GRAD ? A.hdr[0] : 0.f;
     if (threadIdx.x == 0) {
         n_long = 0; n_seg = 0;
-        float lr_t = 0.f;
-        if (A.mode != RECALGO_SCATTER_GRAD) {
-            lr_t = lr_t_of(A.lr, A.b1, A.b2, t);
-            if (blockIdx.x == 0 && A.lr_ring) A.lr_ring[(unsigned)t & (kLrRing - 1)] = lr_t;
-            if (blockIdx.x == 0 && A.lr_ring1) A.lr_ring1[(unsigned)t & (kLrRing - 1)] = lr_t;
-        }
-        s_lr_t = lr_t;
-        A.total[b] = 0;                                       // the plan is consumed: clean for the next step's counts
-        A.cursor[b] = 0;
+        A.total[(size_t)b << A.cs] = 0;                       // the plan is consumed: clean for the next step's counts
+        A.cursor[(size_t)b << A.cs] = 0;
     }
+    if (n == 0) return;                                       // (uniform)
     copy_kernarg_words(reinterpret_cast<unsigned*>(lsrc), offsetof(ApplyArgs, src), sizeof(SrcDev) * kMaxSources);
-    const unsigned beg = A.offs[b], n = A.offs[b + 1] - beg;
     const unsigned long long* in = A.keys + beg;              // the bucket's keys, in the order the tiles placed them
     __syncthreads();
-    const float lr_t = s_lr_t;
-    if (n == 0) return;
     if (n <= kThreads) {
         // ---- small bucket: rank by comparison (one entry per thread); keys are unique ---------------------------------
         const unsigned long long key = threadIdx.x < n ? in[threadIdx.x] : kPadKey;
@@ -1060,16 +1150,17 @@ struct SweepArgs {
     Deferred D;
     const long long* step;
     int step_off;
-    unsigned K, G, R;
+    unsigned K, passes;
     long long row0, row1;
 };
 __global__ __launch_bounds__(kThreads) void sparse_sweep_kernel(SweepArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_u[];
     const int target = (int)(A.step[0] + A.step_off);
     if (target <= 0) return;
-    const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
-    const long long row0 = A.row0 + (idx / A.G) * A.R;
+    const Claims C = claims_carve(lds_u);
     const recalgo_deferred::LrWindow W = recalgo_deferred::lr_window(A.D.lr_ring, target);
-    sweep_rows(A.D, row0, A.row1, A.R, target, (unsigned)(idx & (A.G - 1)), A.G, A.K, W);
+    const long long first = A.row0 + (long long)blockIdx.x * A.passes * kSweepRows;
+    for (unsigned p = 0; p < A.passes; ++p) sweep_pass(A.D, A.K, first + (long long)p * kSweepRows + threadIdx.x, A.row1, target, C, W);
 }
 
 // ---- host helpers -----------------------------------------------------------------------------
@@ -1132,20 +1223,31 @@ inline Deferred deferred_of(const recalgo_deferred_adam_t* d) {
     return Deferred{d->w, d->m, d->v, d->last_step, d->lr_ring, d->beta1, d->beta2, d->eps};
 }
 inline bool nb_ok(int nb_log2) { return nb_log2 >= 8 && nb_log2 <= 13; }
+// The bucket counters take integer atomics from every tile of the plan (one per tile-distinct row in `prepare`, one
+// returning add per (tile, bucket) in `place`).  Atomics on one cache line are served one after the other, so the
+// counters are spread: one every 1 << kCounterShift words (RECALGO_SPARSE_COUNTER_SHIFT, tuning aid).
+inline unsigned counter_shift() {
+    static const unsigned v = [] {
+        const char* e = getenv("RECALGO_SPARSE_COUNTER_SHIFT");
+        const int x = e ? atoi(e) : 4;
+        return (unsigned)(x < 0 ? 0 : (x > 5 ? 5 : x));
+    }();
+    return v;
+}
 
-struct Ws { unsigned* total; unsigned* cursor; unsigned* offs; unsigned* order; unsigned long long* keys; unsigned long long* keys_alt;
+struct Ws { float* hdr; unsigned* total; unsigned* cursor; uint4* sched; unsigned long long* keys; unsigned long long* keys_alt;
             float* partials; float* partials1; };
 inline Ws carve(void* ws, int64_t cap, int nb_log2) {
     const int64_t nb = 1ll << nb_log2;
     char* p = static_cast<char*>(ws);
     Ws w;
     // header (zero-filled by the caller before the first use and whenever counted-but-unapplied sources are dropped):
-    w.total = reinterpret_cast<unsigned*>(p) + 16;          // [nb]  (16 reserved words in front)
-    w.cursor = w.total + nb;                                // [nb]
-    w.offs = w.cursor + nb;                                 // [nb + 8]
-    w.order = w.offs + nb + 8;                              // [nb]
-    uintptr_t k = (reinterpret_cast<uintptr_t>(w.order + nb) + 15) & ~(uintptr_t)15;
-    w.keys = reinterpret_cast<unsigned long long*>(k);
+    const int64_t nc = nb << counter_shift();
+    w.hdr = reinterpret_cast<float*>(p);                    // 32 words (a whole cache line): [0] = lr_t of the step
+    w.total = reinterpret_cast<unsigned*>(p) + 32;          // [nb << cs]
+    w.cursor = w.total + nc;                                // [nb << cs]
+    w.sched = reinterpret_cast<uint4*>(w.cursor + nc);      // [nb]  (16-byte aligned: 32 + 2 nc words in front)
+    w.keys = reinterpret_cast<unsigned long long*>(w.sched + nb);
     w.keys_alt = w.keys + cap;
     w.partials1 = reinterpret_cast<float*>(w.keys_alt + cap);  // [cap]
     w.partials = w.partials1 + cap;                             // [cap][K]
@@ -1163,14 +1265,14 @@ RECALGO_EXPORT int recalgo_scatter_plan_buckets_log2(int64_t n_requests) {
 
 RECALGO_EXPORT int64_t recalgo_scatter_plan_header_bytes(int nb_log2) {
     if (!nb_ok(nb_log2)) return 0;
-    return (16 + 2 * (1ll << nb_log2)) * (int64_t)sizeof(unsigned);
+    return (32 + 2 * ((1ll << nb_log2) << counter_shift())) * (int64_t)sizeof(unsigned);
 }
 
 RECALGO_EXPORT int64_t recalgo_scatter_plan_workspace_bytes(int64_t n_slots, int nb_log2, int K) {
     if (n_slots < 0 || n_slots % kThreads != 0 || !nb_ok(nb_log2) || K < 1) return 0;
     const int64_t nb = 1ll << nb_log2;
     const int64_t cap = n_slots > 0 ? n_slots : kThreads;
-    return (4 * nb + 8 + 16) * (int64_t)sizeof(unsigned) + 2 * cap * (int64_t)sizeof(unsigned long long) +
+    return (4 * nb + 2 * (nb << counter_shift()) + 32) * (int64_t)sizeof(unsigned) + 2 * cap * (int64_t)sizeof(unsigned long long) +
            cap * (int64_t)(K + 1) * (int64_t)sizeof(float) + 64;
 }
 
@@ -1184,6 +1286,7 @@ RECALGO_EXPORT int recalgo_scatter_prepare(const recalgo_scatter_source_t* sourc
     RECALGO_REQUIRE(plan_requests >= 0 && plan_requests % kThreads == 0);
     RECALGO_REQUIRE(rows >= 0 && rows < (1ll << 31) && companion_rows >= 0 && companion_rows < (1ll << 31));
     const bool count = (flags & RECALGO_PREPARE_COUNT) != 0, sweep = (flags & RECALGO_PREPARE_SWEEP) != 0;
+    const bool catchup = (flags & RECALGO_PREPARE_CATCHUP) != 0;
     SrcDev S[kMaxSources];
     unsigned n = 0;
     if (source != nullptr && source->n_ex > 0) {
@@ -1200,6 +1303,7 @@ RECALGO_EXPORT int recalgo_scatter_prepare(const recalgo_scatter_source_t* sourc
     A.S.first = (unsigned)first_request;
     A.total = carve(plan_workspace, plan_requests, nb_log2).total;
     A.nb_log2 = (unsigned)nb_log2;
+    A.cs = counter_shift();
     A.D = deferred_of(deferred);
     A.D1 = deferred_of(companion_deferred);
     RECALGO_REQUIRE(A.D.last_step == nullptr || (step_dev != nullptr && A.D.lr_ring != nullptr));
@@ -1207,26 +1311,29 @@ RECALGO_EXPORT int recalgo_scatter_prepare(const recalgo_scatter_source_t* sourc
     RECALGO_REQUIRE(!sweep || (A.D.last_step != nullptr && sweep_period >= 1 && sweep_period <= (int)kLrRing - 8));
     A.step = reinterpret_cast<const long long*>(step_dev);
     A.step_off = step_offset;
-    A.K = (unsigned)K; A.G = G.G;
+    A.K = (unsigned)K;
     A.n_req = n ? (unsigned)((int64_t)source->n_ex * source->F) : 0u;
-    const unsigned catch_blocks = (A.D.last_step && A.n_req) ? (unsigned)cdiv(A.n_req, kCatchReq) : 0u;
-    const unsigned comp_blocks = (A.D1.last_step && A.n_req) ? (unsigned)cdiv(A.n_req, kThreads) : 0u;
+    RECALGO_REQUIRE(!catchup || A.D.last_step != nullptr);
+    const unsigned catch_blocks = (catchup && A.n_req) ? (unsigned)cdiv(A.n_req, kCatchReq) : 0u;
+    const unsigned comp_blocks = (catchup && A.D1.last_step && A.n_req) ? (unsigned)cdiv(A.n_req, kThreads) : 0u;
     const unsigned count_blocks = (count && n) ? (unsigned)cdiv(n, kThreads) : 0u;
     A.period = sweep_period < 1 ? 1 : sweep_period;
     A.rows = rows; A.rows1 = companion_rows;
-    A.chunk = (rows + A.period - 1) / A.period;
-    A.chunk1 = (companion_rows + A.period - 1) / A.period;
-    A.R = sweep_rows_per_group(A.chunk);
-    A.R1 = sweep_rows_per_group(A.chunk1);
-    const unsigned sweep_blocks = sweep ? (unsigned)cdiv(cdiv(A.chunk, (long long)A.R) * (long long)G.G, kThreads) : 0u;
-    const unsigned sweep1_blocks = (sweep && A.D1.last_step) ? (unsigned)cdiv(cdiv(A.chunk1, (long long)A.R1), kThreads) : 0u;
+    // row blocks (of 256 rows) per step: every P-th block of the arena
+    const long long share = cdiv(cdiv(rows, kThreads), A.period), share1 = cdiv(cdiv(companion_rows, kThreads), A.period);
+    A.passes = sweep_passes(share * kThreads);
+    A.passes1 = sweep_passes(share1 * kThreads);
+    A.sweeping = sweep ? 1 : 0;
+    const unsigned sweep_blocks = sweep ? (unsigned)cdiv(share * (kThreads / kSweepRows), (long long)A.passes) : 0u;
+    const unsigned sweep1_blocks = (sweep && A.D1.last_step) ? (unsigned)cdiv(share1 * (kThreads / kSweepRows), (long long)A.passes1) : 0u;
     A.b_catch = catch_blocks;
     A.b_comp = A.b_catch + comp_blocks;
     A.b_count = A.b_comp + count_blocks;
     A.b_sweep = A.b_count + sweep_blocks;
     const unsigned blocks = A.b_sweep + sweep1_blocks;
     if (blocks == 0) return 0;
-    const size_t smem = kSlots * 9 * sizeof(unsigned);        // (count tiles; the catch-up's claim list is smaller)
+    const size_t smem = kSlots * 9 * sizeof(unsigned);        // (count tiles; the claim lists of the other workgroups are smaller)
+    static_assert(kClaimsLdsBytes <= kSlots * 9 * sizeof(unsigned), "claim lists fit the count tiles' LDS");
     hipLaunchKernelGGL(sparse_prepare_kernel, dim3(blocks), dim3(kThreads), smem, as_stream(stream), A);
     RECALGO_RETURN_LAST();
 }
@@ -1262,9 +1369,16 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
     const unsigned W = (unsigned)cdiv(n_total, kThreads);     // tiles of the plan
     P.n_src = n_sources;
     P.n_total = n_total;
-    P.total = ws.total; P.cursor = ws.cursor; P.offs = ws.offs; P.order = ws.order; P.keys = ws.keys; P.partials = ws.partials;
+    P.total = ws.total; P.cursor = ws.cursor; P.sched = ws.sched; P.keys = ws.keys; P.partials = ws.partials;
+    P.hdr = ws.hdr;
+    P.lr_ring = mode == RECALGO_SCATTER_ADAM ? deferred->lr_ring : nullptr;
+    P.lr_ring1 = (mode == RECALGO_SCATTER_ADAM && companion) ? companion->deferred->lr_ring : nullptr;
+    P.step = mode != RECALGO_SCATTER_GRAD ? reinterpret_cast<const long long*>(step_dev) : nullptr;
+    P.step_off = step_offset;
+    P.lr = lr; P.b1 = beta1; P.b2 = beta2;
     P.partials1 = companion ? ws.partials1 : nullptr;
     P.nb_log2 = (unsigned)nb_log2;
+    P.cs = counter_shift();
     P.KV = G.KV; P.L = G.L;
     P.stage_ok = (size_t)K * kThreads * sizeof(float) <= 32 * 1024;      // (K <= 32: every model of the reference)
     const size_t smem = ((size_t)nb + 8 * kThreads + 8 + 16 + kSlots * 10) * sizeof(unsigned) + kThreads * 4 * sizeof(float) +
@@ -1284,7 +1398,7 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
     ApplyArgs A;
     for (int i = 0; i < kMaxSources; ++i) A.src[i] = P.src[i];
     A.n_src = n_sources;
-    A.offs = ws.offs; A.order = ws.order; A.total = ws.total; A.cursor = ws.cursor;
+    A.sched = ws.sched; A.hdr = ws.hdr; A.total = ws.total; A.cursor = ws.cursor; A.cs = counter_shift();
     A.keys = ws.keys; A.keys_alt = ws.keys_alt; A.partials = ws.partials; A.partials1 = ws.partials1;
     A.mode = mode;
     A.w = w; A.m = m; A.v = v; A.grad = grad;
@@ -1313,7 +1427,7 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
         A.live_count = live->live_count;
     }
     if (A.step == nullptr) {                                  // GRAD mode without a step counter: t is not used
-        A.step = reinterpret_cast<const long long*>(ws.offs);
+        A.step = reinterpret_cast<const long long*>(ws.hdr);
         A.step_off = 0;
     }
     if (G.vec == 4)
@@ -1333,11 +1447,10 @@ RECALGO_EXPORT int recalgo_adam_deferred_sweep(const recalgo_deferred_adam_t* de
     A.D = deferred_of(deferred);
     A.step = reinterpret_cast<const long long*>(step_dev);
     A.step_off = step_offset;
-    A.K = (unsigned)K; A.G = G.G;
+    A.K = (unsigned)K;
     A.row0 = row_begin; A.row1 = row_end;
-    A.R = sweep_rows_per_group(row_end - row_begin);
-    const int64_t threads = cdiv(row_end - row_begin, (int64_t)A.R) * G.G;
-    const dim3 grid((unsigned)((threads + kThreads - 1) / kThreads));
-    hipLaunchKernelGGL(sparse_sweep_kernel, grid, dim3(kThreads), 0, as_stream(stream), A);
+    A.passes = sweep_passes(row_end - row_begin);
+    const dim3 grid((unsigned)cdiv(row_end - row_begin, (int64_t)A.passes * kSweepRows));
+    hipLaunchKernelGGL(sparse_sweep_kernel, grid, dim3(kThreads), kClaimsLdsBytes, as_stream(stream), A);
     RECALGO_RETURN_LAST();
 }

@@ -533,8 +533,12 @@ class Estimator:
         """One eager training step on device-resident inputs; returns the loss tensor."""
         from . import ops
         seed = 1.0 if self.loss_grad_scale is None else float(self.loss_grad_scale)
+        from . import sparse
+        self.store.sparse_side_work = True           # (this method keeps the promise: launch_side_work() right below)
         with ops.loss_seed(seed):
             spec = self._call_model_fn(features, labels, ModeKeys.TRAIN)
+        sparse.launch_side_work(self.store)          # bucket counts + the sweep: beside the backward pass, on the side stream
+        self.store.sparse_side_work = False
         op = spec.train_op
         if self._seed_grad is None or float(self._seed_value) != seed or self._seed_grad.device != op.loss.device:
             self._seed_grad, self._seed_value = torch.full_like(op.loss.detach(), seed), seed   # made once, reused

@@ -28,7 +28,7 @@ import torch
 from . import _lib
 
 MODE_GRAD, MODE_ADAM, MODE_LAZY_ADAM = 0, 1, 2
-PREPARE_COUNT, PREPARE_SWEEP = 1, 2          # include/recalgo.h RECALGO_PREPARE_*
+PREPARE_COUNT, PREPARE_SWEEP, PREPARE_CATCHUP = 1, 2, 4          # include/recalgo.h RECALGO_PREPARE_*
 MAX_SOURCES = 16
 LR_RING = 1024
 
@@ -162,6 +162,7 @@ class ArenaPlan:
         self.nb_log2 = 10
         self.counted = None                    # signature of what the workspace's bucket totals currently hold
         self.swept = False                     # this step's share of the deferred-Adam sweep has been launched
+        self.side_pending: List[Source] = []   # lookups whose counts (and the sweep) wait for launch_side_work
         self.last_step: Optional[torch.Tensor] = None     # deferred-Adam: int32 [rows]
         self.lr_ring: Optional[torch.Tensor] = None
         self.betas = (0.9, 0.999, 1e-8)
@@ -277,20 +278,80 @@ def begin_lookup(arena, store, ids: torch.Tensor, offsets: Optional[torch.Tensor
         cp = plan_of(companion_arena)
         d1 = cp._deferred_struct()             # (the second arena's rows are caught up, and swept, by the same launch)
         c_rows = companion_arena.weight.shape[0] if d1 is not None else 0
-    flags = PREPARE_COUNT
-    if d is not None and not plan.swept:
-        flags |= PREPARE_SWEEP
-        plan.swept = True
-        if d1 is not None:
-            plan_of(companion_arena).swept = True
-    _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), arena.K, ctypes.c_void_p(plan.ws.data_ptr()), plan.capacity, plan.nb_log2,
-                                           first, flags, None if d is None else ctypes.byref(d),
-                                           None if d1 is None else ctypes.byref(d1), arena.weight.shape[0], c_rows, sweep_period(),
-                                           None if step is None else ctypes.c_void_p(step.data_ptr()), 0, _stream(arena.weight)),
-               "recalgo_scatter_prepare")
+    # Only the catch-up has to precede the lookup's forward kernel.  The bucket counts (needed by `place`, after the
+    # backward pass) and the step's share of the sweep (needed by nobody before the next step) are either part of the same
+    # launch, or — when the caller promises to call launch_side_work() between the forward and the backward pass
+    # (Estimator.train_step) — a launch of their own on the step's SIDE stream, beside the backward pass
+    side = side_work_enabled(store)
+    flags = 0 if d is None else PREPARE_CATCHUP
+    if side:
+        plan.side_pending.append(src)
+    else:
+        flags |= PREPARE_COUNT
+        if d is not None and not plan.swept:
+            flags |= PREPARE_SWEEP
+            plan.swept = True
+            if d1 is not None:
+                plan_of(companion_arena).swept = True
+    if flags:
+        _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), arena.K, ctypes.c_void_p(plan.ws.data_ptr()), plan.capacity, plan.nb_log2,
+                                               first, flags, None if d is None else ctypes.byref(d),
+                                               None if d1 is None else ctypes.byref(d1), arena.weight.shape[0], c_rows, sweep_period(),
+                                               None if step is None else ctypes.c_void_p(step.data_ptr()), 0, _stream(arena.weight)),
+                   "recalgo_scatter_prepare")
     plan.sources.append(src)
-    plan.counted = plan.counted[:2] + (plan.counted[2] + (id(src),),)
+    if not side:
+        plan.counted = plan.counted[:2] + (plan.counted[2] + (id(src),),)
     return src
+
+
+def side_work_enabled(store) -> bool:
+    # (measured: SLOWER — DCN 0.248 vs 0.242 ms, DIN 0.658 vs 0.608: the launch beside the backward pass takes 39 us instead of
+    # 28 and the fork / join of the second stream costs more than the overlap buys, as with every other two-stream variant
+    # tried on this stack.  Kept as an experiment switch, off by default.)
+    return bool(getattr(store, "sparse_side_work", False)) and os.environ.get("RECALGO_SPARSE_SIDE", "0") == "1"
+
+
+def launch_side_work(store) -> None:
+    """Between the forward and the backward pass of a TRAIN step: the bucket counts of the step's lookups and the step's share
+    of the deferred-Adam sweep, one launch per lookup on the step's side stream — they overlap the backward pass and are
+    joined by the optimizer (ops.flush_dense_splits -> join_side_streams).  Without this call the optimizer's launch
+    sequence does the same work itself (sparse._run)."""
+    todo = [(ar, plan_of(ar)) for ar in store.arenas.values() if plan_of(ar) is not None and plan_of(ar).side_pending]
+    if not todo:
+        return
+    from . import ops
+    lib = _lib.load()
+    for ar, plan in todo:
+        dev = ar.weight.device
+        cur, side = torch.cuda.current_stream(dev), ops.side_stream(dev)
+        side.wait_stream(cur)
+        st = store.opt_state
+        with torch.cuda.stream(side):
+            sid = ctypes.c_void_p(side.cuda_stream)
+            d = plan._deferred_struct()
+            pending, first = {id(s) for s in plan.side_pending}, 0
+            for s in plan.sources:
+                if id(s) in pending and s.n:
+                    flags, d1, c_rows = PREPARE_COUNT, None, 0
+                    if d is not None and not plan.swept:
+                        flags |= PREPARE_SWEEP
+                        plan.swept = True
+                        if s.companion is not None and plan_of(s.companion.arena).last_step is not None:
+                            cp = plan_of(s.companion.arena)
+                            d1, c_rows = cp._deferred_struct(), s.companion.arena.weight.shape[0]
+                            cp.swept = True
+                    cs = s.c_struct(ar.K)
+                    sw = bool(flags & PREPARE_SWEEP)
+                    _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), ar.K, ctypes.c_void_p(plan.ws.data_ptr()), plan.capacity,
+                                                           plan.nb_log2, first, flags, ctypes.byref(d) if sw else None,
+                                                           None if d1 is None else ctypes.byref(d1), ar.weight.shape[0], c_rows,
+                                                           sweep_period(), ctypes.c_void_p(st["step"].data_ptr()) if sw else None, 0, sid),
+                               "recalgo_scatter_prepare (side)")
+                    plan.counted = plan.counted[:2] + (plan.counted[2] + (id(s),),)
+                first += s.slots
+        plan.side_pending = []
+        ops._side_dirty.add(dev)
 
 
 def companion_enabled() -> bool:
@@ -349,6 +410,7 @@ def new_forward(store) -> None:
             plan.grad_materialized = False
         if plan is not None and plan.sources:
             plan.sources = []
+            plan.side_pending = []
             plan.grad_materialized = False
             if plan.ws is not None and plan.counted is not None and plan.counted[2]:
                 plan.clear_counts()            # (the abandoned forward's entries: normally consumed and cleared by `apply`)
@@ -474,6 +536,7 @@ def _run(plan: ArenaPlan, sources: List[Source], mode: int, step_dev, step_offse
         cp.served = True
         cp.swept = False
     plan.counted = plan._signature([])         # (`apply` left the totals clean: the next step's `prepare` launches add to zero)
+    plan.side_pending = []
 
 
 def _companion_arena(sources: List[Source], mode: int):
@@ -585,4 +648,5 @@ def reset(arena) -> None:
         plan.sources = []
         plan.counted = None
         plan.swept = False
+        plan.side_pending = []
         plan.grad_materialized = False

@@ -26,6 +26,10 @@ def main():
     ap.add_argument("--fields", type=int, default=26)
     ap.add_argument("--emb", type=int, default=16)
     ap.add_argument("--advance", action="store_true", help="advance the step counter every step (real catch-up / sweep work)")
+    ap.add_argument("--data-batches", type=int, default=32, help="distinct batches rotated through (the bench's 32)")
+    ap.add_argument("--split", action="store_true",
+                    help="issue the parts of `prepare` as THREE launches (count | catch-up | sweep) instead of one grid: under "
+                         "rocprofv3 the per-grid-size table of scripts/rocpd_stats.py then shows each part's time")
     a = ap.parse_args()
     from recalgorithm_amd import sparse as sp
     from recalgorithm_amd.io import synth
@@ -39,7 +43,7 @@ def main():
     rb = torch.tensor([ar.tables[n][0] for n in sorted(spec.names)], dtype=torch.int64, device=dev)
     B, F, K = a.batch, a.fields, a.emb
     batches = []
-    for i in range(8):
+    for i in range(a.data_batches):
         feats, _, _ = synth.device_features(spec, B, dev, batch_index=i)
         ids = torch.stack([feats[n] for n in sorted(spec.names)], 1).contiguous()
         if a.uniform:
@@ -54,9 +58,34 @@ def main():
     store = Store()
     step = store.opt_state["step"]
 
+    def split_lookup(ids):
+        """begin_lookup's launch as three: count | catch-up | sweep (same work, same state afterwards)."""
+        import ctypes
+        from recalgorithm_amd import _lib
+        lib = _lib.load()
+        plan = sp.plan_of(ar)
+        src = sp.Source(ids, None, rb, 0, B, F)
+        src.arena = ar
+        plan._ensure_ws(src.slots)
+        d = plan._deferred_struct()
+        cs = src.c_struct(K)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        ws, stp = ctypes.c_void_p(plan.ws.data_ptr()), ctypes.c_void_p(step.data_ptr())
+        rows = ar.weight.shape[0]
+        lib.recalgo_scatter_prepare(ctypes.byref(cs), K, ws, plan.capacity, plan.nb_log2, 0, sp.PREPARE_COUNT, None, None, 0, 0, 1, None, 0, st)
+        if d is not None:
+            lib.recalgo_scatter_prepare(ctypes.byref(cs), K, ws, plan.capacity, plan.nb_log2, 0, 0, ctypes.byref(d), None, rows, 0,
+                                        sp.sweep_period(), stp, 0, st)
+            lib.recalgo_scatter_prepare(None, K, ws, plan.capacity, plan.nb_log2, 0, sp.PREPARE_SWEEP, ctypes.byref(d), None, rows, 0,
+                                        sp.sweep_period(), stp, 0, st)
+            plan.swept = True
+        plan.sources.append(src)
+        plan.counted = plan.counted[:2] + (plan.counted[2] + (id(src),),)
+        return src
+
     def one(i, apply=True):
         ids = batches[i % len(batches)]
-        src = sp.begin_lookup(ar, store, ids, None, rb, 0, B, F, True)
+        src = split_lookup(ids) if (a.split and sp.plan_of(ar) is not None) else sp.begin_lookup(ar, store, ids, None, rb, 0, B, F, True)
         if not apply:
             sp.plan_of(ar).sources = []
             return
@@ -69,7 +98,7 @@ def main():
         else:
             sp.apply(ar, a.mode == "lazy", step, 0.001, 0.9, 0.999, 1e-8)
 
-    for i in range(16):
+    for i in range(max(16, 2 * a.data_batches)):
         one(i)
     torch.cuda.synchronize()
 

@@ -29,7 +29,7 @@ def main(path, top=40):
     if gx is None:
         return
     rows = c.execute(f"select {name}, {gx}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
-                     f"from kernels where {name} like '%dense_%' or {name} like '%cin_%' group by {name}, {gx} "
+                     f"from kernels where {name} like '%dense_%' or {name} like '%cin_%' or {name} like '%sparse_%' group by {name}, {gx} "
                      f"order by 1, 2").fetchall()
     if rows:
         print("\nper launch shape (kernel, grid size):\n")
