@@ -207,6 +207,46 @@ def build_estimator(args, device, rank=0, world=1, before_build=None):
     return est, spec, feats, labels, workload
 
 
+def box_sanity(device):
+    """Which box is this?  The pool's boxes differ (one ran every HBM-bound kernel 30-60 % slower): a device
+    copy rate measured here, and the clocks / power cap rocm-smi reports, let a reader tell a slow box from a slow tree."""
+    out = {}
+    try:
+        x = torch.empty(1 << 28, dtype=torch.uint8, device=device)          # 256 MiB
+        y = torch.empty_like(x)
+        y.copy_(x)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            y.copy_(x)
+        e1.record()
+        e1.synchronize()
+        out["hbm_copy_GBs"] = round(10 * 2 * x.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)     # read + write
+        del x, y
+    except Exception as e:
+        out["hbm_copy_error"] = f"{type(e).__name__}: {e}"
+    try:
+        import subprocess
+        r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showmaxpower", "--json"], capture_output=True, text=True,
+                           timeout=20)
+        js = json.loads(r.stdout.strip().splitlines()[-1]) if r.stdout.strip() else {}
+        card = js.get(f"card{device.index or 0}") or (next(iter(js.values())) if js else {})
+        for k, v in card.items():
+            lk = k.lower()
+            if "sclk" in lk and "level" in lk:
+                out["sclk"] = v
+            elif "mclk" in lk and "level" in lk:
+                out["mclk"] = v
+            elif "max graphics package power" in lk:
+                out["power_cap_W"] = v
+            elif "graphics package power" in lk or "average" in lk and "power" in lk:
+                out["power_W"] = v
+    except Exception as e:
+        out["rocm_smi"] = f"unavailable ({type(e).__name__})"
+    return out
+
+
 def event_time_ms(fn, reps=20, replays=10):
     """Average duration of ONE `fn()` launch, from HIP events recorded on the stream the kernels
     run on.  `reps` launches are captured into a hipGraph and the graph is replayed `replays`
@@ -820,6 +860,9 @@ def main():
         "final_loss": round(loss_v, 6),
         "ms_per_step_by_chunk_of_25": r["chunk_ms"],
     }
+    if rank == 0:
+        out["box"] = box_sanity(device)
+        out["box"]["host_cores"] = os.cpu_count()
     cs = sorted(r["chunk_ms"])
     if cs:          # spread of the per-chunk step times (median and p10 / p90)
         pick = lambda q: cs[min(len(cs) - 1, int(q * len(cs)))]

@@ -577,6 +577,14 @@ int recalgo_adam_tf1_advance(int64_t* step_dev, float lr, float beta1, float bet
  * ------------------------------------------------------------------------------------------ */
 #define RECALGO_ACT_PRELU 0
 #define RECALGO_ACT_DICE 1
+/* tf.concat([...], axis=-1) of 1..4 contiguous row-major parts [B, widths[p]] into out [B, sum widths] AND
+ * sum_out[0] = scale * sum(out^2) — the VALUE of DIN's mini-batch-aware regulariser (din.py:249-257; its gradient is the
+ * beta * C epilogue of the first fcn layer's recalgo_dense_bwd) — in one launch; the per-workgroup partial sums are added in
+ * a fixed order by the workgroup that finishes last (bit-reproducible).  workspace: recalgo_concat_sumsq_workspace_bytes(B)
+ * bytes, the first 64 zero-filled once before the first use. */
+int64_t recalgo_concat_sumsq_workspace_bytes(int B);
+int recalgo_concat_sumsq(const float* const* parts, const int* widths, int n_parts, int B, float* out, float scale,
+                         float* sum_out, void* workspace, recalgo_stream_t stream);
 int recalgo_activation_fwd(const float* x, const float* alpha, int rows, int C, int kind, float* y,
                            recalgo_stream_t stream);
 int64_t recalgo_activation_bwd_workspace_bytes(int rows, int C);

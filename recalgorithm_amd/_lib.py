@@ -99,6 +99,8 @@ SIGNATURES = {
     "recalgo_embedding_bag_mean_fwd_deferred": (c_int, [P, P, P, c_int, c_int, P, c_int, c_int, P, c_int64, P, c_int, P]),
     "recalgo_sequence_gather_fwd_deferred": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, c_int64, P, c_int, P]),
     "recalgo_deepfm_sparse_fwd_deferred": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, P]),
+    "recalgo_concat_sumsq_workspace_bytes": (c_int64, [c_int]),
+    "recalgo_concat_sumsq": (c_int, [P, P, c_int, c_int, P, c_float, P, P, P]),
     "recalgo_scatter_plan_buckets_log2": (c_int, [c_int64]),
     "recalgo_scatter_plan_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
     "recalgo_scatter_source_slots": (c_int64, [c_int, c_int, c_int]),

@@ -82,7 +82,9 @@ def deepfm_model_fn(features, labels, mode, params):
             if params["batch_norm"]:
                 net = nn.batch_normalization(net, training=training)
         deep_logit = nn.dense(net, 1)
-    total_logit = fm_first_order_logit + fm_second_order_logit + deep_logit
+    # deepfm.py:214 (fm_first_order_logit + fm_second_order_logit + deep_logit).  Grouped from the right so that both FM terms
+    # join the lazily evaluated head as addends of the fused logit / loss launch (no elementwise add launch of their own)
+    total_logit = fm_first_order_logit + (fm_second_order_logit + deep_logit)
     return finish_model_fn(
         mode, total_logit, labels, params,
         predictions=lambda prob: {"probabilities": prob, "fm_first_order_logit": fm_first_order_logit,

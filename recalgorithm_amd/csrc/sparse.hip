@@ -571,14 +571,20 @@ __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
         if (i - S.first < S.n) row = slot_row(S, i - S.first, &e, &f);      // (padding between two sources: no request)
     }
     {
+        // (ONE pass over the counters — they are spread over cache lines, a load fetches a line per counter: the totals wait
+        // in LDS for their prefix)
         unsigned sum = 0;
-        for (unsigned k = 0; k < bpt; ++k) sum += A.total[(size_t)(threadIdx.x * bpt + k) << A.cs];
+        for (unsigned k = 0; k < bpt; ++k) {
+            const unsigned b = threadIdx.x * bpt + k, tb = A.total[(size_t)b << A.cs];
+            offs[b] = tb;
+            sum += tb;
+        }
         unsigned total;
         unsigned run = block_excl_scan(sum, sh, total);
         for (unsigned k = 0; k < bpt; ++k) {
-            const unsigned b = threadIdx.x * bpt + k;
+            const unsigned b = threadIdx.x * bpt + k, tb = offs[b];
             offs[b] = run;
-            run += A.total[(size_t)b << A.cs];
+            run += tb;
         }
         if (blockIdx.x == 0 && threadIdx.x == 0 && A.step != nullptr) {
             const long long t = A.step[0] + A.step_off;
@@ -1258,6 +1264,10 @@ inline Ws carve(void* ws, int64_t cap, int nb_log2) {
 
 RECALGO_EXPORT int recalgo_scatter_plan_buckets_log2(int64_t n_requests) {
     // ~100-160 entries per bucket (one workgroup each in `apply`, up to 256 ranked by comparison), 1024 .. 8192 buckets
+    if (const char* e = getenv("RECALGO_SPARSE_NB_LOG2")) {           // (tuning aid)
+        const int v = atoi(e);
+        if (v >= 8 && v <= 13) return v;
+    }
     int l = 10;
     while (l < 13 && (n_requests >> l) > 160) ++l;
     return l;

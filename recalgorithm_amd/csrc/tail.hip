@@ -512,6 +512,110 @@ __global__ void adam_advance_kernel(int64_t* step, float lr, float b1, float b2,
         lr_t[0] = (float)((double)lr * sqrt(1.0 - pow((double)b2, td)) / (1.0 - pow((double)b1, td)));
     }
 }
+// ---------------------------------------------------------------------------------------
+// tf.concat of up to 4 row-major [B, w_p] parts + the value of DIN's mini-batch-aware regulariser over the result
+// (din.py:249-257: l2_lambda / 2 / B * sum(ev^2), ev = concat[category, target, attention output]) in ONE launch:
+// a workgroup copies a block of rows and accumulates their squares; per-workgroup partial sums are added IN FIXED ORDER by
+// the workgroup that arrives last (ticket), so the scalar is bit-reproducible.  Replaces a concat copy, a dot product
+// (two library launches) and a scaling launch.
+// ---------------------------------------------------------------------------------------
+constexpr int kCatMaxParts = 4;
+struct CatArgs {
+    const float* x[kCatMaxParts];
+    int width[kCatMaxParts], off[kCatMaxParts];
+    int n, B, C;              // C = total width (the row stride of `out`)
+    float* out;
+    float scale;
+    float* sum_out;           // scale * sum(out^2)
+    float* partials;          // [gridDim.x]
+    unsigned* ticket;         // zero before the first launch; the last workgroup leaves it zero again
+    int rows_per_block;
+};
+__global__ __launch_bounds__(256) void concat_sumsq_kernel(CatArgs A) {
+    __shared__ float red[4];
+    __shared__ unsigned s_last;
+    const int r0 = blockIdx.x * A.rows_per_block, r1 = min(A.B, r0 + A.rows_per_block);
+    float acc = 0.f;
+    for (int p = 0; p < A.n; ++p) {
+        const int w = A.width[p], n = (r1 - r0) * w;
+        const float* __restrict__ src = A.x[p] + (size_t)r0 * w;
+        float* __restrict__ dst = A.out + (size_t)r0 * A.C + A.off[p];
+        if ((w & 3) == 0 && (A.C & 3) == 0 && (A.off[p] & 3) == 0 && (reinterpret_cast<uintptr_t>(A.x[p]) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(A.out) & 15) == 0) {
+            const int w4 = w >> 2;
+            for (int i = threadIdx.x; i < (n >> 2); i += 256) {
+                const int r = i / w4, c = i - r * w4;
+                const float4 v = reinterpret_cast<const float4*>(src)[i];
+                *reinterpret_cast<float4*>(dst + (size_t)r * A.C + 4 * c) = v;
+                acc = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, acc))));
+            }
+        } else {
+            for (int i = threadIdx.x; i < n; i += 256) {
+                const int r = i / w, c = i - r * w;
+                const float v = src[i];
+                dst[(size_t)r * A.C + c] = v;
+                acc = fmaf(v, v, acc);
+            }
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // publish the partial with a write-through (sc1) store, drain it, then draw a ticket; the workgroup that draws the last
+        // ticket reads every partial with sc1 loads (guides/cdna_hip_programming.md Guideline 16, the drained-sc1 form: no
+        // release fence — a fence would first write back the 27 KB of `out` this workgroup has just dirtied, ~6 us)
+        __hip_atomic_store(&A.partials[blockIdx.x], (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // fixed order: thread t adds partials t, t + 256, ...; then the 256 thread sums in thread order
+    float tot = 0.f;
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += 256)
+        tot += __hip_atomic_load(&A.partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __shared__ float all[256];
+    all[threadIdx.x] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t2 = 0.f;
+        for (int i = 0; i < 256; ++i) t2 += all[i];
+        A.sum_out[0] = A.scale * t2;
+        __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+}  // namespace
+
+RECALGO_EXPORT int64_t recalgo_concat_sumsq_workspace_bytes(int B) {
+    return B > 0 ? (int64_t)(cdiv(B, 16) + 16) * 4 : 64;
+}
+RECALGO_EXPORT int recalgo_concat_sumsq(const float* const* parts, const int* widths, int n_parts, int B, float* out,
+                                        float scale, float* sum_out, void* workspace, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(parts && widths && n_parts >= 1 && n_parts <= kCatMaxParts && B >= 0 && out && sum_out && workspace);
+    CatArgs A;
+    int C = 0;
+    for (int p = 0; p < kCatMaxParts; ++p) {
+        A.x[p] = p < n_parts ? parts[p] : nullptr;
+        A.width[p] = p < n_parts ? widths[p] : 0;
+        A.off[p] = C;
+        if (p < n_parts) {
+            RECALGO_REQUIRE(parts[p] != nullptr && widths[p] >= 1);
+            C += widths[p];
+        }
+    }
+    A.n = n_parts; A.B = B; A.C = C; A.out = out; A.scale = scale; A.sum_out = sum_out;
+    A.rows_per_block = 16;
+    const int blocks = B > 0 ? cdiv(B, A.rows_per_block) : 1;
+    A.ticket = static_cast<unsigned*>(workspace);             // word 0 (zero-initialised by the caller, once)
+    A.partials = reinterpret_cast<float*>(static_cast<unsigned*>(workspace) + 16);
+    hipLaunchKernelGGL(concat_sumsq_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), A);
+    RECALGO_RETURN_LAST();
+}
+
+namespace {
 }  // namespace
 
 RECALGO_EXPORT int recalgo_abi_version(void) { return RECALGO_ABI_VERSION; }

@@ -348,6 +348,20 @@ def input_layers_concat(features, feature_columns) -> torch.Tensor:
     return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
 
 
+_UNIT_OFFSETS = {}
+
+
+def _unit_offsets(B: int, dev) -> torch.Tensor:
+    """offsets [0, 1, ..., B] of B length-1 sequences (made once per batch size: not a launch per step)."""
+    key = (int(B), str(dev))
+    t = _UNIT_OFFSETS.get(key)
+    if t is None:
+        if len(_UNIT_OFFSETS) > 8:
+            _UNIT_OFFSETS.clear()
+        t = _UNIT_OFFSETS[key] = torch.arange(B + 1, device=dev, dtype=torch.int64)
+    return t
+
+
 def sequence_input_layer(features, feature_columns, max_length: Optional[int] = None):
     """tf.contrib.feature_column.sequence_input_layer (A-6): (B, T, H) zero padded with T the
     longest sequence of the batch (or `max_length` when given, for static shapes), and
@@ -368,7 +382,7 @@ def sequence_input_layer(features, feature_columns, max_length: Optional[int] = 
         ids = c.categorical_column.ids(features, dev)
         if isinstance(ids, torch.Tensor):
             B = ids.numel()
-            ids = Ragged(ids.contiguous(), torch.arange(B + 1, device=dev, dtype=torch.int64))
+            ids = Ragged(ids.contiguous(), _unit_offsets(B, dev))
             T = 1
         else:
             T = max_length or max(int((ids.offsets[1:] - ids.offsets[:-1]).max().item()), 1)

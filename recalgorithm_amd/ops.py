@@ -254,6 +254,7 @@ class _SeqGatherFn(Function):
             "recalgo_sequence_gather_fwd")
         ctx.args = (values, offsets, arena, table_name, T)
         ctx.mark_non_differentiable(seq_len)
+        ctx.set_materialize_grads(False)      # (else autograd fills a zero "gradient" for seq_len: one launch per lookup and step)
         return out, seq_len
 
     @staticmethod
@@ -261,6 +262,8 @@ class _SeqGatherFn(Function):
         values, offsets, arena, table_name, T = ctx.args
         B = offsets.numel() - 1
         rb, vocab = arena.tables[table_name]
+        if g is None:                          # (the sequence output was not used)
+            return None, None, None, None, None, None, None
         if ctx.src is not None:
             ctx.src.set_grad(g)              # (no `arena.grad` access here: reading it would sum the pending sources now)
             return None, None, None, None, None, None, None
@@ -1349,6 +1352,44 @@ class _LogitLossFn(Function):
             return (None,) * (6 + len(ctx.dxs) + ctx.n_addends)
         # the seed was baked into dlogit / dx by the forward launch (the caller promises to seed backward with it)
         return (None, None, None, None, None, None, *ctx.dxs, *([ctx.dlogit] * ctx.n_addends))
+
+
+class _ConcatSumsqFn(Function):
+    """torch.cat(parts, -1) with sum(out^2) * scale as a detached by-product (one launch, include/recalgo.h
+    recalgo_concat_sumsq); the gradient of a part is its column block of the output's gradient."""
+
+    @staticmethod
+    def forward(ctx, scale, *parts):
+        lib = _lib_()
+        parts = [t.contiguous() for t in parts]
+        B = parts[0].shape[0]
+        widths = [int(t.shape[1]) for t in parts]
+        dev = parts[0].device
+        out = torch.empty(B, sum(widths), device=dev, dtype=torch.float32)
+        val = torch.empty(1, device=dev, dtype=torch.float32)
+        key = ("concat_sumsq", dev.type, dev.index, B)
+        ws = _dense_ws.get(key)
+        if ws is None:
+            ws = _dense_ws[key] = torch.zeros(int(lib.recalgo_concat_sumsq_workspace_bytes(B)), dtype=torch.uint8, device=dev)
+        wi = (ctypes.c_int * len(parts))(*widths)
+        _lib.check(lib.recalgo_concat_sumsq(_ptr_array(parts), wi, len(parts), B, _p(out), float(scale), _p(val), _p(ws),
+                                            _stream(out)), "recalgo_concat_sumsq")
+        ctx.widths = widths
+        ctx.mark_non_differentiable(val)
+        return out, val
+
+    @staticmethod
+    def backward(ctx, g, _gv):
+        outs, off = [], 0
+        for w in ctx.widths:
+            outs.append(g[:, off:off + w])
+            off += w
+        return (None, *outs)
+
+
+def concat_sumsq(parts, scale: float):
+    """-> (concat(parts, -1) [B, C], scale * sum(concat^2) as a detached [1] tensor); 1..4 fp32 [B, w] device tensors."""
+    return _ConcatSumsqFn.apply(float(scale), *parts)
 
 
 _dlogit_partials = {}
