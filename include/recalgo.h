@@ -357,6 +357,14 @@ int recalgo_relu_bwd_bias(const float* g, const float* y, int rows, int C, float
  * ------------------------------------------------------------------------------------------ */
 int recalgo_dense_fwd(const float* x, int ldx, const float* w, int K, const float* x2, int ldx2, const float* w2, int K2,
                       const float* bias, int M, int N, int relu, float* y, int ldy, recalgo_stream_t stream);
+/* recalgo_dense_fwd that ALSO leaves the batch moments of y for the BatchNorm layer that follows it (tf.layers.dense ->
+ * [dropout 0] -> tf.layers.batch_normalization(training=True): deepfm.py:207-211, pnn.py:187-191, fibinet.py:192-196):
+ * bn_partials [recalgo_batchnorm_partial_rows(M)][2 N] in the layout of recalgo_batchnorm_moments (per 64-row tile: column
+ * means, then sums of squared deviations), written by the epilogue of the tile's workgroups — recalgo_batchnorm_apply then
+ * runs without a moments pass over y.  bn_partials == NULL: recalgo_dense_fwd. */
+int recalgo_dense_fwd_bn(const float* x, int ldx, const float* w, int K, const float* x2, int ldx2, const float* w2, int K2,
+                         const float* bias, int M, int N, int relu, float* y, int ldy, float* bn_partials,
+                         recalgo_stream_t stream);
 int recalgo_dense_bwd_input(const float* g, int ldg, const float* y_mask, const float* w, int M, int N, int K,
                             const float* c_in, int ldc, float beta, float* dx, int lddx, int accumulate,
                             recalgo_stream_t stream);

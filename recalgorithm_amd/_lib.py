@@ -79,6 +79,7 @@ SIGNATURES = {
     "recalgo_cross_layer_fwd": (c_int, [P, P, c_int, P, P, c_int, c_int, P, c_int, P]),
     "recalgo_cross_layer_bwd": (c_int, [P, P, c_int, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P]),
     "recalgo_dense_fwd": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, P, c_int, P]),
+    "recalgo_dense_fwd_bn": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, P, c_int, P, P]),
     "recalgo_dense_bwd_input": (c_int, [P, c_int, P, P, c_int, c_int, c_int, P, c_int, c_float, P, c_int, c_int, P]),
     "recalgo_dense_bwd_weights_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "recalgo_dense_bwd_weights": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, P, P, P, c_int, P]),

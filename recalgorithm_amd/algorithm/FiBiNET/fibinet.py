@@ -74,7 +74,7 @@ def fibinet_model_fn(features, labels, mode, params):
     with variable_scope("dnn_part"):
         net = bi_total
         for unit in params["hidden_units"]:
-            net = nn.dense(net, unit, activation="relu")
+            net = nn.dense(net, unit, activation="relu", bn_stats=bool(params["batch_norm"]) and training)
             if "dropout_rate" in params and 0.0 < params["dropout_rate"] < 1.0:
                 net = nn.dropout(net, params["dropout_rate"], training=training)
             if params["batch_norm"]:

@@ -68,7 +68,7 @@ def nfm_model_fn(features, labels, mode, params):
     with variable_scope("dnn_part"):
         net = x
         for unit in params["hidden_units"]:
-            net = nn.dense(net, unit, activation="relu")
+            net = nn.dense(net, unit, activation="relu", bn_stats=bool(params["batch_norm"]) and training)
             if params["batch_norm"]:
                 net = nn.batch_normalization(net, training=training)
             if "dropout_rate" in params and 0.0 < params["dropout_rate"] < 1.0:

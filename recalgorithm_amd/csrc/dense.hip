@@ -309,6 +309,10 @@ struct FwdArgs {
     float* y;
     int ldy;
     int M, N;
+    // optional: the BatchNorm layer that consumes y (tf.layers.dense -> tf.layers.batch_normalization, deepfm.py:207-211) gets
+    // the batch moments of this workgroup's 64-row tile from the epilogue — [tile][0:N] = mean, [tile][N:2N] = sum of squared
+    // deviations from it, the partial-row layout of recalgo_batchnorm_moments — instead of a pass of its own over y
+    float* bn_partials;
 };
 
 template <bool FAST>
@@ -328,16 +332,58 @@ __global__ __launch_bounds__(kThreads) void dense_fwd_kernel(FwdArgs P) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hi = lane >> 5, l32 = lane & 31;
     const int col = n0 + (wave & 1) * 32 + l32;
-    if (col >= P.N) return;
-    const float bv = P.bias ? P.bias[col] : 0.f;
+    if (P.bn_partials == nullptr) {
+        if (col >= P.N) return;
+        const float bv = P.bias ? P.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (row < P.M) {
+                float v = acc[r] + bv;
+                if (P.relu) v = fmaxf(v, 0.f);
+                P.y[(size_t)row * P.ldy + col] = v;
+            }
+        }
+        return;
+    }
+    // ---- the same store + the tile's column moments (two-pass inside the tile: mean first, then deviations) ----------
+    const bool cok = col < P.N;
+    const float bv = (cok && P.bias) ? P.bias[col] : 0.f;
+    float vals[16];
+    float s = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = m0 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (row < P.M) {
-            float v = acc[r] + bv;
-            if (P.relu) v = fmaxf(v, 0.f);
-            P.y[(size_t)row * P.ldy + col] = v;
-        }
+        float v = acc[r] + bv;
+        if (P.relu) v = fmaxf(v, 0.f);
+        const bool ok = cok && row < P.M;
+        vals[r] = ok ? v : 0.f;
+        if (ok) P.y[(size_t)row * P.ldy + col] = v;
+        s += vals[r];
+    }
+    s += __shfl_xor(s, 32, 64);                               // the wave's 32 rows of this column
+    float* red = As;                                          // [2 row halves][64 columns] (the operand ring is free)
+    __syncthreads();
+    if (hi == 0) red[(wave >> 1) * 64 + (wave & 1) * 32 + l32] = s;
+    __syncthreads();
+    const int cl = (wave & 1) * 32 + l32;
+    const int nrows = min(P.M - m0, BM);
+    const float mean = (red[cl] + red[64 + cl]) * (1.0f / (float)nrows);
+    float q = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float dlt = vals[r] - mean;
+        if (cok && row < P.M) q = fmaf(dlt, dlt, q);
+    }
+    q += __shfl_xor(q, 32, 64);
+    __syncthreads();
+    if (hi == 0) red[(wave >> 1) * 64 + cl] = q;
+    __syncthreads();
+    if ((wave >> 1) == 0 && hi == 0 && cok) {
+        float* prow = P.bn_partials + (size_t)(m0 / BM) * 2 * P.N;
+        prow[col] = mean;
+        prow[P.N + col] = red[cl] + red[64 + cl];
     }
 }
 
@@ -628,6 +674,12 @@ inline size_t wgrad_slab(int K, int N) { return ((size_t)K * N + N + 3) / 4 * 4;
 RECALGO_EXPORT int recalgo_dense_fwd(const float* x, int ldx, const float* w, int K, const float* x2, int ldx2,
                                      const float* w2, int K2, const float* bias, int M, int N, int relu, float* y,
                                      int ldy, recalgo_stream_t stream) {
+    return recalgo_dense_fwd_bn(x, ldx, w, K, x2, ldx2, w2, K2, bias, M, N, relu, y, ldy, nullptr, stream);
+}
+
+RECALGO_EXPORT int recalgo_dense_fwd_bn(const float* x, int ldx, const float* w, int K, const float* x2, int ldx2,
+                                        const float* w2, int K2, const float* bias, int M, int N, int relu, float* y,
+                                        int ldy, float* bn_partials, recalgo_stream_t stream) {
     RECALGO_REQUIRE(M >= 0 && N > 0 && K > 0 && y != nullptr && ldy >= N);
     RECALGO_REQUIRE(x != nullptr && ldx >= K && w != nullptr);
     RECALGO_REQUIRE(x2 == nullptr || (ldx2 >= K2 && K2 > 0 && w2 != nullptr));
@@ -637,6 +689,7 @@ RECALGO_EXPORT int recalgo_dense_fwd(const float* x, int ldx, const float* w, in
     P.seg[1] = Segment{operand(x2, nullptr, ldx2, M, K2), operand(w2, nullptr, N, K2, N), K2};
     P.nseg = x2 ? 2 : 1;
     P.bias = bias; P.relu = relu; P.y = y; P.ldy = ldy; P.M = M; P.N = N;
+    P.bn_partials = bn_partials;
     const int grid = cdiv(M, BM) * cdiv(N, BN);
     const bool fast = fast_rc(P.seg[0].a, K) && fast_rm(P.seg[0].b, N) && fast_rc(P.seg[1].a, K2) && fast_rm(P.seg[1].b, N);
     if (fast) hipLaunchKernelGGL(dense_fwd_kernel<true>, dim3(grid), dim3(kThreads), 0, as_stream(stream), P);

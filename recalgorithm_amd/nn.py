@@ -69,7 +69,7 @@ def _merged_bwd() -> bool:
 class _DenseFn(Function):
     @staticmethod
     def forward(ctx, anchor, x, kernel: Variable, bias: Optional[Variable], relu: bool, input_l2: float = 0.0,
-                grad_join: Optional[GradJoin] = None):
+                grad_join: Optional[GradJoin] = None, bn_partials: Optional[torch.Tensor] = None):
         ctx.input_l2 = float(input_l2)
         ctx.grad_join = grad_join
         x2 = x.reshape(-1, x.shape[-1])
@@ -79,7 +79,7 @@ class _DenseFn(Function):
             if x2.stride(1) != 1:
                 x2 = x2.contiguous()
             # GEMM + bias + ReLU in one launch
-            y = ops.dense_fwd(x2, kernel.data, None if bias is None else bias.data, relu)
+            y = ops.dense_fwd(x2, kernel.data, None if bias is None else bias.data, relu, bn_partials=bn_partials)
         elif bias is not None and relu and x2.is_cuda:
             y = torch._addmm_activation(bias.data, x2, kernel.data)     # GEMM + bias + ReLU epilogue (hipBLASLt)
         else:
@@ -111,7 +111,7 @@ class _DenseFn(Function):
                                    beta=ctx.input_l2, defer=True).view(ctx.xshape)
                 if ctx.grad_join is not None and ctx.grad_join.park(dx):
                     dx = None                      # added by the other consumer of x in its backward kernel
-                return None, dx, None, None, None, None, None
+                return None, dx, None, None, None, None, None, None
             if _wgrad_side_stream():
                 # (measured: slower — DCN step 0.319 vs 0.268 ms: the cross-stream dependencies cost more than the overlap
                 # buys.  Kept as an experiment switch.)
@@ -129,7 +129,7 @@ class _DenseFn(Function):
                                          c_in=x2 if ctx.input_l2 else None, beta=ctx.input_l2).view(ctx.xshape)
                 if ctx.grad_join is not None and ctx.grad_join.park(dx):
                     dx = None                      # added by the other consumer of x in its backward kernel
-            return None, dx, None, None, None, None, None
+            return None, dx, None, None, None, None, None, None
         if not g2.is_contiguous():
             g2 = g2.contiguous()
         if bias is not None and _hip(g2, g2.shape[1]):
@@ -146,7 +146,7 @@ class _DenseFn(Function):
             dx = torch.addmm(x2, g2, kernel.data.t(), beta=ctx.input_l2)
         else:
             dx = g2 @ kernel.data.t()
-        return None, dx.view(ctx.xshape), None, None, None, None, None
+        return None, dx.view(ctx.xshape), None, None, None, None, None, None
 
 
 class _Dense1Fn(Function):
@@ -236,13 +236,17 @@ def concat(values, axis: int = -1):
 
 def dense(x, units, activation: Optional[str] = None,
           use_bias: bool = True, name: Optional[str] = None, input_l2: float = 0.0,
-          grad_join: Optional[GradJoin] = None) -> torch.Tensor:
+          grad_join: Optional[GradJoin] = None, bn_stats: bool = False) -> torch.Tensor:
     """tf.layers.dense(x, units, activation=None|relu, use_bias, name).  `units` may be a
     str (the reference passes FLAGS.hidden_units.split(','), deepfm.py:286; quirk B-2).
     Variables: <scope>/<name>/kernel (glorot-uniform), <scope>/<name>/bias (zeros).
     `input_l2` = c (not a TF argument): the caller adds the loss term (c / 2) * sum(x^2) as a VALUE only
     (`l2_value`) and this layer adds its gradient c * x to the input gradient inside the dgrad GEMM
-    (beta * C epilogue) — c must already contain the loss-gradient seed (ops.loss_seed)."""
+    (beta * C epilogue) — c must already contain the loss-gradient seed (ops.loss_seed).
+    `bn_stats` (not a TF argument): a training-mode tf.layers.batch_normalization consumes this layer's output next (the
+    dense -> [dropout] -> batch_norm order of deepfm.py:207-211): the GEMM's epilogue leaves the batch moments of its tiles
+    and `batch_normalization` runs without a moments pass of its own (it finds them attached to the tensor it is given —
+    a dropout in between makes a new tensor, and the BatchNorm layer computes its own moments as before)."""
     store = current_store()
     units = int(units)
     name = name or store.auto_name("dense")
@@ -261,7 +265,15 @@ def dense(x, units, activation: Optional[str] = None,
             return _Dense1Fn.apply(store.anchor, kernel, bias, *parts)
     if isinstance(x, LazyConcat):
         x = x.materialize()
-    return _DenseFn.apply(store.anchor, x, kernel, bias, activation == "relu", input_l2, grad_join)
+    bn_part = None
+    if (bn_stats and not store.building and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and units % 4 == 0
+            and _mfma_dense(x.shape[1]) and getattr(getattr(store.anchor, "_recalgo_store", None), "sync_bn", None) is None):
+        from . import ops
+        bn_part = torch.empty(ops.bn_partial_rows(x.shape[0]), 2 * units, device=x.device, dtype=torch.float32)
+    out = _DenseFn.apply(store.anchor, x, kernel, bias, activation == "relu", input_l2, grad_join, bn_part)
+    if bn_part is not None:
+        out._recalgo_bn_partials = bn_part
+    return out
 
 
 def dense_with(x: torch.Tensor, kernel: Variable, bias: Optional[Variable] = None, relu: bool = False) -> torch.Tensor:
@@ -286,7 +298,7 @@ def l2_value(x: torch.Tensor, half_coeff: float) -> torch.Tensor:
 class _BatchNormTrainFn(Function):
     @staticmethod
     def forward(ctx, anchor, x, gamma: Variable, beta: Variable, mmean: Variable, mvar: Variable,
-                momentum: float, eps: float):
+                momentum: float, eps: float, partials: Optional[torch.Tensor] = None):
         ctx.vars = (gamma, beta)
         ctx.hip = x.dim() == 2 and x.is_contiguous() and _hip(x, x.shape[1])
         # Sync-BatchNorm (parallel.attach_data_parallel(sync_batch_norm=True)): statistics over the GLOBAL batch
@@ -298,7 +310,8 @@ class _BatchNormTrainFn(Function):
             if ctx.sync is not None:
                 y, mean, rstd = ops.batchnorm_sync_fwd(x, gamma.data, beta.data, mmean.data, mvar.data, momentum, eps, ctx.sync)
             else:
-                y, mean, rstd = ops.batchnorm_train_fwd(x, gamma.data, beta.data, mmean.data, mvar.data, momentum, eps)
+                y, mean, rstd = ops.batchnorm_train_fwd(x, gamma.data, beta.data, mmean.data, mvar.data, momentum, eps,
+                                                        partials=partials)
             ctx.save_for_backward(x, mean, rstd)
             return y
         mean = x.mean(dim=0)
@@ -323,7 +336,7 @@ class _BatchNormTrainFn(Function):
                 dx = ops.batchnorm_sync_bwd(x, gamma.data, mean, rstd, g.contiguous(), gamma.grad, beta.grad, ctx.sync)
             else:
                 dx = ops.batchnorm_train_bwd(x, gamma.data, mean, rstd, g.contiguous(), gamma.grad, beta.grad)
-            return None, dx, None, None, None, None, None, None
+            return None, dx, None, None, None, None, None, None, None
         xhat, rstd = ctx.saved_tensors
         B = g.shape[0]
         dbeta = g.sum(dim=0)
@@ -331,7 +344,7 @@ class _BatchNormTrainFn(Function):
         gamma.grad.copy_(dgamma)
         beta.grad.copy_(dbeta)
         dx = (gamma.data * rstd / B) * (B * g - dbeta - xhat * dgamma)
-        return None, dx, None, None, None, None, None, None
+        return None, dx, None, None, None, None, None, None, None
 
 
 class _BatchNormInferFn(Function):
@@ -359,7 +372,9 @@ def batch_normalization(x: torch.Tensor, training: bool = False,
         mmean = store.get_variable("moving_mean", (C,), zeros, trainable=False)
         mvar = store.get_variable("moving_variance", (C,), ones, trainable=False)
     if training:
-        return _BatchNormTrainFn.apply(store.anchor, x, gamma, beta, mmean, mvar, momentum, epsilon)
+        # (batch moments left behind by the producing dense layer's epilogue, see dense(bn_stats=))
+        pre = getattr(x, "_recalgo_bn_partials", None) if (x.dim() == 2 and x.is_contiguous()) else None
+        return _BatchNormTrainFn.apply(store.anchor, x, gamma, beta, mmean, mvar, momentum, epsilon, pre)
     inv = torch.rsqrt(mvar.data + epsilon) * gamma.data
     return _BatchNormInferFn.apply(x, inv, beta.data - mmean.data * inv)
 

@@ -969,9 +969,16 @@ def _mat(t: torch.Tensor, name: str) -> torch.Tensor:
     return t
 
 
+def bn_partial_rows(rows: int) -> int:
+    return int(_lib_().recalgo_batchnorm_partial_rows(int(rows)))
+
+
 def dense_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu: bool,
-              x2: Optional[torch.Tensor] = None, w2: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """act(x @ w (+ x2 @ w2) + bias) on the fp32 matrix cores (include/recalgo.h recalgo_dense_fwd)."""
+              x2: Optional[torch.Tensor] = None, w2: Optional[torch.Tensor] = None,
+              bn_partials: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(x @ w (+ x2 @ w2) + bias) on the fp32 matrix cores (include/recalgo.h recalgo_dense_fwd).  bn_partials
+    [bn_partial_rows(M), 2 N]: the launch also leaves the per-tile batch moments of the result there (recalgo_dense_fwd_bn),
+    for the BatchNorm layer that consumes it (batchnorm_train_fwd(..., partials=))."""
     x, w = _mat(x, "x"), _mat(w, "w")
     M, K = x.shape
     N = w.shape[1]
@@ -982,9 +989,11 @@ def dense_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], re
         if w2.shape != (x2.shape[1], N) or w2.stride(0) != N or x2.shape[0] != M:
             raise ValueError("dense_fwd: second operand pair does not match")
     y = torch.empty(M, N, device=x.device, dtype=torch.float32)
-    _lib.check(_lib_().recalgo_dense_fwd(
+    if bn_partials is not None and (tuple(bn_partials.shape) != (bn_partial_rows(M), 2 * N) or not bn_partials.is_contiguous()):
+        raise ValueError("dense_fwd: bn_partials must be a contiguous [bn_partial_rows(M), 2 N] tensor")
+    _lib.check(_lib_().recalgo_dense_fwd_bn(
         _p(x), x.stride(0), _p(w), K, _p(x2), 0 if x2 is None else x2.stride(0), _p(w2), 0 if x2 is None else x2.shape[1],
-        _p(bias), M, N, int(relu), _p(y), N, _stream(x)), "recalgo_dense_fwd")
+        _p(bias), M, N, int(relu), _p(y), N, _p(bn_partials), _stream(x)), "recalgo_dense_fwd")
     return y
 
 
@@ -1173,13 +1182,20 @@ def dense1_bwd(parts, w: torch.Tensor, g: torch.Tensor, dxs, dw: torch.Tensor, d
                                       _p(ws), _stream(g)), "recalgo_dense1_bwd")
 
 
-def batchnorm_train_fwd(x, gamma, beta, moving_mean, moving_var, momentum: float, eps: float):
+def batchnorm_train_fwd(x, gamma, beta, moving_mean, moving_var, momentum: float, eps: float, partials=None):
+    """partials: the per-tile moments of x when its producer has already left them (dense_fwd(bn_partials=)): ONE launch
+    (merge + apply) instead of two."""
     rows, C = x.shape
     lib = _lib_()
-    ws = _workspace(lib.recalgo_batchnorm_workspace_bytes(rows, C), x.device)
     y = torch.empty_like(x)
     mean = torch.empty(C, device=x.device, dtype=torch.float32)
     rstd = torch.empty(C, device=x.device, dtype=torch.float32)
+    if partials is not None:
+        _lib.check(lib.recalgo_batchnorm_apply(_p(x), _p(gamma), _p(beta), _p(partials), 1, rows, C, eps, momentum,
+                                               _p(moving_mean), _p(moving_var), _p(y), _p(mean), _p(rstd), _stream(x)),
+                   "recalgo_batchnorm_apply")
+        return y, mean, rstd
+    ws = _workspace(lib.recalgo_batchnorm_workspace_bytes(rows, C), x.device)
     _lib.check(lib.recalgo_batchnorm_train_fwd(_p(x), _p(gamma), _p(beta), rows, C, eps, momentum, _p(moving_mean),
                                                _p(moving_var), _p(y), _p(mean), _p(rstd), _p(ws), _stream(x)),
                "recalgo_batchnorm_train_fwd")

@@ -138,3 +138,41 @@ def test_dense_merged_bwd_is_bit_identical_to_the_two_launches(dev, M, K, N):
     dx2 = ops.dense_bwd_input(g, y, w, c_in=c_in, beta=0.5)
     ops.dense_bwd_weights(x, g, y, dw2, db2)
     assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("M,K,N", [(4096, 416, 512), (4096, 512, 256), (300, 82, 100), (65, 48, 8), (64, 33, 68)])
+def test_dense_fwd_leaves_the_batchnorm_moments_of_its_tiles(dev, M, K, N):
+    """recalgo_dense_fwd_bn: the epilogue's per-tile (mean, sum of squared deviations) rows are what recalgo_batchnorm_moments
+    computes from y in a pass of its own (same layout, same two-pass definition), y itself is unchanged, and BatchNorm fed
+    with them equals BatchNorm computing its own moments (dense -> batch_normalization, deepfm.py:207-211)."""
+    import ctypes
+    from recalgorithm_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=gen).to(dev)
+    w = (torch.randn(K, N, generator=gen) / K ** 0.5).to(dev)
+    b = (torch.randn(N, generator=gen) * 0.1).to(dev)
+    nb = ops.bn_partial_rows(M)
+    part = torch.full((nb, 2 * N), float("nan"), device=dev)
+    y = ops.dense_fwd(x, w, b, True, bn_partials=part)
+    y0 = ops.dense_fwd(x, w, b, True)
+    assert torch.equal(y, y0)
+    want = torch.empty(nb, 2 * N, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.check(lib.recalgo_batchnorm_moments(p(y0), M, N, p(want), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "moments")
+    assert_close(part[:, :N], want[:, :N].double(), what="tile means from the GEMM epilogue")
+    assert_close(part[:, N:], want[:, N:].double(), what="tile M2 from the GEMM epilogue", reduced=True)
+    # against the definition, in fp64
+    yd = y0.double().cpu()
+    for t in (0, nb - 1):
+        rows = yd[t * 64:min(M, t * 64 + 64)]
+        assert_close(part[t, :N], rows.mean(0), what=f"tile {t} mean vs fp64", reduced=True)
+        assert_close(part[t, N:], ((rows - rows.mean(0)) ** 2).sum(0), what=f"tile {t} M2 vs fp64", reduced=True)
+    gamma, beta = torch.rand(N, device=dev) + 0.5, torch.randn(N, device=dev)
+    mm1, mv1, mm2, mv2 = torch.zeros(N, device=dev), torch.ones(N, device=dev), torch.zeros(N, device=dev), torch.ones(N, device=dev)
+    o1, mean1, rstd1 = ops.batchnorm_train_fwd(y0, gamma, beta, mm1, mv1, 0.99, 1e-3)
+    o2, mean2, rstd2 = ops.batchnorm_train_fwd(y0, gamma, beta, mm2, mv2, 0.99, 1e-3, partials=part)
+    assert_close(o2, o1.double(), what="BatchNorm on the epilogue's moments", reduced=True)
+    assert_close(mean2, mean1.double(), what="batch mean")
+    assert_close(rstd2, rstd1.double(), what="batch rstd")
+    assert_close(mv2, mv1.double(), what="moving variance")
