@@ -216,8 +216,13 @@ int recalgo_din_attention_fwd(const float* query, const float* keys, const int32
                               int H, int is_softmax, float* out, recalgo_stream_t stream);
 /* Backward (DIN attention): recomputes the forward, returns dquery [B,H],
  * dkeys [B,T,H] and the six parameter gradients (overwritten; deterministic two-pass sum).
- * workspace: recalgo_din_attention_bwd_workspace_bytes(B, T, H). */
+ * workspace: recalgo_din_attention_bwd_workspace_bytes(B, T, H).  d_f1_w == NULL: the second pass is left to the caller —
+ * the workspace then holds recalgo_din_attention_bwd_partial_rows(B) rows of recalgo_din_attention_bwd_partial_floats(H)
+ * floats laid out [d_f1_w | d_f1_b | d_f2_w | d_f2_b | d_f3_w | d_f3_b], to be summed column-wise in row order (e.g. as
+ * jobs of recalgo_dense_bwd_weights_reduce, the step's deferred-sum launch). */
 int64_t recalgo_din_attention_bwd_workspace_bytes(int B, int T, int H);
+int recalgo_din_attention_bwd_partial_rows(int B);
+int recalgo_din_attention_bwd_partial_floats(int H);
 int recalgo_din_attention_bwd(const float* query, const float* keys, const int32_t* keys_length,
                               const float* f1_w, const float* f1_b, const float* f2_w,
                               const float* f2_b, const float* f3_w, const float* f3_b,
@@ -365,6 +370,14 @@ int recalgo_dense_fwd(const float* x, int ldx, const float* w, int K, const floa
 int recalgo_dense_fwd_bn(const float* x, int ldx, const float* w, int K, const float* x2, int ldx2, const float* w2, int K2,
                          const float* bias, int M, int N, int relu, float* y, int ldy, float* bn_partials,
                          recalgo_stream_t stream);
+/* ... with the per-channel activation of DIN's fcn layers in between (tf.layers.dense -> dice | prelu ->
+ * tf.layers.batch_normalization, /root/reference algorithm/DIN/din.py:262-266): z = x W + b is written to z [M][ldy] (the
+ * activation's backward needs it), y = act(z, act_alpha) and bn_partials are the moments of y.  act_kind: RECALGO_ACT_PRELU /
+ * RECALGO_ACT_DICE (needs bn_partials, relu == 0), or RECALGO_ACT_NONE: recalgo_dense_fwd_bn. */
+#define RECALGO_ACT_NONE (-1)
+int recalgo_dense_fwd_act_bn(const float* x, int ldx, const float* w, int K, const float* x2, int ldx2, const float* w2,
+                             int K2, const float* bias, int M, int N, int relu, int act_kind, const float* act_alpha,
+                             float* z, float* y, int ldy, float* bn_partials, recalgo_stream_t stream);
 int recalgo_dense_bwd_input(const float* g, int ldg, const float* y_mask, const float* w, int M, int N, int K,
                             const float* c_in, int ldc, float beta, float* dx, int lddx, int accumulate,
                             recalgo_stream_t stream);
@@ -412,6 +425,16 @@ int recalgo_batchnorm_train_fwd(const float* x, const float* gamma, const float*
 int recalgo_batchnorm_train_bwd(const float* x, const float* gamma, const float* save_mean,
                                 const float* save_rstd, const float* g, int rows, int C, float* dx,
                                 float* dgamma, float* dbeta, void* workspace, recalgo_stream_t stream);
+/* The same backward, continued through the per-channel activation that produced x = act(act_z, act_alpha) (DIN's dense ->
+ * dice | prelu -> batch_norm, din.py:262-266; see recalgo_activation_bwd): dx is then dL/d(act_z), dalpha [C] = dL/d(alpha).
+ * dalpha == NULL: the recalgo_batchnorm_partial_rows(rows) partial rows [C] of dalpha are left at float offset
+ * partial_rows * 2 * C of the workspace for the caller to sum (a job of recalgo_dense_bwd_weights_reduce).
+ * workspace: recalgo_batchnorm_bwd_act_workspace_bytes(rows, C).  act_kind == RECALGO_ACT_NONE: recalgo_batchnorm_train_bwd. */
+int64_t recalgo_batchnorm_bwd_act_workspace_bytes(int rows, int C);
+int recalgo_batchnorm_train_bwd_act(const float* x, const float* gamma, const float* save_mean, const float* save_rstd,
+                                    const float* g, int rows, int C, int act_kind, const float* act_z, const float* act_alpha,
+                                    float* dx, float* dgamma, float* dbeta, float* dalpha, void* workspace,
+                                    recalgo_stream_t stream);
 /* Sync-BatchNorm building blocks (data parallel, N > 1, `sync_batch_norm`): the two launches of each direction as separate
  * entry points, so that the per-tile partials of all ranks — [recalgo_batchnorm_partial_rows(rows)][2][C] floats per rank:
  * (tile mean | tile M2) forward, (colsum g | colsum g * xhat) backward — can be all-gathered rank-major in between.
@@ -595,6 +618,9 @@ int recalgo_concat_sumsq(const float* const* parts, const int* widths, int n_par
                          float* sum_out, void* workspace, recalgo_stream_t stream);
 int recalgo_activation_fwd(const float* x, const float* alpha, int rows, int C, int kind, float* y,
                            recalgo_stream_t stream);
+/* dalpha == NULL: the column sum over the recalgo_activation_bwd_partial_rows(rows, C) partial rows [C] the kernel leaves in
+ * the workspace is the caller's (a job of the step's deferred-sum launch). */
+int recalgo_activation_bwd_partial_rows(int rows, int C);
 int64_t recalgo_activation_bwd_workspace_bytes(int rows, int C);
 int recalgo_activation_bwd(const float* x, const float* alpha, const float* gy, int rows, int C,
                            int kind, float* dx, float* dalpha, void* workspace,

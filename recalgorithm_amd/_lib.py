@@ -37,6 +37,8 @@ SIGNATURES = {
                                       P, c_int, P, c_int, P, P, P]),
     "recalgo_din_attention_fwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "recalgo_din_attention_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
+    "recalgo_din_attention_bwd_partial_rows": (c_int, [c_int]),
+    "recalgo_din_attention_bwd_partial_floats": (c_int, [c_int]),
     "recalgo_din_attention_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int,
                                           P, P, P, P, P, P, P, P, P, P]),
     "recalgo_senet_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
@@ -56,6 +58,8 @@ SIGNATURES = {
     "recalgo_batchnorm_workspace_bytes": (c_int64, [c_int, c_int]),
     "recalgo_batchnorm_train_fwd": (c_int, [P, P, P, c_int, c_int, c_float, c_float, P, P, P, P, P, P, P]),
     "recalgo_batchnorm_train_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, P, P, P]),
+    "recalgo_batchnorm_bwd_act_workspace_bytes": (c_int64, [c_int, c_int]),
+    "recalgo_batchnorm_train_bwd_act": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P]),
     "recalgo_batchnorm_partial_rows": (c_int, [c_int]),
     "recalgo_batchnorm_moments": (c_int, [P, c_int, c_int, P, P]),
     "recalgo_batchnorm_apply": (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, c_float, P, P, P, P, P, P]),
@@ -80,6 +84,7 @@ SIGNATURES = {
     "recalgo_cross_layer_bwd": (c_int, [P, P, c_int, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P]),
     "recalgo_dense_fwd": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, P, c_int, P]),
     "recalgo_dense_fwd_bn": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, P, c_int, P, P]),
+    "recalgo_dense_fwd_act_bn": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, P, P, c_int, P, P]),
     "recalgo_dense_bwd_input": (c_int, [P, c_int, P, P, c_int, c_int, c_int, P, c_int, c_float, P, c_int, c_int, P]),
     "recalgo_dense_bwd_weights_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "recalgo_dense_bwd_weights": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, P, P, P, c_int, P]),
@@ -95,6 +100,7 @@ SIGNATURES = {
     "recalgo_ffm_pairs_bwd": (c_int, [P, P, c_int, c_int, c_int, P, P]),
     "recalgo_activation_fwd": (c_int, [P, P, c_int, c_int, c_int, P, P]),
     "recalgo_activation_bwd_workspace_bytes": (c_int64, [c_int, c_int]),
+    "recalgo_activation_bwd_partial_rows": (c_int, [c_int, c_int]),
     "recalgo_activation_bwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, P]),
     "recalgo_embedding_gather_fwd_deferred": (c_int, [P, P, P, c_int, c_int, c_int, P, c_int, c_int, P, P, c_int, P]),
     "recalgo_embedding_bag_mean_fwd_deferred": (c_int, [P, P, P, c_int, c_int, P, c_int, c_int, P, c_int64, P, c_int, P]),

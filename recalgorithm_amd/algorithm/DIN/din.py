@@ -88,10 +88,10 @@ def din_model_fn(features, labels, mode, params):
         net = concat_all
         for i, unit in enumerate(params["hidden_units"]):
             layer_index = i + 1
-            net = nn.dense(net, unit, activation=None, input_l2=(seed * mba_coeff if fused_mba and i == 0 else 0.0))
-            net = dice(net, name=layer_index) if params["activation"] == "dice" else prelu(net, name=layer_index)
-            if params["batch_norm"]:
-                net = nn.batch_normalization(net, training=training)
+            # dense -> dice | prelu -> batch_normalization (din.py:262-266): one autograd node in a training step on the GPU
+            net = nn.dense_activation_bn(net, unit, "dice" if params["activation"] == "dice" else "prelu", layer_index,
+                                         bool(params["batch_norm"]), training,
+                                         input_l2=(seed * mba_coeff if fused_mba and i == 0 else 0.0))
             if "dropout_rate" in params and 0.0 < params["dropout_rate"] < 1.0:
                 net = nn.dropout(net, params["dropout_rate"], training=training)
         logit = nn.dense(net, 1)

@@ -30,6 +30,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "act.h"
 
 namespace {
 
@@ -313,6 +314,12 @@ struct FwdArgs {
     // the batch moments of this workgroup's 64-row tile from the epilogue — [tile][0:N] = mean, [tile][N:2N] = sum of squared
     // deviations from it, the partial-row layout of recalgo_batchnorm_moments — instead of a pass of its own over y
     float* bn_partials;
+    // optional, with bn_partials: the per-channel activation between the two (tf.layers.dense -> dice | prelu ->
+    // tf.layers.batch_normalization, din.py:262-266): z = x W + b goes to `z` (the activation's backward needs it), y and the
+    // moments are those of act(z)
+    const float* act_alpha;    // [N]
+    int act_kind;              // 0: none, 1 + RECALGO_ACT_PRELU, 1 + RECALGO_ACT_DICE
+    float* z;                  // [M][ldy]
 };
 
 template <bool FAST>
@@ -349,6 +356,7 @@ __global__ __launch_bounds__(kThreads) void dense_fwd_kernel(FwdArgs P) {
     // ---- the same store + the tile's column moments (two-pass inside the tile: mean first, then deviations) ----------
     const bool cok = col < P.N;
     const float bv = (cok && P.bias) ? P.bias[col] : 0.f;
+    const float av = (cok && P.act_kind) ? P.act_alpha[col] : 0.f;
     float vals[16];
     float s = 0.f;
 #pragma unroll
@@ -357,6 +365,10 @@ __global__ __launch_bounds__(kThreads) void dense_fwd_kernel(FwdArgs P) {
         float v = acc[r] + bv;
         if (P.relu) v = fmaxf(v, 0.f);
         const bool ok = cok && row < P.M;
+        if (P.act_kind) {
+            if (ok) P.z[(size_t)row * P.ldy + col] = v;
+            v = P.act_kind == 1 + RECALGO_ACT_DICE ? recalgo_act::dice(v, av) : recalgo_act::prelu(v, av);
+        }
         vals[r] = ok ? v : 0.f;
         if (ok) P.y[(size_t)row * P.ldy + col] = v;
         s += vals[r];
@@ -532,7 +544,7 @@ __global__ __launch_bounds__(kThreads) void dense_bwd_kernel(DgradArgs D, WgradA
 // (Tried instead: letting the last-arriving workgroup of each tile do the sum inside the wgrad kernel, with the
 // agent-scope release / ticket / acquire hand-off — correct, but the per-workgroup L2 write-back made the
 // [4096 x 256 x 128] wgrad 56 us instead of 18 + 7; the partials of one launch stay cheap only across a kernel boundary.)
-constexpr int kMaxSplitJobs = 16;
+constexpr int kMaxSplitJobs = 32;
 struct SplitJob {
     const float* partials;
     float* out0;
@@ -680,7 +692,17 @@ RECALGO_EXPORT int recalgo_dense_fwd(const float* x, int ldx, const float* w, in
 RECALGO_EXPORT int recalgo_dense_fwd_bn(const float* x, int ldx, const float* w, int K, const float* x2, int ldx2,
                                         const float* w2, int K2, const float* bias, int M, int N, int relu, float* y,
                                         int ldy, float* bn_partials, recalgo_stream_t stream) {
+    return recalgo_dense_fwd_act_bn(x, ldx, w, K, x2, ldx2, w2, K2, bias, M, N, relu, RECALGO_ACT_NONE, nullptr, nullptr, y, ldy,
+                                    bn_partials, stream);
+}
+
+RECALGO_EXPORT int recalgo_dense_fwd_act_bn(const float* x, int ldx, const float* w, int K, const float* x2, int ldx2,
+                                            const float* w2, int K2, const float* bias, int M, int N, int relu, int act_kind,
+                                            const float* act_alpha, float* z, float* y, int ldy, float* bn_partials,
+                                            recalgo_stream_t stream) {
     RECALGO_REQUIRE(M >= 0 && N > 0 && K > 0 && y != nullptr && ldy >= N);
+    RECALGO_REQUIRE(act_kind == RECALGO_ACT_NONE || ((act_kind == RECALGO_ACT_PRELU || act_kind == RECALGO_ACT_DICE) &&
+                                                     act_alpha != nullptr && z != nullptr && bn_partials != nullptr && !relu));
     RECALGO_REQUIRE(x != nullptr && ldx >= K && w != nullptr);
     RECALGO_REQUIRE(x2 == nullptr || (ldx2 >= K2 && K2 > 0 && w2 != nullptr));
     if (M == 0) return 0;
@@ -690,6 +712,7 @@ RECALGO_EXPORT int recalgo_dense_fwd_bn(const float* x, int ldx, const float* w,
     P.nseg = x2 ? 2 : 1;
     P.bias = bias; P.relu = relu; P.y = y; P.ldy = ldy; P.M = M; P.N = N;
     P.bn_partials = bn_partials;
+    P.act_alpha = act_alpha; P.act_kind = act_kind == RECALGO_ACT_NONE ? 0 : 1 + act_kind; P.z = z;
     const int grid = cdiv(M, BM) * cdiv(N, BN);
     const bool fast = fast_rc(P.seg[0].a, K) && fast_rm(P.seg[0].b, N) && fast_rc(P.seg[1].a, K2) && fast_rm(P.seg[1].b, N);
     if (fast) hipLaunchKernelGGL(dense_fwd_kernel<true>, dim3(grid), dim3(kThreads), 0, as_stream(stream), P);

@@ -527,6 +527,11 @@ RECALGO_EXPORT int64_t recalgo_din_attention_bwd_workspace_bytes(int B, int T, i
     return (int64_t)din_grid(B) * pf * (int64_t)sizeof(float);
 }
 
+RECALGO_EXPORT int recalgo_din_attention_bwd_partial_rows(int B) { return B > 0 ? din_grid(B) : 0; }
+RECALGO_EXPORT int recalgo_din_attention_bwd_partial_floats(int H) {
+    return H == 4 ? din_partial_floats<4>() : (H == 8 ? din_partial_floats<8>() : (H == 16 ? din_partial_floats<16>() : 0));
+}
+
 RECALGO_EXPORT int recalgo_din_attention_bwd(const float* query, const float* keys, const int32_t* keys_length,
                                              const float* f1_w, const float* f1_b, const float* f2_w,
                                              const float* f2_b, const float* f3_w, const float* f3_b,
@@ -554,6 +559,7 @@ RECALGO_EXPORT int recalgo_din_attention_bwd(const float* query, const float* ke
 #undef LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
+    if (d_f1_w == nullptr) return 0;              // the caller sums the partial rows (a job of the step's deferred-sum launch)
     // the partial row is laid out exactly as [d_f1_w | d_f1_b | d_f2_w | d_f2_b | d_f3_w | d_f3_b]:
     // reduce it segment by segment into the caller's six buffers
     struct Seg { float* dst; int off, n; };

@@ -16,6 +16,7 @@
 // left for the fixed-order (deterministic) second stage.  (The first version used 8-row blocks:
 // its second stages walked rows/8 partial rows and cost 10-22 us per layer.)  Requires C % 4 == 0.
 #include "common.h"
+#include "act.h"
 
 namespace {
 
@@ -214,11 +215,17 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float4* _
 // dbeta / dgamma = fixed-order column sums of the partial rows (16 interleaved row groups, then the groups), repeated by
 // every workgroup of a column block (see bn_finalize_apply_kernel) and recorded by tile row 0; then
 // dx = gamma * rstd * (g - (dbeta + xhat * dgamma) / rows) on the 64 x 64 tile.
+// ACT = 1 + RECALGO_ACT_PRELU / 1 + RECALGO_ACT_DICE: x = act(z, alpha) came out of a per-channel activation (the dense ->
+// dice -> batch_norm layers of din.py:262-266) and the pass continues through it — dx is then dL/dz and act_partials[tile
+// row][C] the tile's terms of dL/dalpha (the layout and order of act_bwd_tile_kernel in tail.hip) — instead of a launch and a
+// round trip of dL/dx in between.
+template <int ACT>
 __global__ __launch_bounds__(kThreads) void bn_bwd_sum_apply_kernel(
     const float4* __restrict__ x, const float4* __restrict__ g, const float4* __restrict__ gamma,
     const float4* __restrict__ mean, const float4* __restrict__ rstd, const float4* __restrict__ partials,
     unsigned nblk, unsigned nblk_local, unsigned rank, unsigned rows, unsigned C4, float4* __restrict__ dbeta,
-    float4* __restrict__ dgamma, float4* __restrict__ dx) {
+    float4* __restrict__ dgamma, float4* __restrict__ dx, const float4* __restrict__ act_z,
+    const float4* __restrict__ act_alpha, float4* __restrict__ act_partials) {
     // nblk = world * nblk_local partial rows (see bn_finalize_apply_kernel).  dx uses the sums over ALL ranks' tiles;
     // dbeta / dgamma get THIS rank's share (the data-parallel all-reduce of the dense gradients adds the ranks up)
     __shared__ float4 sh[2][16][17];
@@ -269,20 +276,46 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_sum_apply_kernel(
             dgamma[c4] = tg;
         }
     }
-    if (!ok) return;
+    if (!ok && ACT == 0) return;
     const float inv_rows = 1.0f / ((float)rows * (float)(nblk / nblk_local));
-    const float4 mu = mean[c4], rs4 = rstd[c4];
-    const float4 k = f4_mul(gamma[c4], rs4);
-    const unsigned r0 = blockIdx.y * kTileRows;
+    float4 da = f4_zero();
+    if (ok) {
+        const float4 mu = mean[c4], rs4 = rstd[c4];
+        const float4 k = f4_mul(gamma[c4], rs4);
+        const float4 al = ACT ? act_alpha[c4] : f4_zero();
+        const unsigned r0 = blockIdx.y * kTileRows;
 #pragma unroll
-    for (unsigned t = 0; t < kTileRows / 16; ++t) {
-        const unsigned r = r0 + rl + 16 * t;
-        if (r < rows) {
-            const float4 xh = f4_mul(f4_sub(x[(size_t)r * C4 + c4], mu), rs4);
-            const float4 gv = g[(size_t)r * C4 + c4];
-            dx[(size_t)r * C4 + c4] =
-                make_float4(k.x * (gv.x - inv_rows * (db.x + xh.x * dg.x)), k.y * (gv.y - inv_rows * (db.y + xh.y * dg.y)),
-                            k.z * (gv.z - inv_rows * (db.z + xh.z * dg.z)), k.w * (gv.w - inv_rows * (db.w + xh.w * dg.w)));
+        for (unsigned t = 0; t < kTileRows / 16; ++t) {
+            const unsigned r = r0 + rl + 16 * t;
+            if (r < rows) {
+                const float4 xh = f4_mul(f4_sub(x[(size_t)r * C4 + c4], mu), rs4);
+                const float4 gv = g[(size_t)r * C4 + c4];
+                float4 d =
+                    make_float4(k.x * (gv.x - inv_rows * (db.x + xh.x * dg.x)), k.y * (gv.y - inv_rows * (db.y + xh.y * dg.y)),
+                                k.z * (gv.z - inv_rows * (db.z + xh.z * dg.z)), k.w * (gv.w - inv_rows * (db.w + xh.w * dg.w)));
+                if (ACT) {
+                    const float4 z = act_z[(size_t)r * C4 + c4];
+                    float4 t4;
+                    d = make_float4(recalgo_act::bwd<ACT == 1 + RECALGO_ACT_DICE>(z.x, al.x, d.x, t4.x),
+                                    recalgo_act::bwd<ACT == 1 + RECALGO_ACT_DICE>(z.y, al.y, d.y, t4.y),
+                                    recalgo_act::bwd<ACT == 1 + RECALGO_ACT_DICE>(z.z, al.z, d.z, t4.z),
+                                    recalgo_act::bwd<ACT == 1 + RECALGO_ACT_DICE>(z.w, al.w, d.w, t4.w));
+                    da = f4_add(da, t4);
+                }
+                dx[(size_t)r * C4 + c4] = d;
+            }
+        }
+    }
+    if (ACT) {
+        __syncthreads();                                       // (sh: the column sums above are consumed)
+        float4* shf = &sh[0][0][0];
+        shf[threadIdx.x] = da;
+        __syncthreads();
+        if (rl == 0 && ok) {
+            float4 t = shf[cl];
+#pragma unroll
+            for (unsigned q = 1; q < 16; ++q) t = f4_add(t, shf[q * 16 + cl]);
+            act_partials[(size_t)blockIdx.y * C4 + c4] = t;
         }
     }
 }
@@ -627,22 +660,47 @@ RECALGO_EXPORT int recalgo_batchnorm_train_bwd(const float* x, const float* gamm
                                                const float* save_rstd, const float* g, int rows, int C, float* dx,
                                                float* dgamma, float* dbeta, void* workspace,
                                                recalgo_stream_t stream) {
+    return recalgo_batchnorm_train_bwd_act(x, gamma, save_mean, save_rstd, g, rows, C, RECALGO_ACT_NONE, nullptr, nullptr, dx, dgamma,
+                                           dbeta, nullptr, workspace, stream);
+}
+
+RECALGO_EXPORT int64_t recalgo_batchnorm_bwd_act_workspace_bytes(int rows, int C) {
+    if (rows <= 0 || !width_ok(C)) return 0;
+    return (int64_t)nblk_of(rows) * 3 * C * (int64_t)sizeof(float);
+}
+
+RECALGO_EXPORT int recalgo_batchnorm_train_bwd_act(const float* x, const float* gamma, const float* save_mean,
+                                                   const float* save_rstd, const float* g, int rows, int C, int act_kind,
+                                                   const float* act_z, const float* act_alpha, float* dx, float* dgamma,
+                                                   float* dbeta, float* dalpha, void* workspace, recalgo_stream_t stream) {
     RECALGO_REQUIRE(rows > 0 && width_ok(C) && x && gamma && save_mean && save_rstd && g && dx && dgamma && dbeta &&
                     workspace);
+    RECALGO_REQUIRE(act_kind == RECALGO_ACT_NONE ||
+                    ((act_kind == RECALGO_ACT_PRELU || act_kind == RECALGO_ACT_DICE) && act_z && act_alpha));
     hipStream_t st = as_stream(stream);
     const int nb = nblk_of(rows);
     const unsigned C4 = C / 4;
     float* partials = static_cast<float*>(workspace);
+    float* act_partials = partials + (size_t)nb * 2 * C;        // [nb][C]: the tile rows' terms of dalpha
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C4, 16), nb), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
                        reinterpret_cast<const float4*>(g), reinterpret_cast<const float4*>(save_mean),
                        reinterpret_cast<const float4*>(save_rstd), (unsigned)rows, C4,
                        reinterpret_cast<float4*>(partials));
-    hipLaunchKernelGGL(bn_bwd_sum_apply_kernel, dim3(cdiv(C4, 16), nb), dim3(kThreads), 0, st,
-                       reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(g),
-                       reinterpret_cast<const float4*>(gamma), reinterpret_cast<const float4*>(save_mean),
-                       reinterpret_cast<const float4*>(save_rstd), reinterpret_cast<const float4*>(partials), (unsigned)nb,
-                       (unsigned)nb, 0u, (unsigned)rows, C4, reinterpret_cast<float4*>(dbeta), reinterpret_cast<float4*>(dgamma),
-                       reinterpret_cast<float4*>(dx));
+#define RECALGO_BN_APPLY(ACT)                                                                                                   \
+    hipLaunchKernelGGL(bn_bwd_sum_apply_kernel<ACT>, dim3(cdiv(C4, 16), nb), dim3(kThreads), 0, st,                             \
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(g),                                  \
+                       reinterpret_cast<const float4*>(gamma), reinterpret_cast<const float4*>(save_mean),                      \
+                       reinterpret_cast<const float4*>(save_rstd), reinterpret_cast<const float4*>(partials), (unsigned)nb,     \
+                       (unsigned)nb, 0u, (unsigned)rows, C4, reinterpret_cast<float4*>(dbeta), reinterpret_cast<float4*>(dgamma), \
+                       reinterpret_cast<float4*>(dx), reinterpret_cast<const float4*>(act_z),                                   \
+                       reinterpret_cast<const float4*>(act_alpha), reinterpret_cast<float4*>(act_partials))
+    if (act_kind == RECALGO_ACT_NONE) RECALGO_BN_APPLY(0);
+    else if (act_kind == RECALGO_ACT_PRELU) RECALGO_BN_APPLY(1 + RECALGO_ACT_PRELU);
+    else RECALGO_BN_APPLY(1 + RECALGO_ACT_DICE);
+#undef RECALGO_BN_APPLY
+    // dalpha == NULL: the caller sums the nb partial rows (a job of the step's deferred-sum launch)
+    if (act_kind != RECALGO_ACT_NONE && dalpha)
+        launch_colsum16(act_partials, (unsigned)nb, (unsigned)C, dalpha, (unsigned)C, static_cast<float*>(nullptr), st);
     RECALGO_RETURN_LAST();
 }
 
@@ -693,12 +751,13 @@ RECALGO_EXPORT int recalgo_batchnorm_bwd_apply(const float* x, const float* gamm
     RECALGO_REQUIRE(x && gamma && save_mean && save_rstd && g && partials && dx && dgamma && dbeta);
     const int nb = nblk_of(rows);
     const unsigned C4 = C / 4;
-    hipLaunchKernelGGL(bn_bwd_sum_apply_kernel, dim3(cdiv(C4, 16), nb), dim3(kThreads), 0, as_stream(stream),
+    hipLaunchKernelGGL(bn_bwd_sum_apply_kernel<0>, dim3(cdiv(C4, 16), nb), dim3(kThreads), 0, as_stream(stream),
                        reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(g),
                        reinterpret_cast<const float4*>(gamma), reinterpret_cast<const float4*>(save_mean),
                        reinterpret_cast<const float4*>(save_rstd), reinterpret_cast<const float4*>(partials),
                        (unsigned)(nb * world), (unsigned)nb, (unsigned)rank, (unsigned)rows, C4,
-                       reinterpret_cast<float4*>(dbeta), reinterpret_cast<float4*>(dgamma), reinterpret_cast<float4*>(dx));
+                       reinterpret_cast<float4*>(dbeta), reinterpret_cast<float4*>(dgamma), reinterpret_cast<float4*>(dx),
+                       static_cast<const float4*>(nullptr), static_cast<const float4*>(nullptr), static_cast<float4*>(nullptr));
     RECALGO_RETURN_LAST();
 }
 

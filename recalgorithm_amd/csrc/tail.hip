@@ -1,5 +1,6 @@
 // Loss tail (a14), TF1 Adam (a15), DIN activations (a12) — small streaming kernels, gfx950.
 #include "deferred.h"
+#include "act.h"
 
 namespace {
 
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void adam_tf1_list_kernel(float* __restrict__ 
 // ---------------------------------------------------------------------------------------
 // PReLU / Dice (algorithm/DIN/activations.py:4-37), x: [rows, C], alpha: [C].
 // ---------------------------------------------------------------------------------------
-constexpr float kDiceInvStd = 0.99950037468777310f;  // 1/sqrt(1 + 1e-3): BN inference, stats (0,1)
+using recalgo_act::kDiceInvStd;                      // 1/sqrt(1 + 1e-3): BN inference, stats (0,1)
 
 template <bool DICE>
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x,
@@ -778,6 +779,10 @@ RECALGO_EXPORT int64_t recalgo_activation_bwd_workspace_bytes(int rows, int C) {
     return (int64_t)cdiv(rows, kActRowsPerBlk) * C * (int64_t)sizeof(float);
 }
 
+RECALGO_EXPORT int recalgo_activation_bwd_partial_rows(int rows, int C) {
+    if (rows <= 0 || C <= 0) return 0;
+    return C % 4 == 0 ? cdiv(rows, kActTileRows) : cdiv(rows, kActRowsPerBlk);
+}
 RECALGO_EXPORT int recalgo_activation_bwd(const float* x, const float* alpha, const float* gy,
                                           int rows, int C, int kind, float* dx, float* dalpha,
                                           void* workspace, recalgo_stream_t stream) {
@@ -796,7 +801,7 @@ RECALGO_EXPORT int recalgo_activation_bwd(const float* x, const float* alpha, co
             hipLaunchKernelGGL(act_bwd_tile_kernel<false>, grid, dim3(256), 0, st, reinterpret_cast<const float4*>(x),
                                reinterpret_cast<const float4*>(alpha), reinterpret_cast<const float4*>(gy),
                                (unsigned)rows, C4, reinterpret_cast<float4*>(dx), reinterpret_cast<float4*>(partial));
-        launch_colsum16(partial, nt, (unsigned)C, dalpha, (unsigned)C, static_cast<float*>(nullptr), st);
+        if (dalpha) launch_colsum16(partial, nt, (unsigned)C, dalpha, (unsigned)C, static_cast<float*>(nullptr), st);
         RECALGO_RETURN_LAST();
     }
     const unsigned nblk = (unsigned)cdiv(rows, kActRowsPerBlk);
@@ -806,7 +811,7 @@ RECALGO_EXPORT int recalgo_activation_bwd(const float* x, const float* alpha, co
     else
         hipLaunchKernelGGL(act_bwd_kernel<false>, dim3(nblk), dim3(256), 0, st, x, alpha, gy, (unsigned)rows,
                            (unsigned)C, kActRowsPerBlk, dx, partial);
-    launch_colsum16(partial, nblk, (unsigned)C, dalpha, (unsigned)C, static_cast<float*>(nullptr), st);
+    if (dalpha) launch_colsum16(partial, nblk, (unsigned)C, dalpha, (unsigned)C, static_cast<float*>(nullptr), st);
     RECALGO_RETURN_LAST();
 }
 

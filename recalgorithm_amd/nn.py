@@ -379,6 +379,73 @@ def batch_normalization(x: torch.Tensor, training: bool = False,
     return _BatchNormInferFn.apply(x, inv, beta.data - mmean.data * inv)
 
 
+class _DenseActBNFn(Function):
+    """dense -> prelu | dice -> batch_normalization(training=True) as five launches instead of nine: the GEMM's epilogue applies
+    the activation and leaves the BatchNorm tile moments (ops.dense_fwd_act), the BatchNorm backward continues through the
+    activation (ops.batchnorm_train_bwd_act); same arithmetic per element as the three layers one after the other."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, kernel: Variable, bias: Variable, alpha: Variable, kind: int, gamma: Variable, beta: Variable,
+                mmean: Variable, mvar: Variable, momentum: float, eps: float, input_l2: float):
+        from . import ops
+        x2 = x if x.stride(1) == 1 else x.contiguous()
+        M, N = x2.shape[0], kernel.data.shape[1]
+        partials = torch.empty(ops.bn_partial_rows(M), 2 * N, device=x.device, dtype=torch.float32)
+        z, y = ops.dense_fwd_act(x2, kernel.data, bias.data, kind, alpha.data, partials)
+        out, mean, rstd = ops.batchnorm_train_fwd(y, gamma.data, beta.data, mmean.data, mvar.data, momentum, eps, partials=partials)
+        ctx.vars, ctx.kind, ctx.input_l2 = (kernel, bias, alpha, gamma, beta), kind, float(input_l2)
+        ctx.in_step = ops._loss_seed is not None      # Estimator.train_step: its optimizer runs the deferred column sums
+        ctx.save_for_backward(x2, z, y, mean, rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        kernel, bias, alpha, gamma, beta = ctx.vars
+        x2, z, y, mean, rstd = ctx.saved_tensors
+        dz = ops.batchnorm_train_bwd_act(y, gamma.data, mean, rstd, g.contiguous(), gamma.grad, beta.grad, ctx.kind, z, alpha.data,
+                                         alpha.grad, defer=ctx.in_step)
+        dx = None
+        if ctx.needs_input_grad[1]:
+            dx = ops.dense_bwd(x2, dz, None, kernel.data, kernel.grad, bias.grad, c_in=x2 if ctx.input_l2 else None,
+                               beta=ctx.input_l2, defer=True)
+        else:
+            ops.dense_bwd_weights(x2, dz, None, kernel.grad, bias.grad, defer=True)
+        return (None, dx) + (None,) * 11
+
+
+def dense_activation_bn(x: torch.Tensor, units, kind: str, act_name, batch_norm: bool, training: bool,
+                        input_l2: float = 0.0, momentum: float = 0.99, epsilon: float = 1e-3) -> torch.Tensor:
+    """One hidden layer of DIN's `fcn` scope (/root/reference algorithm/DIN/din.py:262-266):
+        net = tf.layers.dense(net, units, activation=None); net = dice | prelu (net, name=act_name)
+        if batch_norm: net = tf.layers.batch_normalization(net, training=training)
+    Variables, scopes and arithmetic are those of the three calls; in a training step on the GPU the three run as ONE
+    autograd node (_DenseActBNFn), otherwise as the three layers."""
+    from . import ops
+    store = current_store()
+    units = int(units)
+    dname = store.auto_name("dense")
+    fused = bool(batch_norm and training and not store.building and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32
+                 and units % 4 == 0 and _mfma_dense(x.shape[1]) and torch.is_grad_enabled()
+                 and getattr(getattr(store.anchor, "_recalgo_store", None), "sync_bn", None) is None)
+    if not fused:
+        net = dense(x, units, activation=None, name=dname, input_l2=input_l2)
+        alpha = store.get_variable(f"{kind}_alpha_{act_name}", (units,), ones)
+        net = ops.activation(store, net, alpha, kind)
+        return batch_normalization(net, training=training, momentum=momentum, epsilon=epsilon) if batch_norm else net
+    with store.variable_scope(dname):
+        kernel = store.get_variable("kernel", (x.shape[-1], units), glorot_uniform)
+        bias = store.get_variable("bias", (units,), zeros)
+    alpha = store.get_variable(f"{kind}_alpha_{act_name}", (units,), ones)
+    with store.variable_scope(store.auto_name("batch_normalization")):
+        gamma = store.get_variable("gamma", (units,), ones)
+        beta = store.get_variable("beta", (units,), zeros)
+        mmean = store.get_variable("moving_mean", (units,), zeros, trainable=False)
+        mvar = store.get_variable("moving_variance", (units,), ones, trainable=False)
+    return _DenseActBNFn.apply(store.anchor, x, kernel, bias, alpha, ops._ACT[kind], gamma, beta, mmean, mvar, momentum, epsilon,
+                               input_l2)
+
+
 DROPOUT_KEEP_MASKS: list = []      # test hook: keep masks consumed (FIFO) by the next training-mode dropout calls
 
 

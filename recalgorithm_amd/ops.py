@@ -618,6 +618,7 @@ class _DinAttentionFn(Function):
             _p(query), _p(keys), _p(keys_length), *[_p(v.data) for v in vs], B, T, H, int(is_softmax),
             _p(out), _stream(query)), "recalgo_din_attention_fwd")
         ctx.vs, ctx.is_softmax, ctx.kl = vs, is_softmax, keys_length
+        ctx.in_step = _loss_seed is not None      # built inside Estimator.train_step: its optimizer runs the deferred sums
         ctx.save_for_backward(query, keys)
         return out
 
@@ -628,8 +629,27 @@ class _DinAttentionFn(Function):
         vs = ctx.vs
         lib = _lib_()
         g = g.contiguous()
-        ws = _workspace(lib.recalgo_din_attention_bwd_workspace_bytes(B, T, H), query.device)
         dq, dk = torch.empty_like(query), torch.empty_like(keys)
+        nbytes = int(lib.recalgo_din_attention_bwd_workspace_bytes(B, T, H))
+        if ctx.in_step:
+            # inside a training step: the six parameter gradients are column sums of the kernel's partial rows — jobs of the
+            # step's deferred-sum launch instead of a launch of their own (the partials need a buffer of their own until then)
+            key = ("din_att", query.device.type, query.device.index, B, T, H, vs[0].grad.data_ptr())
+            ws = _dense_ws.get(key)
+            if ws is None:
+                ws = _dense_ws[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=query.device)
+            _lib.check(lib.recalgo_din_attention_bwd(
+                _p(query), _p(keys), _p(ctx.kl), *[_p(v.data) for v in vs], _p(g), B, T, H,
+                int(ctx.is_softmax), _p(dq), _p(dk), None, None, None, None, None, None, _p(ws), _stream(query)),
+                "recalgo_din_attention_bwd")
+            rows, pf = int(lib.recalgo_din_attention_bwd_partial_rows(B)), int(lib.recalgo_din_attention_bwd_partial_floats(H))
+            wsf, off = ws.view(torch.float32), 0
+            for v in vs:
+                n = v.grad.numel()
+                _colsum_pending.append((wsf, off, rows, pf, n, v.grad))
+                off += n
+            return None, dq, dk, None, None, None
+        ws = _workspace(nbytes, query.device)
         _lib.check(lib.recalgo_din_attention_bwd(
             _p(query), _p(keys), _p(ctx.kl), *[_p(v.data) for v in vs], _p(g), B, T, H,
             int(ctx.is_softmax), _p(dq), _p(dk), *[_p(v.grad) for v in vs], _p(ws), _stream(query)),
@@ -997,6 +1017,26 @@ def dense_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], re
     return y
 
 
+def dense_fwd_act(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kind: int, alpha: torch.Tensor,
+                  bn_partials: torch.Tensor):
+    """z = x @ w + bias, y = prelu | dice (z, alpha) and the per-tile batch moments of y in ONE launch
+    (recalgo_dense_fwd_act_bn): the forward of DIN's dense -> activation -> batch_norm layers up to the BatchNorm merge.
+    -> (z, y)"""
+    x, w = _mat(x, "x"), _mat(w, "w")
+    M, K = x.shape
+    N = w.shape[1]
+    if w.shape[0] != K or w.stride(0) != N:
+        raise ValueError("dense_fwd_act: w must be a contiguous [K, N] matrix")
+    if tuple(bn_partials.shape) != (bn_partial_rows(M), 2 * N) or not bn_partials.is_contiguous():
+        raise ValueError("dense_fwd_act: bn_partials must be a contiguous [bn_partial_rows(M), 2 N] tensor")
+    z = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    _lib.check(_lib_().recalgo_dense_fwd_act_bn(
+        _p(x), x.stride(0), _p(w), K, None, 0, None, 0, _p(bias), M, N, 0, int(kind), _p(alpha), _p(z), _p(y), N,
+        _p(bn_partials), _stream(x)), "recalgo_dense_fwd_act_bn")
+    return z, y
+
+
 def dense_bwd_input(g: torch.Tensor, y_mask: Optional[torch.Tensor], w: torch.Tensor, c_in: Optional[torch.Tensor] = None,
                     beta: float = 0.0, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
     """dx = (g * [y_mask > 0]) @ w^T (+ beta * c_in); y_mask contiguous with g's layout (recalgo_dense_bwd_input)."""
@@ -1200,6 +1240,29 @@ def batchnorm_train_fwd(x, gamma, beta, moving_mean, moving_var, momentum: float
                                                _p(moving_var), _p(y), _p(mean), _p(rstd), _p(ws), _stream(x)),
                "recalgo_batchnorm_train_fwd")
     return y, mean, rstd
+
+
+def batchnorm_train_bwd_act(x, gamma, mean, rstd, g, dgamma, dbeta, kind: int, z, alpha, dalpha, defer: bool) -> torch.Tensor:
+    """BatchNorm backward continued through the per-channel activation x = act(z, alpha) (recalgo_batchnorm_train_bwd_act):
+    -> dL/dz; dgamma / dbeta / dalpha are overwritten (`defer`: dalpha by the step's deferred-sum launch)."""
+    rows, C = x.shape
+    lib = _lib_()
+    nbytes = int(lib.recalgo_batchnorm_bwd_act_workspace_bytes(rows, C))
+    dz = torch.empty_like(x)
+    if defer:
+        key = ("bn_act", x.device.type, x.device.index, rows, C, dalpha.data_ptr())
+        ws = _dense_ws.get(key)
+        if ws is None:
+            ws = _dense_ws[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    else:
+        ws = _workspace(nbytes, x.device)
+    _lib.check(lib.recalgo_batchnorm_train_bwd_act(_p(x), _p(gamma), _p(mean), _p(rstd), _p(g), rows, C, int(kind), _p(z), _p(alpha),
+                                                   _p(dz), _p(dgamma), _p(dbeta), None if defer else _p(dalpha), _p(ws),
+                                                   _stream(x)), "recalgo_batchnorm_train_bwd_act")
+    if defer:
+        nb = bn_partial_rows(rows)
+        _colsum_pending.append((ws.view(torch.float32), nb * 2 * C, nb, C, C, dalpha))
+    return dz
 
 
 def batchnorm_sync_fwd(x, gamma, beta, moving_mean, moving_var, momentum: float, eps: float, sync):
@@ -1448,6 +1511,7 @@ class _ActFn(Function):
         _lib.check(_lib_().recalgo_activation_fwd(_p(x), _p(alpha.data), rows, C, kind, _p(y), _stream(x)),
                    "recalgo_activation_fwd")
         ctx.alpha, ctx.kind = alpha, kind
+        ctx.in_step = _loss_seed is not None      # built inside Estimator.train_step: its optimizer runs the deferred sums
         ctx.save_for_backward(x)
         return y
 
@@ -1457,8 +1521,20 @@ class _ActFn(Function):
         rows, C = x.shape
         lib = _lib_()
         gy = gy.contiguous()
-        ws = _workspace(lib.recalgo_activation_bwd_workspace_bytes(rows, C), x.device)
         dx = torch.empty_like(x)
+        nbytes = int(lib.recalgo_activation_bwd_workspace_bytes(rows, C))
+        if ctx.in_step:
+            # inside a training step: d(alpha) = column sum of the partial rows, a job of the step's deferred-sum launch
+            key = ("act", x.device.type, x.device.index, rows, C, ctx.alpha.grad.data_ptr())
+            ws = _dense_ws.get(key)
+            if ws is None:
+                ws = _dense_ws[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+            _lib.check(lib.recalgo_activation_bwd(_p(x), _p(ctx.alpha.data), _p(gy), rows, C, ctx.kind, _p(dx), None, _p(ws),
+                                                  _stream(x)), "recalgo_activation_bwd")
+            _colsum_pending.append((ws.view(torch.float32), 0, int(lib.recalgo_activation_bwd_partial_rows(rows, C)), C, C,
+                                    ctx.alpha.grad))
+            return None, dx, None, None
+        ws = _workspace(nbytes, x.device)
         _lib.check(lib.recalgo_activation_bwd(_p(x), _p(ctx.alpha.data), _p(gy), rows, C, ctx.kind, _p(dx),
                                               _p(ctx.alpha.grad), _p(ws), _stream(x)),
                    "recalgo_activation_bwd")

@@ -176,3 +176,80 @@ def test_dense_fwd_leaves_the_batchnorm_moments_of_its_tiles(dev, M, K, N):
     assert_close(mean2, mean1.double(), what="batch mean")
     assert_close(rstd2, rstd1.double(), what="batch rstd")
     assert_close(mv2, mv1.double(), what="moving variance")
+
+
+@pytest.mark.parametrize("kind", ["dice", "prelu"])
+@pytest.mark.parametrize("M,K,N", [(4096, 416, 512), (300, 82, 100), (65, 48, 8)])
+def test_dense_activation_batchnorm_as_one_node(dev, M, K, N, kind):
+    """The hidden layer of DIN's fcn scope (dense -> dice | prelu -> batch_normalization, din.py:262-266) as the fused launches
+    (recalgo_dense_fwd_act_bn, recalgo_batchnorm_train_bwd_act) against the three layers' own kernels one after the other —
+    and both against the definition in fp64."""
+    import ctypes
+    from recalgorithm_amd import _lib
+    lib = _lib.load()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    gen = torch.Generator().manual_seed(M + N + len(kind))
+    x = torch.randn(M, K, generator=gen).to(dev)
+    w = (torch.randn(K, N, generator=gen) / K ** 0.5).to(dev)
+    b = (torch.randn(N, generator=gen) * 0.1).to(dev)
+    alpha = (torch.rand(N, generator=gen) * 0.5 + 0.1).to(dev)
+    gamma, beta = (torch.rand(N, generator=gen) + 0.5).to(dev), torch.randn(N, generator=gen).to(dev)
+    g = torch.randn(M, N, generator=gen).to(dev)
+    k = ops._ACT[kind]
+    nb = ops.bn_partial_rows(M)
+    # ---- forward ----
+    part = torch.full((nb, 2 * N), float("nan"), device=dev)
+    z, y = ops.dense_fwd_act(x, w, b, k, alpha, part)
+    z0 = ops.dense_fwd(x, w, b, False)
+    assert torch.equal(z, z0)
+    y0 = torch.empty_like(z0)
+    _lib.check(lib.recalgo_activation_fwd(p(z0), p(alpha), M, N, k, p(y0), st()), "act fwd")
+    assert_close(y, y0.double(), what=f"{kind} in the GEMM epilogue vs the elementwise kernel")
+    zd = z0.double().cpu()
+    ad = alpha.double().cpu()
+    if kind == "dice":
+        px = torch.sigmoid(zd / (1 + 1e-3) ** 0.5)
+        yd = zd * px + ad * zd * (1 - px)
+    else:
+        yd = zd.clamp(min=0) + ad * zd.clamp(max=0)
+    assert_close(y, yd, what=f"{kind} in the GEMM epilogue vs fp64", ref32=y0)
+    want = torch.empty(nb, 2 * N, device=dev)
+    _lib.check(lib.recalgo_batchnorm_moments(p(y), M, N, p(want), st()), "moments")
+    assert_close(part[:, :N], want[:, :N].double(), what="tile means of the activation from the GEMM epilogue")
+    assert_close(part[:, N:], want[:, N:].double(), what="tile M2 of the activation from the GEMM epilogue", reduced=True)
+    mm, mv = torch.zeros(N, device=dev), torch.ones(N, device=dev)
+    out, mean, rstd = ops.batchnorm_train_fwd(y, gamma, beta, mm, mv, 0.99, 1e-3, partials=part)
+    # ---- backward ----
+    dgamma, dbeta, dalpha = (torch.full((N,), float("nan"), device=dev) for _ in range(3))
+    dz = ops.batchnorm_train_bwd_act(y, gamma, mean, rstd, g, dgamma, dbeta, k, z, alpha, dalpha, defer=False)
+    dgamma0, dbeta0, dalpha0 = (torch.empty(N, device=dev) for _ in range(3))
+    dy0 = ops.batchnorm_train_bwd(y, gamma, mean, rstd, g, dgamma0, dbeta0)
+    dz0 = torch.empty_like(z)
+    ws = torch.empty(max(int(lib.recalgo_activation_bwd_workspace_bytes(M, N)), 16), dtype=torch.uint8, device=dev)
+    _lib.check(lib.recalgo_activation_bwd(p(z), p(alpha), p(dy0), M, N, k, p(dz0), p(dalpha0), p(ws), st()), "act bwd")
+    assert torch.equal(dgamma, dgamma0) and torch.equal(dbeta, dbeta0)
+    assert_close(dz, dz0.double(), what=f"d(z) through BatchNorm and {kind} in one launch vs two")
+    assert_close(dalpha, dalpha0.double(), what=f"d({kind} alpha) from the fused backward", reduced=True)
+    # the deferred form leaves the same partial rows for the step's column-sum launch
+    dalpha1 = torch.full((N,), float("nan"), device=dev)
+    dz1 = ops.batchnorm_train_bwd_act(y, gamma, mean, rstd, g, dgamma, dbeta, k, z, alpha, dalpha1, defer=True)
+    ops.flush_dense_splits()
+    assert torch.equal(dz1, dz)
+    assert_close(dalpha1, dalpha.double(), what=f"d({kind} alpha) summed by the deferred launch", reduced=True)
+    # fp64 definition of the whole chain
+    yv = yd.to(dev).requires_grad_(False)
+    zt = zd.clone().requires_grad_(True)
+    at = ad.clone().requires_grad_(True)
+    if kind == "dice":
+        pxt = torch.sigmoid(zt / (1 + 1e-3) ** 0.5)
+        yt = zt * pxt + at * zt * (1 - pxt)
+    else:
+        yt = zt.clamp(min=0) + at * zt.clamp(max=0)
+    mu = yt.mean(0)
+    var = ((yt - mu) ** 2).mean(0)
+    ot = (yt - mu) / torch.sqrt(var + 1e-3) * gamma.double().cpu() + beta.double().cpu()
+    ot.backward(g.double().cpu())
+    assert_close(out, ot.detach(), what="fused layer output vs fp64", reduced=True)
+    assert_close(dz, zt.grad, what="fused layer d(z) vs fp64", reduced=True)
+    assert_close(dalpha, at.grad, what="fused layer d(alpha) vs fp64", reduced=True)
