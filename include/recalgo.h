@@ -230,6 +230,16 @@ int recalgo_din_attention_bwd(const float* query, const float* keys, const int32
                               float* dkeys, float* d_f1_w, float* d_f1_b, float* d_f2_w,
                               float* d_f2_b, float* d_f3_w, float* d_f3_b, void* workspace,
                               recalgo_stream_t stream);
+/* The same backward reading g_out with a row stride (ldg floats, a multiple of 4, rows 16-byte aligned: the attention output's
+ * column block of a wider gradient matrix, in place) and adding dq_extra [B][ld_extra] (or NULL) to dquery — the gradient the
+ * query's OTHER consumer produced (din.py:240-249: the target embedding feeds the attention and the fcn input), instead of a
+ * slice copy and an add launch. */
+int recalgo_din_attention_bwd_joined(const float* query, const float* keys, const int32_t* keys_length, const float* f1_w,
+                                     const float* f1_b, const float* f2_w, const float* f2_b, const float* f3_w,
+                                     const float* f3_b, const float* g_out, int ldg, const float* dq_extra, int ld_extra, int B,
+                                     int T, int H, int is_softmax, float* dquery, float* dkeys, float* d_f1_w, float* d_f1_b,
+                                     float* d_f2_w, float* d_f2_b, float* d_f3_w, float* d_f3_b, void* workspace,
+                                     recalgo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K7  FiBiNET SENET re-weighting.
@@ -388,6 +398,16 @@ int recalgo_dense_bwd_weights(const float* x, int ldx, const float* g, int ldg, 
 int recalgo_dense_bwd(const float* x, int ldx, const float* g, int ldg, const float* y_mask, const float* w, int M, int K,
                       int N, const float* c_in, int ldc, float beta, float* dx, int lddx, float* dw, float* dbias,
                       void* workspace, int defer_reduce, recalgo_stream_t stream);
+/* recalgo_dense_bwd for a layer whose input x IS the output of a training-mode BatchNorm (tf.layers.batch_normalization ->
+ * tf.layers.dense: deepfm.py:207-211, din.py:262-266): the input-gradient tiles' epilogue also leaves the two column sums
+ * that BatchNorm's backward starts with — bn_partials [recalgo_batchnorm_partial_rows(M)][2 K]: per 64-row tile colsum(dx) and
+ * colsum(dx * xhat), xhat = (bn_x - bn_mean) * bn_rstd, bn_x [M][K] contiguous = that BatchNorm's INPUT — i.e. the partial
+ * rows of recalgo_batchnorm_bwd_sums, so recalgo_batchnorm_bwd_apply (world 1) follows without a pass over dx and bn_x.
+ * bn_partials == NULL: recalgo_dense_bwd. */
+int recalgo_dense_bwd_bn(const float* x, int ldx, const float* g, int ldg, const float* y_mask, const float* w, int M, int K,
+                         int N, const float* c_in, int ldc, float beta, float* dx, int lddx, float* dw, float* dbias,
+                         void* workspace, int defer_reduce, const float* bn_x, const float* bn_mean, const float* bn_rstd,
+                         float* bn_partials, recalgo_stream_t stream);
 typedef struct {
     int M, K, N;
     const void* workspace;
@@ -429,10 +449,12 @@ int recalgo_batchnorm_train_bwd(const float* x, const float* gamma, const float*
  * dice | prelu -> batch_norm, din.py:262-266; see recalgo_activation_bwd): dx is then dL/d(act_z), dalpha [C] = dL/d(alpha).
  * dalpha == NULL: the recalgo_batchnorm_partial_rows(rows) partial rows [C] of dalpha are left at float offset
  * partial_rows * 2 * C of the workspace for the caller to sum (a job of recalgo_dense_bwd_weights_reduce).
- * workspace: recalgo_batchnorm_bwd_act_workspace_bytes(rows, C).  act_kind == RECALGO_ACT_NONE: recalgo_batchnorm_train_bwd. */
+ * workspace: recalgo_batchnorm_bwd_act_workspace_bytes(rows, C).  act_kind == RECALGO_ACT_NONE: recalgo_batchnorm_train_bwd.
+ * sums (or NULL): the [partial_rows][2 C] rows (colsum g | colsum g * xhat per 64-row tile) when the kernel that produced g has
+ * already left them (recalgo_dense_bwd_bn) — the first of the two launches is then skipped. */
 int64_t recalgo_batchnorm_bwd_act_workspace_bytes(int rows, int C);
 int recalgo_batchnorm_train_bwd_act(const float* x, const float* gamma, const float* save_mean, const float* save_rstd,
-                                    const float* g, int rows, int C, int act_kind, const float* act_z, const float* act_alpha,
+                                    const float* g, const float* sums, int rows, int C, int act_kind, const float* act_z, const float* act_alpha,
                                     float* dx, float* dgamma, float* dbeta, float* dalpha, void* workspace,
                                     recalgo_stream_t stream);
 /* Sync-BatchNorm building blocks (data parallel, N > 1, `sync_batch_norm`): the two launches of each direction as separate

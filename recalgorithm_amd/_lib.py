@@ -10,7 +10,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librecalgo_hip.so")
+# (RECALGO_HIP_LIB: a developer switch — A/B runs of differently tuned builds of the same library on one GPU box)
+LIB_PATH = os.environ.get("RECALGO_HIP_LIB") or os.path.join(_HERE, "librecalgo_hip.so")
 
 P = c_void_p  # device pointer / stream
 
@@ -41,6 +42,8 @@ SIGNATURES = {
     "recalgo_din_attention_bwd_partial_floats": (c_int, [c_int]),
     "recalgo_din_attention_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int,
                                           P, P, P, P, P, P, P, P, P, P]),
+    "recalgo_din_attention_bwd_joined": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int,
+                                                 P, P, P, P, P, P, P, P, P, P]),
     "recalgo_senet_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "recalgo_senet_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "recalgo_senet_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P]),
@@ -59,7 +62,7 @@ SIGNATURES = {
     "recalgo_batchnorm_train_fwd": (c_int, [P, P, P, c_int, c_int, c_float, c_float, P, P, P, P, P, P, P]),
     "recalgo_batchnorm_train_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, P, P, P]),
     "recalgo_batchnorm_bwd_act_workspace_bytes": (c_int64, [c_int, c_int]),
-    "recalgo_batchnorm_train_bwd_act": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P]),
+    "recalgo_batchnorm_train_bwd_act": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P]),
     "recalgo_batchnorm_partial_rows": (c_int, [c_int]),
     "recalgo_batchnorm_moments": (c_int, [P, c_int, c_int, P, P]),
     "recalgo_batchnorm_apply": (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, c_float, P, P, P, P, P, P]),
@@ -89,6 +92,8 @@ SIGNATURES = {
     "recalgo_dense_bwd_weights_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "recalgo_dense_bwd_weights": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, P, P, P, c_int, P]),
     "recalgo_dense_bwd": (c_int, [P, c_int, P, c_int, P, P, c_int, c_int, c_int, P, c_int, c_float, P, c_int, P, P, P, c_int, P]),
+    "recalgo_dense_bwd_bn": (c_int, [P, c_int, P, c_int, P, P, c_int, c_int, c_int, P, c_int, c_float, P, c_int, P, P, P, c_int,
+                                     P, P, P, P, P]),
     "recalgo_dense_bwd_weights_reduce": (c_int, [P, c_int, P, c_int, P, P]),
     "recalgo_logit_loss_partial_rows": (c_int64, [c_int]),
     "recalgo_logit_loss_fwd_bwd": (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, P, P, P, P, P]),

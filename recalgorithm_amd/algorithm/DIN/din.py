@@ -63,9 +63,12 @@ def din_model_fn(features, labels, mode, params):
     with variable_scope("his_seq_input"):
         seq_input, seq_length = fc.sequence_input_layer(features, params["sequence_feature_columns"],
                                                         max_length=params.get("sequence_max_length"))
+    # the target embedding feeds the attention (as the query) and the fcn input: the gradient block of the second is added to
+    # d(query) inside the attention's backward kernel (nn.GradJoin) instead of by an accumulation launch
+    target_join = nn.GradJoin()
     with variable_scope("attention_part"):
         attention_output = din_attention(target_input, seq_input, seq_length,
-                                         is_softmax=params["use_softmax"])       # (B, H)
+                                         is_softmax=params["use_softmax"], query_join=target_join)   # (B, H)
     # Mini-batch-aware regularisation (din.py:249-254): l2_lambda / 2 / B * sum(ev^2) over ev = [category,
     # target, attention output].  Without dense features ev IS concat_all, the input of the first fcn layer:
     # inside a seeded training step the term is then added to the loss as a value — the by-product of the kernel that
@@ -80,7 +83,7 @@ def din_model_fn(features, labels, mode, params):
     mba_coeff = params["l2_lambda"] / category_input.shape[0] if use_mba else 0.0
     mba_value = None
     if fused_mba:
-        concat_all, mba_value = _ops.concat_sumsq(ev_parts, mba_coeff / 2)
+        concat_all, mba_value = _ops.concat_sumsq(ev_parts, mba_coeff / 2, joins={1: target_join})
     else:
         concat_all = torch.cat(parts + ev_parts, dim=-1)
 

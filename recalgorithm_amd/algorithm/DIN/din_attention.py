@@ -16,13 +16,14 @@ from ...variables import current_store, glorot_uniform, zeros
 
 
 def din_attention(query: torch.Tensor, keys: torch.Tensor, keys_length: torch.Tensor,
-                  is_softmax: bool = False) -> torch.Tensor:
+                  is_softmax: bool = False, query_join=None) -> torch.Tensor:
     """
     Args:
         query: target item, (B, H)
         keys: behaviour history, (B, T, H), zero padded
         keys_length: history lengths, (B,)
         is_softmax: softmax-normalise the attention scores
+        query_join: (not a reference argument) nn.GradJoin shared with the query's other consumer
     Returns:
         (B, H) weighted sum pooling of the history
     """
@@ -33,4 +34,4 @@ def din_attention(query: torch.Tensor, keys: torch.Tensor, keys_length: torch.Te
         with store.variable_scope(name):
             vs.append(store.get_variable("kernel", shape, glorot_uniform))
             vs.append(store.get_variable("bias", (shape[1],), zeros))
-    return ops.din_attention(store, query.contiguous(), keys.contiguous(), keys_length, vs, is_softmax)
+    return ops.din_attention(store, query.contiguous(), keys.contiguous(), keys_length, vs, is_softmax, query_join)

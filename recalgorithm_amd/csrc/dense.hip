@@ -409,6 +409,13 @@ struct DgradArgs {
     int M, K;              // output is [M][K]
     int accumulate;        // dx += result (the second operand pair of the PNN layer)
     int tiles_per_block;   // consecutive output tiles one workgroup computes (>= 1; see bwd_balance)
+    // optional: this layer's input is the output of a training-mode BatchNorm over bn_x [M][K] (contiguous) with the batch
+    // statistics bn_mean / bn_rstd [K] — the epilogue leaves the sums that BatchNorm's backward starts with, per 64-row tile:
+    // bn_partials[tile][0:K] = colsum(dx), [K:2K] = colsum(dx * xhat) (the partial rows of recalgo_batchnorm_bwd_sums)
+    const float* bn_x;
+    const float* bn_mean;
+    const float* bn_rstd;
+    float* bn_partials;
 };
 
 template <bool FAST, bool MASK>
@@ -426,21 +433,69 @@ __device__ __forceinline__ void dgrad_tile(const DgradArgs& P, int block, int nb
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
         float4 unused = f4_zero();
-        tile_mainloop<true, true, FAST, MASK, false, false>(P.seg, m0, n0, P.M, P.K, 0, P.seg.n_red, As, Bs, acc, acc1, unused);
-        acc += acc1;
         const int col = n0 + (wave & 1) * 32 + l32;
-        if (col < P.K) {
+        // (BatchNorm sums: the tile of bn_x this thread will need in the epilogue is requested BEFORE the main loop — the loads
+        // complete in its shadow instead of extending the workgroup's critical path by a round trip to memory)
+        float xb[16];
+        float mu = 0.f, rs = 0.f;
+        if (P.bn_partials != nullptr && col < P.K) {
+            mu = P.bn_mean[col];
+            rs = P.bn_rstd[col];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (row < P.M) {
-                    float v = acc[r];
-                    if (P.c_in) v = fmaf(P.beta, P.c_in[(size_t)row * P.ldc + col], v);
-                    float* o = P.dx + (size_t)row * P.lddx + col;
-                    *o = P.accumulate ? *o + v : v;
-                }
+                xb[r] = row < P.M ? P.bn_x[(size_t)row * P.K + col] : 0.f;
             }
         }
+        tile_mainloop<true, true, FAST, MASK, false, false>(P.seg, m0, n0, P.M, P.K, 0, P.seg.n_red, As, Bs, acc, acc1, unused);
+        acc += acc1;
+        if (P.bn_partials == nullptr) {
+            if (col < P.K) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (row < P.M) {
+                        float v = acc[r];
+                        if (P.c_in) v = fmaf(P.beta, P.c_in[(size_t)row * P.ldc + col], v);
+                        float* o = P.dx + (size_t)row * P.lddx + col;
+                        *o = P.accumulate ? *o + v : v;
+                    }
+                }
+            }
+            continue;
+        }
+        // ---- the same store + the tile's column sums of dx and dx * xhat (fixed order: a lane's 16 rows, the wave's two row
+        //      halves, the workgroup's two wave rows) ----
+        const bool cok = col < P.K;
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (cok && row < P.M) {
+                float v = acc[r];
+                if (P.c_in) v = fmaf(P.beta, P.c_in[(size_t)row * P.ldc + col], v);
+                P.dx[(size_t)row * P.lddx + col] = v;
+                const float xh = (xb[r] - mu) * rs;
+                sg += v;
+                sgx = fmaf(v, xh, sgx);
+            }
+        }
+        sg += __shfl_xor(sg, 32, 64);
+        sgx += __shfl_xor(sgx, 32, 64);
+        float* red = As;                                      // [2 sums][2 wave rows][64 columns] (the operand ring is free)
+        __syncthreads();
+        const int cl = (wave & 1) * 32 + l32;
+        if (hi == 0) {
+            red[(wave >> 1) * 64 + cl] = sg;
+            red[128 + (wave >> 1) * 64 + cl] = sgx;
+        }
+        __syncthreads();
+        if ((wave >> 1) == 0 && hi == 0 && cok) {
+            float* prow = P.bn_partials + (size_t)(m0 / BM) * 2 * P.K;
+            prow[col] = red[cl] + red[64 + cl];
+            prow[P.K + col] = red[128 + cl] + red[192 + cl];
+        }
+        __syncthreads();                                      // (the next tile's staging reuses the ring)
     }
 }
 
@@ -728,6 +783,7 @@ static bool build_dgrad(DgradArgs& P, const float* g, int ldg, const float* y_ma
     P.seg = Segment{operand(g, y_mask, ldg, M, N), operand(w, nullptr, N, K, N), N};
     P.c_in = c_in; P.beta = beta; P.ldc = ldc; P.dx = dx; P.lddx = lddx; P.M = M; P.K = K; P.accumulate = accumulate;
     P.tiles_per_block = 1;
+    P.bn_x = P.bn_mean = P.bn_rstd = nullptr; P.bn_partials = nullptr;
     return true;
 }
 static bool dgrad_fast(const DgradArgs& P) { return fast_rc(P.seg.a, P.seg.n_red) && fast_rc(P.seg.b, P.seg.n_red); }
@@ -824,9 +880,20 @@ RECALGO_EXPORT int recalgo_dense_bwd_weights(const float* x, int ldx, const floa
 RECALGO_EXPORT int recalgo_dense_bwd(const float* x, int ldx, const float* g, int ldg, const float* y_mask, const float* w,
                                      int M, int K, int N, const float* c_in, int ldc, float beta, float* dx, int lddx,
                                      float* dw, float* dbias, void* workspace, int defer_reduce, recalgo_stream_t stream) {
+    return recalgo_dense_bwd_bn(x, ldx, g, ldg, y_mask, w, M, K, N, c_in, ldc, beta, dx, lddx, dw, dbias, workspace, defer_reduce,
+                                nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+RECALGO_EXPORT int recalgo_dense_bwd_bn(const float* x, int ldx, const float* g, int ldg, const float* y_mask, const float* w,
+                                        int M, int K, int N, const float* c_in, int ldc, float beta, float* dx, int lddx,
+                                        float* dw, float* dbias, void* workspace, int defer_reduce, const float* bn_x,
+                                        const float* bn_mean, const float* bn_rstd, float* bn_partials,
+                                        recalgo_stream_t stream) {
     DgradArgs D;
     WgradArgs W;
     RECALGO_REQUIRE(M > 0 && build_dgrad(D, g, ldg, y_mask, w, M, N, K, c_in, ldc, beta, dx, lddx, 0));
+    RECALGO_REQUIRE(bn_partials == nullptr || (bn_x != nullptr && bn_mean != nullptr && bn_rstd != nullptr));
+    D.bn_x = bn_x; D.bn_mean = bn_mean; D.bn_rstd = bn_rstd; D.bn_partials = bn_partials;
     const int S = build_wgrad(W, x, ldx, g, ldg, y_mask, M, K, N, dw, dbias, workspace);
     RECALGO_REQUIRE(S >= 1);
     hipStream_t st = as_stream(stream);

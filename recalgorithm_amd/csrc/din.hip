@@ -248,8 +248,8 @@ __global__ __launch_bounds__(kThreads) void din_attention_bwd_kernel(
     const float* __restrict__ query, const float* __restrict__ keys, const int32_t* __restrict__ keys_length,
     const float* __restrict__ f1w, const float* __restrict__ f1b, const float* __restrict__ f2w,
     const float* __restrict__ f2b, const float* __restrict__ f3w, const float* __restrict__ f3b,
-    const float* __restrict__ g_out, unsigned B, unsigned T, int is_softmax, float* __restrict__ dquery,
-    float* __restrict__ dkeys, float* __restrict__ partials) {
+    const float* __restrict__ g_out, unsigned ldg, const float* __restrict__ dq_extra, unsigned ld_extra, unsigned B,
+    unsigned T, int is_softmax, float* __restrict__ dquery, float* __restrict__ dkeys, float* __restrict__ partials) {
     static_assert(2 * H <= 32, "k and q*k must fit one 32-wide MFMA tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Weights<H>& W = *reinterpret_cast<Weights<H>*>(smem_raw);
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(kThreads) void din_attention_bwd_kernel(
         // ---- attention output backward (lane = row) ----
         float g[H];
         {
-            const float4* gr = reinterpret_cast<const float4*>(g_out + (size_t)ex * H);
+            const float4* gr = reinterpret_cast<const float4*>(g_out + (size_t)ex * ldg);
 #pragma unroll
             for (int i = 0; i < H; i += 4) {
                 float4 v = gr[i / 4];
@@ -414,6 +414,7 @@ __global__ __launch_bounds__(kThreads) void din_attention_bwd_kernel(
             float v = dq[0];
 #pragma unroll
             for (int i = 1; i < H; ++i) v = lane == (unsigned)i ? dq[i] : v;
+            if (dq_extra) v += dq_extra[(size_t)ex * ld_extra + lane];    // the query's other consumer's gradient (GradJoin)
             dquery[(size_t)ex * H + lane] = v;
         }
         __builtin_amdgcn_wave_barrier();
@@ -539,7 +540,21 @@ RECALGO_EXPORT int recalgo_din_attention_bwd(const float* query, const float* ke
                                              float* dquery, float* dkeys, float* d_f1_w, float* d_f1_b,
                                              float* d_f2_w, float* d_f2_b, float* d_f3_w, float* d_f3_b,
                                              void* workspace, recalgo_stream_t stream) {
+    return recalgo_din_attention_bwd_joined(query, keys, keys_length, f1_w, f1_b, f2_w, f2_b, f3_w, f3_b, g_out, H, nullptr, 0, B,
+                                            T, H, is_softmax, dquery, dkeys, d_f1_w, d_f1_b, d_f2_w, d_f2_b, d_f3_w, d_f3_b,
+                                            workspace, stream);
+}
+
+RECALGO_EXPORT int recalgo_din_attention_bwd_joined(const float* query, const float* keys, const int32_t* keys_length,
+                                                    const float* f1_w, const float* f1_b, const float* f2_w,
+                                                    const float* f2_b, const float* f3_w, const float* f3_b,
+                                                    const float* g_out, int ldg, const float* dq_extra, int ld_extra, int B,
+                                                    int T, int H, int is_softmax, float* dquery, float* dkeys, float* d_f1_w,
+                                                    float* d_f1_b, float* d_f2_w, float* d_f2_b, float* d_f3_w, float* d_f3_b,
+                                                    void* workspace, recalgo_stream_t stream) {
     RECALGO_REQUIRE(B > 0 && T >= 1 && T <= 64 && (H == 4 || H == 8 || H == 16) && workspace != nullptr);
+    RECALGO_REQUIRE(g_out != nullptr && ldg >= H && ldg % 4 == 0 && (reinterpret_cast<uintptr_t>(g_out) & 15) == 0);
+    RECALGO_REQUIRE(dq_extra == nullptr || ld_extra >= H);
     hipStream_t st = as_stream(stream);
     float* partials = static_cast<float*>(workspace);
     const int grid = din_grid(B);
@@ -552,8 +567,8 @@ RECALGO_EXPORT int recalgo_din_attention_bwd(const float* query, const float* ke
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);            \
         if (e != hipSuccess) return (int)e;                                                                   \
         hipLaunchKernelGGL(din_attention_bwd_kernel<HH>, dim3(grid), dim3(kThreads), smem, st, query, keys,   \
-                           keys_length, f1_w, f1_b, f2_w, f2_b, f3_w, f3_b, g_out, (unsigned)B, (unsigned)T,  \
-                           is_softmax, dquery, dkeys, partials);                                              \
+                           keys_length, f1_w, f1_b, f2_w, f2_b, f3_w, f3_b, g_out, (unsigned)ldg, dq_extra,       \
+                           (unsigned)ld_extra, (unsigned)B, (unsigned)T, is_softmax, dquery, dkeys, partials);    \
     } while (0)
     if (H == 4) LAUNCH(4); else if (H == 8) LAUNCH(8); else LAUNCH(16);
 #undef LAUNCH

@@ -660,8 +660,8 @@ RECALGO_EXPORT int recalgo_batchnorm_train_bwd(const float* x, const float* gamm
                                                const float* save_rstd, const float* g, int rows, int C, float* dx,
                                                float* dgamma, float* dbeta, void* workspace,
                                                recalgo_stream_t stream) {
-    return recalgo_batchnorm_train_bwd_act(x, gamma, save_mean, save_rstd, g, rows, C, RECALGO_ACT_NONE, nullptr, nullptr, dx, dgamma,
-                                           dbeta, nullptr, workspace, stream);
+    return recalgo_batchnorm_train_bwd_act(x, gamma, save_mean, save_rstd, g, nullptr, rows, C, RECALGO_ACT_NONE, nullptr, nullptr, dx,
+                                           dgamma, dbeta, nullptr, workspace, stream);
 }
 
 RECALGO_EXPORT int64_t recalgo_batchnorm_bwd_act_workspace_bytes(int rows, int C) {
@@ -670,7 +670,8 @@ RECALGO_EXPORT int64_t recalgo_batchnorm_bwd_act_workspace_bytes(int rows, int C
 }
 
 RECALGO_EXPORT int recalgo_batchnorm_train_bwd_act(const float* x, const float* gamma, const float* save_mean,
-                                                   const float* save_rstd, const float* g, int rows, int C, int act_kind,
+                                                   const float* save_rstd, const float* g, const float* sums, int rows, int C,
+                                                   int act_kind,
                                                    const float* act_z, const float* act_alpha, float* dx, float* dgamma,
                                                    float* dbeta, float* dalpha, void* workspace, recalgo_stream_t stream) {
     RECALGO_REQUIRE(rows > 0 && width_ok(C) && x && gamma && save_mean && save_rstd && g && dx && dgamma && dbeta &&
@@ -680,12 +681,15 @@ RECALGO_EXPORT int recalgo_batchnorm_train_bwd_act(const float* x, const float* 
     hipStream_t st = as_stream(stream);
     const int nb = nblk_of(rows);
     const unsigned C4 = C / 4;
-    float* partials = static_cast<float*>(workspace);
-    float* act_partials = partials + (size_t)nb * 2 * C;        // [nb][C]: the tile rows' terms of dalpha
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C4, 16), nb), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
-                       reinterpret_cast<const float4*>(g), reinterpret_cast<const float4*>(save_mean),
-                       reinterpret_cast<const float4*>(save_rstd), (unsigned)rows, C4,
-                       reinterpret_cast<float4*>(partials));
+    float* ws = static_cast<float*>(workspace);
+    float* act_partials = ws + (size_t)nb * 2 * C;              // [nb][C]: the tile rows' terms of dalpha
+    // sums: the partial rows (colsum g | colsum g * xhat per 64-row tile) are already there — left by the epilogue of the
+    // kernel that produced g (recalgo_dense_bwd_bn) — and the pass over g and x that computes them is skipped
+    const float* partials = sums ? sums : ws;
+    if (sums == nullptr)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C4, 16), nb), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
+                           reinterpret_cast<const float4*>(g), reinterpret_cast<const float4*>(save_mean),
+                           reinterpret_cast<const float4*>(save_rstd), (unsigned)rows, C4, reinterpret_cast<float4*>(ws));
 #define RECALGO_BN_APPLY(ACT)                                                                                                   \
     hipLaunchKernelGGL(bn_bwd_sum_apply_kernel<ACT>, dim3(cdiv(C4, 16), nb), dim3(kThreads), 0, st,                             \
                        reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(g),                                  \

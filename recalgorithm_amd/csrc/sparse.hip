@@ -47,12 +47,23 @@
 
 #include "deferred.h"
 
+// tuning knobs of `apply` (build-time): workgroups resident per CU (the register budget follows) and gradient rows in flight
+#ifndef RECALGO_APPLY_WGS
+#define RECALGO_APPLY_WGS 4
+#endif
+#ifndef RECALGO_APPLY_LDS_KEYS
+#define RECALGO_APPLY_LDS_KEYS 2048
+#endif
+#ifndef RECALGO_APPLY_KU
+#define RECALGO_APPLY_KU 8
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxSources = RECALGO_SCATTER_MAX_SOURCES;
 using recalgo_deferred::kLrRing;
-constexpr unsigned kLdsKeys = 2048;                     // sorted keys kept in LDS (16 KB); larger buckets go through global memory
+constexpr unsigned kLdsKeys = RECALGO_APPLY_LDS_KEYS;                    // sorted keys kept in LDS (16 KB); larger buckets go through global memory
 constexpr unsigned kMaxSeg = kThreads;                  // rows (segments) of a small bucket listed in LDS
 constexpr unsigned kSlots = 512;                        // LDS hash of the distinct keys of a tile
 constexpr unsigned kLongSeg = 48;                       // entries per row above which the whole workgroup sums it
@@ -898,7 +909,7 @@ __device__ __forceinline__ void short_row(const ApplyArgs& A, const SrcDev* lsrc
     const RowState<VEC> st = load_state<VEC>(A, row, q);
     // up to eight gradient rows in flight per round trip (a hot row of a field arrives as B / 256 = 16 tile partials: a
     // load -> wait -> add loop over them was most of this launch), added in key order
-    constexpr unsigned kU = 8;
+    constexpr unsigned kU = RECALGO_APPLY_KU;
     V acc = vz<VEC>();
     if (q < A.KV) {
         for (unsigned j = lo; j < hi; j += kU) {
@@ -1083,15 +1094,16 @@ __device__ __forceinline__ unsigned long long* global_merge_sort(unsigned long l
 
 
 template <int VEC>
-__global__ __launch_bounds__(kThreads, 4) void sparse_apply_kernel(ApplyArgs A) {     // 1024 workgroups resident at once
+__global__ __launch_bounds__(kThreads, RECALGO_APPLY_WGS) void sparse_apply_kernel(ApplyArgs A) {   // 256 CUs x this many resident
     __shared__ unsigned long long lds_keys[kLdsKeys];         // the bucket's keys in order (buckets up to kLdsKeys entries)
-    __shared__ unsigned long long ck[kThreads];               // a small bucket's keys as they arrived
     __shared__ unsigned seg_lo[kMaxSeg], seg_n[kMaxSeg];
     __shared__ unsigned long_list[2 * kMaxLong];
     __shared__ unsigned n_long, n_seg;
-    __shared__ float red[kThreads * 4];
+    __shared__ __attribute__((aligned(16))) float red[kThreads * 4];
     __shared__ float red1[kThreads];
     __shared__ SrcDev lsrc[kMaxSources];
+    // (a small bucket's keys as they arrived: only needed until they are ranked, before `red` is)
+    unsigned long long* ck = reinterpret_cast<unsigned long long*>(red);
     const uint4 sc = A.sched[blockIdx.x];                     // (one 16-byte record: bucket, first entry, entries)
     const unsigned b = sc.x, beg = sc.y, n = sc.z;
     const int t = (int)(A.step[0] + A.step_off);

@@ -125,31 +125,55 @@ def make_id_batch(spec: SynthSpec, B: int, batch_index: int = 0, names: Optional
 def device_features(spec: SynthSpec, B: int, device, batch_index: int = 0, sorted_layout: bool = True):
     """Already-encoded, device-resident (features, labels) for the throughput configs.  The id
     matrix is laid out in sorted(column-name) order so that fc.input_layer can hand it to the
-    gather kernel without a copy; features[name] are column views of it."""
+    gather kernel without a copy; features[name] are column views of it.  With a history (the DIN layout) the target
+    `feedid` is a sequence column looked up on its own: it gets its own contiguous [B] vector after the matrix of the other
+    fields, so that both lookups read the batch in place."""
     from ..feature_column import Ragged
     names = sorted(spec.names) if sorted_layout else list(spec.names)
     ids, labels, dense, hist, tags = make_id_batch(spec, B, batch_index, names)
-    # ONE allocation for the id matrix and the labels (int64 [B, F] followed by float32 [B, 1]): a training loop that
-    # copies a batch into the static input buffers of a captured step then moves it with a single copy
-    nid = ids.size * 8
-    host = torch.empty(nid + B * 4, dtype=torch.uint8)
-    host[:nid] = torch.from_numpy(np.ascontiguousarray(ids)).view(-1).view(torch.uint8)
-    host[nid:] = torch.from_numpy(np.ascontiguousarray(labels)).view(-1).view(torch.uint8)
+    # ONE allocation for the whole batch (int64 [B, F] id matrix, float32 [B, 1] labels, then the ragged history / tag
+    # lists, each piece 16-byte aligned): a training loop that copies a batch into the static input buffers of a captured
+    # step then moves it with a single copy
+    own = [nm for nm in names if hist is not None and sorted_layout and nm == "feedid"]
+    own_cols = [np.ascontiguousarray(ids[:, names.index(nm)]) for nm in own]
+    if own:
+        keep = [j for j, nm in enumerate(names) if nm not in own]
+        ids, names = ids[:, keep], [names[j] for j in keep]
+    pieces = [np.ascontiguousarray(ids), np.ascontiguousarray(labels)]
+    for rag in (hist, tags):
+        if rag is not None:
+            pieces += [np.ascontiguousarray(rag[0]), np.ascontiguousarray(rag[1])]
+    pieces[2:2] = own_cols
+    offs, total = [], 0
+    for a in pieces:
+        offs.append(total)
+        total += (a.nbytes + 15) // 16 * 16
+    host = torch.zeros(total, dtype=torch.uint8)
+    for a, o in zip(pieces, offs):
+        host[o:o + a.nbytes] = torch.from_numpy(a).view(-1).view(torch.uint8)
     buf = host.to(device)
-    mat = buf[:nid].view(torch.int64).view(B, len(names))
+
+    def piece(k):
+        a = pieces[k]
+        return buf[offs[k]:offs[k] + a.nbytes].view(getattr(torch, a.dtype.name)).view(a.shape)
+    nid = ids.size * 8
+    mat = piece(0)
     feats: Dict[str, object] = {nm: mat[:, j] for j, nm in enumerate(names)}
     feats_meta = {"__ids_matrix__": mat, "__ids_names__": names}
     if dense is not None:
         d = torch.from_numpy(dense).to(device)
         for j, nm in enumerate(DENSE_FEATURES):
             feats[nm] = d[:, j:j + 1]
+    k = 2
+    for nm in own:
+        feats[nm] = piece(k)
+        k += 1
     if hist is not None:
-        feats["his_read_comment_7d_seq"] = Ragged(torch.from_numpy(hist[0]).to(device),
-                                                  torch.from_numpy(hist[1]).to(device))
+        feats["his_read_comment_7d_seq"] = Ragged(piece(k), piece(k + 1))
+        k += 2
     if tags is not None:
-        feats["manual_tag_list"] = Ragged(torch.from_numpy(tags[0]).to(device),
-                                          torch.from_numpy(tags[1]).to(device))
-    lab = {"read_comment": buf[nid:].view(torch.float32).view(B, 1)}
+        feats["manual_tag_list"] = Ragged(piece(k), piece(k + 1))
+    lab = {"read_comment": piece(1).view(B, 1)}
     return feats, lab, feats_meta
 
 

@@ -66,12 +66,48 @@ def _merged_bwd() -> bool:
     return os.environ.get("RECALGO_DENSE_MERGED_BWD", "1") != "0"
 
 
+class BNLink:
+    """A training-mode BatchNorm whose output feeds a dense layer (tf.layers.batch_normalization -> tf.layers.dense): the
+    dense layer's backward kernel can leave the two column sums BatchNorm's backward starts with (ops.dense_bwd(bn=)).  The
+    BatchNorm attaches a BNLink to its output tensor; a dense layer that finds one on its input fills `sums` in its backward
+    and records which gradient tensor they belong to; the BatchNorm's backward uses them only if that IS the gradient it is
+    given (another consumer of the BatchNorm output, or anything in between, makes autograd hand over a different tensor)."""
+
+    def __init__(self, x, mean, rstd):
+        self.x, self.mean, self.rstd = x, mean, rstd
+        self.sums, self.grad_ptr = None, 0
+
+    def new_sums(self) -> torch.Tensor:
+        from . import ops
+        rows, C = self.x.shape
+        self.sums = torch.empty(ops.bn_partial_rows(rows), 2 * C, device=self.x.device, dtype=torch.float32)
+        return self.sums
+
+    def take(self, g: torch.Tensor):
+        sums, self.sums = self.sums, None
+        return sums if (sums is not None and g.data_ptr() == self.grad_ptr and g.is_contiguous()) else None
+
+
+def _attach_link(out: torch.Tensor) -> torch.Tensor:
+    """the BNLink the node's forward made (ctx.link), hung on the output tensor for the consumer to find"""
+    link = getattr(out.grad_fn, "link", None) if out.grad_fn is not None else None
+    if link is not None:
+        out._recalgo_bn_link = link
+    return out
+
+
+def _bn_link_of(x: torch.Tensor):
+    link = getattr(x, "_recalgo_bn_link", None)
+    return link if (link is not None and x.dim() == 2 and x.is_contiguous() and tuple(x.shape) == tuple(link.x.shape)) else None
+
+
 class _DenseFn(Function):
     @staticmethod
     def forward(ctx, anchor, x, kernel: Variable, bias: Optional[Variable], relu: bool, input_l2: float = 0.0,
                 grad_join: Optional[GradJoin] = None, bn_partials: Optional[torch.Tensor] = None):
         ctx.input_l2 = float(input_l2)
         ctx.grad_join = grad_join
+        ctx.bn_link = _bn_link_of(x)
         x2 = x.reshape(-1, x.shape[-1])
         ctx.hip = x2.is_cuda and x2.dtype == torch.float32 and _mfma_dense(x2.shape[1])
         if ctx.hip:
@@ -107,8 +143,12 @@ class _DenseFn(Function):
             db = None if bias is None else bias.grad
             if ctx.needs_input_grad[1] and _merged_bwd():
                 # input and weight gradient in ONE launch
+                link = ctx.bn_link if ctx.grad_join is None else None
                 dx = ops.dense_bwd(x2, g2, mask, kernel.data, kernel.grad, db, c_in=x2 if ctx.input_l2 else None,
-                                   beta=ctx.input_l2, defer=True).view(ctx.xshape)
+                                   beta=ctx.input_l2, defer=True,
+                                   bn=None if link is None else (link.x, link.mean, link.rstd, link.new_sums())).view(ctx.xshape)
+                if link is not None:
+                    link.grad_ptr = dx.data_ptr()
                 if ctx.grad_join is not None and ctx.grad_join.park(dx):
                     dx = None                      # added by the other consumer of x in its backward kernel
                 return None, dx, None, None, None, None, None, None
@@ -312,6 +352,7 @@ class _BatchNormTrainFn(Function):
             else:
                 y, mean, rstd = ops.batchnorm_train_fwd(x, gamma.data, beta.data, mmean.data, mvar.data, momentum, eps,
                                                         partials=partials)
+                ctx.link = BNLink(x, mean, rstd)       # (attached to the output by batch_normalization())
             ctx.save_for_backward(x, mean, rstd)
             return y
         mean = x.mean(dim=0)
@@ -335,7 +376,8 @@ class _BatchNormTrainFn(Function):
             if ctx.sync is not None:
                 dx = ops.batchnorm_sync_bwd(x, gamma.data, mean, rstd, g.contiguous(), gamma.grad, beta.grad, ctx.sync)
             else:
-                dx = ops.batchnorm_train_bwd(x, gamma.data, mean, rstd, g.contiguous(), gamma.grad, beta.grad)
+                dx = ops.batchnorm_train_bwd(x, gamma.data, mean, rstd, g.contiguous(), gamma.grad, beta.grad,
+                                             sums=ctx.link.take(g))
             return None, dx, None, None, None, None, None, None, None
         xhat, rstd = ctx.saved_tensors
         B = g.shape[0]
@@ -374,7 +416,7 @@ def batch_normalization(x: torch.Tensor, training: bool = False,
     if training:
         # (batch moments left behind by the producing dense layer's epilogue, see dense(bn_stats=))
         pre = getattr(x, "_recalgo_bn_partials", None) if (x.dim() == 2 and x.is_contiguous()) else None
-        return _BatchNormTrainFn.apply(store.anchor, x, gamma, beta, mmean, mvar, momentum, epsilon, pre)
+        return _attach_link(_BatchNormTrainFn.apply(store.anchor, x, gamma, beta, mmean, mvar, momentum, epsilon, pre))
     inv = torch.rsqrt(mvar.data + epsilon) * gamma.data
     return _BatchNormInferFn.apply(x, inv, beta.data - mmean.data * inv)
 
@@ -393,6 +435,8 @@ class _DenseActBNFn(Function):
         partials = torch.empty(ops.bn_partial_rows(M), 2 * N, device=x.device, dtype=torch.float32)
         z, y = ops.dense_fwd_act(x2, kernel.data, bias.data, kind, alpha.data, partials)
         out, mean, rstd = ops.batchnorm_train_fwd(y, gamma.data, beta.data, mmean.data, mvar.data, momentum, eps, partials=partials)
+        ctx.link = BNLink(y, mean, rstd)      # (the next dense layer's backward may leave this BN's sums; see _attach_link)
+        ctx.in_link = _bn_link_of(x)                                 # (... and this one's those of the BatchNorm before it)
         ctx.vars, ctx.kind, ctx.input_l2 = (kernel, bias, alpha, gamma, beta), kind, float(input_l2)
         ctx.in_step = ops._loss_seed is not None      # Estimator.train_step: its optimizer runs the deferred column sums
         ctx.save_for_backward(x2, z, y, mean, rstd)
@@ -404,11 +448,15 @@ class _DenseActBNFn(Function):
         kernel, bias, alpha, gamma, beta = ctx.vars
         x2, z, y, mean, rstd = ctx.saved_tensors
         dz = ops.batchnorm_train_bwd_act(y, gamma.data, mean, rstd, g.contiguous(), gamma.grad, beta.grad, ctx.kind, z, alpha.data,
-                                         alpha.grad, defer=ctx.in_step)
+                                         alpha.grad, defer=ctx.in_step, sums=ctx.link.take(g))
         dx = None
         if ctx.needs_input_grad[1]:
+            link = ctx.in_link
             dx = ops.dense_bwd(x2, dz, None, kernel.data, kernel.grad, bias.grad, c_in=x2 if ctx.input_l2 else None,
-                               beta=ctx.input_l2, defer=True)
+                               beta=ctx.input_l2, defer=True,
+                               bn=None if link is None else (link.x, link.mean, link.rstd, link.new_sums()))
+            if link is not None:
+                link.grad_ptr = dx.data_ptr()
         else:
             ops.dense_bwd_weights(x2, dz, None, kernel.grad, bias.grad, defer=True)
         return (None, dx) + (None,) * 11
@@ -442,8 +490,8 @@ def dense_activation_bn(x: torch.Tensor, units, kind: str, act_name, batch_norm:
         beta = store.get_variable("beta", (units,), zeros)
         mmean = store.get_variable("moving_mean", (units,), zeros, trainable=False)
         mvar = store.get_variable("moving_variance", (units,), ones, trainable=False)
-    return _DenseActBNFn.apply(store.anchor, x, kernel, bias, alpha, ops._ACT[kind], gamma, beta, mmean, mvar, momentum, epsilon,
-                               input_l2)
+    return _attach_link(_DenseActBNFn.apply(store.anchor, x, kernel, bias, alpha, ops._ACT[kind], gamma, beta, mmean, mvar, momentum,
+                                            epsilon, input_l2))
 
 
 DROPOUT_KEEP_MASKS: list = []      # test hook: keep masks consumed (FIFO) by the next training-mode dropout calls

@@ -610,7 +610,7 @@ def cin_layer(store, x0: torch.Tensor, xk: torch.Tensor, filt: Variable):
 # =============================================================================================
 class _DinAttentionFn(Function):
     @staticmethod
-    def forward(ctx, anchor, query, keys, keys_length, vs, is_softmax: bool):
+    def forward(ctx, anchor, query, keys, keys_length, vs, is_softmax: bool, query_join=None):
         # vs = (f1_w, f1_b, f2_w, f2_b, f3_w, f3_b) Variables
         B, T, H = keys.shape
         out = torch.empty(B, H, device=query.device, dtype=torch.float32)
@@ -618,6 +618,7 @@ class _DinAttentionFn(Function):
             _p(query), _p(keys), _p(keys_length), *[_p(v.data) for v in vs], B, T, H, int(is_softmax),
             _p(out), _stream(query)), "recalgo_din_attention_fwd")
         ctx.vs, ctx.is_softmax, ctx.kl = vs, is_softmax, keys_length
+        ctx.query_join = query_join
         ctx.in_step = _loss_seed is not None      # built inside Estimator.train_step: its optimizer runs the deferred sums
         ctx.save_for_backward(query, keys)
         return out
@@ -628,7 +629,12 @@ class _DinAttentionFn(Function):
         B, T, H = keys.shape
         vs = ctx.vs
         lib = _lib_()
-        g = g.contiguous()
+        # g may be a column block of a wider gradient matrix (the fcn input's): read in place when its rows are float4s
+        if not (g.dim() == 2 and g.stride(1) == 1 and g.stride(0) % 4 == 0 and g.stride(0) >= H and g.data_ptr() % 16 == 0):
+            g = g.contiguous()
+        # the gradient the query's other consumer parked (nn.GradJoin): added in this kernel's epilogue
+        extra = ctx.query_join.take() if ctx.query_join is not None else None
+        fused_extra = extra is not None and extra.dim() == 2 and tuple(extra.shape) == (B, H) and extra.stride(1) == 1
         dq, dk = torch.empty_like(query), torch.empty_like(keys)
         nbytes = int(lib.recalgo_din_attention_bwd_workspace_bytes(B, T, H))
         if ctx.in_step:
@@ -638,34 +644,44 @@ class _DinAttentionFn(Function):
             ws = _dense_ws.get(key)
             if ws is None:
                 ws = _dense_ws[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=query.device)
-            _lib.check(lib.recalgo_din_attention_bwd(
-                _p(query), _p(keys), _p(ctx.kl), *[_p(v.data) for v in vs], _p(g), B, T, H,
-                int(ctx.is_softmax), _p(dq), _p(dk), None, None, None, None, None, None, _p(ws), _stream(query)),
-                "recalgo_din_attention_bwd")
+            grads = [None] * 6
+        else:
+            ws = _workspace(nbytes, query.device)
+            grads = [_p(v.grad) for v in vs]
+        _lib.check(lib.recalgo_din_attention_bwd_joined(
+            _p(query), _p(keys), _p(ctx.kl), *[_p(v.data) for v in vs], _p(g), g.stride(0),
+            _p(extra) if fused_extra else None, extra.stride(0) if fused_extra else 0, B, T, H,
+            int(ctx.is_softmax), _p(dq), _p(dk), *grads, _p(ws), _stream(query)), "recalgo_din_attention_bwd")
+        if ctx.in_step:
             rows, pf = int(lib.recalgo_din_attention_bwd_partial_rows(B)), int(lib.recalgo_din_attention_bwd_partial_floats(H))
             wsf, off = ws.view(torch.float32), 0
-            for v in vs:
-                n = v.grad.numel()
-                _colsum_pending.append((wsf, off, rows, pf, n, v.grad))
-                off += n
-            return None, dq, dk, None, None, None
-        ws = _workspace(nbytes, query.device)
-        _lib.check(lib.recalgo_din_attention_bwd(
-            _p(query), _p(keys), _p(ctx.kl), *[_p(v.data) for v in vs], _p(g), B, T, H,
-            int(ctx.is_softmax), _p(dq), _p(dk), *[_p(v.grad) for v in vs], _p(ws), _stream(query)),
-            "recalgo_din_attention_bwd")
-        return None, dq, dk, None, None, None
+            flat = all(vs[i + 1].grad.data_ptr() == vs[i].grad.data_ptr() + 4 * vs[i].grad.numel()
+                       and vs[i + 1].grad.untyped_storage().data_ptr() == vs[0].grad.untyped_storage().data_ptr()
+                       for i in range(5))
+            if flat:      # the six gradients lie in the flat gradient buffer in the partial row's order: ONE job
+                g0 = vs[0].grad
+                out = torch.empty(0, dtype=torch.float32, device=g0.device).set_(g0.untyped_storage(), g0.storage_offset(), (pf,), (1,))
+                _colsum_pending.append((wsf, 0, rows, pf, pf, out))
+            else:
+                for v in vs:
+                    n = v.grad.numel()
+                    _colsum_pending.append((wsf, off, rows, pf, n, v.grad))
+                    off += n
+        if extra is not None and not fused_extra:
+            dq = dq + extra.reshape(dq.shape)
+        return None, dq, dk, None, None, None, None
 
 
-def din_attention(store, query, keys, keys_length, vs, is_softmax=False) -> torch.Tensor:
-    """query [B,H], keys [B,T,H], keys_length [B] int32 -> [B,H]."""
+def din_attention(store, query, keys, keys_length, vs, is_softmax=False, query_join=None) -> torch.Tensor:
+    """query [B,H], keys [B,T,H], keys_length [B] int32 -> [B,H].  query_join (nn.GradJoin): the query's other consumer
+    parks its input gradient there and this op's backward kernel adds it to d(query)."""
     if store.building:
         return torch.zeros_like(query)
     _chk(query, torch.float32, "query")
     _chk(keys, torch.float32, "keys")
     if keys_length.dtype != torch.int32:
         keys_length = keys_length.to(torch.int32)
-    return _DinAttentionFn.apply(store.anchor, query, keys, keys_length.contiguous(), tuple(vs), bool(is_softmax))
+    return _DinAttentionFn.apply(store.anchor, query, keys, keys_length.contiguous(), tuple(vs), bool(is_softmax), query_join)
 
 
 # =============================================================================================
@@ -1125,9 +1141,11 @@ def dense_bwd_weights(x: torch.Tensor, g: torch.Tensor, y_mask: Optional[torch.T
 
 def dense_bwd(x: torch.Tensor, g: torch.Tensor, y_mask: Optional[torch.Tensor], w: torch.Tensor, dw: torch.Tensor,
               dbias: Optional[torch.Tensor], c_in: Optional[torch.Tensor] = None, beta: float = 0.0,
-              defer: bool = False) -> torch.Tensor:
+              defer: bool = False, bn=None) -> torch.Tensor:
     """Both gradients of a dense layer in one launch (recalgo_dense_bwd): returns dx = (g * [y_mask > 0]) @ w^T
-    (+ beta * c_in); dw / dbias as dense_bwd_weights (valid after flush_dense_splits() when `defer`)."""
+    (+ beta * c_in); dw / dbias as dense_bwd_weights (valid after flush_dense_splits() when `defer`).
+    bn = (bn_x [M, K] contiguous, mean [K], rstd [K], partials [bn_partial_rows(M), 2 K]): x is the output of a training-mode
+    BatchNorm over bn_x — the launch also leaves the sums that BatchNorm's backward starts with (recalgo_dense_bwd_bn)."""
     x, g, w = _mat(x, "x"), _mat(g, "g"), _mat(w, "w")
     M, K = x.shape
     N = g.shape[1]
@@ -1146,9 +1164,16 @@ def dense_bwd(x: torch.Tensor, g: torch.Tensor, y_mask: Optional[torch.Tensor], 
         ws = _dense_ws[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
     defer = bool(defer and nbytes > 0)
     dx = torch.empty(M, K, device=g.device, dtype=torch.float32)
-    _lib.check(lib.recalgo_dense_bwd(_p(x), x.stride(0), _p(g), g.stride(0), _p(y_mask), _p(w), M, K, N, _p(c_in),
-                                     0 if c_in is None else c_in.stride(0), float(beta), _p(dx), K, _p(dw), _p(dbias), _p(ws),
-                                     int(defer), _stream(x)), "recalgo_dense_bwd")
+    bnp = (None, None, None, None)
+    if bn is not None:
+        bx, bmean, brstd, bpart = bn
+        if (tuple(bx.shape) != (M, K) or not bx.is_contiguous() or bmean.numel() != K or brstd.numel() != K
+                or tuple(bpart.shape) != (bn_partial_rows(M), 2 * K) or not bpart.is_contiguous()):
+            raise ValueError("dense_bwd: bn = (x [M, K], mean [K], rstd [K], partials [bn_partial_rows(M), 2 K])")
+        bnp = (_p(bx), _p(bmean), _p(brstd), _p(bpart))
+    _lib.check(lib.recalgo_dense_bwd_bn(_p(x), x.stride(0), _p(g), g.stride(0), _p(y_mask), _p(w), M, K, N, _p(c_in),
+                                        0 if c_in is None else c_in.stride(0), float(beta), _p(dx), K, _p(dw), _p(dbias), _p(ws),
+                                        int(defer), *bnp, _stream(x)), "recalgo_dense_bwd")
     if defer:
         _dense_pending.append((M, K, N, ws, dw, dbias))
     return dx
@@ -1242,7 +1267,8 @@ def batchnorm_train_fwd(x, gamma, beta, moving_mean, moving_var, momentum: float
     return y, mean, rstd
 
 
-def batchnorm_train_bwd_act(x, gamma, mean, rstd, g, dgamma, dbeta, kind: int, z, alpha, dalpha, defer: bool) -> torch.Tensor:
+def batchnorm_train_bwd_act(x, gamma, mean, rstd, g, dgamma, dbeta, kind: int, z, alpha, dalpha, defer: bool,
+                            sums=None) -> torch.Tensor:
     """BatchNorm backward continued through the per-channel activation x = act(z, alpha) (recalgo_batchnorm_train_bwd_act):
     -> dL/dz; dgamma / dbeta / dalpha are overwritten (`defer`: dalpha by the step's deferred-sum launch)."""
     rows, C = x.shape
@@ -1256,7 +1282,7 @@ def batchnorm_train_bwd_act(x, gamma, mean, rstd, g, dgamma, dbeta, kind: int, z
             ws = _dense_ws[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
     else:
         ws = _workspace(nbytes, x.device)
-    _lib.check(lib.recalgo_batchnorm_train_bwd_act(_p(x), _p(gamma), _p(mean), _p(rstd), _p(g), rows, C, int(kind), _p(z), _p(alpha),
+    _lib.check(lib.recalgo_batchnorm_train_bwd_act(_p(x), _p(gamma), _p(mean), _p(rstd), _p(g), _p(sums), rows, C, int(kind), _p(z), _p(alpha),
                                                    _p(dz), _p(dgamma), _p(dbeta), None if defer else _p(dalpha), _p(ws),
                                                    _stream(x)), "recalgo_batchnorm_train_bwd_act")
     if defer:
@@ -1301,11 +1327,17 @@ def batchnorm_sync_bwd(x, gamma, mean, rstd, g, dgamma, dbeta, sync) -> torch.Te
     return dx
 
 
-def batchnorm_train_bwd(x, gamma, mean, rstd, g, dgamma, dbeta) -> torch.Tensor:
+def batchnorm_train_bwd(x, gamma, mean, rstd, g, dgamma, dbeta, sums=None) -> torch.Tensor:
+    """sums [bn_partial_rows(rows), 2 C]: the per-tile (colsum g | colsum g * xhat) rows when g's producer has left them
+    (dense_bwd(bn=)): ONE launch (merge + apply) instead of two."""
     rows, C = x.shape
     lib = _lib_()
-    ws = _workspace(lib.recalgo_batchnorm_workspace_bytes(rows, C), x.device)
     dx = torch.empty_like(x)
+    if sums is not None:
+        _lib.check(lib.recalgo_batchnorm_bwd_apply(_p(x), _p(gamma), _p(mean), _p(rstd), _p(g), _p(sums), 1, 0, rows, C, _p(dx),
+                                                   _p(dgamma), _p(dbeta), _stream(x)), "recalgo_batchnorm_bwd_apply")
+        return dx
+    ws = _workspace(lib.recalgo_batchnorm_workspace_bytes(rows, C), x.device)
     _lib.check(lib.recalgo_batchnorm_train_bwd(_p(x), _p(gamma), _p(mean), _p(rstd), _p(g), rows, C, _p(dx), _p(dgamma),
                                                _p(dbeta), _p(ws), _stream(x)), "recalgo_batchnorm_train_bwd")
     return dx
@@ -1438,8 +1470,9 @@ class _ConcatSumsqFn(Function):
     recalgo_concat_sumsq); the gradient of a part is its column block of the output's gradient."""
 
     @staticmethod
-    def forward(ctx, scale, *parts):
+    def forward(ctx, scale, joins, *parts):
         lib = _lib_()
+        ctx.joins = joins or {}
         parts = [t.contiguous() for t in parts]
         B = parts[0].shape[0]
         widths = [int(t.shape[1]) for t in parts]
@@ -1455,20 +1488,27 @@ class _ConcatSumsqFn(Function):
                                             _stream(out)), "recalgo_concat_sumsq")
         ctx.widths = widths
         ctx.mark_non_differentiable(val)
+        ctx.set_materialize_grads(False)      # (else autograd fills a zero "gradient" for val: one launch per step)
         return out, val
 
     @staticmethod
     def backward(ctx, g, _gv):
+        if g is None:
+            return (None, None) + (None,) * len(ctx.widths)
         outs, off = [], 0
-        for w in ctx.widths:
-            outs.append(g[:, off:off + w])
+        for i, w in enumerate(ctx.widths):
+            gi = g[:, off:off + w]
+            join = ctx.joins.get(i)
+            # (a part with a second consumer whose backward kernel adds this block itself: parked, not returned)
+            outs.append(None if join is not None and join.park(gi) else gi)
             off += w
-        return (None, *outs)
+        return (None, None, *outs)
 
 
-def concat_sumsq(parts, scale: float):
-    """-> (concat(parts, -1) [B, C], scale * sum(concat^2) as a detached [1] tensor); 1..4 fp32 [B, w] device tensors."""
-    return _ConcatSumsqFn.apply(float(scale), *parts)
+def concat_sumsq(parts, scale: float, joins=None):
+    """-> (concat(parts, -1) [B, C], scale * sum(concat^2) as a detached [1] tensor); 1..4 fp32 [B, w] device tensors.
+    joins {part index: nn.GradJoin}: that part's gradient block is parked for its other consumer's backward kernel."""
+    return _ConcatSumsqFn.apply(float(scale), joins, *parts)
 
 
 _dlogit_partials = {}

@@ -253,3 +253,44 @@ def test_dense_activation_batchnorm_as_one_node(dev, M, K, N, kind):
     assert_close(out, ot.detach(), what="fused layer output vs fp64", reduced=True)
     assert_close(dz, zt.grad, what="fused layer d(z) vs fp64", reduced=True)
     assert_close(dalpha, at.grad, what="fused layer d(alpha) vs fp64", reduced=True)
+
+
+@pytest.mark.parametrize("M,K,N", [(4096, 512, 256), (4096, 256, 128), (300, 100, 52), (65, 8, 48)])
+def test_dense_bwd_leaves_the_batchnorm_backward_sums(dev, M, K, N):
+    """recalgo_dense_bwd_bn: a layer whose input is a BatchNorm's output (batch_normalization -> dense, deepfm.py:207-211)
+    leaves, per 64-row tile of its input gradient, colsum(dx) and colsum(dx * xhat) — what recalgo_batchnorm_bwd_sums computes
+    from dx in a pass of its own — with dx / dw / dbias unchanged; BatchNorm's backward fed with them equals the two-launch one."""
+    import ctypes
+    from recalgorithm_amd import _lib
+    lib = _lib.load()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    gen = torch.Generator().manual_seed(M + K)
+    bn_in = torch.randn(M, K, generator=gen).to(dev)                   # the BatchNorm's input
+    gamma, beta = (torch.rand(K, generator=gen) + 0.5).to(dev), torch.randn(K, generator=gen).to(dev)
+    mm, mv = torch.zeros(K, device=dev), torch.ones(K, device=dev)
+    x, mean, rstd = ops.batchnorm_train_fwd(bn_in, gamma, beta, mm, mv, 0.99, 1e-3)       # = the dense layer's input
+    w = (torch.randn(K, N, generator=gen) / K ** 0.5).to(dev)
+    g = torch.randn(M, N, generator=gen).to(dev)
+    y = torch.relu(torch.randn(M, N, generator=gen)).to(dev)
+    nb = ops.bn_partial_rows(M)
+    for mask in (None, y):
+        dw0, db0 = torch.empty(K, N, device=dev), torch.empty(N, device=dev)
+        dx0 = ops.dense_bwd(x, g, mask, w, dw0, db0)
+        ops.flush_dense_splits()
+        dw1, db1 = torch.empty(K, N, device=dev), torch.empty(N, device=dev)
+        sums = torch.full((nb, 2 * K), float("nan"), device=dev)
+        dx1 = ops.dense_bwd(x, g, mask, w, dw1, db1, bn=(bn_in, mean, rstd, sums))
+        ops.flush_dense_splits()
+        assert torch.equal(dx1, dx0) and torch.equal(dw1, dw0) and torch.equal(db1, db0)
+        want = torch.empty(nb, 2 * K, device=dev)
+        _lib.check(lib.recalgo_batchnorm_bwd_sums(p(bn_in), p(mean), p(rstd), p(dx0), M, K, p(want), st()), "bwd_sums")
+        assert_close(sums[:, :K], want[:, :K].double(), what="tile colsum(dx) from the dgrad epilogue", reduced=True)
+        assert_close(sums[:, K:], want[:, K:].double(), what="tile colsum(dx * xhat) from the dgrad epilogue", reduced=True)
+        if K % 4 == 0:
+            dg0, dbt0, dg1, dbt1 = (torch.empty(K, device=dev) for _ in range(4))
+            d0 = ops.batchnorm_train_bwd(bn_in, gamma, mean, rstd, dx0, dg0, dbt0)
+            d1 = ops.batchnorm_train_bwd(bn_in, gamma, mean, rstd, dx0, dg1, dbt1, sums=sums)
+            assert_close(d1, d0.double(), what="BatchNorm backward on the epilogue's sums", reduced=True)
+            assert_close(dg1, dg0.double(), what="d(gamma) on the epilogue's sums", reduced=True)
+            assert_close(dbt1, dbt0.double(), what="d(beta) on the epilogue's sums", reduced=True)
