@@ -583,6 +583,19 @@ typedef struct {
 int recalgo_adam_tf1_step(float* p, float* g, float* m, float* v, int64_t n, const recalgo_adam_arena_t* arenas,
                           int n_arenas, int64_t* step_dev, int* ticket_dev, int advance, float lr, float beta1,
                           float beta2, float eps, int zero_grad, recalgo_stream_t stream);
+/* a scatter plan's bucket counters and where their prefix goes (see recalgo_scatter_plan_scan, RECALGO_SCATTER_PRESCANNED) */
+typedef struct {
+    const uint32_t* total;   /* [nb << counter_shift] */
+    uint32_t* offs;          /* [nb] */
+    void* sched;             /* uint4 [nb] */
+    uint32_t counter_shift, nb_log2;
+} recalgo_plan_scan_t;
+/* recalgo_adam_tf1_step plus, as n_scans (<= 4) extra workgroups of the same launch, the prefix scan of the scatter plans whose
+ * recalgo_scatter_apply follows with RECALGO_SCATTER_PRESCANNED (every count of those plans must have been enqueued before). */
+int recalgo_adam_tf1_step_plans(float* p, float* g, float* m, float* v, int64_t n, const recalgo_adam_arena_t* arenas,
+                                int n_arenas, int64_t* step_dev, int* ticket_dev, int advance, float lr, float beta1,
+                                float beta2, float eps, int zero_grad, const recalgo_plan_scan_t* scans, int n_scans,
+                                recalgo_stream_t stream);
 /* Housekeeping for the live-row list: rebuild live_list in ascending row order from the liveness
  * bytes (same set, live_count rewritten with the same total).  recalgo_mark_live_rows appends rows in
  * first-touch order; an address-ordered list lets recalgo_adam_tf1_list walk HBM monotonically.  Run
@@ -710,6 +723,12 @@ int recalgo_activation_bwd(const float* x, const float* alpha, const float* gy, 
 #define RECALGO_SCATTER_GRAD 0
 #define RECALGO_SCATTER_ADAM 1
 #define RECALGO_SCATTER_LAZY_ADAM 2
+/* OR-ed into recalgo_scatter_apply's `mode`: the prefix of the plan's bucket totals (offs, sched) has already been written by a
+ * launch that ran after the plan's last count — recalgo_adam_tf1_step_plans with this plan's recalgo_scatter_plan_scan record —
+ * and `place` reads it instead of every tile scanning the (cache-line-spread) counters itself. */
+#define RECALGO_SCATTER_PRESCANNED 0x100
+/* the record of a plan workspace (as passed to recalgo_scatter_prepare / _apply) for recalgo_adam_tf1_step_plans */
+int recalgo_scatter_plan_scan(void* plan_workspace, int64_t plan_requests, int nb_log2, recalgo_plan_scan_t* out);
 #define RECALGO_PREPARE_COUNT 1      /* recalgo_scatter_prepare flags: add the source's entries to the plan's bucket totals */
 #define RECALGO_PREPARE_SWEEP 2      /* ... run this step's share of the deferred-Adam sweep of the arena(s) in the launch */
 #define RECALGO_PREPARE_CATCHUP 4    /* ... bring the source's lagging rows (and the companion's) up to date: needs `deferred` */

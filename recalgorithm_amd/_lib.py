@@ -82,6 +82,9 @@ SIGNATURES = {
     "recalgo_exchange_plan": (c_int, [P, c_int64, c_int, c_int64, P, P, P, P, P, P]),
     "recalgo_adam_tf1_list": (c_int, [P, P, P, P, P, P, c_int64, c_int, c_float, P, c_float, c_float, c_float, c_int, P]),
     "recalgo_adam_tf1_step": (c_int, [P, P, P, P, c_int64, P, c_int, P, P, c_int, c_float, c_float, c_float, c_float, c_int, P]),
+    "recalgo_adam_tf1_step_plans": (c_int, [P, P, P, P, c_int64, P, c_int, P, P, c_int, c_float, c_float, c_float, c_float, c_int,
+                                            P, c_int, P]),
+    "recalgo_scatter_plan_scan": (c_int, [P, c_int64, c_int, P]),
     "recalgo_adam_tf1_advance": (c_int, [P, c_float, c_float, c_float, P, P]),
     "recalgo_cross_layer_fwd": (c_int, [P, P, c_int, P, P, c_int, c_int, P, c_int, P]),
     "recalgo_cross_layer_bwd": (c_int, [P, P, c_int, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P]),

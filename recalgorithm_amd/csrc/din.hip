@@ -280,6 +280,8 @@ __global__ __launch_bounds__(kThreads) void din_attention_bwd_kernel(
         const bool in_T = lane < T, in_len = in_T && (int)lane < len;
         const float w = attention_weight<H>(s, in_len, in_T, is_softmax);
         // ---- attention output backward (lane = row) ----
+        // (the query's other gradient, added at the very end: requested here, with the loads of g, not in front of the store)
+        const float dq_add = (dq_extra && lane < (unsigned)H) ? dq_extra[(size_t)ex * ld_extra + lane] : 0.f;
         float g[H];
         {
             const float4* gr = reinterpret_cast<const float4*>(g_out + (size_t)ex * ldg);
@@ -289,6 +291,10 @@ __global__ __launch_bounds__(kThreads) void din_attention_bwd_kernel(
                 g[i] = v.x; g[i + 1] = v.y; g[i + 2] = v.z; g[i + 3] = v.w;
             }
         }
+        // (pins the dq_extra load up here, in the shadow of g's round trip: left alone, the compiler sinks it to its use at
+        // the end of the iteration, where one wave per SIMD waits out a whole memory round trip per example — +8 us)
+        float dq_pin = dq_add;
+        asm volatile("" : "+v"(dq_pin));
         float dwt = 0.f;
 #pragma unroll
         for (int i = 0; i < H; ++i) dwt = fmaf(g[i], k[i], dwt);          // d out / d w_t
@@ -414,7 +420,7 @@ __global__ __launch_bounds__(kThreads) void din_attention_bwd_kernel(
             float v = dq[0];
 #pragma unroll
             for (int i = 1; i < H; ++i) v = lane == (unsigned)i ? dq[i] : v;
-            if (dq_extra) v += dq_extra[(size_t)ex * ld_extra + lane];    // the query's other consumer's gradient (GradJoin)
+            v += dq_pin;                                                  // the query's other consumer's gradient (GradJoin)
             dquery[(size_t)ex * H + lane] = v;
         }
         __builtin_amdgcn_wave_barrier();

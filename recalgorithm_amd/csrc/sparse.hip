@@ -532,6 +532,9 @@ struct PlaceArgs {
     const unsigned* total; unsigned* cursor;   // [nb << cs], [nb << cs]
     unsigned cs;
     uint4* sched;                              // [nb]: (bucket, first entry, entries, -) in the order `apply` takes the buckets (the heavy ones first)
+    // prescanned: offs_g / sched already hold the prefix of the totals (recalgo_scatter_plan_scan's record run by the optimizer
+    // launch in front, plan_scan.h) — the tiles then skip their own scan of the counters and its nb words of LDS
+    const unsigned* offs_g; int prescanned;
     // workgroup 0 also evaluates this step's lr_t ONCE for `apply` (header word 0) and records it in the rings
     float* hdr;
     float* lr_ring; float* lr_ring1;           // nullptr: none
@@ -561,8 +564,8 @@ __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
     unsigned* req_s = req_f + kThreads;                       // [kThreads] ... source
     unsigned* jobs = req_s + kThreads;                        // [kThreads] leaders of the duplicated rows
     float* red = reinterpret_cast<float*>(jobs + kThreads);   // [kThreads * 4]
-    unsigned* offs = reinterpret_cast<unsigned*>(red + kThreads * 4);   // [nb]
-    unsigned* sh = offs + nb;                                 // [8]; sh[6] = number of jobs, sh[7] = number of long jobs
+    unsigned* offs = reinterpret_cast<unsigned*>(red + kThreads * 4);   // [nb] (not when the plan is prescanned: offs_g)
+    unsigned* sh = offs + (A.prescanned ? 0u : nb);           // [8]; sh[6] = number of jobs, sh[7] = number of long jobs
     unsigned* ljobs = sh + 8;                                 // [16] leaders of the rows with > kTileLong duplicates (<= 10)
     unsigned* hkey = ljobs + 16;                              // [kSlots]     equal-key bookkeeping (tile_equal)
     unsigned* mask = hkey + kSlots;                           // [kSlots][8]
@@ -581,7 +584,15 @@ __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
         const SrcDev& S = lsrc[si];
         if (i - S.first < S.n) row = slot_row(S, i - S.first, &e, &f);      // (padding between two sources: no request)
     }
-    {
+    if (A.prescanned) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && A.step != nullptr) {
+            const long long t = A.step[0] + A.step_off;
+            const float lr_t = lr_t_of(A.lr, A.b1, A.b2, t);
+            A.hdr[0] = lr_t;
+            if (A.lr_ring) A.lr_ring[(unsigned)t & (kLrRing - 1)] = lr_t;
+            if (A.lr_ring1) A.lr_ring1[(unsigned)t & (kLrRing - 1)] = lr_t;
+        }
+    } else {
         // (ONE pass over the counters — they are spread over cache lines, a load fetches a line per counter: the totals wait
         // in LDS for their prefix)
         unsigned sum = 0;
@@ -656,11 +667,12 @@ __global__ __launch_bounds__(kThreads) void sparse_place_kernel(PlaceArgs A) {
     unsigned slot_b;
     const EqInfo db = tile_equal(b, hkey, mask, &slot_b);
     if (leader && db.before == 0) bbase[slot_b] = atomicAdd(&A.cursor[(size_t)b << A.cs], db.same);
+    const unsigned first_b = !leader ? 0u : (A.prescanned ? A.offs_g[b] : offs[b]);
     __syncthreads();
     if (leader) {
         // a duplicated row's entry refers to the tile's partial sum (written below), a single request to its own row.  The key
         // (row, slot of the leader) is unique: `apply` orders a bucket by it, so the order the tiles arrive in does not matter
-        A.keys[offs[b] + bbase[slot_b] + db.before] = ((unsigned long long)row << 32) | ((unsigned long long)i << 1) | (dupl ? 1u : 0u);
+        A.keys[first_b + bbase[slot_b] + db.before] = ((unsigned long long)row << 32) | ((unsigned long long)i << 1) | (dupl ? 1u : 0u);
     }
     // ---- the duplicated rows of the tile: gradient rows added in request order ---------------------------------------
     const unsigned njobs = sh[6];
@@ -1253,8 +1265,8 @@ inline unsigned counter_shift() {
     return v;
 }
 
-struct Ws { float* hdr; unsigned* total; unsigned* cursor; uint4* sched; unsigned long long* keys; unsigned long long* keys_alt;
-            float* partials; float* partials1; };
+struct Ws { float* hdr; unsigned* total; unsigned* cursor; uint4* sched; unsigned* offs; unsigned long long* keys;
+            unsigned long long* keys_alt; float* partials; float* partials1; };
 inline Ws carve(void* ws, int64_t cap, int nb_log2) {
     const int64_t nb = 1ll << nb_log2;
     char* p = static_cast<char*>(ws);
@@ -1265,7 +1277,8 @@ inline Ws carve(void* ws, int64_t cap, int nb_log2) {
     w.total = reinterpret_cast<unsigned*>(p) + 32;          // [nb << cs]
     w.cursor = w.total + nc;                                // [nb << cs]
     w.sched = reinterpret_cast<uint4*>(w.cursor + nc);      // [nb]  (16-byte aligned: 32 + 2 nc words in front)
-    w.keys = reinterpret_cast<unsigned long long*>(w.sched + nb);
+    w.offs = reinterpret_cast<unsigned*>(w.sched + nb);     // [nb] first entry of every bucket (written by the plan scan)
+    w.keys = reinterpret_cast<unsigned long long*>(w.offs + nb);
     w.keys_alt = w.keys + cap;
     w.partials1 = reinterpret_cast<float*>(w.keys_alt + cap);  // [cap]
     w.partials = w.partials1 + cap;                             // [cap][K]
@@ -1290,11 +1303,20 @@ RECALGO_EXPORT int64_t recalgo_scatter_plan_header_bytes(int nb_log2) {
     return (32 + 2 * ((1ll << nb_log2) << counter_shift())) * (int64_t)sizeof(unsigned);
 }
 
+RECALGO_EXPORT int recalgo_scatter_plan_scan(void* plan_workspace, int64_t plan_requests, int nb_log2, recalgo_plan_scan_t* out) {
+    RECALGO_REQUIRE(plan_workspace != nullptr && out != nullptr && nb_ok(nb_log2) && plan_requests >= 0 &&
+                    plan_requests % kThreads == 0);
+    const Ws ws = carve(plan_workspace, plan_requests, nb_log2);
+    out->total = ws.total; out->offs = ws.offs; out->sched = ws.sched;
+    out->counter_shift = counter_shift(); out->nb_log2 = (unsigned)nb_log2;
+    return 0;
+}
+
 RECALGO_EXPORT int64_t recalgo_scatter_plan_workspace_bytes(int64_t n_slots, int nb_log2, int K) {
     if (n_slots < 0 || n_slots % kThreads != 0 || !nb_ok(nb_log2) || K < 1) return 0;
     const int64_t nb = 1ll << nb_log2;
     const int64_t cap = n_slots > 0 ? n_slots : kThreads;
-    return (4 * nb + 2 * (nb << counter_shift()) + 32) * (int64_t)sizeof(unsigned) + 2 * cap * (int64_t)sizeof(unsigned long long) +
+    return (5 * nb + 2 * (nb << counter_shift()) + 32) * (int64_t)sizeof(unsigned) + 2 * cap * (int64_t)sizeof(unsigned long long) +
            cap * (int64_t)(K + 1) * (int64_t)sizeof(float) + 64;
 }
 
@@ -1369,6 +1391,8 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
                                          recalgo_stream_t stream) {
     RECALGO_REQUIRE(sources != nullptr && n_sources >= 1 && n_sources <= kMaxSources && plan_workspace != nullptr);
     RECALGO_REQUIRE(nb_ok(nb_log2) && rows >= 0 && rows < (1ll << 31));
+    const int prescanned = (mode & RECALGO_SCATTER_PRESCANNED) != 0;
+    mode &= ~RECALGO_SCATTER_PRESCANNED;
     RECALGO_REQUIRE(mode == RECALGO_SCATTER_GRAD || mode == RECALGO_SCATTER_ADAM || mode == RECALGO_SCATTER_LAZY_ADAM);
     RECALGO_REQUIRE(mode != RECALGO_SCATTER_GRAD ? (w && m && v && step_dev) : grad != nullptr);
     RECALGO_REQUIRE(mode != RECALGO_SCATTER_ADAM || (deferred && deferred->last_step && deferred->lr_ring));
@@ -1393,6 +1417,7 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
     P.n_total = n_total;
     P.total = ws.total; P.cursor = ws.cursor; P.sched = ws.sched; P.keys = ws.keys; P.partials = ws.partials;
     P.hdr = ws.hdr;
+    P.offs_g = ws.offs; P.prescanned = prescanned;
     P.lr_ring = mode == RECALGO_SCATTER_ADAM ? deferred->lr_ring : nullptr;
     P.lr_ring1 = (mode == RECALGO_SCATTER_ADAM && companion) ? companion->deferred->lr_ring : nullptr;
     P.step = mode != RECALGO_SCATTER_GRAD ? reinterpret_cast<const long long*>(step_dev) : nullptr;
@@ -1403,7 +1428,7 @@ RECALGO_EXPORT int recalgo_scatter_apply(const recalgo_scatter_source_t* sources
     P.cs = counter_shift();
     P.KV = G.KV; P.L = G.L;
     P.stage_ok = (size_t)K * kThreads * sizeof(float) <= 32 * 1024;      // (K <= 32: every model of the reference)
-    const size_t smem = ((size_t)nb + 8 * kThreads + 8 + 16 + kSlots * 10) * sizeof(unsigned) + kThreads * 4 * sizeof(float) +
+    const size_t smem = ((prescanned ? 0 : (size_t)nb) + 8 * kThreads + 8 + 16 + kSlots * 10) * sizeof(unsigned) + kThreads * 4 * sizeof(float) +
                         kMaxSources * sizeof(SrcDev) + (P.stage_ok ? (size_t)(K + 1) * kThreads * sizeof(float) : 0);
     if (smem > 64 * 1024) {
         hipError_t e = G.vec == 4 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_place_kernel<4>),

@@ -1,6 +1,7 @@
 // Loss tail (a14), TF1 Adam (a15), DIN activations (a12) — small streaming kernels, gfx950.
 #include "deferred.h"
 #include "act.h"
+#include "plan_scan.h"
 
 namespace {
 
@@ -399,10 +400,19 @@ struct AdamStepArgs {
     int advance;
     float lr, b1, b2, eps;
     int zero_grad;
+    // the scatter plans of the arenas on the owner-computes path (sparse.hip): one extra workgroup each turns the plan's bucket
+    // totals into the prefix `place` needs — this launch runs between the step's last count and `place` anyway
+    recalgo_plan::Scan scan[kAdamMaxArenas];
+    unsigned scan_first;      // blocks [scan_first, scan_first + n_scans) are those workgroups
 };
 
 __global__ __launch_bounds__(256) void adam_tf1_step_kernel(AdamStepArgs A) {
     __shared__ float s_lr_t;
+    if (blockIdx.x >= A.scan_first) {                          // (workgroup-uniform)
+        __shared__ unsigned scan_sh[8];
+        recalgo_plan::scan_block(A.scan[blockIdx.x - A.scan_first], scan_sh);
+        return;
+    }
     const long long t = A.step[0] + (A.advance ? 1 : 0);
     if (threadIdx.x == 0) {
         const double td = (double)t;
@@ -498,7 +508,7 @@ __global__ __launch_bounds__(256) void adam_tf1_step_kernel(AdamStepArgs A) {
     __syncthreads();
     if (threadIdx.x == 0) {
         const int arrived = __hip_atomic_fetch_add(A.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (arrived == (int)gridDim.x - 1) {
+        if (arrived == (int)A.scan_first - 1) {                 // (the plan-scan workgroups behind scan_first take no ticket)
             __hip_atomic_store(A.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             A.step[0] = t;
         }
@@ -819,7 +829,17 @@ RECALGO_EXPORT int recalgo_adam_tf1_step(float* p, float* g, float* m, float* v,
                                          const recalgo_adam_arena_t* arenas, int n_arenas, int64_t* step_dev,
                                          int* ticket_dev, int advance, float lr, float beta1, float beta2, float eps,
                                          int zero_grad, recalgo_stream_t stream) {
+    return recalgo_adam_tf1_step_plans(p, g, m, v, n, arenas, n_arenas, step_dev, ticket_dev, advance, lr, beta1, beta2, eps,
+                                       zero_grad, nullptr, 0, stream);
+}
+
+RECALGO_EXPORT int recalgo_adam_tf1_step_plans(float* p, float* g, float* m, float* v, int64_t n,
+                                               const recalgo_adam_arena_t* arenas, int n_arenas, int64_t* step_dev,
+                                               int* ticket_dev, int advance, float lr, float beta1, float beta2, float eps,
+                                               int zero_grad, const recalgo_plan_scan_t* scans, int n_scans,
+                                               recalgo_stream_t stream) {
     RECALGO_REQUIRE(n >= 0 && n_arenas >= 0 && n_arenas <= kAdamMaxArenas && step_dev != nullptr);
+    RECALGO_REQUIRE(n_scans >= 0 && n_scans <= kAdamMaxArenas && (n_scans == 0 || scans != nullptr));
     RECALGO_REQUIRE(!advance || ticket_dev != nullptr);
     RECALGO_REQUIRE(n == 0 || (p && g && m && v));
     RECALGO_REQUIRE(n_arenas == 0 || arenas != nullptr);
@@ -855,6 +875,14 @@ RECALGO_EXPORT int recalgo_adam_tf1_step(float* p, float* g, float* m, float* v,
     A.step = reinterpret_cast<long long*>(step_dev); A.ticket = ticket_dev; A.advance = advance;
     A.lr = lr; A.b1 = beta1; A.b2 = beta2; A.eps = eps; A.zero_grad = zero_grad;
     if (blocks == 0) blocks = 1;                      // still advances the step counter
+    A.scan_first = blocks;
+    for (int i = 0; i < n_scans; ++i) {
+        const recalgo_plan_scan_t& c = scans[i];
+        RECALGO_REQUIRE(c.total && c.offs && c.sched && c.nb_log2 >= 8 && c.nb_log2 <= 13 && c.counter_shift <= 5);
+        A.scan[i] = recalgo_plan::Scan{c.total, c.offs, static_cast<uint4*>(c.sched), c.counter_shift, c.nb_log2};
+    }
+    for (int i = n_scans; i < kAdamMaxArenas; ++i) A.scan[i] = recalgo_plan::Scan{nullptr, nullptr, nullptr, 0, 8};
+    blocks += (unsigned)n_scans;
     hipLaunchKernelGGL(adam_tf1_step_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), A);
     RECALGO_RETURN_LAST();
 }

@@ -100,8 +100,10 @@ class AdamOptimizer:
         if fused:
             # one launch: dense TF1 Adam over the flat buffer + dense-semantics TF1 Adam over the rows a gradient has ever
             # reached (the update is the identity for all others); lr_t derived on the device from the step counter
+            # (+ one workgroup per owner-computes plan: the prefix scan of its bucket totals, which `place` then reads)
+            scans = [r for r in (sparse.plan_scan_record(ar, self.lazy_embeddings) for ar in owned[:4]) if r is not None]
             ops.adam_tf1_step_(store.flat, store.flat_grad, store.flat_m, store.flat_v, arenas, st["step"], None,
-                               self.lr, self.beta1, self.beta2, self.eps, lazy=self.lazy_embeddings)
+                               self.lr, self.beta1, self.beta2, self.eps, lazy=self.lazy_embeddings, plan_scans=scans)
             for ar in owned:
                 sparse.apply(ar, self.lazy_embeddings, st["step"], self.lr, self.beta1, self.beta2, self.eps)
             return

@@ -1645,9 +1645,11 @@ class _AdamArena(ctypes.Structure):          # include/recalgo.h recalgo_adam_ar
 
 def adam_tf1_step_(flat, flat_grad, flat_m, flat_v, arenas, step_dev: torch.Tensor, ticket_dev: Optional[torch.Tensor],
                    lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, zero_grad: bool = True,
-                   advance: bool = False, lazy: bool = False) -> None:
+                   advance: bool = False, lazy: bool = False, plan_scans=()) -> None:
     """ONE launch: TF1 Adam over the flat dense buffer and over the live rows of every arena, lr_t derived on the device
-    from step_dev (already advanced unless `advance`; include/recalgo.h recalgo_adam_tf1_step)."""
+    from step_dev (already advanced unless `advance`; include/recalgo.h recalgo_adam_tf1_step).  plan_scans: the
+    recalgo_plan_scan_t records (sparse.plan_scan_record) of the scatter plans whose `apply` follows — their bucket-total
+    prefix scans ride on this launch (recalgo_adam_tf1_step_plans)."""
     lib = _lib_()
     n = 0 if flat is None else flat.numel()
     for i in range(0, max(len(arenas), 1), 4):
@@ -1661,6 +1663,10 @@ def adam_tf1_step_(flat, flat_grad, flat_m, flat_v, arenas, step_dev: torch.Tens
         first = i == 0
         if not first:
             raise NotImplementedError("more than 4 embedding arenas in one model")
-        _lib.check(lib.recalgo_adam_tf1_step(_p(flat) if n else None, _p(flat_grad) if n else None, _p(flat_m) if n else None,
-                                             _p(flat_v) if n else None, n, arr, len(chunk), _p(step_dev), _p(ticket_dev),
-                                             int(advance), lr, beta1, beta2, eps, int(zero_grad), _stream(step_dev)), "recalgo_adam_tf1_step")
+        scans = None
+        if plan_scans:
+            scans = (type(plan_scans[0]) * len(plan_scans))(*plan_scans)
+        _lib.check(lib.recalgo_adam_tf1_step_plans(_p(flat) if n else None, _p(flat_grad) if n else None, _p(flat_m) if n else None,
+                                                   _p(flat_v) if n else None, n, arr, len(chunk), _p(step_dev), _p(ticket_dev),
+                                                   int(advance), lr, beta1, beta2, eps, int(zero_grad), scans, len(plan_scans),
+                                                   _stream(step_dev)), "recalgo_adam_tf1_step")

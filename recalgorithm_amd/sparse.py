@@ -62,6 +62,11 @@ class _CCompanion(ctypes.Structure):         # include/recalgo.h recalgo_scatter
                 ("grad", ctypes.c_void_p), ("deferred", ctypes.c_void_p), ("rows", ctypes.c_int64)]
 
 
+class _CPlanScan(ctypes.Structure):          # include/recalgo.h recalgo_plan_scan_t
+    _fields_ = [("total", ctypes.c_void_p), ("offs", ctypes.c_void_p), ("sched", ctypes.c_void_p),
+                ("counter_shift", ctypes.c_uint32), ("nb_log2", ctypes.c_uint32)]
+
+
 class _CDeferred(ctypes.Structure):          # include/recalgo.h recalgo_deferred_adam_t
     _fields_ = [("w", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p), ("last_step", ctypes.c_void_p),
                 ("lr_ring", ctypes.c_void_p), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float)]
@@ -163,6 +168,7 @@ class ArenaPlan:
         self.counted = None                    # signature of what the workspace's bucket totals currently hold
         self.swept = False                     # this step's share of the deferred-Adam sweep has been launched
         self.side_pending: List[Source] = []   # lookups whose counts (and the sweep) wait for launch_side_work
+        self.prescanned = None                 # signature the bucket-total prefix (offs / sched) was computed for, this step
         self.last_step: Optional[torch.Tensor] = None     # deferred-Adam: int32 [rows]
         self.lr_ring: Optional[torch.Tensor] = None
         self.betas = (0.9, 0.999, 1e-8)
@@ -455,8 +461,29 @@ def _merge_dense(sources: List[Source], K: int) -> List[Source]:
     return rest + [merged]
 
 
+MODE_PRESCANNED = 0x100        # include/recalgo.h RECALGO_SCATTER_PRESCANNED
+
+
+def plan_scan_record(arena, lazy: bool):
+    """The recalgo_plan_scan_t of the arena's plan, for the optimizer launch that runs between the step's last count and this
+    arena's `apply` (ops.adam_tf1_step_(plan_scans=)) — or None when `apply` will not find the totals of exactly its sources in
+    the workspace (it then counts again, and `place` scans them itself)."""
+    plan = plan_of(arena)
+    if plan is None or plan.ws is None or plan.companions or plan.side_pending or (plan.served and not plan.sources):
+        return None
+    srcs = [s for s in plan.sources if s.g is not None and s.n]
+    if not srcs or len(srcs) > MAX_SOURCES or sum(s.slots for s in srcs) > plan.capacity or plan.counted != plan._signature(srcs):
+        return None
+    rec = _CPlanScan()
+    _lib.check(_lib.load().recalgo_scatter_plan_scan(ctypes.c_void_p(plan.ws.data_ptr()), plan.capacity, plan.nb_log2,
+                                                     ctypes.byref(rec)), "recalgo_scatter_plan_scan")
+    plan.prescanned = plan._signature(srcs)
+    return rec
+
+
 def _run(plan: ArenaPlan, sources: List[Source], mode: int, step_dev, step_offset: int, lr: float, live=None):
     lib = _lib.load()
+    prescanned, plan.prescanned = plan.prescanned, None
     a = plan.arena
     comp_arena = _companion_arena(sources, mode)
     if len([s for s in sources if s.n]) > MAX_SOURCES:
@@ -466,6 +493,8 @@ def _run(plan: ArenaPlan, sources: List[Source], mode: int, step_dev, step_offse
         sources = _merge_dense(sources, a.K)
     srcs = [s for s in sources if s.n]
     plan._ensure_ws(sum(s.slots for s in srcs))
+    if not srcs or prescanned != plan._signature(srcs) or plan.counted != prescanned:
+        prescanned = None
     if plan.counted != plan._signature(srcs):
         # the totals in the workspace are not those of exactly these sources (first step, a forward without a backward, a
         # GRAD pass before the optimizer, a re-sized workspace): count again
@@ -526,7 +555,8 @@ def _run(plan: ArenaPlan, sources: List[Source], mode: int, step_dev, step_offse
                            None if dc is None else ctypes.addressof(dc), c.weight.shape[0])
     grad = a._grad if (mode == MODE_GRAD or plan.grad_materialized) else None
     _lib.check(lib.recalgo_scatter_apply(arr, len(srcs), None if comp is None else ctypes.byref(comp), a.K, p(plan.ws), plan.capacity,
-                                         plan.nb_log2, mode, p(a.weight), p(a.m), p(a.v), p(grad),
+                                         plan.nb_log2, mode | (MODE_PRESCANNED if prescanned is not None else 0), p(a.weight), p(a.m),
+                                         p(a.v), p(grad),
                                          None if d is None else ctypes.byref(d), a.weight.shape[0],
                                          live, p(step_dev), step_offset, lr, b1, b2, eps, _stream(a.weight)),
                "recalgo_scatter_apply")
