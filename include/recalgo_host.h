@@ -56,6 +56,31 @@ int64_t recalgo_reader_id_feature(void* reader, const char* key, const void* voc
 int recalgo_reader_id_matrix(void* reader, int n_keys, const char* const* keys, const void* const* vocabs,
                              int64_t* out, int32_t* multi);
 
+/* ---- asynchronous batch pipeline: TFRecordDataset(file)[.shuffle(buffer)].repeat(epochs).batch(B).map(parse_example)
+ * .prefetch(depth) (/root/reference algorithm/utils.py:18-24) as ONE object.  A producer thread frames and shuffles the records
+ * of batch after batch into a ring of `depth` slots; worker threads decode chunks of 64 records of whichever batches are in the
+ * ring (no fork / join per batch).  id_keys[n_ids] / vocabs[n_ids]: single-valued string features -> int64 [B, n_ids] (column
+ * order as given, -1 = missing / not in the vocabulary); float_keys[n_floats] with float_n / float_default /
+ * float_has_default: FixedLenFeature((n,), float32[, default]) -> float32 [B, sum n].  ids_slots / float_slots: `depth`
+ * caller-owned buffers each (e.g. page-locked), or NULL for the pipeline's own.  threads <= 0: RECALGO_READER_THREADS, else half
+ * the hardware threads (2 .. 64).  NULL on error. */
+void* recalgo_pipeline_open(const char* path, int verify_crc, int64_t num_epochs, int64_t shuffle_buffer_size, uint64_t seed,
+                            int64_t batch_size, int n_ids, const char* const* id_keys, const void* const* vocabs,
+                            int n_floats, const char* const* float_keys, const int32_t* float_n, const float* float_default,
+                            const int32_t* float_has_default, int depth, int64_t* const* ids_slots, float* const* float_slots,
+                            int threads);
+/* The next batch, in order: its number of records (> 0) and *slot = the ring slot holding it, valid until
+ * recalgo_pipeline_release(slot); 0 = end of the data; -1 = framing error / malformed Example, -3 = a required float feature
+ * is missing (recalgo_pipeline_error says which); -2 = an id feature holds several values in some record (decode that file with
+ * the synchronous accessors). */
+int64_t recalgo_pipeline_next(void* pipeline, int* slot);
+void recalgo_pipeline_release(void* pipeline, int slot);
+const int64_t* recalgo_pipeline_ids(void* pipeline, int slot);
+const float* recalgo_pipeline_floats(void* pipeline, int slot);
+const char* recalgo_pipeline_error(void* pipeline);
+int recalgo_pipeline_threads(void* pipeline);
+void recalgo_pipeline_close(void* pipeline);
+
 #ifdef __cplusplus
 }
 #endif

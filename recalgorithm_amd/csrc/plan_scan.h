@@ -38,33 +38,58 @@ __device__ __forceinline__ unsigned excl_scan256(unsigned v, unsigned* sh, unsig
     return before + inc - v;
 }
 
-// all 256 threads of one workgroup; nb is a multiple of 256.  (The counters are read three times — they stay in L2 — rather
-// than parked in nb words of LDS: the host kernel keeps its LDS footprint.)
-__device__ __forceinline__ void scan_block(const Scan& S, unsigned* sh) {
+// all 256 threads of one workgroup; nb is a multiple of 256 (1024 .. 8192: 4 .. 32 buckets per thread).  Up to 8 buckets per
+// thread the counters are read ONCE, all loads in flight together, and kept in registers; larger plans read them again in
+// every pass (they stay in L2) rather than parking nb words in LDS: the host kernel keeps its LDS footprint.
+template <bool REGS>
+__device__ __forceinline__ void scan_block_impl(const Scan& S, unsigned* sh) {
     const unsigned bpt = (1u << S.nb_log2) / 256u, b0 = threadIdx.x * bpt;
+    unsigned cnt[8];
+    if (REGS) {
+#pragma unroll
+        for (unsigned k = 0; k < 8; ++k) cnt[k] = k < bpt ? S.total[(size_t)(b0 + k) << S.cs] : 0u;
+    }
+    auto count = [&](unsigned k) -> unsigned { return REGS ? cnt[k] : S.total[(size_t)(b0 + k) << S.cs]; };
     unsigned sum = 0;
-    for (unsigned k = 0; k < bpt; ++k) sum += S.total[(size_t)(b0 + k) << S.cs];
+    if (REGS) {
+#pragma unroll
+        for (unsigned k = 0; k < 8; ++k) sum += cnt[k];
+    } else {
+        for (unsigned k = 0; k < bpt; ++k) sum += count(k);
+    }
     unsigned total;
-    unsigned run = excl_scan256(sum, sh, total);
+    const unsigned first = excl_scan256(sum, sh, total);
     // the buckets that hold a hot row (many entries: a long tail of `apply` when they start late) are dispatched first
     const unsigned heavy_min = 2u * (total >> S.nb_log2) + 64u;
     unsigned nh = 0;
-    for (unsigned k = 0; k < bpt; ++k) {
-        const unsigned tb = S.total[(size_t)(b0 + k) << S.cs];
-        S.offs[b0 + k] = run;
-        run += tb;
-        nh += tb >= heavy_min;
+    if (REGS) {
+#pragma unroll
+        for (unsigned k = 0; k < 8; ++k) nh += (k < bpt && cnt[k] >= heavy_min) ? 1u : 0u;
+    } else {
+        for (unsigned k = 0; k < bpt; ++k) nh += count(k) >= heavy_min;
     }
-    run -= sum;
     unsigned n_heavy;
     unsigned hrun = excl_scan256(nh, sh, n_heavy);
-    for (unsigned k = 0; k < bpt; ++k) {
-        const unsigned b = b0 + k, tb = S.total[(size_t)b << S.cs];
+    unsigned run = first;
+    auto emit = [&](unsigned k, unsigned tb) {
+        const unsigned b = b0 + k;
+        S.offs[b] = run;
         const uint4 rec = make_uint4(b, run, tb, 0u);
         run += tb;
         if (tb >= heavy_min) S.sched[hrun++] = rec;
         else S.sched[n_heavy + b - hrun] = rec;               // (b - hrun = the light buckets before b)
+    };
+    if (REGS) {
+#pragma unroll
+        for (unsigned k = 0; k < 8; ++k)
+            if (k < bpt) emit(k, cnt[k]);
+    } else {
+        for (unsigned k = 0; k < bpt; ++k) emit(k, count(k));
     }
+}
+__device__ __forceinline__ void scan_block(const Scan& S, unsigned* sh) {
+    if (S.nb_log2 <= 11) scan_block_impl<true>(S, sh);        // (workgroup-uniform)
+    else scan_block_impl<false>(S, sh);
 }
 
 }  // namespace recalgo_plan

@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -507,6 +508,257 @@ int next_record(Reader& r, Span& out) {
     }
 }
 
+
+// =====================================================================================================
+// Asynchronous batch pipeline: TFRecordDataset(file)[.shuffle].repeat().batch(B).map(parse).prefetch(depth) as ONE object.
+// A producer thread frames (and shuffles) the records of batch after batch into a ring of `depth` slots; every slot's
+// decode is cut into chunks of kPipeChunk records that a set of worker threads take from one queue — chunks of SEVERAL
+// batches are in the queue together, so the workers never idle at a batch boundary (the synchronous accessors above
+// fork and join the pool once or twice per batch, and the consumer's own work sits between two batches).  One pass over
+// a record's wire bytes serves every requested feature: single-valued string ids (vocabulary lookups prefetched in
+// groups, as recalgo_reader_id_matrix does) and fixed-length float features (FixedLenFeature((n,), float32, default)).
+// =====================================================================================================
+constexpr size_t kPipeChunk = 64;
+
+struct PipeFloat {
+    std::string key;
+    int n;
+    float def;
+    bool has_def;
+    size_t off;                                            // first column in a row of the float matrix
+};
+
+struct PipeSlot {
+    std::vector<Span> recs;
+    int64_t* ids = nullptr;                                // [B][F]
+    float* floats = nullptr;                               // [B][NF]
+    std::vector<int64_t> own_ids;
+    std::vector<float> own_floats;
+    int state = 0;                                         // 0 free, 1 decoding, 2 ready, 3 end of data, 4 error
+    size_t pending = 0;                                    // chunks not yet decoded (guarded by Pipeline::m)
+    bool multi = false;
+    bool missing = false;                                  // the error is a required feature without a value (not bad bytes)
+    std::string error;
+};
+
+struct Pipeline {
+    Reader* r = nullptr;
+    size_t B = 0, F = 0, NF = 0, depth = 0;
+    std::vector<std::string> keys;                         // id columns
+    std::vector<const Vocab*> vocabs;
+    std::vector<PipeFloat> floats;
+    std::vector<std::string_view> names;                   // ids then floats: the requested feature names
+    std::vector<int> ntab;                                 // name -> index into `names` (open addressing)
+    size_t tcap = 16;
+    std::vector<PipeSlot> slots;
+    std::mutex m;
+    std::condition_variable cv_free, cv_ready, cv_task;
+    std::deque<std::pair<size_t, size_t>> tasks;           // (slot, chunk)
+    std::thread producer;
+    std::vector<std::thread> workers;
+    bool stop = false;
+    uint64_t next_out = 0;                                 // sequence number of the batch the consumer takes next
+    std::string error;
+
+    int lookup(std::string_view name) const {
+        size_t t = name_hash(name) & (tcap - 1);
+        while (ntab[t] >= 0 && names[(size_t)ntab[t]] != name) t = (t + 1) & (tcap - 1);
+        return ntab[t];
+    }
+
+    // records [i0, i1) of a slot: every requested feature from one pass over the wire bytes
+    void decode_chunk(PipeSlot& S, size_t i0, size_t i1) {
+        constexpr size_t kGroup = 8;                       // records whose vocabulary probes are in flight together
+        struct Pending {
+            const char* p;
+            uint32_t len;
+            uint32_t col;
+            uint64_t h;
+            const Vocab* vm;
+        };
+        std::vector<Pending> pend;
+        pend.reserve(kGroup * F);
+        std::vector<int> slot_of(F);
+        std::vector<char> got(floats.size());
+        std::vector<int> order;                            // feature index of the j-th map entry of the previous record
+        auto resolve = [&]() {
+            for (auto& q : pend)
+                if (q.vm) S.ids[q.col] = q.vm->find_hashed(std::string_view(q.p, q.len), q.h);
+            pend.clear();
+        };
+        bool bad = false, multi = false;
+        std::string missing;
+        for (size_t i = i0; i < i1; ++i) {
+            for (size_t f = 0; f < F; ++f) {
+                S.ids[i * F + f] = -1;
+                slot_of[f] = -1;
+            }
+            std::fill(got.begin(), got.end(), 0);
+            size_t j = 0;
+            bool ok = true, inner = true;
+            ok = for_fields(S.recs[i], [&](uint32_t field, uint32_t wt, Span features, uint64_t) {
+                if (field != 1 || wt != 2) return;
+                inner = for_fields(features, [&](uint32_t f2, uint32_t w2, Span entry, uint64_t) {
+                    if (f2 != 1 || w2 != 2) return;
+                    std::string_view name;
+                    Span feat;
+                    for_fields(entry, [&](uint32_t f3, uint32_t w3, Span pl, uint64_t) {
+                        if (w3 != 2) return;
+                        if (f3 == 1) name = std::string_view((const char*)pl.p, pl.n);
+                        else if (f3 == 2) feat = pl;
+                    });
+                    const size_t pos = j++;
+                    int col;
+                    if (pos < order.size() && order[pos] >= 0 && names[(size_t)order[pos]] == name) col = order[pos];
+                    else {
+                        col = lookup(name);
+                        if (pos >= order.size()) order.resize(pos + 1, -1);
+                        order[pos] = col;
+                    }
+                    if (col < 0) return;
+                    if ((size_t)col >= F) {                // a float feature (a repeated map key: the last entry wins)
+                        const PipeFloat& pf = floats[(size_t)col - F];
+                        float* o = S.floats + i * NF + pf.off;
+                        int filled = 0;
+                        for_fields(feat, [&](uint32_t f4, uint32_t w4, Span list, uint64_t) {
+                            if (f4 != 2 || w4 != 2) return;                       // FloatList
+                            for_fields(list, [&](uint32_t f5, uint32_t w5, Span pl, uint64_t) {
+                                if (f5 != 1) return;
+                                if (w5 == 2) {
+                                    for (size_t b = 0; b + 4 <= pl.n && filled < pf.n; b += 4) memcpy(&o[filled++], pl.p + b, 4);
+                                } else if (w5 == 5 && filled < pf.n) {
+                                    memcpy(&o[filled++], pl.p, 4);
+                                }
+                            });
+                        });
+                        got[(size_t)col - F] = filled >= pf.n ? 1 : (filled == 0 ? 0 : 2);
+                        return;
+                    }
+                    const size_t f = (size_t)col;
+                    int n = 0;
+                    Span first;
+                    for_fields(feat, [&](uint32_t f4, uint32_t w4, Span list, uint64_t) {
+                        if (f4 != 1 || w4 != 2) return;                           // BytesList
+                        for_fields(list, [&](uint32_t f5, uint32_t w5, Span pl, uint64_t) {
+                            if (f5 != 1 || w5 != 2) return;
+                            if (n++ == 0) first = pl;
+                        });
+                    });
+                    if (n > 1) multi = true;
+                    if (n == 0) {
+                        if (slot_of[f] >= 0) pend[(size_t)slot_of[f]].vm = nullptr;
+                        slot_of[f] = -1;
+                        S.ids[i * F + f] = -1;
+                        return;
+                    }
+                    const Vocab* vm = vocabs[f];
+                    Pending q{(const char*)first.p, (uint32_t)first.n, (uint32_t)(i * F + f),
+                              Vocab::hash_of((const char*)first.p, first.n), vm};
+                    if (!vm->slots.empty()) __builtin_prefetch(&vm->slots[q.h & vm->mask]);
+                    if (slot_of[f] >= 0) pend[(size_t)slot_of[f]] = q;
+                    else {
+                        slot_of[f] = (int)pend.size();
+                        pend.push_back(q);
+                    }
+                }) && inner;
+            });
+            if (!ok || !inner) bad = true;
+            for (size_t k = 0; k < floats.size(); ++k) {
+                if (got[k] == 1) continue;
+                const PipeFloat& pf = floats[k];
+                if (got[k] == 0 && pf.has_def) {
+                    for (int c = 0; c < pf.n; ++c) S.floats[i * NF + pf.off + (size_t)c] = pf.def;
+                } else if (missing.empty()) {
+                    missing = "feature " + pf.key + " is required but missing in a record";
+                }
+            }
+            if ((i + 1 - i0) % kGroup == 0) resolve();
+        }
+        resolve();
+        if (bad || multi || !missing.empty()) {
+            std::lock_guard<std::mutex> lk(m);
+            if (multi) S.multi = true;
+            if (bad && S.error.empty()) S.error = "malformed Example in a record";
+            if (!missing.empty() && S.error.empty()) { S.error = missing; S.missing = true; }
+        }
+    }
+
+    void work_loop() {
+        for (;;) {
+            std::pair<size_t, size_t> t;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_task.wait(lk, [&] { return stop || !tasks.empty(); });
+                if (stop) return;
+                t = tasks.front();
+                tasks.pop_front();
+            }
+            PipeSlot& S = slots[t.first];
+            decode_chunk(S, t.second * kPipeChunk, std::min(S.recs.size(), (t.second + 1) * kPipeChunk));
+            std::lock_guard<std::mutex> lk(m);
+            if (--S.pending == 0) {
+                S.state = S.error.empty() ? 2 : 4;
+                cv_ready.notify_all();
+            }
+        }
+    }
+
+    void produce_loop() {
+        for (uint64_t seq = 0;; ++seq) {
+            PipeSlot& S = slots[seq % depth];
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_free.wait(lk, [&] { return stop || S.state == 0; });
+                if (stop) return;
+            }
+            // (only this thread touches the reader and a free slot's record list)
+            S.recs.clear();
+            S.error.clear();
+            S.multi = S.missing = false;
+            int rc = 1;
+            for (size_t i = 0; i < B; ++i) {
+                Span rec;
+                rc = next_record(*r, rec);
+                if (rc <= 0) break;
+                S.recs.push_back(rec);
+            }
+            std::lock_guard<std::mutex> lk(m);
+            if (rc < 0) {
+                S.error = r->error;
+                S.state = 4;
+                cv_ready.notify_all();
+                return;
+            }
+            if (S.recs.empty()) {
+                S.state = 3;
+                cv_ready.notify_all();
+                return;
+            }
+            const size_t chunks = (S.recs.size() + kPipeChunk - 1) / kPipeChunk;
+            S.pending = chunks;
+            S.state = 1;
+            for (size_t c = 0; c < chunks; ++c) tasks.emplace_back((size_t)(seq % depth), c);
+            cv_task.notify_all();
+            if (rc == 0) {                                 // the data ended inside this batch: the next slot reports the end
+                // (falls through to the next iteration, whose first next_record returns 0 again)
+            }
+        }
+    }
+
+    ~Pipeline() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv_free.notify_all();
+        cv_task.notify_all();
+        cv_ready.notify_all();
+        if (producer.joinable()) producer.join();
+        for (auto& w : workers)
+            if (w.joinable()) w.join();
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -871,6 +1123,123 @@ EXPORT int recalgo_reader_id_matrix(void* reader, int n_keys, const char* const*
     }
     for (size_t f = 0; f < F; ++f) multi[f] = mflag[f].load();
     return 0;
+}
+
+
+// ---- asynchronous batch pipeline (see struct Pipeline) -------------------------------------------------------------
+// Opens `path` and starts decoding ahead.  id_keys[n_ids] / vocabs[n_ids]: single-valued string features -> the int64
+// [B, n_ids] matrix of a slot (column order as given); float_keys[n_floats] with float_n / float_default /
+// float_has_default: FixedLenFeature((n,), float32[, default]) -> the float32 [B, sum n] matrix.  depth >= 2 slots;
+// ids_slots / float_slots: depth caller-owned buffers each (e.g. pinned), or NULL: the pipeline's own.  threads <= 0:
+// RECALGO_READER_THREADS, else half the hardware threads (2 .. 64).  NULL on error.
+EXPORT void* recalgo_pipeline_open(const char* path, int verify_crc, int64_t num_epochs, int64_t shuffle_buffer_size,
+                                   uint64_t seed, int64_t batch_size, int n_ids, const char* const* id_keys,
+                                   const void* const* vocabs, int n_floats, const char* const* float_keys,
+                                   const int32_t* float_n, const float* float_default, const int32_t* float_has_default,
+                                   int depth, int64_t* const* ids_slots, float* const* float_slots, int threads) {
+    if (!path || batch_size < 1 || n_ids < 0 || n_floats < 0 || depth < 2 || depth > 64) return nullptr;
+    if ((n_ids > 0 && (!id_keys || !vocabs)) || (n_floats > 0 && (!float_keys || !float_n || !float_default || !float_has_default)))
+        return nullptr;
+    void* rh = recalgo_reader_open(path, verify_crc);
+    if (!rh) return nullptr;
+    recalgo_reader_configure(rh, num_epochs, shuffle_buffer_size, seed);
+    auto* P = new Pipeline();
+    P->r = (Reader*)rh;
+    P->B = (size_t)batch_size;
+    P->F = (size_t)n_ids;
+    P->depth = (size_t)depth;
+    for (int f = 0; f < n_ids; ++f) {
+        P->keys.emplace_back(id_keys[f]);
+        P->vocabs.push_back((const Vocab*)vocabs[f]);
+    }
+    size_t off = 0;
+    for (int k = 0; k < n_floats; ++k) {
+        if (float_n[k] < 1) { delete P; recalgo_reader_close(rh); return nullptr; }
+        P->floats.push_back(PipeFloat{float_keys[k], float_n[k], float_default[k], float_has_default[k] != 0, off});
+        off += (size_t)float_n[k];
+    }
+    P->NF = off;
+    for (auto& k : P->keys) P->names.emplace_back(k);
+    for (auto& pf : P->floats) P->names.emplace_back(pf.key);
+    while (P->tcap < 4 * P->names.size() + 4) P->tcap <<= 1;
+    P->ntab.assign(P->tcap, -1);
+    for (size_t f = 0; f < P->names.size(); ++f) {           // a name given twice maps to its first entry
+        size_t i = name_hash(P->names[f]) & (P->tcap - 1);
+        while (P->ntab[i] >= 0 && P->names[(size_t)P->ntab[i]] != P->names[f]) i = (i + 1) & (P->tcap - 1);
+        if (P->ntab[i] < 0) P->ntab[i] = (int)f;
+    }
+    P->slots.resize(P->depth);
+    for (size_t d = 0; d < P->depth; ++d) {
+        PipeSlot& S = P->slots[d];
+        if (ids_slots && ids_slots[d]) S.ids = ids_slots[d];
+        else {
+            S.own_ids.resize(P->B * std::max<size_t>(P->F, 1));
+            S.ids = S.own_ids.data();
+        }
+        if (float_slots && float_slots[d]) S.floats = float_slots[d];
+        else {
+            S.own_floats.resize(P->B * std::max<size_t>(P->NF, 1));
+            S.floats = S.own_floats.data();
+        }
+    }
+    size_t n = 0;
+    if (threads > 0) n = (size_t)threads;
+    else if (const char* e = std::getenv("RECALGO_READER_THREADS")) {
+        long v = std::atol(e);
+        if (v >= 1 && v <= 256) n = (size_t)v;
+    }
+    if (n == 0) {
+        n = std::thread::hardware_concurrency() / 2;
+        n = n < 2 ? 2 : (n > 64 ? 64 : n);
+    }
+    for (size_t i = 0; i < n; ++i) P->workers.emplace_back([P] { P->work_loop(); });
+    P->producer = std::thread([P] { P->produce_loop(); });
+    return P;
+}
+
+// Waits for the next batch (in order).  Returns its number of records (> 0) with *slot = the ring slot holding it
+// (ids at ids_slots[slot] / recalgo_pipeline_ids, floats likewise) — valid until recalgo_pipeline_release(slot);
+// 0 at the end of the data; -1 on a framing error or a malformed Example, -3 when a required float feature is missing
+// (recalgo_pipeline_error says which); -2 when some id feature holds more than one value in a record (not a single-valued
+// feature: decode it with the synchronous reader instead).
+EXPORT int64_t recalgo_pipeline_next(void* pipeline, int* slot) {
+    auto* P = (Pipeline*)pipeline;
+    const size_t d = (size_t)(P->next_out % P->depth);
+    PipeSlot& S = P->slots[d];
+    std::unique_lock<std::mutex> lk(P->m);
+    P->cv_ready.wait(lk, [&] { return S.state >= 2; });
+    if (S.state == 3) return 0;
+    if (S.state == 4) {
+        P->error = S.error;
+        return S.missing ? -3 : -1;
+    }
+    if (S.multi) return -2;
+    ++P->next_out;
+    if (slot) *slot = (int)d;
+    return (int64_t)S.recs.size();
+}
+
+EXPORT void recalgo_pipeline_release(void* pipeline, int slot) {
+    auto* P = (Pipeline*)pipeline;
+    if (slot < 0 || (size_t)slot >= P->depth) return;
+    {
+        std::lock_guard<std::mutex> lk(P->m);
+        if (P->slots[(size_t)slot].state == 2) P->slots[(size_t)slot].state = 0;
+    }
+    P->cv_free.notify_all();
+}
+
+EXPORT const int64_t* recalgo_pipeline_ids(void* pipeline, int slot) { return ((Pipeline*)pipeline)->slots[(size_t)slot].ids; }
+EXPORT const float* recalgo_pipeline_floats(void* pipeline, int slot) { return ((Pipeline*)pipeline)->slots[(size_t)slot].floats; }
+EXPORT const char* recalgo_pipeline_error(void* pipeline) { return ((Pipeline*)pipeline)->error.c_str(); }
+EXPORT int recalgo_pipeline_threads(void* pipeline) { return (int)((Pipeline*)pipeline)->workers.size(); }
+
+EXPORT void recalgo_pipeline_close(void* pipeline) {
+    auto* P = (Pipeline*)pipeline;
+    if (!P) return;
+    Reader* r = P->r;
+    delete P;                                                // (joins the threads)
+    recalgo_reader_close(r);
 }
 
 }  // extern "C"

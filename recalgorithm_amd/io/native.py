@@ -33,6 +33,15 @@ SIGNATURES = {
     "recalgo_reader_float_feature": (c_int, [c_void_p, c_char_p, c_int, c_float, c_int, c_void_p]),
     "recalgo_reader_id_feature": (c_int64, [c_void_p, c_char_p, c_void_p, c_void_p, c_void_p, c_int64]),
     "recalgo_reader_id_matrix": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "recalgo_pipeline_open": (c_void_p, [c_char_p, c_int, c_int64, c_int64, c_uint64, c_int64, c_int, c_void_p, c_void_p, c_int,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int]),
+    "recalgo_pipeline_next": (c_int64, [c_void_p, c_void_p]),
+    "recalgo_pipeline_release": (None, [c_void_p, c_int]),
+    "recalgo_pipeline_ids": (c_void_p, [c_void_p, c_int]),
+    "recalgo_pipeline_floats": (c_void_p, [c_void_p, c_int]),
+    "recalgo_pipeline_error": (c_char_p, [c_void_p]),
+    "recalgo_pipeline_threads": (c_int, [c_void_p]),
+    "recalgo_pipeline_close": (None, [c_void_p]),
 }
 
 _lib = None
@@ -95,6 +104,10 @@ class PackedBatch(dict):
     packed_ids = None
 
 
+class _NotSingleValued(ValueError):
+    """a column declared single-valued holds several values in some record"""
+
+
 class NativeDataset:
     """TFRecordDataset(filepath)[.shuffle(buf)].repeat(epochs).batch(bs).map(parse) with the record
     framing, Example decoding and vocabulary lookup done in C++."""
@@ -124,7 +137,91 @@ class NativeDataset:
             else:
                 raise TypeError(base)
 
+    # -- the asynchronous pipeline (recalgo_pipeline_*): every categorical column single-valued, numeric columns of fixed length --
+    PIPELINE_DEPTH = 4
+
+    def _pipeline_columns(self):
+        """-> (id columns in sorted key order, numeric columns) when the asynchronous pipeline can serve this dataset, else None"""
+        if os.environ.get("RECALGO_READER_PIPELINE", "1") == "0":
+            return None
+        if any(c.is_sequence or c.key in self._multi for c in self.categorical):
+            return None
+        if any(c.default_value is not None and not np.isscalar(c.default_value) for c in self.numeric):
+            return None
+        return sorted(self.categorical, key=lambda c: c.key), list(self.numeric)
+
+    def _iter_pipeline(self, flat, numeric):
+        """Batches from the ring of the C++ pipeline: decoded ahead of the consumer by its own threads; what is handed out is a
+        copy of the slot (the slot goes back to the producer at once), so a batch stays valid for as long as it is referenced."""
+        lib = load()
+        vocabs = [Vocabulary.get(c.vocabulary_file) for c in flat]
+        F, NF = len(flat), sum(int(np.prod(c.shape)) for c in numeric)
+        keys = (ctypes.c_char_p * max(F, 1))(*[c.key.encode() for c in flat])
+        vh = (c_void_p * max(F, 1))(*[v.h for v in vocabs])
+        fkeys = (ctypes.c_char_p * max(len(numeric), 1))(*[c.key.encode() for c in numeric])
+        fn = (ctypes.c_int32 * max(len(numeric), 1))(*[int(np.prod(c.shape)) for c in numeric])
+        fdef = (ctypes.c_float * max(len(numeric), 1))(*[float(c.default_value or 0.0) for c in numeric])
+        fhas = (ctypes.c_int32 * max(len(numeric), 1))(*[int(c.default_value is not None) for c in numeric])
+        h = lib.recalgo_pipeline_open(self.filepath.encode(), int(self.verify), self.epochs, self.shuffle, self.seed, self.bs, F,
+                                      keys, vh, len(numeric), fkeys, fn, fdef, fhas, self.PIPELINE_DEPTH, None, None, 0)
+        if not h:
+            raise IOError(f"cannot open {self.filepath}")
+        try:
+            slot = ctypes.c_int(0)
+            id_keys = [c.key for c in flat]
+            while True:
+                B = int(lib.recalgo_pipeline_next(h, ctypes.byref(slot)))
+                if B == 0:
+                    return
+                if B == -2:
+                    raise _NotSingleValued()
+                if B == -3:
+                    raise ValueError(lib.recalgo_pipeline_error(h).decode())
+                if B < 0:
+                    raise IOError(f"{self.filepath}: {lib.recalgo_pipeline_error(h).decode()}")
+                feats: Dict[str, object] = PackedBatch()
+                if F:
+                    src = (ctypes.c_int64 * (B * F)).from_address(lib.recalgo_pipeline_ids(h, slot.value))
+                    tmat = torch.from_numpy(np.frombuffer(src, dtype=np.int64).reshape(B, F).copy())
+                    for j, k in enumerate(id_keys):
+                        feats[k] = tmat[:, j]
+                    feats.packed_ids = (tmat, id_keys)
+                if NF:
+                    srcf = (ctypes.c_float * (B * NF)).from_address(lib.recalgo_pipeline_floats(h, slot.value))
+                    fmat = torch.from_numpy(np.frombuffer(srcf, dtype=np.float32).reshape(B, NF).copy())
+                    off = 0
+                    for c in numeric:
+                        n = int(np.prod(c.shape))
+                        feats[c.key] = fmat[:, off:off + n].reshape((B,) + tuple(c.shape))
+                        off += n
+                lib.recalgo_pipeline_release(h, slot.value)
+                labels = {k: feats.pop(k) for k in self.label_keys}
+                if feats.packed_ids is not None and any(k in self.label_keys for k in feats.packed_ids[1]):
+                    feats.packed_ids = None
+                yield feats, labels
+        finally:
+            lib.recalgo_pipeline_close(h)
+
     def __iter__(self):
+        cols = self._pipeline_columns()
+        if cols is not None:
+            # (a file whose "single-valued" columns turn out to hold several values per record is found out by the first batch
+            # that has one — before anything of it was handed out when it is the first batch, which is where a dataset's layout
+            # shows; later on the error is raised: the batches already consumed cannot be replayed in a shuffled stream)
+            it = self._iter_pipeline(*cols)
+            try:
+                first = next(it)
+            except StopIteration:
+                return
+            except _NotSingleValued:
+                it = None
+            if it is not None:
+                yield first
+                yield from it
+                return
+        yield from self._iter_sync()
+
+    def _iter_sync(self):
         from ..feature_column import Ragged
         lib = load()
         h = lib.recalgo_reader_open(self.filepath.encode(), int(self.verify))

@@ -53,8 +53,11 @@ def main():
     # reader alone (decode + vocabulary lookup, no device work)
     list(eval_input_fn(path, parser, a.batch))                                          # page cache + vocabularies warm
     t0 = time.perf_counter()
-    n = sum(l["read_comment"].shape[0] for _, l in eval_input_fn(path, parser, a.batch))
+    n = sum(l["read_comment"].shape[0] for _, l in train_input_fn(path, parser, a.batch, 4, 0))
     reader_rate = n / (time.perf_counter() - t0)
+    from recalgorithm_amd.io import native
+    e = os.environ.get("RECALGO_READER_THREADS")
+    reader_threads = int(e) if e else max(2, min(64, (os.cpu_count() or 2) // 2))       # (recalgo_pipeline_open's default)
     # the training loop of Estimator.train, spelled out so that only the steady state is timed (opening the dataset loads
     # 26 vocabulary files; the first steps build the model and capture the graph)
     from recalgorithm_amd.estimator import GraphedTrainStep
@@ -80,7 +83,10 @@ def main():
         "metric": "CTR examples/sec from TFRecord bytes (string keys) to the training step, DCN, batch %d" % a.batch,
         "value": round(steps * a.batch / dt, 1), "unit": "examples/s", "steps": steps,
         "ms_per_step": round(dt / max(steps, 1) * 1e3, 3), "reader_only_examples_per_s": round(reader_rate, 1),
-        "host_threads": os.cpu_count(), "examples": a.examples, "epochs": a.epochs, "shuffle_buffer": 10000,
+        "host": {"cores": os.cpu_count(), "reader_threads": reader_threads, "reader_ex_s": round(reader_rate, 1),
+                 "reader": "asynchronous pipeline (recalgo_pipeline_*)" if os.environ.get("RECALGO_READER_PIPELINE", "1") != "0"
+                 else "synchronous accessors"},
+        "examples": a.examples, "epochs": a.epochs, "shuffle_buffer": 10000,
         "synthetic_write_seconds": round(t_write, 1),
         "note": "steady state (dataset opened, model built, graph captured before the clock starts); host-bound: the GPU "
                 "step of this model takes ~0.24 ms (bench.py), the rest is decode + pack + copy on the host"}), flush=True)

@@ -319,3 +319,41 @@ def test_id_matrix_map_semantics_on_hand_encoded_records(tmp_path):
     # a required float feature missing in a record is an error, not a silent zero
     assert lib.recalgo_reader_float_feature(rd, b"y", 1, ctypes.c_float(0.0), 0, yv.ctypes.data_as(ctypes.c_void_p)) == -1
     lib.recalgo_reader_close(rd)
+
+
+def test_pipeline_batches_equal_the_synchronous_reader(tmp_path, monkeypatch):
+    """recalgo_pipeline_* (producer + worker threads decoding several batches ahead) hands out exactly the batches of the
+    synchronous accessors: same shuffle / repeat order (same seeded stream), same ids, floats and defaults, the last partial
+    batch, and the Python parser's values."""
+    spec = synth.SynthSpec(n_fields=7, max_vocab=400, seed=11, oov_frac=0.1, with_dense=True)
+    vocab_dir = str(tmp_path / "vocabulary") + "/"
+    synth.write_vocabularies(spec, vocab_dir)
+    path = str(tmp_path / "single.tfrecord")
+    synth.write_tfrecord(spec, path, 333, chunk=64)
+    from recalgorithm_amd.algorithm._common import DENSE_FEATURES
+    cols = [fc.numeric_column(k, default_value=0.0) for k in DENSE_FEATURES]
+    cols += [fc.embedding_column(fc.categorical_column_with_vocabulary_file(nm, vocab_dir + nm + ".txt"), 8) for nm in spec.names]
+    cols += [fc.numeric_column("never_written", default_value=2.5)]
+    labels = [fc.numeric_column("read_comment", default_value=0.0)]
+
+    def batches(pipeline, **kw):
+        monkeypatch.setenv("RECALGO_READER_PIPELINE", "1" if pipeline else "0")
+        ds = native.NativeDataset(path, cols + labels, ["read_comment"], 50, seed=5, **kw)
+        assert (ds._pipeline_columns() is not None) == pipeline
+        return list(ds)
+
+    for kw in (dict(num_epochs=1), dict(num_epochs=3, shuffle_buffer_size=40)):
+        a, b = batches(True, **kw), batches(False, **kw)
+        assert len(a) == len(b) and [l["read_comment"].shape[0] for _, l in a] == [l["read_comment"].shape[0] for _, l in b]
+        for (fa, la), (fb, lb) in zip(a, b):
+            assert set(fa) == set(fb)
+            for k in fa:
+                assert fa[k].dtype == fb[k].dtype and fa[k].shape == fb[k].shape and torch.equal(fa[k], fb[k]), k
+            assert torch.equal(la["read_comment"], lb["read_comment"])
+            assert fa.packed_ids is not None and fa.packed_ids[1] == fb.packed_ids[1] and torch.equal(fa.packed_ids[0], fb.packed_ids[0])
+            assert float(fa["never_written"].min()) == 2.5 == float(fa["never_written"].max())
+    # an iterator dropped half way joins its threads (no hang, no leak of the handle)
+    it = iter(native.NativeDataset(path, cols + labels, ["read_comment"], 50, num_epochs=None))
+    for _ in range(3):
+        next(it)
+    it.close()

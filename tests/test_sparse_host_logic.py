@@ -41,6 +41,10 @@ class _FakeLib:
                                      "sources": [(arr[i].n_ex, arr[i].F, bool(arr[i].g)) for i in range(n)]}))
         return 0
 
+    def recalgo_scatter_plan_scan(self, ws, cap, nb, out):
+        self.calls.append(("plan_scan", {"cap": int(cap), "nb": int(nb)}))
+        return 0
+
     def recalgo_adam_deferred_sweep(self, d, K, r0, r1, step, off, stream):
         self.calls.append(("sweep", {"K": K, "rows": (int(r0), int(r1))}))
         return 0
@@ -261,3 +265,36 @@ def test_scatter_mode_knob(monkeypatch):
     monkeypatch.setenv("RECALGO_ADAM_SWEEP_PERIOD", "0")
     with pytest.raises(ValueError):
         sparse.sweep_period()
+
+
+def test_the_plan_prefix_scan_rides_on_the_optimizer_launch_only_when_the_counts_are_those_of_the_applied_sources(lib):
+    """sparse.plan_scan_record hands the optimizer launch a record (and `apply` then runs RECALGO_SCATTER_PRESCANNED) exactly
+    when the workspace's bucket totals are those of the sources `apply` will place; whenever `apply` has to count again (first
+    step: the workspace grew; a lookup without a gradient) there is no record and `place` scans the counters itself."""
+    E, st = _arena(100, 16, "e"), _Store()
+    st.arenas["e"] = E
+
+    def step(with_record=True, drop_second_grad=False):
+        s1 = sparse.begin_lookup(E, st, _ids(300, 5), None, None, 0, 300, 5, True)
+        s2 = sparse.begin_lookup(E, st, _ids(40, 1), None, None, 0, 40, 1, True)
+        s1.set_grad(torch.zeros(300, 5 * 16))
+        if not drop_second_grad:
+            s2.set_grad(torch.zeros(40, 16))
+        st.opt_state["step"] += 1
+        rec = sparse.plan_scan_record(E, False) if with_record else None
+        sparse.apply(E, False, st.opt_state["step"], 0.01, 0.9, 0.999, 1e-8)
+        return rec
+
+    assert step() is None                                   # first step: the second lookup re-sized the workspace -> recount
+    assert lib.calls[-1][0] == "apply" and lib.calls[-1][1]["mode"] == sparse.MODE_ADAM
+    n0 = len(lib.calls)
+    assert step() is not None                               # steady state: counted == the applied sources
+    assert [c[0] for c in lib.calls[n0:]] == ["prepare", "prepare", "plan_scan", "apply"]
+    assert lib.calls[-1][1]["mode"] == sparse.MODE_ADAM | sparse.MODE_PRESCANNED
+    step(with_record=False)                                 # an optimizer path without the fused launch: no flag
+    assert lib.calls[-1][1]["mode"] == sparse.MODE_ADAM
+    n0 = len(lib.calls)
+    assert step(drop_second_grad=True) is None              # counted two lookups, one is applied: `apply` counts again
+    assert lib.calls[-1][1]["mode"] == sparse.MODE_ADAM and lib.calls[-1][1]["n_sources"] == 1
+    assert step() is not None                               # ... and the step after is prescanned again
+    assert lib.calls[-1][1]["mode"] == sparse.MODE_ADAM | sparse.MODE_PRESCANNED
