@@ -63,7 +63,7 @@ int recalgo_reader_id_matrix(void* reader, int n_keys, const char* const* keys, 
  * order as given, -1 = missing / not in the vocabulary); float_keys[n_floats] with float_n / float_default /
  * float_has_default: FixedLenFeature((n,), float32[, default]) -> float32 [B, sum n].  ids_slots / float_slots: `depth`
  * caller-owned buffers each (e.g. page-locked), or NULL for the pipeline's own.  threads <= 0: RECALGO_READER_THREADS, else half
- * the hardware threads (2 .. 64).  NULL on error. */
+ * the hardware threads (2 .. 32).  NULL on error. */
 void* recalgo_pipeline_open(const char* path, int verify_crc, int64_t num_epochs, int64_t shuffle_buffer_size, uint64_t seed,
                             int64_t batch_size, int n_ids, const char* const* id_keys, const void* const* vocabs,
                             int n_floats, const char* const* float_keys, const int32_t* float_n, const float* float_default,

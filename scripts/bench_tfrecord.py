@@ -57,7 +57,7 @@ def main():
     reader_rate = n / (time.perf_counter() - t0)
     from recalgorithm_amd.io import native
     e = os.environ.get("RECALGO_READER_THREADS")
-    reader_threads = int(e) if e else max(2, min(64, (os.cpu_count() or 2) // 2))       # (recalgo_pipeline_open's default)
+    reader_threads = int(e) if e else max(2, min(32, (os.cpu_count() or 2) // 2))       # (recalgo_pipeline_open's default)
     # the training loop of Estimator.train, spelled out so that only the steady state is timed (opening the dataset loads
     # 26 vocabulary files; the first steps build the model and capture the graph)
     from recalgorithm_amd.estimator import GraphedTrainStep

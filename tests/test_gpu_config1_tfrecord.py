@@ -84,3 +84,73 @@ def test_deepfm_from_tfrecord_batch512(dev, tmp_path):
     dumped = dict(np.load(os.path.join(export_dir, "variables.npz")))
     assert "fm_first_order/fm_first_order_dense/kernel" in dumped
     assert dumped["fm_first_order/fm_first_order_dense/kernel"].shape == (sum(spec.vocabs), 1)
+
+
+@pytest.mark.gpu
+def test_reader_batch_reaches_the_device_as_one_allocation(dev):
+    """A batch of the native reader (io/native.py PackedBatch: the features are the columns of ONE [B, F] id matrix) with
+    [B, 1] labels goes to the device in one staged copy and arrives as views of one allocation — id matrix first, labels
+    behind it — with the values unchanged; anything else takes the general path."""
+    from recalgorithm_amd.io.native import PackedBatch
+    est = Estimator(deepfm_model_fn, {}, RunConfig(device="cuda"))
+    B, F = 300, 5
+    mat = torch.randint(-1, 1000, (B, F), dtype=torch.int64)
+    keys = [f"c{j}" for j in range(F)]
+    feats = PackedBatch({k: mat[:, j] for j, k in enumerate(keys)})
+    feats.packed_ids = (mat, keys)
+    labels = {"read_comment": torch.rand(B, 1), "like": torch.rand(B, 1)}
+    f, l = est._to_device(feats, labels)
+    torch.cuda.synchronize()
+    assert all(f[k].is_cuda and torch.equal(f[k].cpu(), mat[:, j]) for j, k in enumerate(keys))
+    assert all(l[k].is_cuda and l[k].shape == (B, 1) and torch.equal(l[k].cpu(), labels[k]) for k in labels)
+    ptrs = {t.untyped_storage().data_ptr() for t in list(f.values()) + list(l.values())}
+    assert len(ptrs) == 1
+    assert f[keys[1]].data_ptr() == f[keys[0]].data_ptr() + 8 and l["read_comment"].data_ptr() == f[keys[0]].data_ptr() + B * F * 8
+    # a batch with one more host feature is not that shape: general path, same values
+    feats2 = PackedBatch(dict(feats))
+    feats2["dense0"] = torch.rand(B, 1)
+    feats2.packed_ids = (mat, keys)
+    f2, l2 = est._to_device(feats2, labels)
+    assert torch.equal(f2["c3"].cpu(), mat[:, 3]) and torch.equal(f2["dense0"].cpu(), feats2["dense0"])
+
+
+@pytest.mark.gpu
+def test_captured_step_loads_a_reader_batch_with_one_span_copy(dev):
+    """GraphedTrainStep.load on DeviceBatch inputs (Estimator._to_device_one_copy): the static buffers end up holding exactly
+    the new batch (ids and labels), through the one-span fast path — and a batch of another layout still takes the general one."""
+    from recalgorithm_amd.estimator import GraphedTrainStep
+    from recalgorithm_amd.io.native import PackedBatch
+    est = Estimator(deepfm_model_fn, {}, RunConfig(device="cuda"))
+    B, F = 256, 4
+    keys = [f"c{j}" for j in range(F)]
+
+    def batch(seed):
+        g = torch.Generator().manual_seed(seed)
+        mat = torch.randint(-1, 1000, (B, F), dtype=torch.int64, generator=g)
+        feats = PackedBatch({k: mat[:, j] for j, k in enumerate(keys)})
+        feats.packed_ids = (mat, keys)
+        return mat, feats, {"y": torch.rand(B, 1, generator=g)}
+
+    seen = []
+
+    def step(f, l):
+        seen.append((torch.stack([f[k] for k in keys], 1).clone(), l["y"].clone()))
+        return l["y"].sum()
+
+    m0, f0, l0 = batch(0)
+    g = GraphedTrainStep(step, *est._to_device(f0, l0), warmup=1)
+    assert g._span_plan is not None
+    m1, f1, l1 = batch(1)
+    d1 = est._to_device(f1, l1)
+    g.load(*d1)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.stack([g.static_f[k] for k in keys], 1).cpu(), m1) and torch.equal(g.static_l["y"].cpu(), l1["y"])
+    out = g()
+    torch.cuda.synchronize()
+    assert abs(float(out) - float(l1["y"].sum())) < 1e-3
+    # same values through the general path (plain dicts: no span)
+    m2, f2, l2 = batch(2)
+    d2 = est._to_device(f2, l2)
+    g.load(dict(d2[0]), d2[1])
+    torch.cuda.synchronize()
+    assert torch.equal(torch.stack([g.static_f[k] for k in keys], 1).cpu(), m2) and torch.equal(g.static_l["y"].cpu(), l2["y"])
