@@ -65,6 +65,9 @@ def parse_args(argv=None):
                          "and a forced all-rows-live run; 0 = off")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-fed", action="store_true",
+                    help="skip the `host_fed` leg (TFRecord bytes -> vocabulary ids -> training step, scripts/bench_tfrecord.py on a "
+                         "bounded file: ~25 s)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-extra-models", action="store_true",
@@ -325,11 +328,13 @@ def kernel_rooflines(args, est, feats, device):
             B * (F * 8 + 2 * d * 4))
         ar.grad.zero_()
     else:
-        # owner-computes scatter fused with the optimizer (csrc/sparse.hip): `prepare` (+ catch-up) before the forward
-        # gather, `scan` (+ sweep of 1/P of the arena), `place` (stable multisplit, duplicates of a tile summed) and `apply`
-        # (per-row sums in request order, TF1 Adam on the owned rows) after the backward pass.  Timed on a scratch copy of
-        # the arena's state in the state the timed steps left it in; lr = 0; the step counter does not advance, so the
-        # replay loops of the deferred Adam have nothing to do here (the in-step rocprofv3 averages include them)
+        # owner-computes scatter fused with the optimizer (csrc/sparse.hip), THREE launches per step for a one-lookup model:
+        # `prepare` with the lookup (bucket counts of its requests + catch-up of their lagging rows + this step's share of
+        # the deferred-Adam sweep, one grid), then `place` (entries into their buckets, a tile's duplicates summed) and `apply`
+        # (per-row sums in request order, TF1 Adam on the owned rows) after the backward pass; the prefix of the bucket
+        # counts rides on the optimizer's dense launch.  Timed on a scratch copy of the arena's state in the state the timed
+        # steps left it in; lr = 0; the step counter does not advance, so the replay loops of the deferred Adam have nothing
+        # to do here (the in-step rocprofv3 averages — `in_step`, below — include them)
         import copy
         sc = copy.copy(ar)
         sc.weight, sc.m, sc.v, sc.grad = ar.weight.clone(), ar.m.clone(), ar.v.clone(), ar.grad
@@ -355,15 +360,14 @@ def kernel_rooflines(args, est, feats, device):
         sparse_step()
         n_req = B * F
         rows_sweep = 0 if lazy else -(-ar.weight.shape[0] // sp.sweep_period())
-        tiles = -(-n_req // 256)
-        alg_prep = n_req * 8 + tiles * 1024 * 2                                  # ids + a row of the count matrix per tile
-        alg_apply = tiles * 1024 * (2 + 4) + n_req * (8 + 8 + 8) + n_req * K * 4 + distinct * (6 * K * 4 + 8) + rows_sweep * 4
-        add("sparse_prepare(tile counts; + catch-up launch: none pending in this loop)", prep_only, alg_prep)
+        alg_prep = n_req * 8 + distinct * 4 + rows_sweep * 4                     # ids, a counter word per distinct row, last_step of the sweep share
+        alg_apply = n_req * (8 + 8 + 8) + n_req * K * 4 + distinct * (6 * K * 4 + 8)    # ids + keys out/in, gradient rows, (w, m, v) in/out + last_step
+        add("sparse_prepare(counts + catch-up + sweep share: the lookup's one launch; nothing lags in this loop)", prep_only, alg_prep)
         sc.sparse.counted = None
-        add("sparse_step(prepare + scan/sweep + place + apply: row sums, Adam on owned rows)", sparse_step, alg_prep + alg_apply)
+        add("sparse_step(prepare + place + apply: row sums, Adam on owned rows)", sparse_step, alg_prep + alg_apply)
         res[-1]["distinct_rows"] = distinct
         res[-1]["requests"] = n_req
-        res[-1]["launches"] = 5                  # a SEQUENCE of launches (per-kernel times: profiles/*_kernel_stats.md): never `roofline`
+        res[-1]["launches"] = 3                  # a SEQUENCE of launches (per-kernel times: `in_step`): never `roofline`
         del sc
     if args.model == "dcn":
         L = 3
@@ -402,9 +406,8 @@ def kernel_rooflines(args, est, feats, device):
         add("deepfm_sparse_fwd", lambda: lib.recalgo_deepfm_sparse_fwd(p(ids), p(ar.weight), p(w1.weight), p(bias), p(rb), B, F, K,
                                                                       p(emb), p(fm1), p(fm2), p(fs), st),
             B * (F * 8 + F * K * 4 + F * 4 + F * K * 4 + 8))                       # 3648 B/example
-        add("deepfm_sparse_bwd", lambda: lib.recalgo_deepfm_sparse_bwd(p(ids), p(emb), p(fs), p(g), p(g1), p(g2), p(rb), B, F, K,
-                                                                      p(ar.grad), p(w1.grad), None, None, st),
-            B * (F * K * 4 + 8 + F * K * 4 + F * 8 + F * K * 4 + F * 4))           # 5312 B/example
+        # (backward: the FM second-order gradient g_emb + g_fm2 * (S - e) is formed where `place` / `apply` load the gradient
+        # rows — sparse_step above — and recalgo_deepfm_sparse_bwd is not part of the step)
         ar.grad.zero_(); w1.grad.zero_()
     if args.model == "din":
         T, H = 50, K
@@ -431,8 +434,7 @@ def kernel_rooflines(args, est, feats, device):
         so, sl = torch.empty(B, T, H, device=device), torch.empty(B, dtype=torch.int32, device=device)
         add("sequence_gather_fwd", lambda: lib.recalgo_sequence_gather_fwd(p(vals), p(offs), p(ar.weight), B, T, H, p(so), p(sl), st),
             B * T * (8 + 2 * H * 4))
-        add("sequence_gather_bwd", lambda: lib.recalgo_sequence_gather_bwd(p(vals), p(offs), p(so), B, T, H, p(ar.grad), None, st),
-            B * T * (8 + 2 * H * 4))
+        # (backward: a ragged source of the arena's scatter plan — sparse_step — not recalgo_sequence_gather_bwd)
         ar.grad.zero_()
     if args.model == "fibinet":
         E = torch.randn(B, F, K, device=device)
@@ -561,6 +563,38 @@ def kernel_rooflines(args, est, feats, device):
     return res
 
 
+def in_step_table(model: str):
+    """The captured step as rocprofv3 saw it: every kernel a step dispatches, calls per step and average duration, from the
+    newest committed `profiles/r*_<model>_kernel_stats.md` (scripts/rocpd_stats.py over `rocprofv3 --kernel-trace --stats` of
+    this same command) — the ATen launches that are still in the step included.  None when no profile is committed."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{model}_kernel_stats.md")))
+    if not files:
+        return None
+    rows = []
+    with open(files[-1]) as f:
+        for line in f:
+            m = re.match(r"\| `(.*?)` \| (\d+) \| (\d+) \| (\d+) \|", line)
+            if m is None:
+                if line.startswith("per launch shape"):
+                    break
+                continue
+            rows.append((m.group(1), int(m.group(2)), int(m.group(4))))
+    steps = next((c for n, c, _ in rows if "adam_tf1_step_kernel" in n), 0)
+    if not steps:
+        return None
+
+    def short(n):
+        n = re.sub(r"\(anonymous namespace\)::", "", n)
+        n = re.sub(r"^void ", "", n)
+        return n.split("(")[0][:80]
+    tab = [{"kernel": short(n), "calls_per_step": round(c / steps, 2), "avg_us": round(a / 1e3, 2)} for n, c, a in rows if c >= 0.9 * steps]
+    return {"source": os.path.relpath(files[-1], ROOT), "steps_profiled": steps,
+            "dispatches_per_step": round(sum(t["calls_per_step"] for t in tab), 1),
+            "kernel_us_per_step": round(sum(t["calls_per_step"] * t["avg_us"] for t in tab), 1), "kernels": tab}
+
+
 def live_fraction(est) -> float:
     """Fraction of the embedding parameters whose row a gradient has reached (= what the optimizer walks every step)."""
     from recalgorithm_amd import sparse as sp
@@ -637,6 +671,25 @@ def optimizer_state_sweep(args, r, device, rank, world):
     pts.append({"phase": "every row forced live (TF1 dense Adam semantics over the whole table)", "live_fraction": round(live_fraction(est), 4),
                 "ms_per_step": round(timed(fresh[4:]), 4)})
     return pts
+
+
+def host_fed(args):
+    """`host_fed`: the reference's own entry path (TFRecord file of string-keyed Examples + vocabulary files -> train_input_fn
+    -> captured step) on a bounded synthetic file, as its own process: examples/s end to end, the reader
+    alone, the host it ran on.  Never the headline `value` (whose inputs are resident in HBM)."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "bench_tfrecord.py"), "--examples", "65536", "--epochs", "80",
+           "--batch", str(args.batch), "--fields", str(args.fields), "--max-vocab", str(args.max_vocab)]
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=240)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        return {"value": d["value"], "unit": "examples/s", "ms_per_step": d["ms_per_step"], "steps": d["steps"], "host": d["host"],
+                "sample": f"DCN, {d['examples']} examples x {d['epochs']} epochs, shuffle buffer {d['shuffle_buffer']}, batch {args.batch}; "
+                          "TFRecord bytes (26 string features + label per Example) -> native decode + vocabulary lookup -> one "
+                          "staged host-to-device copy -> hipGraph replay"}
+    except Exception as e:          # never take the headline line down
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def cpu_baseline(args, seconds):
@@ -936,6 +989,11 @@ def main():
             except (OSError, ValueError, KeyError):
                 pass
             out["kernels"] = ks
+            # the step as profiled (isolated HIP-event numbers above are per kernel in a loop of its own; this is the captured
+            # step under rocprofv3: name for name what a step dispatches, ATen launches included)
+            ist = in_step_table(args.model)
+            if ist:
+                out["in_step"] = ist
             # whole-step view (BASELINE.json: "absolute and as fraction of HBM roofline"): the algorithmic
             # bytes of the step's HBM-bound hand-written kernels over the WHOLE step time, library GEMMs
             # and launch gaps included in the denominator
@@ -956,6 +1014,8 @@ def main():
                 except Exception as e:      # never take the headline line down
                     out["models"].append({"model": name, "error": f"{type(e).__name__}: {e}"})
                 torch.cuda.empty_cache()
+        if not args.no_host_fed and world == 1 and args.model == "dcn" and not args.big_table_rows:
+            out["host_fed"] = host_fed(args)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -372,13 +372,18 @@ class GraphedTrainStep:
                 groups.setdefault((spans[i][0], src.untyped_storage().data_ptr()), []).append((i, src.storage_offset() * spans[i][3]))
             else:
                 dst.copy_(src, non_blocking=True)
+        singles = []
         for items in groups.values():
-            # views of one allocation on both sides with the same relative layout: ONE copy of the byte span they cover
+            # views of one allocation on both sides with the same relative layout: ONE copy of the byte span they cover —
+            # provided no OTHER static input lives inside that span (the copy overwrites the gaps between the views too)
             if len(items) > 1:
                 d_lo = min(spans[i][1] for i, _ in items)
                 d_hi = max(spans[i][2] for i, _ in items)
                 s_lo = min(lo for _, lo in items)
-                if d_hi > d_lo and all(spans[i][1] - d_lo == lo - s_lo for i, lo in items):
+                mine = {i for i, _ in items}
+                st_ptr = spans[items[0][0]][0]
+                alone = all(k in mine or sp[0] != st_ptr or sp[2] <= d_lo or sp[1] >= d_hi for k, sp in enumerate(spans))
+                if alone and d_hi > d_lo and all(spans[i][1] - d_lo == lo - s_lo for i, lo in items):
                     d0, s0 = self._static[items[0][0]][1], new[items[0][0]][1]
                     dv = self._dst_views.get((spans[items[0][0]][0], d_lo, d_hi))
                     if dv is None:
@@ -387,8 +392,9 @@ class GraphedTrainStep:
                     sv = torch.empty(0, dtype=torch.uint8, device=s0.device).set_(s0.untyped_storage(), s_lo, (d_hi - d_lo,), (1,))
                     dv.copy_(sv, non_blocking=True)
                     continue
-            for i, _ in items:
-                self._static[i][1].copy_(new[i][1], non_blocking=True)
+            singles.extend(i for i, _ in items)
+        for i in singles:                        # (after every span copy: a per-tensor copy is never overwritten by one)
+            self._static[i][1].copy_(new[i][1], non_blocking=True)
 
     def _static_spans(self):
         """Per static input: (storage pointer, first byte, end byte, element size) — computed once: the per-step path of a
@@ -934,9 +940,18 @@ def restore_checkpoint_state(store: VariableStore, state: dict, device, where: s
             from . import sparse
             sparse.reset(a)          # (deferred-Adam bookkeeping likewise)
     if state.get("opt_step") is not None:
-        store.opt_state = {
-            "step": torch.tensor([state["opt_step"]], dtype=torch.int64, device=device),
-            "lr_t": torch.zeros(1, device=device)}
+        if store.opt_state is not None and store.opt_state["step"].device == torch.device(device):
+            # in place: the captured step, and the arenas' deferred-Adam plans (sparse.sync_arena), hold THIS tensor
+            store.opt_state["step"].fill_(int(state["opt_step"]))
+        else:
+            store.opt_state = {
+                "step": torch.tensor([state["opt_step"]], dtype=torch.int64, device=device),
+                "lr_t": torch.zeros(1, device=device)}
+        from . import sparse
+        for ar in store.arenas.values():       # (a plan made before the restore must not sync against a stale counter)
+            plan = sparse.plan_of(ar)
+            if plan is not None:
+                plan.step_dev = store.opt_state["step"]
     return int(state["global_step"])
 
 

@@ -1291,11 +1291,31 @@ def batchnorm_train_bwd_act(x, gamma, mean, rstd, g, dgamma, dbeta, kind: int, z
     return dz
 
 
+_syncbn_rows_checked = set()
+
+
+def _syncbn_check_rows(rows: int, world: int, all_gather, device) -> None:
+    """The Sync-BatchNorm kernels weigh every rank's tiles by the LOCAL row count: every rank must hold the same number of
+    examples (weak scaling with drop_remainder; a ragged last batch would give wrong global statistics, or a hang when the
+    tile counts differ).  Checked once per batch size (one tiny all_gather), outside a capture."""
+    key = (int(rows), int(world))
+    if key in _syncbn_rows_checked or (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+        return
+    got = torch.empty(world, 1, device=device, dtype=torch.float32)
+    all_gather(got, torch.full((1,), float(rows), device=device))
+    if not bool((got == float(rows)).all()):
+        raise ValueError(f"sync_batch_norm: every rank must hold the same number of examples per step (this rank: {rows}, "
+                         f"ranks: {got.reshape(-1).tolist()}); drop the ragged last batch")
+    _syncbn_rows_checked.add(key)
+
+
 def batchnorm_sync_fwd(x, gamma, beta, moving_mean, moving_var, momentum: float, eps: float, sync):
     """Sync-BatchNorm forward (include/recalgo.h "Sync-BatchNorm building blocks"): per-tile moments -> all_gather of the
-    partial rows over the data-parallel group -> merge + apply.  sync = (world, rank, all_gather(out [world, n], in [n]))."""
+    partial rows over the data-parallel group -> merge + apply.  sync = (world, rank, all_gather(out [world, n], in [n])).
+    Every rank must hold the same number of rows (checked once per batch size)."""
     world, _, all_gather = sync
     rows, C = x.shape
+    _syncbn_check_rows(rows, world, all_gather, x.device)
     lib = _lib_()
     nb = int(lib.recalgo_batchnorm_partial_rows(rows))
     local = torch.empty(nb * 2 * C, device=x.device, dtype=torch.float32)

@@ -585,8 +585,22 @@ def _companion_arena(sources: List[Source], mode: int):
 def _init_deferred(plan: ArenaPlan, step_dev: torch.Tensor) -> None:
     # rows with state (m, v) are valid for the step before this one; untouched rows are marked 0
     arena = plan.arena
-    alive = ((arena.m != 0) | (arena.v != 0)).any(dim=1)
-    plan.last_step = (alive.to(torch.int64) * (step_dev - 1)).to(torch.int32)
+    rows = arena.weight.shape[0]
+    plan.last_step = torch.zeros(rows, dtype=torch.int32, device=arena.weight.device)
+    prev = (step_dev - 1).to(torch.int32)
+    chunk = 1 << 22                            # (row chunks: the masks of a 100 M-row table are multi-GB transients otherwise)
+    any_alive = torch.zeros((), dtype=torch.bool, device=arena.weight.device)
+    for r0 in range(0, rows, chunk):
+        r1 = min(rows, r0 + chunk)
+        alive = (arena.m[r0:r1] != 0).any(dim=1) | (arena.v[r0:r1] != 0).any(dim=1)
+        plan.last_step[r0:r1] = torch.where(alive, prev, torch.zeros_like(prev))
+        any_alive |= alive.any()
+    capturing = arena.weight.is_cuda and torch.cuda.is_current_stream_capturing()
+    if not capturing and bool(any_alive) and int(step_dev) <= 1:
+        # 0 doubles as "never touched": moments without the step they belong to (restored without opt_step, or set by hand)
+        # cannot be given their pending g = 0 decay — refuse instead of silently deviating from the dense pass
+        raise RuntimeError(f"arena {getattr(arena, 'name', '?')}: Adam moments are non-zero but the optimizer step is {int(step_dev)}: "
+                           "restore the step counter together with the moments (estimator.restore_checkpoint_state does)")
     plan.lr_ring = torch.zeros(LR_RING, dtype=torch.float32, device=arena.weight.device)
 
 

@@ -196,6 +196,14 @@ class VariableStore:
         return blk, subs
 
     # -- packing --------------------------------------------------------------------------
+    def sync(self) -> None:
+        """Every embedding arena reflects ALL completed optimizer steps.  The tables' TF1 Adam is evaluated lazily (sparse.py:
+        a row's g = 0 updates are replayed when the row is next read, swept or flushed), so between steps `arena.weight / m / v`
+        lag for rows no batch has touched for a while.  `named_arrays`, checkpoints, export and `unshard_arena` call this
+        themselves; any OTHER direct reader of `arena.weight`, `arena.table_view(...)`, `arena.m`, `arena.v` must call it first."""
+        from . import sparse
+        sparse.sync_store(self)
+
     def housekeeping(self) -> None:
         """Cheap, sync-free maintenance the training loops call every few dozen steps."""
         if os.environ.get("RECALGO_NO_HOUSEKEEPING") == "1":

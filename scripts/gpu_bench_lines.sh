@@ -5,7 +5,7 @@ TAG=${1:-r02}; shift
 MODELS=${@:-dcn deepfm xdeepfm din fibinet pnn fwfm nfm afm ffm}
 O=$PWD/gpurun_out; mkdir -p $O
 for m in $MODELS; do
-  timeout 300 python bench.py --model $m --steps 300 --warmup 20 --no-cpu-baseline --sweep-batches 0 > $O/bench_${TAG}_$m.json 2> $O/bench_${TAG}_$m.err
+  timeout 300 python bench.py --model $m --steps 300 --warmup 20 --no-cpu-baseline --no-host-fed --sweep-batches 0 > $O/bench_${TAG}_$m.json 2> $O/bench_${TAG}_$m.err
   python - "$O/bench_${TAG}_$m.json" <<'PY'
 import json, sys
 try:

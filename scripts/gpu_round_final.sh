@@ -11,16 +11,16 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 timeout 400 python bench.py > $O/bench_${TAG}_default.json 2> $O/bench_${TAG}_default.err
 # rocprofv3 --kernel-trace --stats of THE SAME default command (agreement with the live HIP-event roofline numbers)
 D=/tmp/prof_${TAG}_default
-(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $D -o dcn -- python $R/bench.py --no-cpu-baseline > $O/prof_${TAG}_default.log 2>&1)
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $D -o dcn -- python $R/bench.py --no-cpu-baseline --no-host-fed > $O/prof_${TAG}_default.log 2>&1)
 DB=$(find $D -name "*_results.db" | head -1)
 if [ -n "$DB" ]; then python $R/scripts/rocpd_stats.py $DB 40 > $O/${TAG}_default_kernel_stats.md; fi
 tail -c 1200 $O/prof_${TAG}_default.log > $O/prof_${TAG}_default.tail; rm -rf $O/prof_${TAG}_default.log $D
 bash scripts/gpu_bench_all.sh $TAG > $O/${TAG}_bench_all.log 2>&1
 bash scripts/gpu_pmc_bench.sh $TAG dcn 64 > $O/${TAG}_pmc_fullrun.log 2>&1
 bash scripts/gpu_pmc_sq.sh $TAG dcn SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE > $O/${TAG}_pmc_sq.log 2>&1
-timeout 400 python bench.py --model deepfm --big-table-rows 100000000 --no-cpu-baseline --sweep-batches 0 > $O/bench_${TAG}_deepfm_100M.json 2> $O/bench_${TAG}_deepfm_100M.err
-timeout 300 python scripts/bench_tfrecord.py > $O/bench_${TAG}_tfrecord_e2e.json 2> $O/bench_${TAG}_tfrecord_e2e.err
-RECALGO_READER_THREADS=32 timeout 300 python scripts/bench_tfrecord.py > $O/bench_${TAG}_tfrecord_e2e_32threads.json 2> $O/bench_${TAG}_tfrecord_e2e_32threads.err
+timeout 400 python bench.py --model deepfm --big-table-rows 100000000 --no-cpu-baseline --no-host-fed --sweep-batches 0 > $O/bench_${TAG}_deepfm_100M.json 2> $O/bench_${TAG}_deepfm_100M.err
+timeout 300 python scripts/bench_tfrecord.py --examples 131072 --epochs 60 > $O/bench_${TAG}_tfrecord_e2e.json 2> $O/bench_${TAG}_tfrecord_e2e.err
+RECALGO_READER_THREADS=64 timeout 300 python scripts/bench_tfrecord.py --examples 131072 --epochs 60 > $O/bench_${TAG}_tfrecord_e2e_64threads.json 2> $O/bench_${TAG}_tfrecord_e2e_64threads.err
 tail -3 $O/${TAG}_pytest_gpu.log; tail -2 $O/${TAG}_smoke.log
 for f in $O/bench_${TAG}_*.json; do python - "$f" <<'PY'
 import json, sys

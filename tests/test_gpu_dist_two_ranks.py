@@ -121,7 +121,7 @@ def test_bench_two_rank_code_path(capacity_factor):
     env = dict(os.environ, RECALGO_DIST_BACKEND="gloo_staged", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "4", "--batch", "512",
-           "--max-vocab", "20000", "--data-batches", "3", "--no-tunable", "--no-cpu-baseline", "--capacity-factor", capacity_factor]
+           "--max-vocab", "20000", "--data-batches", "3", "--no-tunable", "--no-cpu-baseline", "--no-host-fed", "--capacity-factor", capacity_factor]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -142,7 +142,7 @@ def test_bench_launches_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(RECALGO_DIST_BACKEND="gloo_staged", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "512", "--max-vocab", "20000",
-           "--data-batches", "3", "--no-tunable", "--no-cpu-baseline", "--no-kernel-timing", "--capacity-factor", "1.5"]
+           "--data-batches", "3", "--no-tunable", "--no-cpu-baseline", "--no-host-fed", "--no-kernel-timing", "--capacity-factor", "1.5"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
