@@ -306,6 +306,7 @@ struct PrepareArgs {
     long long rows, rows1;
     int period;
     unsigned passes, passes1;      // a workgroup walks `passes` of the step's row blocks
+    unsigned bshift, bshift1;      // sweep blocks are 256 << bshift rows (sweep_block_shift)
     int sweeping;                  // this launch carries the sweep: the catch-up leaves the rows of the step's blocks to it
 };
 
@@ -356,7 +357,8 @@ constexpr size_t kClaimsLdsBytes = (5 * kThreads + 64 + 4) * sizeof(unsigned);
 // state loads, it is only waited for where the winners are published, right before the first replay.  A claim that was not
 // granted is replayed for nothing and dropped.
 __device__ __forceinline__ void replay_claims(const Deferred& D, unsigned K, int target, const Claims& C,
-                                              const recalgo_deferred::LrWindow& W, bool listed, unsigned my_slot, int old, int expect) {
+                                              const recalgo_deferred::LrWindow& W, bool listed, unsigned my_slot, int old, int expect,
+                                              bool all_won = false) {
     const unsigned n = *C.n;
     if (n == 0) return;                                       // (uniform)
     if (threadIdx.x < 64) C.hist[threadIdx.x] = 0;
@@ -396,7 +398,11 @@ __device__ __forceinline__ void replay_claims(const Deferred& D, unsigned K, int
     int sc = mine ? C.s2[k] : target;
     float w = 0.f, m = 0.f, v = 0.f;
     if (mine) { w = D.w[o]; m = D.m[o]; v = D.v[o]; }
-    if (listed) C.won[C.row[my_slot]] = old == expect ? 1 : 0; // (waits for the claim's outcome; the state loads are in flight)
+    if (all_won) {                                            // (the sweep: its rows are its own, nothing was claimed)
+        if (threadIdx.x < n) C.won[threadIdx.x] = 1;
+    } else if (listed) {
+        C.won[C.row[my_slot]] = old == expect ? 1 : 0;        // (waits for the claim's outcome; the state loads are in flight)
+    }
     __syncthreads();
     while (t0 < ntask) {
         const unsigned t1 = t0 + kThreads;
@@ -420,8 +426,16 @@ __device__ __forceinline__ void replay_claims(const Deferred& D, unsigned K, int
 // while a sweep runs, its rows are its own).  64 rows, not 256: a row block of a small, fully live table is 256 x K tasks —
 // sixteen replay rounds on one workgroup, the tail of the whole launch
 constexpr unsigned kSweepRows = 64;
-__device__ __forceinline__ void sweep_pass(const Deferred& D, unsigned K, long long row, long long end, int target, const Claims& C,
-                                           const recalgo_deferred::LrWindow& W) {
+// A workgroup's `passes` (<= 32) units of 64 rows, unit p starting at row unit_row(p).  The steps of ALL its rows are read up
+// front — every thread's loads in flight together, four units per round over the 256 threads — and a round whose rows are all
+// current or untouched (a 100 M-row table a few steps into training: nearly every round) then costs two barriers and no trip
+// to memory.  (The first version walked unit after unit with 64 threads, a dependent load per unit: the sweep share of a
+// 100 M-row table, 3.1 M rows a step, took 0.2 ms of a 0.27 ms step.)
+constexpr unsigned kSweepMaxPasses = 32;
+// one unit (a small share: sweep_passes == 1): its 64 rows by the first wave, no grouping to do — measurably leaner than the
+// general form below (DCN's `prepare` 19.8 vs 21.3 us, DeepFM's two arenas 22.9 vs 27.0 us, same box)
+__device__ __forceinline__ void sweep_one_unit(const Deferred& D, unsigned K, long long row, long long end, int target, const Claims& C,
+                                               const recalgo_deferred::LrWindow& W) {
     if (threadIdx.x == 0) *C.n = 0;
     __syncthreads();
     bool listed = false;
@@ -438,18 +452,86 @@ __device__ __forceinline__ void sweep_pass(const Deferred& D, unsigned K, long l
     __syncthreads();
     replay_claims(D, K, target, C, W, listed, k, 0, 0);
 }
-// first row of unit u (64 rows) of the share of step index c: the row blocks (256 rows) c, c + P, c + 2 P, ..., four units each
-__device__ __forceinline__ long long sweep_unit_row(int c, int period, long long u) {
-    return ((long long)c + (long long)period * (u >> 2)) * kThreads + (u & 3) * kSweepRows;
+template <typename UnitRow>
+__device__ __forceinline__ void sweep_units(const Deferred& D, unsigned K, unsigned passes, UnitRow unit_row, long long end, int target,
+                                            const Claims& C, const recalgo_deferred::LrWindow& W) {
+    if (passes == 1) {                                                    // (uniform over the launch)
+        sweep_one_unit(D, K, unit_row(0) + threadIdx.x, end, target, C, W);
+        return;
+    }
+    constexpr unsigned kPer = kThreads / kSweepRows;                      // units inspected per round
+    constexpr unsigned kRounds = kSweepMaxPasses / kPer;
+    const unsigned up = threadIdx.x / kSweepRows, ur = threadIdx.x % kSweepRows;
+    int sv[kRounds];
+    unsigned rw[kRounds];                                                 // (arena rows are < 2^31; registers are what bounds
+#pragma unroll                                                            //  the occupancy of the whole `prepare` launch)
+    for (unsigned j = 0; j < kRounds; ++j) {
+        const unsigned pu = up + kPer * j;
+        const long long r = pu < passes ? unit_row(pu) + ur : end;
+        rw[j] = (unsigned)(r < end ? r : end);
+        sv[j] = r < end ? D.last_step[r] : 0;
+    }
+    // how many rows of each round lag (block-wide counts: every thread knows them all) ...
+    unsigned cntp[kRounds / 2];                                           // (two 16-bit counts per register)
+#pragma unroll
+    for (unsigned j = 0; j < kRounds / 2; ++j) cntp[j] = 0;
+#pragma unroll
+    for (unsigned j = 0; j < kRounds; ++j)
+        if (kPer * j < passes) cntp[j / 2] |= (unsigned)__syncthreads_count(sv[j] > 0 && sv[j] < target) << (16 * (j & 1));
+    auto cnt = [&](unsigned j) -> unsigned {
+        unsigned v = 0;
+#pragma unroll
+        for (unsigned q = 0; q < kRounds / 2; ++q) v = (j / 2 == q) ? cntp[q] : v;
+        return (v >> (16 * (j & 1))) & 0xffffu;
+    };
+    // ... so that the rounds are replayed in GROUPS of up to kThreads claims: a workgroup whose 2048 rows hold a handful of
+    // lagging ones (a large table: the rows the recent batches touched, spread thin) replays them in ONE pass instead of one
+    // pass — state loads, the replay loop, stores: ~5 us — per round that has any
+    unsigned j0 = 0;
+#pragma unroll 1
+    while (j0 < kRounds && kPer * j0 < passes) {
+        unsigned acc = cnt(j0), j1 = j0 + 1;
+        while (j1 < kRounds && acc + cnt(j1) <= (unsigned)kThreads) acc += cnt(j1++);
+        if (acc > 0) {                                                    // (uniform)
+            if (threadIdx.x == 0) *C.n = 0;
+            __syncthreads();
+#pragma unroll
+            for (unsigned j = 0; j < kRounds; ++j)
+                if (j >= j0 && j < j1 && sv[j] > 0 && sv[j] < target) {
+                    const unsigned k = atomicAdd(C.n, 1u);
+                    C.row[k] = (int)rw[j];
+                    C.s[k] = sv[j];
+                }
+            __syncthreads();
+            replay_claims(D, K, target, C, W, false, 0, 0, 0, true);
+        }
+        j0 = j1;
+    }
+}
+// first row of unit u (64 rows) of the share of step index c: the row blocks c, c + P, c + 2 P, ... of 256 << g rows each
+// (4 << g units).  g = 0 for the tables of the reference's data sets (their hot rows sit at the low ids of every table: small
+// blocks spread them over the steps and the workgroups); large tables take larger blocks (sweep_block_shift) so that a step's
+// share is read in long contiguous runs — 12 k scattered 1 KB pieces of a 400 MB step array per step were 0.13 ms of TLB misses
+__device__ __forceinline__ long long sweep_unit_row(int c, int period, unsigned g, long long u) {
+    return (((long long)c + (long long)period * (u >> (2 + g))) << (8 + g)) + (long long)(u & ((4u << g) - 1u)) * kSweepRows;
+}
+inline unsigned sweep_block_shift(long long rows, int period) {
+    static const int forced = [] { const char* e = getenv("RECALGO_SPARSE_SWEEP_BLOCK_SHIFT"); return e ? atoi(e) : -1; }();   // (tuning aid)
+    if (forced >= 0 && forced <= 8) return (unsigned)forced;
+    unsigned g = 0;
+    while (g < 8 && ((rows >> (8 + g)) / (period < 1 ? 1 : period)) > 512) ++g;
+    return g;
 }
 inline unsigned sweep_passes(long long rows_in_launch) {
+    // (small shares: ONE unit per workgroup — the launch lasts as long as its longest workgroup, and a workgroup with 64 rows
+    // of a densely live table already has a full pass of replay work)
     const long long r = rows_in_launch / 65536;
-    return (unsigned)(r < 1 ? 1 : (r > 32 ? 32 : r));
+    return (unsigned)(r < 1 ? 1 : (r > (long long)kSweepMaxPasses ? (long long)kSweepMaxPasses : r));
 }
 
 // the catch-up of up to kThreads requests: lagging rows claimed (one winner per row), listed, replayed
 __device__ __forceinline__ void catchup_requests(const PrepareArgs& A, const Deferred& D, unsigned K, unsigned r, bool active,
-                                                 long long n_rows, int cidx, int target, const Claims& C) {
+                                                 long long n_rows, unsigned bshift, int cidx, int target, const Claims& C) {
     if (threadIdx.x == 0) *C.n = 0;
     __syncthreads();
     // a lagging row is LISTED at once and claimed by a compare-and-swap whose outcome is not waited for here (one winner per
@@ -460,7 +542,7 @@ __device__ __forceinline__ void catchup_requests(const PrepareArgs& A, const Def
     if (active && r < A.n_req) {
         row = request_row_linear(A.S, r);
         // (rows of the blocks the same launch sweeps are the sweep's)
-        if (row >= 0 && row < n_rows && !(A.sweeping && (int)((row >> 8) % A.period) == cidx)) {
+        if (row >= 0 && row < n_rows && !(A.sweeping && (int)((row >> (8 + bshift)) % A.period) == cidx)) {
             s = __hip_atomic_load(&D.last_step[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             lag = s > 0 && s < target;
         }
@@ -476,19 +558,19 @@ __device__ __forceinline__ void catchup_requests(const PrepareArgs& A, const Def
     replay_claims(D, K, target, C, recalgo_deferred::lr_window(D.lr_ring, target), lag, slot, old, s);
 }
 
-__global__ __launch_bounds__(kThreads) void sparse_prepare_kernel(PrepareArgs A) {
+__global__ __launch_bounds__(kThreads, 8) void sparse_prepare_kernel(PrepareArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds_u[];
     const int target = A.D.last_step ? (int)(A.step[0] + A.step_off) : 0;
     const int cidx = A.period > 0 ? target % A.period : 0;
     if (blockIdx.x < A.b_catch) {
         // ---- catch-up: kCatchReq requests per workgroup, in request order ------------------------------------------------
-        catchup_requests(A, A.D, A.K, blockIdx.x * kCatchReq + threadIdx.x, threadIdx.x < kCatchReq, A.rows, cidx, target,
+        catchup_requests(A, A.D, A.K, blockIdx.x * kCatchReq + threadIdx.x, threadIdx.x < kCatchReq, A.rows, A.bshift, cidx, target,
                          claims_carve(lds_u));
         return;
     }
     if (blockIdx.x < A.b_comp) {
         // ---- the companion arena's rows of the same requests (one float per row) ---------------------------------------
-        catchup_requests(A, A.D1, 1, (blockIdx.x - A.b_catch) * kThreads + threadIdx.x, true, A.rows1, cidx, target,
+        catchup_requests(A, A.D1, 1, (blockIdx.x - A.b_catch) * kThreads + threadIdx.x, true, A.rows1, A.bshift1, cidx, target,
                          claims_carve(lds_u));
         return;
     }
@@ -509,16 +591,19 @@ __global__ __launch_bounds__(kThreads) void sparse_prepare_kernel(PrepareArgs A)
     const Claims C = claims_carve(lds_u);
     if (blockIdx.x < A.b_sweep) {
         const recalgo_deferred::LrWindow W = recalgo_deferred::lr_window(A.D.lr_ring, target);
-        const long long u0 = (long long)(blockIdx.x - A.b_count) * A.passes;       // this workgroup's first unit (64 rows) of the step's share
-        for (unsigned p = 0; p < A.passes; ++p)
-            sweep_pass(A.D, A.K, sweep_unit_row(cidx, A.period, u0 + p) + threadIdx.x, A.rows, target, C, W);
+        // this workgroup's units (64 rows each) of the step's share: STRIDED over the launch's sweep workgroups — the live rows of
+        // a model sit in a few dense regions of the arena (its small tables); consecutive units to one workgroup made ~40 of the
+        // 1500 sweep workgroups of a 100 M-row arena replay nearly all of the step's lagging rows, 15 passes each
+        const long long wg = blockIdx.x - A.b_count, nwg = A.b_sweep - A.b_count;
+        sweep_units(A.D, A.K, A.passes, [&](unsigned pu) { return sweep_unit_row(cidx, A.period, A.bshift, wg + (long long)pu * nwg); },
+                    A.rows, target, C, W);
         return;
     }
     {
         const recalgo_deferred::LrWindow W = recalgo_deferred::lr_window(A.D1.lr_ring, target);
-        const long long u0 = (long long)(blockIdx.x - A.b_sweep) * A.passes1;
-        for (unsigned p = 0; p < A.passes1; ++p)
-            sweep_pass(A.D1, 1, sweep_unit_row(cidx, A.period, u0 + p) + threadIdx.x, A.rows1, target, C, W);
+        const long long wg = blockIdx.x - A.b_sweep, nwg = (long long)gridDim.x - A.b_sweep;
+        sweep_units(A.D1, 1, A.passes1, [&](unsigned pu) { return sweep_unit_row(cidx, A.period, A.bshift1, wg + (long long)pu * nwg); },
+                    A.rows1, target, C, W);
     }
 }
 
@@ -1189,8 +1274,8 @@ __global__ __launch_bounds__(kThreads) void sparse_sweep_kernel(SweepArgs A) {
     if (target <= 0) return;
     const Claims C = claims_carve(lds_u);
     const recalgo_deferred::LrWindow W = recalgo_deferred::lr_window(A.D.lr_ring, target);
-    const long long first = A.row0 + (long long)blockIdx.x * A.passes * kSweepRows;
-    for (unsigned p = 0; p < A.passes; ++p) sweep_pass(A.D, A.K, first + (long long)p * kSweepRows + threadIdx.x, A.row1, target, C, W);
+    sweep_units(A.D, A.K, A.passes, [&](unsigned pu) { return A.row0 + ((long long)blockIdx.x + (long long)pu * gridDim.x) * kSweepRows; },
+                A.row1, target, C, W);
 }
 
 // ---- host helpers -----------------------------------------------------------------------------
@@ -1363,13 +1448,16 @@ RECALGO_EXPORT int recalgo_scatter_prepare(const recalgo_scatter_source_t* sourc
     const unsigned count_blocks = (count && n) ? (unsigned)cdiv(n, kThreads) : 0u;
     A.period = sweep_period < 1 ? 1 : sweep_period;
     A.rows = rows; A.rows1 = companion_rows;
-    // row blocks (of 256 rows) per step: every P-th block of the arena
-    const long long share = cdiv(cdiv(rows, kThreads), A.period), share1 = cdiv(cdiv(companion_rows, kThreads), A.period);
-    A.passes = sweep_passes(share * kThreads);
-    A.passes1 = sweep_passes(share1 * kThreads);
+    // row blocks (of 256 << g rows) per step: every P-th block of the arena
+    A.bshift = sweep_block_shift(rows, A.period);
+    A.bshift1 = sweep_block_shift(companion_rows, A.period);
+    const long long brows = (long long)kThreads << A.bshift, brows1 = (long long)kThreads << A.bshift1;
+    const long long share = cdiv(cdiv(rows, brows), A.period), share1 = cdiv(cdiv(companion_rows, brows1), A.period);
+    A.passes = sweep_passes(share * brows);
+    A.passes1 = sweep_passes(share1 * brows1);
     A.sweeping = sweep ? 1 : 0;
-    const unsigned sweep_blocks = sweep ? (unsigned)cdiv(share * (kThreads / kSweepRows), (long long)A.passes) : 0u;
-    const unsigned sweep1_blocks = (sweep && A.D1.last_step) ? (unsigned)cdiv(share1 * (kThreads / kSweepRows), (long long)A.passes1) : 0u;
+    const unsigned sweep_blocks = sweep ? (unsigned)cdiv(share * (brows / kSweepRows), (long long)A.passes) : 0u;
+    const unsigned sweep1_blocks = (sweep && A.D1.last_step) ? (unsigned)cdiv(share1 * (brows1 / kSweepRows), (long long)A.passes1) : 0u;
     A.b_catch = catch_blocks;
     A.b_comp = A.b_catch + comp_blocks;
     A.b_count = A.b_comp + count_blocks;
