@@ -38,22 +38,23 @@ __device__ __forceinline__ unsigned excl_scan256(unsigned v, unsigned* sh, unsig
     return before + inc - v;
 }
 
-// all 256 threads of one workgroup; nb is a multiple of 256 (1024 .. 8192: 4 .. 32 buckets per thread).  Up to 8 buckets per
+// all 256 threads of one workgroup; nb is a multiple of 256 (1024 .. 8192: 4 .. 32 buckets per thread).  Up to 16 buckets per
 // thread the counters are read ONCE, all loads in flight together, and kept in registers; larger plans read them again in
 // every pass (they stay in L2) rather than parking nb words in LDS: the host kernel keeps its LDS footprint.
+constexpr unsigned kRegs = 16;
 template <bool REGS>
 __device__ __forceinline__ void scan_block_impl(const Scan& S, unsigned* sh) {
     const unsigned bpt = (1u << S.nb_log2) / 256u, b0 = threadIdx.x * bpt;
-    unsigned cnt[8];
+    unsigned cnt[kRegs];
     if (REGS) {
 #pragma unroll
-        for (unsigned k = 0; k < 8; ++k) cnt[k] = k < bpt ? S.total[(size_t)(b0 + k) << S.cs] : 0u;
+        for (unsigned k = 0; k < kRegs; ++k) cnt[k] = k < bpt ? S.total[(size_t)(b0 + k) << S.cs] : 0u;
     }
     auto count = [&](unsigned k) -> unsigned { return REGS ? cnt[k] : S.total[(size_t)(b0 + k) << S.cs]; };
     unsigned sum = 0;
     if (REGS) {
 #pragma unroll
-        for (unsigned k = 0; k < 8; ++k) sum += cnt[k];
+        for (unsigned k = 0; k < kRegs; ++k) sum += cnt[k];
     } else {
         for (unsigned k = 0; k < bpt; ++k) sum += count(k);
     }
@@ -64,7 +65,7 @@ __device__ __forceinline__ void scan_block_impl(const Scan& S, unsigned* sh) {
     unsigned nh = 0;
     if (REGS) {
 #pragma unroll
-        for (unsigned k = 0; k < 8; ++k) nh += (k < bpt && cnt[k] >= heavy_min) ? 1u : 0u;
+        for (unsigned k = 0; k < kRegs; ++k) nh += (k < bpt && cnt[k] >= heavy_min) ? 1u : 0u;
     } else {
         for (unsigned k = 0; k < bpt; ++k) nh += count(k) >= heavy_min;
     }
@@ -81,14 +82,14 @@ __device__ __forceinline__ void scan_block_impl(const Scan& S, unsigned* sh) {
     };
     if (REGS) {
 #pragma unroll
-        for (unsigned k = 0; k < 8; ++k)
+        for (unsigned k = 0; k < kRegs; ++k)
             if (k < bpt) emit(k, cnt[k]);
     } else {
         for (unsigned k = 0; k < bpt; ++k) emit(k, count(k));
     }
 }
 __device__ __forceinline__ void scan_block(const Scan& S, unsigned* sh) {
-    if (S.nb_log2 <= 11) scan_block_impl<true>(S, sh);        // (workgroup-uniform)
+    if (S.nb_log2 <= 12) scan_block_impl<true>(S, sh);        // (workgroup-uniform)
     else scan_block_impl<false>(S, sh);
 }
 
