@@ -680,25 +680,38 @@ int recalgo_activation_bwd(const float* x, const float* alpha, const float* gy, 
  * recalgo_scatter_source_slots(n_ex, F, ragged) slots (id matrix: field-major, F x (n_ex rounded up to 256), so that a
  * tile is 256 consecutive examples of one field; ragged: n_ex * F rounded up), source k starts at the sum of the slots
  * of the sources before it (`first_request`), and plan_requests is the slot capacity the workspace was sized for.
- *   recalgo_scatter_prepare  once per source, any time before `apply` (normally right before the lookup's forward
- *                            kernel): the source's tiles write their rows of the plan's (tile x bucket) count matrix —
- *                            one entry per DISTINCT row of a tile — and, with `deferred`, every requested row whose
- *                            (w, m, v) lags is claimed and brought up to step  step_dev[0] + step_offset  (second
- *                            launch; lookup_index < 16 selects the lookup's claim list).  plan_workspace is required.
- *   recalgo_scatter_apply    once per plan, with the SAME sources in the SAME order (their g now set): three launches
- *                            (column scan of the count matrix + the deferred sweep; stable placement of the entries
- *                            into their hash bucket, the duplicates of a tile summed in request order into one
- *                            partial row; one workgroup per bucket groups its entries by row, still in request order).
- *                            The owner of a row adds its gradient rows in that fixed order — no atomics on global
- *                            memory, bit-reproducible — and finishes, by `mode`:
+ *   recalgo_scatter_prepare  ONE launch per source, any time before `apply` (normally right before the lookup's forward
+ *                            kernel); `flags` selects its parts, which run as workgroup ranges of one grid:
+ *                              RECALGO_PREPARE_COUNT    the source's tiles add ONE entry per DISTINCT row of a tile to the
+ *                                                       row's bucket total (integer atomics on counters spread one per
+ *                                                       64 bytes; bucket = hash(row)); needs `source`;
+ *                              RECALGO_PREPARE_CATCHUP  with `deferred`: every requested row whose (w, m, v) lags is claimed
+ *                                                       (one winner per row over all workgroups) and brought up to step
+ *                                                       step_dev[0] + step_offset; `companion_deferred`: the same rows of
+ *                                                       the second arena (see `companion` below);
+ *                              RECALGO_PREPARE_SWEEP    with `deferred`: this step's share of the arena — every
+ *                                                       sweep_period-th block of rows, c = step % sweep_period — is
+ *                                                       brought up to that step (once per arena and step: the first
+ *                                                       lookup's launch carries it; `source` may be NULL for a
+ *                                                       sweep-only launch), so that no row lags more than P + 1 steps.
+ *                            plan_workspace is required.
+ *   recalgo_scatter_apply    once per plan, with the SAME sources in the SAME order (their g now set): two launches —
+ *                            `place` (every entry goes to its bucket: position = the bucket's prefix + a range drawn from
+ *                            the bucket's cursor + its rank in the tile; the duplicates of a tile are summed in request
+ *                            order into one partial row) and `apply` (one workgroup per bucket orders its entries by
+ *                            the unique key (row, slot) and groups them by row).  The prefix of the bucket totals is
+ *                            computed by `place` itself, or — mode | RECALGO_SCATTER_PRESCANNED — was left by
+ *                            recalgo_adam_tf1_step_plans.  A gradient row may be formed on load from a source's fm_*
+ *                            fields: g + fm_scale[e] * (fm_sum[e, :] - fm_emb[e, f, :]), DeepFM's second-order term
+ *                            (deepfm.py:196-200).  The owner of a row adds its gradient rows in a fixed order — no float
+ *                            atomics, bit-reproducible — and finishes, by `mode`:
  *     RECALGO_SCATTER_GRAD       grad[row, :] += sum            (+ `live`: the row joins the live-row list)
  *     RECALGO_SCATTER_ADAM       TF1 Adam with dense semantics, evaluated lazily but EXACTLY: (w, m, v)[row] first
  *                                replay the g = 0 updates of the steps since last_step[row], then take this step's
- *                                update with lr_t(t), t = step_dev[0] + step_offset; last_step[row] = t.  The same
- *                                call sweeps rows [c*ceil(rows/P), ...), c = (t-1) % P, P = sweep_period, up to
- *                                step t - 1, so that no row lags more than P + 1 steps, and records lr_t(t) in
- *                                deferred->lr_ring.  Bit-identical to recalgo_adam_tf1_dense over the whole arena
- *                                once recalgo_adam_deferred_sweep has flushed it.
+ *                                update with lr_t(t), t = step_dev[0] + step_offset; last_step[row] = t; lr_t(t) is
+ *                                recorded in deferred->lr_ring.  Bit-identical to recalgo_adam_tf1_dense over the whole
+ *                                arena once recalgo_adam_deferred_sweep has flushed it (every Adam update of the library
+ *                                uses the same v_sqrt / v_rcp form, csrc/deferred.h).
  *     RECALGO_SCATTER_LAZY_ADAM  LazyAdamOptimizer: exactly the rows of this step's requests take the Adam update
  *                                (whole rows, also rows whose summed gradient is 0); all other rows keep w, m, v.
  *                            In the ADAM modes a non-NULL `grad` gets the touched rows zeroed (a gradient arena
@@ -706,17 +719,18 @@ int recalgo_activation_bwd(const float* x, const float* alpha, const float* gy, 
  *                            `companion` (NULL, or a recalgo_scatter_companion_t; K <= 32): a second arena of ONE
  *                            float per row that was looked up with exactly these requests (DeepFM's first-order
  *                            weights, deepfm.py:125-141).  It gets its row sums and optimizer step from the SAME placed
- *                            entries: `place` also sums the scalar gradients of a tile's duplicates, one more
- *                            per-bucket launch walks the entries for the second arena, and its share of the sweep
- *                            rides in the scan launch — no second prepare / scan / place.  companion->sources[k]: only
+ *                            entries: `place` also sums the scalar gradients of a tile's duplicates, `apply` updates its
+ *                            row beside the main arena's, and its catch-up and share of the sweep ride in
+ *                            recalgo_scatter_prepare — no launch of its own.  companion->sources[k]: only
  *                            g / g_stride / g_col / g_fmul are read (g = NULL: that lookup had no companion and adds
  *                            nothing).  recalgo_scatter_prepare's companion_deferred brings the claimed rows of the
  *                            second arena up to date along with the first's.
  *   recalgo_adam_deferred_sweep  rows [row_begin, row_end) brought to step_dev[0] + step_offset: the flush before
  *                            EVAL / PREDICT / checkpoint / export, and after the last training step.
  * The workspace (recalgo_scatter_plan_workspace_bytes(plan_requests, nb_log2, K), nb_log2 =
- * recalgo_scatter_plan_buckets_log2(plan_requests)) needs its first 64 bytes zero-filled once before its first use
- * (the claim counters; the kernels keep them clean afterwards).
+ * recalgo_scatter_plan_buckets_log2(plan_requests)) needs its first recalgo_scatter_plan_header_bytes(nb_log2) bytes (the
+ * bucket totals and cursors) zero-filled before its first use and whenever counted sources are dropped without having been
+ * applied; `apply` leaves them clean.
  * ------------------------------------------------------------------------------------------ */
 #define RECALGO_SCATTER_MAX_SOURCES 16
 #define RECALGO_LR_RING 1024
