@@ -5,8 +5,10 @@ atomics, fused with the sparse optimizer) and the deferred-exact TF1 Adam state.
                                                       recalgo_scatter_prepare (ONE launch: bucket counts, catch-up of the
                                                       lookup's lagging rows, the step's share of the deferred-Adam sweep)
     backward of a lookup  Source.set_grad(g)          records where the per-request gradient rows are
-    optimizer             apply(arena, mode, ...)     recalgo_scatter_apply (two launches: place, apply) over all sources of the arena: TF1 Adam with
-                                                      dense semantics evaluated lazily but exactly (tf.train.AdamOptimizer,
+    optimizer             apply(arena, mode, ...)     recalgo_scatter_apply (two launches: place, apply) over all sources of the
+                                                      arena (the prefix of the bucket counts rides on the dense optimizer
+                                                      launch: plan_scan_record): TF1 Adam with dense semantics
+                                                      evaluated lazily but exactly (tf.train.AdamOptimizer,
                                                       /root/reference algorithm/DeepFM/deepfm.py:246-250) or
                                                       tf.contrib.opt.LazyAdamOptimizer (algorithm/DIEN/dien.py:328)
     anyone reading whole  sync(arena) / sync_store    recalgo_adam_deferred_sweep: every row brought to the current step
@@ -127,8 +129,9 @@ class Source:
 class CompanionSource:
     """The lookup of a SECOND arena of one float per row made with exactly the requests of `main` (DeepFM's first-order
     weights beside its embeddings, /root/reference algorithm/DeepFM/deepfm.py:125-141).  It has no plan of its own: the
-    main arena's `place` also sums the scalar gradients of a tile's duplicates, and recalgo_scatter_apply_companion
-    walks the same placed entries for this arena — no second prepare / scan / place."""
+    main arena's `place` also sums the scalar gradients of a tile's duplicates, `apply` updates this arena's row beside
+    the main arena's (the lane that owns the row's first piece), and its catch-up and share of the sweep ride in the main
+    arena's `prepare` launch — no launch of its own."""
 
     def __init__(self, main: Source, arena):
         self.main, self.arena = main, arena
