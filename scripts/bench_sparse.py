@@ -74,8 +74,8 @@ def main():
         rows = ar.weight.shape[0]
         lib.recalgo_scatter_prepare(ctypes.byref(cs), K, ws, plan.capacity, plan.nb_log2, 0, sp.PREPARE_COUNT, None, None, 0, 0, 1, None, 0, st)
         if d is not None:
-            lib.recalgo_scatter_prepare(ctypes.byref(cs), K, ws, plan.capacity, plan.nb_log2, 0, 0, ctypes.byref(d), None, rows, 0,
-                                        sp.sweep_period(), stp, 0, st)
+            lib.recalgo_scatter_prepare(ctypes.byref(cs), K, ws, plan.capacity, plan.nb_log2, 0, sp.PREPARE_CATCHUP, ctypes.byref(d), None,
+                                        rows, 0, sp.sweep_period(), stp, 0, st)
             lib.recalgo_scatter_prepare(None, K, ws, plan.capacity, plan.nb_log2, 0, sp.PREPARE_SWEEP, ctypes.byref(d), None, rows, 0,
                                         sp.sweep_period(), stp, 0, st)
             plan.swept = True

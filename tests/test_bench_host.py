@@ -36,3 +36,33 @@ def test_self_launch_command(monkeypatch):
     i = cmd.index(os.path.abspath(bench.__file__))
     assert cmd[i + 1:] == ["--gpus", "4", "--steps", "7", "--config5"]
     assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_in_step_table_reads_the_newest_committed_kernel_stats(tmp_path, monkeypatch):
+    """bench.in_step_table: the `in_step` object of the bench line is the committed rocprofv3 summary of the same command —
+    calls per step from the optimizer launch's call count, kernels that do not run every step left out."""
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "r01a_dcn_kernel_stats.md").write_text("| `old_kernel(x)` | 10 | 10 | 1 | 1 | 1 | 1 |\n")
+    (prof / "r02b_dcn_kernel_stats.md").write_text(
+        "source: x\n\n| kernel | calls | total_ns | avg_ns | min_ns | max_ns | % |\n|---|---:|---:|---:|---:|---:|---:|\n"
+        "| `void (anonymous namespace)::dense_bwd_kernel<true, true>((anonymous namespace)::DgradArgs)` | 300 | 7500000 | 25000 | 1 | 2 | 50 |\n"
+        "| `(anonymous namespace)::adam_tf1_step_kernel((anonymous namespace)::AdamStepArgs)` | 100 | 600000 | 6000 | 1 | 2 | 10 |\n"
+        "| `void at::native::reduce_kernel<512>(int)` | 1 | 260000 | 260000 | 1 | 2 | 1 |\n"
+        "\nper launch shape (kernel, grid size):\n\n| `(anonymous namespace)::adam_tf1_step_kernel(x)` | 512 | 100 | 6000 | 1 | 2 |\n")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    t = bench.in_step_table("dcn")
+    assert t["source"] == "profiles/r02b_dcn_kernel_stats.md" and t["steps_profiled"] == 100
+    assert [(k["kernel"], k["calls_per_step"], k["avg_us"]) for k in t["kernels"]] == [
+        ("dense_bwd_kernel<true, true>", 3.0, 25.0), ("adam_tf1_step_kernel", 1.0, 6.0)]
+    assert t["dispatches_per_step"] == 4.0 and t["kernel_us_per_step"] == 81.0
+    assert bench.in_step_table("din") is None
+
+
+def test_host_fed_leg_is_bounded_and_optional(monkeypatch):
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--no-host-fed"])
+    assert bench.parse_args().no_host_fed
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    assert not bench.parse_args().no_host_fed
