@@ -359,3 +359,34 @@ def test_graphed_step_input_load_copies_views_of_one_allocation_at_once():
     f5["dense"] = torch.zeros(B, 4)
     with pytest.raises(ValueError):
         g.load(f5, l5)
+
+
+def test_graphed_step_input_load_never_clobbers_a_static_input_inside_a_span():
+    """A group's one-span copy overwrites every byte between its first and last view — so it is only taken when no OTHER static
+    input lives in that range of the static allocation (an input whose new source sits in another storage would otherwise be
+    clobbered whenever it had been copied earlier); and per-tensor copies run after all span copies."""
+    from recalgorithm_amd.estimator import GraphedTrainStep, _tree_tensors
+    from recalgorithm_amd.nn import BNLink
+    B = 16
+    static = torch.zeros(4 * B, dtype=torch.int64)
+    sf = {"a": static[0:B], "b": static[B:2 * B], "intruder": static[2 * B:3 * B]}
+    sl = {"y": static[3 * B:4 * B]}
+    g = GraphedTrainStep.__new__(GraphedTrainStep)
+    g._static = list(_tree_tensors(sf, "f")) + list(_tree_tensors(sl, "l"))
+    src = torch.arange(4 * B, dtype=torch.int64) + 100            # a, b, (gap), y in ONE storage with the static layout ...
+    other = torch.arange(B, dtype=torch.int64) + 7000             # ... the intruder's new value in ANOTHER
+    nf = {"a": src[0:B], "b": src[B:2 * B], "intruder": other}
+    nl = {"y": src[3 * B:4 * B]}
+    g.load(nf, nl)
+    assert torch.equal(sf["a"], src[0:B]) and torch.equal(sf["b"], src[B:2 * B]) and torch.equal(sl["y"], src[3 * B:])
+    assert torch.equal(sf["intruder"], other)                     # (a span copy a .. y would have left src's gap bytes here)
+    # BNLink (nn.py): the sums a dense layer's backward left are handed out only for the gradient tensor they belong to
+    x = torch.zeros(130, 8)
+    link = BNLink(x, torch.zeros(8), torch.ones(8))
+    link.sums, gr = torch.ones(3, 16), torch.zeros(130, 8)
+    link.grad_ptr = gr.data_ptr()
+    assert link.take(gr) is not None and link.take(gr) is None    # consumed once
+    link.sums = torch.ones(3, 16)
+    assert link.take(torch.zeros(130, 8)) is None and link.sums is None      # another tensor (autograd summed two consumers)
+    link.sums = torch.ones(3, 16)
+    assert link.take(gr.t().contiguous().t()) is None             # not the contiguous tensor the sums were computed from
