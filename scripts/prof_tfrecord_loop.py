@@ -73,6 +73,8 @@ def main():
     s = io.StringIO()
     pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(14)
     print(s.getvalue()[:3500])
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
 
 
 if __name__ == "__main__":
