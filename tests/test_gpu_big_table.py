@@ -132,3 +132,47 @@ def test_lookup_scatter_and_deferred_adam_beyond_4gib(dev):
     # every row with state is one of the touched rows (nothing was written through a wrapped address)
     n_state = int((sparse.plan_of(big).last_step > 0).sum())
     assert n_state == n_small, f"{n_state} rows carry optimizer state, {n_small} were touched"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,period", [(5_000_003, 32), (5_000_003, 7), (300_001, 32), (40_000_000, 32)])
+def test_one_sweep_period_reaches_every_row_of_a_large_arena_exactly(dev, rows, period):
+    """The deferred-Adam sweep share of `prepare` (RECALGO_PREPARE_SWEEP) over ONE period brings EVERY row of the arena up to
+    date — large arenas use coarser sweep blocks (256 << g rows), several 64-row units per workgroup and units strided over the
+    launch — and brings it there exactly: (w, m, v) equal the row's g = 0 updates replayed one step at a time by the standalone
+    sweep (recalgo_adam_deferred_sweep) on a copy."""
+    from recalgorithm_amd import _lib, sparse as sp
+    lib = _lib.load()
+    K = 4
+    gen = torch.Generator(device=dev).manual_seed(rows % 1000 + period)
+    w = torch.randn(rows, K, device=dev, generator=gen)
+    m = torch.randn(rows, K, device=dev, generator=gen) * 0.01
+    v = torch.rand(rows, K, device=dev, generator=gen) * 1e-3 + 1e-6
+    last = torch.ones(rows, dtype=torch.int32, device=dev)                    # every row carries state valid for step 1
+    ring = torch.zeros(sp.LR_RING, device=dev)
+    T = period + 1                                                            # steps 2 .. T: one whole period
+    for t in range(1, T + 1):
+        ring[t % sp.LR_RING] = 0.001 * (1.0 + 0.01 * t)                       # (lr_t of the steps the replay reads)
+    w2, m2, v2, last2 = w.clone(), m.clone(), v.clone(), last.clone()
+    step = torch.full((1,), 1, dtype=torch.int64, device=dev)
+    d = sp._CDeferred(w.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(), ring.data_ptr(), 0.9, 0.999, 1e-8)
+    d2 = sp._CDeferred(w2.data_ptr(), m2.data_ptr(), v2.data_ptr(), last2.data_ptr(), ring.data_ptr(), 0.9, 0.999, 1e-8)
+    nb = 10
+    ws = torch.zeros(int(lib.recalgo_scatter_plan_workspace_bytes(256, nb, K)), dtype=torch.uint8, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for t in range(2, T + 1):
+        step.fill_(t)
+        _lib.check(lib.recalgo_scatter_prepare(None, K, ctypes.c_void_p(ws.data_ptr()), 256, nb, 0, sp.PREPARE_SWEEP, ctypes.byref(d), None,
+                                               rows, 0, period, ctypes.c_void_p(step.data_ptr()), 0, st), "prepare (sweep)")
+    # every row was visited exactly in the step whose share it belongs to: its state is valid for a step in 2 .. T
+    assert int(last.min()) >= 2 and int(last.max()) <= T
+    counts = torch.bincount(last.long(), minlength=T + 1)[2:]
+    assert int(counts.sum()) == rows and int(counts.min()) > 0               # and every step of the period swept its share
+    # bring both copies to step T with the standalone sweep and compare bit for bit (the replay is exact, in any grouping)
+    step.fill_(T)
+    for dd in (d, d2):
+        _lib.check(lib.recalgo_adam_deferred_sweep(ctypes.byref(dd), K, 0, rows, ctypes.c_void_p(step.data_ptr()), 0, st), "sweep")
+    assert int(last.min()) == T == int(last2.min())
+    assert_bit_exact(w, w2, "weights after a period of sweep shares vs one full sweep")
+    assert_bit_exact(m, m2, "first moments")
+    assert_bit_exact(v, v2, "second moments")
