@@ -12,12 +12,16 @@
 // is never materialised); the bias gradient accumulated from the staged gradient tiles of the wgrad; the
 // `beta * C` term of the first DIN layer's mini-batch-aware regulariser in the dgrad store.
 //
-// Tile engine: workgroup = 4 waves = 64 x 64 output tile, one 32 x 32 sub-tile per wave held as TWO interleaved
-// accumulator chains (even / odd reduction steps, summed in the epilogue), reduction chunks of 32 through a 3-slot LDS
-// ring with one barrier per chunk; every piece of non-MFMA work of an iteration (global loads three chunks ahead,
-// LDS -> operand registers of the next chunk, registers -> LDS of the chunk after) is issued in the shadow of the
-// iteration's own 16 MFMAs at fixed slots (see tile_mainloop_impl).  LDS layouts are chosen per operand form so that
-// every MFMA operand read is a conflict-free ds_read_b32:
+// Tile engine: workgroup = 4 waves = 64 x 64 output tile, one 32 x 32 sub-tile per wave, reduction chunks of 32 through a
+// 3-slot LDS ring with one barrier per chunk.  Float4-addressable operands (every layer of the benchmark models) run on the
+// round-5 main loop of tile_v2.h: reduction-contiguous operands are fetched from LDS as ONE ds_read_b128 per four MFMA steps
+// (row stride 36), tiles are staged with ds_write_b128, fragments are double-buffered per group of four steps — 0.3-1.25 LDS
+// instructions per MFMA instead of 2.4, main loop at 0.93 of the matrix pipe's rate (round 2: 0.76; scripts/mfma_lab.hip,
+// profiles/r05_mfma_lab.md).  Everything below about ds_read_b32 layouts describes the round-2 main loop, which remains for
+// operands that are not float4-addressable (the reference's default DCN input width 82, odd leading dimensions): one 32 x 32
+// sub-tile per wave held as TWO interleaved accumulator chains, every piece of non-MFMA work of an iteration issued in the
+// shadow of the iteration's own 16 MFMAs at fixed slots (see tile_mainloop_impl), LDS layouts chosen per operand form so
+// that every MFMA operand read is a conflict-free ds_read_b32:
 //   red-contiguous operand ([idx][red] in memory): LDS [64 idx][32 red], row stride 33 (odd): lane l reads
 //       [idx0 + (l & 31)][kk + (l >> 5)] -> 32 distinct banks per half wave; staged by 4 scalar stores;
 //   red-major operand ([red][idx] in memory): LDS [32 red][64 idx], row stride 64: lanes read 32 consecutive
@@ -31,6 +35,7 @@
 
 #include "common.h"
 #include "act.h"
+#include "tile_v2.h"
 
 namespace {
 
@@ -40,7 +45,7 @@ constexpr int kThreads = 256;
 constexpr int BM = 64, BN = 64, BK = 32;
 constexpr int kLdRC = BK + 1;                     // red-contiguous operand: [64][33]
 constexpr int kLdRM = 64;                         // red-major operand:      [32][64]
-constexpr int kBufFloats = 64 * kLdRC;            // 2112 >= 32 * 64
+constexpr int kBufFloats = 64 * tv2::kLdRC;       // 2304: a ring slot of either main loop (round 2: 64 * 33, 32 * 64)
 
 struct Operand {
     const float* p;        // RC: [n_idx][ld] (red contiguous)   RM: [n_red][ld] (idx contiguous)
@@ -291,8 +296,19 @@ __device__ __forceinline__ void tile_mainloop(const Segment& sg, int m0, int n0,
                                               float* __restrict__ As, float* __restrict__ Bs, f32x16& acc, f32x16& acc1, float4& colsum) {
     // whole chunks only (and, for a batch split, split boundaries on chunk boundaries): wave-uniform
     const bool exact = FAST && ((red_end - red_begin) % BK == 0) && (red_begin % BK == 0);
-    if (exact) tile_mainloop_impl<A_RC, B_RC, FAST, MASK_A, MASK_B, COLSUM, FAST>(sg, m0, n0, M, N, red_begin, red_end, As, Bs, acc, acc1, colsum);
-    else tile_mainloop_impl<A_RC, B_RC, FAST, MASK_A, MASK_B, COLSUM, false>(sg, m0, n0, M, N, red_begin, red_end, As, Bs, acc, acc1, colsum);
+    if constexpr (FAST) {
+        // round-5 main loop (tile_v2.h), one sub-tile per wave: same workgroup tile, same wave -> (row, column) map, same
+        // staging thread -> column map (COLSUM) as the round-2 loop below, so every epilogue of this file serves both
+        static_assert(tv2::Geom<true, 1>::kFloats <= kBufFloats && tv2::Geom<false, 1>::kFloats <= kBufFloats, "ring slot size");
+        const tv2::Operand a{sg.a.p, sg.a.mask, sg.a.ld, sg.a.bytes}, b{sg.b.p, sg.b.mask, sg.b.ld, sg.b.bytes};
+        // (two chains per element, as in the round-2 loop: acc takes the even groups of four steps, acc1 the odd ones)
+        tv2::f32x16 (&acc2)[1][1] = *reinterpret_cast<tv2::f32x16 (*)[1][1]>(&acc);
+        tv2::f32x16 (*accb)[1] = reinterpret_cast<tv2::f32x16 (*)[1]>(&acc1);
+        if (exact) tv2::mainloop<A_RC, B_RC, 1, 1, MASK_A, MASK_B, COLSUM, true, true>(a, b, m0, n0, M, N, red_begin, red_end, As, Bs, acc2, colsum, accb);
+        else tv2::mainloop<A_RC, B_RC, 1, 1, MASK_A, MASK_B, COLSUM, false, true>(a, b, m0, n0, M, N, red_begin, red_end, As, Bs, acc2, colsum, accb);
+    } else {
+        tile_mainloop_impl<A_RC, B_RC, FAST, MASK_A, MASK_B, COLSUM, false>(sg, m0, n0, M, N, red_begin, red_end, As, Bs, acc, acc1, colsum);
+    }
 }
 
 // XCD-aware linear block -> (tile_m, tile_n): block b runs on XCD b % 8; give every XCD a contiguous
@@ -320,6 +336,7 @@ struct FwdArgs {
     const float* act_alpha;    // [N]
     int act_kind;              // 0: none, 1 + RECALGO_ACT_PRELU, 1 + RECALGO_ACT_DICE
     float* z;                  // [M][ldy]
+    int vec_store;             // y is float4-addressable (base, ldy, N): the plain epilogue writes whole row segments
 };
 
 template <bool FAST>
@@ -333,12 +350,26 @@ __global__ __launch_bounds__(kThreads) void dense_fwd_kernel(FwdArgs P) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
     float4 unused = f4_zero();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hi = lane >> 5, l32 = lane & 31;
+    // (row-wise epilogue: the lane's four bias values are requested before the main loop, not behind it)
+    const bool rowwise = FAST && P.vec_store && P.bn_partials == nullptr;
+    const int c4 = n0 + (wave & 1) * 32 + (lane & 7) * 4;
+    float4 bias4 = f4_zero();
+    if (rowwise && P.bias && c4 < P.N) bias4 = *reinterpret_cast<const float4*>(P.bias + c4);
     for (int s = 0; s < P.nseg; ++s)
         tile_mainloop<true, false, FAST, false, false, false>(P.seg[s], m0, n0, P.M, P.N, 0, P.seg[s].n_red, As, Bs, acc, acc1, unused);
     acc += acc1;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int hi = lane >> 5, l32 = lane & 31;
     const int col = n0 + (wave & 1) * 32 + l32;
+    if (rowwise) {
+        const int r0 = m0 + (wave >> 1) * 32;
+        tv2::tile_rows(As + wave * tv2::kTileScratch, acc, [&](int row, int, float4 v) {
+            v = f4_add(v, bias4);
+            if (P.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+            if (r0 + row < P.M && c4 < P.N) *reinterpret_cast<float4*>(P.y + (size_t)(r0 + row) * P.ldy + c4) = v;
+        });
+        return;
+    }
     if (P.bn_partials == nullptr) {
         if (col >= P.N) return;
         const float bv = P.bias ? P.bias[col] : 0.f;
@@ -409,6 +440,7 @@ struct DgradArgs {
     int M, K;              // output is [M][K]
     int accumulate;        // dx += result (the second operand pair of the PNN layer)
     int tiles_per_block;   // consecutive output tiles one workgroup computes (>= 1; see bwd_balance)
+    int vec_store;         // dx (and c_in) float4-addressable: the plain epilogue writes whole row segments
     // optional: this layer's input is the output of a training-mode BatchNorm over bn_x [M][K] (contiguous) with the batch
     // statistics bn_mean / bn_rstd [K] — the epilogue leaves the sums that BatchNorm's backward starts with, per 64-row tile:
     // bn_partials[tile][0:K] = colsum(dx), [K:2K] = colsum(dx * xhat) (the partial rows of recalgo_batchnorm_bwd_sums)
@@ -450,6 +482,17 @@ __device__ __forceinline__ void dgrad_tile(const DgradArgs& P, int block, int nb
         tile_mainloop<true, true, FAST, MASK, false, false>(P.seg, m0, n0, P.M, P.K, 0, P.seg.n_red, As, Bs, acc, acc1, unused);
         acc += acc1;
         if (P.bn_partials == nullptr) {
+            if (FAST && P.vec_store) {
+                const int r0 = m0 + (wave >> 1) * 32, c4 = n0 + (wave & 1) * 32 + (lane & 7) * 4;
+                tv2::tile_rows(As + wave * tv2::kTileScratch, acc, [&](int row, int, float4 v) {
+                    if (r0 + row < P.M && c4 < P.K) {
+                        if (P.c_in) v = f4_fma(*reinterpret_cast<const float4*>(P.c_in + (size_t)(r0 + row) * P.ldc + c4), P.beta, v);
+                        float4* o = reinterpret_cast<float4*>(P.dx + (size_t)(r0 + row) * P.lddx + c4);
+                        *o = P.accumulate ? f4_add(*o, v) : v;
+                    }
+                });
+                continue;                                         // (the next tile's main loop starts with a barrier)
+            }
             if (col < P.K) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -514,6 +557,7 @@ struct WgradArgs {
     float* dbias_out;      // splits == 1: dbias or null
     int want_dbias;
     size_t slab;           // floats per split slab (K*N + N rounded)
+    int vec_store;         // the output (slab or dW) is float4-addressable
 };
 
 template <bool FAST, bool MASK>
@@ -548,7 +592,13 @@ __device__ __forceinline__ void wgrad_tile(const WgradArgs& P, int block, float*
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hi = lane >> 5, l32 = lane & 31;
     const int col = n0 + (wave & 1) * 32 + l32;
-    if (col < P.N) {
+    if (FAST && P.vec_store) {
+        const int r0 = m0 + (wave >> 1) * 32, c4 = n0 + (wave & 1) * 32 + (lane & 7) * 4;
+        // (the wave's scratch lies in Bs: the bias sums below go through As)
+        tv2::tile_rows(Bs + wave * tv2::kTileScratch, acc, [&](int row, int, float4 v) {
+            if (r0 + row < P.K && c4 < P.N) *reinterpret_cast<float4*>(base + (size_t)(r0 + row) * P.N + c4) = v;
+        });
+    } else if (col < P.N) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -768,6 +818,7 @@ RECALGO_EXPORT int recalgo_dense_fwd_act_bn(const float* x, int ldx, const float
     P.bias = bias; P.relu = relu; P.y = y; P.ldy = ldy; P.M = M; P.N = N;
     P.bn_partials = bn_partials;
     P.act_alpha = act_alpha; P.act_kind = act_kind == RECALGO_ACT_NONE ? 0 : 1 + act_kind; P.z = z;
+    P.vec_store = (aligned16(y) && ldy % 4 == 0 && N % 4 == 0 && (bias == nullptr || aligned16(bias))) ? 1 : 0;
     const int grid = cdiv(M, BM) * cdiv(N, BN);
     const bool fast = fast_rc(P.seg[0].a, K) && fast_rm(P.seg[0].b, N) && fast_rc(P.seg[1].a, K2) && fast_rm(P.seg[1].b, N);
     if (fast) hipLaunchKernelGGL(dense_fwd_kernel<true>, dim3(grid), dim3(kThreads), 0, as_stream(stream), P);
@@ -784,6 +835,7 @@ static bool build_dgrad(DgradArgs& P, const float* g, int ldg, const float* y_ma
     P.c_in = c_in; P.beta = beta; P.ldc = ldc; P.dx = dx; P.lddx = lddx; P.M = M; P.K = K; P.accumulate = accumulate;
     P.tiles_per_block = 1;
     P.bn_x = P.bn_mean = P.bn_rstd = nullptr; P.bn_partials = nullptr;
+    P.vec_store = (aligned16(dx) && lddx % 4 == 0 && K % 4 == 0 && (c_in == nullptr || (aligned16(c_in) && ldc % 4 == 0))) ? 1 : 0;
     return true;
 }
 static bool dgrad_fast(const DgradArgs& P) { return fast_rc(P.seg.a, P.seg.n_red) && fast_rc(P.seg.b, P.seg.n_red); }
@@ -843,6 +895,7 @@ static int build_wgrad(WgradArgs& P, const float* x, int ldx, const float* g, in
     P.slab = S == 1 ? 0 : wgrad_slab(K, N);
     P.out = S == 1 ? dw : static_cast<float*>(workspace);
     P.dbias_out = dbias;
+    P.vec_store = (aligned16(P.out) && N % 4 == 0) ? 1 : 0;
     return S;
 }
 static bool wgrad_fast(const WgradArgs& P) { return fast_rm(P.seg.a, P.K) && fast_rm(P.seg.b, P.N); }
