@@ -36,7 +36,7 @@ extern "C" {
 typedef void* recalgo_stream_t; /* hipStream_t */
 
 /* ABI version of this header (bumped on any signature change). */
-#define RECALGO_ABI_VERSION 1
+#define RECALGO_ABI_VERSION 2
 int recalgo_abi_version(void);
 /* "gfx950" */
 const char* recalgo_target_arch(void);
@@ -649,6 +649,11 @@ int recalgo_adam_tf1_advance(int64_t* step_dev, float lr, float beta1, float bet
  * a fixed order by the workgroup that finishes last (bit-reproducible).  workspace: recalgo_concat_sumsq_workspace_bytes(B)
  * bytes, the first 64 zero-filled once before the first use. */
 int64_t recalgo_concat_sumsq_workspace_bytes(int B);
+/* dst[0, nbytes) = src[0, nbytes), device to device, one launch sized to the chip (the batch of a captured training step —
+ * id matrix + labels, one allocation, ~0.9 MB — into the graph's static input buffers: the runtime's own copy kernel takes
+ * 7 us for it, this one ~2).  Any alignment; the ranges must not overlap.  Stands for the feed of
+ * dataset.make_one_shot_iterator().get_next() into the graph (algorithm/DCN/dcn.py:216-225). */
+int recalgo_copy_bytes(void* dst, const void* src, int64_t nbytes, recalgo_stream_t stream);
 int recalgo_concat_sumsq(const float* const* parts, const int* widths, int n_parts, int B, float* out, float scale,
                          float* sum_out, void* workspace, recalgo_stream_t stream);
 int recalgo_activation_fwd(const float* x, const float* alpha, int rows, int C, int kind, float* y,

@@ -14,11 +14,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RECALGO_HIP_LIB") or os.path.join(_HERE, "librecalgo_hip.so")
 
 P = c_void_p  # device pointer / stream
+ABI_VERSION = 2  # == RECALGO_ABI_VERSION of include/recalgo.h (bumped on any signature change)
 
 # name -> (restype, argtypes); must list every function of include/recalgo.h
 SIGNATURES = {
     "recalgo_abi_version": (c_int, []),
     "recalgo_target_arch": (c_char_p, []),
+    "recalgo_copy_bytes": (c_int, [P, P, c_int64, P]),
     "recalgo_embedding_gather_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P, c_int, c_int, P]),
     "recalgo_embedding_gather_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "recalgo_scatter_rows_sorted": (c_int, [P, P, P, c_int64, c_int, P, P]),
@@ -152,8 +154,9 @@ def load(path: str = LIB_PATH) -> ctypes.CDLL:
             raise RecalgoError(f"{path} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.recalgo_abi_version() != 1:
-        raise RecalgoError("librecalgo_hip.so ABI version mismatch")
+    if lib.recalgo_abi_version() != ABI_VERSION:
+        raise RecalgoError(f"{path}: ABI version {lib.recalgo_abi_version()}, this binding expects {ABI_VERSION} "
+                           "(a stale build: python -m recalgorithm_amd.build)")
     _lib = lib
     return lib
 

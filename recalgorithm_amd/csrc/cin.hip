@@ -205,6 +205,188 @@ __global__ __launch_bounds__(kThreads, NT <= 2 ? 3 : 2) void cin_contract_kernel
 }
 
 // ---------------------------------------------------------------------------------------------
+// Round 5: the same contraction for the forward shapes of the benchmark (HQ = m <= 32 values of Q per row, C <= 128
+// filter columns, float4-addressable filter), restructured after the lessons of tile_v2.h / profiles/r05_mfma_lab.md:
+//   * a lane's Q values (X^0[b, q = 2 s + hi, d], NSTEP <= 16 of them) live in REGISTERS for the whole kernel: the A operand
+//     of a step is one v_mul of two registers — no LDS read (the kernel above reads Q from LDS for every step);
+//   * a workgroup covers ALL C <= 128 columns with NT sub-tiles interleaved along the columns (sub-tile j holds column
+//     NT * l32 + j): ONE ds_read_b128 of the filter slab feeds the step's four MFMAs (above: one ds_read_b32 per MFMA, two
+//     column chunks per layer each forming the outer-product operand again);
+//   * a slab = the HQ filter rows of ONE p, staged as float4 (global -> registers three slabs ahead -> ds_write_b128) through a
+//     3-slot LDS ring, ONE barrier per slab = per NSTEP * NT <= 52 MFMAs (above: per 32, with scalar loads and stores);
+//   * every non-MFMA instruction is pinned behind a fixed MFMA (sched_barrier), the two-level accumulation is unchanged
+//     (same flush period, same step order: the results are bit-identical to the kernel above).
+// LDS instructions per MFMA: 0.25 + 8 tile stores per 52 (above: 1.5 + 16 scalar stores per 32).
+// ---------------------------------------------------------------------------------------------
+template <int D, int NT, int NSTEP>
+__global__ __launch_bounds__(kThreads, 2) void cin_contract2_kernel(
+    const float* __restrict__ P, const float* __restrict__ Q, const float* __restrict__ F, unsigned B, unsigned HP,
+    unsigned HQ, unsigned C, float* __restrict__ out, int accumulate, float* __restrict__ pool, unsigned pool_stride,
+    unsigned pool_col) {
+    constexpr unsigned EX = kTM / D;           // examples per workgroup
+    constexpr unsigned CS = NT * 32;           // LDS row stride of a slab (columns zero padded)
+    constexpr unsigned QR = 2 * NSTEP;         // slab rows (q zero padded)
+    constexpr unsigned kSlab = QR * CS;        // floats per ring slot
+    constexpr unsigned kStg = (kSlab / 4 + kThreads - 1) / kThreads;     // staged float4 per thread and slab
+    __shared__ __attribute__((aligned(16))) float Fs[3 * kSlab];
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned hi = lane >> 5, l32 = lane & 31;
+    const unsigned row = wave * 32 + l32;      // row of the workgroup tile this lane feeds as A
+    const unsigned exl = row / D, dd = row % D;
+    const unsigned b = blockIdx.x * EX + exl;
+    const bool valid = b < B;
+
+    for (unsigned e = tid; e < 3 * kSlab / 4; e += kThreads) reinterpret_cast<float4*>(Fs)[e] = f4_zero();   // padding rows / columns stay 0
+    float qreg[NSTEP];
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+        const unsigned q = 2 * s + hi;
+        qreg[s] = (valid && q < HQ) ? Q[((size_t)b * HQ + q) * D + dd] : 0.f;
+    }
+    // slab p: rows [p * HQ, (p + 1) * HQ) of F, contiguous (row stride C), C % 4 == 0
+    const unsigned n4 = HQ * C / 4;
+    const unsigned C4 = C / 4;
+    unsigned lds_off[kStg];
+#pragma unroll
+    for (unsigned k = 0; k < kStg; ++k) {
+        const unsigned e = tid + k * kThreads;
+        lds_off[k] = (e / C4) * CS + (e % C4) * 4;
+    }
+    auto stage_load = [&](unsigned p, float4 (&st)[kStg]) {
+        const float4* src = reinterpret_cast<const float4*>(F + (size_t)min(p, HP - 1) * HQ * C);   // (slabs past the end: reloaded, never used)
+#pragma unroll
+        for (unsigned k = 0; k < kStg; ++k) {
+            const unsigned e = tid + k * kThreads;
+            st[k] = e < n4 ? src[e] : f4_zero();
+        }
+    };
+    auto stage_store = [&](unsigned slot, const float4 (&st)[kStg], unsigned k) {
+        if (tid + k * kThreads < n4) *reinterpret_cast<float4*>(Fs + slot * kSlab + lds_off[k]) = st[k];
+    };
+    float4 st0[kStg], st1[kStg];
+    stage_load(0, st0);
+    stage_load(1, st1);
+    const float* Pp = P + ((size_t)b * HP) * D + dd;       // P[b, p, dd] at stride D
+    float a_p = valid ? Pp[0] : 0.f;
+    float a_n1 = (valid && HP > 1) ? Pp[D] : 0.f;          // p + 1
+    __syncthreads();                                        // zero fill done
+#pragma unroll
+    for (unsigned k = 0; k < kStg; ++k) stage_store(0, st0, k);
+#pragma unroll
+    for (unsigned k = 0; k < kStg; ++k) stage_store(1, st1, k);
+    stage_load(2, st0);
+    __syncthreads();
+
+    f32x16 acc[NT], tot[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = tot[nt][r] = 0.f;
+    const unsigned rows_per_slab = min(HQ, (unsigned)kQC);
+    const unsigned flush_every = max(1u, (208u + rows_per_slab / 2) / rows_per_slab);
+    unsigned since_flush = 0;
+
+    // operand values of one step: NT consecutive columns of slab row 2 s + hi
+    struct FragB { float x[NT]; };
+    auto read_frag = [&](unsigned slot, int s, FragB& f) {
+        const float* ptr = Fs + slot * kSlab + (2 * s + hi) * CS + NT * l32;
+        if constexpr (NT == 1) f.x[0] = ptr[0];
+        else if constexpr (NT == 2) { const float2 v = *reinterpret_cast<const float2*>(ptr); f.x[0] = v.x; f.x[1] = v.y; }
+        else { const float4 v = *reinterpret_cast<const float4*>(ptr); f.x[0] = v.x; f.x[1] = v.y; f.x[2] = v.z; f.x[3] = v.w; }
+    };
+    FragB fb[2], fnext;
+    read_frag(0, 0, fb[0]);
+    unsigned s0 = 0, s1 = 1, s2 = 2;                        // ring slots of slabs p, p+1, p+2
+    auto step = [&](unsigned p, float4 (&cur)[kStg], float4 (&nxt)[kStg]) {
+        float a_n2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const float a = a_p * qreg[s];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, fb[s & 1].x[j], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j == 0) {
+                    // fragments of the next step (the first step of the next slab goes to `fnext`: NSTEP may be odd)
+                    if (s + 1 < NSTEP) read_frag(s0, s + 1, fb[(s + 1) & 1]);
+                    else read_frag(s1, 0, fnext);
+                }
+                if (j == NT - 1) {
+                    // global loads of slab p + 3 (steps 0 ..), P of p + 2 (step 1), registers of slab p + 2 -> LDS (from the middle on)
+                    if (s < (int)kStg) {
+                        const unsigned e = tid + s * kThreads;
+                        const float4* src = reinterpret_cast<const float4*>(F + (size_t)min(p + 3, HP - 1) * HQ * C);
+                        nxt[s] = e < n4 ? src[e] : f4_zero();
+                    }
+                    if (s == 1) a_n2 = (valid && p + 2 < HP) ? Pp[(size_t)(p + 2) * D] : 0.f;
+                    constexpr int w0 = NSTEP / 2;
+                    if (s >= w0 && s < w0 + (int)kStg) stage_store(s2, cur, s - w0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (++since_flush == flush_every || p + 1 == HP) {   // uniform over the workgroup
+            since_flush = 0;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    tot[nt][r] += acc[nt][r];
+                    acc[nt][r] = 0.f;
+                }
+        }
+        fb[0] = fnext;
+        a_p = a_n1;
+        a_n1 = a_n2;
+        const unsigned t = s0;
+        s0 = s1; s1 = s2; s2 = t;
+        __syncthreads();
+    };
+    static_assert((int)kStg <= NSTEP / 2 && NSTEP / 2 + (int)kStg <= NSTEP, "side-work slots");
+    for (unsigned p = 0; p < HP; p += 2) {
+        step(p, st0, st1);
+        if (p + 1 < HP) step(p + 1, st1, st0);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = tot[nt];
+
+    // ---- epilogue: out[b, c, d] (float4 of 4 consecutive d) and the sum-pooling over d; column of (sub-tile nt, lane) = NT * l32 + nt
+    const unsigned R0 = blockIdx.x * kTM + wave * 32;      // first (b,d) row of this wave's tile
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const unsigned c = NT * l32 + nt;
+        const bool cok = c < C;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const unsigned R = R0 + 8 * g4 + 4 * hi;
+            const unsigned bb = R / D, d0 = R % D;
+            if (cok && bb < B) {
+                float4* o = reinterpret_cast<float4*>(out + ((size_t)bb * C + c) * D + d0);
+                float4 v = make_float4(acc[nt][4 * g4 + 0], acc[nt][4 * g4 + 1], acc[nt][4 * g4 + 2], acc[nt][4 * g4 + 3]);
+                if (accumulate) v = f4_add(v, *o);
+                *o = v;
+            }
+        }
+        if (pool) {
+            static_assert(D >= 8, "cin_contract2: D >= 8");
+            constexpr int EXW = 32 / D;                 // examples per wave tile
+            constexpr int GPE = 4 / EXW;                // reg groups (of 4 rows x 2 halves) per example
+#pragma unroll
+            for (int e = 0; e < EXW; ++e) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int g = 0; g < GPE; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc += acc[nt][4 * (e * GPE + g) + r];
+                sacc += __shfl_xor(sacc, 32, 64);
+                const unsigned bb = R0 / D + e;
+                if (hi == 0 && cok && bb < B) pool[(size_t)bb * pool_stride + pool_col + c] = sacc;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // input gradients, fused: ONE implicit GEMM  dA^T[(i,j), (b,d)] = sum_n W[(i,j), n] * G[(b,d), n]
 // (the gradient of the never-materialised outer product) whose tiles are consumed on the fly:
 //   dX^k[b,i,d] = sum_j dA[(b,d),(i,j)] * X^0[b,j,d]     dX^0[b,j,d] = sum_i dA[(b,d),(i,j)] * X^k[b,i,d]
@@ -563,9 +745,30 @@ int launch_contract_D(int NT, const float* P, const float* Q, const float* F, in
 
 // out[b, c0:c0+C', d] for C' <= 128 per launch (column chunks of the filter are strided views, so
 // chunking over C needs a compact filter: handled by the callers with C <= 128)
+template <int D, int NT, int NSTEP>
+int launch_contract2(const float* P, const float* Q, const float* F, int B, int HP, int HQ, int C, float* out, int accumulate,
+                     float* pool, int pool_stride, int pool_col, hipStream_t st) {
+    hipLaunchKernelGGL((cin_contract2_kernel<D, NT, NSTEP>), dim3(cdiv((int64_t)B * D, kTM)), dim3(kThreads), 0, st, P, Q, F,
+                       (unsigned)B, (unsigned)HP, (unsigned)HQ, (unsigned)C, out, accumulate, pool, (unsigned)pool_stride,
+                       (unsigned)pool_col);
+    return (int)hipGetLastError();
+}
+
 int launch_contract(const float* P, const float* Q, const float* F, int B, int HP, int HQ, int C, int D, float* out,
                     int accumulate, float* pool, int pool_stride, int pool_col, hipStream_t st) {
     if (C <= 0 || C > 128) return (int)hipErrorInvalidValue;
+    // the register-resident-Q kernel: emb width 16, 17 .. 32 fields (13 .. 16 steps per slab: at most 3 of 16 padded), filter
+    // columns in whole float4s and in (32, 64] or (96, 128] (2 or 4 full column tiles); everything else takes the general kernel
+    if (D == 16 && HQ > 16 && HQ <= 32 && C % 4 == 0 && (reinterpret_cast<uintptr_t>(F) & 15) == 0 && HP >= 1 &&
+        ((C > 32 && C <= 64) || (C > 96 && C <= 128))) {
+        const bool wide = C > 64;
+#define RECALGO_CIN2(NSTEP)                                                                                                          \
+    return wide ? launch_contract2<16, 4, NSTEP>(P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st)           \
+                : launch_contract2<16, 2, NSTEP>(P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st)
+        if (HQ <= 26) { RECALGO_CIN2(13); }
+        RECALGO_CIN2(16);
+#undef RECALGO_CIN2
+    }
     const int NT = cdiv(C, 32);
     switch (D) {
         case 4: return launch_contract_D<4>(NT, P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);

@@ -629,6 +629,46 @@ RECALGO_EXPORT int recalgo_concat_sumsq(const float* const* parts, const int* wi
 namespace {
 }  // namespace
 
+namespace {
+// 16 bytes per thread and pass (8 in flight per thread for large spans); a head / tail of single bytes for any alignment
+__global__ __launch_bounds__(256) void copy_bytes_kernel(unsigned char* __restrict__ dst, const unsigned char* __restrict__ src,
+                                                         size_t head, size_t n16, size_t nbytes) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, T = (size_t)gridDim.x * 256;
+    const uint4* s16 = reinterpret_cast<const uint4*>(src + head);
+    uint4* d16 = reinterpret_cast<uint4*>(dst + head);
+    size_t i = t;
+    for (; i + 3 * T < n16; i += 4 * T) {
+        const uint4 a = s16[i], b = s16[i + T], c = s16[i + 2 * T], d = s16[i + 3 * T];
+        d16[i] = a; d16[i + T] = b; d16[i + 2 * T] = c; d16[i + 3 * T] = d;
+    }
+    for (; i < n16; i += T) d16[i] = s16[i];
+    if (t < head) dst[t] = src[t];
+    const size_t tail0 = head + n16 * 16;
+    if (tail0 + t < nbytes && t < 16) dst[tail0 + t] = src[tail0 + t];
+}
+}  // namespace
+
+RECALGO_EXPORT int recalgo_copy_bytes(void* dst, const void* src, int64_t nbytes, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(nbytes >= 0 && (nbytes == 0 || (dst != nullptr && src != nullptr)));
+    if (nbytes == 0) return 0;
+    const uintptr_t d = reinterpret_cast<uintptr_t>(dst), s = reinterpret_cast<uintptr_t>(src);
+    size_t head = 0, n16 = 0;
+    if ((d & 15) == (s & 15)) {                       // same phase: vector body between a byte head and a byte tail
+        head = (16 - (d & 15)) & 15;
+        if (head > (size_t)nbytes) head = (size_t)nbytes;
+        n16 = ((size_t)nbytes - head) / 16;
+    } else {
+        // different phase: whole span by the byte lanes (rare: every batch allocation of the library is 256-byte aligned);
+        // handled as repeated launches of the byte paths below would be slow, so fall back to the runtime's copy
+        return (int)hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyDeviceToDevice, as_stream(stream));
+    }
+    const size_t want = (n16 + 255) / 256;
+    const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+    hipLaunchKernelGGL(copy_bytes_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), static_cast<unsigned char*>(dst),
+                       static_cast<const unsigned char*>(src), head, n16, (size_t)nbytes);
+    RECALGO_RETURN_LAST();
+}
+
 RECALGO_EXPORT int recalgo_abi_version(void) { return RECALGO_ABI_VERSION; }
 RECALGO_EXPORT const char* recalgo_target_arch(void) { return "gfx950"; }
 

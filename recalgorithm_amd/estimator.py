@@ -357,7 +357,7 @@ class GraphedTrainStep:
         are moved by a single whole-allocation copy."""
         span = getattr(features, "device_span", None)
         if span is not None and self._span_plan is not None and span[1] == self._span_plan[0]:
-            self._span_plan[1].copy_(span[0], non_blocking=True)
+            _device_copy(self._span_plan[1], span[0])
             return
         new = list(_tree_tensors(features, "f")) + list(_tree_tensors(labels, "l"))
         if len(new) != len(self._static):
@@ -390,7 +390,7 @@ class GraphedTrainStep:
                         dv = torch.empty(0, dtype=torch.uint8, device=d0.device).set_(d0.untyped_storage(), d_lo, (d_hi - d_lo,), (1,))
                         self._dst_views[(spans[items[0][0]][0], d_lo, d_hi)] = dv
                     sv = torch.empty(0, dtype=torch.uint8, device=s0.device).set_(s0.untyped_storage(), s_lo, (d_hi - d_lo,), (1,))
-                    dv.copy_(sv, non_blocking=True)
+                    _device_copy(dv, sv)
                     continue
             singles.extend(i for i, _ in items)
         for i in singles:                        # (after every span copy: a per-tensor copy is never overwritten by one)
@@ -418,6 +418,17 @@ class GraphedTrainStep:
 # --------------------------------------------------------------------------------------------
 # Estimator
 # --------------------------------------------------------------------------------------------
+def _device_copy(dst: torch.Tensor, src: torch.Tensor) -> None:
+    """The batch -> static input buffer copy of a captured step.  Device to device on one GPU it is the library's own copy
+    kernel (recalgo_copy_bytes: ~2 us for the 0.9 MB of a 4096-example batch; the runtime's copy kernel took 7.1 us of the
+    230 us DCN step, profiles/r04zz_dcn_kernel_stats.md)."""
+    if dst.is_cuda and src.is_cuda and dst.device == src.device and dst.is_contiguous() and src.is_contiguous():
+        from . import ops
+        ops.copy_bytes(dst, src)
+    else:
+        dst.copy_(src, non_blocking=True)
+
+
 def _host_copy(dst: torch.Tensor, src: torch.Tensor) -> None:
     """dst.copy_(src) for host tensors on the training loop's thread.  Same dtype, both contiguous: ONE memmove — a batch's
     id matrix is ~1 MB, for which Tensor.copy_ starts an intra-op parallel region over every core of the host (128 threads

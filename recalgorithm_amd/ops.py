@@ -36,6 +36,14 @@ def _stream(t: torch.Tensor):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+def copy_bytes(dst: torch.Tensor, src: torch.Tensor) -> None:
+    """dst <- src for two contiguous device tensors of the same byte length on one device (recalgo_copy_bytes)."""
+    n = dst.numel() * dst.element_size()
+    if n != src.numel() * src.element_size() or not dst.is_contiguous() or not src.is_contiguous() or dst.device != src.device:
+        raise ValueError("copy_bytes: contiguous tensors of equal byte length on one device")
+    _lib.check(_lib_().recalgo_copy_bytes(_p(dst), _p(src), n, _stream(dst)), "recalgo_copy_bytes")
+
+
 def _chk(t: torch.Tensor, dtype, name: str):
     if t.dtype != dtype:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")

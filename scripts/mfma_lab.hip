@@ -379,20 +379,20 @@ static void run_fwd(const char* tag, int M, int K, int N, const float* x, const 
     snprintf(buf, sizeof buf, "%s fwd v2<%d,%d> epi %d %dx%dx%d grid %d", tag, WM, WN, EPI, M, K, N, grid);
     report(buf, us, 2.0 * M * K * N, err);
 }
-template <int WM, int WN>
+template <int WM, int WN, bool MASK = true>
 static void run_dgrad(const char* tag, int M, int K, int N, const float* g, const float* ymask, const float* w, float* dx, const float* ref) {
     DgradP P{operand(g, ymask, N, M, N), operand(w, nullptr, N, K, N), dx, M, N, K};
     const int grid = ((M + 64 * WM - 1) / (64 * WM)) * ((K + 64 * WN - 1) / (64 * WN));
     CK(hipMemset(dx, 0, (size_t)M * K * sizeof(float)));
-    hipLaunchKernelGGL((dgrad_kernel<WM, WN, true>), dim3(grid), dim3(kThreads), 0, 0, P);
+    hipLaunchKernelGGL((dgrad_kernel<WM, WN, MASK>), dim3(grid), dim3(kThreads), 0, 0, P);
     CK(hipDeviceSynchronize());
     const double err = ref ? compare(dx, ref, (size_t)M * K) : -1.0;
-    const double us = time_us([&] { hipLaunchKernelGGL((dgrad_kernel<WM, WN, true>), dim3(grid), dim3(kThreads), 0, 0, P); });
+    const double us = time_us([&] { hipLaunchKernelGGL((dgrad_kernel<WM, WN, MASK>), dim3(grid), dim3(kThreads), 0, 0, P); });
     char buf[160];
-    snprintf(buf, sizeof buf, "%s dgrad v2<%d,%d> %dx%dx%d grid %d", tag, WM, WN, M, K, N, grid);
+    snprintf(buf, sizeof buf, "%s dgrad v2<%d,%d> mask %d %dx%dx%d grid %d", tag, WM, WN, (int)MASK, M, K, N, grid);
     report(buf, us, 2.0 * M * K * N, err);
 }
-template <int WM, int WN>
+template <int WM, int WN, bool MASK = true>
 static void run_wgrad(const char* tag, int M, int K, int N, int splits, const float* x, const float* g, const float* ymask, float* ws,
                       float* dw, const float* ref_dw, const float* ref_db) {
     WgradP P;
@@ -403,15 +403,15 @@ static void run_wgrad(const char* tag, int M, int K, int N, int splits, const fl
     P.slab = ((size_t)K * N + N + 3) / 4 * 4;
     const int grid = ((K + 64 * WM - 1) / (64 * WM)) * ((N + 64 * WN - 1) / (64 * WN)) * splits;
     CK(hipMemset(ws, 0, P.slab * splits * sizeof(float)));
-    hipLaunchKernelGGL((wgrad_kernel<WM, WN, true>), dim3(grid), dim3(kThreads), 0, 0, P);
+    hipLaunchKernelGGL((wgrad_kernel<WM, WN, MASK>), dim3(grid), dim3(kThreads), 0, 0, P);
     const size_t n = (size_t)K * N + N;
     hipLaunchKernelGGL(sum_slabs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, ws, dw, P.slab, n, splits);
     CK(hipDeviceSynchronize());
     double err = -1.0;
     if (ref_dw) err = std::max(compare(dw, ref_dw, (size_t)K * N), compare(dw + (size_t)K * N, ref_db, (size_t)N));
-    const double us = time_us([&] { hipLaunchKernelGGL((wgrad_kernel<WM, WN, true>), dim3(grid), dim3(kThreads), 0, 0, P); });
+    const double us = time_us([&] { hipLaunchKernelGGL((wgrad_kernel<WM, WN, MASK>), dim3(grid), dim3(kThreads), 0, 0, P); });
     char buf[160];
-    snprintf(buf, sizeof buf, "%s wgrad v2<%d,%d> %dx%dx%d splits %d grid %d", tag, WM, WN, M, K, N, splits, grid);
+    snprintf(buf, sizeof buf, "%s wgrad v2<%d,%d> mask %d %dx%dx%d splits %d grid %d", tag, WM, WN, (int)MASK, M, K, N, splits, grid);
     report(buf, us, 2.0 * M * K * N, err);
 }
 
@@ -532,15 +532,38 @@ int main(int argc, char** argv) {
     CK(hipGetDeviceProperties(&prop, 0));
     printf("# mfma_lab on %s (%d CUs, %d MHz)\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000);
     // exactness on small integers (any summation order gives the same fp32 result) at an odd shape, then the MLP shapes
-    trace_fwd<1, 1, 0>(M, 416, 512);
-    trace_fwd<1, 1, 1>(M, 416, 512);
-    trace_fwd<1, 1, 2>(M, 416, 512);
-    trace_fwd<1, 2, 0>(M, 416, 512);
-    trace_fwd<1, 2, 2>(M, 416, 512);
-    trace_fwd<1, 1, 2>(M, 512, 256);
-    trace_fwd<1, 1, 0>(M, 256, 128);
-    trace_fwd<1, 1, 2>(M, 256, 128);
+    if (trace_only) trace_fwd<1, 1, 0>(M, 416, 512);
+    if (trace_only) trace_fwd<1, 1, 1>(M, 416, 512);
+    if (trace_only) trace_fwd<1, 1, 2>(M, 416, 512);
+    if (trace_only) trace_fwd<1, 2, 0>(M, 416, 512);
+    if (trace_only) trace_fwd<1, 2, 2>(M, 416, 512);
+    if (trace_only) trace_fwd<1, 1, 2>(M, 512, 256);
+    if (trace_only) trace_fwd<1, 1, 0>(M, 256, 128);
+    if (trace_only) trace_fwd<1, 1, 2>(M, 256, 128);
     if (trace_only) return 0;
+    if (argc > 2 && std::string(argv[2]) == "mask") {
+        for (int K : {416, 1664}) {
+            const int N = 512;
+            printf("\n### %d x %d -> %d: mask cost\n| kernel | us | TFLOP/s | of 157.3 | max rel err |\n|---|---:|---:|---:|---:|\n", M, K, N);
+            float* x = dev_rand((size_t)M * K, 1, 1.0f);
+            float* w = dev_rand((size_t)K * N, 2, 1.0f / std::sqrt((float)K));
+            float* g = dev_rand((size_t)M * N, 4, 1.0f);
+            float* y = dev_rand((size_t)M * N, 5, 1.0f);
+            float* dx = dev_zero((size_t)M * K);
+            float* dw = dev_zero((size_t)K * N + N + 16);
+            float* ws = dev_zero((((size_t)K * N + N + 3) / 4 * 4) * 16);
+            run_dgrad<1, 1, true>("", M, K, N, g, y, w, dx, nullptr);
+            run_dgrad<1, 1, false>("", M, K, N, g, y, w, dx, nullptr);
+            run_dgrad<1, 2, true>("", M, K, N, g, y, w, dx, nullptr);
+            run_dgrad<1, 2, false>("", M, K, N, g, y, w, dx, nullptr);
+            run_wgrad<1, 1, true>("", M, K, N, 8, x, g, y, ws, dw, nullptr, nullptr);
+            run_wgrad<1, 1, false>("", M, K, N, 8, x, g, y, ws, dw, nullptr, nullptr);
+            run_wgrad<1, 2, true>("", M, K, N, 16, x, g, y, ws, dw, nullptr, nullptr);
+            run_wgrad<1, 2, false>("", M, K, N, 16, x, g, y, ws, dw, nullptr, nullptr);
+            for (float* p : {x, w, g, y, dx, dw, ws}) CK(hipFree(p));
+        }
+        return 0;
+    }
     layer(200, 96, 72, true);
     layer(M, 416, 512, true);
     layer(M, 512, 256, true);

@@ -41,7 +41,9 @@ def test_ctypes_binding_matches_header(lib_path):
     bound = set(_lib.SIGNATURES)
     assert declared == bound, f"header-only: {declared - bound}; binding-only: {bound - declared}"
     lib = _lib.load()
-    assert lib.recalgo_abi_version() == 1
+    assert lib.recalgo_abi_version() == _lib.ABI_VERSION
+    m = re.search(r"#define RECALGO_ABI_VERSION (\d+)", open(HEADER).read())
+    assert m and int(m.group(1)) == _lib.ABI_VERSION
     assert lib.recalgo_target_arch() == b"gfx950"
 
 

@@ -485,3 +485,25 @@ def test_dense1_head_against_torch(dev, B, widths, bias, skip_dx):
         if dx is not None:
             assert_close(dx, gl.double() * w.double()[off:off + p.shape[1]].t(), what=f"dense1 dx[{i}]")
         off += p.shape[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nbytes,phase", [(0, 0), (1, 0), (15, 3), (16, 0), (4096 * 26 * 8 + 4096 * 4, 0), (1_000_003, 5), (64 << 20, 0)])
+def test_copy_bytes_is_exact(dev, nbytes, phase):
+    """recalgo_copy_bytes (the batch -> static-input copy of a captured step): every byte, any length, any common
+    alignment phase; bytes outside [0, nbytes) stay untouched."""
+    from recalgorithm_amd import ops
+    g = torch.Generator().manual_seed(nbytes + phase)
+    src_all = torch.randint(0, 256, (nbytes + 64,), dtype=torch.uint8, generator=g).to(dev)
+    dst_all = torch.full((nbytes + 64,), 7, dtype=torch.uint8, device=dev)
+    src, dst = src_all[phase:phase + nbytes], dst_all[phase:phase + nbytes]
+    ops.copy_bytes(dst, src)
+    torch.cuda.synchronize()
+    assert torch.equal(dst, src)
+    assert bool((dst_all[:phase] == 7).all()) and bool((dst_all[phase + nbytes:] == 7).all())
+    # different phases on the two sides: the runtime-copy fallback
+    if nbytes > 32:
+        dst2 = dst_all[phase + 1:phase + 1 + nbytes - 1]
+        ops.copy_bytes(dst2, src[:nbytes - 1])
+        torch.cuda.synchronize()
+        assert torch.equal(dst2, src[:nbytes - 1])
