@@ -691,6 +691,162 @@ __global__ __launch_bounds__(kThreads, 2) void cin_filter_grad_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 5: the filter gradient for the benchmark's shapes (D = 16, HQ = m <= 32, C <= 128 columns in 2 or 4 full tiles).
+// The kernel above transposes every chunk of G, X^k and X^0 into [(b,d)][.] LDS tiles with scalar stores between two barriers
+// (no MFMA in flight meanwhile) and issues 2 + NT ds_read_b32 per NT MFMAs.  Here the reduction index r = (b, d) is consumed
+// in another order — step (b, u, e) contracts d = 4 u + e (lanes 0-31) and d = 8 + 4 u + e (lanes 32-63); any pairing of
+// reduction indices is a valid fp32 chain as long as both operands use the same one — so that ONE ds_read_b128 of a tile
+// kept in its GLOBAL layout [b][row][d] delivers a lane's operand values of four steps:
+//   A: float4 of X^k[b, p(kk), 8 hi + 4 u ..] and of X^0[b, q(kk), ..], four v_mul;  B: float4 of G[b, c, 8 hi + 4 u ..] per tile
+//   -> 2 + NT ds_read_b128 per 4 NT MFMAs (0.375 LDS instructions per MFMA at NT = 4; above: 2.0), tiles staged with
+//   ds_write_b128 straight from the float4 global loads (row stride 20 floats: the 16 lanes served together hit 16
+//   distinct 4-bank groups), a workgroup covers all C columns (the outer-product operand is formed once, not per column
+//   chunk), 2-slot ring with ONE barrier per chunk of 2 examples = 16 NT MFMAs per wave, the next chunk's global loads and
+//   LDS stores pinned into the MFMA shadow.  Two-level accumulation as above (chains of 256 terms).
+// ---------------------------------------------------------------------------------------------
+constexpr int kLdF2 = 20;      // LDS floats per [.][d] row (16 + 4)
+constexpr int kPW2 = 10;       // >= distinct p values of a workgroup's 128 kk rows (HQ >= 17: 127 / 17 + 2 = 9)
+
+template <int NT>
+__global__ __launch_bounds__(kThreads, 2) void cin_filter_grad2_kernel(
+    const float* __restrict__ P, const float* __restrict__ Q, const float* __restrict__ G, unsigned B, unsigned HP,
+    unsigned HQ, unsigned C, unsigned ex_per_split, float* __restrict__ partials) {
+    constexpr unsigned D = 16, EXC = 2, CS = NT * 32;
+    constexpr unsigned kG = EXC * CS * kLdF2, kQ = EXC * 32 * kLdF2, kP = EXC * kPW2 * kLdF2;
+    constexpr unsigned kSlot = kG + kQ + kP;
+    constexpr unsigned GI = EXC * CS * 4 / kThreads;          // staged G float4 per thread (C == CS: exact)
+    __shared__ __attribute__((aligned(16))) float smem[2 * kSlot];
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned hi = lane >> 5, l32 = lane & 31;
+    const unsigned Kdim = HP * HQ;
+    const unsigned kk0 = blockIdx.x * 128;
+    const unsigned kk = min(kk0 + wave * 32 + l32, Kdim - 1);   // (rows past Kdim compute a copy of the last row; never stored)
+    const unsigned p_first = kk0 / HQ;
+    const unsigned p_lane = kk / HQ - p_first, q_lane = kk % HQ;
+    const unsigned p_cnt = min(HP, (min(kk0 + 128, Kdim) - 1) / HQ + 1) - p_first;
+
+    for (unsigned e = tid; e < 2 * kSlot / 4; e += kThreads) reinterpret_cast<float4*>(smem)[e] = f4_zero();   // rows c >= C stay 0
+
+    f32x16 acc[NT], tot[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = tot[nt][r] = 0.f;
+
+    const unsigned ex_begin = blockIdx.y * ex_per_split;
+    const unsigned ex_end = min(B, ex_begin + ex_per_split);
+    const unsigned C4 = C * 4;                                // float4 per example of G
+    const unsigned nQ4 = EXC * HQ * 4, nP4 = EXC * p_cnt * 4;
+    // this thread's staged pieces: GI float4 of G, one of Q (tid < nQ4), one of P (tid < nP4)
+    unsigned g_ex[GI], g_rem[GI], g_dst[GI];
+#pragma unroll
+    for (unsigned k = 0; k < GI; ++k) {
+        const unsigned e = tid + k * kThreads;
+        g_ex[k] = e / C4; g_rem[k] = e % C4;
+        g_dst[k] = (g_ex[k] * CS + g_rem[k] / 4) * kLdF2 + (g_rem[k] % 4) * 4;
+    }
+    const unsigned q_ex = tid / (HQ * 4), q_rem = tid % (HQ * 4);
+    const unsigned q_dst = kG + (q_ex * 32 + q_rem / 4) * kLdF2 + (q_rem % 4) * 4;
+    const unsigned p_ex = tid / (p_cnt * 4), p_rem = tid % (p_cnt * 4);
+    const unsigned p_dst = kG + kQ + (p_ex * kPW2 + p_rem / 4) * kLdF2 + (p_rem % 4) * 4;
+    float4 gst[GI], qst, pst;
+    auto load_piece = [&](unsigned e0, unsigned k) {          // k < GI: G piece k; GI: Q; GI + 1: P
+        if (k < GI) {
+            const unsigned ex = e0 + g_ex[k];
+            gst[k] = (g_ex[k] < EXC && ex < ex_end) ? reinterpret_cast<const float4*>(G + (size_t)ex * C * D)[g_rem[k]] : f4_zero();
+        } else if (k == GI) {
+            const unsigned ex = e0 + q_ex;
+            qst = (tid < nQ4 && ex < ex_end) ? reinterpret_cast<const float4*>(Q + (size_t)ex * HQ * D)[q_rem] : f4_zero();
+        } else {
+            const unsigned ex = e0 + p_ex;
+            pst = (tid < nP4 && ex < ex_end) ? reinterpret_cast<const float4*>(P + ((size_t)ex * HP + p_first) * D)[p_rem] : f4_zero();
+        }
+    };
+    auto store_piece = [&](float* slot, unsigned k) {
+        if (k < GI) { if (g_ex[k] < EXC) *reinterpret_cast<float4*>(slot + g_dst[k]) = gst[k]; }
+        else if (k == GI) { if (tid < nQ4) *reinterpret_cast<float4*>(slot + q_dst) = qst; }
+        else { if (tid < nP4) *reinterpret_cast<float4*>(slot + p_dst) = pst; }
+    };
+    constexpr unsigned kPieces = GI + 2;
+    if (ex_begin < ex_end) {
+#pragma unroll
+        for (unsigned k = 0; k < kPieces; ++k) load_piece(ex_begin, k);
+    }
+    __syncthreads();                                          // zero fill done
+#pragma unroll
+    for (unsigned k = 0; k < kPieces; ++k) store_piece(smem, k);
+    __syncthreads();
+
+    // lane's read offsets inside a slot (floats): + example * stride + 4 u
+    const unsigned offG = l32 * kLdF2 + 8 * hi;                               // + (ex * CS + 32 j) * kLdF2
+    const unsigned offQ = kG + q_lane * kLdF2 + 8 * hi;                       // + ex * 32 * kLdF2
+    const unsigned offP = kG + kQ + p_lane * kLdF2 + 8 * hi;                  // + ex * kPW2 * kLdF2
+    struct Frag { float4 p, q, g[NT]; };
+    auto read_frag = [&](const float* slot, unsigned grp, Frag& f) {          // grp = ex * 2 + u
+        const unsigned ex = grp >> 1, u = grp & 1;
+        f.p = *reinterpret_cast<const float4*>(slot + offP + ex * kPW2 * kLdF2 + 4 * u);
+        f.q = *reinterpret_cast<const float4*>(slot + offQ + ex * 32 * kLdF2 + 4 * u);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) f.g[j] = *reinterpret_cast<const float4*>(slot + offG + (ex * CS + 32 * j) * kLdF2 + 4 * u);
+    };
+    constexpr int NG = EXC * 2;                               // groups of 4 steps per chunk
+    unsigned chunks = 0, cur = 0;
+    Frag fr[2];
+    read_frag(smem, 0, fr[0]);
+    for (unsigned e0 = ex_begin; e0 < ex_end; e0 += EXC) {
+        const float* rs = smem + cur * kSlot;
+        float* ws = smem + (cur ^ 1) * kSlot;
+        const bool more = e0 + EXC < ex_end;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const Frag& f = fr[g & 1];
+            const float a[4] = {f.p.x * f.q.x, f.p.y * f.q.y, f.p.z * f.q.z, f.p.w * f.q.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const float bv = e == 0 ? f.g[j].x : (e == 1 ? f.g[j].y : (e == 2 ? f.g[j].z : f.g[j].w));
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bv, acc[j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int ls = e * NT + j;                // slot inside the group, 0 .. 4 NT - 1
+                    // fragments of the next group of this chunk (the next chunk's first group is read behind the barrier)
+                    if (ls == 0 && g + 1 < NG) read_frag(rs, g + 1, fr[(g + 1) & 1]);
+                    // group 0: the next chunk's global loads; group NG - 1: registers -> the other slot
+                    if (g == 0 && ls >= 1 && ls <= (int)kPieces && more) load_piece(e0 + EXC, ls - 1);
+                    if (g == NG - 1 && ls < (int)kPieces && more) store_piece(ws, ls);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        static_assert((int)kPieces < 4 * NT, "side-work slots");
+        if ((++chunks & 7) == 0 || !more) {                   // chains of 8 chunks = 256 terms (uniform over the workgroup)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    tot[nt][r] += acc[nt][r];
+                    acc[nt][r] = 0.f;
+                }
+        }
+        __syncthreads();
+        cur ^= 1;
+        if (more) read_frag(smem + cur * kSlot, 0, fr[0]);
+    }
+    // ---- write the partial tile: rows kk0 + wave*32 + (r&3) + 8*(r>>2) + 4*hi, col nt*32 + l32 ----
+    float* pout = partials + (size_t)blockIdx.y * Kdim * C;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const unsigned c = nt * 32 + l32;
+        if (c >= C) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            unsigned rr = kk0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (rr < Kdim) pout[(size_t)rr * C + c] = tot[nt][r];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void cin_sum_partials_kernel(const float* __restrict__ partials, unsigned S,
                                                                size_t n, float* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -816,7 +972,15 @@ int launch_input_grad(const float* x0, const float* xk, const float* W, const fl
 }
 
 inline int filter_rc(int /*HQ*/) { return 64; }          // (RC = 128 spills at NT = 2: 27 VGPRs, measured slower)
+// the round-5 kernel (cin_filter_grad2_kernel): emb width 16, 17 .. 32 fields, all columns in one workgroup (C == 64 or 128)
+inline bool filter_grad2_ok(int D, int HQ, int C) { return D == 16 && HQ > 16 && HQ <= 32 && (C == 64 || C == 128); }
 inline int filter_grad_splits(int B, int D, int Kdim, int C, int HQ) {
+    if (filter_grad2_ok(D, HQ, C)) {
+        const int want = 512 / cdiv(Kdim, 128);             // one resident round of 2 workgroups per CU
+        const int max_s = cdiv(B, 2);
+        const int S = want < 1 ? 1 : (want > max_s ? max_s : want);
+        return S > 64 ? 64 : S;
+    }
     int row_blocks = cdiv(Kdim, 128) * cdiv(C, 64);         // x column chunks of <= 2 tiles
     int want = 512 / row_blocks;                            // <= 2 workgroups per CU (VGPR-bound occupancy): no tail round
     int exc = filter_rc(HQ) / D;
@@ -943,6 +1107,16 @@ RECALGO_EXPORT int recalgo_cin_layer_bwd(const float* x0, const float* xk, const
     // dW
     const int S = filter_grad_splits(B, D, Hk * m, N, m);
     const int NT = cdiv(N, 32);
+    if (filter_grad2_ok(D, m, N) && (reinterpret_cast<uintptr_t>(G) & 15) == 0 && (reinterpret_cast<uintptr_t>(x0) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(xk) & 15) == 0) {
+        const int ex_per_split = cdiv(cdiv(B, S), 2) * 2;
+        const dim3 grid(cdiv(Hk * m, 128), S);
+        if (N == 128) hipLaunchKernelGGL((cin_filter_grad2_kernel<4>), grid, dim3(kThreads), 0, st, xk, x0, G, (unsigned)B, (unsigned)Hk,
+                                         (unsigned)m, (unsigned)N, (unsigned)ex_per_split, partials);
+        else hipLaunchKernelGGL((cin_filter_grad2_kernel<2>), grid, dim3(kThreads), 0, st, xk, x0, G, (unsigned)B, (unsigned)Hk,
+                                (unsigned)m, (unsigned)N, (unsigned)ex_per_split, partials);
+        rc = (int)hipGetLastError();
+    } else
     switch (D) {
         case 4: rc = launch_filter_grad_D<4>(NT, xk, x0, G, B, Hk, m, N, S, partials, st); break;
         case 8: rc = launch_filter_grad_D<8>(NT, xk, x0, G, B, Hk, m, N, S, partials, st); break;
