@@ -511,6 +511,173 @@ __global__ __launch_bounds__(kThreads) void cin_input_grad_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 5: the fused input gradients for the benchmark's shapes (D = 16, m <= 32, N = 128, float4-addressable filter).
+// Same implicit GEMM dA^T = W G^T consumed on the fly, other tile orientation and pipeline:
+//   * MFMA rows = 32 consecutive i at ONE j (the kernel above: the m <= 32 values of j at one i, i.e. 26 of 32 rows used):
+//     H_k = 128 is four full row blocks — 104 tiles per 128 columns instead of 128, 19 % fewer MFMAs;
+//   * the W tile ([32 i][128 n], row stride m N in memory) is staged as float4 through a 3-slot LDS ring (row stride 132) and
+//     fetched as ONE ds_read_b128 per four MFMA steps (above: scalar loads / stores, one ds_read_b32 per MFMA);
+//   * the VALU consumption of tile t - 1 (dX^0[j] += sum_i dA X^k[i]; dX^k[i] += dA X^0[j]) runs in the shadow of tile t's
+//     MFMAs on a second accumulator (above: behind the tile's own last MFMA, in front of a barrier);
+//   * X^k of the lane's rows and the dX^k accumulators stay in registers: two passes of up to two row blocks each keep the
+//     kernel under 256 registers (2 waves per SIMD); the second pass adds to dX^0 what the first one stored.
+// ---------------------------------------------------------------------------------------------
+constexpr int kLdW2 = 132;
+
+template <int NIBP /* row blocks of 32 i per pass: 1 or 2 */>
+__global__ __launch_bounds__(kThreads, 2) void cin_input_grad2_kernel(
+    const float* __restrict__ x0, const float* __restrict__ xk, const float* __restrict__ W, const float* __restrict__ G,
+    unsigned B, unsigned m, unsigned Hk, float* __restrict__ dx0, int dx0_accumulate, float* __restrict__ dxk,
+    int dxk_accumulate) {
+    constexpr unsigned D = 16, N = 128, EX = kTM / D;
+    constexpr unsigned kTile = 32 * kLdW2;
+    __shared__ __attribute__((aligned(16))) float Ws[3 * kTile];
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned hi = lane >> 5, l32 = lane & 31;
+    const unsigned col = wave * 32 + l32;
+    const unsigned exl = col / D, dd = col % D;
+    const unsigned b = blockIdx.x * EX + exl;
+    const bool valid = b < B;
+
+    // B operand: G[b, n = 8 g + 4 hi + e, dd] for step 4 g + e, register resident for the whole kernel
+    float Breg[64];
+#pragma unroll
+    for (int s = 0; s < 64; ++s) {
+        const unsigned n = 8 * (s >> 2) + 4 * hi + (s & 3);
+        Breg[s] = valid ? G[((size_t)b * N + n) * D + dd] : 0.f;
+    }
+    // staging: thread -> (row tid / 32 + 8 k, float4 column tid % 32) of a tile
+    const unsigned sr = tid >> 5, sc = tid & 31;
+    const unsigned nib_total = (Hk + 31) / 32;
+    const unsigned npass = (nib_total + NIBP - 1) / NIBP;
+    const float* Wl = Ws + l32 * kLdW2 + 4 * hi;              // + slot * kTile + 8 g
+    const float* x0p = x0 + (size_t)b * m * D + dd;           // X^0[b, j, dd] at stride D
+
+    for (unsigned pass = 0; pass < npass; ++pass) {
+        const unsigned ib0 = pass * NIBP;                     // first row block of this pass
+        const unsigned nib = min((unsigned)NIBP, nib_total - ib0);
+        const unsigned ntiles = m * nib;                      // tile t: j = t / nib, row block ib0 + t % nib
+        // X^k[b, i = 32 (ib0 + q) + acc_row(r, hi), dd] of this lane's column and the dX^k accumulators of the pass
+        float xkv[NIBP][16], dxkacc[NIBP][16];
+#pragma unroll
+        for (int q = 0; q < NIBP; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned i = 32 * (ib0 + q) + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                xkv[q][r] = (valid && i < Hk) ? xk[((size_t)b * Hk + i) * D + dd] : 0.f;
+                dxkacc[q][r] = 0.f;
+            }
+        float4 stg[4];
+        auto tile_load = [&](unsigned t) {
+            const unsigned tt = min(t, ntiles - 1);           // (tiles past the end: reloaded, never used)
+            const unsigned j = tt / nib, ib = ib0 + tt % nib;
+#pragma unroll
+            for (unsigned k = 0; k < 4; ++k) {
+                const unsigned i = 32 * ib + sr + 8 * k;
+                stg[k] = i < Hk ? reinterpret_cast<const float4*>(W + ((size_t)i * m + j) * N)[sc] : f4_zero();
+            }
+        };
+        auto tile_store = [&](unsigned slot, unsigned k) {
+            *reinterpret_cast<float4*>(Ws + slot * kTile + (sr + 8 * k) * kLdW2 + sc * 4) = stg[k];
+        };
+        __syncthreads();                                      // (the previous pass is done with the ring)
+        tile_load(0);
+#pragma unroll
+        for (unsigned k = 0; k < 4; ++k) tile_store(0, k);
+        tile_load(1);
+#pragma unroll
+        for (unsigned k = 0; k < 4; ++k) tile_store(1, k);
+        __syncthreads();
+        f32x16 A, Pv;                                         // the tile being formed, the tile being consumed
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Pv[r] = 0.f;
+        float4 fa[2];
+        fa[0] = *reinterpret_cast<const float4*>(Wl);
+        unsigned s0 = 0, s1 = 1, s2 = 2;
+        float dk = 0.f;
+        float x0_prev = 0.f, x0_cur = valid ? x0p[0] : 0.f, x0_next = 0.f;    // X^0[b, j - 1 | j | j + 1, dd]
+        // consume register r of the tile held in Pv: it belongs to row block qp and the j whose X^0 value is x0c.  Branch-free
+        // in qp (wave-uniform, but a branch per slot would fence the schedule): the other row block gets an exact + 0
+        auto consume = [&](int r, unsigned qp, float x0c) {
+            if constexpr (NIBP == 1) {
+                dk = fmaf(Pv[r], xkv[0][r], dk);
+                dxkacc[0][r] = fmaf(Pv[r], x0c, dxkacc[0][r]);
+            } else {
+                const bool first = qp == 0;
+                dk = fmaf(Pv[r], first ? xkv[0][r] : xkv[1][r], dk);
+                dxkacc[0][r] = fmaf(Pv[r], first ? x0c : 0.f, dxkacc[0][r]);
+                dxkacc[1][r] = fmaf(Pv[r], first ? 0.f : x0c, dxkacc[1][r]);
+            }
+        };
+        auto finish_j = [&](unsigned j) {                     // every row block of j consumed: dX^0[b, j, dd] of this pass
+            const float v = dk + __shfl_xor(dk, 32, 64);
+            if (hi == 0 && valid) {
+                float* pd = dx0 + ((size_t)b * m + j) * D + dd;
+                *pd = (dx0_accumulate || pass > 0) ? *pd + v : v;
+            }
+            dk = 0.f;
+        };
+        unsigned q = 0, j = 0;                                // tile t = (j, row block q)
+        for (unsigned t = 0; t < ntiles; ++t) {
+            const unsigned qp = q == 0 ? nib - 1 : q - 1;     // row block of tile t - 1
+            const float x0c = q == 0 ? x0_prev : x0_cur;      // and the X^0 value of its j
+            const bool cons = t > 0;
+            if (q == 0) x0_next = (valid && j + 1 < m) ? x0p[(size_t)(j + 1) * D] : 0.f;
+            tile_load(t + 2);
+            const float* rd = Wl + s0 * kTile;
+            const float* rn = Wl + s1 * kTile;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float av = e == 0 ? fa[g & 1].x : (e == 1 ? fa[g & 1].y : (e == 2 ? fa[g & 1].z : fa[g & 1].w));
+                    if (g == 0 && e == 0) {
+                        f32x16 z;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                        A = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Breg[0], z, 0, 0, 0);
+                    } else {
+                        A = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Breg[4 * g + e], A, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int ls = 4 * g + e;                 // 0 .. 63
+                    if (e == 0) {
+                        if (g + 1 < 16) fa[(g + 1) & 1] = *reinterpret_cast<const float4*>(rd + 8 * (g + 1));
+                        else fa[0] = *reinterpret_cast<const float4*>(rn);      // first group of the next tile
+                    }
+                    if (ls >= 8 && ls < 24 && cons) consume(ls - 8, qp, x0c);   // the previous tile: one register per slot
+                    if (ls >= 40 && ls < 44) tile_store(s2, ls - 40);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (cons && q == 0) finish_j(j - 1);              // tile t - 1 was the last row block of j - 1
+            Pv = A;                                           // (waits for the tile's last MFMA: ~1 % of a tile)
+            if (++q == nib) { q = 0; ++j; x0_prev = x0_cur; x0_cur = x0_next; }
+            const unsigned tmp = s0;
+            s0 = s1; s1 = s2; s2 = tmp;
+            __syncthreads();
+        }
+        // the last tile: (m - 1, nib - 1)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) consume(r, nib - 1, x0_prev);
+        finish_j(m - 1);
+        // dX^k[b, i, dd] of the pass: lanes of both halves hold their own rows
+        if (valid) {
+#pragma unroll
+            for (int q2 = 0; q2 < NIBP; ++q2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned i = 32 * (ib0 + q2) + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if ((unsigned)q2 < nib && i < Hk) {
+                        float* pk = dxk + ((size_t)b * Hk + i) * D + dd;
+                        *pk = dxk_accumulate ? *pk + dxkacc[q2][r] : dxkacc[q2][r];
+                    }
+                }
+        }
+    }
+}
+
 // F'[(a1*n2 + a2) * n0 + a0] = W[(a0*n1... see callers]  — generic 3-index permutation of the
 // filter: dst[(x*NY + y)*NZ + z] = src[x*sx + y*sy + z*sz]
 __global__ __launch_bounds__(256) void cin_permute_kernel(const float* __restrict__ src, float* __restrict__ dst,
@@ -979,7 +1146,7 @@ inline int filter_grad_splits(int B, int D, int Kdim, int C, int HQ) {
         const int want = 512 / cdiv(Kdim, 128);             // one resident round of 2 workgroups per CU
         const int max_s = cdiv(B, 2);
         const int S = want < 1 ? 1 : (want > max_s ? max_s : want);
-        return S > 64 ? 64 : S;
+        return S > 128 ? 128 : S;                           // (the first layer: 6 row blocks x 85 splits of 50 examples)
     }
     int row_blocks = cdiv(Kdim, 128) * cdiv(C, 64);         // x column chunks of <= 2 tiles
     int want = 512 / row_blocks;                            // <= 2 workgroups per CU (VGPR-bound occupancy): no tail round
@@ -1084,7 +1251,16 @@ RECALGO_EXPORT int recalgo_cin_layer_bwd(const float* x0, const float* xk, const
     }
     const unsigned wn = (unsigned)Hk * m * N;
     int rc;
-    if (m <= 32 && dxk != nullptr) {
+    if (m <= 32 && dxk != nullptr && D == 16 && N == 128 && (reinterpret_cast<uintptr_t>(filters) & 15) == 0) {
+        // fused, round-5 form: row blocks of 32 i (cin_input_grad2_kernel)
+        const dim3 grid(cdiv((int64_t)B * D, kTM));
+        if (Hk > 32) hipLaunchKernelGGL((cin_input_grad2_kernel<2>), grid, dim3(kThreads), 0, st, x0, xk, filters, G, (unsigned)B,
+                                        (unsigned)m, (unsigned)Hk, dx0, dx0_accumulate, dxk, dxk_accumulate);
+        else hipLaunchKernelGGL((cin_input_grad2_kernel<1>), grid, dim3(kThreads), 0, st, x0, xk, filters, G, (unsigned)B,
+                                (unsigned)m, (unsigned)Hk, dx0, dx0_accumulate, dxk, dxk_accumulate);
+        rc = (int)hipGetLastError();
+        if (rc) return rc;
+    } else if (m <= 32 && dxk != nullptr) {
         // fused: one implicit GEMM G W^T feeds both dX^k and dX^0 (cin_input_grad_kernel)
         rc = launch_input_grad(x0, xk, filters, G, B, m, Hk, N, D, dx0, dx0_accumulate, dxk, dxk_accumulate, st);
         if (rc) return rc;

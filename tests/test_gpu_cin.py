@@ -23,6 +23,10 @@ def _oracle(x0, xk, w, go, gp, dtype):
 @pytest.mark.parametrize("B,m,Hk,N,D", [
     (3, 4, 4, 5, 4), (17, 8, 8, 50, 8), (33, 8, 50, 50, 8), (64, 26, 26, 128, 16), (40, 26, 128, 128, 16),
     (9, 5, 7, 33, 32), (130, 26, 100, 100, 16),
+    # the round-5 kernels (cin_contract2 / cin_filter_grad2 / cin_input_grad2) at their edges: 32 fields (16 steps per slab),
+    # a partly filled second row block and a partly filled workgroup; 64 filter columns (two column tiles); three row blocks
+    # (a second pass of one); few fields (the general forward / filter-gradient kernels beside the new input-gradient one)
+    (5, 32, 33, 128, 16), (21, 17, 70, 64, 16), (12, 20, 96, 128, 16), (7, 9, 40, 128, 16),
 ])
 def test_cin_layer_fwd_bwd(dev, B, m, Hk, N, D):
     gen = torch.Generator().manual_seed(B * 7 + N)
