@@ -403,11 +403,15 @@ int recalgo_dense_bwd(const float* x, int ldx, const float* g, int ldg, const fl
  * that BatchNorm's backward starts with — bn_partials [recalgo_batchnorm_partial_rows(M)][2 K]: per 64-row tile colsum(dx) and
  * colsum(dx * xhat), xhat = (bn_x - bn_mean) * bn_rstd, bn_x [M][K] contiguous = that BatchNorm's INPUT — i.e. the partial
  * rows of recalgo_batchnorm_bwd_sums, so recalgo_batchnorm_bwd_apply (world 1) follows without a pass over dx and bn_x.
- * bn_partials == NULL: recalgo_dense_bwd. */
+ * bn_partials == NULL: recalgo_dense_bwd.
+ * dx_relu_mask (may be NULL) [M][ld_mask]: dx := dx_relu_mask > 0 ? dx : 0 before the beta * c_in term — the layer's input x
+ * when x IS the ReLU output of the layer below (for units in hidden_units: net = tf.layers.dense(net, units, relu),
+ * dcn.py:163-166): that layer's backward then receives g * [y > 0] ready-made and is called with y_mask == NULL (no mask
+ * loads in its two GEMMs). */
 int recalgo_dense_bwd_bn(const float* x, int ldx, const float* g, int ldg, const float* y_mask, const float* w, int M, int K,
                          int N, const float* c_in, int ldc, float beta, float* dx, int lddx, float* dw, float* dbias,
                          void* workspace, int defer_reduce, const float* bn_x, const float* bn_mean, const float* bn_rstd,
-                         float* bn_partials, recalgo_stream_t stream);
+                         float* bn_partials, const float* dx_relu_mask, int ld_mask, recalgo_stream_t stream);
 typedef struct {
     int M, K, N;
     const void* workspace;
@@ -514,7 +518,9 @@ int recalgo_sigmoid_ce_fwd_bwd(const float* logits, const float* labels, int B, 
  *              vector: tf.layers.dense(concat, 1) or a sum of one-unit heads, xdeepfm.py:163,175,182,184;
  *              addends: DeepFM's FM first / second order logits, deepfm.py:214)
  *   prob, mean sigmoid-CE as recalgo_sigmoid_ce_fwd_bwd;  dlogit[b] = d loss / d logit * grad_scale
- *   dx_p[b, :] = dlogit[b] * w_p          (dx_parts[p] may be NULL)
+ *   dx_p[b, :] = dlogit[b] * w_p          (dx_parts[p] may be NULL);  relu_parts (host array of n_parts flags, may be NULL):
+ *              dx_p[b, j] = 0 where x_p[b, j] <= 0 — part p IS a ReLU output (the last hidden layer, dcn.py:166-170) and the
+ *              layer that produced it gets its gradient already masked (see recalgo_dense_bwd_bn)
  *   partials [recalgo_logit_loss_partial_rows(B)][C + 2], C = sum of widths: per-workgroup partial sums of
  *   [dw over the C concatenated columns | d bias | loss]; their fixed-order column sums (recalgo_colsum_t jobs of
  *   recalgo_dense_bwd_weights_reduce) are dw_p, d bias and the loss value.  bias, addend0/1 may be NULL.
@@ -524,7 +530,7 @@ int64_t recalgo_logit_loss_partial_rows(int B);
 int recalgo_logit_loss_fwd_bwd(const float* const* x_parts, const float* const* w_parts, const int* widths, int n_parts,
                                const float* bias, const float* addend0, const float* addend1, const float* labels,
                                const float* loss_addend, int B, float grad_scale, float* logit, float* prob, float* dlogit,
-                               float* const* dx_parts, float* partials, recalgo_stream_t stream);
+                               float* const* dx_parts, const int* relu_parts, float* partials, recalgo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * a15  TF1 AdamOptimizer, dense semantics (also what TF1 applies to embedding IndexedSlices:

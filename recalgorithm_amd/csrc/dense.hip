@@ -363,7 +363,7 @@ __global__ __launch_bounds__(kThreads) void dense_fwd_kernel(FwdArgs P) {
     const int col = n0 + (wave & 1) * 32 + l32;
     if (rowwise) {
         const int r0 = m0 + (wave >> 1) * 32;
-        tv2::tile_rows(As + wave * tv2::kTileScratch, acc, [&](int row, int, float4 v) {
+        tv2::tile_rows(As + wave * tv2::kTileScratch, acc, [&](int, int row, int, float4 v) {
             v = f4_add(v, bias4);
             if (P.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
             if (r0 + row < P.M && c4 < P.N) *reinterpret_cast<float4*>(P.y + (size_t)(r0 + row) * P.ldy + c4) = v;
@@ -441,6 +441,11 @@ struct DgradArgs {
     int accumulate;        // dx += result (the second operand pair of the PNN layer)
     int tiles_per_block;   // consecutive output tiles one workgroup computes (>= 1; see bwd_balance)
     int vec_store;         // dx (and c_in) float4-addressable: the plain epilogue writes whole row segments
+    // optional: dx := dx_mask > 0 ? dx : 0, dx_mask [M][ld_mask] — the ReLU output this layer's input IS (tf.layers.dense(...,
+    // relu) -> tf.layers.dense, dcn.py:163-166): the producing layer's backward then gets its gradient already masked and
+    // stages it without mask loads (3 us of a 24 us half-launch, profiles/r05_mfma_lab.md "mask cost")
+    const float* dx_mask;
+    int ld_mask;
     // optional: this layer's input is the output of a training-mode BatchNorm over bn_x [M][K] (contiguous) with the batch
     // statistics bn_mean / bn_rstd [K] — the epilogue leaves the sums that BatchNorm's backward starts with, per 64-row tile:
     // bn_partials[tile][0:K] = colsum(dx), [K:2K] = colsum(dx * xhat) (the partial rows of recalgo_batchnorm_bwd_sums)
@@ -479,13 +484,24 @@ __device__ __forceinline__ void dgrad_tile(const DgradArgs& P, int block, int nb
                 xb[r] = row < P.M ? P.bn_x[(size_t)row * P.K + col] : 0.f;
             }
         }
+        // (row-wise epilogue with an output mask: the lane's four float4 of the mask are requested before the main loop)
+        const bool rowwise = FAST && P.vec_store && P.bn_partials == nullptr;
+        float4 mk[4];
+        if (rowwise && P.dx_mask != nullptr) {
+            const int r0 = m0 + (wave >> 1) * 32 + (lane >> 3), c4 = n0 + (wave & 1) * 32 + (lane & 7) * 4;
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                mk[it] = (r0 + 8 * it < P.M && c4 < P.K) ? *reinterpret_cast<const float4*>(P.dx_mask + (size_t)(r0 + 8 * it) * P.ld_mask + c4)
+                                                         : f4_zero();
+        }
         tile_mainloop<true, true, FAST, MASK, false, false>(P.seg, m0, n0, P.M, P.K, 0, P.seg.n_red, As, Bs, acc, acc1, unused);
         acc += acc1;
         if (P.bn_partials == nullptr) {
-            if (FAST && P.vec_store) {
+            if (rowwise) {
                 const int r0 = m0 + (wave >> 1) * 32, c4 = n0 + (wave & 1) * 32 + (lane & 7) * 4;
-                tv2::tile_rows(As + wave * tv2::kTileScratch, acc, [&](int row, int, float4 v) {
+                tv2::tile_rows(As + wave * tv2::kTileScratch, acc, [&](int it, int row, int, float4 v) {
                     if (r0 + row < P.M && c4 < P.K) {
+                        if (P.dx_mask) v = relu_mask(v, mk[it]);
                         if (P.c_in) v = f4_fma(*reinterpret_cast<const float4*>(P.c_in + (size_t)(r0 + row) * P.ldc + c4), P.beta, v);
                         float4* o = reinterpret_cast<float4*>(P.dx + (size_t)(r0 + row) * P.lddx + c4);
                         *o = P.accumulate ? f4_add(*o, v) : v;
@@ -499,6 +515,7 @@ __device__ __forceinline__ void dgrad_tile(const DgradArgs& P, int block, int nb
                     const int row = m0 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     if (row < P.M) {
                         float v = acc[r];
+                        if (P.dx_mask && !(P.dx_mask[(size_t)row * P.ld_mask + col] > 0.f)) v = 0.f;
                         if (P.c_in) v = fmaf(P.beta, P.c_in[(size_t)row * P.ldc + col], v);
                         float* o = P.dx + (size_t)row * P.lddx + col;
                         *o = P.accumulate ? *o + v : v;
@@ -516,6 +533,7 @@ __device__ __forceinline__ void dgrad_tile(const DgradArgs& P, int block, int nb
             const int row = m0 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
             if (cok && row < P.M) {
                 float v = acc[r];
+                if (P.dx_mask && !(P.dx_mask[(size_t)row * P.ld_mask + col] > 0.f)) v = 0.f;
                 if (P.c_in) v = fmaf(P.beta, P.c_in[(size_t)row * P.ldc + col], v);
                 P.dx[(size_t)row * P.lddx + col] = v;
                 const float xh = (xb[r] - mu) * rs;
@@ -595,7 +613,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradArgs& P, int block, float*
     if (FAST && P.vec_store) {
         const int r0 = m0 + (wave >> 1) * 32, c4 = n0 + (wave & 1) * 32 + (lane & 7) * 4;
         // (the wave's scratch lies in Bs: the bias sums below go through As)
-        tv2::tile_rows(Bs + wave * tv2::kTileScratch, acc, [&](int row, int, float4 v) {
+        tv2::tile_rows(Bs + wave * tv2::kTileScratch, acc, [&](int, int row, int, float4 v) {
             if (r0 + row < P.K && c4 < P.N) *reinterpret_cast<float4*>(base + (size_t)(r0 + row) * P.N + c4) = v;
         });
     } else if (col < P.N) {
@@ -836,6 +854,7 @@ static bool build_dgrad(DgradArgs& P, const float* g, int ldg, const float* y_ma
     P.tiles_per_block = 1;
     P.bn_x = P.bn_mean = P.bn_rstd = nullptr; P.bn_partials = nullptr;
     P.vec_store = (aligned16(dx) && lddx % 4 == 0 && K % 4 == 0 && (c_in == nullptr || (aligned16(c_in) && ldc % 4 == 0))) ? 1 : 0;
+    P.dx_mask = nullptr; P.ld_mask = 0;
     return true;
 }
 static bool dgrad_fast(const DgradArgs& P) { return fast_rc(P.seg.a, P.seg.n_red) && fast_rc(P.seg.b, P.seg.n_red); }
@@ -934,18 +953,21 @@ RECALGO_EXPORT int recalgo_dense_bwd(const float* x, int ldx, const float* g, in
                                      int M, int K, int N, const float* c_in, int ldc, float beta, float* dx, int lddx,
                                      float* dw, float* dbias, void* workspace, int defer_reduce, recalgo_stream_t stream) {
     return recalgo_dense_bwd_bn(x, ldx, g, ldg, y_mask, w, M, K, N, c_in, ldc, beta, dx, lddx, dw, dbias, workspace, defer_reduce,
-                                nullptr, nullptr, nullptr, nullptr, stream);
+                                nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream);
 }
 
 RECALGO_EXPORT int recalgo_dense_bwd_bn(const float* x, int ldx, const float* g, int ldg, const float* y_mask, const float* w,
                                         int M, int K, int N, const float* c_in, int ldc, float beta, float* dx, int lddx,
                                         float* dw, float* dbias, void* workspace, int defer_reduce, const float* bn_x,
                                         const float* bn_mean, const float* bn_rstd, float* bn_partials,
-                                        recalgo_stream_t stream) {
+                                        const float* dx_relu_mask, int ld_mask, recalgo_stream_t stream) {
     DgradArgs D;
     WgradArgs W;
     RECALGO_REQUIRE(M > 0 && build_dgrad(D, g, ldg, y_mask, w, M, N, K, c_in, ldc, beta, dx, lddx, 0));
     RECALGO_REQUIRE(bn_partials == nullptr || (bn_x != nullptr && bn_mean != nullptr && bn_rstd != nullptr));
+    RECALGO_REQUIRE(dx_relu_mask == nullptr || ld_mask >= K);
+    D.dx_mask = dx_relu_mask; D.ld_mask = ld_mask;
+    if (dx_relu_mask != nullptr && !(aligned16(dx_relu_mask) && ld_mask % 4 == 0)) D.vec_store = 0;
     D.bn_x = bn_x; D.bn_mean = bn_mean; D.bn_rstd = bn_rstd; D.bn_partials = bn_partials;
     const int S = build_wgrad(W, x, ldx, g, ldg, y_mask, M, K, N, dw, dbias, workspace);
     RECALGO_REQUIRE(S >= 1);

@@ -428,6 +428,7 @@ struct TailArgs {
     const float* w[kHeadMaxParts];      // one weight vector per part (xDeepFM sums three one-unit heads)
     float* dx[kHeadMaxParts];           // may be null per part
     int width[kHeadMaxParts];
+    int relu[kHeadMaxParts];            // part p is a ReLU output: dx_p := 0 where x_p <= 0 (see recalgo_dense_bwd_bn)
     int n;
     const float* bias;                  // [1] or null
     const float* addend[2];             // [B] extra logit terms or null (DeepFM: FM first / second order)
@@ -537,12 +538,14 @@ __global__ __launch_bounds__(256) void logit_loss_kernel(TailArgs P) {
         const int W = P.width[p], j = c - off;
         float* __restrict__ dxp = P.dx[p] ? P.dx[p] + (size_t)b0 * W + j : nullptr;
         const float wj = wcat[c];
+        const bool relu = P.relu[p] != 0;
         float acc = 0.f;
 #pragma unroll
         for (int r = 0; r < kTailRows; ++r) {
             if (r < nb) {
-                acc = fmaf(s_dl[r], tile[r * C + c], acc);
-                if (dxp) dxp[(size_t)r * W] = s_dl[r] * wj;
+                const float xv = tile[r * C + c];
+                acc = fmaf(s_dl[r], xv, acc);
+                if (dxp) dxp[(size_t)r * W] = (relu && !(xv > 0.f)) ? 0.f : s_dl[r] * wj;
             }
         }
         prow[c] = acc;
@@ -771,7 +774,7 @@ RECALGO_EXPORT int recalgo_logit_loss_fwd_bwd(const float* const* x_parts, const
                                               int n_parts, const float* bias, const float* addend0, const float* addend1,
                                               const float* labels, const float* loss_addend, int B, float grad_scale,
                                               float* logit, float* prob,
-                                              float* dlogit, float* const* dx_parts, float* partials,
+                                              float* dlogit, float* const* dx_parts, const int* relu_parts, float* partials,
                                               recalgo_stream_t stream) {
     RECALGO_REQUIRE(n_parts >= 1 && n_parts <= kHeadMaxParts && x_parts && w_parts && widths && B > 0);
     RECALGO_REQUIRE(labels && logit && prob && dlogit && partials);
@@ -784,6 +787,7 @@ RECALGO_EXPORT int recalgo_logit_loss_fwd_bwd(const float* const* x_parts, const
         P.w[p] = on ? w_parts[p] : nullptr;
         P.dx[p] = on && dx_parts ? dx_parts[p] : nullptr;
         P.width[p] = on ? widths[p] : 0;
+        P.relu[p] = (on && relu_parts) ? relu_parts[p] : 0;
         P.C += P.width[p];
     }
     P.bias = bias; P.addend[0] = addend0; P.addend[1] = addend1; P.labels = labels; P.loss_addend = loss_addend; P.grad_scale = grad_scale;

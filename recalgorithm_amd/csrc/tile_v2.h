@@ -272,7 +272,8 @@ __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r 
 // 128 bytes each): 16 dword stores per lane, and the 512 workgroups of a layer all issue them at once — 3 us of a 21 us launch
 // (scripts/mfma_lab.hip timeline).  Instead the tile goes through `T` (32 x kLdT floats of LDS private to the wave: the operand
 // ring is free after the main loop's last barrier) and every lane gets float4 (row, 4 columns) pieces: 8 lanes per 128-byte
-// row segment, 8 rows per instruction, 4 dwordx4 stores per lane.  f(row, col, v): row / col inside the tile, col % 4 == 0.
+// row segment, 8 rows per instruction, 4 dwordx4 stores per lane.  f(it, row, col, v): piece it < 4 (compile time) of this
+// lane, row = 8 it + lane / 8 and col = 4 (lane % 8) inside the tile.
 constexpr int kLdT = 36;
 constexpr int kTileScratch = 32 * kLdT;
 template <class F>
@@ -284,7 +285,7 @@ __device__ __forceinline__ void tile_rows(float* __restrict__ T, const f32x16& a
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int row = it * 8 + (lane >> 3), col = (lane & 7) * 4;
-        f(row, col, *reinterpret_cast<const float4*>(T + row * kLdT + col));
+        f(it, row, col, *reinterpret_cast<const float4*>(T + row * kLdT + col));
     }
     __builtin_amdgcn_wave_barrier();
 }

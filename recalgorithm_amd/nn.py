@@ -101,13 +101,33 @@ def _bn_link_of(x: torch.Tensor):
     return link if (link is not None and x.dim() == 2 and x.is_contiguous() and tuple(x.shape) == tuple(link.x.shape)) else None
 
 
+class ReluSource:
+    """Rides on the output tensor of a tf.layers.dense(..., relu) (`_recalgo_relu_src`).  A consumer whose backward kernel can
+    mask its input gradient with that tensor itself — the next dense layer (recalgo_dense_bwd_bn dx_relu_mask), the fused
+    loss tail (recalgo_logit_loss_fwd_bwd relu_parts) — does so and leaves the gradient tensor here; the producing layer's
+    backward skips its own mask (the mask loads of both of its GEMMs) when the gradient autograd hands it IS that tensor.
+    Any other consumer of the activation makes autograd sum into a new tensor (the reference held here keeps the engine from
+    accumulating in place): the pointer differs and the mask is applied as before — idempotent on the pre-masked share."""
+    __slots__ = ("premasked",)
+
+    def __init__(self):
+        self.premasked = None
+
+    def take(self, g: torch.Tensor) -> bool:
+        pm, self.premasked = self.premasked, None
+        return pm is not None and pm.data_ptr() == g.data_ptr() and pm.shape == g.shape and pm.stride() == g.stride()
+
+
 class _DenseFn(Function):
     @staticmethod
     def forward(ctx, anchor, x, kernel: Variable, bias: Optional[Variable], relu: bool, input_l2: float = 0.0,
-                grad_join: Optional[GradJoin] = None, bn_partials: Optional[torch.Tensor] = None):
+                grad_join: Optional[GradJoin] = None, bn_partials: Optional[torch.Tensor] = None,
+                relu_src: Optional[ReluSource] = None):
         ctx.input_l2 = float(input_l2)
         ctx.grad_join = grad_join
         ctx.bn_link = _bn_link_of(x)
+        ctx.relu_src = relu_src
+        ctx.x_relu_src = getattr(x, "_recalgo_relu_src", None) if (x.dim() == 2 and x.is_contiguous()) else None
         x2 = x.reshape(-1, x.shape[-1])
         ctx.hip = x2.is_cuda and x2.dtype == torch.float32 and _mfma_dense(x2.shape[1])
         if ctx.hip:
@@ -140,18 +160,24 @@ class _DenseFn(Function):
             # the ReLU mask rides on the staging of g in both GEMMs, the bias gradient on the weight-gradient one; the
             # split partials of the weight gradient are summed by ONE launch per backward pass (ops.flush_dense_splits)
             mask = y if ctx.relu else None
+            if mask is not None and ctx.relu_src is not None and ctx.relu_src.take(g2):
+                mask = None                        # the consumer's backward kernel masked its dx with y already
             db = None if bias is None else bias.grad
             if ctx.needs_input_grad[1] and _merged_bwd():
                 # input and weight gradient in ONE launch
                 link = ctx.bn_link if ctx.grad_join is None else None
+                src = ctx.x_relu_src if ctx.grad_join is None else None
                 dx = ops.dense_bwd(x2, g2, mask, kernel.data, kernel.grad, db, c_in=x2 if ctx.input_l2 else None,
                                    beta=ctx.input_l2, defer=True,
-                                   bn=None if link is None else (link.x, link.mean, link.rstd, link.new_sums())).view(ctx.xshape)
+                                   bn=None if link is None else (link.x, link.mean, link.rstd, link.new_sums()),
+                                   premask=None if src is None else x2).view(ctx.xshape)
+                if src is not None:
+                    src.premasked = dx             # x is the ReLU output of the layer below: its gradient is masked here
                 if link is not None:
                     link.grad_ptr = dx.data_ptr()
                 if ctx.grad_join is not None and ctx.grad_join.park(dx):
                     dx = None                      # added by the other consumer of x in its backward kernel
-                return None, dx, None, None, None, None, None, None
+                return None, dx, None, None, None, None, None, None, None
             if _wgrad_side_stream():
                 # (measured: slower — DCN step 0.319 vs 0.268 ms: the cross-stream dependencies cost more than the overlap
                 # buys.  Kept as an experiment switch.)
@@ -169,7 +195,7 @@ class _DenseFn(Function):
                                          c_in=x2 if ctx.input_l2 else None, beta=ctx.input_l2).view(ctx.xshape)
                 if ctx.grad_join is not None and ctx.grad_join.park(dx):
                     dx = None                      # added by the other consumer of x in its backward kernel
-            return None, dx, None, None, None, None, None, None
+            return None, dx, None, None, None, None, None, None, None
         if not g2.is_contiguous():
             g2 = g2.contiguous()
         if bias is not None and _hip(g2, g2.shape[1]):
@@ -186,7 +212,7 @@ class _DenseFn(Function):
             dx = torch.addmm(x2, g2, kernel.data.t(), beta=ctx.input_l2)
         else:
             dx = g2 @ kernel.data.t()
-        return None, dx.view(ctx.xshape), None, None, None, None, None, None
+        return None, dx.view(ctx.xshape), None, None, None, None, None, None, None
 
 
 class _Dense1Fn(Function):
@@ -310,9 +336,12 @@ def dense(x, units, activation: Optional[str] = None,
             and _mfma_dense(x.shape[1]) and getattr(getattr(store.anchor, "_recalgo_store", None), "sync_bn", None) is None):
         from . import ops
         bn_part = torch.empty(ops.bn_partial_rows(x.shape[0]), 2 * units, device=x.device, dtype=torch.float32)
-    out = _DenseFn.apply(store.anchor, x, kernel, bias, activation == "relu", input_l2, grad_join, bn_part)
+    relu_src = ReluSource() if (activation == "relu" and not store.building) else None
+    out = _DenseFn.apply(store.anchor, x, kernel, bias, activation == "relu", input_l2, grad_join, bn_part, relu_src)
     if bn_part is not None:
         out._recalgo_bn_partials = bn_part
+    if relu_src is not None:
+        out._recalgo_relu_src = relu_src
     return out
 
 

@@ -1149,9 +1149,11 @@ def dense_bwd_weights(x: torch.Tensor, g: torch.Tensor, y_mask: Optional[torch.T
 
 def dense_bwd(x: torch.Tensor, g: torch.Tensor, y_mask: Optional[torch.Tensor], w: torch.Tensor, dw: torch.Tensor,
               dbias: Optional[torch.Tensor], c_in: Optional[torch.Tensor] = None, beta: float = 0.0,
-              defer: bool = False, bn=None) -> torch.Tensor:
+              defer: bool = False, bn=None, premask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Both gradients of a dense layer in one launch (recalgo_dense_bwd): returns dx = (g * [y_mask > 0]) @ w^T
     (+ beta * c_in); dw / dbias as dense_bwd_weights (valid after flush_dense_splits() when `defer`).
+    premask [M, K] (rows contiguous): dx is zeroed where premask <= 0 (before the beta * c_in term) — x itself when x is the
+    ReLU output of the layer below, whose backward then needs no mask (nn.ReluSource).
     bn = (bn_x [M, K] contiguous, mean [K], rstd [K], partials [bn_partial_rows(M), 2 K]): x is the output of a training-mode
     BatchNorm over bn_x — the launch also leaves the sums that BatchNorm's backward starts with (recalgo_dense_bwd_bn)."""
     x, g, w = _mat(x, "x"), _mat(g, "g"), _mat(w, "w")
@@ -1179,9 +1181,12 @@ def dense_bwd(x: torch.Tensor, g: torch.Tensor, y_mask: Optional[torch.Tensor], 
                 or tuple(bpart.shape) != (bn_partial_rows(M), 2 * K) or not bpart.is_contiguous()):
             raise ValueError("dense_bwd: bn = (x [M, K], mean [K], rstd [K], partials [bn_partial_rows(M), 2 K])")
         bnp = (_p(bx), _p(bmean), _p(brstd), _p(bpart))
+    if premask is not None and (tuple(premask.shape) != (M, K) or premask.stride(1) != 1 or premask.dtype != torch.float32):
+        raise ValueError("dense_bwd: premask must be [M, K] fp32 with contiguous rows")
     _lib.check(lib.recalgo_dense_bwd_bn(_p(x), x.stride(0), _p(g), g.stride(0), _p(y_mask), _p(w), M, K, N, _p(c_in),
                                         0 if c_in is None else c_in.stride(0), float(beta), _p(dx), K, _p(dw), _p(dbias), _p(ws),
-                                        int(defer), *bnp, _stream(x)), "recalgo_dense_bwd")
+                                        int(defer), *bnp, _p(premask), 0 if premask is None else premask.stride(0), _stream(x)),
+               "recalgo_dense_bwd")
     if defer:
         _dense_pending.append((M, K, N, ws, dw, dbias))
     return dx
@@ -1461,14 +1466,20 @@ class _LogitLossFn(Function):
         loss = torch.empty(1, device=dev, dtype=torch.float32)
         need = ctx.needs_input_grad[6:6 + n_parts]
         dxs = [torch.empty_like(t) if nd else None for t, nd in zip(parts, need)]
+        # a part that IS the ReLU output of a dense layer gets its gradient already masked (nn.ReluSource)
+        srcs = [getattr(t, "_recalgo_relu_src", None) if nd else None for t, nd in zip(parts, need)]
+        relu_flags = (ctypes.c_int * n_parts)(*[int(sr is not None) for sr in srcs])
         lb = labels.contiguous().view(-1).to(torch.float32)
         wi = (ctypes.c_int * n_parts)(*widths)
         _lib.check(lib.recalgo_logit_loss_fwd_bwd(
             _ptr_array(parts), _ptr_array(ws_w), wi, n_parts, None if bias is None else _p(bias.data),
             _p(addends[0].contiguous().view(-1)) if n_addends > 0 else None,
             _p(addends[1].contiguous().view(-1)) if n_addends > 1 else None,
-            _p(lb), _p(loss_addend), B, float(_loss_seed), _p(logit), _p(prob), _p(dlogit), _ptr_array(dxs), _p(partials), _stream(logit)),
-            "recalgo_logit_loss_fwd_bwd")
+            _p(lb), _p(loss_addend), B, float(_loss_seed), _p(logit), _p(prob), _p(dlogit), _ptr_array(dxs), relu_flags, _p(partials),
+            _stream(logit)), "recalgo_logit_loss_fwd_bwd")
+        for sr, dxp in zip(srcs, dxs):
+            if sr is not None:
+                sr.premasked = dxp
         # deferred column sums: dw of every head (contiguous columns of the partial rows), d bias, the loss value
         col, i = 0, 0
         for kernel, n in heads:

@@ -294,3 +294,78 @@ def test_dense_bwd_leaves_the_batchnorm_backward_sums(dev, M, K, N):
             assert_close(d1, d0.double(), what="BatchNorm backward on the epilogue's sums", reduced=True)
             assert_close(dg1, dg0.double(), what="d(gamma) on the epilogue's sums", reduced=True)
             assert_close(dbt1, dbt0.double(), what="d(beta) on the epilogue's sums", reduced=True)
+
+
+@pytest.mark.parametrize("M,K,N,with_bn", [(4096, 512, 256, False), (300, 100, 52, False), (65, 82, 50, False), (4096, 256, 128, True)])
+def test_dense_bwd_masks_its_input_gradient_with_the_relu_output_below(dev, M, K, N, with_bn):
+    """recalgo_dense_bwd_bn(dx_relu_mask=): dx = (g * [y > 0]) W^T zeroed where the mask tensor is <= 0 (the row-wise
+    epilogue, the element-wise one for widths that are not float4-addressable, the BatchNorm-sums epilogue); dW / db unchanged."""
+    gen = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=gen).clamp(min=0).to(dev)       # a ReLU output: the mask IS the layer's input
+    w = (torch.randn(K, N, generator=gen) / K ** 0.5).to(dev)
+    g, y = torch.randn(M, N, generator=gen).to(dev), torch.randn(M, N, generator=gen).to(dev)
+    dw, db = torch.zeros(K, N, device=dev), torch.zeros(N, device=dev)
+    bn = None
+    if with_bn:
+        bx = torch.randn(M, K, generator=gen).to(dev)
+        mean, rstd = bx.mean(0), 1.0 / (bx.var(0, unbiased=False) + 1e-3).sqrt()
+        part = torch.zeros(ops.bn_partial_rows(M), 2 * K, device=dev)
+        bn = (bx, mean, rstd, part)
+    dx = ops.dense_bwd(x, g, y, w, dw, db, defer=True, bn=bn, premask=x)
+    ops.flush_dense_splits()
+    g2 = (g * (y > 0)).double()
+    ref = (g2 @ w.double().t()) * (x > 0)
+    assert_close(dx, ref, what="dense dgrad, masked by the layer's input", reduced=True)
+    assert bool((dx[x <= 0] == 0).all())
+    assert_close(dw, x.double().t() @ g2, what="dense wgrad beside the masked dgrad", reduced=True)
+    if with_bn:
+        xh = (bx.double() - mean.double()) * rstd.double()
+        s = part.double().view(-1, 2, K).sum(0)
+        assert_close(s[0], ref.sum(0), what="bn sums of the masked dx", reduced=True)
+        assert_close(s[1], (ref * xh).sum(0), what="bn sums of the masked dx * xhat", reduced=True)
+
+
+@pytest.mark.parametrize("second_consumer", [False, True])
+def test_relu_source_protocol(dev, second_consumer):
+    """nn.ReluSource: in a chain dense(relu) -> dense the upper layer's backward masks dx with its input and the lower layer
+    runs WITHOUT a mask; as soon as the activation has another consumer autograd hands the lower layer a summed tensor and
+    it applies its mask as before.  Either way the gradients are those of the definition."""
+    from recalgorithm_amd import nn
+    from recalgorithm_amd.variables import Variable, VariableStore
+    gen = torch.Generator().manual_seed(5 + int(second_consumer))
+    M, K, H, N = 512, 96, 128, 64
+    x = torch.randn(M, K, generator=gen)
+    w1, b1 = torch.randn(K, H, generator=gen) / K ** 0.5, torch.randn(H, generator=gen) * 0.1
+    w2, b2 = torch.randn(H, N, generator=gen) / H ** 0.5, torch.randn(N, generator=gen) * 0.1
+    gy, gz = torch.randn(M, N, generator=gen), torch.randn(M, H, generator=gen)
+    store = VariableStore(dev)
+    k1, c1, k2, c2 = (Variable(n, t.to(dev)) for n, t in (("k1", w1), ("b1", b1), ("k2", w2), ("b2", b2)))
+    xd = x.to(dev).requires_grad_(True)
+    src = nn.ReluSource()
+    y1 = nn._DenseFn.apply(store.anchor, xd, k1, c1, True, 0.0, None, None, src)
+    y1._recalgo_relu_src = src
+    y2 = nn._DenseFn.apply(store.anchor, y1, k2, c2, False, 0.0, None, None, None)
+    loss = (y2 * gy.to(dev)).sum()
+    if second_consumer:
+        loss = loss + (y1 * gz.to(dev)).sum()
+    calls, real = [], ops.dense_bwd
+
+    def spy(x_, g_, mask, *a, **k):
+        calls.append((tuple(g_.shape), mask is not None, k.get("premask") is not None))
+        return real(x_, g_, mask, *a, **k)
+    ops.dense_bwd = spy
+    try:
+        loss.backward()
+    finally:
+        ops.dense_bwd = real
+    ops.flush_dense_splits()
+    # upper layer: no mask of its own (no ReLU), masks its dx; lower layer: masked by the upper one unless it has a second consumer
+    assert calls[0] == ((M, N), False, True)
+    assert calls[1] == ((M, H), second_consumer, False)
+    P = [t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    r1 = torch.relu(P[0] @ P[1] + P[2])
+    rl = ((r1 @ P[3] + P[4]) * gy.double()).sum() + ((r1 * gz.double()).sum() if second_consumer else 0.0)
+    rl.backward()
+    for got, want, what in ((xd.grad, P[0].grad, "dx"), (k1.grad, P[1].grad, "dW1"), (c1.grad, P[2].grad, "db1"),
+                            (k2.grad, P[3].grad, "dW2"), (c2.grad, P[4].grad, "db2")):
+        assert_close(got, want, what=f"relu-source chain {what}", reduced=True)
