@@ -903,9 +903,7 @@ def main():
                                  "updates are replayed bit-identically when the row is next read, swept or flushed), fused with the "
                                  "row-gradient scatter"),
                    "launch": launch,
-                   "dense_layers": ("hipBLASLt (RECALGO_DENSE=blas), " + ("TunableOp" if args.tunable else "default selection")
-                                    if os.environ.get("RECALGO_DENSE") == "blas" else
-                                    "hand-written fp32 MFMA (csrc/dense.hip); layers wider than 4096 inputs on hipBLASLt, "
+                   "dense_layers": ("hand-written fp32 MFMA (csrc/dense.hip + tile_v2.h); layers wider than 4096 inputs on hipBLASLt, "
                                     + ("TunableOp" if args.tunable else "default selection")),
                    "parallelism": (f"dp{world} + embedding rows sharded r % {world} (RCCL all_to_all), dense grads all-reduced"
                                    + (" [gloo_staged bring-up mode: NOT a benchmark]" if staged else "")

@@ -91,12 +91,8 @@ class _Prefetch:
         self.upstream, self.n = upstream, max(int(n), 1)
 
     def __iter__(self):
-        import os
         import queue
         import threading
-        if os.environ.get("RECALGO_PREFETCH", "1") == "0":
-            yield from self.upstream
-            return
         q: "queue.Queue" = queue.Queue(maxsize=self.n)
         stop = threading.Event()
 

@@ -1057,12 +1057,9 @@ int launch_contract_DN(const float* P, const float* Q, const float* F, int B, in
 template <int D>
 int launch_contract_D(int NT, const float* P, const float* Q, const float* F, int B, int HP, int HQ, int C,
                       float* out, int accumulate, float* pool, int pool_stride, int pool_col, hipStream_t st) {
-    // column tiles per workgroup: 2 (128 registers, 4 waves / SIMD) or — RECALGO_CIN_NT=4, tuning knob — up to 4 (one
-    // workgroup covers N <= 128: fewer barriers per MFMA, but 256 registers with the two-level accumulators)
-    static const int nt_max = [] { const char* e = getenv("RECALGO_CIN_NT"); return e && atoi(e) == 4 ? 4 : 2; }();
+    // column tiles per workgroup of the general kernel: at most 2 (128 registers with the two-level accumulators; wider layers
+    // are column chunks over blockIdx.y — the benchmark's shapes take cin_contract2_kernel instead)
     if (NT == 1) return launch_contract_DN<D, 1>(P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);
-    if (nt_max == 4 && NT == 3) return launch_contract_DN<D, 3>(P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);
-    if (nt_max == 4 && NT == 4) return launch_contract_DN<D, 4>(P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);
     return launch_contract_DN<D, 2>(P, Q, F, B, HP, HQ, C, out, accumulate, pool, pool_stride, pool_col, st);
 }
 

@@ -765,10 +765,8 @@ inline bool fast_rm(const Operand& o, int n_idx) { return o.p == nullptr || (o.v
 // rounds, the second 3/4 full, and pays the launch ramp + pipeline fill + epilogue (~6 us) twice: 42 us for 22 us of
 // matrix work.  Instead the grid is sized to ONE resident round with equal work per workgroup: u = total chunk-tiles /
 // resident; a dgrad workgroup takes round(u / chunks per tile) consecutive output tiles, the weight gradient is split over
-// the batch into slabs of ~u chunks.  RECALGO_DENSE_RESIDENT_BLOCKS overrides the 512
-// (RECALGO_DENSE_WGRAD_BLOCKS: a fixed wgrad block target instead, the old policy).
-static const int kResidentBlocks = [] { const char* e = getenv("RECALGO_DENSE_RESIDENT_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
-static const int kWgradTargetBlocks = [] { const char* e = getenv("RECALGO_DENSE_WGRAD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+// the batch into slabs of ~u chunks.
+constexpr int kResidentBlocks = 512;
 
 struct BwdBalance {
     int tiles_per_block;   // dgrad
@@ -779,12 +777,6 @@ inline BwdBalance bwd_balance(int M, int K, int N) {
     const int tw = cdiv(K, BM) * cdiv(N, BN), cw = cdiv(M, BK);           // wgrad: tiles, chunks per tile over the whole batch
     const int max_s = cdiv(M, 4 * BK) < 1 ? 1 : cdiv(M, 4 * BK);         // at least four chunks per split
     BwdBalance b{1, 1};
-    if (kWgradTargetBlocks > 0) {
-        int want = cdiv(kWgradTargetBlocks, tw);
-        if (want >= 8) want = want / 8 * 8;
-        b.splits = want > max_s ? max_s : (want < 1 ? 1 : want);
-        return b;
-    }
     // chunk-tiles per workgroup for one resident round; a layer too large for one round (AFM's attention net: 1.3 M rows)
     // runs several rounds of workgroups of at most 64 chunks
     double u = ((double)gd * cd + (double)tw * cw) / kResidentBlocks;

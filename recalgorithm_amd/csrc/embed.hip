@@ -509,15 +509,8 @@ inline size_t agg_smem(int W, unsigned ex) {
     return 2 * ex * (sizeof(unsigned long long) + (size_t)W * sizeof(float) + sizeof(int)) + 16;
 }
 
-// examples per workgroup of a scatter kernel; RECALGO_SCATTER_TILE=32|64|128|256 overrides (tuning knob)
-inline unsigned scatter_tile(unsigned dflt) {
-    static const unsigned forced = [] {
-        const char* e = getenv("RECALGO_SCATTER_TILE");
-        const long v = e ? atol(e) : 0;
-        return (v == 32 || v == 64 || v == 128 || v == 256) ? (unsigned)v : 0u;
-    }();
-    return forced ? forced : dflt;
-}
+// examples per workgroup of a scatter kernel
+inline unsigned scatter_tile(unsigned dflt) { return dflt; }
 
 // dynamic LDS above 64 KiB must be opted into per kernel
 #define ENSURE_SMEM(kern, bytes)                                                                       \

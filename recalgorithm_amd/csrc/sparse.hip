@@ -516,8 +516,6 @@ __device__ __forceinline__ long long sweep_unit_row(int c, int period, unsigned 
     return (((long long)c + (long long)period * (u >> (2 + g))) << (8 + g)) + (long long)(u & ((4u << g) - 1u)) * kSweepRows;
 }
 inline unsigned sweep_block_shift(long long rows, int period) {
-    static const int forced = [] { const char* e = getenv("RECALGO_SPARSE_SWEEP_BLOCK_SHIFT"); return e ? atoi(e) : -1; }();   // (tuning aid)
-    if (forced >= 0 && forced <= 8) return (unsigned)forced;
     unsigned g = 0;
     while (g < 8 && ((rows >> (8 + g)) / (period < 1 ? 1 : period)) > 512) ++g;
     return g;
@@ -1340,15 +1338,9 @@ inline Deferred deferred_of(const recalgo_deferred_adam_t* d) {
 inline bool nb_ok(int nb_log2) { return nb_log2 >= 8 && nb_log2 <= 13; }
 // The bucket counters take integer atomics from every tile of the plan (one per tile-distinct row in `prepare`, one
 // returning add per (tile, bucket) in `place`).  Atomics on one cache line are served one after the other, so the
-// counters are spread: one every 1 << kCounterShift words (RECALGO_SPARSE_COUNTER_SHIFT, tuning aid).
-inline unsigned counter_shift() {
-    static const unsigned v = [] {
-        const char* e = getenv("RECALGO_SPARSE_COUNTER_SHIFT");
-        const int x = e ? atoi(e) : 4;
-        return (unsigned)(x < 0 ? 0 : (x > 5 ? 5 : x));
-    }();
-    return v;
-}
+// counters are spread: one every 16 words = one per 64-byte line (1024 counters packed into 32 lines cost + 10 us in
+// `prepare` and in `place`; measured in round 4).
+inline unsigned counter_shift() { return 4u; }
 
 struct Ws { float* hdr; unsigned* total; unsigned* cursor; uint4* sched; unsigned* offs; unsigned long long* keys;
             unsigned long long* keys_alt; float* partials; float* partials1; };
@@ -1374,10 +1366,6 @@ inline Ws carve(void* ws, int64_t cap, int nb_log2) {
 
 RECALGO_EXPORT int recalgo_scatter_plan_buckets_log2(int64_t n_requests) {
     // ~64-128 entries per bucket (one workgroup each in `apply`, up to 256 ranked by comparison), 1024 .. 8192 buckets
-    if (const char* e = getenv("RECALGO_SPARSE_NB_LOG2")) {           // (tuning aid)
-        const int v = atoi(e);
-        if (v >= 8 && v <= 13) return v;
-    }
     int l = 10;
     while (l < 13 && (n_requests >> l) > 128) ++l;          // (DIN's 311 k requests: 4096 buckets of ~76 — `apply` 74 -> 65 us)
     return l;

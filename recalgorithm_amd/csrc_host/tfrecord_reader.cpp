@@ -587,6 +587,7 @@ struct Pipeline {
             pend.clear();
         };
         bool bad = false, multi = false;
+        size_t multi_col = 0;
         std::string missing;
         for (size_t i = i0; i < i1; ++i) {
             for (size_t f = 0; f < F; ++f) {
@@ -644,7 +645,7 @@ struct Pipeline {
                             if (n++ == 0) first = pl;
                         });
                     });
-                    if (n > 1) multi = true;
+                    if (n > 1 && !multi) { multi = true; multi_col = f; }
                     if (n == 0) {
                         if (slot_of[f] >= 0) pend[(size_t)slot_of[f]].vm = nullptr;
                         slot_of[f] = -1;
@@ -677,7 +678,10 @@ struct Pipeline {
         resolve();
         if (bad || multi || !missing.empty()) {
             std::lock_guard<std::mutex> lk(m);
-            if (multi) S.multi = true;
+            if (multi && !S.multi) {
+                S.multi = true;
+                S.error = "feature " + keys[multi_col] + " holds more than one value in a record";
+            }
             if (bad && S.error.empty()) S.error = "malformed Example in a record";
             if (!missing.empty() && S.error.empty()) { S.error = missing; S.missing = true; }
         }
@@ -1215,7 +1219,10 @@ EXPORT int64_t recalgo_pipeline_next(void* pipeline, int* slot) {
         P->error = S.error;
         return S.missing ? -3 : -1;
     }
-    if (S.multi) return -2;
+    if (S.multi) {
+        P->error = S.error;                                     // (names the column)
+        return -2;
+    }
     ++P->next_out;
     if (slot) *slot = (int)d;
     return (int64_t)S.recs.size();

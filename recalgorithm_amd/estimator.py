@@ -623,12 +623,8 @@ class Estimator:
         """One eager training step on device-resident inputs; returns the loss tensor."""
         from . import ops
         seed = 1.0 if self.loss_grad_scale is None else float(self.loss_grad_scale)
-        from . import sparse
-        self.store.sparse_side_work = True           # (this method keeps the promise: launch_side_work() right below)
         with ops.loss_seed(seed):
             spec = self._call_model_fn(features, labels, ModeKeys.TRAIN)
-        sparse.launch_side_work(self.store)          # bucket counts + the sweep: beside the backward pass, on the side stream
-        self.store.sparse_side_work = False
         op = spec.train_op
         if self._seed_grad is None or float(self._seed_value) != seed or self._seed_grad.device != op.loss.device:
             self._seed_grad, self._seed_value = torch.full_like(op.loss.detach(), seed), seed   # made once, reused
@@ -893,6 +889,17 @@ def collect_checkpoint_state(store: VariableStore, global_step: int):
     return state, True
 
 
+def _same_device(a, b) -> bool:
+    """torch.device('cuda') and torch.device('cuda:0') name the same GPU when 0 is the current device."""
+    a, b = torch.device(a), torch.device(b)
+    if a.type != b.type:
+        return False
+    if a.type != "cuda":
+        return True
+    cur = torch.cuda.current_device()
+    return (cur if a.index is None else a.index) == (cur if b.index is None else b.index)
+
+
 def restore_checkpoint_state(store: VariableStore, state: dict, device, where: str = "checkpoint") -> int:
     """Load `state` into a built store; returns the global step.  The file holds whole tables (it is independent of
     the number of ranks): a row-sharded arena takes its own rows r % world == rank from them.  A variable that is
@@ -951,7 +958,7 @@ def restore_checkpoint_state(store: VariableStore, state: dict, device, where: s
             from . import sparse
             sparse.reset(a)          # (deferred-Adam bookkeeping likewise)
     if state.get("opt_step") is not None:
-        if store.opt_state is not None and store.opt_state["step"].device == torch.device(device):
+        if store.opt_state is not None and _same_device(store.opt_state["step"].device, device):
             # in place: the captured step, and the arenas' deferred-Adam plans (sparse.sync_arena), hold THIS tensor
             store.opt_state["step"].fill_(int(state["opt_step"]))
         else:

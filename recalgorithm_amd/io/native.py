@@ -174,7 +174,7 @@ class NativeDataset:
                 if B == 0:
                     return
                 if B == -2:
-                    raise _NotSingleValued()
+                    raise _NotSingleValued(lib.recalgo_pipeline_error(h).decode())
                 if B == -3:
                     raise ValueError(lib.recalgo_pipeline_error(h).decode())
                 if B < 0:
@@ -213,13 +213,26 @@ class NativeDataset:
                 first = next(it)
             except StopIteration:
                 return
-            except _NotSingleValued:
+            except _NotSingleValued as e:
+                self._note_multi(str(e))           # (the next iteration of this dataset goes straight to the ragged accessors)
                 it = None
             if it is not None:
                 yield first
-                yield from it
+                try:
+                    yield from it
+                except _NotSingleValued as e:
+                    self._note_multi(str(e))
+                    raise ValueError(f"{self.filepath}: {e} — found after batches of the shuffled stream were already consumed, "
+                                     "which the asynchronous pipeline cannot replay; iterate the dataset again (the column is now "
+                                     "read as a ragged feature) or set RECALGO_READER_PIPELINE=0") from None
                 return
         yield from self._iter_sync()
+
+    def _note_multi(self, message: str) -> None:
+        """`feature <key> holds more than one value in a record` (recalgo_pipeline_error): remember the column."""
+        parts = message.split(" ")
+        if len(parts) > 1 and parts[0] == "feature":
+            self._multi.add(parts[1])
 
     def _iter_sync(self):
         from ..feature_column import Ragged

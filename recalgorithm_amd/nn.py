@@ -21,16 +21,16 @@ def _hip(x: torch.Tensor, C: int) -> bool:
     return x.is_cuda and x.dtype == torch.float32 and ops.mlp_width_supported(C)
 
 
+DENSE_MAX_K = 4096
+
+
 def _mfma_dense(in_features: int = 0) -> bool:
-    """RECALGO_DENSE=blas keeps the library GEMMs (hipBLASLt through torch) for A/B measurements; the default is the
-    hand-written fp32-MFMA kernels with fused epilogues (csrc/dense.hip) for layers up to RECALGO_DENSE_MAX_K input
-    features (default 4096).  Wider layers are plain large GEMMs where the 64 x 64 tile is no longer the right shape:
-    FiBiNET's 9600 -> 512 layer runs 104 TFLOP/s on the hand-written kernel and the step is 10 % faster with the
-    library's TunableOp pick (1.42 vs 1.57 ms, profiles/r02o_fibinet_kernel_stats.md) — those go to hipBLASLt."""
-    import os
-    if os.environ.get("RECALGO_DENSE", "mfma") == "blas":
-        return False
-    return in_features <= int(os.environ.get("RECALGO_DENSE_MAX_K", "4096"))
+    """The hand-written fp32-MFMA kernels with fused epilogues (csrc/dense.hip) serve layers of up to DENSE_MAX_K input
+    features.  Wider layers are plain large GEMMs whose gradient tiles have short reductions (FiBiNET's 9600 -> 512: 150
+    column tiles of 16 chunks each): the per-tile prologue / epilogue of the 64 x 64 engine then costs 25 % — the step is
+    1.546 ms on it against 1.342 ms with the library kernels (round 5, same box; round 2: 1.57 vs 1.42) — those go to
+    hipBLASLt through torch."""
+    return in_features <= DENSE_MAX_K
 
 
 class GradJoin:
@@ -54,16 +54,6 @@ class GradJoin:
     def take(self) -> Optional[torch.Tensor]:
         t, self.pending, self.consumer_done = self.pending, None, True
         return t
-
-
-def _wgrad_side_stream() -> bool:
-    import os
-    return os.environ.get("RECALGO_WGRAD_STREAM", "0") == "1"
-
-
-def _merged_bwd() -> bool:
-    import os
-    return os.environ.get("RECALGO_DENSE_MERGED_BWD", "1") != "0"
 
 
 class BNLink:
@@ -163,7 +153,7 @@ class _DenseFn(Function):
             if mask is not None and ctx.relu_src is not None and ctx.relu_src.take(g2):
                 mask = None                        # the consumer's backward kernel masked its dx with y already
             db = None if bias is None else bias.grad
-            if ctx.needs_input_grad[1] and _merged_bwd():
+            if ctx.needs_input_grad[1]:
                 # input and weight gradient in ONE launch
                 link = ctx.bn_link if ctx.grad_join is None else None
                 src = ctx.x_relu_src if ctx.grad_join is None else None
@@ -178,24 +168,10 @@ class _DenseFn(Function):
                 if ctx.grad_join is not None and ctx.grad_join.park(dx):
                     dx = None                      # added by the other consumer of x in its backward kernel
                 return None, dx, None, None, None, None, None, None, None
-            if _wgrad_side_stream():
-                # (measured: slower — DCN step 0.319 vs 0.268 ms: the cross-stream dependencies cost more than the overlap
-                # buys.  Kept as an experiment switch.)
-                cur, side = torch.cuda.current_stream(g2.device), ops.side_stream(g2.device)
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    ops.dense_bwd_weights(x2, g2, mask, kernel.grad, db, defer=True)
-                ops._side_keepalive.append((x2, g2, y))
-                ops._side_dirty.add(g2.device)
-            else:
-                ops.dense_bwd_weights(x2, g2, mask, kernel.grad, db, defer=True)
-            dx = None
-            if ctx.needs_input_grad[1]:
-                dx = ops.dense_bwd_input(g2, y if ctx.relu else None, kernel.data,
-                                         c_in=x2 if ctx.input_l2 else None, beta=ctx.input_l2).view(ctx.xshape)
-                if ctx.grad_join is not None and ctx.grad_join.park(dx):
-                    dx = None                      # added by the other consumer of x in its backward kernel
-            return None, dx, None, None, None, None, None, None, None
+            # (no input gradient wanted: the first layer over a non-differentiable input.  Tried in round 2: the weight
+            # gradient on a second stream beside the dgrad chain — DCN 0.319 vs 0.268 ms; removed)
+            ops.dense_bwd_weights(x2, g2, mask, kernel.grad, db, defer=True)
+            return None, None, None, None, None, None, None, None, None
         if not g2.is_contiguous():
             g2 = g2.contiguous()
         if bias is not None and _hip(g2, g2.shape[1]):

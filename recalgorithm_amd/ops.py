@@ -101,14 +101,10 @@ def _live(arena, row_offset: int = 0):
     return ctypes.byref(_Live(live.data_ptr(), lst.data_ptr(), cnt.data_ptr(), int(row_offset)))
 
 
-def _sorted_scatter() -> bool:
-    """RECALGO_SPARSE=sorted (or the older RECALGO_SCATTER=sorted): the round-2 deterministic scatter — stable torch.sort +
-    ordered segment sums, live-row-list optimizer.  The default (owner) path is deterministic as well (sparse.py)."""
-    return sparse.scatter_mode() == "sorted"
-
-
 def scatter_rows_sorted(arena, rows: torch.Tensor, vals: torch.Tensor) -> None:
-    """arena.grad[rows[i], :] += vals[i, :] (rows < 0 skipped), deterministically; the rows join the live list."""
+    """arena.grad[rows[i], :] += vals[i, :] (rows < 0 skipped), deterministically (stable sort + ordered segment sums); the
+    rows join the live list.  Only for an arena that is NOT on the owner-computes path while its partner in a fused lookup is
+    (DeepFM's two arenas, one of them frozen or of an unsupported width)."""
     rows = rows.reshape(-1).contiguous()
     vals = vals.reshape(rows.numel(), -1).contiguous()
     srt, perm = torch.sort(rows, stable=True)
@@ -165,11 +161,6 @@ class _GatherFn(Function):
             ctx.src.set_grad(g)              # summed per row (and applied) by the optimizer's recalgo_scatter_apply
             return None, None, None, None, None
         g = g.contiguous()
-        if _sorted_scatter():
-            rows = torch.where(ids >= 0, ids + ctx.row_base.unsqueeze(0), torch.full_like(ids, -1))
-            scatter_rows_sorted(arena, rows, g.reshape(B * F, arena.K))
-            _flush(arena)
-            return None, None, None, None, None
         _lib.check(_lib_().recalgo_embedding_gather_bwd(
             _p(ids), _p(g), _p(ctx.row_base), B, F, arena.K, F * arena.K, 0, _p(arena.grad), _live(arena),
             _stream(ids)), "recalgo_embedding_gather_bwd")
@@ -215,16 +206,11 @@ class _BagMeanFn(Function):
         B = offsets.numel() - 1
         rb, vocab = arena.tables[table_name]
         g = g.contiguous()
-        if ctx.src is not None or _sorted_scatter():
+        if ctx.src is not None:
             lens = offsets[1:] - offsets[:-1]
             bag = torch.repeat_interleave(torch.arange(B, device=values.device), lens)
             cnt = torch.zeros(B, device=values.device).index_add_(0, bag, (values >= 0).float()).clamp_(min=1.0)
-            vals = g[bag] / cnt[bag].unsqueeze(1)
-            if ctx.src is not None:
-                ctx.src.set_grad(vals)
-                return None, None, None, None, None, None
-            scatter_rows_sorted(arena, torch.where(values >= 0, values + rb, torch.full_like(values, -1)), vals)
-            _flush(arena)
+            ctx.src.set_grad(g[bag] / cnt[bag].unsqueeze(1))
             return None, None, None, None, None, None
         gt = arena.grad[rb:rb + vocab]
         _lib.check(_lib_().recalgo_embedding_bag_mean_bwd(
@@ -276,15 +262,6 @@ class _SeqGatherFn(Function):
             ctx.src.set_grad(g)              # (no `arena.grad` access here: reading it would sum the pending sources now)
             return None, None, None, None, None, None, None
         g = g.contiguous()
-        if _sorted_scatter():
-            lens = (offsets[1:] - offsets[:-1]).clamp(max=T)
-            tpos = torch.arange(T, device=values.device).unsqueeze(0)
-            valid = tpos < lens.unsqueeze(1)                                   # [B, T]
-            src = (offsets[:-1].unsqueeze(1) + tpos).clamp(max=max(values.numel() - 1, 0))
-            ids_bt = torch.where(valid, values[src] if values.numel() else torch.full_like(src, -1), torch.full_like(src, -1))
-            scatter_rows_sorted(arena, torch.where(ids_bt >= 0, ids_bt + rb, torch.full_like(ids_bt, -1)), g.reshape(B * T, arena.K))
-            _flush(arena)
-            return None, None, None, None, None, None, None
         gt = arena.grad[rb:rb + vocab]
         _lib.check(_lib_().recalgo_sequence_gather_bwd(
             _p(values), _p(offsets), _p(g), B, T, arena.K, _p(gt), _live(arena, rb), _stream(offsets)),
@@ -357,17 +334,6 @@ class _DeepFMSparseFn(Function):
                 _flush(w1)
             if not colsum_of_dlogit(g_fm1, bias.grad.view(1)):      # (TRAIN step: a job of the step's deferred-sum launch)
                 torch.sum(g_fm1, dim=0, out=bias.grad.view(1))
-            return None, None, None, None, None, None, None
-        if _sorted_scatter():
-            K = arena.K
-            rows = torch.where(ids >= 0, ids + row_base.unsqueeze(0), torch.full_like(ids, -1))
-            e3, s3 = emb.reshape(B, F, K), fsum.reshape(B, 1, K)
-            vals = torch.addcmul(g_emb.reshape(B, F, K), g_fm2.reshape(B, 1, 1), s3 - e3)     # g_emb + g_fm2 * (S - e)
-            scatter_rows_sorted(arena, rows, vals)
-            scatter_rows_sorted(w1, rows, g_fm1.reshape(B, 1, 1).expand(B, F, 1))
-            _flush(arena)
-            _flush(w1)
-            torch.sum(g_fm1, dim=0, out=bias.grad.view(1))
             return None, None, None, None, None, None, None
         _lib.check(_lib_().recalgo_deepfm_sparse_bwd(
             _p(ids), _p(emb), _p(fsum), _p(g_emb), _p(g_fm1), _p(g_fm2), _p(row_base), B, F, arena.K,

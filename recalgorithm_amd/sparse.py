@@ -15,7 +15,7 @@ atomics, fused with the sparse optimizer) and the deferred-exact TF1 Adam state.
     tables                                            (named_arrays, checkpoints, export)
     tests / tools         materialize_grads(store)    the summed row gradients written to arena.grad (GRAD mode)
 
-RECALGO_SPARSE=owner (default) selects this path — for local arenas, and for the OWNER side of a row-sharded arena's
+This is the path of every arena the plan supports — for local arenas, and for the OWNER side of a row-sharded arena's
 exchange (parallel.StagedArena: the rows the peers request are a lookup of the shard's plan); `atomic` / `sorted` keep the
 round-2 kernels (LDS-aggregated float atomics / torch.sort + ordered segment sums) with the live-row-list optimizer.
 """
@@ -35,13 +35,19 @@ MAX_SOURCES = 16
 LR_RING = 1024
 
 
+# Test hooks (module attributes, not environment knobs): tests/test_gpu_sparse.py compares the owner-computes path with the
+# round-1 float-atomic scatter + live-row-list Adam (SCATTER_MODE = "atomic": what an arena outside the plan's domain — rows
+# wider than 256 floats — and the requester side of a row-sharded arena still run), a companion arena with a plan of its own
+# (COMPANION = False), and plans with a forced bucket count (NB_LOG2).
+SCATTER_MODE = "owner"
+COMPANION = True
+NB_LOG2 = None
+
+
 def scatter_mode() -> str:
-    m = os.environ.get("RECALGO_SPARSE")
-    if m is None:
-        m = {"atomic": "atomic", "sorted": "sorted"}.get(os.environ.get("RECALGO_SCATTER", ""), "owner")
-    if m not in ("owner", "atomic", "sorted"):
-        raise ValueError(f"RECALGO_SPARSE={m}: expected owner | atomic | sorted")
-    return m
+    if SCATTER_MODE not in ("owner", "atomic"):
+        raise ValueError(f"sparse.SCATTER_MODE = {SCATTER_MODE!r}: expected owner | atomic")
+    return SCATTER_MODE
 
 
 def sweep_period() -> int:
@@ -170,7 +176,6 @@ class ArenaPlan:
         self.nb_log2 = 10
         self.counted = None                    # signature of what the workspace's bucket totals currently hold
         self.swept = False                     # this step's share of the deferred-Adam sweep has been launched
-        self.side_pending: List[Source] = []   # lookups whose counts (and the sweep) wait for launch_side_work
         self.prescanned = None                 # signature the bucket-total prefix (offs / sched) was computed for, this step
         self.last_step: Optional[torch.Tensor] = None     # deferred-Adam: int32 [rows]
         self.lr_ring: Optional[torch.Tensor] = None
@@ -187,7 +192,7 @@ class ArenaPlan:
             return
         lib = _lib.load()
         cap = max((n_requests + 255) // 256 * 256, 256)          # slots (whole tiles)
-        self.nb_log2 = int(lib.recalgo_scatter_plan_buckets_log2(cap))
+        self.nb_log2 = int(lib.recalgo_scatter_plan_buckets_log2(cap)) if NB_LOG2 is None else int(NB_LOG2)
         self.capacity = cap
         nbytes = int(lib.recalgo_scatter_plan_workspace_bytes(cap, self.nb_log2, self.arena.K))
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.arena.weight.device)
@@ -287,21 +292,16 @@ def begin_lookup(arena, store, ids: torch.Tensor, offsets: Optional[torch.Tensor
         cp = plan_of(companion_arena)
         d1 = cp._deferred_struct()             # (the second arena's rows are caught up, and swept, by the same launch)
         c_rows = companion_arena.weight.shape[0] if d1 is not None else 0
-    # Only the catch-up has to precede the lookup's forward kernel.  The bucket counts (needed by `place`, after the
-    # backward pass) and the step's share of the sweep (needed by nobody before the next step) are either part of the same
-    # launch, or — when the caller promises to call launch_side_work() between the forward and the backward pass
-    # (Estimator.train_step) — a launch of their own on the step's SIDE stream, beside the backward pass
-    side = side_work_enabled(store)
-    flags = 0 if d is None else PREPARE_CATCHUP
-    if side:
-        plan.side_pending.append(src)
-    else:
-        flags |= PREPARE_COUNT
-        if d is not None and not plan.swept:
-            flags |= PREPARE_SWEEP
-            plan.swept = True
-            if d1 is not None:
-                plan_of(companion_arena).swept = True
+    # Only the catch-up has to precede the lookup's forward kernel; the bucket counts (needed by `place`, after the backward
+    # pass) and the step's share of the sweep (needed by nobody before the next step) ride in the same launch.  (Tried in
+    # round 4: those two on a side stream beside the backward pass — DCN 0.248 vs 0.242 ms, DIN 0.658 vs 0.608: the fork /
+    # join of the second stream costs more than the overlap buys; removed.)
+    flags = (0 if d is None else PREPARE_CATCHUP) | PREPARE_COUNT
+    if d is not None and not plan.swept:
+        flags |= PREPARE_SWEEP
+        plan.swept = True
+        if d1 is not None:
+            plan_of(companion_arena).swept = True
     if flags:
         _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), arena.K, ctypes.c_void_p(plan.ws.data_ptr()), plan.capacity, plan.nb_log2,
                                                first, flags, None if d is None else ctypes.byref(d),
@@ -309,62 +309,12 @@ def begin_lookup(arena, store, ids: torch.Tensor, offsets: Optional[torch.Tensor
                                                None if step is None else ctypes.c_void_p(step.data_ptr()), 0, _stream(arena.weight)),
                    "recalgo_scatter_prepare")
     plan.sources.append(src)
-    if not side:
-        plan.counted = plan.counted[:2] + (plan.counted[2] + (id(src),),)
+    plan.counted = plan.counted[:2] + (plan.counted[2] + (id(src),),)
     return src
 
 
-def side_work_enabled(store) -> bool:
-    # (measured: SLOWER — DCN 0.248 vs 0.242 ms, DIN 0.658 vs 0.608: the launch beside the backward pass takes 39 us instead of
-    # 28 and the fork / join of the second stream costs more than the overlap buys, as with every other two-stream variant
-    # tried on this stack.  Kept as an experiment switch, off by default.)
-    return bool(getattr(store, "sparse_side_work", False)) and os.environ.get("RECALGO_SPARSE_SIDE", "0") == "1"
-
-
-def launch_side_work(store) -> None:
-    """Between the forward and the backward pass of a TRAIN step: the bucket counts of the step's lookups and the step's share
-    of the deferred-Adam sweep, one launch per lookup on the step's side stream — they overlap the backward pass and are
-    joined by the optimizer (ops.flush_dense_splits -> join_side_streams).  Without this call the optimizer's launch
-    sequence does the same work itself (sparse._run)."""
-    todo = [(ar, plan_of(ar)) for ar in store.arenas.values() if plan_of(ar) is not None and plan_of(ar).side_pending]
-    if not todo:
-        return
-    from . import ops
-    lib = _lib.load()
-    for ar, plan in todo:
-        dev = ar.weight.device
-        cur, side = torch.cuda.current_stream(dev), ops.side_stream(dev)
-        side.wait_stream(cur)
-        st = store.opt_state
-        with torch.cuda.stream(side):
-            sid = ctypes.c_void_p(side.cuda_stream)
-            d = plan._deferred_struct()
-            pending, first = {id(s) for s in plan.side_pending}, 0
-            for s in plan.sources:
-                if id(s) in pending and s.n:
-                    flags, d1, c_rows = PREPARE_COUNT, None, 0
-                    if d is not None and not plan.swept:
-                        flags |= PREPARE_SWEEP
-                        plan.swept = True
-                        if s.companion is not None and plan_of(s.companion.arena).last_step is not None:
-                            cp = plan_of(s.companion.arena)
-                            d1, c_rows = cp._deferred_struct(), s.companion.arena.weight.shape[0]
-                            cp.swept = True
-                    cs = s.c_struct(ar.K)
-                    sw = bool(flags & PREPARE_SWEEP)
-                    _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), ar.K, ctypes.c_void_p(plan.ws.data_ptr()), plan.capacity,
-                                                           plan.nb_log2, first, flags, ctypes.byref(d) if sw else None,
-                                                           None if d1 is None else ctypes.byref(d1), ar.weight.shape[0], c_rows,
-                                                           sweep_period(), ctypes.c_void_p(st["step"].data_ptr()) if sw else None, 0, sid),
-                               "recalgo_scatter_prepare (side)")
-                    plan.counted = plan.counted[:2] + (plan.counted[2] + (id(s),),)
-                first += s.slots
-        plan.side_pending = []
-        ops._side_dirty.add(dev)
-
-
 def companion_enabled() -> bool:
-    return os.environ.get("RECALGO_SPARSE_COMPANION", "1") != "0"
+    return bool(COMPANION)
 
 
 def _pair(main: Source, main_arena, arena) -> bool:
@@ -419,7 +369,6 @@ def new_forward(store) -> None:
             plan.grad_materialized = False
         if plan is not None and plan.sources:
             plan.sources = []
-            plan.side_pending = []
             plan.grad_materialized = False
             if plan.ws is not None and plan.counted is not None and plan.counted[2]:
                 plan.clear_counts()            # (the abandoned forward's entries: normally consumed and cleared by `apply`)
@@ -457,6 +406,10 @@ def _merge_dense(sources: List[Source], K: int) -> List[Source]:
             g = s.g[:, :K].unsqueeze(1).expand(s.n_ex, s.F, K)
         else:
             g = torch.as_strided(s.g, (s.n_ex, s.F, K), (s.g.stride(0) if s.n_ex > 1 else s.F * fm, fm, 1))
+        if s.fm is not None:
+            # the FM second-order epilogue the kernels form on load (Source.set_grad): g + scale * (field_sum - emb)
+            sc, fs, em = s.fm
+            g = torch.addcmul(g, sc.reshape(-1, 1, 1), fs.reshape(s.n_ex, 1, K) - em.reshape(s.n_ex, s.F, K))
         grads.append(g.reshape(-1, K))
     allrows = torch.cat(rows).reshape(-1, 1).contiguous()
     merged = Source(allrows, None, None, 0, allrows.shape[0], 1)
@@ -472,7 +425,7 @@ def plan_scan_record(arena, lazy: bool):
     arena's `apply` (ops.adam_tf1_step_(plan_scans=)) — or None when `apply` will not find the totals of exactly its sources in
     the workspace (it then counts again, and `place` scans them itself)."""
     plan = plan_of(arena)
-    if plan is None or plan.ws is None or plan.companions or plan.side_pending or (plan.served and not plan.sources):
+    if plan is None or plan.ws is None or plan.companions or (plan.served and not plan.sources):
         return None
     srcs = [s for s in plan.sources if s.g is not None and s.n]
     if not srcs or len(srcs) > MAX_SOURCES or sum(s.slots for s in srcs) > plan.capacity or plan.counted != plan._signature(srcs):
@@ -529,6 +482,18 @@ def _run(plan: ArenaPlan, sources: List[Source], mode: int, step_dev, step_offse
                    "recalgo_scatter_prepare (sweep)")
         if dc0 is not None:
             plan_of(comp_arena).swept = True
+    if mode == MODE_ADAM and comp_arena is not None:
+        # the companion's share of the sweep rides on the launch that carries the MAIN arena's (begin_lookup, or the launch
+        # above).  When the main arena was swept by an earlier plain lookup of the step, the paired lookup's launch carries no
+        # sweep at all: the companion then gets a launch of its own — unswept, its untouched rows would lag past the lr ring
+        cpl = plan_of(comp_arena)
+        if cpl.last_step is not None and not cpl.swept:
+            dc1 = cpl._deferred_struct()
+            _lib.check(lib.recalgo_scatter_prepare(None, 1, ctypes.c_void_p(plan.ws.data_ptr()), plan.capacity, plan.nb_log2, 0,
+                                                   PREPARE_SWEEP, ctypes.byref(dc1), None, comp_arena.weight.shape[0], 0,
+                                                   sweep_period(), ctypes.c_void_p(step_dev.data_ptr()), step_offset - 1,
+                                                   _stream(a.weight)), "recalgo_scatter_prepare (companion sweep)")
+            cpl.swept = True
     if mode != MODE_GRAD:
         plan.swept = False                     # (the next step's first lookup sweeps again)
     b1, b2, eps = plan.betas
@@ -569,7 +534,6 @@ def _run(plan: ArenaPlan, sources: List[Source], mode: int, step_dev, step_offse
         cp.served = True
         cp.swept = False
     plan.counted = plan._signature([])         # (`apply` left the totals clean: the next step's `prepare` launches add to zero)
-    plan.side_pending = []
 
 
 def _companion_arena(sources: List[Source], mode: int):
@@ -695,5 +659,4 @@ def reset(arena) -> None:
         plan.sources = []
         plan.counted = None
         plan.swept = False
-        plan.side_pending = []
         plan.grad_materialized = False

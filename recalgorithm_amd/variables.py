@@ -206,8 +206,6 @@ class VariableStore:
 
     def housekeeping(self) -> None:
         """Cheap, sync-free maintenance the training loops call every few dozen steps."""
-        if os.environ.get("RECALGO_NO_HOUSEKEEPING") == "1":
-            return
         for ar in self.arenas.values():
             if getattr(ar, "tracks_live_rows", False):
                 ar.order_live_list()

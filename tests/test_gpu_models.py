@@ -401,11 +401,10 @@ def test_graphed_step_copies_into_private_buffers(dev):
 
 
 @pytest.mark.parametrize("model", ["dcn", "deepfm"])
-def test_sorted_scatter_makes_steps_and_resume_bit_reproducible(dev, model, tmp_path, monkeypatch):
-    """RECALGO_SCATTER=sorted replaces the float-atomic row-gradient scatter by a stable sort + ordered segment sums:
-    every other kernel of the step already sums in a fixed order, so (a) two runs of the same steps and (b) a run
-    interrupted by save_checkpoint / restore in a NEW estimator are BIT-identical — variables, tables, Adam moments."""
-    monkeypatch.setenv("RECALGO_SCATTER", "sorted")
+def test_steps_and_resume_are_bit_reproducible(dev, model, tmp_path):
+    """No kernel of the step issues a float atomic (the row-gradient scatter is owner-computes, every split sum has a fixed
+    order): (a) two runs of the same steps and (b) a run interrupted by save_checkpoint / restore in a NEW estimator are
+    BIT-identical — variables, tables, Adam moments."""
     from recalgorithm_amd.algorithm.DCN.dcn import dcn_model_fn
     from recalgorithm_amd.algorithm.DeepFM.deepfm import deepfm_model_fn
     fn = {"dcn": dcn_model_fn, "deepfm": deepfm_model_fn}[model]

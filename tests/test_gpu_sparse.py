@@ -280,10 +280,10 @@ def test_lazy_adam_matches_tf_lazy_adam(dev, rows, K):
 
 
 @pytest.mark.parametrize("model", ["dcn", "deepfm"])
-def test_models_train_identically_on_the_owner_and_the_sorted_paths(dev, model, monkeypatch):
+def test_models_train_identically_on_the_owner_and_the_atomic_paths(dev, model, monkeypatch):
     """DCN / DeepFM, three steps: the owner-computes path (deferred Adam; DeepFM's first-order arena as the companion of its
-    embedding arena) and the round-2 deterministic path (sorted scatter + live-list dense Adam) agree — the same
-    arithmetic, summed in a different order."""
+    embedding arena) and the round-1 path that arenas outside the plan's domain still take (LDS-aggregated float atomics +
+    live-list dense Adam; sparse.SCATTER_MODE, a test hook) agree — the same arithmetic, summed in a different order."""
     from recalgorithm_amd import feature_column as fc
     from recalgorithm_amd import sparse
     from recalgorithm_amd.algorithm.DCN.dcn import dcn_model_fn
@@ -292,8 +292,8 @@ def test_models_train_identically_on_the_owner_and_the_sorted_paths(dev, model, 
     from recalgorithm_amd.io import synth
     spec = synth.SynthSpec(n_fields=6, max_vocab=300, seed=11)
     results = {}
-    for mode in ("owner", "sorted"):
-        monkeypatch.setenv("RECALGO_SPARSE", mode)
+    for mode in ("owner", "atomic"):
+        monkeypatch.setattr(sparse, "SCATTER_MODE", mode)
         cats = [fc.categorical_column_with_identity(n, v) for n, v in zip(spec.names, spec.vocabs)]
         if model == "dcn":
             fn = dcn_model_fn
@@ -317,10 +317,10 @@ def test_models_train_identically_on_the_owner_and_the_sorted_paths(dev, model, 
         else:
             assert all(pl is None for pl in plans)
         results[mode] = (losses, {k: v.detach().cpu().double() for k, v in est.store.named_arrays().items()})
-    for a, b in zip(*[results[m][0] for m in ("owner", "sorted")]):
+    for a, b in zip(*[results[m][0] for m in ("owner", "atomic")]):
         assert abs(a - b) <= 1e-5 * abs(b)
-    for k, ref in results["sorted"][1].items():
-        assert_close(results["owner"][1][k], ref, what=f"owner vs sorted path: {k}", rtol=1e-4, reduced=True)
+    for k, ref in results["atomic"][1].items():
+        assert_close(results["owner"][1][k], ref, what=f"owner vs atomic path: {k}", rtol=1e-4, reduced=True)
 
 
 @pytest.mark.parametrize("lazy", [False, True])
@@ -334,7 +334,7 @@ def test_companion_arena_equals_its_own_plan_bit_for_bit(dev, lazy, monkeypatch)
     rows, K, F, n_ex = 4000, 16, 3, 700
     out = {}
     for companion in ("1", "0"):
-        monkeypatch.setenv("RECALGO_SPARSE_COMPANION", companion)
+        monkeypatch.setattr(sparse, "COMPANION", companion == "1")
         gen = torch.Generator().manual_seed(77)
         E, W = _arena(dev, rows, K, seed=3, name="e"), _arena(dev, rows, 1, seed=4, name="w")
         store = _Store(dev)
@@ -409,7 +409,7 @@ def test_plan_prefix_from_the_optimizer_launch_equals_place_scanning_itself(dev,
     identical arenas agree bit for bit after three steps, one arena on each path."""
     from recalgorithm_amd import ops, sparse as sp
     if nb_env is not None:
-        monkeypatch.setenv("RECALGO_SPARSE_NB_LOG2", nb_env)
+        monkeypatch.setattr(sp, "NB_LOG2", int(nb_env))
     n_ex, F = requests
     rows, K = 20000, 16
     gen = torch.Generator().manual_seed(n_ex + F)

@@ -63,9 +63,8 @@ def lib(monkeypatch):
     monkeypatch.setattr(sparse, "_supported", lambda arena: True)
     monkeypatch.setattr(sparse, "_stream", lambda t: None)
     monkeypatch.setattr(sparse.ctypes, "byref", lambda x: x)          # (the stand-in reads the structs directly)
-    monkeypatch.delenv("RECALGO_SPARSE", raising=False)
-    monkeypatch.delenv("RECALGO_SCATTER", raising=False)
-    monkeypatch.delenv("RECALGO_SPARSE_COMPANION", raising=False)
+    monkeypatch.setattr(sparse, "SCATTER_MODE", "owner")
+    monkeypatch.setattr(sparse, "COMPANION", True)
     return fake
 
 
@@ -251,15 +250,11 @@ def test_whole_table_readers_flush_the_deferred_state(lib):
     assert sparse.plan_of(E).last_step is None
 
 
-def test_scatter_mode_knob(monkeypatch):
-    monkeypatch.delenv("RECALGO_SPARSE", raising=False)
-    monkeypatch.delenv("RECALGO_SCATTER", raising=False)
+def test_scatter_mode_hook_and_sweep_period_knob(monkeypatch):
     assert sparse.scatter_mode() == "owner"
-    monkeypatch.setenv("RECALGO_SCATTER", "sorted")
-    assert sparse.scatter_mode() == "sorted"
-    monkeypatch.setenv("RECALGO_SPARSE", "atomic")
+    monkeypatch.setattr(sparse, "SCATTER_MODE", "atomic")
     assert sparse.scatter_mode() == "atomic"
-    monkeypatch.setenv("RECALGO_SPARSE", "bogus")
+    monkeypatch.setattr(sparse, "SCATTER_MODE", "bogus")
     with pytest.raises(ValueError):
         sparse.scatter_mode()
     monkeypatch.setenv("RECALGO_ADAM_SWEEP_PERIOD", "0")
