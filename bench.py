@@ -512,9 +512,10 @@ def kernel_rooflines(args, est, feats, device):
     pa, pw, pdx = ptrs(head_parts), ptrs(hw), ptrs(hdx)
     add("logit_loss(head + sigmoid + CE + head backward)",
         lambda: lib.recalgo_logit_loss_fwd_bwd(pa, pw, wi, len(head_parts), p(hb), None, None, p(lbl), None, B, 1.0, p(lg), p(pr),
-                                               p(dl), pdx, p(partials), st), B * (2 * Ch * 4 + 16) + rows_p * (Ch + 2) * 4)
+                                               p(dl), pdx, None, p(partials), st), B * (2 * Ch * 4 + 16) + rows_p * (Ch + 2) * 4)
     src_b, dst_b = torch.empty(B * F * 8 + B * 4, dtype=torch.uint8, device=device), torch.empty(B * F * 8 + B * 4, dtype=torch.uint8, device=device)
-    add("input_copy(batch -> the graph's static buffers)", lambda: dst_b.copy_(src_b), 2 * src_b.numel())
+    add("input_copy(batch -> the graph's static buffers)",
+        lambda: lib.recalgo_copy_bytes(p(dst_b), p(src_b), src_b.numel(), st), 2 * src_b.numel())
     # context MLP on the fp32 matrix cores (csrc/dense.hip): forward (bias + ReLU fused) and the merged backward launch
     # (input + weight gradient tiles, ReLU mask and bias gradient fused) of the three layers 416 -> 512 -> 256 -> 128
     from recalgorithm_amd import ops
@@ -532,11 +533,15 @@ def kernel_rooflines(args, est, feats, device):
         add(f"dense_fwd({Kd}->{Nd})", lambda: ops.dense_fwd(xd, wd, bd, True), (B * (Kd + Nd) + Kd * Nd) * 4, fl)
         # (the ONE merged launch, as in the step: the fixed-order sum of the batch-split slabs is a job of the step's
         #  deferred-sum launch, listed below — not a second launch per layer)
+        # As in the step (nn.ReluSource): the gradient a layer receives was masked with its ReLU output by the kernel that
+        # produced it (the layer above / the loss tail), so no mask is staged; a layer whose input is itself a ReLU output
+        # (all but the first) masks the input gradient it writes.
+        pm = xd.clamp_(min=0) if li > 0 else None
         def bwd_once():
-            ops.dense_bwd(xd, gd, yd, wd, dwd, dbd, defer=True)
+            ops.dense_bwd(xd, gd, None, wd, dwd, dbd, defer=True, premask=pm)
             ops._dense_pending.clear()
-        add(f"dense_bwd({Kd}->{Nd})", bwd_once, (B * (2 * Kd + 2 * Nd) + 2 * Kd * Nd) * 4, 2.0 * fl)
-        ops.dense_bwd(xd, gd, yd, wd, dwd, dbd, defer=True)          # leaves this layer's split slabs + its pending entry
+        add(f"dense_bwd({Kd}->{Nd})", bwd_once, (B * (2 * Kd + 2 * Nd + (Kd if li > 0 else 0)) + 2 * Kd * Nd) * 4, 2.0 * fl)
+        ops.dense_bwd(xd, gd, None, wd, dwd, dbd, defer=True, premask=pm)          # leaves this layer's split slabs + its pending entry
         keep.append((xd, gd, yd, wd, dwd, dbd))
         slab_bytes += int(lib.recalgo_dense_bwd_weights_workspace_bytes(B, Kd, Nd)) + (Kd * Nd + Nd) * 4
     # the step's deferred-sum launch: fixed-order sums of the three layers' split slabs (in the step it also sums the
