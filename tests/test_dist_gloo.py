@@ -445,3 +445,108 @@ def test_static_exchange_capacity_on_zipf_batches(world):
         errs.append(errq.get())
     assert not errs, "\n".join(errs)
     assert all(p.exitcode == 0 for p in procs)
+
+
+def _worker_config5(rank, port, errq, WORLD):
+    """BASELINE.json configs[4] scaled down (DeepFM: one large table row-sharded over 8 ranks + 25 small ones, 26 fields,
+    the K = 16 embedding arena and the K = 1 first-order arena looked up with the SAME requests): the static, de-duplicated
+    exchange at the bench's capacity factor — forward rows, both arenas' gradient pushes and the dense all-reduce equal the
+    single-process results on the concatenated global batch."""
+    try:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+        from recalgorithm_amd import parallel as P
+        from recalgorithm_amd.variables import EmbeddingArena, VariableStore
+        vocabs = [200_003] + [17 + 13 * i for i in range(25)]            # (200 003 % 8 != 0: uneven shards)
+        F, Bl = len(vocabs), 32
+        arenas = {}
+        for name, K in (("emb", 16), ("w1", 1)):
+            ar = EmbeddingArena(name, K, "cpu", seed=123 + K)
+            for i, v in enumerate(vocabs):
+                ar.add_table(f"t{i}", v)
+            ar.materialize()
+            arenas[name] = ar
+        full = {n: a.weight.clone() for n, a in arenas.items()}
+        rb = torch.tensor([arenas["emb"].tables[f"t{i}"][0] for i in range(F)], dtype=torch.int64)
+        # Zipf-ish ids: a hot head per field + a uniform tail, 1 % OOV
+        g = torch.Generator().manual_seed(77)
+        B = Bl * WORLD
+        head = torch.stack([torch.randint(0, max(2, v // 50), (B,), generator=g) for v in vocabs], 1)
+        tail = torch.stack([torch.randint(0, v, (B,), generator=g) for v in vocabs], 1)
+        ids_all = torch.where(torch.rand(B, F, generator=g) < 0.6, head, tail)
+        ids_all = torch.where(torch.rand(B, F, generator=g) < 0.01, torch.full_like(ids_all, -1), ids_all)
+        ids = ids_all[rank * Bl:(rank + 1) * Bl]
+        store = VariableStore("cpu", seed=7 + rank)
+        with torch.no_grad():
+            store.get_variable("w", (6, 3))
+        for n, a in arenas.items():
+            store.arenas[n] = a
+        store.pack()
+        est = types.SimpleNamespace(_built=True, store=store, grad_hook=None, loss_grad_scale=None)
+        P.attach_data_parallel(est, dist, local_gather=cpu_gather, local_scatter_add=cpu_scatter_add, capacity_factor=0.75,
+                               planner=torch_exchange_plan, dedup=torch_dedup_rows)
+        assert est.loss_grad_scale == 1.0 / WORLD
+        rows = P.global_rows(ids, rb)
+        rows_all = P.global_rows(ids_all, rb)
+        ok_all = rows_all >= 0
+        for n, ar in arenas.items():
+            K = ar.K
+            assert torch.equal(ar.weight, full[n][rank::WORLD]) and torch.equal(P.unshard_arena(ar, "weight"), full[n])
+            plan = ar.sharding.plan(rows)
+            assert isinstance(plan, P.StaticExchangePlan)
+            staged = P.StagedArena(plan, ar)
+            flag = ar.sharding.overflow.float()
+            dist.all_reduce(flag)
+            assert float(flag) == 0.0, f"{n}: bucket overflow at capacity 0.75 x requests / {WORLD}"
+            sid = plan.staged_ids(rows, rows.shape)
+            got = torch.where((sid >= 0).unsqueeze(1), staged.weight[sid.clamp(min=0)], torch.zeros(1, K))
+            expect = torch.where((rows >= 0).unsqueeze(1), full[n][rows.clamp(min=0)], torch.zeros(1, K))
+            assert torch.equal(got, expect), f"{n}: staged rows differ from the table rows"
+            g_all = torch.randn(ids_all.numel(), K, generator=torch.Generator().manual_seed(11 + K))
+            g_loc = g_all[rank * Bl * F:(rank + 1) * Bl * F]
+            staged.grad.index_add_(0, sid[sid >= 0], g_loc[sid >= 0])
+            staged.flush_grad()
+            ref = torch.zeros_like(full[n]).index_add_(0, rows_all[ok_all], g_all[ok_all])
+            # (a hot row sums ~100 gradient rows of this batch: per-rank partial sums added by the owner round differently from
+            # one index_add over the global batch — fp32 reordering, hence 1e-5)
+            got_g = P.unshard_arena(ar, "grad")
+            assert torch.allclose(got_g, ref, rtol=1e-5, atol=1e-5), \
+                f"{n}: sharded gradient != single-process gradient (max abs diff {float((got_g - ref).abs().max()):.3e})"
+            assert float(ref.abs().sum()) > 0
+        x_all = torch.randn(B, 6, generator=torch.Generator().manual_seed(3))
+        wt = store.vars["w"].data.clone().requires_grad_(True)
+        loss_rank = (x_all[rank * Bl:(rank + 1) * Bl] @ wt).pow(2).mean()
+        loss_rank.backward(torch.full_like(loss_rank, est.loss_grad_scale))
+        store.vars["w"].grad.copy_(wt.grad)
+        est.grad_hook(store)
+        wg = store.vars["w"].data.clone().requires_grad_(True)
+        (x_all @ wg).pow(2).mean().backward()
+        assert torch.allclose(store.vars["w"].grad, wg.grad, rtol=1e-6, atol=1e-7)
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        import traceback
+        errq.put(f"rank {rank}:\n{traceback.format_exc()}")
+        raise
+
+
+@pytest.mark.timeout(300)
+def test_config5_shape_world8_matches_single_process():
+    world = 8
+    ctx = mp.get_context("spawn")
+    errq = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_config5, args=(r, port, errq, world)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(250)
+    errs = []
+    while not errq.empty():
+        errs.append(errq.get())
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+            errs.append("worker timed out")
+    assert not errs, "\n".join(errs[:2])
+    assert all(p.exitcode == 0 for p in procs)

@@ -130,6 +130,8 @@ def test_bench_two_rank_code_path(capacity_factor):
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 1024 and out["value"] > 0
     assert out["config"]["launch"] == "eager"                       # host-staged collectives cannot be captured
     assert "roofline" in out
+    assert out["rccl_ranks"] == 2 and out["communication"]["world_size"] == 2
+    assert out["communication"]["per_rank_bytes_per_step"]["all_to_all_rows_and_grads"] > 0
     if capacity_factor == "0.1":
         assert re.search(r"overflow at capacity factor 0.1", r.stderr), r.stderr[-2000:]
 
