@@ -42,6 +42,14 @@ def cin_network(x0: torch.Tensor, feature_maps) -> Tuple[List[torch.Tensor], tor
     """The CIN stack of xdeepfm.py:166-174: every layer's maps are sum-pooled over D and
     concatenated -> p_plus (batch, sum h_i).  The pooling is fused into the layer kernel."""
     store = current_store()
+    # every layer within one launch's width: the whole stack is one autograd node (ops.cin_stack)
+    filts, hk = [], int(x0.shape[1])
+    for i, h in enumerate(feature_maps):
+        filts.append(store.get_variable(f"cin_layer_{i + 1}_filter", (1, hk * int(x0.shape[1]), int(h))))
+        hk = int(h)
+    fused = ops.cin_stack(store, x0, filts)
+    if fused is not None:
+        return fused[1], fused[0]
     xk, xs, pools = x0, [], []
     for i, h in enumerate(feature_maps):
         filt = _filter(store, x0, xk, h, i + 1)

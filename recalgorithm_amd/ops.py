@@ -554,6 +554,90 @@ class _CinFn(Function):
 CIN_MAX_MAPS = 128          # feature maps per launch on either side (csrc/cin.hip)
 
 
+class _CinStackFn(Function):
+    """The whole CIN stack of xdeepfm.py:166-174 as ONE autograd node (every layer <= 128 maps: one launch each way per layer):
+    layer i's sum-pooled maps are written by its kernel straight into their column block of p_plus (no torch.cat), the
+    backward reads each layer's share of d(p_plus) in place (pool_stride / pool_col of recalgo_cin_layer_bwd: no slice
+    copies), the gradient of a layer's output is the next layer's dX^k handed over as is, and dX^0 is accumulated by the
+    kernels across the layers (dx0_accumulate) instead of by autograd (an elementwise launch per layer)."""
+
+    @staticmethod
+    def forward(ctx, anchor, x0, *filts):
+        B, m, D = x0.shape
+        lib = _lib_()
+        Ns = [int(f.data.shape[-1]) for f in filts]
+        p_plus = torch.empty(B, sum(Ns), device=x0.device, dtype=torch.float32)
+        xs, xk, col = [], x0, 0
+        for f, N in zip(filts, Ns):
+            Hk = xk.shape[1]
+            out = torch.empty(B, N, D, device=x0.device, dtype=torch.float32)
+            _lib.check(lib.recalgo_cin_layer_fwd(_p(x0), _p(xk), _p(f.data), B, m, Hk, N, D, _p(out), _p(p_plus), p_plus.shape[1], col,
+                                                 _stream(x0)), "recalgo_cin_layer_fwd")
+            xs.append(out)
+            xk = out
+            col += N
+        ctx.filts, ctx.Ns = filts, Ns
+        ctx.save_for_backward(x0, *xs)
+        ctx.set_materialize_grads(False)
+        return (p_plus, *xs)
+
+    @staticmethod
+    def backward(ctx, g_pplus, *g_xs):
+        x0, *xs = ctx.saved_tensors
+        filts, Ns = ctx.filts, ctx.Ns
+        B, m, D = x0.shape
+        lib = _lib_()
+        L = len(filts)
+        if g_pplus is None and all(g is None for g in g_xs):
+            for f in filts:
+                f.grad.zero_()
+            return (None, torch.zeros_like(x0)) + (None,) * L
+        if g_pplus is not None and (g_pplus.stride(1) != 1 or g_pplus.shape[1] != sum(Ns)):
+            g_pplus = g_pplus.contiguous()
+        dx0 = torch.empty_like(x0)
+        g_next = None                                # d(loss) / d(xs[i]) arriving from layer i + 1
+        cols = [sum(Ns[:i]) for i in range(L)]
+        first = True
+        for i in range(L - 1, -1, -1):
+            xk = x0 if i == 0 else xs[i - 1]
+            Hk, N = xk.shape[1], Ns[i]
+            g_out = g_next
+            if g_xs[i] is not None:                  # a caller that also uses the layer's maps themselves (the reference does not)
+                g_out = g_xs[i].contiguous() if g_out is None else g_out + g_xs[i]
+            if g_out is None and g_pplus is None:
+                filts[i].grad.zero_()
+                g_next = None
+                continue
+            dxk = torch.empty_like(xk)
+            ws = _workspace(lib.recalgo_cin_layer_bwd_workspace_bytes(B, m, Hk, N, D), x0.device)
+            _lib.check(lib.recalgo_cin_layer_bwd(
+                _p(x0), _p(xk), _p(filts[i].data), _p(g_out), _p(g_pplus), 0 if g_pplus is None else g_pplus.stride(0), cols[i],
+                B, m, Hk, N, D, _p(dx0), 0 if first else 1, _p(dxk), 0, _p(filts[i].grad), _p(ws), _stream(x0)),
+                "recalgo_cin_layer_bwd")
+            first = False
+            g_next = dxk
+        if first:
+            dx0.zero_()
+        elif g_next is not None:
+            dx0.add_(g_next)                         # layer 1: X^k IS X^0
+        return (None, dx0) + (None,) * L
+
+
+def cin_stack(store, x0: torch.Tensor, filts):
+    """-> (p_plus [B, sum N_i], [X^1, ..., X^L]) of the CIN stack over x0 [B, m, D] with the filters `filts` (Variables of shape
+    (1, H_{i-1} m, N_i)); None when a layer is wider than one launch takes (the caller then chains ops.cin_layer)."""
+    if store.building or x0.dtype != torch.float32 or not x0.is_cuda:
+        return None
+    Hk = x0.shape[1]
+    for f in filts:
+        N = int(f.data.shape[-1])
+        if Hk > CIN_MAX_MAPS or N > CIN_MAX_MAPS:
+            return None
+        Hk = N
+    res = _CinStackFn.apply(store.anchor, x0.contiguous(), *filts)
+    return res[0], list(res[1:])
+
+
 def cin_layer(store, x0: torch.Tensor, xk: torch.Tensor, filt: Variable):
     """x0 [B,m,D], xk [B,Hk,D], filt (1, Hk*m, N) -> (xk_1 [B,N,D], sum-pooled [B,N]).  Layers wider than the kernels'
     128 x 128 maps per launch (e.g. --cin_layer_feature_maps=200,200) are tiled: output maps in column chunks
