@@ -18,6 +18,8 @@ tail -c 1200 $O/prof_${TAG}_default.log > $O/prof_${TAG}_default.tail; rm -rf $O
 bash scripts/gpu_bench_all.sh $TAG > $O/${TAG}_bench_all.log 2>&1
 bash scripts/gpu_pmc_bench.sh $TAG dcn 64 > $O/${TAG}_pmc_fullrun.log 2>&1
 bash scripts/gpu_pmc_sq.sh $TAG dcn SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE > $O/${TAG}_pmc_sq.log 2>&1
+# the CIN kernels' matrix-pipe counters (north_star: "for CIN, MFMA utilisation vs peak")
+bash scripts/gpu_pmc_sq.sh $TAG xdeepfm SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE > $O/${TAG}_xdeepfm_pmc_sq.log 2>&1
 timeout 400 python bench.py --model deepfm --big-table-rows 100000000 --no-cpu-baseline --no-host-fed --sweep-batches 0 > $O/bench_${TAG}_deepfm_100M.json 2> $O/bench_${TAG}_deepfm_100M.err
 timeout 300 python scripts/bench_tfrecord.py --examples 131072 --epochs 60 > $O/bench_${TAG}_tfrecord_e2e.json 2> $O/bench_${TAG}_tfrecord_e2e.err
 RECALGO_READER_THREADS=64 timeout 300 python scripts/bench_tfrecord.py --examples 131072 --epochs 60 > $O/bench_${TAG}_tfrecord_e2e_64threads.json 2> $O/bench_${TAG}_tfrecord_e2e_64threads.err
