@@ -446,9 +446,12 @@ int recalgo_batchnorm_train_fwd(const float* x, const float* gamma, const float*
                                 float eps, float momentum, float* moving_mean, float* moving_var,
                                 float* y, float* save_mean, float* save_rstd, void* workspace,
                                 recalgo_stream_t stream);
+/* dx_relu != 0 (the three backward entry points): x IS the output of a ReLU (tf.layers.dense(..., relu) ->
+ * tf.layers.batch_normalization, deepfm.py:206-211) — dx is zeroed where x <= 0, i.e. the dense layer's backward receives
+ * g * [y > 0] ready-made and runs without mask loads (see recalgo_dense_bwd_bn). */
 int recalgo_batchnorm_train_bwd(const float* x, const float* gamma, const float* save_mean,
                                 const float* save_rstd, const float* g, int rows, int C, float* dx,
-                                float* dgamma, float* dbeta, void* workspace, recalgo_stream_t stream);
+                                float* dgamma, float* dbeta, void* workspace, int dx_relu, recalgo_stream_t stream);
 /* The same backward, continued through the per-channel activation that produced x = act(act_z, act_alpha) (DIN's dense ->
  * dice | prelu -> batch_norm, din.py:262-266; see recalgo_activation_bwd): dx is then dL/d(act_z), dalpha [C] = dL/d(alpha).
  * dalpha == NULL: the recalgo_batchnorm_partial_rows(rows) partial rows [C] of dalpha are left at float offset
@@ -459,7 +462,7 @@ int recalgo_batchnorm_train_bwd(const float* x, const float* gamma, const float*
 int64_t recalgo_batchnorm_bwd_act_workspace_bytes(int rows, int C);
 int recalgo_batchnorm_train_bwd_act(const float* x, const float* gamma, const float* save_mean, const float* save_rstd,
                                     const float* g, const float* sums, int rows, int C, int act_kind, const float* act_z, const float* act_alpha,
-                                    float* dx, float* dgamma, float* dbeta, float* dalpha, void* workspace,
+                                    float* dx, float* dgamma, float* dbeta, float* dalpha, void* workspace, int dx_relu,
                                     recalgo_stream_t stream);
 /* Sync-BatchNorm building blocks (data parallel, N > 1, `sync_batch_norm`): the two launches of each direction as separate
  * entry points, so that the per-tile partials of all ranks — [recalgo_batchnorm_partial_rows(rows)][2][C] floats per rank:
@@ -477,7 +480,7 @@ int recalgo_batchnorm_bwd_sums(const float* x, const float* save_mean, const flo
                                float* partials, recalgo_stream_t stream);
 int recalgo_batchnorm_bwd_apply(const float* x, const float* gamma, const float* save_mean, const float* save_rstd,
                                 const float* g, const float* partials, int world, int rank, int rows, int C, float* dx,
-                                float* dgamma, float* dbeta, recalgo_stream_t stream);
+                                float* dgamma, float* dbeta, int dx_relu, recalgo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sibling models on the same kernels: their remaining interaction steps.

@@ -62,14 +62,14 @@ SIGNATURES = {
     "recalgo_relu_bwd_bias": (c_int, [P, P, c_int, c_int, P, P, P, P]),
     "recalgo_batchnorm_workspace_bytes": (c_int64, [c_int, c_int]),
     "recalgo_batchnorm_train_fwd": (c_int, [P, P, P, c_int, c_int, c_float, c_float, P, P, P, P, P, P, P]),
-    "recalgo_batchnorm_train_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, P, P, P]),
+    "recalgo_batchnorm_train_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, P, P, c_int, P]),
     "recalgo_batchnorm_bwd_act_workspace_bytes": (c_int64, [c_int, c_int]),
-    "recalgo_batchnorm_train_bwd_act": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P]),
+    "recalgo_batchnorm_train_bwd_act": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, P]),
     "recalgo_batchnorm_partial_rows": (c_int, [c_int]),
     "recalgo_batchnorm_moments": (c_int, [P, c_int, c_int, P, P]),
     "recalgo_batchnorm_apply": (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, c_float, P, P, P, P, P, P]),
     "recalgo_batchnorm_bwd_sums": (c_int, [P, P, P, P, c_int, c_int, P, P]),
-    "recalgo_batchnorm_bwd_apply": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P]),
+    "recalgo_batchnorm_bwd_apply": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, c_int, P]),
     "recalgo_sigmoid_ce_fwd_bwd": (c_int, [P, P, c_int, c_float, P, P, P, P]),
     "recalgo_adam_tf1_dense": (c_int, [P, P, P, P, c_int64, c_float, P, c_float, c_float, c_float, c_int, P]),
     "recalgo_adam_tf1_rows": (c_int, [P, P, P, P, P, c_int64, c_int, c_float, P, c_float, c_float, c_float, c_int, P]),

@@ -225,7 +225,9 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_sum_apply_kernel(
     const float4* __restrict__ mean, const float4* __restrict__ rstd, const float4* __restrict__ partials,
     unsigned nblk, unsigned nblk_local, unsigned rank, unsigned rows, unsigned C4, float4* __restrict__ dbeta,
     float4* __restrict__ dgamma, float4* __restrict__ dx, const float4* __restrict__ act_z,
-    const float4* __restrict__ act_alpha, float4* __restrict__ act_partials) {
+    const float4* __restrict__ act_alpha, float4* __restrict__ act_partials, int dx_relu) {
+    // dx_relu: x IS a ReLU output (tf.layers.dense(..., relu) -> tf.layers.batch_normalization, deepfm.py:206-211): dx is zeroed where
+    // x <= 0, so that the dense layer's backward gets its gradient already masked (see recalgo_dense_bwd_bn dx_relu_mask)
     // nblk = world * nblk_local partial rows (see bn_finalize_apply_kernel).  dx uses the sums over ALL ranks' tiles;
     // dbeta / dgamma get THIS rank's share (the data-parallel all-reduce of the dense gradients adds the ranks up)
     __shared__ float4 sh[2][16][17];
@@ -288,7 +290,8 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_sum_apply_kernel(
         for (unsigned t = 0; t < kTileRows / 16; ++t) {
             const unsigned r = r0 + rl + 16 * t;
             if (r < rows) {
-                const float4 xh = f4_mul(f4_sub(x[(size_t)r * C4 + c4], mu), rs4);
+                const float4 xv = x[(size_t)r * C4 + c4];
+                const float4 xh = f4_mul(f4_sub(xv, mu), rs4);
                 const float4 gv = g[(size_t)r * C4 + c4];
                 float4 d =
                     make_float4(k.x * (gv.x - inv_rows * (db.x + xh.x * dg.x)), k.y * (gv.y - inv_rows * (db.y + xh.y * dg.y)),
@@ -302,6 +305,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_sum_apply_kernel(
                                     recalgo_act::bwd<ACT == 1 + RECALGO_ACT_DICE>(z.w, al.w, d.w, t4.w));
                     da = f4_add(da, t4);
                 }
+                if (dx_relu) d = make_float4(xv.x > 0.f ? d.x : 0.f, xv.y > 0.f ? d.y : 0.f, xv.z > 0.f ? d.z : 0.f, xv.w > 0.f ? d.w : 0.f);
                 dx[(size_t)r * C4 + c4] = d;
             }
         }
@@ -661,10 +665,10 @@ RECALGO_EXPORT int recalgo_batchnorm_train_fwd(const float* x, const float* gamm
 
 RECALGO_EXPORT int recalgo_batchnorm_train_bwd(const float* x, const float* gamma, const float* save_mean,
                                                const float* save_rstd, const float* g, int rows, int C, float* dx,
-                                               float* dgamma, float* dbeta, void* workspace,
+                                               float* dgamma, float* dbeta, void* workspace, int dx_relu,
                                                recalgo_stream_t stream) {
     return recalgo_batchnorm_train_bwd_act(x, gamma, save_mean, save_rstd, g, nullptr, rows, C, RECALGO_ACT_NONE, nullptr, nullptr, dx,
-                                           dgamma, dbeta, nullptr, workspace, stream);
+                                           dgamma, dbeta, nullptr, workspace, dx_relu, stream);
 }
 
 RECALGO_EXPORT int64_t recalgo_batchnorm_bwd_act_workspace_bytes(int rows, int C) {
@@ -676,11 +680,12 @@ RECALGO_EXPORT int recalgo_batchnorm_train_bwd_act(const float* x, const float* 
                                                    const float* save_rstd, const float* g, const float* sums, int rows, int C,
                                                    int act_kind,
                                                    const float* act_z, const float* act_alpha, float* dx, float* dgamma,
-                                                   float* dbeta, float* dalpha, void* workspace, recalgo_stream_t stream) {
+                                                   float* dbeta, float* dalpha, void* workspace, int dx_relu,
+                                                   recalgo_stream_t stream) {
     RECALGO_REQUIRE(rows > 0 && width_ok(C) && x && gamma && save_mean && save_rstd && g && dx && dgamma && dbeta &&
                     workspace);
     RECALGO_REQUIRE(act_kind == RECALGO_ACT_NONE ||
-                    ((act_kind == RECALGO_ACT_PRELU || act_kind == RECALGO_ACT_DICE) && act_z && act_alpha));
+                    ((act_kind == RECALGO_ACT_PRELU || act_kind == RECALGO_ACT_DICE) && act_z && act_alpha && !dx_relu));
     hipStream_t st = as_stream(stream);
     const int nb = nblk_of(rows);
     const unsigned C4 = C / 4;
@@ -700,7 +705,7 @@ RECALGO_EXPORT int recalgo_batchnorm_train_bwd_act(const float* x, const float* 
                        reinterpret_cast<const float4*>(save_rstd), reinterpret_cast<const float4*>(partials), (unsigned)nb,     \
                        (unsigned)nb, 0u, (unsigned)rows, C4, reinterpret_cast<float4*>(dbeta), reinterpret_cast<float4*>(dgamma), \
                        reinterpret_cast<float4*>(dx), reinterpret_cast<const float4*>(act_z),                                   \
-                       reinterpret_cast<const float4*>(act_alpha), reinterpret_cast<float4*>(act_partials))
+                       reinterpret_cast<const float4*>(act_alpha), reinterpret_cast<float4*>(act_partials), dx_relu)
     if (act_kind == RECALGO_ACT_NONE) RECALGO_BN_APPLY(0);
     else if (act_kind == RECALGO_ACT_PRELU) RECALGO_BN_APPLY(1 + RECALGO_ACT_PRELU);
     else RECALGO_BN_APPLY(1 + RECALGO_ACT_DICE);
@@ -753,7 +758,7 @@ RECALGO_EXPORT int recalgo_batchnorm_bwd_sums(const float* x, const float* save_
 
 RECALGO_EXPORT int recalgo_batchnorm_bwd_apply(const float* x, const float* gamma, const float* save_mean, const float* save_rstd,
                                                const float* g, const float* partials, int world, int rank, int rows, int C,
-                                               float* dx, float* dgamma, float* dbeta, recalgo_stream_t stream) {
+                                               float* dx, float* dgamma, float* dbeta, int dx_relu, recalgo_stream_t stream) {
     RECALGO_REQUIRE(rows > 0 && world >= 1 && rank >= 0 && rank < world && width_ok(C));
     RECALGO_REQUIRE(x && gamma && save_mean && save_rstd && g && partials && dx && dgamma && dbeta);
     const int nb = nblk_of(rows);
@@ -764,7 +769,7 @@ RECALGO_EXPORT int recalgo_batchnorm_bwd_apply(const float* x, const float* gamm
                        reinterpret_cast<const float4*>(save_rstd), reinterpret_cast<const float4*>(partials),
                        (unsigned)(nb * world), (unsigned)nb, (unsigned)rank, (unsigned)rows, C4,
                        reinterpret_cast<float4*>(dbeta), reinterpret_cast<float4*>(dgamma), reinterpret_cast<float4*>(dx),
-                       static_cast<const float4*>(nullptr), static_cast<const float4*>(nullptr), static_cast<float4*>(nullptr));
+                       static_cast<const float4*>(nullptr), static_cast<const float4*>(nullptr), static_cast<float4*>(nullptr), dx_relu);
     RECALGO_RETURN_LAST();
 }
 

@@ -346,6 +346,7 @@ class _BatchNormTrainFn(Function):
                 momentum: float, eps: float, partials: Optional[torch.Tensor] = None):
         ctx.vars = (gamma, beta)
         ctx.hip = x.dim() == 2 and x.is_contiguous() and _hip(x, x.shape[1])
+        ctx.x_relu_src = getattr(x, "_recalgo_relu_src", None) if ctx.hip else None
         # Sync-BatchNorm (parallel.attach_data_parallel(sync_batch_norm=True)): statistics over the GLOBAL batch
         ctx.sync = getattr(getattr(anchor, "_recalgo_store", None), "sync_bn", None)
         if ctx.sync is not None and not ctx.hip:
@@ -381,8 +382,13 @@ class _BatchNormTrainFn(Function):
             if ctx.sync is not None:
                 dx = ops.batchnorm_sync_bwd(x, gamma.data, mean, rstd, g.contiguous(), gamma.grad, beta.grad, ctx.sync)
             else:
+                # x is the ReLU output of a dense layer: this kernel masks the gradient it writes (it reads x anyway) and that
+                # layer's backward runs without mask loads (ReluSource)
+                src = ctx.x_relu_src
                 dx = ops.batchnorm_train_bwd(x, gamma.data, mean, rstd, g.contiguous(), gamma.grad, beta.grad,
-                                             sums=ctx.link.take(g))
+                                             sums=ctx.link.take(g), relu_x=src is not None)
+                if src is not None:
+                    src.premasked = dx
             return None, dx, None, None, None, None, None, None, None
         xhat, rstd = ctx.saved_tensors
         B = g.shape[0]

@@ -1346,7 +1346,7 @@ def batchnorm_train_bwd_act(x, gamma, mean, rstd, g, dgamma, dbeta, kind: int, z
     else:
         ws = _workspace(nbytes, x.device)
     _lib.check(lib.recalgo_batchnorm_train_bwd_act(_p(x), _p(gamma), _p(mean), _p(rstd), _p(g), _p(sums), rows, C, int(kind), _p(z), _p(alpha),
-                                                   _p(dz), _p(dgamma), _p(dbeta), None if defer else _p(dalpha), _p(ws),
+                                                   _p(dz), _p(dgamma), _p(dbeta), None if defer else _p(dalpha), _p(ws), 0,
                                                    _stream(x)), "recalgo_batchnorm_train_bwd_act")
     if defer:
         nb = bn_partial_rows(rows)
@@ -1406,23 +1406,24 @@ def batchnorm_sync_bwd(x, gamma, mean, rstd, g, dgamma, dbeta, sync) -> torch.Te
     all_gather(parts, local)
     dx = torch.empty_like(x)
     _lib.check(lib.recalgo_batchnorm_bwd_apply(_p(x), _p(gamma), _p(mean), _p(rstd), _p(g), _p(parts), world, rank, rows, C,
-                                               _p(dx), _p(dgamma), _p(dbeta), _stream(x)), "recalgo_batchnorm_bwd_apply")
+                                               _p(dx), _p(dgamma), _p(dbeta), 0, _stream(x)), "recalgo_batchnorm_bwd_apply")
     return dx
 
 
-def batchnorm_train_bwd(x, gamma, mean, rstd, g, dgamma, dbeta, sums=None) -> torch.Tensor:
+def batchnorm_train_bwd(x, gamma, mean, rstd, g, dgamma, dbeta, sums=None, relu_x: bool = False) -> torch.Tensor:
     """sums [bn_partial_rows(rows), 2 C]: the per-tile (colsum g | colsum g * xhat) rows when g's producer has left them
-    (dense_bwd(bn=)): ONE launch (merge + apply) instead of two."""
+    (dense_bwd(bn=)): ONE launch (merge + apply) instead of two.  relu_x: x is a ReLU output — dx is zeroed where x <= 0
+    (the producing dense layer then needs no mask: nn.ReluSource)."""
     rows, C = x.shape
     lib = _lib_()
     dx = torch.empty_like(x)
     if sums is not None:
         _lib.check(lib.recalgo_batchnorm_bwd_apply(_p(x), _p(gamma), _p(mean), _p(rstd), _p(g), _p(sums), 1, 0, rows, C, _p(dx),
-                                                   _p(dgamma), _p(dbeta), _stream(x)), "recalgo_batchnorm_bwd_apply")
+                                                   _p(dgamma), _p(dbeta), int(relu_x), _stream(x)), "recalgo_batchnorm_bwd_apply")
         return dx
     ws = _workspace(lib.recalgo_batchnorm_workspace_bytes(rows, C), x.device)
     _lib.check(lib.recalgo_batchnorm_train_bwd(_p(x), _p(gamma), _p(mean), _p(rstd), _p(g), rows, C, _p(dx), _p(dgamma),
-                                               _p(dbeta), _p(ws), _stream(x)), "recalgo_batchnorm_train_bwd")
+                                               _p(dbeta), _p(ws), int(relu_x), _stream(x)), "recalgo_batchnorm_train_bwd")
     return dx
 
 

@@ -369,3 +369,28 @@ def test_relu_source_protocol(dev, second_consumer):
     for got, want, what in ((xd.grad, P[0].grad, "dx"), (k1.grad, P[1].grad, "dW1"), (c1.grad, P[2].grad, "db1"),
                             (k2.grad, P[3].grad, "dW2"), (c2.grad, P[4].grad, "db2")):
         assert_close(got, want, what=f"relu-source chain {what}", reduced=True)
+
+
+@pytest.mark.parametrize("with_sums", [False, True])
+def test_batchnorm_backward_masks_dx_with_a_relu_input(dev, with_sums):
+    """recalgo_batchnorm_{train_bwd, bwd_apply}(dx_relu = 1): the BatchNorm whose input is a ReLU output writes
+    dx * [x > 0] — bit-equal to masking the plain backward's dx afterwards; dgamma / dbeta unchanged."""
+    gen = torch.Generator().manual_seed(3 + int(with_sums))
+    M, C = 1000, 96
+    x = torch.randn(M, C, generator=gen).clamp(min=0).to(dev)
+    g = torch.randn(M, C, generator=gen).to(dev)
+    gamma = (torch.rand(C, generator=gen) + 0.5).to(dev)
+    mean, rstd = x.mean(0), 1.0 / (x.var(0, unbiased=False) + 1e-3).sqrt()
+    sums = None
+    if with_sums:                              # the per-tile partial rows a dense layer's dgrad epilogue leaves
+        xh = (x - mean) * rstd
+        nb = ops.bn_partial_rows(M)
+        sums = torch.zeros(nb, 2 * C, device=dev)
+        for t in range(nb):
+            sl = slice(64 * t, min(64 * (t + 1), M))
+            sums[t, :C], sums[t, C:] = g[sl].sum(0), (g[sl] * xh[sl]).sum(0)
+    dg0, db0, dg1, db1 = (torch.empty(C, device=dev) for _ in range(4))
+    plain = ops.batchnorm_train_bwd(x, gamma, mean, rstd, g, dg0, db0, sums=sums)
+    masked = ops.batchnorm_train_bwd(x, gamma, mean, rstd, g, dg1, db1, sums=sums, relu_x=True)
+    assert torch.equal(masked, plain * (x > 0))
+    assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
