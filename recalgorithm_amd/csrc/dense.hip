@@ -386,6 +386,7 @@ __global__ __launch_bounds__(kThreads) void dense_fwd_kernel(FwdArgs P) {
     }
     // ---- the same store + the tile's column moments (two-pass inside the tile: mean first, then deviations) ----------
     const bool cok = col < P.N;
+    const bool rows_y = FAST && P.vec_store;
     const float bv = (cok && P.bias) ? P.bias[col] : 0.f;
     const float av = (cok && P.act_kind) ? P.act_alpha[col] : 0.f;
     float vals[16];
@@ -401,8 +402,18 @@ __global__ __launch_bounds__(kThreads) void dense_fwd_kernel(FwdArgs P) {
             v = P.act_kind == 1 + RECALGO_ACT_DICE ? recalgo_act::dice(v, av) : recalgo_act::prelu(v, av);
         }
         vals[r] = ok ? v : 0.f;
-        if (ok) P.y[(size_t)row * P.ldy + col] = v;
+        if (ok && !rows_y) P.y[(size_t)row * P.ldy + col] = v;
         s += vals[r];
+    }
+    if (rows_y) {
+        // y leaves as whole row segments (the wave's scratch lies in Bs: the moment sums below go through As)
+        f32x16 yv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yv[r] = vals[r];
+        const int r0 = m0 + (wave >> 1) * 32;
+        tv2::tile_rows(Bs + wave * tv2::kTileScratch, yv, [&](int, int row, int, float4 v) {
+            if (r0 + row < P.M && c4 < P.N) *reinterpret_cast<float4*>(P.y + (size_t)(r0 + row) * P.ldy + c4) = v;
+        });
     }
     s += __shfl_xor(s, 32, 64);                               // the wave's 32 rows of this column
     float* red = As;                                          // [2 row halves][64 columns] (the operand ring is free)
@@ -527,19 +538,29 @@ __device__ __forceinline__ void dgrad_tile(const DgradArgs& P, int block, int nb
         // ---- the same store + the tile's column sums of dx and dx * xhat (fixed order: a lane's 16 rows, the wave's two row
         //      halves, the workgroup's two wave rows) ----
         const bool cok = col < P.K;
+        const bool rows_dx = FAST && P.vec_store;
+        f32x16 dxv;
         float sg = 0.f, sgx = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            float v = 0.f;
             if (cok && row < P.M) {
-                float v = acc[r];
+                v = acc[r];
                 if (P.dx_mask && !(P.dx_mask[(size_t)row * P.ld_mask + col] > 0.f)) v = 0.f;
                 if (P.c_in) v = fmaf(P.beta, P.c_in[(size_t)row * P.ldc + col], v);
-                P.dx[(size_t)row * P.lddx + col] = v;
+                if (!rows_dx) P.dx[(size_t)row * P.lddx + col] = v;
                 const float xh = (xb[r] - mu) * rs;
                 sg += v;
                 sgx = fmaf(v, xh, sgx);
             }
+            dxv[r] = v;
+        }
+        if (rows_dx) {
+            const int r0 = m0 + (wave >> 1) * 32, c4 = n0 + (wave & 1) * 32 + (lane & 7) * 4;
+            tv2::tile_rows(Bs + wave * tv2::kTileScratch, dxv, [&](int, int row, int, float4 v) {
+                if (r0 + row < P.M && c4 < P.K) *reinterpret_cast<float4*>(P.dx + (size_t)(r0 + row) * P.lddx + c4) = v;
+            });
         }
         sg += __shfl_xor(sg, 32, 64);
         sgx += __shfl_xor(sgx, 32, 64);
