@@ -24,7 +24,7 @@ namespace {
 constexpr int kFwdThreads = 256;
 constexpr int kBwdThreads = 512;               // 8 waves: <= 256 VGPRs each, no spills
 constexpr int kBwdWaves = kBwdThreads / 64;
-constexpr int kMaxPartialRows = 512;
+constexpr int kMaxPartialRows = 256;
 
 // batched 64-lane butterfly: reduces N independent values with N shuffles in flight per stage
 template <int N>
