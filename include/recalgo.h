@@ -148,6 +148,14 @@ int recalgo_deepfm_sparse_bwd(const int64_t* ids, const float* emb, const float*
  * ------------------------------------------------------------------------------------------ */
 int recalgo_cross_fwd(const float* x0, int x_stride, const float* w, const float* b, int B, int d,
                       int L, float* out, int out_stride, recalgo_stream_t stream);
+/* recalgo_embedding_gather_fwd + recalgo_cross_fwd in ONE launch (fc.input_layer over F single-valued embedding columns of one
+ * width K feeding the cross network, dcn.py:152-160): the wave that computes an example's stack gathers the example's row from
+ * the arena itself — x0 [B, F*K] is an OUTPUT here (bit-exact copy of the table rows, id < 0: zeros; the MLP branch and the
+ * backward read it), out as recalgo_cross_fwd.  K % 4 == 0, F * K <= 1024; arena rows already current (a TRAIN lookup's
+ * recalgo_scatter_prepare ran before). */
+int recalgo_gather_cross_fwd(const int64_t* ids, const float* arena, const int64_t* row_base, int B, int F, int K,
+                             const float* w, const float* b, int L, float* x0, int x_stride, float* out, int out_stride,
+                             recalgo_stream_t stream);
 /* Backward.  Recomputes the per-example scalars from x0 (nothing but x0 is saved by the forward).
  *   g    [B, d] (row stride g_stride) upstream gradient of `out`
  *   g_x0_extra  optional [B, d] (row stride x_stride) added into dx0 (the DNN branch's dx0)

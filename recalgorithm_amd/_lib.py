@@ -31,6 +31,7 @@ SIGNATURES = {
     "recalgo_deepfm_sparse_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P]),
     "recalgo_deepfm_sparse_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P]),
     "recalgo_cross_fwd": (c_int, [P, c_int, P, P, c_int, c_int, c_int, P, c_int, P]),
+    "recalgo_gather_cross_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P, c_int, P, c_int, P, c_int, P]),
     "recalgo_cross_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "recalgo_cross_bwd": (c_int, [P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, P, P, P, P, c_int, P]),
     "recalgo_cross_bwd_partial_rows": (c_int, [c_int]),

@@ -45,6 +45,7 @@ def cross_network(x0: torch.Tensor, num_cross_layer: int, grad_join=None) -> tor
     # outside the fused kernel's envelope — more than 6 layers, d > 1024, or d > 512 with >= 4 fused layers (its backward
     # would spill registers, profiles/r01_kernel_resource_usage.md): layer by layer with the single-layer kernels
     if L > 6 or d > 1024 or (d > 512 and L >= 4):
+        ops.flush_lazy_gathers()                  # (a gather left to the fused kernel runs on its own after all)
         if grad_join is not None:
             grad_join.consumer_done = True        # no fused consumer: the other branch returns its gradient normally
         xl = x0

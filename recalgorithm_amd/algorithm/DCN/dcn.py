@@ -14,7 +14,7 @@ from typing import Tuple
 import torch
 
 from ... import feature_column as fc
-from ... import flags, nn
+from ... import flags, nn, ops
 from ...estimator import (Estimator, EvalSpec, ModeKeys, RunConfig, TrainSpec, train_and_evaluate)
 from ...model_tail import finish_model_fn
 from ...variables import variable_scope
@@ -87,13 +87,20 @@ def dcn_model_fn(features, labels, mode, params):
         dense_cols = params.get("dense_feature_columns") or []
         dense_input = fc.input_layer(features, dense_cols) if dense_cols else None
     with variable_scope("category_input"):
-        category_input = fc.input_layer(features, params["category_feature_columns"])
+        if dense_input is None and int(params["num_cross_layer"]) > 0:
+            # the cross network is the first reader of the embeddings: its forward kernel does the gather (ops.gather_feeds_cross)
+            with ops.gather_feeds_cross() as lz:
+                category_input = fc.input_layer(features, params["category_feature_columns"])
+                lz.keep(category_input)
+        else:
+            category_input = fc.input_layer(features, params["category_feature_columns"])
     concat_all = category_input if dense_input is None else torch.cat([dense_input, category_input], dim=-1)
 
     # concat_all feeds both branches: their two input gradients are summed inside cross_bwd (nn.GradJoin)
     join = nn.GradJoin() if int(params["num_cross_layer"]) > 0 and len(params["hidden_units"]) > 0 else None
     with variable_scope("cross_part"):
         cross_vec = cross_network(concat_all, params["num_cross_layer"], grad_join=join)
+    ops.flush_lazy_gathers()                 # (nothing is pending once the cross network has run)
 
     with variable_scope("dnn_part"):
         dnn_vec = concat_all

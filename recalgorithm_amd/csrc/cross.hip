@@ -42,11 +42,22 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
 // ---------------------------------------------------------------------------------------------
 // fused stack, forward
 // ---------------------------------------------------------------------------------------------
+// Optional: x0 is not read but GATHERED (fc.input_layer over F single-valued embedding columns of width K, dcn.py:152-153: the
+// wave that computes an example's stack has the example's row in registers — it fetches the row's pieces from the embedding
+// arena itself and writes x0 for the other consumers of the input layer (the MLP branch, the backward) on the way: the
+// separate gather launch of a DCN step (5.4 us at its launch floor) disappears.
+struct GatherSrc {
+    const int64_t* ids;        // [B][F], id < 0: zero row;  nullptr: x0 is an input
+    const float4* arena;       // [rows][K / 4]
+    const int64_t* row_base;   // [F]
+    unsigned F, K4;
+};
+
 template <int NV, int L>
 __global__ __launch_bounds__(kFwdThreads) void cross_stack_fwd_kernel(
-    const float* __restrict__ x0, unsigned x_stride, const float4* __restrict__ w,
+    float* __restrict__ x0, unsigned x_stride, const float4* __restrict__ w,
     const float4* __restrict__ b, unsigned B, unsigned d4, float* __restrict__ out,
-    unsigned out_stride) {
+    unsigned out_stride, GatherSrc gs) {
     const unsigned lane = threadIdx.x & 63;
     const unsigned wave = (blockIdx.x * kFwdThreads + threadIdx.x) >> 6;
     const unsigned nwaves = (gridDim.x * kFwdThreads) >> 6;
@@ -70,12 +81,27 @@ __global__ __launch_bounds__(kFwdThreads) void cross_stack_fwd_kernel(
     }
 
     for (unsigned ex = wave; ex < B; ex += nwaves) {
-        const float4* xr = reinterpret_cast<const float4*>(x0 + (size_t)ex * x_stride);
+        float4* xr = reinterpret_cast<float4*>(x0 + (size_t)ex * x_stride);
         float4 xv[NV];
+        if (gs.ids != nullptr) {
+            long long id[NV];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            unsigned idx = lane + v * 64;
-            xv[v] = idx < d4 ? xr[idx] : f4_zero();
+            for (int v = 0; v < NV; ++v) {
+                const unsigned idx = lane + v * 64;
+                id[v] = idx < d4 ? gs.ids[(size_t)ex * gs.F + idx / gs.K4] : -1;
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const unsigned idx = lane + v * 64, f = idx / gs.K4, q = idx - f * gs.K4;
+                xv[v] = id[v] >= 0 ? gs.arena[(size_t)(gs.row_base[f] + id[v]) * gs.K4 + q] : f4_zero();
+                if (idx < d4) xr[idx] = xv[v];
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                unsigned idx = lane + v * 64;
+                xv[v] = idx < d4 ? xr[idx] : f4_zero();
+            }
         }
         float r[2 * L];
 #pragma unroll
@@ -403,13 +429,13 @@ inline int bwd_grid(int B) {
 template <int NV, int L>
 int launch_stack(bool fwd, const float* x0, int x_stride, const float* w, const float* b, const float* g,
                  int g_stride, const float* gx, int B, int d, float* out, int out_stride, float* dw,
-                 float* db, float* partials, hipStream_t st, int defer) {
+                 float* db, float* partials, hipStream_t st, int defer, const GatherSrc* gs) {
     const float4* w4 = reinterpret_cast<const float4*>(w);
     const float4* b4 = reinterpret_cast<const float4*>(b);
     if (fwd) {
         hipLaunchKernelGGL((cross_stack_fwd_kernel<NV, L>), dim3(cdiv(B, kFwdThreads / 64)), dim3(kFwdThreads),
-                           0, st, x0, (unsigned)x_stride, w4, b4, (unsigned)B, (unsigned)(d / 4), out,
-                           (unsigned)out_stride);
+                           0, st, const_cast<float*>(x0), (unsigned)x_stride, w4, b4, (unsigned)B, (unsigned)(d / 4), out,
+                           (unsigned)out_stride, gs ? *gs : GatherSrc{nullptr, nullptr, nullptr, 1u, 1u});
         return (int)hipGetLastError();
     }
     const int grid = bwd_grid(B);
@@ -428,12 +454,12 @@ int launch_stack(bool fwd, const float* x0, int x_stride, const float* w, const 
 template <int NV>
 int dispatch_stack_L(int L, bool fwd, const float* x0, int x_stride, const float* w, const float* b,
                      const float* g, int g_stride, const float* gx, int B, int d, float* out,
-                     int out_stride, float* dw, float* db, float* partials, hipStream_t st, int defer) {
+                     int out_stride, float* dw, float* db, float* partials, hipStream_t st, int defer, const GatherSrc* gs) {
     switch (L) {
 #define CASE_L(LL)                                                                                      \
     case LL:                                                                                            \
         return launch_stack<NV, LL>(fwd, x0, x_stride, w, b, g, g_stride, gx, B, d, out, out_stride, dw, \
-                                    db, partials, st, defer);
+                                    db, partials, st, defer, gs);
         CASE_L(1) CASE_L(2) CASE_L(3) CASE_L(4) CASE_L(5) CASE_L(6)
 #undef CASE_L
         default: return (int)hipErrorInvalidValue;
@@ -442,11 +468,11 @@ int dispatch_stack_L(int L, bool fwd, const float* x0, int x_stride, const float
 
 int dispatch_stack(int L, bool fwd, const float* x0, int x_stride, const float* w, const float* b,
                    const float* g, int g_stride, const float* gx, int B, int d, float* out, int out_stride,
-                   float* dw, float* db, float* partials, hipStream_t st, int defer = 0) {
+                   float* dw, float* db, float* partials, hipStream_t st, int defer = 0, const GatherSrc* gs = nullptr) {
     const int nv = cdiv(d / 4, 64);
-    if (nv <= 1) return dispatch_stack_L<1>(L, fwd, x0, x_stride, w, b, g, g_stride, gx, B, d, out, out_stride, dw, db, partials, st, defer);
-    if (nv <= 2) return dispatch_stack_L<2>(L, fwd, x0, x_stride, w, b, g, g_stride, gx, B, d, out, out_stride, dw, db, partials, st, defer);
-    if (nv <= 4) return dispatch_stack_L<4>(L, fwd, x0, x_stride, w, b, g, g_stride, gx, B, d, out, out_stride, dw, db, partials, st, defer);
+    if (nv <= 1) return dispatch_stack_L<1>(L, fwd, x0, x_stride, w, b, g, g_stride, gx, B, d, out, out_stride, dw, db, partials, st, defer, gs);
+    if (nv <= 2) return dispatch_stack_L<2>(L, fwd, x0, x_stride, w, b, g, g_stride, gx, B, d, out, out_stride, dw, db, partials, st, defer, gs);
+    if (nv <= 4) return dispatch_stack_L<4>(L, fwd, x0, x_stride, w, b, g, g_stride, gx, B, d, out, out_stride, dw, db, partials, st, defer, gs);
     return (int)hipErrorInvalidValue;
 }
 
@@ -463,6 +489,20 @@ RECALGO_EXPORT int recalgo_cross_fwd(const float* x0, int x_stride, const float*
     if (B == 0) return 0;
     return dispatch_stack(L, true, x0, x_stride, w, b, nullptr, 0, nullptr, B, d, out, out_stride, nullptr,
                           nullptr, nullptr, as_stream(stream));
+}
+
+RECALGO_EXPORT int recalgo_gather_cross_fwd(const int64_t* ids, const float* arena, const int64_t* row_base, int B, int F, int K,
+                                            const float* w, const float* b, int L, float* x0, int x_stride, float* out,
+                                            int out_stride, recalgo_stream_t stream) {
+    const int d = F * K;
+    RECALGO_REQUIRE(B >= 0 && F >= 1 && K >= 4 && K % 4 == 0 && d <= 1024 && L >= 1 && L <= 6);
+    RECALGO_REQUIRE(ids != nullptr && arena != nullptr && row_base != nullptr && x0 != nullptr && out != nullptr);
+    RECALGO_REQUIRE(x_stride % 4 == 0 && out_stride % 4 == 0 && x_stride >= d && out_stride >= d);
+    RECALGO_REQUIRE((reinterpret_cast<uintptr_t>(arena) & 15) == 0 && (reinterpret_cast<uintptr_t>(x0) & 15) == 0);
+    if (B == 0) return 0;
+    const GatherSrc gs{ids, reinterpret_cast<const float4*>(arena), row_base, (unsigned)F, (unsigned)(K / 4)};
+    return dispatch_stack(L, true, x0, x_stride, w, b, nullptr, 0, nullptr, B, d, out, out_stride, nullptr, nullptr, nullptr,
+                          as_stream(stream), 0, &gs);
 }
 
 RECALGO_EXPORT int64_t recalgo_cross_bwd_workspace_bytes(int B, int d, int L) {

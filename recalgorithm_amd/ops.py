@@ -137,6 +137,58 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 # =============================================================================================
 # K1: embedding gather
 # =============================================================================================
+# A gather whose output the cross network consumes next (DCN, dcn.py:152-160) is not launched: CrossNet's forward kernel
+# fetches the rows itself and writes x0 on the way (recalgo_gather_cross_fwd).  `gather_feeds_cross` is the model's promise;
+# anything that is still pending when another consumer could read the tensor is launched by flush_lazy_gathers().
+LAZY_GATHER = True                           # module hook (tests / A-B): False = every gather is its own launch
+_lazy_gather_on = False
+_lazy_hit = False
+_lazy_gathers: list = []
+
+
+class gather_feeds_cross:
+    """with ops.gather_feeds_cross() as lz: x = fc.input_layer(...); lz.keep(x) — the single-launch gathers issued inside stay
+    pending only if exactly one was issued and `x` IS its output (one width, no bags, no concat); else they run now."""
+
+    def __enter__(self):
+        global _lazy_gather_on
+        self._prev, _lazy_gather_on = _lazy_gather_on, bool(LAZY_GATHER)
+        self._kept = False
+        return self
+
+    def keep(self, x) -> None:
+        self._kept = (len(_lazy_gathers) == 1 and isinstance(x, torch.Tensor) and _lazy_gathers[0][0] is x)
+
+    def __exit__(self, *exc):
+        global _lazy_gather_on
+        _lazy_gather_on = self._prev
+        if not self._kept:
+            flush_lazy_gathers()
+        return False
+
+
+def flush_lazy_gathers() -> None:
+    while _lazy_gathers:
+        out, ids, arena, row_base = _lazy_gathers.pop()
+        out._recalgo_lazy_gather = None
+        B, F = ids.shape
+        _lib.check(_lib_().recalgo_embedding_gather_fwd(_p(ids), _p(arena.weight), _p(row_base), B, F, arena.K, _p(out), F * arena.K, 0,
+                                                        _stream(ids)), "recalgo_embedding_gather_fwd")
+
+
+def _take_lazy_gather(x0: torch.Tensor):
+    """The pending gather whose output is x0 (-> (ids, arena, row_base)), or None; any OTHER pending gather is launched."""
+    lz = getattr(x0, "_recalgo_lazy_gather", None)
+    if lz is not None:
+        for i, ent in enumerate(_lazy_gathers):
+            if ent[0] is x0:
+                _lazy_gathers.pop(i)
+                break
+        x0._recalgo_lazy_gather = None
+    flush_lazy_gathers()
+    return lz
+
+
 class _GatherFn(Function):
     @staticmethod
     def forward(ctx, anchor, ids, arena: EmbeddingArena, row_base, training=False):
@@ -147,10 +199,16 @@ class _GatherFn(Function):
         ctx.src = sparse.begin_lookup(arena, anchor_store(anchor), ids, None, row_base, 0, B, F, training)
         # deferred Adam: a registered (TRAIN) lookup's rows were just caught up; any other lookup reads lagging rows as of now
         dv, stp = sparse.view_for(ctx.src, arena, anchor_store(anchor))
+        ctx.arena, ctx.ids, ctx.row_base = arena, ids, row_base
+        ctx.lazy = (_lazy_gather_on and dv is None and K % 4 == 0 and F * K <= 1024 and ids.is_contiguous()
+                    and getattr(arena, "sharding", None) is None)
+        if ctx.lazy:
+            global _lazy_hit
+            _lazy_hit = True                 # (embedding_gather() hangs the pending launch on the tensor autograd hands out)
+            return out
         _lib.check(_lib_().recalgo_embedding_gather_fwd_deferred(
             _p(ids), _p(arena.weight), _p(row_base), B, F, K, _p(out), F * K, 0, dv, stp, 0, _stream(ids)),
             "recalgo_embedding_gather_fwd")
-        ctx.arena, ctx.ids, ctx.row_base = arena, ids, row_base
         return out
 
     @staticmethod
@@ -177,7 +235,14 @@ def embedding_gather(store: VariableStore, ids: torch.Tensor, arena: EmbeddingAr
         from . import parallel
         _, staged, ident = _staged(arena, parallel.global_rows(ids, row_base), store)
         return _GatherFn.apply(store.anchor, ident.reshape(ids.shape), staged, torch.zeros_like(row_base), False)
-    return _GatherFn.apply(store.anchor, ids, arena, row_base, torch.is_grad_enabled())
+    global _lazy_hit
+    _lazy_hit = False
+    out = _GatherFn.apply(store.anchor, ids, arena, row_base, torch.is_grad_enabled())
+    if _lazy_hit:
+        _lazy_hit = False
+        out._recalgo_lazy_gather = (ids, arena, row_base)
+        _lazy_gathers.append((out, ids, arena, row_base))
+    return out
 
 
 class _BagMeanFn(Function):
@@ -375,12 +440,23 @@ class _CrossFn(Function):
         ctx.grad_join = grad_join
         B, d = x0.shape
         L = w.data.shape[0]
+        lz = _take_lazy_gather(x0)           # x0 not gathered yet (ops.gather_feeds_cross): this kernel fetches the rows itself
         x0p, wp, bp = _pad4(x0), _pad4(w.data.reshape(L, d)), _pad4(b.data.reshape(L, d))
         dp = x0p.shape[1]
         out = torch.empty(B, dp, device=x0.device, dtype=torch.float32)
-        _lib.check(_lib_().recalgo_cross_fwd(
-            _p(x0p), dp, _p(wp), _p(bp), B, dp, L, _p(out), dp, _stream(x0)),
-            "recalgo_cross_fwd")
+        if lz is not None and dp == d and x0.is_contiguous():
+            ids, arena, row_base = lz
+            _lib.check(_lib_().recalgo_gather_cross_fwd(_p(ids), _p(arena.weight), _p(row_base), B, ids.shape[1], arena.K, _p(wp), _p(bp), L,
+                                                        _p(x0), d, _p(out), dp, _stream(x0)), "recalgo_gather_cross_fwd")
+        else:
+            if lz is not None:               # (cannot be fused after all: the plain gather first)
+                ids, arena, row_base = lz
+                _lib.check(_lib_().recalgo_embedding_gather_fwd(_p(ids), _p(arena.weight), _p(row_base), B, ids.shape[1], arena.K, _p(x0),
+                                                                ids.shape[1] * arena.K, 0, _stream(ids)), "recalgo_embedding_gather_fwd")
+                x0p = _pad4(x0)
+            _lib.check(_lib_().recalgo_cross_fwd(
+                _p(x0p), dp, _p(wp), _p(bp), B, dp, L, _p(out), dp, _stream(x0)),
+                "recalgo_cross_fwd")
         ctx.vars = (w, b)
         ctx.d = d
         ctx.save_for_backward(x0p)

@@ -198,6 +198,68 @@ def test_cross_stack(dev, B, d, L):
     assert_close(bv.grad, gb, what="cross db", reduced=True, ref32=gb32)
 
 
+@pytest.mark.parametrize("B,vocabs,K,L", [(1, [5], 16, 1), (37, [11, 2, 301], 8, 2), (4096, [20000, 106444, 2, 18789] + [997] * 22, 16, 3),
+                                          (513, [1000] * 27, 16, 6), (64, [50] * 64, 16, 3), (4096, [31] * 5, 4, 3)])
+def test_gather_left_to_the_cross_kernel(dev, B, vocabs, K, L):
+    """recalgo_gather_cross_fwd (ops.gather_feeds_cross): x0 and the cross output are BIT-identical to gather-then-cross,
+    and so is every gradient of the step (the backward is the same two kernels either way)."""
+    gen = torch.Generator().manual_seed(B + L)
+    d = len(vocabs) * K
+    ids = make_ids(gen, B, vocabs).to(dev)
+    w = (torch.randn(L, d, generator=gen) / math.sqrt(d)).to(dev)
+    b = (torch.randn(L, d, generator=gen) * 0.1).to(dev)
+    g = torch.randn(B, d, generator=gen).to(dev)
+
+    def run(fused):
+        ar, rb = make_arena(vocabs, K, dev)
+        store = VariableStore(dev)
+        wv, bv = Variable("w", w.clone()), Variable("b", b.clone())
+        if fused:
+            with ops.gather_feeds_cross() as lz:
+                x0 = ops.embedding_gather(store, ids, ar, rb)
+                lz.keep(x0)
+            assert getattr(x0, "_recalgo_lazy_gather", None) is not None     # not launched yet
+        else:
+            x0 = ops.embedding_gather(store, ids, ar, rb)
+        out = ops.cross_stack(store, x0, wv, bv)
+        assert getattr(x0, "_recalgo_lazy_gather", None) is None and not ops._lazy_gathers
+        (out * g).sum().backward()
+        ops.flush_dense_splits()
+        return x0.detach().clone(), out.detach().clone(), ar.grad.clone(), wv.grad.clone(), bv.grad.clone()
+    for what, a, r in zip(("x0", "cross out", "arena grad", "dw", "db"), run(True), run(False)):
+        assert_bit_exact(a, r, what)
+
+
+def test_gather_left_pending_is_launched_when_nobody_takes_it(dev):
+    """The safety net of ops.gather_feeds_cross: not kept (two gathers / a different tensor) or never consumed -> plain gather."""
+    gen = torch.Generator().manual_seed(3)
+    vocabs = [100] * 4
+    ids = make_ids(gen, 33, vocabs).to(dev)
+    ar, rb = make_arena(vocabs, 16, dev)
+    store = VariableStore(dev)
+    ref = ops.embedding_gather(store, ids, ar, rb).detach().clone()
+    with ops.gather_feeds_cross() as lz:                       # not kept -> launched at exit
+        a = ops.embedding_gather(store, ids, ar, rb)
+    assert_bit_exact(a, ref, "not kept")
+    with ops.gather_feeds_cross() as lz:                       # two gathers -> cannot both be x0
+        a = ops.embedding_gather(store, ids, ar, rb)
+        c = ops.embedding_gather(store, ids, ar, rb)
+        lz.keep(a)
+    assert_bit_exact(a, ref, "two gathers a"); assert_bit_exact(c, ref, "two gathers c")
+    with ops.gather_feeds_cross() as lz:                       # kept, then the consumer never comes
+        a = ops.embedding_gather(store, ids, ar, rb)
+        lz.keep(a)
+    ops.flush_lazy_gathers()
+    assert_bit_exact(a, ref, "flushed")
+    with torch.no_grad():                                      # inference lookups take the same route
+        with ops.gather_feeds_cross() as lz:
+            a = ops.embedding_gather(store, ids, ar, rb)
+            lz.keep(a)
+        wv, bv = Variable("w", torch.zeros(1, 64, device=dev)), Variable("b", torch.zeros(1, 64, device=dev))
+        out = ops.cross_stack(store, a, wv, bv)
+    assert_bit_exact(a, ref, "no_grad x0"); assert_bit_exact(out, ref, "no_grad out (w = b = 0 -> x1 = x0)")
+
+
 def test_cross_layer_separate_xl_and_identities(dev):
     gen = torch.Generator().manual_seed(5)
     B, d = 77, 96
