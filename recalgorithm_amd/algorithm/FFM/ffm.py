@@ -104,7 +104,7 @@ def ffm_model_fn(features, labels, mode, params):
     first = None
     if single:                                                   # every single-valued column in ONE gather of (B, n) weights
         rb1 = store.row_base_tensor(w1, [kprefix + cols[i].key for i in single])
-        id1 = torch.stack([ids[i] for i in single], 1).contiguous()
+        id1 = torch.stack([ids[i] for i in single], 1).contiguous()                                  # (B, n): both lookups' ids
         first = ops.embedding_gather(store, id1, w1, rb1).sum(dim=1, keepdim=True)                   # (B, 1)
     for c, x in zip(cols, ids):
         if not isinstance(x, Ragged):
@@ -119,11 +119,15 @@ def ffm_model_fn(features, labels, mode, params):
     first = first + bias.data                                    # (the bias gradient: sum of d logit, below)
     # ---- field-aware lookups: X [B, F, F-1, K] ------------------------------------------------------------------
     if single:
-        s_off = torch.arange(F - 1, device=dev, dtype=torch.int64)
-        idv = torch.stack([torch.where(ids[i].unsqueeze(1) >= 0, ids[i].unsqueeze(1) + s_off * vocab[i],
-                                       torch.full((1, 1), -1, device=dev, dtype=torch.int64)) for i in single], 1)
-        rbv = store.row_base_tensor(arena, [tnames[i] for i in single for _ in range(F - 1)])
-        got = ops.embedding_gather(store, idv.reshape(B, -1).contiguous(), arena, rbv)               # (B, n_single*(F-1)*K)
+        # view s of field i's (F-1, V, K) variable starts at arena row base_i + s * V_i: the F - 1 lookups of a field are the
+        # SAME id against F - 1 row bases (OOV stays -1), so the id matrix is one expanding copy, not 5 launches per field
+        key = (arena.name, "ffm_views", tuple(single))
+        rbv = store._rb_cache.get(key)
+        if rbv is None:
+            rbv = store._rb_cache[key] = torch.tensor([arena.tables[tnames[i]][0] + s * vocab[i] for i in single for s in range(F - 1)],
+                                                      dtype=torch.int64, device=dev)
+        idv = id1.unsqueeze(2).expand(B, len(single), F - 1).reshape(B, -1)
+        got = ops.embedding_gather(store, idv, arena, rbv)                                            # (B, n_single*(F-1)*K)
     if len(single) == F:
         X = got                                                  # all fields single-valued: the gather output IS X
     else:

@@ -296,7 +296,12 @@ __global__ __launch_bounds__(kThreads) void bilinear_fwd_kernel(BiSets a, unsign
 
 // backward wrt the inputs; stores the row gradients dvW[v][b][i][:] (all / each) for the weight
 // gradient kernel.
-template <int K, int NV>
+// COOP = false: one WAVE owns one example (the forward's shape).  With the gradient tile staged (48 KB of LDS per example
+// at F = 26, K = 16, two sets) that is 3 waves per CU, each walking load -> stage -> two sums -> store alone: 138 us for
+// 157 MB.  COOP = true: the whole WORKGROUP (256 threads) owns one example — the same 48 KB now carry 4 waves, three
+// workgroups per CU, and every element is still produced by the same chain of operations in the same order
+// (bit-identical results).  Interaction-type weights keep the wave form (its reductions are wave shuffles).
+template <int K, int NV, bool COOP>
 __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsigned B, unsigned F, int type,
                                                                 const float* __restrict__ g, unsigned g_stride,
                                                                 unsigned g_col, float* __restrict__ dvw_ws,
@@ -306,8 +311,14 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
     unsigned short* ptab = reinterpret_cast<unsigned short*>(smem);
     float* Wl = smem + ptab_floats(P);
     float* wave0 = Wl + (type == kAll ? NV * K * kWS(K) : 0);
-    const unsigned lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const unsigned nwaves = blockDim.x >> 6;         // waves per workgroup (LDS budget decides, <= kWaves)
+    const unsigned lane = COOP ? threadIdx.x : (threadIdx.x & 63);   // index among the NT threads that share an example
+    const unsigned wib = COOP ? 0u : threadIdx.x >> 6;
+    const unsigned NT = COOP ? blockDim.x : 64u;
+    const unsigned nwaves = COOP ? 1u : blockDim.x >> 6;             // examples in flight per workgroup (LDS budget decides)
+    auto sync = [&]() {
+        if (COOP) __syncthreads();
+        else __builtin_amdgcn_wave_barrier();
+    };
     const unsigned per_wave = NV * 2 * (FK + nK) + (stage_g ? P * NV * K : 0);
     float* X = wave0 + wib * per_wave;               // [NV][FK]
     float* vW = X + NV * FK;                         // [NV][nK]
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
     __syncthreads();
 
     constexpr unsigned C4 = NV * K / 4;
-    constexpr unsigned PPP = 64 / C4;
+    const unsigned PPP = NT / C4;                    // pair rows per pass of the NT threads
     constexpr unsigned LPV = K / 4;                  // lanes per (pair, set)
     const unsigned pl = lane / C4, c4 = lane % C4;
     const unsigned v_l = (c4 * 4) / K, k0 = (c4 * 4) % K;
@@ -333,15 +344,15 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const float4* xr = reinterpret_cast<const float4*>(a.x[v] + (size_t)b * FK);
-            for (unsigned i = lane; i < FK / 4; i += 64) reinterpret_cast<float4*>(X + v * FK)[i] = xr[i];
+            for (unsigned i = lane; i < FK / 4; i += NT) reinterpret_cast<float4*>(X + v * FK)[i] = xr[i];
         }
-        __builtin_amdgcn_wave_barrier();
+        sync();
         const float* gb = g + (size_t)b * P * g_stride + g_col;
         if (type != kInteraction) {
             // recompute vW
 #pragma unroll
             for (int v = 0; v < NV; ++v)
-                for (unsigned idx = lane; idx < nK; idx += 64) {
+                for (unsigned idx = lane; idx < nK; idx += NT) {
                     const unsigned i = idx / K, kk = idx % K;
                     const float* xi = X + v * FK + i * K;
                     float acc = 0.f;
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
                     }
                     vW[v * nK + idx] = acc;
                 }
-            __builtin_amdgcn_wave_barrier();
+            sync();
             // dvW[i][k'] = sum_{j>i} g[(i,j)][k'] x_j[k'] ;  dX[j][k'] = sum_{i<j} g[(i,j)][k'] vW[i][k'].
             // Every g element is needed twice (once per sum) along two different walks of the pair
             // triangle.  Fast path: the example's whole gradient tile [P][NV*K] (38.4 KB at F=26, K=16)
@@ -368,7 +379,7 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
                 float4* gL4 = reinterpret_cast<float4*>(gL);
                 // kU whole rows per lane are requested before the first is parked in LDS: a
                 // load -> wait -> ds_write loop would pay the full HBM latency once per row
-                constexpr unsigned kU = 16;
+                constexpr unsigned kU = COOP ? 10 : 16;     // (COOP: 32 pair rows per pass -> 320 rows in flight cover P <= 320 at once)
                 for (unsigned p0 = 0; p0 < P; p0 += PPP * kU) {
                     float4 t[kU];
 #pragma unroll
@@ -383,8 +394,8 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
                         if (pair < P) gL4[pair * C4 + c4] = t[u];
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
-                for (unsigned idx = lane; idx < F * NVK; idx += 64) {
+                sync();
+                for (unsigned idx = lane; idx < F * NVK; idx += NT) {
                     const unsigned r = idx / NVK, c = idx % NVK, v = c / K, kk = c % K;
                     const float* Xv = X + v * FK + kk;
                     const float* vWv = vW + v * nK + kk;
@@ -411,7 +422,7 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
                     const float* gv = gb + v * K;
                     const float* Xv = X + v * FK;
                     const float* vWv = vW + v * nK;
-                    for (unsigned idx = lane; idx < FK; idx += 64) {
+                    for (unsigned idx = lane; idx < FK; idx += NT) {
                         const unsigned r = idx / K, kk = idx % K;
                         float s1 = 0.f, s2 = 0.f;
                         if (r < n) {
@@ -426,11 +437,11 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
                     }
                 }
             }
-            __builtin_amdgcn_wave_barrier();
+            sync();
             // dX[i][k] += sum_k' dvW[i][k'] W[k][k']
 #pragma unroll
             for (int v = 0; v < NV; ++v)
-                for (unsigned idx = lane; idx < nK; idx += 64) {
+                for (unsigned idx = lane; idx < nK; idx += NT) {
                     const unsigned i = idx / K, k = idx % K;
                     const float* dq = dvW + v * nK + i * K;
                     float acc = 0.f;
@@ -445,10 +456,10 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
                     }
                     dX[v * FK + idx] += acc;
                 }
-            __builtin_amdgcn_wave_barrier();
+            sync();
         } else {
-            for (unsigned i = lane; i < NV * FK; i += 64) dX[i] = 0.f;
-            __builtin_amdgcn_wave_barrier();
+            for (unsigned i = lane; i < NV * FK; i += NT) dX[i] = 0.f;
+            sync();
             for (unsigned p0 = 0; p0 < P; p0 += PPP) {
                 const unsigned pair = p0 + pl;
                 const bool ok = pair < P;
@@ -478,14 +489,14 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
                     if (ok && (c4 % LPV) == 0) lds_add(dX + v_l * FK + i * K + k, s);
                 }
             }
-            __builtin_amdgcn_wave_barrier();
+            sync();
         }
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             float4* dr = reinterpret_cast<float4*>(a.dx[v] + (size_t)b * FK);
-            for (unsigned i = lane; i < FK / 4; i += 64) dr[i] = reinterpret_cast<const float4*>(dX + v * FK)[i];
+            for (unsigned i = lane; i < FK / 4; i += NT) dr[i] = reinterpret_cast<const float4*>(dX + v * FK)[i];
         }
-        __builtin_amdgcn_wave_barrier();
+        sync();
     }
 }
 
@@ -621,20 +632,31 @@ int launch_bi_bwd(const BiSets& a, int B, int F, int type, const float* g, int g
     const size_t base = (size_t)NV * 2 * ((size_t)F * K + (size_t)n * K) * sizeof(float);
     const size_t tile = (size_t)P * NV * K * sizeof(float);
     const size_t budget = 160 * 1024;
-    int stage = 0, wpb = 0;
+    int stage = 0, wpb = 0, wpb_budget_all = 1;
     if (type != kInteraction && shared + base + tile <= budget) {
         stage = 1;
         wpb = (int)((budget - shared) / (base + tile));
+        wpb_budget_all = (int)(budget / (shared + base + tile));
     } else if (shared + base <= budget) {
         wpb = (int)((budget - shared) / base);
     }
     if (wpb < 1) return (int)hipErrorInvalidValue;
     if (wpb > kWaves) wpb = kWaves;
     const size_t smem = shared + (size_t)wpb * (base + (stage ? tile : 0));
-    ENSURE_SMEM((bilinear_bwd_kernel<K, NV>), smem);
+    if (stage) {
+        // a workgroup per example (COOP): as many workgroups per CU as the LDS holds, persistent over the batch
+        const size_t smem1 = shared + base + tile;
+        ENSURE_SMEM((bilinear_bwd_kernel<K, NV, true>), smem1);
+        int grid = 256 * wpb_budget_all;
+        if (grid > B) grid = B;
+        hipLaunchKernelGGL((bilinear_bwd_kernel<K, NV, true>), dim3(grid), dim3(kThreads), smem1, st, a, (unsigned)B,
+                           (unsigned)F, type, g, (unsigned)g_stride, (unsigned)g_col, dvw, 1);
+        return (int)hipGetLastError();
+    }
+    ENSURE_SMEM((bilinear_bwd_kernel<K, NV, false>), smem);
     int grid = cdiv(B, wpb);
     if (grid > kMaxBlocks) grid = kMaxBlocks;
-    hipLaunchKernelGGL((bilinear_bwd_kernel<K, NV>), dim3(grid), dim3(64 * wpb), smem, st, a, (unsigned)B,
+    hipLaunchKernelGGL((bilinear_bwd_kernel<K, NV, false>), dim3(grid), dim3(64 * wpb), smem, st, a, (unsigned)B,
                        (unsigned)F, type, g, (unsigned)g_stride, (unsigned)g_col, dvw, stage);
     return (int)hipGetLastError();
 }

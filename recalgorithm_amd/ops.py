@@ -1003,7 +1003,9 @@ class _FieldPairLogitFn(Function):
         _lib.check(lib.recalgo_pnn_features_fwd(_p(emb_flat), B, F, K, 0, _p(phi), T, _stream(emb_flat)),
                    "recalgo_pnn_features_fwd")
         idx = _pair_index(F, dev)
-        w = torch.zeros(T, 1, device=dev, dtype=torch.float32)
+        w = _pair_vectors.get((r.data.data_ptr(), T))      # [T, 1], zero on the Gram diagonal: allocated and cleared once
+        if w is None:
+            w = _pair_vectors[(r.data.data_ptr(), T)] = torch.zeros(T, 1, device=dev, dtype=torch.float32)
         w.index_copy_(0, idx, r.data.reshape(-1, 1))
         ctx.r, ctx.dims = r, (F, K)
         ctx.save_for_backward(emb_flat, phi, w, idx)
@@ -1017,7 +1019,7 @@ class _FieldPairLogitFn(Function):
         dphi = torch.empty_like(phi)
         dw = torch.empty_like(w)
         dense1_bwd([phi], w, g.contiguous(), [dphi], dw, None)
-        ctx.r.grad.copy_(dw.reshape(-1).index_select(0, idx).reshape(ctx.r.grad.shape))
+        torch.index_select(dw.reshape(-1), 0, idx, out=ctx.r.grad.view(-1))
         d_emb = torch.empty_like(emb_flat)
         _lib.check(_lib_().recalgo_pnn_features_bwd(_p(emb_flat), _p(dphi), phi.shape[1], B, F, K, 0, _p(d_emb), 0, _stream(emb_flat)),
                    "recalgo_pnn_features_bwd")
@@ -1025,6 +1027,7 @@ class _FieldPairLogitFn(Function):
 
 
 _pair_index_cache = {}
+_pair_vectors = {}
 
 
 def _pair_index(F: int, device) -> torch.Tensor:
