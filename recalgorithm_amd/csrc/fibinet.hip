@@ -216,7 +216,8 @@ __device__ __forceinline__ void build_pair_table(unsigned short* ptab, unsigned 
 
 // LDS layout helpers (floats); the pair table (uint16[P]) comes first, padded to 16 bytes
 __host__ __device__ inline unsigned ptab_floats(unsigned P) { return ((P * 2 + 15) / 16) * 4; }
-constexpr unsigned kWS(unsigned K) { return K + 1; }          // padded row stride of a staged W
+constexpr unsigned kWS(unsigned K) { return K + 4; }          // row stride of a staged W: rows 16-byte aligned (ds_read_b128), and
+                                                              // 16 lanes walking 16 rows of one column still hit 16 banks (20 k mod 64)
 
 template <int K, int NV>
 __global__ __launch_bounds__(kThreads) void bilinear_fwd_kernel(BiSets a, unsigned B, unsigned F, int type,
@@ -301,8 +302,9 @@ __global__ __launch_bounds__(kThreads) void bilinear_fwd_kernel(BiSets a, unsign
 // 157 MB.  COOP = true: the whole WORKGROUP (256 threads) owns one example — the same 48 KB now carry 4 waves, three
 // workgroups per CU, and every element is still produced by the same chain of operations in the same order
 // (bit-identical results).  Interaction-type weights keep the wave form (its reductions are wave shuffles).
+constexpr int kCoopThreads = 256;
 template <int K, int NV, bool COOP>
-__global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsigned B, unsigned F, int type,
+__global__ __launch_bounds__(COOP ? kCoopThreads : kThreads, COOP ? 3 : 1) void bilinear_bwd_kernel(BiSets a, unsigned B, unsigned F, int type,
                                                                 const float* __restrict__ g, unsigned g_stride,
                                                                 unsigned g_col, float* __restrict__ dvw_ws,
                                                                 int stage_g) {
@@ -340,16 +342,65 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
     const unsigned pl = lane / C4, c4 = lane % C4;
     const unsigned v_l = (c4 * 4) / K, k0 = (c4 * 4) % K;
 
-    for (unsigned b = blockIdx.x * nwaves + wib; b < B; b += gridDim.x * nwaves) {
+    // COOP, the example's gradient tile and input rows a few requests per thread (P <= 320 pair rows at K = 16 x 2 sets):
+    // the NEXT example's requests are issued as soon as the tile of this one is parked in LDS — their HBM round trip runs
+    // under the two sums instead of in front of them
+    constexpr unsigned kUpre = 10;
+    constexpr bool pipelined = COOP;                 // (the launcher picks COOP only for such shapes, all / each types, tile staged)
+    float4 gpre[kUpre], xpre[NV];
+    auto request = [&](unsigned bb) {
+        const float* gbb = g + (size_t)bb * P * g_stride + g_col;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const float4* xr = reinterpret_cast<const float4*>(a.x[v] + (size_t)b * FK);
-            for (unsigned i = lane; i < FK / 4; i += NT) reinterpret_cast<float4*>(X + v * FK)[i] = xr[i];
+        for (unsigned u = 0; u < kUpre; ++u) {
+            const unsigned pair = u * PPP + pl;
+            gpre[u] = pair < P ? *reinterpret_cast<const float4*>(gbb + (size_t)pair * g_stride + c4 * 4) : f4_zero();
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            xpre[v] = lane < FK / 4 ? reinterpret_cast<const float4*>(a.x[v] + (size_t)bb * FK)[lane] : f4_zero();
+    };
+    if (pipelined && blockIdx.x < B) request(blockIdx.x);
+
+    for (unsigned b = blockIdx.x * nwaves + wib; b < B; b += gridDim.x * nwaves) {
+        if (pipelined) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                if (lane < FK / 4) reinterpret_cast<float4*>(X + v * FK)[lane] = xpre[v];
+        } else {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const float4* xr = reinterpret_cast<const float4*>(a.x[v] + (size_t)b * FK);
+                for (unsigned i = lane; i < FK / 4; i += NT) reinterpret_cast<float4*>(X + v * FK)[i] = xr[i];
+            }
         }
         sync();
         const float* gb = g + (size_t)b * P * g_stride + g_col;
-        if (type != kInteraction) {
+        if (COOP || type != kInteraction) {
             // recompute vW
+            if constexpr (COOP) {
+                // four outputs per thread: x_i once (K / 4 ds_read_b128), a float4 of W per k; each output is the same k-ascending chain
+                constexpr unsigned K4 = K / 4;
+                for (unsigned idx = lane; idx < NV * n * K4; idx += NT) {
+                    const unsigned v = idx / (n * K4), rem = idx % (n * K4), i = rem / K4, q = rem % K4;
+                    float xi[K];
+#pragma unroll
+                    for (unsigned u = 0; u < K4; ++u) {
+                        const float4 t = reinterpret_cast<const float4*>(X + v * FK + i * K)[u];
+                        xi[4 * u] = t.x; xi[4 * u + 1] = t.y; xi[4 * u + 2] = t.z; xi[4 * u + 3] = t.w;
+                    }
+                    const float4* W4 = type == kAll ? reinterpret_cast<const float4*>(Wl + v * K * kWS(K)) + q
+                                                    : reinterpret_cast<const float4*>(a.w[v] + (size_t)i * K * K) + q;
+                    const unsigned ws4 = type == kAll ? kWS(K) / 4 : K4;
+                    float4 acc = f4_zero();
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const float4 w = W4[k * ws4];
+                        acc.x = fmaf(xi[k], w.x, acc.x); acc.y = fmaf(xi[k], w.y, acc.y);
+                        acc.z = fmaf(xi[k], w.z, acc.z); acc.w = fmaf(xi[k], w.w, acc.w);
+                    }
+                    *reinterpret_cast<float4*>(vW + v * nK + i * K + 4 * q) = acc;
+                }
+            } else
 #pragma unroll
             for (int v = 0; v < NV; ++v)
                 for (unsigned idx = lane; idx < nK; idx += NT) {
@@ -375,11 +426,18 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
             // are then lane-owned loops over conflict-free ds_read_b32 (lane = column c of one row;
             // LDS float atomics were measured 2x slower than even the direct-from-global walk below).
             constexpr unsigned NVK = NV * K;
-            if (gL) {
+            if (COOP || gL) {
                 float4* gL4 = reinterpret_cast<float4*>(gL);
                 // kU whole rows per lane are requested before the first is parked in LDS: a
                 // load -> wait -> ds_write loop would pay the full HBM latency once per row
-                constexpr unsigned kU = COOP ? 10 : 16;     // (COOP: 32 pair rows per pass -> 320 rows in flight cover P <= 320 at once)
+                constexpr unsigned kU = 16;
+                if constexpr (pipelined) {
+#pragma unroll
+                    for (unsigned u = 0; u < kUpre; ++u) {
+                        const unsigned pair = u * PPP + pl;
+                        if (pair < P) gL4[pair * C4 + c4] = gpre[u];
+                    }
+                } else
                 for (unsigned p0 = 0; p0 < P; p0 += PPP * kU) {
                     float4 t[kU];
 #pragma unroll
@@ -395,6 +453,41 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
                     }
                 }
                 sync();
+                if (pipelined) {
+                    const unsigned nb = b + gridDim.x * nwaves;
+                    if (nb < B) request(nb);
+                }
+                if constexpr (COOP) {
+                    // a thread owns FOUR columns of one row: one ds_read_b128 of the gradient tile and one of X / vW feed four
+                    // chains (each still j- resp. i-ascending: the same sums as the scalar walk below, bit for bit)
+                    const float4* gL4c = reinterpret_cast<const float4*>(gL);
+                    for (unsigned idx = lane; idx < F * C4; idx += NT) {
+                        const unsigned r = idx / C4, q = idx % C4, v = (q * 4) / K, kk = (q * 4) % K;
+                        const float4* Xv = reinterpret_cast<const float4*>(X + v * FK + kk);
+                        const float4* vWv = reinterpret_cast<const float4*>(vW + v * nK + kk);
+                        float4 s1 = f4_zero(), s2 = f4_zero();
+                        if (r < n) {
+                            const float4* gp = gL4c + tri_index(r, r + 1, n) * C4 + q;
+#pragma unroll 8
+                            for (unsigned j = r + 1; j < n; ++j, gp += C4) {
+                                const float4 gv = gp[0], xv = Xv[j * (K / 4)];
+                                s1.x = fmaf(gv.x, xv.x, s1.x); s1.y = fmaf(gv.y, xv.y, s1.y);
+                                s1.z = fmaf(gv.z, xv.z, s1.z); s1.w = fmaf(gv.w, xv.w, s1.w);
+                            }
+                            unsigned t = r - 1;                                              // tri_index(0, r, n)
+#pragma unroll 8
+                            for (unsigned i = 0; i < r; ++i) {
+                                const float4 gv = gL4c[t * C4 + q], wv = vWv[i * (K / 4)];
+                                s2.x = fmaf(gv.x, wv.x, s2.x); s2.y = fmaf(gv.y, wv.y, s2.y);
+                                s2.z = fmaf(gv.z, wv.z, s2.z); s2.w = fmaf(gv.w, wv.w, s2.w);
+                                t += n - i - 2;
+                            }
+                            *reinterpret_cast<float4*>(dvW + v * nK + r * K + kk) = s1;
+                            *reinterpret_cast<float4*>(dvw_ws + ((size_t)v * B + b) * nK + r * K + kk) = s1;
+                        }
+                        *reinterpret_cast<float4*>(dX + v * FK + r * K + kk) = s2;
+                    }
+                } else
                 for (unsigned idx = lane; idx < F * NVK; idx += NT) {
                     const unsigned r = idx / NVK, c = idx % NVK, v = c / K, kk = c % K;
                     const float* Xv = X + v * FK + kk;
@@ -439,6 +532,37 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
             }
             sync();
             // dX[i][k] += sum_k' dvW[i][k'] W[k][k']
+            if constexpr (COOP) {
+                constexpr unsigned K4 = K / 4;
+                for (unsigned idx = lane; idx < NV * n * K4; idx += NT) {
+                    const unsigned v = idx / (n * K4), rem = idx % (n * K4), i = rem / K4, q = rem % K4;
+                    float dq[K];
+#pragma unroll
+                    for (unsigned u = 0; u < K4; ++u) {
+                        const float4 t = reinterpret_cast<const float4*>(dvW + v * nK + i * K)[u];
+                        dq[4 * u] = t.x; dq[4 * u + 1] = t.y; dq[4 * u + 2] = t.z; dq[4 * u + 3] = t.w;
+                    }
+                    const float* Wb = type == kAll ? Wl + v * K * kWS(K) : a.w[v] + (size_t)i * K * K;
+                    const unsigned ws = type == kAll ? kWS(K) : (unsigned)K;
+                    float o[4];
+#pragma unroll
+                    for (unsigned c = 0; c < 4; ++c) {
+                        const float4* Wr = reinterpret_cast<const float4*>(Wb + (4 * q + c) * ws);
+                        float acc = 0.f;
+#pragma unroll
+                        for (unsigned u = 0; u < K4; ++u) {
+                            const float4 w = Wr[u];
+                            acc = fmaf(dq[4 * u], w.x, acc); acc = fmaf(dq[4 * u + 1], w.y, acc);
+                            acc = fmaf(dq[4 * u + 2], w.z, acc); acc = fmaf(dq[4 * u + 3], w.w, acc);
+                        }
+                        o[c] = acc;
+                    }
+                    float4* d = reinterpret_cast<float4*>(dX + v * FK + i * K + 4 * q);
+                    float4 t = *d;
+                    t.x += o[0]; t.y += o[1]; t.z += o[2]; t.w += o[3];
+                    *d = t;
+                }
+            } else
 #pragma unroll
             for (int v = 0; v < NV; ++v)
                 for (unsigned idx = lane; idx < nK; idx += NT) {
@@ -506,14 +630,21 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(BiSets a, unsign
 //   interaction: items (b, pair = m)          q = g[b][m] * x_j   (M = P),  src = i(pair)
 // grid (M, S): split s handles examples [s*per, (s+1)*per); writes partials[s][m][K*K].
 constexpr int kCH = 64;
+struct WgradSets {
+    const float* x[2];      // [B, F, K] per set
+    const float* dvw[2];    // [B, n, K] per set (all / each)
+};
 template <int K>
 __global__ __launch_bounds__(kThreads) void bilinear_wgrad_kernel(
-    const float* __restrict__ x, const float* __restrict__ dvw, const float* __restrict__ g, unsigned g_stride,
-    unsigned g_col, unsigned B, unsigned F, int type, unsigned per, unsigned M, float* __restrict__ partials) {
+    WgradSets sets, const float* __restrict__ g, unsigned g_stride, unsigned g_col0, unsigned B, unsigned F, int type,
+    unsigned per, unsigned M, float* __restrict__ partials) {
     __shared__ float Xs[kCH][K + 1];
     __shared__ float Qs[kCH][K + 1];
     const unsigned n = F - 1, FK = F * K, nK = n * K;
-    const unsigned m = blockIdx.x, s = blockIdx.y;
+    const unsigned m = blockIdx.x, s = blockIdx.y, set = blockIdx.z, nsets = gridDim.z;   // partial row s: [set][m][K*K]
+    const float* __restrict__ x = sets.x[set];
+    const float* __restrict__ dvw = sets.dvw[set];
+    const unsigned g_col = g_col0 + set * K;
     const unsigned b_begin = s * per, b_end = min(B, b_begin + per);
     unsigned pi = 0, pj = 0;
     if (type == kInteraction) {                    // invert the triangular index of pair m
@@ -563,7 +694,7 @@ __global__ __launch_bounds__(kThreads) void bilinear_wgrad_kernel(
 #pragma unroll
     for (unsigned o = 0; o < OPT; ++o) {
         const unsigned idx = threadIdx.x + o * kThreads;
-        if (idx < K * K) partials[((size_t)s * M + m) * K * K + idx] = acc[o];
+        if (idx < K * K) partials[(((size_t)s * nsets + set) * M + m) * K * K + idx] = acc[o];
     }
 }
 
@@ -574,8 +705,10 @@ inline int mats_of(int type, int F) {
     return type == kAll ? 1 : (type == kEach ? n : n * (n - 1) / 2);
 }
 inline int wgrad_splits(int B, int M) {
+    // M x S x sets workgroups.  The 'all' type has ONE matrix: 256 splits left a workgroup 16 examples = 7 dependent
+    // load -> LDS -> accumulate rounds (17.8 us per set); 1024 splits are two rounds
     int S = cdiv(1024, M);
-    if (S > 256) S = 256;
+    if (S > 1024) S = 1024;
     if (S > B) S = B;
     return S < 1 ? 1 : S;
 }
@@ -585,7 +718,7 @@ inline int grid_for(int B) {
 }
 inline size_t bi_smem(int F, int K, int nv, int type, bool bwd) {
     const unsigned n = F - 1, P = n * (n - 1) / 2;
-    size_t fl = (size_t)ptab_floats(P) + (type == kAll ? (size_t)nv * K * (K + 1) : 0);
+    size_t fl = (size_t)ptab_floats(P) + (type == kAll ? (size_t)nv * K * kWS(K) : 0);
     fl += (size_t)kWaves * nv * (bwd ? 2 : 1) * ((size_t)F * K + (size_t)n * K);
     return fl * sizeof(float);
 }
@@ -600,7 +733,7 @@ inline BiWs bi_ws(int B, int F, int K, int nv, int type) {
     size_t off = type == kInteraction ? 0 : al((size_t)nv * B * n * K * sizeof(float));
     w.partials = off;
     const int M = mats_of(type, F);
-    off += al((size_t)wgrad_splits(B, M) * M * K * K * sizeof(float));
+    off += al((size_t)wgrad_splits(B, M) * nv * M * K * K * sizeof(float));
     w.total = off;
     return w;
 }
@@ -628,7 +761,7 @@ int launch_bi_bwd(const BiSets& a, int B, int F, int type, const float* g, int g
                   hipStream_t st) {
     // LDS budget decides the waves per workgroup and whether the per-example gradient tile is staged
     const unsigned n = F - 1, P = n * (n - 1) / 2;
-    const size_t shared = ((size_t)ptab_floats(P) + (type == kAll ? (size_t)NV * K * (K + 1) : 0)) * sizeof(float);
+    const size_t shared = ((size_t)ptab_floats(P) + (type == kAll ? (size_t)NV * K * kWS(K) : 0)) * sizeof(float);
     const size_t base = (size_t)NV * 2 * ((size_t)F * K + (size_t)n * K) * sizeof(float);
     const size_t tile = (size_t)P * NV * K * sizeof(float);
     const size_t budget = 160 * 1024;
@@ -643,13 +776,14 @@ int launch_bi_bwd(const BiSets& a, int B, int F, int type, const float* g, int g
     if (wpb < 1) return (int)hipErrorInvalidValue;
     if (wpb > kWaves) wpb = kWaves;
     const size_t smem = shared + (size_t)wpb * (base + (stage ? tile : 0));
-    if (stage) {
+    const unsigned C4 = NV * K / 4;
+    if (stage && K <= 32 && P <= (kCoopThreads / C4) * 10 && (unsigned)F * K / 4 <= (unsigned)kCoopThreads) {
         // a workgroup per example (COOP): as many workgroups per CU as the LDS holds, persistent over the batch
         const size_t smem1 = shared + base + tile;
         ENSURE_SMEM((bilinear_bwd_kernel<K, NV, true>), smem1);
         int grid = 256 * wpb_budget_all;
         if (grid > B) grid = B;
-        hipLaunchKernelGGL((bilinear_bwd_kernel<K, NV, true>), dim3(grid), dim3(kThreads), smem1, st, a, (unsigned)B,
+        hipLaunchKernelGGL((bilinear_bwd_kernel<K, NV, true>), dim3(grid), dim3(kCoopThreads), smem1, st, a, (unsigned)B,
                            (unsigned)F, type, g, (unsigned)g_stride, (unsigned)g_col, dvw, 1);
         return (int)hipGetLastError();
     }
@@ -661,10 +795,10 @@ int launch_bi_bwd(const BiSets& a, int B, int F, int type, const float* g, int g
     return (int)hipGetLastError();
 }
 template <int K>
-int launch_bi_wgrad(const float* x, const float* dvw, const float* g, int g_stride, int g_col, int B, int F,
-                    int type, int S, int M, float* partials, hipStream_t st) {
+int launch_bi_wgrad(const WgradSets& sets, int nv, const float* g, int g_stride, int g_col, int B, int F, int type, int S,
+                    int M, float* partials, hipStream_t st) {
     const unsigned per = (unsigned)cdiv(B, S);
-    hipLaunchKernelGGL((bilinear_wgrad_kernel<K>), dim3(M, S), dim3(kThreads), 0, st, x, dvw, g, (unsigned)g_stride,
+    hipLaunchKernelGGL((bilinear_wgrad_kernel<K>), dim3(M, S, nv), dim3(kThreads), 0, st, sets, g, (unsigned)g_stride,
                        (unsigned)g_col, (unsigned)B, (unsigned)F, type, per, (unsigned)M, partials);
     return (int)hipGetLastError();
 }
@@ -708,7 +842,8 @@ RECALGO_EXPORT int recalgo_senet_bwd(const float* emb, const float* w1, const fl
     const size_t smem = ((size_t)kWaves * ((2 * (size_t)F * K + 3 * F + 2 * reduction_dim + 3) & ~(size_t)3) +
                          (size_t)kWaves * 2 * WR + 2 * (size_t)WR) * sizeof(float);
     ENSURE_SMEM(senet_bwd_kernel, smem);
-    const int grid = grid_for(B) > 256 ? 256 : grid_for(B);        // persistent: one partial row per workgroup
+    const int grid = grid_for(B);        // one partial row per workgroup; up to 1024 workgroups = 16 waves per CU in flight (256 left
+                                         // one wave per SIMD walking its four examples' latency chains alone: 44 us)
     float* partials = static_cast<float*>(workspace);
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(senet_bwd_kernel, dim3(grid), dim3(kThreads), smem, st, emb, w1, w2, g_v, (unsigned)B,
@@ -762,13 +897,10 @@ RECALGO_EXPORT int recalgo_bilinear_bwd(const float* x0, const float* w0, const 
     const int S = wgrad_splits(B, M);
     const size_t nK = (size_t)(F - 1) * K;
     const unsigned wn = (unsigned)M * K * K;
-    for (int v = 0; v < nv; ++v) {
-        const float* xv = v == 0 ? x0 : x1;
-        float* dwv = v == 0 ? dw0 : dw1;
-        DISPATCH_K(K, rc = (launch_bi_wgrad<KK>(xv, dvw + (size_t)v * B * nK, g, g_stride, g_col + v * K, B, F, type,
-                                                S, M, partials, st)));
-        if (rc) return rc;
-        launch_colsum16(partials, (unsigned)S, wn, dwv, wn, static_cast<float*>(nullptr), st);
-    }
+    // both sets in ONE grid (z = set) and one column-sum launch over the partial rows [S][set][M][K*K]
+    const WgradSets sets{{x0, x1}, {dvw, dvw ? dvw + (size_t)B * nK : nullptr}};
+    DISPATCH_K(K, rc = (launch_bi_wgrad<KK>(sets, nv, g, g_stride, g_col, B, F, type, S, M, partials, st)));
+    if (rc) return rc;
+    launch_colsum16(partials, (unsigned)S, (unsigned)nv * wn, dw0, wn, dw1, st);
     RECALGO_RETURN_LAST();
 }

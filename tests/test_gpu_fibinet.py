@@ -64,7 +64,7 @@ def _weights(gen, F, K, btype):
 
 @pytest.mark.parametrize("btype", ["all", "each", "interaction"])
 @pytest.mark.parametrize("B,F,K,nv", [(130, 26, 16, 2), (37, 8, 8, 2), (21, 8, 8, 1), (9, 5, 4, 1), (11, 12, 32, 2),
-                                      (5, 4, 64, 2)])
+                                      (5, 4, 64, 2), (7, 28, 16, 2), (6, 40, 8, 1)])   # (351 / 741 pairs: the wave-per-example form)
 def test_bilinear_fwd_bwd(dev, btype, B, F, K, nv):
     lib = _lib.load()
     T = {"all": 0, "each": 1, "interaction": 2}[btype]
