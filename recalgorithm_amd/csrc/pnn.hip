@@ -119,6 +119,85 @@ __global__ __launch_bounds__(kThreads) void ipnn_features_bwd_kernel(const float
     }
 }
 
+// The same for K % 4 == 0 (every configuration of the scripts).  The kernel above spends its time on the triangle index
+// (ten integer instructions per fma) and on three dependent rounds of scalar loads: 28 us for 19 MB.  Here the gradient
+// row is spread ONCE per example into the symmetric [F][F] matrix dG (diagonal doubled — the value the walk above forms
+// per step), all of an example's loads are requested together, and a lane owns four columns of one field: per step one
+// broadcast ds_read_b32 of dG[f][c] and one ds_read_b128 of e_c feed four chains — each the same c-ascending chain of fmas
+// as above (bit-identical results).
+__global__ __launch_bounds__(kThreads) void ipnn_features_bwd4_kernel(const float* __restrict__ emb,
+                                                                      const float* __restrict__ dphi, unsigned B,
+                                                                      unsigned F, unsigned K, unsigned ld,
+                                                                      float* __restrict__ d_emb, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const unsigned T = F * (F + 1) / 2, FK = F * K, K4 = K / 4, FK4 = FK / 4;
+    unsigned short* tab = reinterpret_cast<unsigned short*>(smem);
+    const unsigned lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const unsigned per_wave = FK + ((F * F + 3) & ~3u);
+    float* X = smem + tab_floats(T) + wib * per_wave;        // [F][K]
+    float* dG = X + FK;                                      // [F][F]
+    build_tri_table(tab, F);
+    __syncthreads();
+    constexpr unsigned kXU = 4, kPU = 8;                     // float4 of e / floats of dphi requested per lane and round
+    for (unsigned b = blockIdx.x * kWaves + wib; b < B; b += gridDim.x * kWaves) {
+        const float4* er = reinterpret_cast<const float4*>(emb + (size_t)b * FK);
+        const float* pr = dphi + (size_t)b * ld;
+        for (unsigned i0 = 0, t0 = 0; i0 < FK4 || t0 < T; i0 += 64 * kXU, t0 += 64 * kPU) {
+            float4 xv[kXU];
+            float pv[kPU];
+#pragma unroll
+            for (unsigned u = 0; u < kXU; ++u) {
+                const unsigned i = i0 + u * 64 + lane;
+                xv[u] = i < FK4 ? er[i] : f4_zero();
+            }
+#pragma unroll
+            for (unsigned u = 0; u < kPU; ++u) {
+                const unsigned t = t0 + u * 64 + lane;
+                pv[u] = t < T ? pr[t] : 0.f;
+            }
+#pragma unroll
+            for (unsigned u = 0; u < kXU; ++u) {
+                const unsigned i = i0 + u * 64 + lane;
+                if (i < FK4) reinterpret_cast<float4*>(X)[i] = xv[u];
+            }
+#pragma unroll
+            for (unsigned u = 0; u < kPU; ++u) {
+                const unsigned t = t0 + u * 64 + lane;
+                if (t < T) {
+                    const unsigned rc = tab[t], r = rc & 255u, c = rc >> 8;
+                    if (r == c) {
+                        dG[r * F + r] = 2.f * pv[u];
+                    } else {
+                        dG[r * F + c] = pv[u];
+                        dG[c * F + r] = pv[u];
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        float4* dr = reinterpret_cast<float4*>(d_emb + (size_t)b * FK);
+        for (unsigned i = lane; i < FK4; i += 64) {
+            const unsigned f = i / K4, q = i % K4;
+            const float* gr = dG + f * F;
+            const float4* xc = reinterpret_cast<const float4*>(X) + q;
+            float4 acc = f4_zero();
+#pragma unroll 8
+            for (unsigned c = 0; c < F; ++c) {
+                const float w = gr[c];
+                const float4 x = xc[c * K4];
+                acc.x = fmaf(w, x.x, acc.x); acc.y = fmaf(w, x.y, acc.y);
+                acc.z = fmaf(w, x.z, acc.z); acc.w = fmaf(w, x.w, acc.w);
+            }
+            if (accumulate) {
+                const float4 o = dr[i];
+                acc.x = o.x + acc.x; acc.y = o.y + acc.y; acc.z = o.z + acc.z; acc.w = o.w + acc.w;
+            }
+            dr[i] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // OPNN features: s = sum_f e_f ; phi[b, t(a,c)] = s_a s_c
 __global__ __launch_bounds__(kThreads) void opnn_features_fwd_kernel(const float* __restrict__ emb, unsigned B,
                                                                      unsigned F, unsigned K,
@@ -283,6 +362,14 @@ RECALGO_EXPORT int recalgo_pnn_features_bwd(const float* emb, const float* dphi,
     hipStream_t st = as_stream(stream);
     if (method == kIPNN) {
         const unsigned T = (unsigned)F * (F + 1) / 2;
+        const size_t smem4 = ((size_t)tab_floats(T) + (size_t)kWaves * ((size_t)F * K + (((size_t)F * F + 3) & ~(size_t)3))) * sizeof(float);
+        if (K % 4 == 0 && smem4 <= 160 * 1024 && (reinterpret_cast<uintptr_t>(emb) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(d_emb) & 15) == 0) {
+            ENSURE_SMEM(ipnn_features_bwd4_kernel, smem4);
+            hipLaunchKernelGGL(ipnn_features_bwd4_kernel, dim3(grid_for(B)), dim3(kThreads), smem4, st, emb, dphi,
+                               (unsigned)B, (unsigned)F, (unsigned)K, (unsigned)ld_dphi, d_emb, accumulate);
+            RECALGO_RETURN_LAST();
+        }
         const size_t smem = (size_t)kWaves * ((size_t)F * K + T) * sizeof(float);
         ENSURE_SMEM(ipnn_features_bwd_kernel, smem);
         hipLaunchKernelGGL(ipnn_features_bwd_kernel, dim3(grid_for(B)), dim3(kThreads), smem, st, emb, dphi,

@@ -261,7 +261,7 @@ class LazyLogit:
         store = current_store()
         out = None
         for kernel, bias, parts in self.heads:
-            t = _Dense1Fn.apply(store.anchor, kernel, bias, *parts)
+            t = kernel.apply_head(parts) if hasattr(kernel, "apply_head") else _Dense1Fn.apply(store.anchor, kernel, bias, *parts)
             out = t if out is None else out + t
         for t in self.tensors:
             out = t if out is None else out + t

@@ -368,6 +368,7 @@ class _DeepFMSparseFn(Function):
             "recalgo_deepfm_sparse_fwd")
         ctx.args = (ids, arena, w1, bias, row_base)
         ctx.save_for_backward(emb, fsum)
+        ctx.set_materialize_grads(False)      # (FwFM never uses fm2: no zero "gradient" is filled for it, one launch less)
         return emb, fm1, fm2
 
     @staticmethod
@@ -375,7 +376,10 @@ class _DeepFMSparseFn(Function):
         ids, arena, w1, bias, row_base = ctx.args
         emb, fsum = ctx.saved_tensors
         B, F = ids.shape
-        g_emb, g_fm1, g_fm2 = g_emb.contiguous(), g_fm1.contiguous(), g_fm2.contiguous()
+        no_fm2 = g_fm2 is None
+        g_emb = emb.new_zeros(B, F * arena.K) if g_emb is None else g_emb.contiguous()
+        g_fm1 = emb.new_zeros(B, 1) if g_fm1 is None else g_fm1.contiguous()
+        g_fm2 = (emb.new_zeros(B, 1) if ctx.src is None else None) if no_fm2 else g_fm2.contiguous()
         if ctx.src is not None or ctx.src1 is not None:
             # owner-computes path (sparse.py).  The second-order term's gradient g_emb + g_fm2 * (S - e) (Appendix D "FM2") is
             # the EPILOGUE of the embedding lookup's source: `place` / `apply` form it on load — no [B, F, K] tensor, no
@@ -384,7 +388,7 @@ class _DeepFMSparseFn(Function):
             K = arena.K
             rows = None
             if ctx.src is not None:
-                ctx.src.set_grad(g_emb, fm=(g_fm2.reshape(B), fsum, emb))
+                ctx.src.set_grad(g_emb, fm=None if no_fm2 else (g_fm2.reshape(B), fsum, emb))
             elif getattr(arena, "trainable", True):
                 rows = torch.where(ids >= 0, ids + row_base.unsqueeze(0), torch.full_like(ids, -1))
                 e3, s3 = emb.reshape(B, F, K), fsum.reshape(B, 1, K)
@@ -987,43 +991,83 @@ def pnn_product_layer(store, emb_flat: torch.Tensor, linear_w: Variable, product
                                PNN_METHODS["IPNN" if method == "IPNN" else "OPNN"])
 
 
-class _FieldPairLogitFn(Function):
-    """logit[b] = sum_{i<j} r[index(i,j)] * <e_i[b], e_j[b]>  (FwFM second order, fwfm.py:146-158): the Gram
-    upper triangle of the fields is `recalgo_pnn_features_*` (IPNN features, diagonal included), the
-    weighted sum over it the one-unit head (`recalgo_dense1_*`) with the pair strengths scattered into a
-    [T] weight vector whose diagonal entries are 0."""
+class _IpnnFeaturesFn(Function):
+    """phi[b, t(i,j)] = <e_i[b], e_j[b]>, i <= j: the Gram upper triangle of the fields, diagonal included
+    (`recalgo_pnn_features_*`, method IPNN)."""
 
     @staticmethod
-    def forward(ctx, anchor, emb_flat, r: Variable, F, K):
+    def forward(ctx, emb_flat, F, K):
         B = emb_flat.shape[0]
         lib = _lib_()
         T = lib.recalgo_pnn_feature_count(F, K, 0)
-        dev = emb_flat.device
-        phi = torch.empty(B, T, device=dev, dtype=torch.float32)
+        phi = torch.empty(B, T, device=emb_flat.device, dtype=torch.float32)
         _lib.check(lib.recalgo_pnn_features_fwd(_p(emb_flat), B, F, K, 0, _p(phi), T, _stream(emb_flat)),
                    "recalgo_pnn_features_fwd")
-        idx = _pair_index(F, dev)
-        w = _pair_vectors.get((r.data.data_ptr(), T))      # [T, 1], zero on the Gram diagonal: allocated and cleared once
-        if w is None:
-            w = _pair_vectors[(r.data.data_ptr(), T)] = torch.zeros(T, 1, device=dev, dtype=torch.float32)
-        w.index_copy_(0, idx, r.data.reshape(-1, 1))
-        ctx.r, ctx.dims = r, (F, K)
-        ctx.save_for_backward(emb_flat, phi, w, idx)
+        ctx.dims = (F, K)
+        ctx.save_for_backward(emb_flat)
+        return phi
+
+    @staticmethod
+    def backward(ctx, dphi):
+        (emb_flat,) = ctx.saved_tensors
+        F, K = ctx.dims
+        dphi = dphi.contiguous()
+        d_emb = torch.empty_like(emb_flat)
+        _lib.check(_lib_().recalgo_pnn_features_bwd(_p(emb_flat), _p(dphi), dphi.shape[1], emb_flat.shape[0], F, K, 0, _p(d_emb), 0,
+                                                    _stream(emb_flat)), "recalgo_pnn_features_bwd")
+        return d_emb, None, None
+
+
+class _PairKernel:
+    """The one-unit head over phi whose [T, 1] kernel is the pair strengths r scattered to the off-diagonal columns of the
+    Gram triangle (0 on the diagonal).  Quacks like a Variable for the fused loss tail (`data`; its gradient = the column
+    sums of the tail's partial rows, delivered straight into r.grad: row i of the strict triangle is one contiguous run
+    of both index spaces, so the F - 1 runs are F - 1 jobs of the step's deferred-sum launch — no select launch)."""
+
+    def __init__(self, r: Variable, w: torch.Tensor, F: int, anchor):
+        self.r, self.data, self.F, self.anchor = r, w, int(F), anchor
+        self.grad = None
+
+    def colsum_jobs(self, partials, col, rows, stride):
+        F, out, jobs, at = self.F, self.r.grad.view(-1), [], 0
+        for i in range(F - 1):
+            n = F - 1 - i
+            jobs.append((partials, col + i * F - i * (i - 1) // 2 + 1, rows, stride, n, out[at:at + n]))
+            at += n
+        return jobs
+
+    def apply_head(self, parts):
+        return _PairHeadFn.apply(self.anchor, parts[0], self.r, self.F)
+
+
+class _PairHeadFn(Function):
+    """logit[b] = sum_{i<j} r[index(i,j)] * phi[b, t(i,j)]  (FwFM second order, fwfm.py:146-158) outside a TRAIN step's
+    fused tail: the one-unit head kernels (`recalgo_dense1_*`) over phi."""
+
+    @staticmethod
+    def forward(ctx, anchor, phi, r: Variable, F):
+        w = _pair_vector(r, F, phi.shape[1], phi.device)
+        ctx.r, ctx.F = r, F
+        ctx.save_for_backward(phi, w)
         return dense1_fwd([phi], w, None)
 
     @staticmethod
     def backward(ctx, g):
-        emb_flat, phi, w, idx = ctx.saved_tensors
-        F, K = ctx.dims
-        B = emb_flat.shape[0]
-        dphi = torch.empty_like(phi)
+        phi, w = ctx.saved_tensors
+        dphi = torch.empty_like(phi) if ctx.needs_input_grad[1] else None
         dw = torch.empty_like(w)
         dense1_bwd([phi], w, g.contiguous(), [dphi], dw, None)
-        torch.index_select(dw.reshape(-1), 0, idx, out=ctx.r.grad.view(-1))
-        d_emb = torch.empty_like(emb_flat)
-        _lib.check(_lib_().recalgo_pnn_features_bwd(_p(emb_flat), _p(dphi), phi.shape[1], B, F, K, 0, _p(d_emb), 0, _stream(emb_flat)),
-                   "recalgo_pnn_features_bwd")
-        return None, d_emb, None, None, None
+        torch.index_select(dw.reshape(-1), 0, _pair_index(ctx.F, phi.device), out=ctx.r.grad.view(-1))
+        return None, dphi, None, None
+
+
+def _pair_vector(r: Variable, F: int, T: int, dev) -> torch.Tensor:
+    """[T, 1]: r at the off-diagonal columns of the Gram triangle, 0 on its diagonal (allocated and cleared once)."""
+    w = _pair_vectors.get((r.data.data_ptr(), T))
+    if w is None:
+        w = _pair_vectors[(r.data.data_ptr(), T)] = torch.zeros(T, 1, device=dev, dtype=torch.float32)
+    w.index_copy_(0, _pair_index(F, dev), r.data.reshape(-1, 1))
+    return w
 
 
 _pair_index_cache = {}
@@ -1041,12 +1085,19 @@ def _pair_index(F: int, device) -> torch.Tensor:
     return t
 
 
-def field_pair_logit(store, emb_flat: torch.Tensor, r: Variable, F: int, K: int) -> torch.Tensor:
-    """emb_flat [B, F*K], r [F(F-1)/2] -> [B, 1]."""
+def field_pair_logit(store, emb_flat: torch.Tensor, r: Variable, F: int, K: int):
+    """emb_flat [B, F*K], r [F(F-1)/2] -> [B, 1]: sum_{i<j} r[index(i,j)] <e_i, e_j> (fwfm.py:146-158).  In a TRAIN step
+    the sum over the pairs is left to the fused loss tail (nn.LazyLogit: one launch for this head, the loss and the backward
+    of both)."""
     if store.building:
         return emb_flat.new_zeros(emb_flat.shape[0], 1)
     _chk(emb_flat, torch.float32, "fields_embeddings")
-    return _FieldPairLogitFn.apply(store.anchor, emb_flat.contiguous(), r, int(F), int(K))
+    F, K = int(F), int(K)
+    phi = _IpnnFeaturesFn.apply(emb_flat.contiguous(), F, K)
+    if logit_loss_supported([phi], []):
+        from .nn import LazyLogit
+        return LazyLogit([(_PairKernel(r, _pair_vector(r, F, phi.shape[1], phi.device), F, store.anchor), None, [phi])])
+    return _PairHeadFn.apply(store.anchor, phi, r, F)
 
 
 # =============================================================================================
@@ -1614,7 +1665,10 @@ class _LogitLossFn(Function):
         col, i = 0, 0
         for kernel, n in heads:
             wsum = sum(widths[i:i + n])
-            _colsum_pending.append((partials, col, rows, C + 2, wsum, kernel.grad))
+            if hasattr(kernel, "colsum_jobs"):           # (a derived kernel delivers its gradient itself: ops._PairKernel)
+                _colsum_pending.extend(kernel.colsum_jobs(partials, col, rows, C + 2))
+            else:
+                _colsum_pending.append((partials, col, rows, C + 2, wsum, kernel.grad))
             col += wsum
             i += n
         if bias is not None:

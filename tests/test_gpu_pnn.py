@@ -128,3 +128,58 @@ def test_field_pair_logit_against_reference_double_loop(dev, B, F, K):
     out.backward(g.to(dev))
     assert_close(x.grad, ed.grad, what="fwfm d(embeddings)", ref32=ef.grad)
     assert_close(rv.grad, rd.grad, what="fwfm d(pair strengths)", reduced=True, ref32=rf.grad)
+
+
+@pytest.mark.parametrize("B,F,K", [(4096, 26, 16), (37, 6, 8), (5, 2, 4)])
+def test_field_pair_logit_in_the_fused_loss_tail(dev, B, F, K):
+    """Inside a TRAIN step (ops.loss_seed) the pair head is a nn.LazyLogit: the loss launch forms the weighted pair sum, the
+    loss and both gradients; d(pair strengths) reaches r.grad as F - 1 jobs of the deferred-sum launch.  Compared with
+    mean sigmoid-CE(first + second) written as the reference's double loop, fp64."""
+    from recalgorithm_amd import nn, ops
+    from recalgorithm_amd.variables import Variable, VariableStore
+    gen = torch.Generator().manual_seed(B * 17 + F)
+    emb = torch.randn(B, F * K, generator=gen) * 0.5
+    n = F * (F - 1) // 2
+    r = torch.randn(n, generator=gen) * 0.3
+    first = torch.randn(B, 1, generator=gen) * 0.2
+    y = (torch.rand(B, 1, generator=gen) < 0.3).float()
+
+    def oracle(dt):
+        e, rr, f1 = (t.clone().to(dt).requires_grad_(True) for t in (emb, r, first))
+        second, index = torch.zeros(B, 1, dtype=dt), 0
+        for i in range(F - 1):
+            for j in range(i + 1, F):
+                second = second + rr[index] * (e[:, i * K:(i + 1) * K] * e[:, j * K:(j + 1) * K]).sum(1, keepdim=True)
+                index += 1
+        x = f1 + second
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(x, y.to(dt))
+        loss.backward()
+        return loss.detach(), e.grad, rr.grad, f1.grad
+    l64, ge, gr, gf = oracle(torch.float64)
+    l32, ge32, gr32, gf32 = oracle(torch.float32)
+    store = VariableStore(dev)
+    rv = Variable("fields_pair_strength/fields_pair_strength_weight", r.to(dev))
+    x = emb.to(dev).requires_grad_(True)
+    f1 = first.to(dev).requires_grad_(True)
+    with ops.loss_seed(1.0):
+        lazy = f1 + ops.field_pair_logit(store, x, rv, F, K)
+        assert isinstance(lazy, nn.LazyLogit) and lazy.fusable()
+        heads = [(k, len(ps)) for k, _, ps in lazy.heads]
+        parts = [t for _, _, ps in lazy.heads for t in ps]
+        loss, prob, logit = ops.logit_loss(store, y.to(dev), heads, None, parts, lazy.tensors)
+        loss.backward(torch.ones((), device=dev))
+    ops.flush_dense_splits()
+    assert_close(loss.reshape(1), l64.reshape(1), what="fwfm fused loss", reduced=True, ref32=l32.reshape(1))
+    assert_close(x.grad, ge, what="fwfm fused d(embeddings)", ref32=ge32)
+    assert_close(f1.grad, gf, what="fwfm fused d(first order)", ref32=gf32)
+    assert_close(rv.grad, gr, what="fwfm fused d(pair strengths)", reduced=True, ref32=gr32)
+    # the same head outside the tail (materialize): the separate one-unit head kernels
+    rv2 = Variable("fields_pair_strength/fields_pair_strength_weight", r.to(dev))
+    x2 = emb.to(dev).requires_grad_(True)
+    from recalgorithm_amd.variables import use_store
+    with ops.loss_seed(1.0), use_store(store):
+        t = ops.field_pair_logit(store, x2, rv2, F, K).materialize()
+    t.backward(torch.ones_like(t))
+    fields = emb.double().reshape(B, F, K)
+    want = torch.stack([(fields[:, i] * fields[:, j]).sum() for i in range(F - 1) for j in range(i + 1, F)])
+    assert_close(rv2.grad.reshape(-1), want, what="fwfm materialized d(pair strengths)", reduced=True)
