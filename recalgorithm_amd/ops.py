@@ -191,7 +191,7 @@ def _take_lazy_gather(x0: torch.Tensor):
 
 class _GatherFn(Function):
     @staticmethod
-    def forward(ctx, anchor, ids, arena: EmbeddingArena, row_base, training=False):
+    def forward(ctx, anchor, ids, arena: EmbeddingArena, row_base, training=False, lazy_ok=False):
         B, F = ids.shape
         K = arena.K
         out = torch.empty(B, F * K, device=ids.device, dtype=torch.float32)
@@ -200,8 +200,8 @@ class _GatherFn(Function):
         # deferred Adam: a registered (TRAIN) lookup's rows were just caught up; any other lookup reads lagging rows as of now
         dv, stp = sparse.view_for(ctx.src, arena, anchor_store(anchor))
         ctx.arena, ctx.ids, ctx.row_base = arena, ids, row_base
-        ctx.lazy = (_lazy_gather_on and dv is None and K % 4 == 0 and F * K <= 1024 and ids.is_contiguous()
-                    and getattr(arena, "sharding", None) is None)
+        # (lazy_ok: only the plain lookup of embedding_gather() may be left to its consumer — not the staged rows of a sharded arena)
+        ctx.lazy = lazy_ok and _lazy_gather_on and dv is None and K % 4 == 0 and F * K <= 1024 and ids.is_contiguous()
         if ctx.lazy:
             global _lazy_hit
             _lazy_hit = True                 # (embedding_gather() hangs the pending launch on the tensor autograd hands out)
@@ -217,13 +217,13 @@ class _GatherFn(Function):
         B, F = ids.shape
         if ctx.src is not None:
             ctx.src.set_grad(g)              # summed per row (and applied) by the optimizer's recalgo_scatter_apply
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         g = g.contiguous()
         _lib.check(_lib_().recalgo_embedding_gather_bwd(
             _p(ids), _p(g), _p(ctx.row_base), B, F, arena.K, F * arena.K, 0, _p(arena.grad), _live(arena),
             _stream(ids)), "recalgo_embedding_gather_bwd")
         _flush(arena)
-        return None, None, None, None, None
+        return None, None, None, None, None, None
 
 
 def embedding_gather(store: VariableStore, ids: torch.Tensor, arena: EmbeddingArena,
@@ -237,7 +237,7 @@ def embedding_gather(store: VariableStore, ids: torch.Tensor, arena: EmbeddingAr
         return _GatherFn.apply(store.anchor, ident.reshape(ids.shape), staged, torch.zeros_like(row_base), False)
     global _lazy_hit
     _lazy_hit = False
-    out = _GatherFn.apply(store.anchor, ids, arena, row_base, torch.is_grad_enabled())
+    out = _GatherFn.apply(store.anchor, ids, arena, row_base, torch.is_grad_enabled(), True)
     if _lazy_hit:
         _lazy_hit = False
         out._recalgo_lazy_gather = (ids, arena, row_base)
