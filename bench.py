@@ -380,6 +380,14 @@ def kernel_rooflines(args, est, feats, device):
         dw, db, dx0 = torch.empty_like(w), torch.empty_like(b), torch.empty_like(x0)
         ws = torch.empty(lib.recalgo_cross_bwd_workspace_bytes(B, d, L), dtype=torch.uint8, device=device)
         add("cross_fwd", lambda: lib.recalgo_cross_fwd(p(x0), d, p(w), p(b), B, d, L, p(out), d, st), B * 2 * d * 4)
+        if sd is None:
+            # the step runs the gather INSIDE the cross stack's forward launch (ops.gather_feeds_cross): the two separate
+            # kernels above stay in the table for reference, the composite counts the fused launch
+            res[-1]["part_of"] = "gather_cross_fwd"
+            next(r for r in res if r["kernel"] == "gather_fwd")["part_of"] = "gather_cross_fwd"
+            add("gather_cross_fwd(embedding gather + 3 cross layers, x0 written on the way)",
+                lambda: lib.recalgo_gather_cross_fwd(p(ids), p(ar.weight), p(rb), B, F, K, p(w), p(b), L, p(x0), d, p(out), d, st),
+                B * (F * 8 + 3 * d * 4))
         add("cross_bwd", lambda: lib.recalgo_cross_bwd(p(x0), d, p(w), p(b), p(g), d, None, B, d, L, p(dx0), p(dw), p(db), p(ws), 0, st),
             B * 3 * d * 4)
     if args.model == "xdeepfm":
