@@ -152,6 +152,7 @@ class gather_feeds_cross:
 
     def __enter__(self):
         global _lazy_gather_on
+        flush_lazy_gathers()                 # (nothing is pending here unless an earlier model_fn call ended in an exception)
         self._prev, _lazy_gather_on = _lazy_gather_on, bool(LAZY_GATHER)
         self._kept = False
         return self
