@@ -390,3 +390,33 @@ def test_graphed_step_input_load_never_clobbers_a_static_input_inside_a_span():
     assert link.take(torch.zeros(130, 8)) is None and link.sums is None      # another tensor (autograd summed two consumers)
     link.sums = torch.ones(3, 16)
     assert link.take(gr.t().contiguous().t()) is None             # not the contiguous tensor the sums were computed from
+
+
+@pytest.mark.parametrize("F", [2, 3, 6, 26, 40])
+def test_pair_strength_gradient_jobs_cover_the_strict_triangle(F):
+    """ops._PairKernel.colsum_jobs (FwFM head inside the fused loss tail): the F - 1 column-sum jobs together deliver column
+    t(i, j) of the Gram triangle (diagonal included) to r.grad[index_from_upper_triangular(i, j)] (reference utils.py:67-82)
+    for every i < j, each entry exactly once, and never touch a diagonal column."""
+    import torch
+    from recalgorithm_amd import ops
+    from recalgorithm_amd.variables import Variable
+    n, T = F * (F - 1) // 2, F * (F + 1) // 2
+    r = Variable("fields_pair_strength/fields_pair_strength_weight", torch.zeros(n))
+    rows, stride, col0 = 3, T + 2 + 5, 5                      # the head's columns start at column 5 of the partial rows
+    partials = torch.arange(rows * stride, dtype=torch.float32).reshape(rows, stride)
+    jobs = ops._PairKernel(r, torch.zeros(T, 1), F, None).colsum_jobs(partials, col0, rows, stride)
+    assert len(jobs) == F - 1
+    hit = torch.zeros(n, dtype=torch.int64)
+    for part, off, nrows, st, cnt, out in jobs:               # what the deferred-sum launch does with a job
+        assert part is partials and nrows == rows and st == stride and out.numel() == cnt
+        out.copy_(partials[:, off:off + cnt].sum(0))
+        first = (out.data_ptr() - r.grad.data_ptr()) // 4
+        hit[first:first + cnt] += 1
+    assert bool((hit == 1).all())
+    index = 0
+    for i in range(F - 1):
+        for j in range(i + 1, F):
+            t = i * F - i * (i - 1) // 2 + (j - i)
+            assert float(r.grad[index]) == float(partials[:, col0 + t].sum()), (i, j)
+            index += 1
+    assert ops._pair_index(F, "cpu").tolist() == [i * F - i * (i - 1) // 2 + (j - i) for i in range(F - 1) for j in range(i + 1, F)]
