@@ -67,15 +67,13 @@ def main():
     est.build(f, l)
     graphed = GraphedTrainStep(est.train_step, f, l, warmup=2)
     for _ in range(4):
-        f, l = est._to_device(*next(it))
-        graphed(f, l)
+        est.feed_step(graphed, *next(it))
     torch.cuda.synchronize()
     steps, t0 = 0, time.perf_counter()
     for feats, labs in it:
         if labs["read_comment"].shape[0] != a.batch:
             break                                                                         # the last partial batch
-        f, l = est._to_device(feats, labs)
-        graphed(f, l)
+        est.feed_step(graphed, feats, labs)        # (what Estimator.train does per step: host batch -> the graph's inputs -> replay)
         steps += 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0

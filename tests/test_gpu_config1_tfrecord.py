@@ -154,3 +154,41 @@ def test_captured_step_loads_a_reader_batch_with_one_span_copy(dev):
     g.load(dict(d2[0]), d2[1])
     torch.cuda.synchronize()
     assert torch.equal(torch.stack([g.static_f[k] for k in keys], 1).cpu(), m2) and torch.equal(g.static_l["y"].cpu(), l2["y"])
+
+
+@pytest.mark.gpu
+def test_feed_step_copies_a_host_batch_straight_into_the_captured_inputs(dev):
+    """Estimator.feed_step: a reader batch of the captured layout goes from pinned staging into the graph's static input span
+    (no device tensor in between) and the replay sees exactly that batch; more batches than the staging ring has slots keep
+    their order; a batch of another size falls back to the general path (which refuses it: the captured shape is fixed)."""
+    from recalgorithm_amd.estimator import GraphedTrainStep
+    from recalgorithm_amd.io.native import PackedBatch
+    est = Estimator(deepfm_model_fn, {}, RunConfig(device="cuda"))
+    B, F = 256, 4
+    keys = [f"c{j}" for j in range(F)]
+
+    def batch(seed, n=B):
+        g = torch.Generator().manual_seed(seed)
+        mat = torch.randint(-1, 1000, (n, F), dtype=torch.int64, generator=g)
+        feats = PackedBatch({k: mat[:, j] for j, k in enumerate(keys)})
+        feats.packed_ids = (mat, keys)
+        return mat, feats, {"y": torch.rand(n, 1, generator=g)}
+
+    def step(f, l):
+        return torch.stack([f[k] for k in keys], 1).to(torch.float32).sum() + l["y"].sum()
+
+    m0, f0, l0 = batch(0)
+    g = GraphedTrainStep(step, *est._to_device(f0, l0), warmup=1)
+    assert g._span_plan is not None
+    outs, want = [], []
+    for s in range(1, 2 * est._STAGING_RING + 4):
+        m, f, l = batch(s)
+        outs.append(est.feed_step(g, f, l).clone())          # (g.out is overwritten by the next replay)
+        want.append(float(m.to(torch.float64).sum() + l["y"].to(torch.float64).sum()))
+    torch.cuda.synchronize()
+    assert torch.equal(torch.stack([g.static_f[k] for k in keys], 1).cpu(), m) and torch.equal(g.static_l["y"].cpu(), l["y"])
+    for o, w in zip(outs, want):
+        assert abs(float(o) - w) <= 1e-6 * abs(w) + 1e-2
+    m2, f2, l2 = batch(99, n=B - 7)
+    with pytest.raises(ValueError):
+        est.feed_step(g, f2, l2)
