@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--fields", type=int, default=26)
     ap.add_argument("--max-vocab", type=int, default=1_000_000)
+    ap.add_argument("--two-hop-feed", action="store_true", help="A/B: feed the captured step through a staged device tensor + load")
     a = ap.parse_args()
     from recalgorithm_amd import feature_column as fc
     from recalgorithm_amd.algorithm.DCN.dcn import dcn_model_fn
@@ -73,7 +74,10 @@ def main():
     for feats, labs in it:
         if labs["read_comment"].shape[0] != a.batch:
             break                                                                         # the last partial batch
-        est.feed_step(graphed, feats, labs)        # (what Estimator.train does per step: host batch -> the graph's inputs -> replay)
+        if a.two_hop_feed:                         # (A/B: the path before Estimator.feed_step — staged device tensor, then a load)
+            graphed(*est._to_device(feats, labs))
+        else:
+            est.feed_step(graphed, feats, labs)    # (what Estimator.train does per step: host batch -> the graph's inputs -> replay)
         steps += 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
