@@ -119,6 +119,37 @@ bool for_fields(Span s, Fn&& f) {
     return true;
 }
 
+// Canonical encodings, recognised by a few byte compares (what every protobuf writer emits for an Example): the generic
+// field walks below cost ~60 ns per map entry, 27 entries per record — two thirds of a record's decode time once the
+// vocabulary probes are prefetched.  Anything else (other field order, repeated fields, lengths >= 128) -> false, and the
+// caller takes the generic walk, which yields the same (name, feature) / (first value, count).
+//   map entry  = 0x0A klen key 0x12 vlen Feature                       (key = 1, value = 2, both length-delimited)
+inline bool fast_map_entry(Span entry, std::string_view& name, Span& feat) {
+    const uint8_t* e = entry.p;
+    const size_t n = entry.n;
+    if (n < 4 || e[0] != 0x0A || (e[1] & 0x80)) return false;
+    const size_t kl = e[1];
+    if (kl + 4 > n || e[2 + kl] != 0x12 || (e[3 + kl] & 0x80) || kl + 4 + (size_t)e[3 + kl] != n) return false;
+    name = std::string_view((const char*)e + 2, kl);
+    feat = Span{e + 4 + kl, (size_t)e[3 + kl]};
+    return true;
+}
+//   Feature    = 0x0A llen BytesList ;  BytesList = 0x0A slen bytes    (exactly one value) | empty
+inline bool fast_single_bytes(Span feat, Span& first, int& count) {
+    const uint8_t* v = feat.p;
+    if (feat.n < 2 || v[0] != 0x0A || (v[1] & 0x80) || 2 + (size_t)v[1] != feat.n) return false;
+    const uint8_t* l = v + 2;
+    const size_t ln = v[1];
+    if (ln == 0) {
+        count = 0;
+        return true;
+    }
+    if (ln < 2 || l[0] != 0x0A || (l[1] & 0x80) || 2 + (size_t)l[1] != ln) return false;
+    first = Span{l + 2, (size_t)l[1]};
+    count = 1;
+    return true;
+}
+
 // Vocabulary: open-addressing hash table over the file's bytes (keys are views into `blob`).  A lookup is one
 // 64-bit hash of the key (the keys are short: "userid_12345"), a probe that compares stored hashes first and
 // memcmp only on a hash match — about 3x faster than std::unordered_map<string_view> on 10^5..10^6-key
@@ -133,7 +164,40 @@ struct Vocab {
         char key[23] = {0};
     };
     static_assert(sizeof(Slot) == 32, "vocabulary slot layout");
-    std::vector<Slot> slots;
+    // The table of a 10^6-key vocabulary is 64 MB and every probe lands on a random slot: with 4 KB pages each probe is a
+    // TLB miss on top of the cache miss (and a software prefetch that misses the TLB may be dropped).  Tables of 2 MB and
+    // more are 2 MB-aligned and advised MADV_HUGEPAGE (transparent huge pages: "madvise" or "always" mode; a no-op otherwise).
+    struct SlotTable {
+        Slot* p = nullptr;
+        size_t n = 0;
+        SlotTable() = default;
+        SlotTable(const SlotTable&) = delete;
+        SlotTable& operator=(const SlotTable&) = delete;
+        ~SlotTable() { std::free(p); }
+        void assign(size_t cap, const Slot& v) {
+            std::free(p);
+            p = nullptr;
+            n = 0;
+            constexpr size_t kHuge = size_t(1) << 21;
+            const size_t bytes = cap * sizeof(Slot);
+            if (bytes >= kHuge) {
+                const size_t rounded = (bytes + kHuge - 1) & ~(kHuge - 1);
+                p = static_cast<Slot*>(std::aligned_alloc(kHuge, rounded));
+#ifdef MADV_HUGEPAGE
+                if (p) (void)madvise(p, rounded, MADV_HUGEPAGE);
+#endif
+            } else {
+                p = static_cast<Slot*>(std::malloc(bytes ? bytes : sizeof(Slot)));
+            }
+            if (!p) throw std::bad_alloc();
+            for (size_t i = 0; i < cap; ++i) p[i] = v;
+            n = cap;
+        }
+        bool empty() const { return n == 0; }
+        Slot& operator[](size_t i) { return p[i]; }
+        const Slot& operator[](size_t i) const { return p[i]; }
+    };
+    SlotTable slots;
     uint64_t mask = 0;
     size_t count = 0;
 
@@ -539,6 +603,8 @@ struct PipeSlot {
     bool multi = false;
     bool missing = false;                                  // the error is a required feature without a value (not bad bytes)
     std::string error;
+    std::string multi_msg;                                 // names the multi-valued column (NOT an error: the batch is state 2,
+                                                           // recalgo_pipeline_next answers -2 and the caller re-reads the column ragged)
 };
 
 struct Pipeline {
@@ -603,11 +669,12 @@ struct Pipeline {
                     if (f2 != 1 || w2 != 2) return;
                     std::string_view name;
                     Span feat;
-                    for_fields(entry, [&](uint32_t f3, uint32_t w3, Span pl, uint64_t) {
-                        if (w3 != 2) return;
-                        if (f3 == 1) name = std::string_view((const char*)pl.p, pl.n);
-                        else if (f3 == 2) feat = pl;
-                    });
+                    if (!fast_map_entry(entry, name, feat))
+                        for_fields(entry, [&](uint32_t f3, uint32_t w3, Span pl, uint64_t) {
+                            if (w3 != 2) return;
+                            if (f3 == 1) name = std::string_view((const char*)pl.p, pl.n);
+                            else if (f3 == 2) feat = pl;
+                        });
                     const size_t pos = j++;
                     int col;
                     if (pos < order.size() && order[pos] >= 0 && names[(size_t)order[pos]] == name) col = order[pos];
@@ -638,13 +705,14 @@ struct Pipeline {
                     const size_t f = (size_t)col;
                     int n = 0;
                     Span first;
-                    for_fields(feat, [&](uint32_t f4, uint32_t w4, Span list, uint64_t) {
-                        if (f4 != 1 || w4 != 2) return;                           // BytesList
-                        for_fields(list, [&](uint32_t f5, uint32_t w5, Span pl, uint64_t) {
-                            if (f5 != 1 || w5 != 2) return;
-                            if (n++ == 0) first = pl;
+                    if (!fast_single_bytes(feat, first, n))
+                        for_fields(feat, [&](uint32_t f4, uint32_t w4, Span list, uint64_t) {
+                            if (f4 != 1 || w4 != 2) return;                       // BytesList
+                            for_fields(list, [&](uint32_t f5, uint32_t w5, Span pl, uint64_t) {
+                                if (f5 != 1 || w5 != 2) return;
+                                if (n++ == 0) first = pl;
+                            });
                         });
-                    });
                     if (n > 1 && !multi) { multi = true; multi_col = f; }
                     if (n == 0) {
                         if (slot_of[f] >= 0) pend[(size_t)slot_of[f]].vm = nullptr;
@@ -680,7 +748,7 @@ struct Pipeline {
             std::lock_guard<std::mutex> lk(m);
             if (multi && !S.multi) {
                 S.multi = true;
-                S.error = "feature " + keys[multi_col] + " holds more than one value in a record";
+                S.multi_msg = "feature " + keys[multi_col] + " holds more than one value in a record";
             }
             if (bad && S.error.empty()) S.error = "malformed Example in a record";
             if (!missing.empty() && S.error.empty()) { S.error = missing; S.missing = true; }
@@ -719,6 +787,7 @@ struct Pipeline {
             S.recs.clear();
             S.error.clear();
             S.multi = S.missing = false;
+            S.multi_msg.clear();
             int rc = 1;
             for (size_t i = 0; i < B; ++i) {
                 Span rec;
@@ -1066,11 +1135,12 @@ EXPORT int recalgo_reader_id_matrix(void* reader, int n_keys, const char* const*
                     if (f2 != 1 || w2 != 2) return;
                     std::string_view name;
                     Span feat;
-                    for_fields(entry, [&](uint32_t f3, uint32_t w3, Span pl, uint64_t) {
-                        if (w3 != 2) return;
-                        if (f3 == 1) name = std::string_view((const char*)pl.p, pl.n);
-                        else if (f3 == 2) feat = pl;
-                    });
+                    if (!fast_map_entry(entry, name, feat))
+                        for_fields(entry, [&](uint32_t f3, uint32_t w3, Span pl, uint64_t) {
+                            if (w3 != 2) return;
+                            if (f3 == 1) name = std::string_view((const char*)pl.p, pl.n);
+                            else if (f3 == 2) feat = pl;
+                        });
                     const size_t pos = j++;
                     int col;
                     if (pos < order.size() && order[pos] >= 0 && ks[(size_t)order[pos]] == name) {
@@ -1086,13 +1156,14 @@ EXPORT int recalgo_reader_id_matrix(void* reader, int n_keys, const char* const*
                     const size_t f = (size_t)col;
                     int n = 0;
                     Span first;
-                    for_fields(feat, [&](uint32_t f4, uint32_t w4, Span list, uint64_t) {
-                        if (f4 != 1 || w4 != 2) return;                           // BytesList
-                        for_fields(list, [&](uint32_t f5, uint32_t w5, Span pl, uint64_t) {
-                            if (f5 != 1 || w5 != 2) return;
-                            if (n++ == 0) first = pl;
+                    if (!fast_single_bytes(feat, first, n))
+                        for_fields(feat, [&](uint32_t f4, uint32_t w4, Span list, uint64_t) {
+                            if (f4 != 1 || w4 != 2) return;                       // BytesList
+                            for_fields(list, [&](uint32_t f5, uint32_t w5, Span pl, uint64_t) {
+                                if (f5 != 1 || w5 != 2) return;
+                                if (n++ == 0) first = pl;
+                            });
                         });
-                    });
                     if (n > 1) mflag[f].store(1, std::memory_order_relaxed);
                     // a repeated map key: the last entry wins (protobuf map semantics) -> overwrite this column's entry
                     if (n == 0) {
@@ -1220,7 +1291,7 @@ EXPORT int64_t recalgo_pipeline_next(void* pipeline, int* slot) {
         return S.missing ? -3 : -1;
     }
     if (S.multi) {
-        P->error = S.error;                                     // (names the column)
+        P->error = S.multi_msg;                                 // (names the column)
         return -2;
     }
     ++P->next_out;

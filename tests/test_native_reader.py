@@ -357,3 +357,34 @@ def test_pipeline_batches_equal_the_synchronous_reader(tmp_path, monkeypatch):
     for _ in range(3):
         next(it)
     it.close()
+
+
+def test_pipeline_hands_a_multi_valued_column_back_to_the_ragged_reader(tmp_path, monkeypatch):
+    """A column declared like any other categorical column whose records hold SEVERAL values (`manual_tag_list`) is found out
+    by the asynchronous pipeline only at run time: recalgo_pipeline_next answers -2 naming the column (not the error state)
+    and the dataset re-reads — same batches as with the pipeline switched off, the bag column ragged."""
+    spec = synth.SynthSpec(n_fields=6, max_vocab=300, seed=5, oov_frac=0.1, with_tags=True)
+    vocab_dir = str(tmp_path / "vocabulary") + "/"
+    synth.write_vocabularies(spec, vocab_dir)
+    path = str(tmp_path / "tags.tfrecord")
+    synth.write_tfrecord(spec, path, 200, chunk=64)
+    cols = [fc.embedding_column(fc.categorical_column_with_vocabulary_file(nm, vocab_dir + nm + ".txt"), 8) for nm in spec.names]
+    cols += [fc.embedding_column(fc.categorical_column_with_vocabulary_file("manual_tag_list", vocab_dir + "manual_tag_id.txt"), 8)]
+    labels = [fc.numeric_column("read_comment", default_value=0.0)]
+
+    def batches(pipeline):
+        monkeypatch.setenv("RECALGO_READER_PIPELINE", "1" if pipeline else "0")
+        return list(native.NativeDataset(path, cols + labels, ["read_comment"], 64, num_epochs=2, shuffle_buffer_size=7, seed=3))
+
+    a, b = batches(True), batches(False)
+    assert len(a) == len(b) == 7
+    ragged = 0
+    for (fa, la), (fb, lb) in zip(a, b):
+        assert set(fa) == set(fb) and torch.equal(la["read_comment"], lb["read_comment"])
+        for k in fa:
+            if isinstance(fb[k], torch.Tensor):
+                assert torch.equal(fa[k], fb[k]), k
+            else:
+                ragged += 1
+                assert k == "manual_tag_list" and torch.equal(fa[k].values, fb[k].values) and torch.equal(fa[k].offsets, fb[k].offsets)
+    assert ragged == 7
