@@ -183,8 +183,7 @@ class NativeDataset:
                 if F:
                     src = (ctypes.c_int64 * (B * F)).from_address(lib.recalgo_pipeline_ids(h, slot.value))
                     tmat = torch.from_numpy(np.frombuffer(src, dtype=np.int64).reshape(B, F).copy())
-                    for j, k in enumerate(id_keys):
-                        feats[k] = tmat[:, j]
+                    feats.update(zip(id_keys, tmat.unbind(1)))      # (the F column views in one call: 26 slicing calls were 25 us per batch)
                     feats.packed_ids = (tmat, id_keys)
                 if NF:
                     srcf = (ctypes.c_float * (B * NF)).from_address(lib.recalgo_pipeline_floats(h, slot.value))
