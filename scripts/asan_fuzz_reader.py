@@ -8,7 +8,10 @@ never read out of bounds.
 
 Round 1: clean (150 mutated files + framing corruption, epochs + shuffle on the valid file).
 Round 4: second phase through the asynchronous pipeline (recalgo_pipeline_*: single-valued columns only), also run under
-ThreadSanitizer (-fsanitize=thread, LD_PRELOAD libtsan.so, RECALGO_READER_THREADS=6): clean."""
+ThreadSanitizer (-fsanitize=thread, LD_PRELOAD libtsan.so, RECALGO_READER_THREADS=6): clean.
+Round 5: after the canonical-encoding fast paths, the huge-page vocabulary tables, the one-multiplication key hash and the
+multi-valued-column fix of the pipeline: both phases clean under ASan + UBSan and under TSan (the bag column of this script's
+dataset is what exposed the pipeline's -1 instead of -2)."""
 import sys, os, tempfile, numpy as np
 sys.path.insert(0,'/root/repo')
 from recalgorithm_amd.io import native
