@@ -35,8 +35,9 @@ extern "C" {
 
 typedef void* recalgo_stream_t; /* hipStream_t */
 
-/* ABI version of this header (bumped on any signature change). */
-#define RECALGO_ABI_VERSION 2
+/* ABI version of this header (bumped on any signature change).  include/recalgo.abi records the hash of the declarations
+ * each version stands for; tests/test_abi.py fails when the declarations change and this number does not. */
+#define RECALGO_ABI_VERSION 3
 int recalgo_abi_version(void);
 /* "gfx950" */
 const char* recalgo_target_arch(void);

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RECALGO_HIP_LIB") or os.path.join(_HERE, "librecalgo_hip.so")
 
 P = c_void_p  # device pointer / stream
-ABI_VERSION = 2  # == RECALGO_ABI_VERSION of include/recalgo.h (bumped on any signature change)
+ABI_VERSION = 3  # == RECALGO_ABI_VERSION of include/recalgo.h (bumped on any signature change)
 
 # name -> (restype, argtypes); must list every function of include/recalgo.h
 SIGNATURES = {

@@ -312,6 +312,8 @@ def input_layer(features, feature_columns, _layer_name: Optional[str] = None) ->
                 ok = ids >= 0
                 mh[torch.arange(B, device=dev)[ok], ids[ok]] = 1.0
             parts.append(mh)
+    if len(parts) > 1:
+        ops.flush_lazy_gathers()             # (a gather left to its consumer, ops.gather_feeds_cross, must have run before the concat reads it)
     return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
 
 
@@ -345,6 +347,8 @@ def input_layers_concat(features, feature_columns) -> torch.Tensor:
         else:
             rb = store.row_base_tensor(ar, [tname])
             parts.append(ops.embedding_gather(store, ids.reshape(-1, 1).contiguous(), ar, rb))
+    if len(parts) > 1:
+        ops.flush_lazy_gathers()
     return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
 
 

@@ -236,8 +236,13 @@ def embedding_gather(store: VariableStore, ids: torch.Tensor, arena: EmbeddingAr
         from . import parallel
         _, staged, ident = _staged(arena, parallel.global_rows(ids, row_base), store)
         return _GatherFn.apply(store.anchor, ident.reshape(ids.shape), staged, torch.zeros_like(row_base), False)
-    global _lazy_hit
+    global _lazy_hit, _lazy_gather_on
     _lazy_hit = False
+    if _lazy_gather_on and _lazy_gathers:
+        # a SECOND gather inside gather_feeds_cross(): the outputs are about to be combined by somebody else (input_layer's
+        # per-column path + torch.cat), so neither can be x0 of the cross kernel — launch the pending one, go eager from here on
+        flush_lazy_gathers()
+        _lazy_gather_on = False
     out = _GatherFn.apply(store.anchor, ids, arena, row_base, torch.is_grad_enabled(), True)
     if _lazy_hit:
         _lazy_hit = False

@@ -47,6 +47,28 @@ def test_ctypes_binding_matches_header(lib_path):
     assert lib.recalgo_target_arch() == b"gfx950"
 
 
+def declaration_hash(path=HEADER):
+    """sha256 over the header's declarations: comments, the version number and white space removed."""
+    import hashlib
+    src = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+    src = re.sub(r"#define RECALGO_ABI_VERSION \d+", "", src)
+    return hashlib.sha256(re.sub(r"\s+", " ", src).strip().encode()).hexdigest()
+
+
+def test_declarations_do_not_change_without_a_version_bump():
+    """include/recalgo.abi: one `version sha256` line per ABI version.  A stale librecalgo_hip.so with re-ordered
+    arguments corrupts calls silently; _lib.load() catches it only if the version moved with the declarations."""
+    version = int(re.search(r"#define RECALGO_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    recorded = dict((int(v), h) for v, h in (ln.split() for ln in open(os.path.join(ROOT, "include", "recalgo.abi"))
+                                             if ln.strip() and not ln.startswith("#")))
+    h = declaration_hash()
+    assert version == max(recorded), f"recalgo.h is at ABI {version}, include/recalgo.abi ends at {max(recorded)}"
+    assert recorded[version] == h, (
+        f"the declarations of include/recalgo.h changed (sha256 {h}) but RECALGO_ABI_VERSION is still {version}: bump it in "
+        f"recalgo.h and _lib.py and append `<version> {h}` to include/recalgo.abi")
+    assert len(set(recorded.values())) == len(recorded), "two ABI versions with identical declarations"
+
+
 def test_header_arg_counts_match_binding():
     from recalgorithm_amd import _lib
     src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
