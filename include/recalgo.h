@@ -685,6 +685,23 @@ int recalgo_activation_bwd(const float* x, const float* alpha, const float* gy, 
                            recalgo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * tf.layers.dropout(x, rate, training=True): y = x * keep / (1 - rate), keep ~ Bernoulli(1 - rate) per element
+ * (algorithm/DeepFM/deepfm.py:208-209 — dropout_rate defaults to 0.1, :39; DIN/din.py:235-236; FiBiNET/fibinet.py:193-194;
+ * PNN/pnn.py:188-189; NFM/nfm.py:170).  The keep decision of flat element i is a counter-based hash of (seed, call, *step, i)
+ * (csrc/dropout.h) — `seed` the variable store's (+ rank), `call` the index of the dropout call inside the model_fn, `step` the
+ * optimizer's device-side int64 step counter (NULL: 0), read at run time so that a captured step draws a new mask per replay —
+ * or, keep_mask != NULL, the explicit mask (1 = keep, 0 = drop; parity tests replay the masks of the reference run).  No mask
+ * is stored: the backward is the same map applied to the gradient with the same key.  recalgo_dropout_keep_mask writes the
+ * mask the hash stands for (tests, debugging).  n < 2^32 elements; pointers 16-byte aligned; 0 < rate < 1 (a double: TF forms
+ * 1 / (1 - rate) from the Python float and casts it to x.dtype once). */
+int recalgo_dropout_fwd(const float* x, int64_t n, double rate, const float* keep_mask, unsigned seed, unsigned call,
+                        const int64_t* step, float* y, recalgo_stream_t stream);
+int recalgo_dropout_bwd(const float* g, int64_t n, double rate, const float* keep_mask, unsigned seed, unsigned call,
+                        const int64_t* step, float* dx, recalgo_stream_t stream);
+int recalgo_dropout_keep_mask(int64_t n, double rate, unsigned seed, unsigned call, const int64_t* step, float* out,
+                              recalgo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * a15 / a16 / f1  Row-gradient scatter without float atomics, fused with the sparse optimizer.
  * Replaces, for every embedding variable, TF autodiff's IndexedSlices gradient of the lookup plus
  * tf.train.AdamOptimizer(...).minimize (algorithm/DeepFM/deepfm.py:246-250, same in all six hot-path models;

@@ -281,6 +281,11 @@ def model_goldens(tf, vocab_dir):
     run("model_deepfm", _import_ref("DeepFM", "deepfm"), "deepfm_model_fn", deepfm_params,
         dict(common, embedding_dim=8, dropout_rate=0.0, batch_norm=True))
 
+    # the reference's DEFAULT training configuration has dropout_rate = 0.1 (deepfm.py:39): dense(relu) -> dropout -> BN;
+    # the keep masks the run drew are part of the golden (aux/dropout_mask_<i>, call order)
+    run("model_deepfm_dropout", _import_ref("DeepFM", "deepfm"), "deepfm_model_fn", deepfm_params,
+        dict(common, embedding_dim=8, dropout_rate=0.1, batch_norm=True))
+
     def dcn_params(m):
         dense_c, cat, label = m.create_feature_columns()
         return ({"category_feature_columns": cat, "dense_feature_columns": dense_c,
@@ -313,6 +318,10 @@ def model_goldens(tf, vocab_dir):
         dict(common, dropout_rate=0.0, batch_norm=True, activation="prelu", mini_batch_aware_regularization=False,
              l2_lambda=0.2, use_softmax=True))
 
+    run("model_din_dice_dropout", din, "din_model_fn", din_params,                         # din.py:41 default rate; BN -> dropout
+        dict(common, dropout_rate=0.1, batch_norm=True, activation="dice", mini_batch_aware_regularization=True,
+             l2_lambda=0.2, use_softmax=False))
+
     def fibinet_params(m):
         dense_c, cat, label = m.create_feature_columns()
         F = m.FLAGS
@@ -326,6 +335,10 @@ def model_goldens(tf, vocab_dir):
         run(f"model_fibinet_{ty}", fib, "fibinet_model_fn", fibinet_params,
             dict(common, embedding_dim=8, dropout_rate=0.0, batch_norm=True, reduction_ratio=2,
                  bilinear_interaction_type=ty))
+
+    run("model_fibinet_all_dropout", fib, "fibinet_model_fn", fibinet_params,                 # fibinet.py:42 default rate
+        dict(common, embedding_dim=8, dropout_rate=0.1, batch_norm=True, reduction_ratio=2,
+             bilinear_interaction_type="all"))
 
     def pnn_params(m):
         cat, label = m.create_feature_columns()
@@ -341,6 +354,13 @@ def model_goldens(tf, vocab_dir):
     run("model_pnn_opnn_reg", pnn, "pnn_model_fn", pnn_params,
         dict(common, embedding_dim=8, dropout_rate=0.0, batch_norm=True, output_dimension=20,
              product_method="OPNN", weight_regularizer=0.01))
+
+    run("model_pnn_ipnn_dropout", pnn, "pnn_model_fn", pnn_params,                            # pnn.py:39 default rate
+        dict(common, embedding_dim=8, dropout_rate=0.1, batch_norm=True, output_dimension=20,
+             product_method="IPNN", weight_regularizer=0.0))
+    run("model_pnn_ipnn_dropout_nobn", pnn, "pnn_model_fn", pnn_params,                       # dropout feeding a dense layer directly
+        dict(common, embedding_dim=8, dropout_rate=0.25, batch_norm=False, output_dimension=20,
+             product_method="IPNN", weight_regularizer=0.0))
 
     # §8f-3 sibling: FwFM (first-order dense over indicators + field-pair-weighted inner products, no MLP)
     def fwfm_params(m):

@@ -57,6 +57,19 @@ def _mlp(P, x, scope, names, relu=True):
     return x
 
 
+def _dropout(net, params, training, masks):
+    """tf.layers.dropout(net, params["dropout_rate"], training=...) as the model scripts guard it (deepfm.py:208-209,
+    din.py:235-236, fibinet.py:193-194, pnn.py:188-189): keep mask * 1 / (1 - rate) in TRAIN mode, identity otherwise.
+    TF's random stream cannot be reproduced: `masks` is the list of keep masks in call order (the golden's
+    aux/dropout_mask_<i>), consumed from the front."""
+    rate = float(params.get("dropout_rate") or 0.0)
+    if not (training and 0.0 < rate < 1.0):
+        return net
+    if not masks:
+        raise ValueError("training-mode dropout needs its keep masks (dropout_masks=[...], call order)")
+    return net * masks.pop(0).to(net.dtype) / (1.0 - rate)
+
+
 def _tail(logit, labels, extra=None):
     out = {"logit": logit, "prob": torch.sigmoid(logit)}
     if labels is not None:
@@ -87,9 +100,10 @@ def dcn(P, feats, labels, params, training=False):
     return _tail(logit, None if labels is None else labels["read_comment"])
 
 
-def deepfm(P, feats, labels, params, training=False, bn_state=None):
-    """algorithm/DeepFM/deepfm.py:165-235.  Dropout is the identity here (rate 0 / eval);
-    batch norm uses batch statistics when `training`."""
+def deepfm(P, feats, labels, params, training=False, bn_state=None, dropout_masks=None):
+    """algorithm/DeepFM/deepfm.py:165-235.  MLP order dense(relu) -> dropout -> BN (:207-211); batch norm uses batch
+    statistics when `training`; training-mode dropout takes its keep masks from `dropout_masks` (call order)."""
+    masks = list(dropout_masks or [])
     first_cols = _sorted(params["first_order_feature_columns"])
     # fm_first_order: (B, sum V) multi-hot @ kernel + bias == sum of per-column weight lookups
     w1 = [P[f"fm_first_order/fm_first_order_dense/kernel/{c.key}"] for c in first_cols]
@@ -104,6 +118,7 @@ def deepfm(P, feats, labels, params, training=False, bn_state=None):
     for i, _ in enumerate(params["hidden_units"]):
         dn = "dense" if i == 0 else f"dense_{i}"
         net = R.dense(net, P[f"fm_deep/{dn}/kernel"], P[f"fm_deep/{dn}/bias"], relu=True)
+        net = _dropout(net, params, training, masks)                               # :208-209
         if params.get("batch_norm"):
             bn = "batch_normalization" if i == 0 else f"batch_normalization_{i}"
             net = R.batch_norm(net, P[f"fm_deep/{bn}/gamma"], P[f"fm_deep/{bn}/beta"],
@@ -280,8 +295,9 @@ def xdeepfm(P, feats, labels, params, training=False):
     return _tail(linear_logit + cin_logit + dnn_logit, None if labels is None else labels["read_comment"])
 
 
-def din(P, feats, labels, params, training=False):
-    """algorithm/DIN/din.py:186-257 (dropout is the identity here: rate 0 / eval)."""
+def din(P, feats, labels, params, training=False, dropout_masks=None):
+    """algorithm/DIN/din.py:186-257; fcn order dense -> dice | prelu -> BN -> dropout (:227-236)."""
+    masks = list(dropout_masks or [])
     reg = {}
     parts = []
     dense_cols = params.get("dense_feature_columns") or []
@@ -312,6 +328,7 @@ def din(P, feats, labels, params, training=False):
             bn = "batch_normalization" if i == 0 else f"batch_normalization_{i}"
             net = R.batch_norm(net, P[f"fcn/{bn}/gamma"], P[f"fcn/{bn}/beta"], P[f"fcn/{bn}/moving_mean"],
                                P[f"fcn/{bn}/moving_variance"], training)
+        net = _dropout(net, params, training, masks)                                               # :235-236
     n = len(params["hidden_units"])
     dn = "dense" if n == 0 else f"dense_{n}"
     logit = R.dense(net, P[f"fcn/{dn}/kernel"], P[f"fcn/{dn}/bias"])
@@ -321,11 +338,12 @@ def din(P, feats, labels, params, training=False):
     return _tail(logit, None if labels is None else labels["read_comment"], extra)
 
 
-def _dnn_bn(P, net, scope, hidden_units, batch_norm, training):
-    """dense(relu) -> [dropout: identity here] -> BN, the DeepFM/PNN/FiBiNET MLP order (quirk B-7)."""
+def _dnn_bn(P, net, scope, hidden_units, batch_norm, training, params=None, masks=None):
+    """dense(relu) -> dropout -> BN, the DeepFM/PNN/FiBiNET MLP order (quirk B-7)."""
     for i, _ in enumerate(hidden_units):
         dn = "dense" if i == 0 else f"dense_{i}"
         net = R.dense(net, P[f"{scope}/{dn}/kernel"], P[f"{scope}/{dn}/bias"], relu=True)
+        net = _dropout(net, params or {}, training, masks)
         if batch_norm:
             bn = "batch_normalization" if i == 0 else f"batch_normalization_{i}"
             net = R.batch_norm(net, P[f"{scope}/{bn}/gamma"], P[f"{scope}/{bn}/beta"],
@@ -335,7 +353,7 @@ def _dnn_bn(P, net, scope, hidden_units, batch_norm, training):
     return R.dense(net, P[f"{scope}/{dn}/kernel"], P[f"{scope}/{dn}/bias"])
 
 
-def fibinet(P, feats, labels, params, training=False):
+def fibinet(P, feats, labels, params, training=False, dropout_masks=None):
     """algorithm/FiBiNET/fibinet.py:143-221."""
     dense_cols = params.get("dense_feature_columns") or []
     cat = input_layer(P, feats, params["category_feature_columns"], "category_input/input_layer", {})
@@ -345,14 +363,15 @@ def fibinet(P, feats, labels, params, training=False):
     bi = R.fibinet_interaction(cat, P["senet_part/senet_w1"], P["senet_part/senet_w2"],
                                P[f"bilinear_interaction_part/orginal_w_{t}"],
                                P[f"bilinear_interaction_part/senet_w_{t}"], t)                     # :171-187
-    logit = _dnn_bn(P, bi, "dnn_part", params["hidden_units"], params.get("batch_norm"), training)  # :189-197
+    logit = _dnn_bn(P, bi, "dnn_part", params["hidden_units"], params.get("batch_norm"), training, params,
+                    list(dropout_masks or []))                                                     # :189-197
     if dense_cols:
         dense_in = input_layer(P, feats, dense_cols, "dense_input/input_layer")
         logit = R.dense(dense_in, P["linear_part/dense/kernel"], P["linear_part/dense/bias"]) + logit   # :168,199
     return _tail(logit, None if labels is None else labels["read_comment"])
 
 
-def pnn(P, feats, labels, params, training=False):
+def pnn(P, feats, labels, params, training=False, dropout_masks=None):
     """algorithm/PNN/pnn.py:112-214."""
     fields, reg = [], {}
     for i, c in enumerate(params["category_feature_columns"]):                                     # :126-129 list order
@@ -363,7 +382,8 @@ def pnn(P, feats, labels, params, training=False):
     method = params["product_method"]
     pw = P["product_part/inner_product_w"] if method == "IPNN" else P["product_part/outer_product_w"]
     _, _, product_final = R.pnn_product_fast(emb, P["linear_part/linear_w"], pw, P["bias"], F, K, method)   # :133-181
-    logit = _dnn_bn(P, product_final, "fcn", params["hidden_units"], params.get("batch_norm"), training)    # :184-193
+    logit = _dnn_bn(P, product_final, "fcn", params["hidden_units"], params.get("batch_norm"), training, params,
+                    list(dropout_masks or []))                                                              # :184-193
     extra = None
     wr = float(params.get("weight_regularizer") or 0.0)
     if labels is not None and wr > 0:            # tf.contrib.layers.l2_regularizer(scale): scale * sum(w^2) / 2

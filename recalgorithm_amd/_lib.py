@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (RECALGO_HIP_LIB: a developer switch — A/B runs of differently tuned builds of the same library on one GPU box)
@@ -71,6 +71,9 @@ SIGNATURES = {
     "recalgo_batchnorm_apply": (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, c_float, P, P, P, P, P, P]),
     "recalgo_batchnorm_bwd_sums": (c_int, [P, P, P, P, c_int, c_int, P, P]),
     "recalgo_batchnorm_bwd_apply": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, c_int, P]),
+    "recalgo_dropout_fwd": (c_int, [P, c_int64, c_double, P, c_int, c_int, P, P, P]),
+    "recalgo_dropout_bwd": (c_int, [P, c_int64, c_double, P, c_int, c_int, P, P, P]),
+    "recalgo_dropout_keep_mask": (c_int, [c_int64, c_double, c_int, c_int, P, P, P]),
     "recalgo_sigmoid_ce_fwd_bwd": (c_int, [P, P, c_int, c_float, P, P, P, P]),
     "recalgo_adam_tf1_dense": (c_int, [P, P, P, P, c_int64, c_float, P, c_float, c_float, c_float, c_int, P]),
     "recalgo_adam_tf1_rows": (c_int, [P, P, P, P, P, c_int64, c_int, c_float, P, c_float, c_float, c_float, c_int, P]),

@@ -78,12 +78,7 @@ class AdamOptimizer:
         return TrainOp(self, loss, current_store())
 
     def apply_gradients(self, store: VariableStore, grad_hook: Optional[Callable] = None):
-        st = store.opt_state
-        if st is None:
-            st = store.opt_state = {
-                "step": torch.zeros(1, dtype=torch.int64, device=store.device),
-                "lr_t": torch.zeros(1, dtype=torch.float32, device=store.device),
-            }
+        st = store.ensure_opt_state()
         from . import nn, sparse
         arenas = [ar for ar in store.arenas.values() if ar.weight is not None and ar.trainable]
         # arenas on the owner-computes path (sparse.py): their optimizer step is fused with the row-gradient scatter

@@ -506,17 +506,44 @@ def dense_activation_bn(x: torch.Tensor, units, kind: str, act_name, batch_norm:
 
 
 DROPOUT_KEEP_MASKS: list = []      # test hook: keep masks consumed (FIFO) by the next training-mode dropout calls
+DROPOUT_SPECS: list = []           # test hook: when not None, every training-mode dropout call appends its ops.DropSpec
+
+
+def drop_spec(x_shape, rate: float, device):
+    """The ops.DropSpec of the next training-mode dropout call of the current model_fn invocation: an injected keep mask
+    (DROPOUT_KEEP_MASKS), else the hash stream (store seed + rank, call index, the optimizer's device step counter)."""
+    from . import ops
+    store = current_store()
+    call = store._drop_calls
+    store._drop_calls += 1
+    mask = None
+    if DROPOUT_KEEP_MASKS:
+        mask = DROPOUT_KEEP_MASKS.pop(0).to(device=device, dtype=torch.float32).reshape(tuple(x_shape)).contiguous()
+    rank = getattr(getattr(store, "sync_bn", None), "rank", 0) or 0
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            rank = dist.get_rank()
+    except Exception:
+        pass
+    d = ops.DropSpec(rate, mask, store.seed * 1000003 + 7919 * rank, call, store.ensure_opt_state()["step"])
+    if DROPOUT_SPECS is not None:
+        DROPOUT_SPECS.append(d)
+        del DROPOUT_SPECS[:-64]
+    return d
 
 
 def dropout(x: torch.Tensor, rate: float, training: bool = False) -> torch.Tensor:
     """tf.layers.dropout: keep prob 1-rate, scaled by 1/(1-rate); identity when not training.  TF's random stream
-    cannot be reproduced: parity tests inject the keep mask the golden recorded through DROPOUT_KEEP_MASKS."""
+    cannot be reproduced: parity tests inject the keep mask the golden recorded through DROPOUT_KEEP_MASKS; otherwise the
+    keep decisions are the counter-based hash of csrc/dropout.h (a new mask per optimizer step, also under hipGraph replay)."""
     if not training or rate <= 0.0:
         return x
-    if DROPOUT_KEEP_MASKS:
-        keep = DROPOUT_KEEP_MASKS.pop(0).to(device=x.device, dtype=x.dtype)
-        return x * keep / (1.0 - rate)
-    return torch.nn.functional.dropout(x, p=rate, training=True)
+    store = current_store()
+    if store.building:
+        return x
+    from . import ops
+    return ops.dropout(x, drop_spec(x.shape, rate, x.device))
 
 
 class _L2RegFn(Function):

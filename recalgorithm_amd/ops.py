@@ -1817,6 +1817,55 @@ def activation(store, x: torch.Tensor, alpha: Variable, kind: str) -> torch.Tens
 
 
 # =============================================================================================
+# tf.layers.dropout (training mode)
+# =============================================================================================
+class DropSpec:
+    """One training-mode tf.layers.dropout call: rate, and where its keep decisions come from — an explicit mask (parity
+    tests replay the reference run's), or the counter-based hash of csrc/dropout.h keyed by (seed, call, device step counter)."""
+    __slots__ = ("rate", "mask", "seed", "call", "step")
+
+    def __init__(self, rate: float, mask: Optional[torch.Tensor], seed: int, call: int, step: Optional[torch.Tensor]):
+        self.rate, self.mask, self.seed, self.call, self.step = float(rate), mask, int(seed) & 0x7FFFFFFF, int(call), step
+
+    @property
+    def scale(self) -> float:
+        return 1.0 / (1.0 - self.rate)
+
+
+def _dropout_launch(fn_name: str, x: torch.Tensor, d: DropSpec) -> torch.Tensor:
+    y = torch.empty_like(x)
+    _lib.check(getattr(_lib_(), fn_name)(_p(x), x.numel(), d.rate, _p(d.mask), d.seed, d.call, _p(d.step), _p(y), _stream(x)), fn_name)
+    return y
+
+
+class _DropoutFn(Function):
+    @staticmethod
+    def forward(ctx, x, d: DropSpec):
+        ctx.d = d
+        return _dropout_launch("recalgo_dropout_fwd", x.contiguous(), d)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _dropout_launch("recalgo_dropout_bwd", g.contiguous(), ctx.d), None
+
+
+def dropout(x: torch.Tensor, d: DropSpec) -> torch.Tensor:
+    """y = x * keep / (1 - rate) as its own launch each way (a dropout no neighbouring kernel can absorb)."""
+    _chk(x, torch.float32, "x")
+    if d.mask is not None and (d.mask.shape != x.shape or d.mask.dtype != torch.float32 or not d.mask.is_contiguous()):
+        raise ValueError("dropout: the explicit keep mask must be a contiguous fp32 tensor of x's shape")
+    return _DropoutFn.apply(x, d)
+
+
+def dropout_keep_mask(shape, d: DropSpec, device) -> torch.Tensor:
+    """The keep mask (1 / 0) the hash of `d` stands for at the CURRENT value of the step counter."""
+    out = torch.empty(*shape, dtype=torch.float32, device=device)
+    _lib.check(_lib_().recalgo_dropout_keep_mask(out.numel(), d.rate, d.seed, d.call, _p(d.step), _p(out), _stream(out)),
+               "recalgo_dropout_keep_mask")
+    return out
+
+
+# =============================================================================================
 # a15: TF1 Adam
 # =============================================================================================
 def adam_tf1_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int,

@@ -102,6 +102,7 @@ class VariableStore:
         self.building = False
         self.shared_tables: Dict[tuple, str] = {}
         self.opt_state = None            # device-side Adam step counter / lr_t (estimator.py)
+        self._drop_calls = 0             # training-mode dropout calls of the current model_fn invocation (nn.dropout)
         self._rb_cache: Dict[tuple, torch.Tensor] = {}
 
     def row_base_tensor(self, arena: "EmbeddingArena", table_names: Sequence[str]) -> torch.Tensor:
@@ -137,8 +138,17 @@ class VariableStore:
         """A model_fn invocation == a fresh TF graph: auto-naming counters restart."""
         self._auto.clear()
         self._scope.clear()
+        self._drop_calls = 0
         from . import sparse
         sparse.new_forward(self)
+
+    def ensure_opt_state(self) -> dict:
+        """The optimizer's device-side state {step int64[1], lr_t float[1]}: created on first use (the optimizer's first
+        apply_gradients, or a training-mode dropout — its keep masks are keyed by the step counter)."""
+        if self.opt_state is None:
+            self.opt_state = {"step": torch.zeros(1, dtype=torch.int64, device=self.device),
+                              "lr_t": torch.zeros(1, dtype=torch.float32, device=self.device)}
+        return self.opt_state
 
     def scope_name(self) -> str:
         return "/".join(self._scope)

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 T=${3:-q}
 if [ -n "${1:-}" ]; then
-  timeout 900 python -m pytest $1 -x -q 2>&1 | tail -15 > gpurun_out/${T}_pytest.log
+  timeout 900 python -m pytest $1 -x -q 2>&1 | tail -120 > gpurun_out/${T}_pytest.log
   tail -3 gpurun_out/${T}_pytest.log
 fi
 for m in ${2:-dcn}; do

@@ -9,7 +9,19 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 MODELS = ["model_deepfm", "model_dcn", "model_xdeepfm", "model_din_dice", "model_din_prelu_softmax",
           "model_fibinet_all", "model_fibinet_each", "model_fibinet_interaction", "model_pnn_ipnn",
-          "model_pnn_opnn_reg", "model_fwfm", "model_nfm", "model_afm", "model_ffm"]
+          "model_pnn_opnn_reg", "model_fwfm", "model_nfm", "model_afm", "model_ffm",
+          # the reference's default dropout_rate (0.1) switched on: keep masks in aux/dropout_mask_<i>
+          "model_deepfm_dropout", "model_din_dice_dropout", "model_fibinet_all_dropout", "model_pnn_ipnn_dropout",
+          "model_pnn_ipnn_dropout_nobn"]
+
+
+def dropout_masks(d):
+    """The keep masks a golden's TRAIN run drew, in call order."""
+    out, i = [], 0
+    while f"aux/dropout_mask_{i}" in d:
+        out.append(torch.from_numpy(d[f"aux/dropout_mask_{i}"].copy()))
+        i += 1
+    return out
 
 
 def load(name):
@@ -56,12 +68,14 @@ def mirror_setup(name, vocab_dir):
         setattr(FL, k, v)
     hidden = str(fl.get("hidden_units", "")).split(",")
     lr = float(fl["learning_rate"])
-    if name == "model_deepfm":
+    drop = float(fl.get("dropout_rate", 0.0))
+    bnorm = bool(fl.get("batch_norm", True))
+    if name.startswith("model_deepfm"):
         from recalgorithm_amd.algorithm.DeepFM import deepfm as m
         first, second, _ = m.create_feature_columns()
         return m.deepfm_model_fn, {"first_order_feature_columns": first, "second_order_feature_columns": second,
-                                   "hidden_units": hidden, "learning_rate": lr, "dropout_rate": 0.0,
-                                   "batch_norm": True}, "deepfm"
+                                   "hidden_units": hidden, "learning_rate": lr, "dropout_rate": drop,
+                                   "batch_norm": bnorm}, "deepfm"
     if name == "model_dcn":
         from recalgorithm_amd.algorithm.DCN import dcn as m
         dense, cat, _ = m.create_feature_columns()
@@ -80,7 +94,7 @@ def mirror_setup(name, vocab_dir):
         dense, cat, tgt, seq, _ = m.create_feature_columns()
         return m.din_model_fn, {"dense_feature_columns": dense, "category_feature_columns": cat,
                                 "sequence_feature_columns": seq, "target_feedid_feature_columns": tgt,
-                                "hidden_units": hidden, "dropout_rate": 0.0, "batch_norm": True, "learning_rate": lr,
+                                "hidden_units": hidden, "dropout_rate": drop, "batch_norm": bnorm, "learning_rate": lr,
                                 "activation": str(fl["activation"]),
                                 "mini_batch_aware_regularization": bool(fl["mini_batch_aware_regularization"]),
                                 "l2_lambda": float(fl["l2_lambda"]), "use_softmax": bool(fl["use_softmax"])}, "din"
@@ -88,15 +102,15 @@ def mirror_setup(name, vocab_dir):
         from recalgorithm_amd.algorithm.FiBiNET import fibinet as m
         dense, cat, _ = m.create_feature_columns()
         return m.fibinet_model_fn, {"category_feature_columns": cat, "dense_feature_columns": dense,
-                                    "hidden_units": hidden, "dropout_rate": 0.0, "batch_norm": True,
+                                    "hidden_units": hidden, "dropout_rate": drop, "batch_norm": bnorm,
                                     "learning_rate": lr, "embedding_dim": int(fl["embedding_dim"]),
                                     "reduction_ratio": int(fl["reduction_ratio"]),
                                     "bilinear_interaction_type": str(fl["bilinear_interaction_type"])}, "fibinet"
     if name.startswith("model_pnn"):
         from recalgorithm_amd.algorithm.PNN import pnn as m
         cat, _ = m.create_feature_columns()
-        return m.pnn_model_fn, {"category_feature_columns": cat, "hidden_units": hidden, "dropout_rate": 0.0,
-                                "batch_norm": True, "learning_rate": lr,
+        return m.pnn_model_fn, {"category_feature_columns": cat, "hidden_units": hidden, "dropout_rate": drop,
+                                "batch_norm": bnorm, "learning_rate": lr,
                                 "output_dimension": int(fl["output_dimension"]),
                                 "product_method": str(fl["product_method"]),
                                 "weight_regularizer": float(fl["weight_regularizer"]),
@@ -143,7 +157,7 @@ def golden_to_oracle_vars(name, gvars, params):
     out = dict(gvars)
     prefix = {"model_deepfm": "fm_first_order/fm_first_order_dense/kernel",
               "model_fwfm": "fwfm_first_order/fwfm_first_order_dense/kernel",
-              "model_ffm": "ffm_first_order/fm_first_order_dense/kernel"}.get(name)
+              "model_ffm": "ffm_first_order/fm_first_order_dense/kernel"}.get("model_deepfm" if name.startswith("model_deepfm") else name)
     if prefix:
         kern = out.pop(prefix)
         row = 0

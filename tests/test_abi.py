@@ -82,7 +82,7 @@ def test_header_arg_counts_match_binding():
 def test_header_arg_types_match_binding():
     """Every parameter and return type of recalgo.h against the ctypes signature (int vs int64_t vs float vs
     pointer): a wrong width here silently corrupts arguments at call time."""
-    from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+    from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
     from recalgorithm_amd import _lib
     src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
 
@@ -91,7 +91,7 @@ def test_header_arg_types_match_binding():
         if "*" in decl or decl.startswith("recalgo_stream_t"):
             return c_void_p
         base = decl.rsplit(" ", 1)[0].replace("const ", "").strip()
-        return {"int": c_int, "int64_t": c_int64, "float": c_float, "unsigned": c_int, "unsigned int": c_int}[base]
+        return {"int": c_int, "int64_t": c_int64, "float": c_float, "double": c_double, "unsigned": c_int, "unsigned int": c_int}[base]
 
     for name, (res, args) in _lib.SIGNATURES.items():
         m = re.search(r"([A-Za-z_0-9 \*]+?)\b" + name + r"\s*\(([^)]*)\)", src)

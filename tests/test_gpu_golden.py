@@ -138,10 +138,12 @@ def test_model_golden(dev, name, tmp_path):
     for k, v in GU.section(d, "predict/").items():
         assert_close(pr.predictions[k], torch.from_numpy(v), what=f"{name} predict/{k}")
     # TRAIN: loss, gradients, one TF1-Adam step
-    if "aux/dropout_mask_0" in d:       # NFM's hard-coded dropout: the keep mask the reference run drew is part of the golden
-        from recalgorithm_amd import nn
-        nn.DROPOUT_KEEP_MASKS[:] = [torch.from_numpy(d["aux/dropout_mask_0"])]
+    # training-mode dropout (NFM's hard-coded one; the reference's default rate 0.1 in the *_dropout goldens): the keep masks
+    # the reference run drew are part of the golden, consumed in call order
+    from recalgorithm_amd import nn
+    nn.DROPOUT_KEEP_MASKS[:] = GU.dropout_masks(d)
     spec = est._call_model_fn(feats, labels, ModeKeys.TRAIN)
+    assert not nn.DROPOUT_KEEP_MASKS, "the mirror made fewer dropout calls than the reference"
     assert_close(spec.loss, torch.from_numpy(d["train/loss"]), what=f"{name} loss")
     spec.loss.backward()
     grads = named_grads(est.store)

@@ -464,13 +464,13 @@ def test_dcn_without_dense_columns_on_every_input_layer_path(dev, layout):
             spec_.loss.backward()
             ops.flush_dense_splits()
             g = {k: v.detach().clone() for k, v in named_grads(est.store).items()}
-            return spec_.loss.detach().clone(), spec_.predictions["logit"].detach().clone(), g
+            return spec_.loss.detach().clone(), spec_.predictions["probabilities"].detach().clone(), g
         finally:
             ops.LAZY_GATHER = prev
     la, pa, ga = run(True)
     lb, pb, gb = run(False)
     assert_bit_exact(la, lb, f"{layout} loss")
-    assert_bit_exact(pa, pb, f"{layout} logit")
+    assert_bit_exact(pa, pb, f"{layout} probabilities")
     assert set(ga) == set(gb)
     for k in ga:
         assert_bit_exact(ga[k], gb[k], f"{layout} d({k})")

@@ -127,8 +127,8 @@ def test_model_golden(name, tmp_path):
             close(out[k], d[f"predict/{k}"], f"{name} {k}")
     # TRAIN: loss and every gradient
     extra = {}
-    if "aux/dropout_mask_0" in d:       # NFM's hard-coded dropout: the keep mask the reference run drew is part of the golden
-        extra["dropout_masks"] = [torch.from_numpy(d["aux/dropout_mask_0"])]
+    if "aux/dropout_mask_0" in d:       # training-mode dropout: the keep masks the reference run drew are part of the golden
+        extra["dropout_masks"] = GU.dropout_masks(d)
     out = fn(P, feats, {"read_comment": labels}, params, training=True, **extra)
     close(out["loss"], d["train/loss"], f"{name} loss")
     out["loss"].backward()
