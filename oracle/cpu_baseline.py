@@ -25,7 +25,7 @@ from . import ref_ops as R
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(model: str, batch=4096, fields=26, emb=16, max_vocab=1_000_000, seconds=15.0, threads=None):
+def run(model: str, batch=4096, fields=26, emb=16, max_vocab=1_000_000, seconds=15.0, threads=None, also_threads=None):
     # threads actually used: the cores this process may run on, capped at 32 (the per-op work of
     # a 4096-example batch does not scale past that; TF1's default intra-op pool has the same
     # problem on many-core hosts)
@@ -74,20 +74,36 @@ def run(model: str, batch=4096, fields=26, emb=16, max_vocab=1_000_000, seconds=
     t0 = time.perf_counter()
     step(1)                                            # warm-up (allocations, MKL init)
     warm = time.perf_counter() - t0
-    times, t, t_start = [], 2, time.perf_counter()
-    while True:
-        t0 = time.perf_counter()
-        step(t)
-        times.append(time.perf_counter() - t0)
-        t += 1
-        if time.perf_counter() - t_start > seconds or len(times) >= 50:
-            break
+    t = 2
+
+    def sample(secs, max_steps=50, min_steps=1):
+        nonlocal t
+        times, t_start = [], time.perf_counter()
+        while True:
+            t0 = time.perf_counter()
+            step(t)
+            times.append(time.perf_counter() - t0)
+            t += 1
+            if (time.perf_counter() - t_start > secs and len(times) >= min_steps) or len(times) >= max_steps:
+                break
+        return times
+    times = sample(seconds)
     med = float(np.median(times))
-    return {"value": round(cpu_batch / med, 1), "unit": "examples/s", "cores": threads, "kind": "port",
-            "sample": f"{len(times)} full train steps (fwd+bwd+dense TF1-Adam over {rows} embedding rows) of "
-                      f"[{workload.replace(f'batch {cpu_batch}/GPU', f'batch {cpu_batch}')}], median "
-                      f"{med * 1e3:.1f} ms/step (warm-up {warm:.1f} s), torch-CPU fp32 op-for-op restatement of the "
-                      f"reference graph (TF 1.14 not installable)"}
+    out = {"value": round(cpu_batch / med, 1), "unit": "examples/s", "cores": threads, "kind": "port",
+           "sample": f"{len(times)} full train steps (fwd+bwd+dense TF1-Adam over {rows} embedding rows) of "
+                     f"[{workload.replace(f'batch {cpu_batch}/GPU', f'batch {cpu_batch}')}], median "
+                     f"{med * 1e3:.1f} ms/step (warm-up {warm:.1f} s), torch-CPU fp32 op-for-op restatement of the "
+                     f"reference graph (TF 1.14 not installable)"}
+    if also_threads and also_threads != threads:
+        # the same process, model and state at another intra-op thread count ("N = all host cores"): no second
+        # import / build / warm-up, a bounded number of steps (an oversubscribed pool can take seconds per step)
+        torch.set_num_threads(also_threads)
+        step(t); t += 1                                # (the pool's threads are spawned here, not inside the timed steps)
+        t2 = sample(max(3.0, seconds / 3), max_steps=20, min_steps=3)
+        m2 = float(np.median(t2))
+        out["other_sample"] = {"cores": also_threads, "value": round(cpu_batch / m2, 1), "unit": "examples/s",
+                               "note": f"{len(t2)} steps of the same process at {also_threads} intra-op threads, median {m2 * 1e3:.1f} ms/step"}
+    return out
 
 
 if __name__ == "__main__":
@@ -101,5 +117,6 @@ if __name__ == "__main__":
     ap.add_argument("--max-vocab", type=int, default=1_000_000)
     ap.add_argument("--seconds", type=float, default=15.0)
     ap.add_argument("--threads", type=int, default=None)
+    ap.add_argument("--also-threads", type=int, default=None)
     a = ap.parse_args()
-    print(json.dumps(run(a.model, a.batch, a.fields, a.emb, a.max_vocab, a.seconds, a.threads)), flush=True)
+    print(json.dumps(run(a.model, a.batch, a.fields, a.emb, a.max_vocab, a.seconds, a.threads, a.also_threads)), flush=True)

@@ -203,10 +203,15 @@ class _ReluPattern:
         return out
 
 
-@pytest.mark.parametrize("model", ["dcn", "xdeepfm", "din", "deepfm", "fibinet", "pnn"])
+@pytest.mark.parametrize("model", ["dcn", "xdeepfm", "din", "deepfm", "fibinet", "pnn",
+                                   # the reference's DEFAULT dropout_rate 0.1 (deepfm.py:39, din.py:41, fibinet.py:42, pnn.py:39)
+                                   "din+dropout", "deepfm+dropout", "fibinet+dropout", "pnn+dropout"])
 def test_model_step_at_baseline_config(dev, model):
+    model, _, drop = model.partition("+")
     est, feats, labels, workload = _bench_estimator(model, dev)
     params = est.params
+    if drop:
+        params["dropout_rate"] = 0.1
     if model == "din":       # alpha = 1 makes Dice the identity (activations.py:31): move it so the kernel is exercised
         g = torch.Generator().manual_seed(99)
         for name, v in est.store.vars.items():
@@ -222,7 +227,19 @@ def test_model_step_at_baseline_config(dev, model):
     # round 5's main loop contracts the reduction in another order and put ONE unit of DeepFM's first layer, 3e-7 * rms from
     # the kink, on the other side: one column of d(dense/kernel) off by 1e-2, everything behind xDeepFM's BatchNorm by
     # 200 x fp32 noise).  The flips themselves are asserted to be within rounding of the kink below.
+    from recalgorithm_amd import nn
+    nn.DROPOUT_SPECS[:] = []
     spec = pattern.record_hip(lambda: est._call_model_fn(feats, labels, ModeKeys.TRAIN))
+    extra = {}
+    if drop:
+        # the keep masks the library's hash stream stood for in this step (the step counter has not moved), for both oracles
+        dspecs = list(nn.DROPOUT_SPECS)
+        assert len(dspecs) == 3 and all(d.mask is None for d in dspecs)
+        masks = [ops.dropout_keep_mask((B, w), d, dev).cpu() for d, w in zip(dspecs, (512, 256, 128))]
+        assert all(0.88 < float(m.mean()) < 0.92 for m in masks)
+        extra = {"dropout_masks": masks}
+    fn_ = fn
+    fn = (lambda *a, **k: fn_(*a, **k, dropout_masks=[m.clone() for m in extra["dropout_masks"]])) if drop else fn_
     if model in ("fibinet", "pnn"):
         assert len(pattern.masks) == (4 if model == "pnn" else 3)
     ref = pattern.oracle(lambda: fn(P, cf, cl, params, training=True), check=True)

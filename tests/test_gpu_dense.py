@@ -80,7 +80,7 @@ def test_dense_two_operand_pairs_and_beta_c(dev):
     base = torch.randn(M, K, generator=gen)
     out = base.to(dev).clone()
     ops.dense_bwd_input(g.to(dev), None, w.to(dev), out=out, accumulate=True)
-    assert_close(out, base.double() + g.double() @ w.double().t(), what="dgrad accumulate", reduced=True)
+    assert_close(out, base.double() + g.double() @ w.double().t(), what="dgrad accumulate", reduced=True, ref32=base + g @ w.t())
 
 
 def test_dense_strided_views(dev):
@@ -92,7 +92,7 @@ def test_dense_strided_views(dev):
     w = (torch.randn(128, 64, generator=gen) / 11).to(dev)
     for v in (x, xu):
         y = ops.dense_fwd(v, w, None, False)
-        assert_close(y, v.cpu().double() @ w.cpu().double(), what="strided fwd", reduced=True)
+        assert_close(y, v.cpu().double() @ w.cpu().double(), what="strided fwd", reduced=True, ref32=v.cpu() @ w.cpu())
 
 
 def test_dense_matches_exact_fmaf_order(dev):
@@ -121,8 +121,9 @@ def test_dense_wgrad_split_handoff_stress(dev, M, K, N):
         ops.dense_bwd_weights(x, g, y, dw2, db2)
         g2 = (g * (y > 0)).double()
         ref = x.double().t() @ g2
-        assert_close(dw, ref, what=f"wgrad launch {it}", reduced=True)
-        assert_close(db, g2.sum(0), what=f"dbias launch {it}", reduced=True)
+        g2f = (g * (y > 0)).cpu()
+        assert_close(dw, ref, what=f"wgrad launch {it}", reduced=True, ref32=x.cpu().t() @ g2f)
+        assert_close(db, g2.sum(0), what=f"dbias launch {it}", reduced=True, ref32=g2f.sum(0))
         assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
@@ -250,9 +251,23 @@ def test_dense_activation_batchnorm_as_one_node(dev, M, K, N, kind):
     var = ((yt - mu) ** 2).mean(0)
     ot = (yt - mu) / torch.sqrt(var + 1e-3) * gamma.double().cpu() + beta.double().cpu()
     ot.backward(g.double().cpu())
-    assert_close(out, ot.detach(), what="fused layer output vs fp64", reduced=True)
-    assert_close(dz, zt.grad, what="fused layer d(z) vs fp64", reduced=True)
-    assert_close(dalpha, at.grad, what="fused layer d(alpha) vs fp64", reduced=True)
+
+    def chain32():
+        z3, a3 = zd.float().clone().requires_grad_(True), ad.float().clone().requires_grad_(True)
+        if kind == "dice":
+            p3 = torch.sigmoid(z3 / (1 + 1e-3) ** 0.5)
+            y3 = z3 * p3 + a3 * z3 * (1 - p3)
+        else:
+            y3 = z3.clamp(min=0) + a3 * z3.clamp(max=0)
+        m3 = y3.mean(0)
+        v3 = ((y3 - m3) ** 2).mean(0)
+        o3 = (y3 - m3) / torch.sqrt(v3 + 1e-3) * gamma.float().cpu() + beta.float().cpu()
+        o3.backward(g.float().cpu())
+        return o3.detach(), z3.grad, a3.grad
+    o32, dz32, da32 = chain32()
+    assert_close(out, ot.detach(), what="fused layer output vs fp64", reduced=True, ref32=o32)
+    assert_close(dz, zt.grad, what="fused layer d(z) vs fp64", reduced=True, ref32=dz32)
+    assert_close(dalpha, at.grad, what="fused layer d(alpha) vs fp64", reduced=True, ref32=da32)
 
 
 @pytest.mark.parametrize("M,K,N", [(4096, 512, 256), (4096, 256, 128), (300, 100, 52), (65, 8, 48)])
@@ -315,9 +330,10 @@ def test_dense_bwd_masks_its_input_gradient_with_the_relu_output_below(dev, M, K
     ops.flush_dense_splits()
     g2 = (g * (y > 0)).double()
     ref = (g2 @ w.double().t()) * (x > 0)
-    assert_close(dx, ref, what="dense dgrad, masked by the layer's input", reduced=True)
+    g2f = (g * (y > 0)).cpu()
+    assert_close(dx, ref, what="dense dgrad, masked by the layer's input", reduced=True, ref32=(g2f @ w.cpu().t()) * (x > 0).cpu())
     assert bool((dx[x <= 0] == 0).all())
-    assert_close(dw, x.double().t() @ g2, what="dense wgrad beside the masked dgrad", reduced=True)
+    assert_close(dw, x.double().t() @ g2, what="dense wgrad beside the masked dgrad", reduced=True, ref32=x.cpu().t() @ g2f)
     if with_bn:
         xh = (bx.double() - mean.double()) * rstd.double()
         s = part.double().view(-1, 2, K).sum(0)
