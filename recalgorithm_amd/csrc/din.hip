@@ -495,6 +495,647 @@ __global__ __launch_bounds__(256) void din_sum_partials_kernel(const float* __re
     if (slice == 0 && col < ncols) out[col] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
 }
 
+
+// =============================================================================================
+// H == 16 (the reference's fixed hidden size, din.py:103): the round-6 kernels.  Same math, same partial-row layout, but the
+// three-layer MLP is a chain of TRANSPOSED products so that the accumulator layout of one MFMA is the B-operand layout of the
+// next — activations never go through LDS between layers:
+//     H1^T [64 j x 32 t] = Wx^T X^T (+ cq)      A = weights (LDS, ds_read_b128), B = this lane's key row k_t / q*k_t (registers)
+//     H2^T [32 n x 32 t] = W2^T relu(H1^T)      B = the accumulator registers of the line above: reg r of lane (t, hi) holds row
+//                                               acc_row(r, hi), i.e. exactly the K pair (j, j + 4) of one 32x32x2 step
+//     dH1^T = W2 dH2^T,  dX^T = Wx dH1^T        the same chain backwards
+// Only the two weight-gradient products (dW2 += H1 dH2^T, dWx += X^T dH1: reduction over t) need t in the K position; H1 / dH2 /
+// dH1 / X go through one LDS transpose each ([row][t'] tiles, columns permuted t' = (t & 1) * 16 + (t >> 1) so that the K order
+// (t = 2u + hi) is contiguous per half wave: ds_read_b128 fragments, and the reduction stops at the tile's last valid row).
+// A 32-row tile at a time (T <= 32: one tile — half the matrix work of the 64-row formulation), d(cq) falls out of the dWx
+// operand reads as row sums, dk / dq / out need 8 values per lane (the rows of dX^T a half wave holds), the next example's rows
+// are requested before the current example's matrix work.  Round 5: one wave per SIMD with ~860 LDS instructions per example
+// outside the MFMA loops and 1.3 ds_read_b32 per MFMA inside them (106 us for B = 4096, T = 50; matrix pipe 39 % busy).
+// =============================================================================================
+namespace din16 {
+
+// scripts/din_lab.hip builds this file with -DDIN16_TIMELINE: shader-clock totals per phase of wave 0 of workgroup 0
+#ifdef DIN16_TIMELINE
+__device__ unsigned long long din16_tl[32];
+#define DIN16_TL_BEGIN() unsigned long long tl_prev_ = clock64()
+#define DIN16_TL(i)                                              \
+    do {                                                         \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        const unsigned long long t_ = clock64();                 \
+        if (blockIdx.x == 0 && threadIdx.x == 0) din16_tl[i] += t_ - tl_prev_; \
+        tl_prev_ = t_;                                           \
+        __builtin_amdgcn_sched_barrier(0);                       \
+    } while (0)
+#define DIN16_TL_ARG , unsigned long long& tl_prev_
+#define DIN16_TL_PASS , tl_prev_
+#else
+#define DIN16_TL_BEGIN()
+#define DIN16_TL(i)
+#define DIN16_TL_ARG
+#define DIN16_TL_PASS
+#endif
+
+constexpr int H = 16;
+constexpr int SA = 20;                           // row stride of 16-float fragments (ds_read_b128: 8 lanes x 4 banks distinct)
+constexpr int SB = 36;                           // row stride of 32-float tiles
+
+struct Weights {
+    float WxA[2][2][32][SA];     // [jt][hi][j][s]       = Wx[hi * 16 + s][jt * 32 + j]            layer 1, A operand
+    float W2A[2][32][SB];        // [hi][n][jt * 16 + r] = W2[jt * 32 + acc_row(r, hi)][n]         layer 2, A operand
+    float W2B[2][2][32][SA];     // [jt][hi][j][r]       = W2[jt * 32 + j][acc_row(r, hi)]         dH1, A operand
+    float WxB[2][32][SB];        // [hi][c][jt * 16 + r] = Wx[c][jt * 32 + acc_row(r, hi)]         dX, A operand
+    float Wq[H][N1];             // W1a + W1c
+    float WqF[2][2][32][8];      // [jt][hi][l32][m] = Wq[i(m, hi)][jt * 32 + l32], i(m, hi) = 8 * (m >> 2) + 4 * hi + (m & 3)   (d cq -> d q)
+    float b1[N1];
+    float b2[N2];
+    float W3[N2];
+    float b3[4];
+};
+struct Scratch {                 // one per wave
+    float P[64][SB];             // relu(H1) tile [j][t'], later dH1 [j][t']
+    float Q[32][SB];             // dH2 [n][t']
+    float R[32][SB];             // X^T [c][t']
+    float cq[N1];
+    float qg[2 * H];             // q | g_out row of the current example
+};
+
+__device__ __forceinline__ float wx_of(const float* __restrict__ f1w, unsigned c, unsigned j) {
+    return c < (unsigned)H ? f1w[(H + c) * N1 + j] - f1w[(2 * H + c) * N1 + j] : f1w[(3 * H + (c - H)) * N1 + j];
+}
+
+__device__ __forceinline__ void stage_weights(Weights& S, const float* __restrict__ f1w, const float* __restrict__ f1b,
+                                              const float* __restrict__ f2w, const float* __restrict__ f2b,
+                                              const float* __restrict__ f3w, const float* __restrict__ f3b) {
+    for (unsigned e = threadIdx.x; e < 2 * 2 * 32 * 16; e += kThreads) {
+        const unsigned s = e & 15, j = (e >> 4) & 31, hi = (e >> 9) & 1, jt = e >> 10;
+        S.WxA[jt][hi][j][s] = wx_of(f1w, hi * 16 + s, jt * 32 + j);
+        S.W2B[jt][hi][j][s] = f2w[(jt * 32 + j) * N2 + acc_row((int)s, hi)];
+    }
+    for (unsigned e = threadIdx.x; e < 2 * 32 * 32; e += kThreads) {
+        const unsigned x = e & 31, row = (e >> 5) & 31, hi = e >> 10;
+        const unsigned jt = x >> 4, r = x & 15;
+        S.W2A[hi][row][x] = f2w[(jt * 32 + acc_row((int)r, hi)) * N2 + row];
+        S.WxB[hi][row][x] = wx_of(f1w, row, jt * 32 + acc_row((int)r, hi));
+    }
+    for (unsigned e = threadIdx.x; e < H * N1; e += kThreads) {
+        const unsigned i = e / N1, j = e - i * N1;
+        S.Wq[i][j] = f1w[i * N1 + j] + f1w[(2 * H + i) * N1 + j];
+    }
+    for (unsigned e = threadIdx.x; e < 2 * 2 * 32 * 8; e += kThreads) {
+        const unsigned m = e & 7, l = (e >> 3) & 31, hi = (e >> 8) & 1, jt = e >> 9;
+        const unsigned i = 8 * (m >> 2) + 4 * hi + (m & 3), j = jt * 32 + l;
+        S.WqF[jt][hi][l][m] = f1w[i * N1 + j] + f1w[(2 * H + i) * N1 + j];
+    }
+    if (threadIdx.x < N1) S.b1[threadIdx.x] = f1b[threadIdx.x];
+    if (threadIdx.x < N2) {
+        S.b2[threadIdx.x] = f2b[threadIdx.x];
+        S.W3[threadIdx.x] = f3w[threadIdx.x];
+    }
+    if (threadIdx.x == 0) S.b3[0] = f3b[0];
+}
+
+__device__ __forceinline__ float4 lds4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float f4_at(const float4& v, int x) { return x == 0 ? v.x : (x == 1 ? v.y : (x == 2 ? v.z : v.w)); }
+// column of row t inside a transposed tile (see above)
+__device__ __forceinline__ unsigned tcol(unsigned l32) { return (l32 & 1) * 16 + (l32 >> 1); }
+
+struct Lane {                    // lane coordinates (per-lane weight constants are read from LDS where they are used: registers are
+    unsigned lane, hi, l32;      // the scarce resource of the backward kernel)
+};
+// W3 / b2 at the rows acc_row(r, hi) this lane's H2^T registers hold: four contiguous runs of four
+__device__ __forceinline__ void sel16(const float* __restrict__ v32, unsigned hi, float (&o)[16]) {
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 c = *reinterpret_cast<const float4*>(v32 + 8 * g4 + 4 * hi);
+        o[4 * g4] = c.x; o[4 * g4 + 1] = c.y; o[4 * g4 + 2] = c.z; o[4 * g4 + 3] = c.w;
+    }
+}
+// the 8 hidden indices a half wave's dX^T registers cover: m = 4 * bl + x  ->  i = 8 * bl + 4 * hi + x
+#define DIN16_SEL(arr, bl, x, hi) ((hi) ? (arr)[8 * (bl) + 4 + (x)] : (arr)[8 * (bl) + (x)])
+
+__device__ __forceinline__ void init_lane(Lane& L, const Weights& W) {
+    L.lane = threadIdx.x & 63; L.hi = L.lane >> 5; L.l32 = L.lane & 31;
+}
+
+// the lane's key row of tile `tile` (zero beyond T); both half waves hold the same rows
+__device__ __forceinline__ void load_row(const Lane& L, unsigned ex, unsigned tile, unsigned T, const float* __restrict__ keys,
+                                         float (&k)[H]) {
+    const unsigned t = tile * 32 + L.l32;
+    if (t < T) {
+        const float4* kr = reinterpret_cast<const float4*>(keys + ((size_t)ex * T + t) * H);
+#pragma unroll
+        for (int i = 0; i < H; i += 4) {
+            const float4 v = kr[i / 4];
+            k[i] = v.x; k[i + 1] = v.y; k[i + 2] = v.z; k[i + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < H; ++i) k[i] = 0.f;
+    }
+}
+// 16 wave-uniform floats out of the wave's scratch (broadcast ds_read_b128)
+__device__ __forceinline__ void lds_vec16(const float* p, float (&v)[H]) {
+#pragma unroll
+    for (int i = 0; i < H; i += 4) {
+        const float4 x = lds4(p + i);
+        v[i] = x.x; v[i + 1] = x.y; v[i + 2] = x.z; v[i + 3] = x.w;
+    }
+}
+
+// per example: q (and the upstream gradient g) into the wave's scratch — one coalesced load, read back as broadcasts where they
+// are used (32 registers fewer than holding them) — and cq[j] = b1[j] + sum_i q_i (W1a + W1c)[i][j] (lane = j)
+__device__ __forceinline__ void begin_example(const Lane& L, const Weights& W, Scratch& sc, const float* __restrict__ qrow,
+                                              const float* __restrict__ grow) {
+    if (L.lane < (unsigned)H) sc.qg[L.lane] = qrow[L.lane];
+    else if (L.lane < 2u * H && grow != nullptr) sc.qg[L.lane] = grow[L.lane - H];
+    __builtin_amdgcn_wave_barrier();
+    float c = W.b1[L.lane], q[H];
+    lds_vec16(sc.qg, q);
+#pragma unroll
+    for (int i = 0; i < H; ++i) c = fmaf(q[i], W.Wq[i][L.lane], c);
+    sc.cq[L.lane] = c;
+    __builtin_amdgcn_wave_barrier();
+}
+
+// forward of one 32-row tile: a1[jt] = H1^T (pre-ReLU), a2 = H2^T (pre-ReLU), returns the raw score of row t = tile * 32 + l32
+__device__ __forceinline__ float fwd_tile(const Lane& L, const Weights& W, const Scratch& sc, const float (&k)[H],
+                                          f32x16 (&a1)[2], f32x16& a2, float (&xb)[H]) {
+    {
+        float q[H];
+        lds_vec16(sc.qg, q);
+#pragma unroll
+        for (int s = 0; s < H; ++s) xb[s] = L.hi ? q[s] * k[s] : k[s];
+    }
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 c = lds4(&sc.cq[jt * 32 + 8 * g4 + 4 * L.hi]);
+            a1[jt][4 * g4] = c.x; a1[jt][4 * g4 + 1] = c.y; a1[jt][4 * g4 + 2] = c.z; a1[jt][4 * g4 + 3] = c.w;
+        }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const float4 w0 = lds4(&W.WxA[0][L.hi][L.l32][4 * v]), w1 = lds4(&W.WxA[1][L.hi][L.l32][4 * v]);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            a1[0] = mfma(f4_at(w0, x), xb[4 * v + x], a1[0]);
+            a1[1] = mfma(f4_at(w1, x), xb[4 * v + x], a1[1]);
+        }
+    }
+    f32x16 a2b;
+    {
+        float b2s[16];
+        sel16(W.b2, L.hi, b2s);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a2[r] = b2s[r]; a2b[r] = 0.f; }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const float4 w0 = lds4(&W.W2A[L.hi][L.l32][4 * v]), w1 = lds4(&W.W2A[L.hi][L.l32][16 + 4 * v]);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            a2 = mfma(f4_at(w0, x), fmaxf(a1[0][4 * v + x], 0.f), a2);
+            a2b = mfma(f4_at(w1, x), fmaxf(a1[1][4 * v + x], 0.f), a2b);
+        }
+    }
+    a2 += a2b;
+    float sp = 0.f, w3s[16];
+    sel16(W.W3, L.hi, w3s);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sp = fmaf(fmaxf(a2[r], 0.f), w3s[r], sp);
+    return W.b3[0] + (sp + __shfl_xor(sp, 32, 64));
+}
+
+// sum over the 32 lanes of a half wave (every lane of the half gets the total)
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+struct AttnW { float w[2], ds[2]; };
+// attention weights (and, for the backward, d loss / d score) of the lane's two rows from their raw scores
+template <bool BWD>
+__device__ __forceinline__ AttnW attention(const Lane& L, const float (&s)[2], unsigned T, int len, int is_softmax,
+                                           const float (&dwt)[2]) {
+    AttnW a;
+    bool in_T[2], in_len[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const unsigned t = tt * 32 + L.l32;
+        in_T[tt] = t < T;
+        in_len[tt] = in_T[tt] && (int)t < len;
+    }
+    if (is_softmax) {
+        const float rs = 1.0f / sqrtf((float)H);
+        float v[2], e[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) v[tt] = (in_len[tt] ? s[tt] : kPadScore) / sqrtf((float)H);      // mask, then scale (:32-34)
+        const float mx = wave_max(fmaxf(in_T[0] ? v[0] : -INFINITY, in_T[1] ? v[1] : -INFINITY));
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) e[tt] = in_T[tt] ? expf(v[tt] - mx) : 0.f;
+        const float den = wave_sum(L.hi == 0 ? e[0] + e[1] : 0.f);                                        // (both half waves hold every row)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) a.w[tt] = e[tt] / den;
+        if (BWD) {
+            const float dot = wave_sum(L.hi == 0 ? fmaf(a.w[0], dwt[0], a.w[1] * dwt[1]) : 0.f);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) a.ds[tt] = in_len[tt] ? a.w[tt] * (dwt[tt] - dot) * rs : 0.f;     // only masked-in scores get grad
+        }
+    } else {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            a.w[tt] = in_len[tt] ? s[tt] : 0.f;                                                            // s * mask (:37-38)
+            if (BWD) a.ds[tt] = in_len[tt] ? dwt[tt] : 0.f;
+        }
+    }
+    return a;
+}
+
+__global__ __launch_bounds__(kThreads) void fwd_kernel(
+    const float* __restrict__ query, const float* __restrict__ keys, const int32_t* __restrict__ keys_length,
+    const float* __restrict__ f1w, const float* __restrict__ f1b, const float* __restrict__ f2w,
+    const float* __restrict__ f2b, const float* __restrict__ f3w, const float* __restrict__ f3b, unsigned B,
+    unsigned T, int is_softmax, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Weights& W = *reinterpret_cast<Weights*>(smem_raw);
+    Scratch* scs = reinterpret_cast<Scratch*>(smem_raw + ((sizeof(Weights) + 15) & ~(size_t)15));
+    stage_weights(W, f1w, f1b, f2w, f2b, f3w, f3b);
+    __syncthreads();
+    Lane L;
+    init_lane(L, W);
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    Scratch& sc = scs[wave];
+    const unsigned ntile = T > 32 ? 2 : 1;
+    const unsigned stride = gridDim.x * kWaves;
+    unsigned ex = blockIdx.x * kWaves + wave;
+    float k[2][H];
+    if (ex < B) { load_row(L, ex, 0, T, keys, k[0]); load_row(L, ex, 1, T, keys, k[1]); }
+    for (; ex < B; ex += stride) {
+        float kn[2][H];                                 // the next example's rows, requested before this one's matrix work
+        const unsigned nx = ex + stride;
+        if (nx < B) { load_row(L, nx, 0, T, keys, kn[0]); load_row(L, nx, 1, T, keys, kn[1]); }
+        const int len = keys_length[ex];
+        begin_example(L, W, sc, query + (size_t)ex * H, nullptr);
+        float s[2] = {0.f, 0.f}, xb[H];
+        f32x16 a1[2], a2;
+        s[0] = fwd_tile(L, W, sc, k[0], a1, a2, xb);
+        if (ntile > 1) s[1] = fwd_tile(L, W, sc, k[1], a1, a2, xb);
+        const float dw0[2] = {0.f, 0.f};
+        const AttnW a = attention<false>(L, s, T, len, is_softmax, dw0);
+        float o[8];
+#pragma unroll
+        for (int bl = 0; bl < 2; ++bl)
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+                o[4 * bl + x] = half_sum(fmaf(a.w[0], DIN16_SEL(k[0], bl, x, L.hi), a.w[1] * DIN16_SEL(k[1], bl, x, L.hi)));
+        if (L.l32 == 0) {
+            float4* orow = reinterpret_cast<float4*>(out + (size_t)ex * H + 4 * L.hi);
+            orow[0] = make_float4(o[0], o[1], o[2], o[3]);
+            orow[2] = make_float4(o[4], o[5], o[6], o[7]);
+        }
+        __builtin_amdgcn_wave_barrier();               // (q / cq of the next example are written after this one's reads)
+        if (nx < B) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int i = 0; i < H; ++i) k[tt][i] = kn[tt][i];
+        }
+    }
+}
+
+struct BwdAcc {                  // weight-gradient accumulators of a wave (registers, across its examples)
+    f32x16 accX[2], acc2[2];     // dWx [32 c x 64 j], dW2 [64 j x 32 n]
+    float dWq[H];                // lane j: sum_b q_i d cq_j
+    float dW3[16], db2[16];      // partial over the lane's rows, at n = acc_row(r, hi)
+    float db1, db3;
+};
+
+// backward of one 32-row tile (forward state a1 / a2 / xb of THIS tile in registers)
+__device__ __forceinline__ void bwd_tile(const Lane& L, const Weights& W, Scratch& sc, BwdAcc& A, unsigned tile, unsigned T,
+                                         unsigned ex, const float (&k)[H], const f32x16 (&a1)[2], const f32x16& a2,
+                                         const float (&xb)[H], float w, float ds, float (&dqacc)[8], float* __restrict__ dkeys DIN16_TL_ARG) {
+    const unsigned col = tcol(L.l32);
+    const unsigned valid = T - tile * 32 < 32 ? T - tile * 32 : 32;     // rows of this tile inside T
+    const unsigned u_end = (valid + 1) / 2;                             // K steps (t = 2u + hi) that can carry non-zero rows
+    // ---- layer 3 / 2 gradients in registers: dW3, dH2^T, db2 ----
+    f32x16 d2;
+    {
+        float w3s[16];
+        sel16(W.W3, L.hi, w3s);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float h = a2[r];
+            A.dW3[r] = fmaf(ds, fmaxf(h, 0.f), A.dW3[r]);
+            d2[r] = h > 0.f ? ds * w3s[r] : 0.f;
+            A.db2[r] += d2[r];
+        }
+    }
+    if (L.hi == 0) A.db3 += ds;
+    // ---- transposes for dW2: relu(H1) -> P[j][t'], dH2 -> Q[n][t'] ----
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc.P[jt * 32 + acc_row(r, L.hi)][col] = fmaxf(a1[jt][r], 0.f);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc.Q[acc_row(r, L.hi)][col] = d2[r];
+    DIN16_TL(3);
+    // ---- dH1^T = W2 dH2^T (chained: B = d2 registers) ----
+    f32x16 d1[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d1[jt][r] = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const float4 w0 = lds4(&W.W2B[0][L.hi][L.l32][4 * v]), w1 = lds4(&W.W2B[1][L.hi][L.l32][4 * v]);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            d1[0] = mfma(f4_at(w0, x), d2[4 * v + x], d1[0]);
+            d1[1] = mfma(f4_at(w1, x), d2[4 * v + x], d1[1]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    DIN16_TL(4);
+    // ---- dW2 += H1 dH2^T over the tile's rows: A[j][t] from P, B[t][n] from Q ----
+    for (unsigned v = 0; 4 * v < u_end; ++v) {
+        const float4 b = lds4(&sc.Q[L.l32][L.hi * 16 + 4 * v]);
+        const float4 p0 = lds4(&sc.P[L.l32][L.hi * 16 + 4 * v]), p1 = lds4(&sc.P[32 + L.l32][L.hi * 16 + 4 * v]);
+        // (K steps past the last valid row multiply zeros: whole groups of four are skipped, the rest is not worth a branch)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            A.acc2[0] = mfma(f4_at(p0, x), f4_at(b, x), A.acc2[0]);
+            A.acc2[1] = mfma(f4_at(p1, x), f4_at(b, x), A.acc2[1]);
+        }
+    }
+    DIN16_TL(5);
+    // ---- ReLU mask of layer 1, then dH1 -> P[j][t'] and X^T -> R[c][t'] ----
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d1[jt][r] = a1[jt][r] > 0.f ? d1[jt][r] : 0.f;
+    __builtin_amdgcn_wave_barrier();                   // (the dW2 reads of P are issued before these writes)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc.P[jt * 32 + acc_row(r, L.hi)][col] = d1[jt][r];
+#pragma unroll
+    for (int s = 0; s < H; ++s) sc.R[L.hi * 16 + s][col] = xb[s];
+    DIN16_TL(6);
+    // ---- dX^T = Wx dH1^T (chained: B = d1 registers), two chains ----
+    f32x16 dx, dxb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dx[r] = dxb[r] = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const float4 w0 = lds4(&W.WxB[L.hi][L.l32][4 * v]), w1 = lds4(&W.WxB[L.hi][L.l32][16 + 4 * v]);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            dx = mfma(f4_at(w0, x), d1[0][4 * v + x], dx);
+            dxb = mfma(f4_at(w1, x), d1[1][4 * v + x], dxb);
+        }
+    }
+    dx += dxb;
+    __builtin_amdgcn_wave_barrier();
+    DIN16_TL(7);
+    // ---- dWx += X^T dH1 over the tile's rows: A[c][t] from R, B[t][j] from P; the row sums of dH1 are d(cq) ----
+    float rs0 = 0.f, rs1 = 0.f;
+    for (unsigned v = 0; 4 * v < u_end; ++v) {
+        const float4 a = lds4(&sc.R[L.l32][L.hi * 16 + 4 * v]);
+        const float4 p0 = lds4(&sc.P[L.l32][L.hi * 16 + 4 * v]), p1 = lds4(&sc.P[32 + L.l32][L.hi * 16 + 4 * v]);
+        rs0 += (p0.x + p0.y) + (p0.z + p0.w);
+        rs1 += (p1.x + p1.y) + (p1.z + p1.w);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            A.accX[0] = mfma(f4_at(a, x), f4_at(p0, x), A.accX[0]);
+            A.accX[1] = mfma(f4_at(a, x), f4_at(p1, x), A.accX[1]);
+        }
+    }
+    DIN16_TL(8);
+    const float dcq0 = rs0 + __shfl_xor(rs0, 32, 64), dcq1 = rs1 + __shfl_xor(rs1, 32, 64);   // column j = l32 / 32 + l32
+    const float dcq_own = L.hi ? dcq1 : dcq0;                                                    // column j = lane
+    A.db1 += dcq_own;
+    float q[H], g[H];
+    lds_vec16(sc.qg, q);
+    lds_vec16(sc.qg + H, g);
+#pragma unroll
+    for (int i = 0; i < H; ++i) A.dWq[i] = fmaf(q[i], dcq_own, A.dWq[i]);
+    // ---- dk (this lane's 8 columns of its row), dq partials ----
+    const unsigned t = tile * 32 + L.l32;
+    float wqf[2][8];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int bl = 0; bl < 2; ++bl) {
+            const float4 c = lds4(&W.WqF[jt][L.hi][L.l32][4 * bl]);
+            wqf[jt][4 * bl] = c.x; wqf[jt][4 * bl + 1] = c.y; wqf[jt][4 * bl + 2] = c.z; wqf[jt][4 * bl + 3] = c.w;
+        }
+#pragma unroll
+    for (int bl = 0; bl < 2; ++bl) {
+        float dk[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const float dxk = dx[4 * bl + x], dxd = dx[8 + 4 * bl + x];
+            const float qi = DIN16_SEL(q, bl, x, L.hi), ki = DIN16_SEL(k, bl, x, L.hi), gi = DIN16_SEL(g, bl, x, L.hi);
+            dk[x] = fmaf(w, gi, fmaf(dxd, qi, dxk));
+            float acc = fmaf(dxd, ki, dqacc[4 * bl + x]);
+            acc = fmaf(dcq0, wqf[0][4 * bl + x], acc);                // this lane's columns j = l32, 32 + l32 of d(cq) Wq^T
+            dqacc[4 * bl + x] = fmaf(dcq1, wqf[1][4 * bl + x], acc);
+        }
+        if (t < T)
+            *reinterpret_cast<float4*>(dkeys + ((size_t)ex * T + t) * H + 8 * bl + 4 * L.hi) = make_float4(dk[0], dk[1], dk[2], dk[3]);
+    }
+    __builtin_amdgcn_wave_barrier();                   // (P / Q / R are rewritten by the next tile)
+    DIN16_TL(9);
+}
+
+template <bool SOFTMAX>
+__global__ __launch_bounds__(kThreads) void bwd_kernel(
+    const float* __restrict__ query, const float* __restrict__ keys, const int32_t* __restrict__ keys_length,
+    const float* __restrict__ f1w, const float* __restrict__ f1b, const float* __restrict__ f2w,
+    const float* __restrict__ f2b, const float* __restrict__ f3w, const float* __restrict__ f3b,
+    const float* __restrict__ g_out, unsigned ldg, const float* __restrict__ dq_extra, unsigned ld_extra, unsigned B,
+    unsigned T, float* __restrict__ dquery, float* __restrict__ dkeys, float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Weights& W = *reinterpret_cast<Weights*>(smem_raw);
+    Scratch* scs = reinterpret_cast<Scratch*>(smem_raw + ((sizeof(Weights) + 15) & ~(size_t)15));
+    stage_weights(W, f1w, f1b, f2w, f2b, f3w, f3b);
+    __syncthreads();
+    Lane L;
+    init_lane(L, W);
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    Scratch& sc = scs[wave];
+    const unsigned ntile = T > 32 ? 2 : 1;
+    const unsigned stride = gridDim.x * kWaves;
+    BwdAcc A;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) A.accX[t][r] = A.acc2[t][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < H; ++i) A.dWq[i] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) A.dW3[r] = A.db2[r] = 0.f;
+    A.db1 = A.db3 = 0.f;
+
+    // the wave walks (example, tile) pairs; the key row of the NEXT pair is requested before the current pair's matrix work
+    unsigned ex = blockIdx.x * kWaves + wave;
+    float kc[H];
+    if (ex < B) load_row(L, ex, 0, T, keys, kc);
+    DIN16_TL_BEGIN();
+    DIN16_TL(12);
+    for (; ex < B; ex += stride) {
+        begin_example(L, W, sc, query + (size_t)ex * H, g_out + (size_t)ex * ldg);
+        DIN16_TL(0);
+        // (the query's other gradient, added at the very end: requested here, not in front of the store)
+        float dq_add[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) dq_add[m] = 0.f;
+        if (dq_extra && L.l32 == 0) {
+#pragma unroll
+            for (int bl = 0; bl < 2; ++bl)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) dq_add[4 * bl + x] = dq_extra[(size_t)ex * ld_extra + 8 * bl + 4 * L.hi + x];
+        }
+        const int len = keys_length[ex];
+        float dqacc[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) dqacc[m] = 0.f;
+        AttnW aw;
+        if (SOFTMAX) {
+            // the weights of all rows come first (a softmax over t): the scores of both tiles, then each tile's forward again
+            float s[2] = {0.f, 0.f}, dwt[2] = {0.f, 0.f}, g[H];
+            lds_vec16(sc.qg + H, g);
+            for (unsigned tile = 0; tile < ntile; ++tile) {
+                float kt[H], xb[H];
+                f32x16 a1[2], a2;
+                if (tile == 0) {
+#pragma unroll
+                    for (int i = 0; i < H; ++i) kt[i] = kc[i];
+                } else {
+                    load_row(L, ex, tile, T, keys, kt);
+                }
+                const float sv = fwd_tile(L, W, sc, kt, a1, a2, xb);
+                float d = 0.f;
+#pragma unroll
+                for (int i = 0; i < H; ++i) d = fmaf(g[i], kt[i], d);
+                if (tile == 0) { s[0] = sv; dwt[0] = d; } else { s[1] = sv; dwt[1] = d; }
+            }
+            aw = attention<true>(L, s, T, len, 1, dwt);
+        }
+        for (unsigned tile = 0; tile < ntile; ++tile) {
+            float kn[H];
+            const bool last = tile + 1 == ntile;
+            const unsigned nex = last ? ex + stride : ex, ntl = last ? 0 : tile + 1;
+            if (nex < B) load_row(L, nex, ntl, T, keys, kn);
+            f32x16 a1[2], a2;
+            float xb[H];
+            DIN16_TL(1);
+            const float sv = fwd_tile(L, W, sc, kc, a1, a2, xb);
+            DIN16_TL(2);
+            float w, ds;
+            if (SOFTMAX) {
+                w = tile ? aw.w[1] : aw.w[0];
+                ds = tile ? aw.ds[1] : aw.ds[0];
+            } else {
+                // default branch: w_t = s_t * mask, d s_t = mask * <g, k_t> (d out / d w_t)
+                const unsigned t = tile * 32 + L.l32;
+                const bool in_len = t < T && (int)t < len;
+                float g[H], d = 0.f;
+                lds_vec16(sc.qg + H, g);
+#pragma unroll
+                for (int i = 0; i < H; ++i) d = fmaf(g[i], kc[i], d);
+                w = in_len ? sv : 0.f;
+                ds = in_len ? d : 0.f;
+            }
+            bwd_tile(L, W, sc, A, tile, T, ex, kc, a1, a2, xb, w, ds, dqacc, dkeys DIN16_TL_PASS);
+            if (nex < B) {
+#pragma unroll
+                for (int i = 0; i < H; ++i) kc[i] = kn[i];
+            }
+        }
+        // ---- dq: the half wave's 8 columns, summed over its 32 lanes (rows t and columns j = l32, 32 + l32 of the fold) ----
+#pragma unroll
+        for (int m = 0; m < 8; ++m) dqacc[m] = half_sum(dqacc[m]);
+        if (L.l32 == 0) {
+            float4* dqr = reinterpret_cast<float4*>(dquery + (size_t)ex * H + 4 * L.hi);
+            dqr[0] = make_float4(dqacc[0] + dq_add[0], dqacc[1] + dq_add[1], dqacc[2] + dq_add[2], dqacc[3] + dq_add[3]);
+            dqr[2] = make_float4(dqacc[4] + dq_add[4], dqacc[5] + dq_add[5], dqacc[6] + dq_add[6], dqacc[7] + dq_add[7]);
+        }
+        DIN16_TL(10);
+    }
+
+    // ---- the lane-partial vectors: sums over the half wave's lanes (rows) ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { A.dW3[r] = half_sum(A.dW3[r]); A.db2[r] = half_sum(A.db2[r]); }
+    A.db3 = wave_sum(A.db3);
+    // ---- workgroup reduction of the weight-gradient partials: every wave stores its accumulators into its OWN region of
+    // the (now free) dynamic LDS — plain stores, all four waves at once — and the 256 threads then add the four copies in
+    // wave order while they write the partial row, laid out as the caller's six buffers.  (The round-2 form, one wave after
+    // the other read-modify-writing one shared row, was a chain of ~150 dependent LDS round trips per wave: 20 % of the
+    // kernel, profiles/r06_din_lab.md.)
+    constexpr int PF = din_partial_floats<H>();
+    constexpr unsigned kRegion = 3 * H * N1 + N1 + N1 * N2 + N2 + N2 + 4;     // dWk | dWqk | dWq | db1 | dW2 | db2 | dW3 | db3
+    constexpr unsigned r_wk = 0, r_wqk = H * N1, r_wq = 2 * H * N1, r_b1 = 3 * H * N1, r_w2 = r_b1 + N1, r_b2 = r_w2 + N1 * N2,
+                       r_w3 = r_b2 + N2, r_b3 = r_w3 + N2;
+    static_assert(kWaves * kRegion * sizeof(float) <= sizeof(Weights) + kWaves * sizeof(Scratch), "the four regions must fit the dynamic LDS");
+    __syncthreads();                                   // (weights and scratch are dead from here on)
+    float* regions = reinterpret_cast<float*>(smem_raw);
+    {
+        float* reg = regions + wave * kRegion;
+        const unsigned hi = L.hi, l32 = L.l32, lane = L.lane;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // rows c = acc_row(r, hi) of dWx: r < 8 -> the k part (c < 16), else the q*k part (c - 16)
+                const unsigned c = acc_row(r, hi), j = jt * 32 + l32;
+                if (r < 8) reg[r_wk + c * N1 + j] = A.accX[jt][r];
+                else reg[r_wqk + (c - H) * N1 + j] = A.accX[jt][r];
+            }
+#pragma unroll
+        for (int i = 0; i < H; ++i) reg[r_wq + i * N1 + lane] = A.dWq[i];
+        reg[r_b1 + lane] = A.db1;
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) reg[r_w2 + (it * 32 + acc_row(r, hi)) * N2 + l32] = A.acc2[it][r];
+        if (l32 == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                reg[r_b2 + acc_row(r, hi)] = A.db2[r];
+                reg[r_w3 + acc_row(r, hi)] = A.dW3[r];
+            }
+        }
+        if (lane == 0) reg[r_b3] = A.db3;
+    }
+    __syncthreads();
+    float* prow = partials + (size_t)blockIdx.x * PF;
+    for (unsigned e = threadIdx.x; e < (unsigned)PF; e += kThreads) {
+        // final dW1 = [dWq ; dWk ; dWq - dWk ; dWqk]   (blocks a, b, c, d of f1's kernel), then db1 | dW2 | db2 | dW3 | db3
+        unsigned src, src2 = ~0u;
+        if (e < 4u * H * N1) {
+            const unsigned blk = e / (H * N1), rem = e - blk * (H * N1);
+            src = (blk == 0 ? r_wq : (blk == 1 ? r_wk : (blk == 2 ? r_wq : r_wqk))) + rem;
+            if (blk == 2) src2 = r_wk + rem;
+        } else {
+            src = r_b1 + (e - 4u * H * N1);            // db1 | dW2 | db2 | dW3 | db3 are contiguous in both layouts
+        }
+        float v = 0.f;
+#pragma unroll
+        for (unsigned wv = 0; wv < kWaves; ++wv) {
+            const float* reg = regions + wv * kRegion;
+            v += src2 == ~0u ? reg[src] : reg[src] - reg[src2];
+        }
+        prow[e] = v;
+    }
+    DIN16_TL(11);
+}
+
+inline size_t smem_bytes() { return ((sizeof(Weights) + 15) & ~(size_t)15) + (size_t)kWaves * sizeof(Scratch); }
+
+}  // namespace din16
+
 inline int din_grid(int B) {
     int need = cdiv(B, kWaves);
     return need < 1 ? 1 : (need > 256 ? 256 : need);
@@ -512,6 +1153,15 @@ RECALGO_EXPORT int recalgo_din_attention_fwd(const float* query, const float* ke
     RECALGO_REQUIRE(B >= 0 && T >= 1 && T <= 64 && (H == 4 || H == 8 || H == 16));
     if (B == 0) return 0;
     hipStream_t st = as_stream(stream);
+    if (H == 16 && (reinterpret_cast<uintptr_t>(query) & 15) == 0 && (reinterpret_cast<uintptr_t>(keys) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        const size_t smem = din16::smem_bytes();
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&din16::fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(din16::fwd_kernel, dim3(din_grid(B)), dim3(kThreads), smem, st, query, keys, keys_length, f1_w, f1_b, f2_w, f2_b,
+                           f3_w, f3_b, (unsigned)B, (unsigned)T, is_softmax, out);
+        RECALGO_RETURN_LAST();
+    }
 #define LAUNCH(HH)                                                                                          \
     do {                                                                                                    \
         size_t smem = din_smem<HH>();                                                                       \
@@ -576,7 +1226,17 @@ RECALGO_EXPORT int recalgo_din_attention_bwd_joined(const float* query, const fl
                            keys_length, f1_w, f1_b, f2_w, f2_b, f3_w, f3_b, g_out, (unsigned)ldg, dq_extra,       \
                            (unsigned)ld_extra, (unsigned)B, (unsigned)T, is_softmax, dquery, dkeys, partials);    \
     } while (0)
-    if (H == 4) LAUNCH(4); else if (H == 8) LAUNCH(8); else LAUNCH(16);
+    const bool v16 = H == 16 && (reinterpret_cast<uintptr_t>(query) & 15) == 0 && (reinterpret_cast<uintptr_t>(keys) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(dquery) & 15) == 0 && (reinterpret_cast<uintptr_t>(dkeys) & 15) == 0;
+    if (v16) {
+        pf = din_partial_floats<16>();
+        const size_t smem = din16::smem_bytes();
+        auto kern = is_softmax ? &din16::bwd_kernel<true> : &din16::bwd_kernel<false>;
+        hipError_t e16 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e16 != hipSuccess) return (int)e16;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), smem, st, query, keys, keys_length, f1_w, f1_b, f2_w, f2_b, f3_w,
+                           f3_b, g_out, (unsigned)ldg, dq_extra, (unsigned)ld_extra, (unsigned)B, (unsigned)T, dquery, dkeys, partials);
+    } else if (H == 4) LAUNCH(4); else if (H == 8) LAUNCH(8); else LAUNCH(16);
 #undef LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
