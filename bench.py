@@ -438,11 +438,11 @@ def kernel_rooflines(args, est, feats, device):
         byt = B * ((T + 1) * H * 4 + 4 + H * 4)
         add("din_attention_fwd", lambda: lib.recalgo_din_attention_fwd(p(q), p(keys), p(kl), p(f1w), p(f1b), p(f2w), p(f2b), p(f3w),
                                                                       p(f3b), B, T, H, 0, p(o), st), byt, fl)
-        res[-1]["prof"] = ["din_attention_fwd", 0]
+        res[-1]["prof"] = ["din16::fwd_kernel", 0]
         add("din_attention_bwd", lambda: lib.recalgo_din_attention_bwd(p(q), p(keys), p(kl), p(f1w), p(f1b), p(f2w), p(f2b), p(f3w),
                                                                       p(f3b), p(go), B, T, H, 0, p(dq), p(dk), *[p(t) for t in dws],
                                                                       p(ws), st), 2 * byt + B * T * H * 4, 2.0 * fl)       # bwd = 2x fwd (the kernel's recompute of the forward is not useful work)
-        res[-1]["prof"] = ["din_attention_bwd", 0]
+        res[-1]["prof"] = ["din16::bwd_kernel", 0]
         vals = torch.randint(0, 1000, (B * T,), device=device)
         offs = torch.arange(0, B * T + 1, T, device=device, dtype=torch.int64)
         so, sl = torch.empty(B, T, H, device=device), torch.empty(B, dtype=torch.int32, device=device)

@@ -551,12 +551,14 @@ struct Weights {
     float W3[N2];
     float b3[4];
 };
-struct Scratch {                 // one per wave
+struct FwdScratch {              // one per wave
+    float cq[N1];
+    float qg[2 * H];             // q | g_out row of the current example
+};
+struct Scratch : FwdScratch {    // one per wave (backward)
     float P[64][SB];             // relu(H1) tile [j][t'], later dH1 [j][t']
     float Q[32][SB];             // dH2 [n][t']
     float R[32][SB];             // X^T [c][t']
-    float cq[N1];
-    float qg[2 * H];             // q | g_out row of the current example
 };
 
 __device__ __forceinline__ float wx_of(const float* __restrict__ f1w, unsigned c, unsigned j) {
@@ -644,7 +646,7 @@ __device__ __forceinline__ void lds_vec16(const float* p, float (&v)[H]) {
 
 // per example: q (and the upstream gradient g) into the wave's scratch — one coalesced load, read back as broadcasts where they
 // are used (32 registers fewer than holding them) — and cq[j] = b1[j] + sum_i q_i (W1a + W1c)[i][j] (lane = j)
-__device__ __forceinline__ void begin_example(const Lane& L, const Weights& W, Scratch& sc, const float* __restrict__ qrow,
+__device__ __forceinline__ void begin_example(const Lane& L, const Weights& W, FwdScratch& sc, const float* __restrict__ qrow,
                                               const float* __restrict__ grow) {
     if (L.lane < (unsigned)H) sc.qg[L.lane] = qrow[L.lane];
     else if (L.lane < 2u * H && grow != nullptr) sc.qg[L.lane] = grow[L.lane - H];
@@ -658,7 +660,7 @@ __device__ __forceinline__ void begin_example(const Lane& L, const Weights& W, S
 }
 
 // forward of one 32-row tile: a1[jt] = H1^T (pre-ReLU), a2 = H2^T (pre-ReLU), returns the raw score of row t = tile * 32 + l32
-__device__ __forceinline__ float fwd_tile(const Lane& L, const Weights& W, const Scratch& sc, const float (&k)[H],
+__device__ __forceinline__ float fwd_tile(const Lane& L, const Weights& W, const FwdScratch& sc, const float (&k)[H],
                                           f32x16 (&a1)[2], f32x16& a2, float (&xb)[H]) {
     {
         float q[H];
@@ -752,29 +754,30 @@ __device__ __forceinline__ AttnW attention(const Lane& L, const float (&s)[2], u
     return a;
 }
 
-__global__ __launch_bounds__(kThreads) void fwd_kernel(
+// (the forward needs cq / qg of the scratch only: two workgroups per CU, i.e. two waves per SIMD — one wave's layer-3 / attention
+// / reduction phases run under the other's MFMAs — if the kernel stays within 256 registers)
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void fwd_kernel(
     const float* __restrict__ query, const float* __restrict__ keys, const int32_t* __restrict__ keys_length,
     const float* __restrict__ f1w, const float* __restrict__ f1b, const float* __restrict__ f2w,
     const float* __restrict__ f2b, const float* __restrict__ f3w, const float* __restrict__ f3b, unsigned B,
     unsigned T, int is_softmax, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Weights& W = *reinterpret_cast<Weights*>(smem_raw);
-    Scratch* scs = reinterpret_cast<Scratch*>(smem_raw + ((sizeof(Weights) + 15) & ~(size_t)15));
+    FwdScratch* scs = reinterpret_cast<FwdScratch*>(smem_raw + ((sizeof(Weights) + 15) & ~(size_t)15));
     stage_weights(W, f1w, f1b, f2w, f2b, f3w, f3b);
     __syncthreads();
     Lane L;
     init_lane(L, W);
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    Scratch& sc = scs[wave];
+    FwdScratch& sc = scs[wave];
     const unsigned ntile = T > 32 ? 2 : 1;
     const unsigned stride = gridDim.x * kWaves;
-    unsigned ex = blockIdx.x * kWaves + wave;
-    float k[2][H];
-    if (ex < B) { load_row(L, ex, 0, T, keys, k[0]); load_row(L, ex, 1, T, keys, k[1]); }
-    for (; ex < B; ex += stride) {
-        float kn[2][H];                                 // the next example's rows, requested before this one's matrix work
-        const unsigned nx = ex + stride;
-        if (nx < B) { load_row(L, nx, 0, T, keys, kn[0]); load_row(L, nx, 1, T, keys, kn[1]); }
+    // (no software prefetch of the next example's rows here: the co-resident wave of the SIMD covers the load latency, and the
+    // 32 registers it would take are what keeps the kernel at two waves per SIMD)
+    for (unsigned ex = blockIdx.x * kWaves + wave; ex < B; ex += stride) {
+        float k[2][H];
+        load_row(L, ex, 0, T, keys, k[0]);
+        load_row(L, ex, 1, T, keys, k[1]);
         const int len = keys_length[ex];
         begin_example(L, W, sc, query + (size_t)ex * H, nullptr);
         float s[2] = {0.f, 0.f}, xb[H];
@@ -795,12 +798,6 @@ __global__ __launch_bounds__(kThreads) void fwd_kernel(
             orow[2] = make_float4(o[4], o[5], o[6], o[7]);
         }
         __builtin_amdgcn_wave_barrier();               // (q / cq of the next example are written after this one's reads)
-        if (nx < B) {
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                for (int i = 0; i < H; ++i) k[tt][i] = kn[tt][i];
-        }
     }
 }
 
@@ -1133,6 +1130,11 @@ __global__ __launch_bounds__(kThreads) void bwd_kernel(
 }
 
 inline size_t smem_bytes() { return ((sizeof(Weights) + 15) & ~(size_t)15) + (size_t)kWaves * sizeof(Scratch); }
+inline size_t fwd_smem_bytes() { return ((sizeof(Weights) + 15) & ~(size_t)15) + (size_t)kWaves * sizeof(FwdScratch); }
+inline int fwd_grid(int B) {      // two workgroups per CU
+    const int need = cdiv(B, kWaves);
+    return need < 1 ? 1 : (need > 512 ? 512 : need);
+}
 
 }  // namespace din16
 
@@ -1155,10 +1157,10 @@ RECALGO_EXPORT int recalgo_din_attention_fwd(const float* query, const float* ke
     hipStream_t st = as_stream(stream);
     if (H == 16 && (reinterpret_cast<uintptr_t>(query) & 15) == 0 && (reinterpret_cast<uintptr_t>(keys) & 15) == 0 &&
         (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
-        const size_t smem = din16::smem_bytes();
+        const size_t smem = din16::fwd_smem_bytes();
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&din16::fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(din16::fwd_kernel, dim3(din_grid(B)), dim3(kThreads), smem, st, query, keys, keys_length, f1_w, f1_b, f2_w, f2_b,
+        hipLaunchKernelGGL(din16::fwd_kernel, dim3(din16::fwd_grid(B)), dim3(kThreads), smem, st, query, keys, keys_length, f1_w, f1_b, f2_w, f2_b,
                            f3_w, f3_b, (unsigned)B, (unsigned)T, is_softmax, out);
         RECALGO_RETURN_LAST();
     }
