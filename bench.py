@@ -853,26 +853,38 @@ def cpu_baseline(args, seconds):
         cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--model", args.model, "--batch", str(args.batch),
                "--fields", str(args.fields), "--emb", str(args.emb), "--max-vocab", str(args.max_vocab),
                "--seconds", str(secs)] + (["--also-threads", str(also_threads)] if also_threads else [])
+        limit = limit or max(150.0, 10 * secs)
+        note, text = None, ""
         try:
-            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=limit or max(120.0, 8 * secs))
-            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            if r.returncode == 0 and line:
-                return json.loads(line[-1])
-            note = f"child failed rc={r.returncode}: {r.stderr.strip()[-300:]}"
-        except subprocess.TimeoutExpired:
-            note = f"child exceeded {limit or max(120.0, 8 * secs):.0f} s"
-        return {"value": None, "unit": "examples/s", "cores": 0, "kind": "port", "sample": note}
-    # two samples from ONE child (one import / build / warm-up): <= 32 threads (where the per-op work of one 4096-example batch
-    # stops scaling: the better number on every box measured so far) and ALL host cores (SURVEY.md 8d's definition);
-    # `value` / `cores` are those of the faster one, the other is `other_sample`
+            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=limit)
+            text = r.stdout or ""
+            if r.returncode != 0:
+                note = f"child failed rc={r.returncode}: {r.stderr.strip()[-300:]}"
+        except subprocess.TimeoutExpired as e:
+            text = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+            note = f"child cut off after {limit:.0f} s (the samples it had finished by then are reported)"
+        line = [l for l in text.splitlines() if l.startswith("{")]
+        if line:
+            d = json.loads(line[-1])          # the child prints its result after every completed sample
+            if note:
+                d["note"] = note
+            return d
+        return {"value": None, "unit": "examples/s", "cores": 0, "kind": "port", "sample": note or "child printed nothing"}
+    # ONE child (one import / build / warm-up): <= 32 threads (where the per-op work of one 4096-example batch stops scaling: the
+    # better number on every box measured so far), then half of the host's hardware threads and ALL of them (SURVEY.md 8d's
+    # definition); `value` / `cores` are those of the fastest sample, the others are `other_samples`
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     a = child(avail if avail > 32 else None, seconds)
-    b = a.get("other_sample")
-    if b and (b.get("value") or 0) > (a.get("value") or 0):
+    others = a.get("other_samples") or []
+    best = max(others, key=lambda o: o.get("value") or 0, default=None)
+    if best and (best.get("value") or 0) > (a.get("value") or 0):
         a = dict(a)
-        a["other_sample"] = {"cores": a["cores"], "value": a["value"], "unit": "examples/s", "note": "the <= 32-thread sample: " + a["sample"][:120]}
-        a["value"], a["cores"] = b["value"], b["cores"]
-        a["sample"] = b["note"] + "; " + a["sample"]
+        rest = [o for o in others if o is not best] + [{"cores": a["cores"], "value": a["value"], "unit": "examples/s",
+                                                        "note": "the <= 32-thread sample: " + a["sample"][:120]}]
+        a["value"], a["cores"], a["sample"] = best["value"], best["cores"], best["note"] + "; " + a["sample"]
+        a["other_samples"] = rest
+    if a.get("other_samples"):
+        a["other_sample"] = a["other_samples"][-1]            # (the all-cores sample, under the key earlier rounds used)
     return a
 
 
@@ -972,7 +984,7 @@ def timed_run(args, device, rank, world, dist, capacity_factor):
         # are a property of the configuration, not of the batch)
         one = torch.ones(1, device=device)
         dist.all_reduce(one)
-        rows_b = ids_b = 0
+        rows_b = ids_b = link_ids = link_rows = 0
         for ar in est.store.arenas.values():
             sd = getattr(ar, "sharding", None)
             if sd is None or sd.capacity_factor is None:
@@ -981,11 +993,19 @@ def timed_run(args, device, rank, world, dist, capacity_factor):
             cap = int(-(-n_req * sd.capacity_factor // world))
             ids_b += world * cap * 8                                   # local row numbers to the owners
             rows_b += 2 * world * cap * ar.K * 4                       # rows back, gradient rows forth
+            link_ids += cap * 8                                        # ... of which ONE peer's bucket crosses ONE xGMI link
+            link_rows += 2 * cap * ar.K * 4
         dense_b = 0 if est.store.flat_grad is None else est.store.flat_grad.numel() * 4
         comm = {"backend": "gloo (host-staged bring-up)" if os.environ.get("RECALGO_DIST_BACKEND") == "gloo_staged" else dist.get_backend(),
                 "ranks_in_all_reduce": int(float(one)), "world_size": dist.get_world_size(),
                 "per_rank_bytes_per_step": {"all_to_all_ids": int(ids_b), "all_to_all_rows_and_grads": int(rows_b),
                                             "all_reduce_dense_grads": int(dense_b)},
+                # what ONE point-to-point xGMI link (~153 GB/s per direction) carries per step, for a one-glance sanity check of the
+                # first real N-GPU run: an all_to_all is link-parallel on the full mesh (one peer bucket per link); a ring
+                # all-reduce moves 2 (N - 1) / N of the buffer over every link of the ring
+                "per_link_bytes_per_step": {"all_to_all_ids": int(link_ids), "all_to_all_rows_and_grads": int(link_rows),
+                                            "all_reduce_dense_grads_ring": int(2 * (world - 1) * dense_b // world)},
+                "per_link_us_at_153GBs": round((link_ids + link_rows + 2 * (world - 1) * dense_b / world) / 153e9 * 1e6, 2),
                 "note": "static exchange plan: every bucket is sent at its fixed capacity (unused slots carry id -1 / zero rows)"}
     return {"est": est, "spec": spec, "feats": feats, "workload": workload, "dt": dt, "loss": float(loss), "graphed": graphed,
             "launch": launch, "overflow": overflow, "chunk_ms": chunk_ms, "step_fn": step, "comm": comm}

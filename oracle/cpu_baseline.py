@@ -94,15 +94,27 @@ def run(model: str, batch=4096, fields=26, emb=16, max_vocab=1_000_000, seconds=
                      f"[{workload.replace(f'batch {cpu_batch}/GPU', f'batch {cpu_batch}')}], median "
                      f"{med * 1e3:.1f} ms/step (warm-up {warm:.1f} s), torch-CPU fp32 op-for-op restatement of the "
                      f"reference graph (TF 1.14 not installable)"}
-    if also_threads and also_threads != threads:
-        # the same process, model and state at another intra-op thread count ("N = all host cores"): no second
-        # import / build / warm-up, a bounded number of steps (an oversubscribed pool can take seconds per step)
-        torch.set_num_threads(also_threads)
+    # the primary sample leaves first: a parent that has to cut the child off still has it (bench.py reads the last complete line)
+    import json
+    print(json.dumps(out), flush=True)
+    others = []
+    for n in ([also_threads // 2, also_threads] if also_threads and also_threads > 2 * threads else ([also_threads] if also_threads else [])):
+        if n == threads or n < 1:
+            continue
+        # the same process, model and state at another intra-op thread count ("N = all host cores"; half of them =
+        # the physical cores of an SMT host): no second import / build / warm-up, a bounded number of steps — an oversubscribed
+        # pool can take seconds per step
+        torch.set_num_threads(n)
+        t0 = time.perf_counter()
         step(t); t += 1                                # (the pool's threads are spawned here, not inside the timed steps)
-        t2 = sample(max(3.0, seconds / 3), max_steps=20, min_steps=3)
+        first = time.perf_counter() - t0
+        budget = max(3.0, seconds / 3)
+        t2 = sample(budget, max_steps=20, min_steps=1) if first < 2 * budget else [first]
         m2 = float(np.median(t2))
-        out["other_sample"] = {"cores": also_threads, "value": round(cpu_batch / m2, 1), "unit": "examples/s",
-                               "note": f"{len(t2)} steps of the same process at {also_threads} intra-op threads, median {m2 * 1e3:.1f} ms/step"}
+        others.append({"cores": n, "value": round(cpu_batch / m2, 1), "unit": "examples/s",
+                       "note": f"{len(t2)} steps of the same process at {n} intra-op threads, median {m2 * 1e3:.1f} ms/step"})
+        out["other_samples"] = others
+        print(json.dumps(out), flush=True)
     return out
 
 

@@ -153,6 +153,29 @@ def test_bench_launches_its_own_ranks():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 1024 and out["value"] > 0
 
 
+@pytest.mark.timeout(1500)
+def test_bench_eight_ranks_config5_code_path():
+    """`python bench.py --gpus 8 --config5` (BASELINE.json configs[4]: DeepFM, one big row-sharded table, the id / row / gradient
+    all_to_all and the dense all-reduce) through bench.py ITSELF at world 8 — the command the driver's scaling run issues — on the
+    bring-up backend (8 ranks share the test box's GPU, collectives bounce through host memory; a reduced table and batch): the
+    line must come from 8 ranks that all took part in the collectives, with the static exchange plan's per-link bytes in it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(RECALGO_DIST_BACKEND="gloo_staged", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "bench.py", "--gpus", "8", "--config5", "--big-table-rows", "400000", "--steps", "2", "--warmup", "2",
+           "--batch", "256", "--max-vocab", "20000", "--data-batches", "2", "--no-tunable", "--no-cpu-baseline", "--no-host-fed",
+           "--no-kernel-timing", "--capacity-factor", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["global_batch"] == 8 * 256 and out["value"] > 0
+    assert out["rccl_ranks"] == 8 and out["communication"]["world_size"] == 8
+    link, rank = out["communication"]["per_link_bytes_per_step"], out["communication"]["per_rank_bytes_per_step"]
+    assert link["all_to_all_rows_and_grads"] * 8 == rank["all_to_all_rows_and_grads"] and link["all_to_all_ids"] > 0
+    assert "DeepFM" in out["config"]["workload"] and "r % 8" in out["config"]["parallelism"]
+
+
 def test_bench_refuses_more_gpus_than_the_node_has():
     """Without the bring-up backend, asking for more GPUs than the node exposes is an error, not a 1-GPU line."""
     import torch
