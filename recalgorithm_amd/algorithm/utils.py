@@ -83,7 +83,7 @@ class _Dataset:
 class _Prefetch:
     """dataset.prefetch(n) (utils.py:24,43): a background thread runs the upstream pipeline up to n batches ahead of the
     consumer, so decoding batch i+1 overlaps the host side of step i (packing, the host-to-device copy, the launches; the
-    native decoder releases the GIL, and the device runs asynchronously anyway).  RECALGO_PREFETCH=0 iterates inline.
+    native decoder releases the GIL, and the device runs asynchronously anyway).
     Still an iterable of batches: type checks on the dataset itself look at `.upstream`."""
     _END = object()
 

@@ -485,7 +485,8 @@ __global__ __launch_bounds__(kThreads) void deepfm_sparse_bwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Deterministic scatter (RECALGO_SCATTER=sorted): the (row, item) pairs arrive sorted by row (stable: items of one
+// Deterministic scatter (recalgo_scatter_rows_sorted; round 2's parity mode, not on the training path since the owner-computes
+// scatter of sparse.hip became the default): the (row, item) pairs arrive sorted by row (stable: items of one
 // row keep their original order); the thread that holds the first item of a row sums the row's items in that order
 // and adds the total to the gradient row with a plain read-modify-write (one writer per row per launch) — no float
 // atomics, so two runs are bit-identical.  A parity / resume mode: a hot row is summed by one lane group sequentially.

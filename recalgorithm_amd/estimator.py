@@ -304,6 +304,12 @@ def _quiesce_collectives() -> None:
     time.sleep(0.5)
 
 
+class BatchShapeMismatch(ValueError):
+    """A batch whose structure / shapes are not those the step was captured on (the last partial batch of an epoch): the
+    ONLY condition under which the training loop runs a step eagerly beside a captured graph — any other error of the
+    replay path propagates."""
+
+
 class GraphedTrainStep:
     """Capture `step_fn(features, labels)` (forward + backward + optimizer, everything enqueued
     on the current stream) into a hipGraph over static input buffers; `__call__` copies the new
@@ -356,12 +362,12 @@ class GraphedTrainStep:
             return
         new = list(_tree_tensors(features, "f")) + list(_tree_tensors(labels, "l"))
         if len(new) != len(self._static):
-            raise ValueError("graphed step: the input structure changed")
+            raise BatchShapeMismatch("graphed step: the input structure changed")
         spans = self._static_spans()
         groups = {}
         for i, ((k0, dst), (k1, src)) in enumerate(zip(self._static, new)):
             if k0 != k1 or dst.shape != src.shape:
-                raise ValueError(f"graphed step: input {k1} changed shape/structure")
+                raise BatchShapeMismatch(f"graphed step: input {k1} changed shape/structure")
             if dst.dtype == src.dtype and dst.stride() == src.stride() and src.device == dst.device:
                 # (same shape, strides and dtype: the source covers a byte span of the same length as the destination's)
                 groups.setdefault((spans[i][0], src.untyped_storage().data_ptr()), []).append((i, src.storage_offset() * spans[i][3]))
@@ -557,14 +563,14 @@ class Estimator:
                 _host_copy(buf[nid + 4 * B * i:nid + 4 * B * (i + 1)].view(torch.float32), v.reshape(-1))
         return mat, keys, labs, nid, total, sig, fill
 
-    def feed_step(self, graphed: "GraphedTrainStep", features, labels):
+    def feed_step(self, graphed: "GraphedTrainStep", features, labels, pb=None):
         """One replay of a captured step on a HOST batch.  A native-reader batch with the layout the step was captured on goes
         from its pinned staging buffer STRAIGHT into the graph's static input span — one asynchronous copy; no intermediate
         device tensor, no per-column views, no device-to-device load (together they were 0.3 ms of host time per step, more
         than the GPU step).  Any other batch: `_to_device` + `graphed(features, labels)` as before."""
         plan = graphed._span_plan
         if plan is not None:
-            pb = self._packed_host_batch(features, labels)
+            pb = pb if pb is not None else self._packed_host_batch(features, labels)     # (the training loop passes its own)
             if pb is not None and pb[5] == plan[0] and plan[1].numel() == pb[4]:
                 self._h2d(pb[6], (pb[4],), torch.uint8, dst=plan[1])
                 return graphed()
@@ -672,11 +678,12 @@ class Estimator:
             except StopIteration:
                 break
             loss = None
-            if graphed is not None and self._packed_host_batch(features, labels) is not None:
+            pb = self._packed_host_batch(features, labels) if graphed is not None else None
+            if pb is not None:
                 host = (features, labels)
                 try:
-                    loss = self.feed_step(graphed, features, labels)     # (host batch -> the graph's input span, one copy)
-                except ValueError:       # last partial batch: eager step
+                    loss = self.feed_step(graphed, features, labels, pb)     # (host batch -> the graph's input span, one copy)
+                except BatchShapeMismatch:       # last partial batch: eager step
                     features, labels = self._to_device(*host)
                     loss = self.train_step(features, labels)
             else:
@@ -693,7 +700,7 @@ class Estimator:
                         loss = graphed()
                     else:
                         loss = graphed(features, labels)
-                except ValueError:       # last partial batch: eager step
+                except BatchShapeMismatch:       # last partial batch: eager step
                     loss = self.train_step(features, labels)
             else:
                 loss = self.train_step(features, labels)

@@ -108,6 +108,9 @@ class _NotSingleValued(ValueError):
     """a column declared single-valued holds several values in some record"""
 
 
+_MULTI_VALUED_KEYS: Dict[tuple, set] = {}    # (absolute path, mtime, size) of a file -> feature keys found to be multi-valued (process-wide)
+
+
 class NativeDataset:
     """TFRecordDataset(filepath)[.shuffle(buf)].repeat(epochs).batch(bs).map(parse) with the record
     framing, Example decoding and vocabulary lookup done in C++."""
@@ -118,7 +121,14 @@ class NativeDataset:
         self.filepath, self.bs = filepath, int(batch_size)
         self.epochs = -1 if num_epochs is None else int(num_epochs)
         self.shuffle, self.seed, self.verify = int(shuffle_buffer_size or 0), int(seed), verify_crc
-        self._multi = set()          # keys seen holding several values per record: decoded as ragged features
+        # keys seen holding several values per record: decoded as ragged features.  Remembered PER FILE, not per object: an input_fn
+        # that builds a new dataset per call (the usual Estimator pattern) must not rediscover the column mid-stream every time
+        try:
+            st = os.stat(filepath)
+            ident = (os.path.abspath(filepath), st.st_mtime_ns, st.st_size)
+        except OSError:
+            ident = (os.path.abspath(filepath), 0, 0)
+        self._multi = _MULTI_VALUED_KEYS.setdefault(ident, set())
         self.label_keys = list(label_keys)
         self.numeric: List[NumericColumn] = []
         self.categorical: List[CategoricalColumn] = []
@@ -222,16 +232,18 @@ class NativeDataset:
                 except _NotSingleValued as e:
                     self._note_multi(str(e))
                     raise ValueError(f"{self.filepath}: {e} — found after batches of the shuffled stream were already consumed, "
-                                     "which the asynchronous pipeline cannot replay; iterate the dataset again (the column is now "
-                                     "read as a ragged feature) or set RECALGO_READER_PIPELINE=0") from None
+                                     "which the asynchronous pipeline cannot replay; read the file again (the column is now known "
+                                     "as multi-valued for every dataset over this file in this process and is read as a ragged "
+                                     "feature) or set RECALGO_READER_PIPELINE=0") from None
                 return
         yield from self._iter_sync()
 
     def _note_multi(self, message: str) -> None:
-        """`feature <key> holds more than one value in a record` (recalgo_pipeline_error): remember the column."""
-        parts = message.split(" ")
-        if len(parts) > 1 and parts[0] == "feature":
-            self._multi.add(parts[1])
+        """`feature <key> holds more than one value in a record` (recalgo_pipeline_error): remember the column (a key may
+        itself contain spaces: everything between the fixed prefix and suffix is the key)."""
+        pre, suf = "feature ", " holds more than one value in a record"
+        if message.startswith(pre) and message.endswith(suf):
+            self._multi.add(message[len(pre):len(message) - len(suf)])
 
     def _iter_sync(self):
         from ..feature_column import Ragged

@@ -2,7 +2,7 @@
 
 These are the "context" MLP of the models.  `dense` runs on the hand-written fp32-MFMA
 kernels of csrc/dense.hip (bias + ReLU fused in the forward, the ReLU mask and the bias gradient fused in the
-backward); RECALGO_DENSE=blas switches back to hipBLASLt through torch for A/B measurements.  Parameter
+backward); layers wider than DENSE_MAX_K inputs (FiBiNET's 9600 -> 512) run on hipBLASLt through torch.  Parameter
 gradients are written straight into the flat gradient buffer (variables.py).
 """
 from __future__ import annotations

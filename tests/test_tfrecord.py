@@ -142,7 +142,7 @@ def test_input_fns_batching_epochs_and_shuffle(tmp_path, monkeypatch):
 
 def test_prefetch_stage_order_errors_and_early_stop(monkeypatch):
     """dataset.prefetch(1) (utils.py:24): same batches in the same order, upstream errors reach the consumer, a consumer
-    that stops early does not leave the producer blocked, RECALGO_PREFETCH=0 iterates inline."""
+    that stops early does not leave the producer blocked."""
     import threading
     import time
     from recalgorithm_amd.algorithm.utils import _Prefetch
@@ -170,5 +170,3 @@ def test_prefetch_stage_order_errors_and_early_stop(monkeypatch):
     time.sleep(0.2)
     assert len(produced) == n and n <= 5              # the producer stopped, at most the prefetch depth ahead
     assert not [t for t in threading.enumerate() if t.name == "recalgo-prefetch" and t.is_alive()]
-    monkeypatch.setenv("RECALGO_PREFETCH", "0")
-    assert list(_Prefetch(range(5), 1)) == [0, 1, 2, 3, 4]
