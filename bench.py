@@ -73,6 +73,10 @@ def parse_args(argv=None):
                          "bounded file: ~25 s)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--dropout-rate", type=float, default=0.0,
+                    help="training-mode tf.layers.dropout rate of the models that have one (DeepFM / DIN / FiBiNET / PNN / NFM; the "
+                         "reference scripts default to 0.1, deepfm.py:39).  Default 0 = BASELINE.json's parity configuration; a run "
+                         "with a rate > 0 says so in config.workload")
     ap.add_argument("--no-extra-models", action="store_true",
                     help="default run (--model dcn, N = 1): skip the DeepFM / xDeepFM / DIN lines appended under `models`")
     args = ap.parse_args(argv)
@@ -205,6 +209,9 @@ def build_estimator(args, device, rank=0, world=1, before_build=None):
     if args.big_table_rows:
         workload += (f"; one {int(args.big_table_rows):,}-row table among the fields"
                      + (f", rows sharded r % {world} (BASELINE.json configs[4])" if world > 1 else " (BASELINE.json configs[4] on one GPU)"))
+    if getattr(args, "dropout_rate", 0.0) > 0 and "dropout_rate" in params:
+        params["dropout_rate"] = float(args.dropout_rate)
+        workload += f"; dropout {args.dropout_rate:g} (hash-keyed masks, csrc/dropout.h)"
     est = Estimator(model_fn=model_fn, params=params, config=RunConfig(device=device, seed=42))
     feats, labels, _ = synth.device_features(spec, args.batch, device, batch_index=rank)
     if before_build is not None:

@@ -694,12 +694,42 @@ int recalgo_activation_bwd(const float* x, const float* alpha, const float* gy, 
  * is stored: the backward is the same map applied to the gradient with the same key.  recalgo_dropout_keep_mask writes the
  * mask the hash stands for (tests, debugging).  n < 2^32 elements; pointers 16-byte aligned; 0 < rate < 1 (a double: TF forms
  * 1 / (1 - rate) from the Python float and casts it to x.dtype once). */
+typedef struct recalgo_dropout {   /* one training-mode dropout call for the kernels that apply it themselves (the *_drop entry points) */
+    double rate;
+    const float* keep_mask;        /* NULL: the hash */
+    unsigned seed, call;
+    const int64_t* step;           /* device step counter, NULL: 0 */
+} recalgo_dropout_t;
 int recalgo_dropout_fwd(const float* x, int64_t n, double rate, const float* keep_mask, unsigned seed, unsigned call,
                         const int64_t* step, float* y, recalgo_stream_t stream);
 int recalgo_dropout_bwd(const float* g, int64_t n, double rate, const float* keep_mask, unsigned seed, unsigned call,
                         const int64_t* step, float* dx, recalgo_stream_t stream);
 int recalgo_dropout_keep_mask(int64_t n, double rate, unsigned seed, unsigned call, const int64_t* step, float* out,
                               recalgo_stream_t stream);
+/* The dropout applied by its NEIGHBOURS instead of by launches of its own (element index = row * width + column of the contiguous
+ * [rows, width] tensor, the index space of recalgo_dropout_fwd; drop == NULL: the plain entry point):
+ *   recalgo_dense_fwd_drop             recalgo_dense_fwd_bn whose epilogue multiplies y = act(x w + b) by keep / (1 - rate) before
+ *                                      the store and the BatchNorm tile moments — tf.layers.dense(relu) -> tf.layers.dropout
+ *                                      [-> tf.layers.batch_normalization], deepfm.py:207-211 / pnn.py:187-191 / fibinet.py:192-196.
+ *                                      ldy == N.  Its backward needs no mask of its own: y > 0 <=> relu > 0 and kept, so the
+ *                                      consumer that masks its input gradient with y (recalgo_batchnorm_train_bwd_drop dx_relu)
+ *                                      only has to scale it by dx_scale = 1 / (1 - rate);
+ *   recalgo_batchnorm_apply_drop       recalgo_batchnorm_apply whose store multiplies by keep / (1 - rate) — tf.layers.
+ *                                      batch_normalization -> tf.layers.dropout, din.py:233-236;
+ *   recalgo_batchnorm_train_bwd_drop   recalgo_batchnorm_train_bwd_act with g read as g * keep / (1 - rate) (g_drop: the dropout
+ *                                      BEHIND the BatchNorm; sums must be NULL — sums left by a dgrad epilogue are those of the
+ *                                      un-dropped gradient) and / or dx scaled where dx_relu lets it through (dx_scale: the
+ *                                      dropout IN FRONT of the BatchNorm). */
+int recalgo_dense_fwd_drop(const float* x, int ldx, const float* w, int K, const float* x2, int ldx2, const float* w2, int K2,
+                           const float* bias, int M, int N, int relu, float* y, int ldy, float* bn_partials,
+                           const recalgo_dropout_t* drop, recalgo_stream_t stream);
+int recalgo_batchnorm_apply_drop(const float* x, const float* gamma, const float* beta, const float* partials, int world, int rows,
+                                 int C, float eps, float momentum, float* moving_mean, float* moving_var, float* y, float* save_mean,
+                                 float* save_rstd, const recalgo_dropout_t* out_drop, recalgo_stream_t stream);
+int recalgo_batchnorm_train_bwd_drop(const float* x, const float* gamma, const float* save_mean, const float* save_rstd,
+                                     const float* g, const float* sums, int rows, int C, int act_kind, const float* act_z,
+                                     const float* act_alpha, float* dx, float* dgamma, float* dbeta, float* dalpha, void* workspace,
+                                     int dx_relu, float dx_scale, const recalgo_dropout_t* g_drop, recalgo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * a15 / a16 / f1  Row-gradient scatter without float atomics, fused with the sparse optimizer.

@@ -74,6 +74,9 @@ SIGNATURES = {
     "recalgo_dropout_fwd": (c_int, [P, c_int64, c_double, P, c_int, c_int, P, P, P]),
     "recalgo_dropout_bwd": (c_int, [P, c_int64, c_double, P, c_int, c_int, P, P, P]),
     "recalgo_dropout_keep_mask": (c_int, [c_int64, c_double, c_int, c_int, P, P, P]),
+    "recalgo_dense_fwd_drop": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, P, c_int, P, P, P]),
+    "recalgo_batchnorm_apply_drop": (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, c_float, P, P, P, P, P, P, P]),
+    "recalgo_batchnorm_train_bwd_drop": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, c_float, P, P]),
     "recalgo_sigmoid_ce_fwd_bwd": (c_int, [P, P, c_int, c_float, P, P, P, P]),
     "recalgo_adam_tf1_dense": (c_int, [P, P, P, P, c_int64, c_float, P, c_float, c_float, c_float, c_int, P]),
     "recalgo_adam_tf1_rows": (c_int, [P, P, P, P, P, c_int64, c_int, c_float, P, c_float, c_float, c_float, c_int, P]),

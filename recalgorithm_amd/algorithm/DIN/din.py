@@ -94,9 +94,9 @@ def din_model_fn(features, labels, mode, params):
             # dense -> dice | prelu -> batch_normalization (din.py:262-266): one autograd node in a training step on the GPU
             net = nn.dense_activation_bn(net, unit, "dice" if params["activation"] == "dice" else "prelu", layer_index,
                                          bool(params["batch_norm"]), training,
-                                         input_l2=(seed * mba_coeff if fused_mba and i == 0 else 0.0))
-            if "dropout_rate" in params and 0.0 < params["dropout_rate"] < 1.0:
-                net = nn.dropout(net, params["dropout_rate"], training=training)
+                                         input_l2=(seed * mba_coeff if fused_mba and i == 0 else 0.0),
+                                         # ... -> dropout (din.py:235-236): in the BatchNorm's store / its backward's loads
+                                         dropout_rate=params["dropout_rate"] if "dropout_rate" in params else None)
         logit = nn.dense(net, 1)
 
     def mba_reg():

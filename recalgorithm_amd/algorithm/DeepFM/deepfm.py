@@ -76,11 +76,10 @@ def deepfm_model_fn(features, labels, mode, params):
     with variable_scope("fm_deep"):
         net = deep_input
         for unit in params["hidden_units"]:
-            net = nn.dense(net, unit, activation="relu", bn_stats=bool(params["batch_norm"]) and training)
-            if "dropout_rate" in params and 0.0 < params["dropout_rate"] < 1.0:
-                net = nn.dropout(net, params["dropout_rate"], training=training)
-            if params["batch_norm"]:
-                net = nn.batch_normalization(net, training=training)
+            # dense(relu) -> [dropout] -> [batch_normalization], deepfm.py:207-211 (nn.dense_relu_dropout_bn: in a training step the
+            # dropout rides in the dense layer's epilogue and the BatchNorm's backward)
+            net = nn.dense_relu_dropout_bn(net, unit, params["dropout_rate"] if "dropout_rate" in params else None,
+                                           bool(params["batch_norm"]), training)
         deep_logit = nn.dense(net, 1)
     # deepfm.py:214 (fm_first_order_logit + fm_second_order_logit + deep_logit).  Grouped from the right so that both FM terms
     # join the lazily evaluated head as addends of the fused logit / loss launch (no elementwise add launch of their own)

@@ -74,11 +74,10 @@ def fibinet_model_fn(features, labels, mode, params):
     with variable_scope("dnn_part"):
         net = bi_total
         for unit in params["hidden_units"]:
-            net = nn.dense(net, unit, activation="relu", bn_stats=bool(params["batch_norm"]) and training)
-            if "dropout_rate" in params and 0.0 < params["dropout_rate"] < 1.0:
-                net = nn.dropout(net, params["dropout_rate"], training=training)
-            if params["batch_norm"]:
-                net = nn.batch_normalization(net, training=training)
+            # dense(relu) -> [dropout] -> [batch_normalization], fibinet.py:192-196 (nn.dense_relu_dropout_bn: in a training step the
+            # dropout rides in the dense layer's epilogue and the BatchNorm's backward)
+            net = nn.dense_relu_dropout_bn(net, unit, params["dropout_rate"] if "dropout_rate" in params else None,
+                                           bool(params["batch_norm"]), training)
         fibinet_logit = nn.dense(net, 1)
 
     total_logit = fibinet_logit if linear_logit is None else linear_logit + fibinet_logit

@@ -36,6 +36,7 @@
 #include "common.h"
 #include "act.h"
 #include "tile_v2.h"
+#include "dropout.h"
 
 namespace {
 
@@ -337,6 +338,9 @@ struct FwdArgs {
     int act_kind;              // 0: none, 1 + RECALGO_ACT_PRELU, 1 + RECALGO_ACT_DICE
     float* z;                  // [M][ldy]
     int vec_store;             // y is float4-addressable (base, ldy, N): the plain epilogue writes whole row segments
+    // optional (ldy == N): the tf.layers.dropout that follows the layer (tf.layers.dense(relu) -> tf.layers.dropout [-> batch_normalization],
+    // deepfm.py:207-211): y := y * keep / (1 - rate) before the store and the moments (csrc/dropout.h; element index row * N + col)
+    recalgo_drop::Spec drop;
 };
 
 template <bool FAST>
@@ -361,12 +365,20 @@ __global__ __launch_bounds__(kThreads) void dense_fwd_kernel(FwdArgs P) {
         tile_mainloop<true, false, FAST, false, false, false>(P.seg[s], m0, n0, P.M, P.N, 0, P.seg[s].n_red, As, Bs, acc, acc1, unused);
     acc += acc1;
     const int col = n0 + (wave & 1) * 32 + l32;
+    const bool dropping = recalgo_drop::enabled(P.drop);
+    const recalgo_drop::Key dkey = dropping ? recalgo_drop::make_key(P.drop) : recalgo_drop::Key{0u, 0u};
     if (rowwise) {
         const int r0 = m0 + (wave >> 1) * 32;
         tv2::tile_rows(As + wave * tv2::kTileScratch, acc, [&](int, int row, int, float4 v) {
             v = f4_add(v, bias4);
             if (P.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-            if (r0 + row < P.M && c4 < P.N) *reinterpret_cast<float4*>(P.y + (size_t)(r0 + row) * P.ldy + c4) = v;
+            if (r0 + row < P.M && c4 < P.N) {
+                if (dropping) {
+                    const float4 f = recalgo_drop::factor4(P.drop, dkey, (uint32_t)(r0 + row) * (uint32_t)P.N + (uint32_t)c4);
+                    v = make_float4(v.x * f.x, v.y * f.y, v.z * f.z, v.w * f.w);
+                }
+                *reinterpret_cast<float4*>(P.y + (size_t)(r0 + row) * P.ldy + c4) = v;
+            }
         });
         return;
     }
@@ -379,6 +391,7 @@ __global__ __launch_bounds__(kThreads) void dense_fwd_kernel(FwdArgs P) {
             if (row < P.M) {
                 float v = acc[r] + bv;
                 if (P.relu) v = fmaxf(v, 0.f);
+                if (dropping) v *= recalgo_drop::factor(P.drop, dkey, (uint32_t)row * (uint32_t)P.N + (uint32_t)col);
                 P.y[(size_t)row * P.ldy + col] = v;
             }
         }
@@ -401,6 +414,7 @@ __global__ __launch_bounds__(kThreads) void dense_fwd_kernel(FwdArgs P) {
             if (ok) P.z[(size_t)row * P.ldy + col] = v;
             v = P.act_kind == 1 + RECALGO_ACT_DICE ? recalgo_act::dice(v, av) : recalgo_act::prelu(v, av);
         }
+        if (dropping && ok) v *= recalgo_drop::factor(P.drop, dkey, (uint32_t)row * (uint32_t)P.N + (uint32_t)col);
         vals[r] = ok ? v : 0.f;
         if (ok && !rows_y) P.y[(size_t)row * P.ldy + col] = v;
         s += vals[r];
@@ -832,10 +846,27 @@ RECALGO_EXPORT int recalgo_dense_fwd_bn(const float* x, int ldx, const float* w,
                                     bn_partials, stream);
 }
 
+static int dense_fwd_impl(const float* x, int ldx, const float* w, int K, const float* x2, int ldx2, const float* w2, int K2,
+                          const float* bias, int M, int N, int relu, int act_kind, const float* act_alpha, float* z, float* y, int ldy,
+                          float* bn_partials, const recalgo_dropout_t* drop, recalgo_stream_t stream);
+
 RECALGO_EXPORT int recalgo_dense_fwd_act_bn(const float* x, int ldx, const float* w, int K, const float* x2, int ldx2,
                                             const float* w2, int K2, const float* bias, int M, int N, int relu, int act_kind,
                                             const float* act_alpha, float* z, float* y, int ldy, float* bn_partials,
                                             recalgo_stream_t stream) {
+    return dense_fwd_impl(x, ldx, w, K, x2, ldx2, w2, K2, bias, M, N, relu, act_kind, act_alpha, z, y, ldy, bn_partials, nullptr, stream);
+}
+
+RECALGO_EXPORT int recalgo_dense_fwd_drop(const float* x, int ldx, const float* w, int K, const float* x2, int ldx2,
+                                          const float* w2, int K2, const float* bias, int M, int N, int relu, float* y, int ldy,
+                                          float* bn_partials, const recalgo_dropout_t* drop, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(drop == nullptr || (ldy == N && (int64_t)M * N < ((int64_t)1 << 32) && recalgo_drop::abi_ok(drop)));
+    return dense_fwd_impl(x, ldx, w, K, x2, ldx2, w2, K2, bias, M, N, relu, RECALGO_ACT_NONE, nullptr, nullptr, y, ldy, bn_partials, drop, stream);
+}
+
+static int dense_fwd_impl(const float* x, int ldx, const float* w, int K, const float* x2, int ldx2, const float* w2, int K2,
+                          const float* bias, int M, int N, int relu, int act_kind, const float* act_alpha, float* z, float* y, int ldy,
+                          float* bn_partials, const recalgo_dropout_t* drop, recalgo_stream_t stream) {
     RECALGO_REQUIRE(M >= 0 && N > 0 && K > 0 && y != nullptr && ldy >= N);
     RECALGO_REQUIRE(act_kind == RECALGO_ACT_NONE || ((act_kind == RECALGO_ACT_PRELU || act_kind == RECALGO_ACT_DICE) &&
                                                      act_alpha != nullptr && z != nullptr && bn_partials != nullptr && !relu));
@@ -850,6 +881,7 @@ RECALGO_EXPORT int recalgo_dense_fwd_act_bn(const float* x, int ldx, const float
     P.bn_partials = bn_partials;
     P.act_alpha = act_alpha; P.act_kind = act_kind == RECALGO_ACT_NONE ? 0 : 1 + act_kind; P.z = z;
     P.vec_store = (aligned16(y) && ldy % 4 == 0 && N % 4 == 0 && (bias == nullptr || aligned16(bias))) ? 1 : 0;
+    P.drop = recalgo_drop::from_abi(drop);
     const int grid = cdiv(M, BM) * cdiv(N, BN);
     const bool fast = fast_rc(P.seg[0].a, K) && fast_rm(P.seg[0].b, N) && fast_rc(P.seg[1].a, K2) && fast_rm(P.seg[1].b, N);
     if (fast) hipLaunchKernelGGL(dense_fwd_kernel<true>, dim3(grid), dim3(kThreads), 0, as_stream(stream), P);

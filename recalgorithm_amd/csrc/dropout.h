@@ -22,6 +22,27 @@ __host__ __device__ __forceinline__ uint32_t threshold_of(double rate) {
     return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
 }
 
+__host__ __device__ __forceinline__ bool enabled(const Spec& s) { return s.scale != 0.f; }     // (scale = 1 / (1 - rate) >= 1 when on)
+inline Spec disabled() {
+    Spec s;
+    s.mask = nullptr; s.step = nullptr; s.seed = s.call = 0; s.threshold = 0; s.scale = 0.f;
+    return s;
+}
+// the C-ABI form (include/recalgo.h recalgo_dropout_t) -> Spec; NULL: disabled
+template <class T>
+inline Spec from_abi(const T* d) {
+    if (d == nullptr) return disabled();
+    Spec s;
+    s.mask = d->keep_mask; s.step = d->step; s.seed = d->seed; s.call = d->call;
+    s.threshold = threshold_of(d->rate);
+    s.scale = (float)(1.0 / (1.0 - d->rate));
+    return s;
+}
+template <class T>
+inline bool abi_ok(const T* d) {
+    return d == nullptr || (d->rate > 0.0 && d->rate < 1.0 && (reinterpret_cast<uintptr_t>(d->keep_mask) & 15) == 0);
+}
+
 struct Key {
     uint32_t k0, k1;
 };

@@ -17,6 +17,7 @@
 // its second stages walked rows/8 partial rows and cost 10-22 us per layer.)  Requires C % 4 == 0.
 #include "common.h"
 #include "act.h"
+#include "dropout.h"
 
 namespace {
 
@@ -116,7 +117,9 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_apply_kernel(
     const float4* __restrict__ x, const float4* __restrict__ gamma, const float4* __restrict__ beta,
     const float4* __restrict__ partials, unsigned nblk, unsigned nblk_local, unsigned rows, unsigned C4, float eps,
     float momentum, float4* __restrict__ moving_mean, float4* __restrict__ moving_var, float4* __restrict__ save_mean,
-    float4* __restrict__ save_rstd, float4* __restrict__ y) {
+    float4* __restrict__ save_rstd, float4* __restrict__ y, recalgo_drop::Spec out_drop) {
+    // out_drop: the tf.layers.dropout that follows the BatchNorm (dense -> dice | prelu -> batch_norm -> dropout, din.py:227-236):
+    // y := y * keep / (1 - rate) in the store (csrc/dropout.h; element index row * C + col)
     // nblk = world * nblk_local partial rows (Sync-BatchNorm: the tiles of all ranks, rank major; every rank holds `rows`
     // examples); world = 1: nblk == nblk_local
     __shared__ float4 sh[16][17];
@@ -169,13 +172,16 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_apply_kernel(
     }
     const float4 sc = f4_mul(rstd, gamma[c4]), bt = beta[c4];
     const unsigned r0 = blockIdx.y * kTileRows;
+    const bool dropping = recalgo_drop::enabled(out_drop);
+    const recalgo_drop::Key dkey = dropping ? recalgo_drop::make_key(out_drop) : recalgo_drop::Key{0u, 0u};
 #pragma unroll
     for (unsigned k = 0; k < kTileRows / 16; ++k) {
         const unsigned r = r0 + rl + 16 * k;
         if (r < rows) {
             const float4 xh = f4_sub(x[(size_t)r * C4 + c4], mean);
-            y[(size_t)r * C4 + c4] = make_float4(fmaf(xh.x, sc.x, bt.x), fmaf(xh.y, sc.y, bt.y), fmaf(xh.z, sc.z, bt.z),
-                                                 fmaf(xh.w, sc.w, bt.w));
+            float4 o = make_float4(fmaf(xh.x, sc.x, bt.x), fmaf(xh.y, sc.y, bt.y), fmaf(xh.z, sc.z, bt.z), fmaf(xh.w, sc.w, bt.w));
+            if (dropping) o = f4_mul(o, recalgo_drop::factor4(out_drop, dkey, (r * C4 + c4) * 4u));
+            y[(size_t)r * C4 + c4] = o;
         }
     }
 }
@@ -185,11 +191,15 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float4* _
                                                                  const float4* __restrict__ g,
                                                                  const float4* __restrict__ mean,
                                                                  const float4* __restrict__ rstd, unsigned rows,
-                                                                 unsigned C4, float4* __restrict__ partials) {
+                                                                 unsigned C4, float4* __restrict__ partials,
+                                                                 recalgo_drop::Spec g_drop) {
+    // g_drop: the BatchNorm's output went through a dropout (see bn_finalize_apply_kernel): its gradient is g * keep / (1 - rate)
     __shared__ float4 sh[kThreads];
     const unsigned cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const unsigned c4 = blockIdx.x * 16 + cl;
     const unsigned r0 = blockIdx.y * kTileRows;
+    const bool dropping = recalgo_drop::enabled(g_drop);
+    const recalgo_drop::Key dkey = dropping ? recalgo_drop::make_key(g_drop) : recalgo_drop::Key{0u, 0u};
     float4 sg = f4_zero(), sgx = f4_zero();
     if (c4 < C4) {
         const float4 mu = mean[c4], rs4 = rstd[c4];
@@ -197,7 +207,8 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float4* _
         for (unsigned k = 0; k < kTileRows / 16; ++k) {
             const unsigned r = r0 + rl + 16 * k;
             if (r < rows) {
-                const float4 gv = g[(size_t)r * C4 + c4];
+                float4 gv = g[(size_t)r * C4 + c4];
+                if (dropping) gv = f4_mul(gv, recalgo_drop::factor4(g_drop, dkey, (r * C4 + c4) * 4u));
                 const float4 xh = f4_mul(f4_sub(x[(size_t)r * C4 + c4], mu), rs4);
                 sg = f4_add(sg, gv);
                 sgx = f4_add(sgx, f4_mul(gv, xh));
@@ -225,7 +236,11 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_sum_apply_kernel(
     const float4* __restrict__ mean, const float4* __restrict__ rstd, const float4* __restrict__ partials,
     unsigned nblk, unsigned nblk_local, unsigned rank, unsigned rows, unsigned C4, float4* __restrict__ dbeta,
     float4* __restrict__ dgamma, float4* __restrict__ dx, const float4* __restrict__ act_z,
-    const float4* __restrict__ act_alpha, float4* __restrict__ act_partials, int dx_relu) {
+    const float4* __restrict__ act_alpha, float4* __restrict__ act_partials, int dx_relu, float dx_scale,
+    recalgo_drop::Spec g_drop) {
+    // dx_scale (with dx_relu): x is a ReLU output that went through a dropout BEFORE this BatchNorm (dense(relu) -> dropout ->
+    // batch_norm, deepfm.py:207-211; x = relu * keep / (1 - rate), so x > 0 <=> relu > 0 and kept): dx := dx / (1 - rate) there.
+    // g_drop: a dropout AFTER this BatchNorm (see bn_bwd_reduce_kernel)
     // dx_relu: x IS a ReLU output (tf.layers.dense(..., relu) -> tf.layers.batch_normalization, deepfm.py:206-211): dx is zeroed where
     // x <= 0, so that the dense layer's backward gets its gradient already masked (see recalgo_dense_bwd_bn dx_relu_mask)
     // nblk = world * nblk_local partial rows (see bn_finalize_apply_kernel).  dx uses the sums over ALL ranks' tiles;
@@ -280,6 +295,8 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_sum_apply_kernel(
     }
     if (!ok && ACT == 0) return;
     const float inv_rows = 1.0f / ((float)rows * (float)(nblk / nblk_local));
+    const bool dropping = recalgo_drop::enabled(g_drop);
+    const recalgo_drop::Key dkey = dropping ? recalgo_drop::make_key(g_drop) : recalgo_drop::Key{0u, 0u};
     float4 da = f4_zero();
     if (ok) {
         const float4 mu = mean[c4], rs4 = rstd[c4];
@@ -292,7 +309,8 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_sum_apply_kernel(
             if (r < rows) {
                 const float4 xv = x[(size_t)r * C4 + c4];
                 const float4 xh = f4_mul(f4_sub(xv, mu), rs4);
-                const float4 gv = g[(size_t)r * C4 + c4];
+                float4 gv = g[(size_t)r * C4 + c4];
+                if (dropping) gv = f4_mul(gv, recalgo_drop::factor4(g_drop, dkey, (r * C4 + c4) * 4u));
                 float4 d =
                     make_float4(k.x * (gv.x - inv_rows * (db.x + xh.x * dg.x)), k.y * (gv.y - inv_rows * (db.y + xh.y * dg.y)),
                                 k.z * (gv.z - inv_rows * (db.z + xh.z * dg.z)), k.w * (gv.w - inv_rows * (db.w + xh.w * dg.w)));
@@ -305,7 +323,8 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_sum_apply_kernel(
                                     recalgo_act::bwd<ACT == 1 + RECALGO_ACT_DICE>(z.w, al.w, d.w, t4.w));
                     da = f4_add(da, t4);
                 }
-                if (dx_relu) d = make_float4(xv.x > 0.f ? d.x : 0.f, xv.y > 0.f ? d.y : 0.f, xv.z > 0.f ? d.z : 0.f, xv.w > 0.f ? d.w : 0.f);
+                if (dx_relu) d = make_float4(xv.x > 0.f ? d.x * dx_scale : 0.f, xv.y > 0.f ? d.y * dx_scale : 0.f,
+                                             xv.z > 0.f ? d.z * dx_scale : 0.f, xv.w > 0.f ? d.w * dx_scale : 0.f);
                 dx[(size_t)r * C4 + c4] = d;
             }
         }
@@ -660,7 +679,7 @@ RECALGO_EXPORT int recalgo_batchnorm_train_fwd(const float* x, const float* gamm
                        reinterpret_cast<const float4*>(beta), reinterpret_cast<const float4*>(partials), (unsigned)nb,
                        (unsigned)nb, (unsigned)rows, C4, eps, momentum, reinterpret_cast<float4*>(moving_mean),
                        reinterpret_cast<float4*>(moving_var), reinterpret_cast<float4*>(save_mean),
-                       reinterpret_cast<float4*>(save_rstd), reinterpret_cast<float4*>(y));
+                       reinterpret_cast<float4*>(save_rstd), reinterpret_cast<float4*>(y), recalgo_drop::disabled());
     RECALGO_RETURN_LAST();
 }
 
@@ -683,6 +702,17 @@ RECALGO_EXPORT int recalgo_batchnorm_train_bwd_act(const float* x, const float* 
                                                    const float* act_z, const float* act_alpha, float* dx, float* dgamma,
                                                    float* dbeta, float* dalpha, void* workspace, int dx_relu,
                                                    recalgo_stream_t stream) {
+    return recalgo_batchnorm_train_bwd_drop(x, gamma, save_mean, save_rstd, g, sums, rows, C, act_kind, act_z, act_alpha, dx, dgamma, dbeta,
+                                            dalpha, workspace, dx_relu, 1.0f, nullptr, stream);
+}
+
+RECALGO_EXPORT int recalgo_batchnorm_train_bwd_drop(const float* x, const float* gamma, const float* save_mean,
+                                                    const float* save_rstd, const float* g, const float* sums, int rows, int C,
+                                                    int act_kind, const float* act_z, const float* act_alpha, float* dx,
+                                                    float* dgamma, float* dbeta, float* dalpha, void* workspace, int dx_relu,
+                                                    float dx_scale, const recalgo_dropout_t* g_drop, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(recalgo_drop::abi_ok(g_drop) && (g_drop == nullptr || (sums == nullptr && (int64_t)rows * C < ((int64_t)1 << 32))));
+    const recalgo_drop::Spec gd = recalgo_drop::from_abi(g_drop);
     RECALGO_REQUIRE(rows > 0 && width_ok(C) && x && gamma && save_mean && save_rstd && g && dx && dgamma && dbeta &&
                     workspace);
     RECALGO_REQUIRE(act_kind == RECALGO_ACT_NONE ||
@@ -698,7 +728,7 @@ RECALGO_EXPORT int recalgo_batchnorm_train_bwd_act(const float* x, const float* 
     if (sums == nullptr)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C4, 16), nb), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
                            reinterpret_cast<const float4*>(g), reinterpret_cast<const float4*>(save_mean),
-                           reinterpret_cast<const float4*>(save_rstd), (unsigned)rows, C4, reinterpret_cast<float4*>(ws));
+                           reinterpret_cast<const float4*>(save_rstd), (unsigned)rows, C4, reinterpret_cast<float4*>(ws), gd);
 #define RECALGO_BN_APPLY(ACT)                                                                                                   \
     hipLaunchKernelGGL(bn_bwd_sum_apply_kernel<ACT>, dim3(cdiv(C4, 16), nb), dim3(kThreads), 0, st,                             \
                        reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(g),                                  \
@@ -706,7 +736,7 @@ RECALGO_EXPORT int recalgo_batchnorm_train_bwd_act(const float* x, const float* 
                        reinterpret_cast<const float4*>(save_rstd), reinterpret_cast<const float4*>(partials), (unsigned)nb,     \
                        (unsigned)nb, 0u, (unsigned)rows, C4, reinterpret_cast<float4*>(dbeta), reinterpret_cast<float4*>(dgamma), \
                        reinterpret_cast<float4*>(dx), reinterpret_cast<const float4*>(act_z),                                   \
-                       reinterpret_cast<const float4*>(act_alpha), reinterpret_cast<float4*>(act_partials), dx_relu)
+                       reinterpret_cast<const float4*>(act_alpha), reinterpret_cast<float4*>(act_partials), dx_relu, dx_scale, gd)
     if (act_kind == RECALGO_ACT_NONE) RECALGO_BN_APPLY(0);
     else if (act_kind == RECALGO_ACT_PRELU) RECALGO_BN_APPLY(1 + RECALGO_ACT_PRELU);
     else RECALGO_BN_APPLY(1 + RECALGO_ACT_DICE);
@@ -733,6 +763,15 @@ RECALGO_EXPORT int recalgo_batchnorm_apply(const float* x, const float* gamma, c
                                            int world, int rows, int C, float eps, float momentum, float* moving_mean,
                                            float* moving_var, float* y, float* save_mean, float* save_rstd,
                                            recalgo_stream_t stream) {
+    return recalgo_batchnorm_apply_drop(x, gamma, beta, partials, world, rows, C, eps, momentum, moving_mean, moving_var, y, save_mean,
+                                        save_rstd, nullptr, stream);
+}
+
+RECALGO_EXPORT int recalgo_batchnorm_apply_drop(const float* x, const float* gamma, const float* beta, const float* partials,
+                                                int world, int rows, int C, float eps, float momentum, float* moving_mean,
+                                                float* moving_var, float* y, float* save_mean, float* save_rstd,
+                                                const recalgo_dropout_t* out_drop, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(recalgo_drop::abi_ok(out_drop) && (out_drop == nullptr || (int64_t)rows * C < ((int64_t)1 << 32)));
     RECALGO_REQUIRE(rows > 0 && world >= 1 && width_ok(C) && x && gamma && beta && partials && y && save_mean && save_rstd);
     RECALGO_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr));
     const int nb = nblk_of(rows);
@@ -742,7 +781,8 @@ RECALGO_EXPORT int recalgo_batchnorm_apply(const float* x, const float* gamma, c
                        reinterpret_cast<const float4*>(beta), reinterpret_cast<const float4*>(partials),
                        (unsigned)(nb * world), (unsigned)nb, (unsigned)rows, C4, eps, momentum,
                        reinterpret_cast<float4*>(moving_mean), reinterpret_cast<float4*>(moving_var),
-                       reinterpret_cast<float4*>(save_mean), reinterpret_cast<float4*>(save_rstd), reinterpret_cast<float4*>(y));
+                       reinterpret_cast<float4*>(save_mean), reinterpret_cast<float4*>(save_rstd), reinterpret_cast<float4*>(y),
+                       recalgo_drop::from_abi(out_drop));
     RECALGO_RETURN_LAST();
 }
 
@@ -753,7 +793,7 @@ RECALGO_EXPORT int recalgo_batchnorm_bwd_sums(const float* x, const float* save_
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C4, 16), nblk_of(rows)), dim3(kThreads), 0, as_stream(stream),
                        reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(g),
                        reinterpret_cast<const float4*>(save_mean), reinterpret_cast<const float4*>(save_rstd), (unsigned)rows, C4,
-                       reinterpret_cast<float4*>(partials));
+                       reinterpret_cast<float4*>(partials), recalgo_drop::disabled());
     RECALGO_RETURN_LAST();
 }
 
@@ -770,7 +810,8 @@ RECALGO_EXPORT int recalgo_batchnorm_bwd_apply(const float* x, const float* gamm
                        reinterpret_cast<const float4*>(save_rstd), reinterpret_cast<const float4*>(partials),
                        (unsigned)(nb * world), (unsigned)nb, (unsigned)rank, (unsigned)rows, C4,
                        reinterpret_cast<float4*>(dbeta), reinterpret_cast<float4*>(dgamma), reinterpret_cast<float4*>(dx),
-                       static_cast<const float4*>(nullptr), static_cast<const float4*>(nullptr), static_cast<float4*>(nullptr), dx_relu);
+                       static_cast<const float4*>(nullptr), static_cast<const float4*>(nullptr), static_cast<float4*>(nullptr), dx_relu, 1.0f,
+                       recalgo_drop::disabled());
     RECALGO_RETURN_LAST();
 }
 

@@ -112,12 +112,15 @@ class _DenseFn(Function):
     @staticmethod
     def forward(ctx, anchor, x, kernel: Variable, bias: Optional[Variable], relu: bool, input_l2: float = 0.0,
                 grad_join: Optional[GradJoin] = None, bn_partials: Optional[torch.Tensor] = None,
-                relu_src: Optional[ReluSource] = None):
+                relu_src: Optional[ReluSource] = None, drop=None):
         ctx.input_l2 = float(input_l2)
+        ctx.drop_scale = 1.0 if drop is None else float(drop.scale)
         ctx.grad_join = grad_join
         ctx.bn_link = _bn_link_of(x)
         ctx.relu_src = relu_src
         ctx.x_relu_src = getattr(x, "_recalgo_relu_src", None) if (x.dim() == 2 and x.is_contiguous()) else None
+        if getattr(x, "_recalgo_relu_scale", 1.0) != 1.0:
+            ctx.x_relu_src = None              # (only the BatchNorm backward scales while it masks: the producer does it itself)
         x2 = x.reshape(-1, x.shape[-1])
         ctx.hip = x2.is_cuda and x2.dtype == torch.float32 and _mfma_dense(x2.shape[1])
         if ctx.hip:
@@ -125,7 +128,10 @@ class _DenseFn(Function):
             if x2.stride(1) != 1:
                 x2 = x2.contiguous()
             # GEMM + bias + ReLU in one launch
-            y = ops.dense_fwd(x2, kernel.data, None if bias is None else bias.data, relu, bn_partials=bn_partials)
+            # (drop: the tf.layers.dropout behind the layer applied by the epilogue — y IS the dropped tensor, y > 0 <=> relu > 0 and kept)
+            y = ops.dense_fwd(x2, kernel.data, None if bias is None else bias.data, relu, bn_partials=bn_partials, drop=drop)
+        elif drop is not None:
+            raise ValueError("dense(drop=): only with the hand-written kernels (the caller checks nn.dense_drop_supported)")
         elif bias is not None and relu and x2.is_cuda:
             y = torch._addmm_activation(bias.data, x2, kernel.data)     # GEMM + bias + ReLU epilogue (hipBLASLt)
         else:
@@ -151,7 +157,9 @@ class _DenseFn(Function):
             # split partials of the weight gradient are summed by ONE launch per backward pass (ops.flush_dense_splits)
             mask = y if ctx.relu else None
             if mask is not None and ctx.relu_src is not None and ctx.relu_src.take(g2):
-                mask = None                        # the consumer's backward kernel masked its dx with y already
+                mask = None                        # the consumer's backward kernel masked (and, behind a fused dropout, scaled) its dx with y already
+            elif ctx.drop_scale != 1.0:
+                g2 = g2 * ctx.drop_scale           # (no consumer did it: d/d relu of relu * keep / (1 - rate), the keep part is the mask y > 0)
             db = None if bias is None else bias.grad
             if ctx.needs_input_grad[1]:
                 # input and weight gradient in ONE launch
@@ -167,11 +175,11 @@ class _DenseFn(Function):
                     link.grad_ptr = dx.data_ptr()
                 if ctx.grad_join is not None and ctx.grad_join.park(dx):
                     dx = None                      # added by the other consumer of x in its backward kernel
-                return None, dx, None, None, None, None, None, None, None
+                return None, dx, None, None, None, None, None, None, None, None
             # (no input gradient wanted: the first layer over a non-differentiable input.  Tried in round 2: the weight
             # gradient on a second stream beside the dgrad chain — DCN 0.319 vs 0.268 ms; removed)
             ops.dense_bwd_weights(x2, g2, mask, kernel.grad, db, defer=True)
-            return None, None, None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None, None, None
         if not g2.is_contiguous():
             g2 = g2.contiguous()
         if bias is not None and _hip(g2, g2.shape[1]):
@@ -188,7 +196,7 @@ class _DenseFn(Function):
             dx = torch.addmm(x2, g2, kernel.data.t(), beta=ctx.input_l2)
         else:
             dx = g2 @ kernel.data.t()
-        return None, dx.view(ctx.xshape), None, None, None, None, None, None, None
+        return None, dx.view(ctx.xshape), None, None, None, None, None, None, None, None
 
 
 class _Dense1Fn(Function):
@@ -276,9 +284,18 @@ def concat(values, axis: int = -1):
     return torch.cat(values, dim=axis)
 
 
+def dense_drop_supported(x, units: int) -> bool:
+    """dense(drop=) — the dropout behind a ReLU layer applied by the layer's own epilogue — is served for what the hand-written
+    forward kernel serves: a 2-D fp32 device tensor of up to DENSE_MAX_K features, outside Sync-BatchNorm."""
+    store = current_store()
+    return (not store.building and isinstance(x, torch.Tensor) and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32
+            and _mfma_dense(x.shape[1]) and int(units) % 4 == 0 and x.shape[0] * int(units) < (1 << 32)
+            and getattr(getattr(store.anchor, "_recalgo_store", None), "sync_bn", None) is None)
+
+
 def dense(x, units, activation: Optional[str] = None,
           use_bias: bool = True, name: Optional[str] = None, input_l2: float = 0.0,
-          grad_join: Optional[GradJoin] = None, bn_stats: bool = False) -> torch.Tensor:
+          grad_join: Optional[GradJoin] = None, bn_stats: bool = False, drop=None) -> torch.Tensor:
     """tf.layers.dense(x, units, activation=None|relu, use_bias, name).  `units` may be a
     str (the reference passes FLAGS.hidden_units.split(','), deepfm.py:286; quirk B-2).
     Variables: <scope>/<name>/kernel (glorot-uniform), <scope>/<name>/bias (zeros).
@@ -312,13 +329,39 @@ def dense(x, units, activation: Optional[str] = None,
             and _mfma_dense(x.shape[1]) and getattr(getattr(store.anchor, "_recalgo_store", None), "sync_bn", None) is None):
         from . import ops
         bn_part = torch.empty(ops.bn_partial_rows(x.shape[0]), 2 * units, device=x.device, dtype=torch.float32)
+    if drop is not None and (activation != "relu" or not dense_drop_supported(x, units)):
+        raise ValueError("dense(drop=) needs activation='relu' and nn.dense_drop_supported(x, units)")
     relu_src = ReluSource() if (activation == "relu" and not store.building) else None
-    out = _DenseFn.apply(store.anchor, x, kernel, bias, activation == "relu", input_l2, grad_join, bn_part, relu_src)
+    out = _DenseFn.apply(store.anchor, x, kernel, bias, activation == "relu", input_l2, grad_join, bn_part, relu_src, drop)
     if bn_part is not None:
         out._recalgo_bn_partials = bn_part
     if relu_src is not None:
         out._recalgo_relu_src = relu_src
+        if drop is not None:
+            out._recalgo_relu_scale = float(drop.scale)      # (a consumer that masks its dx with this tensor also scales it)
     return out
+
+
+def dense_relu_dropout_bn(x, units, dropout_rate, batch_norm: bool, training: bool) -> torch.Tensor:
+    """One hidden layer of the DeepFM / PNN / FiBiNET / NFM MLPs (/root/reference algorithm/DeepFM/deepfm.py:207-211):
+        net = tf.layers.dense(net, unit, activation=tf.nn.relu)
+        if "dropout_rate" in params and 0.0 < params["dropout_rate"] < 1.0: net = tf.layers.dropout(net, rate, training=...)
+        if params["batch_norm"]: net = tf.layers.batch_normalization(net, training=...)
+    Same variables, scopes and arithmetic as the three calls.  In a training step with both the dropout and the BatchNorm on,
+    the dropout costs no launch: the dense layer's epilogue applies it (and leaves the BatchNorm's tile moments of the DROPPED
+    tensor), and the BatchNorm's backward — which masks its input gradient with that tensor anyway — scales it by 1 / (1 - rate)."""
+    rate = float(dropout_rate) if dropout_rate is not None else 0.0
+    drop_on = bool(training) and 0.0 < rate < 1.0
+    if drop_on and batch_norm and isinstance(x, torch.Tensor) and dense_drop_supported(x, units):
+        d = drop_spec((x.shape[0], int(units)), rate, x.device)
+        net = dense(x, units, activation="relu", bn_stats=True, drop=d)
+        return batch_normalization(net, training=True)
+    net = dense(x, units, activation="relu", bn_stats=bool(batch_norm) and bool(training) and not drop_on)
+    if 0.0 < rate < 1.0:
+        net = dropout(net, rate, training=training)
+    if batch_norm:
+        net = batch_normalization(net, training=training)
+    return net
 
 
 def dense_with(x: torch.Tensor, kernel: Variable, bias: Optional[Variable] = None, relu: bool = False) -> torch.Tensor:
@@ -347,6 +390,7 @@ class _BatchNormTrainFn(Function):
         ctx.vars = (gamma, beta)
         ctx.hip = x.dim() == 2 and x.is_contiguous() and _hip(x, x.shape[1])
         ctx.x_relu_src = getattr(x, "_recalgo_relu_src", None) if ctx.hip else None
+        ctx.x_relu_scale = float(getattr(x, "_recalgo_relu_scale", 1.0)) if ctx.x_relu_src is not None else 1.0
         # Sync-BatchNorm (parallel.attach_data_parallel(sync_batch_norm=True)): statistics over the GLOBAL batch
         ctx.sync = getattr(getattr(anchor, "_recalgo_store", None), "sync_bn", None)
         if ctx.sync is not None and not ctx.hip:
@@ -386,10 +430,10 @@ class _BatchNormTrainFn(Function):
                 # layer's backward runs without mask loads (ReluSource)
                 src = ctx.x_relu_src
                 dx = ops.batchnorm_train_bwd(x, gamma.data, mean, rstd, g.contiguous(), gamma.grad, beta.grad,
-                                             sums=ctx.link.take(g), relu_x=src is not None)
+                                             sums=ctx.link.take(g), relu_x=src is not None, relu_scale=ctx.x_relu_scale)
                 if src is not None:
                     src.premasked = dx
-            return None, dx, None, None, None, None, None, None, None
+            return None, dx, None, None, None, None, None, None, None, None
         xhat, rstd = ctx.saved_tensors
         B = g.shape[0]
         dbeta = g.sum(dim=0)
@@ -397,7 +441,7 @@ class _BatchNormTrainFn(Function):
         gamma.grad.copy_(dgamma)
         beta.grad.copy_(dbeta)
         dx = (gamma.data * rstd / B) * (B * g - dbeta - xhat * dgamma)
-        return None, dx, None, None, None, None, None, None, None
+        return None, dx, None, None, None, None, None, None, None, None
 
 
 class _BatchNormInferFn(Function):
@@ -439,14 +483,19 @@ class _DenseActBNFn(Function):
 
     @staticmethod
     def forward(ctx, anchor, x, kernel: Variable, bias: Variable, alpha: Variable, kind: int, gamma: Variable, beta: Variable,
-                mmean: Variable, mvar: Variable, momentum: float, eps: float, input_l2: float):
+                mmean: Variable, mvar: Variable, momentum: float, eps: float, input_l2: float, drop=None):
         from . import ops
         x2 = x if x.stride(1) == 1 else x.contiguous()
         M, N = x2.shape[0], kernel.data.shape[1]
         partials = torch.empty(ops.bn_partial_rows(M), 2 * N, device=x.device, dtype=torch.float32)
         z, y = ops.dense_fwd_act(x2, kernel.data, bias.data, kind, alpha.data, partials)
-        out, mean, rstd = ops.batchnorm_train_fwd(y, gamma.data, beta.data, mmean.data, mvar.data, momentum, eps, partials=partials)
-        ctx.link = BNLink(y, mean, rstd)      # (the next dense layer's backward may leave this BN's sums; see _attach_link)
+        # drop: the tf.layers.dropout BEHIND the BatchNorm (din.py:233-236) rides in the BatchNorm's store, and in the loads of its backward
+        out, mean, rstd = ops.batchnorm_train_fwd(y, gamma.data, beta.data, mmean.data, mvar.data, momentum, eps, partials=partials,
+                                                  out_drop=drop)
+        ctx.drop = drop
+        # (the next dense layer's backward may leave this BN's sums, see _attach_link — not behind a dropout: they would be sums of
+        # the un-dropped gradient)
+        ctx.link = BNLink(y, mean, rstd) if drop is None else None
         ctx.in_link = _bn_link_of(x)                                 # (... and this one's those of the BatchNorm before it)
         ctx.vars, ctx.kind, ctx.input_l2 = (kernel, bias, alpha, gamma, beta), kind, float(input_l2)
         ctx.in_step = ops._loss_seed is not None      # Estimator.train_step: its optimizer runs the deferred column sums
@@ -459,7 +508,8 @@ class _DenseActBNFn(Function):
         kernel, bias, alpha, gamma, beta = ctx.vars
         x2, z, y, mean, rstd = ctx.saved_tensors
         dz = ops.batchnorm_train_bwd_act(y, gamma.data, mean, rstd, g.contiguous(), gamma.grad, beta.grad, ctx.kind, z, alpha.data,
-                                         alpha.grad, defer=ctx.in_step, sums=ctx.link.take(g))
+                                         alpha.grad, defer=ctx.in_step, sums=None if ctx.link is None else ctx.link.take(g),
+                                         g_drop=ctx.drop)
         dx = None
         if ctx.needs_input_grad[1]:
             link = ctx.in_link
@@ -470,16 +520,19 @@ class _DenseActBNFn(Function):
                 link.grad_ptr = dx.data_ptr()
         else:
             ops.dense_bwd_weights(x2, dz, None, kernel.grad, bias.grad, defer=True)
-        return (None, dx) + (None,) * 11
+        return (None, dx) + (None,) * 12
 
 
 def dense_activation_bn(x: torch.Tensor, units, kind: str, act_name, batch_norm: bool, training: bool,
-                        input_l2: float = 0.0, momentum: float = 0.99, epsilon: float = 1e-3) -> torch.Tensor:
-    """One hidden layer of DIN's `fcn` scope (/root/reference algorithm/DIN/din.py:262-266):
+                        input_l2: float = 0.0, momentum: float = 0.99, epsilon: float = 1e-3, dropout_rate=None) -> torch.Tensor:
+    """One hidden layer of DIN's `fcn` scope (/root/reference algorithm/DIN/din.py:227-236):
         net = tf.layers.dense(net, units, activation=None); net = dice | prelu (net, name=act_name)
         if batch_norm: net = tf.layers.batch_normalization(net, training=training)
-    Variables, scopes and arithmetic are those of the three calls; in a training step on the GPU the three run as ONE
-    autograd node (_DenseActBNFn), otherwise as the three layers."""
+        if "dropout_rate" in params and 0.0 < rate < 1.0: net = tf.layers.dropout(net, rate, training=training)   (dropout_rate=)
+    Variables, scopes and arithmetic are those of the calls; in a training step on the GPU they run as ONE autograd node
+    (_DenseActBNFn: the dropout in the BatchNorm's store and in the loads of its backward), otherwise as the separate layers."""
+    rate = float(dropout_rate) if dropout_rate is not None else 0.0
+    drop_on = bool(training) and 0.0 < rate < 1.0
     from . import ops
     store = current_store()
     units = int(units)
@@ -491,7 +544,8 @@ def dense_activation_bn(x: torch.Tensor, units, kind: str, act_name, batch_norm:
         net = dense(x, units, activation=None, name=dname, input_l2=input_l2)
         alpha = store.get_variable(f"{kind}_alpha_{act_name}", (units,), ones)
         net = ops.activation(store, net, alpha, kind)
-        return batch_normalization(net, training=training, momentum=momentum, epsilon=epsilon) if batch_norm else net
+        net = batch_normalization(net, training=training, momentum=momentum, epsilon=epsilon) if batch_norm else net
+        return dropout(net, rate, training=training) if 0.0 < rate < 1.0 else net
     with store.variable_scope(dname):
         kernel = store.get_variable("kernel", (x.shape[-1], units), glorot_uniform)
         bias = store.get_variable("bias", (units,), zeros)
@@ -501,8 +555,10 @@ def dense_activation_bn(x: torch.Tensor, units, kind: str, act_name, batch_norm:
         beta = store.get_variable("beta", (units,), zeros)
         mmean = store.get_variable("moving_mean", (units,), zeros, trainable=False)
         mvar = store.get_variable("moving_variance", (units,), ones, trainable=False)
-    return _attach_link(_DenseActBNFn.apply(store.anchor, x, kernel, bias, alpha, ops._ACT[kind], gamma, beta, mmean, mvar, momentum,
-                                            epsilon, input_l2))
+    d = drop_spec((x.shape[0], units), rate, x.device) if (drop_on and x.shape[0] * units < (1 << 32)) else None
+    out = _attach_link(_DenseActBNFn.apply(store.anchor, x, kernel, bias, alpha, ops._ACT[kind], gamma, beta, mmean, mvar, momentum,
+                                           epsilon, input_l2, d))
+    return dropout(out, rate, training=training) if (drop_on and d is None) else out
 
 
 DROPOUT_KEEP_MASKS: list = []      # test hook: keep masks consumed (FIFO) by the next training-mode dropout calls

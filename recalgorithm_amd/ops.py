@@ -1205,7 +1205,7 @@ def bn_partial_rows(rows: int) -> int:
 
 def dense_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu: bool,
               x2: Optional[torch.Tensor] = None, w2: Optional[torch.Tensor] = None,
-              bn_partials: Optional[torch.Tensor] = None) -> torch.Tensor:
+              bn_partials: Optional[torch.Tensor] = None, drop: Optional["DropSpec"] = None) -> torch.Tensor:
     """act(x @ w (+ x2 @ w2) + bias) on the fp32 matrix cores (include/recalgo.h recalgo_dense_fwd).  bn_partials
     [bn_partial_rows(M), 2 N]: the launch also leaves the per-tile batch moments of the result there (recalgo_dense_fwd_bn),
     for the BatchNorm layer that consumes it (batchnorm_train_fwd(..., partials=))."""
@@ -1221,6 +1221,14 @@ def dense_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], re
     y = torch.empty(M, N, device=x.device, dtype=torch.float32)
     if bn_partials is not None and (tuple(bn_partials.shape) != (bn_partial_rows(M), 2 * N) or not bn_partials.is_contiguous()):
         raise ValueError("dense_fwd: bn_partials must be a contiguous [bn_partial_rows(M), 2 N] tensor")
+    if drop is not None:
+        # the dropout behind the layer rides in the epilogue (recalgo_dense_fwd_drop): y, and the moments, are those of the dropped tensor
+        drop.check_mask((M, N))
+        cd, _keep = _cdrop(drop)
+        _lib.check(_lib_().recalgo_dense_fwd_drop(
+            _p(x), x.stride(0), _p(w), K, _p(x2), 0 if x2 is None else x2.stride(0), _p(w2), 0 if x2 is None else x2.shape[1],
+            _p(bias), M, N, int(relu), _p(y), N, _p(bn_partials), cd, _stream(x)), "recalgo_dense_fwd_drop")
+        return y
     _lib.check(_lib_().recalgo_dense_fwd_bn(
         _p(x), x.stride(0), _p(w), K, _p(x2), 0 if x2 is None else x2.stride(0), _p(w2), 0 if x2 is None else x2.shape[1],
         _p(bias), M, N, int(relu), _p(y), N, _p(bn_partials), _stream(x)), "recalgo_dense_fwd")
@@ -1446,14 +1454,25 @@ def dense1_bwd(parts, w: torch.Tensor, g: torch.Tensor, dxs, dw: torch.Tensor, d
                                       _p(ws), _stream(g)), "recalgo_dense1_bwd")
 
 
-def batchnorm_train_fwd(x, gamma, beta, moving_mean, moving_var, momentum: float, eps: float, partials=None):
+def batchnorm_train_fwd(x, gamma, beta, moving_mean, moving_var, momentum: float, eps: float, partials=None,
+                        out_drop: Optional["DropSpec"] = None):
     """partials: the per-tile moments of x when its producer has already left them (dense_fwd(bn_partials=)): ONE launch
-    (merge + apply) instead of two."""
+    (merge + apply) instead of two.  out_drop: the dropout BEHIND the BatchNorm rides in the store (recalgo_batchnorm_apply_drop)."""
     rows, C = x.shape
     lib = _lib_()
     y = torch.empty_like(x)
     mean = torch.empty(C, device=x.device, dtype=torch.float32)
     rstd = torch.empty(C, device=x.device, dtype=torch.float32)
+    if out_drop is not None:
+        out_drop.check_mask((rows, C))
+        if partials is None:
+            partials = torch.empty(bn_partial_rows(rows), 2 * C, device=x.device, dtype=torch.float32)
+            _lib.check(lib.recalgo_batchnorm_moments(_p(x), rows, C, _p(partials), _stream(x)), "recalgo_batchnorm_moments")
+        cd, _keep = _cdrop(out_drop)
+        _lib.check(lib.recalgo_batchnorm_apply_drop(_p(x), _p(gamma), _p(beta), _p(partials), 1, rows, C, eps, momentum,
+                                                    _p(moving_mean), _p(moving_var), _p(y), _p(mean), _p(rstd), cd, _stream(x)),
+                   "recalgo_batchnorm_apply_drop")
+        return y, mean, rstd
     if partials is not None:
         _lib.check(lib.recalgo_batchnorm_apply(_p(x), _p(gamma), _p(beta), _p(partials), 1, rows, C, eps, momentum,
                                                _p(moving_mean), _p(moving_var), _p(y), _p(mean), _p(rstd), _stream(x)),
@@ -1467,7 +1486,7 @@ def batchnorm_train_fwd(x, gamma, beta, moving_mean, moving_var, momentum: float
 
 
 def batchnorm_train_bwd_act(x, gamma, mean, rstd, g, dgamma, dbeta, kind: int, z, alpha, dalpha, defer: bool,
-                            sums=None) -> torch.Tensor:
+                            sums=None, g_drop: Optional["DropSpec"] = None) -> torch.Tensor:
     """BatchNorm backward continued through the per-channel activation x = act(z, alpha) (recalgo_batchnorm_train_bwd_act):
     -> dL/dz; dgamma / dbeta / dalpha are overwritten (`defer`: dalpha by the step's deferred-sum launch)."""
     rows, C = x.shape
@@ -1481,9 +1500,16 @@ def batchnorm_train_bwd_act(x, gamma, mean, rstd, g, dgamma, dbeta, kind: int, z
             ws = _dense_ws[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
     else:
         ws = _workspace(nbytes, x.device)
-    _lib.check(lib.recalgo_batchnorm_train_bwd_act(_p(x), _p(gamma), _p(mean), _p(rstd), _p(g), _p(sums), rows, C, int(kind), _p(z), _p(alpha),
-                                                   _p(dz), _p(dgamma), _p(dbeta), None if defer else _p(dalpha), _p(ws), 0,
-                                                   _stream(x)), "recalgo_batchnorm_train_bwd_act")
+    if g_drop is not None:
+        # the BatchNorm's output went through a dropout: g is read as g * keep / (1 - rate) (sums of the un-dropped g are of no use)
+        cd, _keep = _cdrop(g_drop)
+        _lib.check(lib.recalgo_batchnorm_train_bwd_drop(_p(x), _p(gamma), _p(mean), _p(rstd), _p(g), None, rows, C, int(kind), _p(z), _p(alpha),
+                                                        _p(dz), _p(dgamma), _p(dbeta), None if defer else _p(dalpha), _p(ws), 0, 1.0,
+                                                        cd, _stream(x)), "recalgo_batchnorm_train_bwd_drop")
+    else:
+        _lib.check(lib.recalgo_batchnorm_train_bwd_act(_p(x), _p(gamma), _p(mean), _p(rstd), _p(g), _p(sums), rows, C, int(kind), _p(z), _p(alpha),
+                                                       _p(dz), _p(dgamma), _p(dbeta), None if defer else _p(dalpha), _p(ws), 0,
+                                                       _stream(x)), "recalgo_batchnorm_train_bwd_act")
     if defer:
         nb = bn_partial_rows(rows)
         _colsum_pending.append((ws.view(torch.float32), nb * 2 * C, nb, C, C, dalpha))
@@ -1546,13 +1572,22 @@ def batchnorm_sync_bwd(x, gamma, mean, rstd, g, dgamma, dbeta, sync) -> torch.Te
     return dx
 
 
-def batchnorm_train_bwd(x, gamma, mean, rstd, g, dgamma, dbeta, sums=None, relu_x: bool = False) -> torch.Tensor:
+def batchnorm_train_bwd(x, gamma, mean, rstd, g, dgamma, dbeta, sums=None, relu_x: bool = False, relu_scale: float = 1.0,
+                        g_drop: Optional["DropSpec"] = None) -> torch.Tensor:
     """sums [bn_partial_rows(rows), 2 C]: the per-tile (colsum g | colsum g * xhat) rows when g's producer has left them
     (dense_bwd(bn=)): ONE launch (merge + apply) instead of two.  relu_x: x is a ReLU output — dx is zeroed where x <= 0
-    (the producing dense layer then needs no mask: nn.ReluSource)."""
+    (the producing dense layer then needs no mask: nn.ReluSource); relu_scale = 1 / (1 - rate) when x also went through a
+    dropout in front of this BatchNorm (dense(relu) -> dropout -> batch_norm).  g_drop: a dropout BEHIND this BatchNorm."""
     rows, C = x.shape
     lib = _lib_()
     dx = torch.empty_like(x)
+    if relu_scale != 1.0 or g_drop is not None:
+        ws = _workspace(lib.recalgo_batchnorm_bwd_act_workspace_bytes(rows, C), x.device)
+        cd, _keep = _cdrop(g_drop)
+        _lib.check(lib.recalgo_batchnorm_train_bwd_drop(_p(x), _p(gamma), _p(mean), _p(rstd), _p(g), None if g_drop is not None else _p(sums),
+                                                        rows, C, -1, None, None, _p(dx), _p(dgamma), _p(dbeta), None, _p(ws),
+                                                        int(relu_x), float(relu_scale), cd, _stream(x)), "recalgo_batchnorm_train_bwd_drop")
+        return dx
     if sums is not None:
         _lib.check(lib.recalgo_batchnorm_bwd_apply(_p(x), _p(gamma), _p(mean), _p(rstd), _p(g), _p(sums), 1, 0, rows, C, _p(dx),
                                                    _p(dgamma), _p(dbeta), int(relu_x), _stream(x)), "recalgo_batchnorm_bwd_apply")
@@ -1654,7 +1689,9 @@ class _LogitLossFn(Function):
         need = ctx.needs_input_grad[6:6 + n_parts]
         dxs = [torch.empty_like(t) if nd else None for t, nd in zip(parts, need)]
         # a part that IS the ReLU output of a dense layer gets its gradient already masked (nn.ReluSource)
-        srcs = [getattr(t, "_recalgo_relu_src", None) if nd else None for t, nd in zip(parts, need)]
+        # (not one that also went through a fused dropout: the mask here does not scale — its producer masks and scales itself)
+        srcs = [getattr(t, "_recalgo_relu_src", None) if (nd and getattr(t, "_recalgo_relu_scale", 1.0) == 1.0) else None
+                for t, nd in zip(parts, need)]
         relu_flags = (ctypes.c_int * n_parts)(*[int(sr is not None) for sr in srcs])
         lb = labels.contiguous().view(-1).to(torch.float32)
         wi = (ctypes.c_int * n_parts)(*widths)
@@ -1830,6 +1867,24 @@ class DropSpec:
     @property
     def scale(self) -> float:
         return 1.0 / (1.0 - self.rate)
+
+    def check_mask(self, shape) -> None:
+        if self.mask is not None and (tuple(self.mask.shape) != tuple(shape) or self.mask.dtype != torch.float32
+                                      or not self.mask.is_contiguous()):
+            raise ValueError("dropout: the explicit keep mask must be a contiguous fp32 tensor of the dropped tensor's shape")
+
+
+class _CDrop(ctypes.Structure):              # include/recalgo.h recalgo_dropout_t
+    _fields_ = [("rate", ctypes.c_double), ("keep_mask", ctypes.c_void_p), ("seed", ctypes.c_uint), ("call", ctypes.c_uint),
+                ("step", ctypes.c_void_p)]
+
+
+def _cdrop(d: Optional["DropSpec"]):
+    """-> (byref argument or None, keep-alive)"""
+    if d is None:
+        return None, None
+    c = _CDrop(d.rate, None if d.mask is None else d.mask.data_ptr(), d.seed, d.call, None if d.step is None else d.step.data_ptr())
+    return ctypes.byref(c), c
 
 
 def _dropout_launch(fn_name: str, x: torch.Tensor, d: DropSpec) -> torch.Tensor:

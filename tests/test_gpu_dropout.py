@@ -163,3 +163,55 @@ def test_captured_step_with_dropout_equals_eager(dev, model):
     estA.store.opt_state["step"] += 1
     k6 = ops.dropout_keep_mask((512, 64), d0, dev)
     assert 0.7 < float((k5 == k6).float().mean()) < 0.9
+
+
+@pytest.mark.parametrize("M,K,N", [(4096, 416, 512), (300, 82, 52), (65, 48, 8)])
+@pytest.mark.parametrize("explicit", [False, True])
+def test_dropout_in_the_dense_epilogue_and_the_batchnorm_kernels_equals_the_separate_launches(dev, M, K, N, explicit):
+    """recalgo_dense_fwd_drop / recalgo_batchnorm_apply_drop / recalgo_batchnorm_train_bwd_drop against the same layers with the
+    dropout as launches of its own (ops.dropout): bit-identical outputs, tile moments of the DROPPED tensor, and gradients."""
+    gen = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=gen).to(dev)
+    w = (torch.randn(K, N, generator=gen) / K ** 0.5).to(dev)
+    b = (torch.randn(N, generator=gen) * 0.1).to(dev)
+    gamma, beta = (torch.rand(N, generator=gen) + 0.5).to(dev), torch.randn(N, generator=gen).to(dev)
+    g = torch.randn(M, N, generator=gen).to(dev)
+    mask = (torch.rand(M, N, generator=gen) >= 0.2).float().to(dev) if explicit else None
+    d = _spec(0.2, dev, mask, call=3, step=7)
+    s = torch.tensor(d.scale, dtype=torch.float32, device=dev)
+    keep = mask if explicit else ops.dropout_keep_mask((M, N), d, dev)
+    # ---- dense(relu) -> dropout -> batch_norm (deepfm.py:207-211) ----
+    nb = ops.bn_partial_rows(M)
+    part = torch.full((nb, 2 * N), float("nan"), device=dev)
+    y = ops.dense_fwd(x, w, b, True, bn_partials=part, drop=d)
+    y0 = ops.dense_fwd(x, w, b, True)
+    assert_bit_exact(y, y0 * (keep * s), "dense epilogue dropout")
+    if N % 4 == 0:
+        want = torch.empty(nb, 2 * N, device=dev)
+        from recalgorithm_amd import _lib
+        _lib.check(_lib.load().recalgo_batchnorm_moments(ops._p(y), M, N, ops._p(want), ops._stream(y)), "moments")
+        assert_close(part[:, :N], want[:, :N].double(), what="tile means of the dropped tensor")
+        assert_close(part[:, N:], want[:, N:].double(), what="tile M2 of the dropped tensor", reduced=True)
+        mm, mv = torch.zeros(N, device=dev), torch.ones(N, device=dev)
+        o, mean, rstd = ops.batchnorm_train_fwd(y, gamma, beta, mm, mv, 0.99, 1e-3, partials=part)
+        # BatchNorm backward: masks dx with x (= the dropped ReLU output) and scales it by 1 / (1 - rate) ...
+        dg, db_ = torch.empty(N, device=dev), torch.empty(N, device=dev)
+        dx = ops.batchnorm_train_bwd(y, gamma, mean, rstd, g, dg, db_, relu_x=True, relu_scale=d.scale)
+        # ... == the plain BatchNorm backward followed by the dropout's and the ReLU's
+        dg0, db0 = torch.empty(N, device=dev), torch.empty(N, device=dev)
+        dx0 = ops.batchnorm_train_bwd(y, gamma, mean, rstd, g, dg0, db0)
+        assert_bit_exact(dx, torch.where(y > 0, dx0 * s, torch.zeros_like(dx0)), "dx through the fused dropout + ReLU")
+        assert torch.equal(dg, dg0) and torch.equal(db_, db0)
+        # ---- batch_norm -> dropout (din.py:233-236) ----
+        mm2, mv2 = torch.zeros(N, device=dev), torch.ones(N, device=dev)
+        od, mean2, rstd2 = ops.batchnorm_train_fwd(y0, gamma, beta, mm2, mv2, 0.99, 1e-3, out_drop=d)
+        mm3, mv3 = torch.zeros(N, device=dev), torch.ones(N, device=dev)
+        o3, mean3, rstd3 = ops.batchnorm_train_fwd(y0, gamma, beta, mm3, mv3, 0.99, 1e-3)
+        assert_bit_exact(od, o3 * (keep * s), "BatchNorm store dropout")
+        assert torch.equal(mean2, mean3) and torch.equal(rstd2, rstd3) and torch.equal(mm2, mm3)
+        dg1, db1 = torch.empty(N, device=dev), torch.empty(N, device=dev)
+        dxa = ops.batchnorm_train_bwd(y0, gamma, mean3, rstd3, g, dg1, db1, g_drop=d)
+        dg2, db2 = torch.empty(N, device=dev), torch.empty(N, device=dev)
+        dxb = ops.batchnorm_train_bwd(y0, gamma, mean3, rstd3, g * (keep * s), dg2, db2)
+        assert_bit_exact(dxa, dxb, "BatchNorm backward reading g through the dropout")
+        assert torch.equal(dg1, dg2) and torch.equal(db1, db2)
