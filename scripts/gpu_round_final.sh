@@ -5,7 +5,7 @@
 # usage: scripts/gpu_round_final.sh <tag>
 TAG=${1:-r02}
 R=$PWD; O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
-timeout 1200 python -m pytest tests -m gpu -q > $O/${TAG}_pytest_gpu_full.log 2>&1; grep -v "^| tests" $O/${TAG}_pytest_gpu_full.log | tail -40 > $O/${TAG}_pytest_gpu.log
+timeout 1700 python -m pytest tests -m gpu -q > $O/${TAG}_pytest_gpu_full.log 2>&1; grep -v "^| tests" $O/${TAG}_pytest_gpu_full.log | tail -40 > $O/${TAG}_pytest_gpu.log
 cp $O/strict_parity.md $O/${TAG}_strict_parity_all_gpu_tests.md 2>/dev/null
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/${TAG}_smoke.log 2>&1
 timeout 400 python bench.py > $O/bench_${TAG}_default.json 2> $O/bench_${TAG}_default.err
@@ -23,6 +23,9 @@ bash scripts/gpu_pmc_sq.sh $TAG xdeepfm SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_M
 timeout 400 python bench.py --model deepfm --big-table-rows 100000000 --no-cpu-baseline --no-host-fed --sweep-batches 0 > $O/bench_${TAG}_deepfm_100M.json 2> $O/bench_${TAG}_deepfm_100M.err
 timeout 300 python scripts/bench_tfrecord.py --examples 131072 --epochs 60 > $O/bench_${TAG}_tfrecord_e2e.json 2> $O/bench_${TAG}_tfrecord_e2e.err
 RECALGO_READER_THREADS=64 timeout 300 python scripts/bench_tfrecord.py --examples 131072 --epochs 60 > $O/bench_${TAG}_tfrecord_e2e_64threads.json 2> $O/bench_${TAG}_tfrecord_e2e_64threads.err
+# round 6: the DIN attention lab (plain kernel times + per-phase timeline) and the cost of the reference's default dropout
+bash scripts/gpu_din_lab.sh 50 > $O/${TAG}_din_lab.md 2>&1
+bash scripts/gpu_dropout_cost.sh deepfm din pnn fibinet > $O/${TAG}_dropout_cost.md 2>&1
 tail -3 $O/${TAG}_pytest_gpu.log; tail -2 $O/${TAG}_smoke.log
 for f in $O/bench_${TAG}_*.json; do python - "$f" <<'PY'
 import json, sys
