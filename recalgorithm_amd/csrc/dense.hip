@@ -760,21 +760,10 @@ __global__ __launch_bounds__(256) void dense_sum_slabs_kernel(SplitJobs J) {
     if (jb.vec) {
         const size_t i = t * 4;
         if (i >= jb.n) return;
-        // the slab loads are independent: up to sixteen in flight per thread (a layer's 6 .. 16 batch splits in ONE round trip;
-        // four at a time was 2 .. 4 dependent round trips, most of this launch), added in slab order (the sum's order is fixed)
+        // the slab loads are independent: four in flight per thread, added in slab order (the sum's order is fixed)
         const float* base = jb.partials + i;
         float4 acc = *reinterpret_cast<const float4*>(base);
         int s = 1;
-        if (jb.S <= 16) {
-            float4 a[15];
-#pragma unroll
-            for (int u = 0; u < 15; ++u)
-                if (u + 1 < jb.S) a[u] = *reinterpret_cast<const float4*>(base + (size_t)(u + 1) * jb.slab);
-#pragma unroll
-            for (int u = 0; u < 15; ++u)
-                if (u + 1 < jb.S) acc = f4_add(acc, a[u]);
-            s = jb.S;
-        }
         for (; s + 4 <= jb.S; s += 4) {
             const float4 a0 = *reinterpret_cast<const float4*>(base + (size_t)s * jb.slab);
             const float4 a1 = *reinterpret_cast<const float4*>(base + (size_t)(s + 1) * jb.slab);

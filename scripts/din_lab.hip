@@ -47,8 +47,8 @@ int main(int argc, char** argv) {
         unsigned long long tl[32];
         hipMemcpyFromSymbol(tl, HIP_SYMBOL(din16::din16_tl), sizeof(tl));
         printf("bwd rc %d  %.1f us (instrumented)\n", rc, ms * 1e3);
-        const char* names[] = {"begin_example", "tile prologue (prefetch issue)", "fwd_tile", "d2 (layer 3 / 2 gradients)",
-                               "dH1 chain + P / Q / R stores + mask", "dX chain + P2 stores", "dW2 GEMM", "(barrier)", "dWx GEMM + rowsums",
+        const char* names[] = {"begin_example (q / g -> scratch, cq)", "tile prologue (next key row requested)", "fwd_tile (layers 1-3)",
+                               "d2 + P / Q stores", "dH1 chain", "dW2 GEMM", "mask + P / R stores", "dX chain", "dWx GEMM + row sums",
                                "dcq / dWq / dk / dq + stores", "dq finalize", "final reduction + partial row", "weights staging + first row"};
         unsigned long long tot = 0;
         for (int i = 0; i < 13; ++i) tot += tl[i];
