@@ -673,6 +673,24 @@ def dense_layer_table(args, d):
     return [d, 512, 256, 128], None
 
 
+def cpu_quota():
+    """CPUs the container may USE (cgroup CFS quota / period), as opposed to the hardware threads it can SEE: the GPU boxes of this
+    pool show 256 hardware threads under a quota of 16 CPUs (`cpu.max` = 1600000 100000) — more runnable threads than that are
+    throttled, which is what "the reader anti-scales beyond 32 threads" and "one oracle step takes 56 s at 256 threads" were.
+    None: no quota."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(p), 2)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / p, 2)
+    except (OSError, ValueError):
+        return None
+
+
 def composite_roofline(ks, ms_per_step):
     """The whole step against its kernels' rooflines: sum over the step's hand-written kernels of t_min = max(algorithmic
     bytes / HBM peak, algorithmic FLOP / fp32 MFMA peak), divided by the measured step time (launch gaps, latency-bound
@@ -882,6 +900,8 @@ def cpu_baseline(args, seconds):
     # definition); `value` / `cores` are those of the fastest sample, the others are `other_samples`
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     a = child(avail if avail > 32 else None, seconds)
+    a["host_hardware_threads"] = avail
+    a["host_cpu_quota"] = cpu_quota()         # (a cgroup quota below the thread count: the sample ran on that many CPUs' worth of time)
     others = a.get("other_samples") or []
     best = max(others, key=lambda o: o.get("value") or 0, default=None)
     if best and (best.get("value") or 0) > (a.get("value") or 0):
@@ -1139,6 +1159,7 @@ def main():
     if rank == 0:
         out["box"] = box_sanity(device)
         out["box"]["host_cores"] = os.cpu_count()
+        out["box"]["host_cpu_quota"] = cpu_quota()       # CPUs the cgroup lets the process USE (None: no quota); host_cores = hardware threads visible
     cs = sorted(r["chunk_ms"])
     if cs:          # spread of the per-chunk step times (median and p10 / p90)
         pick = lambda q: cs[min(len(cs) - 1, int(q * len(cs)))]

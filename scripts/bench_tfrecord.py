@@ -19,6 +19,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _cpu_quota():
+    """CPUs the cgroup lets the process use (None: no quota) — see bench.cpu_quota."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(p), 2)
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--examples", type=int, default=32768)
@@ -85,7 +94,7 @@ def main():
         "metric": "CTR examples/sec from TFRecord bytes (string keys) to the training step, DCN, batch %d" % a.batch,
         "value": round(steps * a.batch / dt, 1), "unit": "examples/s", "steps": steps,
         "ms_per_step": round(dt / max(steps, 1) * 1e3, 3), "reader_only_examples_per_s": round(reader_rate, 1),
-        "host": {"cores": os.cpu_count(), "reader_threads": reader_threads, "reader_ex_s": round(reader_rate, 1),
+        "host": {"cores": os.cpu_count(), "cpu_quota": _cpu_quota(), "reader_threads": reader_threads, "reader_ex_s": round(reader_rate, 1),
                  "reader": "asynchronous pipeline (recalgo_pipeline_*)" if os.environ.get("RECALGO_READER_PIPELINE", "1") != "0"
                  else "synchronous accessors"},
         "examples": a.examples, "epochs": a.epochs, "shuffle_buffer": 10000,
