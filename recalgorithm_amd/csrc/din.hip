@@ -646,10 +646,14 @@ __device__ __forceinline__ void lds_vec16(const float* p, float (&v)[H]) {
 
 // per example: q (and the upstream gradient g) into the wave's scratch — one coalesced load, read back as broadcasts where they
 // are used (32 registers fewer than holding them) — and cq[j] = b1[j] + sum_i q_i (W1a + W1c)[i][j] (lane = j)
-__device__ __forceinline__ void begin_example(const Lane& L, const Weights& W, FwdScratch& sc, const float* __restrict__ qrow,
-                                              const float* __restrict__ grow) {
-    if (L.lane < (unsigned)H) sc.qg[L.lane] = qrow[L.lane];
-    else if (L.lane < 2u * H && grow != nullptr) sc.qg[L.lane] = grow[L.lane - H];
+// lane i < 16: q[i], 16 <= i < 32: g[i - 16] of an example (one coalesced load; 0 elsewhere / without a gradient row)
+__device__ __forceinline__ float load_qg(const Lane& L, const float* __restrict__ qrow, const float* __restrict__ grow) {
+    if (L.lane < (unsigned)H) return qrow[L.lane];
+    if (L.lane < 2u * H && grow != nullptr) return grow[L.lane - H];
+    return 0.f;
+}
+__device__ __forceinline__ void begin_example(const Lane& L, const Weights& W, FwdScratch& sc, float qg) {
+    if (L.lane < 2u * H) sc.qg[L.lane] = qg;
     __builtin_amdgcn_wave_barrier();
     float c = W.b1[L.lane], q[H];
     lds_vec16(sc.qg, q);
@@ -779,7 +783,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         load_row(L, ex, 0, T, keys, k[0]);
         load_row(L, ex, 1, T, keys, k[1]);
         const int len = keys_length[ex];
-        begin_example(L, W, sc, query + (size_t)ex * H, nullptr);
+        begin_example(L, W, sc, load_qg(L, query + (size_t)ex * H, nullptr));
         float s[2] = {0.f, 0.f}, xb[H];
         f32x16 a1[2], a2;
         s[0] = fwd_tile(L, W, sc, k[0], a1, a2, xb);
@@ -977,12 +981,17 @@ __global__ __launch_bounds__(kThreads) void bwd_kernel(
 
     // the wave walks (example, tile) pairs; the key row of the NEXT pair is requested before the current pair's matrix work
     unsigned ex = blockIdx.x * kWaves + wave;
-    float kc[H];
-    if (ex < B) load_row(L, ex, 0, T, keys, kc);
+    float kc[H], qg = 0.f;
+    if (ex < B) {
+        load_row(L, ex, 0, T, keys, kc);
+        qg = load_qg(L, query + (size_t)ex * H, g_out + (size_t)ex * ldg);
+    }
     DIN16_TL_BEGIN();
     DIN16_TL(12);
     for (; ex < B; ex += stride) {
-        begin_example(L, W, sc, query + (size_t)ex * H, g_out + (size_t)ex * ldg);
+        begin_example(L, W, sc, qg);
+        // (the next example's q / g row is requested now, a whole example of matrix work ahead of its use)
+        if (ex + stride < B) qg = load_qg(L, query + (size_t)(ex + stride) * H, g_out + (size_t)(ex + stride) * ldg);
         DIN16_TL(0);
         // (the query's other gradient, added at the very end: requested here, not in front of the store)
         float dq_add[8];
