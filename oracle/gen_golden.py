@@ -396,6 +396,8 @@ def model_goldens(tf, vocab_dir):
                  "dropout_rate": m.FLAGS.dropout_rate, "batch_norm": m.FLAGS.batch_norm}, dense_c + cat)
     run("model_nfm", _import_ref("NFM", "nfm"), "nfm_model_fn", nfm_params,
         dict(common, embedding_dim=8, dropout_rate=0.0, batch_norm=True))
+    run("model_nfm_dropout", _import_ref("NFM", "nfm"), "nfm_model_fn", nfm_params,          # nfm.py:41 default rate: dense -> BN -> dropout
+        dict(common, embedding_dim=8, dropout_rate=0.1, batch_norm=True))
 
     # the shared batch
     batch = {"dense": dense, "labels": labels, "dense_names": np.array(DENSE)}

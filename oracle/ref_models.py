@@ -254,12 +254,11 @@ def nfm(P, feats, labels, params, training=False, dropout_masks=None):
     x = 0.5 * (s_ ** 2 - q_)                                                                                    # :163-167
     b = "bi_interaction_part/bi_interaction_bn"
     x = R.batch_norm(x, P[f"{b}/gamma"], P[f"{b}/beta"], P[f"{b}/moving_mean"], P[f"{b}/moving_variance"], training)  # :168
+    masks = list(dropout_masks or [])
     if training:                                                                                                # :170
-        if not dropout_masks:
+        if not masks:
             raise ValueError("nfm(training=True) needs the keep mask of the hard-coded dropout (rate 0.1)")
-        x = x * dropout_masks[0] / 0.9
-    if 0.0 < float(params.get("dropout_rate", 0.0)) < 1.0 and training:
-        raise NotImplementedError("the MLP dropouts are only restated at rate 0")
+        x = x * masks.pop(0).to(x.dtype) / 0.9
     net = x
     for i, _ in enumerate(params["hidden_units"]):                                                              # :174-180
         dn = "dense" if i == 0 else f"dense_{i}"
@@ -268,6 +267,7 @@ def nfm(P, feats, labels, params, training=False, dropout_masks=None):
             bn = "batch_normalization" if i == 0 else f"batch_normalization_{i}"
             net = R.batch_norm(net, P[f"dnn_part/{bn}/gamma"], P[f"dnn_part/{bn}/beta"],
                                P[f"dnn_part/{bn}/moving_mean"], P[f"dnn_part/{bn}/moving_variance"], training)
+        net = _dropout(net, params, training, masks)                                                            # :178-179 (behind the BN)
     n = len(params["hidden_units"])
     dn = "dense" if n == 0 else f"dense_{n}"
     nfm_logit = R.dense(net, P[f"dnn_part/{dn}/kernel"], P[f"dnn_part/{dn}/bias"])                               # :181

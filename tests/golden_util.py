@@ -12,7 +12,7 @@ MODELS = ["model_deepfm", "model_dcn", "model_xdeepfm", "model_din_dice", "model
           "model_pnn_opnn_reg", "model_fwfm", "model_nfm", "model_afm", "model_ffm",
           # the reference's default dropout_rate (0.1) switched on: keep masks in aux/dropout_mask_<i>
           "model_deepfm_dropout", "model_din_dice_dropout", "model_fibinet_all_dropout", "model_pnn_ipnn_dropout",
-          "model_pnn_ipnn_dropout_nobn"]
+          "model_pnn_ipnn_dropout_nobn", "model_nfm_dropout"]
 
 
 def dropout_masks(d):
@@ -120,7 +120,7 @@ def mirror_setup(name, vocab_dir):
         first, second, _ = m.create_feature_columns()
         return m.fwfm_model_fn, {"first_order_feature_columns": first, "second_order_feature_columns": second,
                                  "embedding_dim": int(fl["embedding_dim"]), "learning_rate": lr}, "fwfm"
-    if name == "model_nfm":
+    if name.startswith("model_nfm"):
         from recalgorithm_amd.algorithm.NFM import nfm as m
         dense, cat, _ = m.create_feature_columns()
         return m.nfm_model_fn, {"dense_feature_columns": dense, "category_feature_columns": cat, "hidden_units": hidden,
