@@ -786,8 +786,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         begin_example(L, W, sc, load_qg(L, query + (size_t)ex * H, nullptr));
         float s[2] = {0.f, 0.f}, xb[H];
         f32x16 a1[2], a2;
-        s[0] = fwd_tile(L, W, sc, k[0], a1, a2, xb);
-        if (ntile > 1) s[1] = fwd_tile(L, W, sc, k[1], a1, a2, xb);
+        // (default branch: a tile without a row inside the history's length only produces weights that are masked to 0)
+        if (is_softmax || len > 0) s[0] = fwd_tile(L, W, sc, k[0], a1, a2, xb);
+        if (ntile > 1 && (is_softmax || len > 32)) s[1] = fwd_tile(L, W, sc, k[1], a1, a2, xb);
         const float dw0[2] = {0.f, 0.f};
         const AttnW a = attention<false>(L, s, T, len, is_softmax, dw0);
         float o[8];
@@ -813,11 +814,13 @@ struct BwdAcc {                  // weight-gradient accumulators of a wave (regi
 };
 
 // backward of one 32-row tile (forward state a1 / a2 / xb of THIS tile in registers)
-__device__ __forceinline__ void bwd_tile(const Lane& L, const Weights& W, Scratch& sc, BwdAcc& A, unsigned tile, unsigned T,
+__device__ __forceinline__ void bwd_tile(const Lane& L, const Weights& W, Scratch& sc, BwdAcc& A, unsigned tile, unsigned T, unsigned Tv,
                                          unsigned ex, const float (&k)[H], const f32x16 (&a1)[2], const f32x16& a2,
                                          const float (&xb)[H], float w, float ds, float (&dqacc)[8], float* __restrict__ dkeys DIN16_TL_ARG) {
     const unsigned col = tcol(L.l32);
-    const unsigned valid = T - tile * 32 < 32 ? T - tile * 32 : 32;     // rows of this tile inside T
+    // rows of this tile that can carry a non-zero gradient: inside T, and — default branch — inside the example's history
+    // (Tv = min(T, length): a row beyond it has weight 0 and d score 0, hence dH2 = dH1 = 0)
+    const unsigned valid = Tv <= tile * 32 ? 0u : (Tv - tile * 32 < 32 ? Tv - tile * 32 : 32u);
     const unsigned u_end = (valid + 1) / 2;                             // K steps (t = 2u + hi) that can carry non-zero rows
     // ---- layer 3 / 2 gradients in registers: dW3, dH2^T, db2 ----
     f32x16 d2;
@@ -1029,9 +1032,16 @@ __global__ __launch_bounds__(kThreads) void bwd_kernel(
             }
             aw = attention<true>(L, s, T, len, 1, dwt);
         }
-        for (unsigned tile = 0; tile < ntile; ++tile) {
+        // default branch: a row at or beyond the history's length has weight 0 AND d score 0 — it contributes exactly nothing to
+        // any gradient and its own dk is 0: tiles that hold only such rows are skipped (their dk rows are written as zeros).
+        // Histories of <= 32 items cost one tile, empty ones none.  (Softmax: a padded row's weight is exp(-2^32 / 4 - max), not
+        // structurally zero when the history is empty — din_attention.py:31-35 — so that branch walks every tile.)
+        const unsigned Tv = SOFTMAX ? T : (len <= 0 ? 0u : ((unsigned)len < T ? (unsigned)len : T));
+        const unsigned nt_ex = SOFTMAX ? ntile : (Tv + 31) / 32;
+        if (nt_ex == 0 && ex + stride < B) load_row(L, ex + stride, 0, T, keys, kc);      // (nothing to overlap the request with)
+        for (unsigned tile = 0; tile < nt_ex; ++tile) {
             float kn[H];
-            const bool last = tile + 1 == ntile;
+            const bool last = tile + 1 == nt_ex;
             const unsigned nex = last ? ex + stride : ex, ntl = last ? 0 : tile + 1;
             if (nex < B) load_row(L, nex, ntl, T, keys, kn);
             f32x16 a1[2], a2;
@@ -1054,10 +1064,18 @@ __global__ __launch_bounds__(kThreads) void bwd_kernel(
                 w = in_len ? sv : 0.f;
                 ds = in_len ? d : 0.f;
             }
-            bwd_tile(L, W, sc, A, tile, T, ex, kc, a1, a2, xb, w, ds, dqacc, dkeys DIN16_TL_PASS);
+            bwd_tile(L, W, sc, A, tile, T, Tv, ex, kc, a1, a2, xb, w, ds, dqacc, dkeys DIN16_TL_PASS);
             if (nex < B) {
 #pragma unroll
                 for (int i = 0; i < H; ++i) kc[i] = kn[i];
+            }
+        }
+        for (unsigned tile = nt_ex; tile < ntile; ++tile) {            // skipped tiles: dk = 0
+            const unsigned t = tile * 32 + L.l32;
+            if (t < T) {
+                float4* dkr = reinterpret_cast<float4*>(dkeys + ((size_t)ex * T + t) * H + 4 * L.hi);
+                dkr[0] = f4_zero();
+                dkr[2] = f4_zero();
             }
         }
         // ---- dq: the half wave's 8 columns, summed over its 32 lanes (rows t and columns j = l32, 32 + l32 of the fold) ----

@@ -15,6 +15,8 @@ int main(int argc, char** argv) {
     auto rnd = [] { return (float)rand() / RAND_MAX - 0.5f; };
     for (auto* v : {&hq, &hk, &hg, &w1, &b1, &w2, &b2, &w3, &b3}) for (auto& x : *v) x = rnd() * 0.5f;
     std::vector<int> hl(B, T);
+    if (argc > 2 && atoi(argv[2]) != 0)                    // ragged: lengths ~ U{0..T}
+        for (auto& l : hl) l = rand() % (T + 1);
     float *q, *k, *g, *W1, *B1, *W2, *B2, *W3, *B3, *dq, *dk, *ws, *o;
     int* len;
     auto up = [](float** d, const std::vector<float>& h) { hipMalloc(d, h.size() * 4); hipMemcpy(*d, h.data(), h.size() * 4, hipMemcpyHostToDevice); };
