@@ -575,7 +575,7 @@ def drop_spec(x_shape, rate: float, device):
     mask = None
     if DROPOUT_KEEP_MASKS:
         mask = DROPOUT_KEEP_MASKS.pop(0).to(device=device, dtype=torch.float32).reshape(tuple(x_shape)).contiguous()
-    rank = getattr(getattr(store, "sync_bn", None), "rank", 0) or 0
+    rank = 0                       # (data parallel: every rank drops its own slice of the global batch with its own stream)
     try:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
