@@ -531,9 +531,13 @@ def kernel_rooflines(args, est, feats, device):
     ptrs = lambda ts: (_ct.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
     wi = (_ct.c_int * len(head_parts))(*[t.shape[1] for t in head_parts])
     pa, pw, pdx = ptrs(head_parts), ptrs(hw), ptrs(hdx)
+    # (DCN's step runs head + loss inside the fused last-layer launch, below: the row stays in the table for reference only)
+    fused_tail = args.model == "dcn" and bool(lib.recalgo_tail_dense_head_supported(256, 128, d))
     add("logit_loss(head + sigmoid + CE + head backward)",
         lambda: lib.recalgo_logit_loss_fwd_bwd(pa, pw, wi, len(head_parts), p(hb), None, None, p(lbl), None, B, 1.0, p(lg), p(pr),
                                                p(dl), pdx, None, p(partials), st), B * (2 * Ch * 4 + 16) + rows_p * (Ch + 2) * 4)
+    if fused_tail:
+        res[-1]["part_of"] = "tail_dense_head"
     src_b, dst_b = torch.empty(B * F * 8 + B * 4, dtype=torch.uint8, device=device), torch.empty(B * F * 8 + B * 4, dtype=torch.uint8, device=device)
     add("input_copy(batch -> the graph's static buffers)",
         lambda: lib.recalgo_copy_bytes(p(dst_b), p(src_b), src_b.numel(), st), 2 * src_b.numel())
@@ -610,19 +614,56 @@ def kernel_rooflines(args, est, feats, device):
         yd = ops.dense_fwd(xd, wd, bd, True)
         dwd, dbd = torch.empty_like(wd), torch.empty_like(bd)
         fl = 2.0 * B * Kd * Nd
+        last_fused = fused_tail and li == len(widths) - 2
         add(f"dense_fwd({Kd}->{Nd})", lambda: ops.dense_fwd(xd, wd, bd, True), (B * (Kd + Nd) + Kd * Nd) * 4, fl)
         res[-1]["prof"] = ["dense_fwd_kernel", li + (1 if first_kind == "pnn" else 0)]
+        if last_fused:
+            # DCN's last hidden layer runs inside ONE launch with the head, the loss and the backward of all three down to
+            # the layer's input (csrc/tailfuse.hip, dcn.py:166-172); its weight gradient is a launch of its own.  The separate
+            # forward / merged-backward rows of this layer stay in the table for reference (`part_of`).
+            res[-1].pop("prof")
+            res[-1]["part_of"] = "tail_dense_head"
+            xd.clamp_(min=0)
+            side_t, wh_t = torch.randn(B, d, device=device), torch.randn(d + Nd, device=device) * 0.05
+            rows_t = int(lib.recalgo_tail_partial_rows(B))
+            part_t = torch.empty(rows_t, d + Nd + 2, device=device)
+            dsd_t, dz_t, dh_t = torch.empty_like(side_t), torch.empty(B, Nd, device=device), torch.empty_like(xd)
+            add(f"tail_dense_head(dense {Kd}->{Nd} + head over [{d} | {Nd}] + sigmoid-CE + backward to the layer's input)",
+                lambda: lib.recalgo_tail_dense_head_fwd_bwd(p(xd), Kd, p(wd), p(bd), Nd, p(side_t), d, 1, p(wh_t), p(wh_t[d:]), p(hb),
+                                                            p(lbl), None, B, 1.0, p(lg), p(pr), p(dl), p(dsd_t), p(dz_t), p(dh_t),
+                                                            p(part_t), st),
+                B * (2 * Kd + 2 * d + Nd + 16) * 4 + Kd * Nd * 4 + rows_t * (d + Nd + 2) * 4, 2.0 * fl)
+            res[-1]["prof"] = ["tail_dense_head_kernel", 0]
+            dwd, dbd = torch.empty_like(wd), torch.empty_like(bd)
+
+            n_pend = len(ops._dense_pending)
+
+            def wgrad_once():
+                ops.dense_bwd_weights(xd, dz_t, None, dwd, dbd, defer=True)
+                del ops._dense_pending[n_pend:]
+            add(f"dense_wgrad({Kd}->{Nd}: the fused layer's weight gradient, slabs summed by the deferred-sum launch)", wgrad_once,
+                (B * (Kd + Nd) + Kd * Nd) * 4, fl)
+            res[-1]["prof"] = ["dense_wgrad_kernel", 0]
+            ops.dense_bwd_weights(xd, dz_t, None, dwd, dbd, defer=True)       # leaves the layer's split slabs + its pending entry
+            keep.append((xd, wd, bd, side_t, wh_t, part_t, dsd_t, dz_t, dh_t, dwd, dbd))
+            slab_bytes += int(lib.recalgo_dense_bwd_weights_workspace_bytes(B, Kd, Nd)) + (Kd * Nd + Nd) * 4
         # (the ONE merged launch, as in the step: the fixed-order sum of the batch-split slabs is a job of the step's
         #  deferred-sum launch, listed below — not a second launch per layer)
         # As in the step (nn.ReluSource): the gradient a layer receives was masked with its ReLU output by the kernel that
         # produced it (the layer above / the loss tail), so no mask is staged; a layer whose input is itself a ReLU output
         # (all but the first of a plain stack; every layer behind PNN's / FiBiNET's first one) masks the input gradient it writes.
         pm = xd.clamp_(min=0) if (li > 0 or first_kind is not None) else None
+        n_pend = len(ops._dense_pending)            # (the layers before this one keep their entries for the deferred-sum row)
+
         def bwd_once():
             ops.dense_bwd(xd, gd, None, wd, dwd, dbd, defer=True, premask=pm)
-            ops._dense_pending.clear()
+            del ops._dense_pending[n_pend:]
         add(f"dense_bwd({Kd}->{Nd})", bwd_once, (B * (2 * Kd + 2 * Nd + (Kd if pm is not None else 0)) + 2 * Kd * Nd) * 4, 2.0 * fl)
         res[-1]["prof"] = ["dense_bwd_kernel<true, false>", li]
+        if last_fused:
+            res[-1].pop("prof")
+            res[-1]["part_of"] = "tail_dense_head"
+            continue
         res[-1]["grad_zero_fraction"] = 0.5
         res[-1]["mask_mode"] = "gradient arrives pre-masked (no y mask staged)" + ("; dx masked with the layer's input" if pm is not None else "")
         ops.dense_bwd(xd, gd, None, wd, dwd, dbd, defer=True, premask=pm)          # leaves this layer's split slabs + its pending entry

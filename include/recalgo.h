@@ -544,6 +544,26 @@ int recalgo_logit_loss_fwd_bwd(const float* const* x_parts, const float* const* 
                                const float* loss_addend, int B, float grad_scale, float* logit, float* prob, float* dlogit,
                                float* const* dx_parts, const int* relu_parts, float* partials, recalgo_stream_t stream);
 
+/* The last hidden layer TOGETHER WITH that tail, in ONE launch (algorithm/DCN/dcn.py:166-172: the last tf.layers.dense(.., relu)
+ * of dnn_part, tf.concat([cross_vec, dnn_vec], -1), tf.layers.dense(output, 1), and the loss tail above):
+ *   h3 = relu(h2 w3 + b3)                               h2 [B, K2]: the ReLU output of the layer below; w3 [K2, N3], b3 [N3]
+ *   logit[b] = <side[b, :], w_side> + <h3[b, :], w_h3> + head_bias       side [B, Cs] (Cs = 0: no side part, side may be NULL)
+ *   prob, mean sigmoid-CE, dlogit as recalgo_logit_loss_fwd_bwd;  d_side = dlogit w_side (d_side may be NULL)
+ *   dz3 [B, N3] = dlogit w_h3 where h3 > 0, else 0        the gradient at the layer's pre-activation: its weight gradient is
+ *                                                         recalgo_dense_bwd_weights(h2, dz3, mask NULL, ..), a launch of its own
+ *   dh2 [B, K2] = (dz3 w3^T) where h2 > 0, else 0         (already masked for the layer that produced h2, see recalgo_dense_bwd_bn)
+ *   partials [recalgo_tail_partial_rows(B)][Cs + N3 + 2]: [dw over the head's concatenated columns | d bias | loss] per
+ *   workgroup, as recalgo_logit_loss_fwd_bwd's; side_first != 0: the head's columns are [side | h3] (dcn.py:171), else [h3 | side].
+ * h3 never reaches HBM.  Served shapes: recalgo_tail_dense_head_supported(K2, N3, Cs) (N3 == 128, K2 in {128, 256, 384, 512},
+ * Cs % 4 == 0, Cs <= 1024); h2, w3, side, d_side 16-byte aligned. */
+int recalgo_tail_partial_rows(int B);
+int recalgo_tail_dense_head_supported(int K2, int N3, int Cs);
+int recalgo_tail_dense_head_fwd_bwd(const float* h2, int K2, const float* w3, const float* b3, int N3, const float* side, int Cs,
+                                    int side_first, const float* w_side, const float* w_h3, const float* head_bias,
+                                    const float* labels, const float* loss_addend, int B, float grad_scale, float* logit,
+                                    float* prob, float* dlogit, float* d_side, float* dz3, float* dh2, float* partials,
+                                    recalgo_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * a15  TF1 AdamOptimizer, dense semantics (also what TF1 applies to embedding IndexedSlices:
  * duplicates summed, then m and v of ALL rows decay).  algorithm/DeepFM/deepfm.py:246-250.

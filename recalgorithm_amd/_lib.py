@@ -109,6 +109,10 @@ SIGNATURES = {
     "recalgo_dense_bwd_weights_reduce": (c_int, [P, c_int, P, c_int, P, P]),
     "recalgo_logit_loss_partial_rows": (c_int64, [c_int]),
     "recalgo_logit_loss_fwd_bwd": (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, P, P, P, P, P, P]),
+    "recalgo_tail_partial_rows": (c_int, [c_int]),
+    "recalgo_tail_dense_head_supported": (c_int, [c_int, c_int, c_int]),
+    "recalgo_tail_dense_head_fwd_bwd": (c_int, [P, c_int, P, P, c_int, P, c_int, c_int, P, P, P, P, P, c_int, c_float,
+                                                P, P, P, P, P, P, P, P]),
     "recalgo_bi_interaction_fwd": (c_int, [P, c_int, c_int, c_int, P, P]),
     "recalgo_bi_interaction_bwd": (c_int, [P, P, c_int, c_int, c_int, P, P]),
     "recalgo_attention_pool_fwd": (c_int, [P, P, c_int, c_int, c_int, P, P, P]),

@@ -105,7 +105,8 @@ def dcn_model_fn(features, labels, mode, params):
     with variable_scope("dnn_part"):
         dnn_vec = concat_all
         for i, unit in enumerate(params["hidden_units"]):
-            dnn_vec = nn.dense(dnn_vec, unit, activation="relu", name=f"dnn_dense_{i}", grad_join=join if i == 0 else None)
+            dnn_vec = nn.dense(dnn_vec, unit, activation="relu", name=f"dnn_dense_{i}", grad_join=join if i == 0 else None,
+                               last_hidden=(i == len(params["hidden_units"]) - 1))
 
     with variable_scope("output_part"):
         output = nn.concat([cross_vec, dnn_vec], axis=-1)       # read in place by the one-unit head (nn.LazyConcat)

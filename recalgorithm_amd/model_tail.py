@@ -23,12 +23,17 @@ def finish_model_fn(mode, logit: torch.Tensor, labels, params,
     from .nn import LazyLogit
     lazy = logit if isinstance(logit, LazyLogit) else None
     extra = None
-    if lazy is not None:
+    tail = lazy.tail() if (lazy is not None and mode == ModeKeys.TRAIN and not current_store().building) else None
+    if tail is not None and extra_loss is not None:
+        extra = extra_loss()
+        if extra is not None and extra.requires_grad:
+            tail = None
+    if lazy is not None and tail is None:
         ok = mode == ModeKeys.TRAIN and lazy.fusable() and not current_store().building
         if ok and extra_loss is not None:
             # the fused tail delivers the loss VALUE through the step's deferred sums: an extra term can only join it as
             # a detached addend (DIN's regulariser value; its gradient rides on the first fcn layer)
-            extra = extra_loss()
+            extra = extra_loss() if extra is None else extra
             ok = extra is None or not extra.requires_grad
         if not ok:
             logit, lazy = lazy.materialize(), None
@@ -38,7 +43,13 @@ def finish_model_fn(mode, logit: torch.Tensor, labels, params,
         return EstimatorSpec(mode, predictions=preds, export_outputs={"prediction": preds})
 
     y = labels[label_key]
-    if lazy is not None:
+    if tail is not None:
+        # one launch: the last hidden layer + the one-unit head over [side, layer] + sigmoid-CE + the backward of all of it
+        side, ld, side_first = tail
+        head_kernel, head_bias, _ = lazy.heads[0]
+        loss, prob, logit = ops.tail_dense_head(current_store(), y, head_kernel, head_bias, ld.kernel, ld.bias, ld.x, side,
+                                                side_first, loss_addend=extra)
+    elif lazy is not None:
         # one launch: one-unit head(s) + sigmoid-CE + the backward of both (the loss-gradient seed is known)
         heads = [(k, len(ps)) for k, _, ps in lazy.heads]
         bias = next((b for _, b, _ in lazy.heads if b is not None), None)

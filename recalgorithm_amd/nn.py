@@ -219,6 +219,37 @@ class _Dense1Fn(Function):
         return (None, None, None, *dxs)
 
 
+class LazyDense:
+    """`tf.layers.dense(x, units, relu)` — the LAST hidden layer of a TRAIN step — not evaluated yet: when its only consumer
+    turns out to be the one-unit head in front of the loss (dcn.py:166-172), model_tail.finish_model_fn runs layer, head, loss and
+    their backward as ONE kernel (ops.tail_dense_head).  Any other use goes through `materialize()`: the layer as `dense` runs it."""
+
+    def __init__(self, x, kernel: Variable, bias: Variable, grad_join=None):
+        self.x, self.kernel, self.bias, self.grad_join = x, kernel, bias, grad_join
+        self._out = None
+
+    @property
+    def shape(self):
+        return (*self.x.shape[:-1], int(self.kernel.data.shape[1]))
+
+    def dim(self):
+        return self.x.dim()
+
+    is_cuda = True
+
+    def materialize(self) -> torch.Tensor:
+        if self._out is None:
+            store = current_store()
+            src = ReluSource()
+            self._out = _DenseFn.apply(store.anchor, self.x, self.kernel, self.bias, True, 0.0, self.grad_join, None, src, None)
+            self._out._recalgo_relu_src = src
+        return self._out
+
+
+def _resolved(t):
+    return t.materialize() if isinstance(t, LazyDense) else t
+
+
 class LazyConcat:
     """`tf.concat(values, axis=-1)` whose consumer is a one-unit `dense`: the head kernel reads the
     parts in place, so the [B, sum(widths)] copy (and the two slice copies of its gradient) never
@@ -232,7 +263,7 @@ class LazyConcat:
         return (*self.parts[0].shape[:-1], sum(int(t.shape[-1]) for t in self.parts))
 
     def materialize(self) -> torch.Tensor:
-        return torch.cat(self.parts, dim=-1)
+        return torch.cat([_resolved(t) for t in self.parts], dim=-1)
 
 
 class LazyLogit:
@@ -259,8 +290,30 @@ class LazyLogit:
 
     __radd__ = __add__
 
+    def tail(self):
+        """(side part | None, LazyDense, side_first) when this is ONE head over [side, last hidden layer] (either order) with
+        nothing else added and the fused layer + head + loss kernel serves the shapes; else None."""
+        from . import ops
+        if len(self.heads) != 1 or self.tensors:
+            return None
+        kernel, _, parts = self.heads[0]
+        lazies = [i for i, t in enumerate(parts) if isinstance(t, LazyDense)]
+        if len(lazies) != 1 or len(parts) > 2 or hasattr(kernel, "apply_head"):
+            return None
+        ld = parts[lazies[0]]
+        side = parts[1 - lazies[0]] if len(parts) == 2 else None
+        if not ops.tail_dense_head_supported(ld.x, ld.shape[-1], side):
+            return None
+        return side, ld, lazies[0] == 1
+
+    def resolve(self):
+        """the un-evaluated last hidden layer (LazyDense), if any, run as an ordinary dense layer"""
+        self.heads = [(k, b, [_resolved(t) for t in ps]) for k, b, ps in self.heads]
+        return self
+
     def fusable(self) -> bool:
         from . import ops
+        self.resolve()
         parts = [t for _, _, ps in self.heads for t in ps]
         return (len(self.heads) >= 1 and sum(b is not None for _, b, _ in self.heads) <= 1
                 and ops.logit_loss_supported(parts, self.tensors))
@@ -268,7 +321,7 @@ class LazyLogit:
     def materialize(self) -> torch.Tensor:
         store = current_store()
         out = None
-        for kernel, bias, parts in self.heads:
+        for kernel, bias, parts in self.resolve().heads:
             t = kernel.apply_head(parts) if hasattr(kernel, "apply_head") else _Dense1Fn.apply(store.anchor, kernel, bias, *parts)
             out = t if out is None else out + t
         for t in self.tensors:
@@ -281,7 +334,7 @@ def concat(values, axis: int = -1):
     values = list(values)
     if axis in (-1, values[0].dim() - 1) and len(values) <= 4 and all(t.dim() == 2 and t.is_cuda for t in values):
         return LazyConcat(values)
-    return torch.cat(values, dim=axis)
+    return torch.cat([_resolved(t) for t in values], dim=axis)
 
 
 def dense_drop_supported(x, units: int) -> bool:
@@ -295,7 +348,7 @@ def dense_drop_supported(x, units: int) -> bool:
 
 def dense(x, units, activation: Optional[str] = None,
           use_bias: bool = True, name: Optional[str] = None, input_l2: float = 0.0,
-          grad_join: Optional[GradJoin] = None, bn_stats: bool = False, drop=None) -> torch.Tensor:
+          grad_join: Optional[GradJoin] = None, bn_stats: bool = False, drop=None, last_hidden: bool = False) -> torch.Tensor:
     """tf.layers.dense(x, units, activation=None|relu, use_bias, name).  `units` may be a
     str (the reference passes FLAGS.hidden_units.split(','), deepfm.py:286; quirk B-2).
     Variables: <scope>/<name>/kernel (glorot-uniform), <scope>/<name>/bias (zeros).
@@ -305,9 +358,13 @@ def dense(x, units, activation: Optional[str] = None,
     `bn_stats` (not a TF argument): a training-mode tf.layers.batch_normalization consumes this layer's output next (the
     dense -> [dropout] -> batch_norm order of deepfm.py:207-211): the GEMM's epilogue leaves the batch moments of its tiles
     and `batch_normalization` runs without a moments pass of its own (it finds them attached to the tensor it is given —
-    a dropout in between makes a new tensor, and the BatchNorm layer computes its own moments as before)."""
+    a dropout in between makes a new tensor, and the BatchNorm layer computes its own moments as before).
+    `last_hidden` (not a TF argument): this ReLU layer's output goes to the one-unit head in front of the loss (dcn.py:166-172);
+    in a TRAIN step it is returned un-evaluated (LazyDense) for the fused layer + head + loss kernel."""
     store = current_store()
     units = int(units)
+    if isinstance(x, LazyDense):
+        x = x.materialize()
     name = name or store.auto_name("dense")
     with store.variable_scope(name):
         kernel = store.get_variable("kernel", (x.shape[-1], units), glorot_uniform)
@@ -317,13 +374,25 @@ def dense(x, units, activation: Optional[str] = None,
     parts = x.parts if isinstance(x, LazyConcat) else [x]
     if units == 1 and activation is None:
         from . import ops
-        parts = [t if t.is_contiguous() else t.contiguous() for t in parts]
+        parts = [t if (isinstance(t, LazyDense) or t.is_contiguous()) else t.contiguous() for t in parts]
+        if any(isinstance(t, LazyDense) for t in parts):
+            lazy = LazyLogit([(kernel, bias, parts)])
+            if not store.building and lazy.tail() is not None:
+                return lazy                                   # TRAIN step: layer + head + loss + their backward in one launch
+            parts = lazy.resolve().heads[0][2]
         if ops.dense1_supported(parts):
             if ops.logit_loss_supported(parts, []) and not store.building:
                 return LazyLogit([(kernel, bias, parts)])     # TRAIN step: evaluated together with the loss
             return _Dense1Fn.apply(store.anchor, kernel, bias, *parts)
+        x = LazyConcat(parts) if isinstance(x, LazyConcat) else parts[0]
     if isinstance(x, LazyConcat):
         x = x.materialize()
+    if (last_hidden and activation == "relu" and use_bias and not store.building and input_l2 == 0.0 and not bn_stats and drop is None
+            and grad_join is None and isinstance(x, torch.Tensor) and getattr(x, "_recalgo_relu_src", None) is not None
+            and getattr(x, "_recalgo_relu_scale", 1.0) == 1.0):
+        from . import ops
+        if ops.tail_dense_head_supported(x, units, None):
+            return LazyDense(x, kernel, bias, grad_join)
     bn_part = None
     if (bn_stats and not store.building and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and units % 4 == 0
             and _mfma_dense(x.shape[1]) and getattr(getattr(store.anchor, "_recalgo_store", None), "sync_bn", None) is None):

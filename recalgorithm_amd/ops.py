@@ -1731,6 +1731,85 @@ class _LogitLossFn(Function):
         return (None, None, None, None, None, None, *ctx.dxs, *([ctx.dlogit] * ctx.n_addends))
 
 
+class _TailDenseHeadFn(Function):
+    """The last hidden layer + the one-unit head + sigmoid-CE + the backward of all three down to the layer's input, in ONE
+    launch (include/recalgo.h recalgo_tail_dense_head_fwd_bwd; DCN's tail, dcn.py:166-172).  As _LogitLossFn: the loss-gradient
+    seed is known, the forward launch produces the gradients, the backward hands them out — and launches the layer's weight
+    gradient (a batch reduction: its own launch, split partials summed by the step's deferred-sum launch)."""
+
+    @staticmethod
+    def forward(ctx, anchor, labels, head_kernel, head_bias, w3, b3, side_first, loss_addend, h2, side):
+        ctx.set_materialize_grads(False)
+        lib = _lib_()
+        B, K2 = h2.shape
+        N3 = int(w3.data.shape[1])
+        Cs = 0 if side is None else int(side.shape[1])
+        C = Cs + N3
+        dev = h2.device
+        hk = head_kernel.data.reshape(-1)
+        w_side, w_h3 = (hk[:Cs], hk[Cs:]) if side_first else (hk[N3:], hk[:N3])
+        rows = int(lib.recalgo_tail_partial_rows(B))
+        partials = torch.empty(rows, C + 2, device=dev, dtype=torch.float32)
+        logit = torch.empty(B, 1, device=dev, dtype=torch.float32)
+        prob, dlogit = torch.empty_like(logit), torch.empty_like(logit)
+        loss = torch.empty(1, device=dev, dtype=torch.float32)
+        d_side = torch.empty_like(side) if (side is not None and ctx.needs_input_grad[9]) else None
+        dz3 = torch.empty(B, N3, device=dev, dtype=torch.float32)
+        dh2 = torch.empty_like(h2)
+        lb = labels.contiguous().view(-1).to(torch.float32)
+        _lib.check(lib.recalgo_tail_dense_head_fwd_bwd(
+            _p(h2), K2, _p(w3.data), _p(b3.data), N3, _p(side), Cs, int(bool(side_first)), _p(w_side) if Cs else None, _p(w_h3),
+            None if head_bias is None else _p(head_bias.data), _p(lb), _p(loss_addend), B, float(_loss_seed), _p(logit), _p(prob),
+            _p(dlogit), _p(d_side), _p(dz3), _p(dh2), _p(partials), _stream(logit)), "recalgo_tail_dense_head_fwd_bwd")
+        src = getattr(h2, "_recalgo_relu_src", None)
+        if src is not None:
+            src.premasked = dh2                        # masked with h2 > 0 by the kernel: the producing layer skips its own mask
+        if hasattr(head_kernel, "colsum_jobs"):
+            _colsum_pending.extend(head_kernel.colsum_jobs(partials, 0, rows, C + 2))
+        else:
+            _colsum_pending.append((partials, 0, rows, C + 2, C, head_kernel.grad))
+        if head_bias is not None:
+            _colsum_pending.append((partials, C, rows, C + 2, 1, head_bias.grad))
+        _colsum_pending.append((partials, C + 1, rows, C + 2, 1, loss))
+        _dlogit_partials.clear()
+        _dlogit_partials[dlogit.data_ptr()] = (partials, C, rows, C + 2, B)
+        ctx.h2, ctx.dz3, ctx.dh2, ctx.d_side, ctx.vars = h2, dz3, dh2, d_side, (w3, b3)
+        ctx.mark_non_differentiable(prob, logit)
+        return loss.view(()), prob, logit
+
+    @staticmethod
+    def backward(ctx, gloss, _gprob, _glogit):
+        if gloss is None:
+            return (None,) * 10
+        w3, b3 = ctx.vars
+        dense_bwd_weights(ctx.h2, ctx.dz3, None, w3.grad, b3.grad, defer=True)
+        return (None, None, None, None, None, None, None, None, ctx.dh2, ctx.d_side)
+
+
+def tail_dense_head_supported(h2, units: int, side) -> bool:
+    """recalgo_tail_dense_head_fwd_bwd serves this last-hidden-layer / head pair (inside a training step whose loss seed is known)."""
+    if _loss_seed is None or not torch.is_grad_enabled():
+        return False
+    for t in (h2, side):
+        if t is None:
+            continue
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous()
+                and t.data_ptr() % 16 == 0):
+            return False
+    if side is not None and side.shape[0] != h2.shape[0]:
+        return False
+    return bool(_lib_().recalgo_tail_dense_head_supported(int(h2.shape[1]), int(units), 0 if side is None else int(side.shape[1])))
+
+
+def tail_dense_head(store, labels, head_kernel, head_bias, w3, b3, h2, side, side_first: bool,
+                    loss_addend: Optional[torch.Tensor] = None):
+    """-> (mean sigmoid-CE loss (+ loss_addend), probabilities [B, 1], logit [B, 1]) of
+    logit = dense1(concat([side, relu(h2 w3 + b3)]) in the given order) + head_bias."""
+    if loss_addend is not None:
+        loss_addend = loss_addend.detach().reshape(1).to(torch.float32)
+    return _TailDenseHeadFn.apply(store.anchor, labels, head_kernel, head_bias, w3, b3, bool(side_first), loss_addend, h2, side)
+
+
 class _ConcatSumsqFn(Function):
     """torch.cat(parts, -1) with sum(out^2) * scale as a detached by-product (one launch, include/recalgo.h
     recalgo_concat_sumsq); the gradient of a part is its column block of the output's gradient."""

@@ -1,0 +1,151 @@
+"""-m gpu: the fused DCN tail (recalgo_tail_dense_head_fwd_bwd: last hidden layer + one-unit head + sigmoid-CE + the backward of
+all three, /root/reference algorithm/DCN/dcn.py:166-172 + the loss tail) against a float64 restatement of the same TF ops,
+with the float32 restatement's own rounding as the strict guard (tests/util.py assert_close(ref32=))."""
+import pytest
+import torch
+
+from recalgorithm_amd import nn, ops
+from recalgorithm_amd.variables import Variable, VariableStore, use_store
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(B, K2, Cs, seed):
+    g = torch.Generator().manual_seed(seed)
+    h2 = torch.relu(torch.randn(B, K2, generator=g))                      # a ReLU output: about half zeros
+    w3 = torch.randn(K2, 128, generator=g) * (1.5 / K2 ** 0.5)
+    b3 = torch.randn(128, generator=g) * 0.1
+    side = torch.randn(B, Cs, generator=g) if Cs else None
+    wh = torch.randn(Cs + 128, 1, generator=g) * 0.15
+    bh = torch.randn(1, generator=g) * 0.1
+    y = (torch.rand(B, 1, generator=g) < 0.3).float()
+    return h2, w3, b3, side, wh, bh, y
+
+
+def _oracle(dt, h2, w3, b3, side, wh, bh, y, side_first, seed_scale):
+    h2 = h2.clone().to(dt).requires_grad_(True)
+    w3, b3, wh, bh = (t.clone().to(dt).requires_grad_(True) for t in (w3, b3, wh, bh))
+    sd = None if side is None else side.clone().to(dt).requires_grad_(True)
+    z3 = h2 @ w3 + b3
+    h3 = torch.relu(z3)
+    cat = h3 if sd is None else (torch.cat([sd, h3], 1) if side_first else torch.cat([h3, sd], 1))
+    x = cat @ wh + bh
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(x, y.to(dt))
+    (loss * seed_scale).backward()
+    out = dict(loss=loss.detach().reshape(1), logit=x.detach(), prob=torch.sigmoid(x.detach()), dh2=h2.grad * (h2.detach() > 0),
+               dw3=w3.grad, db3=b3.grad, dwh=wh.grad, dbh=bh.grad, z3=z3.detach())
+    if sd is not None:
+        out["dside"] = sd.grad
+    return out
+
+
+@pytest.mark.parametrize("B,K2,Cs,side_first", [
+    (1, 128, 0, True), (31, 256, 416, True), (32, 256, 416, False), (77, 384, 20, True), (1000, 512, 1024, True),
+    (4096, 256, 416, True), (4096, 256, 0, True), (333, 128, 4, False)])
+def test_tail_dense_head_against_float64(dev, B, K2, Cs, side_first):
+    case = _case(B, K2, Cs, seed=B + K2 + Cs)
+    h2, w3, b3, side, wh, bh, y = case
+    seed_scale = 1.0 if B != 77 else 8.0
+    o64 = _oracle(torch.float64, *case, side_first, seed_scale)
+    o32 = _oracle(torch.float32, *case, side_first, seed_scale)
+    store = VariableStore(dev)
+    kv, bv = Variable("dnn_part/dnn_dense_2/kernel", w3.to(dev)), Variable("dnn_part/dnn_dense_2/bias", b3.to(dev))
+    hk, hb = Variable("output_part/dense/kernel", wh.to(dev)), Variable("output_part/dense/bias", bh.to(dev))
+    x = h2.to(dev).requires_grad_(True)
+    sd = None if side is None else side.to(dev).requires_grad_(True)
+    with ops.loss_seed(seed_scale), use_store(store):
+        assert ops.tail_dense_head_supported(x, 128, sd)
+        loss, prob, logit = ops.tail_dense_head(store, y.to(dev), hk, hb, kv, bv, x, sd, side_first)
+        loss.backward(torch.full((), seed_scale, device=dev))
+    ops.flush_dense_splits()
+    nm = f"tail B={B} K2={K2} Cs={Cs}"
+    assert_close(loss.reshape(1), o64["loss"], what=f"{nm} loss", reduced=True, ref32=o32["loss"])
+    assert_close(logit, o64["logit"], what=f"{nm} logit", ref32=o32["logit"])
+    assert_close(prob, o64["prob"], what=f"{nm} prob", ref32=o32["prob"])
+    # a unit whose pre-activation is within fp32 rounding of 0 may be on the other side of the ReLU in fp32: its share of the
+    # gradients is bounded by |dlogit w_h3 w3| of those few units — they are excluded by comparing at a floor of that size
+    near0 = (o64["z3"].abs() < 1e-6 * o64["z3"].abs().max()).sum().item()
+    floor = 0.0 if near0 == 0 else float(o64["dh2"].abs().max()) * 1e-3
+    assert_close(x.grad, o64["dh2"], what=f"{nm} d(h2)", reduced=True, floor=floor, ref32=None if near0 else o32["dh2"])
+    if sd is not None:
+        assert_close(sd.grad, o64["dside"], what=f"{nm} d(side)", ref32=o32["dside"])
+    assert_close(kv.grad, o64["dw3"], what=f"{nm} d(w3)", reduced=True, floor=floor, ref32=None if near0 else o32["dw3"])
+    assert_close(bv.grad, o64["db3"], what=f"{nm} d(b3)", reduced=True, floor=floor, ref32=None if near0 else o32["db3"])
+    assert_close(hk.grad, o64["dwh"], what=f"{nm} d(head kernel)", reduced=True, ref32=o32["dwh"])
+    assert_close(hb.grad, o64["dbh"], what=f"{nm} d(head bias)", reduced=True, ref32=o32["dbh"])
+
+
+def test_tail_equals_the_three_separate_launches(dev):
+    """nn.dense(last_hidden=True) -> nn.concat -> nn.dense(1) -> finish_model_fn: the fused launch and the separate
+    dense / head+loss / dense-backward launches give the same loss, probabilities and gradients (different summation orders:
+    compared at the §8c tolerance); outside a TRAIN step the same calls run the separate kernels."""
+    from recalgorithm_amd.estimator import ModeKeys
+    from recalgorithm_amd.model_tail import finish_model_fn
+    B, K1, K2, Cs = 512, 64, 256, 416
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(B, K1, generator=g)
+    side0 = torch.randn(B, Cs, generator=g)
+    y = {"read_comment": (torch.rand(B, 1, generator=g) < 0.4).float().to(dev)}
+    params = {"learning_rate": 0.001}
+
+    def run(fused):
+        store = VariableStore(dev, seed=11)
+        x = x0.to(dev)
+        side = side0.to(dev).requires_grad_(True)
+
+        def model():
+            store.begin_call()
+            h = nn.dense(x, K2, activation="relu", name="l0")
+            h = nn.dense(h, 128, activation="relu", name="l1", last_hidden=fused)
+            if fused and not store.building:
+                assert isinstance(h, nn.LazyDense)
+            logit = nn.dense(nn.concat([side, h], axis=-1), 1, name="head")
+            return finish_model_fn(ModeKeys.TRAIN, logit, y, params)
+        with use_store(store):
+            store.building = True
+            with torch.no_grad():
+                model()
+            store.building = False
+            store.finalize()
+            with ops.loss_seed(1.0):
+                spec = model()
+            spec.loss.backward(torch.ones((), device=dev))
+        nn.apply_parked_grads()
+        ops.flush_dense_splits()
+        grads = {k: v.grad.clone() for k, v in store.vars.items()}
+        return spec.loss.detach().clone(), spec.predictions["probabilities"].clone(), side.grad.clone(), grads
+    l1, p1, s1, g1 = run(True)
+    l0, p0, s0, g0 = run(False)
+    assert_close(l1.reshape(1), l0.reshape(1), what="fused vs separate loss", reduced=True)
+    assert_close(p1, p0, what="fused vs separate prob")
+    assert_close(s1, s0, what="fused vs separate d(side)")
+    assert set(g1) == set(g0)
+    for k in g0:
+        assert_close(g1[k], g0[k], what=f"fused vs separate d({k})", reduced=True)
+
+
+def test_last_hidden_falls_back_outside_the_served_shapes(dev):
+    """units != 128, an input that is not a ReLU output, no loss seed: `last_hidden` is a plain dense layer."""
+    store = VariableStore(dev, seed=2)
+    x = torch.randn(64, 256, device=dev)
+    with use_store(store):
+        store.building = True
+        with torch.no_grad():
+            nn.dense(nn.dense(x, 256, activation="relu", name="a"), 64, activation="relu", name="b", last_hidden=True)
+            nn.dense(nn.dense(x, 256, activation="relu", name="a"), 128, activation="relu", name="c", last_hidden=True)
+            nn.dense(x, 128, activation="relu", name="d", last_hidden=True)
+        store.building = False
+        store.finalize()
+        with ops.loss_seed(1.0):
+            h = nn.dense(x, 256, activation="relu", name="a")
+            assert isinstance(nn.dense(h, 64, activation="relu", name="b", last_hidden=True), torch.Tensor)
+            assert isinstance(nn.dense(x, 128, activation="relu", name="d", last_hidden=True), torch.Tensor)
+            lazy = nn.dense(h, 128, activation="relu", name="c", last_hidden=True)
+            assert isinstance(lazy, nn.LazyDense)
+            out = lazy.materialize()
+            assert out is lazy.materialize() and tuple(out.shape) == (64, 128)
+            assert torch.equal(out, torch.relu(torch.addmm(store.vars["c/bias"].data, h, store.vars["c/kernel"].data))) or \
+                torch.allclose(out, torch.relu(torch.addmm(store.vars["c/bias"].data, h, store.vars["c/kernel"].data)), rtol=1e-5, atol=1e-6)
+        assert isinstance(nn.dense(nn.dense(x, 256, activation="relu", name="a"), 128, activation="relu", name="c", last_hidden=True),
+                          torch.Tensor)
