@@ -421,6 +421,22 @@ int recalgo_dense_bwd_bn(const float* x, int ldx, const float* g, int ldg, const
                          int N, const float* c_in, int ldc, float beta, float* dx, int lddx, float* dw, float* dbias,
                          void* workspace, int defer_reduce, const float* bn_x, const float* bn_mean, const float* bn_rstd,
                          float* bn_partials, const float* dx_relu_mask, int ld_mask, recalgo_stream_t stream);
+/* recalgo_dense_bwd_bn carrying a RIDER in the same launch: the weight gradient of ANOTHER layer over the same M examples —
+ *   r_dw [r_K][r_N] = r_x^T r_g,  r_dbias [r_N] = colsum(r_g)      (r_g arrives masked: no mask is staged for the rider)
+ * as recalgo_dense_bwd_weights(r_x, r_ldx, r_g, r_ldg, NULL, M, r_K, r_N, r_dw, r_dbias, r_workspace, defer_reduce = 1, ..): its
+ * split partials are summed by recalgo_dense_bwd_weights_reduce.  The layer above this one when its input gradient came out of
+ * recalgo_tail_dense_head_fwd_bwd (dcn.py:166-172: dnn_dense_2's weight gradient rides with dnn_dense_1's backward) — 0.27 GFLOP
+ * that would otherwise be a launch of its own.  Only where recalgo_dense_bwd_rider_supported(..) == 1 (all three GEMMs on the
+ * vectorised tile paths); else the caller launches the two separately. */
+int recalgo_dense_bwd_rider_supported(const float* x, int ldx, const float* g, int ldg, const float* y_mask, const float* w, int M,
+                                      int K, int N, float* dx, int lddx, const float* r_x, int r_ldx, const float* r_g, int r_ldg,
+                                      int r_K, int r_N);
+int recalgo_dense_bwd_rider(const float* x, int ldx, const float* g, int ldg, const float* y_mask, const float* w, int M, int K,
+                            int N, const float* c_in, int ldc, float beta, float* dx, int lddx, float* dw, float* dbias,
+                            void* workspace, int defer_reduce, const float* bn_x, const float* bn_mean, const float* bn_rstd,
+                            float* bn_partials, const float* dx_relu_mask, int ld_mask, const float* r_x, int r_ldx,
+                            const float* r_g, int r_ldg, int r_K, int r_N, float* r_dw, float* r_dbias, void* r_workspace,
+                            recalgo_stream_t stream);
 typedef struct {
     int M, K, N;
     const void* workspace;

@@ -697,6 +697,22 @@ __global__ __launch_bounds__(kThreads) void dense_bwd_kernel(DgradArgs D, WgradA
     else wgrad_tile<FAST, MASK>(W, blockIdx.x - dgrad_blocks, As, Bs);
 }
 
+// The same launch carrying a RIDER: the weight-gradient tiles of ANOTHER layer (same batch) whose operands are ready — the layer
+// above this one, whose input gradient came out of a fused kernel (csrc/tailfuse.hip) and whose weight gradient would otherwise be
+// a 7 us launch of its own for 0.27 GFLOP.  Rider tiles never stage a mask (their gradient operand arrives masked).
+template <bool FAST, bool MASK>
+__global__ __launch_bounds__(kThreads) void dense_bwd_rider_kernel(DgradArgs D, WgradArgs W, WgradArgs R, int dgrad_blocks,
+                                                                   int rider_blocks) {
+    __shared__ __attribute__((aligned(16))) float As[kStages * kBufFloats];
+    __shared__ __attribute__((aligned(16))) float Bs[kStages * kBufFloats];
+    // the rider's (short) tiles are dispatched first: they share the CUs with the first round of the layer's own tiles instead
+    // of forming a round of their own behind them
+    const int b = (int)blockIdx.x - rider_blocks;
+    if (b < 0) wgrad_tile<FAST, false>(R, (int)blockIdx.x, As, Bs);
+    else if (b < dgrad_blocks) dgrad_tile<FAST, MASK>(D, b, dgrad_blocks, As, Bs);
+    else wgrad_tile<FAST, MASK>(W, b - dgrad_blocks, As, Bs);
+}
+
 // fixed-order sum of split slabs, batched over up to kMaxSplitJobs weight gradients (one launch for all the layers
 // of a backward pass): out[i] = sum_s partials[s][i]; elements [0, n0) -> out0 (dW), [n0, n) -> out1 (dbias).
 // (Tried instead: letting the last-arriving workgroup of each tile do the sum inside the wgrad kernel, with the
@@ -1025,6 +1041,52 @@ RECALGO_EXPORT int recalgo_dense_bwd_bn(const float* x, int ldx, const float* g,
     else if (y_mask) hipLaunchKernelGGL((dense_bwd_kernel<false, true>), dim3(gd + gw), dim3(kThreads), 0, st, D, W, gd);
     else hipLaunchKernelGGL((dense_bwd_kernel<false, false>), dim3(gd + gw), dim3(kThreads), 0, st, D, W, gd);
     return finish_wgrad(S, defer_reduce, K, N, dw, dbias, workspace, st);
+}
+
+RECALGO_EXPORT int recalgo_dense_bwd_rider(const float* x, int ldx, const float* g, int ldg, const float* y_mask, const float* w,
+                                           int M, int K, int N, const float* c_in, int ldc, float beta, float* dx, int lddx,
+                                           float* dw, float* dbias, void* workspace, int defer_reduce, const float* bn_x,
+                                           const float* bn_mean, const float* bn_rstd, float* bn_partials,
+                                           const float* dx_relu_mask, int ld_mask, const float* r_x, int r_ldx, const float* r_g,
+                                           int r_ldg, int r_K, int r_N, float* r_dw, float* r_dbias, void* r_workspace,
+                                           recalgo_stream_t stream) {
+    DgradArgs D;
+    WgradArgs W, R;
+    RECALGO_REQUIRE(M > 0 && build_dgrad(D, g, ldg, y_mask, w, M, N, K, c_in, ldc, beta, dx, lddx, 0));
+    RECALGO_REQUIRE(bn_partials == nullptr || (bn_x != nullptr && bn_mean != nullptr && bn_rstd != nullptr));
+    RECALGO_REQUIRE(dx_relu_mask == nullptr || ld_mask >= K);
+    D.dx_mask = dx_relu_mask; D.ld_mask = ld_mask;
+    if (dx_relu_mask != nullptr && !(aligned16(dx_relu_mask) && ld_mask % 4 == 0)) D.vec_store = 0;
+    D.bn_x = bn_x; D.bn_mean = bn_mean; D.bn_rstd = bn_rstd; D.bn_partials = bn_partials;
+    const int S = build_wgrad(W, x, ldx, g, ldg, y_mask, M, K, N, dw, dbias, workspace);
+    RECALGO_REQUIRE(S >= 1);
+    // the rider's split partials are always left to recalgo_dense_bwd_weights_reduce (a rider with a single split writes dw itself)
+    const int SR = build_wgrad(R, r_x, r_ldx, r_g, r_ldg, nullptr, M, r_K, r_N, r_dw, r_dbias, r_workspace);
+    RECALGO_REQUIRE(SR >= 1);
+    hipStream_t st = as_stream(stream);
+    D.tiles_per_block = bwd_balance(M, K, N).tiles_per_block;
+    const int gd = cdiv(cdiv(M, BM) * cdiv(K, BN), D.tiles_per_block), gw = cdiv(K, BM) * cdiv(N, BN) * S;
+    const int gr = cdiv(r_K, BM) * cdiv(r_N, BN) * SR;
+    RECALGO_REQUIRE(dgrad_fast(D) && wgrad_fast(W) && wgrad_fast(R));
+    if (y_mask) hipLaunchKernelGGL((dense_bwd_rider_kernel<true, true>), dim3(gd + gw + gr), dim3(kThreads), 0, st, D, W, R, gd, gr);
+    else hipLaunchKernelGGL((dense_bwd_rider_kernel<true, false>), dim3(gd + gw + gr), dim3(kThreads), 0, st, D, W, R, gd, gr);
+    return finish_wgrad(S, defer_reduce, K, N, dw, dbias, workspace, st);
+}
+
+// 1: recalgo_dense_bwd_rider serves these shapes (the vectorised tile paths of all three GEMMs), 0: launch the rider's weight
+// gradient on its own (recalgo_dense_bwd_weights)
+RECALGO_EXPORT int recalgo_dense_bwd_rider_supported(const float* x, int ldx, const float* g, int ldg, const float* y_mask,
+                                                     const float* w, int M, int K, int N, float* dx, int lddx, const float* r_x,
+                                                     int r_ldx, const float* r_g, int r_ldg, int r_K, int r_N) {
+    if (!(M > 0 && K > 0 && N > 0 && r_K > 0 && r_N > 0 && x && g && w && dx && r_x && r_g)) return 0;
+    DgradArgs D;
+    WgradArgs W, R;
+    static float dummy[4];
+    if (!build_dgrad(D, g, ldg, y_mask, w, M, N, K, nullptr, 0, 0.f, dx, lddx, 0)) return 0;
+    alignas(16) static char ws[16];
+    if (build_wgrad(W, x, ldx, g, ldg, y_mask, M, K, N, dummy, nullptr, ws) < 1) return 0;
+    if (build_wgrad(R, r_x, r_ldx, r_g, r_ldg, nullptr, M, r_K, r_N, dummy, nullptr, ws) < 1) return 0;
+    return (dgrad_fast(D) && wgrad_fast(W) && wgrad_fast(R)) ? 1 : 0;
 }
 
 RECALGO_EXPORT int recalgo_dense_bwd_weights_reduce(const recalgo_dense_split_t* jobs, int n_jobs,

@@ -1377,6 +1377,23 @@ def dense_bwd(x: torch.Tensor, g: torch.Tensor, y_mask: Optional[torch.Tensor], 
         bnp = (_p(bx), _p(bmean), _p(brstd), _p(bpart))
     if premask is not None and (tuple(premask.shape) != (M, K) or premask.stride(1) != 1 or premask.dtype != torch.float32):
         raise ValueError("dense_bwd: premask must be [M, K] fp32 with contiguous rows")
+    rider = _take_wgrad_rider(M, x.device) if defer else None
+    if rider is not None:
+        rx, rg, rdw, rdb = rider
+        rK, rN = rx.shape[1], rg.shape[1]
+        if lib.recalgo_dense_bwd_rider_supported(_p(x), x.stride(0), _p(g), g.stride(0), _p(y_mask), _p(w), M, K, N, _p(dx), K,
+                                                 _p(rx), rx.stride(0), _p(rg), rg.stride(0), rK, rN):
+            rws = _wgrad_workspace(rx.device, M, rK, rN, rdw)
+            _lib.check(lib.recalgo_dense_bwd_rider(_p(x), x.stride(0), _p(g), g.stride(0), _p(y_mask), _p(w), M, K, N, _p(c_in),
+                                                   0 if c_in is None else c_in.stride(0), float(beta), _p(dx), K, _p(dw), _p(dbias),
+                                                   _p(ws), int(defer), *bnp, _p(premask), 0 if premask is None else premask.stride(0),
+                                                   _p(rx), rx.stride(0), _p(rg), rg.stride(0), rK, rN, _p(rdw), _p(rdb), _p(rws),
+                                                   _stream(x)), "recalgo_dense_bwd_rider")
+            _dense_pending.append((M, K, N, ws, dw, dbias))
+            if int(lib.recalgo_dense_bwd_weights_workspace_bytes(M, rK, rN)) > 0:
+                _dense_pending.append((M, rK, rN, rws, rdw, rdb))
+            return dx
+        dense_bwd_weights(rx, rg, None, rdw, rdb, defer=True)          # (not on the vectorised tile paths: a launch of its own)
     _lib.check(lib.recalgo_dense_bwd_bn(_p(x), x.stride(0), _p(g), g.stride(0), _p(y_mask), _p(w), M, K, N, _p(c_in),
                                         0 if c_in is None else c_in.stride(0), float(beta), _p(dx), K, _p(dw), _p(dbias), _p(ws),
                                         int(defer), *bnp, _p(premask), 0 if premask is None else premask.stride(0), _stream(x)),
@@ -1386,11 +1403,47 @@ def dense_bwd(x: torch.Tensor, g: torch.Tensor, y_mask: Optional[torch.Tensor], 
     return dx
 
 
+# A weight gradient waiting for a launch to ride in (recalgo_dense_bwd_rider): left by the fused tail's backward (its layer's
+# operands are ready, the layer below runs its merged backward next), taken by the next deferred dense_bwd over the same batch;
+# whatever is still here when the deferred sums are flushed (or another rider arrives) is launched on its own.
+_wgrad_rider = []
+
+
+def defer_wgrad_rider(x: torch.Tensor, g: torch.Tensor, dw: torch.Tensor, dbias: Optional[torch.Tensor]) -> None:
+    launch_wgrad_rider()
+    _wgrad_rider.append((_mat(x, "x"), _mat(g, "g"), dw, dbias))
+
+
+def _take_wgrad_rider(M: int, device):
+    if not _wgrad_rider:
+        return None
+    rx, rg, rdw, rdb = _wgrad_rider[0]
+    if rx.shape[0] != M or rx.device != device or rdb is None or not rdw.is_contiguous():
+        return None
+    return _wgrad_rider.pop()
+
+
+def launch_wgrad_rider() -> None:
+    while _wgrad_rider:
+        rx, rg, rdw, rdb = _wgrad_rider.pop()
+        dense_bwd_weights(rx, rg, None, rdw, rdb, defer=True)
+
+
+def _wgrad_workspace(device, M, K, N, dw):
+    nbytes = int(_lib_().recalgo_dense_bwd_weights_workspace_bytes(M, K, N))
+    key = (device.type, device.index, M, K, N, dw.data_ptr())
+    ws = _dense_ws.get(key)
+    if ws is None:
+        ws = _dense_ws[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
+    return ws
+
+
 def flush_dense_splits(step_dev: Optional[torch.Tensor] = None) -> None:
     """Finish every deferred sum of the step in ONE launch: the weight-gradient split reductions of `dense`, the column
     sums the loss tail left behind, and (`step_dev`, the optimizer's int64 step counter) the step increment — the
     optimizer kernel that follows then only reads the counter."""
     join_side_streams()
+    launch_wgrad_rider()
     if not _dense_pending and not _colsum_pending and step_dev is None:
         return
     jobs = (_DenseSplit * max(len(_dense_pending), 1))()
@@ -1782,7 +1835,8 @@ class _TailDenseHeadFn(Function):
         if gloss is None:
             return (None,) * 10
         w3, b3 = ctx.vars
-        dense_bwd_weights(ctx.h2, ctx.dz3, None, w3.grad, b3.grad, defer=True)
+        # (rides in the launch of the layer below's backward, which autograd runs next: ops.dense_bwd picks it up)
+        defer_wgrad_rider(ctx.h2, ctx.dz3, w3.grad, b3.grad)
         return (None, None, None, None, None, None, None, None, ctx.dh2, ctx.d_side)
 
 

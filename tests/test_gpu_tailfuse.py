@@ -91,7 +91,7 @@ def test_tail_equals_the_three_separate_launches(dev):
 
     def run(fused):
         store = VariableStore(dev, seed=11)
-        x = x0.to(dev)
+        x = x0.to(dev).requires_grad_(True)        # (l0 then runs the merged backward launch: the fused layer's weight gradient rides in it)
         side = side0.to(dev).requires_grad_(True)
 
         def model():
@@ -111,9 +111,11 @@ def test_tail_equals_the_three_separate_launches(dev):
             with ops.loss_seed(1.0):
                 spec = model()
             spec.loss.backward(torch.ones((), device=dev))
+        assert not ops._wgrad_rider, "the fused layer's weight gradient did not ride in the next layer's backward launch"
         nn.apply_parked_grads()
         ops.flush_dense_splits()
         grads = {k: v.grad.clone() for k, v in store.vars.items()}
+        grads["x"] = x.grad.clone()
         return spec.loss.detach().clone(), spec.predictions["probabilities"].clone(), side.grad.clone(), grads
     l1, p1, s1, g1 = run(True)
     l0, p0, s0, g0 = run(False)
