@@ -421,22 +421,30 @@ int recalgo_dense_bwd_bn(const float* x, int ldx, const float* g, int ldg, const
                          int N, const float* c_in, int ldc, float beta, float* dx, int lddx, float* dw, float* dbias,
                          void* workspace, int defer_reduce, const float* bn_x, const float* bn_mean, const float* bn_rstd,
                          float* bn_partials, const float* dx_relu_mask, int ld_mask, recalgo_stream_t stream);
-/* recalgo_dense_bwd_bn carrying a RIDER in the same launch: the weight gradient of ANOTHER layer over the same M examples —
- *   r_dw [r_K][r_N] = r_x^T r_g,  r_dbias [r_N] = colsum(r_g)      (r_g arrives masked: no mask is staged for the rider)
- * as recalgo_dense_bwd_weights(r_x, r_ldx, r_g, r_ldg, NULL, M, r_K, r_N, r_dw, r_dbias, r_workspace, defer_reduce = 1, ..): its
- * split partials are summed by recalgo_dense_bwd_weights_reduce.  The layer above this one when its input gradient came out of
- * recalgo_tail_dense_head_fwd_bwd (dcn.py:166-172: dnn_dense_2's weight gradient rides with dnn_dense_1's backward) — 0.27 GFLOP
- * that would otherwise be a launch of its own.  Only where recalgo_dense_bwd_rider_supported(..) == 1 (all three GEMMs on the
- * vectorised tile paths); else the caller launches the two separately. */
+/* recalgo_dense_bwd_bn carrying RIDERS in the same launch: work of OTHER layers over the same M examples whose operands are ready
+ * and which nothing in this launch depends on.  Either may be absent (r_x == NULL / c_x0 == NULL), not both.
+ *   weight-gradient rider:  r_dw [r_K][r_N] = r_x^T r_g,  r_dbias [r_N] = colsum(r_g)   (r_g arrives masked: no mask is staged)
+ *       as recalgo_dense_bwd_weights(r_x, r_ldx, r_g, r_ldg, NULL, M, r_K, r_N, r_dw, r_dbias, r_workspace, defer_reduce = 1, ..):
+ *       the layer above this one when its input gradient came out of recalgo_tail_dense_head_fwd_bwd (dcn.py:166-172:
+ *       dnn_dense_2's weight gradient rides with dnn_dense_1's backward);
+ *   CrossNet rider:  recalgo_cross_bwd(c_x0, c_x_stride, c_w, c_b, c_g, c_g_stride, NULL, M, c_d, c_L, c_dx0, NULL, NULL, c_workspace,
+ *       defer_reduce = 1, ..) — the cross branch's backward (dcn.py:157-160), whose upstream gradient is ready as soon as the head's
+ *       is; c_workspace: recalgo_cross_bwd_workspace_bytes(M, c_d, c_L), partial rows as recalgo_cross_bwd leaves them
+ *       (recalgo_cross_bwd_partial_rows(M) rows).  Its dx0 is NOT joined here: the layer below adds it (c_in, beta = 1).
+ *       Only with y_mask == NULL and recalgo_dense_bwd_cross_rider_supported(c_d, c_L) (c_d % 4 == 0, c_d <= 512, 2 <= c_L <= 4).
+ * The riders' split partials / partial rows are summed by recalgo_dense_bwd_weights_reduce.  Only where
+ * recalgo_dense_bwd_rider_supported(..) == 1 (the GEMMs on the vectorised tile paths); else the caller launches them separately. */
 int recalgo_dense_bwd_rider_supported(const float* x, int ldx, const float* g, int ldg, const float* y_mask, const float* w, int M,
                                       int K, int N, float* dx, int lddx, const float* r_x, int r_ldx, const float* r_g, int r_ldg,
                                       int r_K, int r_N);
+int recalgo_dense_bwd_cross_rider_supported(int d, int L);
 int recalgo_dense_bwd_rider(const float* x, int ldx, const float* g, int ldg, const float* y_mask, const float* w, int M, int K,
                             int N, const float* c_in, int ldc, float beta, float* dx, int lddx, float* dw, float* dbias,
                             void* workspace, int defer_reduce, const float* bn_x, const float* bn_mean, const float* bn_rstd,
                             float* bn_partials, const float* dx_relu_mask, int ld_mask, const float* r_x, int r_ldx,
                             const float* r_g, int r_ldg, int r_K, int r_N, float* r_dw, float* r_dbias, void* r_workspace,
-                            recalgo_stream_t stream);
+                            const float* c_x0, int c_x_stride, const float* c_w, const float* c_b, const float* c_g, int c_g_stride,
+                            int c_d, int c_L, float* c_dx0, void* c_workspace, recalgo_stream_t stream);
 typedef struct {
     int M, K, N;
     const void* workspace;

@@ -108,8 +108,10 @@ SIGNATURES = {
                                      P, P, P, P, P, c_int, P]),
     "recalgo_dense_bwd_rider_supported": (c_int, [P, c_int, P, c_int, P, P, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int,
                                                   c_int, c_int]),
+    "recalgo_dense_bwd_cross_rider_supported": (c_int, [c_int, c_int]),
     "recalgo_dense_bwd_rider": (c_int, [P, c_int, P, c_int, P, P, c_int, c_int, c_int, P, c_int, c_float, P, c_int, P, P, P, c_int,
-                                        P, P, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, P, P, P, P]),
+                                        P, P, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, P, P, P,
+                                        P, c_int, P, P, P, c_int, c_int, c_int, P, P, P]),
     "recalgo_dense_bwd_weights_reduce": (c_int, [P, c_int, P, c_int, P, P]),
     "recalgo_logit_loss_partial_rows": (c_int64, [c_int]),
     "recalgo_logit_loss_fwd_bwd": (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, P, P, P, P, P, P]),

@@ -34,6 +34,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "cross_bwd.h"
 #include "act.h"
 #include "tile_v2.h"
 #include "dropout.h"
@@ -697,20 +698,40 @@ __global__ __launch_bounds__(kThreads) void dense_bwd_kernel(DgradArgs D, WgradA
     else wgrad_tile<FAST, MASK>(W, blockIdx.x - dgrad_blocks, As, Bs);
 }
 
-// The same launch carrying a RIDER: the weight-gradient tiles of ANOTHER layer (same batch) whose operands are ready — the layer
-// above this one, whose input gradient came out of a fused kernel (csrc/tailfuse.hip) and whose weight gradient would otherwise be
-// a 7 us launch of its own for 0.27 GFLOP.  Rider tiles never stage a mask (their gradient operand arrives masked).
-template <bool FAST, bool MASK>
-__global__ __launch_bounds__(kThreads) void dense_bwd_rider_kernel(DgradArgs D, WgradArgs W, WgradArgs R, int dgrad_blocks,
+// The same launch carrying RIDERS: work of OTHER layers over the same batch whose operands are ready and which nothing in this
+// launch depends on —
+//   * the weight-gradient tiles of the layer above, when its input gradient came out of a fused kernel (csrc/tailfuse.hip):
+//     0.27 GFLOP that would otherwise be a 7 us launch of their own.  Rider tiles never stage a mask (their gradient arrives masked);
+//   * the CrossNet backward (csrc/cross_bwd.h; dcn.py:157-160: the cross branch's gradient is ready as soon as the head's is):
+//     an HBM / latency-bound kernel of 11 us beside this MFMA-bound one, 4 waves per workgroup here instead of 8.
+// Riders are dispatched first: they share the CUs with the first round of the layer's own tiles instead of forming a round of
+// their own behind them.  (A second HIP stream inside the captured graph costs more than it hides: scripts/lab_fork_join.py,
+// 39.8 us forked against 32.0 in series for exactly this pair.)
+struct CrossRider {
+    const float* x0; const float4* w; const float4* b; const float* g;
+    float* dx0; float* partials;
+    unsigned x_stride, g_stride, B, d4, blocks;
+};
+
+template <bool MASK, int NV, int L>
+__global__ __launch_bounds__(kThreads) void dense_bwd_rider_kernel(DgradArgs D, WgradArgs W, WgradArgs R, CrossRider C, int dgrad_blocks,
                                                                    int rider_blocks) {
     __shared__ __attribute__((aligned(16))) float As[kStages * kBufFloats];
     __shared__ __attribute__((aligned(16))) float Bs[kStages * kBufFloats];
-    // the rider's (short) tiles are dispatched first: they share the CUs with the first round of the layer's own tiles instead
-    // of forming a round of their own behind them
-    const int b = (int)blockIdx.x - rider_blocks;
-    if (b < 0) wgrad_tile<FAST, false>(R, (int)blockIdx.x, As, Bs);
-    else if (b < dgrad_blocks) dgrad_tile<FAST, MASK>(D, b, dgrad_blocks, As, Bs);
-    else wgrad_tile<FAST, MASK>(W, b - dgrad_blocks, As, Bs);
+    int b = (int)blockIdx.x;
+    if (NV > 0) {
+        if (b < (int)C.blocks) {
+            static_assert(kThreads / 64 * 512 + (kThreads / 64 + 1) * 6 <= kStages * kBufFloats, "the cross rider's scratch lies in As");
+            recalgo_cross::cross_stack_bwd_block<(NV > 0 ? NV : 1), (L > 0 ? L : 1), kThreads / 64>(
+                C.x0, C.x_stride, C.w, C.b, C.g, C.g_stride, nullptr, C.B, C.d4, C.dx0, C.partials, (unsigned)b, C.blocks, As);
+            return;
+        }
+        b -= (int)C.blocks;
+    }
+    b -= rider_blocks;
+    if (b < 0) wgrad_tile<true, false>(R, b + rider_blocks, As, Bs);
+    else if (b < dgrad_blocks) dgrad_tile<true, MASK>(D, b, dgrad_blocks, As, Bs);
+    else wgrad_tile<true, MASK>(W, b - dgrad_blocks, As, Bs);
 }
 
 // fixed-order sum of split slabs, batched over up to kMaxSplitJobs weight gradients (one launch for all the layers
@@ -1043,50 +1064,95 @@ RECALGO_EXPORT int recalgo_dense_bwd_bn(const float* x, int ldx, const float* g,
     return finish_wgrad(S, defer_reduce, K, N, dw, dbias, workspace, st);
 }
 
+// partial rows (= workgroups) of a CrossNet backward riding in recalgo_dense_bwd_rider: recalgo_cross_bwd_partial_rows(B)
+static int cross_rider_blocks(int B) { const int need = cdiv(B, 8); return need < 1 ? 1 : (need > 256 ? 256 : need); }
+
+RECALGO_EXPORT int recalgo_dense_bwd_cross_rider_supported(int d, int L) {
+    return (d > 0 && d % 4 == 0 && d <= 512 && L >= 2 && L <= 4) ? 1 : 0;
+}
+
 RECALGO_EXPORT int recalgo_dense_bwd_rider(const float* x, int ldx, const float* g, int ldg, const float* y_mask, const float* w,
                                            int M, int K, int N, const float* c_in, int ldc, float beta, float* dx, int lddx,
                                            float* dw, float* dbias, void* workspace, int defer_reduce, const float* bn_x,
                                            const float* bn_mean, const float* bn_rstd, float* bn_partials,
                                            const float* dx_relu_mask, int ld_mask, const float* r_x, int r_ldx, const float* r_g,
                                            int r_ldg, int r_K, int r_N, float* r_dw, float* r_dbias, void* r_workspace,
+                                           const float* c_x0, int c_x_stride, const float* c_w, const float* c_b, const float* c_g,
+                                           int c_g_stride, int c_d, int c_L, float* c_dx0, void* c_workspace,
                                            recalgo_stream_t stream) {
     DgradArgs D;
     WgradArgs W, R;
     RECALGO_REQUIRE(M > 0 && build_dgrad(D, g, ldg, y_mask, w, M, N, K, c_in, ldc, beta, dx, lddx, 0));
     RECALGO_REQUIRE(bn_partials == nullptr || (bn_x != nullptr && bn_mean != nullptr && bn_rstd != nullptr));
     RECALGO_REQUIRE(dx_relu_mask == nullptr || ld_mask >= K);
+    RECALGO_REQUIRE(r_x != nullptr || c_x0 != nullptr);
     D.dx_mask = dx_relu_mask; D.ld_mask = ld_mask;
     if (dx_relu_mask != nullptr && !(aligned16(dx_relu_mask) && ld_mask % 4 == 0)) D.vec_store = 0;
     D.bn_x = bn_x; D.bn_mean = bn_mean; D.bn_rstd = bn_rstd; D.bn_partials = bn_partials;
     const int S = build_wgrad(W, x, ldx, g, ldg, y_mask, M, K, N, dw, dbias, workspace);
     RECALGO_REQUIRE(S >= 1);
-    // the rider's split partials are always left to recalgo_dense_bwd_weights_reduce (a rider with a single split writes dw itself)
-    const int SR = build_wgrad(R, r_x, r_ldx, r_g, r_ldg, nullptr, M, r_K, r_N, r_dw, r_dbias, r_workspace);
-    RECALGO_REQUIRE(SR >= 1);
+    // the riders' partials are always left to recalgo_dense_bwd_weights_reduce (a weight-gradient rider with a single split writes dw itself)
+    int gr = 0;
+    if (r_x != nullptr) {
+        const int SR = build_wgrad(R, r_x, r_ldx, r_g, r_ldg, nullptr, M, r_K, r_N, r_dw, r_dbias, r_workspace);
+        RECALGO_REQUIRE(SR >= 1 && wgrad_fast(R));
+        gr = cdiv(r_K, BM) * cdiv(r_N, BN) * SR;
+    } else {
+        R = W;
+    }
+    CrossRider C{};
+    if (c_x0 != nullptr) {
+        RECALGO_REQUIRE(recalgo_dense_bwd_cross_rider_supported(c_d, c_L) && c_w && c_b && c_g && c_dx0 && c_workspace);
+        RECALGO_REQUIRE(c_x_stride % 4 == 0 && c_g_stride % 4 == 0 && c_x_stride >= c_d && c_g_stride >= c_d);
+        RECALGO_REQUIRE(aligned16(c_x0) && aligned16(c_w) && aligned16(c_b) && aligned16(c_g) && aligned16(c_dx0));
+        C = CrossRider{c_x0, reinterpret_cast<const float4*>(c_w), reinterpret_cast<const float4*>(c_b), c_g, c_dx0,
+                       static_cast<float*>(c_workspace), (unsigned)c_x_stride, (unsigned)c_g_stride, (unsigned)M, (unsigned)(c_d / 4),
+                       (unsigned)cross_rider_blocks(M)};
+    }
     hipStream_t st = as_stream(stream);
     D.tiles_per_block = bwd_balance(M, K, N).tiles_per_block;
     const int gd = cdiv(cdiv(M, BM) * cdiv(K, BN), D.tiles_per_block), gw = cdiv(K, BM) * cdiv(N, BN) * S;
-    const int gr = cdiv(r_K, BM) * cdiv(r_N, BN) * SR;
-    RECALGO_REQUIRE(dgrad_fast(D) && wgrad_fast(W) && wgrad_fast(R));
-    if (y_mask) hipLaunchKernelGGL((dense_bwd_rider_kernel<true, true>), dim3(gd + gw + gr), dim3(kThreads), 0, st, D, W, R, gd, gr);
-    else hipLaunchKernelGGL((dense_bwd_rider_kernel<true, false>), dim3(gd + gw + gr), dim3(kThreads), 0, st, D, W, R, gd, gr);
+    RECALGO_REQUIRE(dgrad_fast(D) && wgrad_fast(W));
+    const dim3 grid(gd + gw + gr + (int)C.blocks), block(kThreads);
+    const int nv = c_x0 ? cdiv(c_d / 4, 64) : 0;
+#define RIDER_LAUNCH(MASK, NV, L) hipLaunchKernelGGL((dense_bwd_rider_kernel<MASK, NV, L>), grid, block, 0, st, D, W, R, C, gd, gr)
+#define RIDER_L(MASK, NV)                                             \
+    switch (c_L) {                                                    \
+        case 2: RIDER_LAUNCH(MASK, NV, 2); break;                     \
+        case 3: RIDER_LAUNCH(MASK, NV, 3); break;                     \
+        default: RIDER_LAUNCH(MASK, NV, 4); break;                    \
+    }
+    if (nv == 0) {
+        if (y_mask) RIDER_LAUNCH(true, 0, 0);
+        else RIDER_LAUNCH(false, 0, 0);
+    } else {
+        RECALGO_REQUIRE(y_mask == nullptr);          // (a cross rider only beside a layer whose gradient arrives masked: dcn.py's stack)
+        if (nv == 1) { RIDER_L(false, 1) } else { RIDER_L(false, 2) }
+    }
+#undef RIDER_L
+#undef RIDER_LAUNCH
     return finish_wgrad(S, defer_reduce, K, N, dw, dbias, workspace, st);
 }
 
-// 1: recalgo_dense_bwd_rider serves these shapes (the vectorised tile paths of all three GEMMs), 0: launch the rider's weight
-// gradient on its own (recalgo_dense_bwd_weights)
+// 1: recalgo_dense_bwd_rider serves these shapes (the vectorised tile paths of all three GEMMs; r_x == NULL: no weight-gradient
+// rider), 0: launch the riders on their own
 RECALGO_EXPORT int recalgo_dense_bwd_rider_supported(const float* x, int ldx, const float* g, int ldg, const float* y_mask,
                                                      const float* w, int M, int K, int N, float* dx, int lddx, const float* r_x,
                                                      int r_ldx, const float* r_g, int r_ldg, int r_K, int r_N) {
-    if (!(M > 0 && K > 0 && N > 0 && r_K > 0 && r_N > 0 && x && g && w && dx && r_x && r_g)) return 0;
+    if (!(M > 0 && K > 0 && N > 0 && x && g && w && dx)) return 0;
     DgradArgs D;
     WgradArgs W, R;
     static float dummy[4];
-    if (!build_dgrad(D, g, ldg, y_mask, w, M, N, K, nullptr, 0, 0.f, dx, lddx, 0)) return 0;
     alignas(16) static char ws[16];
+    if (!build_dgrad(D, g, ldg, y_mask, w, M, N, K, nullptr, 0, 0.f, dx, lddx, 0)) return 0;
     if (build_wgrad(W, x, ldx, g, ldg, y_mask, M, K, N, dummy, nullptr, ws) < 1) return 0;
-    if (build_wgrad(R, r_x, r_ldx, r_g, r_ldg, nullptr, M, r_K, r_N, dummy, nullptr, ws) < 1) return 0;
-    return (dgrad_fast(D) && wgrad_fast(W) && wgrad_fast(R)) ? 1 : 0;
+    if (!(dgrad_fast(D) && wgrad_fast(W))) return 0;
+    if (r_x != nullptr) {
+        if (!(r_K > 0 && r_N > 0 && r_g)) return 0;
+        if (build_wgrad(R, r_x, r_ldx, r_g, r_ldg, nullptr, M, r_K, r_N, dummy, nullptr, ws) < 1) return 0;
+        if (!wgrad_fast(R)) return 0;
+    }
+    return 1;
 }
 
 RECALGO_EXPORT int recalgo_dense_bwd_weights_reduce(const recalgo_dense_split_t* jobs, int n_jobs,

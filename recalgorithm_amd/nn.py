@@ -22,6 +22,7 @@ def _hip(x: torch.Tensor, C: int) -> bool:
 
 
 DENSE_MAX_K = 4096
+FUSED_TAIL = True           # dense(last_hidden=True) may hand the layer to the fused layer + head + loss kernel (tests switch it off to compare)
 
 
 def _mfma_dense(in_features: int = 0) -> bool:
@@ -44,6 +45,16 @@ class GradJoin:
     def __init__(self):
         self.pending: Optional[torch.Tensor] = None
         self.consumer_done = False
+        # the OTHER direction (ops.defer_cross_rider): the cross network's backward already ran — as a rider of an upper dense
+        # layer's launch — and left its dx0 here; the MLP's first layer adds it in its input-gradient epilogue (beta * C, beta = 1)
+        self.early_dx: Optional[torch.Tensor] = None
+        self.early_used = False
+
+    def take_early(self) -> Optional[torch.Tensor]:
+        t, self.early_dx = self.early_dx, None
+        if t is not None:
+            self.early_used = True
+        return t
 
     def park(self, dx: torch.Tensor) -> bool:
         if self.consumer_done or self.pending is not None:
@@ -165,15 +176,21 @@ class _DenseFn(Function):
                 # input and weight gradient in ONE launch
                 link = ctx.bn_link if ctx.grad_join is None else None
                 src = ctx.x_relu_src if ctx.grad_join is None else None
-                dx = ops.dense_bwd(x2, g2, mask, kernel.data, kernel.grad, db, c_in=x2 if ctx.input_l2 else None,
-                                   beta=ctx.input_l2, defer=True,
+                c_in, beta = (x2, ctx.input_l2) if ctx.input_l2 else (None, 0.0)
+                early = None
+                if ctx.grad_join is not None and c_in is None and ctx.grad_join.early_dx is not None:
+                    e = ctx.grad_join.early_dx
+                    if tuple(e.shape) == tuple(x2.shape) and e.is_contiguous():
+                        early = ctx.grad_join.take_early()       # the other consumer's input gradient, already computed: dx += it
+                        c_in, beta = early, 1.0
+                dx = ops.dense_bwd(x2, g2, mask, kernel.data, kernel.grad, db, c_in=c_in, beta=beta, defer=True,
                                    bn=None if link is None else (link.x, link.mean, link.rstd, link.new_sums()),
-                                   premask=None if src is None else x2).view(ctx.xshape)
+                                   premask=None if src is None else x2, cross_rider=ctx.grad_join is None).view(ctx.xshape)
                 if src is not None:
                     src.premasked = dx             # x is the ReLU output of the layer below: its gradient is masked here
                 if link is not None:
                     link.grad_ptr = dx.data_ptr()
-                if ctx.grad_join is not None and ctx.grad_join.park(dx):
+                if ctx.grad_join is not None and early is None and ctx.grad_join.park(dx):
                     dx = None                      # added by the other consumer of x in its backward kernel
                 return None, dx, None, None, None, None, None, None, None, None
             # (no input gradient wanted: the first layer over a non-differentiable input.  Tried in round 2: the weight
@@ -387,7 +404,7 @@ def dense(x, units, activation: Optional[str] = None,
         x = LazyConcat(parts) if isinstance(x, LazyConcat) else parts[0]
     if isinstance(x, LazyConcat):
         x = x.materialize()
-    if (last_hidden and activation == "relu" and use_bias and not store.building and input_l2 == 0.0 and not bn_stats and drop is None
+    if (last_hidden and FUSED_TAIL and activation == "relu" and use_bias and not store.building and input_l2 == 0.0 and not bn_stats and drop is None
             and grad_join is None and isinstance(x, torch.Tensor) and getattr(x, "_recalgo_relu_src", None) is not None
             and getattr(x, "_recalgo_relu_scale", 1.0) == 1.0):
         from . import ops

@@ -479,6 +479,24 @@ class _CrossFn(Function):
         B, dp = x0p.shape
         d = ctx.d
         L = w.data.shape[0]
+        _cross_rider[:] = [e for e in _cross_rider if e[0] is not ctx]      # (nobody gave it a ride: computed here, as always)
+        early, ctx.early = getattr(ctx, "early", None), None
+        stale_dx = None
+        if early is not None:
+            # this backward already ran as a rider of a dense layer's launch (dense_bwd), on the gradient the fused tail produced
+            eg, edx, jobs, used = early
+            if eg.data_ptr() == g.data_ptr() and eg.shape == g.shape and eg.stride() == g.stride():
+                if used():
+                    return None, None, None, None, None          # ... and the MLP's first layer added dx0 to its own input gradient
+                extra = ctx.grad_join.take() if ctx.grad_join is not None else None
+                return None, (edx if extra is None else edx + extra.reshape(edx.shape)), None, None, None
+            # the cross output had another consumer after all (autograd summed into a different tensor): the early result is
+            # void — its deferred column sums are withdrawn, the backward runs here on the full gradient, and what the MLP's first
+            # layer may already have added is taken back out
+            for j in jobs:
+                if any(j is e for e in _colsum_pending):
+                    _colsum_pending[:] = [e for e in _colsum_pending if e is not j]
+            stale_dx = edx if used() else None
         g = _pad4(g).contiguous()
         lib = _lib_()
         # unpadded width: the column sum of the partial rows joins the step's deferred-sum launch (its own scratch: the
@@ -514,6 +532,8 @@ class _CrossFn(Function):
             dx0 = dx0[:, :d]
         if extra is not None and not fused_extra:
             dx0 = dx0 + extra.reshape(dx0.shape)
+        if stale_dx is not None:
+            dx0 = dx0 - stale_dx.reshape(dx0.shape)
         return None, dx0, None, None, None
 
 
@@ -522,7 +542,10 @@ def cross_stack(store, x0: torch.Tensor, w: Variable, b: Variable, grad_join=Non
     if store.building:
         return torch.zeros_like(x0)
     _chk(x0, torch.float32, "x0")
-    return _CrossFn.apply(store.anchor, x0, w, b, grad_join)
+    out = _CrossFn.apply(store.anchor, x0, w, b, grad_join)
+    if grad_join is not None and out.grad_fn is not None:
+        out._recalgo_cross_node = out.grad_fn        # (the fused tail hands the branch's gradient over early: defer_cross_rider)
+    return out
 
 
 class _CrossLayerFn(Function):
@@ -1343,7 +1366,7 @@ def dense_bwd_weights(x: torch.Tensor, g: torch.Tensor, y_mask: Optional[torch.T
 
 def dense_bwd(x: torch.Tensor, g: torch.Tensor, y_mask: Optional[torch.Tensor], w: torch.Tensor, dw: torch.Tensor,
               dbias: Optional[torch.Tensor], c_in: Optional[torch.Tensor] = None, beta: float = 0.0,
-              defer: bool = False, bn=None, premask: Optional[torch.Tensor] = None) -> torch.Tensor:
+              defer: bool = False, bn=None, premask: Optional[torch.Tensor] = None, cross_rider: bool = True) -> torch.Tensor:
     """Both gradients of a dense layer in one launch (recalgo_dense_bwd): returns dx = (g * [y_mask > 0]) @ w^T
     (+ beta * c_in); dw / dbias as dense_bwd_weights (valid after flush_dense_splits() when `defer`).
     premask [M, K] (rows contiguous): dx is zeroed where premask <= 0 (before the beta * c_in term) — x itself when x is the
@@ -1378,22 +1401,35 @@ def dense_bwd(x: torch.Tensor, g: torch.Tensor, y_mask: Optional[torch.Tensor], 
     if premask is not None and (tuple(premask.shape) != (M, K) or premask.stride(1) != 1 or premask.dtype != torch.float32):
         raise ValueError("dense_bwd: premask must be [M, K] fp32 with contiguous rows")
     rider = _take_wgrad_rider(M, x.device) if defer else None
-    if rider is not None:
-        rx, rg, rdw, rdb = rider
-        rK, rN = rx.shape[1], rg.shape[1]
+    crider = _take_cross_rider(M, x.device) if (defer and cross_rider and y_mask is None) else None
+    if rider is not None or crider is not None:
+        rx, rg, rdw, rdb = rider if rider is not None else (None, None, None, None)
+        rK, rN = (rx.shape[1], rg.shape[1]) if rider is not None else (0, 0)
         if lib.recalgo_dense_bwd_rider_supported(_p(x), x.stride(0), _p(g), g.stride(0), _p(y_mask), _p(w), M, K, N, _p(dx), K,
-                                                 _p(rx), rx.stride(0), _p(rg), rg.stride(0), rK, rN):
-            rws = _wgrad_workspace(rx.device, M, rK, rN, rdw)
+                                                 _p(rx), 0 if rx is None else rx.stride(0), _p(rg), 0 if rg is None else rg.stride(0),
+                                                 rK, rN):
+            rws = _wgrad_workspace(rx.device, M, rK, rN, rdw) if rider is not None else None
+            cargs, cdone = (None, 0, None, None, None, 0, 0, 0, None, None), None
+            if crider is not None:
+                cargs, cdone = _cross_rider_args(*crider)
             _lib.check(lib.recalgo_dense_bwd_rider(_p(x), x.stride(0), _p(g), g.stride(0), _p(y_mask), _p(w), M, K, N, _p(c_in),
                                                    0 if c_in is None else c_in.stride(0), float(beta), _p(dx), K, _p(dw), _p(dbias),
                                                    _p(ws), int(defer), *bnp, _p(premask), 0 if premask is None else premask.stride(0),
-                                                   _p(rx), rx.stride(0), _p(rg), rg.stride(0), rK, rN, _p(rdw), _p(rdb), _p(rws),
-                                                   _stream(x)), "recalgo_dense_bwd_rider")
+                                                   _p(rx), 0 if rx is None else rx.stride(0), _p(rg), 0 if rg is None else rg.stride(0),
+                                                   rK, rN, _p(rdw), _p(rdb), _p(rws), *cargs, _stream(x)), "recalgo_dense_bwd_rider")
             _dense_pending.append((M, K, N, ws, dw, dbias))
-            if int(lib.recalgo_dense_bwd_weights_workspace_bytes(M, rK, rN)) > 0:
-                _dense_pending.append((M, rK, rN, rws, rdw, rdb))
+            if rider is not None:
+                rider_stats["wgrad"] += 1
+                if int(lib.recalgo_dense_bwd_weights_workspace_bytes(M, rK, rN)) > 0:
+                    _dense_pending.append((M, rK, rN, rws, rdw, rdb))
+            if cdone is not None:
+                rider_stats["cross"] += 1
+                cdone()
             return dx
-        dense_bwd_weights(rx, rg, None, rdw, rdb, defer=True)          # (not on the vectorised tile paths: a launch of its own)
+        if rider is not None:
+            dense_bwd_weights(rx, rg, None, rdw, rdb, defer=True)          # (not on the vectorised tile paths: a launch of its own)
+        if crider is not None:
+            _cross_rider.append(crider)                                    # (left to the cross node's own backward)
     _lib.check(lib.recalgo_dense_bwd_bn(_p(x), x.stride(0), _p(g), g.stride(0), _p(y_mask), _p(w), M, K, N, _p(c_in),
                                         0 if c_in is None else c_in.stride(0), float(beta), _p(dx), K, _p(dw), _p(dbias), _p(ws),
                                         int(defer), *bnp, _p(premask), 0 if premask is None else premask.stride(0), _stream(x)),
@@ -1427,6 +1463,61 @@ def launch_wgrad_rider() -> None:
     while _wgrad_rider:
         rx, rg, rdw, rdb = _wgrad_rider.pop()
         dense_bwd_weights(rx, rg, None, rdw, rdb, defer=True)
+
+
+# The CrossNet backward waiting for a ride (recalgo_dense_bwd_rider's c_* arguments): left by the fused tail's backward, which
+# produces the cross branch's upstream gradient long before autograd runs the cross node (created first, it runs last); taken by
+# the next deferred dense_bwd WITHOUT a GradJoin of its own (the layer that shares x0 with the cross network needs the result).
+_cross_rider = []
+rider_stats = {"wgrad": 0, "cross": 0}       # launches that carried a rider (tests / bench read it)
+
+
+def defer_cross_rider(node, g: torch.Tensor) -> None:
+    """node: the _CrossFn node of the cross output whose gradient g [B, d] the caller has just produced."""
+    _cross_rider.clear()
+    if getattr(node, "grad_join", None) is None or not cross_riders_enabled:
+        return
+    w, _ = node.vars
+    L = int(w.data.shape[0])
+    if (g.dim() == 2 and g.is_contiguous() and g.dtype == torch.float32 and g.shape[1] == node.d and node.d % 4 == 0
+            and g.data_ptr() % 16 == 0 and _lib_().recalgo_dense_bwd_cross_rider_supported(int(node.d), L)):
+        _cross_rider.append((node, g))
+
+
+cross_riders_enabled = True
+
+
+def _take_cross_rider(M: int, device):
+    if not _cross_rider:
+        return None
+    node, g = _cross_rider[0]
+    if g.shape[0] != M or g.device != device:
+        return None
+    return _cross_rider.pop()
+
+
+def _cross_rider_args(node, g):
+    """-> (the c_* arguments of recalgo_dense_bwd_rider, what to do once the launch is out)"""
+    lib = _lib_()
+    w, b = node.vars
+    (x0p,) = node.saved_tensors
+    B, dp = x0p.shape
+    L = int(w.data.shape[0])
+    key = ("cross", x0p.device.type, x0p.device.index, B, dp, L, w.grad.data_ptr())
+    ws = _dense_ws.get(key)
+    if ws is None:
+        ws = _dense_ws[key] = torch.empty(max(int(lib.recalgo_cross_bwd_workspace_bytes(B, dp, L)), 16), dtype=torch.uint8,
+                                          device=x0p.device)
+    dx0 = torch.empty_like(x0p)
+    join = node.grad_join
+
+    def done():
+        rows, wsf = int(lib.recalgo_cross_bwd_partial_rows(B)), ws.view(torch.float32)
+        jobs = [(wsf, 0, rows, 2 * L * dp, L * dp, w.grad), (wsf, L * dp, rows, 2 * L * dp, L * dp, b.grad)]
+        _colsum_pending.extend(jobs)
+        join.early_dx, join.early_used = dx0, False
+        node.early = (g, dx0, jobs, lambda: join.early_used)
+    return (_p(x0p), dp, _p(w.data), _p(b.data), _p(g), g.stride(0), dp, L, _p(dx0), _p(ws)), done
 
 
 def _wgrad_workspace(device, M, K, N, dw):
@@ -1827,6 +1918,7 @@ class _TailDenseHeadFn(Function):
         _dlogit_partials.clear()
         _dlogit_partials[dlogit.data_ptr()] = (partials, C, rows, C + 2, B)
         ctx.h2, ctx.dz3, ctx.dh2, ctx.d_side, ctx.vars = h2, dz3, dh2, d_side, (w3, b3)
+        ctx.cross_node = getattr(side, "_recalgo_cross_node", None) if side is not None else None
         ctx.mark_non_differentiable(prob, logit)
         return loss.view(()), prob, logit
 
@@ -1837,6 +1929,9 @@ class _TailDenseHeadFn(Function):
         w3, b3 = ctx.vars
         # (rides in the launch of the layer below's backward, which autograd runs next: ops.dense_bwd picks it up)
         defer_wgrad_rider(ctx.h2, ctx.dz3, w3.grad, b3.grad)
+        if ctx.cross_node is not None and ctx.d_side is not None:
+            # ... and so does the backward of the cross network `side` came out of: autograd would run that node last
+            defer_cross_rider(ctx.cross_node, ctx.d_side)
         return (None, None, None, None, None, None, None, None, ctx.dh2, ctx.d_side)
 
 
