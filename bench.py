@@ -397,6 +397,8 @@ def kernel_rooflines(args, est, feats, device):
                 B * (F * 8 + 3 * d * 4))
         add("cross_bwd", lambda: lib.recalgo_cross_bwd(p(x0), d, p(w), p(b), p(g), d, None, B, d, L, p(dx0), p(dw), p(db), p(ws), 0, st),
             B * 3 * d * 4)
+        cross_row = res[-1]
+        cross_ops = (x0, w, b, g, dx0, ws, L)
     if args.model == "xdeepfm":
         m, D = F, K
         x3 = torch.randn(B, m, D, device=device)
@@ -643,7 +645,7 @@ def kernel_rooflines(args, est, feats, device):
                 del ops._dense_pending[n_pend:]
             add(f"dense_wgrad({Kd}->{Nd}: the fused layer's weight gradient, slabs summed by the deferred-sum launch)", wgrad_once,
                 (B * (Kd + Nd) + Kd * Nd) * 4, fl)
-            res[-1]["prof"] = ["dense_wgrad_kernel", 0]
+            res[-1]["part_of"] = "dense_bwd_rider"            # (in the step it rides in the launch of the layer below's backward)
             ops.dense_bwd_weights(xd, dz_t, None, dwd, dbd, defer=True)       # leaves the layer's split slabs + its pending entry
             keep.append((xd, wd, bd, side_t, wh_t, part_t, dsd_t, dz_t, dh_t, dwd, dbd))
             slab_bytes += int(lib.recalgo_dense_bwd_weights_workspace_bytes(B, Kd, Nd)) + (Kd * Nd + Nd) * 4
@@ -664,6 +666,28 @@ def kernel_rooflines(args, est, feats, device):
             res[-1].pop("prof")
             res[-1]["part_of"] = "tail_dense_head"
             continue
+        if fused_tail and li == len(widths) - 3 and li > 0 and lib.recalgo_dense_bwd_cross_rider_supported(d, cross_ops[6]):
+            # In DCN's step this layer's merged backward launch also carries, as RIDERS dispatched in front of its own tiles, the
+            # weight gradient of the fused last layer and the CrossNet backward (recalgo_dense_bwd_rider): timed here as the ONE
+            # launch the step runs; the three separate rows stay in the table for reference (`part_of`)
+            res[-1].pop("prof")
+            res[-1]["part_of"] = "dense_bwd_rider"
+            cross_row["part_of"] = "dense_bwd_rider"
+            Kn, Nn = widths[li + 1], widths[li + 2]
+            rx, rg = torch.randn(B, Kn, device=device).clamp_(min=0), torch.randn(B, Nn, device=device) * (torch.rand(B, Nn, device=device) > 0.5)
+            rdw, rdb = torch.empty(Kn, Nn, device=device), torch.empty(Nn, device=device)
+            rws = torch.empty(max(int(lib.recalgo_dense_bwd_weights_workspace_bytes(B, Kn, Nn)), 16), dtype=torch.uint8, device=device)
+            cx0, cw, cb, cg, cdx0, cws, cL = cross_ops
+            dxr = torch.empty_like(xd)
+            wsr = ops._wgrad_workspace(device, B, Kd, Nd, dwd)
+            add(f"dense_bwd_rider(dense_bwd {Kd}->{Nd} + riders: dense_wgrad {Kn}->{Nn}, cross_bwd)",
+                lambda: lib.recalgo_dense_bwd_rider(p(xd), Kd, p(gd), Nd, None, p(wd), B, Kd, Nd, None, 0, 0.0, p(dxr), Kd, p(dwd), p(dbd),
+                                                    p(wsr), 1, None, None, None, None, p(xd), Kd, p(rx), Kn, p(rg), Nn, Kn, Nn, p(rdw),
+                                                    p(rdb), p(rws), p(cx0), d, p(cw), p(cb), p(cg), d, d, cL, p(cdx0), p(cws), st),
+                (B * (3 * Kd + 2 * Nd) + 2 * Kd * Nd) * 4 + (B * (Kn + Nn) + Kn * Nn) * 4 + B * 3 * d * 4, 2.0 * fl + 2.0 * B * Kn * Nn)
+            res[-1]["prof"] = ["dense_bwd_rider_kernel", 0]
+            res[-1]["grad_zero_fraction"] = 0.5
+            keep.append((rx, rg, rdw, rdb, rws, dxr))
         res[-1]["grad_zero_fraction"] = 0.5
         res[-1]["mask_mode"] = "gradient arrives pre-masked (no y mask staged)" + ("; dx masked with the layer's input" if pm is not None else "")
         ops.dense_bwd(xd, gd, None, wd, dwd, dbd, defer=True, premask=pm)          # leaves this layer's split slabs + its pending entry
