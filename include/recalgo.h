@@ -431,7 +431,7 @@ int recalgo_dense_bwd_bn(const float* x, int ldx, const float* g, int ldg, const
  *       defer_reduce = 1, ..) — the cross branch's backward (dcn.py:157-160), whose upstream gradient is ready as soon as the head's
  *       is; c_workspace: recalgo_cross_bwd_workspace_bytes(M, c_d, c_L), partial rows as recalgo_cross_bwd leaves them
  *       (recalgo_cross_bwd_partial_rows(M) rows).  Its dx0 is NOT joined here: the layer below adds it (c_in, beta = 1).
- *       Only with y_mask == NULL and recalgo_dense_bwd_cross_rider_supported(c_d, c_L) (c_d % 4 == 0, c_d <= 512, 2 <= c_L <= 4).
+ *       Only with y_mask == NULL and recalgo_dense_bwd_cross_rider_supported(c_d, c_L) (c_d % 4 == 0, c_d <= 512, 1 <= c_L <= 4).
  * The riders' split partials / partial rows are summed by recalgo_dense_bwd_weights_reduce.  Only where
  * recalgo_dense_bwd_rider_supported(..) == 1 (the GEMMs on the vectorised tile paths); else the caller launches them separately. */
 int recalgo_dense_bwd_rider_supported(const float* x, int ldx, const float* g, int ldg, const float* y_mask, const float* w, int M,

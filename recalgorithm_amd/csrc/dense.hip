@@ -1068,7 +1068,7 @@ RECALGO_EXPORT int recalgo_dense_bwd_bn(const float* x, int ldx, const float* g,
 static int cross_rider_blocks(int B) { const int need = cdiv(B, 8); return need < 1 ? 1 : (need > 256 ? 256 : need); }
 
 RECALGO_EXPORT int recalgo_dense_bwd_cross_rider_supported(int d, int L) {
-    return (d > 0 && d % 4 == 0 && d <= 512 && L >= 2 && L <= 4) ? 1 : 0;
+    return (d > 0 && d % 4 == 0 && d <= 512 && L >= 1 && L <= 4) ? 1 : 0;
 }
 
 RECALGO_EXPORT int recalgo_dense_bwd_rider(const float* x, int ldx, const float* g, int ldg, const float* y_mask, const float* w,
@@ -1118,6 +1118,7 @@ RECALGO_EXPORT int recalgo_dense_bwd_rider(const float* x, int ldx, const float*
 #define RIDER_LAUNCH(MASK, NV, L) hipLaunchKernelGGL((dense_bwd_rider_kernel<MASK, NV, L>), grid, block, 0, st, D, W, R, C, gd, gr)
 #define RIDER_L(MASK, NV)                                             \
     switch (c_L) {                                                    \
+        case 1: RIDER_LAUNCH(MASK, NV, 1); break;                     \
         case 2: RIDER_LAUNCH(MASK, NV, 2); break;                     \
         case 3: RIDER_LAUNCH(MASK, NV, 3); break;                     \
         default: RIDER_LAUNCH(MASK, NV, 4); break;                    \

@@ -26,6 +26,9 @@ RECALGO_READER_THREADS=64 timeout 300 python scripts/bench_tfrecord.py --example
 # round 6: the DIN attention lab (plain kernel times + per-phase timeline) and the cost of the reference's default dropout
 bash scripts/gpu_din_lab.sh 50 > $O/${TAG}_din_lab.md 2>&1
 bash scripts/gpu_dropout_cost.sh deepfm din pnn fibinet > $O/${TAG}_dropout_cost.md 2>&1
+# round 6: the fused DCN tail (plain kernel time, per-phase timeline) and the fork / join experiment its riders replace
+bash scripts/gpu_tailfuse_lab.sh > $O/${TAG}_tailfuse_lab.md 2>&1
+timeout 300 python scripts/lab_fork_join.py 2>/dev/null > $O/${TAG}_fork_join_lab.md
 tail -3 $O/${TAG}_pytest_gpu.log; tail -2 $O/${TAG}_smoke.log
 for f in $O/bench_${TAG}_*.json; do python - "$f" <<'PY'
 import json, sys

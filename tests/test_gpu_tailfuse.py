@@ -153,8 +153,9 @@ def test_last_hidden_falls_back_outside_the_served_shapes(dev):
                           torch.Tensor)
 
 
-@pytest.mark.parametrize("hidden,riders", [(("256", "256", "128"), (1, 1)), (("256", "128"), (1, 0)), (("128",), (0, 0))])
-def test_dcn_step_with_fused_tail_and_riders_matches_the_plain_step(dev, hidden, riders):
+@pytest.mark.parametrize("hidden,riders,L", [(("256", "256", "128"), (1, 1), 3), (("256", "128"), (1, 0), 3), (("128",), (0, 0), 3),
+                                             (("512", "256", "128"), (1, 1), 1)])
+def test_dcn_step_with_fused_tail_and_riders_matches_the_plain_step(dev, hidden, riders, L):
     """DCN training steps with the fused tail and its riders (the last layer's weight gradient and the cross network's backward
     inside the launch of the layer below's backward; the cross dx0 joined by the first layer's beta * C epilogue) against the same
     steps with both switched off (separate dense / head+loss launches, cross backward last with the GradJoin inside it).
@@ -162,8 +163,8 @@ def test_dcn_step_with_fused_tail_and_riders_matches_the_plain_step(dev, hidden,
     weight gradient rides; one: no ReLU input, no fused tail at all."""
     from recalgorithm_amd.variables import named_grads
     from tests.test_gpu_models import make
-    a, _, feats, labels = make("dcn", dev, hidden=hidden)
-    b, _, _, _ = make("dcn", dev, hidden=hidden)
+    a, _, feats, labels = make("dcn", dev, hidden=hidden, num_cross_layer=L)       # (L = 1: the reference's flag default, dcn.py:40)
+    b, _, _, _ = make("dcn", dev, hidden=hidden, num_cross_layer=L)
     before = dict(ops.rider_stats)
     spec = None
     with ops.loss_seed(1.0):
