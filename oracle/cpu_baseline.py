@@ -104,10 +104,10 @@ def run(model: str, batch=4096, fields=26, emb=16, max_vocab=1_000_000, seconds=
         quota = None if qv == "max" else max(1, int(int(qv) / int(pv)))
     except (OSError, ValueError):
         pass
-    extra = [also_threads // 2, also_threads] if also_threads and also_threads > 2 * threads else ([also_threads] if also_threads else [])
+    more = [also_threads // 2, also_threads] if also_threads and also_threads > 2 * threads else ([also_threads] if also_threads else [])
     if quota and quota < threads:
-        extra.insert(0, quota)                         # one thread per CPU of the cgroup's quota
-    for n in extra:
+        more.insert(0, quota)                          # one thread per CPU of the cgroup's quota
+    for n in more:
         if n == threads or n < 1:
             continue
         # the same process, model and state at another intra-op thread count ("N = all host cores"; half of them =
