@@ -801,7 +801,10 @@ def in_step_table(model: str):
     return {"source": os.path.relpath(files[-1], ROOT), "steps_profiled": steps,
             "dispatches_per_step": round(sum(t["calls_per_step"] for t in tab), 1),
             "kernel_us_per_step": round(sum(t["calls_per_step"] * t["avg_us"] for t in tab), 1), "kernels": tab,
-            "_shapes": [(n, g, c, a) for n, g, c, a in shapes if c >= 0.9 * steps]}
+            "_shapes": [(n, g, c, a) for n, g, c, a in shapes if c >= 0.9 * steps] +
+                       # (kernels the per-shape section does not list — it covers the dense / CIN / sparse families — have ONE launch
+                       #  shape when they run once per step: their row of the main table is that shape)
+                       [(n, 0, c, a) for n, c, a in rows if 0.9 * steps <= c <= 1.1 * steps and not any(n[:60] == sn[:60] for sn, _, _, _ in shapes)]}
 
 
 def attach_in_step(ks, ist):
