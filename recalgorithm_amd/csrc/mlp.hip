@@ -113,6 +113,7 @@ __global__ __launch_bounds__(kThreads) void bn_moments_kernel(const float4* __re
 // 64 columns of this workgroup, then y = (x - mean) * rstd * gamma + beta on its 64 x 64 tile.  Every workgroup of a
 // column block repeats the merge (nblk x 2 x 64 floats of L2-resident partials — cheaper than a launch in between);
 // the workgroups of tile row 0 record mean / rstd for the backward pass and update the moving statistics.
+constexpr unsigned kBnPre = 8;
 __global__ __launch_bounds__(kThreads) void bn_finalize_apply_kernel(
     const float4* __restrict__ x, const float4* __restrict__ gamma, const float4* __restrict__ beta,
     const float4* __restrict__ partials, unsigned nblk, unsigned nblk_local, unsigned rows, unsigned C4, float eps,
@@ -127,13 +128,48 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_apply_kernel(
     const unsigned c4 = blockIdx.x * 16 + cl;
     const bool ok = c4 < C4;
     const float inv_rows = 1.0f / ((float)rows * (float)(nblk / nblk_local));
+    // ONE memory round trip instead of three: the tile's x rows and this thread's partial rows (both moments) are requested
+    // together, before the first reduction — the launch is a latency chain (5.9 us in the step for 2 us of traffic), and neither
+    // the second pass over the partials nor the x loads depend on the first pass's result, only their arithmetic does.
+    // (up to kBnPre partial rows per thread in registers: nblk <= 128, i.e. B <= 8192 on one rank; more: the loops as before)
+    const unsigned r0 = blockIdx.y * kTileRows;
+    float4 xv[kTileRows / 16];
+#pragma unroll
+    for (unsigned k = 0; k < kTileRows / 16; ++k) {
+        const unsigned r = r0 + rl + 16 * k;
+        xv[k] = (ok && r < rows) ? x[(size_t)r * C4 + c4] : f4_zero();
+    }
+    const bool pre = nblk <= 16 * kBnPre;
+    float4 pm[kBnPre], pq[kBnPre];
+    if (pre && ok) {
+#pragma unroll
+        for (unsigned u = 0; u < kBnPre; ++u) {
+            const unsigned b = rl + 16 * u;
+            if (b < nblk) {
+                pm[u] = partials[(size_t)b * 2 * C4 + c4];
+                pq[u] = partials[(size_t)b * 2 * C4 + C4 + c4];
+            }
+        }
+    }
     float4 acc = f4_zero();
     if (ok) {
+        if (pre) {
+#pragma unroll
+            for (unsigned u = 0; u < kBnPre; ++u) {
+                const unsigned b = rl + 16 * u;
+                if (b < nblk) {
+                    const unsigned bl = b % nblk_local;
+                    const float nb = (float)(min(rows, (bl + 1) * kTileRows) - bl * kTileRows);
+                    acc = f4_fma(pm[u], nb, acc);
+                }
+            }
+        } else {
 #pragma unroll 4                                                // (the partial rows are independent loads: several in flight)
-        for (unsigned b = rl; b < nblk; b += 16) {
-            const unsigned bl = b % nblk_local;
-            const float nb = (float)(min(rows, (bl + 1) * kTileRows) - bl * kTileRows);
-            acc = f4_fma(partials[(size_t)b * 2 * C4 + c4], nb, acc);
+            for (unsigned b = rl; b < nblk; b += 16) {
+                const unsigned bl = b % nblk_local;
+                const float nb = (float)(min(rows, (bl + 1) * kTileRows) - bl * kTileRows);
+                acc = f4_fma(partials[(size_t)b * 2 * C4 + c4], nb, acc);
+            }
         }
     }
     sh[rl][cl] = acc;
@@ -145,12 +181,25 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_apply_kernel(
     __syncthreads();
     acc = f4_zero();
     if (ok) {
+        if (pre) {
+#pragma unroll
+            for (unsigned u = 0; u < kBnPre; ++u) {
+                const unsigned b = rl + 16 * u;
+                if (b < nblk) {
+                    const unsigned bl = b % nblk_local;
+                    const float nb = (float)(min(rows, (bl + 1) * kTileRows) - bl * kTileRows);
+                    const float4 d = f4_sub(pm[u], mean);
+                    acc = f4_add(acc, f4_fma(f4_mul(d, d), nb, pq[u]));
+                }
+            }
+        } else {
 #pragma unroll 4
-        for (unsigned b = rl; b < nblk; b += 16) {
-            const unsigned bl = b % nblk_local;
-            const float nb = (float)(min(rows, (bl + 1) * kTileRows) - bl * kTileRows);
-            const float4 d = f4_sub(partials[(size_t)b * 2 * C4 + c4], mean);
-            acc = f4_add(acc, f4_fma(f4_mul(d, d), nb, partials[(size_t)b * 2 * C4 + C4 + c4]));
+            for (unsigned b = rl; b < nblk; b += 16) {
+                const unsigned bl = b % nblk_local;
+                const float nb = (float)(min(rows, (bl + 1) * kTileRows) - bl * kTileRows);
+                const float4 d = f4_sub(partials[(size_t)b * 2 * C4 + c4], mean);
+                acc = f4_add(acc, f4_fma(f4_mul(d, d), nb, partials[(size_t)b * 2 * C4 + C4 + c4]));
+            }
         }
     }
     sh[rl][cl] = acc;
@@ -171,14 +220,13 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_apply_kernel(
         }
     }
     const float4 sc = f4_mul(rstd, gamma[c4]), bt = beta[c4];
-    const unsigned r0 = blockIdx.y * kTileRows;
     const bool dropping = recalgo_drop::enabled(out_drop);
     const recalgo_drop::Key dkey = dropping ? recalgo_drop::make_key(out_drop) : recalgo_drop::Key{0u, 0u};
 #pragma unroll
     for (unsigned k = 0; k < kTileRows / 16; ++k) {
         const unsigned r = r0 + rl + 16 * k;
         if (r < rows) {
-            const float4 xh = f4_sub(x[(size_t)r * C4 + c4], mean);
+            const float4 xh = f4_sub(xv[k], mean);
             float4 o = make_float4(fmaf(xh.x, sc.x, bt.x), fmaf(xh.y, sc.y, bt.y), fmaf(xh.z, sc.z, bt.z), fmaf(xh.w, sc.w, bt.w));
             if (dropping) o = f4_mul(o, recalgo_drop::factor4(out_drop, dkey, (r * C4 + c4) * 4u));
             y[(size_t)r * C4 + c4] = o;
@@ -249,6 +297,18 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_sum_apply_kernel(
     const unsigned cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const unsigned c4 = blockIdx.x * 16 + cl;
     const bool ok = c4 < C4;
+    // (as bn_finalize_apply_kernel: the tile's operands are requested together with the partial rows, before the reduction —
+    // one memory round trip instead of two)
+    const unsigned r0 = blockIdx.y * kTileRows;
+    float4 xq[kTileRows / 16], gq[kTileRows / 16], zq[kTileRows / 16];
+#pragma unroll
+    for (unsigned t = 0; t < kTileRows / 16; ++t) {
+        const unsigned r = r0 + rl + 16 * t;
+        const bool in = ok && r < rows;
+        xq[t] = in ? x[(size_t)r * C4 + c4] : f4_zero();
+        gq[t] = in ? g[(size_t)r * C4 + c4] : f4_zero();
+        if (ACT) zq[t] = in ? act_z[(size_t)r * C4 + c4] : f4_zero();
+    }
     float4 sb = f4_zero(), sg = f4_zero();
     if (ok) {
 #pragma unroll 4
@@ -302,20 +362,19 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_sum_apply_kernel(
         const float4 mu = mean[c4], rs4 = rstd[c4];
         const float4 k = f4_mul(gamma[c4], rs4);
         const float4 al = ACT ? act_alpha[c4] : f4_zero();
-        const unsigned r0 = blockIdx.y * kTileRows;
 #pragma unroll
         for (unsigned t = 0; t < kTileRows / 16; ++t) {
             const unsigned r = r0 + rl + 16 * t;
             if (r < rows) {
-                const float4 xv = x[(size_t)r * C4 + c4];
+                const float4 xv = xq[t];
                 const float4 xh = f4_mul(f4_sub(xv, mu), rs4);
-                float4 gv = g[(size_t)r * C4 + c4];
+                float4 gv = gq[t];
                 if (dropping) gv = f4_mul(gv, recalgo_drop::factor4(g_drop, dkey, (r * C4 + c4) * 4u));
                 float4 d =
                     make_float4(k.x * (gv.x - inv_rows * (db.x + xh.x * dg.x)), k.y * (gv.y - inv_rows * (db.y + xh.y * dg.y)),
                                 k.z * (gv.z - inv_rows * (db.z + xh.z * dg.z)), k.w * (gv.w - inv_rows * (db.w + xh.w * dg.w)));
                 if (ACT) {
-                    const float4 z = act_z[(size_t)r * C4 + c4];
+                    const float4 z = zq[t];
                     float4 t4;
                     d = make_float4(recalgo_act::bwd<ACT == 1 + RECALGO_ACT_DICE>(z.x, al.x, d.x, t4.x),
                                     recalgo_act::bwd<ACT == 1 + RECALGO_ACT_DICE>(z.y, al.y, d.y, t4.y),
