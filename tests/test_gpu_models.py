@@ -118,10 +118,13 @@ def test_string_hyperparameters_accepted(dev):
     assert est.store.vars["dnn_part/dnn_dense_0/kernel"].shape == (8 * 16, 32)
 
 
-@pytest.mark.parametrize("model", ["dcn", "deepfm"])
+@pytest.mark.parametrize("model", ["dcn", "deepfm", "dcn_tail"])
 def test_hipgraph_replay_matches_eager(dev, model):
-    estA, params, feats, labels = make(model, dev, B=512)
-    estB, _, _, _ = make(model, dev, B=512)
+    # dcn_tail: hidden units for which the step runs the fused last layer + head + loss kernel and its riders (csrc/tailfuse.hip)
+    kw = dict(hidden=("256", "256", "128")) if model == "dcn_tail" else {}
+    model = "dcn" if model == "dcn_tail" else model
+    estA, params, feats, labels = make(model, dev, B=512, **kw)
+    estB, _, _, _ = make(model, dev, B=512, **kw)
     for _ in range(5):
         la = estA.train_step(feats, labels)
     g = GraphedTrainStep(estB.train_step, feats, labels, warmup=3)   # 3 eager + capture
@@ -297,7 +300,7 @@ def test_pnn_forward_backward(dev, method, wr):
         assert float(torch.tril(gw, diagonal=-1).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("model", ["dcn", "deepfm"])
+@pytest.mark.parametrize("model", ["dcn", "deepfm", "dcn_tail"])
 def test_checkpoint_resume_equals_uninterrupted_training(dev, model, tmp_path):
     """4 training steps in one process == 2 steps, save_checkpoint, a NEW estimator restoring from model_dir,
     2 more steps: variables, Adam moments and losses (the live-row list is rebuilt from the restored moments in
@@ -305,8 +308,10 @@ def test_checkpoint_resume_equals_uninterrupted_training(dev, model, tmp_path):
     the last bits because the row-gradient scatter adds with float atomics."""
     from recalgorithm_amd.algorithm.DCN.dcn import dcn_model_fn
     from recalgorithm_amd.algorithm.DeepFM.deepfm import deepfm_model_fn
+    kw = dict(hidden=("256", "256", "128")) if model == "dcn_tail" else {}      # (the fused tail and its riders, csrc/tailfuse.hip)
+    model = "dcn" if model == "dcn_tail" else model
     fn = {"dcn": dcn_model_fn, "deepfm": deepfm_model_fn}[model]
-    ref, params, feats, labels = make(model, dev)
+    ref, params, feats, labels = make(model, dev, **kw)
     spec = synth.SynthSpec(n_fields=8, max_vocab=400, seed=11, oov_frac=0.05)
     batches = [(feats, labels)] + [synth.device_features(spec, 300, dev, batch_index=i)[:2] for i in (1, 2, 3)]
     losses_ref = [float(ref.train_step(*b)) for b in batches]
@@ -400,19 +405,21 @@ def test_graphed_step_copies_into_private_buffers(dev):
     assert any(v.data_ptr() != g.static_f[k].data_ptr() for k, v in feats.items())
 
 
-@pytest.mark.parametrize("model", ["dcn", "deepfm"])
+@pytest.mark.parametrize("model", ["dcn", "deepfm", "dcn_tail"])
 def test_steps_and_resume_are_bit_reproducible(dev, model, tmp_path):
     """No kernel of the step issues a float atomic (the row-gradient scatter is owner-computes, every split sum has a fixed
     order): (a) two runs of the same steps and (b) a run interrupted by save_checkpoint / restore in a NEW estimator are
     BIT-identical — variables, tables, Adam moments."""
     from recalgorithm_amd.algorithm.DCN.dcn import dcn_model_fn
     from recalgorithm_amd.algorithm.DeepFM.deepfm import deepfm_model_fn
+    kw = dict(hidden=("256", "256", "128")) if model == "dcn_tail" else {}      # (the fused tail and its riders, csrc/tailfuse.hip)
+    model = "dcn" if model == "dcn_tail" else model
     fn = {"dcn": dcn_model_fn, "deepfm": deepfm_model_fn}[model]
-    ref, params, feats, labels = make(model, dev)
+    ref, params, feats, labels = make(model, dev, **kw)
     spec = synth.SynthSpec(n_fields=8, max_vocab=400, seed=11, oov_frac=0.05)
     batches = [(feats, labels)] + [synth.device_features(spec, 300, dev, batch_index=i)[:2] for i in (1, 2, 3)]
     losses_ref = [float(ref.train_step(*b)) for b in batches]
-    again, _, _, _ = make(model, dev)
+    again, _, _, _ = make(model, dev, **kw)
     assert [float(again.train_step(*b)) for b in batches] == losses_ref
     md = str(tmp_path / "model_dir")
     a = Estimator(fn, params, RunConfig(device=dev, seed=5, model_dir=md, use_hip_graph=False))
