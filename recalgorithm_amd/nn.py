@@ -252,7 +252,9 @@ class LazyDense:
     def dim(self):
         return self.x.dim()
 
-    is_cuda = True
+    @property
+    def is_cuda(self):
+        return self.x.is_cuda
 
     def materialize(self) -> torch.Tensor:
         if self._out is None:
