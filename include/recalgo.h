@@ -920,6 +920,15 @@ int recalgo_scatter_prepare(const recalgo_scatter_source_t* source, int K, void*
                             int nb_log2, int64_t first_request, int flags, const recalgo_deferred_adam_t* deferred,
                             const recalgo_deferred_adam_t* companion_deferred, int64_t rows, int64_t companion_rows,
                             int sweep_period, const int64_t* step_dev, int step_offset, recalgo_stream_t stream);
+/* recalgo_scatter_prepare for SEVERAL lookups into one arena in ONE launch (n_sources <= 4; first_requests[i]: the first plan slot
+ * of source i, as recalgo_scatter_prepare's first_request): their bucket counts, the catch-up of their requests' lagging rows and
+ * — RECALGO_PREPARE_SWEEP — the step's share of the sweep, once.  For lookups the model issues together (DIN's profile fields,
+ * target item and history, din.py:198-213: three launches of 6 .. 17 us as separate calls); every forward kernel of those lookups
+ * must be enqueued AFTER this call.  No companion arena. */
+int recalgo_scatter_prepare_multi(const recalgo_scatter_source_t* sources, int n_sources, const int64_t* first_requests, int K,
+                                  void* plan_workspace, int64_t plan_requests, int nb_log2, int flags,
+                                  const recalgo_deferred_adam_t* deferred, int64_t rows, int sweep_period, const int64_t* step_dev,
+                                  int step_offset, recalgo_stream_t stream);
 int recalgo_scatter_apply(const recalgo_scatter_source_t* sources, int n_sources, const recalgo_scatter_companion_t* companion,
                           int K, void* plan_workspace, int64_t plan_requests, int nb_log2, int mode, float* w, float* m,
                           float* v, float* grad, const recalgo_deferred_adam_t* deferred, int64_t rows,

@@ -289,8 +289,16 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned* sh, un
 // ---------------------------------------------------------------------------------------------
 // 1. prepare: catch-up of the lookup's rows | the companion's | bucket counts | the sweep of both arenas
 // ---------------------------------------------------------------------------------------------
+// sources one `prepare` launch serves: a step's lookups into one arena that the model issues together (sparse.batch_lookups:
+// DIN's profile fields, target item and history are three lookups into one arena — three launches of 6 .. 17 us until round 6)
+constexpr int kPrepSources = 4;
 struct PrepareArgs {
-    SrcDev S;
+    SrcDev S;                      // source 0 (the only one of a single-lookup launch)
+    SrcDev Sx[kPrepSources - 1];   // sources 1 .. n_src - 1
+    unsigned n_src;
+    unsigned nreq_x[kPrepSources - 1];        // n_ex * F of sources 1 ..
+    unsigned catch_end[kPrepSources];         // catch-up workgroups [catch_end[i-1], catch_end[i]) walk source i's requests
+    unsigned count_end[kPrepSources];         // the same for the count workgroups (relative to b_comp)
     unsigned* total;               // [nb << cs] entries per bucket (count workgroups), one counter every 1 << cs words
     unsigned nb_log2, cs;
     Deferred D;                    // D.last_step == nullptr: no deferred state (no catch-up, no sweep)
@@ -528,8 +536,9 @@ inline unsigned sweep_passes(long long rows_in_launch) {
 }
 
 // the catch-up of up to kThreads requests: lagging rows claimed (one winner per row), listed, replayed
-__device__ __forceinline__ void catchup_requests(const PrepareArgs& A, const Deferred& D, unsigned K, unsigned r, bool active,
-                                                 long long n_rows, unsigned bshift, int cidx, int target, const Claims& C) {
+__device__ __forceinline__ void catchup_requests(const PrepareArgs& A, const SrcDev& S, unsigned n_req, const Deferred& D, unsigned K,
+                                                 unsigned r, bool active, long long n_rows, unsigned bshift, int cidx, int target,
+                                                 const Claims& C) {
     if (threadIdx.x == 0) *C.n = 0;
     __syncthreads();
     // a lagging row is LISTED at once and claimed by a compare-and-swap whose outcome is not waited for here (one winner per
@@ -537,8 +546,8 @@ __device__ __forceinline__ void catchup_requests(const PrepareArgs& A, const Def
     int s = 0, old = 0;
     bool lag = false;
     long long row = -1;
-    if (active && r < A.n_req) {
-        row = request_row_linear(A.S, r);
+    if (active && r < n_req) {
+        row = request_row_linear(S, r);
         // (rows of the blocks the same launch sweeps are the sweep's)
         if (row >= 0 && row < n_rows && !(A.sweeping && (int)((row >> (8 + bshift)) % A.period) == cidx)) {
             s = __hip_atomic_load(&D.last_step[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -562,23 +571,49 @@ __global__ __launch_bounds__(kThreads, 8) void sparse_prepare_kernel(PrepareArgs
     const int cidx = A.period > 0 ? target % A.period : 0;
     if (blockIdx.x < A.b_catch) {
         // ---- catch-up: kCatchReq requests per workgroup, in request order ------------------------------------------------
-        catchup_requests(A, A.D, A.K, blockIdx.x * kCatchReq + threadIdx.x, threadIdx.x < kCatchReq, A.rows, A.bshift, cidx, target,
-                         claims_carve(lds_u));
+        if (A.n_src > 1) {                                    // (uniform over the launch; the source: uniform over the workgroup)
+            unsigned si = 0, b0 = 0;
+#pragma unroll
+            for (int i = 1; i < kPrepSources; ++i)
+                if ((unsigned)i < A.n_src && blockIdx.x >= A.catch_end[i - 1]) { si = i; b0 = A.catch_end[i - 1]; }
+            SrcDev S = A.S;
+            unsigned n_req = A.n_req;
+#pragma unroll
+            for (int i = 1; i < kPrepSources; ++i)
+                if (si == (unsigned)i) { S = A.Sx[i - 1]; n_req = A.nreq_x[i - 1]; }
+            catchup_requests(A, S, n_req, A.D, A.K, (blockIdx.x - b0) * kCatchReq + threadIdx.x, threadIdx.x < kCatchReq, A.rows, A.bshift,
+                             cidx, target, claims_carve(lds_u));
+            return;
+        }
+        catchup_requests(A, A.S, A.n_req, A.D, A.K, blockIdx.x * kCatchReq + threadIdx.x, threadIdx.x < kCatchReq, A.rows, A.bshift, cidx,
+                         target, claims_carve(lds_u));
         return;
     }
     if (blockIdx.x < A.b_comp) {
-        // ---- the companion arena's rows of the same requests (one float per row) ---------------------------------------
-        catchup_requests(A, A.D1, 1, (blockIdx.x - A.b_catch) * kThreads + threadIdx.x, true, A.rows1, A.bshift1, cidx, target,
-                         claims_carve(lds_u));
+        // ---- the companion arena's rows of the same requests (one float per row; single-source launches only) -----------
+        catchup_requests(A, A.S, A.n_req, A.D1, 1, (blockIdx.x - A.b_catch) * kThreads + threadIdx.x, true, A.rows1, A.bshift1, cidx,
+                         target, claims_carve(lds_u));
         return;
     }
     if (blockIdx.x < A.b_count) {
         // ---- count: one entry per DISTINCT row of the tile (its first request, the leader) -----------------------------
         unsigned* hkey = lds_u;                               // [kSlots]     the tile's distinct rows ...
         unsigned* mask = hkey + kSlots;                       // [kSlots][8]  ... and which threads request them
-        const unsigned li = (blockIdx.x - A.b_comp) * kThreads + threadIdx.x;
+        unsigned cb = blockIdx.x - A.b_comp;
+        SrcDev S = A.S;
+        if (A.n_src > 1) {
+            unsigned si = 0, b0 = 0;
+#pragma unroll
+            for (int i = 1; i < kPrepSources; ++i)
+                if ((unsigned)i < A.n_src && cb >= A.count_end[i - 1]) { si = i; b0 = A.count_end[i - 1]; }
+#pragma unroll
+            for (int i = 1; i < kPrepSources; ++i)
+                if (si == (unsigned)i) S = A.Sx[i - 1];
+            cb -= b0;
+        }
+        const unsigned li = cb * kThreads + threadIdx.x;
         unsigned e, f;
-        const long long row = li < A.S.n ? slot_row(A.S, li, &e, &f) : -1;
+        const long long row = li < S.n ? slot_row(S, li, &e, &f) : -1;
         unsigned slot;
         const EqInfo eq = tile_equal(row >= 0 ? (unsigned)row : 0xffffffffu, hkey, mask, &slot);
         if (row >= 0 && eq.before == 0) atomicAdd(&A.total[(size_t)bucket_of((unsigned)row, A.nb_log2) << A.cs], 1u);
@@ -1393,20 +1428,47 @@ RECALGO_EXPORT int64_t recalgo_scatter_plan_workspace_bytes(int64_t n_slots, int
            cap * (int64_t)(K + 1) * (int64_t)sizeof(float) + 64;
 }
 
+static int scatter_prepare_impl(const recalgo_scatter_source_t* source, int n_sources, const int64_t* first_requests, int K,
+                                void* plan_workspace, int64_t plan_requests, int nb_log2, int flags,
+                                const recalgo_deferred_adam_t* deferred, const recalgo_deferred_adam_t* companion_deferred,
+                                int64_t rows, int64_t companion_rows, int sweep_period, const int64_t* step_dev, int step_offset,
+                                recalgo_stream_t stream);
+
 RECALGO_EXPORT int recalgo_scatter_prepare(const recalgo_scatter_source_t* source, int K, void* plan_workspace,
                                            int64_t plan_requests, int nb_log2, int64_t first_request, int flags,
                                            const recalgo_deferred_adam_t* deferred,
                                            const recalgo_deferred_adam_t* companion_deferred, int64_t rows, int64_t companion_rows,
                                            int sweep_period, const int64_t* step_dev, int step_offset, recalgo_stream_t stream) {
+    return scatter_prepare_impl(source, (source != nullptr && source->n_ex > 0) ? 1 : 0, &first_request, K, plan_workspace, plan_requests,
+                                nb_log2, flags, deferred, companion_deferred, rows, companion_rows, sweep_period, step_dev, step_offset,
+                                stream);
+}
+
+RECALGO_EXPORT int recalgo_scatter_prepare_multi(const recalgo_scatter_source_t* sources, int n_sources, const int64_t* first_requests,
+                                                 int K, void* plan_workspace, int64_t plan_requests, int nb_log2, int flags,
+                                                 const recalgo_deferred_adam_t* deferred, int64_t rows, int sweep_period,
+                                                 const int64_t* step_dev, int step_offset, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(sources != nullptr && first_requests != nullptr && n_sources >= 1 && n_sources <= kPrepSources);
+    for (int i = 0; i < n_sources; ++i) RECALGO_REQUIRE(sources[i].n_ex > 0);
+    return scatter_prepare_impl(sources, n_sources, first_requests, K, plan_workspace, plan_requests, nb_log2, flags, deferred, nullptr,
+                                rows, 0, sweep_period, step_dev, step_offset, stream);
+}
+
+static int scatter_prepare_impl(const recalgo_scatter_source_t* source, int n_sources, const int64_t* first_requests, int K,
+                                void* plan_workspace, int64_t plan_requests, int nb_log2, int flags,
+                                const recalgo_deferred_adam_t* deferred, const recalgo_deferred_adam_t* companion_deferred,
+                                int64_t rows, int64_t companion_rows, int sweep_period, const int64_t* step_dev, int step_offset,
+                                recalgo_stream_t stream) {
     RECALGO_REQUIRE(nb_ok(nb_log2) && plan_workspace != nullptr);
-    RECALGO_REQUIRE(first_request >= 0 && first_request % kThreads == 0 && first_request < (1ll << 31));
     RECALGO_REQUIRE(plan_requests >= 0 && plan_requests % kThreads == 0);
     RECALGO_REQUIRE(rows >= 0 && rows < (1ll << 31) && companion_rows >= 0 && companion_rows < (1ll << 31));
     const bool count = (flags & RECALGO_PREPARE_COUNT) != 0, sweep = (flags & RECALGO_PREPARE_SWEEP) != 0;
     const bool catchup = (flags & RECALGO_PREPARE_CATCHUP) != 0;
+    const int64_t first_request = first_requests[0];
+    RECALGO_REQUIRE(first_request >= 0 && first_request % kThreads == 0 && first_request < (1ll << 31));
     SrcDev S[kMaxSources];
     unsigned n = 0;
-    if (source != nullptr && source->n_ex > 0) {
+    if (n_sources >= 1) {
         RECALGO_REQUIRE(to_dev(source, 1, S, &n, false));
         RECALGO_REQUIRE(first_request + (int64_t)n <= plan_requests);
     } else {
@@ -1418,6 +1480,23 @@ RECALGO_EXPORT int recalgo_scatter_prepare(const recalgo_scatter_source_t* sourc
     PrepareArgs A;
     A.S = S[0];
     A.S.first = (unsigned)first_request;
+    A.n_src = n_sources > 1 ? (unsigned)n_sources : 1u;
+    unsigned n_x[kPrepSources - 1] = {0, 0, 0};
+    for (int i = 1; i < kPrepSources; ++i) {
+        A.Sx[i - 1] = S[1];                                    // (an unused slot: first = 0xffffffff, n = 0)
+        A.nreq_x[i - 1] = 0;
+        if (i < n_sources) {
+            SrcDev T[kMaxSources];
+            unsigned ni = 0;
+            RECALGO_REQUIRE(first_requests[i] >= 0 && first_requests[i] % kThreads == 0 && first_requests[i] < (1ll << 31));
+            RECALGO_REQUIRE(to_dev(source + i, 1, T, &ni, false) && first_requests[i] + (int64_t)ni <= plan_requests);
+            RECALGO_REQUIRE(companion_deferred == nullptr);   // (a companion arena rides on single-lookup launches only)
+            A.Sx[i - 1] = T[0];
+            A.Sx[i - 1].first = (unsigned)first_requests[i];
+            A.nreq_x[i - 1] = (unsigned)((int64_t)source[i].n_ex * source[i].F);
+            n_x[i - 1] = ni;
+        }
+    }
     A.total = carve(plan_workspace, plan_requests, nb_log2).total;
     A.nb_log2 = (unsigned)nb_log2;
     A.cs = counter_shift();
@@ -1431,9 +1510,19 @@ RECALGO_EXPORT int recalgo_scatter_prepare(const recalgo_scatter_source_t* sourc
     A.K = (unsigned)K;
     A.n_req = n ? (unsigned)((int64_t)source->n_ex * source->F) : 0u;
     RECALGO_REQUIRE(!catchup || A.D.last_step != nullptr);
-    const unsigned catch_blocks = (catchup && A.n_req) ? (unsigned)cdiv(A.n_req, kCatchReq) : 0u;
+    unsigned catch_blocks = (catchup && A.n_req) ? (unsigned)cdiv(A.n_req, kCatchReq) : 0u;
     const unsigned comp_blocks = (catchup && A.D1.last_step && A.n_req) ? (unsigned)cdiv(A.n_req, kThreads) : 0u;
-    const unsigned count_blocks = (count && n) ? (unsigned)cdiv(n, kThreads) : 0u;
+    unsigned count_blocks = (count && n) ? (unsigned)cdiv(n, kThreads) : 0u;
+    A.catch_end[0] = catch_blocks;
+    A.count_end[0] = count_blocks;
+    for (int i = 1; i < kPrepSources; ++i) {
+        if (i < n_sources) {
+            if (catchup) catch_blocks += (unsigned)cdiv(A.nreq_x[i - 1], kCatchReq);
+            if (count) count_blocks += (unsigned)cdiv(n_x[i - 1], kThreads);
+        }
+        A.catch_end[i] = catch_blocks;
+        A.count_end[i] = count_blocks;
+    }
     A.period = sweep_period < 1 ? 1 : sweep_period;
     A.rows = rows; A.rows1 = companion_rows;
     // row blocks (of 256 << g rows) per step: every P-th block of the arena

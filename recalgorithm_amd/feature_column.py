@@ -20,7 +20,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from . import ops
+from . import ops, sparse
 from .variables import EmbeddingArena, current_store, truncated_normal
 
 Ragged = namedtuple("Ragged", ["values", "offsets"])   # int64 [nnz], int64 [B+1]
@@ -314,6 +314,7 @@ def input_layer(features, feature_columns, _layer_name: Optional[str] = None) ->
             parts.append(mh)
     if len(parts) > 1:
         ops.flush_lazy_gathers()             # (a gather left to its consumer, ops.gather_feeds_cross, must have run before the concat reads it)
+        sparse.flush_batch()                 # (the same for lookups collected by sparse.batch_lookups)
     return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
 
 
@@ -349,6 +350,7 @@ def input_layers_concat(features, feature_columns) -> torch.Tensor:
             parts.append(ops.embedding_gather(store, ids.reshape(-1, 1).contiguous(), ar, rb))
     if len(parts) > 1:
         ops.flush_lazy_gathers()
+        sparse.flush_batch()
     return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
 
 
@@ -393,6 +395,8 @@ def sequence_input_layer(features, feature_columns, max_length: Optional[int] = 
         o, l = ops.sequence_gather(store, ids.values, ids.offsets, ar, tname, T)
         outs.append(o)
         lens = l
+    if len(outs) > 1:
+        sparse.flush_batch()                 # (inside sparse.batch_lookups(): the outputs are read by the cat)
     return (outs[0] if len(outs) == 1 else torch.cat(outs, dim=-1)), lens
 
 

@@ -202,14 +202,22 @@ class _GatherFn(Function):
         dv, stp = sparse.view_for(ctx.src, arena, anchor_store(anchor))
         ctx.arena, ctx.ids, ctx.row_base = arena, ids, row_base
         # (lazy_ok: only the plain lookup of embedding_gather() may be left to its consumer — not the staged rows of a sharded arena)
-        ctx.lazy = lazy_ok and _lazy_gather_on and dv is None and K % 4 == 0 and F * K <= 1024 and ids.is_contiguous()
+        batched = ctx.src is not None and getattr(ctx.src, "deferred", False)       # (sparse.batch_lookups: prepare work pending)
+        ctx.lazy = (lazy_ok and _lazy_gather_on and not batched and dv is None and K % 4 == 0 and F * K <= 1024
+                    and ids.is_contiguous())
         if ctx.lazy:
             global _lazy_hit
             _lazy_hit = True                 # (embedding_gather() hangs the pending launch on the tensor autograd hands out)
             return out
-        _lib.check(_lib_().recalgo_embedding_gather_fwd_deferred(
-            _p(ids), _p(arena.weight), _p(row_base), B, F, K, _p(out), F * K, 0, dv, stp, 0, _stream(ids)),
-            "recalgo_embedding_gather_fwd")
+
+        def launch():
+            _lib.check(_lib_().recalgo_embedding_gather_fwd_deferred(
+                _p(ids), _p(arena.weight), _p(row_base), B, F, K, _p(out), F * K, 0, dv, stp, 0, _stream(ids)),
+                "recalgo_embedding_gather_fwd")
+        if batched:
+            sparse.defer_launch(launch)      # behind the block's one `prepare` launch (the rows it catches up are read here)
+        else:
+            launch()
         return out
 
     @staticmethod
@@ -314,9 +322,15 @@ class _SeqGatherFn(Function):
             ctx.src = sparse.begin_lookup(arena, anchor_store(anchor), values, offsets, None, arena.tables[table_name][0], B, T, training)
         dv, stp = (None, None) if table_name == "__staged__" else sparse.view_for(ctx.src, arena, anchor_store(anchor))
         rb0 = 0 if table_name == "__staged__" else arena.tables[table_name][0]
-        _lib.check(_lib_().recalgo_sequence_gather_fwd_deferred(
-            _p(values), _p(offsets), _p(table), B, T, K, _p(out), _p(seq_len), dv, rb0, stp, 0, _stream(offsets)),
-            "recalgo_sequence_gather_fwd")
+
+        def launch():
+            _lib.check(_lib_().recalgo_sequence_gather_fwd_deferred(
+                _p(values), _p(offsets), _p(table), B, T, K, _p(out), _p(seq_len), dv, rb0, stp, 0, _stream(offsets)),
+                "recalgo_sequence_gather_fwd")
+        if ctx.src is not None and getattr(ctx.src, "deferred", False):
+            sparse.defer_launch(launch)      # (sparse.batch_lookups: behind the block's one `prepare` launch)
+        else:
+            launch()
         ctx.args = (values, offsets, arena, table_name, T)
         ctx.mark_non_differentiable(seq_len)
         ctx.set_materialize_grads(False)      # (else autograd fills a zero "gradient" for seq_len: one launch per lookup and step)

@@ -302,7 +302,12 @@ def begin_lookup(arena, store, ids: torch.Tensor, offsets: Optional[torch.Tensor
         plan.swept = True
         if d1 is not None:
             plan_of(companion_arena).swept = True
-    if flags:
+    if _batch is not None and d1 is None and companion_arena is None:
+        # the model issues several lookups together (batch_lookups): ONE launch for all of an arena's at the end of the block; the
+        # forward kernels of these lookups are enqueued behind it (ops: defer_launch)
+        src.deferred = True
+        _batch["arenas"].setdefault(id(arena), (arena, plan, []))[2].append((src, cs, first, flags, d, step))
+    elif flags:
         _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), arena.K, ctypes.c_void_p(plan.ws.data_ptr()), plan.capacity, plan.nb_log2,
                                                first, flags, None if d is None else ctypes.byref(d),
                                                None if d1 is None else ctypes.byref(d1), arena.weight.shape[0], c_rows, sweep_period(),
@@ -311,6 +316,86 @@ def begin_lookup(arena, store, ids: torch.Tensor, offsets: Optional[torch.Tensor
     plan.sources.append(src)
     plan.counted = plan.counted[:2] + (plan.counted[2] + (id(src),),)
     return src
+
+
+# ---- several lookups issued together: one `prepare` launch per arena -------------------------------------------------------------
+_batch = None                # the active batch_lookups() block: {"arenas": {id(arena): (arena, plan, [entries])}, "launches": [fn]}
+MAX_PREPARE_SOURCES = 4      # recalgo_scatter_prepare_multi
+BATCH_LOOKUPS = True         # False: batch_lookups() blocks change nothing (tests compare the two)
+
+
+class batch_lookups:
+    """with sparse.batch_lookups(): a = fc.input_layer(..); b, n = fc.sequence_input_layer(..)
+    The TRAIN lookups issued inside register with their arena's plan as always, but their `prepare` work (bucket counts, catch-up
+    of lagging rows, the step's share of the sweep) is ONE launch per arena at the end of the block instead of one per lookup,
+    and their forward kernels run behind it (DIN: three launches of 6 / 17 / 17 us -> one).  Nothing inside the block may READ a
+    lookup's output (the tensors are returned unfilled); code that has to — a torch.cat of per-column outputs — calls flush_batch()
+    first."""
+
+    def __enter__(self):
+        global _batch
+        self.prev = _batch
+        if BATCH_LOOKUPS:
+            _batch = {"arenas": {}, "launches": []}
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _batch
+        if not BATCH_LOOKUPS and _batch is self.prev:
+            return False
+        b, _batch = _batch, self.prev
+        if et is None and b is not None:
+            _flush_batch(b)
+        return False
+
+
+def batching() -> bool:
+    return _batch is not None
+
+
+def defer_launch(fn) -> None:
+    """the forward kernel of a lookup whose prepare work is pending: enqueued by flush_batch() / the end of the block"""
+    _batch["launches"].append(fn)
+
+
+def flush_batch() -> None:
+    """inside a batch_lookups() block: launch what is pending now (the block goes on collecting)"""
+    global _batch
+    if _batch is not None and (_batch["arenas"] or _batch["launches"]):
+        b, _batch = _batch, {"arenas": {}, "launches": []}
+        _flush_batch(b)
+
+
+def _flush_batch(b) -> None:
+    lib = _lib.load()
+    for arena, plan, entries in b["arenas"].values():
+        for i in range(0, len(entries), MAX_PREPARE_SOURCES):
+            chunk = entries[i:i + MAX_PREPARE_SOURCES]
+            flags = 0
+            for e in chunk:
+                flags |= e[3]
+            d = next((e[4] for e in chunk if e[4] is not None), None)
+            step = next((e[5] for e in chunk if e[5] is not None), None)
+            ws = ctypes.c_void_p(plan.ws.data_ptr())
+            stp = None if step is None else ctypes.c_void_p(step.data_ptr())
+            if len(chunk) == 1:
+                _, cs, first, _, _, _ = chunk[0]
+                _lib.check(lib.recalgo_scatter_prepare(ctypes.byref(cs), arena.K, ws, plan.capacity, plan.nb_log2, first, flags,
+                                                       None if d is None else ctypes.byref(d), None, arena.weight.shape[0], 0,
+                                                       sweep_period(), stp, 0, _stream(arena.weight)), "recalgo_scatter_prepare")
+            else:
+                arr = (_CSource * len(chunk))(*[e[1] for e in chunk])
+                firsts = (ctypes.c_int64 * len(chunk))(*[e[2] for e in chunk])
+                _lib.check(lib.recalgo_scatter_prepare_multi(arr, len(chunk), firsts, arena.K, ws, plan.capacity, plan.nb_log2, flags,
+                                                             None if d is None else ctypes.byref(d), arena.weight.shape[0],
+                                                             sweep_period(), stp, 0, _stream(arena.weight)),
+                           "recalgo_scatter_prepare_multi")
+                prepare_stats["merged"] += len(chunk) - 1
+    for fn in b["launches"]:
+        fn()
+
+
+prepare_stats = {"merged": 0}        # `prepare` launches saved by batch_lookups (tests read it)
 
 
 def companion_enabled() -> bool:

@@ -482,3 +482,35 @@ def test_dcn_without_dense_columns_on_every_input_layer_path(dev, layout):
     for k in ga:
         assert_bit_exact(ga[k], gb[k], f"{layout} d({k})")
     assert torch.isfinite(pa).all()
+
+
+def test_din_batched_lookups_are_bit_identical_to_separate_prepares(dev):
+    """DIN issues its three lookups (profile fields, target item, history) inside sparse.batch_lookups(): ONE `prepare` launch for
+    the arena (recalgo_scatter_prepare_multi) and the three forward kernels behind it, against one launch per lookup in front of
+    each forward kernel.  The counts, the catch-up and the sweep are the same work on the same rows: every variable, table and
+    optimizer slot bit-identical after 4 steps."""
+    import bench
+    from recalgorithm_amd import sparse
+    runs = {}
+    for batched in (True, False):
+        sparse.BATCH_LOOKUPS = batched
+        try:
+            args = bench.parse_args(["--model", "din", "--batch", "256", "--fields", "8", "--max-vocab", "500"])
+            est, spec, feats, labels, _ = bench.build_estimator(args, dev)
+            merged0 = sparse.prepare_stats["merged"]
+            losses = [float(est.train_step(feats, labels)) for _ in range(4)]
+            merged = sparse.prepare_stats["merged"] - merged0
+            torch.cuda.synchronize()
+            sparse.sync_store(est.store)
+            arrays = {k: v.detach().clone() for k, v in est.store.named_arrays().items()}
+            arrays["flat_m"], arrays["flat_v"] = est.store.flat_m.clone(), est.store.flat_v.clone()
+            for n, a in est.store.arenas.items():
+                if a.weight is not None:
+                    arrays[f"{n}/m"], arrays[f"{n}/v"] = a.m.clone(), a.v.clone()
+            runs[batched] = (losses, arrays, merged)
+        finally:
+            sparse.BATCH_LOOKUPS = True
+    assert runs[True][2] >= 4 and runs[False][2] == 0, "the batched run was expected to save `prepare` launches, the other none"
+    assert runs[True][0] == runs[False][0]
+    for k in runs[False][1]:
+        assert_bit_exact(runs[True][1][k], runs[False][1][k], what=f"din {k}: batched lookups vs separate prepares")
