@@ -302,7 +302,8 @@ def begin_lookup(arena, store, ids: torch.Tensor, offsets: Optional[torch.Tensor
         plan.swept = True
         if d1 is not None:
             plan_of(companion_arena).swept = True
-    if _batch is not None and d1 is None and companion_arena is None:
+    if (_batch is not None and d1 is None and companion_arena is None and getattr(arena, "sharding", None) is None
+            and "__staged__" not in getattr(arena, "tables", {})):
         # the model issues several lookups together (batch_lookups): ONE launch for all of an arena's at the end of the block; the
         # forward kernels of these lookups are enqueued behind it (ops: defer_launch)
         src.deferred = True
