@@ -759,11 +759,20 @@ def cpu_quota():
 def composite_roofline(ks, ms_per_step):
     """The whole step against its kernels' rooflines: sum over the step's hand-written kernels of t_min = max(algorithmic
     bytes / HBM peak, algorithmic FLOP / fp32 MFMA peak), divided by the measured step time (launch gaps, latency-bound
-    kernels and everything else in the denominator)."""
-    t_min = sum(max(k["alg_bytes"] / (HBM_PEAK_GBS * 1e9), k.get("alg_flops", 0.0) / (FP32_PEAK_TFLOPS * 1e12))
-                for k in ks if not k.get("part_of"))
-    return {"t_min_us": round(t_min * 1e6, 2), "ms_per_step": ms_per_step, "frac": round(t_min / (ms_per_step * 1e-3), 4),
-            "kernels_counted": sum(1 for k in ks if not k.get("part_of"))}
+    kernels and everything else in the denominator).  A FUSED launch (DCN's tail, its rider launch) counts with the max over
+    its summed bytes and FLOPs — less than the sum of the t_min of the launches it replaced; `frac_unfused` is the same ratio
+    with those launches' own t_min instead (the accounting of the lines before the fusion: comparable across rounds)."""
+    tm = lambda k: max(k["alg_bytes"] / (HBM_PEAK_GBS * 1e9), k.get("alg_flops", 0.0) / (FP32_PEAK_TFLOPS * 1e12))
+    t_min = sum(tm(k) for k in ks if not k.get("part_of"))
+    out = {"t_min_us": round(t_min * 1e6, 2), "ms_per_step": ms_per_step, "frac": round(t_min / (ms_per_step * 1e-3), 4),
+           "kernels_counted": sum(1 for k in ks if not k.get("part_of"))}
+    fused = {"tail_dense_head", "dense_bwd_rider"}
+    if any(k.get("part_of") in fused for k in ks):
+        t_un = sum(tm(k) for k in ks if (not k.get("part_of") and not any(k["kernel"].startswith(f + "(") for f in fused))
+                   or (k.get("part_of") in fused and not k["kernel"].startswith("dense_wgrad(")))
+        out["t_min_unfused_us"] = round(t_un * 1e6, 2)
+        out["frac_unfused"] = round(t_un / (ms_per_step * 1e-3), 4)
+    return out
 
 
 def in_step_table(model: str):
