@@ -920,6 +920,21 @@ int recalgo_scatter_prepare(const recalgo_scatter_source_t* source, int K, void*
                             int nb_log2, int64_t first_request, int flags, const recalgo_deferred_adam_t* deferred,
                             const recalgo_deferred_adam_t* companion_deferred, int64_t rows, int64_t companion_rows,
                             int sweep_period, const int64_t* step_dev, int step_offset, recalgo_stream_t stream);
+/* The FORWARD kernels of several plain lookups in one launch (n_jobs <= 4): kind 0 = recalgo_embedding_gather_fwd(ids = ids [B, F],
+ * arena = table, row_base = aux, .., out, out_stride, out_col), kind 1 = recalgo_sequence_gather_fwd(values = ids, offsets = aux,
+ * table, B, T = F_or_T, K, out, seq_len).  For the lookups a model issues together behind one recalgo_scatter_prepare_multi
+ * (DIN: profile fields, target item, history — three launches of ~5 us each): no deferred view, the rows are current. */
+typedef struct {
+    int kind;                  /* 0: id-matrix gather, 1: zero-padded sequence gather */
+    const int64_t* ids;
+    const int64_t* aux;        /* kind 0: row_base [F]; kind 1: offsets [B + 1] */
+    const float* table;        /* kind 0: the arena; kind 1: row 0 of the table */
+    int B, F_or_T, K;
+    float* out;
+    int out_stride, out_col;   /* kind 0 only */
+    int32_t* seq_len;          /* kind 1 only */
+} recalgo_lookup_job_t;
+int recalgo_lookup_multi_fwd(const recalgo_lookup_job_t* jobs, int n_jobs, recalgo_stream_t stream);
 /* recalgo_scatter_prepare for SEVERAL lookups into one arena in ONE launch (n_sources <= 4; first_requests[i]: the first plan slot
  * of source i, as recalgo_scatter_prepare's first_request): their bucket counts, the catch-up of their requests' lagging rows and
  * — RECALGO_PREPARE_SWEEP — the step's share of the sweep, once.  For lookups the model issues together (DIN's profile fields,

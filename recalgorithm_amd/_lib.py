@@ -140,6 +140,7 @@ SIGNATURES = {
     "recalgo_scatter_source_slots": (c_int64, [c_int, c_int, c_int]),
     "recalgo_scatter_plan_header_bytes": (c_int64, [c_int]),
     "recalgo_scatter_prepare": (c_int, [P, c_int, P, c_int64, c_int, c_int64, c_int, P, P, c_int64, c_int64, c_int, P, c_int, P]),
+    "recalgo_lookup_multi_fwd": (c_int, [P, c_int, P]),
     "recalgo_scatter_prepare_multi": (c_int, [P, c_int, P, c_int, P, c_int64, c_int, c_int, P, c_int64, c_int, P, c_int, P]),
     "recalgo_scatter_apply": (c_int, [P, c_int, P, c_int, P, c_int64, c_int, c_int, P, P, P, P, P, c_int64, P, P, c_int,
                                       c_float, c_float, c_float, c_float, P]),

@@ -334,6 +334,52 @@ __global__ __launch_bounds__(kThreads) void seq_gather_fwd_kernel(
     reinterpret_cast<V*>(out)[i] = v;
 }
 
+// Several plain lookups in ONE launch (the lookups a model issues together, behind one `prepare` launch: sparse.batch_lookups):
+// job j owns the workgroups [first_block[j], first_block[j + 1]); kind 0 = the id-matrix gather above, kind 1 = the sequence
+// gather above — the same per-thread work, no deferred view (the rows were caught up by the launch in front).
+constexpr int kMultiLookups = 4;
+struct LookupJob {
+    const int64_t* ids;        // gather: ids [B, F]; sequence: values
+    const int64_t* aux;        // gather: row_base [F]; sequence: offsets [B + 1]
+    const float* table;        // gather: the arena; sequence: the table's first row
+    float* out;
+    int32_t* seq_len;          // sequence only
+    unsigned total, FT, KV, out_stride, out_col, kind, first_block;
+};
+struct LookupJobs { LookupJob job[kMultiLookups]; int n; };
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void lookup_multi_fwd_kernel(LookupJobs J) {
+    using V = typename VecT<VEC>::type;
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < kMultiLookups; ++k)
+        if (k < J.n && blockIdx.x >= J.job[k].first_block) j = k;
+    LookupJob A = J.job[0];                                   // (select by value: a dynamic index into the kernel arguments
+#pragma unroll                                                //  would go through scratch)
+    for (int k = 1; k < kMultiLookups; ++k)
+        if (j == k) A = J.job[k];
+    const unsigned i = (blockIdx.x - A.first_block) * kThreads + threadIdx.x;
+    if (i >= A.total) return;
+    const unsigned row = i / A.KV, q = i - row * A.KV;
+    const unsigned b = row / A.FT, f = row - b * A.FT;
+    V v = vzero<VEC>();
+    if (A.kind == 0) {
+        const int64_t id = A.ids[row];
+        if (id >= 0) v = reinterpret_cast<const V*>(A.table)[(A.aux[f] + id) * A.KV + q];
+        *reinterpret_cast<V*>(A.out + (size_t)b * A.out_stride + A.out_col + (f * A.KV + q) * VEC) = v;
+    } else {
+        const int64_t beg = A.aux[b];
+        const int64_t len = A.aux[b + 1] - beg;
+        if (f == 0 && q == 0) A.seq_len[b] = (int32_t)(len < (int64_t)A.FT ? len : (int64_t)A.FT);
+        if ((int64_t)f < len) {
+            const int64_t id = A.ids[beg + f];
+            if (id >= 0) v = reinterpret_cast<const V*>(A.table)[id * A.KV + q];
+        }
+        reinterpret_cast<V*>(A.out)[i] = v;
+    }
+}
+
 // workgroup = ex consecutive (b, t) positions
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void seq_gather_bwd_kernel(
@@ -676,6 +722,39 @@ RECALGO_EXPORT int recalgo_sequence_gather_fwd_deferred(const int64_t* values, c
         hipLaunchKernelGGL(seq_gather_fwd_kernel<1>, dim3(cdiv(total, kThreads)), dim3(kThreads), 0,
                            as_stream(stream), values, offsets, table, (unsigned)total, (unsigned)T, (unsigned)K,
                            out, seq_len, D);
+    RECALGO_RETURN_LAST();
+}
+
+RECALGO_EXPORT int recalgo_lookup_multi_fwd(const recalgo_lookup_job_t* jobs, int n_jobs, recalgo_stream_t stream) {
+    RECALGO_REQUIRE(jobs != nullptr && n_jobs >= 1 && n_jobs <= kMultiLookups);
+    LookupJobs J;
+    J.n = n_jobs;
+    unsigned blocks = 0;
+    int vec = 4;
+    for (int i = 0; i < n_jobs; ++i) {
+        const recalgo_lookup_job_t& c = jobs[i];
+        RECALGO_REQUIRE(c.B >= 0 && c.F_or_T > 0 && c.K > 0 && c.ids && c.aux && c.table && c.out);
+        if (c.kind == 0) {
+            RECALGO_REQUIRE(c.out_stride >= c.out_col + c.F_or_T * c.K);
+            if (vec_of(c.K, c.out_stride, c.out_col) != 4) vec = 1;
+        } else {
+            RECALGO_REQUIRE(c.kind == 1 && c.seq_len != nullptr);
+            if (c.K % 4 != 0) vec = 1;
+        }
+    }
+    for (int i = 0; i < kMultiLookups; ++i) {
+        LookupJob& A = J.job[i];
+        if (i >= n_jobs) { A = LookupJob{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, 1, 0, 0, 0, 0xffffffffu}; continue; }
+        const recalgo_lookup_job_t& c = jobs[i];
+        const int64_t total = (int64_t)c.B * c.F_or_T * (c.K / vec);
+        RECALGO_REQUIRE(total < (1ll << 31));
+        A = LookupJob{c.ids, c.aux, c.table, c.out, c.seq_len, (unsigned)total, (unsigned)c.F_or_T, (unsigned)(c.K / vec),
+                      (unsigned)c.out_stride, (unsigned)c.out_col, (unsigned)c.kind, blocks};
+        blocks += (unsigned)cdiv(total, kThreads);
+    }
+    if (blocks == 0) return 0;
+    if (vec == 4) hipLaunchKernelGGL(lookup_multi_fwd_kernel<4>, dim3(blocks), dim3(kThreads), 0, as_stream(stream), J);
+    else hipLaunchKernelGGL(lookup_multi_fwd_kernel<1>, dim3(blocks), dim3(kThreads), 0, as_stream(stream), J);
     RECALGO_RETURN_LAST();
 }
 

@@ -215,7 +215,10 @@ class _GatherFn(Function):
                 _p(ids), _p(arena.weight), _p(row_base), B, F, K, _p(out), F * K, 0, dv, stp, 0, _stream(ids)),
                 "recalgo_embedding_gather_fwd")
         if batched:
-            sparse.defer_launch(launch)      # behind the block's one `prepare` launch (the rows it catches up are read here)
+            # behind the block's one `prepare` launch (the rows it catches up are read here); a plain lookup: it may share its
+            # launch with the block's other plain lookups
+            job = (0, ids, row_base, arena.weight, B, F, K, out, F * K, 0, None) if (dv is None and ids.is_contiguous()) else None
+            sparse.defer_launch(launch, job)
         else:
             launch()
         return out
@@ -328,7 +331,9 @@ class _SeqGatherFn(Function):
                 _p(values), _p(offsets), _p(table), B, T, K, _p(out), _p(seq_len), dv, rb0, stp, 0, _stream(offsets)),
                 "recalgo_sequence_gather_fwd")
         if ctx.src is not None and getattr(ctx.src, "deferred", False):
-            sparse.defer_launch(launch)      # (sparse.batch_lookups: behind the block's one `prepare` launch)
+            # (sparse.batch_lookups: behind the block's one `prepare` launch, possibly sharing ONE forward launch)
+            job = (1, values, offsets, table, B, T, K, out, 0, 0, seq_len) if (dv is None and values.is_contiguous()) else None
+            sparse.defer_launch(launch, job)
         else:
             launch()
         ctx.args = (values, offsets, arena, table_name, T)

@@ -354,9 +354,17 @@ def batching() -> bool:
     return _batch is not None
 
 
-def defer_launch(fn) -> None:
-    """the forward kernel of a lookup whose prepare work is pending: enqueued by flush_batch() / the end of the block"""
-    _batch["launches"].append(fn)
+class _CLookupJob(ctypes.Structure):         # include/recalgo.h recalgo_lookup_job_t
+    _fields_ = [("kind", ctypes.c_int), ("ids", ctypes.c_void_p), ("aux", ctypes.c_void_p), ("table", ctypes.c_void_p),
+                ("B", ctypes.c_int), ("F_or_T", ctypes.c_int), ("K", ctypes.c_int), ("out", ctypes.c_void_p),
+                ("out_stride", ctypes.c_int), ("out_col", ctypes.c_int), ("seq_len", ctypes.c_void_p)]
+
+
+def defer_launch(fn, job=None) -> None:
+    """the forward kernel of a lookup whose prepare work is pending: enqueued by flush_batch() / the end of the block.
+    job = (kind, ids, aux, table, B, F_or_T, K, out, out_stride, out_col, seq_len | None): a plain lookup that may share ONE launch
+    with the block's other plain lookups (recalgo_lookup_multi_fwd); fn launches it on its own."""
+    _batch["launches"].append((fn, job))
 
 
 def flush_batch() -> None:
@@ -392,11 +400,23 @@ def _flush_batch(b) -> None:
                                                              sweep_period(), stp, 0, _stream(arena.weight)),
                            "recalgo_scatter_prepare_multi")
                 prepare_stats["merged"] += len(chunk) - 1
-    for fn in b["launches"]:
-        fn()
+    plain = [(fn, job) for fn, job in b["launches"] if job is not None]
+    for fn, job in b["launches"]:
+        if job is None:
+            fn()
+    for i in range(0, len(plain), 4):
+        chunk = plain[i:i + 4]
+        if len(chunk) == 1:
+            chunk[0][0]()
+            continue
+        ptr = lambda t: None if t is None else t.data_ptr()
+        arr = (_CLookupJob * len(chunk))(*[_CLookupJob(j[0], ptr(j[1]), ptr(j[2]), ptr(j[3]), j[4], j[5], j[6], ptr(j[7]), j[8], j[9],
+                                                        ptr(j[10])) for _, j in chunk])
+        _lib.check(lib.recalgo_lookup_multi_fwd(arr, len(chunk), _stream(chunk[0][1][7])), "recalgo_lookup_multi_fwd")
+        prepare_stats["merged_lookups"] += len(chunk) - 1
 
 
-prepare_stats = {"merged": 0}        # `prepare` launches saved by batch_lookups (tests read it)
+prepare_stats = {"merged": 0, "merged_lookups": 0}        # `prepare` / forward launches saved by batch_lookups (tests read it)
 
 
 def companion_enabled() -> bool:

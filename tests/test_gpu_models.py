@@ -497,9 +497,10 @@ def test_din_batched_lookups_are_bit_identical_to_separate_prepares(dev):
         try:
             args = bench.parse_args(["--model", "din", "--batch", "256", "--fields", "8", "--max-vocab", "500"])
             est, spec, feats, labels, _ = bench.build_estimator(args, dev)
-            merged0 = sparse.prepare_stats["merged"]
+            merged0, ml0 = sparse.prepare_stats["merged"], sparse.prepare_stats["merged_lookups"]
             losses = [float(est.train_step(feats, labels)) for _ in range(4)]
             merged = sparse.prepare_stats["merged"] - merged0
+            assert sparse.prepare_stats["merged_lookups"] - ml0 == (8 if batched else 0)   # (three forward kernels -> one, four steps)
             torch.cuda.synchronize()
             sparse.sync_store(est.store)
             arrays = {k: v.detach().clone() for k, v in est.store.named_arrays().items()}
