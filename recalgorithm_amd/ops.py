@@ -197,7 +197,7 @@ class _GatherFn(Function):
         K = arena.K
         out = torch.empty(B, F * K, device=ids.device, dtype=torch.float32)
         # owner-computes scatter (sparse.py): the lookup joins the arena's plan; deferred-Adam rows are caught up first
-        ctx.src = sparse.begin_lookup(arena, anchor_store(anchor), ids, None, row_base, 0, B, F, training)
+        ctx.src = sparse.begin_lookup(arena, anchor_store(anchor), ids, None, row_base, 0, B, F, training, can_defer=True)
         # deferred Adam: a registered (TRAIN) lookup's rows were just caught up; any other lookup reads lagging rows as of now
         dv, stp = sparse.view_for(ctx.src, arena, anchor_store(anchor))
         ctx.arena, ctx.ids, ctx.row_base = arena, ids, row_base
@@ -322,7 +322,8 @@ class _SeqGatherFn(Function):
         seq_len = torch.empty(B, device=offsets.device, dtype=torch.int32)
         ctx.src = None
         if table_name != "__staged__":
-            ctx.src = sparse.begin_lookup(arena, anchor_store(anchor), values, offsets, None, arena.tables[table_name][0], B, T, training)
+            ctx.src = sparse.begin_lookup(arena, anchor_store(anchor), values, offsets, None, arena.tables[table_name][0], B, T, training,
+                                          can_defer=True)
         dv, stp = (None, None) if table_name == "__staged__" else sparse.view_for(ctx.src, arena, anchor_store(anchor))
         rb0 = 0 if table_name == "__staged__" else arena.tables[table_name][0]
 

@@ -253,7 +253,8 @@ def deferred_view(arena, store):
 
 
 def begin_lookup(arena, store, ids: torch.Tensor, offsets: Optional[torch.Tensor], row_base: Optional[torch.Tensor],
-                 base: int, n_ex: int, F: int, training: Optional[bool] = None, companion_arena=None) -> Optional[Source]:
+                 base: int, n_ex: int, F: int, training: Optional[bool] = None, companion_arena=None,
+                 can_defer: bool = False) -> Optional[Source]:
     """Called by a lookup's forward in TRAIN mode.  Returns the Source to attach the gradient to (owner mode), or None.
     Launches recalgo_scatter_prepare: the lookup's tiles are counted into the arena's plan and — deferred Adam — its
     lagging rows are brought up to date (and the arena's share of the sweep runs).  (Lookups that are NOT registered — EVAL / PREDICT — read lagging rows through
@@ -302,7 +303,9 @@ def begin_lookup(arena, store, ids: torch.Tensor, offsets: Optional[torch.Tensor
         plan.swept = True
         if d1 is not None:
             plan_of(companion_arena).swept = True
-    if (_batch is not None and d1 is None and companion_arena is None and getattr(arena, "sharding", None) is None
+    # (can_defer: the caller enqueues its forward kernel through defer_launch when the Source comes back `deferred` — a caller
+    # that does not would read rows the pending launch has not caught up yet)
+    if (_batch is not None and can_defer and d1 is None and companion_arena is None and getattr(arena, "sharding", None) is None
             and "__staged__" not in getattr(arena, "tables", {})):
         # the model issues several lookups together (batch_lookups): ONE launch for all of an arena's at the end of the block; the
         # forward kernels of these lookups are enqueued behind it (ops: defer_launch)
@@ -400,6 +403,10 @@ def _flush_batch(b) -> None:
                                                              sweep_period(), stp, 0, _stream(arena.weight)),
                            "recalgo_scatter_prepare_multi")
                 prepare_stats["merged"] += len(chunk) - 1
+        # what the workspace holds now: EVERY entry of the block (also one registered before a later lookup re-sized — and
+        # cleared — the workspace, whose id the book-keeping dropped then) beside the sources counted by launches of their own
+        have = set(plan.counted[2]) | {id(e[0]) for e in entries}
+        plan.counted = plan.counted[:2] + (tuple(id(s) for s in plan.sources if id(s) in have),)
     plain = [(fn, job) for fn, job in b["launches"] if job is not None]
     for fn, job in b["launches"]:
         if job is None:

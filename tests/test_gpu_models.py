@@ -515,3 +515,31 @@ def test_din_batched_lookups_are_bit_identical_to_separate_prepares(dev):
     assert runs[True][0] == runs[False][0]
     for k in runs[False][1]:
         assert_bit_exact(runs[True][1][k], runs[False][1][k], what=f"din {k}: batched lookups vs separate prepares")
+
+
+def test_nfm_batched_lookups_with_an_unused_lookup_are_bit_identical(dev):
+    """NFM looks the category columns up twice — once unused (nfm.py:150-151) — inside sparse.batch_lookups().  The unused lookup is
+    counted into the plan's workspace by the block's one launch but takes no part in `apply`: the plan's book-keeping has to say so
+    (a workspace re-sized between the two registrations used to leave totals that `apply` trusted: buckets overflowed).  Steps with
+    the block against steps with one `prepare` launch per lookup: bit-identical."""
+    import bench
+    from recalgorithm_amd import sparse
+    runs = {}
+    for batched in (True, False):
+        sparse.BATCH_LOOKUPS = batched
+        try:
+            args = bench.parse_args(["--model", "nfm", "--batch", "1024", "--fields", "12", "--max-vocab", "3000"])
+            est, spec, feats, labels, _ = bench.build_estimator(args, dev)
+            losses = [float(est.train_step(feats, labels)) for _ in range(4)]
+            torch.cuda.synchronize()
+            sparse.sync_store(est.store)
+            arrays = {k: v.detach().clone() for k, v in est.store.named_arrays().items()}
+            for n, a in est.store.arenas.items():
+                if a.weight is not None:
+                    arrays[f"{n}/m"], arrays[f"{n}/v"] = a.m.clone(), a.v.clone()
+            runs[batched] = (losses, arrays)
+        finally:
+            sparse.BATCH_LOOKUPS = True
+    assert runs[True][0] == runs[False][0]
+    for k in runs[False][1]:
+        assert_bit_exact(runs[True][1][k], runs[False][1][k], what=f"nfm {k}: batched lookups vs separate prepares")
